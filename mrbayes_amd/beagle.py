@@ -1,0 +1,327 @@
+"""ctypes binding of the engine's C ABI (include/libhmsbeagle/beagle.h).
+
+This is the Python twin of what an FFI client of libhmsbeagle does: plain pointers and sizes in,
+status codes out.  It loads mrbayes_amd/libhmsbeagle.so -- the HIP library built by
+`python -m mrbayes_amd.build` -- and raises if it is missing: there is no fallback implementation.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import Optional, Sequence
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+DEFAULT_LIB = os.path.join(HERE, "libhmsbeagle.so")
+
+BEAGLE_SUCCESS = 0
+BEAGLE_ERROR_GENERAL = -1
+BEAGLE_ERROR_OUT_OF_MEMORY = -2
+BEAGLE_ERROR_UNINITIALIZED_INSTANCE = -4
+BEAGLE_ERROR_OUT_OF_RANGE = -5
+BEAGLE_ERROR_NO_RESOURCE = -6
+BEAGLE_ERROR_NO_IMPLEMENTATION = -7
+BEAGLE_ERROR_FLOATING_POINT = -8
+BEAGLE_OP_NONE = -1
+
+BEAGLE_FLAG_PRECISION_SINGLE = 1 << 0
+BEAGLE_FLAG_SCALING_ALWAYS = 1 << 8
+BEAGLE_FLAG_SCALERS_LOG = 1 << 10
+BEAGLE_FLAG_PROCESSOR_GPU = 1 << 16
+BEAGLE_FLAG_SCALING_DYNAMIC = 1 << 25
+
+
+class BeagleInstanceDetails(C.Structure):
+    _fields_ = [("resourceNumber", C.c_int), ("resourceName", C.c_char_p), ("implName", C.c_char_p),
+                ("implDescription", C.c_char_p), ("flags", C.c_long)]
+
+
+class BeagleResource(C.Structure):
+    _fields_ = [("name", C.c_char_p), ("description", C.c_char_p), ("supportFlags", C.c_long),
+                ("requiredFlags", C.c_long)]
+
+
+class BeagleResourceList(C.Structure):
+    _fields_ = [("list", C.POINTER(BeagleResource)), ("length", C.c_int)]
+
+
+class BeagleOperation(C.Structure):
+    _fields_ = [("destinationPartials", C.c_int), ("destinationScaleWrite", C.c_int),
+                ("destinationScaleRead", C.c_int), ("child1Partials", C.c_int),
+                ("child1TransitionMatrix", C.c_int), ("child2Partials", C.c_int),
+                ("child2TransitionMatrix", C.c_int)]
+
+
+EXPORTS = [
+    "beagleGetVersion", "beagleGetCitation", "beagleGetResourceList", "beagleCreateInstance",
+    "beagleFinalizeInstance", "beagleFinalize", "beagleSetTipStates", "beagleSetTipPartials", "beagleSetPartials",
+    "beagleGetPartials", "beagleSetEigenDecomposition", "beagleSetStateFrequencies", "beagleSetCategoryWeights",
+    "beagleSetCategoryRates", "beagleSetPatternWeights", "beagleUpdateTransitionMatrices",
+    "beagleSetTransitionMatrix", "beagleGetTransitionMatrix", "beagleUpdatePartials", "beagleWaitForPartials",
+    "beagleAccumulateScaleFactors", "beagleRemoveScaleFactors", "beagleResetScaleFactors", "beagleCopyScaleFactors",
+    "beagleGetScaleFactors", "beagleCalculateRootLogLikelihoods", "beagleCalculateEdgeLogLikelihoods",
+    "beagleGetSiteLogLikelihoods", "mbamdSynchronize", "mbamdGetLastError", "mbamdKernelTiming",
+    "mbamdGetKernelTiming", "mbamdSetKernelPath", "mbamdSetDeferredResult", "mbamdFetchLogLikelihood",
+]
+
+_dp = C.POINTER(C.c_double)
+_ip = C.POINTER(C.c_int)
+
+
+class BeagleError(RuntimeError):
+    def __init__(self, code: int, where: str, detail: str = ""):
+        super().__init__("%s failed with code %d%s" % (where, code, (": " + detail) if detail else ""))
+        self.code = code
+
+
+def _d(a) -> np.ndarray:
+    return np.ascontiguousarray(a, dtype=np.float64)
+
+
+def _i(a) -> np.ndarray:
+    return np.ascontiguousarray(a, dtype=np.int32)
+
+
+class BeagleLibrary:
+    """The shared library, with argument types declared."""
+
+    def __init__(self, path: Optional[str] = None):
+        path = path or os.environ.get("MBAMD_LIBRARY") or DEFAULT_LIB
+        if not os.path.exists(path):
+            raise FileNotFoundError(
+                "%s not found: build the HIP engine first (python -m mrbayes_amd.build). "
+                "There is no CPU implementation to fall back to." % path)
+        self.path = path
+        self.lib = C.CDLL(path)
+        for name in EXPORTS:
+            if not hasattr(self.lib, name):
+                raise AttributeError("%s does not export %s" % (path, name))
+        L = self.lib
+        L.beagleGetVersion.restype = C.c_char_p
+        L.beagleGetCitation.restype = C.c_char_p
+        L.mbamdGetLastError.restype = C.c_char_p
+        L.beagleGetResourceList.restype = C.POINTER(BeagleResourceList)
+        L.beagleCreateInstance.argtypes = [C.c_int] * 9 + [_ip, C.c_int, C.c_long, C.c_long,
+                                                          C.POINTER(BeagleInstanceDetails)]
+        L.beagleSetTipStates.argtypes = [C.c_int, C.c_int, _ip]
+        L.beagleSetTipPartials.argtypes = [C.c_int, C.c_int, _dp]
+        L.beagleSetPartials.argtypes = [C.c_int, C.c_int, _dp]
+        L.beagleGetPartials.argtypes = [C.c_int, C.c_int, C.c_int, _dp]
+        L.beagleSetEigenDecomposition.argtypes = [C.c_int, C.c_int, _dp, _dp, _dp]
+        L.beagleSetStateFrequencies.argtypes = [C.c_int, C.c_int, _dp]
+        L.beagleSetCategoryWeights.argtypes = [C.c_int, C.c_int, _dp]
+        L.beagleSetCategoryRates.argtypes = [C.c_int, _dp]
+        L.beagleSetPatternWeights.argtypes = [C.c_int, _dp]
+        L.beagleUpdateTransitionMatrices.argtypes = [C.c_int, C.c_int, _ip, _ip, _ip, _dp, C.c_int]
+        L.beagleSetTransitionMatrix.argtypes = [C.c_int, C.c_int, _dp, C.c_double]
+        L.beagleGetTransitionMatrix.argtypes = [C.c_int, C.c_int, _dp]
+        L.beagleUpdatePartials.argtypes = [C.c_int, C.POINTER(BeagleOperation), C.c_int, C.c_int]
+        L.beagleWaitForPartials.argtypes = [C.c_int, _ip, C.c_int]
+        L.beagleAccumulateScaleFactors.argtypes = [C.c_int, _ip, C.c_int, C.c_int]
+        L.beagleRemoveScaleFactors.argtypes = [C.c_int, _ip, C.c_int, C.c_int]
+        L.beagleResetScaleFactors.argtypes = [C.c_int, C.c_int]
+        L.beagleCopyScaleFactors.argtypes = [C.c_int, C.c_int, C.c_int]
+        L.beagleGetScaleFactors.argtypes = [C.c_int, C.c_int, _dp]
+        L.beagleCalculateRootLogLikelihoods.argtypes = [C.c_int, _ip, _ip, _ip, _ip, C.c_int, _dp]
+        L.beagleCalculateEdgeLogLikelihoods.argtypes = [C.c_int, _ip, _ip, _ip, _ip, _ip, _ip, _ip, _ip, C.c_int,
+                                                        _dp, _dp, _dp]
+        L.beagleGetSiteLogLikelihoods.argtypes = [C.c_int, _dp]
+        L.mbamdGetKernelTiming.argtypes = [C.c_int, _dp, C.POINTER(C.c_long), C.c_int]
+        L.mbamdFetchLogLikelihood.argtypes = [C.c_int, _dp]
+
+    def version(self) -> str:
+        return self.lib.beagleGetVersion().decode()
+
+    def last_error(self) -> str:
+        return self.lib.mbamdGetLastError().decode()
+
+    def resources(self):
+        rl = self.lib.beagleGetResourceList().contents
+        return [(rl.list[i].name.decode(), rl.list[i].description.decode(), rl.list[i].supportFlags)
+                for i in range(rl.length)]
+
+
+_default: Optional[BeagleLibrary] = None
+
+
+def library(path: Optional[str] = None) -> BeagleLibrary:
+    global _default
+    if path is not None:
+        return BeagleLibrary(path)
+    if _default is None:
+        _default = BeagleLibrary()
+    return _default
+
+
+class BeagleInstance:
+    """One engine instance; methods are the beagle* functions minus the instance argument."""
+
+    def __init__(self, lib: BeagleLibrary, tip_count, partials_buffer_count, compact_buffer_count, state_count,
+                 pattern_count, eigen_buffer_count, matrix_buffer_count, category_count, scale_buffer_count,
+                 resource: Optional[int] = None, preference_flags=0, requirement_flags=0):
+        self._L = lib
+        self.lib = lib.lib
+        self.details = BeagleInstanceDetails()
+        rl = None
+        rc = 0
+        if resource is not None:
+            arr = (C.c_int * 1)(resource)
+            rl, rc = C.cast(arr, _ip), 1
+        self.id = self.lib.beagleCreateInstance(tip_count, partials_buffer_count, compact_buffer_count, state_count,
+                                                pattern_count, eigen_buffer_count, matrix_buffer_count,
+                                                category_count, scale_buffer_count, rl, rc, preference_flags,
+                                                requirement_flags, C.byref(self.details))
+        if self.id < 0:
+            raise BeagleError(self.id, "beagleCreateInstance", lib.last_error())
+        self.state_count, self.pattern_count, self.category_count = state_count, pattern_count, category_count
+
+    def _chk(self, code: int, where: str, allow=()):
+        if code != BEAGLE_SUCCESS and code not in allow:
+            raise BeagleError(code, where, self._L.last_error())
+        return code
+
+    def finalize(self):
+        if self.id >= 0:
+            self.lib.beagleFinalizeInstance(self.id)
+            self.id = -1
+
+    def __del__(self):
+        try:
+            self.finalize()
+        except Exception:
+            pass
+
+    # ---- data -----------------------------------------------------------------------------------
+    def set_tip_states(self, tip, states):
+        a = _i(states)
+        self._chk(self.lib.beagleSetTipStates(self.id, tip, a.ctypes.data_as(_ip)), "beagleSetTipStates")
+
+    def set_tip_partials(self, tip, partials):
+        a = _d(partials)
+        self._chk(self.lib.beagleSetTipPartials(self.id, tip, a.ctypes.data_as(_dp)), "beagleSetTipPartials")
+
+    def set_partials(self, idx, partials):
+        a = _d(partials)
+        self._chk(self.lib.beagleSetPartials(self.id, idx, a.ctypes.data_as(_dp)), "beagleSetPartials")
+
+    def get_partials(self, idx) -> np.ndarray:
+        out = np.empty((self.category_count, self.pattern_count, self.state_count))
+        self._chk(self.lib.beagleGetPartials(self.id, idx, BEAGLE_OP_NONE, out.ctypes.data_as(_dp)), "beagleGetPartials")
+        return out
+
+    def set_eigen_decomposition(self, idx, evec, ivec, evals):
+        a, b, c = _d(evec), _d(ivec), _d(evals)
+        self._chk(self.lib.beagleSetEigenDecomposition(self.id, idx, a.ctypes.data_as(_dp), b.ctypes.data_as(_dp),
+                                                       c.ctypes.data_as(_dp)), "beagleSetEigenDecomposition")
+
+    def set_state_frequencies(self, idx, f):
+        a = _d(f)
+        self._chk(self.lib.beagleSetStateFrequencies(self.id, idx, a.ctypes.data_as(_dp)), "beagleSetStateFrequencies")
+
+    def set_category_weights(self, idx, w):
+        a = _d(w)
+        self._chk(self.lib.beagleSetCategoryWeights(self.id, idx, a.ctypes.data_as(_dp)), "beagleSetCategoryWeights")
+
+    def set_category_rates(self, r):
+        a = _d(r)
+        self._chk(self.lib.beagleSetCategoryRates(self.id, a.ctypes.data_as(_dp)), "beagleSetCategoryRates")
+
+    def set_pattern_weights(self, w):
+        a = _d(w)
+        self._chk(self.lib.beagleSetPatternWeights(self.id, a.ctypes.data_as(_dp)), "beagleSetPatternWeights")
+
+    # ---- matrices -------------------------------------------------------------------------------
+    def update_transition_matrices(self, eigen_index, prob_indices, edge_lengths):
+        p, e = _i(prob_indices), _d(edge_lengths)
+        self._chk(self.lib.beagleUpdateTransitionMatrices(self.id, eigen_index, p.ctypes.data_as(_ip), None, None,
+                                                          e.ctypes.data_as(_dp), len(p)),
+                  "beagleUpdateTransitionMatrices")
+
+    def set_transition_matrix(self, idx, m):
+        a = _d(m)
+        self._chk(self.lib.beagleSetTransitionMatrix(self.id, idx, a.ctypes.data_as(_dp), 0.0), "beagleSetTransitionMatrix")
+
+    def get_transition_matrix(self, idx) -> np.ndarray:
+        out = np.empty((self.category_count, self.state_count, self.state_count))
+        self._chk(self.lib.beagleGetTransitionMatrix(self.id, idx, out.ctypes.data_as(_dp)), "beagleGetTransitionMatrix")
+        return out
+
+    # ---- partials / scaling -----------------------------------------------------------------------
+    def update_partials(self, operations, cumulative_scale_index=BEAGLE_OP_NONE):
+        """operations: int array [n][7] in BeagleOperation field order, or a ctypes array."""
+        if isinstance(operations, np.ndarray) or isinstance(operations, (list, tuple)):
+            a = _i(operations).reshape(-1, 7)
+            ptr = C.cast(a.ctypes.data, C.POINTER(BeagleOperation))
+            n = a.shape[0]
+        else:
+            ptr, n = operations, len(operations)
+        self._chk(self.lib.beagleUpdatePartials(self.id, ptr, n, cumulative_scale_index), "beagleUpdatePartials")
+
+    def wait_for_partials(self):
+        self._chk(self.lib.beagleWaitForPartials(self.id, None, 0), "beagleWaitForPartials")
+
+    def accumulate_scale_factors(self, indices, cum):
+        a = _i(indices)
+        self._chk(self.lib.beagleAccumulateScaleFactors(self.id, a.ctypes.data_as(_ip), len(a), cum), "beagleAccumulateScaleFactors")
+
+    def remove_scale_factors(self, indices, cum):
+        a = _i(indices)
+        self._chk(self.lib.beagleRemoveScaleFactors(self.id, a.ctypes.data_as(_ip), len(a), cum), "beagleRemoveScaleFactors")
+
+    def reset_scale_factors(self, cum):
+        self._chk(self.lib.beagleResetScaleFactors(self.id, cum), "beagleResetScaleFactors")
+
+    def copy_scale_factors(self, dst, src):
+        self._chk(self.lib.beagleCopyScaleFactors(self.id, dst, src), "beagleCopyScaleFactors")
+
+    def get_scale_factors(self, idx) -> np.ndarray:
+        out = np.empty(self.pattern_count)
+        self._chk(self.lib.beagleGetScaleFactors(self.id, idx, out.ctypes.data_as(_dp)), "beagleGetScaleFactors")
+        return out
+
+    # ---- likelihood -------------------------------------------------------------------------------
+    def calculate_root_log_likelihoods(self, buffers, weights, freqs, cums):
+        """Returns (return code, lnL); BEAGLE_ERROR_FLOATING_POINT is passed through, as MrBayes expects."""
+        b, w, f, c = _i(buffers), _i(weights), _i(freqs), _i(cums)
+        out = C.c_double(0.0)
+        rc = self.lib.beagleCalculateRootLogLikelihoods(self.id, b.ctypes.data_as(_ip), w.ctypes.data_as(_ip),
+                                                        f.ctypes.data_as(_ip), c.ctypes.data_as(_ip), len(b), C.byref(out))
+        self._chk(rc, "beagleCalculateRootLogLikelihoods", allow=(BEAGLE_ERROR_FLOATING_POINT,))
+        return rc, out.value
+
+    def calculate_edge_log_likelihoods(self, parents, children, probs, weights, freqs, cums):
+        p, ch, pr, w, f, c = _i(parents), _i(children), _i(probs), _i(weights), _i(freqs), _i(cums)
+        out = C.c_double(0.0)
+        rc = self.lib.beagleCalculateEdgeLogLikelihoods(self.id, p.ctypes.data_as(_ip), ch.ctypes.data_as(_ip),
+                                                        pr.ctypes.data_as(_ip), None, None, w.ctypes.data_as(_ip),
+                                                        f.ctypes.data_as(_ip), c.ctypes.data_as(_ip), len(p),
+                                                        C.byref(out), None, None)
+        self._chk(rc, "beagleCalculateEdgeLogLikelihoods", allow=(BEAGLE_ERROR_FLOATING_POINT,))
+        return rc, out.value
+
+    def get_site_log_likelihoods(self) -> np.ndarray:
+        out = np.empty(self.pattern_count)
+        self._chk(self.lib.beagleGetSiteLogLikelihoods(self.id, out.ctypes.data_as(_dp)), "beagleGetSiteLogLikelihoods")
+        return out
+
+    # ---- engine extensions --------------------------------------------------------------------------
+    def synchronize(self):
+        self._chk(self.lib.mbamdSynchronize(self.id), "mbamdSynchronize")
+
+    def kernel_timing(self, enable: bool):
+        self._chk(self.lib.mbamdKernelTiming(self.id, 1 if enable else 0), "mbamdKernelTiming")
+
+    def get_kernel_timing(self, reset=True):
+        ms, n = C.c_double(0.0), C.c_long(0)
+        self._chk(self.lib.mbamdGetKernelTiming(self.id, C.byref(ms), C.byref(n), 1 if reset else 0), "mbamdGetKernelTiming")
+        return ms.value, n.value
+
+    def set_deferred_result(self, enable: bool):
+        self._chk(self.lib.mbamdSetDeferredResult(self.id, 1 if enable else 0), "mbamdSetDeferredResult")
+
+    def fetch_log_likelihood(self):
+        out = C.c_double(0.0)
+        rc = self.lib.mbamdFetchLogLikelihood(self.id, C.byref(out))
+        self._chk(rc, "mbamdFetchLogLikelihood", allow=(BEAGLE_ERROR_FLOATING_POINT,))
+        return rc, out.value

@@ -1,0 +1,249 @@
+"""Parity checks of the engine (through its C ABI) against the CPU oracle and the golden fixtures.
+
+The same checks run in two harnesses:
+  * tests/test_engine_gpu.py      (-m gpu)      the product library mrbayes_amd/libhmsbeagle.so on a MI355X
+  * tests/test_engine_hostemu.py  (-m "not gpu") the host-emulation build of the same sources, which
+                                                exercises the host logic and kernel indexing without a GPU
+Tolerances (stated once, used everywhere):
+  * log-likelihood vs the reference's fp64 build: relative 2e-6; vs its FMA build: relative 1e-5
+    (the reference's own fp32 self-consistency band is 8e-9 .. 8.4e-7);
+  * log-likelihood vs the oracle on the same inputs: relative 2e-6; vs the fp64 reference also
+    |diff| <= 2 x (the reference's own |fp32 - fp64| on that data set) + 1e-3;
+  * partials / transition matrices element-wise: 2e-6 absolute + 2e-5 relative (fp32 round-off with
+    a different summation order / FMA contraction than the scalar reference).
+"""
+import json
+import math
+import os
+
+import numpy as np
+
+from mrbayes_amd import beagle as bg
+from mrbayes_amd import likelihood as lk
+from mrbayes_amd import tree as mbtree
+from mrbayes_amd.division import build_division, division_from_golden, synthetic_division
+
+REL_FP64 = 2e-6
+REL_FMA = 1e-5
+
+
+def close_partials(a, b):
+    return np.allclose(a, b, rtol=2e-5, atol=2e-6)
+
+
+def gold(golden_dir, case):
+    with open(os.path.join(golden_dir, case + ".json")) as fh:
+        return json.load(fh)
+
+
+# ------------------------------------------------------------------------------------------------
+def check_transition_matrices(lib, oracle, div):
+    bd = lk.BeagleDivision(div, lib)
+    try:
+        bd.UpDateCijk(0)
+        bd.TreeTiProbs_Beagle(0)
+        t = div.tree
+        for p in t.all_down_pass[:: max(1, len(t.all_down_pass) // 7)]:
+            length = min(max(t.length[p], lk.BRLENS_MIN), lk.BRLENS_MAX)
+            ref = oracle.tiprobs(div, length)                 # [K or parts][S][S]
+            for i in range(div.n_cijk_parts):
+                got = bd.inst.get_transition_matrix(bd.tiProbsIndex[0][p] + i)     # [ncat][S][S]
+                want = ref if div.n_cijk_parts == 1 else ref[i:i + 1]
+                assert got.shape == want.shape
+                assert np.allclose(got, want, rtol=1e-5, atol=2e-7), (p, i, np.abs(got - want).max())
+                assert got.min() >= 0.0
+                assert np.allclose(got.sum(axis=2), 1.0, atol=1e-5)
+    finally:
+        bd.finalize()
+
+
+def _dense_tip(states, nstates, ncat):
+    P = len(states)
+    cl = np.zeros((ncat, P, nstates), dtype=np.float32)
+    for c, s in enumerate(states):
+        if s >= nstates:
+            cl[:, c, :] = 1.0
+        else:
+            cl[:, c, s] = 1.0
+    return cl
+
+
+def check_single_operations(lib, oracle, nstates, ncat, npat, seed=1):
+    """One beagleUpdatePartials operation per child-kind combination, no scaling, then with scaling:
+    compares the destination partials element-wise with CondLikeDown of the oracle."""
+    rng = np.random.default_rng(seed)
+    S, K, P = nstates, ncat, npat
+    inst = bg.BeagleInstance(lib, 2, 8, 2, S, P, 1, 4, K, 4)
+    try:
+        # random reversible-ish transition matrices: rows sum to one
+        def rand_ti():
+            m = rng.random((K, S, S)) + 0.05
+            return m / m.sum(axis=2, keepdims=True)
+        ti1, ti2 = rand_ti(), rand_ti()
+        inst.set_transition_matrix(0, ti1)
+        inst.set_transition_matrix(1, ti2)
+        assert np.allclose(inst.get_transition_matrix(0), ti1.astype(np.float32), atol=1e-7)
+        st1 = rng.integers(0, S + 1, size=P).astype(np.int32)       # includes the missing code S
+        st2 = rng.integers(0, S + 1, size=P).astype(np.int32)
+        inst.set_tip_states(0, st1)
+        inst.set_tip_states(1, st2)
+        pa = (rng.random((K, P, S)) * 0.9 + 0.05)
+        pb = (rng.random((K, P, S)) * 0.9 + 0.05) * 1e-3
+        inst.set_partials(2, pa)
+        inst.set_partials(3, pb)
+        assert np.allclose(inst.get_partials(2), pa.astype(np.float32), rtol=1e-7)
+        t1 = np.ascontiguousarray(ti1, dtype=np.float32)
+        t2 = np.ascontiguousarray(ti2, dtype=np.float32)
+        fa = np.ascontiguousarray(pa, dtype=np.float32)
+        fb = np.ascontiguousarray(pb, dtype=np.float32)
+        combos = [("states,states", 0, 1, None, st1, None, st2),
+                  ("states,partials", 0, 3, None, st1, fb, None),
+                  ("partials,states", 2, 1, fa, None, None, st2),
+                  ("partials,partials", 2, 3, fa, None, fb, None)]
+        for name, c1, c2, cl1, s1, cl2, s2 in combos:
+            want = oracle.condlike_down(S, K, P, cl1, s1, t1, cl2, s2, t2)
+            # the engine treats a compact tip as the dense 0/1 vector (what the reference's SIMD kernels
+            # do); for a missing state that is the row sum instead of the scalar short-cut's literal 1.0
+            inst.update_partials(np.array([[4, -1, -1, c1, 0, c2, 1]], dtype=np.int32), bg.BEAGLE_OP_NONE)
+            got = inst.get_partials(4)
+            assert close_partials(got, want), (name, np.abs(got - want).max())
+            # with rescaling: got2 * 2^e == unscaled, max over (k,i) in [0.5, 1)
+            inst.reset_scale_factors(1)
+            inst.update_partials(np.array([[5, 0, -1, c1, 0, c2, 1]], dtype=np.int32), 1)
+            got2 = inst.get_partials(5)
+            lnsc = inst.get_scale_factors(0)
+            cum = inst.get_scale_factors(1)
+            assert np.allclose(lnsc, cum)
+            e = np.rint(lnsc / math.log(2.0))
+            assert np.allclose(e * math.log(2.0), lnsc, atol=1e-9)
+            assert np.allclose(got2 * np.exp2(e)[None, :, None], got, rtol=1e-6, atol=0)
+            mx = got2.max(axis=(0, 2))
+            assert np.all((mx >= 0.5 - 1e-6) & (mx < 1.0 + 1e-6))
+            # "divide by the factors already stored" (dynamic scaling's no-rescale pass)
+            inst.update_partials(np.array([[6, -1, 0, c1, 0, c2, 1]], dtype=np.int32), bg.BEAGLE_OP_NONE)
+            got3 = inst.get_partials(6)
+            assert np.array_equal(got3, got2)
+            # remove / accumulate are exact inverses
+            inst.remove_scale_factors([0], 1)
+            assert np.all(inst.get_scale_factors(1) == 0.0)
+            inst.accumulate_scale_factors([0, 0], 1)
+            assert np.allclose(inst.get_scale_factors(1), 2 * lnsc)
+    finally:
+        inst.finalize()
+
+
+def engine_lnl(lib, div, scaling=lk.MB_BEAGLE_SCALE_ALWAYS, nchains=1, chain=0):
+    bd = lk.BeagleDivision(div, lib, nchains=nchains, scaling=scaling)
+    try:
+        return bd.LogLike(chain)
+    finally:
+        bd.finalize()
+
+
+def check_golden_case(lib, oracle, golden_dir, case, scaling=lk.MB_BEAGLE_SCALE_ALWAYS):
+    g = gold(golden_dir, case)
+    div = division_from_golden(golden_dir, case)
+    lnl = engine_lnl(lib, div, scaling)
+    ref64, reffma = g["lnL"]["fp64"], g["lnL"]["fma"]
+    assert abs(lnl - ref64) / abs(ref64) < REL_FP64, (case, lnl, ref64)
+    assert abs(lnl - reffma) / abs(reffma) < REL_FMA, (case, lnl, reffma)
+    want = oracle.tree_loglike(div, use_shortcuts=False)
+    assert abs(lnl - want) / abs(want) < REL_FP64, (case, lnl, want)
+    # and it must sit inside (twice) the reference's own fp32-vs-fp64 band on this data set
+    band = max(abs(reffma - ref64), abs(g["lnL"]["scalar"] - ref64))
+    assert abs(lnl - ref64) <= 2.0 * band + 1e-3, (case, lnl, ref64, band)
+    return lnl
+
+
+def check_site_likelihoods(lib, oracle, div):
+    bd = lk.BeagleDivision(div, lib)
+    try:
+        lnl = bd.LogLike(0)
+        site = bd.inst.get_site_log_likelihoods()
+        want_lnl, want_site = oracle.tree_loglike(div, use_shortcuts=False, want_sites=True)
+        if div.pinvar == 0.0:
+            assert np.allclose(site, want_site, rtol=2e-6, atol=2e-5)
+            assert abs(float((site * div.weights).sum()) - lnl) < 1e-6 * abs(lnl)
+        assert abs(lnl - want_lnl) / abs(want_lnl) < REL_FP64
+    finally:
+        bd.finalize()
+
+
+def check_partial_update_and_reject(lib, oracle, div, scaling=lk.MB_BEAGLE_SCALE_ALWAYS):
+    """An MCMC-style sequence on one chain: full evaluation; change one branch (only the path to the
+    root is recomputed); reject (flips undone) ; change another branch and accept; every value must
+    equal a from-scratch evaluation of the same state."""
+    import copy
+    t = div.tree
+    bd = lk.BeagleDivision(div, lib, scaling=scaling)
+    try:
+        lnl0 = bd.LogLike(0)
+        bd.AcceptMove(0)
+        assert abs(lnl0 - oracle.tree_loglike(div, use_shortcuts=False)) / abs(lnl0) < REL_FP64
+        deep = max(range(t.ntaxa), key=lambda i: _depth(t, i))
+        old = t.length[deep]
+        t.length[deep] = old * 3.7
+        bd.TouchBranch(0, deep)
+        lnl1 = bd.LogLike(0)
+        want1 = oracle.tree_loglike(div, use_shortcuts=False)
+        assert abs(lnl1 - want1) / abs(want1) < REL_FP64, (lnl1, want1)
+        assert abs(lnl1 - lnl0) > 1e-6 * abs(lnl0)
+        # reject: restore the branch, undo the flips; a no-op evaluation must give lnl0 again
+        t.length[deep] = old
+        bd.ResetFlips(0)
+        lnl_back = bd.LogLike(0)
+        assert abs(lnl_back - lnl0) <= 1e-9 * abs(lnl0), (lnl_back, lnl0)
+        bd.AcceptMove(0)
+        # second move on an interior branch, accepted
+        inner = t.int_down_pass[0]
+        old2 = t.length[inner]
+        t.length[inner] = old2 * 0.3 + 0.01
+        bd.TouchBranch(0, inner)
+        lnl2 = bd.LogLike(0)
+        want2 = oracle.tree_loglike(div, use_shortcuts=False)
+        assert abs(lnl2 - want2) / abs(want2) < REL_FP64, (lnl2, want2)
+        bd.AcceptMove(0)
+        t.length[inner] = old2
+    finally:
+        bd.finalize()
+
+
+def _depth(t, i):
+    d = 0
+    while t.anc[i] != -1 and t.anc[i] != t.root:
+        i = t.anc[i]
+        d += 1
+    return d
+
+
+def check_multi_chain(lib, oracle, div, nchains=3):
+    """All local chains live in one instance (as in MrBayes); their buffers must not interfere."""
+    bd = lk.BeagleDivision(div, lib, nchains=nchains)
+    try:
+        want = oracle.tree_loglike(div, use_shortcuts=False)
+        vals = [bd.LogLike(c) for c in range(nchains)]
+        for v in vals:
+            assert abs(v - want) / abs(want) < REL_FP64
+        assert max(vals) - min(vals) <= 1e-9 * abs(want)
+        # re-evaluating chain 0 after the others ran still gives the same number
+        bd.TouchAllTreeNodes(0)
+        assert abs(bd.LogLike(0) - vals[0]) <= 1e-9 * abs(want)
+    finally:
+        bd.finalize()
+
+
+def check_dynamic_rescaling_state_machine(lib, oracle, div):
+    """A tree deep enough to underflow fp32 without scaling: the first (no-rescale) pass must report
+    BEAGLE_ERROR_FLOATING_POINT and the rescale-all retry must land on the right value."""
+    bd = lk.BeagleDivision(div, lib, scaling=lk.MB_BEAGLE_SCALE_DYNAMIC)
+    try:
+        bd.UpDateCijk(0)
+        bd.TreeTiProbs_Beagle(0)
+        bd.TreeCondLikes_Beagle_No_Rescale(0)
+        rc, lnl = bd.TreeLikelihood_Beagle(0)
+        assert rc == bg.BEAGLE_ERROR_FLOATING_POINT, (rc, lnl)
+    finally:
+        bd.finalize()
+    lnl = engine_lnl(lib, div, scaling=lk.MB_BEAGLE_SCALE_DYNAMIC)
+    want = oracle.tree_loglike(div, use_shortcuts=False)
+    assert abs(lnl - want) / abs(want) < REL_FP64, (lnl, want)

@@ -1,0 +1,113 @@
+// hip_emu.h -- TEST INFRASTRUCTURE ONLY.  A few dozen lines of "HIP on the host" so that the engine's
+// host logic (buffer bookkeeping, operation scheduling, LDS-slot allocation, layout conversion, the
+// BEAGLE call protocol) can be exercised by `pytest -m "not gpu"` in a container without a GPU.
+// Kernels are run one thread after another (they use no barriers / cross-lane operations).
+//
+// It is compiled only into tests/hostemu/_build/libmbamd_hostemu_TESTONLY.so.  The product library
+// (mrbayes_amd/libhmsbeagle.so) is always built by hipcc for gfx950 against the real HIP runtime and has
+// no CPU path; nothing under mrbayes_amd/ references this file.
+#ifndef MBAMD_HIP_EMU_H_
+#define MBAMD_HIP_EMU_H_
+
+#include <algorithm>
+#include <chrono>
+#include <cmath>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <memory>
+#include <vector>
+
+#define __global__
+#define __device__
+#define __host__
+#define __forceinline__ inline
+#define __launch_bounds__(...)
+#ifndef __restrict__
+#define __restrict__
+#endif
+
+struct dim3 {
+    unsigned x, y, z;
+    dim3(unsigned x_ = 1, unsigned y_ = 1, unsigned z_ = 1) : x(x_), y(y_), z(z_) {}
+};
+struct float4 { float x, y, z, w; };
+
+inline dim3& emu_threadIdx() { static thread_local dim3 v; return v; }
+inline dim3& emu_blockIdx()  { static thread_local dim3 v; return v; }
+inline dim3& emu_blockDim()  { static thread_local dim3 v; return v; }
+inline dim3& emu_gridDim()   { static thread_local dim3 v; return v; }
+#define threadIdx emu_threadIdx()
+#define blockIdx  emu_blockIdx()
+#define blockDim  emu_blockDim()
+#define gridDim   emu_gridDim()
+
+inline void*& emu_lds_ptr() { static thread_local void* p = nullptr; return p; }
+inline void* mbamd_emu_dyn_lds() { return emu_lds_ptr(); }
+
+inline int atomicAdd(int* p, int v) { int o = *p; *p += v; return o; }
+
+typedef int hipError_t;
+typedef int hipStream_t;
+struct EmuEvent { std::chrono::steady_clock::time_point t; };
+typedef EmuEvent* hipEvent_t;
+enum { hipSuccess = 0, hipErrorOutOfMemory = 2, hipErrorInvalidValue = 1 };
+enum hipMemcpyKind { hipMemcpyHostToDevice, hipMemcpyDeviceToHost, hipMemcpyDeviceToDevice };
+#define hipStreamNonBlocking 0
+#define hipHostMallocDefault 0
+struct hipDeviceProp_t { char name[256]; size_t totalGlobalMem; int multiProcessorCount; char gcnArchName[256]; };
+
+inline const char* hipGetErrorString(hipError_t) { return "host-emulation error"; }
+inline hipError_t hipGetLastError() { return hipSuccess; }
+inline hipError_t hipGetDeviceCount(int* n) { *n = 1; return hipSuccess; }
+inline hipError_t hipSetDevice(int) { return hipSuccess; }
+inline hipError_t hipGetDeviceProperties(hipDeviceProp_t* p, int) {
+    std::snprintf(p->name, sizeof p->name, "host emulation (TEST ONLY)");
+    std::snprintf(p->gcnArchName, sizeof p->gcnArchName, "hostemu");
+    p->totalGlobalMem = (size_t) 8 << 30; p->multiProcessorCount = 1; return hipSuccess; }
+inline hipError_t hipMalloc(void** p, size_t n) { *p = std::calloc(1, n ? n : 1); return *p ? hipSuccess : hipErrorOutOfMemory; }
+template <class T> inline hipError_t hipMalloc(T** p, size_t n) { return hipMalloc((void**) p, n); }
+inline hipError_t hipFree(void* p) { std::free(p); return hipSuccess; }
+inline hipError_t hipHostMalloc(void** p, size_t n, unsigned = 0) { return hipMalloc(p, n); }
+template <class T> inline hipError_t hipHostMalloc(T** p, size_t n, unsigned f = 0) { return hipHostMalloc((void**) p, n, f); }
+inline hipError_t hipHostFree(void* p) { std::free(p); return hipSuccess; }
+inline hipError_t hipMemcpy(void* d, const void* s, size_t n, hipMemcpyKind) { std::memcpy(d, s, n); return hipSuccess; }
+inline hipError_t hipMemcpyAsync(void* d, const void* s, size_t n, hipMemcpyKind, hipStream_t) { std::memcpy(d, s, n); return hipSuccess; }
+inline hipError_t hipMemsetAsync(void* d, int v, size_t n, hipStream_t) { std::memset(d, v, n); return hipSuccess; }
+inline hipError_t hipMemset(void* d, int v, size_t n) { std::memset(d, v, n); return hipSuccess; }
+inline hipError_t hipStreamCreateWithFlags(hipStream_t* s, unsigned) { *s = 0; return hipSuccess; }
+inline hipError_t hipStreamDestroy(hipStream_t) { return hipSuccess; }
+inline hipError_t hipStreamSynchronize(hipStream_t) { return hipSuccess; }
+inline hipError_t hipDeviceSynchronize() { return hipSuccess; }
+inline hipError_t hipEventCreate(hipEvent_t* e) { *e = new EmuEvent; return hipSuccess; }
+inline hipError_t hipEventDestroy(hipEvent_t e) { delete e; return hipSuccess; }
+inline hipError_t hipEventRecord(hipEvent_t e, hipStream_t) { e->t = std::chrono::steady_clock::now(); return hipSuccess; }
+inline hipError_t hipEventSynchronize(hipEvent_t) { return hipSuccess; }
+inline hipError_t hipEventElapsedTime(float* ms, hipEvent_t a, hipEvent_t b) {
+    *ms = std::chrono::duration<float, std::milli>(b->t - a->t).count(); return hipSuccess; }
+
+template <class Kernel, class... Args>
+inline void emu_launch(Kernel kernel, dim3 grid, dim3 block, size_t lds_bytes, Args... args)
+{
+    std::vector<unsigned char> lds(lds_bytes + 64);
+    emu_gridDim() = grid;
+    emu_blockDim() = block;
+    for (unsigned bz = 0; bz < grid.z; ++bz)
+        for (unsigned by = 0; by < grid.y; ++by)
+            for (unsigned bx = 0; bx < grid.x; ++bx) {
+                emu_blockIdx() = dim3(bx, by, bz);
+                void* base = lds.data();
+                size_t space = lds.size();
+                emu_lds_ptr() = std::align(16, lds_bytes, base, space);
+                for (unsigned tz = 0; tz < block.z; ++tz)
+                    for (unsigned ty = 0; ty < block.y; ++ty)
+                        for (unsigned tx = 0; tx < block.x; ++tx) {
+                            emu_threadIdx() = dim3(tx, ty, tz);
+                            kernel(args...);
+                        }
+            }
+}
+#define MBAMD_LAUNCH(kernel, grid, block, lds, stream, ...) emu_launch(kernel, dim3(grid), dim3(block), lds, __VA_ARGS__)
+
+#endif

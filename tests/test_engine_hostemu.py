@@ -1,0 +1,105 @@
+"""Host logic of the engine, run on the CPU through the TEST-ONLY host-emulation build
+(tests/hostemu/): BEAGLE call protocol, buffer/index bookkeeping, operation scheduling, LDS-slot
+allocation of the tree-walk path, layout conversions, scaling arithmetic, dynamic-rescale protocol.
+The GPU twin of these checks is tests/test_engine_gpu.py (-m gpu), which runs the product library."""
+import os
+
+import numpy as np
+import pytest
+
+from mrbayes_amd import beagle as bg
+from mrbayes_amd import likelihood as lk
+from mrbayes_amd import tree as mbtree
+from mrbayes_amd.division import division_from_golden, synthetic_division
+from tests import engine_checks as ec
+from tests.hostemu import build_emu
+
+SMALL = ["primates_gtr_g4", "primates_gtr_ig4", "primates_gtr_equal", "avian_wag_g4", "replicase_m3",
+         "synth_dna_gaps", "synth_aa_wag", "synth_codon_m3"]
+
+
+@pytest.fixture(scope="module")
+def emu():
+    return bg.library(build_emu.build())
+
+
+def test_emu_is_not_the_product(emu):
+    assert "TESTONLY" in emu.path
+    assert emu.resources()[0][0].startswith("host emulation")
+
+
+@pytest.mark.parametrize("case", ["primates_gtr_g4", "avian_wag_g4", "replicase_m3"])
+def test_transition_matrices(emu, oracle, golden_dir, case):
+    ec.check_transition_matrices(emu, oracle, division_from_golden(golden_dir, case))
+
+
+@pytest.mark.parametrize("nstates,ncat,npat", [(4, 4, 100), (4, 1, 64), (4, 3, 65), (20, 4, 70), (61, 1, 33),
+                                                 (16, 2, 10), (2, 4, 5)])
+def test_single_operations(emu, oracle, nstates, ncat, npat):
+    ec.check_single_operations(emu, oracle, nstates, ncat, npat)
+
+
+@pytest.mark.parametrize("case", SMALL)
+def test_golden_always_rescale(emu, oracle, golden_dir, case):
+    ec.check_golden_case(emu, oracle, golden_dir, case, lk.MB_BEAGLE_SCALE_ALWAYS)
+
+
+@pytest.mark.parametrize("case", ["primates_gtr_g4", "synth_dna_gaps", "synth_aa_wag"])
+def test_golden_dynamic_rescale(emu, oracle, golden_dir, case):
+    ec.check_golden_case(emu, oracle, golden_dir, case, lk.MB_BEAGLE_SCALE_DYNAMIC)
+
+
+def test_site_likelihoods(emu, oracle, golden_dir):
+    ec.check_site_likelihoods(emu, oracle, division_from_golden(golden_dir, "primates_gtr_g4"))
+    ec.check_site_likelihoods(emu, oracle, division_from_golden(golden_dir, "replicase_m3"))
+
+
+@pytest.mark.parametrize("case", ["primates_gtr_g4", "synth_dna_gaps", "avian_wag_g4"])
+@pytest.mark.parametrize("scaling", [lk.MB_BEAGLE_SCALE_ALWAYS, lk.MB_BEAGLE_SCALE_DYNAMIC])
+def test_partial_update_and_reject(emu, oracle, golden_dir, case, scaling):
+    ec.check_partial_update_and_reject(emu, oracle, division_from_golden(golden_dir, case), scaling)
+
+
+def test_multi_chain(emu, oracle, golden_dir):
+    ec.check_multi_chain(emu, oracle, division_from_golden(golden_dir, "primates_gtr_g4"))
+
+
+def test_dynamic_rescaling_state_machine(emu, oracle):
+    div = synthetic_division("gtr", 300, 96, seed=31, tree_seed=32)
+    ec.check_dynamic_rescaling_state_machine(emu, oracle, div)
+
+
+def test_generic_kernels_on_dna(emu, oracle, golden_dir, monkeypatch):
+    """MBAMD_FORCE_GENERIC routes 4-state data through the general-state kernels (state-major layout)."""
+    monkeypatch.setenv("MBAMD_FORCE_GENERIC", "1")
+    ec.check_golden_case(emu, oracle, golden_dir, "primates_gtr_g4")
+    ec.check_golden_case(emu, oracle, golden_dir, "primates_gtr_equal")
+    ec.check_single_operations(emu, oracle, 4, 4, 70)
+    ec.check_single_operations(emu, oracle, 4, 3, 70)      # unfused (two-pass) variant
+
+
+def test_lds_stack_eviction(emu, oracle, monkeypatch):
+    """With only two LDS slots the tree-walk scheduler must evict and re-read its own stores."""
+    monkeypatch.setenv("MBAMD_MAX_LDS_SLOTS", "2")
+    div = synthetic_division("gtr", 60, 130, seed=41, tree_seed=42)
+    lnl = ec.engine_lnl(emu, div)
+    want = oracle.tree_loglike(div, use_shortcuts=False)
+    assert abs(lnl - want) / abs(want) < ec.REL_FP64
+    cat = synthetic_division("gtr", 40, 70, seed=43, tree_seed=44)
+    cat.tree = mbtree.caterpillar_tree(40)
+    lnl = ec.engine_lnl(emu, cat)
+    want = oracle.tree_loglike(cat, use_shortcuts=False)
+    assert abs(lnl - want) / abs(want) < ec.REL_FP64
+
+
+def test_error_codes(emu):
+    inst = bg.BeagleInstance(emu, 2, 4, 2, 4, 10, 1, 2, 4, 2)
+    with pytest.raises(bg.BeagleError) as e:
+        inst.update_partials(np.array([[9, -1, -1, 0, 0, 1, 1]], dtype=np.int32))
+    assert e.value.code == bg.BEAGLE_ERROR_OUT_OF_RANGE
+    with pytest.raises(bg.BeagleError) as e:
+        inst.update_partials(np.array([[3, -1, -1, 0, 0, 1, 1]], dtype=np.int32))   # children never written
+    assert e.value.code == bg.BEAGLE_ERROR_OUT_OF_RANGE
+    with pytest.raises(bg.BeagleError):
+        bg.BeagleInstance(emu, 2, 4, 2, 65, 10, 1, 2, 4, 2)                         # > 64 states
+    inst.finalize()
