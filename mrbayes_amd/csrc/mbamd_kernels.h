@@ -8,7 +8,7 @@
 //   k_scale_*            Copy/Reset/RemoveNodeScalers bookkeeping (src/likelihood.c:7981-8131)
 //
 // Data layout in HBM (all fp32 unless noted), P_pad = patterns rounded up to 64:
-//   4-state partials   : float4 [K][P_pad]            one float4 = the 4 states of (category, pattern)
+//   4-state partials   : f4 [K][P_pad]            one f4 = the 4 states of (category, pattern)
 //   general partials   : float  [K][S][P_pad]         state-major: lanes = consecutive patterns -> coalesced
 //   4-state matrices   : float  [K][4][4]             row = from-state (same as the reference ti[k][i][j])
 //   general matrices   : float  [K][SP][SP] transposed (mT[k][j][i] = P_k(i->j)), zero padded to SP
@@ -38,9 +38,13 @@
 #if defined(MBAMD_HOST_EMU)
 #define MBAMD_AS_GLOBAL
 #define MBAMD_AS_CONST
+namespace mbamd { typedef float4 f4; }
 #else
 #define MBAMD_AS_GLOBAL __attribute__((address_space(1)))
 #define MBAMD_AS_CONST __attribute__((address_space(4)))
+// a native clang vector (not HIP's f4 class) so that it can be loaded/stored through
+// address-space qualified pointers as one dwordx4 access
+namespace mbamd { typedef float f4 __attribute__((ext_vector_type(4))); }
 #endif
 
 namespace mbamd {
@@ -106,12 +110,12 @@ __device__ __forceinline__ float scale_pow2(float v, int neg_e)
 #endif
 }
 
-__device__ __forceinline__ float max4(float4 v) { return fmaxf(fmaxf(v.x, v.y), fmaxf(v.z, v.w)); }
+__device__ __forceinline__ float max4(f4 v) { return fmaxf(fmaxf(v.x, v.y), fmaxf(v.z, v.w)); }
 
-// 4x4 matrix (row-major, uniform -> scalar registers) times float4
-__device__ __forceinline__ float4 mat4_mul(const MBAMD_AS_CONST float* __restrict__ m, float4 v)
+// 4x4 matrix (row-major, uniform -> scalar registers) times f4
+__device__ __forceinline__ f4 mat4_mul(const MBAMD_AS_CONST float* __restrict__ m, f4 v)
 {
-    float4 r;
+    f4 r;
     r.x = fmaf(m[3], v.w, fmaf(m[2], v.z, fmaf(m[1], v.y, m[0] * v.x)));
     r.y = fmaf(m[7], v.w, fmaf(m[6], v.z, fmaf(m[5], v.y, m[4] * v.x)));
     r.z = fmaf(m[11], v.w, fmaf(m[10], v.z, fmaf(m[9], v.y, m[8] * v.x)));
@@ -119,14 +123,14 @@ __device__ __forceinline__ float4 mat4_mul(const MBAMD_AS_CONST float* __restric
     return r;
 }
 
-// a float4 this lane itself stored earlier in the same launch: bypass the (non-coherent) vector L1
-__device__ __forceinline__ float4 load_own_store(const float4* p)
+// a f4 this lane itself stored earlier in the same launch: bypass the (non-coherent) vector L1
+__device__ __forceinline__ f4 load_own_store(const f4* p)
 {
 #if defined(MBAMD_HOST_EMU)
     return *p;
 #else
     const float* f = reinterpret_cast<const float*>(p);
-    float4 r;
+    f4 r;
     r.x = __hip_atomic_load(f + 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     r.y = __hip_atomic_load(f + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     r.z = __hip_atomic_load(f + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -150,14 +154,14 @@ __device__ __forceinline__ float4 load_own_store(const float4* p)
 // ---------------------------------------------------------------------------------------------
 template <int K>
 __device__ __forceinline__ void walk_load_child(const void* ptr, int kind, int slot, int Ppad, int c, int lane,
-                                                const float4* lds, float4 (&v)[K])
+                                                const f4* lds, f4 (&v)[K])
 {
     if (kind == CHILD_LDS) {
 #pragma unroll
         for (int k = 0; k < K; ++k) v[k] = lds[(slot * K + k) * 64 + lane];
     } else if (kind == CHILD_STATES) {
         const unsigned s = as_global(reinterpret_cast<const uint8_t*>(ptr))[c];
-        float4 one;
+        f4 one;
         one.x = (s == 0u || s >= 4u) ? 1.0f : 0.0f;
         one.y = (s == 1u || s >= 4u) ? 1.0f : 0.0f;
         one.z = (s == 2u || s >= 4u) ? 1.0f : 0.0f;
@@ -165,11 +169,11 @@ __device__ __forceinline__ void walk_load_child(const void* ptr, int kind, int s
 #pragma unroll
         for (int k = 0; k < K; ++k) v[k] = one;
     } else if (kind == CHILD_PARTIALS) {
-        const MBAMD_AS_GLOBAL float4* p = as_global(reinterpret_cast<const float4*>(ptr));
+        const MBAMD_AS_GLOBAL f4* p = as_global(reinterpret_cast<const f4*>(ptr));
 #pragma unroll
         for (int k = 0; k < K; ++k) v[k] = p[(size_t) k * Ppad + c];
     } else {
-        const float4* p = reinterpret_cast<const float4*>(ptr);
+        const f4* p = reinterpret_cast<const f4*>(ptr);
 #pragma unroll
         for (int k = 0; k < K; ++k) v[k] = load_own_store(p + (size_t) k * Ppad + c);
     }
@@ -180,9 +184,9 @@ __global__ void __launch_bounds__(64)
 k_walk_s4(const PartialsOp* __restrict__ ops, int nops, int Ppad, int32_t* __restrict__ cumulative)
 {
 #if defined(MBAMD_HOST_EMU)
-    float4* lds = reinterpret_cast<float4*>(mbamd_emu_dyn_lds());
+    f4* lds = reinterpret_cast<f4*>(mbamd_emu_dyn_lds());
 #else
-    extern __shared__ float4 lds[];
+    extern __shared__ f4 lds[];
 #endif
     const int lane = threadIdx.x;
     const int c = blockIdx.x * 64 + lane;
@@ -198,18 +202,18 @@ k_walk_s4(const PartialsOp* __restrict__ ops, int nops, int Ppad, int32_t* __res
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #endif
         }
-        float4 a[K], b[K];
+        f4 a[K], b[K];
         walk_load_child<K>(op->c1, k1, op->c1_slot, Ppad, c, lane, lds, a);
         walk_load_child<K>(op->c2, k2, op->c2_slot, Ppad, c, lane, lds, b);
 
         const MBAMD_AS_CONST float* __restrict__ m1 = as_const(op->m1);
         const MBAMD_AS_CONST float* __restrict__ m2 = as_const(op->m2);
-        float4 out[K];
+        f4 out[K];
         float mx = 0.0f;
 #pragma unroll
         for (int k = 0; k < K; ++k) {
-            const float4 f1 = mat4_mul(m1 + 16 * k, a[k]);
-            const float4 f2 = mat4_mul(m2 + 16 * k, b[k]);
+            const f4 f1 = mat4_mul(m1 + 16 * k, a[k]);
+            const f4 f2 = mat4_mul(m2 + 16 * k, b[k]);
             out[k].x = f1.x * f2.x;
             out[k].y = f1.y * f2.y;
             out[k].z = f1.z * f2.z;
@@ -237,7 +241,7 @@ k_walk_s4(const PartialsOp* __restrict__ ops, int nops, int Ppad, int32_t* __res
             }
         }
 
-        MBAMD_AS_GLOBAL float4* __restrict__ dst = as_global(reinterpret_cast<float4*>(op->dst));
+        MBAMD_AS_GLOBAL f4* __restrict__ dst = as_global(reinterpret_cast<f4*>(op->dst));
 #pragma unroll
         for (int k = 0; k < K; ++k) dst[(size_t) k * Ppad + c] = out[k];
         const int ds = op->dst_slot;

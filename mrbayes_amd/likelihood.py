@@ -374,3 +374,60 @@ class BeagleDivision:
         lnl = self.LaunchBEAGLELogLikeForDivision(chain)
         self.ClearTouches(chain)
         return lnl
+
+
+# ------------------------------------------------------------------------------------------------
+# Call recording / replay.  MrBayes' host side is C: the handful of BEAGLE calls of one generation
+# cost it microseconds.  The Python twin above spends milliseconds building the same arguments, so
+# throughput measurements record the exact C-ABI call sequence of an evaluation once (function
+# pointer + already marshalled ctypes arguments) and replay it: the engine sees byte-for-byte the
+# calls an unmodified MrBayes makes, without the interpreter in the timed path.
+# ------------------------------------------------------------------------------------------------
+class _RecordingLib:
+    def __init__(self, real, log):
+        self._real, self._log = real, log
+
+    def __getattr__(self, name):
+        fn = getattr(self._real, name)
+
+        def call(*args):
+            self._log.append((fn, args))
+            return fn(*args)
+        return call
+
+
+class RecordedEvaluation:
+    """The C-ABI calls of one LogLike(chain), replayable with `run()` -> (return code, lnL)."""
+
+    def __init__(self, calls):
+        self.calls = calls
+        self._out = None
+        for fn, args in calls:
+            if fn.__name__ in ("beagleCalculateEdgeLogLikelihoods", "beagleCalculateRootLogLikelihoods"):
+                ref = args[-3] if fn.__name__ == "beagleCalculateEdgeLogLikelihoods" else args[-1]
+                self._out = ref._obj
+        if self._out is None:
+            raise ValueError("the recorded evaluation contains no log-likelihood call")
+
+    def run(self):
+        rc = 0
+        for fn, args in self.calls:
+            r = fn(*args)
+            if r != 0:
+                rc = r
+        return rc, self._out.value
+
+
+def record_evaluation(bd: BeagleDivision, chain: int = 0, touch_all: bool = True) -> RecordedEvaluation:
+    """Run bd.LogLike(chain) once while logging every C-ABI call it makes."""
+    log = []
+    real = bd.inst.lib
+    bd.inst.lib = _RecordingLib(real, log)
+    try:
+        if touch_all:
+            bd.TouchAllTreeNodes(chain)
+        bd.LogLike(chain)
+        bd.AcceptMove(chain)
+    finally:
+        bd.inst.lib = real
+    return RecordedEvaluation(log)

@@ -1,0 +1,234 @@
+"""Parity tests proper: the PRODUCT library (mrbayes_amd/libhmsbeagle.so, HIP, gfx950) on a real MI355X,
+called through its C ABI and compared with the CPU oracle, the golden fixtures written by the real
+reference binaries, and -- at the BASELINE sizes -- size-independent properties of the recursion.
+
+Every test is `@pytest.mark.gpu`; the library is loaded from the tree (never a CPU build) and the
+fixture fails loudly when it or the GPU is missing.
+"""
+import os
+
+import numpy as np
+import pytest
+
+from mrbayes_amd import beagle as bg
+from mrbayes_amd import likelihood as lk
+from mrbayes_amd import tree as mbtree
+from mrbayes_amd.division import division_from_golden, synthetic_division
+from tests import engine_checks as ec
+
+pytestmark = pytest.mark.gpu
+
+SMALL = ["primates_gtr_g4", "primates_gtr_ig4", "primates_gtr_equal", "avian_wag_g4", "replicase_m3",
+         "synth_dna_gaps", "synth_aa_wag", "synth_codon_m3"]
+
+
+@pytest.fixture(scope="module")
+def gpu():
+    lib = bg.library()                       # raises if libhmsbeagle.so was not built
+    assert "hostemu" not in lib.path
+    res = lib.resources()
+    assert res, "no HIP device visible: the engine has no CPU path"
+    assert res[0][2] & bg.BEAGLE_FLAG_PROCESSOR_GPU
+    return lib
+
+
+def test_resource_is_a_gpu(gpu):
+    name, desc, flags = gpu.resources()[0]
+    assert "gfx" in desc
+
+
+@pytest.mark.parametrize("case", ["primates_gtr_g4", "avian_wag_g4", "replicase_m3"])
+def test_transition_matrices(gpu, oracle, golden_dir, case):
+    ec.check_transition_matrices(gpu, oracle, division_from_golden(golden_dir, case))
+
+
+@pytest.mark.parametrize("nstates,ncat,npat", [(4, 4, 100), (4, 1, 64), (4, 3, 65), (4, 8, 130), (20, 4, 70),
+                                                 (20, 1, 200), (61, 1, 33), (61, 1, 129), (61, 3, 40),
+                                                 (16, 2, 10), (2, 4, 5), (20, 4, 1), (4, 4, 1)])
+def test_single_operations(gpu, oracle, nstates, ncat, npat):
+    ec.check_single_operations(gpu, oracle, nstates, ncat, npat)
+
+
+@pytest.mark.parametrize("case", SMALL)
+def test_golden_always_rescale(gpu, oracle, golden_dir, case):
+    ec.check_golden_case(gpu, oracle, golden_dir, case, lk.MB_BEAGLE_SCALE_ALWAYS)
+
+
+@pytest.mark.parametrize("case", ["primates_gtr_g4", "synth_dna_gaps", "synth_aa_wag", "replicase_m3"])
+def test_golden_dynamic_rescale(gpu, oracle, golden_dir, case):
+    ec.check_golden_case(gpu, oracle, golden_dir, case, lk.MB_BEAGLE_SCALE_DYNAMIC)
+
+
+def test_site_likelihoods(gpu, oracle, golden_dir):
+    ec.check_site_likelihoods(gpu, oracle, division_from_golden(golden_dir, "primates_gtr_g4"))
+    ec.check_site_likelihoods(gpu, oracle, division_from_golden(golden_dir, "replicase_m3"))
+    ec.check_site_likelihoods(gpu, oracle, division_from_golden(golden_dir, "avian_wag_g4"))
+
+
+@pytest.mark.parametrize("case", ["primates_gtr_g4", "synth_dna_gaps", "avian_wag_g4", "replicase_m3"])
+@pytest.mark.parametrize("scaling", [lk.MB_BEAGLE_SCALE_ALWAYS, lk.MB_BEAGLE_SCALE_DYNAMIC])
+def test_partial_update_and_reject(gpu, oracle, golden_dir, case, scaling):
+    ec.check_partial_update_and_reject(gpu, oracle, division_from_golden(golden_dir, case), scaling)
+
+
+def test_multi_chain(gpu, oracle, golden_dir):
+    ec.check_multi_chain(gpu, oracle, division_from_golden(golden_dir, "primates_gtr_g4"))
+    ec.check_multi_chain(gpu, oracle, division_from_golden(golden_dir, "avian_wag_g4"), nchains=2)
+
+
+def test_dynamic_rescaling_state_machine(gpu, oracle):
+    div = synthetic_division("gtr", 300, 96, seed=31, tree_seed=32)
+    ec.check_dynamic_rescaling_state_machine(gpu, oracle, div)
+
+
+def test_generic_kernels_on_dna(gpu, oracle, golden_dir, monkeypatch):
+    monkeypatch.setenv("MBAMD_FORCE_GENERIC", "1")
+    ec.check_golden_case(gpu, oracle, golden_dir, "primates_gtr_g4")
+    ec.check_single_operations(gpu, oracle, 4, 4, 70)
+    ec.check_single_operations(gpu, oracle, 4, 3, 70)
+
+
+def test_vector_kernels_on_protein_and_codon(gpu, oracle, golden_dir, monkeypatch):
+    """MBAMD_NO_MFMA routes 20/61-state data through the VALU general-state kernels: both paths must agree
+    with the oracle (and therefore with each other)."""
+    monkeypatch.setenv("MBAMD_NO_MFMA", "1")
+    ec.check_golden_case(gpu, oracle, golden_dir, "avian_wag_g4")
+    ec.check_golden_case(gpu, oracle, golden_dir, "replicase_m3")
+    ec.check_single_operations(gpu, oracle, 20, 4, 70)
+    ec.check_single_operations(gpu, oracle, 61, 1, 33)
+
+
+def test_lds_stack_eviction(gpu, oracle, monkeypatch):
+    monkeypatch.setenv("MBAMD_MAX_LDS_SLOTS", "2")
+    div = synthetic_division("gtr", 60, 130, seed=41, tree_seed=42)
+    lnl = ec.engine_lnl(gpu, div)
+    want = oracle.tree_loglike(div, use_shortcuts=False)
+    assert abs(lnl - want) / abs(want) < ec.REL_FP64
+    cat = synthetic_division("gtr", 40, 70, seed=43, tree_seed=44)
+    cat.tree = mbtree.caterpillar_tree(40)
+    lnl = ec.engine_lnl(gpu, cat)
+    want = oracle.tree_loglike(cat, use_shortcuts=False)
+    assert abs(lnl - want) / abs(want) < ec.REL_FP64
+
+
+@pytest.mark.parametrize("waves", [1, 2, 4, 8])
+def test_walk_waves_agree(gpu, oracle, monkeypatch, waves):
+    """The tree-walk kernel scheduled over 1/2/4/8 waves per pattern block gives bit-identical partials
+    (the arithmetic per node does not depend on which wave executes it), hence identical lnL."""
+    div = synthetic_division("gtr", 150, 1000, seed=51, tree_seed=52, p_gap=0.05)
+    monkeypatch.setenv("MBAMD_WALK_WAVES", "1")
+    base = ec.engine_lnl(gpu, div)
+    monkeypatch.setenv("MBAMD_WALK_WAVES", str(waves))
+    assert ec.engine_lnl(gpu, div) == base
+    want = oracle.tree_loglike(div, use_shortcuts=False)
+    assert abs(base - want) / abs(want) < ec.REL_FP64
+
+
+def test_error_codes(gpu):
+    inst = bg.BeagleInstance(gpu, 2, 4, 2, 4, 10, 1, 2, 4, 2)
+    with pytest.raises(bg.BeagleError) as e:
+        inst.update_partials(np.array([[9, -1, -1, 0, 0, 1, 1]], dtype=np.int32))
+    assert e.value.code == bg.BEAGLE_ERROR_OUT_OF_RANGE
+    with pytest.raises(bg.BeagleError):
+        bg.BeagleInstance(gpu, 2, 4, 2, 65, 10, 1, 2, 4, 2)
+    inst.finalize()
+
+
+# ---- BASELINE-size cases ---------------------------------------------------------------------------
+def test_config2_dna_500x20k_against_reference(gpu, golden_dir):
+    """configs[1]: the engine's lnL on the 500 x 20 000 GTR+G4 alignment vs the lnL the real reference
+    printed for the same alignment/tree/parameters (fp64 build and FMA build)."""
+    import json
+    with open(os.path.join(golden_dir, "synth_dna_500x20k.json")) as fh:
+        g = json.load(fh)
+    div = division_from_golden(golden_dir, "synth_dna_500x20k")
+    assert div.npatterns == g["npatterns"]
+    for scaling in (lk.MB_BEAGLE_SCALE_ALWAYS, lk.MB_BEAGLE_SCALE_DYNAMIC):
+        lnl = ec.engine_lnl(gpu, div, scaling)
+        assert abs(lnl - g["lnL"]["fp64"]) / abs(g["lnL"]["fp64"]) < ec.REL_FP64, (scaling, lnl)
+        assert abs(lnl - g["lnL"]["fma"]) / abs(g["lnL"]["fma"]) < ec.REL_FMA, (scaling, lnl)
+
+
+def _additivity(gpu, kind, ntaxa, npat, cut, **kw):
+    """Site patterns are independent: lnL(all patterns) == lnL(first block) + lnL(rest), and the per-site
+    values of the blocks are the corresponding slices (a checksum of checksums at any size)."""
+    div = synthetic_division(kind, ntaxa, npat, **kw)
+    bd = lk.BeagleDivision(div, gpu)
+    whole = bd.LogLike(0)
+    site = bd.inst.get_site_log_likelihoods()
+    bd.finalize()
+    assert np.isfinite(whole)
+    assert abs(site.sum() - whole) <= 1e-9 * abs(whole)
+    parts = []
+    for lo, hi in ((0, cut), (cut, npat)):
+        sub = synthetic_division(kind, ntaxa, npat, **kw)
+        sub.weights = sub.weights[lo:hi]
+        sub.tip_states = [s[lo:hi].copy() for s in sub.tip_states]
+        bs = lk.BeagleDivision(sub, gpu)
+        parts.append(bs.LogLike(0))
+        s2 = bs.inst.get_site_log_likelihoods()
+        bs.finalize()
+        assert np.array_equal(s2, site[lo:hi])
+    assert abs(sum(parts) - whole) <= 1e-9 * abs(whole)
+    return div, whole
+
+
+def test_config2_additivity_and_sample(gpu, oracle):
+    div, whole = _additivity(gpu, "gtr", 500, 20000, 7777)
+    # oracle on a sample of the patterns (the full problem takes the scalar oracle about a minute)
+    sub = synthetic_division("gtr", 500, 20000)
+    sub.weights = sub.weights[:1500]
+    sub.tip_states = [s[:1500].copy() for s in sub.tip_states]
+    bs = lk.BeagleDivision(sub, gpu)
+    got = bs.LogLike(0)
+    bs.finalize()
+    want = oracle.tree_loglike(sub, use_shortcuts=False)
+    assert abs(got - want) / abs(want) < ec.REL_FP64
+
+
+def test_config3_aa_200x10k(gpu, oracle, golden_dir):
+    div, whole = _additivity(gpu, "wag", 200, 10000, 3333, seed=5, tree_seed=9, golden_dir=golden_dir)
+    sub = synthetic_division("wag", 200, 10000, seed=5, tree_seed=9, golden_dir=golden_dir)
+    sub.weights = sub.weights[:300]
+    sub.tip_states = [s[:300].copy() for s in sub.tip_states]
+    bs = lk.BeagleDivision(sub, gpu)
+    got = bs.LogLike(0)
+    bs.finalize()
+    want = oracle.tree_loglike(sub, use_shortcuts=False)
+    assert abs(got - want) / abs(want) < ec.REL_FP64
+
+
+def test_config5_codon_100x5k(gpu, oracle):
+    div, whole = _additivity(gpu, "m3", 100, 5000, 1234, seed=6, tree_seed=10)
+    sub = synthetic_division("m3", 100, 5000, seed=6, tree_seed=10)
+    sub.weights = sub.weights[:100]
+    sub.tip_states = [s[:100].copy() for s in sub.tip_states]
+    bs = lk.BeagleDivision(sub, gpu)
+    got = bs.LogLike(0)
+    bs.finalize()
+    want = oracle.tree_loglike(sub, use_shortcuts=False)
+    assert abs(got - want) / abs(want) < ec.REL_FP64
+
+
+def test_config4_dna_1000x50k_two_chains(gpu):
+    """configs[3] shape on one GPU: 1000 taxa x 50 000 patterns, two chains in one instance (6.4 GB of
+    partials each): the chains agree with each other, a reject restores the previous value exactly, and
+    pattern-block additivity holds."""
+    div = synthetic_division("gtr", 1000, 50000, seed=6, tree_seed=10)
+    bd = lk.BeagleDivision(div, gpu, nchains=2)
+    a = bd.LogLike(0)
+    b = bd.LogLike(1)
+    assert np.isfinite(a) and a == b
+    bd.AcceptMove(0)
+    t = div.tree
+    old = t.length[5]
+    t.length[5] = 0.31
+    bd.TouchBranch(0, 5)
+    c = bd.LogLike(0)
+    assert c != a
+    t.length[5] = old
+    bd.ResetFlips(0)
+    assert bd.LogLike(0) == a
+    site = bd.inst.get_site_log_likelihoods()
+    assert abs(site.sum() - a) <= 1e-9 * abs(a)
+    bd.finalize()
