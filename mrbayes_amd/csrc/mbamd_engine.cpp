@@ -27,6 +27,9 @@
 
 #include "libhmsbeagle/beagle.h"
 #include "mbamd_kernels.h"
+#if !defined(MBAMD_HOST_EMU)
+#include "mbamd_kernels_mfma.h"
+#endif
 
 namespace mbamd {
 
@@ -51,22 +54,48 @@ static inline int round_up(int v, int m) { return (v + m - 1) / m * m; }
 
 enum KernelPath { PATH_AUTO = 0, PATH_GENERIC = 1, PATH_WALK = 2, PATH_MFMA = 3 };
 
+// A compiled operation list: the device-resident table a partials kernel walks, cached under the exact
+// BeagleOperation array it was built from.  MrBayes re-issues the same lists all the time (every move
+// that dirties the whole tree alternates between the two buffer-flip states), so the host-side
+// scheduling and the table upload happen once per distinct list, not once per generation.
+struct Plan {
+    std::vector<int> key;            // the BeagleOperation ints + cumulative index + layout epoch
+    uint64_t hash = 0, lastUse = 0;
+    PartialsOp* d_table = nullptr;
+    size_t cap = 0;                  // bytes allocated for d_table
+    int nsteps = 0, W = 1, slotsUsed = 0;        // tree-walk schedule
+    std::vector<int> start;                      // general path: first table entry of each dependency level
+    bool anyScale = false;
+};
+
 struct Instance {
     int device = 0;
     hipStream_t stream{};
     int tipCount = 0, nBuffers = 0, S = 0, SP = 0, P = 0, Ppad = 0, nEigen = 0, nMatrices = 0, K = 0, nScale = 0;
     bool s4 = false;                 // 4-state float4 layout + tree-walk kernel
+    bool mfma = false;               // general-state path on the matrix cores (mbamd_kernels_mfma.h)
+    int walkWaves = 1, walkSlots = 16;   // tree-walk kernel: waves per pattern block, LDS slots per workgroup
+    int lastWalkSteps = 0, lastWalkSlots = 0;
+    int walkAblate = 0;              // MBAMD_WALK_ABLATE: timing experiments only (results are wrong when set)
+    int NT = 0, T = 0;               // MFMA packing: i-tiles of 32 rows, j-pairs
     long flags = 0;
     size_t partialsFloats = 0, matrixFloats = 0, eigenDoubles = 0;
     int path = PATH_AUTO;
 
-    std::vector<float*> partials;
-    std::vector<uint8_t*> tipStates;
+    std::vector<float*> partials;      // general path: allocated on first use; 4-state path: slices of the arena
+    std::vector<uint8_t*> tipStates;   // non-null while the buffer holds compact tip states
     std::vector<int32_t*> scale;
+    std::vector<char> valid;           // partials buffer has been written (import or operation destination)
+    // 4-state path: pattern-block-major arenas (see mbamd_kernels.h), one allocation each
+    float* arenaPartials = nullptr;
+    uint8_t* arenaTips = nullptr;
+    int32_t* arenaScale = nullptr;
+    BlockGeom geom{64, 64, 64};        // general path: linear [P_pad] arrays == block stride 64
     float* matrices = nullptr;
     double *d_eigen = nullptr, *d_freqs = nullptr, *d_weights = nullptr, *d_rates = nullptr, *d_pweights = nullptr;
-    double *d_site = nullptr, *d_wsite = nullptr, *d_sums = nullptr;
-    int nchunks = 0, chunk = 128;
+    double *d_site = nullptr;
+    int nblocks = 0;                  // P_pad / 64 partial sums of the weighted site log-likelihoods
+    RatesArg rates{};                 // category rates, passed to kernels by value
     bool haveSite = false;
 
     // growable device scratch
@@ -79,7 +108,9 @@ struct Instance {
     // pinned staging ring for small asynchronous uploads / downloads
     unsigned char* stage = nullptr;
     size_t stageCap = 0, stageOff = 0;
-    double* h_sums = nullptr;         // pinned, nchunks doubles
+    double* h_sums = nullptr;         // pinned host memory the integration kernel writes its block sums to
+    double* h_sums_dev = nullptr;     // the device-side address of h_sums
+    unsigned char* stage_dev = nullptr;   // the device-side address of the staging ring
 
     // timing of the partials kernels
     bool timing = false;
@@ -88,6 +119,11 @@ struct Instance {
     long timedLaunches = 0, pendingLaunches = 0;
 
     bool deferred = false, pendingResult = false;
+
+    std::vector<Plan*> plans;        // small LRU cache of compiled operation lists
+    uint64_t planClock = 0;
+    int layoutEpoch = 0;             // bumped whenever a buffer changes between compact-tip and partials form
+    long planHits = 0, planMisses = 0;
 
     // ---- helpers ----------------------------------------------------------------------------
     int grow(void** p, size_t* cap, size_t bytes)
@@ -122,9 +158,26 @@ struct Instance {
         return BEAGLE_SUCCESS;
     }
 
+    // small kernel inputs (job lists, pointer lists): placed in the pinned ring and read by the kernel
+    // directly over the host link -- no copy engine, no extra stream operation
+    int stageDirect(const void* src, size_t bytes, const void** devPtr)
+    {
+        size_t need = (bytes + 63) & ~(size_t) 63;
+        if (need > stageCap / 2) return fail(BEAGLE_ERROR_OUT_OF_MEMORY, "staging ring too small");
+        if (stageOff + need > stageCap) {
+            HIP_TRY(hipStreamSynchronize(stream));
+            stageOff = 0;
+        }
+        std::memcpy(stage + stageOff, src, bytes);
+        *devPtr = stage_dev + stageOff;
+        stageOff += need;
+        return BEAGLE_SUCCESS;
+    }
+
     int ensurePartials(int idx)
     {
         if (partials[idx]) return BEAGLE_SUCCESS;
+        if (s4) return fail(BEAGLE_ERROR_GENERAL, "4-state arena not initialised");
         float* p = nullptr;
         HIP_TRY(hipMalloc(&p, partialsFloats * sizeof(float)));
         HIP_TRY(hipMemsetAsync(p, 0, partialsFloats * sizeof(float), stream));
@@ -134,6 +187,7 @@ struct Instance {
     int ensureScale(int idx)
     {
         if (scale[idx]) return BEAGLE_SUCCESS;
+        if (s4) return fail(BEAGLE_ERROR_GENERAL, "4-state arena not initialised");
         int32_t* p = nullptr;
         HIP_TRY(hipMalloc(&p, (size_t) Ppad * sizeof(int32_t)));
         HIP_TRY(hipMemsetAsync(p, 0, (size_t) Ppad * sizeof(int32_t), stream));
@@ -146,6 +200,7 @@ struct Instance {
                int eigenBufferCount, int matrixBufferCount, int categoryCount, int scaleBufferCount, int dev);
     void destroy();
 
+    int configureWalk();
     int setTipStates(int tip, const int* states);
     int importPartials(int idx, const double* in, bool hasCategories);
     int getPartials(int idx, double* out);
@@ -154,10 +209,14 @@ struct Instance {
     int setMatrix(int idx, const double* in);
     int getMatrix(int idx, double* out);
     int updatePartials(const BeagleOperation* ops, int n, int cumIdx);
-    int launchWalk(std::vector<PartialsOp>& dev, const std::vector<int>& dstIdx, const std::vector<int>& c1Idx,
-                   const std::vector<int>& c2Idx, int32_t* cum);
-    int launchGeneric(std::vector<PartialsOp>& dev, const std::vector<int>& dstIdx, const std::vector<int>& c1Idx,
-                      const std::vector<int>& c2Idx, int32_t* cum);
+    int buildWalk(Plan& plan, std::vector<PartialsOp>& dev, const std::vector<int>& dstIdx, const std::vector<int>& c1Idx,
+                  const std::vector<int>& c2Idx);
+    int buildGeneric(Plan& plan, std::vector<PartialsOp>& dev, const std::vector<int>& dstIdx, const std::vector<int>& c1Idx,
+                     const std::vector<int>& c2Idx);
+    int runWalk(const Plan& plan, int32_t* cum);
+    int runGeneric(const Plan& plan, int32_t* cum);
+    int planTable(Plan& plan, const std::vector<PartialsOp>& table);
+    int timedRun(const Plan& plan, int32_t* cum);
     int accumulate(const int* idx, int n, int cumIdx, int sign);
     int integrate(const int* parent, const int* child, const int* prob, const int* wIdx, const int* fIdx,
                   const int* cumIdx, int count, double* out);
@@ -200,12 +259,41 @@ int Instance::create(int tipCount_, int partialsBufferCount, int compactBufferCo
     else if (S <= 20) SP = 20;
     else if (S <= 32) SP = 32;
     else SP = 64;
+#if !defined(MBAMD_HOST_EMU)
+    NT = (S + 31) / 32;
+    T = (S + 1) / 2;
+    mfma = !s4 && S >= 5 && S <= 64 && ((NT == 1 && K <= 4) || (NT == 2 && K <= 2)) &&
+           std::getenv("MBAMD_NO_MFMA") == nullptr;
+    if (mfma) SP = 32 * NT;          // transposed matrices padded to the MFMA tile height
+#endif
     partialsFloats = s4 ? (size_t) K * Ppad * 4 : (size_t) K * S * Ppad;
-    matrixFloats = (size_t) K * SP * SP;
+    matrixFloats = (size_t) K * SP * SP + (mfma ? (size_t) K * NT * T * 64 : 0);
+    if (s4) {
+        int rc = configureWalk();
+        if (rc) return rc;
+    }
     eigenDoubles = (size_t) 2 * S * S + S;
     partials.assign(nBuffers, nullptr);
     tipStates.assign(nBuffers, nullptr);
     scale.assign(std::max(nScale, 1), nullptr);
+    valid.assign(nBuffers, 0);
+    if (s4) {
+        // everything up front, like the reference's InitChainCondLikes (src/mcmc.c:5756-5834): one arena per
+        // kind, block-major so that a 64-pattern workgroup owns one contiguous slice of each
+        const size_t nb = (size_t) Ppad / 64;
+        geom.pstride = (unsigned long) nBuffers * K * 64;
+        geom.tstride = (unsigned) nBuffers * 64;
+        geom.sstride = (unsigned) scale.size() * 64;
+        const size_t pBytes = nb * geom.pstride * 16, tBytes = nb * geom.tstride, sBytes = nb * geom.sstride * 4;
+        HIP_TRY(hipMalloc(&arenaPartials, pBytes));
+        HIP_TRY(hipMalloc(&arenaTips, tBytes));
+        HIP_TRY(hipMalloc(&arenaScale, sBytes));
+        HIP_TRY(hipMemsetAsync(arenaPartials, 0, pBytes, stream));
+        HIP_TRY(hipMemsetAsync(arenaTips, 0, tBytes, stream));
+        HIP_TRY(hipMemsetAsync(arenaScale, 0, sBytes, stream));
+        for (int i = 0; i < nBuffers; ++i) partials[i] = arenaPartials + (size_t) i * K * 64 * 4;
+        for (size_t i = 0; i < scale.size(); ++i) scale[i] = arenaScale + i * 64;
+    }
 
     HIP_TRY(hipMalloc(&matrices, std::max<size_t>(1, (size_t) nMatrices * matrixFloats) * sizeof(float)));
     HIP_TRY(hipMemsetAsync(matrices, 0, std::max<size_t>(1, (size_t) nMatrices * matrixFloats) * sizeof(float), stream));
@@ -215,16 +303,17 @@ int Instance::create(int tipCount_, int partialsBufferCount, int compactBufferCo
     HIP_TRY(hipMalloc(&d_rates, (size_t) K * sizeof(double)));
     HIP_TRY(hipMalloc(&d_pweights, (size_t) Ppad * sizeof(double)));
     HIP_TRY(hipMalloc(&d_site, (size_t) Ppad * sizeof(double)));
-    HIP_TRY(hipMalloc(&d_wsite, (size_t) Ppad * sizeof(double)));
-    nchunks = (P + chunk - 1) / chunk;
-    HIP_TRY(hipMalloc(&d_sums, (size_t) nchunks * sizeof(double)));
-    HIP_TRY(hipHostMalloc(&h_sums, (size_t) nchunks * sizeof(double), hipHostMallocDefault));
+    nblocks = Ppad / 64;
+    HIP_TRY(hipHostMalloc(&h_sums, (size_t) nblocks * sizeof(double), hipHostMallocDefault));
+    HIP_TRY(hipHostGetDevicePointer((void**) &h_sums_dev, h_sums, 0));
     stageCap = (size_t) 8 << 20;
     HIP_TRY(hipHostMalloc(&stage, stageCap, hipHostMallocDefault));
+    HIP_TRY(hipHostGetDevicePointer((void**) &stage_dev, stage, 0));
 
     // defaults: unit rates, uniform category weights, unit pattern weights (BEAGLE clients normally set them)
     std::vector<double> ones(std::max(Ppad, K), 1.0);
     HIP_TRY(hipMemcpy(d_rates, ones.data(), (size_t) K * sizeof(double), hipMemcpyHostToDevice));
+    for (int k = 0; k < MBAMD_MAX_RATES; ++k) rates.r[k] = 1.0;
     std::vector<double> pw(Ppad, 0.0);
     std::fill(pw.begin(), pw.begin() + P, 1.0);
     HIP_TRY(hipMemcpy(d_pweights, pw.data(), (size_t) Ppad * sizeof(double), hipMemcpyHostToDevice));
@@ -238,10 +327,17 @@ void Instance::destroy()
 {
     (void) hipSetDevice(device);
     (void) hipStreamSynchronize(stream);
-    for (float* p : partials) if (p) (void) hipFree(p);
-    for (uint8_t* p : tipStates) if (p) (void) hipFree(p);
-    for (int32_t* p : scale) if (p) (void) hipFree(p);
-    void* bufs[] = {matrices, d_eigen, d_freqs, d_weights, d_rates, d_pweights, d_site, d_wsite, d_sums,
+    if (s4) {
+        void* arenas[] = {arenaPartials, arenaTips, arenaScale};
+        for (void* a : arenas) if (a) (void) hipFree(a);
+    } else {
+        for (float* p : partials) if (p) (void) hipFree(p);
+        for (uint8_t* p : tipStates) if (p) (void) hipFree(p);
+        for (int32_t* p : scale) if (p) (void) hipFree(p);
+    }
+    for (Plan* pl : plans) { if (pl->d_table) (void) hipFree(pl->d_table); delete pl; }
+    plans.clear();
+    void* bufs[] = {matrices, d_eigen, d_freqs, d_weights, d_rates, d_pweights, d_site,
                     d_ops, d_jobs, d_ev, d_tmp, (void*) d_ptrs};
     for (void* b : bufs) if (b) (void) hipFree(b);
     if (h_sums) (void) hipHostFree(h_sums);
@@ -251,12 +347,70 @@ void Instance::destroy()
 }
 
 // ---------------------------------------------------------------------------------------------
+// Tree-walk geometry: W waves per 64-pattern workgroup and the number of LDS slots (K KiB each) it may
+// use, chosen so that every workgroup of the grid is resident at once when the chip allows it.
+int Instance::configureWalk()
+{
+#if defined(MBAMD_HOST_EMU)
+    walkWaves = 4;
+    walkSlots = std::min(64, (64 * 1024) / (K * 1024));
+    if (const char* e = std::getenv("MBAMD_WALK_WAVES")) {
+        const int w = std::atoi(e);
+        if (w == 1 || w == 2 || w == 4 || w == 8) walkWaves = w;
+    }
+#else
+    int numCU = 256;
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0) numCU = prop.multiProcessorCount;
+    const int wgs = Ppad / 64;
+    const int perCU = (wgs + numCU - 1) / numCU;       // workgroups a CU must host for full residency
+    const int resident = std::max(1, std::min(perCU, 4));
+    walkWaves = perCU >= 8 ? 2 : (perCU >= 4 ? 4 : 8);
+    const int ldsBudget = (160 * 1024) / resident - 512;
+    walkSlots = std::max(2, std::min(64, ldsBudget / (K * 1024)));
+    if (const char* e = std::getenv("MBAMD_WALK_WAVES")) {
+        const int w = std::atoi(e);
+        if (w == 1 || w == 2 || w == 4 || w == 8) walkWaves = w;
+    }
+    hipError_t err = hipSuccess;
+    const int maxLds = 160 * 1024;
+    switch (K) {
+#define MBAMD_WALK_ATTR(KK) \
+    case KK: err = hipFuncSetAttribute((const void*) k_walk_s4<KK>, hipFuncAttributeMaxDynamicSharedMemorySize, maxLds); break;
+        MBAMD_WALK_ATTR(1) MBAMD_WALK_ATTR(2) MBAMD_WALK_ATTR(3) MBAMD_WALK_ATTR(4)
+        MBAMD_WALK_ATTR(5) MBAMD_WALK_ATTR(6) MBAMD_WALK_ATTR(7) MBAMD_WALK_ATTR(8)
+#undef MBAMD_WALK_ATTR
+        default: break;
+    }
+    if (err != hipSuccess) {                          // stay within the default 64 KiB
+        (void) hipGetLastError();
+        walkSlots = std::min(walkSlots, (64 * 1024) / (K * 1024));
+    }
+#endif
+    if (const char* ab = std::getenv("MBAMD_WALK_ABLATE")) walkAblate = std::atoi(ab);
+    if (const char* dbg = std::getenv("MBAMD_MAX_LDS_SLOTS")) walkSlots = std::max(1, std::min(walkSlots, std::atoi(dbg)));
+    return BEAGLE_SUCCESS;
+}
+
 int Instance::setTipStates(int tip, const int* states)
 {
     if (tip < 0 || tip >= nBuffers) return fail(BEAGLE_ERROR_OUT_OF_RANGE, "beagleSetTipStates: tip index");
     std::vector<uint8_t> h(Ppad, (uint8_t) S);
     for (int c = 0; c < P; ++c) h[c] = (uint8_t) ((states[c] < 0 || states[c] >= S) ? S : states[c]);
-    if (!tipStates[tip]) HIP_TRY(hipMalloc(&tipStates[tip], (size_t) Ppad));
+    if (s4) {
+        int rc = grow(&d_tmp, &tmpCap, (size_t) Ppad);
+        if (rc) return rc;
+        rc = upload(d_tmp, h.data(), (size_t) Ppad);
+        if (rc) return rc;
+        if (!tipStates[tip]) layoutEpoch++;
+        tipStates[tip] = arenaTips + (size_t) tip * 64;
+        MBAMD_LAUNCH(k_scatter_bytes, (unsigned) ((Ppad + 255) / 256), 256, 0, stream, (const uint8_t*) d_tmp, Ppad,
+                     geom.tstride, tipStates[tip]);
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipStreamSynchronize(stream));          // d_tmp is reused by the next call
+        return BEAGLE_SUCCESS;
+    }
+    if (!tipStates[tip]) { HIP_TRY(hipMalloc(&tipStates[tip], (size_t) Ppad)); layoutEpoch++; }
     return upload(tipStates[tip], h.data(), (size_t) Ppad);
 }
 
@@ -272,26 +426,28 @@ int Instance::importPartials(int idx, const double* in, bool hasCategories)
     HIP_TRY(hipMemcpy(d_tmp, in, nIn * sizeof(double), hipMemcpyHostToDevice));
     const size_t total = (size_t) K * P * S;
     const unsigned blocks = (unsigned) ((total + 255) / 256);
-    if (s4) MBAMD_LAUNCH(k_import_partials<true>, blocks, 256, 0, stream, (const double*) d_tmp, hasCategories ? 1 : 0, S, K, P, Ppad, partials[idx]);
-    else    MBAMD_LAUNCH(k_import_partials<false>, blocks, 256, 0, stream, (const double*) d_tmp, hasCategories ? 1 : 0, S, K, P, Ppad, partials[idx]);
+    if (s4) MBAMD_LAUNCH(k_import_partials<true>, blocks, 256, 0, stream, (const double*) d_tmp, hasCategories ? 1 : 0, S, K, P, Ppad, (size_t) geom.pstride, partials[idx]);
+    else    MBAMD_LAUNCH(k_import_partials<false>, blocks, 256, 0, stream, (const double*) d_tmp, hasCategories ? 1 : 0, S, K, P, Ppad, (size_t) geom.pstride, partials[idx]);
     HIP_TRY(hipGetLastError());
-    if (idx < tipCount && tipStates[idx]) {      // a tip switches from compact to partials form
+    valid[idx] = 1;
+    if (tipStates[idx]) {                        // a tip switches from compact to partials form
         HIP_TRY(hipStreamSynchronize(stream));
-        (void) hipFree(tipStates[idx]);
+        if (!s4) (void) hipFree(tipStates[idx]);
         tipStates[idx] = nullptr;
+        layoutEpoch++;
     }
     return BEAGLE_SUCCESS;
 }
 
 int Instance::getPartials(int idx, double* out)
 {
-    if (idx < 0 || idx >= nBuffers || !partials[idx]) return fail(BEAGLE_ERROR_OUT_OF_RANGE, "beagleGetPartials: buffer");
+    if (idx < 0 || idx >= nBuffers || !valid[idx]) return fail(BEAGLE_ERROR_OUT_OF_RANGE, "beagleGetPartials: buffer");
     const size_t total = (size_t) K * P * S;
     int rc = grow(&d_tmp, &tmpCap, total * sizeof(double));
     if (rc) return rc;
     const unsigned blocks = (unsigned) ((total + 255) / 256);
-    if (s4) MBAMD_LAUNCH(k_export_partials<true>, blocks, 256, 0, stream, (const float*) partials[idx], S, K, P, Ppad, (double*) d_tmp);
-    else    MBAMD_LAUNCH(k_export_partials<false>, blocks, 256, 0, stream, (const float*) partials[idx], S, K, P, Ppad, (double*) d_tmp);
+    if (s4) MBAMD_LAUNCH(k_export_partials<true>, blocks, 256, 0, stream, (const float*) partials[idx], S, K, P, Ppad, (size_t) geom.pstride, (double*) d_tmp);
+    else    MBAMD_LAUNCH(k_export_partials<false>, blocks, 256, 0, stream, (const float*) partials[idx], S, K, P, Ppad, (size_t) geom.pstride, (double*) d_tmp);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipStreamSynchronize(stream));
     HIP_TRY(hipMemcpy(out, d_tmp, total * sizeof(double), hipMemcpyDeviceToHost));
@@ -318,19 +474,28 @@ int Instance::updateMatrices(int eigenIndex, const int* probIdx, const double* l
         jobs[i].out = matrixPtr(probIdx[i]);
         jobs[i].length = lengths[i];
     }
-    int rc = grow((void**) &d_jobs, &jobsCap, sizeof(MatrixJob) * count);
-    if (rc) return rc;
+    const MatrixJob* djobs = nullptr;
+    int rc;
+    if (K <= MBAMD_MAX_RATES) {
+        rc = stageDirect(jobs.data(), sizeof(MatrixJob) * count, (const void**) &djobs);
+        if (rc) return rc;
+    } else {
+        return fail(BEAGLE_ERROR_NO_IMPLEMENTATION, "more than 16 rate categories");
+    }
+    const double* eig = d_eigen + (size_t) eigenIndex * eigenDoubles;
+    if (s4) {
+        const int total = count * K;
+        MBAMD_LAUNCH(k_transition_matrices_s4, (unsigned) ((total + 255) / 256), 256, 0, stream, djobs, eig, rates, K, total);
+        HIP_TRY(hipGetLastError());
+        return BEAGLE_SUCCESS;
+    }
     const size_t nev = (size_t) count * K * S;
     rc = grow((void**) &d_ev, &evCap, nev * sizeof(double));
     if (rc) return rc;
-    rc = upload(d_jobs, jobs.data(), sizeof(MatrixJob) * count);
-    if (rc) return rc;
-    const double* eig = d_eigen + (size_t) eigenIndex * eigenDoubles;
-    MBAMD_LAUNCH(k_eigen_exponentials, (unsigned) ((nev + 255) / 256), 256, 0, stream, (const MatrixJob*) d_jobs, eig,
-                 (const double*) d_rates, S, K, (int) nev, d_ev);
+    MBAMD_LAUNCH(k_eigen_exponentials, (unsigned) ((nev + 255) / 256), 256, 0, stream, djobs, eig, rates, S, K, (int) nev, d_ev);
     const int threads = std::min(256, round_up(S * S, 64));
-    MBAMD_LAUNCH(k_transition_matrices_ev, (unsigned) (count * K), threads, 0, stream, (const MatrixJob*) d_jobs, eig,
-                 (const double*) d_ev, S, SP, K, s4 ? 0 : 1);
+    MBAMD_LAUNCH(k_transition_matrices_ev, (unsigned) (count * K), threads, 0, stream, djobs, eig,
+                 (const double*) d_ev, S, SP, K, 1, mfma ? T : 0);
     HIP_TRY(hipGetLastError());
     return BEAGLE_SUCCESS;
 }
@@ -343,8 +508,9 @@ int Instance::setMatrix(int idx, const double* in)
         for (int i = 0; i < S; ++i)
             for (int j = 0; j < S; ++j) {
                 const float v = (float) in[((size_t) k * S + i) * S + j];
-                if (s4) h[(size_t) k * 16 + i * 4 + j] = v;
-                else    h[(size_t) k * SP * SP + (size_t) j * SP + i] = v;
+                h[(size_t) k * SP * SP + (size_t) j * SP + i] = v;
+                if (mfma)
+                    h[(size_t) K * SP * SP + ((size_t) (k * NT + i / 32) * T + j / 2) * 64 + (i % 32) + 32 * (j % 2)] = v;
             }
     return upload(matrixPtr(idx), h.data(), matrixFloats * sizeof(float));
 }
@@ -358,8 +524,7 @@ int Instance::getMatrix(int idx, double* out)
     for (int k = 0; k < K; ++k)
         for (int i = 0; i < S; ++i)
             for (int j = 0; j < S; ++j)
-                out[((size_t) k * S + i) * S + j] =
-                    s4 ? h[(size_t) k * 16 + i * 4 + j] : h[(size_t) k * SP * SP + (size_t) j * SP + i];
+                out[((size_t) k * S + i) * S + j] = h[(size_t) k * SP * SP + (size_t) j * SP + i];
     return BEAGLE_SUCCESS;
 }
 
@@ -372,6 +537,27 @@ int Instance::updatePartials(const BeagleOperation* ops, int n, int cumIdx)
     if (n <= 0) return BEAGLE_SUCCESS;
     if (cumIdx != BEAGLE_OP_NONE && (cumIdx < 0 || cumIdx >= nScale))
         return fail(BEAGLE_ERROR_OUT_OF_RANGE, "beagleUpdatePartials: cumulative scale index");
+    int32_t* cumPtr = nullptr;
+    if (cumIdx != BEAGLE_OP_NONE) {
+        int rc = ensureScale(cumIdx);
+        if (rc) return rc;
+        cumPtr = scale[cumIdx];
+    }
+    // ---- plan cache ------------------------------------------------------------------------
+    static_assert(sizeof(BeagleOperation) == 7 * sizeof(int), "BeagleOperation is 7 ints");
+    const int* raw = reinterpret_cast<const int*>(ops);
+    const size_t nints = (size_t) n * 7;
+    uint64_t h = 1469598103934665603ull;
+    for (size_t i = 0; i < nints; ++i) h = (h ^ (uint64_t) (uint32_t) raw[i]) * 1099511628211ull;
+    h = (h ^ (uint64_t) (uint32_t) layoutEpoch) * 1099511628211ull;
+    for (Plan* pl : plans)
+        if (pl->hash == h && pl->key.size() == nints + 1 && pl->key[nints] == layoutEpoch &&
+            std::memcmp(pl->key.data(), raw, nints * sizeof(int)) == 0) {
+            pl->lastUse = ++planClock;
+            planHits++;
+            return timedRun(*pl, cumPtr);
+        }
+    planMisses++;
     std::vector<PartialsOp> dev(n);
     std::vector<int> dstIdx(n), c1Idx(n), c2Idx(n);
     std::vector<char> written(nBuffers, 0);
@@ -396,7 +582,7 @@ int Instance::updatePartials(const BeagleOperation* ops, int n, int cumIdx)
                 cp[s] = tipStates[ci[s]];
                 ck[s] = CHILD_STATES;
             } else {
-                if (!partials[ci[s]]) return fail(BEAGLE_ERROR_OUT_OF_RANGE, "beagleUpdatePartials: child buffer was never written");
+                if (!valid[ci[s]] && !written[ci[s]]) return fail(BEAGLE_ERROR_OUT_OF_RANGE, "beagleUpdatePartials: child buffer was never written");
                 cp[s] = partials[ci[s]];
                 ck[s] = CHILD_PARTIALS;
             }
@@ -427,21 +613,52 @@ int Instance::updatePartials(const BeagleOperation* ops, int n, int cumIdx)
         c2Idx[o] = b.child2Partials;
         written[b.destinationPartials] = 1;
     }
-    int32_t* cum = nullptr;
-    if (cumIdx != BEAGLE_OP_NONE) {
-        int rc = ensureScale(cumIdx);
-        if (rc) return rc;
-        cum = scale[cumIdx];
+    for (int o = 0; o < n; ++o) valid[dstIdx[o]] = 1;
+    // ---- compile the list into a plan (evicting the least recently used one) ----------------------
+    Plan* plan;
+    const size_t maxPlans = 24;
+    if (plans.size() < maxPlans) {
+        plan = new Plan();
+        plans.push_back(plan);
+    } else {
+        plan = plans[0];
+        for (Plan* pl : plans) if (pl->lastUse < plan->lastUse) plan = pl;
     }
+    plan->key.assign(raw, raw + nints);
+    plan->key.push_back(layoutEpoch);
+    plan->hash = h;
+    plan->lastUse = ++planClock;
+    int rc = s4 ? buildWalk(*plan, dev, dstIdx, c1Idx, c2Idx) : buildGeneric(*plan, dev, dstIdx, c1Idx, c2Idx);
+    if (rc) { plan->hash = 0; plan->key.clear(); return rc; }
+    return timedRun(*plan, cumPtr);
+}
+
+// upload a freshly built table into the plan's own device buffer
+int Instance::planTable(Plan& plan, const std::vector<PartialsOp>& table)
+{
+    const size_t bytes = table.size() * sizeof(PartialsOp);
+    if (bytes > plan.cap) {
+        HIP_TRY(hipStreamSynchronize(stream));       // the old table may still be read by a running kernel
+        if (plan.d_table) HIP_TRY(hipFree(plan.d_table));
+        plan.d_table = nullptr;
+        plan.cap = 0;
+        HIP_TRY(hipMalloc(&plan.d_table, bytes + bytes / 2));
+        plan.cap = bytes + bytes / 2;
+    } else {
+        HIP_TRY(hipStreamSynchronize(stream));
+    }
+    return upload(plan.d_table, table.data(), bytes);
+}
+
+int Instance::timedRun(const Plan& plan, int32_t* cum)
+{
     hipEvent_t ev0{}, ev1{};
     if (timing) {
         HIP_TRY(hipEventCreate(&ev0));
         HIP_TRY(hipEventCreate(&ev1));
         HIP_TRY(hipEventRecord(ev0, stream));
     }
-    int rc;
-    if (s4) rc = launchWalk(dev, dstIdx, c1Idx, c2Idx, cum);
-    else                            rc = launchGeneric(dev, dstIdx, c1Idx, c2Idx, cum);
+    const int rc = s4 ? runWalk(plan, cum) : runGeneric(plan, cum);
     if (timing) {
         HIP_TRY(hipEventRecord(ev1, stream));
         events.emplace_back(ev0, ev1);
@@ -449,92 +666,208 @@ int Instance::updatePartials(const BeagleOperation* ops, int n, int cumIdx)
     return rc;
 }
 
-// Tree-walk path: give every freshly produced partial that is consumed later in the same list an LDS
-// stack slot (Belady eviction when the stack is full), so the kernel re-reads children from LDS.
-int Instance::launchWalk(std::vector<PartialsOp>& dev, const std::vector<int>& dstIdx, const std::vector<int>& c1Idx,
-                         const std::vector<int>& c2Idx, int32_t* cum)
+// Tree-walk path.  The operation list becomes a schedule of steps of up to W mutually independent
+// operations (one per wave of the workgroup that owns a 64-pattern block); every freshly produced
+// partial that is consumed later in the list gets an LDS slot (Belady eviction when the slots run
+// out), so the kernel re-reads children from LDS, never from HBM.
+int Instance::buildWalk(Plan& plan, std::vector<PartialsOp>& dev, const std::vector<int>& dstIdx,
+                        const std::vector<int>& c1Idx, const std::vector<int>& c2Idx)
 {
     const int n = (int) dev.size();
-    int maxSlots = std::min(64, (64 * 1024) / (K * 1024));
-    if (const char* dbg = std::getenv("MBAMD_MAX_LDS_SLOTS")) maxSlots = std::max(1, std::min(maxSlots, std::atoi(dbg)));
-    // next reader of each op's output (before the buffer is overwritten again)
-    std::vector<int> nextUse(n, -1);
+    int W = walkWaves;
+    const int maxSlots = walkSlots;
+
+    // ---- dependencies ------------------------------------------------------------------------
+    // producer[o][s]: index of the operation of this list that produces child s of op o (or -1);
+    // a list with write-after-read / write-after-write hazards on buffer indices (never produced
+    // by MrBayes) is executed strictly in list order by a single wave.
+    std::vector<int> prod1(n, -1), prod2(n, -1);
     {
-        std::vector<int> lastReader(nBuffers, -1);
-        for (int o = n - 1; o >= 0; --o) {
-            // the output of op o is read by the nearest later reader of dstIdx[o] that comes before
-            // the next writer of that buffer; scanning backwards, lastReader holds exactly that.
-            nextUse[o] = lastReader[dstIdx[o]];
-            lastReader[dstIdx[o]] = -1;             // older readers see older contents
-            lastReader[c1Idx[o]] = o;
-            lastReader[c2Idx[o]] = o;
+        std::vector<int> lastWriter(nBuffers, -1);
+        std::vector<char> readOld(nBuffers, 0);
+        bool hazard = false;
+        for (int o = 0; o < n; ++o) {
+            prod1[o] = lastWriter[c1Idx[o]];
+            prod2[o] = lastWriter[c2Idx[o]];
+            readOld[c1Idx[o]] = 1;
+            readOld[c2Idx[o]] = 1;
+            if (readOld[dstIdx[o]] || lastWriter[dstIdx[o]] >= 0) hazard = true;
+            lastWriter[dstIdx[o]] = o;
+        }
+        if (hazard) W = 1;
+    }
+    std::vector<std::vector<int>> consumers(n);
+    std::vector<int> indeg(n, 0);
+    for (int o = 0; o < n; ++o) {
+        if (prod1[o] >= 0) { consumers[prod1[o]].push_back(o); indeg[o]++; }
+        if (prod2[o] >= 0 && prod2[o] != prod1[o]) { consumers[prod2[o]].push_back(o); indeg[o]++; }
+    }
+
+    // ---- list scheduling: lowest list position first (keeps the walk depth-first, hence few live values)
+    std::vector<int> stepOf(n, -1);
+    std::vector<std::vector<int>> steps;
+    if (W == 1) {
+        steps.resize(n);
+        for (int o = 0; o < n; ++o) { steps[o].push_back(o); stepOf[o] = o; }
+    } else {
+        std::vector<int> ready, next;
+        for (int o = 0; o < n; ++o) if (indeg[o] == 0) ready.push_back(o);
+        int live = 0;                                   // produced values still waiting for a consumer
+        int done = 0;
+        while (done < n) {
+            std::sort(ready.begin(), ready.end());
+            // under LDS pressure prefer operations that retire live values (children produced in this list)
+            if (live + W > maxSlots)
+                std::stable_sort(ready.begin(), ready.end(), [&](int a, int b) {
+                    const int ra = (prod1[a] >= 0) + (prod2[a] >= 0), rb = (prod1[b] >= 0) + (prod2[b] >= 0);
+                    return ra > rb;
+                });
+            const int take = std::min<int>(W, (int) ready.size());
+            std::vector<int> cur(ready.begin(), ready.begin() + take);
+            ready.erase(ready.begin(), ready.begin() + take);
+            const int sidx = (int) steps.size();
+            for (int o : cur) {
+                stepOf[o] = sidx;
+                live -= (prod1[o] >= 0) + (prod2[o] >= 0 && prod2[o] != prod1[o]);
+                if (!consumers[o].empty()) live += 1;
+            }
+            for (int o : cur)
+                for (int q : consumers[o])
+                    if (--indeg[q] == 0) ready.push_back(q);
+            done += take;
+            steps.push_back(std::move(cur));
         }
     }
-    std::vector<int> slotOfBuffer(nBuffers, -1);     // buffer -> LDS slot while resident
-    std::vector<char> producedHere(nBuffers, 0);
-    std::vector<int> slotBuffer(maxSlots, -1), slotNext(maxSlots, -1);
+    const int nsteps = (int) steps.size();
+
+    // ---- LDS slots --------------------------------------------------------------------------------
+    // value of op o lives from stepOf[o] to its last consumer's step; slots freed in step s are
+    // reusable from step s+1 (or, within step s, by the very operation that consumed them).
+    std::vector<int> slotOfOp(n, -1), lastUse(n, -1);
+    for (int o = 0; o < n; ++o)
+        for (int q : consumers[o]) lastUse[o] = std::max(lastUse[o], stepOf[q]);
+    auto nextUseAfter = [&](int o, int s) {             // earliest consumer step > s
+        int best = 1 << 30;
+        for (int q : consumers[o]) if (stepOf[q] > s) best = std::min(best, stepOf[q]);
+        return best;
+    };
+    std::vector<int> slotHolder(maxSlots, -1);            // op whose value occupies the slot
+    std::vector<int> slotFreeFrom(maxSlots, 0);           // first step in which the slot may be overwritten
+    std::vector<char> drainBefore(nsteps + 1, 0);         // step s must start with every wave's stores drained
     int slotsUsed = 0;
-    for (int o = 0; o < n; ++o) {
-        PartialsOp& d = dev[o];
-        const int ci[2] = {c1Idx[o], c2Idx[o]};
-        uint8_t* kind[2] = {&d.c1_kind, &d.c2_kind};
-        uint8_t* slot[2] = {&d.c1_slot, &d.c2_slot};
-        for (int s = 0; s < 2; ++s) {
-            if (*kind[s] == CHILD_STATES) continue;
-            const int b = ci[s];
-            if (slotOfBuffer[b] >= 0) {
-                *kind[s] = CHILD_LDS;
-                *slot[s] = (uint8_t) slotOfBuffer[b];
-            } else if (producedHere[b]) {
-                *kind[s] = CHILD_RELOAD;
+    for (int s = 0; s < nsteps; ++s) {
+        // reads
+        for (int o : steps[s]) {
+            PartialsOp& d = dev[o];
+            const int pr[2] = {prod1[o], prod2[o]};
+            uint8_t* kind[2] = {&d.c1_kind, &d.c2_kind};
+            uint8_t* slot[2] = {&d.c1_slot, &d.c2_slot};
+            for (int t = 0; t < 2; ++t) {
+                if (*kind[t] == CHILD_STATES || pr[t] < 0) continue;
+                const int sl = slotOfOp[pr[t]];
+                if (sl >= 0) { *kind[t] = CHILD_LDS; *slot[t] = (uint8_t) sl; }
+                else         { *kind[t] = CHILD_RELOAD; drainBefore[s] = 1; }
             }
         }
-        // release slots whose content was consumed for the last time by this op
-        for (int s = 0; s < 2; ++s) {
-            const int b = ci[s];
-            const int sl = slotOfBuffer[b];
-            if (sl >= 0 && slotNext[sl] <= o) {
-                slotOfBuffer[b] = -1;
-                slotBuffer[sl] = -1;
+        // release the slots of values consumed for the last time in this step
+        for (int o : steps[s]) {
+            const int pr[2] = {prod1[o], prod2[o]};
+            for (int t = 0; t < 2; ++t) {
+                if (pr[t] < 0) continue;
+                const int sl = slotOfOp[pr[t]];
+                if (sl >= 0 && lastUse[pr[t]] <= s && slotHolder[sl] == pr[t]) {
+                    slotHolder[sl] = -1;
+                    slotFreeFrom[sl] = s + 1;
+                    slotOfOp[pr[t]] = -1;
+                }
             }
         }
-        // the destination buffer's previous content (if resident) is dead now
-        if (slotOfBuffer[dstIdx[o]] >= 0) {
-            slotBuffer[slotOfBuffer[dstIdx[o]]] = -1;
-            slotOfBuffer[dstIdx[o]] = -1;
-        }
-        producedHere[dstIdx[o]] = 1;
-        if (nextUse[o] >= 0) {
+        // writes
+        for (int o : steps[s]) {
+            if (consumers[o].empty()) continue;
+            PartialsOp& d = dev[o];
             int sl = -1;
-            for (int t = 0; t < maxSlots; ++t)
-                if (slotBuffer[t] < 0) { sl = t; break; }
-            if (sl < 0) {                             // evict the resident value needed farthest in the future
-                int far = -1;
+            // a slot this very operation just released may be reused at once (same lanes read, then write)
+            // -- provided no other operation of this step reads that value too
+            auto soleReader = [&](int producer) {
+                int cnt = 0;
+                for (int q : consumers[producer]) cnt += stepOf[q] == s;
+                return cnt == 1;
+            };
+            if (d.c1_kind == CHILD_LDS && slotHolder[d.c1_slot] < 0 && slotFreeFrom[d.c1_slot] == s + 1 &&
+                soleReader(prod1[o])) sl = d.c1_slot;
+            else if (d.c2_kind == CHILD_LDS && slotHolder[d.c2_slot] < 0 && slotFreeFrom[d.c2_slot] == s + 1 &&
+                     soleReader(prod2[o])) sl = d.c2_slot;
+            if (sl < 0)
                 for (int t = 0; t < maxSlots; ++t)
-                    if (far < 0 || slotNext[t] > slotNext[far]) far = t;
-                if (slotNext[far] > nextUse[o]) {
-                    slotOfBuffer[slotBuffer[far]] = -1;
+                    if (slotHolder[t] < 0 && slotFreeFrom[t] <= s) { sl = t; break; }
+            if (sl < 0) {                                 // evict the resident value needed farthest in the future
+                int far = -1, farUse = -1;
+                for (int t = 0; t < maxSlots; ++t) {
+                    const int h = slotHolder[t];
+                    if (h < 0 || stepOf[h] >= s) continue;               // free-later slot / written in this step
+                    bool readNow = false;                                   // still read by an op of this step?
+                    for (int q : consumers[h]) readNow |= stepOf[q] == s;
+                    if (readNow) continue;
+                    const int u = nextUseAfter(h, s);
+                    if (u > farUse) { farUse = u; far = t; }
+                }
+                if (far >= 0 && farUse > nextUseAfter(o, s)) {
+                    slotOfOp[slotHolder[far]] = -1;
+                    slotHolder[far] = -1;
                     sl = far;
                 }
             }
             if (sl >= 0) {
-                slotBuffer[sl] = dstIdx[o];
-                slotNext[sl] = nextUse[o];
-                slotOfBuffer[dstIdx[o]] = sl;
+                slotHolder[sl] = o;
+                slotOfOp[o] = sl;
                 d.dst_slot = (uint8_t) sl;
                 slotsUsed = std::max(slotsUsed, sl + 1);
             }
         }
     }
-    int rc = grow((void**) &d_ops, &opsCap, sizeof(PartialsOp) * n);
-    if (rc) return rc;
-    rc = upload(d_ops, dev.data(), sizeof(PartialsOp) * n);
-    if (rc) return rc;
-    const size_t lds = (size_t) std::max(1, slotsUsed) * K * 1024;
+
+    // ---- device table [nsteps][W] ----------------------------------------------------------------------
+    // (+4 empty rows: the kernel's prefetch pipeline reads that far ahead; empty entries carry valid
+    //  dummy pointers because their matrix rows / tip bytes are requested before `dst` is looked at)
+    std::vector<PartialsOp> table((size_t) (nsteps + 4) * W);
+    std::memset(table.data(), 0, table.size() * sizeof(PartialsOp));
+    for (int s = 0; s < nsteps + 4; ++s) {
+        const uint8_t fl = (s + 1 < nsteps && drainBefore[s + 1]) ? MBAMD_OP_DRAIN : 0;
+        for (int w = 0; w < W; ++w) {
+            PartialsOp& e = table[(size_t) s * W + w];
+            if (s < nsteps && w < (int) steps[s].size()) e = dev[steps[s][w]];
+            else {
+                e.c1_slot = e.c2_slot = e.dst_slot = MBAMD_NO_SLOT;
+                e.c1_kind = e.c2_kind = CHILD_PARTIALS;
+                e.m1 = e.m2 = matrices;
+            }
+            e.flags = fl;
+        }
+    }
+    lastWalkSteps = nsteps;
+    lastWalkSlots = slotsUsed;
+    plan.nsteps = nsteps;
+    plan.W = W;
+    plan.slotsUsed = slotsUsed;
+    return planTable(plan, table);
+}
+
+int Instance::runWalk(const Plan& plan, int32_t* cum)
+{
+    const int W = plan.W, nsteps = plan.nsteps;
+    // value slots (K KiB each) + per-wave matrix staging (8K rows of 16 bytes)
+    const size_t lds = (size_t) std::max(1, plan.slotsUsed) * K * 1024 + (size_t) W * K * 128;
     const unsigned grid = (unsigned) (Ppad / 64);
+#if defined(MBAMD_HOST_EMU)
+    const int walkThreads = 64;
+    const int walkArgW = std::getenv("MBAMD_EMU_REVERSE_STEP") ? -W : W;
+#else
+    const int walkThreads = W * 64, walkArgW = W;
+#endif
     switch (K) {
 #define MBAMD_WALK_CASE(KK) \
-    case KK: MBAMD_LAUNCH(k_walk_s4<KK>, grid, 64, lds, stream, (const PartialsOp*) d_ops, n, Ppad, cum); break;
+    case KK: MBAMD_LAUNCH(k_walk_s4<KK>, grid, walkThreads, lds, stream, (const PartialsOp*) plan.d_table, nsteps, walkArgW, geom, cum, walkAblate); break;
         MBAMD_WALK_CASE(1) MBAMD_WALK_CASE(2) MBAMD_WALK_CASE(3) MBAMD_WALK_CASE(4)
         MBAMD_WALK_CASE(5) MBAMD_WALK_CASE(6) MBAMD_WALK_CASE(7) MBAMD_WALK_CASE(8)
 #undef MBAMD_WALK_CASE
@@ -545,6 +878,36 @@ int Instance::launchWalk(std::vector<PartialsOp>& dev, const std::vector<int>& d
     return BEAGLE_SUCCESS;
 }
 
+#if !defined(MBAMD_HOST_EMU)
+template <int NT_, int SC_, int KC_>
+static void launch_mfma_t(Instance& in, const PartialsOp* ops, int count, int32_t* cum)
+{
+    const int gx = (in.Ppad + 127) / 128;
+    const unsigned grid = (unsigned) (8 * ((gx + 7) / 8) * count);
+    auto kern = k_partials_mfma<NT_, SC_, KC_>;
+    MBAMD_LAUNCH(kern, grid, 256, 0, in.stream, ops, in.S, in.SP, in.Ppad, gx, cum);
+}
+static bool launch_mfma(Instance& in, const PartialsOp* ops, int count, int32_t* cum)
+{
+    const int S = in.S, K = in.K;
+    if (in.NT == 1) {
+        if (S == 20 && K == 4) launch_mfma_t<1, 20, 4>(in, ops, count, cum);
+        else if (S == 20 && K == 1) launch_mfma_t<1, 20, 1>(in, ops, count, cum);
+        else if (K == 1) launch_mfma_t<1, 0, 1>(in, ops, count, cum);
+        else if (K == 2) launch_mfma_t<1, 0, 2>(in, ops, count, cum);
+        else if (K == 3) launch_mfma_t<1, 0, 3>(in, ops, count, cum);
+        else if (K == 4) launch_mfma_t<1, 0, 4>(in, ops, count, cum);
+        else return false;
+    } else {
+        if (S == 61 && K == 1) launch_mfma_t<2, 61, 1>(in, ops, count, cum);
+        else if (K == 1) launch_mfma_t<2, 0, 1>(in, ops, count, cum);
+        else if (K == 2) launch_mfma_t<2, 0, 2>(in, ops, count, cum);
+        else return false;
+    }
+    return true;
+}
+#endif
+
 template <int SP_, int FK_>
 static void launch_gen(Instance& in, const PartialsOp* ops, int count, int32_t* cum)
 {
@@ -554,8 +917,8 @@ static void launch_gen(Instance& in, const PartialsOp* ops, int count, int32_t* 
 
 // General path: order the operations by dependency level (RAW, WAR and WAW on buffer indices) and
 // launch one grid per level.
-int Instance::launchGeneric(std::vector<PartialsOp>& dev, const std::vector<int>& dstIdx, const std::vector<int>& c1Idx,
-                            const std::vector<int>& c2Idx, int32_t* cum)
+int Instance::buildGeneric(Plan& plan, std::vector<PartialsOp>& dev, const std::vector<int>& dstIdx,
+                           const std::vector<int>& c1Idx, const std::vector<int>& c2Idx)
 {
     const int n = (int) dev.size();
     std::vector<int> lastWrite(nBuffers, -1), lastRead(nBuffers, -1), level(n, 0);
@@ -580,19 +943,33 @@ int Instance::launchGeneric(std::vector<PartialsOp>& dev, const std::vector<int>
         std::vector<int> fill(start.begin(), start.end() - 1);
         for (int o = 0; o < n; ++o) sorted[fill[level[o]]++] = dev[o];
     }
-    int rc = grow((void**) &d_ops, &opsCap, sizeof(PartialsOp) * n);
-    if (rc) return rc;
-    rc = upload(d_ops, sorted.data(), sizeof(PartialsOp) * n);
-    if (rc) return rc;
-    bool anyScale = false;
-    for (const PartialsOp& d : sorted) anyScale |= d.scale_mode != SCALE_NONE;
+    plan.anyScale = false;
+    for (const PartialsOp& d : sorted) plan.anyScale |= d.scale_mode != SCALE_NONE;
+    plan.start = start;
+    return planTable(plan, sorted);
+}
+
+int Instance::runGeneric(const Plan& plan, int32_t* cum)
+{
+    const std::vector<int>& start = plan.start;
+    const int nLevels = (int) start.size() - 1;
+    const bool anyScale = plan.anyScale;
     for (int l = 0; l < nLevels; ++l) {
         int off = start[l];
         int remaining = start[l + 1] - start[l];
         while (remaining > 0) {
             const int count = std::min(remaining, 32768);
-            const PartialsOp* ops = d_ops + off;
+            const PartialsOp* ops = plan.d_table + off;
             bool fused = true;
+#if !defined(MBAMD_HOST_EMU)
+            if (mfma && launch_mfma(*this, ops, std::min(count, 8192), cum)) {
+                const int done = std::min(count, 8192);
+                pendingLaunches += 1;
+                off += done;
+                remaining -= done;
+                continue;
+            }
+#endif
             if (SP == 20 && K == 4) launch_gen<20, 4>(*this, ops, count, cum);
             else if (SP == 20 && K == 1) launch_gen<20, 1>(*this, ops, count, cum);
             else if (SP == 64 && K == 1) launch_gen<64, 1>(*this, ops, count, cum);
@@ -635,12 +1012,11 @@ int Instance::accumulate(const int* idx, int n, int cumIdx, int sign)
         if (rc) return rc;
         ptrs[i] = scale[idx[i]];
     }
-    rc = grow((void**) &d_ptrs, &ptrsCap, sizeof(void*) * n);
+    const int32_t* const* dptrs = nullptr;
+    rc = stageDirect(ptrs.data(), sizeof(void*) * n, (const void**) &dptrs);
     if (rc) return rc;
-    rc = upload((void*) d_ptrs, ptrs.data(), sizeof(void*) * n);
-    if (rc) return rc;
-    MBAMD_LAUNCH(k_scale_accumulate, (unsigned) ((Ppad + 255) / 256), 256, 0, stream, (const int32_t* const*) d_ptrs, n, sign,
-                 Ppad, scale[cumIdx]);
+    MBAMD_LAUNCH(k_scale_accumulate, (unsigned) ((Ppad + 255) / 256), 256, 0, stream, dptrs, n, sign,
+                 Ppad, geom.sstride, scale[cumIdx]);
     HIP_TRY(hipGetLastError());
     return BEAGLE_SUCCESS;
 }
@@ -653,7 +1029,7 @@ int Instance::integrate(const int* parent, const int* child, const int* prob, co
     std::memset(&a, 0, sizeof a);
     a.count = count;
     for (int n = 0; n < count; ++n) {
-        if (parent[n] < 0 || parent[n] >= nBuffers || !partials[parent[n]])
+        if (parent[n] < 0 || parent[n] >= nBuffers || !valid[parent[n]])
             return fail(BEAGLE_ERROR_OUT_OF_RANGE, "log-likelihood: parent buffer");
         a.parent[n] = partials[parent[n]];
         if (child) {
@@ -661,7 +1037,7 @@ int Instance::integrate(const int* parent, const int* child, const int* prob, co
             if (ci < 0 || ci >= nBuffers || prob[n] < 0 || prob[n] >= nMatrices)
                 return fail(BEAGLE_ERROR_OUT_OF_RANGE, "edge log-likelihood: child buffer / matrix");
             if (tipStates[ci]) { a.child[n] = tipStates[ci]; a.child_kind[n] = CHILD_STATES; }
-            else if (partials[ci]) { a.child[n] = partials[ci]; a.child_kind[n] = CHILD_PARTIALS; }
+            else if (valid[ci]) { a.child[n] = partials[ci]; a.child_kind[n] = CHILD_PARTIALS; }
             else return fail(BEAGLE_ERROR_OUT_OF_RANGE, "edge log-likelihood: child buffer was never written");
             a.matrix[n] = matrixPtr(prob[n]);
         }
@@ -676,11 +1052,9 @@ int Instance::integrate(const int* parent, const int* child, const int* prob, co
             a.cum[n] = scale[cumIdx[n]];
         }
     }
-    if (s4) MBAMD_LAUNCH(k_integrate_lnl<true>, (unsigned) (Ppad / 64), 64, 0, stream, a, S, SP, K, P, Ppad, (const double*) d_pweights, d_site, d_wsite);
-    else    MBAMD_LAUNCH(k_integrate_lnl<false>, (unsigned) (Ppad / 64), 64, 0, stream, a, S, SP, K, P, Ppad, (const double*) d_pweights, d_site, d_wsite);
-    MBAMD_LAUNCH(k_chunk_sums, (unsigned) ((nchunks + 63) / 64), 64, 0, stream, (const double*) d_wsite, P, chunk, nchunks, d_sums);
+    if (s4) MBAMD_LAUNCH(k_integrate_lnl<true>, (unsigned) nblocks, 64, 0, stream, a, S, SP, K, P, Ppad, geom, (const double*) d_pweights, d_site, h_sums_dev);
+    else    MBAMD_LAUNCH(k_integrate_lnl<false>, (unsigned) nblocks, 64, 0, stream, a, S, SP, K, P, Ppad, geom, (const double*) d_pweights, d_site, h_sums_dev);
     HIP_TRY(hipGetLastError());
-    HIP_TRY(hipMemcpyAsync(h_sums, d_sums, (size_t) nchunks * sizeof(double), hipMemcpyDeviceToHost, stream));
     haveSite = true;
     pendingResult = true;
     if (deferred) {
@@ -696,7 +1070,7 @@ int Instance::fetchResult(double* out)
     HIP_TRY(hipStreamSynchronize(stream));
     pendingResult = false;
     double s = 0.0;
-    for (int i = 0; i < nchunks; ++i) s += h_sums[i];
+    for (int i = 0; i < nblocks; ++i) s += h_sums[i];
     if (out) *out = s;
     if (!(s == s) || s > 1.79e308 || s < -1.79e308) return BEAGLE_ERROR_FLOATING_POINT;
     return BEAGLE_SUCCESS;
@@ -813,7 +1187,8 @@ int beagleCreateInstance(int tipCount, int partialsBufferCount, int compactBuffe
         returnInfo->resourceNumber = dev;
         returnInfo->resourceName = (dev < g_resources.length) ? g_resources.list[dev].name : const_cast<char*>("HIP device");
         returnInfo->implName = const_cast<char*>(in->s4 ? "mbamd HIP gfx950: 4-state tree-walk kernels"
-                                                        : "mbamd HIP gfx950: general-state kernels");
+                                                 : in->mfma ? "mbamd HIP gfx950: general-state MFMA (v_mfma_f32_32x32x2_f32) kernels"
+                                                            : "mbamd HIP gfx950: general-state vector kernels");
         returnInfo->implDescription = const_cast<char*>("hand-written HIP kernels for AMD CDNA4 (MI355X)");
         returnInfo->flags = in->flags;
     }
@@ -889,7 +1264,9 @@ int beagleSetCategoryWeights(int instance, int idx, const double* w)
 int beagleSetCategoryRates(int instance, const double* r)
 {
     GET_INSTANCE(instance);
-    return in->upload(in->d_rates, r, sizeof(double) * in->K);
+    if (in->K > MBAMD_MAX_RATES) return fail(BEAGLE_ERROR_NO_IMPLEMENTATION, "more than 16 rate categories");
+    for (int k = 0; k < in->K; ++k) in->rates.r[k] = r[k];
+    return BEAGLE_SUCCESS;
 }
 int beagleSetPatternWeights(int instance, const double* w)
 {
@@ -944,7 +1321,9 @@ int beagleResetScaleFactors(int instance, int cumulativeScaleIndex)
     if (cumulativeScaleIndex < 0 || cumulativeScaleIndex >= in->nScale)
         return fail(BEAGLE_ERROR_OUT_OF_RANGE, "beagleResetScaleFactors: index");
     if (!in->scale[cumulativeScaleIndex]) return in->ensureScale(cumulativeScaleIndex);   // allocated zeroed
-    HIP_TRY(hipMemsetAsync(in->scale[cumulativeScaleIndex], 0, (size_t) in->Ppad * sizeof(int32_t), in->stream));
+    MBAMD_LAUNCH(k_scale_copy, (unsigned) ((in->Ppad + 255) / 256), 256, 0, in->stream, (const int32_t*) nullptr, in->Ppad,
+                 in->geom.sstride, in->scale[cumulativeScaleIndex]);
+    HIP_TRY(hipGetLastError());
     return BEAGLE_SUCCESS;
 }
 int beagleCopyScaleFactors(int instance, int destScalingIndex, int srcScalingIndex)
@@ -956,8 +1335,9 @@ int beagleCopyScaleFactors(int instance, int destScalingIndex, int srcScalingInd
     if (rc) return rc;
     rc = in->ensureScale(srcScalingIndex);
     if (rc) return rc;
-    HIP_TRY(hipMemcpyAsync(in->scale[destScalingIndex], in->scale[srcScalingIndex], (size_t) in->Ppad * sizeof(int32_t),
-                           hipMemcpyDeviceToDevice, in->stream));
+    MBAMD_LAUNCH(k_scale_copy, (unsigned) ((in->Ppad + 255) / 256), 256, 0, in->stream,
+                 (const int32_t*) in->scale[srcScalingIndex], in->Ppad, in->geom.sstride, in->scale[destScalingIndex]);
+    HIP_TRY(hipGetLastError());
     return BEAGLE_SUCCESS;
 }
 int beagleGetScaleFactors(int instance, int srcScalingIndex, double* outScaleFactors)
@@ -967,8 +1347,13 @@ int beagleGetScaleFactors(int instance, int srcScalingIndex, double* outScaleFac
     int rc = in->ensureScale(srcScalingIndex);
     if (rc) return rc;
     std::vector<int32_t> h(in->Ppad);
+    rc = in->grow(&in->d_tmp, &in->tmpCap, (size_t) in->Ppad * sizeof(int32_t));
+    if (rc) return rc;
+    MBAMD_LAUNCH(k_gather_ints, (unsigned) ((in->Ppad + 255) / 256), 256, 0, in->stream,
+                 (const int32_t*) in->scale[srcScalingIndex], in->Ppad, in->geom.sstride, (int32_t*) in->d_tmp);
+    HIP_TRY(hipGetLastError());
     HIP_TRY(hipStreamSynchronize(in->stream));
-    HIP_TRY(hipMemcpy(h.data(), in->scale[srcScalingIndex], (size_t) in->Ppad * sizeof(int32_t), hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(h.data(), in->d_tmp, (size_t) in->Ppad * sizeof(int32_t), hipMemcpyDeviceToHost));
     for (int c = 0; c < in->P; ++c) outScaleFactors[c] = (double) h[c] * 0.69314718055994530942;
     return BEAGLE_SUCCESS;
 }

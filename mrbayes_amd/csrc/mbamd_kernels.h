@@ -8,10 +8,14 @@
 //   k_scale_*            Copy/Reset/RemoveNodeScalers bookkeeping (src/likelihood.c:7981-8131)
 //
 // Data layout in HBM (all fp32 unless noted), P_pad = patterns rounded up to 64:
-//   4-state partials   : f4 [K][P_pad]            one f4 = the 4 states of (category, pattern)
+//   4-state partials   : f4 [P_pad/64][buffer][K][64]  pattern-block-major arena: one f4 = the 4 states of
+//                        (category, pattern); everything a 64-pattern workgroup ever touches (all nodes of
+//                        all chains) is one contiguous region -> a few 2 MiB pages per workgroup (TLB), 4 KiB
+//                        contiguous per node update (DRAM pages).  Tip states and scale buffers of the
+//                        4-state path use the same block-major arrangement ([P_pad/64][buffer][64]).
 //   general partials   : float  [K][S][P_pad]         state-major: lanes = consecutive patterns -> coalesced
-//   4-state matrices   : float  [K][4][4]             row = from-state (same as the reference ti[k][i][j])
-//   general matrices   : float  [K][SP][SP] transposed (mT[k][j][i] = P_k(i->j)), zero padded to SP
+//   matrices           : float  [K][SP][SP] transposed (mT[k][j][i] = P_k(i->j)), zero padded to SP
+//                        (SP = 4 on the 4-state path); MFMA path: + A-operand copy, see mbamd_kernels_mfma.h
 //   tip states         : uint8  [P_pad]               value >= S = missing
 //   scale buffers      : int32  [P_pad]               binary exponents (see below), node and cumulative alike
 //   pattern weights    : double [P_pad]; site lnL double [P_pad]
@@ -58,6 +62,16 @@ template <class T> __device__ __forceinline__ const MBAMD_AS_CONST T* as_const(c
     return (const MBAMD_AS_CONST T*) (uintptr_t) p;
 }
 
+// Block-major addressing (4-state path): consecutive 64-pattern blocks of one buffer are `*_stride`
+// elements apart; within a block a partials buffer is [K][64] f4, tips / scale buffers are [64].
+// The general-state path keeps linear [P_pad] arrays, which is the same formula with stride 64.
+struct BlockGeom {
+    unsigned long pstride;     // f4 elements between the blocks of a partials buffer
+    unsigned tstride;          // bytes between the blocks of a tip-state buffer
+    unsigned sstride;          // int32 elements between the blocks of a scale buffer
+};
+__host__ __device__ inline size_t blk_index(int c, size_t stride) { return (size_t) (c >> 6) * stride + (size_t) (c & 63); }
+
 enum ChildKind : uint8_t {
     CHILD_PARTIALS = 0,   // dense partials in HBM, not written by this launch
     CHILD_STATES   = 1,   // compact tip: uint8 state codes
@@ -79,7 +93,8 @@ struct alignas(16) PartialsOp {
     uint8_t      c1_slot, c2_slot;
     uint8_t      dst_slot;     // 0xFF: do not keep in LDS
     uint8_t      scale_mode;
-    uint8_t      pad_[2];
+    uint8_t      flags;        // MBAMD_OP_* (tree-walk kernel)
+    uint8_t      pad_[1];
     int32_t      pad2_[2];
 };
 static_assert(sizeof(PartialsOp) == 64, "PartialsOp must be 64 bytes");
@@ -112,24 +127,77 @@ __device__ __forceinline__ float scale_pow2(float v, int neg_e)
 
 __device__ __forceinline__ float max4(f4 v) { return fmaxf(fmaxf(v.x, v.y), fmaxf(v.z, v.w)); }
 
-// 4x4 matrix (row-major, uniform -> scalar registers) times f4
-__device__ __forceinline__ f4 mat4_mul(const MBAMD_AS_CONST float* __restrict__ m, f4 v)
+// 4x4 transition matrix times the 4 states of one (category, pattern).  The matrix is stored
+// transposed, mT[j][i] = P(i->j); it is wave-uniform data.  On the GPU each lane fetches only the
+// 16-byte row (lane & 3) of mT -- one dwordx4 load per matrix, four distinct addresses per wave --
+// and element (i, j) reaches every lane through a DPP quad broadcast from quad-lane j: a 4x4 matrix
+// costs 4 VGPRs and one vector load instead of 16 scalar registers, so all 2K matrices of an
+// operation are requested in one batch (one L2 round trip) and the scalar-register file no longer
+// limits how many are in flight.
+struct Mat4 {
+#if defined(MBAMD_HOST_EMU)
+    const float* m;
+#else
+    f4 col;       // (P(0->j), P(1->j), P(2->j), P(3->j)) with j = lane & 3
+#endif
+};
+__device__ __forceinline__ Mat4 mat4_load(const float* mT, int lane)
+{
+    Mat4 r;
+#if defined(MBAMD_HOST_EMU)
+    (void) lane;
+    r.m = mT;
+#else
+    r.col = as_global(reinterpret_cast<const f4*>(mT))[lane & 3];
+#endif
+    return r;
+}
+__device__ __forceinline__ f4 mat4_mul(const Mat4& M, f4 v)
 {
     f4 r;
-    r.x = fmaf(m[3], v.w, fmaf(m[2], v.z, fmaf(m[1], v.y, m[0] * v.x)));
-    r.y = fmaf(m[7], v.w, fmaf(m[6], v.z, fmaf(m[5], v.y, m[4] * v.x)));
-    r.z = fmaf(m[11], v.w, fmaf(m[10], v.z, fmaf(m[9], v.y, m[8] * v.x)));
-    r.w = fmaf(m[15], v.w, fmaf(m[14], v.z, fmaf(m[13], v.y, m[12] * v.x)));
+#if defined(MBAMD_HOST_EMU)
+    const float* m = M.m;
+    r.x = fmaf(m[12], v.w, fmaf(m[8], v.z, fmaf(m[4], v.y, m[0] * v.x)));
+    r.y = fmaf(m[13], v.w, fmaf(m[9], v.z, fmaf(m[5], v.y, m[1] * v.x)));
+    r.z = fmaf(m[14], v.w, fmaf(m[10], v.z, fmaf(m[6], v.y, m[2] * v.x)));
+    r.w = fmaf(m[15], v.w, fmaf(m[11], v.z, fmaf(m[7], v.y, m[3] * v.x)));
+#else
+    // r_i = fma(P(i->3), v.w, fma(P(i->2), v.z, fma(P(i->1), v.y, P(i->0) * v.x))), P(i->j) read from
+    // quad-lane j of M.col[i] by the DPP source modifier of v_mul/v_fmac (no broadcast temporaries).
+    // The DPP operands come from ds_read/global loads; the leading s_nop covers the 2 wait states a
+    // compiler-inserted VALU copy of them would need before a DPP read.
+    float rx, ry, rz, rw;
+    asm("s_nop 1\n\t"
+        "v_mul_f32_dpp %0, %4, %8 quad_perm:[0,0,0,0] row_mask:0xf bank_mask:0xf\n\t"
+        "v_mul_f32_dpp %1, %5, %8 quad_perm:[0,0,0,0] row_mask:0xf bank_mask:0xf\n\t"
+        "v_mul_f32_dpp %2, %6, %8 quad_perm:[0,0,0,0] row_mask:0xf bank_mask:0xf\n\t"
+        "v_mul_f32_dpp %3, %7, %8 quad_perm:[0,0,0,0] row_mask:0xf bank_mask:0xf\n\t"
+        "v_fmac_f32_dpp %0, %4, %9 quad_perm:[1,1,1,1] row_mask:0xf bank_mask:0xf\n\t"
+        "v_fmac_f32_dpp %1, %5, %9 quad_perm:[1,1,1,1] row_mask:0xf bank_mask:0xf\n\t"
+        "v_fmac_f32_dpp %2, %6, %9 quad_perm:[1,1,1,1] row_mask:0xf bank_mask:0xf\n\t"
+        "v_fmac_f32_dpp %3, %7, %9 quad_perm:[1,1,1,1] row_mask:0xf bank_mask:0xf\n\t"
+        "v_fmac_f32_dpp %0, %4, %10 quad_perm:[2,2,2,2] row_mask:0xf bank_mask:0xf\n\t"
+        "v_fmac_f32_dpp %1, %5, %10 quad_perm:[2,2,2,2] row_mask:0xf bank_mask:0xf\n\t"
+        "v_fmac_f32_dpp %2, %6, %10 quad_perm:[2,2,2,2] row_mask:0xf bank_mask:0xf\n\t"
+        "v_fmac_f32_dpp %3, %7, %10 quad_perm:[2,2,2,2] row_mask:0xf bank_mask:0xf\n\t"
+        "v_fmac_f32_dpp %0, %4, %11 quad_perm:[3,3,3,3] row_mask:0xf bank_mask:0xf\n\t"
+        "v_fmac_f32_dpp %1, %5, %11 quad_perm:[3,3,3,3] row_mask:0xf bank_mask:0xf\n\t"
+        "v_fmac_f32_dpp %2, %6, %11 quad_perm:[3,3,3,3] row_mask:0xf bank_mask:0xf\n\t"
+        "v_fmac_f32_dpp %3, %7, %11 quad_perm:[3,3,3,3] row_mask:0xf bank_mask:0xf"
+        : "=&v"(rx), "=&v"(ry), "=&v"(rz), "=&v"(rw)
+        : "v"(M.col.x), "v"(M.col.y), "v"(M.col.z), "v"(M.col.w), "v"(v.x), "v"(v.y), "v"(v.z), "v"(v.w));
+    r.x = rx; r.y = ry; r.z = rz; r.w = rw;
+#endif
     return r;
 }
 
-// a f4 this lane itself stored earlier in the same launch: bypass the (non-coherent) vector L1
+// a float4 this lane itself stored earlier in the same launch: bypass the (non-coherent) vector L1
 __device__ __forceinline__ f4 load_own_store(const f4* p)
 {
 #if defined(MBAMD_HOST_EMU)
     return *p;
 #else
-    const float* f = reinterpret_cast<const float*>(p);
+    const MBAMD_AS_GLOBAL float* f = as_global(reinterpret_cast<const float*>(p));
     f4 r;
     r.x = __hip_atomic_load(f + 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     r.y = __hip_atomic_load(f + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -142,115 +210,266 @@ __device__ __forceinline__ f4 load_own_store(const f4* p)
 // ---------------------------------------------------------------------------------------------
 // 4-state tree-walk kernel.
 //
-// One wave (= one 64-thread workgroup) owns 64 site patterns for the whole operation list: lane =
-// pattern, all K categories in registers.  Site patterns are independent through the entire
-// pruning recursion, so the wave walks the post-order list by itself -- no inter-workgroup
-// dependency, one launch per beagleUpdatePartials instead of one per tree level.  A freshly
-// computed node is written to HBM (it must persist for later partial updates) AND pushed into
-// a per-wave LDS stack slot chosen by the host, so its parent reads it back from LDS: HBM sees
-// each interior partial exactly once, as a streaming 1 KiB-per-instruction store.  Transition
-// matrices are wave-uniform and arrive through scalar loads; per-pattern max-rescaling (the
-// reference's separate CondLikeScaler pass) and the cumulative-scaler update are fused in.
+// One workgroup (W waves, W = blockDim.x / 64) owns 64 site patterns for the whole operation list:
+// lane = pattern, all K categories in registers.  Site patterns are independent through the entire
+// pruning recursion, so the workgroup walks the tree by itself -- no inter-workgroup dependency,
+// one launch per beagleUpdatePartials instead of one per tree level.  The host turns the list into
+// a schedule of steps: step s holds up to W mutually independent operations (one per wave) whose
+// inputs were produced in earlier steps; a workgroup barrier separates steps.  A freshly computed
+// node is written to HBM (it must persist for later partial updates) AND kept in an LDS slot
+// chosen by the host (Belady eviction), so its parent reads it back from LDS: HBM sees each
+// interior partial exactly once, as streaming 1 KiB-per-instruction stores, and never re-reads
+// it.  Transition matrices are wave-uniform and arrive through scalar loads as SGPR operands;
+// the per-pattern max-rescale (the reference's separate CondLikeScaler pass) and the cumulative
+// scaler update are fused in.  Several waves per SIMD hide the scalar-load / tip-load latency of
+// a step behind the arithmetic of the others.
+//
+// The step barrier only orders LDS traffic (s_waitcnt lgkmcnt(0) + s_barrier): global stores stay
+// in flight across steps.  Only when a value had to be evicted from LDS and is re-read from memory
+// (CHILD_RELOAD) does the host flag the preceding step OP_DRAIN so every wave waits for its stores
+// first; the re-read bypasses the vector L1.
 // ---------------------------------------------------------------------------------------------
-template <int K>
-__device__ __forceinline__ void walk_load_child(const void* ptr, int kind, int slot, int Ppad, int c, int lane,
-                                                const f4* lds, f4 (&v)[K])
+#define MBAMD_OP_DRAIN 1      // PartialsOp::flags: wait for this wave's global stores before the step barrier
+
+__device__ __forceinline__ void walk_step_barrier(bool drain)
 {
-    if (kind == CHILD_LDS) {
-#pragma unroll
-        for (int k = 0; k < K; ++k) v[k] = lds[(slot * K + k) * 64 + lane];
-    } else if (kind == CHILD_STATES) {
-        const unsigned s = as_global(reinterpret_cast<const uint8_t*>(ptr))[c];
+#if !defined(MBAMD_HOST_EMU)
+    if (drain) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+#else
+    (void) drain;
+#endif
+}
+
+// the fields of a PartialsOp as the walk kernel holds them in (scalar) registers
+struct WalkFields {
+    float* dst;
+    const void *c1, *c2;
+    const float *m1, *m2;
+    int32_t* scale;
+    int c1_kind, c2_kind, c1_slot, c2_slot, dst_slot, scale_mode, flags;
+};
+__device__ __forceinline__ WalkFields walk_fields(const PartialsOp* p)
+{
+    WalkFields f;
+    f.dst = p->dst; f.c1 = p->c1; f.c2 = p->c2; f.m1 = p->m1; f.m2 = p->m2; f.scale = p->scale;
+    f.c1_kind = p->c1_kind; f.c2_kind = p->c2_kind; f.c1_slot = p->c1_slot; f.c2_slot = p->c2_slot;
+    f.dst_slot = p->dst_slot; f.scale_mode = p->scale_mode; f.flags = p->flags;
+    return f;
+}
+
+// What one operation needs from memory besides LDS-resident children: its 2K transposed 4x4
+// matrices (8K rows of 16 bytes, fetched by lanes 0..8K-1 with ONE dwordx4 load) and the state
+// codes of compact tip children.  Requested one step ahead of use, so that the loads are older
+// than the previous step's stores in the (in-order) vmcnt queue and never wait behind them; they
+// cost 6 VGPRs while in flight.  At use the matrix rows go through a per-wave 128K-byte LDS
+// staging area from which every lane picks row (lane & 3) of each matrix (see Mat4).
+struct WalkInputs {
+    f4 mrow;            // lane l < 4K: row l of m1's K matrices; 4K <= l < 8K: row l-4K of m2's
+    unsigned s1, s2;
+};
+template <int K>
+__device__ __forceinline__ void walk_request(const WalkFields& op, size_t toff, int lane, WalkInputs& in)
+{
+#if defined(MBAMD_HOST_EMU)
+    in.mrow = f4{0.0f, 0.0f, 0.0f, 0.0f};
+#else
+    in.mrow = f4{0.0f, 0.0f, 0.0f, 0.0f};
+    if (lane < 8 * K) {
+        const bool first = lane < 4 * K;
+        const float* base = first ? op.m1 : op.m2;
+        in.mrow = as_global(reinterpret_cast<const f4*>(base))[first ? lane : lane - 4 * K];
+    }
+#endif
+    in.s1 = (op.c1_kind == CHILD_STATES) ? (unsigned) as_global(reinterpret_cast<const uint8_t*>(op.c1))[toff] : 0u;
+    in.s2 = (op.c2_kind == CHILD_STATES) ? (unsigned) as_global(reinterpret_cast<const uint8_t*>(op.c2))[toff] : 0u;
+}
+
+// one category of a child: LDS slot, compact tip (0/1 vector from the state code), or global memory
+__device__ __forceinline__ f4 walk_child_k(const void* ptr, int kind, int slot, unsigned s, int K, int k, size_t poff,
+                                           int lane, const f4* lds)
+{
+    if (kind == CHILD_LDS) return lds[(slot * K + k) * 64 + lane];
+    if (kind == CHILD_STATES) {
         f4 one;
         one.x = (s == 0u || s >= 4u) ? 1.0f : 0.0f;
         one.y = (s == 1u || s >= 4u) ? 1.0f : 0.0f;
         one.z = (s == 2u || s >= 4u) ? 1.0f : 0.0f;
         one.w = (s == 3u || s >= 4u) ? 1.0f : 0.0f;
-#pragma unroll
-        for (int k = 0; k < K; ++k) v[k] = one;
-    } else if (kind == CHILD_PARTIALS) {
-        const MBAMD_AS_GLOBAL f4* p = as_global(reinterpret_cast<const f4*>(ptr));
-#pragma unroll
-        for (int k = 0; k < K; ++k) v[k] = p[(size_t) k * Ppad + c];
-    } else {
-        const f4* p = reinterpret_cast<const f4*>(ptr);
-#pragma unroll
-        for (int k = 0; k < K; ++k) v[k] = load_own_store(p + (size_t) k * Ppad + c);
+        return one;
     }
+    // CHILD_PARTIALS, and CHILD_RELOAD: a value this workgroup stored earlier in the launch.  Its
+    // producer wave drained its stores before a step barrier (MBAMD_OP_DRAIN) and all waves of a
+    // workgroup share one vector L1, so a plain load observes it.
+    return as_global(reinterpret_cast<const f4*>(ptr))[poff + k * 64];
 }
 
 template <int K>
-__global__ void __launch_bounds__(64)
-k_walk_s4(const PartialsOp* __restrict__ ops, int nops, int Ppad, int32_t* __restrict__ cumulative)
+__device__ __forceinline__ void walk_op(const WalkFields& op, const WalkInputs& in, f4* stage, size_t poff, size_t soff,
+                                        int lane, f4* lds, int& cum_e, int ablate = 0)
 {
+    Mat4 M1[K], M2[K];
 #if defined(MBAMD_HOST_EMU)
-    f4* lds = reinterpret_cast<f4*>(mbamd_emu_dyn_lds());
+    (void) stage;
+#pragma unroll
+    for (int k = 0; k < K; ++k) { M1[k] = mat4_load(op.m1 + 16 * k, lane); M2[k] = mat4_load(op.m2 + 16 * k, lane); }
 #else
-    extern __shared__ f4 lds[];
+    // spread the prefetched matrix rows over the wave: 8K rows -> LDS -> row (lane & 3) of each matrix
+    if (lane < 8 * K) stage[lane] = in.mrow;
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+        M1[k].col = stage[4 * k + (lane & 3)];
+        M2[k].col = stage[4 * K + 4 * k + (lane & 3)];
+    }
 #endif
-    const int lane = threadIdx.x;
-    const int c = blockIdx.x * 64 + lane;
-    int cum_e = 0;
-
-    const MBAMD_AS_CONST PartialsOp* __restrict__ cops = as_const(ops);
-    for (int o = 0; o < nops; ++o) {
-        const MBAMD_AS_CONST PartialsOp* __restrict__ op = cops + o;
-        const int k1 = op->c1_kind, k2 = op->c2_kind;
-        if (k1 == CHILD_RELOAD || k2 == CHILD_RELOAD) {
-            // our own earlier stores must have reached L2 before we read them back
-#if !defined(MBAMD_HOST_EMU)
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-#endif
+    // children are consumed category by category (one category ahead in flight) to keep the register
+    // footprint at 128 VGPRs with the next step's inputs already resident
+    f4 out[K];
+    float mx = 0.0f;
+    f4 a = walk_child_k(op.c1, op.c1_kind, op.c1_slot, in.s1, K, 0, poff, lane, lds);
+    f4 b = walk_child_k(op.c2, op.c2_kind, op.c2_slot, in.s2, K, 0, poff, lane, lds);
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+        f4 an = a, bn = b;
+        if (k + 1 < K) {
+            an = walk_child_k(op.c1, op.c1_kind, op.c1_slot, in.s1, K, k + 1, poff, lane, lds);
+            bn = walk_child_k(op.c2, op.c2_kind, op.c2_slot, in.s2, K, k + 1, poff, lane, lds);
         }
-        f4 a[K], b[K];
-        walk_load_child<K>(op->c1, k1, op->c1_slot, Ppad, c, lane, lds, a);
-        walk_load_child<K>(op->c2, k2, op->c2_slot, Ppad, c, lane, lds, b);
+        const f4 f1 = mat4_mul(M1[k], a);
+        const f4 f2 = mat4_mul(M2[k], b);
+        out[k].x = f1.x * f2.x;
+        out[k].y = f1.y * f2.y;
+        out[k].z = f1.z * f2.z;
+        out[k].w = f1.w * f2.w;
+        mx = fmaxf(mx, max4(out[k]));
+        a = an;
+        b = bn;
+    }
 
-        const MBAMD_AS_CONST float* __restrict__ m1 = as_const(op->m1);
-        const MBAMD_AS_CONST float* __restrict__ m2 = as_const(op->m2);
-        f4 out[K];
-        float mx = 0.0f;
+    const int mode = op.scale_mode;
+    if (mode != SCALE_NONE) {
+        int e;
+        MBAMD_AS_GLOBAL int32_t* sc = as_global(op.scale);
+        if (mode == SCALE_WRITE) {
+            e = scale_exponent(mx);
+            sc[soff] = e;
+            cum_e += e;
+        } else {
+            e = sc[soff];
+        }
 #pragma unroll
         for (int k = 0; k < K; ++k) {
-            const f4 f1 = mat4_mul(m1 + 16 * k, a[k]);
-            const f4 f2 = mat4_mul(m2 + 16 * k, b[k]);
-            out[k].x = f1.x * f2.x;
-            out[k].y = f1.y * f2.y;
-            out[k].z = f1.z * f2.z;
-            out[k].w = f1.w * f2.w;
-            mx = fmaxf(mx, max4(out[k]));
-        }
-
-        const int mode = op->scale_mode;
-        if (mode != SCALE_NONE) {
-            int e;
-            MBAMD_AS_GLOBAL int32_t* sc = as_global(op->scale);
-            if (mode == SCALE_WRITE) {
-                e = scale_exponent(mx);
-                sc[c] = e;
-                cum_e += e;
-            } else {
-                e = sc[c];
-            }
-#pragma unroll
-            for (int k = 0; k < K; ++k) {
-                out[k].x = scale_pow2(out[k].x, -e);
-                out[k].y = scale_pow2(out[k].y, -e);
-                out[k].z = scale_pow2(out[k].z, -e);
-                out[k].w = scale_pow2(out[k].w, -e);
-            }
-        }
-
-        MBAMD_AS_GLOBAL f4* __restrict__ dst = as_global(reinterpret_cast<f4*>(op->dst));
-#pragma unroll
-        for (int k = 0; k < K; ++k) dst[(size_t) k * Ppad + c] = out[k];
-        const int ds = op->dst_slot;
-        if (ds != MBAMD_NO_SLOT) {
-#pragma unroll
-            for (int k = 0; k < K; ++k) lds[(ds * K + k) * 64 + lane] = out[k];
+            out[k].x = scale_pow2(out[k].x, -e);
+            out[k].y = scale_pow2(out[k].y, -e);
+            out[k].z = scale_pow2(out[k].z, -e);
+            out[k].w = scale_pow2(out[k].w, -e);
         }
     }
-    if (cumulative != nullptr && cum_e != 0) cumulative[c] += cum_e;
+
+    MBAMD_AS_GLOBAL f4* __restrict__ dst = as_global(reinterpret_cast<f4*>(op.dst)) + poff;
+    if (!(ablate & 1)) {           // (timing experiments only: MBAMD_WALK_ABLATE)
+#pragma unroll
+        for (int k = 0; k < K; ++k) dst[k * 64] = out[k];     // 4K KiB contiguous per node update
+    }
+    const int ds = op.dst_slot;
+    if (ds != MBAMD_NO_SLOT && !(ablate & 2)) {
+#pragma unroll
+        for (int k = 0; k < K; ++k) lds[(ds * K + k) * 64 + lane] = out[k];
+    }
+}
+
+#if !defined(MBAMD_HOST_EMU)
+// One row of the schedule = the W descriptors of a step = 16*W dwords.  A wave fetches a row with
+// two coalesced dword loads (lane l holds dwords l and l+64; the vector L1 serves the other waves
+// of the workgroup) and later picks its own 16 dwords out of the lanes with v_readlane: the
+// descriptors travel through the vmcnt queue like every other prefetch and end up in SGPRs.
+struct WalkRow { unsigned lo, hi; };
+__device__ __forceinline__ WalkRow walk_row_request(const PartialsOp* ops, int step, int W, int lane)
+{
+    const MBAMD_AS_GLOBAL unsigned* p = as_global(reinterpret_cast<const unsigned*>(ops)) + (size_t) step * W * 16;
+    WalkRow r;
+    r.lo = p[lane < W * 16 ? lane : 0];
+    r.hi = (W > 4) ? p[64 + lane] : 0u;
+    return r;
+}
+__device__ __forceinline__ WalkFields walk_row_fields(const WalkRow& r, int wave)
+{
+    const unsigned v = (wave >= 4) ? r.hi : r.lo;
+    const int base = (wave & 3) * 16;
+    unsigned d[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) d[i] = (unsigned) __builtin_amdgcn_readlane((int) v, base + i);
+    WalkFields f;
+    f.dst = reinterpret_cast<float*>(((unsigned long) d[1] << 32) | d[0]);
+    f.c1 = reinterpret_cast<const void*>(((unsigned long) d[3] << 32) | d[2]);
+    f.c2 = reinterpret_cast<const void*>(((unsigned long) d[5] << 32) | d[4]);
+    f.m1 = reinterpret_cast<const float*>(((unsigned long) d[7] << 32) | d[6]);
+    f.m2 = reinterpret_cast<const float*>(((unsigned long) d[9] << 32) | d[8]);
+    f.scale = reinterpret_cast<int32_t*>(((unsigned long) d[11] << 32) | d[10]);
+    const unsigned lo = d[12], hi = d[13];
+    f.c1_kind = lo & 0xFF; f.c2_kind = (lo >> 8) & 0xFF; f.c1_slot = (lo >> 16) & 0xFF; f.c2_slot = lo >> 24;
+    f.dst_slot = hi & 0xFF; f.scale_mode = (hi >> 8) & 0xFF; f.flags = (hi >> 16) & 0xFF;
+    return f;
+}
+#endif
+
+// ops: [nsteps + 4][W] (an empty entry has dst == nullptr and valid dummy matrix pointers; flags are
+// replicated over a step's entries; three empty rows pad the end for the prefetch pipeline).
+// blockDim.x == 64*W.  (Host emulation: one 64-thread block whose threads run the W entries of a
+// step one after the other -- lanes never exchange data, so that is the same computation.)
+template <int K>
+__global__ void __launch_bounds__(512, (K <= 4 ? 4 : 2))
+k_walk_s4(const PartialsOp* __restrict__ ops, int nsteps, int W, BlockGeom g, int32_t* __restrict__ cumulative, int ablate)
+{
+    const int lane = threadIdx.x & 63;
+    const size_t poff = (size_t) blockIdx.x * g.pstride + lane;     // this workgroup's block in every buffer
+    const size_t toff = (size_t) blockIdx.x * g.tstride + lane;
+    const size_t soff = (size_t) blockIdx.x * g.sstride + lane;
+    int cum_e = 0;
+#if defined(MBAMD_HOST_EMU)
+    (void) ablate;
+    f4* lds = reinterpret_cast<f4*>(mbamd_emu_dyn_lds());
+    const bool reversed = W < 0;                 // test hook: run a step's entries in the opposite order
+    if (reversed) W = -W;
+    for (int s = 0; s < nsteps; ++s)
+        for (int i = 0; i < W; ++i) {
+            const PartialsOp* op = ops + (size_t) s * W + (reversed ? W - 1 - i : i);
+            if (op->dst == nullptr) continue;
+            const WalkFields f = walk_fields(op);
+            WalkInputs in;
+            walk_request<K>(f, toff, lane, in);
+            walk_op<K>(f, in, nullptr, poff, soff, lane, lds, cum_e);
+        }
+#else
+    extern __shared__ f4 lds_all[];
+    const int wave = __builtin_amdgcn_readfirstlane((int) (threadIdx.x >> 6));
+    f4* stage = lds_all + wave * (8 * K);         // per-wave matrix staging: 8K rows of 16 bytes
+    f4* lds = lds_all + W * (8 * K);              // value slots: [slot][K][64 lanes]
+    // software pipeline: while step s computes, the inputs of step s+1 and the descriptor rows of
+    // steps s+2, s+3 are in flight
+    WalkFields cur = walk_row_fields(walk_row_request(ops, 0, W, lane), wave);
+    WalkFields nxt = walk_row_fields(walk_row_request(ops, 1, W, lane), wave);
+    WalkRow row2 = walk_row_request(ops, 2, W, lane);
+    WalkInputs in_cur;
+    walk_request<K>(cur, toff, lane, in_cur);
+    for (int s = 0; s < nsteps; ++s) {
+        WalkInputs in_nxt = in_cur;
+        if (!(ablate & 16)) walk_request<K>(nxt, toff, lane, in_nxt);
+        WalkRow row3 = row2;
+        if (!(ablate & 32)) row3 = walk_row_request(ops, s + 3, W, lane);
+        if ((ablate & 64) && blockIdx.x == 0 && threadIdx.x == 0)      // timing experiments: per-step clock trace
+            reinterpret_cast<long long*>(cumulative)[s] = (long long) __builtin_readcyclecounter();
+        if (cur.dst != nullptr && !(ablate & 4)) walk_op<K>(cur, in_cur, stage, poff, soff, lane, lds, cum_e, ablate);
+        if (!(ablate & 8)) walk_step_barrier((cur.flags & MBAMD_OP_DRAIN) != 0);
+        cur = nxt;
+        in_cur = in_nxt;
+        nxt = walk_row_fields(row2, wave);
+        row2 = row3;
+    }
+#endif
+    if (cumulative != nullptr && cum_e != 0) atomicAdd(cumulative + soff, cum_e);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -385,23 +604,54 @@ struct MatrixJob {
     double length;     // branch length
 };
 
+// category rates travel as a kernel argument (no host-to-device copy per beagleSetCategoryRates)
+#define MBAMD_MAX_RATES 16
+struct RatesArg { double r[MBAMD_MAX_RATES]; };
+
 // exp(lambda*t) hoisted: one thread per (job, k, s) fills ev[(job*K+k)*S + s]; the matrix kernel
 // below then reads it (second launch on the same stream, so no barrier is needed).
+// `jobs` may live in pinned host memory (read once, directly over the host link).
 __global__ void __launch_bounds__(256)
 k_eigen_exponentials(const MatrixJob* __restrict__ jobs, const double* __restrict__ eig,
-                     const double* __restrict__ rates, int S, int K, int total, double* __restrict__ ev)
+                     RatesArg rates, int S, int K, int total, double* __restrict__ ev)
 {
     const int g = blockIdx.x * blockDim.x + threadIdx.x;
     if (g >= total) return;
     const int s = g % S, bk = g / S;
     const int b = bk / K, k = bk % K;
     const double* __restrict__ lam = eig + (size_t) 2 * S * S;
-    ev[g] = exp(lam[s] * jobs[b].length * rates[k]);
+    ev[g] = exp(lam[s] * jobs[b].length * rates.r[k]);
 }
 
+// 4-state path: one thread per (branch, category) does the whole 4x4 matrix, exps included
+// (TiProbs_Gen for S = 4, src/likelihood.c:9498-9545); output transposed mT[j][i] = P(i->j).
+__global__ void __launch_bounds__(256)
+k_transition_matrices_s4(const MatrixJob* __restrict__ jobs, const double* __restrict__ eig, RatesArg rates,
+                         int K, int total)
+{
+    const int g = blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= total) return;
+    const int b = g / K, k = g % K;
+    const double* __restrict__ U = eig;
+    const double* __restrict__ Ui = eig + 16;
+    const double* __restrict__ lam = eig + 32;
+    const MatrixJob job = jobs[b];
+    double e[4];
+    for (int s = 0; s < 4; ++s) e[s] = exp(lam[s] * job.length * rates.r[k]);
+    float* __restrict__ out = job.out + (size_t) k * 16;
+    for (int i = 0; i < 4; ++i)
+        for (int j = 0; j < 4; ++j) {
+            double sum = 0.0;
+            for (int s = 0; s < 4; ++s) sum += U[i * 4 + s] * e[s] * Ui[s * 4 + j];
+            out[j * 4 + i] = (sum < 0.0) ? 0.0f : (float) sum;
+        }
+}
+
+// packedT > 0: additionally write the MFMA A-operand copy behind the K transposed matrices:
+//   packed[((k*NT + i/32)*T + j/2)*64 + (i%32) + 32*(j%2)] = P_k(i->j),  NT = ceil(S/32), T = packedT = ceil(S/2)
 __global__ void __launch_bounds__(256)
 k_transition_matrices_ev(const MatrixJob* __restrict__ jobs, const double* __restrict__ eig,
-                         const double* __restrict__ ev, int S, int SP, int K, int transposed)
+                         const double* __restrict__ ev, int S, int SP, int K, int transposed, int packedT)
 {
     const int b = blockIdx.x / K, k = blockIdx.x % K;
     const double* __restrict__ U = eig;
@@ -416,6 +666,11 @@ k_transition_matrices_ev(const MatrixJob* __restrict__ jobs, const double* __res
         const float v = (sum < 0.0) ? 0.0f : (float) sum;
         if (transposed) out[(size_t) j * SP + i] = v;
         else            out[(size_t) i * SP + j] = v;
+        if (packedT > 0) {
+            const int NT = (S + 31) / 32;
+            float* __restrict__ packed = jobs[b].out + (size_t) K * SP * SP;
+            packed[((size_t) (k * NT + i / 32) * packedT + j / 2) * 64 + (i % 32) + 32 * (j % 2)] = v;
+        }
     }
 }
 
@@ -424,7 +679,7 @@ k_transition_matrices_ev(const MatrixJob* __restrict__ jobs, const double* __res
 // SURVEY Appendix B).  One thread per pattern:
 //   L_n = sum_k w_nk sum_i pi_ni parent_n[k,c,i] * (sum_j P_nk[i,j] child_n[k,c,j])    (edge)
 //   lnL_c = log( sum_n L_n 2^(e_n - emax) ) + emax ln2,  e_n = cumulative exponent of subset n
-//   site[c] = lnL_c ; wsite[c] = weight_c * lnL_c   (summed by k_chunk_sums + host)
+//   site[c] = lnL_c ; wsite[block] = sum over the block's 64 patterns of weight_c * lnL_c (host adds the blocks)
 // ---------------------------------------------------------------------------------------------
 #define MBAMD_MAX_SUBSETS 8
 struct IntegrateArgs {
@@ -439,29 +694,27 @@ struct IntegrateArgs {
 };
 
 template <bool S4>
-__device__ __forceinline__ float part_at(const float* p, int S, int Ppad, int k, int c, int i)
+__device__ __forceinline__ float part_at(const float* p, int S, int Ppad, size_t pstride, int k, int c, int i)
 {
-    return S4 ? p[((size_t) k * Ppad + c) * 4 + i] : p[((size_t) k * S + i) * Ppad + c];
+    return S4 ? p[(blk_index(c, pstride) + (size_t) k * 64) * 4 + i] : p[((size_t) k * S + i) * Ppad + c];
 }
 template <bool S4>
 __device__ __forceinline__ float mat_at(const float* m, int SP, int k, int i, int j)
 {
-    return S4 ? m[k * 16 + i * 4 + j] : m[(size_t) k * SP * SP + (size_t) j * SP + i];
+    return S4 ? m[k * 16 + j * 4 + i] : m[(size_t) k * SP * SP + (size_t) j * SP + i];
 }
 
 template <bool S4>
 __global__ void __launch_bounds__(64)
-k_integrate_lnl(IntegrateArgs a, int S, int SP, int K, int P, int Ppad,
+k_integrate_lnl(IntegrateArgs a, int S, int SP, int K, int P, int Ppad, BlockGeom g,
                 const double* __restrict__ pattern_weights, double* __restrict__ site, double* __restrict__ wsite)
 {
     const int c = blockIdx.x * 64 + threadIdx.x;
-    if (c >= P) {
-        if (c < Ppad) { site[c] = 0.0; wsite[c] = 0.0; }
-        return;
-    }
+    double wl = 0.0;
+    if (c < P) {
     int emax = -2147483647;
     for (int n = 0; n < a.count; ++n) {
-        const int e = a.cum[n] ? a.cum[n][c] : 0;
+        const int e = a.cum[n] ? a.cum[n][blk_index(c, g.sstride)] : 0;
         emax = e > emax ? e : emax;
     }
     double total = 0.0;
@@ -470,56 +723,82 @@ k_integrate_lnl(IntegrateArgs a, int S, int SP, int K, int P, int Ppad,
         for (int k = 0; k < K; ++k) {
             double cat = 0.0;
             if (a.child[n] == nullptr) {
-                for (int i = 0; i < S; ++i) cat += (double) part_at<S4>(a.parent[n], S, Ppad, k, c, i) * a.freqs[n][i];
+                for (int i = 0; i < S; ++i) cat += (double) part_at<S4>(a.parent[n], S, Ppad, g.pstride, k, c, i) * a.freqs[n][i];
             } else if (a.child_kind[n] == CHILD_STATES) {
-                const unsigned s = reinterpret_cast<const uint8_t*>(a.child[n])[c];
+                const unsigned s = reinterpret_cast<const uint8_t*>(a.child[n])[blk_index(c, g.tstride)];
                 for (int i = 0; i < S; ++i) {
                     const float pc = (s >= (unsigned) S) ? 1.0f : mat_at<S4>(a.matrix[n], SP, k, i, (int) s);
-                    cat += (double) (part_at<S4>(a.parent[n], S, Ppad, k, c, i) * pc) * a.freqs[n][i];
+                    cat += (double) (part_at<S4>(a.parent[n], S, Ppad, g.pstride, k, c, i) * pc) * a.freqs[n][i];
                 }
             } else {
                 const float* ch = reinterpret_cast<const float*>(a.child[n]);
                 for (int i = 0; i < S; ++i) {
                     float acc = 0.0f;
                     for (int j = 0; j < S; ++j)
-                        acc = fmaf(mat_at<S4>(a.matrix[n], SP, k, i, j), part_at<S4>(ch, S, Ppad, k, c, j), acc);
-                    cat += (double) (part_at<S4>(a.parent[n], S, Ppad, k, c, i) * acc) * a.freqs[n][i];
+                        acc = fmaf(mat_at<S4>(a.matrix[n], SP, k, i, j), part_at<S4>(ch, S, Ppad, g.pstride, k, c, j), acc);
+                    cat += (double) (part_at<S4>(a.parent[n], S, Ppad, g.pstride, k, c, i) * acc) * a.freqs[n][i];
                 }
             }
             like += cat * a.weights[n][k];
         }
-        const int e = a.cum[n] ? a.cum[n][c] : 0;
+        const int e = a.cum[n] ? a.cum[n][blk_index(c, g.sstride)] : 0;
         total += ldexp(like, e - emax);
     }
     const double lnl = log(total) + (double) emax * 0.69314718055994530942;
     site[c] = lnl;
-    wsite[c] = lnl * pattern_weights[c];
-}
-
-// sums[t] = sum of wsite[t*chunk .. (t+1)*chunk): the few hundred partial sums go to the host,
-// which adds them in a fixed order (deterministic, fp64).
-__global__ void __launch_bounds__(64)
-k_chunk_sums(const double* __restrict__ wsite, int n, int chunk, int nchunks, double* __restrict__ sums)
-{
-    const int t = blockIdx.x * 64 + threadIdx.x;
-    if (t >= nchunks) return;
-    const int lo = t * chunk, hi = (lo + chunk < n) ? lo + chunk : n;
-    double s = 0.0;
-    for (int i = lo; i < hi; ++i) s += wsite[i];
-    sums[t] = s;
+    wl = lnl * pattern_weights[c];
+    } else if (c < Ppad) {
+        site[c] = 0.0;
+    }
+    // one partial sum per 64-pattern block, reduced in a fixed order (deterministic); `wsite` is an
+    // array of P_pad/64 doubles that may live in pinned host memory: the host adds them up
+#if defined(MBAMD_HOST_EMU)
+    if (threadIdx.x == 0) wsite[blockIdx.x] = 0.0;
+    wsite[blockIdx.x] += wl;
+#else
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) wl += __shfl_down(wl, off);
+    if (threadIdx.x == 0) wsite[blockIdx.x] = wl;
+#endif
 }
 
 // ---------------------------------------------------------------------------------------------
 // cumulative scale-factor bookkeeping (exact integer arithmetic)
 // ---------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(256)
-k_scale_accumulate(const int32_t* const* __restrict__ src, int count, int sign, int n, int32_t* __restrict__ cum)
+k_scale_accumulate(const int32_t* const* __restrict__ src, int count, int sign, int n, unsigned sstride,
+                   int32_t* __restrict__ cum)
 {
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= n) return;
+    const size_t o = blk_index(c, sstride);
     int acc = 0;
-    for (int i = 0; i < count; ++i) acc += src[i][c];
-    cum[c] += sign * acc;
+    for (int i = 0; i < count; ++i) acc += src[i][o];
+    cum[o] += sign * acc;
+}
+
+// dst[c] = src ? src[c] : 0 over one (possibly block-major) scale buffer
+__global__ void __launch_bounds__(256)
+k_scale_copy(const int32_t* __restrict__ src, int n, unsigned sstride, int32_t* __restrict__ dst)
+{
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= n) return;
+    const size_t o = blk_index(c, sstride);
+    dst[o] = src ? src[o] : 0;
+}
+
+// linear [n] <-> block-major conversion of byte / int32 arrays (tip states in, scale factors out)
+__global__ void __launch_bounds__(256)
+k_scatter_bytes(const uint8_t* __restrict__ linear, int n, unsigned tstride, uint8_t* __restrict__ out)
+{
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c < n) out[blk_index(c, tstride)] = linear[c];
+}
+__global__ void __launch_bounds__(256)
+k_gather_ints(const int32_t* __restrict__ in, int n, unsigned sstride, int32_t* __restrict__ linear)
+{
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c < n) linear[c] = in[blk_index(c, sstride)];
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -527,7 +806,7 @@ k_scale_accumulate(const int32_t* const* __restrict__ src, int count, int sign, 
 // ---------------------------------------------------------------------------------------------
 template <bool S4>
 __global__ void __launch_bounds__(256)
-k_import_partials(const double* __restrict__ in, int in_has_categories, int S, int K, int P, int Ppad,
+k_import_partials(const double* __restrict__ in, int in_has_categories, int S, int K, int P, int Ppad, size_t pstride,
                   float* __restrict__ out)
 {
     const size_t total = (size_t) K * P * S;
@@ -537,13 +816,13 @@ k_import_partials(const double* __restrict__ in, int in_has_categories, int S, i
     const int c = (int) ((g / S) % P);
     const int k = (int) (g / ((size_t) S * P));
     const double v = in_has_categories ? in[g] : in[(size_t) c * S + i];
-    if (S4) out[((size_t) k * Ppad + c) * 4 + i] = (float) v;
+    if (S4) out[(blk_index(c, pstride) + (size_t) k * 64) * 4 + i] = (float) v;
     else    out[((size_t) k * S + i) * Ppad + c] = (float) v;
 }
 
 template <bool S4>
 __global__ void __launch_bounds__(256)
-k_export_partials(const float* __restrict__ in, int S, int K, int P, int Ppad, double* __restrict__ out)
+k_export_partials(const float* __restrict__ in, int S, int K, int P, int Ppad, size_t pstride, double* __restrict__ out)
 {
     const size_t total = (size_t) K * P * S;
     const size_t g = (size_t) blockIdx.x * blockDim.x + threadIdx.x;
@@ -551,7 +830,7 @@ k_export_partials(const float* __restrict__ in, int S, int K, int P, int Ppad, d
     const int i = (int) (g % S);
     const int c = (int) ((g / S) % P);
     const int k = (int) (g / ((size_t) S * P));
-    out[g] = S4 ? (double) in[((size_t) k * Ppad + c) * 4 + i] : (double) in[((size_t) k * S + i) * Ppad + c];
+    out[g] = S4 ? (double) in[(blk_index(c, pstride) + (size_t) k * 64) * 4 + i] : (double) in[((size_t) k * S + i) * Ppad + c];
 }
 
 }  // namespace mbamd

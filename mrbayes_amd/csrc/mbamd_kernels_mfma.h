@@ -1,0 +1,175 @@
+// mbamd_kernels_mfma.h -- matrix-core (MFMA) kernels of the general-state path: 20-state amino-acid
+// and 61-state codon models (any 5 <= S <= 64).  gfx950 only; there is no host-emulation twin.
+//
+// Replaces CondLikeDown_Gen[_SSE] / CondLikeDown_NY98[_SSE] + CondLikeScaler_Gen / _NY98
+// (reference src/likelihood.c:204-588, 1575-1900, 4939-5070, 5413-5545).
+//
+// One conditional-likelihood update is, per rate/omega category k, two dense contractions
+//     F_c[i][p] = sum_j P_c,k[i][j] * cl_c[k][j][p]        (c = left, right child; p = site pattern)
+// followed by the element-wise product F_1 .* F_2 and the per-pattern rescale.  Each contraction
+// is mapped on v_mfma_f32_32x32x2_f32 (exact fp32, 64 FLOP/clk/SIMD):
+//     A (32 x 2)  = transition matrix tile   P[32*it + (lane&31)][2t + (lane>>5)]
+//     B (2 x 32)  = conditional likelihoods  cl[2t + (lane>>5)][c0 + (lane&31)]
+//     D (32 x 32) = F[i][p]: lane holds p = c0 + (lane&31), rows i = 32*it + (r&3) + 8*(r>>2) + 4*(lane>>5)
+// The B operand is exactly one coalesced dword load from the state-major partials layout
+// [K][S][P_pad] (two 128-byte row segments per wave instruction) -- no LDS staging, no transposes.
+// The A operand comes pre-packed in MFMA lane order from k_transition_matrices_ev (one coalesced
+// 256-byte load per MFMA, L1/L2 resident: a matrix set is 10-48 KiB).  A compact tip child needs
+// no contraction at all: its factor is column `state` of P, gathered with dwordx4 loads.
+// One wave owns 32 patterns of one operation for all K categories, so the per-pattern maximum over
+// (k, i) -- the reference's separate CondLikeScaler pass -- is a register reduction plus one
+// cross-half exchange, and the rescaled result is written exactly once.
+#ifndef MBAMD_KERNELS_MFMA_H_
+#define MBAMD_KERNELS_MFMA_H_
+
+#include "mbamd_kernels.h"
+
+namespace mbamd {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+// floats of the MFMA-packed copy of one category's matrix: NT i-tiles x T j-pairs x 64 lanes
+__host__ __device__ inline int mfma_tiles(int S) { return (S + 31) / 32; }
+__host__ __device__ inline int mfma_pairs(int S) { return (S + 1) / 2; }
+
+// blockIdx -> (pattern block x, operation y) such that a pattern block always lands on the same
+// XCD (block b runs on XCD b % 8): the children written by the previous dependency level for these
+// patterns were written through the same XCD's L2.
+__device__ __forceinline__ bool xcd_aware_block(int gx, int& x, int& y)
+{
+    const int id = blockIdx.x;
+    const int xcd = id & 7, q = id >> 3;
+    const int nxb = (gx + 7) >> 3;
+    x = (q % nxb) * 8 + xcd;
+    y = q / nxb;
+    return x < gx;
+}
+
+template <int NT, int SC>     // SC: compile-time state count (0 = run-time S)
+__device__ __forceinline__ void mfma_child_factor(const void* ptr, int kind, const float* mbase, int S_rt, int SP,
+                                                  int K, int k, int Ppad, int c0, int lane, f32x16 (&acc)[NT])
+{
+    const int S = SC > 0 ? SC : S_rt;
+    const int T = (S + 1) / 2;
+    const int half = lane >> 5, col = lane & 31;
+    if (kind == CHILD_STATES) {
+        const unsigned s = as_global(reinterpret_cast<const uint8_t*>(ptr))[c0 + col];
+        const bool missing = s >= (unsigned) S;
+        const MBAMD_AS_GLOBAL float* row = as_global(mbase) + ((size_t) k * SP + (missing ? 0u : s)) * SP + 4 * half;
+#pragma unroll
+        for (int it = 0; it < NT; ++it) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int i0 = 32 * it + 8 * q;                 // + 4*half + (0..3)
+                f4 v = *reinterpret_cast<const MBAMD_AS_GLOBAL f4*>(row + i0);
+                if (missing) {
+                    const int ib = i0 + 4 * half;
+                    v.x = (ib + 0 < S) ? 1.0f : 0.0f;
+                    v.y = (ib + 1 < S) ? 1.0f : 0.0f;
+                    v.z = (ib + 2 < S) ? 1.0f : 0.0f;
+                    v.w = (ib + 3 < S) ? 1.0f : 0.0f;
+                }
+                acc[it][4 * q + 0] = v.x;
+                acc[it][4 * q + 1] = v.y;
+                acc[it][4 * q + 2] = v.z;
+                acc[it][4 * q + 3] = v.w;
+            }
+        }
+        return;
+    }
+#pragma unroll
+    for (int it = 0; it < NT; ++it)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[it][r] = 0.0f;
+    // packed A operands of category k: [NT][T][64] after the K transposed SPxSP matrices
+    const MBAMD_AS_GLOBAL float* __restrict__ pa =
+        as_global(mbase) + (size_t) K * SP * SP + (size_t) k * NT * T * 64 + lane;
+    const MBAMD_AS_GLOBAL float* __restrict__ cl =
+        as_global(reinterpret_cast<const float*>(ptr)) + (size_t) k * S * Ppad + (size_t) half * Ppad + c0 + col;
+    const int Tfull = S / 2;                    // pairs with both rows < S
+#pragma unroll 5
+    for (int t = 0; t < Tfull; ++t) {
+        const float b = cl[(size_t) (2 * t) * Ppad];
+#pragma unroll
+        for (int it = 0; it < NT; ++it) {
+            const float a = pa[(size_t) (it * T + t) * 64];
+            acc[it] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[it], 0, 0, 0);
+        }
+    }
+    if (S & 1) {                                // last pair: row S does not exist, feed zeros
+        const int t = Tfull;
+        const float b = half ? 0.0f : cl[(size_t) (2 * t) * Ppad];
+#pragma unroll
+        for (int it = 0; it < NT; ++it) {
+            const float a = pa[(size_t) (it * T + t) * 64];
+            acc[it] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[it], 0, 0, 0);
+        }
+    }
+}
+
+// grid: 8 * ceil(gx/8) * count blocks of 256 threads (4 waves, one 32-pattern tile each),
+// gx = ceil(P_pad / 128).  KC = compile-time category count.
+template <int NT, int SC, int KC>
+__global__ void __launch_bounds__(256)
+k_partials_mfma(const PartialsOp* __restrict__ ops, int S_rt, int SP, int Ppad, int gx, int32_t* __restrict__ cumulative)
+{
+    const int S = SC > 0 ? SC : S_rt;
+    int bx, by;
+    if (!xcd_aware_block(gx, bx, by)) return;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int c0 = (bx * 4 + wave) * 32;
+    if (c0 >= Ppad) return;
+    const MBAMD_AS_CONST PartialsOp* __restrict__ op = as_const(ops) + by;
+    const int k1 = op->c1_kind, k2 = op->c2_kind;
+    const void* c1 = op->c1;
+    const void* c2 = op->c2;
+    const float* m1 = op->m1;
+    const float* m2 = op->m2;
+    const int mode = op->scale_mode;
+    const int half = lane >> 5, col = lane & 31;
+
+    f32x16 out[KC][NT];
+    float mx = 0.0f;
+#pragma unroll
+    for (int k = 0; k < KC; ++k) {
+        f32x16 f2[NT];
+        mfma_child_factor<NT, SC>(c1, k1, m1, S, SP, KC, k, Ppad, c0, lane, out[k]);
+        mfma_child_factor<NT, SC>(c2, k2, m2, S, SP, KC, k, Ppad, c0, lane, f2);
+#pragma unroll
+        for (int it = 0; it < NT; ++it)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float v = out[k][it][r] * f2[it][r];
+                out[k][it][r] = v;
+                const int i = 32 * it + (r & 3) + 8 * (r >> 2) + 4 * half;
+                mx = fmaxf(mx, (i < S) ? v : 0.0f);
+            }
+    }
+    int e = 0;
+    if (mode == SCALE_WRITE) {
+        mx = fmaxf(mx, __shfl_xor(mx, 32));
+        e = scale_exponent(mx);
+        if (half == 0) {
+            as_global(op->scale)[c0 + col] = e;
+            if (cumulative != nullptr && e != 0) atomicAdd(cumulative + c0 + col, e);
+        }
+    } else if (mode == SCALE_READ) {
+        e = as_global(op->scale)[c0 + col];
+    }
+    MBAMD_AS_GLOBAL float* __restrict__ dst = as_global(op->dst) + c0 + col;
+#pragma unroll
+    for (int k = 0; k < KC; ++k)
+#pragma unroll
+        for (int it = 0; it < NT; ++it)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int i = 32 * it + (r & 3) + 8 * (r >> 2) + 4 * half;
+                if (i < S) {
+                    const float v = out[k][it][r];
+                    dst[((size_t) k * S + i) * Ppad] = (mode != SCALE_NONE) ? scale_pow2(v, -e) : v;
+                }
+            }
+}
+
+}  // namespace mbamd
+#endif

@@ -103,3 +103,31 @@ def test_error_codes(emu):
     with pytest.raises(bg.BeagleError):
         bg.BeagleInstance(emu, 2, 4, 2, 65, 10, 1, 2, 4, 2)                         # > 64 states
     inst.finalize()
+
+
+@pytest.mark.parametrize("waves", [1, 2, 4, 8])
+@pytest.mark.parametrize("slots", [2, 3, 16])
+@pytest.mark.parametrize("reverse", [False, True])
+def test_walk_schedule(emu, oracle, monkeypatch, waves, slots, reverse):
+    """The W-wave step schedule + LDS slot allocation of the tree-walk path (host logic): the result is
+    bit-identical for every W / slot budget / intra-step order, because each node's arithmetic does not
+    depend on where its inputs were staged."""
+    div = synthetic_division("gtr", 90, 130, seed=61, tree_seed=62, p_gap=0.03)
+    monkeypatch.setenv("MBAMD_WALK_WAVES", "1")
+    base = ec.engine_lnl(emu, div)
+    monkeypatch.setenv("MBAMD_WALK_WAVES", str(waves))
+    monkeypatch.setenv("MBAMD_MAX_LDS_SLOTS", str(slots))
+    if reverse:
+        monkeypatch.setenv("MBAMD_EMU_REVERSE_STEP", "1")
+    assert ec.engine_lnl(emu, div) == base
+    bd = lk.BeagleDivision(div, emu)
+    bd.LogLike(0)
+    bd.AcceptMove(0)
+    t = div.tree
+    t.length[3] *= 2.0
+    bd.TouchBranch(0, 3)
+    got = bd.LogLike(0)
+    bd.finalize()
+    want = oracle.tree_loglike(div, use_shortcuts=False)
+    t.length[3] /= 2.0
+    assert abs(got - want) / abs(want) < ec.REL_FP64

@@ -19,12 +19,5 @@ if [[ "$WHAT" == all || "$WHAT" == bench ]]; then
   done
 fi
 if [[ "$WHAT" == all || "$WHAT" == prof ]]; then
-  for c in c2 c3 c5; do
-    rm -rf $OUT/prof_$c
-    (cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats -d $OLDPWD/$OUT/prof_$c -o $c -- python $OLDPWD/bench.py --config $c --steps 20 --warmup 3 --no-cpu-baseline > $OLDPWD/$OUT/prof_$c.log 2>&1); echo "rocprof $c exit $?"
-    find $OUT/prof_$c -name "*kernel_stats*" | head -2
-    f=$(find $OUT/prof_$c -name "*kernel_stats.csv" | head -1); [[ -n "$f" ]] && head -12 "$f"
-    # keep only the summaries (the per-dispatch trace can be large)
-    find $OUT/prof_$c -name "*kernel_trace.csv" -size +8M -delete
-  done
+  for c in c2 c3 c5; do bash tools/prof_one.sh $c; done
 fi
