@@ -284,6 +284,9 @@ BEAGLE_DLLEXPORT int mbamdSetKernelPath(int instance, int path);
 /* Calculate*LogLikelihoods without the device->host copy: leaves the sum on the device and returns
  * immediately; mbamdFetchLogLikelihood blocks and returns it (same error convention). */
 BEAGLE_DLLEXPORT int mbamdSetDeferredResult(int instance, int enable);
+/* timing experiments only: per-step clock stamps of workgroup 0 of the tree-walk kernel (needs MBAMD_WALK_TRACE
+ * in the environment when the instance is created); out: [steps][8][3] 64-bit stamps */
+BEAGLE_DLLEXPORT int mbamdWalkTrace(int instance, long long* out, int maxSteps, int* outSteps, int* outWaves);
 BEAGLE_DLLEXPORT int mbamdFetchLogLikelihood(int instance, double* outSumLogLikelihood);
 
 #ifdef __cplusplus

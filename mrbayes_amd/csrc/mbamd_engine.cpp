@@ -76,7 +76,8 @@ struct Instance {
     bool mfma = false;               // general-state path on the matrix cores (mbamd_kernels_mfma.h)
     int walkWaves = 1, walkSlots = 16;   // tree-walk kernel: waves per pattern block, LDS slots per workgroup
     int lastWalkSteps = 0, lastWalkSlots = 0;
-    int walkAblate = 0;              // MBAMD_WALK_ABLATE: timing experiments only (results are wrong when set)
+    long long* d_trace = nullptr;    // MBAMD_WALK_TRACE: per-step clock stamps of workgroup 0 (timing experiments)
+
     int NT = 0, T = 0;               // MFMA packing: i-tiles of 32 rows, j-pairs
     long flags = 0;
     size_t partialsFloats = 0, matrixFloats = 0, eigenDoubles = 0;
@@ -283,7 +284,7 @@ int Instance::create(int tipCount_, int partialsBufferCount, int compactBufferCo
         const size_t nb = (size_t) Ppad / 64;
         geom.pstride = (unsigned long) nBuffers * K * 64;
         geom.tstride = (unsigned) nBuffers * 64;
-        geom.sstride = (unsigned) scale.size() * 64;
+        geom.sstride = (unsigned) (scale.size() + 1) * 64;     // + one scratch buffer (sink of non-rescaling operations)
         const size_t pBytes = nb * geom.pstride * 16, tBytes = nb * geom.tstride, sBytes = nb * geom.sstride * 4;
         HIP_TRY(hipMalloc(&arenaPartials, pBytes));
         HIP_TRY(hipMalloc(&arenaTips, tBytes));
@@ -347,31 +348,21 @@ void Instance::destroy()
 }
 
 // ---------------------------------------------------------------------------------------------
-// Tree-walk geometry: W waves per 64-pattern workgroup and the number of LDS slots (K KiB each) it may
-// use, chosen so that every workgroup of the grid is resident at once when the chip allows it.
+// Tree-walk geometry: W compute waves (+1 writer wave) per 64-pattern workgroup and the number of LDS
+// slots it may use, chosen so that every workgroup of the grid is resident at once when the chip allows it.
 int Instance::configureWalk()
 {
-#if defined(MBAMD_HOST_EMU)
-    walkWaves = 4;
-    walkSlots = std::min(64, (64 * 1024) / (K * 1024));
-    if (const char* e = std::getenv("MBAMD_WALK_WAVES")) {
-        const int w = std::atoi(e);
-        if (w == 1 || w == 2 || w == 4 || w == 8) walkWaves = w;
-    }
-#else
+    int total = 4;                                     // waves per workgroup, writer included
+    int ldsBudget = 64 * 1024;
+#if !defined(MBAMD_HOST_EMU)
     int numCU = 256;
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0) numCU = prop.multiProcessorCount;
     const int wgs = Ppad / 64;
     const int perCU = (wgs + numCU - 1) / numCU;       // workgroups a CU must host for full residency
     const int resident = std::max(1, std::min(perCU, 4));
-    walkWaves = perCU >= 8 ? 2 : (perCU >= 4 ? 4 : 8);
-    const int ldsBudget = (160 * 1024) / resident - 512;
-    walkSlots = std::max(2, std::min(64, ldsBudget / (K * 1024)));
-    if (const char* e = std::getenv("MBAMD_WALK_WAVES")) {
-        const int w = std::atoi(e);
-        if (w == 1 || w == 2 || w == 4 || w == 8) walkWaves = w;
-    }
+    total = perCU >= 8 ? 2 : (perCU >= 3 ? 4 : 8);    // keep waves per CU <= 16 (VGPR budget of 128)
+    ldsBudget = (160 * 1024) / resident - 512;
     hipError_t err = hipSuccess;
     const int maxLds = 160 * 1024;
     switch (K) {
@@ -384,11 +375,21 @@ int Instance::configureWalk()
     }
     if (err != hipSuccess) {                          // stay within the default 64 KiB
         (void) hipGetLastError();
-        walkSlots = std::min(walkSlots, (64 * 1024) / (K * 1024));
+        ldsBudget = std::min(ldsBudget, 64 * 1024);
     }
 #endif
-    if (const char* ab = std::getenv("MBAMD_WALK_ABLATE")) walkAblate = std::atoi(ab);
-    if (const char* dbg = std::getenv("MBAMD_MAX_LDS_SLOTS")) walkSlots = std::max(1, std::min(walkSlots, std::atoi(dbg)));
+    if (const char* e = std::getenv("MBAMD_WALK_WAVES")) {
+        const int w = std::atoi(e);
+        if (w == 2 || w == 4 || w == 8) total = w;
+    }
+    if (std::getenv("MBAMD_WALK_TRACE") && !d_trace) {
+        HIP_TRY(hipMalloc(&d_trace, (size_t) 4096 * 8 * 3 * sizeof(long long)));
+        HIP_TRY(hipMemset(d_trace, 0, (size_t) 4096 * 8 * 3 * sizeof(long long)));
+    }
+    walkWaves = total - 1;
+    const int fixedUnits = walk_lds_units(K, walkWaves, 0);
+    walkSlots = std::max(2, std::min(64, (ldsBudget / 16 - fixedUnits) / walk_slot_units(K)));
+    if (const char* dbg = std::getenv("MBAMD_MAX_LDS_SLOTS")) walkSlots = std::max(2, std::min(walkSlots, std::atoi(dbg)));
     return BEAGLE_SUCCESS;
 }
 
@@ -667,9 +668,16 @@ int Instance::timedRun(const Plan& plan, int32_t* cum)
 }
 
 // Tree-walk path.  The operation list becomes a schedule of steps of up to W mutually independent
-// operations (one per wave of the workgroup that owns a 64-pattern block); every freshly produced
-// partial that is consumed later in the list gets an LDS slot (Belady eviction when the slots run
-// out), so the kernel re-reads children from LDS, never from HBM.
+// operations (one per compute wave of the workgroup that owns a 64-pattern block).  Scheduling and LDS
+// slot allocation happen in one pass over the steps, because they constrain each other:
+//   * every result occupies a slot from the step that produces it (p) at least until the writer wave has
+//     copied it to HBM (during step p+1), and until its last consumer has read it;
+//   * a slot released in step s can be overwritten from step s+1 on -- or in step s by the very operation
+//     that consumed it, if nobody else (another consumer, the writer) still reads it;
+//   * when no slot is free the resident value needed farthest in the future is evicted (Belady on list
+//     position); its consumers re-read it from HBM (CHILD_RELOAD), which is legal from step p+2 on, after
+//     the writer drained its stores (MBAMD_OP_DRAIN on step q-2 for a re-read in step q);
+//   * an operation that can get neither its inputs nor a slot in this step simply waits for a later one.
 int Instance::buildWalk(Plan& plan, std::vector<PartialsOp>& dev, const std::vector<int>& dstIdx,
                         const std::vector<int>& c1Idx, const std::vector<int>& c2Idx)
 {
@@ -677,10 +685,9 @@ int Instance::buildWalk(Plan& plan, std::vector<PartialsOp>& dev, const std::vec
     int W = walkWaves;
     const int maxSlots = walkSlots;
 
-    // ---- dependencies ------------------------------------------------------------------------
-    // producer[o][s]: index of the operation of this list that produces child s of op o (or -1);
-    // a list with write-after-read / write-after-write hazards on buffer indices (never produced
-    // by MrBayes) is executed strictly in list order by a single wave.
+    // ---- dependencies: prodN[o] = operation of this list producing child N of o (or -1).  A list with
+    // write-after-read / write-after-write hazards on buffer indices (never produced by MrBayes) is
+    // executed strictly in list order by a single compute wave.
     std::vector<int> prod1(n, -1), prod2(n, -1);
     {
         std::vector<int> lastWriter(nBuffers, -1);
@@ -696,153 +703,142 @@ int Instance::buildWalk(Plan& plan, std::vector<PartialsOp>& dev, const std::vec
         }
         if (hazard) W = 1;
     }
+    W = std::max(1, std::min(W, maxSlots / 2));
     std::vector<std::vector<int>> consumers(n);
-    std::vector<int> indeg(n, 0);
+    std::vector<int> indeg(n, 0), pendingReads(n, 0);
     for (int o = 0; o < n; ++o) {
         if (prod1[o] >= 0) { consumers[prod1[o]].push_back(o); indeg[o]++; }
         if (prod2[o] >= 0 && prod2[o] != prod1[o]) { consumers[prod2[o]].push_back(o); indeg[o]++; }
     }
-
-    // ---- list scheduling: lowest list position first (keeps the walk depth-first, hence few live values)
-    std::vector<int> stepOf(n, -1);
-    std::vector<std::vector<int>> steps;
-    if (W == 1) {
-        steps.resize(n);
-        for (int o = 0; o < n; ++o) { steps[o].push_back(o); stepOf[o] = o; }
-    } else {
-        std::vector<int> ready, next;
-        for (int o = 0; o < n; ++o) if (indeg[o] == 0) ready.push_back(o);
-        int live = 0;                                   // produced values still waiting for a consumer
-        int done = 0;
-        while (done < n) {
-            std::sort(ready.begin(), ready.end());
-            // under LDS pressure prefer operations that retire live values (children produced in this list)
-            if (live + W > maxSlots)
-                std::stable_sort(ready.begin(), ready.end(), [&](int a, int b) {
-                    const int ra = (prod1[a] >= 0) + (prod2[a] >= 0), rb = (prod1[b] >= 0) + (prod2[b] >= 0);
-                    return ra > rb;
-                });
-            const int take = std::min<int>(W, (int) ready.size());
-            std::vector<int> cur(ready.begin(), ready.begin() + take);
-            ready.erase(ready.begin(), ready.begin() + take);
-            const int sidx = (int) steps.size();
-            for (int o : cur) {
-                stepOf[o] = sidx;
-                live -= (prod1[o] >= 0) + (prod2[o] >= 0 && prod2[o] != prod1[o]);
-                if (!consumers[o].empty()) live += 1;
-            }
-            for (int o : cur)
-                for (int q : consumers[o])
-                    if (--indeg[q] == 0) ready.push_back(q);
-            done += take;
-            steps.push_back(std::move(cur));
-        }
-    }
-    const int nsteps = (int) steps.size();
-
-    // ---- LDS slots --------------------------------------------------------------------------------
-    // value of op o lives from stepOf[o] to its last consumer's step; slots freed in step s are
-    // reusable from step s+1 (or, within step s, by the very operation that consumed them).
-    std::vector<int> slotOfOp(n, -1), lastUse(n, -1);
-    for (int o = 0; o < n; ++o)
-        for (int q : consumers[o]) lastUse[o] = std::max(lastUse[o], stepOf[q]);
-    auto nextUseAfter = [&](int o, int s) {             // earliest consumer step > s
+    for (int o = 0; o < n; ++o) pendingReads[o] = (int) consumers[o].size();
+    auto nextUse = [&](int o) {                           // list position of the earliest unscheduled consumer
         int best = 1 << 30;
-        for (int q : consumers[o]) if (stepOf[q] > s) best = std::min(best, stepOf[q]);
+        for (int q : consumers[o]) best = std::min(best, q);   // (scheduled consumers were removed, see below)
         return best;
     };
-    std::vector<int> slotHolder(maxSlots, -1);            // op whose value occupies the slot
-    std::vector<int> slotFreeFrom(maxSlots, 0);           // first step in which the slot may be overwritten
-    std::vector<char> drainBefore(nsteps + 1, 0);         // step s must start with every wave's stores drained
-    int slotsUsed = 0;
-    for (int s = 0; s < nsteps; ++s) {
-        // reads
-        for (int o : steps[s]) {
-            PartialsOp& d = dev[o];
+
+    std::vector<int> stepOf(n, -1), slotOf(n, -1);
+    std::vector<int> slotHolder(maxSlots, -1), slotFreeFrom(maxSlots, 0);
+    std::vector<std::vector<int>> steps;
+    std::vector<char> drainBefore;                        // step q re-reads a value from HBM
+    std::vector<int> ready;
+    for (int o = 0; o < n; ++o) if (indeg[o] == 0) ready.push_back(o);
+    int slotsUsed = 0, done = 0;
+    const bool inOrder = (W == 1 && walkWaves != 1) || std::getenv("MBAMD_WALK_IN_ORDER") != nullptr;
+
+    for (int s = 0; done < n; ++s) {
+        if (s > 4 * n + 16) return fail(BEAGLE_ERROR_GENERAL, "tree-walk scheduler made no progress");
+        std::sort(ready.begin(), ready.end());
+        int live = 0;
+        for (int t = 0; t < maxSlots; ++t) live += slotHolder[t] >= 0;
+        if (!inOrder && live + 2 * W > maxSlots)            // under LDS pressure prefer operations that retire values
+            std::stable_sort(ready.begin(), ready.end(), [&](int x, int y) {
+                const int rx = (prod1[x] >= 0 && slotOf[prod1[x]] >= 0) + (prod2[x] >= 0 && slotOf[prod2[x]] >= 0);
+                const int ry = (prod1[y] >= 0 && slotOf[prod1[y]] >= 0) + (prod2[y] >= 0 && slotOf[prod2[y]] >= 0);
+                return rx > ry;
+            });
+        std::vector<int> chosen;
+        std::vector<char> readThisStep(n, 0);              // values read by operations already placed in this step
+        bool needDrain = false;
+        for (size_t ri = 0; ri < ready.size() && (int) chosen.size() < W; ++ri) {
+            const int o = ready[ri];
+            if (inOrder && o != done) break;
+            PartialsOp d = dev[o];
             const int pr[2] = {prod1[o], prod2[o]};
             uint8_t* kind[2] = {&d.c1_kind, &d.c2_kind};
             uint8_t* slot[2] = {&d.c1_slot, &d.c2_slot};
-            for (int t = 0; t < 2; ++t) {
+            bool ok = true, reload = false;
+            for (int t = 0; t < 2 && ok; ++t) {
                 if (*kind[t] == CHILD_STATES || pr[t] < 0) continue;
-                const int sl = slotOfOp[pr[t]];
-                if (sl >= 0) { *kind[t] = CHILD_LDS; *slot[t] = (uint8_t) sl; }
-                else         { *kind[t] = CHILD_RELOAD; drainBefore[s] = 1; }
+                if (slotOf[pr[t]] >= 0) { *kind[t] = CHILD_LDS; *slot[t] = (uint8_t) slotOf[pr[t]]; }
+                else if (stepOf[pr[t]] <= s - 2) { *kind[t] = CHILD_RELOAD; reload = true; }
+                else ok = false;                              // evicted too recently: its store is not drained yet
             }
-        }
-        // release the slots of values consumed for the last time in this step
-        for (int o : steps[s]) {
-            const int pr[2] = {prod1[o], prod2[o]};
-            for (int t = 0; t < 2; ++t) {
-                if (pr[t] < 0) continue;
-                const int sl = slotOfOp[pr[t]];
-                if (sl >= 0 && lastUse[pr[t]] <= s && slotHolder[sl] == pr[t]) {
-                    slotHolder[sl] = -1;
-                    slotFreeFrom[sl] = s + 1;
-                    slotOfOp[pr[t]] = -1;
-                }
-            }
-        }
-        // writes
-        for (int o : steps[s]) {
-            if (consumers[o].empty()) continue;
-            PartialsOp& d = dev[o];
-            int sl = -1;
-            // a slot this very operation just released may be reused at once (same lanes read, then write)
-            // -- provided no other operation of this step reads that value too
-            auto soleReader = [&](int producer) {
-                int cnt = 0;
-                for (int q : consumers[producer]) cnt += stepOf[q] == s;
-                return cnt == 1;
+            if (!ok) continue;
+            // ---- destination slot
+            auto lastReaderIsMe = [&](int producer) {         // o is the only remaining consumer, nobody else reads it now
+                return producer >= 0 && pendingReads[producer] == 1 && !readThisStep[producer] && stepOf[producer] <= s - 2;
             };
-            if (d.c1_kind == CHILD_LDS && slotHolder[d.c1_slot] < 0 && slotFreeFrom[d.c1_slot] == s + 1 &&
-                soleReader(prod1[o])) sl = d.c1_slot;
-            else if (d.c2_kind == CHILD_LDS && slotHolder[d.c2_slot] < 0 && slotFreeFrom[d.c2_slot] == s + 1 &&
-                     soleReader(prod2[o])) sl = d.c2_slot;
-            if (sl < 0)
-                for (int t = 0; t < maxSlots; ++t)
-                    if (slotHolder[t] < 0 && slotFreeFrom[t] <= s) { sl = t; break; }
-            if (sl < 0) {                                 // evict the resident value needed farthest in the future
+            int sl = -1;
+            for (int t = 0; t < maxSlots && sl < 0; ++t)
+                if (slotHolder[t] < 0 && slotFreeFrom[t] <= s) sl = t;
+            if (sl < 0 && d.c1_kind == CHILD_LDS && lastReaderIsMe(pr[0])) sl = d.c1_slot;
+            if (sl < 0 && d.c2_kind == CHILD_LDS && pr[1] != pr[0] && lastReaderIsMe(pr[1])) sl = d.c2_slot;
+            if (sl < 0) {                                     // evict
                 int far = -1, farUse = -1;
                 for (int t = 0; t < maxSlots; ++t) {
                     const int h = slotHolder[t];
-                    if (h < 0 || stepOf[h] >= s) continue;               // free-later slot / written in this step
-                    bool readNow = false;                                   // still read by an op of this step?
-                    for (int q : consumers[h]) readNow |= stepOf[q] == s;
-                    if (readNow) continue;
-                    const int u = nextUseAfter(h, s);
+                    if (h < 0 || stepOf[h] > s - 2 || readThisStep[h] || h == pr[0] || h == pr[1]) continue;
+                    const int u = nextUse(h);
                     if (u > farUse) { farUse = u; far = t; }
                 }
-                if (far >= 0 && farUse > nextUseAfter(o, s)) {
-                    slotOfOp[slotHolder[far]] = -1;
-                    slotHolder[far] = -1;
-                    sl = far;
+                if (far >= 0) { slotOf[slotHolder[far]] = -1; slotHolder[far] = -1; sl = far; }
+            }
+            if (sl < 0) continue;                             // no room in this step
+            // ---- commit
+            for (int t = 0; t < 2; ++t) {
+                if (pr[t] < 0 || (t == 1 && pr[1] == pr[0])) continue;
+                readThisStep[pr[t]] = 1;
+                auto& cs = consumers[pr[t]];
+                cs.erase(std::find(cs.begin(), cs.end(), o));
+                if (--pendingReads[pr[t]] == 0 && slotOf[pr[t]] >= 0 && slotOf[pr[t]] != sl) {
+                    const int ps = slotOf[pr[t]];             // last consumer: the slot is free from the next step on
+                    slotHolder[ps] = -1;                       // (the writer copied it in step stepOf+1 <= s)
+                    slotFreeFrom[ps] = s + 1;
+                    slotOf[pr[t]] = -1;
+                } else if (pendingReads[pr[t]] == 0 && slotOf[pr[t]] == sl) {
+                    slotOf[pr[t]] = -1;                        // taken over by this operation's own result
                 }
             }
-            if (sl >= 0) {
-                slotHolder[sl] = o;
-                slotOfOp[o] = sl;
-                d.dst_slot = (uint8_t) sl;
-                slotsUsed = std::max(slotsUsed, sl + 1);
-            }
+            d.dst_slot = (uint8_t) sl;
+            d.flags = 0;
+            if (d.c1_kind == CHILD_PARTIALS || d.c1_kind == CHILD_RELOAD || d.c2_kind == CHILD_PARTIALS ||
+                d.c2_kind == CHILD_RELOAD || d.scale_mode == SCALE_READ)
+                d.flags |= MBAMD_OP_SLOW;
+            if (d.scale_mode == SCALE_NONE) d.scale = arenaScale + scale.size() * 64;     // scratch sink
+            dev[o] = d;
+            slotHolder[sl] = o;
+            slotOf[o] = sl;
+            stepOf[o] = s;
+            slotsUsed = std::max(slotsUsed, sl + 1);
+            needDrain |= reload;
+            chosen.push_back(o);
         }
+        // values nobody in this list consumes only wait for the writer: free from step s+2 on
+        for (int o : chosen)
+            if (pendingReads[o] == 0) { slotFreeFrom[slotOf[o]] = s + 2; slotHolder[slotOf[o]] = -1; slotOf[o] = -1; }
+        for (int o : chosen) {
+            ready.erase(std::find(ready.begin(), ready.end(), o));
+            // consumers were pruned from `consumers[]` as they got scheduled; walk the static relation instead
+        }
+        steps.push_back(chosen);
+        drainBefore.push_back(needDrain ? 1 : 0);
+        done += (int) chosen.size();
+        for (int o : chosen)
+            for (int q = o + 1; q < n; ++q)
+                if ((prod1[q] == o || prod2[q] == o) && --indeg[q] == 0) ready.push_back(q);
     }
+    const int nsteps = (int) steps.size();
 
-    // ---- device table [nsteps][W] ----------------------------------------------------------------------
-    // (+4 empty rows: the kernel's prefetch pipeline reads that far ahead; empty entries carry valid
+    // ---- device table [nsteps + 5][W] -----------------------------------------------------------------
+    // (+5 empty rows: the kernel's prefetch pipeline reads that far ahead; empty entries carry valid
     //  dummy pointers because their matrix rows / tip bytes are requested before `dst` is looked at)
-    std::vector<PartialsOp> table((size_t) (nsteps + 4) * W);
+    std::vector<PartialsOp> table((size_t) (nsteps + 5) * W);
     std::memset(table.data(), 0, table.size() * sizeof(PartialsOp));
-    for (int s = 0; s < nsteps + 4; ++s) {
-        const uint8_t fl = (s + 1 < nsteps && drainBefore[s + 1]) ? MBAMD_OP_DRAIN : 0;
+    for (int s = 0; s < nsteps + 5; ++s) {
+        const uint8_t fl = (s + 2 < nsteps && drainBefore[s + 2]) ? MBAMD_OP_DRAIN : 0;
         for (int w = 0; w < W; ++w) {
             PartialsOp& e = table[(size_t) s * W + w];
-            if (s < nsteps && w < (int) steps[s].size()) e = dev[steps[s][w]];
-            else {
+            if (s < nsteps && w < (int) steps[s].size()) {
+                e = dev[steps[s][w]];
+            } else {                                  // empty entry: everything the prefetch touches is readable
                 e.c1_slot = e.c2_slot = e.dst_slot = MBAMD_NO_SLOT;
                 e.c1_kind = e.c2_kind = CHILD_PARTIALS;
+                e.c1 = e.c2 = arenaTips;
                 e.m1 = e.m2 = matrices;
+                e.flags = 0;
             }
-            e.flags = fl;
+            e.flags |= fl;
         }
     }
     lastWalkSteps = nsteps;
@@ -856,18 +852,17 @@ int Instance::buildWalk(Plan& plan, std::vector<PartialsOp>& dev, const std::vec
 int Instance::runWalk(const Plan& plan, int32_t* cum)
 {
     const int W = plan.W, nsteps = plan.nsteps;
-    // value slots (K KiB each) + per-wave matrix staging (8K rows of 16 bytes)
-    const size_t lds = (size_t) std::max(1, plan.slotsUsed) * K * 1024 + (size_t) W * K * 128;
+    const size_t lds = (size_t) walk_lds_units(K, W, std::max(1, plan.slotsUsed)) * 16;
     const unsigned grid = (unsigned) (Ppad / 64);
 #if defined(MBAMD_HOST_EMU)
     const int walkThreads = 64;
     const int walkArgW = std::getenv("MBAMD_EMU_REVERSE_STEP") ? -W : W;
 #else
-    const int walkThreads = W * 64, walkArgW = W;
+    const int walkThreads = (W + 1) * 64, walkArgW = W;       // W compute waves + the writer wave
 #endif
     switch (K) {
 #define MBAMD_WALK_CASE(KK) \
-    case KK: MBAMD_LAUNCH(k_walk_s4<KK>, grid, walkThreads, lds, stream, (const PartialsOp*) plan.d_table, nsteps, walkArgW, geom, cum, walkAblate); break;
+    case KK: MBAMD_LAUNCH(k_walk_s4<KK>, grid, walkThreads, lds, stream, (const PartialsOp*) plan.d_table, nsteps, walkArgW, geom, cum, d_trace); break;
         MBAMD_WALK_CASE(1) MBAMD_WALK_CASE(2) MBAMD_WALK_CASE(3) MBAMD_WALK_CASE(4)
         MBAMD_WALK_CASE(5) MBAMD_WALK_CASE(6) MBAMD_WALK_CASE(7) MBAMD_WALK_CASE(8)
 #undef MBAMD_WALK_CASE
@@ -1424,6 +1419,17 @@ int mbamdSetKernelPath(int instance, int path)
     GET_INSTANCE(instance);
     if (path < 0 || path > 3) return fail(BEAGLE_ERROR_OUT_OF_RANGE, "mbamdSetKernelPath");
     in->path = path;
+    return BEAGLE_SUCCESS;
+}
+int mbamdWalkTrace(int instance, long long* out, int maxSteps, int* outSteps, int* outWaves)
+{
+    GET_INSTANCE(instance);
+    if (!in->d_trace) return fail(BEAGLE_ERROR_GENERAL, "set MBAMD_WALK_TRACE before creating the instance");
+    HIP_TRY(hipStreamSynchronize(in->stream));
+    const int n = std::min(maxSteps, std::min(4096, in->lastWalkSteps));
+    HIP_TRY(hipMemcpy(out, in->d_trace, (size_t) n * 8 * 3 * sizeof(long long), hipMemcpyDeviceToHost));
+    if (outSteps) *outSteps = n;
+    if (outWaves) *outWaves = in->walkWaves + 1;
     return BEAGLE_SUCCESS;
 }
 int mbamdSetDeferredResult(int instance, int enable)

@@ -191,286 +191,9 @@ __device__ __forceinline__ f4 mat4_mul(const Mat4& M, f4 v)
     return r;
 }
 
-// a float4 this lane itself stored earlier in the same launch: bypass the (non-coherent) vector L1
-__device__ __forceinline__ f4 load_own_store(const f4* p)
-{
-#if defined(MBAMD_HOST_EMU)
-    return *p;
-#else
-    const MBAMD_AS_GLOBAL float* f = as_global(reinterpret_cast<const float*>(p));
-    f4 r;
-    r.x = __hip_atomic_load(f + 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    r.y = __hip_atomic_load(f + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    r.z = __hip_atomic_load(f + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    r.w = __hip_atomic_load(f + 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    return r;
-#endif
-}
-
-// ---------------------------------------------------------------------------------------------
-// 4-state tree-walk kernel.
-//
-// One workgroup (W waves, W = blockDim.x / 64) owns 64 site patterns for the whole operation list:
-// lane = pattern, all K categories in registers.  Site patterns are independent through the entire
-// pruning recursion, so the workgroup walks the tree by itself -- no inter-workgroup dependency,
-// one launch per beagleUpdatePartials instead of one per tree level.  The host turns the list into
-// a schedule of steps: step s holds up to W mutually independent operations (one per wave) whose
-// inputs were produced in earlier steps; a workgroup barrier separates steps.  A freshly computed
-// node is written to HBM (it must persist for later partial updates) AND kept in an LDS slot
-// chosen by the host (Belady eviction), so its parent reads it back from LDS: HBM sees each
-// interior partial exactly once, as streaming 1 KiB-per-instruction stores, and never re-reads
-// it.  Transition matrices are wave-uniform and arrive through scalar loads as SGPR operands;
-// the per-pattern max-rescale (the reference's separate CondLikeScaler pass) and the cumulative
-// scaler update are fused in.  Several waves per SIMD hide the scalar-load / tip-load latency of
-// a step behind the arithmetic of the others.
-//
-// The step barrier only orders LDS traffic (s_waitcnt lgkmcnt(0) + s_barrier): global stores stay
-// in flight across steps.  Only when a value had to be evicted from LDS and is re-read from memory
-// (CHILD_RELOAD) does the host flag the preceding step OP_DRAIN so every wave waits for its stores
-// first; the re-read bypasses the vector L1.
-// ---------------------------------------------------------------------------------------------
-#define MBAMD_OP_DRAIN 1      // PartialsOp::flags: wait for this wave's global stores before the step barrier
-
-__device__ __forceinline__ void walk_step_barrier(bool drain)
-{
-#if !defined(MBAMD_HOST_EMU)
-    if (drain) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-    asm volatile("" ::: "memory");
-#else
-    (void) drain;
-#endif
-}
-
-// the fields of a PartialsOp as the walk kernel holds them in (scalar) registers
-struct WalkFields {
-    float* dst;
-    const void *c1, *c2;
-    const float *m1, *m2;
-    int32_t* scale;
-    int c1_kind, c2_kind, c1_slot, c2_slot, dst_slot, scale_mode, flags;
-};
-__device__ __forceinline__ WalkFields walk_fields(const PartialsOp* p)
-{
-    WalkFields f;
-    f.dst = p->dst; f.c1 = p->c1; f.c2 = p->c2; f.m1 = p->m1; f.m2 = p->m2; f.scale = p->scale;
-    f.c1_kind = p->c1_kind; f.c2_kind = p->c2_kind; f.c1_slot = p->c1_slot; f.c2_slot = p->c2_slot;
-    f.dst_slot = p->dst_slot; f.scale_mode = p->scale_mode; f.flags = p->flags;
-    return f;
-}
-
-// What one operation needs from memory besides LDS-resident children: its 2K transposed 4x4
-// matrices (8K rows of 16 bytes, fetched by lanes 0..8K-1 with ONE dwordx4 load) and the state
-// codes of compact tip children.  Requested one step ahead of use, so that the loads are older
-// than the previous step's stores in the (in-order) vmcnt queue and never wait behind them; they
-// cost 6 VGPRs while in flight.  At use the matrix rows go through a per-wave 128K-byte LDS
-// staging area from which every lane picks row (lane & 3) of each matrix (see Mat4).
-struct WalkInputs {
-    f4 mrow;            // lane l < 4K: row l of m1's K matrices; 4K <= l < 8K: row l-4K of m2's
-    unsigned s1, s2;
-};
-template <int K>
-__device__ __forceinline__ void walk_request(const WalkFields& op, size_t toff, int lane, WalkInputs& in)
-{
-#if defined(MBAMD_HOST_EMU)
-    in.mrow = f4{0.0f, 0.0f, 0.0f, 0.0f};
-#else
-    in.mrow = f4{0.0f, 0.0f, 0.0f, 0.0f};
-    if (lane < 8 * K) {
-        const bool first = lane < 4 * K;
-        const float* base = first ? op.m1 : op.m2;
-        in.mrow = as_global(reinterpret_cast<const f4*>(base))[first ? lane : lane - 4 * K];
-    }
-#endif
-    in.s1 = (op.c1_kind == CHILD_STATES) ? (unsigned) as_global(reinterpret_cast<const uint8_t*>(op.c1))[toff] : 0u;
-    in.s2 = (op.c2_kind == CHILD_STATES) ? (unsigned) as_global(reinterpret_cast<const uint8_t*>(op.c2))[toff] : 0u;
-}
-
-// one category of a child: LDS slot, compact tip (0/1 vector from the state code), or global memory
-__device__ __forceinline__ f4 walk_child_k(const void* ptr, int kind, int slot, unsigned s, int K, int k, size_t poff,
-                                           int lane, const f4* lds)
-{
-    if (kind == CHILD_LDS) return lds[(slot * K + k) * 64 + lane];
-    if (kind == CHILD_STATES) {
-        f4 one;
-        one.x = (s == 0u || s >= 4u) ? 1.0f : 0.0f;
-        one.y = (s == 1u || s >= 4u) ? 1.0f : 0.0f;
-        one.z = (s == 2u || s >= 4u) ? 1.0f : 0.0f;
-        one.w = (s == 3u || s >= 4u) ? 1.0f : 0.0f;
-        return one;
-    }
-    // CHILD_PARTIALS, and CHILD_RELOAD: a value this workgroup stored earlier in the launch.  Its
-    // producer wave drained its stores before a step barrier (MBAMD_OP_DRAIN) and all waves of a
-    // workgroup share one vector L1, so a plain load observes it.
-    return as_global(reinterpret_cast<const f4*>(ptr))[poff + k * 64];
-}
-
-template <int K>
-__device__ __forceinline__ void walk_op(const WalkFields& op, const WalkInputs& in, f4* stage, size_t poff, size_t soff,
-                                        int lane, f4* lds, int& cum_e, int ablate = 0)
-{
-    Mat4 M1[K], M2[K];
-#if defined(MBAMD_HOST_EMU)
-    (void) stage;
-#pragma unroll
-    for (int k = 0; k < K; ++k) { M1[k] = mat4_load(op.m1 + 16 * k, lane); M2[k] = mat4_load(op.m2 + 16 * k, lane); }
-#else
-    // spread the prefetched matrix rows over the wave: 8K rows -> LDS -> row (lane & 3) of each matrix
-    if (lane < 8 * K) stage[lane] = in.mrow;
-#pragma unroll
-    for (int k = 0; k < K; ++k) {
-        M1[k].col = stage[4 * k + (lane & 3)];
-        M2[k].col = stage[4 * K + 4 * k + (lane & 3)];
-    }
-#endif
-    // children are consumed category by category (one category ahead in flight) to keep the register
-    // footprint at 128 VGPRs with the next step's inputs already resident
-    f4 out[K];
-    float mx = 0.0f;
-    f4 a = walk_child_k(op.c1, op.c1_kind, op.c1_slot, in.s1, K, 0, poff, lane, lds);
-    f4 b = walk_child_k(op.c2, op.c2_kind, op.c2_slot, in.s2, K, 0, poff, lane, lds);
-#pragma unroll
-    for (int k = 0; k < K; ++k) {
-        f4 an = a, bn = b;
-        if (k + 1 < K) {
-            an = walk_child_k(op.c1, op.c1_kind, op.c1_slot, in.s1, K, k + 1, poff, lane, lds);
-            bn = walk_child_k(op.c2, op.c2_kind, op.c2_slot, in.s2, K, k + 1, poff, lane, lds);
-        }
-        const f4 f1 = mat4_mul(M1[k], a);
-        const f4 f2 = mat4_mul(M2[k], b);
-        out[k].x = f1.x * f2.x;
-        out[k].y = f1.y * f2.y;
-        out[k].z = f1.z * f2.z;
-        out[k].w = f1.w * f2.w;
-        mx = fmaxf(mx, max4(out[k]));
-        a = an;
-        b = bn;
-    }
-
-    const int mode = op.scale_mode;
-    if (mode != SCALE_NONE) {
-        int e;
-        MBAMD_AS_GLOBAL int32_t* sc = as_global(op.scale);
-        if (mode == SCALE_WRITE) {
-            e = scale_exponent(mx);
-            sc[soff] = e;
-            cum_e += e;
-        } else {
-            e = sc[soff];
-        }
-#pragma unroll
-        for (int k = 0; k < K; ++k) {
-            out[k].x = scale_pow2(out[k].x, -e);
-            out[k].y = scale_pow2(out[k].y, -e);
-            out[k].z = scale_pow2(out[k].z, -e);
-            out[k].w = scale_pow2(out[k].w, -e);
-        }
-    }
-
-    MBAMD_AS_GLOBAL f4* __restrict__ dst = as_global(reinterpret_cast<f4*>(op.dst)) + poff;
-    if (!(ablate & 1)) {           // (timing experiments only: MBAMD_WALK_ABLATE)
-#pragma unroll
-        for (int k = 0; k < K; ++k) dst[k * 64] = out[k];     // 4K KiB contiguous per node update
-    }
-    const int ds = op.dst_slot;
-    if (ds != MBAMD_NO_SLOT && !(ablate & 2)) {
-#pragma unroll
-        for (int k = 0; k < K; ++k) lds[(ds * K + k) * 64 + lane] = out[k];
-    }
-}
-
-#if !defined(MBAMD_HOST_EMU)
-// One row of the schedule = the W descriptors of a step = 16*W dwords.  A wave fetches a row with
-// two coalesced dword loads (lane l holds dwords l and l+64; the vector L1 serves the other waves
-// of the workgroup) and later picks its own 16 dwords out of the lanes with v_readlane: the
-// descriptors travel through the vmcnt queue like every other prefetch and end up in SGPRs.
-struct WalkRow { unsigned lo, hi; };
-__device__ __forceinline__ WalkRow walk_row_request(const PartialsOp* ops, int step, int W, int lane)
-{
-    const MBAMD_AS_GLOBAL unsigned* p = as_global(reinterpret_cast<const unsigned*>(ops)) + (size_t) step * W * 16;
-    WalkRow r;
-    r.lo = p[lane < W * 16 ? lane : 0];
-    r.hi = (W > 4) ? p[64 + lane] : 0u;
-    return r;
-}
-__device__ __forceinline__ WalkFields walk_row_fields(const WalkRow& r, int wave)
-{
-    const unsigned v = (wave >= 4) ? r.hi : r.lo;
-    const int base = (wave & 3) * 16;
-    unsigned d[16];
-#pragma unroll
-    for (int i = 0; i < 16; ++i) d[i] = (unsigned) __builtin_amdgcn_readlane((int) v, base + i);
-    WalkFields f;
-    f.dst = reinterpret_cast<float*>(((unsigned long) d[1] << 32) | d[0]);
-    f.c1 = reinterpret_cast<const void*>(((unsigned long) d[3] << 32) | d[2]);
-    f.c2 = reinterpret_cast<const void*>(((unsigned long) d[5] << 32) | d[4]);
-    f.m1 = reinterpret_cast<const float*>(((unsigned long) d[7] << 32) | d[6]);
-    f.m2 = reinterpret_cast<const float*>(((unsigned long) d[9] << 32) | d[8]);
-    f.scale = reinterpret_cast<int32_t*>(((unsigned long) d[11] << 32) | d[10]);
-    const unsigned lo = d[12], hi = d[13];
-    f.c1_kind = lo & 0xFF; f.c2_kind = (lo >> 8) & 0xFF; f.c1_slot = (lo >> 16) & 0xFF; f.c2_slot = lo >> 24;
-    f.dst_slot = hi & 0xFF; f.scale_mode = (hi >> 8) & 0xFF; f.flags = (hi >> 16) & 0xFF;
-    return f;
-}
-#endif
-
-// ops: [nsteps + 4][W] (an empty entry has dst == nullptr and valid dummy matrix pointers; flags are
-// replicated over a step's entries; three empty rows pad the end for the prefetch pipeline).
-// blockDim.x == 64*W.  (Host emulation: one 64-thread block whose threads run the W entries of a
-// step one after the other -- lanes never exchange data, so that is the same computation.)
-template <int K>
-__global__ void __launch_bounds__(512, (K <= 4 ? 4 : 2))
-k_walk_s4(const PartialsOp* __restrict__ ops, int nsteps, int W, BlockGeom g, int32_t* __restrict__ cumulative, int ablate)
-{
-    const int lane = threadIdx.x & 63;
-    const size_t poff = (size_t) blockIdx.x * g.pstride + lane;     // this workgroup's block in every buffer
-    const size_t toff = (size_t) blockIdx.x * g.tstride + lane;
-    const size_t soff = (size_t) blockIdx.x * g.sstride + lane;
-    int cum_e = 0;
-#if defined(MBAMD_HOST_EMU)
-    (void) ablate;
-    f4* lds = reinterpret_cast<f4*>(mbamd_emu_dyn_lds());
-    const bool reversed = W < 0;                 // test hook: run a step's entries in the opposite order
-    if (reversed) W = -W;
-    for (int s = 0; s < nsteps; ++s)
-        for (int i = 0; i < W; ++i) {
-            const PartialsOp* op = ops + (size_t) s * W + (reversed ? W - 1 - i : i);
-            if (op->dst == nullptr) continue;
-            const WalkFields f = walk_fields(op);
-            WalkInputs in;
-            walk_request<K>(f, toff, lane, in);
-            walk_op<K>(f, in, nullptr, poff, soff, lane, lds, cum_e);
-        }
-#else
-    extern __shared__ f4 lds_all[];
-    const int wave = __builtin_amdgcn_readfirstlane((int) (threadIdx.x >> 6));
-    f4* stage = lds_all + wave * (8 * K);         // per-wave matrix staging: 8K rows of 16 bytes
-    f4* lds = lds_all + W * (8 * K);              // value slots: [slot][K][64 lanes]
-    // software pipeline: while step s computes, the inputs of step s+1 and the descriptor rows of
-    // steps s+2, s+3 are in flight
-    WalkFields cur = walk_row_fields(walk_row_request(ops, 0, W, lane), wave);
-    WalkFields nxt = walk_row_fields(walk_row_request(ops, 1, W, lane), wave);
-    WalkRow row2 = walk_row_request(ops, 2, W, lane);
-    WalkInputs in_cur;
-    walk_request<K>(cur, toff, lane, in_cur);
-    for (int s = 0; s < nsteps; ++s) {
-        WalkInputs in_nxt = in_cur;
-        if (!(ablate & 16)) walk_request<K>(nxt, toff, lane, in_nxt);
-        WalkRow row3 = row2;
-        if (!(ablate & 32)) row3 = walk_row_request(ops, s + 3, W, lane);
-        if ((ablate & 64) && blockIdx.x == 0 && threadIdx.x == 0)      // timing experiments: per-step clock trace
-            reinterpret_cast<long long*>(cumulative)[s] = (long long) __builtin_readcyclecounter();
-        if (cur.dst != nullptr && !(ablate & 4)) walk_op<K>(cur, in_cur, stage, poff, soff, lane, lds, cum_e, ablate);
-        if (!(ablate & 8)) walk_step_barrier((cur.flags & MBAMD_OP_DRAIN) != 0);
-        cur = nxt;
-        in_cur = in_nxt;
-        nxt = walk_row_fields(row2, wave);
-        row2 = row3;
-    }
-#endif
-    if (cumulative != nullptr && cum_e != 0) atomicAdd(cumulative + soff, cum_e);
-}
+}  // namespace mbamd
+#include "mbamd_walk_s4.h"
+namespace mbamd {
 
 // ---------------------------------------------------------------------------------------------
 // General state count: level-synchronous kernel.  grid = (P_pad/64, ops in this dependency level),

@@ -111,12 +111,12 @@ def test_lds_stack_eviction(gpu, oracle, monkeypatch):
     assert abs(lnl - want) / abs(want) < ec.REL_FP64
 
 
-@pytest.mark.parametrize("waves", [1, 2, 4, 8])
+@pytest.mark.parametrize("waves", [2, 4, 8])
 def test_walk_waves_agree(gpu, oracle, monkeypatch, waves):
-    """The tree-walk kernel scheduled over 1/2/4/8 waves per pattern block gives bit-identical partials
+    """The tree-walk kernel scheduled over 1/3/7 compute waves (+ the writer wave) per pattern block gives bit-identical partials
     (the arithmetic per node does not depend on which wave executes it), hence identical lnL."""
     div = synthetic_division("gtr", 150, 1000, seed=51, tree_seed=52, p_gap=0.05)
-    monkeypatch.setenv("MBAMD_WALK_WAVES", "1")
+    monkeypatch.setenv("MBAMD_WALK_WAVES", "2")
     base = ec.engine_lnl(gpu, div)
     monkeypatch.setenv("MBAMD_WALK_WAVES", str(waves))
     assert ec.engine_lnl(gpu, div) == base

@@ -105,15 +105,15 @@ def test_error_codes(emu):
     inst.finalize()
 
 
-@pytest.mark.parametrize("waves", [1, 2, 4, 8])
-@pytest.mark.parametrize("slots", [2, 3, 16])
+@pytest.mark.parametrize("waves", [2, 4, 8])
+@pytest.mark.parametrize("slots", [2, 3, 7, 16])
 @pytest.mark.parametrize("reverse", [False, True])
 def test_walk_schedule(emu, oracle, monkeypatch, waves, slots, reverse):
     """The W-wave step schedule + LDS slot allocation of the tree-walk path (host logic): the result is
     bit-identical for every W / slot budget / intra-step order, because each node's arithmetic does not
     depend on where its inputs were staged."""
     div = synthetic_division("gtr", 90, 130, seed=61, tree_seed=62, p_gap=0.03)
-    monkeypatch.setenv("MBAMD_WALK_WAVES", "1")
+    monkeypatch.setenv("MBAMD_WALK_WAVES", "2")
     base = ec.engine_lnl(emu, div)
     monkeypatch.setenv("MBAMD_WALK_WAVES", str(waves))
     monkeypatch.setenv("MBAMD_MAX_LDS_SLOTS", str(slots))
