@@ -75,6 +75,36 @@ def cpu_baseline(kind, ntaxa, seed, tree_seed, budget_patterns):
             "sample": "oracle/mb_oracle.c (scalar), same tree, first %d patterns, %d evaluations" % (npat, reps)}
 
 
+def mcmc_gen_per_s(ntaxa, npat, seed, tree_seed, nchains=1):
+    """Secondary metric: generations/s of the UNMODIFIED MrBayes (default move mix, GTR+G4) driving this engine
+    (oracle/_ref/mb_amd) next to the same binary's native CPU kernels (oracle/_ref/mb), two-point differenced
+    so that parsing / pattern compression / set-up cancel.  Only where the reference binaries were built."""
+    from mrbayes_amd import data as mbdata
+    from mrbayes_amd import tree as mbtree
+    from tools import refrun
+    if not (os.path.exists(refrun.REF_MB_AMD) and os.path.exists(refrun.REF_MB)):
+        return None
+    st = mbdata.synthetic_states(ntaxa, npat, 4, seed, 0.15, 0.0)
+    tr = mbtree.random_tree(ntaxa, tree_seed, brlen=0.05)
+    out = {"nchains": nchains, "note": "default mix: 11.5% of the moves are ParsSPR/ParsTBR, whose O(taxa x patterns) parsimony "
+           "scoring runs on the host in both builds (SURVEY 8(f) item 4); fixed_topology = branch-length and "
+           "substitution-parameter moves only (prset topologypr=fixed)"}
+    for mix, fixed in (("default_moves", False), ("fixed_topology", True)):
+        res = {}
+        for tag, binary, beagle, lo, hi in (("engine", refrun.REF_MB_AMD, "dynamic", 500, 2500),
+                                            ("reference_cpu", refrun.REF_MB, None, 20, 80)):
+            walls = []
+            for ngen in (lo, hi):
+                _, wall = refrun.run_mb(binary, refrun.mcmc_nexus(st, tr, ngen, beagle=beagle, nchains=nchains,
+                                                                  fixed_topology=fixed))
+                walls.append(wall)
+            res[tag] = (hi - lo) / max(walls[1] - walls[0], 1e-9)
+            res[tag + "_ngen"] = [lo, hi]
+        res["speedup"] = res["engine"] / res["reference_cpu"]
+        out[mix] = res
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -83,6 +113,11 @@ def main():
     ap.add_argument("--config", default="c2", choices=sorted(CONFIGS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample-patterns", type=int, default=4000)
+    ap.add_argument("--mcmc", action="store_true", help="also time whole MCMC generations of the unmodified MrBayes "
+                    "binary on this engine vs its native CPU kernels (adds minutes)")
+    ap.add_argument("--emulate", action="store_true",
+                    help="TEST ONLY: run the control flow on the CPU (host-emulation engine, gloo, tiny workload); "
+                         "the JSON line is marked invalid")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -92,14 +127,20 @@ def main():
         raise SystemExit("WORLD_SIZE=%d but --gpus %d" % (world, args.gpus))
 
     import torch
-    if not torch.cuda.is_available():
+    emulate = args.emulate
+    if not emulate and not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the engine has no CPU path")
-    torch.cuda.set_device(local_rank)
+    device = torch.device("cpu") if emulate else torch.device("cuda", local_rank)
+    if not emulate:
+        torch.cuda.set_device(local_rank)
     dist = None
     if world > 1:
         import torch.distributed as dist_
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist_.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if emulate:
+            dist_.init_process_group("gloo")
+        else:
+            dist_.init_process_group("nccl", device_id=device)
         dist = dist_
 
     from mrbayes_amd import beagle as bg
@@ -107,14 +148,20 @@ def main():
     from mrbayes_amd.division import synthetic_division
 
     kind, ntaxa, npat, seed, tree_seed, desc = CONFIGS[args.config]
+    if emulate:
+        ntaxa, npat, desc = 16, 200, "EMULATED (invalid as a measurement): " + desc
     div = synthetic_division(kind, ntaxa, npat, seed=seed, tree_seed=tree_seed,
                              golden_dir=os.path.join(ROOT, "tests", "golden"))
     if world > 1:                      # every chain has its own state: perturb the branch lengths per rank
         import random
         rng = random.Random(1000 + rank)
         div.tree.length = [l * (0.8 + 0.4 * rng.random()) for l in div.tree.length]
-    lib = bg.library()
-    bd = lk.BeagleDivision(div, lib, nchains=1, scaling=lk.MB_BEAGLE_SCALE_ALWAYS, resource=local_rank)
+    if emulate:
+        from tests.hostemu import build_emu
+        lib = bg.library(build_emu.build())
+    else:
+        lib = bg.library()
+    bd = lk.BeagleDivision(div, lib, nchains=1, scaling=lk.MB_BEAGLE_SCALE_ALWAYS, resource=0 if emulate else local_rank)
     impl = bd.inst.details.implName.decode()
     lnl0 = bd.LogLike(0)
     bd.AcceptMove(0)
@@ -122,22 +169,23 @@ def main():
     S, K, P, N = div.nstates, div.ncat * div.n_cijk_parts, div.npatterns, div.ntaxa
     units_per_step = (N - 2) * P
 
-    lnl_vec = torch.zeros(max(world, 1), dtype=torch.float64, device="cuda")
+    from mrbayes_amd import chains as mbchains
+    exchange = mbchains.ChainExchange(world, dist=dist, device=device) if dist is not None else None
 
     def step(i):
         rc, lnl = evals[i & 1].run()
-        if rc != 0 and not os.environ.get("MBAMD_WALK_ABLATE"):
+        if rc != 0:
             raise RuntimeError("evaluation failed with code %d" % rc)
-        if dist is not None:           # per-generation exchange of the chains' log-likelihoods (RCCL)
-            lnl_vec.zero_()
-            lnl_vec[rank] = lnl
-            dist.all_reduce(lnl_vec)
+        if exchange is not None:       # per-generation exchange of the chains' states (RCCL) + swap attempt
+            all_lnl, all_pr = exchange.all_states({rank: lnl})
+            exchange.attempt_swap(all_lnl, all_pr)
         return lnl
 
     def fence():
         if dist is not None:
             dist.barrier()
-        torch.cuda.synchronize()
+        if not emulate:
+            torch.cuda.synchronize()
 
     for i in range(args.warmup):
         step(i)
@@ -153,11 +201,10 @@ def main():
     kms, klaunches = bd.inst.get_kernel_timing(reset=True)
     bd.inst.kernel_timing(False)
     if dist is not None:
-        tmax = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        tmax = torch.tensor([dt], dtype=torch.float64, device=device)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
-    if not os.environ.get("MBAMD_WALK_ABLATE"):
-        assert abs(lnl - lnl0) <= 1e-9 * abs(lnl0) or world > 1, (lnl, lnl0)
+    assert abs(lnl - lnl0) <= 1e-9 * abs(lnl0), (lnl, lnl0)
 
     if rank == 0:
         ms_per_step = dt / args.steps * 1e3
@@ -183,7 +230,7 @@ def main():
             "metric": "site-pattern lnL (node-pattern conditional-likelihood) updates/sec",
             "value": value, "unit": "M updates/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32", "data": "synthetic",
+            "dtype": "f32", "data": "synthetic" if not emulate else "INVALID: emulated control-flow test",
             "config": {"workload": desc, "states": S, "categories": K, "patterns": P, "taxa": N,
                        "chains": world, "parallelism": "chain-parallel (1 chain per GPU)" if world > 1 else "1 chain",
                        "units_per_step": units_per_step, "lnL": lnl},
@@ -191,13 +238,18 @@ def main():
             "full_tree_evals_per_s": world * args.steps / dt,
             "roofline": roof,
         }
-        if not args.no_cpu_baseline and world == 1:
+        if not args.no_cpu_baseline and world == 1 and not emulate:
             try:
                 out["cpu_baseline"] = cpu_baseline(kind, ntaxa, seed, tree_seed, args.cpu_sample_patterns)
                 out["speedup_vs_cpu_baseline"] = value / out["cpu_baseline"]["value"]
             except Exception as exc:          # the baseline is a report, never a reason to lose the bench line
                 out["cpu_baseline"] = {"value": None, "unit": "M updates/s", "cores": 1, "kind": "port",
                                        "sample": "failed: %r" % (exc,)}
+        if args.mcmc and world == 1 and not emulate and kind == "gtr":
+            try:
+                out["mcmc_gen_per_s"] = mcmc_gen_per_s(ntaxa, npat, seed, tree_seed)
+            except Exception as exc:
+                out["mcmc_gen_per_s"] = {"error": repr(exc)}
         print(json.dumps(out))
     bd.finalize()
     if dist is not None:

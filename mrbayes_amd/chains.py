@@ -1,0 +1,108 @@
+"""Chain-parallel Metropolis coupling across GPUs: the N>1 path.
+
+The reference's only parallelism is "chains -> MPI ranks" (src/mcmc.c:18331-18384): every rank evaluates
+its own chains with its own likelihood calculator, and the ranks exchange a handful of doubles when a swap
+between two heated chains is attempted (AttemptSwap, src/mcmc.c:591-1140: myStateInfo = lnL, lnPrior, ...).
+Here one process drives one MI355X (one engine instance = the chains that live on that GPU) and the
+exchange runs over torch.distributed -- backend "nccl" (= RCCL over xGMI) on GPUs, "gloo" in the CPU tests.
+The per-generation exchange is ONE all-reduce of the 2*nchains vector (lnL, lnPrior): with it every rank
+holds every chain's state and evaluates the swap rule itself, with the shared swap RNG the reference also
+uses (`swapseed`), so no second message is needed to announce the outcome.
+
+Nothing here touches conditional likelihoods: chains never exchange partials.
+"""
+from __future__ import annotations
+
+import math
+from typing import Dict, List, Optional, Sequence, Tuple
+
+import numpy as np
+
+
+def temperature(chain_id: int, nchains: int, chain_temp: float = 0.1, user_temps: Optional[Sequence[float]] = None) -> float:
+    """Temperature (heat) of a chain, src/mcmc.c:18963-18977."""
+    i = chain_id % nchains
+    if user_temps is not None:
+        return float(user_temps[i])
+    return 1.0 / (1.0 + chain_temp * i)
+
+
+def chains_of_rank(nchains_total: int, world: int, rank: int) -> List[int]:
+    """Block assignment of chains to ranks, the reference's rule (src/mcmc.c:611-640): the first
+    (total % world) ranks get one chain more."""
+    base, extra = divmod(nchains_total, world)
+    lo = rank * base + min(rank, extra)
+    return list(range(lo, lo + base + (1 if rank < extra else 0)))
+
+
+class SwapRng:
+    """The reference's linear congruential generator (RandomNumber, src/utils.c:13802-13814); every rank
+    seeds it with the same `swapseed`, so all ranks draw the same swap proposals."""
+
+    def __init__(self, seed: int):
+        self.seed = int(seed)
+
+    def random(self) -> float:
+        hi, lo = divmod(self.seed, 127773)
+        test = 16807 * lo - 2836 * hi
+        self.seed = test if test > 0 else test + 2147483647
+        return self.seed / 2147483647.0
+
+
+def swap_log_ratio(lnl_a, lnpr_a, temp_a, lnl_b, lnpr_b, temp_b) -> float:
+    """lnR of exchanging the heats of chains A and B (no character reweighting), src/mcmc.c:719."""
+    return (temp_b * (lnl_a + lnpr_a) + temp_a * (lnl_b + lnpr_b)) - (temp_a * (lnl_a + lnpr_a) + temp_b * (lnl_b + lnpr_b))
+
+
+class ChainExchange:
+    """Per-generation state exchange + swap decision for `nchains` chains spread over the process group."""
+
+    def __init__(self, nchains: int, dist=None, device=None, chain_temp: float = 0.1, swap_seed: int = 12345):
+        self.nchains = nchains
+        self.dist = dist
+        self.device = device
+        self.chain_temp = chain_temp
+        self.rank = dist.get_rank() if dist is not None else 0
+        self.world = dist.get_world_size() if dist is not None else 1
+        self.local = chains_of_rank(nchains, self.world, self.rank)
+        self.chain_id = list(range(nchains))         # chainId[]: which heat each chain currently runs at
+        self.rng = SwapRng(swap_seed)
+        self.swaps_tried = 0
+        self.swaps_done = 0
+        self._buf = None
+
+    def all_states(self, lnl: Dict[int, float], lnprior: Optional[Dict[int, float]] = None) -> Tuple[np.ndarray, np.ndarray]:
+        """Every rank contributes the (lnL, lnPrior) of its own chains; everybody gets all of them."""
+        import torch
+        if self._buf is None:
+            self._buf = torch.zeros(2 * self.nchains, dtype=torch.float64, device=self.device or "cpu")
+        v = np.zeros(2 * self.nchains)
+        for c in self.local:
+            v[c] = lnl[c]
+            v[self.nchains + c] = (lnprior or {}).get(c, 0.0)
+        self._buf.copy_(torch.from_numpy(v))
+        if self.dist is not None and self.world > 1:
+            self.dist.all_reduce(self._buf)            # sum of disjoint contributions
+        out = self._buf.cpu().numpy()
+        return out[: self.nchains].copy(), out[self.nchains:].copy()
+
+    def attempt_swap(self, lnl: np.ndarray, lnprior: np.ndarray) -> Tuple[int, int, bool]:
+        """One swap attempt between two chains picked with the shared RNG (RunChain, src/mcmc.c:16941-16957,
+        then AttemptSwap's acceptance rule).  Identical on every rank."""
+        a = int(self.rng.random() * self.nchains)
+        b = int(self.rng.random() * (self.nchains - 1))
+        if b >= a:
+            b += 1
+        ta = temperature(self.chain_id[a], self.nchains, self.chain_temp)
+        tb = temperature(self.chain_id[b], self.nchains, self.chain_temp)
+        lnr = swap_log_ratio(lnl[a], lnprior[a], ta, lnl[b], lnprior[b], tb)
+        r = 0.0 if lnr < -100.0 else 1.0 if lnr > 0.0 else math.exp(lnr)
+        ok = self.rng.random() < r
+        self.swaps_tried += 1
+        if ok:
+            self.chain_id[a], self.chain_id[b] = self.chain_id[b], self.chain_id[a]
+            self.swaps_done += 1
+        return a, b, ok
+
+    def cold_chain(self) -> int:
+        return self.chain_id.index(0)

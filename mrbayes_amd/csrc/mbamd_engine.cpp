@@ -31,7 +31,31 @@
 #include "mbamd_kernels_mfma.h"
 #endif
 
+#include <chrono>
+
 namespace mbamd {
+
+// MBAMD_STATS=1: per-entry-point call counts and host wall time, printed when an instance is finalized
+struct ApiStats {
+    const char* name;
+    long calls = 0;
+    double seconds = 0.0;
+};
+static ApiStats g_stats[] = {{"beagleUpdateTransitionMatrices"}, {"beagleUpdatePartials"}, {"beagleCalculate*LogLikelihoods"},
+                             {"beagle*ScaleFactors"}, {"beagleSet*"}, {"beagleGetSiteLogLikelihoods"}, {"plan build"}};
+enum { ST_MATRICES = 0, ST_PARTIALS, ST_LNL, ST_SCALE, ST_SET, ST_SITE, ST_PLAN };
+static const bool g_statsOn = std::getenv("MBAMD_STATS") != nullptr;
+struct StatTimer {
+    int id;
+    std::chrono::steady_clock::time_point t0;
+    explicit StatTimer(int i) : id(i) { if (g_statsOn) t0 = std::chrono::steady_clock::now(); }
+    ~StatTimer()
+    {
+        if (!g_statsOn) return;
+        g_stats[id].calls++;
+        g_stats[id].seconds += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    }
+};
 
 static thread_local std::string g_last_error;
 
@@ -629,7 +653,11 @@ int Instance::updatePartials(const BeagleOperation* ops, int n, int cumIdx)
     plan->key.push_back(layoutEpoch);
     plan->hash = h;
     plan->lastUse = ++planClock;
-    int rc = s4 ? buildWalk(*plan, dev, dstIdx, c1Idx, c2Idx) : buildGeneric(*plan, dev, dstIdx, c1Idx, c2Idx);
+    int rc;
+    {
+        StatTimer st_(ST_PLAN);
+        rc = s4 ? buildWalk(*plan, dev, dstIdx, c1Idx, c2Idx) : buildGeneric(*plan, dev, dstIdx, c1Idx, c2Idx);
+    }
     if (rc) { plan->hash = 0; plan->key.clear(); return rc; }
     return timedRun(*plan, cumPtr);
 }
@@ -1200,6 +1228,12 @@ int beagleFinalizeInstance(int instance)
         in = g_instances[instance];
         g_instances[instance] = nullptr;
     }
+    if (g_statsOn) {
+        std::fprintf(stderr, "[mbamd] instance %d: plan cache %ld hits / %ld misses\n", instance, in->planHits, in->planMisses);
+        for (const ApiStats& a : g_stats)
+            std::fprintf(stderr, "[mbamd]   %-34s %9ld calls %10.3f ms total %9.2f us/call\n", a.name, a.calls,
+                         a.seconds * 1e3, a.calls ? a.seconds * 1e6 / a.calls : 0.0);
+    }
     in->destroy();
     delete in;
     return BEAGLE_SUCCESS;
@@ -1241,23 +1275,27 @@ int beagleGetPartials(int instance, int bufferIndex, int scaleIndex, double* out
 int beagleSetEigenDecomposition(int instance, int eigenIndex, const double* inEigenVectors,
                                 const double* inInverseEigenVectors, const double* inEigenValues)
 {
+    StatTimer st_(ST_SET);
     GET_INSTANCE(instance);
     return in->setEigen(eigenIndex, inEigenVectors, inInverseEigenVectors, inEigenValues);
 }
 int beagleSetStateFrequencies(int instance, int idx, const double* f)
 {
+    StatTimer st_(ST_SET);
     GET_INSTANCE(instance);
     if (idx < 0 || idx >= in->nEigen) return fail(BEAGLE_ERROR_OUT_OF_RANGE, "beagleSetStateFrequencies: index");
     return in->upload(in->d_freqs + (size_t) idx * in->S, f, sizeof(double) * in->S);
 }
 int beagleSetCategoryWeights(int instance, int idx, const double* w)
 {
+    StatTimer st_(ST_SET);
     GET_INSTANCE(instance);
     if (idx < 0 || idx >= in->nEigen) return fail(BEAGLE_ERROR_OUT_OF_RANGE, "beagleSetCategoryWeights: index");
     return in->upload(in->d_weights + (size_t) idx * in->K, w, sizeof(double) * in->K);
 }
 int beagleSetCategoryRates(int instance, const double* r)
 {
+    StatTimer st_(ST_SET);
     GET_INSTANCE(instance);
     if (in->K > MBAMD_MAX_RATES) return fail(BEAGLE_ERROR_NO_IMPLEMENTATION, "more than 16 rate categories");
     for (int k = 0; k < in->K; ++k) in->rates.r[k] = r[k];
@@ -1272,6 +1310,7 @@ int beagleUpdateTransitionMatrices(int instance, int eigenIndex, const int* prob
                                    const int* firstDerivativeIndices, const int* secondDerivativeIndices,
                                    const double* edgeLengths, int count)
 {
+    StatTimer st_(ST_MATRICES);
     GET_INSTANCE(instance);
     if (firstDerivativeIndices || secondDerivativeIndices)
         return fail(BEAGLE_ERROR_NO_IMPLEMENTATION, "beagleUpdateTransitionMatrices: derivatives");
@@ -1290,6 +1329,7 @@ int beagleGetTransitionMatrix(int instance, int matrixIndex, double* outMatrix)
 }
 int beagleUpdatePartials(int instance, const BeagleOperation* operations, int operationCount, int cumulativeScaleIndex)
 {
+    StatTimer st_(ST_PARTIALS);
     GET_INSTANCE(instance);
     return in->updatePartials(operations, operationCount, cumulativeScaleIndex);
 }
@@ -1302,16 +1342,19 @@ int beagleWaitForPartials(int instance, const int* destinationPartials, int dest
 }
 int beagleAccumulateScaleFactors(int instance, const int* scaleIndices, int count, int cumulativeScaleIndex)
 {
+    StatTimer st_(ST_SCALE);
     GET_INSTANCE(instance);
     return in->accumulate(scaleIndices, count, cumulativeScaleIndex, +1);
 }
 int beagleRemoveScaleFactors(int instance, const int* scaleIndices, int count, int cumulativeScaleIndex)
 {
+    StatTimer st_(ST_SCALE);
     GET_INSTANCE(instance);
     return in->accumulate(scaleIndices, count, cumulativeScaleIndex, -1);
 }
 int beagleResetScaleFactors(int instance, int cumulativeScaleIndex)
 {
+    StatTimer st_(ST_SCALE);
     GET_INSTANCE(instance);
     if (cumulativeScaleIndex < 0 || cumulativeScaleIndex >= in->nScale)
         return fail(BEAGLE_ERROR_OUT_OF_RANGE, "beagleResetScaleFactors: index");
@@ -1323,6 +1366,7 @@ int beagleResetScaleFactors(int instance, int cumulativeScaleIndex)
 }
 int beagleCopyScaleFactors(int instance, int destScalingIndex, int srcScalingIndex)
 {
+    StatTimer st_(ST_SCALE);
     GET_INSTANCE(instance);
     if (destScalingIndex < 0 || destScalingIndex >= in->nScale || srcScalingIndex < 0 || srcScalingIndex >= in->nScale)
         return fail(BEAGLE_ERROR_OUT_OF_RANGE, "beagleCopyScaleFactors: index");
@@ -1356,6 +1400,7 @@ int beagleCalculateRootLogLikelihoods(int instance, const int* bufferIndices, co
                                       const int* stateFrequenciesIndices, const int* cumulativeScaleIndices, int count,
                                       double* outSumLogLikelihood)
 {
+    StatTimer st_(ST_LNL);
     GET_INSTANCE(instance);
     return in->integrate(bufferIndices, nullptr, nullptr, categoryWeightsIndices, stateFrequenciesIndices,
                          cumulativeScaleIndices, count, outSumLogLikelihood);
@@ -1367,6 +1412,7 @@ int beagleCalculateEdgeLogLikelihoods(int instance, const int* parentBufferIndic
                                       double* outSumLogLikelihood, double* outSumFirstDerivative,
                                       double* outSumSecondDerivative)
 {
+    StatTimer st_(ST_LNL);
     GET_INSTANCE(instance);
     if (firstDerivativeIndices || secondDerivativeIndices || outSumFirstDerivative || outSumSecondDerivative)
         return fail(BEAGLE_ERROR_NO_IMPLEMENTATION, "beagleCalculateEdgeLogLikelihoods: derivatives");
@@ -1375,6 +1421,7 @@ int beagleCalculateEdgeLogLikelihoods(int instance, const int* parentBufferIndic
 }
 int beagleGetSiteLogLikelihoods(int instance, double* outLogLikelihoods)
 {
+    StatTimer st_(ST_SITE);
     GET_INSTANCE(instance);
     if (!in->haveSite) return fail(BEAGLE_ERROR_GENERAL, "beagleGetSiteLogLikelihoods: no likelihood computed yet");
     HIP_TRY(hipStreamSynchronize(in->stream));

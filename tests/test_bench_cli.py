@@ -1,0 +1,37 @@
+"""bench.py's control flow on the CPU (--emulate: host-emulation engine, gloo): single process and the
+2-rank launch the driver uses for N>1 (torch.distributed.run on 127.0.0.1).  The numbers are meaningless;
+the contract of the JSON line and the N>1 path (rendezvous, chain exchange, max-over-ranks timing) are not."""
+import json
+import os
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+KEYS = {"metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+        "vs_baseline", "dtype", "data", "config", "roofline"}
+
+
+def _json_line(out):
+    lines = [l for l in out.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out[-2000:]
+    return json.loads(lines[0])
+
+
+def test_single_process():
+    res = subprocess.run([sys.executable, "bench.py", "--emulate", "--steps", "3", "--warmup", "1"], cwd=ROOT,
+                         capture_output=True, text=True, timeout=600)
+    assert res.returncode == 0, res.stderr[-2000:]
+    d = _json_line(res.stdout)
+    assert KEYS <= set(d) and d["n_gpus"] == 1 and d["steps"] == 3 and d["value"] > 0
+    assert {"bound", "achieved", "peak", "unit", "frac", "traffic"} <= set(d["roofline"])
+
+
+def test_two_ranks():
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1")
+    res = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                          "--master-addr", "127.0.0.1", "--master-port", "29671", "bench.py", "--gpus", "2",
+                          "--steps", "3", "--warmup", "1", "--emulate"], cwd=ROOT, env=env, capture_output=True,
+                         text=True, timeout=900)
+    assert res.returncode == 0, (res.stdout + res.stderr)[-3000:]
+    d = _json_line(res.stdout)
+    assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["config"]["chains"] == 2

@@ -1,0 +1,82 @@
+"""The N>1 path on CPU: world_size-2 `gloo` process group, each rank driving its own engine instance (the
+TEST-ONLY host-emulation build stands in for the GPU here) for its own heated chains; the per-generation
+exchange and the swap decisions must be identical on every rank and equal to a single-process run."""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    import torch.distributed as dist
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from mrbayes_amd import beagle as bg
+    from mrbayes_amd import chains as ch
+    from mrbayes_amd import likelihood as lk
+    from mrbayes_amd.division import synthetic_division
+    from tests.hostemu import build_emu
+    lib = bg.library(build_emu.build())
+    nchains = 4
+    ex = ch.ChainExchange(nchains, dist=dist, chain_temp=0.1, swap_seed=777)
+    trace = []
+    engines = {}
+    for c in ex.local:                      # every chain has its own state (branch lengths differ)
+        div = synthetic_division("gtr", 24, 150, seed=5, tree_seed=6)
+        div.tree.length = [l * (1.0 + 0.1 * c) for l in div.tree.length]
+        engines[c] = lk.BeagleDivision(div, lib)
+    for gen in range(6):
+        lnl = {}
+        for c, bd in engines.items():
+            bd.TouchAllTreeNodes(0)
+            lnl[c] = bd.LogLike(0)
+            bd.AcceptMove(0)
+        all_lnl, all_pr = ex.all_states(lnl)
+        a, b, ok = ex.attempt_swap(all_lnl, all_pr)
+        trace.append((all_lnl.tolist(), a, b, ok, list(ex.chain_id)))
+    for bd in engines.values():
+        bd.finalize()
+    q.put((rank, trace))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_chain_assignment():
+    sys.path.insert(0, ROOT)
+    from mrbayes_amd import chains as ch
+    assert ch.chains_of_rank(8, 8, 3) == [3]
+    assert ch.chains_of_rank(8, 2, 1) == [4, 5, 6, 7]
+    assert ch.chains_of_rank(5, 2, 0) == [0, 1, 2] and ch.chains_of_rank(5, 2, 1) == [3, 4]
+    assert sorted(sum((ch.chains_of_rank(7, 4, r) for r in range(4)), [])) == list(range(7))
+    assert ch.temperature(0, 4) == 1.0 and abs(ch.temperature(2, 4, 0.1) - 1 / 1.2) < 1e-15
+    # exchanging identical states is always accepted; the rule is antisymmetric in (A, B)
+    assert ch.swap_log_ratio(-10.0, -1.0, 1.0, -10.0, -1.0, 0.5) == 0.0
+    assert ch.swap_log_ratio(-10.0, 0.0, 1.0, -12.0, 0.0, 0.5) < 0.0 < ch.swap_log_ratio(-12.0, 0.0, 1.0, -10.0, 0.0, 0.5)
+
+
+def test_two_ranks_agree_with_one():
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    results = {}
+    for world in (1, 2):
+        q = ctx.Queue()
+        port = 29650 + world
+        procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+        for p in procs:
+            p.start()
+        got = [q.get(timeout=300) for _ in range(world)]
+        for p in procs:
+            p.join(timeout=60)
+            assert p.exitcode == 0
+        results[world] = dict(got)
+    single = results[1][0]
+    for r in (0, 1):
+        assert results[2][r] == single, "rank %d diverged from the single-process run" % r
+    assert any(t[3] for t in single) or True      # (swap outcomes are data dependent; equality above is the test)
+    lnl0 = np.array(single[0][0])
+    assert np.all(np.isfinite(lnl0)) and len(set(lnl0.tolist())) == 4

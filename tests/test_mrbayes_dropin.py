@@ -1,0 +1,64 @@
+"""The drop-in boundary end to end: the UNMODIFIED reference MrBayes (compiled from /root/reference/src with
+-DBEAGLE_ENABLED against include/libhmsbeagle/beagle.h, see oracle/Makefile) driving this engine through
+src/mbbeagle.c, compared with the same reference's native CPU kernels on the same fixed state.
+
+  * CPU  (`not gpu`): oracle/_ref/mb_emu -- linked to the TEST-ONLY host-emulation build of the engine; needs
+    the reference sources, i.e. runs in the build container only (skipped elsewhere).
+  * GPU  (`gpu`): oracle/_ref/mb_amd -- linked to the product library mrbayes_amd/libhmsbeagle.so; the binary
+    travels to the GPU box with the repository snapshot.
+"""
+import json
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from mrbayes_amd import data as mbdata
+from mrbayes_amd import tree as mbtree
+from tools import refrun
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REVMAT, PI, ALPHA = [0.10, 0.30, 0.05, 0.08, 0.40, 0.07], [0.35, 0.25, 0.15, 0.25], 0.6
+
+
+def _case(ntaxa, nsites, p_gap):
+    st = mbdata.synthetic_states(ntaxa, nsites, 4, 11, 0.15, p_gap)
+    tr = mbtree.random_tree(ntaxa, 12, brlen=0.05)
+    return st, tr
+
+
+def _lnl(binary, st, tr, beagle):
+    out, _ = refrun.run_mb(binary, refrun.known_answer_nexus(st, tr, REVMAT, PI, ALPHA, beagle=beagle))
+    return refrun.initial_lnl(out), out
+
+
+@pytest.mark.parametrize("scaling", ["dynamic", "always"])
+def test_unmodified_mrbayes_on_emulated_engine(scaling):
+    if not os.path.isdir("/root/reference/src"):
+        pytest.skip("reference sources not present (build container only)")
+    from tests.hostemu import build_emu
+    build_emu.build()
+    subprocess.check_call(["make", "-C", os.path.join(ROOT, "oracle"), "_ref/mb", "_ref/mb_emu"],
+                          stdout=subprocess.DEVNULL)
+    st, tr = _case(30, 600, 0.03)
+    native, _ = _lnl(refrun.REF_MB, st, tr, None)
+    ours, out = _lnl(refrun.REF_MB_EMU, st, tr, scaling)
+    assert "mbamd" in out                                  # MrBayes reports the engine it picked
+    assert abs(ours - native) / abs(native) < 1e-5, (ours, native)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("scaling", ["dynamic", "always"])
+def test_unmodified_mrbayes_on_mi355x(scaling):
+    if not os.path.exists(refrun.REF_MB_AMD):
+        pytest.skip("oracle/_ref/mb_amd was not built (needs the reference sources at build time)")
+    st, tr = _case(60, 3000, 0.02)
+    ours, out = _lnl(refrun.REF_MB_AMD, st, tr, scaling)
+    assert "mbamd HIP gfx950" in out
+    if os.path.exists(refrun.REF_MB):
+        native, _ = _lnl(refrun.REF_MB, st, tr, None)
+        assert abs(ours - native) / abs(native) < 1e-5, (ours, native)
+    # and a short MCMC run (default moves, 2 heated chains) must complete on the GPU engine
+    out, _ = refrun.run_mb(refrun.REF_MB_AMD, refrun.mcmc_nexus(st, tr, 300, beagle=scaling, nchains=2))
+    assert "Analysis completed" in out, out[-1500:]

@@ -13,6 +13,8 @@ import time
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 REF_MB = os.path.join(ROOT, "oracle", "_ref", "mb")
+REF_MB_AMD = os.path.join(ROOT, "oracle", "_ref", "mb_amd")     # the unmodified reference linked to OUR libhmsbeagle.so
+REF_MB_EMU = os.path.join(ROOT, "oracle", "_ref", "mb_emu")     # same objects, TEST-ONLY host-emulation engine
 
 _NUC = "ACGT-"
 
@@ -69,3 +71,68 @@ def time_reference_dna(states, tree, ngen_lo=10, ngen_hi=60, lset="lset nst=6 ra
     dt = out["hi"][1] - out["lo"][1]
     out["sec_per_eval"] = dt / dgen
     return out
+
+
+def known_answer_nexus(states, tree, revmat, pi, alpha, beagle=None, ngen=1, fname="ka"):
+    """NEXUS text of the known-answer recipe: data + fixed tree + startvals, GTR+G4.
+    beagle: None (native kernels) or the `beaglescaling` value ("dynamic" / "always")."""
+    names = ["t%d" % (i + 1) for i in range(states.shape[0])]
+    seqs = ["".join(_NUC[x] for x in row) for row in states]
+    s = "#NEXUS\nbegin data;\n  dimensions ntax=%d nchar=%d;\n" % (len(names), len(seqs[0]))
+    s += "  format datatype=dna interleave=no gap=- missing=?;\n  matrix\n"
+    for n, q in zip(names, seqs):
+        s += "%s  %s\n" % (n, q)
+    s += "  ;\nend;\nbegin mrbayes;\n  set autoclose=yes nowarnings=yes seed=12345 swapseed=12345 precision=15;\n"
+    s += "  lset nst=6 rates=gamma ngammacat=4;\n"
+    if beagle:
+        s += "  set usebeagle=yes beagledevice=gpu beagleprecision=single beaglescaling=%s;\n" % beagle
+    s += "end;\nbegin trees;\n  tree t = [&U] %s\nend;\n" % tree.to_newick(names)
+    vec = lambda v: "(" + ",".join("%.15g" % x for x in v) + ")"
+    s += "begin mrbayes;\n  startvals tau=t V=t Revmat=%s Pi=%s Alpha=(%.15g);\n" % (vec(revmat), vec(pi), alpha)
+    s += "  mcmc ngen=%d nchains=1 nruns=1 samplefreq=%d printfreq=%d diagnfreq=%d filename=%s;\nend;\n" % (
+        ngen, max(ngen, 1), max(ngen, 1), max(ngen, 1), fname)
+    return s
+
+
+def run_mb(binary, nexus_text, timeout=1800, env=None):
+    """Run a MrBayes binary on a NEXUS text in a scratch directory -> (stdout, wall seconds)."""
+    with tempfile.TemporaryDirectory() as wd:
+        with open(os.path.join(wd, "run.nex"), "w") as fh:
+            fh.write(nexus_text)
+        t0 = time.time()
+        res = subprocess.run([binary, "run.nex"], cwd=wd, capture_output=True, text=True, timeout=timeout,
+                             env=dict(os.environ, **(env or {})))
+        return res.stdout + res.stderr, time.time() - t0
+
+
+def initial_lnl(stdout):
+    m = re.search(r"Chain 1 -- (-?[0-9.]+) --", stdout)
+    if not m:
+        raise RuntimeError("no initial log-likelihood in the MrBayes output:\n" + stdout[-2000:])
+    return float(m.group(1))
+
+
+def mcmc_nexus(states, tree_or_none, ngen, beagle=None, nchains=1, fname="mc", fixed_topology=False):
+    """A default-move-mix MCMC run (GTR+G4) on the given alignment: what `MCMC gen/s` is quoted on."""
+    names = ["t%d" % (i + 1) for i in range(states.shape[0])]
+    seqs = ["".join(_NUC[x] for x in row) for row in states]
+    s = "#NEXUS\nbegin data;\n  dimensions ntax=%d nchar=%d;\n" % (len(names), len(seqs[0]))
+    s += "  format datatype=dna interleave=no gap=- missing=?;\n  matrix\n"
+    for n, q in zip(names, seqs):
+        s += "%s  %s\n" % (n, q)
+    s += "  ;\nend;\nbegin mrbayes;\n  set autoclose=yes nowarnings=yes seed=12345 swapseed=12345;\n"
+    s += "  lset nst=6 rates=gamma ngammacat=4;\n"
+    if beagle:
+        s += "  set usebeagle=yes beagledevice=gpu beagleprecision=single beaglescaling=%s;\n" % beagle
+    s += "end;\n"
+    if tree_or_none is not None:
+        s += "begin trees;\n  tree t = [&U] %s\nend;\nbegin mrbayes;\n  %s;\nend;\n" % (
+            tree_or_none.to_newick(names), "prset topologypr=fixed(t); startvals V=t" if fixed_topology else "startvals tau=t V=t")
+    s += "begin mrbayes;\n  mcmc ngen=%d nchains=%d nruns=1 samplefreq=%d printfreq=%d diagnfreq=%d filename=%s;\nend;\n" % (
+        ngen, nchains, max(ngen, 1), max(ngen, 1), max(ngen, 1), fname)
+    return s
+
+
+def analysis_seconds(stdout):
+    m = re.search(r"Analysis used ([0-9.]+) seconds of CPU time", stdout)
+    return float(m.group(1)) if m else None
