@@ -316,6 +316,10 @@ int Instance::create(int tipCount_, int partialsBufferCount, int compactBufferCo
         HIP_TRY(hipMemsetAsync(arenaPartials, 0, pBytes, stream));
         HIP_TRY(hipMemsetAsync(arenaTips, 0, tBytes, stream));
         HIP_TRY(hipMemsetAsync(arenaScale, 0, sBytes, stream));
+        if (std::getenv("MBAMD_VERBOSE"))
+            std::fprintf(stderr, "[mbamd] arenas: partials %p +%zu, tips %p +%zu, scale %p +%zu, matrices %p +%zu\n",
+                         (void*) arenaPartials, pBytes, (void*) arenaTips, tBytes, (void*) arenaScale, sBytes, (void*) matrices,
+                         (size_t) nMatrices * matrixFloats * 4);
         for (int i = 0; i < nBuffers; ++i) partials[i] = arenaPartials + (size_t) i * K * 64 * 4;
         for (size_t i = 0; i < scale.size(); ++i) scale[i] = arenaScale + i * 64;
     }
@@ -385,7 +389,9 @@ int Instance::configureWalk()
     const int wgs = Ppad / 64;
     const int perCU = (wgs + numCU - 1) / numCU;       // workgroups a CU must host for full residency
     const int resident = std::max(1, std::min(perCU, 4));
-    total = perCU >= 8 ? 2 : (perCU >= 3 ? 4 : 8);    // keep waves per CU <= 16 (VGPR budget of 128)
+    // measured (profiles/): once every CU has a workgroup, 3 compute waves + loader beat 7 + loader (LDS slots
+    // per workgroup, not waves, are the scarce resource); small grids take the wider workgroup for tree parallelism
+    total = perCU >= 8 ? 2 : (wgs >= numCU ? 4 : 8);
     ldsBudget = (160 * 1024) / resident - 512;
     hipError_t err = hipSuccess;
     const int maxLds = 160 * 1024;
@@ -698,29 +704,31 @@ int Instance::timedRun(const Plan& plan, int32_t* cum)
 // Tree-walk path.  The operation list becomes a schedule of steps of up to W mutually independent
 // operations (one per compute wave of the workgroup that owns a 64-pattern block).  Scheduling and LDS
 // slot allocation happen in one pass over the steps, because they constrain each other:
-//   * every result occupies a slot from the step that produces it (p) at least until the writer wave has
-//     copied it to HBM (during step p+1), and until its last consumer has read it;
-//   * a slot released in step s can be overwritten from step s+1 on -- or in step s by the very operation
-//     that consumed it, if nobody else (another consumer, the writer) still reads it;
+//   * a result that a later operation of the list consumes occupies an LDS slot from the step that
+//     produces it until its last consumer has read it; the slot can be overwritten from the next step on
+//     -- or in that very step by the operation that consumed it, if nobody else reads it;
+//   * a child that lives in global memory (a buffer this list does not produce, or an evicted value) needs a
+//     slot for the step before its consumer (the loader wave copies it in) and the consumer's step;
 //   * when no slot is free the resident value needed farthest in the future is evicted (Belady on list
 //     position); its consumers re-read it from HBM (CHILD_RELOAD), which is legal from step p+2 on, after
-//     the writer drained its stores (MBAMD_OP_DRAIN on step q-2 for a re-read in step q);
-//   * an operation that can get neither its inputs nor a slot in this step simply waits for a later one.
+//     the compute waves drained their stores (MBAMD_OP_DRAIN on step q-2 for a re-read in step q);
+//   * an operation that can get neither its inputs nor the slots it needs in this step waits for a later one.
 int Instance::buildWalk(Plan& plan, std::vector<PartialsOp>& dev, const std::vector<int>& dstIdx,
                         const std::vector<int>& c1Idx, const std::vector<int>& c2Idx)
 {
     const int n = (int) dev.size();
     int W = walkWaves;
     const int maxSlots = walkSlots;
+    int32_t* scratchScale = arenaScale + scale.size() * 64;      // readable / writable sink for unused scale pointers
 
     // ---- dependencies: prodN[o] = operation of this list producing child N of o (or -1).  A list with
     // write-after-read / write-after-write hazards on buffer indices (never produced by MrBayes) is
     // executed strictly in list order by a single compute wave.
     std::vector<int> prod1(n, -1), prod2(n, -1);
+    bool hazard = false;
     {
         std::vector<int> lastWriter(nBuffers, -1);
         std::vector<char> readOld(nBuffers, 0);
-        bool hazard = false;
         for (int o = 0; o < n; ++o) {
             prod1[o] = lastWriter[c1Idx[o]];
             prod2[o] = lastWriter[c2Idx[o]];
@@ -729,9 +737,10 @@ int Instance::buildWalk(Plan& plan, std::vector<PartialsOp>& dev, const std::vec
             if (readOld[dstIdx[o]] || lastWriter[dstIdx[o]] >= 0) hazard = true;
             lastWriter[dstIdx[o]] = o;
         }
-        if (hazard) W = 1;
     }
-    W = std::max(1, std::min(W, maxSlots / 2));
+    const bool inOrder = hazard || std::getenv("MBAMD_WALK_IN_ORDER") != nullptr;
+    if (inOrder) W = 1;
+    W = std::max(1, std::min(W, std::max(1, maxSlots / 2)));
     std::vector<std::vector<int>> consumers(n);
     std::vector<int> indeg(n, 0), pendingReads(n, 0);
     for (int o = 0; o < n; ++o) {
@@ -741,18 +750,17 @@ int Instance::buildWalk(Plan& plan, std::vector<PartialsOp>& dev, const std::vec
     for (int o = 0; o < n; ++o) pendingReads[o] = (int) consumers[o].size();
     auto nextUse = [&](int o) {                           // list position of the earliest unscheduled consumer
         int best = 1 << 30;
-        for (int q : consumers[o]) best = std::min(best, q);   // (scheduled consumers were removed, see below)
+        for (int q : consumers[o]) best = std::min(best, q);   // (scheduled consumers are removed as they are placed)
         return best;
     };
 
     std::vector<int> stepOf(n, -1), slotOf(n, -1);
-    std::vector<int> slotHolder(maxSlots, -1), slotFreeFrom(maxSlots, 0);
+    std::vector<int> slotHolder(maxSlots, -1), slotFreeFrom(maxSlots, -1);
     std::vector<std::vector<int>> steps;
-    std::vector<char> drainBefore;                        // step q re-reads a value from HBM
+    std::vector<char> drainBefore;                        // step q re-reads a value this list stored earlier
     std::vector<int> ready;
     for (int o = 0; o < n; ++o) if (indeg[o] == 0) ready.push_back(o);
     int slotsUsed = 0, done = 0;
-    const bool inOrder = (W == 1 && walkWaves != 1) || std::getenv("MBAMD_WALK_IN_ORDER") != nullptr;
 
     for (int s = 0; done < n; ++s) {
         if (s > 4 * n + 16) return fail(BEAGLE_ERROR_GENERAL, "tree-walk scheduler made no progress");
@@ -776,69 +784,99 @@ int Instance::buildWalk(Plan& plan, std::vector<PartialsOp>& dev, const std::vec
             uint8_t* kind[2] = {&d.c1_kind, &d.c2_kind};
             uint8_t* slot[2] = {&d.c1_slot, &d.c2_slot};
             bool ok = true, reload = false;
-            for (int t = 0; t < 2 && ok; ++t) {
-                if (*kind[t] == CHILD_STATES || pr[t] < 0) continue;
-                if (slotOf[pr[t]] >= 0) { *kind[t] = CHILD_LDS; *slot[t] = (uint8_t) slotOf[pr[t]]; }
-                else if (stepOf[pr[t]] <= s - 2) { *kind[t] = CHILD_RELOAD; reload = true; }
-                else ok = false;                              // evicted too recently: its store is not drained yet
-            }
-            if (!ok) continue;
-            // ---- destination slot
-            auto lastReaderIsMe = [&](int producer) {         // o is the only remaining consumer, nobody else reads it now
-                return producer >= 0 && pendingReads[producer] == 1 && !readThisStep[producer] && stepOf[producer] <= s - 2;
+            std::vector<int> taken;                         // slots claimed by this operation so far (rolled back on failure)
+            auto claimFree = [&](int fromStep) {            // a slot nobody uses from `fromStep` on
+                for (int t = 0; t < maxSlots; ++t)
+                    if (slotHolder[t] < 0 && slotFreeFrom[t] <= fromStep && std::find(taken.begin(), taken.end(), t) == taken.end())
+                        return t;
+                return -1;
             };
-            int sl = -1;
-            for (int t = 0; t < maxSlots && sl < 0; ++t)
-                if (slotHolder[t] < 0 && slotFreeFrom[t] <= s) sl = t;
-            if (sl < 0 && d.c1_kind == CHILD_LDS && lastReaderIsMe(pr[0])) sl = d.c1_slot;
-            if (sl < 0 && d.c2_kind == CHILD_LDS && pr[1] != pr[0] && lastReaderIsMe(pr[1])) sl = d.c2_slot;
-            if (sl < 0) {                                     // evict
+            auto evict = [&](int fromStep) {                // farthest next use among values idle since `fromStep`
                 int far = -1, farUse = -1;
                 for (int t = 0; t < maxSlots; ++t) {
                     const int h = slotHolder[t];
-                    if (h < 0 || stepOf[h] > s - 2 || readThisStep[h] || h == pr[0] || h == pr[1]) continue;
+                    if (h < 0 || stepOf[h] >= fromStep || readThisStep[h] || h == pr[0] || h == pr[1]) continue;
+                    if (std::find(taken.begin(), taken.end(), t) != taken.end()) continue;
                     const int u = nextUse(h);
                     if (u > farUse) { farUse = u; far = t; }
                 }
-                if (far >= 0) { slotOf[slotHolder[far]] = -1; slotHolder[far] = -1; sl = far; }
+                return far;
+            };
+            std::vector<std::pair<int, int>> evicted;       // (slot, value) evicted for this operation
+            for (int t = 0; t < 2 && ok; ++t) {
+                if (*kind[t] == CHILD_STATES) continue;
+                if (pr[t] >= 0 && slotOf[pr[t]] >= 0) { *kind[t] = CHILD_LDS; *slot[t] = (uint8_t) slotOf[pr[t]]; continue; }
+                if (t == 1 && *kind[0] != CHILD_STATES && *kind[0] != CHILD_LDS && c2Idx[o] == c1Idx[o]) {
+                    *kind[1] = *kind[0]; *slot[1] = *slot[0]; continue;       // same buffer twice: one copy serves both
+                }
+                if (pr[t] >= 0) {                                            // evicted value: re-read from HBM
+                    if (stepOf[pr[t]] > s - 2) { ok = false; break; }        // its store is not drained yet
+                    *kind[t] = CHILD_RELOAD;
+                    reload = true;
+                } else {
+                    *kind[t] = CHILD_PARTIALS;
+                }
+                // the loader copies it in during step s-1: the slot must be unused from step s-1 on
+                int sl = claimFree(s - 1);
+                if (sl < 0) {
+                    // (a value evicted now was last touched before step s-1, so nobody reads it in s-1)
+                    const int ev = evict(s - 1);
+                    if (ev >= 0) { evicted.emplace_back(ev, slotHolder[ev]); sl = ev; }
+                }
+                if (sl < 0) { ok = false; break; }
+                taken.push_back(sl);
+                *slot[t] = (uint8_t) sl;
             }
-            if (sl < 0) continue;                             // no room in this step
+            // ---- destination slot (only if somebody in this list reads the result)
+            int dsl = -1;
+            if (ok && pendingReads[o] > 0) {
+                auto lastReaderIsMe = [&](int producer) {     // o is the only remaining consumer, nobody else reads it now
+                    return producer >= 0 && pendingReads[producer] == 1 && !readThisStep[producer];
+                };
+                dsl = claimFree(s);
+                if (dsl < 0 && d.c1_kind == CHILD_LDS && lastReaderIsMe(pr[0])) dsl = d.c1_slot;
+                if (dsl < 0 && d.c2_kind == CHILD_LDS && pr[1] != pr[0] && lastReaderIsMe(pr[1])) dsl = d.c2_slot;
+                if (dsl < 0) {
+                    const int ev = evict(s);
+                    if (ev >= 0) { evicted.emplace_back(ev, slotHolder[ev]); dsl = ev; }
+                }
+                if (dsl < 0 && !taken.empty()) {              // take over one of its own staging slots
+                    dsl = taken.back();
+                    taken.pop_back();
+                }
+                if (dsl < 0) ok = false;
+            }
+            if (!ok) continue;                                // not in this step
             // ---- commit
+            for (auto& ev : evicted) { slotOf[ev.second] = -1; slotHolder[ev.first] = -1; }
+            for (int sl : taken) { slotHolder[sl] = -1; slotFreeFrom[sl] = s + 1; slotsUsed = std::max(slotsUsed, sl + 1); }
             for (int t = 0; t < 2; ++t) {
                 if (pr[t] < 0 || (t == 1 && pr[1] == pr[0])) continue;
                 readThisStep[pr[t]] = 1;
                 auto& cs = consumers[pr[t]];
                 cs.erase(std::find(cs.begin(), cs.end(), o));
-                if (--pendingReads[pr[t]] == 0 && slotOf[pr[t]] >= 0 && slotOf[pr[t]] != sl) {
-                    const int ps = slotOf[pr[t]];             // last consumer: the slot is free from the next step on
-                    slotHolder[ps] = -1;                       // (the writer copied it in step stepOf+1 <= s)
+                if (--pendingReads[pr[t]] == 0 && slotOf[pr[t]] >= 0) {
+                    const int ps = slotOf[pr[t]];             // last consumer: free from the next step on (or taken over below)
+                    slotHolder[ps] = -1;
                     slotFreeFrom[ps] = s + 1;
                     slotOf[pr[t]] = -1;
-                } else if (pendingReads[pr[t]] == 0 && slotOf[pr[t]] == sl) {
-                    slotOf[pr[t]] = -1;                        // taken over by this operation's own result
                 }
             }
-            d.dst_slot = (uint8_t) sl;
+            d.dst_slot = MBAMD_NO_SLOT;
+            if (dsl >= 0) {
+                d.dst_slot = (uint8_t) dsl;
+                slotHolder[dsl] = o;
+                slotOf[o] = dsl;
+                slotsUsed = std::max(slotsUsed, dsl + 1);
+            }
             d.flags = 0;
-            if (d.c1_kind == CHILD_PARTIALS || d.c1_kind == CHILD_RELOAD || d.c2_kind == CHILD_PARTIALS ||
-                d.c2_kind == CHILD_RELOAD || d.scale_mode == SCALE_READ)
-                d.flags |= MBAMD_OP_SLOW;
-            if (d.scale_mode == SCALE_NONE) d.scale = arenaScale + scale.size() * 64;     // scratch sink
+            if (d.scale_mode == SCALE_NONE) d.scale = scratchScale;
             dev[o] = d;
-            slotHolder[sl] = o;
-            slotOf[o] = sl;
             stepOf[o] = s;
-            slotsUsed = std::max(slotsUsed, sl + 1);
             needDrain |= reload;
             chosen.push_back(o);
         }
-        // values nobody in this list consumes only wait for the writer: free from step s+2 on
-        for (int o : chosen)
-            if (pendingReads[o] == 0) { slotFreeFrom[slotOf[o]] = s + 2; slotHolder[slotOf[o]] = -1; slotOf[o] = -1; }
-        for (int o : chosen) {
-            ready.erase(std::find(ready.begin(), ready.end(), o));
-            // consumers were pruned from `consumers[]` as they got scheduled; walk the static relation instead
-        }
+        for (int o : chosen) ready.erase(std::find(ready.begin(), ready.end(), o));
         steps.push_back(chosen);
         drainBefore.push_back(needDrain ? 1 : 0);
         done += (int) chosen.size();
@@ -848,22 +886,31 @@ int Instance::buildWalk(Plan& plan, std::vector<PartialsOp>& dev, const std::vec
     }
     const int nsteps = (int) steps.size();
 
-    // ---- device table [nsteps + 5][W] -----------------------------------------------------------------
-    // (+5 empty rows: the kernel's prefetch pipeline reads that far ahead; empty entries carry valid
-    //  dummy pointers because their matrix rows / tip bytes are requested before `dst` is looked at)
-    std::vector<PartialsOp> table((size_t) (nsteps + 5) * W);
+    // ---- device table [nsteps + 4][W] -----------------------------------------------------------------
+    // (+4 empty rows: the loader reads that far ahead; empty entries carry valid dummy pointers because
+    //  the loader fetches through every pointer of a row without looking at `dst`)
+    std::vector<PartialsOp> table((size_t) (nsteps + 4) * W);
     std::memset(table.data(), 0, table.size() * sizeof(PartialsOp));
-    for (int s = 0; s < nsteps + 5; ++s) {
-        const uint8_t fl = (s + 2 < nsteps && drainBefore[s + 2]) ? MBAMD_OP_DRAIN : 0;
+    for (int s = 0; s < nsteps + 4; ++s) {
+        uint8_t fl = (s + 2 < nsteps && drainBefore[s + 2]) ? MBAMD_OP_DRAIN : 0;
+        if (s < nsteps)
+            for (int o : steps[s]) {
+                const PartialsOp& d = dev[o];
+                if (d.scale_mode == SCALE_READ) fl |= MBAMD_OP_HAS_READ;
+                if (d.c1_kind == CHILD_PARTIALS || d.c1_kind == CHILD_RELOAD || d.c2_kind == CHILD_PARTIALS ||
+                    d.c2_kind == CHILD_RELOAD)
+                    fl |= MBAMD_OP_HAS_GLOBAL;
+            }
         for (int w = 0; w < W; ++w) {
             PartialsOp& e = table[(size_t) s * W + w];
             if (s < nsteps && w < (int) steps[s].size()) {
                 e = dev[steps[s][w]];
-            } else {                                  // empty entry: everything the prefetch touches is readable
+            } else {
                 e.c1_slot = e.c2_slot = e.dst_slot = MBAMD_NO_SLOT;
-                e.c1_kind = e.c2_kind = CHILD_PARTIALS;
+                e.c1_kind = e.c2_kind = CHILD_STATES;
                 e.c1 = e.c2 = arenaTips;
                 e.m1 = e.m2 = matrices;
+                e.scale = scratchScale;
                 e.flags = 0;
             }
             e.flags |= fl;
@@ -890,7 +937,7 @@ int Instance::runWalk(const Plan& plan, int32_t* cum)
 #endif
     switch (K) {
 #define MBAMD_WALK_CASE(KK) \
-    case KK: MBAMD_LAUNCH(k_walk_s4<KK>, grid, walkThreads, lds, stream, (const PartialsOp*) plan.d_table, nsteps, walkArgW, geom, cum, d_trace); break;
+    case KK: MBAMD_LAUNCH(k_walk_s4<KK>, grid, walkThreads, lds, stream, (const PartialsOp*) plan.d_table, nsteps, walkArgW, std::max(1, plan.slotsUsed), geom, cum, d_trace); break;
         MBAMD_WALK_CASE(1) MBAMD_WALK_CASE(2) MBAMD_WALK_CASE(3) MBAMD_WALK_CASE(4)
         MBAMD_WALK_CASE(5) MBAMD_WALK_CASE(6) MBAMD_WALK_CASE(7) MBAMD_WALK_CASE(8)
 #undef MBAMD_WALK_CASE
