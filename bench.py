@@ -218,7 +218,15 @@ def main():
         else:
             roof = {"bound": "hbm", "achieved": abytes / (k_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s"}
         roof["frac"] = roof["achieved"] / roof["peak"]
-        roof["traffic"] = None
+        roof["traffic"] = None            # HBM bytes per launch from committed PMC passes of this workload, if any
+        try:
+            with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as fh:
+                pmc = json.load(fh).get(args.config)
+            if pmc and not emulate:
+                roof["traffic"] = pmc["traffic_bytes"]
+                roof["traffic_source"] = pmc["source"]
+        except (OSError, ValueError):
+            pass
         roof["kernel"] = impl
         roof["kernel_ms_per_step"] = k_ms
         roof["launches_per_step"] = klaunches / max(args.steps, 1)

@@ -98,6 +98,7 @@ struct Instance {
     int tipCount = 0, nBuffers = 0, S = 0, SP = 0, P = 0, Ppad = 0, nEigen = 0, nMatrices = 0, K = 0, nScale = 0;
     bool s4 = false;                 // 4-state float4 layout + tree-walk kernel
     bool mfma = false;               // general-state path on the matrix cores (mbamd_kernels_mfma.h)
+    bool mfmaWhole = false;          // MBAMD_MFMA_WHOLE: one wave per (operation, 32 patterns) instead of per factor tile
     int walkWaves = 1, walkSlots = 16;   // tree-walk kernel: waves per pattern block, LDS slots per workgroup
     int lastWalkSteps = 0, lastWalkSlots = 0;
     long long* d_trace = nullptr;    // MBAMD_WALK_TRACE: per-step clock stamps of workgroup 0 (timing experiments)
@@ -290,6 +291,7 @@ int Instance::create(int tipCount_, int partialsBufferCount, int compactBufferCo
     mfma = !s4 && S >= 5 && S <= 64 && ((NT == 1 && K <= 4) || (NT == 2 && K <= 2)) &&
            std::getenv("MBAMD_NO_MFMA") == nullptr;
     if (mfma) SP = 32 * NT;          // transposed matrices padded to the MFMA tile height
+    mfmaWhole = std::getenv("MBAMD_MFMA_WHOLE") != nullptr;
 #endif
     partialsFloats = s4 ? (size_t) K * Ppad * 4 : (size_t) K * S * Ppad;
     matrixFloats = (size_t) K * SP * SP + (mfma ? (size_t) K * NT * T * 64 : 0);
@@ -520,6 +522,14 @@ int Instance::updateMatrices(int eigenIndex, const int* probIdx, const double* l
         HIP_TRY(hipGetLastError());
         return BEAGLE_SUCCESS;
     }
+#if !defined(MBAMD_HOST_EMU)
+    if (S > 8 && (size_t) (S * S + S) * sizeof(double) <= 60 * 1024) {
+        MBAMD_LAUNCH(k_transition_matrices_lds, (unsigned) (count * K * 4), 256, (size_t) (S * S + S) * sizeof(double), stream,
+                     djobs, eig, rates, S, SP, K, mfma ? T : 0);
+        HIP_TRY(hipGetLastError());
+        return BEAGLE_SUCCESS;
+    }
+#endif
     const size_t nev = (size_t) count * K * S;
     rc = grow((void**) &d_ev, &evCap, nev * sizeof(double));
     if (rc) return rc;
@@ -957,9 +967,28 @@ static void launch_mfma_t(Instance& in, const PartialsOp* ops, int count, int32_
     auto kern = k_partials_mfma<NT_, SC_, KC_>;
     MBAMD_LAUNCH(kern, grid, 256, 0, in.stream, ops, in.S, in.SP, in.Ppad, gx, cum);
 }
+template <int NT_, int SC_, int KC_>
+static void launch_mfma_split_t(Instance& in, const PartialsOp* ops, int count, int32_t* cum)
+{
+    constexpr int NP = 2 * KC_ * NT_;
+    const int gx = in.Ppad / 32;
+    auto kern = k_partials_mfma_split<NT_, SC_, KC_>;
+    MBAMD_LAUNCH(kern, (unsigned) (gx * count), 64 * NP, (size_t) NP * (16 * 64 + 32) * sizeof(float), in.stream, ops, in.S,
+                 in.SP, in.Ppad, gx, cum);
+}
 static bool launch_mfma(Instance& in, const PartialsOp* ops, int count, int32_t* cum)
 {
     const int S = in.S, K = in.K;
+    if (!in.mfmaWhole) {                 // default: one wave per factor tile (MBAMD_MFMA_WHOLE=1 selects the wave-per-tile-column kernel)
+        if (in.NT == 1 && S == 20 && K == 4) { launch_mfma_split_t<1, 20, 4>(in, ops, count, cum); return true; }
+        if (in.NT == 1 && S == 20 && K == 1) { launch_mfma_split_t<1, 20, 1>(in, ops, count, cum); return true; }
+        if (in.NT == 2 && S == 61 && K == 1) { launch_mfma_split_t<2, 61, 1>(in, ops, count, cum); return true; }
+        if (in.NT == 1 && K == 1) { launch_mfma_split_t<1, 0, 1>(in, ops, count, cum); return true; }
+        if (in.NT == 1 && K == 2) { launch_mfma_split_t<1, 0, 2>(in, ops, count, cum); return true; }
+        if (in.NT == 1 && K == 4) { launch_mfma_split_t<1, 0, 4>(in, ops, count, cum); return true; }
+        if (in.NT == 2 && K == 1) { launch_mfma_split_t<2, 0, 1>(in, ops, count, cum); return true; }
+        if (in.NT == 2 && K == 2) { launch_mfma_split_t<2, 0, 2>(in, ops, count, cum); return true; }
+    }
     if (in.NT == 1) {
         if (S == 20 && K == 4) launch_mfma_t<1, 20, 4>(in, ops, count, cum);
         else if (S == 20 && K == 1) launch_mfma_t<1, 20, 1>(in, ops, count, cum);

@@ -171,5 +171,153 @@ k_partials_mfma(const PartialsOp* __restrict__ ops, int S_rt, int SP, int Ppad, 
             }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Finer-grained variant: one workgroup per (operation, 32 patterns), one WAVE per factor tile
+// (category k, child c, row tile it): 2*K*NT waves.  A wave runs only T = ceil(S/2) dependent
+// MFMAs (10 for S=20, 31 for S=61) instead of 2*K*NT*T, so the small dependency levels near the
+// root of the tree -- a handful of operations -- still put thousands of waves on the chip.
+// The factor tiles meet in LDS: [piece][reg 0..15][64 lanes] floats (lane-contiguous, conflict
+// free); the two child waves of an output tile then split its 16 accumulator registers (rows),
+// multiply, reduce the per-pattern maximum through LDS, rescale and store.
+// blockDim.x = 64 * 2*K*NT (<= 512), dynamic LDS = 2*K*NT * 4 KiB + 2*K*NT * 32 floats.
+// ---------------------------------------------------------------------------------------------
+template <int NT, int SC, int KC>
+__global__ void __launch_bounds__(64 * 2 * KC * NT)
+k_partials_mfma_split(const PartialsOp* __restrict__ ops, int S_rt, int SP, int Ppad, int gx, int32_t* __restrict__ cumulative)
+{
+    constexpr int NP = 2 * KC * NT;                 // pieces = waves
+    extern __shared__ float lds_f[];
+    float* tiles = lds_f;                           // [NP][16][64]
+    float* smax = lds_f + NP * 16 * 64;             // [NP][32]
+    const int S = SC > 0 ? SC : S_rt;
+    const int bx = blockIdx.x % gx, by = blockIdx.x / gx;       // gx = P_pad / 32 tiles
+    const int wave = __builtin_amdgcn_readfirstlane((int) (threadIdx.x >> 6)), lane = threadIdx.x & 63;
+    const int k = wave / (2 * NT), c = (wave / NT) & 1, it = wave % NT;
+    const int c0 = bx * 32;
+    const MBAMD_AS_CONST PartialsOp* __restrict__ op = as_const(ops) + by;
+    const int kind = c ? op->c2_kind : op->c1_kind;
+    const void* child = c ? op->c2 : op->c1;
+    const float* mbase = c ? op->m2 : op->m1;
+    const int mode = op->scale_mode;
+    const int half = lane >> 5, col = lane & 31;
+    const int T = (S + 1) / 2;
+
+    // ---- this wave's factor tile F_c[k][32*it .. 32*it+31][c0 .. c0+31]
+    f32x16 acc;
+    if (kind == CHILD_STATES) {
+        const unsigned s = as_global(reinterpret_cast<const uint8_t*>(child))[c0 + col];
+        const bool missing = s >= (unsigned) S;
+        const MBAMD_AS_GLOBAL float* row = as_global(mbase) + ((size_t) k * SP + (missing ? 0u : s)) * SP + 4 * half;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int i0 = 32 * it + 8 * q;
+            f4 v = *reinterpret_cast<const MBAMD_AS_GLOBAL f4*>(row + i0);
+            if (missing) {
+                const int ib = i0 + 4 * half;
+                v.x = (ib + 0 < S) ? 1.0f : 0.0f;
+                v.y = (ib + 1 < S) ? 1.0f : 0.0f;
+                v.z = (ib + 2 < S) ? 1.0f : 0.0f;
+                v.w = (ib + 3 < S) ? 1.0f : 0.0f;
+            }
+            acc[4 * q + 0] = v.x; acc[4 * q + 1] = v.y; acc[4 * q + 2] = v.z; acc[4 * q + 3] = v.w;
+        }
+    } else {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
+        const MBAMD_AS_GLOBAL float* __restrict__ pa =
+            as_global(mbase) + (size_t) KC * SP * SP + ((size_t) (k * NT + it) * T) * 64 + lane;
+        const MBAMD_AS_GLOBAL float* __restrict__ cl =
+            as_global(reinterpret_cast<const float*>(child)) + (size_t) k * S * Ppad + (size_t) half * Ppad + c0 + col;
+        const int Tfull = S / 2;
+#pragma unroll 8
+        for (int t = 0; t < Tfull; ++t)
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(pa[(size_t) t * 64], cl[(size_t) (2 * t) * Ppad], acc, 0, 0, 0);
+        if (S & 1) {
+            const float b = half ? 0.0f : cl[(size_t) (2 * Tfull) * Ppad];
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(pa[(size_t) Tfull * 64], b, acc, 0, 0, 0);
+        }
+    }
+    float* mine = tiles + (size_t) wave * 16 * 64;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) mine[r * 64 + lane] = acc[r];
+    __syncthreads();
+
+    // ---- output tile (k, it): this wave takes registers 8c .. 8c+7 of it (rows (r&3) + 8(r>>2) + 4 half)
+    const float* other = tiles + (size_t) ((k * 2 + (1 - c)) * NT + it) * 16 * 64;
+    float out[8];
+    float mx = 0.0f;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int r = 8 * c + j;
+        const float v = acc[r] * other[r * 64 + lane];
+        out[j] = v;
+        const int i = 32 * it + (r & 3) + 8 * (r >> 2) + 4 * half;
+        mx = fmaxf(mx, (i < S) ? v : 0.0f);
+    }
+    int e = 0;
+    if (mode == SCALE_WRITE) {
+        mx = fmaxf(mx, __shfl_xor(mx, 32));
+        if (half == 0) smax[wave * 32 + col] = mx;
+        __syncthreads();
+        float m = 0.0f;
+#pragma unroll
+        for (int p = 0; p < NP; ++p) m = fmaxf(m, smax[p * 32 + col]);
+        e = scale_exponent(m);
+        if (wave == 0 && half == 0) {
+            as_global(op->scale)[c0 + col] = e;
+            if (cumulative != nullptr && e != 0) atomicAdd(cumulative + c0 + col, e);
+        }
+    } else if (mode == SCALE_READ) {
+        e = as_global(op->scale)[c0 + col];
+    }
+    MBAMD_AS_GLOBAL float* __restrict__ dst = as_global(op->dst) + c0 + col;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int r = 8 * c + j;
+        const int i = 32 * it + (r & 3) + 8 * (r >> 2) + 4 * half;
+        if (i < S) dst[((size_t) k * S + i) * Ppad] = (mode != SCALE_NONE) ? scale_pow2(out[j], -e) : out[j];
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Transition matrices for larger state counts (TiProbs_Gen / TiProbs_GenCov, reference
+// src/likelihood.c:9424-9700): P_k = U diag(exp(lambda t r_k)) U^-1 in fp64, clamped at 0, stored as
+// fp32 transposed + in MFMA A-operand order.  One workgroup per (branch, category, quarter of the
+// rows): the S exponentials and the scaled inverse W[s][j] = e_s Uinv[s][j] are formed once in
+// LDS, then every thread accumulates its entries with one fp64 FMA per term.
+// grid = count * K * 4, block = 256, dynamic LDS = (S*S + S) doubles.
+// ---------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256)
+k_transition_matrices_lds(const MatrixJob* __restrict__ jobs, const double* __restrict__ eig, RatesArg rates, int S,
+                          int SP, int K, int packedT)
+{
+    extern __shared__ double lds_d[];
+    double* W = lds_d;                 // [S][S]
+    double* ev = lds_d + S * S;        // [S]
+    const int part = blockIdx.x & 3, bk = blockIdx.x >> 2;
+    const int b = bk / K, k = bk % K;
+    const double* __restrict__ U = eig;
+    const double* __restrict__ Ui = eig + (size_t) S * S;
+    const double* __restrict__ lam = eig + (size_t) 2 * S * S;
+    const MatrixJob job = jobs[b];
+    for (int s = threadIdx.x; s < S; s += 256) ev[s] = exp(lam[s] * job.length * rates.r[k]);
+    __syncthreads();
+    for (int idx = threadIdx.x; idx < S * S; idx += 256) W[idx] = ev[idx / S] * Ui[idx];
+    __syncthreads();
+    const int rows = (S + 3) / 4, i0 = part * rows, i1 = min(S, i0 + rows);
+    float* __restrict__ out = job.out + (size_t) k * SP * SP;
+    float* __restrict__ packed = job.out + (size_t) K * SP * SP;
+    const int NT = (S + 31) / 32;
+    for (int idx = threadIdx.x; idx < (i1 - i0) * S; idx += 256) {
+        const int i = i0 + idx / S, j = idx % S;
+        const double* __restrict__ u = U + (size_t) i * S;
+        double sum = 0.0;
+        for (int s = 0; s < S; ++s) sum = fma(u[s], W[s * S + j], sum);
+        const float v = (sum < 0.0) ? 0.0f : (float) sum;
+        out[(size_t) j * SP + i] = v;
+        if (packedT > 0) packed[((size_t) (k * NT + i / 32) * packedT + j / 2) * 64 + (i % 32) + 32 * (j % 2)] = v;
+    }
+}
+
 }  // namespace mbamd
 #endif
