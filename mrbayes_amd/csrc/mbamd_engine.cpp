@@ -90,6 +90,7 @@ struct Plan {
     int nsteps = 0, W = 1, slotsUsed = 0;        // tree-walk schedule
     std::vector<int> start;                      // general path: first table entry of each dependency level
     bool anyScale = false;
+    std::vector<int> bufsRead, bufsWritten, scalesUsed;   // buffer / scale indices the list touches (deferral hazards)
 };
 
 struct Instance {
@@ -146,6 +147,7 @@ struct Instance {
 
     bool deferred = false, pendingResult = false;
 
+    std::vector<std::pair<Plan*, int>> pending;   // deferred general-path lists (plan, cumulative scale index or -1)
     std::vector<Plan*> plans;        // small LRU cache of compiled operation lists
     uint64_t planClock = 0;
     int layoutEpoch = 0;             // bumped whenever a buffer changes between compact-tip and partials form
@@ -243,11 +245,22 @@ struct Instance {
     int runGeneric(const Plan& plan, int32_t* cum);
     int planTable(Plan& plan, const std::vector<PartialsOp>& table);
     int timedRun(const Plan& plan, int32_t* cum);
+    int flushPending();
+    int flushMatrices();
+    std::vector<MatrixJob> pendingJobs;          // queued beagleUpdateTransitionMatrices work
+    std::vector<char> pendingMatrixOut;          // matrix buffers the queued jobs write
+    int submit(Plan* plan, int cumIdx, int32_t* cumPtr);
+    bool noDefer = false;            // MBAMD_NO_DEFER: run every list at once
+    bool independentOfPending(const Plan& plan, int cumIdx);
     int accumulate(const int* idx, int n, int cumIdx, int sign);
     int integrate(const int* parent, const int* child, const int* prob, const int* wIdx, const int* fIdx,
                   const int* cumIdx, int count, double* out);
     int fetchResult(double* out);
 };
+
+#if !defined(MBAMD_HOST_EMU)
+static bool launch_mfma_split(Instance& in, const OpTables& tabs, int count);
+#endif
 
 static std::mutex g_mutex;
 static std::vector<Instance*> g_instances;
@@ -292,6 +305,7 @@ int Instance::create(int tipCount_, int partialsBufferCount, int compactBufferCo
            std::getenv("MBAMD_NO_MFMA") == nullptr;
     if (mfma) SP = 32 * NT;          // transposed matrices padded to the MFMA tile height
     mfmaWhole = std::getenv("MBAMD_MFMA_WHOLE") != nullptr;
+    noDefer = std::getenv("MBAMD_NO_DEFER") != nullptr;
 #endif
     partialsFloats = s4 ? (size_t) K * Ppad * 4 : (size_t) K * S * Ppad;
     matrixFloats = (size_t) K * SP * SP + (mfma ? (size_t) K * NT * T * 64 : 0);
@@ -366,6 +380,7 @@ void Instance::destroy()
         for (uint8_t* p : tipStates) if (p) (void) hipFree(p);
         for (int32_t* p : scale) if (p) (void) hipFree(p);
     }
+    pending.clear();
     for (Plan* pl : plans) { if (pl->d_table) (void) hipFree(pl->d_table); delete pl; }
     plans.clear();
     void* bufs[] = {matrices, d_eigen, d_freqs, d_weights, d_rates, d_pweights, d_site,
@@ -412,7 +427,7 @@ int Instance::configureWalk()
 #endif
     if (const char* e = std::getenv("MBAMD_WALK_WAVES")) {
         const int w = std::atoi(e);
-        if (w == 2 || w == 4 || w == 8) total = w;
+        if (w >= 2 && w <= 8) total = w;
     }
     if (std::getenv("MBAMD_WALK_TRACE") && !d_trace) {
         HIP_TRY(hipMalloc(&d_trace, (size_t) 4096 * 8 * 3 * sizeof(long long)));
@@ -497,35 +512,54 @@ int Instance::setEigen(int idx, const double* U, const double* Ui, const double*
     return upload(d_eigen + (size_t) idx * eigenDoubles, h.data(), eigenDoubles * sizeof(double));
 }
 
+// beagleUpdateTransitionMatrices only queues its jobs: MrBayes calls it once per eigen-system part (reference
+// src/mbbeagle.c:1475-1486), and all parts of an evaluation go out as ONE launch when the next other call arrives.
 int Instance::updateMatrices(int eigenIndex, const int* probIdx, const double* lengths, int count)
 {
     if (eigenIndex < 0 || eigenIndex >= nEigen) return fail(BEAGLE_ERROR_OUT_OF_RANGE, "beagleUpdateTransitionMatrices: eigen index");
     if (count <= 0) return BEAGLE_SUCCESS;
-    std::vector<MatrixJob> jobs(count);
-    for (int i = 0; i < count; ++i) {
+    if (K > MBAMD_MAX_RATES) return fail(BEAGLE_ERROR_NO_IMPLEMENTATION, "more than 16 rate categories");
+    for (int i = 0; i < count; ++i)
         if (probIdx[i] < 0 || probIdx[i] >= nMatrices) return fail(BEAGLE_ERROR_OUT_OF_RANGE, "beagleUpdateTransitionMatrices: matrix index");
-        jobs[i].out = matrixPtr(probIdx[i]);
-        jobs[i].length = lengths[i];
-    }
-    const MatrixJob* djobs = nullptr;
-    int rc;
-    if (K <= MBAMD_MAX_RATES) {
-        rc = stageDirect(jobs.data(), sizeof(MatrixJob) * count, (const void**) &djobs);
+    if (pendingMatrixOut.size() != (size_t) nMatrices) pendingMatrixOut.assign(nMatrices, 0);
+    bool clash = false;
+    for (int i = 0; i < count && !clash; ++i) clash = pendingMatrixOut[probIdx[i]] != 0;
+    if (clash || (pendingJobs.size() + count) * sizeof(MatrixJob) > stageCap / 4) {
+        int rc = flushMatrices();
         if (rc) return rc;
-    } else {
-        return fail(BEAGLE_ERROR_NO_IMPLEMENTATION, "more than 16 rate categories");
     }
     const double* eig = d_eigen + (size_t) eigenIndex * eigenDoubles;
+    for (int i = 0; i < count; ++i) {
+        MatrixJob j;
+        j.out = matrixPtr(probIdx[i]);
+        j.length = lengths[i];
+        j.eig = eig;
+        j.pad_ = 0.0;
+        pendingJobs.push_back(j);
+        pendingMatrixOut[probIdx[i]] = 1;
+    }
+    return BEAGLE_SUCCESS;
+}
+
+int Instance::flushMatrices()
+{
+    if (pendingJobs.empty()) return BEAGLE_SUCCESS;
+    const int count = (int) pendingJobs.size();
+    const MatrixJob* djobs = nullptr;
+    int rc = stageDirect(pendingJobs.data(), sizeof(MatrixJob) * count, (const void**) &djobs);
+    pendingJobs.clear();
+    std::fill(pendingMatrixOut.begin(), pendingMatrixOut.end(), 0);
+    if (rc) return rc;
     if (s4) {
         const int total = count * K;
-        MBAMD_LAUNCH(k_transition_matrices_s4, (unsigned) ((total + 255) / 256), 256, 0, stream, djobs, eig, rates, K, total);
+        MBAMD_LAUNCH(k_transition_matrices_s4, (unsigned) ((total + 255) / 256), 256, 0, stream, djobs, rates, K, total);
         HIP_TRY(hipGetLastError());
         return BEAGLE_SUCCESS;
     }
 #if !defined(MBAMD_HOST_EMU)
     if (S > 8 && (size_t) (S * S + S) * sizeof(double) <= 60 * 1024) {
         MBAMD_LAUNCH(k_transition_matrices_lds, (unsigned) (count * K * 4), 256, (size_t) (S * S + S) * sizeof(double), stream,
-                     djobs, eig, rates, S, SP, K, mfma ? T : 0);
+                     djobs, rates, S, SP, K, mfma ? T : 0);
         HIP_TRY(hipGetLastError());
         return BEAGLE_SUCCESS;
     }
@@ -533,10 +567,10 @@ int Instance::updateMatrices(int eigenIndex, const int* probIdx, const double* l
     const size_t nev = (size_t) count * K * S;
     rc = grow((void**) &d_ev, &evCap, nev * sizeof(double));
     if (rc) return rc;
-    MBAMD_LAUNCH(k_eigen_exponentials, (unsigned) ((nev + 255) / 256), 256, 0, stream, djobs, eig, rates, S, K, (int) nev, d_ev);
+    MBAMD_LAUNCH(k_eigen_exponentials, (unsigned) ((nev + 255) / 256), 256, 0, stream, djobs, rates, S, K, (int) nev, d_ev);
     const int threads = std::min(256, round_up(S * S, 64));
-    MBAMD_LAUNCH(k_transition_matrices_ev, (unsigned) (count * K), threads, 0, stream, djobs, eig,
-                 (const double*) d_ev, S, SP, K, 1, mfma ? T : 0);
+    MBAMD_LAUNCH(k_transition_matrices_ev, (unsigned) (count * K), threads, 0, stream, djobs, (const double*) d_ev, S, SP, K, 1,
+                 mfma ? T : 0);
     HIP_TRY(hipGetLastError());
     return BEAGLE_SUCCESS;
 }
@@ -596,7 +630,7 @@ int Instance::updatePartials(const BeagleOperation* ops, int n, int cumIdx)
             std::memcmp(pl->key.data(), raw, nints * sizeof(int)) == 0) {
             pl->lastUse = ++planClock;
             planHits++;
-            return timedRun(*pl, cumPtr);
+            return submit(pl, cumIdx, cumPtr);
         }
     planMisses++;
     std::vector<PartialsOp> dev(n);
@@ -664,6 +698,8 @@ int Instance::updatePartials(const BeagleOperation* ops, int n, int cumIdx)
     } else {
         plan = plans[0];
         for (Plan* pl : plans) if (pl->lastUse < plan->lastUse) plan = pl;
+        for (auto& pp : pending)
+            if (pp.first == plan) { int frc = flushPending(); if (frc) return frc; break; }
     }
     plan->key.assign(raw, raw + nints);
     plan->key.push_back(layoutEpoch);
@@ -675,7 +711,101 @@ int Instance::updatePartials(const BeagleOperation* ops, int n, int cumIdx)
         rc = s4 ? buildWalk(*plan, dev, dstIdx, c1Idx, c2Idx) : buildGeneric(*plan, dev, dstIdx, c1Idx, c2Idx);
     }
     if (rc) { plan->hash = 0; plan->key.clear(); return rc; }
+    plan->bufsRead.assign(c1Idx.begin(), c1Idx.end());
+    plan->bufsRead.insert(plan->bufsRead.end(), c2Idx.begin(), c2Idx.end());
+    plan->bufsWritten.assign(dstIdx.begin(), dstIdx.end());
+    plan->scalesUsed.clear();
+    for (int o = 0; o < n; ++o) {
+        if (ops[o].destinationScaleWrite != BEAGLE_OP_NONE) plan->scalesUsed.push_back(ops[o].destinationScaleWrite);
+        if (ops[o].destinationScaleRead != BEAGLE_OP_NONE) plan->scalesUsed.push_back(ops[o].destinationScaleRead);
+    }
+    return submit(plan, cumIdx, cumPtr);
+}
+
+// Run a compiled list now, or -- general-state MFMA path -- defer it: consecutive mutually independent lists
+// (one per eigen-system part, reference src/mbbeagle.c:1062-1104) are executed together, one launch per
+// dependency level over all of them, when the next call that is not a beagleUpdatePartials arrives.
+int Instance::submit(Plan* plan, int cumIdx, int32_t* cumPtr)
+{
+    {
+        int mrc = flushMatrices();
+        if (mrc) return mrc;
+    }
+#if !defined(MBAMD_HOST_EMU)
+    if (!s4 && mfma && !mfmaWhole && !noDefer) {
+        if ((int) pending.size() >= MBAMD_MAX_TABLES || !independentOfPending(*plan, cumIdx)) {
+            int rc = flushPending();
+            if (rc) return rc;
+        }
+        pending.emplace_back(plan, cumIdx);
+        return BEAGLE_SUCCESS;
+    }
+#endif
+    (void) cumIdx;
     return timedRun(*plan, cumPtr);
+}
+
+bool Instance::independentOfPending(const Plan& plan, int cumIdx)
+{
+    if (pending.empty()) return true;
+    std::vector<char> wr(nBuffers, 0), rd(nBuffers, 0), sc(scale.size(), 0);
+    for (auto& pp : pending) {
+        if (pp.first == &plan) return false;
+        for (int b : pp.first->bufsWritten) wr[b] = 1;
+        for (int b : pp.first->bufsRead) rd[b] = 1;
+        for (int i : pp.first->scalesUsed) sc[i] = 1;
+        if (pp.second >= 0) sc[pp.second] = 1;
+    }
+    for (int b : plan.bufsWritten) if (wr[b] || rd[b]) return false;
+    for (int b : plan.bufsRead) if (wr[b]) return false;
+    for (int i : plan.scalesUsed) if (sc[i]) return false;
+    if (cumIdx >= 0 && sc[cumIdx]) return false;
+    return true;
+}
+
+int Instance::flushPending()
+{
+    int mrc = flushMatrices();                   // (queued matrix jobs precede the lists that read them)
+    if (mrc) return mrc;
+    if (pending.empty()) return BEAGLE_SUCCESS;
+    std::vector<std::pair<Plan*, int>> work;
+    work.swap(pending);
+    auto cumOf = [&](int idx) { return idx >= 0 ? scale[idx] : (int32_t*) nullptr; };
+    if (work.size() == 1) return timedRun(*work[0].first, cumOf(work[0].second));
+#if !defined(MBAMD_HOST_EMU)
+    hipEvent_t ev0{}, ev1{};
+    if (timing) {
+        HIP_TRY(hipEventCreate(&ev0));
+        HIP_TRY(hipEventCreate(&ev1));
+        HIP_TRY(hipEventRecord(ev0, stream));
+    }
+    size_t maxLevels = 0;
+    for (auto& w : work) maxLevels = std::max(maxLevels, w.first->start.size() - 1);
+    for (size_t l = 0; l < maxLevels; ++l) {
+        OpTables tabs;
+        std::memset(&tabs, 0, sizeof tabs);
+        int t = 0, total = 0;
+        for (auto& w : work) {
+            const std::vector<int>& st = w.first->start;
+            if (l + 1 >= st.size() || st[l + 1] == st[l]) continue;
+            tabs.ops[t] = w.first->d_table + st[l];
+            tabs.cum[t] = cumOf(w.second);
+            tabs.start[t] = total;
+            total += st[l + 1] - st[l];
+            ++t;
+        }
+        for (int u = t; u <= MBAMD_MAX_TABLES; ++u) tabs.start[u] = 1 << 30;
+        if (total == 0) continue;
+        if (!launch_mfma_split(*this, tabs, total)) return fail(BEAGLE_ERROR_GENERAL, "no MFMA kernel for a deferred list");
+        pendingLaunches += 1;
+    }
+    HIP_TRY(hipGetLastError());
+    if (timing) {
+        HIP_TRY(hipEventRecord(ev1, stream));
+        events.emplace_back(ev0, ev1);
+    }
+#endif
+    return BEAGLE_SUCCESS;
 }
 
 // upload a freshly built table into the plan's own device buffer
@@ -968,26 +1098,38 @@ static void launch_mfma_t(Instance& in, const PartialsOp* ops, int count, int32_
     MBAMD_LAUNCH(kern, grid, 256, 0, in.stream, ops, in.S, in.SP, in.Ppad, gx, cum);
 }
 template <int NT_, int SC_, int KC_>
-static void launch_mfma_split_t(Instance& in, const PartialsOp* ops, int count, int32_t* cum)
+static void launch_mfma_split_t(Instance& in, const OpTables& tabs, int count)
 {
     constexpr int NP = 2 * KC_ * NT_;
     const int gx = in.Ppad / 32;
     auto kern = k_partials_mfma_split<NT_, SC_, KC_>;
-    MBAMD_LAUNCH(kern, (unsigned) (gx * count), 64 * NP, (size_t) NP * (16 * 64 + 32) * sizeof(float), in.stream, ops, in.S,
-                 in.SP, in.Ppad, gx, cum);
+    MBAMD_LAUNCH(kern, (unsigned) (gx * count), 64 * NP, (size_t) NP * (16 * 64 + 32) * sizeof(float), in.stream, tabs, in.S,
+                 in.SP, in.Ppad, gx);
+}
+// one launch over up to four operation tables (false: no split kernel for this shape)
+static bool launch_mfma_split(Instance& in, const OpTables& tabs, int count)
+{
+    const int S = in.S, K = in.K;
+    if (in.NT == 1 && S == 20 && K == 4) { launch_mfma_split_t<1, 20, 4>(in, tabs, count); return true; }
+    if (in.NT == 1 && S == 20 && K == 1) { launch_mfma_split_t<1, 20, 1>(in, tabs, count); return true; }
+    if (in.NT == 2 && S == 61 && K == 1) { launch_mfma_split_t<2, 61, 1>(in, tabs, count); return true; }
+    if (in.NT == 1 && K == 1) { launch_mfma_split_t<1, 0, 1>(in, tabs, count); return true; }
+    if (in.NT == 1 && K == 2) { launch_mfma_split_t<1, 0, 2>(in, tabs, count); return true; }
+    if (in.NT == 1 && K == 4) { launch_mfma_split_t<1, 0, 4>(in, tabs, count); return true; }
+    if (in.NT == 2 && K == 1) { launch_mfma_split_t<2, 0, 1>(in, tabs, count); return true; }
+    if (in.NT == 2 && K == 2) { launch_mfma_split_t<2, 0, 2>(in, tabs, count); return true; }
+    return false;
 }
 static bool launch_mfma(Instance& in, const PartialsOp* ops, int count, int32_t* cum)
 {
     const int S = in.S, K = in.K;
     if (!in.mfmaWhole) {                 // default: one wave per factor tile (MBAMD_MFMA_WHOLE=1 selects the wave-per-tile-column kernel)
-        if (in.NT == 1 && S == 20 && K == 4) { launch_mfma_split_t<1, 20, 4>(in, ops, count, cum); return true; }
-        if (in.NT == 1 && S == 20 && K == 1) { launch_mfma_split_t<1, 20, 1>(in, ops, count, cum); return true; }
-        if (in.NT == 2 && S == 61 && K == 1) { launch_mfma_split_t<2, 61, 1>(in, ops, count, cum); return true; }
-        if (in.NT == 1 && K == 1) { launch_mfma_split_t<1, 0, 1>(in, ops, count, cum); return true; }
-        if (in.NT == 1 && K == 2) { launch_mfma_split_t<1, 0, 2>(in, ops, count, cum); return true; }
-        if (in.NT == 1 && K == 4) { launch_mfma_split_t<1, 0, 4>(in, ops, count, cum); return true; }
-        if (in.NT == 2 && K == 1) { launch_mfma_split_t<2, 0, 1>(in, ops, count, cum); return true; }
-        if (in.NT == 2 && K == 2) { launch_mfma_split_t<2, 0, 2>(in, ops, count, cum); return true; }
+        OpTables tabs;
+        std::memset(&tabs, 0, sizeof tabs);
+        tabs.ops[0] = ops;
+        tabs.cum[0] = cum;
+        for (int t = 1; t <= MBAMD_MAX_TABLES; ++t) tabs.start[t] = 1 << 30;
+        if (launch_mfma_split(in, tabs, count)) return true;
     }
     if (in.NT == 1) {
         if (S == 20 && K == 4) launch_mfma_t<1, 20, 4>(in, ops, count, cum);
@@ -1152,6 +1294,9 @@ int Instance::integrate(const int* parent, const int* child, const int* prob, co
         }
     }
     if (s4) MBAMD_LAUNCH(k_integrate_lnl<true>, (unsigned) nblocks, 64, 0, stream, a, S, SP, K, P, Ppad, geom, (const double*) d_pweights, d_site, h_sums_dev);
+#if !defined(MBAMD_HOST_EMU)
+    else if (S >= 8) MBAMD_LAUNCH(k_integrate_lnl_wide, (unsigned) nblocks, 256, 0, stream, a, S, SP, K, P, Ppad, (const double*) d_pweights, d_site, h_sums_dev);
+#endif
     else    MBAMD_LAUNCH(k_integrate_lnl<false>, (unsigned) nblocks, 64, 0, stream, a, S, SP, K, P, Ppad, geom, (const double*) d_pweights, d_site, h_sums_dev);
     HIP_TRY(hipGetLastError());
     haveSite = true;
@@ -1219,10 +1364,17 @@ static void buildResources()
 // =============================================================================================
 using namespace mbamd;
 
-#define GET_INSTANCE(id)                                                                             \
+#define GET_INSTANCE_NOFLUSH(id)                                                                     \
     Instance* in = lookup(id);                                                                       \
     if (!in) return fail(BEAGLE_ERROR_UNINITIALIZED_INSTANCE, "no such instance");                   \
     (void) hipSetDevice(in->device)
+// every entry point except beagleUpdatePartials first runs the lists deferred so far
+#define GET_INSTANCE(id)                                                                             \
+    GET_INSTANCE_NOFLUSH(id);                                                                        \
+    if (!in->pending.empty() || !in->pendingJobs.empty()) {                                          \
+        int frc_ = in->flushPending();                                                               \
+        if (frc_ != BEAGLE_SUCCESS) return frc_;                                                     \
+    }
 
 extern "C" {
 
@@ -1387,7 +1539,11 @@ int beagleUpdateTransitionMatrices(int instance, int eigenIndex, const int* prob
                                    const double* edgeLengths, int count)
 {
     StatTimer st_(ST_MATRICES);
-    GET_INSTANCE(instance);
+    GET_INSTANCE_NOFLUSH(instance);
+    if (!in->pending.empty()) {                  // deferred lists read the matrices about to be replaced
+        int frc_ = in->flushPending();
+        if (frc_ != BEAGLE_SUCCESS) return frc_;
+    }
     if (firstDerivativeIndices || secondDerivativeIndices)
         return fail(BEAGLE_ERROR_NO_IMPLEMENTATION, "beagleUpdateTransitionMatrices: derivatives");
     return in->updateMatrices(eigenIndex, probabilityIndices, edgeLengths, count);
@@ -1406,7 +1562,7 @@ int beagleGetTransitionMatrix(int instance, int matrixIndex, double* outMatrix)
 int beagleUpdatePartials(int instance, const BeagleOperation* operations, int operationCount, int cumulativeScaleIndex)
 {
     StatTimer st_(ST_PARTIALS);
-    GET_INSTANCE(instance);
+    GET_INSTANCE_NOFLUSH(instance);
     return in->updatePartials(operations, operationCount, cumulativeScaleIndex);
 }
 int beagleWaitForPartials(int instance, const int* destinationPartials, int destinationPartialsCount)

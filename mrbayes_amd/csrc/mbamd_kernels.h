@@ -323,8 +323,10 @@ k_rescale_gen(const PartialsOp* __restrict__ ops, int S, int K, int Ppad, int32_
 //   transposed == 1: out[k][j][i] zero-padded rows of SP floats (general path)
 // ---------------------------------------------------------------------------------------------
 struct MatrixJob {
-    float* out;        // matrix buffer (K matrices)
-    double length;     // branch length
+    float* out;          // matrix buffer (K matrices)
+    double length;       // branch length
+    const double* eig;   // its eigen-system [U | U^-1 | lambda]: jobs of several systems share one launch
+    double pad_;
 };
 
 // category rates travel as a kernel argument (no host-to-device copy per beagleSetCategoryRates)
@@ -335,30 +337,28 @@ struct RatesArg { double r[MBAMD_MAX_RATES]; };
 // below then reads it (second launch on the same stream, so no barrier is needed).
 // `jobs` may live in pinned host memory (read once, directly over the host link).
 __global__ void __launch_bounds__(256)
-k_eigen_exponentials(const MatrixJob* __restrict__ jobs, const double* __restrict__ eig,
-                     RatesArg rates, int S, int K, int total, double* __restrict__ ev)
+k_eigen_exponentials(const MatrixJob* __restrict__ jobs, RatesArg rates, int S, int K, int total, double* __restrict__ ev)
 {
     const int g = blockIdx.x * blockDim.x + threadIdx.x;
     if (g >= total) return;
     const int s = g % S, bk = g / S;
     const int b = bk / K, k = bk % K;
-    const double* __restrict__ lam = eig + (size_t) 2 * S * S;
+    const double* __restrict__ lam = jobs[b].eig + (size_t) 2 * S * S;
     ev[g] = exp(lam[s] * jobs[b].length * rates.r[k]);
 }
 
 // 4-state path: one thread per (branch, category) does the whole 4x4 matrix, exps included
 // (TiProbs_Gen for S = 4, src/likelihood.c:9498-9545); output transposed mT[j][i] = P(i->j).
 __global__ void __launch_bounds__(256)
-k_transition_matrices_s4(const MatrixJob* __restrict__ jobs, const double* __restrict__ eig, RatesArg rates,
-                         int K, int total)
+k_transition_matrices_s4(const MatrixJob* __restrict__ jobs, RatesArg rates, int K, int total)
 {
     const int g = blockIdx.x * blockDim.x + threadIdx.x;
     if (g >= total) return;
     const int b = g / K, k = g % K;
-    const double* __restrict__ U = eig;
-    const double* __restrict__ Ui = eig + 16;
-    const double* __restrict__ lam = eig + 32;
     const MatrixJob job = jobs[b];
+    const double* __restrict__ U = job.eig;
+    const double* __restrict__ Ui = job.eig + 16;
+    const double* __restrict__ lam = job.eig + 32;
     double e[4];
     for (int s = 0; s < 4; ++s) e[s] = exp(lam[s] * job.length * rates.r[k]);
     float* __restrict__ out = job.out + (size_t) k * 16;
@@ -373,12 +373,12 @@ k_transition_matrices_s4(const MatrixJob* __restrict__ jobs, const double* __res
 // packedT > 0: additionally write the MFMA A-operand copy behind the K transposed matrices:
 //   packed[((k*NT + i/32)*T + j/2)*64 + (i%32) + 32*(j%2)] = P_k(i->j),  NT = ceil(S/32), T = packedT = ceil(S/2)
 __global__ void __launch_bounds__(256)
-k_transition_matrices_ev(const MatrixJob* __restrict__ jobs, const double* __restrict__ eig,
-                         const double* __restrict__ ev, int S, int SP, int K, int transposed, int packedT)
+k_transition_matrices_ev(const MatrixJob* __restrict__ jobs, const double* __restrict__ ev, int S, int SP, int K,
+                         int transposed, int packedT)
 {
     const int b = blockIdx.x / K, k = blockIdx.x % K;
-    const double* __restrict__ U = eig;
-    const double* __restrict__ Ui = eig + (size_t) S * S;
+    const double* __restrict__ U = jobs[b].eig;
+    const double* __restrict__ Ui = jobs[b].eig + (size_t) S * S;
     const double* __restrict__ e = ev + (size_t) blockIdx.x * S;
     float* __restrict__ out = jobs[b].out + (size_t) k * SP * SP;
     for (int idx = threadIdx.x; idx < S * S; idx += blockDim.x) {

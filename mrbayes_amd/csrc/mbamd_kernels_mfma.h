@@ -181,9 +181,19 @@ k_partials_mfma(const PartialsOp* __restrict__ ops, int S_rt, int SP, int Ppad, 
 // multiply, reduce the per-pattern maximum through LDS, rescale and store.
 // blockDim.x = 64 * 2*K*NT (<= 512), dynamic LDS = 2*K*NT * 4 KiB + 2*K*NT * 32 floats.
 // ---------------------------------------------------------------------------------------------
+// Up to four operation tables per launch: MrBayes issues one beagleUpdatePartials per eigen-system part
+// (codon M3: three), mutually independent; the engine defers them and runs each dependency level
+// of all parts as ONE launch.
+#define MBAMD_MAX_TABLES 4
+struct OpTables {
+    const PartialsOp* ops[MBAMD_MAX_TABLES];
+    int32_t* cum[MBAMD_MAX_TABLES];
+    int start[MBAMD_MAX_TABLES + 1];       // operation index range [start[t], start[t+1]) belongs to table t
+};
+
 template <int NT, int SC, int KC>
 __global__ void __launch_bounds__(64 * 2 * KC * NT)
-k_partials_mfma_split(const PartialsOp* __restrict__ ops, int S_rt, int SP, int Ppad, int gx, int32_t* __restrict__ cumulative)
+k_partials_mfma_split(OpTables tabs, int S_rt, int SP, int Ppad, int gx)
 {
     constexpr int NP = 2 * KC * NT;                 // pieces = waves
     extern __shared__ float lds_f[];
@@ -194,7 +204,11 @@ k_partials_mfma_split(const PartialsOp* __restrict__ ops, int S_rt, int SP, int 
     const int wave = __builtin_amdgcn_readfirstlane((int) (threadIdx.x >> 6)), lane = threadIdx.x & 63;
     const int k = wave / (2 * NT), c = (wave / NT) & 1, it = wave % NT;
     const int c0 = bx * 32;
-    const MBAMD_AS_CONST PartialsOp* __restrict__ op = as_const(ops) + by;
+    int tsel = 0;
+#pragma unroll
+    for (int t = 1; t < MBAMD_MAX_TABLES; ++t) tsel += by >= tabs.start[t] ? 1 : 0;
+    const MBAMD_AS_CONST PartialsOp* __restrict__ op = as_const(tabs.ops[tsel]) + (by - tabs.start[tsel]);
+    int32_t* __restrict__ cumulative = tabs.cum[tsel];
     const int kind = c ? op->c2_kind : op->c1_kind;
     const void* child = c ? op->c2 : op->c1;
     const float* mbase = c ? op->m2 : op->m1;
@@ -288,18 +302,17 @@ k_partials_mfma_split(const PartialsOp* __restrict__ ops, int S_rt, int SP, int 
 // grid = count * K * 4, block = 256, dynamic LDS = (S*S + S) doubles.
 // ---------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(256)
-k_transition_matrices_lds(const MatrixJob* __restrict__ jobs, const double* __restrict__ eig, RatesArg rates, int S,
-                          int SP, int K, int packedT)
+k_transition_matrices_lds(const MatrixJob* __restrict__ jobs, RatesArg rates, int S, int SP, int K, int packedT)
 {
     extern __shared__ double lds_d[];
     double* W = lds_d;                 // [S][S]
     double* ev = lds_d + S * S;        // [S]
     const int part = blockIdx.x & 3, bk = blockIdx.x >> 2;
     const int b = bk / K, k = bk % K;
-    const double* __restrict__ U = eig;
-    const double* __restrict__ Ui = eig + (size_t) S * S;
-    const double* __restrict__ lam = eig + (size_t) 2 * S * S;
     const MatrixJob job = jobs[b];
+    const double* __restrict__ U = job.eig;
+    const double* __restrict__ Ui = job.eig + (size_t) S * S;
+    const double* __restrict__ lam = job.eig + (size_t) 2 * S * S;
     for (int s = threadIdx.x; s < S; s += 256) ev[s] = exp(lam[s] * job.length * rates.r[k]);
     __syncthreads();
     for (int idx = threadIdx.x; idx < S * S; idx += 256) W[idx] = ev[idx / S] * Ui[idx];
@@ -317,6 +330,75 @@ k_transition_matrices_lds(const MatrixJob* __restrict__ jobs, const double* __re
         out[(size_t) j * SP + i] = v;
         if (packedT > 0) packed[((size_t) (k * NT + i / 32) * packedT + j / 2) * 64 + (i % 32) + 32 * (j % 2)] = v;
     }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Root / edge integration for the general-state path with four threads per pattern (each takes the
+// states i = g mod 4): same arithmetic as k_integrate_lnl<false>, a quarter of the serial chain.
+// grid = P_pad/64, block = 256 (lane = pattern, wave = state group).
+// ---------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256)
+k_integrate_lnl_wide(IntegrateArgs a, int S, int SP, int K, int P, int Ppad, const double* __restrict__ pattern_weights,
+                     double* __restrict__ site, double* __restrict__ wsite)
+{
+    __shared__ double part[MBAMD_MAX_SUBSETS][4][64];
+    const int p = threadIdx.x & 63, g = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + p;
+    const bool live = c < P;
+    for (int n = 0; n < a.count; ++n) {
+        double like = 0.0;
+        if (live) {
+            const float* __restrict__ par = a.parent[n];
+            const double* __restrict__ fr = a.freqs[n];
+            for (int k = 0; k < K; ++k) {
+                double cat = 0.0;
+                if (a.child[n] == nullptr) {
+                    for (int i = g; i < S; i += 4) cat += (double) par[((size_t) k * S + i) * Ppad + c] * fr[i];
+                } else if (a.child_kind[n] == CHILD_STATES) {
+                    const unsigned s = reinterpret_cast<const uint8_t*>(a.child[n])[c];
+                    const float* __restrict__ mrow = a.matrix[n] + (size_t) k * SP * SP + (size_t) (s < (unsigned) S ? s : 0) * SP;
+                    for (int i = g; i < S; i += 4) {
+                        const float pc = (s >= (unsigned) S) ? 1.0f : mrow[i];
+                        cat += (double) (par[((size_t) k * S + i) * Ppad + c] * pc) * fr[i];
+                    }
+                } else {
+                    const float* __restrict__ ch = reinterpret_cast<const float*>(a.child[n]);
+                    const float* __restrict__ m = a.matrix[n] + (size_t) k * SP * SP;
+                    for (int i = g; i < S; i += 4) {
+                        float acc = 0.0f;
+                        for (int j = 0; j < S; ++j) acc = fmaf(m[(size_t) j * SP + i], ch[((size_t) k * S + j) * Ppad + c], acc);
+                        cat += (double) (par[((size_t) k * S + i) * Ppad + c] * acc) * fr[i];
+                    }
+                }
+                like += cat * a.weights[n][k];
+            }
+        }
+        part[n][g][p] = like;
+    }
+    __syncthreads();
+    if (g != 0) return;
+    double wl = 0.0;
+    if (live) {
+        int emax = -2147483647;
+        for (int n = 0; n < a.count; ++n) {
+            const int e = a.cum[n] ? a.cum[n][c] : 0;
+            emax = e > emax ? e : emax;
+        }
+        double total = 0.0;
+        for (int n = 0; n < a.count; ++n) {
+            const double like = (part[n][0][p] + part[n][1][p]) + (part[n][2][p] + part[n][3][p]);
+            const int e = a.cum[n] ? a.cum[n][c] : 0;
+            total += ldexp(like, e - emax);
+        }
+        const double lnl = log(total) + (double) emax * 0.69314718055994530942;
+        site[c] = lnl;
+        wl = lnl * pattern_weights[c];
+    } else if (c < Ppad) {
+        site[c] = 0.0;
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) wl += __shfl_down(wl, off);
+    if (p == 0) wsite[blockIdx.x] = wl;
 }
 
 }  // namespace mbamd

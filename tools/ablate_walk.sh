@@ -8,6 +8,5 @@ for l in sys.stdin:
     elif 'amdgpu.ids' not in l: print(l.strip()[:300])
 "; }
 {
-timeout 600 python -m pytest tests/test_engine_gpu.py -x -q 2>&1 | tail -5
-for W in 4 8; do for cfg in c2 c4; do echo "== $cfg total waves=$W"; CFG=$cfg MBAMD_WALK_WAVES=$W run; done; done
+for W in ${WAVES:-3 4 5 6 7 8}; do for cfg in c2 c4; do echo "== $cfg total waves=$W"; CFG=$cfg MBAMD_WALK_WAVES=$W run; done; done
 } 2>&1 | tee gpurun_out/ablate_walk.log

@@ -18,7 +18,7 @@ acc=collections.defaultdict(lambda: collections.defaultdict(list))
 for r in csv.DictReader(open(sys.argv[1])):
     acc[r['Kernel_Name'][:48]][r['Counter_Name']].append(float(r['Counter_Value']))
 for k,v in acc.items():
-    if 'walk' in k or 'mfma' in k:
+    if "walk" in k or "mfma" in k:
         print(k, {c: round(sum(x)/len(x),1) for c,x in v.items()}, 'dispatches', len(next(iter(v.values()))))
 PY
 done
