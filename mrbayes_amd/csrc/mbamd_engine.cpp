@@ -102,6 +102,7 @@ struct Instance {
     bool mfmaWhole = false;          // MBAMD_MFMA_WHOLE: one wave per (operation, 32 patterns) instead of per factor tile
     int walkWaves = 1, walkSlots = 16;   // tree-walk kernel: waves per pattern block, LDS slots per workgroup
     int lastWalkSteps = 0, lastWalkSlots = 0;
+    bool walkKSplit = false;         // MBAMD_WALK_KSPLIT=1: two waves per operation (category split); measured slower (profiles/)
     long long* d_trace = nullptr;    // MBAMD_WALK_TRACE: per-step clock stamps of workgroup 0 (timing experiments)
 
     int NT = 0, T = 0;               // MFMA packing: i-tiles of 32 rows, j-pairs
@@ -408,7 +409,7 @@ int Instance::configureWalk()
     const int resident = std::max(1, std::min(perCU, 4));
     // measured (profiles/): once every CU has a workgroup, 3 compute waves + loader beat 7 + loader (LDS slots
     // per workgroup, not waves, are the scarce resource); small grids take the wider workgroup for tree parallelism
-    total = perCU >= 8 ? 2 : (wgs >= numCU ? 4 : 8);
+    total = perCU >= 8 ? 2 : (perCU >= 3 ? 4 : (wgs >= numCU ? 5 : 8));
     ldsBudget = (160 * 1024) / resident - 512;
     hipError_t err = hipSuccess;
     const int maxLds = 160 * 1024;
@@ -433,6 +434,7 @@ int Instance::configureWalk()
         HIP_TRY(hipMalloc(&d_trace, (size_t) 4096 * 8 * 3 * sizeof(long long)));
         HIP_TRY(hipMemset(d_trace, 0, (size_t) 4096 * 8 * 3 * sizeof(long long)));
     }
+    if (const char* ks = std::getenv("MBAMD_WALK_KSPLIT")) walkKSplit = std::atoi(ks) != 0;
     walkWaves = total - 1;
     const int fixedUnits = walk_lds_units(K, walkWaves, 0);
     walkSlots = std::max(2, std::min(64, (ldsBudget / 16 - fixedUnits) / walk_slot_units(K)));
@@ -888,9 +890,39 @@ int Instance::buildWalk(Plan& plan, std::vector<PartialsOp>& dev, const std::vec
         if (prod2[o] >= 0 && prod2[o] != prod1[o]) { consumers[prod2[o]].push_back(o); indeg[o]++; }
     }
     for (int o = 0; o < n; ++o) pendingReads[o] = (int) consumers[o].size();
+    // Scheduling priority: Sethi-Ullman order of the operation forest (at every node the child subtree
+    // that needs more live values first).  MrBayes' own post-order visits the left child first whatever
+    // its size, which on a 500-taxon tree keeps up to ~23 partials live; this order needs ~log2(N).
+    std::vector<int> prio(n, 0);
+    if (!inOrder) {
+        std::vector<int> need(n, 1);
+        for (int o = 0; o < n; ++o) {                     // children precede parents in the list
+            const int a = prod1[o], b = (prod2[o] != prod1[o]) ? prod2[o] : -1;
+            const int na = a >= 0 ? need[a] : 0, nb = b >= 0 ? need[b] : 0;
+            need[o] = std::max(1, (na == nb) ? na + (na > 0 ? 1 : 0) : std::max(na, nb));
+        }
+        int counter = 0;
+        std::vector<std::pair<int, int>> stack;           // (op, state)
+        for (int root = n - 1; root >= 0; --root) {
+            if (!consumers[root].empty()) continue;
+            stack.emplace_back(root, 0);
+            while (!stack.empty()) {
+                auto [o, st] = stack.back();
+                stack.pop_back();
+                if (st == 1) { prio[o] = counter++; continue; }
+                stack.emplace_back(o, 1);
+                int a = prod1[o], b = (prod2[o] != prod1[o]) ? prod2[o] : -1;
+                if (a >= 0 && b >= 0 && need[b] > need[a]) std::swap(a, b);
+                if (b >= 0) stack.emplace_back(b, 0);     // pushed first = visited second
+                if (a >= 0) stack.emplace_back(a, 0);
+            }
+        }
+    } else {
+        for (int o = 0; o < n; ++o) prio[o] = o;
+    }
     auto nextUse = [&](int o) {                           // list position of the earliest unscheduled consumer
         int best = 1 << 30;
-        for (int q : consumers[o]) best = std::min(best, q);   // (scheduled consumers are removed as they are placed)
+        for (int q : consumers[o]) best = std::min(best, prio[q]);   // (scheduled consumers are removed as they are placed)
         return best;
     };
 
@@ -904,7 +936,7 @@ int Instance::buildWalk(Plan& plan, std::vector<PartialsOp>& dev, const std::vec
 
     for (int s = 0; done < n; ++s) {
         if (s > 4 * n + 16) return fail(BEAGLE_ERROR_GENERAL, "tree-walk scheduler made no progress");
-        std::sort(ready.begin(), ready.end());
+        std::sort(ready.begin(), ready.end(), [&](int x, int y) { return prio[x] < prio[y]; });
         int live = 0;
         for (int t = 0; t < maxSlots; ++t) live += slotHolder[t] >= 0;
         if (!inOrder && live + 2 * W > maxSlots)            // under LDS pressure prefer operations that retire values
@@ -916,9 +948,14 @@ int Instance::buildWalk(Plan& plan, std::vector<PartialsOp>& dev, const std::vec
         std::vector<int> chosen;
         std::vector<char> readThisStep(n, 0);              // values read by operations already placed in this step
         bool needDrain = false;
+        // pass 0 places what fits without evicting anything; only a step that would stay empty may evict
+        // (a re-read from HBM costs a store drain and a synchronous copy by the loader -- far more than a bubble)
+        for (int pass = 0; pass < 2; ++pass) {
+        if (pass == 1 && !chosen.empty()) break;
+        const bool mayEvict = pass == 1;
         for (size_t ri = 0; ri < ready.size() && (int) chosen.size() < W; ++ri) {
             const int o = ready[ri];
-            if (inOrder && o != done) break;
+            if (inOrder && o != (int) (done + chosen.size())) break;
             PartialsOp d = dev[o];
             const int pr[2] = {prod1[o], prod2[o]};
             uint8_t* kind[2] = {&d.c1_kind, &d.c2_kind};
@@ -958,7 +995,7 @@ int Instance::buildWalk(Plan& plan, std::vector<PartialsOp>& dev, const std::vec
                 }
                 // the loader copies it in during step s-1: the slot must be unused from step s-1 on
                 int sl = claimFree(s - 1);
-                if (sl < 0) {
+                if (sl < 0 && mayEvict) {
                     // (a value evicted now was last touched before step s-1, so nobody reads it in s-1)
                     const int ev = evict(s - 1);
                     if (ev >= 0) { evicted.emplace_back(ev, slotHolder[ev]); sl = ev; }
@@ -976,7 +1013,7 @@ int Instance::buildWalk(Plan& plan, std::vector<PartialsOp>& dev, const std::vec
                 dsl = claimFree(s);
                 if (dsl < 0 && d.c1_kind == CHILD_LDS && lastReaderIsMe(pr[0])) dsl = d.c1_slot;
                 if (dsl < 0 && d.c2_kind == CHILD_LDS && pr[1] != pr[0] && lastReaderIsMe(pr[1])) dsl = d.c2_slot;
-                if (dsl < 0) {
+                if (dsl < 0 && mayEvict) {
                     const int ev = evict(s);
                     if (ev >= 0) { evicted.emplace_back(ev, slotHolder[ev]); dsl = ev; }
                 }
@@ -1015,6 +1052,7 @@ int Instance::buildWalk(Plan& plan, std::vector<PartialsOp>& dev, const std::vec
             stepOf[o] = s;
             needDrain |= reload;
             chosen.push_back(o);
+        }
         }
         for (int o : chosen) ready.erase(std::find(ready.begin(), ready.end(), o));
         steps.push_back(chosen);
@@ -1056,6 +1094,16 @@ int Instance::buildWalk(Plan& plan, std::vector<PartialsOp>& dev, const std::vec
             e.flags |= fl;
         }
     }
+    if (std::getenv("MBAMD_VERBOSE")) {
+        int reloads = 0, globals = 0, drains = 0;
+        for (int o = 0; o < n; ++o) {
+            reloads += (dev[o].c1_kind == CHILD_RELOAD) + (dev[o].c2_kind == CHILD_RELOAD);
+            globals += (dev[o].c1_kind == CHILD_PARTIALS) + (dev[o].c2_kind == CHILD_PARTIALS);
+        }
+        for (char d : drainBefore) drains += d;
+        std::fprintf(stderr, "[mbamd] walk plan: %d ops, W=%d, %d steps, %d slots (max %d), %d reloads, %d global children, %d drains\n",
+                     n, W, nsteps, slotsUsed, maxSlots, reloads, globals, drains);
+    }
     lastWalkSteps = nsteps;
     lastWalkSlots = slotsUsed;
     plan.nsteps = nsteps;
@@ -1072,12 +1120,15 @@ int Instance::runWalk(const Plan& plan, int32_t* cum)
 #if defined(MBAMD_HOST_EMU)
     const int walkThreads = 64;
     const int walkArgW = std::getenv("MBAMD_EMU_REVERSE_STEP") ? -W : W;
+    const int ksplit = 1;
 #else
-    const int walkThreads = (W + 1) * 64, walkArgW = W;       // W compute waves + the writer wave
+    // two waves per table entry (category split) when K is even and the workgroup stays within 8 waves
+    const int ksplit = (walkKSplit && K % 2 == 0 && 2 * W + 1 <= 8) ? 2 : 1;
+    const int walkThreads = (W * ksplit + 1) * 64, walkArgW = W;      // compute waves + the loader wave
 #endif
     switch (K) {
 #define MBAMD_WALK_CASE(KK) \
-    case KK: MBAMD_LAUNCH(k_walk_s4<KK>, grid, walkThreads, lds, stream, (const PartialsOp*) plan.d_table, nsteps, walkArgW, std::max(1, plan.slotsUsed), geom, cum, d_trace); break;
+    case KK: MBAMD_LAUNCH(k_walk_s4<KK>, grid, walkThreads, lds, stream, (const PartialsOp*) plan.d_table, nsteps, walkArgW, std::max(1, plan.slotsUsed), ksplit, geom, cum, d_trace); break;
         MBAMD_WALK_CASE(1) MBAMD_WALK_CASE(2) MBAMD_WALK_CASE(3) MBAMD_WALK_CASE(4)
         MBAMD_WALK_CASE(5) MBAMD_WALK_CASE(6) MBAMD_WALK_CASE(7) MBAMD_WALK_CASE(8)
 #undef MBAMD_WALK_CASE

@@ -44,7 +44,8 @@ __host__ __device__ inline int walk_input_units(int K) { return 4 + 8 * K + 8 + 
 __host__ __device__ inline int walk_slot_units(int K) { return 64 * K; }               // f4 per value slot
 __host__ __device__ inline int walk_lds_units(int K, int W, int slots)
 {
-    return 2 * W * walk_input_units(K) + slots * walk_slot_units(K) + 7 * 4;      // + the loader's descriptor staging
+    return 2 * W * walk_input_units(K) + slots * walk_slot_units(K) + 7 * 4      // + the loader's descriptor staging
+           + W * 2 * 16;                                                          // + per-entry max exchange (category split)
 }
 #define MBAMD_WALK_MAXW 7
 
@@ -74,19 +75,18 @@ struct WalkFields {
     int c1_kind, c2_kind, c1_slot, c2_slot, dst_slot, scale_mode, flags;
 };
 
-// One operation, all inputs already in LDS / registers:
-//   M1, M2   the lane's rows of the 2K transposed matrices (Mat4)
+// One operation (or the KN categories [k0, k0+KN) of it), all inputs already in LDS / registers:
+//   M1, M2   the lane's rows of the transposed matrices (Mat4)
 //   a, b     the children's values per category (tips: the 0/1 vector)
-// product of the two child factors, rescale, result -> LDS slot (if a parent will read it) and HBM.
-template <int K>
-__device__ __forceinline__ void walk_math(const WalkFields& op, const Mat4 (&M1)[K], const Mat4 (&M2)[K], const f4 (&a)[K],
-                                          const f4 (&b)[K], int e_read, size_t poff, size_t soff, int lane, f4* slots,
-                                          int& cum_e)
+// walk_products: product of the two child factors and its per-pattern maximum;
+// walk_store:    rescale by 2^-e, result -> HBM and -> LDS slot (if a parent will read it).
+template <int KN>
+__device__ __forceinline__ float walk_products(const Mat4 (&M1)[KN], const Mat4 (&M2)[KN], const f4 (&a)[KN], const f4 (&b)[KN],
+                                               f4 (&out)[KN])
 {
-    f4 out[K];
     float mx = 0.0f;
 #pragma unroll
-    for (int k = 0; k < K; ++k) {
+    for (int k = 0; k < KN; ++k) {
         const f4 f1 = mat4_mul(M1[k], a[k]);
         const f4 f2 = mat4_mul(M2[k], b[k]);
         out[k].x = f1.x * f2.x;
@@ -95,24 +95,39 @@ __device__ __forceinline__ void walk_math(const WalkFields& op, const Mat4 (&M1)
         out[k].w = f1.w * f2.w;
         mx = fmaxf(mx, max4(out[k]));
     }
-    int e = 0;
-    if (op.scale_mode == SCALE_WRITE) { e = scale_exponent(mx); cum_e += e; }
-    else if (op.scale_mode == SCALE_READ) e = e_read;
-    MBAMD_AS_GLOBAL f4* __restrict__ dst = as_global(reinterpret_cast<f4*>(op.dst)) + poff;
+    return mx;
+}
+template <int K, int KN>
+__device__ __forceinline__ void walk_store(const WalkFields& op, f4 (&out)[KN], int e, int k0, bool owner, size_t poff, size_t soff,
+                                           int lane, f4* slots)
+{
+    MBAMD_AS_GLOBAL f4* __restrict__ dst = as_global(reinterpret_cast<f4*>(op.dst)) + poff + k0 * 64;
 #pragma unroll
-    for (int k = 0; k < K; ++k) {           // multiplying by 2^0 is exact: no branch needed
+    for (int k = 0; k < KN; ++k) {          // multiplying by 2^0 is exact: no branch needed
         out[k].x = scale_pow2(out[k].x, -e);
         out[k].y = scale_pow2(out[k].y, -e);
         out[k].z = scale_pow2(out[k].z, -e);
         out[k].w = scale_pow2(out[k].w, -e);
         dst[k * 64] = out[k];               // 4K KiB contiguous per node update; never waited for
     }
-    if (op.scale_mode == SCALE_WRITE) as_global(op.scale)[soff] = e;
+    if (owner && op.scale_mode == SCALE_WRITE) as_global(op.scale)[soff] = e;
     if (op.dst_slot != MBAMD_NO_SLOT) {
-        f4* slot = slots + op.dst_slot * walk_slot_units(K) + lane;
+        f4* slot = slots + op.dst_slot * walk_slot_units(K) + k0 * 64 + lane;
 #pragma unroll
-        for (int k = 0; k < K; ++k) slot[k * 64] = out[k];
+        for (int k = 0; k < KN; ++k) slot[k * 64] = out[k];
     }
+}
+template <int K>
+__device__ __forceinline__ void walk_math(const WalkFields& op, const Mat4 (&M1)[K], const Mat4 (&M2)[K], const f4 (&a)[K],
+                                          const f4 (&b)[K], int e_read, size_t poff, size_t soff, int lane, f4* slots,
+                                          int& cum_e)
+{
+    f4 out[K];
+    const float mx = walk_products<K>(M1, M2, a, b, out);
+    int e = 0;
+    if (op.scale_mode == SCALE_WRITE) { e = scale_exponent(mx); cum_e += e; }
+    else if (op.scale_mode == SCALE_READ) e = e_read;
+    walk_store<K, K>(op, out, e, 0, true, poff, soff, lane, slots);
 }
 
 #if !defined(MBAMD_HOST_EMU)
@@ -237,7 +252,7 @@ __device__ __forceinline__ void walk_load_global_children(const WalkRow& row, in
 //  other -- lanes never exchange data -- and plays the loader where the GPU's loader would act.)
 template <int K>
 __global__ void __launch_bounds__(512, (K <= 4 ? 4 : 2))
-k_walk_s4(const PartialsOp* __restrict__ ops, int nsteps, int W, int nslots, BlockGeom g,
+k_walk_s4(const PartialsOp* __restrict__ ops, int nsteps, int W, int nslots, int ksplit, BlockGeom g,
           int32_t* __restrict__ cumulative, long long* __restrict__ trace)
 {
     const int lane = threadIdx.x & 63;
@@ -246,7 +261,7 @@ k_walk_s4(const PartialsOp* __restrict__ ops, int nsteps, int W, int nslots, Blo
     const size_t soff = (size_t) blockIdx.x * g.sstride + lane;
     int cum_e = 0;
 #if defined(MBAMD_HOST_EMU)
-    (void) trace; (void) nslots;
+    (void) trace; (void) nslots; (void) ksplit;
     const bool reversed = W < 0;                 // test hook: run a step's entries in the opposite order
     if (reversed) W = -W;
     f4* slots = reinterpret_cast<f4*>(mbamd_emu_dyn_lds()) + 2 * W * walk_input_units(K);
@@ -294,7 +309,8 @@ k_walk_s4(const PartialsOp* __restrict__ ops, int nsteps, int W, int nslots, Blo
     // (timing experiments: MBAMD_WALK_TRACE makes block 0 record s_memtime stamps [step][wave][3])
     const bool tracing = trace != nullptr && blockIdx.x == 0 && lane == 0;
 #define MBAMD_STAMP(STEP, I) if (tracing) trace[((size_t) (STEP) * 8 + wave) * 3 + (I)] = (long long) __builtin_amdgcn_s_memtime();
-    if (wave == W) {
+    const int CW = W * ksplit;                                       // compute waves: `ksplit` per table entry
+    if (wave == CW) {
         // ---- loader wave: inputs of step s+1 go to LDS while the compute waves work on step s ------------
         unsigned* fdesc = reinterpret_cast<unsigned*>(slots + nslots * walk_slot_units(K));   // [7][16] dwords
         const size_t tblock = (size_t) blockIdx.x * g.tstride;
@@ -318,6 +334,7 @@ k_walk_s4(const PartialsOp* __restrict__ ops, int nsteps, int W, int nslots, Blo
             if (walk_row_dword(rowB, 0, 13) & (MBAMD_OP_HAS_GLOBAL << 16)) walk_load_global_children<K>(rowB, W, poff, lane, slots);
             rowB = rowC;
             rowC = walk_row_request(ops, s + 3, W, lane);
+            if (ksplit == 2) walk_step_barrier();                    // (the compute waves' max exchange)
             MBAMD_STAMP(s, 1)
             walk_step_barrier();
             MBAMD_STAMP(s, 2)
@@ -325,10 +342,16 @@ k_walk_s4(const PartialsOp* __restrict__ ops, int nsteps, int W, int nslots, Blo
         return;
     }
     // ---- compute waves: LDS in, arithmetic, stores out; no vector loads -------------------------------
+    // ksplit == 2 (even K): two waves share a table entry, each takes half of its categories; the
+    // per-pattern maximum is exchanged through LDS at a mid-step barrier.  Halves the serial
+    // instruction stream of an operation without needing more LDS slots.
+    const int entry = ksplit == 2 ? wave >> 1 : wave;
+    const int khalf = ksplit == 2 ? wave & 1 : 0;
+    float* mxbuf = reinterpret_cast<float*>(slots + nslots * walk_slot_units(K) + 7 * 4) + (entry * 2) * 64;
     walk_step_barrier();                                             // barrier(-1)
     for (int s = 0; s < nsteps; ++s) {
         MBAMD_STAMP(s, 0)
-        const f4* in = lds_all + ((s & 1) * W + wave) * IU;
+        const f4* in = lds_all + ((s & 1) * W + entry) * IU;
         const f4 d0 = in[0], d2 = in[2], d3 = in[3];                 // descriptor dwords 0-3, 8-11, 12-15 (broadcast reads)
         // (readfirstlane returns int: go through unsigned before widening, or bit 31 smears into the high half)
         auto sgpr = [](float v) { return (unsigned long) (unsigned) __builtin_amdgcn_readfirstlane((int) __float_as_uint(v)); };
@@ -339,23 +362,52 @@ k_walk_s4(const PartialsOp* __restrict__ ops, int nsteps, int W, int nslots, Blo
         const unsigned hi = (unsigned) sgpr(d3.y);
         op.c1_kind = lo & 0xFF; op.c2_kind = (lo >> 8) & 0xFF; op.c1_slot = (lo >> 16) & 0xFF; op.c2_slot = lo >> 24;
         op.dst_slot = hi & 0xFF; op.scale_mode = (hi >> 8) & 0xFF; op.flags = (hi >> 16) & 0xFF;
-        if (op.dst != nullptr) {
+        const uint8_t* tips = reinterpret_cast<const uint8_t*>(in + 4 + 8 * K);
+        const bool tip1 = op.c1_kind == CHILD_STATES, tip2 = op.c2_kind == CHILD_STATES;
+        const f4* l1 = slots + (tip1 ? 0 : op.c1_slot) * walk_slot_units(K) + lane;       // tips read slot 0 and discard it
+        const f4* l2 = slots + (tip2 ? 0 : op.c2_slot) * walk_slot_units(K) + lane;
+        if (ksplit == 2) {
+            if constexpr (K % 2 == 0) {
+                constexpr int KN = K / 2;
+                const int k0 = khalf * KN;
+                f4 out[KN];
+                float mx = 0.0f;
+                if (op.dst != nullptr) {
+                    Mat4 M1[KN], M2[KN];
+                    f4 a[KN], b[KN];
+                    const f4 one1 = tip_vector(tips[lane]), one2 = tip_vector(tips[64 + lane]);
+#pragma unroll
+                    for (int k = 0; k < KN; ++k) {
+                        M1[k].col = in[4 + 4 * (k0 + k) + (lane & 3)];
+                        M2[k].col = in[4 + 4 * K + 4 * (k0 + k) + (lane & 3)];
+                        const f4 va = l1[(k0 + k) * 64], vb = l2[(k0 + k) * 64];
+                        a[k] = tip1 ? one1 : va;
+                        b[k] = tip2 ? one2 : vb;
+                    }
+                    mx = walk_products<KN>(M1, M2, a, b, out);
+                    mxbuf[khalf * 64 + lane] = mx;
+                }
+                walk_step_barrier();                                 // both halves' maxima are in LDS
+                if (op.dst != nullptr) {
+                    int e = 0;
+                    if (op.scale_mode == SCALE_WRITE) {
+                        e = scale_exponent(fmaxf(mx, mxbuf[(1 - khalf) * 64 + lane]));
+                        if (khalf == 0) cum_e += e;
+                    } else if (op.scale_mode == SCALE_READ) {
+                        e = reinterpret_cast<const int*>(in + 4 + 8 * K + 8)[lane];
+                    }
+                    walk_store<K, KN>(op, out, e, k0, khalf == 0, poff, soff, lane, slots);
+                }
+            }
+        } else if (op.dst != nullptr) {
             Mat4 M1[K], M2[K];
+            f4 a[K], b[K];
+            const f4 one1 = tip_vector(tips[lane]), one2 = tip_vector(tips[64 + lane]);
+            const int e_read = reinterpret_cast<const int*>(in + 4 + 8 * K + 8)[lane];
 #pragma unroll
             for (int k = 0; k < K; ++k) {
                 M1[k].col = in[4 + 4 * k + (lane & 3)];
                 M2[k].col = in[4 + 4 * K + 4 * k + (lane & 3)];
-            }
-            const uint8_t* tips = reinterpret_cast<const uint8_t*>(in + 4 + 8 * K);
-            const unsigned s1 = tips[lane], s2 = tips[64 + lane];
-            const int e_read = reinterpret_cast<const int*>(in + 4 + 8 * K + 8)[lane];
-            const bool tip1 = op.c1_kind == CHILD_STATES, tip2 = op.c2_kind == CHILD_STATES;
-            const f4* l1 = slots + (tip1 ? 0 : op.c1_slot) * walk_slot_units(K) + lane;   // tips read slot 0 and discard it
-            const f4* l2 = slots + (tip2 ? 0 : op.c2_slot) * walk_slot_units(K) + lane;
-            f4 a[K], b[K];
-            const f4 one1 = tip_vector(s1), one2 = tip_vector(s2);
-#pragma unroll
-            for (int k = 0; k < K; ++k) {
                 const f4 va = l1[k * 64], vb = l2[k * 64];
                 a[k] = tip1 ? one1 : va;
                 b[k] = tip2 ? one2 : vb;
