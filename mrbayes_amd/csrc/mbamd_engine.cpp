@@ -127,11 +127,8 @@ struct Instance {
     bool haveSite = false;
 
     // growable device scratch
-    PartialsOp* d_ops = nullptr;      size_t opsCap = 0;
-    MatrixJob* d_jobs = nullptr;      size_t jobsCap = 0;
     double* d_ev = nullptr;           size_t evCap = 0;
     void* d_tmp = nullptr;            size_t tmpCap = 0;
-    const int32_t** d_ptrs = nullptr; size_t ptrsCap = 0;
 
     // pinned staging ring for small asynchronous uploads / downloads
     unsigned char* stage = nullptr;
@@ -385,7 +382,7 @@ void Instance::destroy()
     for (Plan* pl : plans) { if (pl->d_table) (void) hipFree(pl->d_table); delete pl; }
     plans.clear();
     void* bufs[] = {matrices, d_eigen, d_freqs, d_weights, d_rates, d_pweights, d_site,
-                    d_ops, d_jobs, d_ev, d_tmp, (void*) d_ptrs};
+                    d_ev, d_tmp};
     for (void* b : bufs) if (b) (void) hipFree(b);
     if (h_sums) (void) hipHostFree(h_sums);
     if (stage) (void) hipHostFree(stage);

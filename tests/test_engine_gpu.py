@@ -232,3 +232,62 @@ def test_config4_dna_1000x50k_two_chains(gpu):
     site = bd.inst.get_site_log_likelihoods()
     assert abs(site.sum() - a) <= 1e-9 * abs(a)
     bd.finalize()
+
+
+# ---- execution-strategy invariance: every alternative way the engine can run a list gives the same bits ----
+def _lnl_and_sites(gpu, div, scaling=lk.MB_BEAGLE_SCALE_ALWAYS):
+    bd = lk.BeagleDivision(div, gpu, scaling=scaling)
+    lnl = bd.LogLike(0)
+    site = bd.inst.get_site_log_likelihoods()
+    bd.finalize()
+    return lnl, site
+
+
+@pytest.mark.parametrize("case", ["replicase_m3", "avian_wag_g4"])
+def test_deferred_lists_equal_immediate(gpu, golden_dir, monkeypatch, case):
+    """Lists of several eigen-system parts run merged (one launch per level over all parts) or one by one
+    (MBAMD_NO_DEFER): identical results."""
+    div = division_from_golden(golden_dir, case)
+    a, sa = _lnl_and_sites(gpu, div)
+    monkeypatch.setenv("MBAMD_NO_DEFER", "1")
+    b, sb = _lnl_and_sites(gpu, div)
+    assert a == b and np.array_equal(sa, sb)
+
+
+@pytest.mark.parametrize("case", ["replicase_m3", "avian_wag_g4", "synth_aa_wag"])
+def test_mfma_kernel_variants_agree(gpu, golden_dir, monkeypatch, case):
+    """wave-per-factor-tile (default) vs wave-per-tile-column MFMA kernels: same k-ordered fp32 FMA chains."""
+    div = division_from_golden(golden_dir, case)
+    a, sa = _lnl_and_sites(gpu, div)
+    monkeypatch.setenv("MBAMD_MFMA_WHOLE", "1")
+    b, sb = _lnl_and_sites(gpu, div)
+    assert a == b and np.array_equal(sa, sb)
+
+
+def test_walk_category_split_agrees(gpu, monkeypatch):
+    div = synthetic_division("gtr", 120, 700, seed=71, tree_seed=72, p_gap=0.04)
+    a, sa = _lnl_and_sites(gpu, div)
+    monkeypatch.setenv("MBAMD_WALK_KSPLIT", "1")
+    b, sb = _lnl_and_sites(gpu, div)
+    assert a == b and np.array_equal(sa, sb)
+    monkeypatch.setenv("MBAMD_WALK_IN_ORDER", "1")          # strict list order, one compute wave
+    c, sc = _lnl_and_sites(gpu, div)
+    assert a == c and np.array_equal(sa, sc)
+
+
+def test_instances_created_and_destroyed_repeatedly(gpu):
+    """Buffers land at different device addresses every time (address-dependent bugs, e.g. a pointer whose low
+    half has bit 31 set, show up here); results must not move."""
+    div = synthetic_division("gtr", 150, 1000, seed=51, tree_seed=52, p_gap=0.05)
+    vals = set()
+    keep = []
+    for rep in range(6):
+        bd = lk.BeagleDivision(div, gpu, nchains=1 + rep % 3)
+        vals.add(bd.LogLike(0))
+        if rep % 2:
+            keep.append(bd)                  # leave some alive so the allocator moves on
+        else:
+            bd.finalize()
+    for bd in keep:
+        bd.finalize()
+    assert len(vals) == 1
