@@ -62,3 +62,39 @@ def test_unmodified_mrbayes_on_mi355x(scaling):
     # and a short MCMC run (default moves, 2 heated chains) must complete on the GPU engine
     out, _ = refrun.run_mb(refrun.REF_MB_AMD, refrun.mcmc_nexus(st, tr, 300, beagle=scaling, nchains=2))
     assert "Analysis completed" in out, out[-1500:]
+
+
+# ---- the reference's own integration check (testing/test1.nex style), engine-driven ------------------------
+def _tap_expected():
+    with open(os.path.join(ROOT, "tests", "golden", "primates_tap.json")) as fh:
+        return json.load(fh)
+
+
+def test_tap_style_run_on_emulated_engine():
+    """Short version on the CPU (host-emulation engine): mixed nst + invgamma (pInvar goes through
+    beagleGetSiteLogLikelihoods), 2 runs x 4 chains, swaps: completes and climbs to a sane likelihood."""
+    if not os.path.exists(refrun.REF_MB_EMU):
+        pytest.skip("oracle/_ref/mb_emu not built (build container only)")
+    from tools import gen_tap_fixture as tap
+    names, seqs = tap.alignment_from_fixture()
+    out, _ = refrun.run_mb(refrun.REF_MB_EMU, tap.tap_nexus(names, seqs, 1500, beagle="dynamic"))
+    res = tap.parse(out)
+    assert res["completed"] == 1, out[-1500:]
+    assert -6200.0 < res["best_cold_lnL_run1"] < -5690.0, res
+
+
+@pytest.mark.gpu
+def test_tap_style_run_on_mi355x():
+    """The full 20 000-generation check on the GPU against the statistics the reference's native kernels produced
+    for the same analysis (tests/golden/primates_tap.json, tools/gen_tap_fixture.py): the reference's own test
+    accepts a 15-unit window for the best cold-chain lnL (testing/runtests.sh.in:82-100)."""
+    if not os.path.exists(refrun.REF_MB_AMD):
+        pytest.skip("oracle/_ref/mb_amd was not built (needs the reference sources at build time)")
+    from tools import gen_tap_fixture as tap
+    want = _tap_expected()
+    names, seqs = tap.alignment_from_fixture()
+    out, _ = refrun.run_mb(refrun.REF_MB_AMD, tap.tap_nexus(names, seqs, 20000, beagle="dynamic"), timeout=1200)
+    res = tap.parse(out)
+    assert res["completed"] == 1, out[-1500:]
+    assert abs(res["best_cold_lnL_run1"] - want["best_cold_lnL_run1"]) < 15.0, (res, want)
+    assert abs(res["TL_mean"] - want["TL_mean"]) < 0.35 * want["TL_mean"], (res, want)
