@@ -102,6 +102,7 @@ struct Instance {
     bool mfmaWhole = false;          // MBAMD_MFMA_WHOLE: one wave per (operation, 32 patterns) instead of per factor tile
     int walkWaves = 1, walkSlots = 16;   // tree-walk kernel: waves per pattern block, LDS slots per workgroup
     int lastWalkSteps = 0, lastWalkSlots = 0;
+    bool noIdleLoads = false;        // MBAMD_WALK_NO_IDLE_LOADS: global children are only copied by the loader wave
     bool walkKSplit = false;         // MBAMD_WALK_KSPLIT=1: two waves per operation (category split); measured slower (profiles/)
     long long* d_trace = nullptr;    // MBAMD_WALK_TRACE: per-step clock stamps of workgroup 0 (timing experiments)
 
@@ -432,6 +433,7 @@ int Instance::configureWalk()
         HIP_TRY(hipMemset(d_trace, 0, (size_t) 4096 * 8 * 3 * sizeof(long long)));
     }
     if (const char* ks = std::getenv("MBAMD_WALK_KSPLIT")) walkKSplit = std::atoi(ks) != 0;
+    noIdleLoads = std::getenv("MBAMD_WALK_NO_IDLE_LOADS") != nullptr;
     walkWaves = total - 1;
     const int fixedUnits = walk_lds_units(K, walkWaves, 0);
     walkSlots = std::max(2, std::min(64, (ldsBudget / 16 - fixedUnits) / walk_slot_units(K)));
@@ -926,6 +928,7 @@ int Instance::buildWalk(Plan& plan, std::vector<PartialsOp>& dev, const std::vec
     std::vector<int> stepOf(n, -1), slotOf(n, -1);
     std::vector<int> slotHolder(maxSlots, -1), slotFreeFrom(maxSlots, -1);
     std::vector<std::vector<int>> steps;
+    std::vector<std::vector<PartialsOp>> stepLoads;       // LOAD entries (idle compute waves prefetch global children)
     std::vector<char> drainBefore;                        // step q re-reads a value this list stored earlier
     std::vector<int> ready;
     for (int o = 0; o < n; ++o) if (indeg[o] == 0) ready.push_back(o);
@@ -977,6 +980,7 @@ int Instance::buildWalk(Plan& plan, std::vector<PartialsOp>& dev, const std::vec
                 return far;
             };
             std::vector<std::pair<int, int>> evicted;       // (slot, value) evicted for this operation
+            std::vector<std::pair<int, PartialsOp>> loadsHere;   // (step, LOAD entry) claimed by this operation
             for (int t = 0; t < 2 && ok; ++t) {
                 if (*kind[t] == CHILD_STATES) continue;
                 if (pr[t] >= 0 && slotOf[pr[t]] >= 0) { *kind[t] = CHILD_LDS; *slot[t] = (uint8_t) slotOf[pr[t]]; continue; }
@@ -992,6 +996,28 @@ int Instance::buildWalk(Plan& plan, std::vector<PartialsOp>& dev, const std::vec
                 }
                 // the loader copies it in during step s-1: the slot must be unused from step s-1 on
                 int sl = claimFree(s - 1);
+                if (sl >= 0 && pr[t] < 0 && s >= 1 && !noIdleLoads) {
+                    // a buffer this list does not write: let an idle compute wave of an earlier step fetch it
+                    // (latest step with a free wave, not before the slot is idle)
+                    for (int q = s - 1; q >= std::max(slotFreeFrom[sl], 0); --q) {
+                        int claimed = 0;
+                        for (auto& ld : loadsHere) claimed += ld.first == q;
+                        if ((int) (steps[q].size() + stepLoads[q].size()) + claimed >= W) continue;
+                        PartialsOp ld;
+                        std::memset(&ld, 0, sizeof ld);
+                        ld.dst = const_cast<float*>(reinterpret_cast<const float*>(t == 0 ? d.c1 : d.c2));
+                        ld.c1 = ld.c2 = arenaTips;
+                        ld.m1 = ld.m2 = matrices;
+                        ld.scale = scratchScale;
+                        ld.c1_kind = ld.c2_kind = CHILD_STATES;
+                        ld.c1_slot = ld.c2_slot = MBAMD_NO_SLOT;
+                        ld.dst_slot = (uint8_t) sl;
+                        ld.flags = MBAMD_OP_LOAD;
+                        loadsHere.emplace_back(q, ld);
+                        *kind[t] = CHILD_LDS;                 // by step s it is an ordinary slot
+                        break;
+                    }
+                }
                 if (sl < 0 && mayEvict) {
                     // (a value evicted now was last touched before step s-1, so nobody reads it in s-1)
                     const int ev = evict(s - 1);
@@ -1023,6 +1049,7 @@ int Instance::buildWalk(Plan& plan, std::vector<PartialsOp>& dev, const std::vec
             if (!ok) continue;                                // not in this step
             // ---- commit
             for (auto& ev : evicted) { slotOf[ev.second] = -1; slotHolder[ev.first] = -1; }
+            for (auto& ld : loadsHere) stepLoads[ld.first].push_back(ld.second);
             for (int sl : taken) { slotHolder[sl] = -1; slotFreeFrom[sl] = s + 1; slotsUsed = std::max(slotsUsed, sl + 1); }
             for (int t = 0; t < 2; ++t) {
                 if (pr[t] < 0 || (t == 1 && pr[1] == pr[0])) continue;
@@ -1053,6 +1080,7 @@ int Instance::buildWalk(Plan& plan, std::vector<PartialsOp>& dev, const std::vec
         }
         for (int o : chosen) ready.erase(std::find(ready.begin(), ready.end(), o));
         steps.push_back(chosen);
+        stepLoads.emplace_back();
         drainBefore.push_back(needDrain ? 1 : 0);
         done += (int) chosen.size();
         for (int o : chosen)
@@ -1080,6 +1108,8 @@ int Instance::buildWalk(Plan& plan, std::vector<PartialsOp>& dev, const std::vec
             PartialsOp& e = table[(size_t) s * W + w];
             if (s < nsteps && w < (int) steps[s].size()) {
                 e = dev[steps[s][w]];
+            } else if (s < nsteps && w < (int) (steps[s].size() + stepLoads[s].size())) {
+                e = stepLoads[s][w - steps[s].size()];
             } else {
                 e.c1_slot = e.c2_slot = e.dst_slot = MBAMD_NO_SLOT;
                 e.c1_kind = e.c2_kind = CHILD_STATES;

@@ -39,6 +39,7 @@ namespace mbamd {
 #define MBAMD_OP_DRAIN 1      // PartialsOp::flags: compute waves drain their stores before this step's barrier
 #define MBAMD_OP_HAS_READ 2   // (replicated over the row) some entry of this step divides by stored scale factors
 #define MBAMD_OP_HAS_GLOBAL 4 // (replicated over the row) some entry of this step has a child in global memory
+#define MBAMD_OP_LOAD 16      // (this entry only) not an operation: copy buffer `dst` (global) into LDS slot dst_slot
 
 __host__ __device__ inline int walk_input_units(int K) { return 4 + 8 * K + 8 + 16; }   // f4 per step-input entry
 __host__ __device__ inline int walk_slot_units(int K) { return 64 * K; }               // f4 per value slot
@@ -283,6 +284,11 @@ k_walk_s4(const PartialsOp* __restrict__ ops, int nsteps, int W, int nslots, int
         for (int i = 0; i < W; ++i) {
             const PartialsOp* op = ops + (size_t) s * W + (reversed ? W - 1 - i : i);
             if (op->dst == nullptr) continue;
+            if (op->flags & MBAMD_OP_LOAD) {
+                for (int k = 0; k < K; ++k)
+                    slots[op->dst_slot * walk_slot_units(K) + k * 64 + lane] = reinterpret_cast<const f4*>(op->dst)[poff + k * 64];
+                continue;
+            }
             WalkFields f;
             f.dst = op->dst; f.scale = op->scale; f.c1_kind = op->c1_kind; f.c2_kind = op->c2_kind;
             f.c1_slot = op->c1_slot; f.c2_slot = op->c2_slot; f.dst_slot = op->dst_slot;
@@ -366,7 +372,20 @@ k_walk_s4(const PartialsOp* __restrict__ ops, int nsteps, int W, int nslots, int
         const bool tip1 = op.c1_kind == CHILD_STATES, tip2 = op.c2_kind == CHILD_STATES;
         const f4* l1 = slots + (tip1 ? 0 : op.c1_slot) * walk_slot_units(K) + lane;       // tips read slot 0 and discard it
         const f4* l2 = slots + (tip2 ? 0 : op.c2_slot) * walk_slot_units(K) + lane;
-        if (ksplit == 2) {
+        if (op.flags & MBAMD_OP_LOAD) {
+            // an idle compute wave plays prefetcher: a child that lives in global memory (the sibling on a
+            // path-to-root update) is copied into its LDS slot one or more steps before its consumer runs
+            if (khalf == 0) {
+                const MBAMD_AS_GLOBAL f4* p = as_global(reinterpret_cast<const f4*>(op.dst)) + poff;
+                f4 v[K];
+#pragma unroll
+                for (int k = 0; k < K; ++k) v[k] = p[k * 64];
+                f4* sl = slots + op.dst_slot * walk_slot_units(K) + lane;
+#pragma unroll
+                for (int k = 0; k < K; ++k) sl[k * 64] = v[k];
+            }
+            if (ksplit == 2) walk_step_barrier();
+        } else if (ksplit == 2) {
             if constexpr (K % 2 == 0) {
                 constexpr int KN = K / 2;
                 const int k0 = khalf * KN;
