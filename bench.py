@@ -91,8 +91,8 @@ def mcmc_gen_per_s(ntaxa, npat, seed, tree_seed, nchains=1):
            "substitution-parameter moves only (prset topologypr=fixed)"}
     for mix, fixed in (("default_moves", False), ("fixed_topology", True)):
         res = {}
-        for tag, binary, beagle, lo, hi in (("engine", refrun.REF_MB_AMD, "dynamic", 500, 2500),
-                                            ("reference_cpu", refrun.REF_MB, None, 20, 80)):
+        for tag, binary, beagle, lo, hi in (("engine", refrun.REF_MB_AMD, "dynamic", 2000 if fixed else 500, 22000 if fixed else 2500),
+                                            ("reference_cpu", refrun.REF_MB, None, 20, 120 if fixed else 80)):
             walls = []
             for ngen in (lo, hi):
                 _, wall = refrun.run_mb(binary, refrun.mcmc_nexus(st, tr, ngen, beagle=beagle, nchains=nchains,
