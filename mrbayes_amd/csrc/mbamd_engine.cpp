@@ -90,6 +90,7 @@ struct Plan {
     int nsteps = 0, W = 1, slotsUsed = 0;        // tree-walk schedule
     std::vector<int> start;                      // general path: first table entry of each dependency level
     bool anyScale = false;
+    bool narrow = false;                         // general path: few operations per level -> one serial launch
     std::vector<int> bufsRead, bufsWritten, scalesUsed;   // buffer / scale indices the list touches (deferral hazards)
 };
 
@@ -250,6 +251,7 @@ struct Instance {
     std::vector<char> pendingMatrixOut;          // matrix buffers the queued jobs write
     int submit(Plan* plan, int cumIdx, int32_t* cumPtr);
     bool noDefer = false;            // MBAMD_NO_DEFER: run every list at once
+    int serialRatio = 4;             // MBAMD_MFMA_SERIAL: lists with <= ratio * levels operations run as ONE serial launch (0 = never)
     bool independentOfPending(const Plan& plan, int cumIdx);
     int accumulate(const int* idx, int n, int cumIdx, int sign);
     int integrate(const int* parent, const int* child, const int* prob, const int* wIdx, const int* fIdx,
@@ -259,6 +261,7 @@ struct Instance {
 
 #if !defined(MBAMD_HOST_EMU)
 static bool launch_mfma_split(Instance& in, const OpTables& tabs, int count);
+static bool launch_mfma_serial(Instance& in, const OpTables& tabs, int ntables);
 #endif
 
 static std::mutex g_mutex;
@@ -305,6 +308,7 @@ int Instance::create(int tipCount_, int partialsBufferCount, int compactBufferCo
     if (mfma) SP = 32 * NT;          // transposed matrices padded to the MFMA tile height
     mfmaWhole = std::getenv("MBAMD_MFMA_WHOLE") != nullptr;
     noDefer = std::getenv("MBAMD_NO_DEFER") != nullptr;
+    if (const char* e = std::getenv("MBAMD_MFMA_SERIAL")) serialRatio = std::max(0, std::atoi(e));
 #endif
     partialsFloats = s4 ? (size_t) K * Ppad * 4 : (size_t) K * S * Ppad;
     matrixFloats = (size_t) K * SP * SP + (mfma ? (size_t) K * NT * T * 64 : 0);
@@ -781,7 +785,26 @@ int Instance::flushPending()
         HIP_TRY(hipEventRecord(ev0, stream));
     }
     size_t maxLevels = 0;
-    for (auto& w : work) maxLevels = std::max(maxLevels, w.first->start.size() - 1);
+    bool allNarrow = true;
+    for (auto& w : work) {
+        maxLevels = std::max(maxLevels, w.first->start.size() - 1);
+        allNarrow = allNarrow && w.first->narrow;
+    }
+    if (allNarrow) {                             // every list is a root-ward path: one launch walks them all
+        OpTables tabs;
+        std::memset(&tabs, 0, sizeof tabs);
+        int t = 0;
+        for (auto& w : work) {
+            tabs.ops[t] = w.first->d_table;
+            tabs.cum[t] = cumOf(w.second);
+            tabs.start[t] = w.first->start.back();
+            ++t;
+        }
+        if (launch_mfma_serial(*this, tabs, t)) {
+            pendingLaunches += 1;
+            maxLevels = 0;
+        }
+    }
     for (size_t l = 0; l < maxLevels; ++l) {
         OpTables tabs;
         std::memset(&tabs, 0, sizeof tabs);
@@ -1198,6 +1221,34 @@ static bool launch_mfma_split(Instance& in, const OpTables& tabs, int count)
     if (in.NT == 2 && K == 2) { launch_mfma_split_t<2, 0, 2>(in, tabs, count); return true; }
     return false;
 }
+template <int NT_, int SC_, int KC_>
+static void launch_mfma_serial_t(Instance& in, const OpTables& tabs, int ntables)
+{
+    constexpr int NP = 2 * KC_ * NT_;
+    const int gx = in.Ppad / 32;
+    auto kern = k_partials_mfma_serial<NT_, SC_, KC_>;
+    if (!in.d_trace && std::getenv("MBAMD_WALK_TRACE")) {
+        if (hipMalloc(&in.d_trace, (size_t) 4096 * 8 * 3 * sizeof(long long)) != hipSuccess) in.d_trace = nullptr;
+        else (void) hipMemset(in.d_trace, 0, (size_t) 4096 * 8 * 3 * sizeof(long long));
+    }
+    MBAMD_LAUNCH(kern, (unsigned) (gx * ntables), 64 * NP, (size_t) NP * (16 * 64 + 32) * sizeof(float), in.stream, tabs, in.S,
+                 in.SP, in.Ppad, gx, in.d_trace);
+    if (in.d_trace) { in.lastWalkSteps = tabs.start[0]; in.walkWaves = NP - 1; }
+}
+// one launch that walks up to four whole (narrow) operation lists; tabs.start[t] = operations of list t
+static bool launch_mfma_serial(Instance& in, const OpTables& tabs, int ntables)
+{
+    const int S = in.S, K = in.K;
+    if (in.NT == 1 && S == 20 && K == 4) { launch_mfma_serial_t<1, 20, 4>(in, tabs, ntables); return true; }
+    if (in.NT == 1 && S == 20 && K == 1) { launch_mfma_serial_t<1, 20, 1>(in, tabs, ntables); return true; }
+    if (in.NT == 2 && S == 61 && K == 1) { launch_mfma_serial_t<2, 61, 1>(in, tabs, ntables); return true; }
+    if (in.NT == 1 && K == 1) { launch_mfma_serial_t<1, 0, 1>(in, tabs, ntables); return true; }
+    if (in.NT == 1 && K == 2) { launch_mfma_serial_t<1, 0, 2>(in, tabs, ntables); return true; }
+    if (in.NT == 1 && K == 4) { launch_mfma_serial_t<1, 0, 4>(in, tabs, ntables); return true; }
+    if (in.NT == 2 && K == 1) { launch_mfma_serial_t<2, 0, 1>(in, tabs, ntables); return true; }
+    if (in.NT == 2 && K == 2) { launch_mfma_serial_t<2, 0, 2>(in, tabs, ntables); return true; }
+    return false;
+}
 static bool launch_mfma(Instance& in, const PartialsOp* ops, int count, int32_t* cum)
 {
     const int S = in.S, K = in.K;
@@ -1265,6 +1316,7 @@ int Instance::buildGeneric(Plan& plan, std::vector<PartialsOp>& dev, const std::
     plan.anyScale = false;
     for (const PartialsOp& d : sorted) plan.anyScale |= d.scale_mode != SCALE_NONE;
     plan.start = start;
+    plan.narrow = serialRatio > 0 && n <= serialRatio * nLevels;
     return planTable(plan, sorted);
 }
 
@@ -1273,6 +1325,20 @@ int Instance::runGeneric(const Plan& plan, int32_t* cum)
     const std::vector<int>& start = plan.start;
     const int nLevels = (int) start.size() - 1;
     const bool anyScale = plan.anyScale;
+#if !defined(MBAMD_HOST_EMU)
+    if (plan.narrow && mfma && !mfmaWhole) {
+        OpTables tabs;
+        std::memset(&tabs, 0, sizeof tabs);
+        tabs.ops[0] = plan.d_table;
+        tabs.cum[0] = cum;
+        tabs.start[0] = start[nLevels];
+        if (launch_mfma_serial(*this, tabs, 1)) {
+            pendingLaunches += 1;
+            HIP_TRY(hipGetLastError());
+            return BEAGLE_SUCCESS;
+        }
+    }
+#endif
     for (int l = 0; l < nLevels; ++l) {
         int off = start[l];
         int remaining = start[l + 1] - start[l];

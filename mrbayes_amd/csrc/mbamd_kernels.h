@@ -72,6 +72,15 @@ struct BlockGeom {
 };
 __host__ __device__ inline size_t blk_index(int c, size_t stride) { return (size_t) (c >> 6) * stride + (size_t) (c & 63); }
 
+// General-state partials (any S other than the 4-state arenas) are stored TILE-MAJOR:
+//     [P_pad / 32 tiles][K categories][S states][32 patterns]   fp32
+// so the K*S*32 values of one 32-pattern tile -- what one workgroup of the MFMA kernels reads per child
+// and writes per result -- are one contiguous run (10 KiB for 20 states x 4 categories, 7.6 KiB for 61
+// states) instead of K*S separate 128-byte segments 4*P_pad bytes apart (one DRAM page each).
+// gen_base(c) is the offset of element (k = 0, i = 0) of pattern c; element (k, i) is (k*S + i) * 32 further.
+__host__ __device__ inline size_t gen_base(int K, int S, int c) { return (size_t) (c >> 5) * K * S * 32 + (c & 31); }
+__host__ __device__ inline size_t gen_index(int K, int S, int k, int i, int c) { return gen_base(K, S, c) + ((size_t) k * S + i) * 32; }
+
 enum ChildKind : uint8_t {
     CHILD_PARTIALS = 0,   // dense partials in HBM, not written by this launch
     CHILD_STATES   = 1,   // compact tip: uint8 state codes
@@ -205,8 +214,8 @@ namespace mbamd {
 //   FUSED_K == 0: any K; writes unscaled partials, k_rescale_gen does the scaling pass.
 // ---------------------------------------------------------------------------------------------
 template <int SP>
-__device__ __forceinline__ void gen_child_factor(const void* ptr, int kind, const float* mT_, int S, int k,
-                                                 int Ppad, int c, float (&f)[SP])
+__device__ __forceinline__ void gen_child_factor(const void* ptr, int kind, const float* mT_, int S, int K, int k,
+                                                 int c, float (&f)[SP])
 {
     if (kind == CHILD_STATES) {
         const unsigned s = as_global(reinterpret_cast<const uint8_t*>(ptr))[c];
@@ -221,12 +230,12 @@ __device__ __forceinline__ void gen_child_factor(const void* ptr, int kind, cons
     } else {
         const MBAMD_AS_CONST float* __restrict__ mT = as_const(mT_);
         const MBAMD_AS_GLOBAL float* __restrict__ cl =
-            as_global(reinterpret_cast<const float*>(ptr)) + (size_t) k * S * Ppad + c;
+            as_global(reinterpret_cast<const float*>(ptr)) + gen_index(K, S, k, 0, c);
 #pragma unroll
         for (int i = 0; i < SP; ++i) f[i] = 0.0f;
 #pragma unroll 2
         for (int j = 0; j < S; ++j) {
-            const float vj = cl[(size_t) j * Ppad];
+            const float vj = cl[(size_t) j * 32];
             const MBAMD_AS_CONST float* __restrict__ col = mT + (size_t) j * SP;
 #pragma unroll
             for (int i = 0; i < SP; ++i) f[i] = fmaf(col[i], vj, f[i]);
@@ -245,7 +254,7 @@ k_partials_gen(const PartialsOp* __restrict__ ops, int S, int K, int Ppad, int32
     const void* c2 = op->c2;
     const float* m1 = op->m1;
     const float* m2 = op->m2;
-    MBAMD_AS_GLOBAL float* __restrict__ dst = as_global(op->dst) + c;
+    MBAMD_AS_GLOBAL float* __restrict__ dst = as_global(op->dst) + gen_base(K, S, c);
     MBAMD_AS_GLOBAL int32_t* sc = as_global(op->scale);
     const int mode = op->scale_mode;
 
@@ -256,8 +265,8 @@ k_partials_gen(const PartialsOp* __restrict__ ops, int S, int K, int Ppad, int32
 #pragma unroll
         for (int k = 0; k < KK; ++k) {
             float f2[SP];
-            gen_child_factor<SP>(c1, k1, m1 + (size_t) k * SP * SP, S, k, Ppad, c, out[k]);
-            gen_child_factor<SP>(c2, k2, m2 + (size_t) k * SP * SP, S, k, Ppad, c, f2);
+            gen_child_factor<SP>(c1, k1, m1 + (size_t) k * SP * SP, S, K, k, c, out[k]);
+            gen_child_factor<SP>(c2, k2, m2 + (size_t) k * SP * SP, S, K, k, c, f2);
 #pragma unroll
             for (int i = 0; i < SP; ++i) {
                 out[k][i] *= f2[i];
@@ -276,16 +285,16 @@ k_partials_gen(const PartialsOp* __restrict__ ops, int S, int K, int Ppad, int32
         for (int k = 0; k < KK; ++k) {
 #pragma unroll
             for (int i = 0; i < SP; ++i)
-                if (i < S) dst[((size_t) k * S + i) * Ppad] = (mode != SCALE_NONE) ? scale_pow2(out[k][i], -e) : out[k][i];
+                if (i < S) dst[((size_t) k * S + i) * 32] = (mode != SCALE_NONE) ? scale_pow2(out[k][i], -e) : out[k][i];
         }
     } else {
         for (int k = 0; k < K; ++k) {
             float f1[SP], f2[SP];
-            gen_child_factor<SP>(c1, k1, m1 + (size_t) k * SP * SP, S, k, Ppad, c, f1);
-            gen_child_factor<SP>(c2, k2, m2 + (size_t) k * SP * SP, S, k, Ppad, c, f2);
+            gen_child_factor<SP>(c1, k1, m1 + (size_t) k * SP * SP, S, K, k, c, f1);
+            gen_child_factor<SP>(c2, k2, m2 + (size_t) k * SP * SP, S, K, k, c, f2);
 #pragma unroll
             for (int i = 0; i < SP; ++i)
-                if (i < S) dst[((size_t) k * S + i) * Ppad] = f1[i] * f2[i];
+                if (i < S) dst[((size_t) k * S + i) * 32] = f1[i] * f2[i];
         }
     }
 }
@@ -298,13 +307,13 @@ k_rescale_gen(const PartialsOp* __restrict__ ops, int S, int K, int Ppad, int32_
     const int mode = op->scale_mode;
     if (mode == SCALE_NONE) return;
     const int c = blockIdx.x * 64 + threadIdx.x;
-    MBAMD_AS_GLOBAL float* __restrict__ dst = as_global(op->dst) + c;
+    MBAMD_AS_GLOBAL float* __restrict__ dst = as_global(op->dst) + gen_base(K, S, c);
     MBAMD_AS_GLOBAL int32_t* sc = as_global(op->scale);
     const int n = K * S;
     int e;
     if (mode == SCALE_WRITE) {
         float mx = 0.0f;
-        for (int r = 0; r < n; ++r) mx = fmaxf(mx, dst[(size_t) r * Ppad]);
+        for (int r = 0; r < n; ++r) mx = fmaxf(mx, dst[(size_t) r * 32]);
         e = scale_exponent(mx);
         sc[c] = e;
         if (cumulative != nullptr && e != 0) atomicAdd(cumulative + c, e);
@@ -312,7 +321,7 @@ k_rescale_gen(const PartialsOp* __restrict__ ops, int S, int K, int Ppad, int32_
         e = sc[c];
     }
     if (e != 0)
-        for (int r = 0; r < n; ++r) dst[(size_t) r * Ppad] = scale_pow2(dst[(size_t) r * Ppad], -e);
+        for (int r = 0; r < n; ++r) dst[(size_t) r * 32] = scale_pow2(dst[(size_t) r * 32], -e);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -417,9 +426,9 @@ struct IntegrateArgs {
 };
 
 template <bool S4>
-__device__ __forceinline__ float part_at(const float* p, int S, int Ppad, size_t pstride, int k, int c, int i)
+__device__ __forceinline__ float part_at(const float* p, int S, int K, size_t pstride, int k, int c, int i)
 {
-    return S4 ? p[(blk_index(c, pstride) + (size_t) k * 64) * 4 + i] : p[((size_t) k * S + i) * Ppad + c];
+    return S4 ? p[(blk_index(c, pstride) + (size_t) k * 64) * 4 + i] : p[gen_index(K, S, k, i, c)];
 }
 template <bool S4>
 __device__ __forceinline__ float mat_at(const float* m, int SP, int k, int i, int j)
@@ -446,20 +455,20 @@ k_integrate_lnl(IntegrateArgs a, int S, int SP, int K, int P, int Ppad, BlockGeo
         for (int k = 0; k < K; ++k) {
             double cat = 0.0;
             if (a.child[n] == nullptr) {
-                for (int i = 0; i < S; ++i) cat += (double) part_at<S4>(a.parent[n], S, Ppad, g.pstride, k, c, i) * a.freqs[n][i];
+                for (int i = 0; i < S; ++i) cat += (double) part_at<S4>(a.parent[n], S, K, g.pstride, k, c, i) * a.freqs[n][i];
             } else if (a.child_kind[n] == CHILD_STATES) {
                 const unsigned s = reinterpret_cast<const uint8_t*>(a.child[n])[blk_index(c, g.tstride)];
                 for (int i = 0; i < S; ++i) {
                     const float pc = (s >= (unsigned) S) ? 1.0f : mat_at<S4>(a.matrix[n], SP, k, i, (int) s);
-                    cat += (double) (part_at<S4>(a.parent[n], S, Ppad, g.pstride, k, c, i) * pc) * a.freqs[n][i];
+                    cat += (double) (part_at<S4>(a.parent[n], S, K, g.pstride, k, c, i) * pc) * a.freqs[n][i];
                 }
             } else {
                 const float* ch = reinterpret_cast<const float*>(a.child[n]);
                 for (int i = 0; i < S; ++i) {
                     float acc = 0.0f;
                     for (int j = 0; j < S; ++j)
-                        acc = fmaf(mat_at<S4>(a.matrix[n], SP, k, i, j), part_at<S4>(ch, S, Ppad, g.pstride, k, c, j), acc);
-                    cat += (double) (part_at<S4>(a.parent[n], S, Ppad, g.pstride, k, c, i) * acc) * a.freqs[n][i];
+                        acc = fmaf(mat_at<S4>(a.matrix[n], SP, k, i, j), part_at<S4>(ch, S, K, g.pstride, k, c, j), acc);
+                    cat += (double) (part_at<S4>(a.parent[n], S, K, g.pstride, k, c, i) * acc) * a.freqs[n][i];
                 }
             }
             like += cat * a.weights[n][k];
@@ -540,7 +549,7 @@ k_import_partials(const double* __restrict__ in, int in_has_categories, int S, i
     const int k = (int) (g / ((size_t) S * P));
     const double v = in_has_categories ? in[g] : in[(size_t) c * S + i];
     if (S4) out[(blk_index(c, pstride) + (size_t) k * 64) * 4 + i] = (float) v;
-    else    out[((size_t) k * S + i) * Ppad + c] = (float) v;
+    else    out[gen_index(K, S, k, i, c)] = (float) v;
 }
 
 template <bool S4>
@@ -553,7 +562,7 @@ k_export_partials(const float* __restrict__ in, int S, int K, int P, int Ppad, s
     const int i = (int) (g % S);
     const int c = (int) ((g / S) % P);
     const int k = (int) (g / ((size_t) S * P));
-    out[g] = S4 ? (double) in[(blk_index(c, pstride) + (size_t) k * 64) * 4 + i] : (double) in[((size_t) k * S + i) * Ppad + c];
+    out[g] = S4 ? (double) in[(blk_index(c, pstride) + (size_t) k * 64) * 4 + i] : (double) in[gen_index(K, S, k, i, c)];
 }
 
 }  // namespace mbamd

@@ -11,8 +11,9 @@
 //     A (32 x 2)  = transition matrix tile   P[32*it + (lane&31)][2t + (lane>>5)]
 //     B (2 x 32)  = conditional likelihoods  cl[2t + (lane>>5)][c0 + (lane&31)]
 //     D (32 x 32) = F[i][p]: lane holds p = c0 + (lane&31), rows i = 32*it + (r&3) + 8*(r>>2) + 4*(lane>>5)
-// The B operand is exactly one coalesced dword load from the state-major partials layout
-// [K][S][P_pad] (two 128-byte row segments per wave instruction) -- no LDS staging, no transposes.
+// The B operand is exactly one coalesced dword load from the tile-major partials layout
+// [P_pad/32][K][S][32] (gen_index, mbamd_kernels.h): rows 2t and 2t+1 of a 32-pattern tile are 64
+// consecutive floats, one contiguous 256-byte access per wave instruction -- no LDS staging, no transposes.
 // The A operand comes pre-packed in MFMA lane order from k_transition_matrices_ev (one coalesced
 // 256-byte load per MFMA, L1/L2 resident: a matrix set is 10-48 KiB).  A compact tip child needs
 // no contraction at all: its factor is column `state` of P, gathered with dwordx4 loads.
@@ -43,6 +44,57 @@ __device__ __forceinline__ bool xcd_aware_block(int gx, int& x, int& y)
     x = (q % nxb) * 8 + xcd;
     y = q / nxb;
     return x < gx;
+}
+
+// F[32 x 32] += P_tile[32 x S] * cl[S x 32] as T = ceil(S/2) chained MFMAs.  ALL operand loads are issued
+// before the first MFMA (register arrays + a scheduling barrier): left alone the compiler keeps one load
+// pair in flight and every MFMA waits a full memory round trip (measured: 21 000 of 23 000 cycles of a
+// 61-state operation).  pa: packed A operands of this (category, row tile), lane-offset; cl: this
+// category's rows of the child's 32-pattern tile + lane (tile-major layout: rows 2t and 2t+1 are the 64
+// consecutive floats at 64 t, so every B load is one contiguous 256-byte wave access).
+template <int SC>
+__device__ __forceinline__ f32x16 mfma_contract(const MBAMD_AS_GLOBAL float* __restrict__ pa,
+                                                const MBAMD_AS_GLOBAL float* __restrict__ cl, int S_rt, int half, f32x16 acc)
+{
+    if constexpr (SC > 0) {
+        constexpr int T = (SC + 1) / 2, Tfull = SC / 2;
+        float a[T], b[T];
+#pragma unroll
+        for (int t = 0; t < Tfull; ++t) {
+            a[t] = pa[(size_t) t * 64];
+            b[t] = cl[64 * t];
+        }
+        if (SC & 1) {                               // last pair: row S does not exist, feed zeros
+            a[T - 1] = pa[(size_t) (T - 1) * 64];
+            b[T - 1] = 0.0f;
+            if (!half) b[T - 1] = cl[64 * Tfull];
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int t = 0; t < T; ++t) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[t], b[t], acc, 0, 0, 0);
+    } else {
+        constexpr int CH = 16;                      // run-time S: chunks of 16 pairs in flight
+        const int Tfull = S_rt / 2;
+        for (int t0 = 0; t0 < Tfull; t0 += CH) {
+            float a[CH], b[CH];
+#pragma unroll
+            for (int u = 0; u < CH; ++u) {
+                const int t = min(t0 + u, Tfull - 1);
+                a[u] = pa[(size_t) t * 64];
+                b[u] = cl[64 * t];
+                if (t0 + u >= Tfull) a[u] = 0.0f;
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int u = 0; u < CH; ++u) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[u], b[u], acc, 0, 0, 0);
+        }
+        if (S_rt & 1) {
+            float b = 0.0f;
+            if (!half) b = cl[64 * Tfull];
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(pa[(size_t) Tfull * 64], b, acc, 0, 0, 0);
+        }
+    }
+    return acc;
 }
 
 template <int NT, int SC>     // SC: compile-time state count (0 = run-time S)
@@ -85,26 +137,9 @@ __device__ __forceinline__ void mfma_child_factor(const void* ptr, int kind, con
     const MBAMD_AS_GLOBAL float* __restrict__ pa =
         as_global(mbase) + (size_t) K * SP * SP + (size_t) k * NT * T * 64 + lane;
     const MBAMD_AS_GLOBAL float* __restrict__ cl =
-        as_global(reinterpret_cast<const float*>(ptr)) + (size_t) k * S * Ppad + (size_t) half * Ppad + c0 + col;
-    const int Tfull = S / 2;                    // pairs with both rows < S
-#pragma unroll 5
-    for (int t = 0; t < Tfull; ++t) {
-        const float b = cl[(size_t) (2 * t) * Ppad];
+        as_global(reinterpret_cast<const float*>(ptr)) + gen_index(K, S, k, 0, c0) + lane;
 #pragma unroll
-        for (int it = 0; it < NT; ++it) {
-            const float a = pa[(size_t) (it * T + t) * 64];
-            acc[it] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[it], 0, 0, 0);
-        }
-    }
-    if (S & 1) {                                // last pair: row S does not exist, feed zeros
-        const int t = Tfull;
-        const float b = half ? 0.0f : cl[(size_t) (2 * t) * Ppad];
-#pragma unroll
-        for (int it = 0; it < NT; ++it) {
-            const float a = pa[(size_t) (it * T + t) * 64];
-            acc[it] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[it], 0, 0, 0);
-        }
-    }
+    for (int it = 0; it < NT; ++it) acc[it] = mfma_contract<SC>(pa + (size_t) it * T * 64, cl, S, half, acc[it]);
 }
 
 // grid: 8 * ceil(gx/8) * count blocks of 256 threads (4 waves, one 32-pattern tile each),
@@ -156,7 +191,7 @@ k_partials_mfma(const PartialsOp* __restrict__ ops, int S_rt, int SP, int Ppad, 
     } else if (mode == SCALE_READ) {
         e = as_global(op->scale)[c0 + col];
     }
-    MBAMD_AS_GLOBAL float* __restrict__ dst = as_global(op->dst) + c0 + col;
+    MBAMD_AS_GLOBAL float* __restrict__ dst = as_global(op->dst) + gen_base(KC, S, c0) + col;
 #pragma unroll
     for (int k = 0; k < KC; ++k)
 #pragma unroll
@@ -166,7 +201,7 @@ k_partials_mfma(const PartialsOp* __restrict__ ops, int S_rt, int SP, int Ppad, 
                 const int i = 32 * it + (r & 3) + 8 * (r >> 2) + 4 * half;
                 if (i < S) {
                     const float v = out[k][it][r];
-                    dst[((size_t) k * S + i) * Ppad] = (mode != SCALE_NONE) ? scale_pow2(v, -e) : v;
+                    dst[((size_t) k * S + i) * 32] = (mode != SCALE_NONE) ? scale_pow2(v, -e) : v;
                 }
             }
 }
@@ -191,24 +226,14 @@ struct OpTables {
     int start[MBAMD_MAX_TABLES + 1];       // operation index range [start[t], start[t+1]) belongs to table t
 };
 
+// One operation for one 32-pattern tile, executed by the 2*K*NT waves of a workgroup (two barriers).
 template <int NT, int SC, int KC>
-__global__ void __launch_bounds__(64 * 2 * KC * NT)
-k_partials_mfma_split(OpTables tabs, int S_rt, int SP, int Ppad, int gx)
+__device__ __forceinline__ void mfma_split_op(const MBAMD_AS_CONST PartialsOp* __restrict__ op, int32_t* __restrict__ cumulative,
+                                              int S_rt, int SP, int Ppad, int c0, int wave, int lane, float* tiles, float* smax)
 {
     constexpr int NP = 2 * KC * NT;                 // pieces = waves
-    extern __shared__ float lds_f[];
-    float* tiles = lds_f;                           // [NP][16][64]
-    float* smax = lds_f + NP * 16 * 64;             // [NP][32]
     const int S = SC > 0 ? SC : S_rt;
-    const int bx = blockIdx.x % gx, by = blockIdx.x / gx;       // gx = P_pad / 32 tiles
-    const int wave = __builtin_amdgcn_readfirstlane((int) (threadIdx.x >> 6)), lane = threadIdx.x & 63;
     const int k = wave / (2 * NT), c = (wave / NT) & 1, it = wave % NT;
-    const int c0 = bx * 32;
-    int tsel = 0;
-#pragma unroll
-    for (int t = 1; t < MBAMD_MAX_TABLES; ++t) tsel += by >= tabs.start[t] ? 1 : 0;
-    const MBAMD_AS_CONST PartialsOp* __restrict__ op = as_const(tabs.ops[tsel]) + (by - tabs.start[tsel]);
-    int32_t* __restrict__ cumulative = tabs.cum[tsel];
     const int kind = c ? op->c2_kind : op->c1_kind;
     const void* child = c ? op->c2 : op->c1;
     const float* mbase = c ? op->m2 : op->m1;
@@ -241,15 +266,8 @@ k_partials_mfma_split(OpTables tabs, int S_rt, int SP, int Ppad, int gx)
         const MBAMD_AS_GLOBAL float* __restrict__ pa =
             as_global(mbase) + (size_t) KC * SP * SP + ((size_t) (k * NT + it) * T) * 64 + lane;
         const MBAMD_AS_GLOBAL float* __restrict__ cl =
-            as_global(reinterpret_cast<const float*>(child)) + (size_t) k * S * Ppad + (size_t) half * Ppad + c0 + col;
-        const int Tfull = S / 2;
-#pragma unroll 8
-        for (int t = 0; t < Tfull; ++t)
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(pa[(size_t) t * 64], cl[(size_t) (2 * t) * Ppad], acc, 0, 0, 0);
-        if (S & 1) {
-            const float b = half ? 0.0f : cl[(size_t) (2 * Tfull) * Ppad];
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(pa[(size_t) Tfull * 64], b, acc, 0, 0, 0);
-        }
+            as_global(reinterpret_cast<const float*>(child)) + gen_index(KC, S, k, 0, c0) + lane;
+        acc = mfma_contract<SC>(pa, cl, S, half, acc);
     }
     float* mine = tiles + (size_t) wave * 16 * 64;
 #pragma unroll
@@ -284,12 +302,59 @@ k_partials_mfma_split(OpTables tabs, int S_rt, int SP, int Ppad, int gx)
     } else if (mode == SCALE_READ) {
         e = as_global(op->scale)[c0 + col];
     }
-    MBAMD_AS_GLOBAL float* __restrict__ dst = as_global(op->dst) + c0 + col;
+    MBAMD_AS_GLOBAL float* __restrict__ dst = as_global(op->dst) + gen_index(KC, S, k, 0, c0) + col;
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
         const int r = 8 * c + j;
         const int i = 32 * it + (r & 3) + 8 * (r >> 2) + 4 * half;
-        if (i < S) dst[((size_t) k * S + i) * Ppad] = (mode != SCALE_NONE) ? scale_pow2(out[j], -e) : out[j];
+        if (i < S) dst[i * 32] = (mode != SCALE_NONE) ? scale_pow2(out[j], -e) : out[j];
+    }
+}
+
+// grid = (P_pad / 32) * operations of all tables; one dependency level per launch
+template <int NT, int SC, int KC>
+__global__ void __launch_bounds__(64 * 2 * KC * NT)
+k_partials_mfma_split(OpTables tabs, int S_rt, int SP, int Ppad, int gx)
+{
+    constexpr int NP = 2 * KC * NT;
+    extern __shared__ float lds_f[];
+    float* tiles = lds_f;                           // [NP][16][64]
+    float* smax = lds_f + NP * 16 * 64;             // [NP][32]
+    const int bx = blockIdx.x % gx, by = blockIdx.x / gx;       // gx = P_pad / 32 tiles
+    const int wave = __builtin_amdgcn_readfirstlane((int) (threadIdx.x >> 6)), lane = threadIdx.x & 63;
+    int tsel = 0;
+#pragma unroll
+    for (int t = 1; t < MBAMD_MAX_TABLES; ++t) tsel += by >= tabs.start[t] ? 1 : 0;
+    const MBAMD_AS_CONST PartialsOp* __restrict__ op = as_const(tabs.ops[tsel]) + (by - tabs.start[tsel]);
+    mfma_split_op<NT, SC, KC>(op, tabs.cum[tsel], S_rt, SP, Ppad, bx * 32, wave, lane, tiles, smax);
+}
+
+// Serial variant for narrow lists (the root-ward path a single MCMC move dirties: one operation per
+// dependency level): ONE launch, the workgroup that owns a 32-pattern tile executes the operations of
+// its table one after the other.  Patterns are independent, so list order inside the workgroup is all
+// the synchronisation a dependent operation needs: the result tile written by the previous
+// operation is re-read by the same workgroup (same CU, same write-through L1) after the barrier.
+// grid = (P_pad / 32) * tables; tabs.start[t] holds the operation COUNT of table t.
+template <int NT, int SC, int KC>
+__global__ void __launch_bounds__(64 * 2 * KC * NT)
+k_partials_mfma_serial(OpTables tabs, int S_rt, int SP, int Ppad, int gx, long long* __restrict__ trace)
+{
+    constexpr int NP = 2 * KC * NT;
+    extern __shared__ float lds_f[];
+    float* tiles = lds_f;
+    float* smax = lds_f + NP * 16 * 64;
+    const int bx = blockIdx.x % gx, tsel = blockIdx.x / gx;
+    const int wave = __builtin_amdgcn_readfirstlane((int) (threadIdx.x >> 6)), lane = threadIdx.x & 63;
+    const MBAMD_AS_CONST PartialsOp* __restrict__ ops = as_const(tabs.ops[tsel]);
+    int32_t* __restrict__ cumulative = tabs.cum[tsel];
+    const int count = tabs.start[tsel];
+    const bool tracing = trace != nullptr && blockIdx.x == 0 && lane == 0;      // MBAMD_WALK_TRACE (timing experiments)
+    for (int o = 0; o < count; ++o) {
+        if (tracing) trace[((size_t) o * 8 + wave) * 3 + 0] = (long long) __builtin_amdgcn_s_memtime();
+        mfma_split_op<NT, SC, KC>(ops + o, cumulative, S_rt, SP, Ppad, bx * 32, wave, lane, tiles, smax);
+        if (tracing) trace[((size_t) o * 8 + wave) * 3 + 1] = (long long) __builtin_amdgcn_s_memtime();
+        __syncthreads();                            // results visible; tiles / smax reusable
+        if (tracing) trace[((size_t) o * 8 + wave) * 3 + 2] = (long long) __builtin_amdgcn_s_memtime();
     }
 }
 
@@ -353,21 +418,21 @@ k_integrate_lnl_wide(IntegrateArgs a, int S, int SP, int K, int P, int Ppad, con
             for (int k = 0; k < K; ++k) {
                 double cat = 0.0;
                 if (a.child[n] == nullptr) {
-                    for (int i = g; i < S; i += 4) cat += (double) par[((size_t) k * S + i) * Ppad + c] * fr[i];
+                    for (int i = g; i < S; i += 4) cat += (double) par[gen_index(K, S, k, i, c)] * fr[i];
                 } else if (a.child_kind[n] == CHILD_STATES) {
                     const unsigned s = reinterpret_cast<const uint8_t*>(a.child[n])[c];
                     const float* __restrict__ mrow = a.matrix[n] + (size_t) k * SP * SP + (size_t) (s < (unsigned) S ? s : 0) * SP;
                     for (int i = g; i < S; i += 4) {
                         const float pc = (s >= (unsigned) S) ? 1.0f : mrow[i];
-                        cat += (double) (par[((size_t) k * S + i) * Ppad + c] * pc) * fr[i];
+                        cat += (double) (par[gen_index(K, S, k, i, c)] * pc) * fr[i];
                     }
                 } else {
                     const float* __restrict__ ch = reinterpret_cast<const float*>(a.child[n]);
                     const float* __restrict__ m = a.matrix[n] + (size_t) k * SP * SP;
                     for (int i = g; i < S; i += 4) {
                         float acc = 0.0f;
-                        for (int j = 0; j < S; ++j) acc = fmaf(m[(size_t) j * SP + i], ch[((size_t) k * S + j) * Ppad + c], acc);
-                        cat += (double) (par[((size_t) k * S + i) * Ppad + c] * acc) * fr[i];
+                        for (int j = 0; j < S; ++j) acc = fmaf(m[(size_t) j * SP + i], ch[gen_index(K, S, k, j, c)], acc);
+                        cat += (double) (par[gen_index(K, S, k, i, c)] * acc) * fr[i];
                     }
                 }
                 like += cat * a.weights[n][k];

@@ -258,11 +258,11 @@ k_walk_s4(const PartialsOp* __restrict__ ops, int nsteps, int W, int nslots, int
 {
     const int lane = threadIdx.x & 63;
     const size_t poff = (size_t) blockIdx.x * g.pstride + lane;     // this workgroup's block in every buffer
-    const size_t toff = (size_t) blockIdx.x * g.tstride + lane;
     const size_t soff = (size_t) blockIdx.x * g.sstride + lane;
     int cum_e = 0;
 #if defined(MBAMD_HOST_EMU)
     (void) trace; (void) nslots; (void) ksplit;
+    const size_t toff = (size_t) blockIdx.x * g.tstride + lane;
     const bool reversed = W < 0;                 // test hook: run a step's entries in the opposite order
     if (reversed) W = -W;
     f4* slots = reinterpret_cast<f4*>(mbamd_emu_dyn_lds()) + 2 * W * walk_input_units(K);

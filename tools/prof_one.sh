@@ -7,3 +7,4 @@ rm -rf /tmp/prof_$c
 db=$(find /tmp/prof_$c -name "*.db" | head -1)
 python tools/rocpd_summary.py $db | tee gpurun_out/prof_${c}_summary.txt | cut -c1-200
 grep '^{' gpurun_out/prof_$c.log | cut -c1-400
+python tools/rocpd_timeline.py $db ${TIMELINE:-0} > gpurun_out/prof_${c}_timeline.txt 2>/dev/null || true

@@ -1,0 +1,33 @@
+"""Timing experiment: in-kernel per-operation clock stamps of the serial general-state kernel (partial update)."""
+import ctypes as C, os, sys
+import numpy as np
+os.environ["MBAMD_WALK_TRACE"] = "1"
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+from mrbayes_amd import beagle as bg, likelihood as lk
+from mrbayes_amd.division import synthetic_division
+model = sys.argv[1] if len(sys.argv) > 1 else "m3"
+shape = {"wag": (200, 10000), "m3": (100, 5000)}[model]
+div = synthetic_division(model, shape[0], shape[1], seed=7, tree_seed=3)
+lib = bg.library()
+bd = lk.BeagleDivision(div, lib, scaling=lk.MB_BEAGLE_SCALE_DYNAMIC)
+bd.LogLike(0); bd.AcceptMove(0)
+t = div.tree
+def depth(i):
+    d = 0
+    while t.anc[i] != -1 and t.anc[i] != t.root:
+        i = t.anc[i]; d += 1
+    return d
+deep = max(range(t.ntaxa), key=depth)
+for rep in range(3):
+    t.length[deep] *= 1.1
+    bd.TouchBranch(0, deep)
+    bd.LogLike(0); bd.AcceptMove(0)
+out = np.zeros((4096, 8, 3), dtype=np.int64)
+ns, nw = C.c_int(0), C.c_int(0)
+lib.lib.mbamdWalkTrace.argtypes = [C.c_int, C.c_void_p, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]
+lib.lib.mbamdWalkTrace(bd.inst.id, out.ctypes.data, 4096, C.byref(ns), C.byref(nw))
+ns, nw = ns.value, nw.value
+tt = out[:ns, :nw, :].astype(np.float64)
+print("depth", depth(deep), "ops", ns, "waves", nw, "total (100 MHz ticks)", tt[-1, :, 2].max() - tt[0, :, 0].min())
+for s in range(ns):
+    print(s, "op", " ".join("%6.0f" % x for x in tt[s, :, 1] - tt[s, :, 0]), "| barrier", " ".join("%6.0f" % x for x in tt[s, :, 2] - tt[s, :, 1]))
