@@ -23,6 +23,7 @@
 #include <cstring>
 #include <mutex>
 #include <string>
+#include <limits>
 #include <vector>
 
 #include "libhmsbeagle/beagle.h"
@@ -91,6 +92,8 @@ struct Plan {
     std::vector<int> start;                      // general path: first table entry of each dependency level
     bool anyScale = false;
     bool narrow = false;                         // general path: few operations per level -> one serial launch
+    int serialFrom = 0;                          // general path: levels >= serialFrom hold one operation each (the spine
+                                                 // towards the root): they run as one serial launch after the level launches
     std::vector<int> bufsRead, bufsWritten, scalesUsed;   // buffer / scale indices the list touches (deferral hazards)
 };
 
@@ -105,6 +108,7 @@ struct Instance {
     int lastWalkSteps = 0, lastWalkSlots = 0;
     bool noIdleLoads = false;        // MBAMD_WALK_NO_IDLE_LOADS: global children are only copied by the loader wave
     bool walkKSplit = false;         // MBAMD_WALK_KSPLIT=1: two waves per operation (category split); measured slower (profiles/)
+    std::vector<double> h_freqs, h_weights;      // host mirrors of d_freqs / d_weights (uploadIfChanged)
     long long* d_trace = nullptr;    // MBAMD_WALK_TRACE: per-step clock stamps of workgroup 0 (timing experiments)
 
     int NT = 0, T = 0;               // MFMA packing: i-tiles of 32 rows, j-pairs
@@ -124,7 +128,7 @@ struct Instance {
     float* matrices = nullptr;
     double *d_eigen = nullptr, *d_freqs = nullptr, *d_weights = nullptr, *d_rates = nullptr, *d_pweights = nullptr;
     double *d_site = nullptr;
-    int nblocks = 0;                  // P_pad / 64 partial sums of the weighted site log-likelihoods
+    int nblocks = 0;                  // partial sums of the weighted site log-likelihoods (one per integration workgroup)
     RatesArg rates{};                 // category rates, passed to kernels by value
     bool haveSite = false;
 
@@ -184,6 +188,16 @@ struct Instance {
         HIP_TRY(hipMemcpyAsync(dst, stage + stageOff, bytes, hipMemcpyHostToDevice, stream));
         stageOff += need;
         return BEAGLE_SUCCESS;
+    }
+
+    // MrBayes re-sends state frequencies and category weights before every evaluation (reference
+    // src/mbbeagle.c:1179-1225); only a changed vector costs a stream operation.  `shadow` mirrors the device array.
+    int uploadIfChanged(std::vector<double>& shadow, size_t off, double* devBase, const double* src, int n)
+    {
+        if (shadow.size() < off + n) shadow.resize(off + n, std::numeric_limits<double>::quiet_NaN());
+        if (std::memcmp(shadow.data() + off, src, sizeof(double) * n) == 0) return BEAGLE_SUCCESS;
+        std::memcpy(shadow.data() + off, src, sizeof(double) * n);
+        return upload(devBase + off, src, sizeof(double) * n);
     }
 
     // small kernel inputs (job lists, pointer lists): placed in the pinned ring and read by the kernel
@@ -352,6 +366,9 @@ int Instance::create(int tipCount_, int partialsBufferCount, int compactBufferCo
     HIP_TRY(hipMalloc(&d_pweights, (size_t) Ppad * sizeof(double)));
     HIP_TRY(hipMalloc(&d_site, (size_t) Ppad * sizeof(double)));
     nblocks = Ppad / 64;
+#if !defined(MBAMD_HOST_EMU)
+    if (!s4 && S >= 8) nblocks = Ppad / 32;      // k_integrate_lnl_wide: one block sum per 32-pattern tile
+#endif
     HIP_TRY(hipHostMalloc(&h_sums, (size_t) nblocks * sizeof(double), hipHostMallocDefault));
     HIP_TRY(hipHostGetDevicePointer((void**) &h_sums_dev, h_sums, 0));
     stageCap = (size_t) 8 << 20;
@@ -562,9 +579,15 @@ int Instance::flushMatrices()
         return BEAGLE_SUCCESS;
     }
 #if !defined(MBAMD_HOST_EMU)
-    if (S > 8 && (size_t) (S * S + S) * sizeof(double) <= 60 * 1024) {
-        MBAMD_LAUNCH(k_transition_matrices_lds, (unsigned) (count * K * 4), 256, (size_t) (S * S + S) * sizeof(double), stream,
-                     djobs, rates, S, SP, K, mfma ? T : 0);
+    if (S > 8 && S <= 64) {                       // fp64 matrix cores, one wave per 16 rows
+        const unsigned grid = (unsigned) (count * K);
+        const int packedT = mfma ? T : 0;
+        switch ((S + 15) / 16) {
+            case 1: MBAMD_LAUNCH(k_transition_matrices_mfma<1>, grid, 64, 0, stream, djobs, rates, S, SP, K, packedT); break;
+            case 2: MBAMD_LAUNCH(k_transition_matrices_mfma<2>, grid, 128, 0, stream, djobs, rates, S, SP, K, packedT); break;
+            case 3: MBAMD_LAUNCH(k_transition_matrices_mfma<3>, grid, 192, 0, stream, djobs, rates, S, SP, K, packedT); break;
+            default: MBAMD_LAUNCH(k_transition_matrices_mfma<4>, grid, 256, 0, stream, djobs, rates, S, SP, K, packedT); break;
+        }
         HIP_TRY(hipGetLastError());
         return BEAGLE_SUCCESS;
     }
@@ -805,7 +828,15 @@ int Instance::flushPending()
             maxLevels = 0;
         }
     }
-    for (size_t l = 0; l < maxLevels; ++l) {
+    // levels every list runs as level launches; from spineFrom on each list is a spine of single operations
+    size_t spineFrom = 0;
+    for (auto& w : work) spineFrom = std::max(spineFrom, (size_t) w.first->serialFrom);
+    if (maxLevels > 0) {
+        int spineOps = 0;
+        for (auto& w : work) spineOps += std::max(0, w.first->start.back() - w.first->start[std::min(spineFrom, w.first->start.size() - 1)]);
+        if (spineOps < 2) spineFrom = maxLevels;
+    }
+    for (size_t l = 0; l < std::min(maxLevels, spineFrom); ++l) {
         OpTables tabs;
         std::memset(&tabs, 0, sizeof tabs);
         int t = 0, total = 0;
@@ -822,6 +853,23 @@ int Instance::flushPending()
         if (total == 0) continue;
         if (!launch_mfma_split(*this, tabs, total)) return fail(BEAGLE_ERROR_GENERAL, "no MFMA kernel for a deferred list");
         pendingLaunches += 1;
+    }
+    if (spineFrom < maxLevels) {
+        OpTables tabs;
+        std::memset(&tabs, 0, sizeof tabs);
+        int t = 0;
+        for (auto& w : work) {
+            const std::vector<int>& st = w.first->start;
+            if (spineFrom + 1 >= st.size()) continue;
+            tabs.ops[t] = w.first->d_table + st[spineFrom];
+            tabs.cum[t] = cumOf(w.second);
+            tabs.start[t] = st.back() - st[spineFrom];
+            ++t;
+        }
+        if (t > 0) {
+            if (!launch_mfma_serial(*this, tabs, t)) return fail(BEAGLE_ERROR_GENERAL, "no serial MFMA kernel for a deferred list");
+            pendingLaunches += 1;
+        }
     }
     HIP_TRY(hipGetLastError());
     if (timing) {
@@ -1204,7 +1252,7 @@ static void launch_mfma_split_t(Instance& in, const OpTables& tabs, int count)
     constexpr int NP = 2 * KC_ * NT_;
     const int gx = in.Ppad / 32;
     auto kern = k_partials_mfma_split<NT_, SC_, KC_>;
-    MBAMD_LAUNCH(kern, (unsigned) (gx * count), 64 * NP, (size_t) NP * (16 * 64 + 32) * sizeof(float), in.stream, tabs, in.S,
+    MBAMD_LAUNCH(kern, (unsigned) (gx * count), 64 * NP, (size_t) NP * (8 * 64 + 32 + 16 * 32) * sizeof(float), in.stream, tabs, in.S,
                  in.SP, in.Ppad, gx);
 }
 // one launch over up to four operation tables (false: no split kernel for this shape)
@@ -1231,7 +1279,7 @@ static void launch_mfma_serial_t(Instance& in, const OpTables& tabs, int ntables
         if (hipMalloc(&in.d_trace, (size_t) 4096 * 8 * 3 * sizeof(long long)) != hipSuccess) in.d_trace = nullptr;
         else (void) hipMemset(in.d_trace, 0, (size_t) 4096 * 8 * 3 * sizeof(long long));
     }
-    MBAMD_LAUNCH(kern, (unsigned) (gx * ntables), 64 * NP, (size_t) NP * (16 * 64 + 32) * sizeof(float), in.stream, tabs, in.S,
+    MBAMD_LAUNCH(kern, (unsigned) (gx * ntables), 64 * NP, (size_t) NP * (8 * 64 + 32 + 16 * 32) * sizeof(float), in.stream, tabs, in.S,
                  in.SP, in.Ppad, gx, in.d_trace);
     if (in.d_trace) { in.lastWalkSteps = tabs.start[0]; in.walkWaves = NP - 1; }
 }
@@ -1317,6 +1365,9 @@ int Instance::buildGeneric(Plan& plan, std::vector<PartialsOp>& dev, const std::
     for (const PartialsOp& d : sorted) plan.anyScale |= d.scale_mode != SCALE_NONE;
     plan.start = start;
     plan.narrow = serialRatio > 0 && n <= serialRatio * nLevels;
+    plan.serialFrom = nLevels;
+    while (plan.serialFrom > 0 && start[plan.serialFrom] - start[plan.serialFrom - 1] == 1) plan.serialFrom--;
+    if (serialRatio == 0 || nLevels - plan.serialFrom < 2) plan.serialFrom = nLevels;
     return planTable(plan, sorted);
 }
 
@@ -1339,7 +1390,11 @@ int Instance::runGeneric(const Plan& plan, int32_t* cum)
         }
     }
 #endif
-    for (int l = 0; l < nLevels; ++l) {
+    int levelEnd = nLevels;
+#if !defined(MBAMD_HOST_EMU)
+    if (mfma && !mfmaWhole) levelEnd = plan.serialFrom;
+#endif
+    for (int l = 0; l < levelEnd; ++l) {
         int off = start[l];
         int remaining = start[l + 1] - start[l];
         while (remaining > 0) {
@@ -1380,6 +1435,17 @@ int Instance::runGeneric(const Plan& plan, int32_t* cum)
             remaining -= count;
         }
     }
+#if !defined(MBAMD_HOST_EMU)
+    if (levelEnd < nLevels) {                    // the spine: one launch walks it
+        OpTables tabs;
+        std::memset(&tabs, 0, sizeof tabs);
+        tabs.ops[0] = plan.d_table + start[levelEnd];
+        tabs.cum[0] = cum;
+        tabs.start[0] = start[nLevels] - start[levelEnd];
+        if (!launch_mfma_serial(*this, tabs, 1)) return fail(BEAGLE_ERROR_GENERAL, "no serial MFMA kernel for this shape");
+        pendingLaunches += 1;
+    }
+#endif
     HIP_TRY(hipGetLastError());
     return BEAGLE_SUCCESS;
 }
@@ -1656,14 +1722,14 @@ int beagleSetStateFrequencies(int instance, int idx, const double* f)
     StatTimer st_(ST_SET);
     GET_INSTANCE(instance);
     if (idx < 0 || idx >= in->nEigen) return fail(BEAGLE_ERROR_OUT_OF_RANGE, "beagleSetStateFrequencies: index");
-    return in->upload(in->d_freqs + (size_t) idx * in->S, f, sizeof(double) * in->S);
+    return in->uploadIfChanged(in->h_freqs, (size_t) idx * in->S, in->d_freqs, f, in->S);
 }
 int beagleSetCategoryWeights(int instance, int idx, const double* w)
 {
     StatTimer st_(ST_SET);
     GET_INSTANCE(instance);
     if (idx < 0 || idx >= in->nEigen) return fail(BEAGLE_ERROR_OUT_OF_RANGE, "beagleSetCategoryWeights: index");
-    return in->upload(in->d_weights + (size_t) idx * in->K, w, sizeof(double) * in->K);
+    return in->uploadIfChanged(in->h_weights, (size_t) idx * in->K, in->d_weights, w, in->K);
 }
 int beagleSetCategoryRates(int instance, const double* r)
 {

@@ -211,10 +211,10 @@ k_partials_mfma(const PartialsOp* __restrict__ ops, int S_rt, int SP, int Ppad, 
 // (category k, child c, row tile it): 2*K*NT waves.  A wave runs only T = ceil(S/2) dependent
 // MFMAs (10 for S=20, 31 for S=61) instead of 2*K*NT*T, so the small dependency levels near the
 // root of the tree -- a handful of operations -- still put thousands of waves on the chip.
-// The factor tiles meet in LDS: [piece][reg 0..15][64 lanes] floats (lane-contiguous, conflict
-// free); the two child waves of an output tile then split its 16 accumulator registers (rows),
-// multiply, reduce the per-pattern maximum through LDS, rescale and store.
-// blockDim.x = 64 * 2*K*NT (<= 512), dynamic LDS = 2*K*NT * 4 KiB + 2*K*NT * 32 floats.
+// The two child waves of an output tile split its 16 accumulator registers (rows): each hands the
+// eight registers it does not keep to its partner through LDS ([piece][8][64 lanes] floats, lane-
+// contiguous, conflict free), multiplies, reduces the per-pattern maximum through LDS, rescales and stores.
+// blockDim.x = 64 * 2*K*NT (<= 512), dynamic LDS = 2*K*NT * (2 KiB exchange + 128 B maxima + 2 KiB store staging).
 // ---------------------------------------------------------------------------------------------
 // Up to four operation tables per launch: MrBayes issues one beagleUpdatePartials per eigen-system part
 // (codon M3: three), mutually independent; the engine defers them and runs each dependency level
@@ -226,65 +226,96 @@ struct OpTables {
     int start[MBAMD_MAX_TABLES + 1];       // operation index range [start[t], start[t+1]) belongs to table t
 };
 
-// One operation for one 32-pattern tile, executed by the 2*K*NT waves of a workgroup (two barriers).
+// Eight rows of a tip child's factor: column `state` of P (a row of the transposed matrix), registers
+// 8c .. 8c+7 of the 32x32 tile layout = rows 32 it + 8 q + 4 half + (0..3), q = 2c, 2c+1.
+template <int SC>
+__device__ __forceinline__ void mfma_tip_rows(const void* child, const float* mbase, int S, int SP, int k, int it, int c,
+                                              int c0, int half, int col, float (&f)[8])
+{
+    const unsigned s = as_global(reinterpret_cast<const uint8_t*>(child))[c0 + col];
+    const bool missing = s >= (unsigned) S;
+    const MBAMD_AS_GLOBAL float* row = as_global(mbase) + ((size_t) k * SP + (missing ? 0u : s)) * SP + 4 * half;
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+        const int i0 = 32 * it + 8 * (2 * c + q);
+        f4 v = *reinterpret_cast<const MBAMD_AS_GLOBAL f4*>(row + i0);
+        if (missing) {
+            const int ib = i0 + 4 * half;
+            v.x = (ib + 0 < S) ? 1.0f : 0.0f;
+            v.y = (ib + 1 < S) ? 1.0f : 0.0f;
+            v.z = (ib + 2 < S) ? 1.0f : 0.0f;
+            v.w = (ib + 3 < S) ? 1.0f : 0.0f;
+        }
+        f[4 * q + 0] = v.x; f[4 * q + 1] = v.y; f[4 * q + 2] = v.z; f[4 * q + 3] = v.w;
+    }
+}
+
+// One operation for one 32-pattern tile, executed by the 2*K*NT waves of a workgroup.  Wave (k, c, it)
+// produces registers 8c .. 8c+7 (eight of the 32 rows) of output tile (k, it).
 template <int NT, int SC, int KC>
 __device__ __forceinline__ void mfma_split_op(const MBAMD_AS_CONST PartialsOp* __restrict__ op, int32_t* __restrict__ cumulative,
                                               int S_rt, int SP, int Ppad, int c0, int wave, int lane, float* tiles, float* smax)
 {
     constexpr int NP = 2 * KC * NT;                 // pieces = waves
+    float* stg = smax + NP * 32;                    // [NP][16][32] store staging
     const int S = SC > 0 ? SC : S_rt;
     const int k = wave / (2 * NT), c = (wave / NT) & 1, it = wave % NT;
-    const int kind = c ? op->c2_kind : op->c1_kind;
-    const void* child = c ? op->c2 : op->c1;
-    const float* mbase = c ? op->m2 : op->m1;
+    const int k1 = op->c1_kind, k2 = op->c2_kind;
     const int mode = op->scale_mode;
     const int half = lane >> 5, col = lane & 31;
     const int T = (S + 1) / 2;
-
-    // ---- this wave's factor tile F_c[k][32*it .. 32*it+31][c0 .. c0+31]
-    f32x16 acc;
-    if (kind == CHILD_STATES) {
-        const unsigned s = as_global(reinterpret_cast<const uint8_t*>(child))[c0 + col];
-        const bool missing = s >= (unsigned) S;
-        const MBAMD_AS_GLOBAL float* row = as_global(mbase) + ((size_t) k * SP + (missing ? 0u : s)) * SP + 4 * half;
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const int i0 = 32 * it + 8 * q;
-            f4 v = *reinterpret_cast<const MBAMD_AS_GLOBAL f4*>(row + i0);
-            if (missing) {
-                const int ib = i0 + 4 * half;
-                v.x = (ib + 0 < S) ? 1.0f : 0.0f;
-                v.y = (ib + 1 < S) ? 1.0f : 0.0f;
-                v.z = (ib + 2 < S) ? 1.0f : 0.0f;
-                v.w = (ib + 3 < S) ? 1.0f : 0.0f;
-            }
-            acc[4 * q + 0] = v.x; acc[4 * q + 1] = v.y; acc[4 * q + 2] = v.z; acc[4 * q + 3] = v.w;
-        }
-    } else {
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
-        const MBAMD_AS_GLOBAL float* __restrict__ pa =
-            as_global(mbase) + (size_t) KC * SP * SP + ((size_t) (k * NT + it) * T) * 64 + lane;
-        const MBAMD_AS_GLOBAL float* __restrict__ cl =
-            as_global(reinterpret_cast<const float*>(child)) + gen_index(KC, S, k, 0, c0) + lane;
-        acc = mfma_contract<SC>(pa, cl, S, half, acc);
-    }
-    float* mine = tiles + (size_t) wave * 16 * 64;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) mine[r * 64 + lane] = acc[r];
-    __syncthreads();
-
-    // ---- output tile (k, it): this wave takes registers 8c .. 8c+7 of it (rows (r&3) + 8(r>>2) + 4 half)
-    const float* other = tiles + (size_t) ((k * 2 + (1 - c)) * NT + it) * 16 * 64;
     float out[8];
     float mx = 0.0f;
+
+    if (k1 == CHILD_STATES && k2 == CHILD_STATES) {
+        // ---- both children are tips (a third of the operations of a full evaluation): no contraction
+        // and no tile exchange -- the wave gathers its eight rows of both factors itself
+        float f1[8], f2[8];
+        mfma_tip_rows<SC>(op->c1, op->m1, S, SP, k, it, c, c0, half, col, f1);
+        mfma_tip_rows<SC>(op->c2, op->m2, S, SP, k, it, c, c0, half, col, f2);
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
-        const int r = 8 * c + j;
-        const float v = acc[r] * other[r * 64 + lane];
-        out[j] = v;
-        const int i = 32 * it + (r & 3) + 8 * (r >> 2) + 4 * half;
-        mx = fmaxf(mx, (i < S) ? v : 0.0f);
+        for (int j = 0; j < 8; ++j) {
+            const int r = 8 * c + j;
+            const float v = f1[j] * f2[j];
+            out[j] = v;
+            const int i = 32 * it + (r & 3) + 8 * (r >> 2) + 4 * half;
+            mx = fmaxf(mx, (i < S) ? v : 0.0f);
+        }
+    } else {
+        // ---- this wave's factor tile F_c[k][32*it .. 32*it+31][c0 .. c0+31], exchanged through LDS
+        const int kind = c ? k2 : k1;
+        const void* child = c ? op->c2 : op->c1;
+        const float* mbase = c ? op->m2 : op->m1;
+        f32x16 acc;
+        if (kind == CHILD_STATES) {
+            float lo[8], hi[8];
+            mfma_tip_rows<SC>(child, mbase, S, SP, k, it, 0, c0, half, col, lo);
+            mfma_tip_rows<SC>(child, mbase, S, SP, k, it, 1, c0, half, col, hi);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { acc[j] = lo[j]; acc[8 + j] = hi[j]; }
+        } else {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
+            const MBAMD_AS_GLOBAL float* __restrict__ pa =
+                as_global(mbase) + (size_t) KC * SP * SP + ((size_t) (k * NT + it) * T) * 64 + lane;
+            const MBAMD_AS_GLOBAL float* __restrict__ cl =
+                as_global(reinterpret_cast<const float*>(child)) + gen_index(KC, S, k, 0, c0) + lane;
+            acc = mfma_contract<SC>(pa, cl, S, half, acc);
+        }
+        // the partner wave (other child, same k and it) needs the eight registers this wave does not keep
+        float* mine = tiles + (size_t) wave * 8 * 64;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) mine[j * 64 + lane] = acc[8 * (1 - c) + j];
+        __syncthreads();
+        const float* other = tiles + (size_t) ((k * 2 + (1 - c)) * NT + it) * 8 * 64;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int r = 8 * c + j;
+            const float v = acc[r] * other[j * 64 + lane];
+            out[j] = v;
+            const int i = 32 * it + (r & 3) + 8 * (r >> 2) + 4 * half;
+            mx = fmaxf(mx, (i < S) ? v : 0.0f);
+        }
     }
     int e = 0;
     if (mode == SCALE_WRITE) {
@@ -302,12 +333,21 @@ __device__ __forceinline__ void mfma_split_op(const MBAMD_AS_CONST PartialsOp* _
     } else if (mode == SCALE_READ) {
         e = as_global(op->scale)[c0 + col];
     }
-    MBAMD_AS_GLOBAL float* __restrict__ dst = as_global(op->dst) + gen_index(KC, S, k, 0, c0) + col;
+    // ---- store: the wave's 16 rows x 32 patterns are 2 KiB contiguous in the tile-major layout; turn the
+    // MFMA register layout (lane = pattern) around in LDS so that each store instruction writes 1 KiB
+    // contiguous (dwordx4 per lane, 8 rows) instead of two separate 128-byte rows
+    float* stage = stg + (size_t) wave * 512;       // [16 local rows][32 patterns]; local row lr = row - 32 it - 16 c
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
-        const int r = 8 * c + j;
-        const int i = 32 * it + (r & 3) + 8 * (r >> 2) + 4 * half;
-        if (i < S) dst[i * 32] = (mode != SCALE_NONE) ? scale_pow2(out[j], -e) : out[j];
+        const int lr = (j & 3) + 4 * half + 8 * (j >> 2);
+        stage[lr * 32 + col] = (mode != SCALE_NONE) ? scale_pow2(out[j], -e) : out[j];
+    }
+    MBAMD_AS_GLOBAL float* __restrict__ dst = as_global(op->dst) + gen_index(KC, S, k, 32 * it + 16 * c, c0) + 4 * (lane & 7);
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+        const int lr = (lane >> 3) + 8 * u;
+        const f4 v = *reinterpret_cast<const f4*>(stage + lr * 32 + 4 * (lane & 7));
+        if (32 * it + 16 * c + lr < S) *reinterpret_cast<MBAMD_AS_GLOBAL f4*>(dst + lr * 32) = v;
     }
 }
 
@@ -318,8 +358,8 @@ k_partials_mfma_split(OpTables tabs, int S_rt, int SP, int Ppad, int gx)
 {
     constexpr int NP = 2 * KC * NT;
     extern __shared__ float lds_f[];
-    float* tiles = lds_f;                           // [NP][16][64]
-    float* smax = lds_f + NP * 16 * 64;             // [NP][32]
+    float* tiles = lds_f;                           // [NP][8][64]
+    float* smax = lds_f + NP * 8 * 64;              // [NP][32]
     const int bx = blockIdx.x % gx, by = blockIdx.x / gx;       // gx = P_pad / 32 tiles
     const int wave = __builtin_amdgcn_readfirstlane((int) (threadIdx.x >> 6)), lane = threadIdx.x & 63;
     int tsel = 0;
@@ -342,7 +382,7 @@ k_partials_mfma_serial(OpTables tabs, int S_rt, int SP, int Ppad, int gx, long l
     constexpr int NP = 2 * KC * NT;
     extern __shared__ float lds_f[];
     float* tiles = lds_f;
-    float* smax = lds_f + NP * 16 * 64;
+    float* smax = lds_f + NP * 8 * 64;
     const int bx = blockIdx.x % gx, tsel = blockIdx.x / gx;
     const int wave = __builtin_amdgcn_readfirstlane((int) (threadIdx.x >> 6)), lane = threadIdx.x & 63;
     const MBAMD_AS_CONST PartialsOp* __restrict__ ops = as_const(tabs.ops[tsel]);
@@ -361,78 +401,123 @@ k_partials_mfma_serial(OpTables tabs, int S_rt, int SP, int Ppad, int gx, long l
 // ---------------------------------------------------------------------------------------------
 // Transition matrices for larger state counts (TiProbs_Gen / TiProbs_GenCov, reference
 // src/likelihood.c:9424-9700): P_k = U diag(exp(lambda t r_k)) U^-1 in fp64, clamped at 0, stored as
-// fp32 transposed + in MFMA A-operand order.  One workgroup per (branch, category, quarter of the
-// rows): the S exponentials and the scaled inverse W[s][j] = e_s Uinv[s][j] are formed once in
-// LDS, then every thread accumulates its entries with one fp64 FMA per term.
-// grid = count * K * 4, block = 256, dynamic LDS = (S*S + S) doubles.
+// fp32 transposed + in MFMA A-operand order.  The S x S x S contraction runs on the fp64 matrix cores
+// (v_mfma_f64_16x16x4_f64): one wave per 16 rows of P,
+//     A (16 x 4)  = U[i0 + (lane&15)][4 st + (lane>>4)] * exp(lambda_s t r_k)
+//     B (4 x 16)  = U^-1[4 st + (lane>>4)][16 jt + (lane&15)]
+//     D (16 x 16) : lane holds column 16 jt + (lane&15), rows i0 + (lane>>4) + 4 reg
+// with all operands of a chunk of 8 contraction steps loaded before its MFMAs.  The eigen-system (2 S^2
+// doubles, <= 64 KiB) is L2 resident.  grid = count * K workgroups of ceil(S/16) waves; NJ = ceil(S/16).
 // ---------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(256)
-k_transition_matrices_lds(const MatrixJob* __restrict__ jobs, RatesArg rates, int S, int SP, int K, int packedT)
+typedef double f64x4 __attribute__((ext_vector_type(4)));
+
+template <int NJ>
+__global__ void __launch_bounds__(64 * NJ)
+k_transition_matrices_mfma(const MatrixJob* __restrict__ jobs, RatesArg rates, int S, int SP, int K, int packedT)
 {
-    extern __shared__ double lds_d[];
-    double* W = lds_d;                 // [S][S]
-    double* ev = lds_d + S * S;        // [S]
-    const int part = blockIdx.x & 3, bk = blockIdx.x >> 2;
-    const int b = bk / K, k = bk % K;
+    __shared__ double ev[64];
+    const int b = blockIdx.x / K, k = blockIdx.x % K;
     const MatrixJob job = jobs[b];
-    const double* __restrict__ U = job.eig;
-    const double* __restrict__ Ui = job.eig + (size_t) S * S;
-    const double* __restrict__ lam = job.eig + (size_t) 2 * S * S;
-    for (int s = threadIdx.x; s < S; s += 256) ev[s] = exp(lam[s] * job.length * rates.r[k]);
+    const MBAMD_AS_GLOBAL double* __restrict__ U = as_global(job.eig);
+    const MBAMD_AS_GLOBAL double* __restrict__ Ui = U + (size_t) S * S;
+    const MBAMD_AS_GLOBAL double* __restrict__ lam = U + (size_t) 2 * S * S;
+    if ((int) threadIdx.x < S) ev[threadIdx.x] = exp(lam[threadIdx.x] * job.length * rates.r[k]);
     __syncthreads();
-    for (int idx = threadIdx.x; idx < S * S; idx += 256) W[idx] = ev[idx / S] * Ui[idx];
-    __syncthreads();
-    const int rows = (S + 3) / 4, i0 = part * rows, i1 = min(S, i0 + rows);
-    float* __restrict__ out = job.out + (size_t) k * SP * SP;
-    float* __restrict__ packed = job.out + (size_t) K * SP * SP;
-    const int NT = (S + 31) / 32;
-    for (int idx = threadIdx.x; idx < (i1 - i0) * S; idx += 256) {
-        const int i = i0 + idx / S, j = idx % S;
-        const double* __restrict__ u = U + (size_t) i * S;
-        double sum = 0.0;
-        for (int s = 0; s < S; ++s) sum = fma(u[s], W[s * S + j], sum);
-        const float v = (sum < 0.0) ? 0.0f : (float) sum;
-        out[(size_t) j * SP + i] = v;
-        if (packedT > 0) packed[((size_t) (k * NT + i / 32) * packedT + j / 2) * 64 + (i % 32) + 32 * (j % 2)] = v;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int li = lane & 15, ls = lane >> 4;
+    const int i = 16 * wave + li;                    // A row of this lane
+    const int ic = min(i, S - 1);                    // (out-of-range operands: load a valid address, feed zero)
+    f64x4 acc[NJ];
+#pragma unroll
+    for (int jt = 0; jt < NJ; ++jt) acc[jt] = (f64x4) (0.0);
+    constexpr int CH = 8;
+    const int steps = (S + 3) / 4;
+    for (int st0 = 0; st0 < steps; st0 += CH) {
+        double a[CH], bb[NJ][CH];
+#pragma unroll
+        for (int u = 0; u < CH; ++u) {
+            const int s = 4 * (st0 + u) + ls;
+            const int sc = min(s, S - 1);
+            a[u] = U[(size_t) ic * S + sc];
+#pragma unroll
+            for (int jt = 0; jt < NJ; ++jt) bb[jt][u] = Ui[(size_t) sc * S + min(16 * jt + li, S - 1)];
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int u = 0; u < CH; ++u) {
+            const int s = 4 * (st0 + u) + ls;
+            const double av = (s < S && i < S) ? a[u] * ev[min(s, S - 1)] : 0.0;      // zero A kills the padded terms
+#pragma unroll
+            for (int jt = 0; jt < NJ; ++jt) acc[jt] = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bb[jt][u], acc[jt], 0, 0, 0);
+        }
     }
+    MBAMD_AS_GLOBAL float* __restrict__ out = as_global(job.out) + (size_t) k * SP * SP;
+    MBAMD_AS_GLOBAL float* __restrict__ packed = as_global(job.out) + (size_t) K * SP * SP;
+    const int NT = (S + 31) / 32;
+#pragma unroll
+    for (int jt = 0; jt < NJ; ++jt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int row = 16 * wave + ls + 4 * r, j = 16 * jt + li;
+            if (row < S && j < S) {
+                const double sum = acc[jt][r];
+                const float v = (sum < 0.0) ? 0.0f : (float) sum;
+                out[(size_t) j * SP + row] = v;
+                if (packedT > 0) packed[((size_t) (k * NT + row / 32) * packedT + j / 2) * 64 + (row % 32) + 32 * (j % 2)] = v;
+            }
+        }
 }
 
 // ---------------------------------------------------------------------------------------------
-// Root / edge integration for the general-state path with four threads per pattern (each takes the
-// states i = g mod 4): same arithmetic as k_integrate_lnl<false>, a quarter of the serial chain.
-// grid = P_pad/64, block = 256 (lane = pattern, wave = state group).
+// Root / edge integration for the general-state path (Likelihood_Gen / _NY98, reference
+// src/likelihood.c:6037-6260, 6671-6800): eight threads per pattern (each takes the states i = g mod 8),
+// a workgroup per 32-pattern tile of the tile-major layout -- same arithmetic as k_integrate_lnl<false>,
+// an eighth of the serial chain and twice the workgroups.  The root case issues all its loads first.
+// grid = P_pad/32, block = 256 (lane & 31 = pattern, threadIdx >> 5 = state group).
 // ---------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(256)
 k_integrate_lnl_wide(IntegrateArgs a, int S, int SP, int K, int P, int Ppad, const double* __restrict__ pattern_weights,
                      double* __restrict__ site, double* __restrict__ wsite)
 {
-    __shared__ double part[MBAMD_MAX_SUBSETS][4][64];
-    const int p = threadIdx.x & 63, g = threadIdx.x >> 6;
-    const int c = blockIdx.x * 64 + p;
+    __shared__ double part[MBAMD_MAX_SUBSETS][8][32];
+    const int p = threadIdx.x & 31, g = threadIdx.x >> 5;
+    const int c = blockIdx.x * 32 + p;
     const bool live = c < P;
     for (int n = 0; n < a.count; ++n) {
         double like = 0.0;
         if (live) {
-            const float* __restrict__ par = a.parent[n];
+            const float* __restrict__ par = a.parent[n] + gen_base(K, S, c);
             const double* __restrict__ fr = a.freqs[n];
             for (int k = 0; k < K; ++k) {
                 double cat = 0.0;
+                const float* __restrict__ pk = par + (size_t) k * S * 32;
                 if (a.child[n] == nullptr) {
-                    for (int i = g; i < S; i += 4) cat += (double) par[gen_index(K, S, k, i, c)] * fr[i];
+                    for (int i0 = 0; i0 < S; i0 += 64) {
+                        float v[8];
+                        double f[8];
+#pragma unroll
+                        for (int u = 0; u < 8; ++u) {
+                            const int i = i0 + g + 8 * u;
+                            v[u] = (i < S) ? pk[i * 32] : 0.0f;
+                            f[u] = (i < S) ? fr[i] : 0.0;
+                        }
+#pragma unroll
+                        for (int u = 0; u < 8; ++u) cat += (double) v[u] * f[u];
+                    }
                 } else if (a.child_kind[n] == CHILD_STATES) {
                     const unsigned s = reinterpret_cast<const uint8_t*>(a.child[n])[c];
                     const float* __restrict__ mrow = a.matrix[n] + (size_t) k * SP * SP + (size_t) (s < (unsigned) S ? s : 0) * SP;
-                    for (int i = g; i < S; i += 4) {
+                    for (int i = g; i < S; i += 8) {
                         const float pc = (s >= (unsigned) S) ? 1.0f : mrow[i];
-                        cat += (double) (par[gen_index(K, S, k, i, c)] * pc) * fr[i];
+                        cat += (double) (pk[i * 32] * pc) * fr[i];
                     }
                 } else {
-                    const float* __restrict__ ch = reinterpret_cast<const float*>(a.child[n]);
+                    const float* __restrict__ ch = reinterpret_cast<const float*>(a.child[n]) + gen_index(K, S, k, 0, c);
                     const float* __restrict__ m = a.matrix[n] + (size_t) k * SP * SP;
-                    for (int i = g; i < S; i += 4) {
+                    for (int i = g; i < S; i += 8) {
                         float acc = 0.0f;
-                        for (int j = 0; j < S; ++j) acc = fmaf(m[(size_t) j * SP + i], ch[gen_index(K, S, k, j, c)], acc);
-                        cat += (double) (par[gen_index(K, S, k, i, c)] * acc) * fr[i];
+                        for (int j = 0; j < S; ++j) acc = fmaf(m[(size_t) j * SP + i], ch[j * 32], acc);
+                        cat += (double) (pk[i * 32] * acc) * fr[i];
                     }
                 }
                 like += cat * a.weights[n][k];
@@ -441,7 +526,7 @@ k_integrate_lnl_wide(IntegrateArgs a, int S, int SP, int K, int P, int Ppad, con
         part[n][g][p] = like;
     }
     __syncthreads();
-    if (g != 0) return;
+    if (g != 0) return;                              // lanes 0..31 of wave 0 finish
     double wl = 0.0;
     if (live) {
         int emax = -2147483647;
@@ -451,7 +536,8 @@ k_integrate_lnl_wide(IntegrateArgs a, int S, int SP, int K, int P, int Ppad, con
         }
         double total = 0.0;
         for (int n = 0; n < a.count; ++n) {
-            const double like = (part[n][0][p] + part[n][1][p]) + (part[n][2][p] + part[n][3][p]);
+            const double like = ((part[n][0][p] + part[n][1][p]) + (part[n][2][p] + part[n][3][p])) +
+                                ((part[n][4][p] + part[n][5][p]) + (part[n][6][p] + part[n][7][p]));
             const int e = a.cum[n] ? a.cum[n][c] : 0;
             total += ldexp(like, e - emax);
         }
@@ -462,7 +548,7 @@ k_integrate_lnl_wide(IntegrateArgs a, int S, int SP, int K, int P, int Ppad, con
         site[c] = 0.0;
     }
 #pragma unroll
-    for (int off = 32; off > 0; off >>= 1) wl += __shfl_down(wl, off);
+    for (int off = 16; off > 0; off >>= 1) wl += __shfl_down(wl, off, 32);
     if (p == 0) wsite[blockIdx.x] = wl;
 }
 
