@@ -92,6 +92,7 @@ struct Plan {
     std::vector<int> start;                      // general path: first table entry of each dependency level
     bool anyScale = false;
     bool narrow = false;                         // general path: few operations per level -> one serial launch
+    int tipTip = 0;                              // general path: the first tipTip operations of level 0 have two compact tip children
     int serialFrom = 0;                          // general path: levels >= serialFrom hold one operation each (the spine
                                                  // towards the root): they run as one serial launch after the level launches
     std::vector<int> bufsRead, bufsWritten, scalesUsed;   // buffer / scale indices the list touches (deferral hazards)
@@ -265,6 +266,7 @@ struct Instance {
     std::vector<char> pendingMatrixOut;          // matrix buffers the queued jobs write
     int submit(Plan* plan, int cumIdx, int32_t* cumPtr);
     bool noDefer = false;            // MBAMD_NO_DEFER: run every list at once
+    bool noSpine = false;            // MBAMD_NO_SPINE: serial launches use the plain (not software-pipelined) kernel
     int serialRatio = 4;             // MBAMD_MFMA_SERIAL: lists with <= ratio * levels operations run as ONE serial launch (0 = never)
     bool independentOfPending(const Plan& plan, int cumIdx);
     int accumulate(const int* idx, int n, int cumIdx, int sign);
@@ -276,6 +278,7 @@ struct Instance {
 #if !defined(MBAMD_HOST_EMU)
 static bool launch_mfma_split(Instance& in, const OpTables& tabs, int count);
 static bool launch_mfma_serial(Instance& in, const OpTables& tabs, int ntables);
+static bool launch_tips(Instance& in, const OpTables& tabs, int count);
 #endif
 
 static std::mutex g_mutex;
@@ -323,6 +326,7 @@ int Instance::create(int tipCount_, int partialsBufferCount, int compactBufferCo
     mfmaWhole = std::getenv("MBAMD_MFMA_WHOLE") != nullptr;
     noDefer = std::getenv("MBAMD_NO_DEFER") != nullptr;
     if (const char* e = std::getenv("MBAMD_MFMA_SERIAL")) serialRatio = std::max(0, std::atoi(e));
+    noSpine = std::getenv("MBAMD_NO_SPINE") != nullptr;
 #endif
     partialsFloats = s4 ? (size_t) K * Ppad * 4 : (size_t) K * S * Ppad;
     matrixFloats = (size_t) K * SP * SP + (mfma ? (size_t) K * NT * T * 64 : 0);
@@ -840,13 +844,34 @@ int Instance::flushPending()
         OpTables tabs;
         std::memset(&tabs, 0, sizeof tabs);
         int t = 0, total = 0;
+        bool tipsDone = false;
+        if (l == 0) {                            // operations on two compact tips: their own kernel
+            for (auto& w : work) {
+                if (w.first->tipTip == 0) continue;
+                tabs.ops[t] = w.first->d_table;
+                tabs.cum[t] = cumOf(w.second);
+                tabs.start[t] = total;
+                total += w.first->tipTip;
+                ++t;
+            }
+            for (int u = t; u <= MBAMD_MAX_TABLES; ++u) tabs.start[u] = 1 << 30;
+            if (total > 0 && launch_tips(*this, tabs, total)) {
+                pendingLaunches += 1;
+                tipsDone = true;
+            }
+            std::memset(&tabs, 0, sizeof tabs);
+            t = 0;
+            total = 0;
+        }
         for (auto& w : work) {
             const std::vector<int>& st = w.first->start;
             if (l + 1 >= st.size() || st[l + 1] == st[l]) continue;
-            tabs.ops[t] = w.first->d_table + st[l];
+            const int skip = (l == 0 && tipsDone) ? w.first->tipTip : 0;
+            if (st[l + 1] - st[l] - skip == 0) continue;
+            tabs.ops[t] = w.first->d_table + st[l] + skip;
             tabs.cum[t] = cumOf(w.second);
             tabs.start[t] = total;
-            total += st[l + 1] - st[l];
+            total += st[l + 1] - st[l] - skip;
             ++t;
         }
         for (int u = t; u <= MBAMD_MAX_TABLES; ++u) tabs.start[u] = 1 << 30;
@@ -1269,6 +1294,25 @@ static bool launch_mfma_split(Instance& in, const OpTables& tabs, int count)
     if (in.NT == 2 && K == 2) { launch_mfma_split_t<2, 0, 2>(in, tabs, count); return true; }
     return false;
 }
+template <int SC_, int KC_>
+static void launch_tips_t(Instance& in, const OpTables& tabs, int count)
+{
+    const int gx4 = (in.Ppad + 127) / 128;
+    auto kern = k_partials_tips<SC_, KC_>;
+    MBAMD_LAUNCH(kern, (unsigned) (gx4 * count), 256, (size_t) 4 * in.S * 32 * sizeof(float), in.stream, tabs, in.S, in.SP, in.Ppad, gx4);
+}
+// operations on two compact tips, up to four tables (false: no kernel for this shape)
+static bool launch_tips(Instance& in, const OpTables& tabs, int count)
+{
+    const int S = in.S, K = in.K;
+    if (S > 64) return false;
+    if (S == 20 && K == 4) { launch_tips_t<20, 4>(in, tabs, count); return true; }
+    if (S == 20 && K == 1) { launch_tips_t<20, 1>(in, tabs, count); return true; }
+    if (S == 61 && K == 1) { launch_tips_t<61, 1>(in, tabs, count); return true; }
+    if (K == 1) { launch_tips_t<0, 1>(in, tabs, count); return true; }
+    if (K == 2 && S <= 32) { launch_tips_t<0, 2>(in, tabs, count); return true; }
+    return false;
+}
 template <int NT_, int SC_, int KC_>
 static void launch_mfma_serial_t(Instance& in, const OpTables& tabs, int ntables)
 {
@@ -1283,10 +1327,29 @@ static void launch_mfma_serial_t(Instance& in, const OpTables& tabs, int ntables
                  in.SP, in.Ppad, gx, in.d_trace);
     if (in.d_trace) { in.lastWalkSteps = tabs.start[0]; in.walkWaves = NP - 1; }
 }
+template <int NT_, int SC_, int KC_>
+static void launch_mfma_spine_t(Instance& in, const OpTables& tabs, int ntables)
+{
+    constexpr int NP = 2 * KC_ * NT_;
+    const int gx = in.Ppad / 32;
+    if (!in.d_trace && std::getenv("MBAMD_WALK_TRACE")) {
+        if (hipMalloc(&in.d_trace, (size_t) 4096 * 8 * 3 * sizeof(long long)) != hipSuccess) in.d_trace = nullptr;
+        else (void) hipMemset(in.d_trace, 0, (size_t) 4096 * 8 * 3 * sizeof(long long));
+    }
+    auto kern = k_partials_mfma_spine<NT_, SC_, KC_>;
+    MBAMD_LAUNCH(kern, (unsigned) (gx * ntables), 64 * (NP + 1), ((size_t) NP * (8 * 64 + 32) + (size_t) 2 * KC_ * SC_ * 32) * sizeof(float),
+                 in.stream, tabs, in.SP, gx, in.d_trace);
+    if (in.d_trace) { in.lastWalkSteps = tabs.start[0]; in.walkWaves = NP - 1; }
+}
 // one launch that walks up to four whole (narrow) operation lists; tabs.start[t] = operations of list t
 static bool launch_mfma_serial(Instance& in, const OpTables& tabs, int ntables)
 {
     const int S = in.S, K = in.K;
+    if (!in.noSpine) {                           // software-pipelined variant (MBAMD_NO_SPINE=1: plain serial kernel)
+        if (in.NT == 1 && S == 20 && K == 4) { launch_mfma_spine_t<1, 20, 4>(in, tabs, ntables); return true; }
+        if (in.NT == 1 && S == 20 && K == 1) { launch_mfma_spine_t<1, 20, 1>(in, tabs, ntables); return true; }
+        if (in.NT == 2 && S == 61 && K == 1) { launch_mfma_spine_t<2, 61, 1>(in, tabs, ntables); return true; }
+    }
     if (in.NT == 1 && S == 20 && K == 4) { launch_mfma_serial_t<1, 20, 4>(in, tabs, ntables); return true; }
     if (in.NT == 1 && S == 20 && K == 1) { launch_mfma_serial_t<1, 20, 1>(in, tabs, ntables); return true; }
     if (in.NT == 2 && S == 61 && K == 1) { launch_mfma_serial_t<2, 61, 1>(in, tabs, ntables); return true; }
@@ -1361,6 +1424,9 @@ int Instance::buildGeneric(Plan& plan, std::vector<PartialsOp>& dev, const std::
         std::vector<int> fill(start.begin(), start.end() - 1);
         for (int o = 0; o < n; ++o) sorted[fill[level[o]]++] = dev[o];
     }
+    // level 0: operations on two compact tips first (they get their own kernel)
+    auto tipPair = [](const PartialsOp& d) { return d.c1_kind == CHILD_STATES && d.c2_kind == CHILD_STATES; };
+    plan.tipTip = nLevels > 0 ? (int) (std::stable_partition(sorted.begin(), sorted.begin() + start[1], tipPair) - sorted.begin()) : 0;
     plan.anyScale = false;
     for (const PartialsOp& d : sorted) plan.anyScale |= d.scale_mode != SCALE_NONE;
     plan.start = start;
@@ -1397,6 +1463,20 @@ int Instance::runGeneric(const Plan& plan, int32_t* cum)
     for (int l = 0; l < levelEnd; ++l) {
         int off = start[l];
         int remaining = start[l + 1] - start[l];
+#if !defined(MBAMD_HOST_EMU)
+        if (l == 0 && mfma && !mfmaWhole && plan.tipTip > 0 && plan.tipTip <= 8192) {
+            OpTables tabs;
+            std::memset(&tabs, 0, sizeof tabs);
+            tabs.ops[0] = plan.d_table;
+            tabs.cum[0] = cum;
+            for (int t = 1; t <= MBAMD_MAX_TABLES; ++t) tabs.start[t] = 1 << 30;
+            if (launch_tips(*this, tabs, plan.tipTip)) {
+                pendingLaunches += 1;
+                off += plan.tipTip;
+                remaining -= plan.tipTip;
+            }
+        }
+#endif
         while (remaining > 0) {
             const int count = std::min(remaining, 32768);
             const PartialsOp* ops = plan.d_table + off;

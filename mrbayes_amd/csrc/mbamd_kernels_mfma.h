@@ -351,6 +351,102 @@ __device__ __forceinline__ void mfma_split_op(const MBAMD_AS_CONST PartialsOp* _
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Operations whose children are BOTH tips with compact states (a third of the operations of a full
+// evaluation, the whole first dependency level): no contraction -- the result is the product of two
+// matrix columns.  Pure write traffic, so the unit of work is made large: ONE wave produces the whole
+// 32-pattern tile (all K categories, all S rows = 10 KiB for 20 states x 4 categories), no
+// cross-wave communication, every gather issued before the first use, rows turned around in a
+// per-wave LDS strip so that every store is 1 KiB contiguous.
+// Lane (col = lane & 31, half = lane >> 5) holds rows 8 q + 4 half + (0..3) of each category.
+// grid = (P_pad / 128) * operations, block = 256 (4 waves = 4 tiles), dynamic LDS = 4 * S * 32 floats.
+// ---------------------------------------------------------------------------------------------
+template <int SC, int KC>
+__global__ void __launch_bounds__(256)
+k_partials_tips(OpTables tabs, int S_rt, int SP, int Ppad, int gx4)
+{
+    constexpr int QC = SC > 0 ? (SC + 7) / 8 : 8;   // 8-row groups per category
+    extern __shared__ float lds_f[];
+    const int S = SC > 0 ? SC : S_rt;
+    const int Q = SC > 0 ? QC : (S + 7) / 8;
+    const int bx = blockIdx.x % gx4, by = blockIdx.x / gx4;
+    const int wave = __builtin_amdgcn_readfirstlane((int) (threadIdx.x >> 6)), lane = threadIdx.x & 63;
+    const int c0 = (bx * 4 + wave) * 32;
+    if (c0 >= Ppad) return;
+    int tsel = 0;
+#pragma unroll
+    for (int t = 1; t < MBAMD_MAX_TABLES; ++t) tsel += by >= tabs.start[t] ? 1 : 0;
+    const MBAMD_AS_CONST PartialsOp* __restrict__ op = as_const(tabs.ops[tsel]) + (by - tabs.start[tsel]);
+    int32_t* __restrict__ cumulative = tabs.cum[tsel];
+    const int mode = op->scale_mode;
+    const int half = lane >> 5, col = lane & 31;
+    const unsigned s1 = as_global(reinterpret_cast<const uint8_t*>(op->c1))[c0 + col];
+    const unsigned s2 = as_global(reinterpret_cast<const uint8_t*>(op->c2))[c0 + col];
+    const bool miss1 = s1 >= (unsigned) S, miss2 = s2 >= (unsigned) S;
+    const MBAMD_AS_GLOBAL float* r1 = as_global(op->m1) + (size_t) (miss1 ? 0u : s1) * SP + 4 * half;
+    const MBAMD_AS_GLOBAL float* r2 = as_global(op->m2) + (size_t) (miss2 ? 0u : s2) * SP + 4 * half;
+    f4 g1[KC][QC], g2[KC][QC];
+#pragma unroll
+    for (int k = 0; k < KC; ++k)
+#pragma unroll
+        for (int q = 0; q < QC; ++q) {
+            const int qq = (SC > 0 || q < Q) ? q : 0;
+            g1[k][q] = *reinterpret_cast<const MBAMD_AS_GLOBAL f4*>(r1 + (size_t) k * SP * SP + 8 * qq);
+            g2[k][q] = *reinterpret_cast<const MBAMD_AS_GLOBAL f4*>(r2 + (size_t) k * SP * SP + 8 * qq);
+        }
+    float mx = 0.0f;
+#pragma unroll
+    for (int k = 0; k < KC; ++k)
+#pragma unroll
+        for (int q = 0; q < QC; ++q) {
+            const int ib = 8 * q + 4 * half;
+            f4 a = g1[k][q], b = g2[k][q];
+            if (miss1) a = (f4) (1.0f);
+            if (miss2) b = (f4) (1.0f);
+            f4 v = a * b;
+            v.x = (ib + 0 < S) ? v.x : 0.0f;         // rows >= S (matrix padding / missing-state ones) do not exist
+            v.y = (ib + 1 < S) ? v.y : 0.0f;
+            v.z = (ib + 2 < S) ? v.z : 0.0f;
+            v.w = (ib + 3 < S) ? v.w : 0.0f;
+            g1[k][q] = v;
+            mx = fmaxf(mx, fmaxf(fmaxf(v.x, v.y), fmaxf(v.z, v.w)));
+        }
+    int e = 0;
+    if (mode == SCALE_WRITE) {
+        mx = fmaxf(mx, __shfl_xor(mx, 32));
+        e = scale_exponent(mx);
+        if (half == 0) {
+            as_global(op->scale)[c0 + col] = e;
+            if (cumulative != nullptr && e != 0) atomicAdd(cumulative + c0 + col, e);
+        }
+    } else if (mode == SCALE_READ) {
+        e = as_global(op->scale)[c0 + col];
+    }
+    float* strip = lds_f + (size_t) wave * S * 32;   // [S rows][32 patterns] of one category
+    MBAMD_AS_GLOBAL float* __restrict__ dst = as_global(op->dst) + gen_base(KC, S, c0) + 4 * (lane & 7);
+#pragma unroll
+    for (int k = 0; k < KC; ++k) {
+#pragma unroll
+        for (int q = 0; q < QC; ++q) {
+            const int ib = 8 * q + 4 * half;
+            f4 v = g1[k][q];
+            if (mode != SCALE_NONE) { v.x = scale_pow2(v.x, -e); v.y = scale_pow2(v.y, -e); v.z = scale_pow2(v.z, -e); v.w = scale_pow2(v.w, -e); }
+            if (ib + 0 < S) strip[(ib + 0) * 32 + col] = v.x;
+            if (ib + 1 < S) strip[(ib + 1) * 32 + col] = v.y;
+            if (ib + 2 < S) strip[(ib + 2) * 32 + col] = v.z;
+            if (ib + 3 < S) strip[(ib + 3) * 32 + col] = v.w;
+        }
+#pragma unroll
+        for (int u = 0; u < QC; ++u) {
+            const int row = (lane >> 3) + 8 * u;
+            if (row < S) {
+                const f4 v = *reinterpret_cast<const f4*>(strip + row * 32 + 4 * (lane & 7));
+                *reinterpret_cast<MBAMD_AS_GLOBAL f4*>(dst + ((size_t) k * S + row) * 32) = v;
+            }
+        }
+    }
+}
+
 // grid = (P_pad / 32) * operations of all tables; one dependency level per launch
 template <int NT, int SC, int KC>
 __global__ void __launch_bounds__(64 * 2 * KC * NT)
@@ -395,6 +491,254 @@ k_partials_mfma_serial(OpTables tabs, int S_rt, int SP, int Ppad, int gx, long l
         if (tracing) trace[((size_t) o * 8 + wave) * 3 + 1] = (long long) __builtin_amdgcn_s_memtime();
         __syncthreads();                            // results visible; tiles / smax reusable
         if (tracing) trace[((size_t) o * 8 + wave) * 3 + 2] = (long long) __builtin_amdgcn_s_memtime();
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Software-pipelined serial kernel (compile-time state counts): same work split as k_partials_mfma_serial,
+// but the latencies that bound a chain of dependent operations are taken off its critical path:
+//   * the operands of operation o+1 that do not depend on operation o -- its packed matrices, the
+//     child that is not o's result, tip states -- are loaded into a second register set while o computes;
+//   * the result of o stays in LDS (a [K][S][32] copy of the tile, which also stages the 1 KiB stores):
+//     when o+1 consumes it, its B operand is a ds_read, not a store -> L2 -> load round trip.
+// What remains per operation is the MFMA chain, the two LDS exchanges and three barriers.
+// ---------------------------------------------------------------------------------------------
+// An operation descriptor in scalar registers: four s_load_dwordx4 (the uint8 fields of PartialsOp would
+// otherwise be fetched with VECTOR loads, whose in-order counter then makes every descriptor access
+// wait for the previous operation's stores).
+struct SpineDesc {
+    uint64_t dst, c1, c2, m1, m2, scale;
+    uint32_t kinds;                 // c1_kind | c2_kind << 8 | ...
+    uint32_t modes;                 // dst_slot | scale_mode << 8 | flags << 16
+};
+__device__ __forceinline__ SpineDesc spine_desc(const MBAMD_AS_CONST PartialsOp* op)
+{
+    typedef unsigned u4 __attribute__((ext_vector_type(4)));
+    const MBAMD_AS_CONST u4* q = reinterpret_cast<const MBAMD_AS_CONST u4*>(op);
+    const u4 a = q[0], b = q[1], c = q[2], e = q[3];
+    SpineDesc d;
+    d.dst = a.x | ((uint64_t) a.y << 32);
+    d.c1 = a.z | ((uint64_t) a.w << 32);
+    d.c2 = b.x | ((uint64_t) b.y << 32);
+    d.m1 = b.z | ((uint64_t) b.w << 32);
+    d.m2 = c.x | ((uint64_t) c.y << 32);
+    d.scale = c.z | ((uint64_t) c.w << 32);
+    d.kinds = e.x;
+    d.modes = e.y;
+    return d;
+}
+static_assert(offsetof(PartialsOp, c1_kind) == 48 && offsetof(PartialsOp, scale_mode) == 53, "SpineDesc unpacking");
+
+template <int SC>
+struct SpineOperands {
+    static constexpr int T = (SC + 1) / 2;
+    float a[T], b[T];               // packed matrix tile / child rows
+    unsigned state;                 // tip child: this lane's state code
+    int eread;                      // SCALE_READ: this pattern's exponent
+};
+
+// Issue the loads of an operation's operands for compute wave (k, c, it): ALWAYS the same 2T + 2 vector
+// loads, with harmless addresses where an operand is not needed (tip child, forwarded child, no
+// SCALE_READ).  Compute waves issue no other vector-memory instruction, so the in-order counter lets
+// operation o wait for exactly its own operands while those of o+1 stay in flight.
+// A tip child contributes its state code only: its B operand is the one-hot vector of that state, so a
+// tip costs an MFMA chain but no dependent gather.
+template <int NT, int SC, int KC>
+__device__ __forceinline__ void spine_prefetch(const SpineDesc& d, uint64_t prev1, uint64_t prev2, int SP, int k, int c, int it,
+                                               int c0, int lane, SpineOperands<SC>& n)
+{
+    constexpr int T = (SC + 1) / 2;
+    const int col = lane & 31;
+    const int kind = (d.kinds >> (8 * c)) & 0xFF;
+    const int mode = (d.modes >> 8) & 0xFF;
+    const uint64_t child = c ? d.c2 : d.c1;
+    const float* mbase = reinterpret_cast<const float*>(c ? d.m2 : d.m1);
+    const MBAMD_AS_GLOBAL float* __restrict__ pa =
+        as_global(mbase) + (size_t) KC * SP * SP + ((size_t) (k * NT + it) * T) * 64 + lane;
+    const bool fromGlobal = kind != CHILD_STATES && child != prev1 && child != prev2;
+    const MBAMD_AS_GLOBAL float* __restrict__ cl =
+        fromGlobal ? as_global(reinterpret_cast<const float*>(child)) + gen_index(KC, SC, k, 0, c0) + lane : pa;
+    const MBAMD_AS_GLOBAL uint8_t* st = (kind == CHILD_STATES) ? as_global(reinterpret_cast<const uint8_t*>(child)) + c0 + col
+                                                                : reinterpret_cast<const MBAMD_AS_GLOBAL uint8_t*>(pa);
+    const MBAMD_AS_GLOBAL int32_t* er = (mode == SCALE_READ) ? as_global(reinterpret_cast<const int32_t*>(d.scale)) + c0 + col
+                                                              : reinterpret_cast<const MBAMD_AS_GLOBAL int32_t*>(pa);
+#pragma unroll
+    for (int t = 0; t < T; ++t) n.a[t] = pa[(size_t) t * 64];
+#pragma unroll
+    for (int t = 0; t < T; ++t) n.b[t] = cl[64 * min(t, (SC - 1 - (lane >> 5)) / 2)];   // (odd S: lanes >= 32 have no row S)
+    n.state = *st;
+    n.eread = *er;
+}
+
+// Compute waves: factor tile -> exchange -> product -> maximum -> rescaled result rows into LDS slot `mySlot`.
+template <int NT, int SC, int KC>
+__device__ __forceinline__ void spine_compute(const SpineDesc& d, uint64_t prev1, uint64_t prev2, int k, int c, int it, int wave,
+                                              int lane, const SpineOperands<SC>& cur, float* tiles, float* smax, float* slotPrev1,
+                                              float* slotPrev2, float* mySlot)
+{
+    constexpr int NP = 2 * KC * NT;
+    constexpr int S = SC, T = (SC + 1) / 2, Tfull = SC / 2;
+    const int half = lane >> 5, col = lane & 31;
+    const int mode = (d.modes >> 8) & 0xFF;
+    const int kind = (d.kinds >> (8 * c)) & 0xFF;
+    const uint64_t child = c ? d.c2 : d.c1;
+    float b[T];
+    bool missing = false;
+    if (kind == CHILD_STATES) {                     // one-hot column selector (a missing state is patched below)
+        missing = cur.state >= (unsigned) S;
+#pragma unroll
+        for (int t = 0; t < T; ++t) b[t] = (cur.state == (unsigned) (2 * t + half)) ? 1.0f : 0.0f;
+    } else if (child == prev1 || child == prev2) {  // one of the last two results, still in LDS
+        const float* fl = (child == prev1 ? slotPrev1 : slotPrev2) + (size_t) k * S * 32 + lane;
+#pragma unroll
+        for (int t = 0; t < Tfull; ++t) b[t] = fl[64 * t];
+        if (SC & 1) b[T - 1] = half ? 0.0f : fl[64 * Tfull];
+    } else {
+#pragma unroll
+        for (int t = 0; t < T; ++t) b[t] = cur.b[t];
+        if (SC & 1) b[T - 1] = half ? 0.0f : b[T - 1];
+    }
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
+#pragma unroll
+    for (int t = 0; t < T; ++t) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(cur.a[t], b[t], acc, 0, 0, 0);
+    if (kind == CHILD_STATES) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int i = 32 * it + (r & 3) + 8 * (r >> 2) + 4 * half;
+            acc[r] = missing ? ((i < S) ? 1.0f : 0.0f) : acc[r];
+        }
+    }
+    // hand the eight registers this wave does not keep to its partner (other child, same k and it)
+    float* mine = tiles + (size_t) wave * 8 * 64;
+    float keep[8];
+    if (c) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { mine[j * 64 + lane] = acc[j]; keep[j] = acc[8 + j]; }
+    } else {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { mine[j * 64 + lane] = acc[8 + j]; keep[j] = acc[j]; }
+    }
+    __syncthreads();
+    const float* other = tiles + (size_t) ((k * 2 + (1 - c)) * NT + it) * 8 * 64;
+    float out[8];
+    float mx = 0.0f;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const float v = keep[j] * other[j * 64 + lane];
+        out[j] = v;
+        const int i = 32 * it + 16 * c + (j & 3) + 8 * (j >> 2) + 4 * half;
+        mx = fmaxf(mx, (i < S) ? v : 0.0f);
+    }
+    int e = 0;
+    if (mode == SCALE_WRITE) {
+        mx = fmaxf(mx, __shfl_xor(mx, 32));
+        if (half == 0) smax[wave * 32 + col] = mx;
+        __syncthreads();
+        float m = 0.0f;
+#pragma unroll
+        for (int p = 0; p < NP; ++p) m = fmaxf(m, smax[p * 32 + col]);
+        e = scale_exponent(m);
+    } else if (mode == SCALE_READ) {
+        e = cur.eread;
+    }
+    float* frow = mySlot + ((size_t) k * S + 32 * it + 16 * c) * 32;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int lr = (j & 3) + 4 * half + 8 * (j >> 2);
+        if (32 * it + 16 * c + lr < S) frow[lr * 32 + col] = (mode != SCALE_NONE) ? scale_pow2(out[j], -e) : out[j];
+    }
+    __syncthreads();
+}
+
+// Writer wave: same barriers; stores the exponents (+ cumulative atomics) and copies the finished tile --
+// K*S*32 contiguous floats both in the LDS slot and in the tile-major buffer -- out with 1 KiB stores.
+template <int NT, int SC, int KC>
+__device__ __forceinline__ void spine_write(const SpineDesc& d, int32_t* __restrict__ cumulative, int c0, int lane,
+                                            const float* smax, const float* mySlot)
+{
+    constexpr int NP = 2 * KC * NT;
+    constexpr int F4 = KC * SC * 32 / 4;            // float4s per tile
+    const int mode = (d.modes >> 8) & 0xFF;
+    __syncthreads();                                // factor tiles exchanged
+    if (mode == SCALE_WRITE) {
+        __syncthreads();                            // maxima posted
+        if (lane < 32) {
+            float m = 0.0f;
+#pragma unroll
+            for (int p = 0; p < NP; ++p) m = fmaxf(m, smax[p * 32 + lane]);
+            const int e = scale_exponent(m);
+            as_global(reinterpret_cast<int32_t*>(d.scale))[c0 + lane] = e;
+            if (cumulative != nullptr && e != 0) atomicAdd(cumulative + c0 + lane, e);
+        }
+    }
+    __syncthreads();                                // result tile complete in LDS
+    MBAMD_AS_GLOBAL f4* __restrict__ dst =
+        reinterpret_cast<MBAMD_AS_GLOBAL f4*>(as_global(reinterpret_cast<float*>(d.dst)) + gen_base(KC, SC, c0));
+    const f4* src = reinterpret_cast<const f4*>(mySlot);
+#pragma unroll
+    for (int u = 0; u < (F4 + 63) / 64; ++u) {
+        const int idx = 64 * u + lane;
+        if (idx < F4) dst[idx] = src[idx];
+    }
+}
+
+// grid = (P_pad / 32) * tables; tabs.start[t] = operations of table t; block = 64 * (2*K*NT + 1);
+// dynamic LDS = NP * (2 KiB + 128 B) + 2 * K*S*32 floats.  Pipeline: while operation o computes, the operands
+// of o+1 and the descriptor of o+2 are in flight and the writer wave is still storing o-1.
+template <int NT, int SC, int KC>
+__global__ void __launch_bounds__(64 * (2 * KC * NT + 1))
+k_partials_mfma_spine(OpTables tabs, int SP, int gx, long long* __restrict__ trace)
+{
+    static_assert(SC > 0, "compile-time state count required");
+    constexpr int NP = 2 * KC * NT;
+    constexpr int TILE = KC * SC * 32;
+    extern __shared__ float lds_f[];
+    float* tiles = lds_f;                           // [NP][8][64]
+    float* smax = lds_f + NP * 8 * 64;              // [NP][32]
+    float* slots = smax + NP * 32;                  // [2][K][S][32]: the last two results
+    const int bx = blockIdx.x % gx, tsel = blockIdx.x / gx;
+    const int wave = __builtin_amdgcn_readfirstlane((int) (threadIdx.x >> 6)), lane = threadIdx.x & 63;
+    const int c0 = bx * 32;
+    const MBAMD_AS_CONST PartialsOp* __restrict__ ops = as_const(tabs.ops[tsel]);
+    int32_t* __restrict__ cumulative = tabs.cum[tsel];
+    const int count = tabs.start[tsel];
+    if (count <= 0) return;
+    const bool tracing = trace != nullptr && blockIdx.x == 0 && lane == 0;      // MBAMD_WALK_TRACE (timing experiments)
+    if (wave == NP) {                               // ---- writer wave
+        for (int o = 0; o < count; ++o) {
+            const SpineDesc d = spine_desc(ops + o);
+            spine_write<NT, SC, KC>(d, cumulative, c0, lane, smax, slots + (size_t) (o & 1) * TILE);
+        }
+        return;
+    }
+    const int k = wave / (2 * NT), c = (wave / NT) & 1, it = wave % NT;
+    SpineOperands<SC> A, B;
+    SpineDesc d = spine_desc(ops);                                  // operation o
+    SpineDesc dn = spine_desc(ops + (count > 1 ? 1 : 0));           // operation o + 1
+    uint64_t prev1 = 0, prev2 = 0;                                  // results of o-1, o-2 (LDS slots (o-1)&1, o&1)
+    spine_prefetch<NT, SC, KC>(d, prev1, prev2, SP, k, c, it, c0, lane, A);
+    for (int o = 0; o < count; o += 2) {
+        float* s0 = slots;                           // even operations write slot 0
+        float* s1 = slots + TILE;
+        {
+            if (tracing) trace[((size_t) o * 8 + (wave & 7)) * 3 + 0] = (long long) __builtin_amdgcn_s_memtime();
+            const SpineDesc dnn = spine_desc(ops + min(o + 2, count - 1));
+            spine_prefetch<NT, SC, KC>(dn, d.dst, prev1, SP, k, c, it, c0, lane, B);     // (harmless repeat of the last operation at the end)
+            spine_compute<NT, SC, KC>(d, prev1, prev2, k, c, it, wave, lane, A, tiles, smax, s1, s0, s0);
+            if (tracing) trace[((size_t) o * 8 + (wave & 7)) * 3 + 2] = (long long) __builtin_amdgcn_s_memtime();
+            prev2 = prev1; prev1 = d.dst; d = dn; dn = dnn;
+        }
+        if (o + 1 >= count) break;
+        {
+            if (tracing) trace[((size_t) (o + 1) * 8 + (wave & 7)) * 3 + 0] = (long long) __builtin_amdgcn_s_memtime();
+            const SpineDesc dnn = spine_desc(ops + min(o + 3, count - 1));
+            spine_prefetch<NT, SC, KC>(dn, d.dst, prev1, SP, k, c, it, c0, lane, A);
+            spine_compute<NT, SC, KC>(d, prev1, prev2, k, c, it, wave, lane, B, tiles, smax, s0, s1, s1);
+            if (tracing) trace[((size_t) (o + 1) * 8 + (wave & 7)) * 3 + 2] = (long long) __builtin_amdgcn_s_memtime();
+            prev2 = prev1; prev1 = d.dst; d = dn; dn = dnn;
+        }
     }
 }
 

@@ -34,10 +34,11 @@ lib.lib.mbamdWalkTrace.argtypes = [C.c_int, C.c_void_p, C.c_int, C.POINTER(C.c_i
 lib.lib.mbamdWalkTrace(bd.inst.id, out.ctypes.data, 4096, C.byref(ns), C.byref(nw))
 ns, nw = ns.value, nw.value
 tt = out[:ns, :nw, :].astype(np.float64)
-print("depth", depth(deep), "ops", ns, "waves", nw, "total (100 MHz ticks)", tt[-1, :, 2].max() - tt[0, :, 0].min())
+print("depth", depth(deep), "ops", ns, "waves", nw, "total (shader clocks)", tt[-1, :, 2].max() - tt[0, :, 0].min())
 if full:
     per = (tt[:, :, 2].max(axis=1) - tt[:, :, 0].min(axis=1))
     print("per-op ticks: min %.0f  p25 %.0f  median %.0f  p75 %.0f  max %.0f  sum %.0f" % (per.min(), np.percentile(per, 25), np.median(per), np.percentile(per, 75), per.max(), per.sum()))
     print(" ".join("%.0f" % x for x in per))
 for s in range(0 if not full else ns, ns):
-    print(s, "op", " ".join("%6.0f" % x for x in tt[s, :, 1] - tt[s, :, 0]), "| barrier", " ".join("%6.0f" % x for x in tt[s, :, 2] - tt[s, :, 1]))
+    nxt = tt[s + 1, :, 0] if s + 1 < ns else tt[s, :, 2]
+    print(s, "op (start -> end)", " ".join("%6.0f" % x for x in tt[s, :, 2] - tt[s, :, 0]), "| to next start", " ".join("%5.0f" % x for x in nxt - tt[s, :, 2]))
