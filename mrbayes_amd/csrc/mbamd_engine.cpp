@@ -86,6 +86,7 @@ enum KernelPath { PATH_AUTO = 0, PATH_GENERIC = 1, PATH_WALK = 2, PATH_MFMA = 3 
 struct Plan {
     std::vector<int> key;            // the BeagleOperation ints + cumulative index + layout epoch
     uint64_t hash = 0, lastUse = 0;
+    uint64_t lastLaunch = 0;         // Instance::launchClock value of the latest launch that reads d_table
     PartialsOp* d_table = nullptr;
     size_t cap = 0;                  // bytes allocated for d_table
     int nsteps = 0, W = 1, slotsUsed = 0;        // tree-walk schedule
@@ -109,6 +110,7 @@ struct Instance {
     int lastWalkSteps = 0, lastWalkSlots = 0;
     bool noIdleLoads = false;        // MBAMD_WALK_NO_IDLE_LOADS: global children are only copied by the loader wave
     bool walkKSplit = false;         // MBAMD_WALK_KSPLIT=1: two waves per operation (category split); measured slower (profiles/)
+    uint64_t launchClock = 0, syncedClock = 0;   // launches issued / launches known complete (last stream synchronisation)
     std::vector<double> h_freqs, h_weights;      // host mirrors of d_freqs / d_weights (uploadIfChanged)
     long long* d_trace = nullptr;    // MBAMD_WALK_TRACE: per-step clock stamps of workgroup 0 (timing experiments)
 
@@ -266,6 +268,7 @@ struct Instance {
     std::vector<char> pendingMatrixOut;          // matrix buffers the queued jobs write
     int submit(Plan* plan, int cumIdx, int32_t* cumPtr);
     bool noDefer = false;            // MBAMD_NO_DEFER: run every list at once
+    bool envInOrder = false, envVerbose = false, envReverseStep = false, envTrace = false;   // MBAMD_WALK_IN_ORDER, _VERBOSE, _EMU_REVERSE_STEP, _WALK_TRACE (read once)
     bool noSpine = false;            // MBAMD_NO_SPINE: serial launches use the plain (not software-pipelined) kernel
     int serialRatio = 4;             // MBAMD_MFMA_SERIAL: lists with <= ratio * levels operations run as ONE serial launch (0 = never)
     bool independentOfPending(const Plan& plan, int cumIdx);
@@ -327,6 +330,10 @@ int Instance::create(int tipCount_, int partialsBufferCount, int compactBufferCo
     noDefer = std::getenv("MBAMD_NO_DEFER") != nullptr;
     if (const char* e = std::getenv("MBAMD_MFMA_SERIAL")) serialRatio = std::max(0, std::atoi(e));
     noSpine = std::getenv("MBAMD_NO_SPINE") != nullptr;
+    envInOrder = std::getenv("MBAMD_WALK_IN_ORDER") != nullptr;
+    envVerbose = std::getenv("MBAMD_VERBOSE") != nullptr;
+    envReverseStep = std::getenv("MBAMD_EMU_REVERSE_STEP") != nullptr;
+    envTrace = std::getenv("MBAMD_WALK_TRACE") != nullptr;
 #endif
     partialsFloats = s4 ? (size_t) K * Ppad * 4 : (size_t) K * S * Ppad;
     matrixFloats = (size_t) K * SP * SP + (mfma ? (size_t) K * NT * T * 64 : 0);
@@ -665,6 +672,11 @@ int Instance::updatePartials(const BeagleOperation* ops, int n, int cumIdx)
             return submit(pl, cumIdx, cumPtr);
         }
     planMisses++;
+    if (s4 || !mfma || mfmaWhole || noDefer || pending.empty()) {
+        // launch the queued transition-matrix jobs now: the kernel runs while the host compiles the list
+        int mrc = flushMatrices();
+        if (mrc) return mrc;
+    }
     std::vector<PartialsOp> dev(n);
     std::vector<int> dstIdx(n), c1Idx(n), c2Idx(n);
     std::vector<char> written(nBuffers, 0);
@@ -802,6 +814,8 @@ int Instance::flushPending()
     if (pending.empty()) return BEAGLE_SUCCESS;
     std::vector<std::pair<Plan*, int>> work;
     work.swap(pending);
+    ++launchClock;
+    for (auto& w : work) w.first->lastLaunch = launchClock;
     auto cumOf = [&](int idx) { return idx >= 0 ? scale[idx] : (int32_t*) nullptr; };
     if (work.size() == 1) return timedRun(*work[0].first, cumOf(work[0].second));
 #if !defined(MBAMD_HOST_EMU)
@@ -909,21 +923,24 @@ int Instance::flushPending()
 int Instance::planTable(Plan& plan, const std::vector<PartialsOp>& table)
 {
     const size_t bytes = table.size() * sizeof(PartialsOp);
+    const bool inFlight = plan.lastLaunch > syncedClock;     // the old table may still be read by a running kernel
     if (bytes > plan.cap) {
-        HIP_TRY(hipStreamSynchronize(stream));       // the old table may still be read by a running kernel
+        if (inFlight) { HIP_TRY(hipStreamSynchronize(stream)); syncedClock = launchClock; }
         if (plan.d_table) HIP_TRY(hipFree(plan.d_table));
         plan.d_table = nullptr;
         plan.cap = 0;
         HIP_TRY(hipMalloc(&plan.d_table, bytes + bytes / 2));
         plan.cap = bytes + bytes / 2;
-    } else {
+    } else if (inFlight) {
         HIP_TRY(hipStreamSynchronize(stream));
+        syncedClock = launchClock;
     }
     return upload(plan.d_table, table.data(), bytes);
 }
 
 int Instance::timedRun(const Plan& plan, int32_t* cum)
 {
+    const_cast<Plan&>(plan).lastLaunch = ++launchClock;
     hipEvent_t ev0{}, ev1{};
     if (timing) {
         HIP_TRY(hipEventCreate(&ev0));
@@ -975,7 +992,7 @@ int Instance::buildWalk(Plan& plan, std::vector<PartialsOp>& dev, const std::vec
             lastWriter[dstIdx[o]] = o;
         }
     }
-    const bool inOrder = hazard || std::getenv("MBAMD_WALK_IN_ORDER") != nullptr;
+    const bool inOrder = hazard || envInOrder;
     if (inOrder) W = 1;
     W = std::max(1, std::min(W, std::max(1, maxSlots / 2)));
     std::vector<std::vector<int>> consumers(n);
@@ -1217,7 +1234,7 @@ int Instance::buildWalk(Plan& plan, std::vector<PartialsOp>& dev, const std::vec
             e.flags |= fl;
         }
     }
-    if (std::getenv("MBAMD_VERBOSE")) {
+    if (envVerbose) {
         int reloads = 0, globals = 0, drains = 0;
         for (int o = 0; o < n; ++o) {
             reloads += (dev[o].c1_kind == CHILD_RELOAD) + (dev[o].c2_kind == CHILD_RELOAD);
@@ -1242,7 +1259,7 @@ int Instance::runWalk(const Plan& plan, int32_t* cum)
     const unsigned grid = (unsigned) (Ppad / 64);
 #if defined(MBAMD_HOST_EMU)
     const int walkThreads = 64;
-    const int walkArgW = std::getenv("MBAMD_EMU_REVERSE_STEP") ? -W : W;
+    const int walkArgW = envReverseStep ? -W : W;
     const int ksplit = 1;
 #else
     // two waves per table entry (category split) when K is even and the workgroup stays within 8 waves
@@ -1319,7 +1336,7 @@ static void launch_mfma_serial_t(Instance& in, const OpTables& tabs, int ntables
     constexpr int NP = 2 * KC_ * NT_;
     const int gx = in.Ppad / 32;
     auto kern = k_partials_mfma_serial<NT_, SC_, KC_>;
-    if (!in.d_trace && std::getenv("MBAMD_WALK_TRACE")) {
+    if (!in.d_trace && in.envTrace) {
         if (hipMalloc(&in.d_trace, (size_t) 4096 * 8 * 3 * sizeof(long long)) != hipSuccess) in.d_trace = nullptr;
         else (void) hipMemset(in.d_trace, 0, (size_t) 4096 * 8 * 3 * sizeof(long long));
     }
@@ -1332,7 +1349,7 @@ static void launch_mfma_spine_t(Instance& in, const OpTables& tabs, int ntables)
 {
     constexpr int NP = 2 * KC_ * NT_;
     const int gx = in.Ppad / 32;
-    if (!in.d_trace && std::getenv("MBAMD_WALK_TRACE")) {
+    if (!in.d_trace && in.envTrace) {
         if (hipMalloc(&in.d_trace, (size_t) 4096 * 8 * 3 * sizeof(long long)) != hipSuccess) in.d_trace = nullptr;
         else (void) hipMemset(in.d_trace, 0, (size_t) 4096 * 8 * 3 * sizeof(long long));
     }
@@ -1602,6 +1619,7 @@ int Instance::fetchResult(double* out)
 {
     if (!pendingResult) return fail(BEAGLE_ERROR_GENERAL, "no log-likelihood pending");
     HIP_TRY(hipStreamSynchronize(stream));
+    syncedClock = launchClock;
     pendingResult = false;
     double s = 0.0;
     for (int i = 0; i < nblocks; ++i) s += h_sums[i];
