@@ -94,8 +94,8 @@ struct Plan {
     bool anyScale = false;
     bool narrow = false;                         // general path: few operations per level -> one serial launch
     int tipTip = 0;                              // general path: the first tipTip operations of level 0 have two compact tip children
-    int serialFrom = 0;                          // general path: levels >= serialFrom hold one operation each (the spine
-                                                 // towards the root): they run as one serial launch after the level launches
+    int serialFrom = 0;                          // general path: levels >= serialFrom are narrow (the spine towards the
+                                                 // root): they run as one serial launch after the level launches
     std::vector<int> bufsRead, bufsWritten, scalesUsed;   // buffer / scale indices the list touches (deferral hazards)
 };
 
@@ -270,6 +270,7 @@ struct Instance {
     bool noDefer = false;            // MBAMD_NO_DEFER: run every list at once
     bool envInOrder = false, envVerbose = false, envReverseStep = false, envTrace = false;   // MBAMD_WALK_IN_ORDER, _VERBOSE, _EMU_REVERSE_STEP, _WALK_TRACE (read once)
     bool noSpine = false;            // MBAMD_NO_SPINE: serial launches use the plain (not software-pipelined) kernel
+    int spineWidth = 1;              // MBAMD_SPINE_WIDTH: trailing levels of at most this many operations join the serial launch
     int serialRatio = 4;             // MBAMD_MFMA_SERIAL: lists with <= ratio * levels operations run as ONE serial launch (0 = never)
     bool independentOfPending(const Plan& plan, int cumIdx);
     int accumulate(const int* idx, int n, int cumIdx, int sign);
@@ -330,6 +331,7 @@ int Instance::create(int tipCount_, int partialsBufferCount, int compactBufferCo
     noDefer = std::getenv("MBAMD_NO_DEFER") != nullptr;
     if (const char* e = std::getenv("MBAMD_MFMA_SERIAL")) serialRatio = std::max(0, std::atoi(e));
     noSpine = std::getenv("MBAMD_NO_SPINE") != nullptr;
+    if (const char* e = std::getenv("MBAMD_SPINE_WIDTH")) spineWidth = std::max(1, std::atoi(e));
     envInOrder = std::getenv("MBAMD_WALK_IN_ORDER") != nullptr;
     envVerbose = std::getenv("MBAMD_VERBOSE") != nullptr;
     envReverseStep = std::getenv("MBAMD_EMU_REVERSE_STEP") != nullptr;
@@ -1449,7 +1451,7 @@ int Instance::buildGeneric(Plan& plan, std::vector<PartialsOp>& dev, const std::
     plan.start = start;
     plan.narrow = serialRatio > 0 && n <= serialRatio * nLevels;
     plan.serialFrom = nLevels;
-    while (plan.serialFrom > 0 && start[plan.serialFrom] - start[plan.serialFrom - 1] == 1) plan.serialFrom--;
+    while (plan.serialFrom > 0 && start[plan.serialFrom] - start[plan.serialFrom - 1] <= spineWidth) plan.serialFrom--;
     if (serialRatio == 0 || nLevels - plan.serialFrom < 2) plan.serialFrom = nLevels;
     return planTable(plan, sorted);
 }

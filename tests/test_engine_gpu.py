@@ -264,6 +264,63 @@ def test_mfma_kernel_variants_agree(gpu, golden_dir, monkeypatch, case):
     assert a == b and np.array_equal(sa, sb)
 
 
+@pytest.mark.parametrize("case", ["replicase_m3", "avian_wag_g4", "synth_aa_wag"])
+@pytest.mark.parametrize("scaling", [lk.MB_BEAGLE_SCALE_ALWAYS, lk.MB_BEAGLE_SCALE_DYNAMIC])
+def test_general_state_schedules_agree(gpu, golden_dir, monkeypatch, case, scaling):
+    """The general-state path picks per list between level launches (tip-pair kernel + one wave per factor
+    tile), the software-pipelined spine kernel (narrow lists, trailing single-operation levels) and the plain
+    serial kernel.  Every choice runs the same k-ordered fp32 chains: bit-identical lnL and site lnLs."""
+    div = division_from_golden(golden_dir, case)
+    base = _lnl_and_sites(gpu, div, scaling)
+    for env in ({"MBAMD_MFMA_SERIAL": "0"},                        # level launches only
+                {"MBAMD_MFMA_SERIAL": "100000"},                   # the whole list through the spine kernel
+                {"MBAMD_MFMA_SERIAL": "100000", "MBAMD_NO_SPINE": "1"},   # ... through the plain serial kernel
+                {"MBAMD_SPINE_WIDTH": "8"}):                       # wider trailing levels join the spine launch
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        got = _lnl_and_sites(gpu, div, scaling)
+        for k in env:
+            monkeypatch.delenv(k)
+        assert got[0] == base[0] and np.array_equal(got[1], base[1]), env
+
+
+@pytest.mark.parametrize("kind,ntaxa,npat", [("wag", 60, 700), ("m3", 40, 330)])
+def test_general_state_partial_updates_track_full_evaluation(gpu, oracle, kind, ntaxa, npat):
+    """A run of single-branch moves (the root-ward path of each is one spine launch; accepted and rejected
+    ones mixed) leaves the chain at exactly the lnL a fresh instance computes for the final tree."""
+    div = synthetic_division(kind, ntaxa, npat, seed=31, tree_seed=32, p_gap=0.03)
+    bd = lk.BeagleDivision(div, gpu, scaling=lk.MB_BEAGLE_SCALE_DYNAMIC)
+    bd.LogLike(0)
+    bd.AcceptMove(0)
+    t = div.tree
+    rng = np.random.default_rng(9)
+    nodes = [i for i in range(len(t.anc)) if t.anc[i] != -1 and i != t.root]
+    lnl = None
+    for rep in range(40):
+        b = int(rng.choice(nodes))
+        old = t.length[b]
+        t.length[b] = old * float(np.exp(0.6 * (rng.random() - 0.5)))
+        bd.TouchBranch(0, b)
+        lnl = bd.LogLike(0)
+        if rep % 3 == 2:                                           # reject: restore the branch, flip back
+            t.length[b] = old
+            bd.ResetFlips(0)
+            lnl = None
+        else:
+            bd.AcceptMove(0)
+    if lnl is None:
+        bd.TouchBranch(0, nodes[0])
+        lnl = bd.LogLike(0)
+        bd.AcceptMove(0)
+    bd.finalize()
+    fresh = lk.BeagleDivision(div, gpu, scaling=lk.MB_BEAGLE_SCALE_DYNAMIC)
+    want = fresh.LogLike(0)
+    fresh.finalize()
+    assert lnl == pytest.approx(want, rel=2e-7)
+    ref = oracle.tree_loglike(div, use_shortcuts=False)
+    assert abs(lnl - ref) / abs(ref) < 2e-6
+
+
 def test_walk_category_split_agrees(gpu, monkeypatch):
     div = synthetic_division("gtr", 120, 700, seed=71, tree_seed=72, p_gap=0.04)
     a, sa = _lnl_and_sites(gpu, div)
