@@ -13,7 +13,8 @@
 //                        all chains) is one contiguous region -> a few 2 MiB pages per workgroup (TLB), 4 KiB
 //                        contiguous per node update (DRAM pages).  Tip states and scale buffers of the
 //                        4-state path use the same block-major arrangement ([P_pad/64][buffer][64]).
-//   general partials   : float  [K][S][P_pad]         state-major: lanes = consecutive patterns -> coalesced
+//   general partials   : float  [P_pad/32][K][S][32]   tile-major (gen_index): lanes = consecutive patterns of a
+//                        32-pattern tile -> coalesced; a tile of one buffer is one contiguous K*S*128-byte run
 //   matrices           : float  [K][SP][SP] transposed (mT[k][j][i] = P_k(i->j)), zero padded to SP
 //                        (SP = 4 on the 4-state path); MFMA path: + A-operand copy, see mbamd_kernels_mfma.h
 //   tip states         : uint8  [P_pad]               value >= S = missing
@@ -206,8 +207,8 @@ namespace mbamd {
 
 // ---------------------------------------------------------------------------------------------
 // General state count: level-synchronous kernel.  grid = (P_pad/64, ops in this dependency level),
-// one thread per pattern, loop over categories.  State-major layout makes every load/store a
-// coalesced 256-byte wave access; the (transposed, zero-padded) transition matrix column
+// one thread per pattern, loop over categories.  The tile-major layout makes every load/store two
+// coalesced 128-byte half-wave accesses; the (transposed, zero-padded) transition matrix column
 // mT[k][j][0..SP) is wave-uniform and is consumed as scalar operands of v_fmac.
 //   FUSED_K > 0 : K == FUSED_K, all K*SP outputs stay in registers and the per-pattern rescale is
 //                 fused (power-of-two, see top of file);
