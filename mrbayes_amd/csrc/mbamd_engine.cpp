@@ -46,6 +46,20 @@ static ApiStats g_stats[] = {{"beagleUpdateTransitionMatrices"}, {"beagleUpdateP
                              {"beagle*ScaleFactors"}, {"beagleSet*"}, {"beagleGetSiteLogLikelihoods"}, {"plan build"}};
 enum { ST_MATRICES = 0, ST_PARTIALS, ST_LNL, ST_SCALE, ST_SET, ST_SITE, ST_PLAN };
 static const bool g_statsOn = std::getenv("MBAMD_STATS") != nullptr;
+// MBAMD_API_TRACE=1: one stderr line per C-ABI call (integration debugging: what does the client really send?)
+static const bool g_apiTrace = std::getenv("MBAMD_API_TRACE") != nullptr;
+#define API_TRACE(...) do { if (g_apiTrace) { std::fprintf(stderr, "[mbamd api] " __VA_ARGS__); std::fputc('\n', stderr); } } while (0)
+static std::string trace_ints(const int* v, int n) {
+    std::string r = "[";
+    for (int i = 0; v && i < n; ++i) r += (i ? "," : "") + std::to_string(v[i]);
+    return r + "]";
+}
+static std::string trace_doubles(const double* v, int n) {
+    std::string r = "[";
+    char buf[32];
+    for (int i = 0; v && i < n; ++i) { std::snprintf(buf, sizeof buf, "%s%.6g", i ? "," : "", v[i]); r += buf; }
+    return r + "]";
+}
 struct StatTimer {
     int id;
     std::chrono::steady_clock::time_point t0;
@@ -1707,6 +1721,9 @@ int beagleCreateInstance(int tipCount, int partialsBufferCount, int compactBuffe
                          int scaleBufferCount, int* resourceList, int resourceCount, long preferenceFlags,
                          long requirementFlags, BeagleInstanceDetails* returnInfo)
 {
+    API_TRACE("beagleCreateInstance(tips=%d, partials=%d, compact=%d, states=%d, patterns=%d, eigen=%d, matrices=%d, categories=%d, scale=%d)",
+              tipCount, partialsBufferCount, compactBufferCount, stateCount, patternCount, eigenBufferCount, matrixBufferCount,
+              categoryCount, scaleBufferCount);
     (void) preferenceFlags;
     if (tipCount < 0 || partialsBufferCount < 0 || compactBufferCount < 0 || stateCount < 2 || patternCount < 1 ||
         eigenBufferCount < 0 || matrixBufferCount < 0 || categoryCount < 1 || scaleBufferCount < 0)
@@ -1792,11 +1809,13 @@ int beagleFinalize(void)
 int beagleSetTipStates(int instance, int tipIndex, const int* inStates)
 {
     GET_INSTANCE(instance);
+    API_TRACE("beagleSetTipStates(tip=%d, states=%s...)", tipIndex, trace_ints(inStates, std::min(8, in->P)).c_str());
     return in->setTipStates(tipIndex, inStates);
 }
 int beagleSetTipPartials(int instance, int tipIndex, const double* inPartials)
 {
     GET_INSTANCE(instance);
+    API_TRACE("beagleSetTipPartials(tip=%d, %s...)", tipIndex, trace_doubles(inPartials, std::min(8, in->S)).c_str());
     return in->importPartials(tipIndex, inPartials, false);
 }
 int beagleSetPartials(int instance, int bufferIndex, const double* inPartials)
@@ -1815,12 +1834,14 @@ int beagleSetEigenDecomposition(int instance, int eigenIndex, const double* inEi
 {
     StatTimer st_(ST_SET);
     GET_INSTANCE(instance);
+    API_TRACE("beagleSetEigenDecomposition(eigen=%d, values=%s...)", eigenIndex, trace_doubles(inEigenValues, std::min(6, in->S)).c_str());
     return in->setEigen(eigenIndex, inEigenVectors, inInverseEigenVectors, inEigenValues);
 }
 int beagleSetStateFrequencies(int instance, int idx, const double* f)
 {
     StatTimer st_(ST_SET);
     GET_INSTANCE(instance);
+    API_TRACE("beagleSetStateFrequencies(%d, %s...)", idx, trace_doubles(f, std::min(6, in->S)).c_str());
     if (idx < 0 || idx >= in->nEigen) return fail(BEAGLE_ERROR_OUT_OF_RANGE, "beagleSetStateFrequencies: index");
     return in->uploadIfChanged(in->h_freqs, (size_t) idx * in->S, in->d_freqs, f, in->S);
 }
@@ -1828,6 +1849,7 @@ int beagleSetCategoryWeights(int instance, int idx, const double* w)
 {
     StatTimer st_(ST_SET);
     GET_INSTANCE(instance);
+    API_TRACE("beagleSetCategoryWeights(%d, %s)", idx, trace_doubles(w, in->K).c_str());
     if (idx < 0 || idx >= in->nEigen) return fail(BEAGLE_ERROR_OUT_OF_RANGE, "beagleSetCategoryWeights: index");
     return in->uploadIfChanged(in->h_weights, (size_t) idx * in->K, in->d_weights, w, in->K);
 }
@@ -1835,6 +1857,7 @@ int beagleSetCategoryRates(int instance, const double* r)
 {
     StatTimer st_(ST_SET);
     GET_INSTANCE(instance);
+    API_TRACE("beagleSetCategoryRates(%s)", trace_doubles(r, in->K).c_str());
     if (in->K > MBAMD_MAX_RATES) return fail(BEAGLE_ERROR_NO_IMPLEMENTATION, "more than 16 rate categories");
     for (int k = 0; k < in->K; ++k) in->rates.r[k] = r[k];
     return BEAGLE_SUCCESS;
@@ -1850,6 +1873,8 @@ int beagleUpdateTransitionMatrices(int instance, int eigenIndex, const int* prob
 {
     StatTimer st_(ST_MATRICES);
     GET_INSTANCE_NOFLUSH(instance);
+    API_TRACE("beagleUpdateTransitionMatrices(eigen=%d, count=%d, indices=%s..., lengths=%s...)", eigenIndex, count,
+              trace_ints(probabilityIndices, std::min(6, count)).c_str(), trace_doubles(edgeLengths, std::min(6, count)).c_str());
     if (!in->pending.empty()) {                  // deferred lists read the matrices about to be replaced
         int frc_ = in->flushPending();
         if (frc_ != BEAGLE_SUCCESS) return frc_;
@@ -1873,6 +1898,9 @@ int beagleUpdatePartials(int instance, const BeagleOperation* operations, int op
 {
     StatTimer st_(ST_PARTIALS);
     GET_INSTANCE_NOFLUSH(instance);
+    API_TRACE("beagleUpdatePartials(count=%d, cumulative=%d, first=%s, last=%s)", operationCount, cumulativeScaleIndex,
+              trace_ints(reinterpret_cast<const int*>(operations), operationCount > 0 ? 7 : 0).c_str(),
+              trace_ints(reinterpret_cast<const int*>(operations + std::max(0, operationCount - 1)), operationCount > 0 ? 7 : 0).c_str());
     return in->updatePartials(operations, operationCount, cumulativeScaleIndex);
 }
 int beagleWaitForPartials(int instance, const int* destinationPartials, int destinationPartialsCount)
@@ -1944,8 +1972,13 @@ int beagleCalculateRootLogLikelihoods(int instance, const int* bufferIndices, co
 {
     StatTimer st_(ST_LNL);
     GET_INSTANCE(instance);
-    return in->integrate(bufferIndices, nullptr, nullptr, categoryWeightsIndices, stateFrequenciesIndices,
-                         cumulativeScaleIndices, count, outSumLogLikelihood);
+    const int rc_ = in->integrate(bufferIndices, nullptr, nullptr, categoryWeightsIndices, stateFrequenciesIndices,
+                                  cumulativeScaleIndices, count, outSumLogLikelihood);
+    API_TRACE("beagleCalculateRootLogLikelihoods(buffers=%s, weights=%s, freqs=%s, cumulative=%s) -> %d, lnL %.6f",
+              trace_ints(bufferIndices, count).c_str(), trace_ints(categoryWeightsIndices, count).c_str(),
+              trace_ints(stateFrequenciesIndices, count).c_str(), trace_ints(cumulativeScaleIndices, count).c_str(), rc_,
+              outSumLogLikelihood ? *outSumLogLikelihood : 0.0);
+    return rc_;
 }
 int beagleCalculateEdgeLogLikelihoods(int instance, const int* parentBufferIndices, const int* childBufferIndices,
                                       const int* probabilityIndices, const int* firstDerivativeIndices,
@@ -1958,8 +1991,14 @@ int beagleCalculateEdgeLogLikelihoods(int instance, const int* parentBufferIndic
     GET_INSTANCE(instance);
     if (firstDerivativeIndices || secondDerivativeIndices || outSumFirstDerivative || outSumSecondDerivative)
         return fail(BEAGLE_ERROR_NO_IMPLEMENTATION, "beagleCalculateEdgeLogLikelihoods: derivatives");
-    return in->integrate(parentBufferIndices, childBufferIndices, probabilityIndices, categoryWeightsIndices,
-                         stateFrequenciesIndices, cumulativeScaleIndices, count, outSumLogLikelihood);
+    const int rc_ = in->integrate(parentBufferIndices, childBufferIndices, probabilityIndices, categoryWeightsIndices,
+                                  stateFrequenciesIndices, cumulativeScaleIndices, count, outSumLogLikelihood);
+    API_TRACE("beagleCalculateEdgeLogLikelihoods(parents=%s, children=%s, matrices=%s, weights=%s, freqs=%s, cumulative=%s) -> %d, lnL %.6f",
+              trace_ints(parentBufferIndices, count).c_str(), trace_ints(childBufferIndices, count).c_str(),
+              trace_ints(probabilityIndices, count).c_str(), trace_ints(categoryWeightsIndices, count).c_str(),
+              trace_ints(stateFrequenciesIndices, count).c_str(), trace_ints(cumulativeScaleIndices, count).c_str(), rc_,
+              outSumLogLikelihood ? *outSumLogLikelihood : 0.0);
+    return rc_;
 }
 int beagleGetSiteLogLikelihoods(int instance, double* outLogLikelihoods)
 {

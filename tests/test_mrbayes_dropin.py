@@ -64,6 +64,65 @@ def test_unmodified_mrbayes_on_mi355x(scaling):
     assert "Analysis completed" in out, out[-1500:]
 
 
+# ---- general-state models through the real src/mbbeagle.c ---------------------------------------------------
+def _general_case(kind, ntaxa, nsites):
+    nstates = {"wag": 20, "m3": 61}[kind]
+    st = mbdata.synthetic_states(ntaxa, nsites, nstates, 11, 0.15, 0.03)
+    tr = mbtree.random_tree(ntaxa, 12, brlen=0.05)
+    return st, tr
+
+
+def _check_wag(binary):
+    """Protein data, fixed WAG + gamma(4): no randomly drawn starting values, so the engine-driven binary must
+    print the native kernels' initial lnL."""
+    st, tr = _general_case("wag", 14, 300)
+    out, _ = refrun.run_mb(binary, refrun.model_nexus("wag", st, tr, beagle="dynamic"))
+    assert "mbamd" in out, out[-1500:]
+    ours = refrun.initial_lnl(out)
+    if os.path.exists(refrun.REF_MB):
+        native = refrun.initial_lnl(refrun.run_mb(refrun.REF_MB, refrun.model_nexus("wag", st, tr))[0])
+        assert abs(ours - native) / abs(native) < 1e-5, (ours, native)
+    return ours
+
+
+def _check_m3(binary, oracle):
+    """Codon M3 (three eigen-systems mixed at the root, nCijkParts = 3, reference src/mbbeagle.c:1194-1206,
+    1231-1274).  MrBayes draws the omega-class frequencies at start-up (and draws them differently in its BEAGLE
+    and native configurations), so the check is against the CPU oracle evaluated at the values this very run
+    started from (generation-0 row of its .p file)."""
+    from mrbayes_amd.division import build_division, _tips_from_states
+    st, tr = _general_case("m3", 9, 80)
+    out, row = refrun.run_mb_with_samples(binary, refrun.model_nexus("m3", st, tr, ngen=1, beagle="dynamic"))
+    assert "mbamd" in out, out[-1500:]
+    ours = refrun.initial_lnl(out)
+    omegas = [row["omega(%d)" % i] for i in (1, 2, 3)]
+    freqs = [row["pi(%d)" % i] for i in (1, 2, 3)]
+    cols, counts = np.unique(st, axis=1, return_counts=True)
+    tip_states, tip_partials = _tips_from_states(cols)
+    div = build_division("m3", tr, counts.astype(float), tip_states, tip_partials, omegas=omegas, omega_freqs=freqs, ncat=1)
+    want = oracle.tree_loglike(div, use_shortcuts=False)
+    assert abs(ours - want) / abs(want) < 2e-6, (ours, want, omegas, freqs)
+
+
+def test_general_state_models_on_emulated_engine(oracle):
+    if not os.path.exists(refrun.REF_MB_EMU):
+        pytest.skip("oracle/_ref/mb_emu not built (build container only)")
+    _check_wag(refrun.REF_MB_EMU)
+    _check_m3(refrun.REF_MB_EMU, oracle)
+
+
+@pytest.mark.gpu
+def test_general_state_models_on_mi355x(oracle):
+    if not os.path.exists(refrun.REF_MB_AMD):
+        pytest.skip("oracle/_ref/mb_amd was not built (needs the reference sources at build time)")
+    _check_wag(refrun.REF_MB_AMD)
+    _check_m3(refrun.REF_MB_AMD, oracle)
+    # a short protein MCMC run (default moves: partial updates -> spine kernel) must complete on the GPU engine
+    st, tr = _general_case("wag", 14, 300)
+    out, _ = refrun.run_mb(refrun.REF_MB_AMD, refrun.model_nexus("wag", st, tr, ngen=400, beagle="dynamic"))
+    assert "Analysis completed" in out, out[-1500:]
+
+
 # ---- the reference's own integration check (testing/test1.nex style), engine-driven ------------------------
 def _tap_expected():
     with open(os.path.join(ROOT, "tests", "golden", "primates_tap.json")) as fh:

@@ -136,3 +136,52 @@ def mcmc_nexus(states, tree_or_none, ngen, beagle=None, nchains=1, fname="mc", f
 def analysis_seconds(stdout):
     m = re.search(r"Analysis used ([0-9.]+) seconds of CPU time", stdout)
     return float(m.group(1)) if m else None
+
+
+_AA = "ARNDCQEGHILKMFPSTWYV"
+_SENSE_CODONS = [a + b + c for a in "ACGT" for b in "ACGT" for c in "ACGT" if a + b + c not in ("TAA", "TAG", "TGA")]
+
+
+def model_nexus(kind, states, tree, ngen=1, beagle=None, fname="mk"):
+    """Known-answer / short-run NEXUS text for the general-state models of the hot path: kind "wag" (protein,
+    fixed WAG + gamma 4) or "m3" (codon, omegavar=M3).  states: int array [ntaxa][nsites], value >= nstates = gap."""
+    names = ["t%d" % (i + 1) for i in range(states.shape[0])]
+    if kind == "wag":
+        seqs = ["".join(_AA[x] if x < 20 else "-" for x in row) for row in states]
+        datatype, lset = "protein", "prset aamodelpr=fixed(wag); lset rates=gamma ngammacat=4;"
+    elif kind == "m3":
+        seqs = ["".join(_SENSE_CODONS[x] if x < 61 else "---" for x in row) for row in states]
+        datatype, lset = "dna", "lset nucmodel=codon omegavar=M3;"
+    else:
+        raise ValueError(kind)
+    s = "#NEXUS\nbegin data;\n  dimensions ntax=%d nchar=%d;\n" % (len(names), len(seqs[0]))
+    s += "  format datatype=%s interleave=no gap=- missing=?;\n  matrix\n" % datatype
+    for n, q in zip(names, seqs):
+        s += "%s  %s\n" % (n, q)
+    s += "  ;\nend;\nbegin mrbayes;\n  set autoclose=yes nowarnings=yes seed=12345 swapseed=12345 precision=15;\n  %s\n" % lset
+    if beagle:
+        s += "  set usebeagle=yes beagledevice=gpu beagleprecision=single beaglescaling=%s;\n" % beagle
+    s += "end;\nbegin trees;\n  tree t = [&U] %s\nend;\n" % tree.to_newick(names)
+    s += "begin mrbayes;\n  startvals tau=t V=t;\n"
+    s += "  mcmc ngen=%d nchains=1 nruns=1 samplefreq=%d printfreq=%d diagnfreq=%d filename=%s;\nend;\n" % (
+        ngen, max(ngen, 1), max(ngen, 1), max(ngen, 1), fname)
+    return s
+
+
+def run_mb_with_samples(binary, nexus_text, timeout=1800, env=None):
+    """Like run_mb, but also returns the first sampled row of the run's .p file as a dict (column -> float):
+    the generation-0 row holds the starting values MrBayes drew, e.g. the M3 omega-class frequencies."""
+    with tempfile.TemporaryDirectory() as wd:
+        with open(os.path.join(wd, "run.nex"), "w") as fh:
+            fh.write(nexus_text)
+        res = subprocess.run([binary, "run.nex"], cwd=wd, capture_output=True, text=True, timeout=timeout,
+                             env=dict(os.environ, **(env or {})))
+        row = {}
+        for f in sorted(os.listdir(wd)):
+            if f.endswith(".p"):
+                with open(os.path.join(wd, f)) as fh:
+                    lines = [l for l in fh.read().splitlines() if l and not l.startswith("[")]
+                if len(lines) >= 2:
+                    row = dict(zip(lines[0].split("\t"), (float(x) for x in lines[1].split("\t"))))
+                break
+        return res.stdout + res.stderr, row
