@@ -107,6 +107,8 @@ struct Plan {
     std::vector<int> start;                      // general path: first table entry of each dependency level
     bool anyScale = false;
     bool narrow = false;                         // general path: few operations per level -> one serial launch
+    std::vector<std::pair<int, int>> chains;     // narrow general-state lists: (first table entry, operations) of up to four
+                                                 // mutually independent sub-lists (they walk in parallel workgroups)
     int tipTip = 0;                              // general path: the first tipTip operations of level 0 have two compact tip children
     int serialFrom = 0;                          // general path: levels >= serialFrom are narrow (the spine towards the
                                                  // root): they run as one serial launch after the level launches
@@ -847,15 +849,26 @@ int Instance::flushPending()
         maxLevels = std::max(maxLevels, w.first->start.size() - 1);
         allNarrow = allNarrow && w.first->narrow;
     }
-    if (allNarrow) {                             // every list is a root-ward path: one launch walks them all
+    if (allNarrow) {                             // every list is a set of root-ward paths: one launch walks them all
+        size_t nchains = 0;
+        for (auto& w : work) nchains += w.first->chains.size();
         OpTables tabs;
         std::memset(&tabs, 0, sizeof tabs);
         int t = 0;
         for (auto& w : work) {
-            tabs.ops[t] = w.first->d_table;
-            tabs.cum[t] = cumOf(w.second);
-            tabs.start[t] = w.first->start.back();
-            ++t;
+            if (nchains <= MBAMD_MAX_TABLES) {
+                for (auto& ch : w.first->chains) {
+                    tabs.ops[t] = w.first->d_table + ch.first;
+                    tabs.cum[t] = cumOf(w.second);
+                    tabs.start[t] = ch.second;
+                    ++t;
+                }
+            } else {                             // too many sub-lists: each list in its own order
+                tabs.ops[t] = w.first->d_table;
+                tabs.cum[t] = cumOf(w.second);
+                tabs.start[t] = w.first->start.back();
+                ++t;
+            }
         }
         if (launch_mfma_serial(*this, tabs, t)) {
             pendingLaunches += 1;
@@ -1464,6 +1477,55 @@ int Instance::buildGeneric(Plan& plan, std::vector<PartialsOp>& dev, const std::
     for (const PartialsOp& d : sorted) plan.anyScale |= d.scale_mode != SCALE_NONE;
     plan.start = start;
     plan.narrow = serialRatio > 0 && n <= serialRatio * nLevels;
+    plan.chains.clear();
+    if (plan.narrow) {
+        // A narrow list usually is several independent root-ward paths interleaved (MrBayes puts the operations of
+        // all eigen-system parts of a codon model into one list, reference src/mbbeagle.c:1029-1100): split it into
+        // connected components of the "touches a buffer somebody writes" relation and append them, each in list
+        // order, behind the level-sorted table; the serial kernel walks them side by side.
+        std::vector<int> comp(n);
+        for (int o = 0; o < n; ++o) comp[o] = o;
+        auto find = [&](int x) { while (comp[x] != x) x = comp[x] = comp[comp[x]]; return x; };
+        auto unite = [&](int a, int b) { a = find(a); b = find(b); if (a != b) comp[std::max(a, b)] = std::min(a, b); };
+        std::vector<int> owner(nBuffers, -1);                    // an operation of the component that writes the buffer
+        for (int o = 0; o < n; ++o) {
+            if (owner[dstIdx[o]] >= 0) unite(o, owner[dstIdx[o]]);
+            owner[dstIdx[o]] = o;
+        }
+        for (int o = 0; o < n; ++o) {
+            if (owner[c1Idx[o]] >= 0) unite(o, owner[c1Idx[o]]);
+            if (owner[c2Idx[o]] >= 0) unite(o, owner[c2Idx[o]]);
+        }
+        for (int a = 0; a < n; ++a)                              // node scale buffers written by one, read by another
+            for (int b = a + 1; b < n; ++b)
+                if (dev[a].scale == dev[b].scale && dev[a].scale_mode != SCALE_NONE && dev[b].scale_mode != SCALE_NONE &&
+                    (dev[a].scale_mode == SCALE_WRITE || dev[b].scale_mode == SCALE_WRITE))
+                    unite(a, b);
+        std::vector<int> roots;
+        for (int o = 0; o < n; ++o) if (find(o) == o) roots.push_back(o);
+        if (roots.size() > 1) {
+            // at most MBAMD_MAX_TABLES bins, largest components first, each into the currently shortest bin
+            std::vector<int> size(n, 0);
+            for (int o = 0; o < n; ++o) size[find(o)]++;
+            std::sort(roots.begin(), roots.end(), [&](int a, int b) { return size[a] > size[b]; });
+            const int nb = std::min<int>(MBAMD_MAX_TABLES, (int) roots.size());
+            std::vector<int> binLen(nb, 0), binOf(n, 0);
+            for (int r : roots) {
+                const int bsel = (int) (std::min_element(binLen.begin(), binLen.end()) - binLen.begin());
+                binOf[r] = bsel;
+                binLen[bsel] += size[r];
+            }
+            int off = n;
+            for (int bsel = 0; bsel < nb; ++bsel) {
+                const int first = off;
+                for (int o = 0; o < n; ++o)
+                    if (binOf[find(o)] == bsel) { sorted.push_back(dev[o]); ++off; }
+                if (off > first) plan.chains.emplace_back(first, off - first);
+            }
+        } else {
+            plan.chains.emplace_back(0, n);
+        }
+    }
     plan.serialFrom = nLevels;
     while (plan.serialFrom > 0 && start[plan.serialFrom] - start[plan.serialFrom - 1] <= spineWidth) plan.serialFrom--;
     if (serialRatio == 0 || nLevels - plan.serialFrom < 2) plan.serialFrom = nLevels;
@@ -1479,10 +1541,14 @@ int Instance::runGeneric(const Plan& plan, int32_t* cum)
     if (plan.narrow && mfma && !mfmaWhole) {
         OpTables tabs;
         std::memset(&tabs, 0, sizeof tabs);
-        tabs.ops[0] = plan.d_table;
-        tabs.cum[0] = cum;
-        tabs.start[0] = start[nLevels];
-        if (launch_mfma_serial(*this, tabs, 1)) {
+        int nt = 0;
+        for (auto& ch : plan.chains) {
+            tabs.ops[nt] = plan.d_table + ch.first;
+            tabs.cum[nt] = cum;
+            tabs.start[nt] = ch.second;
+            ++nt;
+        }
+        if (launch_mfma_serial(*this, tabs, nt)) {
             pendingLaunches += 1;
             HIP_TRY(hipGetLastError());
             return BEAGLE_SUCCESS;
