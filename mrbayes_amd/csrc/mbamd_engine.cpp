@@ -126,6 +126,16 @@ struct Instance {
     int lastWalkSteps = 0, lastWalkSlots = 0;
     bool noIdleLoads = false;        // MBAMD_WALK_NO_IDLE_LOADS: global children are only copied by the loader wave
     bool walkKSplit = false;         // MBAMD_WALK_KSPLIT=1: two waves per operation (category split); measured slower (profiles/)
+    // scratch of Instance::buildWalk, kept between calls (a move compiles a fresh list every generation: no allocations)
+    struct WalkScratch {
+        std::vector<int> prod1, prod2, lastWriter, indeg, pendingReads, prio, need, stepOf, slotOf, slotHolder, slotFreeFrom,
+                         ready, chosen;
+        std::vector<char> readOld, readThisStep, drainBefore;
+        std::vector<std::vector<int>> consumers, steps;
+        std::vector<std::vector<PartialsOp>> stepLoads;
+        std::vector<std::pair<int, int>> stack;
+        std::vector<PartialsOp> table;
+    } ws;
     uint64_t launchClock = 0, syncedClock = 0;   // launches issued / launches known complete (last stream synchronisation)
     std::vector<double> h_freqs, h_weights;      // host mirrors of d_freqs / d_weights (uploadIfChanged)
     long long* d_trace = nullptr;    // MBAMD_WALK_TRACE: per-step clock stamps of workgroup 0 (timing experiments)
@@ -1007,11 +1017,15 @@ int Instance::buildWalk(Plan& plan, std::vector<PartialsOp>& dev, const std::vec
     // ---- dependencies: prodN[o] = operation of this list producing child N of o (or -1).  A list with
     // write-after-read / write-after-write hazards on buffer indices (never produced by MrBayes) is
     // executed strictly in list order by a single compute wave.
-    std::vector<int> prod1(n, -1), prod2(n, -1);
+    std::vector<int>&prod1 = ws.prod1, &prod2 = ws.prod2;
+    prod1.assign(n, -1);
+    prod2.assign(n, -1);
     bool hazard = false;
     {
-        std::vector<int> lastWriter(nBuffers, -1);
-        std::vector<char> readOld(nBuffers, 0);
+        std::vector<int>& lastWriter = ws.lastWriter;
+        std::vector<char>& readOld = ws.readOld;
+        lastWriter.assign(nBuffers, -1);
+        readOld.assign(nBuffers, 0);
         for (int o = 0; o < n; ++o) {
             prod1[o] = lastWriter[c1Idx[o]];
             prod2[o] = lastWriter[c2Idx[o]];
@@ -1024,8 +1038,12 @@ int Instance::buildWalk(Plan& plan, std::vector<PartialsOp>& dev, const std::vec
     const bool inOrder = hazard || envInOrder;
     if (inOrder) W = 1;
     W = std::max(1, std::min(W, std::max(1, maxSlots / 2)));
-    std::vector<std::vector<int>> consumers(n);
-    std::vector<int> indeg(n, 0), pendingReads(n, 0);
+    std::vector<std::vector<int>>& consumers = ws.consumers;
+    if ((int) consumers.size() < n) consumers.resize(n);
+    for (int o = 0; o < n; ++o) consumers[o].clear();
+    std::vector<int>&indeg = ws.indeg, &pendingReads = ws.pendingReads;
+    indeg.assign(n, 0);
+    pendingReads.assign(n, 0);
     for (int o = 0; o < n; ++o) {
         if (prod1[o] >= 0) { consumers[prod1[o]].push_back(o); indeg[o]++; }
         if (prod2[o] >= 0 && prod2[o] != prod1[o]) { consumers[prod2[o]].push_back(o); indeg[o]++; }
@@ -1034,16 +1052,19 @@ int Instance::buildWalk(Plan& plan, std::vector<PartialsOp>& dev, const std::vec
     // Scheduling priority: Sethi-Ullman order of the operation forest (at every node the child subtree
     // that needs more live values first).  MrBayes' own post-order visits the left child first whatever
     // its size, which on a 500-taxon tree keeps up to ~23 partials live; this order needs ~log2(N).
-    std::vector<int> prio(n, 0);
+    std::vector<int>& prio = ws.prio;
+    prio.assign(n, 0);
     if (!inOrder) {
-        std::vector<int> need(n, 1);
+        std::vector<int>& need = ws.need;
+        need.assign(n, 1);
         for (int o = 0; o < n; ++o) {                     // children precede parents in the list
             const int a = prod1[o], b = (prod2[o] != prod1[o]) ? prod2[o] : -1;
             const int na = a >= 0 ? need[a] : 0, nb = b >= 0 ? need[b] : 0;
             need[o] = std::max(1, (na == nb) ? na + (na > 0 ? 1 : 0) : std::max(na, nb));
         }
         int counter = 0;
-        std::vector<std::pair<int, int>> stack;           // (op, state)
+        std::vector<std::pair<int, int>>& stack = ws.stack;   // (op, state)
+        stack.clear();
         for (int root = n - 1; root >= 0; --root) {
             if (!consumers[root].empty()) continue;
             stack.emplace_back(root, 0);
@@ -1067,12 +1088,18 @@ int Instance::buildWalk(Plan& plan, std::vector<PartialsOp>& dev, const std::vec
         return best;
     };
 
-    std::vector<int> stepOf(n, -1), slotOf(n, -1);
-    std::vector<int> slotHolder(maxSlots, -1), slotFreeFrom(maxSlots, -1);
-    std::vector<std::vector<int>> steps;
-    std::vector<std::vector<PartialsOp>> stepLoads;       // LOAD entries (idle compute waves prefetch global children)
-    std::vector<char> drainBefore;                        // step q re-reads a value this list stored earlier
-    std::vector<int> ready;
+    std::vector<int>&stepOf = ws.stepOf, &slotOf = ws.slotOf, &slotHolder = ws.slotHolder, &slotFreeFrom = ws.slotFreeFrom;
+    stepOf.assign(n, -1);
+    slotOf.assign(n, -1);
+    slotHolder.assign(maxSlots, -1);
+    slotFreeFrom.assign(maxSlots, -1);
+    std::vector<std::vector<int>>& steps = ws.steps;      // steps[0 .. nstepsBuilt)
+    std::vector<std::vector<PartialsOp>>& stepLoads = ws.stepLoads;   // LOAD entries (idle compute waves prefetch global children)
+    int nstepsBuilt = 0;
+    std::vector<char>& drainBefore = ws.drainBefore;      // step q re-reads a value this list stored earlier
+    drainBefore.clear();
+    std::vector<int>& ready = ws.ready;
+    ready.clear();
     for (int o = 0; o < n; ++o) if (indeg[o] == 0) ready.push_back(o);
     int slotsUsed = 0, done = 0;
 
@@ -1087,8 +1114,10 @@ int Instance::buildWalk(Plan& plan, std::vector<PartialsOp>& dev, const std::vec
                 const int ry = (prod1[y] >= 0 && slotOf[prod1[y]] >= 0) + (prod2[y] >= 0 && slotOf[prod2[y]] >= 0);
                 return rx > ry;
             });
-        std::vector<int> chosen;
-        std::vector<char> readThisStep(n, 0);              // values read by operations already placed in this step
+        std::vector<int>& chosen = ws.chosen;
+        chosen.clear();
+        std::vector<char>& readThisStep = ws.readThisStep;  // values read by operations already placed in this step
+        readThisStep.assign(n, 0);
         bool needDrain = false;
         // pass 0 places what fits without evicting anything; only a step that would stay empty may evict
         // (a re-read from HBM costs a store drain and a synchronous copy by the loader -- far more than a bubble)
@@ -1103,10 +1132,12 @@ int Instance::buildWalk(Plan& plan, std::vector<PartialsOp>& dev, const std::vec
             uint8_t* kind[2] = {&d.c1_kind, &d.c2_kind};
             uint8_t* slot[2] = {&d.c1_slot, &d.c2_slot};
             bool ok = true, reload = false;
-            std::vector<int> taken;                         // slots claimed by this operation so far (rolled back on failure)
+            struct Small { int v[4]; int n = 0; void push_back(int x) { v[n++] = x; } bool has(int x) const { for (int i = 0; i < n; ++i) if (v[i] == x) return true; return false; }
+                           bool empty() const { return n == 0; } int back() const { return v[n - 1]; } void pop_back() { --n; } };
+            Small taken;                                    // slots claimed by this operation so far (rolled back on failure)
             auto claimFree = [&](int fromStep) {            // a slot nobody uses from `fromStep` on
                 for (int t = 0; t < maxSlots; ++t)
-                    if (slotHolder[t] < 0 && slotFreeFrom[t] <= fromStep && std::find(taken.begin(), taken.end(), t) == taken.end())
+                    if (slotHolder[t] < 0 && slotFreeFrom[t] <= fromStep && !taken.has(t))
                         return t;
                 return -1;
             };
@@ -1115,14 +1146,16 @@ int Instance::buildWalk(Plan& plan, std::vector<PartialsOp>& dev, const std::vec
                 for (int t = 0; t < maxSlots; ++t) {
                     const int h = slotHolder[t];
                     if (h < 0 || stepOf[h] >= fromStep || readThisStep[h] || h == pr[0] || h == pr[1]) continue;
-                    if (std::find(taken.begin(), taken.end(), t) != taken.end()) continue;
+                    if (taken.has(t)) continue;
                     const int u = nextUse(h);
                     if (u > farUse) { farUse = u; far = t; }
                 }
                 return far;
             };
-            std::vector<std::pair<int, int>> evicted;       // (slot, value) evicted for this operation
-            std::vector<std::pair<int, PartialsOp>> loadsHere;   // (step, LOAD entry) claimed by this operation
+            std::pair<int, int> evicted[4];                 // (slot, value) evicted for this operation
+            int nEvicted = 0;
+            std::pair<int, PartialsOp> loadsHere[2];        // (step, LOAD entry) claimed by this operation
+            int nLoadsHere = 0;
             for (int t = 0; t < 2 && ok; ++t) {
                 if (*kind[t] == CHILD_STATES) continue;
                 if (pr[t] >= 0 && slotOf[pr[t]] >= 0) { *kind[t] = CHILD_LDS; *slot[t] = (uint8_t) slotOf[pr[t]]; continue; }
@@ -1143,7 +1176,7 @@ int Instance::buildWalk(Plan& plan, std::vector<PartialsOp>& dev, const std::vec
                     // (latest step with a free wave, not before the slot is idle)
                     for (int q = s - 1; q >= std::max(slotFreeFrom[sl], 0); --q) {
                         int claimed = 0;
-                        for (auto& ld : loadsHere) claimed += ld.first == q;
+                        for (int li = 0; li < nLoadsHere; ++li) claimed += loadsHere[li].first == q;
                         if ((int) (steps[q].size() + stepLoads[q].size()) + claimed >= W) continue;
                         PartialsOp ld;
                         std::memset(&ld, 0, sizeof ld);
@@ -1155,7 +1188,7 @@ int Instance::buildWalk(Plan& plan, std::vector<PartialsOp>& dev, const std::vec
                         ld.c1_slot = ld.c2_slot = MBAMD_NO_SLOT;
                         ld.dst_slot = (uint8_t) sl;
                         ld.flags = MBAMD_OP_LOAD;
-                        loadsHere.emplace_back(q, ld);
+                        loadsHere[nLoadsHere++] = std::make_pair(q, ld);
                         *kind[t] = CHILD_LDS;                 // by step s it is an ordinary slot
                         break;
                     }
@@ -1163,7 +1196,7 @@ int Instance::buildWalk(Plan& plan, std::vector<PartialsOp>& dev, const std::vec
                 if (sl < 0 && mayEvict) {
                     // (a value evicted now was last touched before step s-1, so nobody reads it in s-1)
                     const int ev = evict(s - 1);
-                    if (ev >= 0) { evicted.emplace_back(ev, slotHolder[ev]); sl = ev; }
+                    if (ev >= 0) { evicted[nEvicted++] = std::make_pair(ev, slotHolder[ev]); sl = ev; }
                 }
                 if (sl < 0) { ok = false; break; }
                 taken.push_back(sl);
@@ -1180,7 +1213,7 @@ int Instance::buildWalk(Plan& plan, std::vector<PartialsOp>& dev, const std::vec
                 if (dsl < 0 && d.c2_kind == CHILD_LDS && pr[1] != pr[0] && lastReaderIsMe(pr[1])) dsl = d.c2_slot;
                 if (dsl < 0 && mayEvict) {
                     const int ev = evict(s);
-                    if (ev >= 0) { evicted.emplace_back(ev, slotHolder[ev]); dsl = ev; }
+                    if (ev >= 0) { evicted[nEvicted++] = std::make_pair(ev, slotHolder[ev]); dsl = ev; }
                 }
                 if (dsl < 0 && !taken.empty()) {              // take over one of its own staging slots
                     dsl = taken.back();
@@ -1190,9 +1223,9 @@ int Instance::buildWalk(Plan& plan, std::vector<PartialsOp>& dev, const std::vec
             }
             if (!ok) continue;                                // not in this step
             // ---- commit
-            for (auto& ev : evicted) { slotOf[ev.second] = -1; slotHolder[ev.first] = -1; }
-            for (auto& ld : loadsHere) stepLoads[ld.first].push_back(ld.second);
-            for (int sl : taken) { slotHolder[sl] = -1; slotFreeFrom[sl] = s + 1; slotsUsed = std::max(slotsUsed, sl + 1); }
+            for (int ei = 0; ei < nEvicted; ++ei) { slotOf[evicted[ei].second] = -1; slotHolder[evicted[ei].first] = -1; }
+            for (int li = 0; li < nLoadsHere; ++li) stepLoads[loadsHere[li].first].push_back(loadsHere[li].second);
+            for (int ti = 0; ti < taken.n; ++ti) { const int sl = taken.v[ti]; slotHolder[sl] = -1; slotFreeFrom[sl] = s + 1; slotsUsed = std::max(slotsUsed, sl + 1); }
             for (int t = 0; t < 2; ++t) {
                 if (pr[t] < 0 || (t == 1 && pr[1] == pr[0])) continue;
                 readThisStep[pr[t]] = 1;
@@ -1221,20 +1254,23 @@ int Instance::buildWalk(Plan& plan, std::vector<PartialsOp>& dev, const std::vec
         }
         }
         for (int o : chosen) ready.erase(std::find(ready.begin(), ready.end(), o));
-        steps.push_back(chosen);
-        stepLoads.emplace_back();
+        if ((int) steps.size() <= nstepsBuilt) { steps.emplace_back(); stepLoads.emplace_back(); }
+        steps[nstepsBuilt] = chosen;
+        stepLoads[nstepsBuilt].clear();               // (filled by operations of later steps)
+        ++nstepsBuilt;
         drainBefore.push_back(needDrain ? 1 : 0);
         done += (int) chosen.size();
         for (int o : chosen)
             for (int q = o + 1; q < n; ++q)
                 if ((prod1[q] == o || prod2[q] == o) && --indeg[q] == 0) ready.push_back(q);
     }
-    const int nsteps = (int) steps.size();
+    const int nsteps = nstepsBuilt;
 
     // ---- device table [nsteps + 4][W] -----------------------------------------------------------------
     // (+4 empty rows: the loader reads that far ahead; empty entries carry valid dummy pointers because
     //  the loader fetches through every pointer of a row without looking at `dst`)
-    std::vector<PartialsOp> table((size_t) (nsteps + 4) * W);
+    std::vector<PartialsOp>& table = ws.table;
+    table.resize((size_t) (nsteps + 4) * W);
     std::memset(table.data(), 0, table.size() * sizeof(PartialsOp));
     for (int s = 0; s < nsteps + 4; ++s) {
         uint8_t fl = (s + 2 < nsteps && drainBefore[s + 2]) ? MBAMD_OP_DRAIN : 0;

@@ -110,6 +110,7 @@ struct alignas(16) PartialsOp {
 static_assert(sizeof(PartialsOp) == 64, "PartialsOp must be 64 bytes");
 
 #define MBAMD_NO_SLOT 0xFF
+#define MBAMD_MAX_TABLES 4      // operation tables (lists / independent sub-lists) one general-state launch can take
 
 // ---------------------------------------------------------------------------------------------
 // exact power-of-two rescaling helpers

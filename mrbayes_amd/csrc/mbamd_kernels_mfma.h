@@ -219,7 +219,6 @@ k_partials_mfma(const PartialsOp* __restrict__ ops, int S_rt, int SP, int Ppad, 
 // Up to four operation tables per launch: MrBayes issues one beagleUpdatePartials per eigen-system part
 // (codon M3: three), mutually independent; the engine defers them and runs each dependency level
 // of all parts as ONE launch.
-#define MBAMD_MAX_TABLES 4
 struct OpTables {
     const PartialsOp* ops[MBAMD_MAX_TABLES];
     int32_t* cum[MBAMD_MAX_TABLES];
