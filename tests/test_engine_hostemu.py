@@ -70,7 +70,7 @@ def test_dynamic_rescaling_state_machine(emu, oracle):
 
 
 def test_generic_kernels_on_dna(emu, oracle, golden_dir, monkeypatch):
-    """MBAMD_FORCE_GENERIC routes 4-state data through the general-state kernels (state-major layout)."""
+    """MBAMD_FORCE_GENERIC routes 4-state data through the general-state kernels (tile-major layout)."""
     monkeypatch.setenv("MBAMD_FORCE_GENERIC", "1")
     ec.check_golden_case(emu, oracle, golden_dir, "primates_gtr_g4")
     ec.check_golden_case(emu, oracle, golden_dir, "primates_gtr_equal")
