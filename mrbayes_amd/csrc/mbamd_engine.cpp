@@ -358,11 +358,13 @@ int Instance::create(int tipCount_, int partialsBufferCount, int compactBufferCo
     if (const char* e = std::getenv("MBAMD_MFMA_SERIAL")) serialRatio = std::max(0, std::atoi(e));
     noSpine = std::getenv("MBAMD_NO_SPINE") != nullptr;
     if (const char* e = std::getenv("MBAMD_SPINE_WIDTH")) spineWidth = std::max(1, std::atoi(e));
+    // serial / spine kernels exist for these shapes only (other category counts: level launches throughout)
+    if (!((NT == 1 && (K == 1 || K == 2 || K == 4)) || (NT == 2 && (K == 1 || K == 2)))) serialRatio = 0;
+#endif
     envInOrder = std::getenv("MBAMD_WALK_IN_ORDER") != nullptr;
     envVerbose = std::getenv("MBAMD_VERBOSE") != nullptr;
     envReverseStep = std::getenv("MBAMD_EMU_REVERSE_STEP") != nullptr;
     envTrace = std::getenv("MBAMD_WALK_TRACE") != nullptr;
-#endif
     partialsFloats = s4 ? (size_t) K * Ppad * 4 : (size_t) K * S * Ppad;
     matrixFloats = (size_t) K * SP * SP + (mfma ? (size_t) K * NT * T * 64 : 0);
     if (s4) {

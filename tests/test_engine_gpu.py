@@ -44,7 +44,8 @@ def test_transition_matrices(gpu, oracle, golden_dir, case):
 
 @pytest.mark.parametrize("nstates,ncat,npat", [(4, 4, 100), (4, 1, 64), (4, 3, 65), (4, 8, 130), (20, 4, 70),
                                                  (20, 1, 200), (61, 1, 33), (61, 1, 129), (61, 3, 40),
-                                                 (16, 2, 10), (2, 4, 5), (20, 4, 1), (4, 4, 1)])
+                                                 (16, 2, 10), (2, 4, 5), (20, 4, 1), (4, 4, 1),
+                                                 (20, 3, 95), (20, 2, 64), (61, 2, 70), (33, 1, 50), (5, 4, 40), (64, 1, 31)])
 def test_single_operations(gpu, oracle, nstates, ncat, npat):
     ec.check_single_operations(gpu, oracle, nstates, ncat, npat)
 
@@ -319,6 +320,15 @@ def test_general_state_partial_updates_track_full_evaluation(gpu, oracle, kind, 
     assert lnl == pytest.approx(want, rel=2e-7)
     ref = oracle.tree_loglike(div, use_shortcuts=False)
     assert abs(lnl - ref) / abs(ref) < 2e-6
+
+
+@pytest.mark.parametrize("ncat", [1, 2, 3])
+def test_protein_other_category_counts(gpu, oracle, ncat):
+    """WAG with 1-3 gamma categories: every category count takes its own mix of kernels (3 has no serial /
+    tip-pair / per-factor-tile instance and runs on the wave-per-tile kernel); full evaluation + a partial update."""
+    div = synthetic_division("wag", 40, 330, seed=41, tree_seed=42, p_gap=0.03, ncat=ncat)
+    ec.check_partial_update_and_reject(gpu, oracle, div, scaling=lk.MB_BEAGLE_SCALE_DYNAMIC)
+    ec.check_partial_update_and_reject(gpu, oracle, div, scaling=lk.MB_BEAGLE_SCALE_ALWAYS)
 
 
 def test_walk_category_split_agrees(gpu, monkeypatch):
