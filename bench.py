@@ -8,7 +8,8 @@ move dirties the whole tree (reference src/proposal.c:17682, src/mbbeagle.c:400-
 
 N > 1 (launched by torch.distributed.run, one rank per GPU): every rank owns one heated chain of the same
 shape on its own GPU (chain-parallel MCMCMC, the reference's MPI strategy, src/mcmc.c:18331-18384); the only
-exchange is the per-generation all-reduce of the chains' lnL vector over RCCL.  Weak scaling.
+exchange is the per-generation swap attempt: the two ranks that own the drawn chains send each other (lnL,
+lnPrior, heat) over RCCL, everybody else carries on (src/mcmc.c:653-668).  Weak scaling.
 
 Prints ONE JSON line on rank 0.  Unit of work = node-pattern update: one interior-node
 conditional-likelihood update of one unique site pattern over all categories, rescale included.
@@ -171,14 +172,15 @@ def main():
 
     from mrbayes_amd import chains as mbchains
     exchange = mbchains.ChainExchange(world, dist=dist, device=device) if dist is not None else None
+    if exchange is not None:
+        exchange.warm_up()             # open the pairwise connections outside the timed region
 
     def step(i):
         rc, lnl = evals[i & 1].run()
         if rc != 0:
             raise RuntimeError("evaluation failed with code %d" % rc)
-        if exchange is not None:       # per-generation exchange of the chains' states (RCCL) + swap attempt
-            all_lnl, all_pr = exchange.all_states({rank: lnl})
-            exchange.attempt_swap(all_lnl, all_pr)
+        if exchange is not None:       # per-generation swap attempt: the two ranks that own the chains exchange states (RCCL)
+            exchange.swap_generation({rank: lnl})
         return lnl
 
     def fence():

@@ -5,9 +5,11 @@ its own chains with its own likelihood calculator, and the ranks exchange a hand
 between two heated chains is attempted (AttemptSwap, src/mcmc.c:591-1140: myStateInfo = lnL, lnPrior, ...).
 Here one process drives one MI355X (one engine instance = the chains that live on that GPU) and the
 exchange runs over torch.distributed -- backend "nccl" (= RCCL over xGMI) on GPUs, "gloo" in the CPU tests.
-The per-generation exchange is ONE all-reduce of the 2*nchains vector (lnL, lnPrior): with it every rank
-holds every chain's state and evaluates the swap rule itself, with the shared swap RNG the reference also
-uses (`swapseed`), so no second message is needed to announce the outcome.
+As in the reference, a swap attempt is a PAIRWISE exchange: every rank draws the same two chains and the same
+acceptance number from the shared swap RNG (`swapseed`); only the (at most two) ranks that own those chains
+talk -- one send/receive of (lnL, lnPrior, heat id) each way -- and everybody else goes straight on to the
+next generation ("chains that do not swap, continue", src/mcmc.c:653-668).  `all_states` (one all-reduce of
+the 2*nchains vector) is the collective used for reporting only.
 
 Nothing here touches conditional likelihoods: chains never exchange partials.
 """
@@ -101,6 +103,65 @@ class ChainExchange:
         self.swaps_tried += 1
         if ok:
             self.chain_id[a], self.chain_id[b] = self.chain_id[b], self.chain_id[a]
+            self.swaps_done += 1
+        return a, b, ok
+
+    # ---- the reference's pattern: only the ranks that own the two chains communicate ------------------
+    def rank_of_chain(self, chain: int) -> int:
+        base, extra = divmod(self.nchains, self.world)
+        cut = extra * (base + 1)
+        return chain // (base + 1) if chain < cut else extra + (chain - cut) // max(base, 1)
+
+    def _pair_exchange(self, peer: int, mine: Sequence[float]) -> List[float]:
+        import torch
+        send = torch.tensor(list(mine), dtype=torch.float64, device=self.device or "cpu")
+        recv = torch.empty_like(send)
+        ops = [self.dist.P2POp(self.dist.isend, send, peer), self.dist.P2POp(self.dist.irecv, recv, peer)]
+        if self.rank > peer:
+            ops.reverse()
+        for req in self.dist.batch_isend_irecv(ops):
+            req.wait()
+        return recv.cpu().tolist()
+
+    def warm_up(self) -> None:
+        """Open every pairwise connection once (outside any timed region)."""
+        if self.dist is None or self.world < 2:
+            return
+        for i in range(self.world):
+            for j in range(i + 1, self.world):
+                if self.rank in (i, j):
+                    self._pair_exchange(j if self.rank == i else i, [0.0, 0.0, 0.0])
+
+    def swap_generation(self, lnl: Dict[int, float], lnprior: Optional[Dict[int, float]] = None):
+        """One swap attempt of this generation (RunChain picks the pair, src/mcmc.c:16941-16957; AttemptSwap,
+        src/mcmc.c:591-1140).  `lnl` / `lnprior`: this rank's own chains.  Returns (a, b, accepted) with
+        accepted = None on a rank that owns neither chain (it does not communicate and does not learn the outcome,
+        exactly like a reference rank; `chain_id` is authoritative for a rank's own chains only)."""
+        a = int(self.rng.random() * self.nchains)
+        b = int(self.rng.random() * (self.nchains - 1))
+        if b >= a:
+            b += 1
+        u = self.rng.random()                               # drawn by everybody: the streams stay in step
+        self.swaps_tried += 1
+        ra, rb = self.rank_of_chain(a), self.rank_of_chain(b)
+        if self.rank not in (ra, rb):
+            return a, b, None
+        pr = lnprior or {}
+        state = {}
+        for c in (a, b):
+            if self.rank_of_chain(c) == self.rank:
+                state[c] = (float(lnl[c]), float(pr.get(c, 0.0)), float(self.chain_id[c]))
+        if ra != rb:
+            mine, other = (a, b) if self.rank == ra else (b, a)
+            state[other] = tuple(self._pair_exchange(rb if self.rank == ra else ra, state[mine]))
+        ta = temperature(int(state[a][2]), self.nchains, self.chain_temp)
+        tb = temperature(int(state[b][2]), self.nchains, self.chain_temp)
+        lnr = swap_log_ratio(state[a][0], state[a][1], ta, state[b][0], state[b][1], tb)
+        r = 0.0 if lnr < -100.0 else 1.0 if lnr > 0.0 else math.exp(lnr)
+        ok = u < r
+        if ok:
+            ida, idb = int(state[a][2]), int(state[b][2])
+            self.chain_id[a], self.chain_id[b] = idb, ida   # (entries of chains this rank does not own are not used)
             self.swaps_done += 1
         return a, b, ok
 
