@@ -361,7 +361,7 @@ __device__ __forceinline__ void mfma_split_op(const MBAMD_AS_CONST PartialsOp* _
 // grid = (P_pad / 128) * operations, block = 256 (4 waves = 4 tiles), dynamic LDS = 4 * S * 32 floats.
 // ---------------------------------------------------------------------------------------------
 template <int SC, int KC>
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(256, (SC > 0 ? 6 : 4))
 k_partials_tips(OpTables tabs, int S_rt, int SP, int Ppad, int gx4)
 {
     constexpr int QC = SC > 0 ? (SC + 7) / 8 : 8;   // 8-row groups per category
@@ -384,22 +384,23 @@ k_partials_tips(OpTables tabs, int S_rt, int SP, int Ppad, int gx4)
     const bool miss1 = s1 >= (unsigned) S, miss2 = s2 >= (unsigned) S;
     const MBAMD_AS_GLOBAL float* r1 = as_global(op->m1) + (size_t) (miss1 ? 0u : s1) * SP + 4 * half;
     const MBAMD_AS_GLOBAL float* r2 = as_global(op->m2) + (size_t) (miss2 ? 0u : s2) * SP + 4 * half;
-    f4 g1[KC][QC], g2[KC][QC];
+    // products of the two gathered columns, category by category (the factors themselves are transient: the
+    // register budget decides how many waves a CU keeps in flight, and in-flight waves are what a write stream needs)
+    f4 g1[KC][QC];
+    float mx = 0.0f;
 #pragma unroll
-    for (int k = 0; k < KC; ++k)
+    for (int k = 0; k < KC; ++k) {
+        f4 ga[QC], gb[QC];
 #pragma unroll
         for (int q = 0; q < QC; ++q) {
             const int qq = (SC > 0 || q < Q) ? q : 0;
-            g1[k][q] = *reinterpret_cast<const MBAMD_AS_GLOBAL f4*>(r1 + (size_t) k * SP * SP + 8 * qq);
-            g2[k][q] = *reinterpret_cast<const MBAMD_AS_GLOBAL f4*>(r2 + (size_t) k * SP * SP + 8 * qq);
+            ga[q] = *reinterpret_cast<const MBAMD_AS_GLOBAL f4*>(r1 + (size_t) k * SP * SP + 8 * qq);
+            gb[q] = *reinterpret_cast<const MBAMD_AS_GLOBAL f4*>(r2 + (size_t) k * SP * SP + 8 * qq);
         }
-    float mx = 0.0f;
-#pragma unroll
-    for (int k = 0; k < KC; ++k)
 #pragma unroll
         for (int q = 0; q < QC; ++q) {
             const int ib = 8 * q + 4 * half;
-            f4 a = g1[k][q], b = g2[k][q];
+            f4 a = ga[q], b = gb[q];
             if (miss1) a = (f4) (1.0f);
             if (miss2) b = (f4) (1.0f);
             f4 v = a * b;
@@ -410,6 +411,7 @@ k_partials_tips(OpTables tabs, int S_rt, int SP, int Ppad, int gx4)
             g1[k][q] = v;
             mx = fmaxf(mx, fmaxf(fmaxf(v.x, v.y), fmaxf(v.z, v.w)));
         }
+    }
     int e = 0;
     if (mode == SCALE_WRITE) {
         mx = fmaxf(mx, __shfl_xor(mx, 32));
