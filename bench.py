@@ -227,6 +227,8 @@ def main():
             if pmc and not emulate:
                 roof["traffic"] = pmc["traffic_bytes"]
                 roof["traffic_source"] = pmc["source"]
+                if "mfma_busy_fraction" in pmc:       # SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE x CUs), same PMC passes
+                    roof["mfma_busy_fraction"] = pmc["mfma_busy_fraction"]
         except (OSError, ValueError):
             pass
         roof["kernel"] = impl
