@@ -14,12 +14,20 @@
 // The B operand is exactly one coalesced dword load from the tile-major partials layout
 // [P_pad/32][K][S][32] (gen_index, mbamd_kernels.h): rows 2t and 2t+1 of a 32-pattern tile are 64
 // consecutive floats, one contiguous 256-byte access per wave instruction -- no LDS staging, no transposes.
-// The A operand comes pre-packed in MFMA lane order from k_transition_matrices_ev (one coalesced
+// The A operand comes pre-packed in MFMA lane order from the transition-matrix kernels (one coalesced
 // 256-byte load per MFMA, L1/L2 resident: a matrix set is 10-48 KiB).  A compact tip child needs
 // no contraction at all: its factor is column `state` of P, gathered with dwordx4 loads.
-// One wave owns 32 patterns of one operation for all K categories, so the per-pattern maximum over
-// (k, i) -- the reference's separate CondLikeScaler pass -- is a register reduction plus one
-// cross-half exchange, and the rescaled result is written exactly once.
+// The per-pattern maximum over (k, i) -- the reference's separate CondLikeScaler pass -- is fused
+// (register reduction + LDS exchange), and the rescaled result is written exactly once.
+//
+// Kernels (the host picks per operation list, Instance::runGeneric / flushPending in mbamd_engine.cpp):
+//   k_partials_tips        operations on two compact tips (a full evaluation's first dependency level)
+//   k_partials_mfma_split  one launch per dependency level, one wave per factor tile (the default)
+//   k_partials_mfma_spine  narrow lists / trailing single-operation levels: one launch walks them, software-pipelined
+//   k_partials_mfma_serial   plain variant of the spine kernel for run-time state counts
+//   k_partials_mfma        one wave per (operation, tile): cross-check (MBAMD_MFMA_WHOLE=1)
+//   k_transition_matrices_mfma  P = U exp(L t) U^-1 on the fp64 matrix cores
+//   k_integrate_lnl_wide   root / edge integration, 8 threads per pattern
 #ifndef MBAMD_KERNELS_MFMA_H_
 #define MBAMD_KERNELS_MFMA_H_
 
