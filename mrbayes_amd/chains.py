@@ -127,6 +127,11 @@ class ChainExchange:
         """Open every pairwise connection once (outside any timed region)."""
         if self.dist is None or self.world < 2:
             return
+        # (with the NCCL backend the first operation on a group has to involve all of its ranks; batched
+        #  send/receive between two of them is allowed from then on)
+        import torch
+        first = torch.zeros(1, dtype=torch.float64, device=self.device or "cpu")
+        self.dist.all_reduce(first)
         for i in range(self.world):
             for j in range(i + 1, self.world):
                 if self.rank in (i, j):
