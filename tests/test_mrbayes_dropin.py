@@ -64,6 +64,46 @@ def test_unmodified_mrbayes_on_mi355x(scaling):
     assert "Analysis completed" in out, out[-1500:]
 
 
+# ---- partially ambiguous tips (IUPAC codes): those taxa reach the engine as tip PARTIALS ------------------------
+def _ambiguous_nexus(beagle):
+    st, tr = _case(20, 500, 0.02)
+    text = refrun.known_answer_nexus(st, tr, REVMAT, PI, ALPHA, beagle=beagle)
+    rng = np.random.default_rng(3)
+    lines = text.split("\n")
+    for i, line in enumerate(lines):
+        parts = line.split("  ")
+        if len(parts) == 2 and parts[0].startswith("t") and set(parts[1]) <= set("ACGT-"):
+            if int(parts[0][1:]) % 3 == 0:                     # every third taxon carries IUPAC ambiguity codes
+                seq = list(parts[1])
+                for j in rng.choice(len(seq), size=len(seq) // 10, replace=False):
+                    seq[j] = "RYMKSWBDHVN"[int(rng.integers(0, 11))]
+                lines[i] = parts[0] + "  " + "".join(seq)
+    return "\n".join(lines)
+
+
+def test_ambiguity_codes_on_emulated_engine():
+    if not os.path.exists(refrun.REF_MB_EMU):
+        pytest.skip("oracle/_ref/mb_emu not built (build container only)")
+    native = refrun.initial_lnl(refrun.run_mb(refrun.REF_MB, _ambiguous_nexus(None))[0])
+    out, _ = refrun.run_mb(refrun.REF_MB_EMU, _ambiguous_nexus("dynamic"))
+    assert "mbamd" in out
+    assert abs(refrun.initial_lnl(out) - native) / abs(native) < 1e-5
+
+
+@pytest.mark.gpu
+def test_ambiguity_codes_on_mi355x():
+    if not os.path.exists(refrun.REF_MB_AMD):
+        pytest.skip("oracle/_ref/mb_amd was not built (needs the reference sources at build time)")
+    out, _ = refrun.run_mb(refrun.REF_MB_AMD, _ambiguous_nexus("always"))
+    assert "mbamd HIP gfx950" in out
+    ours = refrun.initial_lnl(out)
+    if os.path.exists(refrun.REF_MB):
+        native = refrun.initial_lnl(refrun.run_mb(refrun.REF_MB, _ambiguous_nexus(None))[0])
+        assert abs(ours - native) / abs(native) < 1e-5, (ours, native)
+    out, _ = refrun.run_mb(refrun.REF_MB_AMD, _ambiguous_nexus("dynamic").replace("ngen=1 ", "ngen=300 "))
+    assert "Analysis completed" in out, out[-1500:]
+
+
 # ---- general-state models through the real src/mbbeagle.c ---------------------------------------------------
 def _general_case(kind, ntaxa, nsites):
     nstates = {"wag": 20, "m3": 61}[kind]
