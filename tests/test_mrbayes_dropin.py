@@ -104,6 +104,51 @@ def test_ambiguity_codes_on_mi355x():
     assert "Analysis completed" in out, out[-1500:]
 
 
+# ---- partitioned analysis: one engine instance per division, both alive in the same MrBayes process -------------
+def _partitioned_nexus(beagle, ngen=1):
+    st, tr = _case(16, 600, 0.02)
+    names = ["t%d" % (i + 1) for i in range(st.shape[0])]
+    seqs = ["".join("ACGT-"[x] for x in row) for row in st]
+    s = "#NEXUS\nbegin data;\n  dimensions ntax=%d nchar=%d;\n" % (len(names), len(seqs[0]))
+    s += "  format datatype=dna interleave=no gap=- missing=?;\n  matrix\n"
+    for n, q in zip(names, seqs):
+        s += "%s  %s\n" % (n, q)
+    s += "  ;\nend;\nbegin mrbayes;\n  set autoclose=yes nowarnings=yes seed=12345 swapseed=12345 precision=15;\n"
+    s += "  charset first = 1-350;\n  charset second = 351-600;\n  partition genes = 2: first, second;\n  set partition=genes;\n"
+    s += "  lset applyto=(1) nst=6 rates=gamma ngammacat=4;\n  lset applyto=(2) nst=2 rates=propinv;\n"
+    s += "  unlink revmat=(all) tratio=(all) statefreq=(all) shape=(all) pinvar=(all);\n  prset applyto=(all) ratepr=variable;\n"
+    if beagle:
+        s += "  set usebeagle=yes beagledevice=gpu beagleprecision=single beaglescaling=%s;\n" % beagle
+    s += "end;\nbegin trees;\n  tree t = [&U] %s\nend;\n" % tr.to_newick(names)
+    s += "begin mrbayes;\n  startvals tau=t V=t;\n"
+    s += "  mcmc ngen=%d nchains=2 nruns=1 samplefreq=%d printfreq=%d diagnfreq=%d filename=part;\nend;\n" % (
+        ngen, max(ngen, 1), max(ngen, 1), max(ngen, 1))
+    return s
+
+
+def _check_partitioned(binary, marker):
+    native = refrun.initial_lnl(refrun.run_mb(refrun.REF_MB, _partitioned_nexus(None))[0])
+    out, _ = refrun.run_mb(binary, _partitioned_nexus("dynamic"))
+    assert out.count(marker) >= 2, out[-2500:]             # both divisions run on the engine
+    ours = refrun.initial_lnl(out)
+    assert abs(ours - native) / abs(native) < 1e-5, (ours, native)
+    out, _ = refrun.run_mb(binary, _partitioned_nexus("dynamic", ngen=400))
+    assert "Analysis completed" in out, out[-1500:]
+
+
+def test_partitioned_analysis_on_emulated_engine():
+    if not (os.path.exists(refrun.REF_MB_EMU) and os.path.exists(refrun.REF_MB)):
+        pytest.skip("oracle/_ref binaries not built (build container only)")
+    _check_partitioned(refrun.REF_MB_EMU, "Impl Name : mbamd")
+
+
+@pytest.mark.gpu
+def test_partitioned_analysis_on_mi355x():
+    if not (os.path.exists(refrun.REF_MB_AMD) and os.path.exists(refrun.REF_MB)):
+        pytest.skip("oracle/_ref binaries not built (need the reference sources at build time)")
+    _check_partitioned(refrun.REF_MB_AMD, "Impl Name : mbamd HIP gfx950")
+
+
 # ---- general-state models through the real src/mbbeagle.c ---------------------------------------------------
 def _general_case(kind, ntaxa, nsites):
     nstates = {"wag": 20, "m3": 61}[kind]
