@@ -109,6 +109,7 @@ struct Plan {
     bool narrow = false;                         // general path: few operations per level -> one serial launch
     std::vector<std::pair<int, int>> chains;     // narrow general-state lists: (first table entry, operations) of up to four
                                                  // mutually independent sub-lists (they walk in parallel workgroups)
+    std::vector<std::pair<int, int>> spineChains;   // the same for the serial tail of a level-launched list (levels >= serialFrom)
     int tipTip = 0;                              // general path: the first tipTip operations of level 0 have two compact tip children
     int serialFrom = 0;                          // general path: levels >= serialFrom are narrow (the spine towards the
                                                  // root): they run as one serial launch after the level launches
@@ -1515,58 +1516,90 @@ int Instance::buildGeneric(Plan& plan, std::vector<PartialsOp>& dev, const std::
     for (const PartialsOp& d : sorted) plan.anyScale |= d.scale_mode != SCALE_NONE;
     plan.start = start;
     plan.narrow = serialRatio > 0 && n <= serialRatio * nLevels;
-    plan.chains.clear();
-    if (plan.narrow) {
-        // A narrow list usually is several independent root-ward paths interleaved (MrBayes puts the operations of
-        // all eigen-system parts of a codon model into one list, reference src/mbbeagle.c:1029-1100): split it into
-        // connected components of the "touches a buffer somebody writes" relation and append them, each in list
-        // order, behind the level-sorted table; the serial kernel walks them side by side.
-        std::vector<int> comp(n);
-        for (int o = 0; o < n; ++o) comp[o] = o;
+    // Independent sub-lists.  A list often is several root-ward paths interleaved (MrBayes puts the operations of all
+    // eigen-system parts of a codon model into one list, reference src/mbbeagle.c:1029-1100).  chainsOf() splits a
+    // subset of the list (original indices, list order) into connected components of the "touches a buffer a member
+    // writes" relation and packs them into at most MBAMD_MAX_TABLES bins; the serial kernel walks the bins side by side.
+    auto chainsOf = [&](const std::vector<int>& sub) {
+        const int m = (int) sub.size();
+        std::vector<int> comp(m);
+        for (int x = 0; x < m; ++x) comp[x] = x;
         auto find = [&](int x) { while (comp[x] != x) x = comp[x] = comp[comp[x]]; return x; };
         auto unite = [&](int a, int b) { a = find(a); b = find(b); if (a != b) comp[std::max(a, b)] = std::min(a, b); };
-        std::vector<int> owner(nBuffers, -1);                    // an operation of the component that writes the buffer
-        for (int o = 0; o < n; ++o) {
-            if (owner[dstIdx[o]] >= 0) unite(o, owner[dstIdx[o]]);
-            owner[dstIdx[o]] = o;
+        std::vector<int> owner(nBuffers, -1);                    // a member that writes the buffer
+        for (int x = 0; x < m; ++x) {
+            const int o = sub[x];
+            if (owner[dstIdx[o]] >= 0) unite(x, owner[dstIdx[o]]);
+            owner[dstIdx[o]] = x;
         }
-        for (int o = 0; o < n; ++o) {
-            if (owner[c1Idx[o]] >= 0) unite(o, owner[c1Idx[o]]);
-            if (owner[c2Idx[o]] >= 0) unite(o, owner[c2Idx[o]]);
+        for (int x = 0; x < m; ++x) {
+            const int o = sub[x];
+            if (owner[c1Idx[o]] >= 0) unite(x, owner[c1Idx[o]]);
+            if (owner[c2Idx[o]] >= 0) unite(x, owner[c2Idx[o]]);
         }
-        for (int a = 0; a < n; ++a)                              // node scale buffers written by one, read by another
-            for (int b = a + 1; b < n; ++b)
-                if (dev[a].scale == dev[b].scale && dev[a].scale_mode != SCALE_NONE && dev[b].scale_mode != SCALE_NONE &&
-                    (dev[a].scale_mode == SCALE_WRITE || dev[b].scale_mode == SCALE_WRITE))
-                    unite(a, b);
-        std::vector<int> roots;
-        for (int o = 0; o < n; ++o) if (find(o) == o) roots.push_back(o);
-        if (roots.size() > 1) {
-            // at most MBAMD_MAX_TABLES bins, largest components first, each into the currently shortest bin
-            std::vector<int> size(n, 0);
-            for (int o = 0; o < n; ++o) size[find(o)]++;
-            std::sort(roots.begin(), roots.end(), [&](int a, int b) { return size[a] > size[b]; });
-            const int nb = std::min<int>(MBAMD_MAX_TABLES, (int) roots.size());
-            std::vector<int> binLen(nb, 0), binOf(n, 0);
-            for (int r : roots) {
-                const int bsel = (int) (std::min_element(binLen.begin(), binLen.end()) - binLen.begin());
-                binOf[r] = bsel;
-                binLen[bsel] += size[r];
+        for (int x = 0; x < m; ++x)                              // node scale buffers written by one, used by another
+            for (int y = x + 1; y < m; ++y) {
+                const PartialsOp &dx = dev[sub[x]], &dy = dev[sub[y]];
+                if (dx.scale == dy.scale && dx.scale_mode != SCALE_NONE && dy.scale_mode != SCALE_NONE &&
+                    (dx.scale_mode == SCALE_WRITE || dy.scale_mode == SCALE_WRITE))
+                    unite(x, y);
             }
-            int off = n;
-            for (int bsel = 0; bsel < nb; ++bsel) {
-                const int first = off;
-                for (int o = 0; o < n; ++o)
-                    if (binOf[find(o)] == bsel) { sorted.push_back(dev[o]); ++off; }
-                if (off > first) plan.chains.emplace_back(first, off - first);
+        std::vector<int> roots, size(m, 0);
+        for (int x = 0; x < m; ++x) { size[find(x)]++; if (find(x) == x) roots.push_back(x); }
+        std::sort(roots.begin(), roots.end(), [&](int a, int b) { return size[a] > size[b]; });
+        const int nb = std::min<int>(MBAMD_MAX_TABLES, (int) roots.size());
+        std::vector<int> binLen(nb, 0), binOf(m, 0);
+        for (int r : roots) {                                    // largest first, each into the currently shortest bin
+            const int bsel = (int) (std::min_element(binLen.begin(), binLen.end()) - binLen.begin());
+            binOf[r] = bsel;
+            binLen[bsel] += size[r];
+        }
+        std::vector<std::vector<int>> bins(nb);
+        for (int x = 0; x < m; ++x) bins[binOf[find(x)]].push_back(sub[x]);
+        return bins;
+    };
+    auto appendBins = [&](const std::vector<std::vector<int>>& bins, std::vector<std::pair<int, int>>& out) {
+        for (const auto& bin : bins) {
+            if (bin.empty()) continue;
+            out.emplace_back((int) sorted.size(), (int) bin.size());
+            for (int o : bin) sorted.push_back(dev[o]);          // (list order inside a bin = dependency order)
+        }
+    };
+    plan.chains.clear();
+    plan.spineChains.clear();
+    plan.serialFrom = nLevels;
+    if (plan.narrow) {
+        std::vector<int> all(n);
+        for (int o = 0; o < n; ++o) all[o] = o;
+        const auto bins = chainsOf(all);
+        if (bins.size() > 1) appendBins(bins, plan.chains);
+        else plan.chains.emplace_back(0, n);
+    } else if (serialRatio > 0) {
+        // the tail of a level-launched list: trailing levels of a few operations each.  If they fall apart into parallel
+        // chains (three codon parts -> three chains) one serial launch walks them side by side; otherwise only the
+        // strictly single-operation levels (the spine towards the root) go serial.
+        int from = nLevels;
+        while (from > 0 && start[from] - start[from - 1] <= MBAMD_MAX_TABLES) from--;
+        if (nLevels - from >= 2) {
+            std::vector<int> sub;
+            for (int o = 0; o < n; ++o) if (level[o] >= from) sub.push_back(o);
+            const auto bins = chainsOf(sub);
+            size_t longest = 0;
+            for (const auto& bin : bins) longest = std::max(longest, bin.size());
+            if (bins.size() >= 2 && 4 * longest <= 5 * (size_t) (nLevels - from)) {
+                plan.serialFrom = from;
+                appendBins(bins, plan.spineChains);
             }
-        } else {
-            plan.chains.emplace_back(0, n);
+        }
+        if (plan.spineChains.empty()) {
+            from = nLevels;
+            while (from > 0 && start[from] - start[from - 1] <= spineWidth) from--;
+            if (nLevels - from >= 2) {
+                plan.serialFrom = from;
+                plan.spineChains.emplace_back(start[from], n - start[from]);
+            }
         }
     }
-    plan.serialFrom = nLevels;
-    while (plan.serialFrom > 0 && start[plan.serialFrom] - start[plan.serialFrom - 1] <= spineWidth) plan.serialFrom--;
-    if (serialRatio == 0 || nLevels - plan.serialFrom < 2) plan.serialFrom = nLevels;
     return planTable(plan, sorted);
 }
 
@@ -1656,10 +1689,14 @@ int Instance::runGeneric(const Plan& plan, int32_t* cum)
     if (levelEnd < nLevels) {                    // the spine: one launch walks it
         OpTables tabs;
         std::memset(&tabs, 0, sizeof tabs);
-        tabs.ops[0] = plan.d_table + start[levelEnd];
-        tabs.cum[0] = cum;
-        tabs.start[0] = start[nLevels] - start[levelEnd];
-        if (!launch_mfma_serial(*this, tabs, 1)) return fail(BEAGLE_ERROR_GENERAL, "no serial MFMA kernel for this shape");
+        int nt = 0;
+        for (auto& ch : plan.spineChains) {
+            tabs.ops[nt] = plan.d_table + ch.first;
+            tabs.cum[nt] = cum;
+            tabs.start[nt] = ch.second;
+            ++nt;
+        }
+        if (!launch_mfma_serial(*this, tabs, nt)) return fail(BEAGLE_ERROR_GENERAL, "no serial MFMA kernel for this shape");
         pendingLaunches += 1;
     }
 #endif
