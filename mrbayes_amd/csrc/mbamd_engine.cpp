@@ -158,6 +158,13 @@ struct Instance {
     float* matrices = nullptr;
     double *d_eigen = nullptr, *d_freqs = nullptr, *d_weights = nullptr, *d_rates = nullptr, *d_pweights = nullptr;
     double *d_site = nullptr;
+    // Clients that read the per-pattern values after every evaluation (MrBayes does for +I models,
+    // src/mbbeagle.c:1295-1358) get them written straight into pinned host memory by the integration kernel:
+    // switched on by the first beagleGetSiteLogLikelihoods call, from then on that call is a host memcpy.
+    double* h_site = nullptr;
+    double* h_site_dev = nullptr;
+    bool siteToHost = false, siteOnHost = false;   // mode / where the latest evaluation put its values
+    bool noSiteHost = false;                       // MBAMD_NO_SITE_HOST: always copy from device memory (comparison switch)
     int nblocks = 0;                  // partial sums of the weighted site log-likelihoods (one per integration workgroup)
     RatesArg rates{};                 // category rates, passed to kernels by value
     bool haveSite = false;
@@ -366,6 +373,7 @@ int Instance::create(int tipCount_, int partialsBufferCount, int compactBufferCo
     envVerbose = std::getenv("MBAMD_VERBOSE") != nullptr;
     envReverseStep = std::getenv("MBAMD_EMU_REVERSE_STEP") != nullptr;
     envTrace = std::getenv("MBAMD_WALK_TRACE") != nullptr;
+    noSiteHost = std::getenv("MBAMD_NO_SITE_HOST") != nullptr;
     partialsFloats = s4 ? (size_t) K * Ppad * 4 : (size_t) K * S * Ppad;
     matrixFloats = (size_t) K * SP * SP + (mfma ? (size_t) K * NT * T * 64 : 0);
     if (s4) {
@@ -449,6 +457,7 @@ void Instance::destroy()
                     d_ev, d_tmp};
     for (void* b : bufs) if (b) (void) hipFree(b);
     if (h_sums) (void) hipHostFree(h_sums);
+    if (h_site) (void) hipHostFree(h_site);
     if (stage) (void) hipHostFree(stage);
     for (auto& ev : events) { (void) hipEventDestroy(ev.first); (void) hipEventDestroy(ev.second); }
     (void) hipStreamDestroy(stream);
@@ -1757,11 +1766,13 @@ int Instance::integrate(const int* parent, const int* child, const int* prob, co
             a.cum[n] = scale[cumIdx[n]];
         }
     }
-    if (s4) MBAMD_LAUNCH(k_integrate_lnl<true>, (unsigned) nblocks, 64, 0, stream, a, S, SP, K, P, Ppad, geom, (const double*) d_pweights, d_site, h_sums_dev);
+    double* const siteOut = (siteToHost && h_site_dev) ? h_site_dev : d_site;
+    siteOnHost = siteOut != d_site;
+    if (s4) MBAMD_LAUNCH(k_integrate_lnl<true>, (unsigned) nblocks, 64, 0, stream, a, S, SP, K, P, Ppad, geom, (const double*) d_pweights, siteOut, h_sums_dev);
 #if !defined(MBAMD_HOST_EMU)
-    else if (S >= 8) MBAMD_LAUNCH(k_integrate_lnl_wide, (unsigned) nblocks, 256, 0, stream, a, S, SP, K, P, Ppad, (const double*) d_pweights, d_site, h_sums_dev);
+    else if (S >= 8) MBAMD_LAUNCH(k_integrate_lnl_wide, (unsigned) nblocks, 256, 0, stream, a, S, SP, K, P, Ppad, (const double*) d_pweights, siteOut, h_sums_dev);
 #endif
-    else    MBAMD_LAUNCH(k_integrate_lnl<false>, (unsigned) nblocks, 64, 0, stream, a, S, SP, K, P, Ppad, geom, (const double*) d_pweights, d_site, h_sums_dev);
+    else    MBAMD_LAUNCH(k_integrate_lnl<false>, (unsigned) nblocks, 64, 0, stream, a, S, SP, K, P, Ppad, geom, (const double*) d_pweights, siteOut, h_sums_dev);
     HIP_TRY(hipGetLastError());
     haveSite = true;
     pendingResult = true;
@@ -2147,7 +2158,15 @@ int beagleGetSiteLogLikelihoods(int instance, double* outLogLikelihoods)
     GET_INSTANCE(instance);
     if (!in->haveSite) return fail(BEAGLE_ERROR_GENERAL, "beagleGetSiteLogLikelihoods: no likelihood computed yet");
     HIP_TRY(hipStreamSynchronize(in->stream));
-    HIP_TRY(hipMemcpy(outLogLikelihoods, in->d_site, (size_t) in->P * sizeof(double), hipMemcpyDeviceToHost));
+    if (in->siteOnHost) {
+        std::memcpy(outLogLikelihoods, in->h_site, (size_t) in->P * sizeof(double));
+    } else {
+        HIP_TRY(hipMemcpy(outLogLikelihoods, in->d_site, (size_t) in->P * sizeof(double), hipMemcpyDeviceToHost));
+        if (!in->h_site && hipHostMalloc((void**) &in->h_site, (size_t) in->Ppad * sizeof(double), hipHostMallocDefault) == hipSuccess) {
+            if (hipHostGetDevicePointer((void**) &in->h_site_dev, in->h_site, 0) != hipSuccess) in->h_site_dev = nullptr;
+        }
+        in->siteToHost = in->h_site_dev != nullptr && !in->noSiteHost;   // this client reads them: later evaluations write to the host directly
+    }
     return BEAGLE_SUCCESS;
 }
 

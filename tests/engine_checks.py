@@ -165,6 +165,24 @@ def check_site_likelihoods(lib, oracle, div):
             assert np.allclose(site, want_site, rtol=2e-6, atol=2e-5)
             assert abs(float((site * div.weights).sum()) - lnl) < 1e-6 * abs(lnl)
         assert abs(lnl - want_lnl) / abs(want_lnl) < REL_FP64
+        # a client that reads the site values gets them through pinned host memory from the second evaluation on
+        # (beagleGetSiteLogLikelihoods): same numbers either way, and they follow the state
+        bd.AcceptMove(0)
+        bd.TouchAllTreeNodes(0)
+        assert bd.LogLike(0) == lnl
+        assert np.array_equal(bd.inst.get_site_log_likelihoods(), site)
+        bd.AcceptMove(0)
+        t = div.tree
+        deep = max(range(t.ntaxa), key=lambda i: _depth(t, i))
+        old = t.length[deep]
+        t.length[deep] = old * 2.5
+        bd.TouchBranch(0, deep)
+        lnl2 = bd.LogLike(0)
+        site2 = bd.inst.get_site_log_likelihoods()
+        t.length[deep] = old
+        assert lnl2 != lnl and not np.array_equal(site2, site)
+        if div.pinvar == 0.0:
+            assert abs(float((site2 * div.weights).sum()) - lnl2) < 1e-6 * abs(lnl2)
     finally:
         bd.finalize()
 
