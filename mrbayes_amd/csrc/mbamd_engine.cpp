@@ -24,6 +24,7 @@
 #include <mutex>
 #include <string>
 #include <limits>
+#include <unordered_map>
 #include <vector>
 
 #include "libhmsbeagle/beagle.h"
@@ -127,10 +128,24 @@ struct Instance {
     int lastWalkSteps = 0, lastWalkSlots = 0;
     bool noIdleLoads = false;        // MBAMD_WALK_NO_IDLE_LOADS: global children are only copied by the loader wave
     bool walkKSplit = false;         // MBAMD_WALK_KSPLIT=1: two waves per operation (category split); measured slower (profiles/)
+    // Schedules of the tree-walk path are a function of the list's dependency STRUCTURE only (who produces whose
+    // child, which children are tips): the buffer / matrix / scale indices -- which change with every accept / reject
+    // flip -- just fill the slots of the table.  A move that touches the branches it touched before (same root-ward
+    // path, or the whole tree) therefore re-uses its schedule and only re-fills the table.
+    struct WalkSchedule {
+        std::vector<int> key;
+        int nsteps = 0, slotsUsed = 0;
+        std::vector<uint8_t> opFields;           // per operation: c1_kind, c2_kind, c1_slot, c2_slot, dst_slot
+        std::vector<int> stepStart, stepOps;     // operations of each step
+        std::vector<int> loadStart, loadOps;     // LOAD entries of each step: (operation, child, slot)
+        std::vector<char> drainBefore;
+    };
+    std::unordered_map<uint64_t, WalkSchedule> schedules;
+    uint64_t scheduleHits = 0, scheduleMisses = 0;
     // scratch of Instance::buildWalk, kept between calls (a move compiles a fresh list every generation: no allocations)
     struct WalkScratch {
         std::vector<int> prod1, prod2, lastWriter, indeg, pendingReads, prio, need, stepOf, slotOf, slotHolder, slotFreeFrom,
-                         ready, chosen;
+                         ready, chosen, skey;
         std::vector<char> readOld, readThisStep, drainBefore;
         std::vector<std::vector<int>> consumers, steps;
         std::vector<std::vector<PartialsOp>> stepLoads;
@@ -1050,6 +1065,65 @@ int Instance::buildWalk(Plan& plan, std::vector<PartialsOp>& dev, const std::vec
     const bool inOrder = hazard || envInOrder;
     if (inOrder) W = 1;
     W = std::max(1, std::min(W, std::max(1, maxSlots / 2)));
+    // ---- structural key -> cached schedule?
+    std::vector<int>& skey = ws.skey;
+    skey.clear();
+    skey.push_back(n); skey.push_back(W); skey.push_back(maxSlots); skey.push_back((inOrder ? 1 : 0) | (noIdleLoads ? 2 : 0));
+    for (int o = 0; o < n; ++o) {
+        skey.push_back(prod1[o]);
+        skey.push_back(prod2[o]);
+        skey.push_back((int) dev[o].c1_kind | ((int) dev[o].c2_kind << 8) | (c1Idx[o] == c2Idx[o] ? 1 << 16 : 0));
+    }
+    uint64_t shash = 1469598103934665603ull;
+    for (int v : skey) shash = (shash ^ (uint64_t) (uint32_t) v) * 1099511628211ull;
+    const WalkSchedule* cached = nullptr;
+    {
+        auto it = schedules.find(shash);
+        if (it != schedules.end() && it->second.key == skey) cached = &it->second;
+    }
+    auto makeLoad = [&](const PartialsOp& d, int t, int sl, int o) {   // LOAD entry: an idle wave copies child t of o into slot sl
+        PartialsOp ld;
+        std::memset(&ld, 0, sizeof ld);
+        ld.dst = const_cast<float*>(reinterpret_cast<const float*>(t == 0 ? d.c1 : d.c2));
+        ld.c1 = ld.c2 = arenaTips;
+        ld.m1 = ld.m2 = matrices;
+        ld.scale = scratchScale;
+        ld.c1_kind = ld.c2_kind = CHILD_STATES;
+        ld.c1_slot = ld.c2_slot = MBAMD_NO_SLOT;
+        ld.dst_slot = (uint8_t) sl;
+        ld.flags = MBAMD_OP_LOAD;
+        ld.pad2_[0] = o;                                         // (host bookkeeping, unused by the kernel)
+        ld.pad2_[1] = t;
+        return ld;
+    };
+    std::vector<std::vector<int>>& steps = ws.steps;      // steps[0 .. nstepsBuilt)
+    std::vector<std::vector<PartialsOp>>& stepLoads = ws.stepLoads;   // LOAD entries (idle compute waves prefetch global children)
+    std::vector<char>& drainBefore = ws.drainBefore;      // step q re-reads a value this list stored earlier
+    drainBefore.clear();
+    int nstepsBuilt = 0, slotsUsed = 0;
+    if (cached) {
+        scheduleHits++;
+        nstepsBuilt = cached->nsteps;
+        slotsUsed = cached->slotsUsed;
+        while ((int) steps.size() < nstepsBuilt) { steps.emplace_back(); stepLoads.emplace_back(); }
+        for (int o = 0; o < n; ++o) {
+            PartialsOp& d = dev[o];
+            const uint8_t* f = &cached->opFields[(size_t) o * 5];
+            d.c1_kind = f[0]; d.c2_kind = f[1]; d.c1_slot = f[2]; d.c2_slot = f[3]; d.dst_slot = f[4];
+            d.flags = 0;
+            if (d.scale_mode == SCALE_NONE) d.scale = scratchScale;
+        }
+        for (int q = 0; q < nstepsBuilt; ++q) {
+            steps[q].assign(cached->stepOps.begin() + cached->stepStart[q], cached->stepOps.begin() + cached->stepStart[q + 1]);
+            stepLoads[q].clear();
+            for (int li = cached->loadStart[q]; li < cached->loadStart[q + 1]; ++li) {
+                const int lo = cached->loadOps[3 * li], lt = cached->loadOps[3 * li + 1], lsl = cached->loadOps[3 * li + 2];
+                stepLoads[q].push_back(makeLoad(dev[lo], lt, lsl, lo));
+            }
+        }
+        drainBefore.assign(cached->drainBefore.begin(), cached->drainBefore.end());
+    } else {
+    scheduleMisses++;
     std::vector<std::vector<int>>& consumers = ws.consumers;
     if ((int) consumers.size() < n) consumers.resize(n);
     for (int o = 0; o < n; ++o) consumers[o].clear();
@@ -1105,15 +1179,10 @@ int Instance::buildWalk(Plan& plan, std::vector<PartialsOp>& dev, const std::vec
     slotOf.assign(n, -1);
     slotHolder.assign(maxSlots, -1);
     slotFreeFrom.assign(maxSlots, -1);
-    std::vector<std::vector<int>>& steps = ws.steps;      // steps[0 .. nstepsBuilt)
-    std::vector<std::vector<PartialsOp>>& stepLoads = ws.stepLoads;   // LOAD entries (idle compute waves prefetch global children)
-    int nstepsBuilt = 0;
-    std::vector<char>& drainBefore = ws.drainBefore;      // step q re-reads a value this list stored earlier
-    drainBefore.clear();
     std::vector<int>& ready = ws.ready;
     ready.clear();
     for (int o = 0; o < n; ++o) if (indeg[o] == 0) ready.push_back(o);
-    int slotsUsed = 0, done = 0;
+    int done = 0;
 
     for (int s = 0; done < n; ++s) {
         if (s > 4 * n + 16) return fail(BEAGLE_ERROR_GENERAL, "tree-walk scheduler made no progress");
@@ -1190,17 +1259,7 @@ int Instance::buildWalk(Plan& plan, std::vector<PartialsOp>& dev, const std::vec
                         int claimed = 0;
                         for (int li = 0; li < nLoadsHere; ++li) claimed += loadsHere[li].first == q;
                         if ((int) (steps[q].size() + stepLoads[q].size()) + claimed >= W) continue;
-                        PartialsOp ld;
-                        std::memset(&ld, 0, sizeof ld);
-                        ld.dst = const_cast<float*>(reinterpret_cast<const float*>(t == 0 ? d.c1 : d.c2));
-                        ld.c1 = ld.c2 = arenaTips;
-                        ld.m1 = ld.m2 = matrices;
-                        ld.scale = scratchScale;
-                        ld.c1_kind = ld.c2_kind = CHILD_STATES;
-                        ld.c1_slot = ld.c2_slot = MBAMD_NO_SLOT;
-                        ld.dst_slot = (uint8_t) sl;
-                        ld.flags = MBAMD_OP_LOAD;
-                        loadsHere[nLoadsHere++] = std::make_pair(q, ld);
+                        loadsHere[nLoadsHere++] = std::make_pair(q, makeLoad(d, t, sl, o));
                         *kind[t] = CHILD_LDS;                 // by step s it is an ordinary slot
                         break;
                     }
@@ -1275,6 +1334,33 @@ int Instance::buildWalk(Plan& plan, std::vector<PartialsOp>& dev, const std::vec
         for (int o : chosen)
             for (int q = o + 1; q < n; ++q)
                 if ((prod1[q] == o || prod2[q] == o) && --indeg[q] == 0) ready.push_back(q);
+    }
+    // ---- remember the schedule under its structural key
+    if (schedules.size() >= 8192) schedules.clear();
+    WalkSchedule& rec = schedules[shash];
+    rec.key = skey;
+    rec.nsteps = nstepsBuilt;
+    rec.slotsUsed = slotsUsed;
+    rec.opFields.resize((size_t) n * 5);
+    for (int o = 0; o < n; ++o) {
+        uint8_t* f = &rec.opFields[(size_t) o * 5];
+        f[0] = dev[o].c1_kind; f[1] = dev[o].c2_kind; f[2] = dev[o].c1_slot; f[3] = dev[o].c2_slot; f[4] = dev[o].dst_slot;
+    }
+    rec.stepStart.assign(1, 0);
+    rec.stepOps.clear();
+    rec.loadStart.assign(1, 0);
+    rec.loadOps.clear();
+    for (int q = 0; q < nstepsBuilt; ++q) {
+        rec.stepOps.insert(rec.stepOps.end(), steps[q].begin(), steps[q].end());
+        rec.stepStart.push_back((int) rec.stepOps.size());
+        for (const PartialsOp& ld : stepLoads[q]) {
+            rec.loadOps.push_back(ld.pad2_[0]);
+            rec.loadOps.push_back(ld.pad2_[1]);
+            rec.loadOps.push_back(ld.dst_slot);
+        }
+        rec.loadStart.push_back((int) rec.loadOps.size() / 3);
+    }
+    rec.drainBefore.assign(drainBefore.begin(), drainBefore.end());
     }
     const int nsteps = nstepsBuilt;
 
@@ -1936,7 +2022,8 @@ int beagleFinalizeInstance(int instance)
         g_instances[instance] = nullptr;
     }
     if (g_statsOn) {
-        std::fprintf(stderr, "[mbamd] instance %d: plan cache %ld hits / %ld misses\n", instance, in->planHits, in->planMisses);
+        std::fprintf(stderr, "[mbamd] instance %d: plan cache %ld hits / %ld misses; tree-walk schedules re-used %llu / built %llu\n", instance,
+                     in->planHits, in->planMisses, (unsigned long long) in->scheduleHits, (unsigned long long) in->scheduleMisses);
         for (const ApiStats& a : g_stats)
             std::fprintf(stderr, "[mbamd]   %-34s %9ld calls %10.3f ms total %9.2f us/call\n", a.name, a.calls,
                          a.seconds * 1e3, a.calls ? a.seconds * 1e6 / a.calls : 0.0);
