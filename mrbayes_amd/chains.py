@@ -72,6 +72,7 @@ class ChainExchange:
         self.swaps_tried = 0
         self.swaps_done = 0
         self._buf = None
+        self.pairwise = True                         # False: swap attempts use the all-reduce of all chains' states
 
     def all_states(self, lnl: Dict[int, float], lnprior: Optional[Dict[int, float]] = None) -> Tuple[np.ndarray, np.ndarray]:
         """Every rank contributes the (lnL, lnPrior) of its own chains; everybody gets all of them."""
@@ -132,16 +133,26 @@ class ChainExchange:
         import torch
         first = torch.zeros(1, dtype=torch.float64, device=self.device or "cpu")
         self.dist.all_reduce(first)
-        for i in range(self.world):
-            for j in range(i + 1, self.world):
-                if self.rank in (i, j):
-                    self._pair_exchange(j if self.rank == i else i, [0.0, 0.0, 0.0])
+        ok = 1.0
+        try:
+            for i in range(self.world):
+                for j in range(i + 1, self.world):
+                    if self.rank in (i, j):
+                        self._pair_exchange(j if self.rank == i else i, [0.0, 0.0, 0.0])
+        except Exception:                      # a backend without subset send/recv: everybody falls back together
+            ok = 0.0
+        agree = torch.tensor([ok], dtype=torch.float64, device=self.device or "cpu")
+        self.dist.all_reduce(agree, op=self.dist.ReduceOp.MIN)
+        self.pairwise = bool(agree.item() > 0.5)
 
     def swap_generation(self, lnl: Dict[int, float], lnprior: Optional[Dict[int, float]] = None):
         """One swap attempt of this generation (RunChain picks the pair, src/mcmc.c:16941-16957; AttemptSwap,
         src/mcmc.c:591-1140).  `lnl` / `lnprior`: this rank's own chains.  Returns (a, b, accepted) with
         accepted = None on a rank that owns neither chain (it does not communicate and does not learn the outcome,
         exactly like a reference rank; `chain_id` is authoritative for a rank's own chains only)."""
+        if not self.pairwise:                               # collective fallback: every rank learns every state
+            all_lnl, all_pr = self.all_states(lnl, lnprior)
+            return self.attempt_swap(all_lnl, all_pr)
         a = int(self.rng.random() * self.nchains)
         b = int(self.rng.random() * (self.nchains - 1))
         if b >= a:

@@ -60,6 +60,21 @@ def test_chain_assignment():
     assert ch.swap_log_ratio(-10.0, 0.0, 1.0, -12.0, 0.0, 0.5) < 0.0 < ch.swap_log_ratio(-12.0, 0.0, 1.0, -10.0, 0.0, 0.5)
 
 
+def test_collective_fallback_makes_the_same_decisions():
+    """ChainExchange.pairwise = False (set by warm_up when the backend cannot do subset send/recv) routes swap
+    attempts through the all-reduce of every chain's state: same draws, same outcomes."""
+    sys.path.insert(0, ROOT)
+    from mrbayes_amd import chains as ch
+    lnl = {0: -1000.0, 1: -1003.5, 2: -998.2, 3: -1010.0}
+    p2p, coll = ch.ChainExchange(4, swap_seed=99), ch.ChainExchange(4, swap_seed=99)
+    coll.pairwise = False
+    for gen in range(50):
+        cur = {c: v - 0.1 * gen * (c + 1) for c, v in lnl.items()}
+        assert p2p.swap_generation(cur) == coll.swap_generation(cur)
+        assert p2p.chain_id == coll.chain_id
+    assert p2p.swaps_done == coll.swaps_done > 0
+
+
 def test_two_ranks_agree_with_one():
     import torch.multiprocessing as mp
     ctx = mp.get_context("spawn")
