@@ -1,6 +1,6 @@
 """Timing experiment: run the unmodified MrBayes binary on the engine for N generations with MBAMD_STATS=1."""
 import os, sys
-sys.path.insert(0, os.getcwd())
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
 from mrbayes_amd import data as mbdata, tree as mbtree
 from tools import refrun
 ntaxa, npat, ngen = int(sys.argv[1]), int(sys.argv[2]), int(sys.argv[3])

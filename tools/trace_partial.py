@@ -3,7 +3,7 @@ import ctypes as C, os, sys
 import numpy as np
 os.environ["MBAMD_WALK_TRACE"] = "1"
 os.environ["MBAMD_VERBOSE"] = "1"
-sys.path.insert(0, os.getcwd())
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
 from mrbayes_amd import beagle as bg, likelihood as lk
 from mrbayes_amd.division import synthetic_division
 scaling = lk.MB_BEAGLE_SCALE_DYNAMIC if (len(sys.argv) > 1 and sys.argv[1] == "dynamic") else lk.MB_BEAGLE_SCALE_ALWAYS

@@ -2,7 +2,7 @@
 import ctypes as C, os, sys
 import numpy as np
 os.environ["MBAMD_WALK_TRACE"] = "1"
-sys.path.insert(0, os.getcwd())
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
 from mrbayes_amd import beagle as bg, likelihood as lk
 from mrbayes_amd.division import synthetic_division
 cfg = sys.argv[1] if len(sys.argv) > 1 else "c2"
