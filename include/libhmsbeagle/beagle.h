@@ -272,6 +272,10 @@ BEAGLE_DLLEXPORT int beagleGetSiteLogLikelihoods(int instance, double* outLogLik
  * ------------------------------------------------------------------------------------------- */
 /* Block until all queued device work of the instance has finished. */
 BEAGLE_DLLEXPORT int mbamdSynchronize(int instance);
+/* The binary exponents behind a scale buffer: out[k * patternCount + c].  The 4-state path keeps one exponent per
+ * (pattern, category) -- beagleGetScaleFactors reports the largest of a pattern's exponents times ln 2; the general-state
+ * path keeps one per pattern (every category row is the same). */
+BEAGLE_DLLEXPORT int mbamdGetScaleExponents(int instance, int srcScalingIndex, int* out);
 /* Last HIP/engine error text of the calling thread ("" if none). */
 BEAGLE_DLLEXPORT const char* mbamdGetLastError(void);
 /* Device-side timing of the partials kernels: accumulates HIP-event time (ms) and launch count of every

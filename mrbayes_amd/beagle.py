@@ -63,6 +63,7 @@ EXPORTS = [
     "beagleGetScaleFactors", "beagleCalculateRootLogLikelihoods", "beagleCalculateEdgeLogLikelihoods",
     "beagleGetSiteLogLikelihoods", "mbamdSynchronize", "mbamdGetLastError", "mbamdKernelTiming",
     "mbamdGetKernelTiming", "mbamdSetKernelPath", "mbamdSetDeferredResult", "mbamdFetchLogLikelihood",
+    "mbamdGetScaleExponents",
 ]
 
 _dp = C.POINTER(C.c_double)
@@ -278,6 +279,12 @@ class BeagleInstance:
     def get_scale_factors(self, idx) -> np.ndarray:
         out = np.empty(self.pattern_count)
         self._chk(self.lib.beagleGetScaleFactors(self.id, idx, out.ctypes.data_as(_dp)), "beagleGetScaleFactors")
+        return out
+
+    def get_scale_exponents(self, idx) -> np.ndarray:
+        """Engine extension: the binary exponents behind a scale buffer, [categories][patterns]."""
+        out = np.empty((self.category_count, self.pattern_count), dtype=np.int32)
+        self._chk(self.lib.mbamdGetScaleExponents(self.id, idx, out.ctypes.data_as(_ip)), "mbamdGetScaleExponents")
         return out
 
     # ---- likelihood -------------------------------------------------------------------------------

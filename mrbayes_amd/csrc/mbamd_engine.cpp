@@ -13,6 +13,7 @@
 #include <hip/hip_runtime.h>
 #define MBAMD_LAUNCH(kernel, grid, block, lds, stream, ...) \
     hipLaunchKernelGGL(kernel, dim3(grid), dim3(block), lds, stream, __VA_ARGS__)
+#define MBAMD_LAUNCH_BARRIER MBAMD_LAUNCH          // (the host emulation runs kernels with workgroup barriers as fibers)
 #endif
 
 #include <algorithm>
@@ -29,6 +30,7 @@
 
 #include "libhmsbeagle/beagle.h"
 #include "mbamd_kernels.h"
+#include "mbamd_walk4_host.h"
 #if !defined(MBAMD_HOST_EMU)
 #include "mbamd_kernels_mfma.h"
 #endif
@@ -104,7 +106,8 @@ struct Plan {
     uint64_t lastLaunch = 0;         // Instance::launchClock value of the latest launch that reads d_table
     PartialsOp* d_table = nullptr;
     size_t cap = 0;                  // bytes allocated for d_table
-    int nsteps = 0, W = 1, slotsUsed = 0;        // tree-walk schedule
+    struct Segment { size_t first; int W, entries, nslots; };   // tree-walk path: one launch per hazard-free segment
+    std::vector<Segment> segments;               // (Walk4Entry index of its program in d_table, geometry)
     std::vector<int> start;                      // general path: first table entry of each dependency level
     bool anyScale = false;
     bool narrow = false;                         // general path: few operations per level -> one serial launch
@@ -124,34 +127,21 @@ struct Instance {
     bool s4 = false;                 // 4-state float4 layout + tree-walk kernel
     bool mfma = false;               // general-state path on the matrix cores (mbamd_kernels_mfma.h)
     bool mfmaWhole = false;          // MBAMD_MFMA_WHOLE: one wave per (operation, 32 patterns) instead of per factor tile
-    int walkWaves = 1, walkSlots = 16;   // tree-walk kernel: waves per pattern block, LDS slots per workgroup
-    int lastWalkSteps = 0, lastWalkSlots = 0;
-    bool noIdleLoads = false;        // MBAMD_WALK_NO_IDLE_LOADS: global children are only copied by the loader wave
-    bool walkKSplit = false;         // MBAMD_WALK_KSPLIT=1: two waves per operation (category split); measured slower (profiles/)
-    // Schedules of the tree-walk path are a function of the list's dependency STRUCTURE only (who produces whose
-    // child, which children are tips): the buffer / matrix / scale indices -- which change with every accept / reject
-    // flip -- just fill the slots of the table.  A move that touches the branches it touched before (same root-ward
-    // path, or the whole tree) therefore re-uses its schedule and only re-fills the table.
-    struct WalkSchedule {
-        std::vector<int> key;
-        int nsteps = 0, slotsUsed = 0;
-        std::vector<uint8_t> opFields;           // per operation: c1_kind, c2_kind, c1_slot, c2_slot, dst_slot
-        std::vector<int> stepStart, stepOps;     // operations of each step
-        std::vector<int> loadStart, loadOps;     // LOAD entries of each step: (operation, child, slot)
-        std::vector<char> drainBefore;
-    };
-    std::unordered_map<uint64_t, WalkSchedule> schedules;
+    int walkWaves = 1, lastWalkSteps = 0;   // (kernel trace bookkeeping of the serial MFMA kernels, tools/trace_*.py)
+    // ---- 4-state tree-walk path (mbamd_walk4.h / mbamd_walk4_host.h) -------------------------------------------
+    Walk4Builder w4;                 // launch geometry limits + the program compiler
+    // Programs are a function of the list's dependency STRUCTURE only (who produces whose child, which children are
+    // tips): the buffer / matrix / scale indices -- which change with every accept / reject flip -- just fill the
+    // entries.  A move that touches the branches it touched before re-uses its template and only re-fills it.
+    std::unordered_map<uint64_t, Walk4Template> w4templates;
     uint64_t scheduleHits = 0, scheduleMisses = 0;
-    // scratch of Instance::buildWalk, kept between calls (a move compiles a fresh list every generation: no allocations)
-    struct WalkScratch {
-        std::vector<int> prod1, prod2, lastWriter, indeg, pendingReads, prio, need, stepOf, slotOf, slotHolder, slotFreeFrom,
-                         ready, chosen, skey;
-        std::vector<char> readOld, readThisStep, drainBefore;
-        std::vector<std::vector<int>> consumers, steps;
-        std::vector<std::vector<PartialsOp>> stepLoads;
-        std::vector<std::pair<int, int>> stack;
-        std::vector<PartialsOp> table;
-    } ws;
+    std::vector<Walk4Op> w4ops;      // scratch
+    std::vector<Walk4Entry> w4table;
+    int8_t* arenaExp = nullptr;      // node exponents int8 [block][scale buffer][K][64] (+ one scratch buffer)
+    unsigned estride = 0;            // bytes between blocks
+    std::vector<int32_t*> wideScale; // cumulative exponents int32 [K][Ppad], allocated on first use
+    std::vector<char> scaleState;    // 0 = never written (zero), 1 = node exponents in the arena, 2 = cumulative (wide)
+    int lastWalkW = 0, lastWalkSlots = 0, lastWalkEntries = 0, lastWalkPhases = 0;
     uint64_t launchClock = 0, syncedClock = 0;   // launches issued / launches known complete (last stream synchronisation)
     std::vector<double> h_freqs, h_weights;      // host mirrors of d_freqs / d_weights (uploadIfChanged)
     long long* d_trace = nullptr;    // MBAMD_WALK_TRACE: per-step clock stamps of workgroup 0 (timing experiments)
@@ -167,8 +157,7 @@ struct Instance {
     std::vector<char> valid;           // partials buffer has been written (import or operation destination)
     // 4-state path: pattern-block-major arenas (see mbamd_kernels.h), one allocation each
     float* arenaPartials = nullptr;
-    uint8_t* arenaTips = nullptr;
-    int32_t* arenaScale = nullptr;
+    uint64_t* arenaTips = nullptr;     // state bitplanes uint64 [block][buffer][4]
     BlockGeom geom{64, 64, 64};        // general path: linear [P_pad] arrays == block stride 64
     float* matrices = nullptr;
     double *d_eigen = nullptr, *d_freqs = nullptr, *d_weights = nullptr, *d_rates = nullptr, *d_pweights = nullptr;
@@ -296,6 +285,7 @@ struct Instance {
 
     int configureWalk();
     int setTipStates(int tip, const int* states);
+    int setTipMasks(int tip, const std::vector<uint8_t>& masks);
     int importPartials(int idx, const double* in, bool hasCategories);
     int getPartials(int idx, double* out);
     int setEigen(int idx, const double* U, const double* Ui, const double* lam);
@@ -303,8 +293,12 @@ struct Instance {
     int setMatrix(int idx, const double* in);
     int getMatrix(int idx, double* out);
     int updatePartials(const BeagleOperation* ops, int n, int cumIdx);
-    int buildWalk(Plan& plan, std::vector<PartialsOp>& dev, const std::vector<int>& dstIdx, const std::vector<int>& c1Idx,
-                  const std::vector<int>& c2Idx);
+    int updatePartials4(const BeagleOperation* ops, int n, int cumIdx);
+    int buildWalk(Plan& plan, const BeagleOperation* ops, int n);
+    int ensureWide(int idx);
+    int accumulate4(const int* idx, int n, int cumIdx, int sign);
+    int integrate4(const int* parent, const int* child, const int* prob, const int* wIdx, const int* fIdx,
+                   const int* cumIdx, int count);
     int buildGeneric(Plan& plan, std::vector<PartialsOp>& dev, const std::vector<int>& dstIdx, const std::vector<int>& c1Idx,
                      const std::vector<int>& c2Idx);
     int runWalk(const Plan& plan, int32_t* cum);
@@ -317,7 +311,7 @@ struct Instance {
     std::vector<char> pendingMatrixOut;          // matrix buffers the queued jobs write
     int submit(Plan* plan, int cumIdx, int32_t* cumPtr);
     bool noDefer = false;            // MBAMD_NO_DEFER: run every list at once
-    bool envInOrder = false, envVerbose = false, envReverseStep = false, envTrace = false;   // MBAMD_WALK_IN_ORDER, _VERBOSE, _EMU_REVERSE_STEP, _WALK_TRACE (read once)
+    bool envVerbose = false, envTrace = false;   // MBAMD_VERBOSE, MBAMD_WALK_TRACE (read once)
     bool noSpine = false;            // MBAMD_NO_SPINE: serial launches use the plain (not software-pipelined) kernel
     int spineWidth = 1;              // MBAMD_SPINE_WIDTH: trailing levels of at most this many operations join the serial launch
     int serialRatio = 4;             // MBAMD_MFMA_SERIAL: lists with <= ratio * levels operations run as ONE serial launch (0 = never)
@@ -362,7 +356,8 @@ int Instance::create(int tipCount_, int partialsBufferCount, int compactBufferCo
     nMatrices = matrixBufferCount;
     nScale = scaleBufferCount;
     const bool forceGeneric = std::getenv("MBAMD_FORCE_GENERIC") != nullptr;
-    s4 = (S == 4 && K >= 1 && K <= 8 && !forceGeneric);
+    // the 4-state tree walk addresses buffers with 16-bit indices (Walk4Entry)
+    s4 = (S == 4 && !forceGeneric && nBuffers < 65536 && nMatrices < 65536 && nScale + 1 < 65536 && K <= 1024);
     if (s4) SP = 4;
     else if (S <= 4) SP = 4;
     else if (S <= 8) SP = 8;
@@ -384,9 +379,7 @@ int Instance::create(int tipCount_, int partialsBufferCount, int compactBufferCo
     // serial / spine kernels exist for these shapes only (other category counts: level launches throughout)
     if (!((NT == 1 && (K == 1 || K == 2 || K == 4)) || (NT == 2 && (K == 1 || K == 2)))) serialRatio = 0;
 #endif
-    envInOrder = std::getenv("MBAMD_WALK_IN_ORDER") != nullptr;
     envVerbose = std::getenv("MBAMD_VERBOSE") != nullptr;
-    envReverseStep = std::getenv("MBAMD_EMU_REVERSE_STEP") != nullptr;
     envTrace = std::getenv("MBAMD_WALK_TRACE") != nullptr;
     noSiteHost = std::getenv("MBAMD_NO_SITE_HOST") != nullptr;
     partialsFloats = s4 ? (size_t) K * Ppad * 4 : (size_t) K * S * Ppad;
@@ -405,21 +398,22 @@ int Instance::create(int tipCount_, int partialsBufferCount, int compactBufferCo
         // kind, block-major so that a 64-pattern workgroup owns one contiguous slice of each
         const size_t nb = (size_t) Ppad / 64;
         geom.pstride = (unsigned long) nBuffers * K * 64;
-        geom.tstride = (unsigned) nBuffers * 64;
-        geom.sstride = (unsigned) (scale.size() + 1) * 64;     // + one scratch buffer (sink of non-rescaling operations)
-        const size_t pBytes = nb * geom.pstride * 16, tBytes = nb * geom.tstride, sBytes = nb * geom.sstride * 4;
+        geom.tstride = (unsigned) nBuffers * 4;
+        geom.sstride = 64;
+        estride = (unsigned) (scale.size() + 1) * K * 64;       // + one scratch buffer (sink of non-rescaling operations)
+        const size_t pBytes = nb * geom.pstride * 16, tBytes = nb * geom.tstride * 8, eBytes = nb * (size_t) estride;
         HIP_TRY(hipMalloc(&arenaPartials, pBytes));
         HIP_TRY(hipMalloc(&arenaTips, tBytes));
-        HIP_TRY(hipMalloc(&arenaScale, sBytes));
+        HIP_TRY(hipMalloc(&arenaExp, eBytes));
         HIP_TRY(hipMemsetAsync(arenaPartials, 0, pBytes, stream));
-        HIP_TRY(hipMemsetAsync(arenaTips, 0, tBytes, stream));
-        HIP_TRY(hipMemsetAsync(arenaScale, 0, sBytes, stream));
+        HIP_TRY(hipMemsetAsync(arenaTips, 0xFF, tBytes, stream));            // (a tip never set = all states compatible)
+        HIP_TRY(hipMemsetAsync(arenaExp, 0, eBytes, stream));
+        wideScale.assign(scale.size(), nullptr);
+        scaleState.assign(scale.size(), 0);
         if (std::getenv("MBAMD_VERBOSE"))
-            std::fprintf(stderr, "[mbamd] arenas: partials %p +%zu, tips %p +%zu, scale %p +%zu, matrices %p +%zu\n",
-                         (void*) arenaPartials, pBytes, (void*) arenaTips, tBytes, (void*) arenaScale, sBytes, (void*) matrices,
-                         (size_t) nMatrices * matrixFloats * 4);
+            std::fprintf(stderr, "[mbamd] arenas: partials %p +%zu, tips %p +%zu, exponents %p +%zu\n",
+                         (void*) arenaPartials, pBytes, (void*) arenaTips, tBytes, (void*) arenaExp, eBytes);
         for (int i = 0; i < nBuffers; ++i) partials[i] = arenaPartials + (size_t) i * K * 64 * 4;
-        for (size_t i = 0; i < scale.size(); ++i) scale[i] = arenaScale + i * 64;
     }
 
     HIP_TRY(hipMalloc(&matrices, std::max<size_t>(1, (size_t) nMatrices * matrixFloats) * sizeof(float)));
@@ -458,8 +452,9 @@ void Instance::destroy()
     (void) hipSetDevice(device);
     (void) hipStreamSynchronize(stream);
     if (s4) {
-        void* arenas[] = {arenaPartials, arenaTips, arenaScale};
+        void* arenas[] = {arenaPartials, arenaTips, arenaExp};
         for (void* a : arenas) if (a) (void) hipFree(a);
+        for (int32_t* w : wideScale) if (w) (void) hipFree(w);
     } else {
         for (float* p : partials) if (p) (void) hipFree(p);
         for (uint8_t* p : tipStates) if (p) (void) hipFree(p);
@@ -469,7 +464,7 @@ void Instance::destroy()
     for (Plan* pl : plans) { if (pl->d_table) (void) hipFree(pl->d_table); delete pl; }
     plans.clear();
     void* bufs[] = {matrices, d_eigen, d_freqs, d_weights, d_rates, d_pweights, d_site,
-                    d_ev, d_tmp};
+                    d_ev, d_tmp, d_trace};
     for (void* b : bufs) if (b) (void) hipFree(b);
     if (h_sums) (void) hipHostFree(h_sums);
     if (h_site) (void) hipHostFree(h_site);
@@ -479,52 +474,51 @@ void Instance::destroy()
 }
 
 // ---------------------------------------------------------------------------------------------
-// Tree-walk geometry: W compute waves (+1 writer wave) per 64-pattern workgroup and the number of LDS
-// slots it may use, chosen so that every workgroup of the grid is resident at once when the chip allows it.
+// Tree-walk geometry.  The grid is (pattern blocks) x (categories) workgroups of W waves; each wave owns `slots` LDS
+// slots of 1 KiB.  W and the slot count are chosen so that the whole grid is resident at once when the chip allows it:
+// few blocks -> more tree parallelism per block, many blocks -> single-wave workgroups with deep slot stacks.
 int Instance::configureWalk()
 {
-    int total = 4;                                     // waves per workgroup, writer included
-    int ldsBudget = 64 * 1024;
-#if !defined(MBAMD_HOST_EMU)
     int numCU = 256;
+#if !defined(MBAMD_HOST_EMU)
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0) numCU = prop.multiProcessorCount;
-    const int wgs = Ppad / 64;
-    const int perCU = (wgs + numCU - 1) / numCU;       // workgroups a CU must host for full residency
-    const int resident = std::max(1, std::min(perCU, 4));
-    // measured (profiles/): once every CU has a workgroup, 3 compute waves + loader beat 7 + loader (LDS slots
-    // per workgroup, not waves, are the scarce resource); small grids take the wider workgroup for tree parallelism
-    total = perCU >= 8 ? 2 : (perCU >= 3 ? 4 : (wgs >= numCU ? 5 : 8));
-    ldsBudget = (160 * 1024) / resident - 512;
-    hipError_t err = hipSuccess;
     const int maxLds = 160 * 1024;
-    switch (K) {
-#define MBAMD_WALK_ATTR(KK) \
-    case KK: err = hipFuncSetAttribute((const void*) k_walk_s4<KK>, hipFuncAttributeMaxDynamicSharedMemorySize, maxLds); break;
-        MBAMD_WALK_ATTR(1) MBAMD_WALK_ATTR(2) MBAMD_WALK_ATTR(3) MBAMD_WALK_ATTR(4)
-        MBAMD_WALK_ATTR(5) MBAMD_WALK_ATTR(6) MBAMD_WALK_ATTR(7) MBAMD_WALK_ATTR(8)
-#undef MBAMD_WALK_ATTR
-        default: break;
-    }
-    if (err != hipSuccess) {                          // stay within the default 64 KiB
+    if (hipFuncSetAttribute((const void*) k_walk4, hipFuncAttributeMaxDynamicSharedMemorySize, maxLds) != hipSuccess)
         (void) hipGetLastError();
-        ldsBudget = std::min(ldsBudget, 64 * 1024);
-    }
 #endif
-    if (const char* e = std::getenv("MBAMD_WALK_WAVES")) {
-        const int w = std::atoi(e);
-        if (w >= 2 && w <= 8) total = w;
-    }
-    if (std::getenv("MBAMD_WALK_TRACE") && !d_trace) {
-        HIP_TRY(hipMalloc(&d_trace, (size_t) 4096 * 8 * 3 * sizeof(long long)));
-        HIP_TRY(hipMemset(d_trace, 0, (size_t) 4096 * 8 * 3 * sizeof(long long)));
-    }
-    if (const char* ks = std::getenv("MBAMD_WALK_KSPLIT")) walkKSplit = std::atoi(ks) != 0;
-    noIdleLoads = std::getenv("MBAMD_WALK_NO_IDLE_LOADS") != nullptr;
-    walkWaves = total - 1;
-    const int fixedUnits = walk_lds_units(K, walkWaves, 0);
-    walkSlots = std::max(2, std::min(64, (ldsBudget / 16 - fixedUnits) / walk_slot_units(K)));
-    if (const char* dbg = std::getenv("MBAMD_MAX_LDS_SLOTS")) walkSlots = std::max(2, std::min(walkSlots, std::atoi(dbg)));
+    const long wgs = (long) (Ppad / 64) * K;
+    const int perCU = (int) std::max(1L, (wgs + numCU - 1) / numCU);          // workgroups a CU must host for full residency
+    const int ldsPerWG = (160 * 1024) / std::min(perCU, 32) - 64;
+    auto slotsFor = [&](int W) { return ldsPerWG / W / 1024; };
+    int W = std::max(1, std::min(MBAMD_W4_MAXW, 32 / std::min(perCU, 32)));
+    while (W > 1 && slotsFor(W) < 7) --W;
+    if (const char* e = std::getenv("MBAMD_WALK_WAVES")) W = std::max(1, std::min(MBAMD_W4_MAXW, std::atoi(e)));
+    int slots = std::max(3, std::min(48, slotsFor(W)));
+    if (const char* e = std::getenv("MBAMD_MAX_LDS_SLOTS")) slots = std::max(3, std::min(150 / W, std::atoi(e)));
+    w4.maxW = W;
+    w4.maxSlots = slots;
+    w4.maxSlots1 = std::max(slots, std::min(40, slotsFor(1)));
+    if (std::getenv("MBAMD_MAX_LDS_SLOTS")) w4.maxSlots1 = slots;
+    if (const char* e = std::getenv("MBAMD_WALK_PREFETCH")) w4.prefetchDistance = std::max(0, std::atoi(e));
+    w4.safeWaits = std::getenv("MBAMD_WALK_SAFE") != nullptr;
+    if (const char* e = std::getenv("MBAMD_WALK_SMALL_PHASE")) w4.smallPhase = std::max(1, std::atoi(e));
+    if (envVerbose) std::fprintf(stderr, "[mbamd] tree walk: %ld workgroups (%d per CU), up to %d waves x %d slots\n", wgs, perCU, W, slots);
+    return BEAGLE_SUCCESS;
+}
+
+// 4-state path: one tip's state masks (bit i = state i compatible) -> four 64-bit bitplanes per pattern block
+int Instance::setTipMasks(int tip, const std::vector<uint8_t>& h)
+{
+    const size_t nb = (size_t) Ppad / 64;
+    std::vector<uint64_t> planes(nb * 4, 0);
+    for (int c = 0; c < Ppad; ++c)
+        for (int i = 0; i < 4; ++i)
+            if (h[c] >> i & 1u) planes[(size_t) (c >> 6) * 4 + i] |= (uint64_t) 1 << (c & 63);
+    HIP_TRY(hipStreamSynchronize(stream));
+    HIP_TRY(hipMemcpy2D(arenaTips + (size_t) tip * 4, (size_t) geom.tstride * 8, planes.data(), 32, 32, nb, hipMemcpyHostToDevice));
+    if (!tipStates[tip]) layoutEpoch++;
+    tipStates[tip] = reinterpret_cast<uint8_t*>(arenaTips + (size_t) tip * 4);
     return BEAGLE_SUCCESS;
 }
 
@@ -534,17 +528,8 @@ int Instance::setTipStates(int tip, const int* states)
     std::vector<uint8_t> h(Ppad, (uint8_t) S);
     for (int c = 0; c < P; ++c) h[c] = (uint8_t) ((states[c] < 0 || states[c] >= S) ? S : states[c]);
     if (s4) {
-        int rc = grow(&d_tmp, &tmpCap, (size_t) Ppad);
-        if (rc) return rc;
-        rc = upload(d_tmp, h.data(), (size_t) Ppad);
-        if (rc) return rc;
-        if (!tipStates[tip]) layoutEpoch++;
-        tipStates[tip] = arenaTips + (size_t) tip * 64;
-        MBAMD_LAUNCH(k_scatter_bytes, (unsigned) ((Ppad + 255) / 256), 256, 0, stream, (const uint8_t*) d_tmp, Ppad,
-                     geom.tstride, tipStates[tip]);
-        HIP_TRY(hipGetLastError());
-        HIP_TRY(hipStreamSynchronize(stream));          // d_tmp is reused by the next call
-        return BEAGLE_SUCCESS;
+        for (int c = 0; c < Ppad; ++c) h[c] = (uint8_t) (h[c] >= 4 ? 0xF : 1u << h[c]);   // state masks (mbamd_walk4.h)
+        return setTipMasks(tip, h);
     }
     if (!tipStates[tip]) { HIP_TRY(hipMalloc(&tipStates[tip], (size_t) Ppad)); layoutEpoch++; }
     return upload(tipStates[tip], h.data(), (size_t) Ppad);
@@ -553,6 +538,22 @@ int Instance::setTipStates(int tip, const int* states)
 int Instance::importPartials(int idx, const double* in, bool hasCategories)
 {
     if (idx < 0 || idx >= nBuffers) return fail(BEAGLE_ERROR_OUT_OF_RANGE, "partials buffer index");
+    if (s4 && !hasCategories) {
+        // beagleSetTipPartials with 0/1 entries (IUPAC ambiguity codes, reference src/mbbeagle.c:150-166): a state mask
+        // per pattern says the same thing in one byte, and the tree walk reads it like any compact tip
+        std::vector<uint8_t> h(Ppad, 0xF);
+        bool binary = true;
+        for (int c = 0; c < P && binary; ++c) {
+            unsigned m = 0;
+            for (int i = 0; i < 4; ++i) {
+                const double v = in[(size_t) c * 4 + i];
+                if (v == 1.0) m |= 1u << i;
+                else if (v != 0.0) binary = false;
+            }
+            h[c] = (uint8_t) m;
+        }
+        if (binary) return setTipMasks(idx, h);
+    }
     int rc = ensurePartials(idx);
     if (rc) return rc;
     const size_t nIn = (size_t) (hasCategories ? K : 1) * P * S;
@@ -706,6 +707,7 @@ int Instance::updatePartials(const BeagleOperation* ops, int n, int cumIdx)
     if (n <= 0) return BEAGLE_SUCCESS;
     if (cumIdx != BEAGLE_OP_NONE && (cumIdx < 0 || cumIdx >= nScale))
         return fail(BEAGLE_ERROR_OUT_OF_RANGE, "beagleUpdatePartials: cumulative scale index");
+    if (s4) return updatePartials4(ops, n, cumIdx);
     int32_t* cumPtr = nullptr;
     if (cumIdx != BEAGLE_OP_NONE) {
         int rc = ensureScale(cumIdx);
@@ -727,7 +729,7 @@ int Instance::updatePartials(const BeagleOperation* ops, int n, int cumIdx)
             return submit(pl, cumIdx, cumPtr);
         }
     planMisses++;
-    if (s4 || !mfma || mfmaWhole || noDefer || pending.empty()) {
+    if (!mfma || mfmaWhole || noDefer || pending.empty()) {
         // launch the queued transition-matrix jobs now: the kernel runs while the host compiles the list
         int mrc = flushMatrices();
         if (mrc) return mrc;
@@ -807,7 +809,7 @@ int Instance::updatePartials(const BeagleOperation* ops, int n, int cumIdx)
     int rc;
     {
         StatTimer st_(ST_PLAN);
-        rc = s4 ? buildWalk(*plan, dev, dstIdx, c1Idx, c2Idx) : buildGeneric(*plan, dev, dstIdx, c1Idx, c2Idx);
+        rc = buildGeneric(*plan, dev, dstIdx, c1Idx, c2Idx);
     }
     if (rc) { plan->hash = 0; plan->key.clear(); return rc; }
     plan->bufsRead.assign(c1Idx.begin(), c1Idx.end());
@@ -1021,424 +1023,261 @@ int Instance::timedRun(const Plan& plan, int32_t* cum)
     return rc;
 }
 
-// Tree-walk path.  The operation list becomes a schedule of steps of up to W mutually independent
-// operations (one per compute wave of the workgroup that owns a 64-pattern block).  Scheduling and LDS
-// slot allocation happen in one pass over the steps, because they constrain each other:
-//   * a result that a later operation of the list consumes occupies an LDS slot from the step that
-//     produces it until its last consumer has read it; the slot can be overwritten from the next step on
-//     -- or in that very step by the operation that consumed it, if nobody else reads it;
-//   * a child that lives in global memory (a buffer this list does not produce, or an evicted value) needs a
-//     slot for the step before its consumer (the loader wave copies it in) and the consumer's step;
-//   * when no slot is free the resident value needed farthest in the future is evicted (Belady on list
-//     position); its consumers re-read it from HBM (CHILD_RELOAD), which is legal from step p+2 on, after
-//     the compute waves drained their stores (MBAMD_OP_DRAIN on step q-2 for a re-read in step q);
-//   * an operation that can get neither its inputs nor the slots it needs in this step waits for a later one.
-int Instance::buildWalk(Plan& plan, std::vector<PartialsOp>& dev, const std::vector<int>& dstIdx,
-                        const std::vector<int>& c1Idx, const std::vector<int>& c2Idx)
+// ---------------------------------------------------------------------------------------------
+// 4-state path: beagleUpdatePartials -> per-wave programs of the tree-walk kernel (mbamd_walk4.h).
+// ---------------------------------------------------------------------------------------------
+int Instance::ensureWide(int idx)
 {
-    const int n = (int) dev.size();
-    int W = walkWaves;
-    const int maxSlots = walkSlots;
-    int32_t* scratchScale = arenaScale + scale.size() * 64;      // readable / writable sink for unused scale pointers
+    if (!wideScale[idx]) {
+        HIP_TRY(hipMalloc(&wideScale[idx], (size_t) K * Ppad * sizeof(int32_t)));
+        if (scaleState[idx] != 1) HIP_TRY(hipMemsetAsync(wideScale[idx], 0, (size_t) K * Ppad * sizeof(int32_t), stream));
+    }
+    if (scaleState[idx] == 1) {                  // node exponents so far: a cumulative buffer continues from them
+        MBAMD_LAUNCH(k_exp_widen, (unsigned) (((size_t) K * Ppad + 255) / 256), 256, 0, stream, (const int8_t*) arenaExp, estride, idx, K, Ppad,
+                     wideScale[idx]);
+        HIP_TRY(hipGetLastError());
+    } else if (scaleState[idx] == 0) {
+        HIP_TRY(hipMemsetAsync(wideScale[idx], 0, (size_t) K * Ppad * sizeof(int32_t), stream));
+    }
+    scaleState[idx] = 2;
+    return BEAGLE_SUCCESS;
+}
 
-    // ---- dependencies: prodN[o] = operation of this list producing child N of o (or -1).  A list with
-    // write-after-read / write-after-write hazards on buffer indices (never produced by MrBayes) is
-    // executed strictly in list order by a single compute wave.
-    std::vector<int>&prod1 = ws.prod1, &prod2 = ws.prod2;
-    prod1.assign(n, -1);
-    prod2.assign(n, -1);
-    bool hazard = false;
-    {
-        std::vector<int>& lastWriter = ws.lastWriter;
-        std::vector<char>& readOld = ws.readOld;
-        lastWriter.assign(nBuffers, -1);
-        readOld.assign(nBuffers, 0);
-        for (int o = 0; o < n; ++o) {
-            prod1[o] = lastWriter[c1Idx[o]];
-            prod2[o] = lastWriter[c2Idx[o]];
-            readOld[c1Idx[o]] = 1;
-            readOld[c2Idx[o]] = 1;
-            if (readOld[dstIdx[o]] || lastWriter[dstIdx[o]] >= 0) hazard = true;
-            lastWriter[dstIdx[o]] = o;
+int Instance::updatePartials4(const BeagleOperation* ops, int n, int cumIdx)
+{
+    int32_t* cumPtr = nullptr;
+    if (cumIdx != BEAGLE_OP_NONE) {
+        int rc = ensureWide(cumIdx);
+        if (rc) return rc;
+        cumPtr = wideScale[cumIdx];
+    }
+    // ---- plan cache ------------------------------------------------------------------------
+    const int* raw = reinterpret_cast<const int*>(ops);
+    const size_t nints = (size_t) n * 7;
+    uint64_t h = 1469598103934665603ull;
+    for (size_t i = 0; i < nints; ++i) h = (h ^ (uint64_t) (uint32_t) raw[i]) * 1099511628211ull;
+    h = (h ^ (uint64_t) (uint32_t) layoutEpoch) * 1099511628211ull;
+    Plan* plan = nullptr;
+    for (Plan* pl : plans)
+        if (pl->hash == h && pl->key.size() == nints + 1 && pl->key[nints] == layoutEpoch &&
+            std::memcmp(pl->key.data(), raw, nints * sizeof(int)) == 0) {
+            pl->lastUse = ++planClock;
+            planHits++;
+            plan = pl;
+            break;
         }
+    if (!plan) {
+        planMisses++;
+        int mrc = flushMatrices();               // the matrix kernel runs while the host compiles the list
+        if (mrc) return mrc;
+        const size_t maxPlans = 24;
+        if (plans.size() < maxPlans) {
+            plan = new Plan();
+            plans.push_back(plan);
+        } else {
+            plan = plans[0];
+            for (Plan* pl : plans) if (pl->lastUse < plan->lastUse) plan = pl;
+        }
+        plan->key.assign(raw, raw + nints);
+        plan->key.push_back(layoutEpoch);
+        plan->hash = h;
+        plan->lastUse = ++planClock;
+        int rc;
+        {
+            StatTimer st_(ST_PLAN);
+            rc = buildWalk(*plan, ops, n);
+        }
+        if (rc) { plan->hash = 0; plan->key.clear(); return rc; }
     }
-    const bool inOrder = hazard || envInOrder;
-    if (inOrder) W = 1;
-    W = std::max(1, std::min(W, std::max(1, maxSlots / 2)));
-    // ---- structural key -> cached schedule?
-    std::vector<int>& skey = ws.skey;
-    skey.clear();
-    skey.push_back(n); skey.push_back(W); skey.push_back(maxSlots); skey.push_back((inOrder ? 1 : 0) | (noIdleLoads ? 2 : 0));
+    // bookkeeping the list implies, whether compiled now or before: destinations valid, exponent buffers in node form
     for (int o = 0; o < n; ++o) {
-        skey.push_back(prod1[o]);
-        skey.push_back(prod2[o]);
-        skey.push_back((int) dev[o].c1_kind | ((int) dev[o].c2_kind << 8) | (c1Idx[o] == c2Idx[o] ? 1 << 16 : 0));
+        valid[ops[o].destinationPartials] = 1;
+        if (ops[o].destinationScaleWrite != BEAGLE_OP_NONE) scaleState[ops[o].destinationScaleWrite] = 1;
     }
-    uint64_t shash = 1469598103934665603ull;
-    for (int v : skey) shash = (shash ^ (uint64_t) (uint32_t) v) * 1099511628211ull;
-    const WalkSchedule* cached = nullptr;
-    {
-        auto it = schedules.find(shash);
-        if (it != schedules.end() && it->second.key == skey) cached = &it->second;
-    }
-    auto makeLoad = [&](const PartialsOp& d, int t, int sl, int o) {   // LOAD entry: an idle wave copies child t of o into slot sl
-        PartialsOp ld;
-        std::memset(&ld, 0, sizeof ld);
-        ld.dst = const_cast<float*>(reinterpret_cast<const float*>(t == 0 ? d.c1 : d.c2));
-        ld.c1 = ld.c2 = arenaTips;
-        ld.m1 = ld.m2 = matrices;
-        ld.scale = scratchScale;
-        ld.c1_kind = ld.c2_kind = CHILD_STATES;
-        ld.c1_slot = ld.c2_slot = MBAMD_NO_SLOT;
-        ld.dst_slot = (uint8_t) sl;
-        ld.flags = MBAMD_OP_LOAD;
-        ld.pad2_[0] = o;                                         // (host bookkeeping, unused by the kernel)
-        ld.pad2_[1] = t;
-        return ld;
+    int mrc = flushMatrices();
+    if (mrc) return mrc;
+    return timedRun(*plan, cumPtr);
+}
+
+// Compile one operation list: validate, cut into hazard-free segments, build (or re-use) the structural template of
+// each segment and fill it with this list's buffer / matrix / scale indices.
+int Instance::buildWalk(Plan& plan, const BeagleOperation* ops, int n)
+{
+    const int scratchScale = (int) scale.size();              // sink / source of entries that do not rescale
+    std::vector<char> written(nBuffers, 0);
+    w4table.clear();
+    plan.segments.clear();
+    std::vector<Walk4Op>& seg = w4ops;
+    seg.clear();
+    // segment state: buffers / exponent buffers the current segment has read or written
+    std::vector<char> segRead(nBuffers, 0), segWritten(nBuffers, 0), segScale(scale.size() + 1, 0);
+    int reloads = 0, externals = 0, phases = 0;
+    auto flushSegment = [&]() -> int {
+        if (seg.empty()) return BEAGLE_SUCCESS;
+        // structural key
+        std::vector<int> key;
+        key.reserve(seg.size() * 3 + 4);
+        key.push_back((int) seg.size()); key.push_back(w4.maxW); key.push_back(w4.maxSlots + 256 * w4.maxSlots1);
+        key.push_back(w4.prefetchDistance * 2 + (w4.safeWaits ? 1 : 0));
+        {
+            std::unordered_map<int, int> writer;
+            for (size_t o = 0; o < seg.size(); ++o) {
+                auto p1 = seg[o].tip1 ? writer.end() : writer.find(seg[o].c1);
+                auto p2 = seg[o].tip2 ? writer.end() : writer.find(seg[o].c2);
+                key.push_back(p1 == writer.end() ? -1 : p1->second);
+                key.push_back(p2 == writer.end() ? -1 : p2->second);
+                key.push_back((int) seg[o].tip1 | ((int) seg[o].tip2 << 1) | ((!seg[o].tip1 && !seg[o].tip2 && seg[o].c1 == seg[o].c2) ? 4 : 0));
+                writer[seg[o].dst] = (int) o;
+            }
+        }
+        uint64_t kh = 1469598103934665603ull;
+        for (int v : key) kh = (kh ^ (uint64_t) (uint32_t) v) * 1099511628211ull;
+        auto it = w4templates.find(kh);
+        if (it == w4templates.end() || it->second.key != key) {
+            scheduleMisses++;
+            if (w4templates.size() >= 8192) w4templates.clear();
+            Walk4Template& t = w4templates[kh];
+            bool ok = w4.build(seg, t);
+            if (!ok) {                           // out of slots with look-ahead prefetches: retry without, then on one wave
+                Walk4Builder plain = w4;
+                plain.prefetchDistance = 0;
+                ok = plain.build(seg, t);
+                if (!ok) { plain.maxW = 1; ok = plain.build(seg, t); }
+            }
+            if (!ok) { w4templates.erase(kh); return fail(BEAGLE_ERROR_GENERAL, "tree-walk scheduler: cannot place this list"); }
+            t.key = key;
+            it = w4templates.find(kh);
+        } else {
+            scheduleHits++;
+        }
+        const Walk4Template& t = it->second;
+        reloads += t.reloads; externals += t.externals; phases = std::max(phases, t.phases);
+        Plan::Segment sg;
+        sg.first = w4table.size();
+        sg.W = t.W; sg.entries = t.entries; sg.nslots = t.nslots;
+        plan.segments.push_back(sg);
+        w4table.resize(sg.first + t.prog.size());
+        for (size_t i = 0; i < t.prog.size(); ++i) {
+            const Walk4Template::Entry& te = t.prog[i];
+            Walk4Entry& e = w4table[sg.first + i];
+            std::memset(&e, 0, sizeof e);
+            e.dst = 0xFF0000u | ((uint32_t) te.flags << 24);
+            e.scale = (uint32_t) scratchScale | ((uint32_t) SCALE_NONE << 16) | ((uint32_t) te.vmwait << 24);
+            e.sread = (uint32_t) scratchScale;
+            for (int q = 0; q < 2; ++q) {
+                if (te.pfOp[q] < 0) continue;
+                const Walk4Op& po = seg[te.pfOp[q]];
+                const uint32_t word = (uint32_t) (te.pfChild[q] == 0 ? po.c1 : po.c2) | ((uint32_t) te.pfSlot[q] << 16) | (1u << 24);
+                (q == 0 ? e.pf0 : e.pf1) = word;
+            }
+            if (te.op < 0) continue;
+            const Walk4Op& op = seg[te.op];
+            e.dst = (uint32_t) op.dst | ((uint32_t) te.dslot << 16) | ((uint32_t) te.flags << 24);
+            e.c1 = op.tip1 ? ((uint32_t) op.c1 | (MBAMD_W4_TIP << 24)) : ((uint32_t) te.c1slot << 16);
+            e.c2 = op.tip2 ? ((uint32_t) op.c2 | (MBAMD_W4_TIP << 24)) : ((uint32_t) te.c2slot << 16);
+            e.mats = (uint32_t) op.m1 | ((uint32_t) op.m2 << 16);
+            const uint32_t mode = op.scaleWrite >= 0 ? SCALE_WRITE : (op.scaleRead >= 0 ? SCALE_READ : SCALE_NONE);
+            e.scale = (uint32_t) (op.scaleWrite >= 0 ? op.scaleWrite : scratchScale) | (mode << 16) | ((uint32_t) te.vmwait << 24);
+            e.sread = (uint32_t) (op.scaleRead >= 0 ? op.scaleRead : scratchScale);
+        }
+        lastWalkW = t.W; lastWalkSlots = t.nslots; lastWalkEntries = t.entries; lastWalkPhases = t.phases;
+        seg.clear();
+        std::fill(segRead.begin(), segRead.end(), 0);
+        std::fill(segWritten.begin(), segWritten.end(), 0);
+        std::fill(segScale.begin(), segScale.end(), 0);
+        return BEAGLE_SUCCESS;
     };
-    std::vector<std::vector<int>>& steps = ws.steps;      // steps[0 .. nstepsBuilt)
-    std::vector<std::vector<PartialsOp>>& stepLoads = ws.stepLoads;   // LOAD entries (idle compute waves prefetch global children)
-    std::vector<char>& drainBefore = ws.drainBefore;      // step q re-reads a value this list stored earlier
-    drainBefore.clear();
-    int nstepsBuilt = 0, slotsUsed = 0;
-    if (cached) {
-        scheduleHits++;
-        nstepsBuilt = cached->nsteps;
-        slotsUsed = cached->slotsUsed;
-        while ((int) steps.size() < nstepsBuilt) { steps.emplace_back(); stepLoads.emplace_back(); }
-        for (int o = 0; o < n; ++o) {
-            PartialsOp& d = dev[o];
-            const uint8_t* f = &cached->opFields[(size_t) o * 5];
-            d.c1_kind = f[0]; d.c2_kind = f[1]; d.c1_slot = f[2]; d.c2_slot = f[3]; d.dst_slot = f[4];
-            d.flags = 0;
-            if (d.scale_mode == SCALE_NONE) d.scale = scratchScale;
-        }
-        for (int q = 0; q < nstepsBuilt; ++q) {
-            steps[q].assign(cached->stepOps.begin() + cached->stepStart[q], cached->stepOps.begin() + cached->stepStart[q + 1]);
-            stepLoads[q].clear();
-            for (int li = cached->loadStart[q]; li < cached->loadStart[q + 1]; ++li) {
-                const int lo = cached->loadOps[3 * li], lt = cached->loadOps[3 * li + 1], lsl = cached->loadOps[3 * li + 2];
-                stepLoads[q].push_back(makeLoad(dev[lo], lt, lsl, lo));
-            }
-        }
-        drainBefore.assign(cached->drainBefore.begin(), cached->drainBefore.end());
-    } else {
-    scheduleMisses++;
-    std::vector<std::vector<int>>& consumers = ws.consumers;
-    if ((int) consumers.size() < n) consumers.resize(n);
-    for (int o = 0; o < n; ++o) consumers[o].clear();
-    std::vector<int>&indeg = ws.indeg, &pendingReads = ws.pendingReads;
-    indeg.assign(n, 0);
-    pendingReads.assign(n, 0);
     for (int o = 0; o < n; ++o) {
-        if (prod1[o] >= 0) { consumers[prod1[o]].push_back(o); indeg[o]++; }
-        if (prod2[o] >= 0 && prod2[o] != prod1[o]) { consumers[prod2[o]].push_back(o); indeg[o]++; }
-    }
-    for (int o = 0; o < n; ++o) pendingReads[o] = (int) consumers[o].size();
-    // Scheduling priority: Sethi-Ullman order of the operation forest (at every node the child subtree
-    // that needs more live values first).  MrBayes' own post-order visits the left child first whatever
-    // its size, which on a 500-taxon tree keeps up to ~23 partials live; this order needs ~log2(N).
-    std::vector<int>& prio = ws.prio;
-    prio.assign(n, 0);
-    if (!inOrder) {
-        std::vector<int>& need = ws.need;
-        need.assign(n, 1);
-        for (int o = 0; o < n; ++o) {                     // children precede parents in the list
-            const int a = prod1[o], b = (prod2[o] != prod1[o]) ? prod2[o] : -1;
-            const int na = a >= 0 ? need[a] : 0, nb = b >= 0 ? need[b] : 0;
-            need[o] = std::max(1, (na == nb) ? na + (na > 0 ? 1 : 0) : std::max(na, nb));
+        const BeagleOperation& b = ops[o];
+        if (b.destinationPartials < 0 || b.destinationPartials >= nBuffers || b.child1Partials < 0 ||
+            b.child1Partials >= nBuffers || b.child2Partials < 0 || b.child2Partials >= nBuffers)
+            return fail(BEAGLE_ERROR_OUT_OF_RANGE, "beagleUpdatePartials: partials index");
+        if (b.child1TransitionMatrix < 0 || b.child1TransitionMatrix >= nMatrices || b.child2TransitionMatrix < 0 ||
+            b.child2TransitionMatrix >= nMatrices)
+            return fail(BEAGLE_ERROR_OUT_OF_RANGE, "beagleUpdatePartials: matrix index");
+        Walk4Op w;
+        w.dst = b.destinationPartials;
+        w.c1 = b.child1Partials; w.c2 = b.child2Partials;
+        w.m1 = b.child1TransitionMatrix; w.m2 = b.child2TransitionMatrix;
+        const int ci[2] = {w.c1, w.c2};
+        uint8_t tip[2];
+        for (int c = 0; c < 2; ++c) {
+            tip[c] = (tipStates[ci[c]] && !written[ci[c]]) ? 1 : 0;
+            if (!tip[c] && !valid[ci[c]] && !written[ci[c]])
+                return fail(BEAGLE_ERROR_OUT_OF_RANGE, "beagleUpdatePartials: child buffer was never written");
         }
-        int counter = 0;
-        std::vector<std::pair<int, int>>& stack = ws.stack;   // (op, state)
-        stack.clear();
-        for (int root = n - 1; root >= 0; --root) {
-            if (!consumers[root].empty()) continue;
-            stack.emplace_back(root, 0);
-            while (!stack.empty()) {
-                auto [o, st] = stack.back();
-                stack.pop_back();
-                if (st == 1) { prio[o] = counter++; continue; }
-                stack.emplace_back(o, 1);
-                int a = prod1[o], b = (prod2[o] != prod1[o]) ? prod2[o] : -1;
-                if (a >= 0 && b >= 0 && need[b] > need[a]) std::swap(a, b);
-                if (b >= 0) stack.emplace_back(b, 0);     // pushed first = visited second
-                if (a >= 0) stack.emplace_back(a, 0);
-            }
+        w.tip1 = tip[0]; w.tip2 = tip[1];
+        w.scaleWrite = w.scaleRead = -1;
+        if (b.destinationScaleWrite != BEAGLE_OP_NONE) {
+            if (b.destinationScaleWrite < 0 || b.destinationScaleWrite >= nScale)
+                return fail(BEAGLE_ERROR_OUT_OF_RANGE, "beagleUpdatePartials: scale write index");
+            w.scaleWrite = b.destinationScaleWrite;
+        } else if (b.destinationScaleRead != BEAGLE_OP_NONE) {
+            if (b.destinationScaleRead < 0 || b.destinationScaleRead >= nScale)
+                return fail(BEAGLE_ERROR_OUT_OF_RANGE, "beagleUpdatePartials: scale read index");
+            if (scaleState[b.destinationScaleRead] == 2 && !segScale[b.destinationScaleRead])
+                return fail(BEAGLE_ERROR_NO_IMPLEMENTATION, "beagleUpdatePartials: destinationScaleRead names a cumulative buffer");
+            w.scaleRead = b.destinationScaleRead;
         }
-    } else {
-        for (int o = 0; o < n; ++o) prio[o] = o;
-    }
-    auto nextUse = [&](int o) {                           // list position of the earliest unscheduled consumer
-        int best = 1 << 30;
-        for (int q : consumers[o]) best = std::min(best, prio[q]);   // (scheduled consumers are removed as they are placed)
-        return best;
-    };
-
-    std::vector<int>&stepOf = ws.stepOf, &slotOf = ws.slotOf, &slotHolder = ws.slotHolder, &slotFreeFrom = ws.slotFreeFrom;
-    stepOf.assign(n, -1);
-    slotOf.assign(n, -1);
-    slotHolder.assign(maxSlots, -1);
-    slotFreeFrom.assign(maxSlots, -1);
-    std::vector<int>& ready = ws.ready;
-    ready.clear();
-    for (int o = 0; o < n; ++o) if (indeg[o] == 0) ready.push_back(o);
-    int done = 0;
-
-    for (int s = 0; done < n; ++s) {
-        if (s > 4 * n + 16) return fail(BEAGLE_ERROR_GENERAL, "tree-walk scheduler made no progress");
-        std::sort(ready.begin(), ready.end(), [&](int x, int y) { return prio[x] < prio[y]; });
-        int live = 0;
-        for (int t = 0; t < maxSlots; ++t) live += slotHolder[t] >= 0;
-        if (!inOrder && live + 2 * W > maxSlots)            // under LDS pressure prefer operations that retire values
-            std::stable_sort(ready.begin(), ready.end(), [&](int x, int y) {
-                const int rx = (prod1[x] >= 0 && slotOf[prod1[x]] >= 0) + (prod2[x] >= 0 && slotOf[prod2[x]] >= 0);
-                const int ry = (prod1[y] >= 0 && slotOf[prod1[y]] >= 0) + (prod2[y] >= 0 && slotOf[prod2[y]] >= 0);
-                return rx > ry;
-            });
-        std::vector<int>& chosen = ws.chosen;
-        chosen.clear();
-        std::vector<char>& readThisStep = ws.readThisStep;  // values read by operations already placed in this step
-        readThisStep.assign(n, 0);
-        bool needDrain = false;
-        // pass 0 places what fits without evicting anything; only a step that would stay empty may evict
-        // (a re-read from HBM costs a store drain and a synchronous copy by the loader -- far more than a bubble)
-        for (int pass = 0; pass < 2; ++pass) {
-        if (pass == 1 && !chosen.empty()) break;
-        const bool mayEvict = pass == 1;
-        for (size_t ri = 0; ri < ready.size() && (int) chosen.size() < W; ++ri) {
-            const int o = ready[ri];
-            if (inOrder && o != (int) (done + chosen.size())) break;
-            PartialsOp d = dev[o];
-            const int pr[2] = {prod1[o], prod2[o]};
-            uint8_t* kind[2] = {&d.c1_kind, &d.c2_kind};
-            uint8_t* slot[2] = {&d.c1_slot, &d.c2_slot};
-            bool ok = true, reload = false;
-            struct Small { int v[4]; int n = 0; void push_back(int x) { v[n++] = x; } bool has(int x) const { for (int i = 0; i < n; ++i) if (v[i] == x) return true; return false; }
-                           bool empty() const { return n == 0; } int back() const { return v[n - 1]; } void pop_back() { --n; } };
-            Small taken;                                    // slots claimed by this operation so far (rolled back on failure)
-            auto claimFree = [&](int fromStep) {            // a slot nobody uses from `fromStep` on
-                for (int t = 0; t < maxSlots; ++t)
-                    if (slotHolder[t] < 0 && slotFreeFrom[t] <= fromStep && !taken.has(t))
-                        return t;
-                return -1;
-            };
-            auto evict = [&](int fromStep) {                // farthest next use among values idle since `fromStep`
-                int far = -1, farUse = -1;
-                for (int t = 0; t < maxSlots; ++t) {
-                    const int h = slotHolder[t];
-                    if (h < 0 || stepOf[h] >= fromStep || readThisStep[h] || h == pr[0] || h == pr[1]) continue;
-                    if (taken.has(t)) continue;
-                    const int u = nextUse(h);
-                    if (u > farUse) { farUse = u; far = t; }
-                }
-                return far;
-            };
-            std::pair<int, int> evicted[4];                 // (slot, value) evicted for this operation
-            int nEvicted = 0;
-            std::pair<int, PartialsOp> loadsHere[2];        // (step, LOAD entry) claimed by this operation
-            int nLoadsHere = 0;
-            for (int t = 0; t < 2 && ok; ++t) {
-                if (*kind[t] == CHILD_STATES) continue;
-                if (pr[t] >= 0 && slotOf[pr[t]] >= 0) { *kind[t] = CHILD_LDS; *slot[t] = (uint8_t) slotOf[pr[t]]; continue; }
-                if (t == 1 && *kind[0] != CHILD_STATES && *kind[0] != CHILD_LDS && c2Idx[o] == c1Idx[o]) {
-                    *kind[1] = *kind[0]; *slot[1] = *slot[0]; continue;       // same buffer twice: one copy serves both
-                }
-                if (pr[t] >= 0) {                                            // evicted value: re-read from HBM
-                    if (stepOf[pr[t]] > s - 2) { ok = false; break; }        // its store is not drained yet
-                    *kind[t] = CHILD_RELOAD;
-                    reload = true;
-                } else {
-                    *kind[t] = CHILD_PARTIALS;
-                }
-                // the loader copies it in during step s-1: the slot must be unused from step s-1 on
-                int sl = claimFree(s - 1);
-                if (sl >= 0 && pr[t] < 0 && s >= 1 && !noIdleLoads) {
-                    // a buffer this list does not write: let an idle compute wave of an earlier step fetch it
-                    // (latest step with a free wave, not before the slot is idle)
-                    for (int q = s - 1; q >= std::max(slotFreeFrom[sl], 0); --q) {
-                        int claimed = 0;
-                        for (int li = 0; li < nLoadsHere; ++li) claimed += loadsHere[li].first == q;
-                        if ((int) (steps[q].size() + stepLoads[q].size()) + claimed >= W) continue;
-                        loadsHere[nLoadsHere++] = std::make_pair(q, makeLoad(d, t, sl, o));
-                        *kind[t] = CHILD_LDS;                 // by step s it is an ordinary slot
-                        break;
-                    }
-                }
-                if (sl < 0 && mayEvict) {
-                    // (a value evicted now was last touched before step s-1, so nobody reads it in s-1)
-                    const int ev = evict(s - 1);
-                    if (ev >= 0) { evicted[nEvicted++] = std::make_pair(ev, slotHolder[ev]); sl = ev; }
-                }
-                if (sl < 0) { ok = false; break; }
-                taken.push_back(sl);
-                *slot[t] = (uint8_t) sl;
-            }
-            // ---- destination slot (only if somebody in this list reads the result)
-            int dsl = -1;
-            if (ok && pendingReads[o] > 0) {
-                auto lastReaderIsMe = [&](int producer) {     // o is the only remaining consumer, nobody else reads it now
-                    return producer >= 0 && pendingReads[producer] == 1 && !readThisStep[producer];
-                };
-                dsl = claimFree(s);
-                if (dsl < 0 && d.c1_kind == CHILD_LDS && lastReaderIsMe(pr[0])) dsl = d.c1_slot;
-                if (dsl < 0 && d.c2_kind == CHILD_LDS && pr[1] != pr[0] && lastReaderIsMe(pr[1])) dsl = d.c2_slot;
-                if (dsl < 0 && mayEvict) {
-                    const int ev = evict(s);
-                    if (ev >= 0) { evicted[nEvicted++] = std::make_pair(ev, slotHolder[ev]); dsl = ev; }
-                }
-                if (dsl < 0 && !taken.empty()) {              // take over one of its own staging slots
-                    dsl = taken.back();
-                    taken.pop_back();
-                }
-                if (dsl < 0) ok = false;
-            }
-            if (!ok) continue;                                // not in this step
-            // ---- commit
-            for (int ei = 0; ei < nEvicted; ++ei) { slotOf[evicted[ei].second] = -1; slotHolder[evicted[ei].first] = -1; }
-            for (int li = 0; li < nLoadsHere; ++li) stepLoads[loadsHere[li].first].push_back(loadsHere[li].second);
-            for (int ti = 0; ti < taken.n; ++ti) { const int sl = taken.v[ti]; slotHolder[sl] = -1; slotFreeFrom[sl] = s + 1; slotsUsed = std::max(slotsUsed, sl + 1); }
-            for (int t = 0; t < 2; ++t) {
-                if (pr[t] < 0 || (t == 1 && pr[1] == pr[0])) continue;
-                readThisStep[pr[t]] = 1;
-                auto& cs = consumers[pr[t]];
-                cs.erase(std::find(cs.begin(), cs.end(), o));
-                if (--pendingReads[pr[t]] == 0 && slotOf[pr[t]] >= 0) {
-                    const int ps = slotOf[pr[t]];             // last consumer: free from the next step on (or taken over below)
-                    slotHolder[ps] = -1;
-                    slotFreeFrom[ps] = s + 1;
-                    slotOf[pr[t]] = -1;
-                }
-            }
-            d.dst_slot = MBAMD_NO_SLOT;
-            if (dsl >= 0) {
-                d.dst_slot = (uint8_t) dsl;
-                slotHolder[dsl] = o;
-                slotOf[o] = dsl;
-                slotsUsed = std::max(slotsUsed, dsl + 1);
-            }
-            d.flags = 0;
-            if (d.scale_mode == SCALE_NONE) d.scale = scratchScale;
-            dev[o] = d;
-            stepOf[o] = s;
-            needDrain |= reload;
-            chosen.push_back(o);
+        // hazards that the in-launch dependency analysis does not cover end the segment (MrBayes never produces them):
+        // a buffer written twice or written after it was read, an exponent buffer touched twice unless only read
+        bool hazard = segWritten[w.dst] || segRead[w.dst];
+        if (w.scaleWrite >= 0 && segScale[w.scaleWrite]) hazard = true;
+        if (w.scaleRead >= 0 && segScale[w.scaleRead] == 2) hazard = true;
+        if (hazard) {
+            int rc = flushSegment();
+            if (rc) return rc;
         }
-        }
-        for (int o : chosen) ready.erase(std::find(ready.begin(), ready.end(), o));
-        if ((int) steps.size() <= nstepsBuilt) { steps.emplace_back(); stepLoads.emplace_back(); }
-        steps[nstepsBuilt] = chosen;
-        stepLoads[nstepsBuilt].clear();               // (filled by operations of later steps)
-        ++nstepsBuilt;
-        drainBefore.push_back(needDrain ? 1 : 0);
-        done += (int) chosen.size();
-        for (int o : chosen)
-            for (int q = o + 1; q < n; ++q)
-                if ((prod1[q] == o || prod2[q] == o) && --indeg[q] == 0) ready.push_back(q);
+        segWritten[w.dst] = 1;
+        if (!tip[0]) segRead[w.c1] = 1;
+        if (!tip[1]) segRead[w.c2] = 1;
+        if (w.scaleWrite >= 0) segScale[w.scaleWrite] = 2;
+        if (w.scaleRead >= 0 && !segScale[w.scaleRead]) segScale[w.scaleRead] = 1;
+        written[w.dst] = 1;
+        seg.push_back(w);
     }
-    // ---- remember the schedule under its structural key
-    if (schedules.size() >= 8192) schedules.clear();
-    WalkSchedule& rec = schedules[shash];
-    rec.key = skey;
-    rec.nsteps = nstepsBuilt;
-    rec.slotsUsed = slotsUsed;
-    rec.opFields.resize((size_t) n * 5);
-    for (int o = 0; o < n; ++o) {
-        uint8_t* f = &rec.opFields[(size_t) o * 5];
-        f[0] = dev[o].c1_kind; f[1] = dev[o].c2_kind; f[2] = dev[o].c1_slot; f[3] = dev[o].c2_slot; f[4] = dev[o].dst_slot;
-    }
-    rec.stepStart.assign(1, 0);
-    rec.stepOps.clear();
-    rec.loadStart.assign(1, 0);
-    rec.loadOps.clear();
-    for (int q = 0; q < nstepsBuilt; ++q) {
-        rec.stepOps.insert(rec.stepOps.end(), steps[q].begin(), steps[q].end());
-        rec.stepStart.push_back((int) rec.stepOps.size());
-        for (const PartialsOp& ld : stepLoads[q]) {
-            rec.loadOps.push_back(ld.pad2_[0]);
-            rec.loadOps.push_back(ld.pad2_[1]);
-            rec.loadOps.push_back(ld.dst_slot);
-        }
-        rec.loadStart.push_back((int) rec.loadOps.size() / 3);
-    }
-    rec.drainBefore.assign(drainBefore.begin(), drainBefore.end());
-    }
-    const int nsteps = nstepsBuilt;
-
-    // ---- device table [nsteps + 4][W] -----------------------------------------------------------------
-    // (+4 empty rows: the loader reads that far ahead; empty entries carry valid dummy pointers because
-    //  the loader fetches through every pointer of a row without looking at `dst`)
-    std::vector<PartialsOp>& table = ws.table;
-    table.resize((size_t) (nsteps + 4) * W);
-    std::memset(table.data(), 0, table.size() * sizeof(PartialsOp));
-    for (int s = 0; s < nsteps + 4; ++s) {
-        uint8_t fl = (s + 2 < nsteps && drainBefore[s + 2]) ? MBAMD_OP_DRAIN : 0;
-        if (s < nsteps)
-            for (int o : steps[s]) {
-                const PartialsOp& d = dev[o];
-                if (d.scale_mode == SCALE_READ) fl |= MBAMD_OP_HAS_READ;
-                if (d.c1_kind == CHILD_PARTIALS || d.c1_kind == CHILD_RELOAD || d.c2_kind == CHILD_PARTIALS ||
-                    d.c2_kind == CHILD_RELOAD)
-                    fl |= MBAMD_OP_HAS_GLOBAL;
-            }
-        for (int w = 0; w < W; ++w) {
-            PartialsOp& e = table[(size_t) s * W + w];
-            if (s < nsteps && w < (int) steps[s].size()) {
-                e = dev[steps[s][w]];
-            } else if (s < nsteps && w < (int) (steps[s].size() + stepLoads[s].size())) {
-                e = stepLoads[s][w - steps[s].size()];
-            } else {
-                e.c1_slot = e.c2_slot = e.dst_slot = MBAMD_NO_SLOT;
-                e.c1_kind = e.c2_kind = CHILD_STATES;
-                e.c1 = e.c2 = arenaTips;
-                e.m1 = e.m2 = matrices;
-                e.scale = scratchScale;
-                e.flags = 0;
-            }
-            e.flags |= fl;
+    int rc = flushSegment();
+    if (rc) return rc;
+    if (envVerbose)
+        std::fprintf(stderr, "[mbamd] walk plan: %d ops, %zu segment(s), W=%d, %d entries/wave, %d slots/wave, %d phases, %d reloads, %d external children\n",
+                     n, plan.segments.size(), lastWalkW, lastWalkEntries, lastWalkSlots, phases, reloads, externals);
+    // upload the programs into the plan's device buffer
+    const size_t bytes = w4table.size() * sizeof(Walk4Entry);
+    const bool inFlight = plan.lastLaunch > syncedClock;
+    if (bytes > plan.cap || inFlight) {
+        if (inFlight) { HIP_TRY(hipStreamSynchronize(stream)); syncedClock = launchClock; }
+        if (bytes > plan.cap) {
+            if (plan.d_table) HIP_TRY(hipFree(plan.d_table));
+            plan.d_table = nullptr;
+            plan.cap = 0;
+            HIP_TRY(hipMalloc(&plan.d_table, bytes + bytes / 2));
+            plan.cap = bytes + bytes / 2;
         }
     }
-    if (envVerbose) {
-        int reloads = 0, globals = 0, drains = 0;
-        for (int o = 0; o < n; ++o) {
-            reloads += (dev[o].c1_kind == CHILD_RELOAD) + (dev[o].c2_kind == CHILD_RELOAD);
-            globals += (dev[o].c1_kind == CHILD_PARTIALS) + (dev[o].c2_kind == CHILD_PARTIALS);
-        }
-        for (char d : drainBefore) drains += d;
-        std::fprintf(stderr, "[mbamd] walk plan: %d ops, W=%d, %d steps, %d slots (max %d), %d reloads, %d global children, %d drains\n",
-                     n, W, nsteps, slotsUsed, maxSlots, reloads, globals, drains);
-    }
-    lastWalkSteps = nsteps;
-    lastWalkSlots = slotsUsed;
-    plan.nsteps = nsteps;
-    plan.W = W;
-    plan.slotsUsed = slotsUsed;
-    return planTable(plan, table);
+    return upload(plan.d_table, w4table.data(), bytes);
 }
 
 int Instance::runWalk(const Plan& plan, int32_t* cum)
 {
-    const int W = plan.W, nsteps = plan.nsteps;
-    const size_t lds = (size_t) walk_lds_units(K, W, std::max(1, plan.slotsUsed)) * 16;
-    const unsigned grid = (unsigned) (Ppad / 64);
-#if defined(MBAMD_HOST_EMU)
-    const int walkThreads = 64;
-    const int walkArgW = envReverseStep ? -W : W;
-    const int ksplit = 1;
-#else
-    // two waves per table entry (category split) when K is even and the workgroup stays within 8 waves
-    const int ksplit = (walkKSplit && K % 2 == 0 && 2 * W + 1 <= 8) ? 2 : 1;
-    const int walkThreads = (W * ksplit + 1) * 64, walkArgW = W;      // compute waves + the loader wave
-#endif
-    switch (K) {
-#define MBAMD_WALK_CASE(KK) \
-    case KK: MBAMD_LAUNCH(k_walk_s4<KK>, grid, walkThreads, lds, stream, (const PartialsOp*) plan.d_table, nsteps, walkArgW, std::max(1, plan.slotsUsed), ksplit, geom, cum, d_trace); break;
-        MBAMD_WALK_CASE(1) MBAMD_WALK_CASE(2) MBAMD_WALK_CASE(3) MBAMD_WALK_CASE(4)
-        MBAMD_WALK_CASE(5) MBAMD_WALK_CASE(6) MBAMD_WALK_CASE(7) MBAMD_WALK_CASE(8)
-#undef MBAMD_WALK_CASE
-        default: return fail(BEAGLE_ERROR_NO_IMPLEMENTATION, "tree-walk kernel: category count");
+    for (const Plan::Segment& sg : plan.segments) {
+        Walk4Args a;
+        a.prog = reinterpret_cast<const Walk4Entry*>(plan.d_table) + sg.first;
+        a.entries = sg.entries;
+        a.nslots = sg.nslots;
+        a.partials = reinterpret_cast<f4*>(arenaPartials);
+        a.pstride = geom.pstride;
+        a.tips = arenaTips;
+        a.tstride = geom.tstride;
+        a.exps = arenaExp;
+        a.estride = estride;
+        a.matrices = matrices;
+        a.cum = cum;
+        a.K = K;
+        a.Ppad = Ppad;
+        MBAMD_LAUNCH_BARRIER(k_walk4, dim3((unsigned) (Ppad / 64), (unsigned) K), 64 * sg.W, walk4_lds_bytes(sg.W, sg.nslots), stream, a);
+        HIP_TRY(hipGetLastError());
+        pendingLaunches += 1;
     }
-    HIP_TRY(hipGetLastError());
-    pendingLaunches += 1;
     return BEAGLE_SUCCESS;
 }
 
@@ -1816,7 +1655,35 @@ int Instance::accumulate(const int* idx, int n, int cumIdx, int sign)
     rc = stageDirect(ptrs.data(), sizeof(void*) * n, (const void**) &dptrs);
     if (rc) return rc;
     MBAMD_LAUNCH(k_scale_accumulate, (unsigned) ((Ppad + 255) / 256), 256, 0, stream, dptrs, n, sign,
-                 Ppad, geom.sstride, scale[cumIdx]);
+                 Ppad, scale[cumIdx]);
+    HIP_TRY(hipGetLastError());
+    return BEAGLE_SUCCESS;
+}
+
+// 4-state path: sources are node-exponent buffers of the arena (int8 per pattern and category) or cumulative ones
+int Instance::accumulate4(const int* idx, int n, int cumIdx, int sign)
+{
+    if (cumIdx < 0 || cumIdx >= nScale) return fail(BEAGLE_ERROR_OUT_OF_RANGE, "scale factors: cumulative index");
+    if (n <= 0) return BEAGLE_SUCCESS;
+    std::vector<ExpSource> src;
+    src.reserve(n);
+    for (int i = 0; i < n; ++i) {
+        if (idx[i] < 0 || idx[i] >= nScale) return fail(BEAGLE_ERROR_OUT_OF_RANGE, "scale factors: index");
+        if (scaleState[idx[i]] == 0) continue;                       // never written: zero
+        ExpSource e;
+        e.wide = scaleState[idx[i]] == 2 ? wideScale[idx[i]] : nullptr;
+        e.narrow = idx[i];
+        e.pad_ = 0;
+        src.push_back(e);
+    }
+    int rc = ensureWide(cumIdx);
+    if (rc) return rc;
+    if (src.empty()) return BEAGLE_SUCCESS;
+    const ExpSource* dsrc = nullptr;
+    rc = stageDirect(src.data(), sizeof(ExpSource) * src.size(), (const void**) &dsrc);
+    if (rc) return rc;
+    MBAMD_LAUNCH(k_exp_accumulate, (unsigned) (((size_t) K * Ppad + 255) / 256), 256, 0, stream, dsrc, (int) src.size(), sign, K, Ppad,
+                 (const int8_t*) arenaExp, estride, wideScale[cumIdx]);
     HIP_TRY(hipGetLastError());
     return BEAGLE_SUCCESS;
 }
@@ -1825,6 +1692,17 @@ int Instance::integrate(const int* parent, const int* child, const int* prob, co
                         const int* cumIdx, int count, double* out)
 {
     if (count < 1 || count > MBAMD_MAX_SUBSETS) return fail(BEAGLE_ERROR_NO_IMPLEMENTATION, "log-likelihood: subset count");
+    if (s4) {
+        int rc = integrate4(parent, child, prob, wIdx, fIdx, cumIdx, count);
+        if (rc) return rc;
+        haveSite = true;
+        pendingResult = true;
+        if (deferred) {
+            if (out) *out = 0.0;
+            return BEAGLE_SUCCESS;
+        }
+        return fetchResult(out);
+    }
     IntegrateArgs a;
     std::memset(&a, 0, sizeof a);
     a.count = count;
@@ -1854,11 +1732,11 @@ int Instance::integrate(const int* parent, const int* child, const int* prob, co
     }
     double* const siteOut = (siteToHost && h_site_dev) ? h_site_dev : d_site;
     siteOnHost = siteOut != d_site;
-    if (s4) MBAMD_LAUNCH(k_integrate_lnl<true>, (unsigned) nblocks, 64, 0, stream, a, S, SP, K, P, Ppad, geom, (const double*) d_pweights, siteOut, h_sums_dev);
 #if !defined(MBAMD_HOST_EMU)
-    else if (S >= 8) MBAMD_LAUNCH(k_integrate_lnl_wide, (unsigned) nblocks, 256, 0, stream, a, S, SP, K, P, Ppad, (const double*) d_pweights, siteOut, h_sums_dev);
+    if (S >= 8) MBAMD_LAUNCH(k_integrate_lnl_wide, (unsigned) nblocks, 256, 0, stream, a, S, SP, K, P, Ppad, (const double*) d_pweights, siteOut, h_sums_dev);
+    else
 #endif
-    else    MBAMD_LAUNCH(k_integrate_lnl<false>, (unsigned) nblocks, 64, 0, stream, a, S, SP, K, P, Ppad, geom, (const double*) d_pweights, siteOut, h_sums_dev);
+        MBAMD_LAUNCH(k_integrate_lnl, (unsigned) nblocks, 64, 0, stream, a, S, SP, K, P, Ppad, (const double*) d_pweights, siteOut, h_sums_dev);
     HIP_TRY(hipGetLastError());
     haveSite = true;
     pendingResult = true;
@@ -1867,6 +1745,45 @@ int Instance::integrate(const int* parent, const int* child, const int* prob, co
         return BEAGLE_SUCCESS;
     }
     return fetchResult(out);
+}
+
+int Instance::integrate4(const int* parent, const int* child, const int* prob, const int* wIdx, const int* fIdx,
+                         const int* cumIdx, int count)
+{
+    IntegrateArgs4 a;
+    std::memset(&a, 0, sizeof a);
+    a.count = count;
+    for (int n = 0; n < count; ++n) {
+        if (parent[n] < 0 || parent[n] >= nBuffers || !valid[parent[n]] || tipStates[parent[n]])
+            return fail(BEAGLE_ERROR_OUT_OF_RANGE, "log-likelihood: parent buffer");
+        a.parent[n] = reinterpret_cast<const f4*>(partials[parent[n]]);
+        if (child) {
+            const int ci = child[n];
+            if (ci < 0 || ci >= nBuffers || prob[n] < 0 || prob[n] >= nMatrices)
+                return fail(BEAGLE_ERROR_OUT_OF_RANGE, "edge log-likelihood: child buffer / matrix");
+            if (tipStates[ci]) { a.child[n] = tipStates[ci]; a.child_kind[n] = CHILD_STATES; }
+            else if (valid[ci]) { a.child[n] = partials[ci]; a.child_kind[n] = CHILD_PARTIALS; }
+            else return fail(BEAGLE_ERROR_OUT_OF_RANGE, "edge log-likelihood: child buffer was never written");
+            a.matrix[n] = matrixPtr(prob[n]);
+        }
+        if (wIdx[n] < 0 || wIdx[n] >= nEigen || fIdx[n] < 0 || fIdx[n] >= nEigen)
+            return fail(BEAGLE_ERROR_OUT_OF_RANGE, "log-likelihood: weights / frequencies index");
+        a.weights[n] = d_weights + (size_t) wIdx[n] * K;
+        a.freqs[n] = d_freqs + (size_t) fIdx[n] * S;
+        if (cumIdx && cumIdx[n] != BEAGLE_OP_NONE) {
+            if (cumIdx[n] < 0 || cumIdx[n] >= nScale) return fail(BEAGLE_ERROR_OUT_OF_RANGE, "log-likelihood: cumulative scale index");
+            if (scaleState[cumIdx[n]] != 0) {
+                int rc = ensureWide(cumIdx[n]);
+                if (rc) return rc;
+                a.cum[n] = wideScale[cumIdx[n]];
+            }
+        }
+    }
+    double* const siteOut = (siteToHost && h_site_dev) ? h_site_dev : d_site;
+    siteOnHost = siteOut != d_site;
+    MBAMD_LAUNCH(k_integrate_lnl_s4, (unsigned) nblocks, 64, 0, stream, a, K, P, Ppad, geom, (const double*) d_pweights, siteOut, h_sums_dev);
+    HIP_TRY(hipGetLastError());
+    return BEAGLE_SUCCESS;
 }
 
 int Instance::fetchResult(double* out)
@@ -2153,12 +2070,14 @@ int beagleAccumulateScaleFactors(int instance, const int* scaleIndices, int coun
 {
     StatTimer st_(ST_SCALE);
     GET_INSTANCE(instance);
+    if (in->s4) return in->accumulate4(scaleIndices, count, cumulativeScaleIndex, +1);
     return in->accumulate(scaleIndices, count, cumulativeScaleIndex, +1);
 }
 int beagleRemoveScaleFactors(int instance, const int* scaleIndices, int count, int cumulativeScaleIndex)
 {
     StatTimer st_(ST_SCALE);
     GET_INSTANCE(instance);
+    if (in->s4) return in->accumulate4(scaleIndices, count, cumulativeScaleIndex, -1);
     return in->accumulate(scaleIndices, count, cumulativeScaleIndex, -1);
 }
 int beagleResetScaleFactors(int instance, int cumulativeScaleIndex)
@@ -2167,9 +2086,20 @@ int beagleResetScaleFactors(int instance, int cumulativeScaleIndex)
     GET_INSTANCE(instance);
     if (cumulativeScaleIndex < 0 || cumulativeScaleIndex >= in->nScale)
         return fail(BEAGLE_ERROR_OUT_OF_RANGE, "beagleResetScaleFactors: index");
+    if (in->s4) {
+        // MrBayes resets every scale buffer once at start-up (reference src/mcmc.c:6270): nothing is allocated or
+        // launched for a buffer until it is used -- "never written" reads as zero everywhere
+        if (in->scaleState[cumulativeScaleIndex] == 1) {           // node exponents in the arena: later reads must see zeros
+            MBAMD_LAUNCH(k_exp_copy, (unsigned) (((size_t) in->K * in->Ppad + 255) / 256), 256, 0, in->stream, in->arenaExp, in->estride,
+                         -1, cumulativeScaleIndex, in->K, in->Ppad);
+            HIP_TRY(hipGetLastError());
+        }
+        in->scaleState[cumulativeScaleIndex] = 0;
+        return BEAGLE_SUCCESS;
+    }
     if (!in->scale[cumulativeScaleIndex]) return in->ensureScale(cumulativeScaleIndex);   // allocated zeroed
     MBAMD_LAUNCH(k_scale_copy, (unsigned) ((in->Ppad + 255) / 256), 256, 0, in->stream, (const int32_t*) nullptr, in->Ppad,
-                 in->geom.sstride, in->scale[cumulativeScaleIndex]);
+                 in->scale[cumulativeScaleIndex]);
     HIP_TRY(hipGetLastError());
     return BEAGLE_SUCCESS;
 }
@@ -2179,30 +2109,81 @@ int beagleCopyScaleFactors(int instance, int destScalingIndex, int srcScalingInd
     GET_INSTANCE(instance);
     if (destScalingIndex < 0 || destScalingIndex >= in->nScale || srcScalingIndex < 0 || srcScalingIndex >= in->nScale)
         return fail(BEAGLE_ERROR_OUT_OF_RANGE, "beagleCopyScaleFactors: index");
+    if (in->s4) {
+        const int st = in->scaleState[srcScalingIndex];
+        if (st == 2) {
+            in->scaleState[destScalingIndex] = 0;
+            int rc4 = in->ensureWide(destScalingIndex);
+            if (rc4) return rc4;
+            HIP_TRY(hipMemcpyAsync(in->wideScale[destScalingIndex], in->wideScale[srcScalingIndex],
+                                   (size_t) in->K * in->Ppad * sizeof(int32_t), hipMemcpyDeviceToDevice, in->stream));
+        } else if (st == 1) {
+            MBAMD_LAUNCH(k_exp_copy, (unsigned) (((size_t) in->K * in->Ppad + 255) / 256), 256, 0, in->stream, in->arenaExp, in->estride,
+                         srcScalingIndex, destScalingIndex, in->K, in->Ppad);
+            HIP_TRY(hipGetLastError());
+            in->scaleState[destScalingIndex] = 1;
+        } else {
+            return beagleResetScaleFactors(instance, destScalingIndex);
+        }
+        return BEAGLE_SUCCESS;
+    }
     int rc = in->ensureScale(destScalingIndex);
     if (rc) return rc;
     rc = in->ensureScale(srcScalingIndex);
     if (rc) return rc;
     MBAMD_LAUNCH(k_scale_copy, (unsigned) ((in->Ppad + 255) / 256), 256, 0, in->stream,
-                 (const int32_t*) in->scale[srcScalingIndex], in->Ppad, in->geom.sstride, in->scale[destScalingIndex]);
+                 (const int32_t*) in->scale[srcScalingIndex], in->Ppad, in->scale[destScalingIndex]);
     HIP_TRY(hipGetLastError());
     return BEAGLE_SUCCESS;
 }
+// engine extension: the binary exponents behind a scale buffer, out[k * patternCount + c] (the general-state
+// path keeps one exponent per pattern: every category row is the same)
+int mbamdGetScaleExponents(int instance, int srcScalingIndex, int* out)
+{
+    GET_INSTANCE(instance);
+    if (srcScalingIndex < 0 || srcScalingIndex >= in->nScale) return fail(BEAGLE_ERROR_OUT_OF_RANGE, "scale exponents: index");
+    const int K = in->K, P = in->P, Ppad = in->Ppad;
+    HIP_TRY(hipStreamSynchronize(in->stream));
+    if (!in->s4) {
+        int rc = in->ensureScale(srcScalingIndex);
+        if (rc) return rc;
+        std::vector<int32_t> h(Ppad);
+        HIP_TRY(hipStreamSynchronize(in->stream));
+        HIP_TRY(hipMemcpy(h.data(), in->scale[srcScalingIndex], (size_t) Ppad * sizeof(int32_t), hipMemcpyDeviceToHost));
+        for (int k = 0; k < K; ++k) for (int c = 0; c < P; ++c) out[(size_t) k * P + c] = h[c];
+        return BEAGLE_SUCCESS;
+    }
+    const int st = in->scaleState[srcScalingIndex];
+    if (st == 0) { std::fill(out, out + (size_t) K * P, 0); return BEAGLE_SUCCESS; }
+    std::vector<int32_t> h((size_t) K * Ppad);
+    if (st == 2) {
+        HIP_TRY(hipMemcpy(h.data(), in->wideScale[srcScalingIndex], h.size() * sizeof(int32_t), hipMemcpyDeviceToHost));
+    } else {
+        int rc = in->grow(&in->d_tmp, &in->tmpCap, h.size() * sizeof(int32_t));
+        if (rc) return rc;
+        MBAMD_LAUNCH(k_exp_widen, (unsigned) ((h.size() + 255) / 256), 256, 0, in->stream, (const int8_t*) in->arenaExp, in->estride,
+                     srcScalingIndex, K, Ppad, (int32_t*) in->d_tmp);
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipStreamSynchronize(in->stream));
+        HIP_TRY(hipMemcpy(h.data(), in->d_tmp, h.size() * sizeof(int32_t), hipMemcpyDeviceToHost));
+    }
+    for (int k = 0; k < K; ++k) for (int c = 0; c < P; ++c) out[(size_t) k * P + c] = h[(size_t) k * Ppad + c];
+    return BEAGLE_SUCCESS;
+}
+// BEAGLE's scale factors are one log value per pattern.  The 4-state path keeps an exponent per (pattern, category):
+// reported here is the largest of a pattern's exponents (times ln 2), the factor a per-pattern scaler would have used.
 int beagleGetScaleFactors(int instance, int srcScalingIndex, double* outScaleFactors)
 {
     GET_INSTANCE(instance);
     if (srcScalingIndex < 0 || srcScalingIndex >= in->nScale) return fail(BEAGLE_ERROR_OUT_OF_RANGE, "beagleGetScaleFactors: index");
-    int rc = in->ensureScale(srcScalingIndex);
+    std::vector<int> e((size_t) in->K * in->P);
+    int rc = mbamdGetScaleExponents(instance, srcScalingIndex, e.data());
     if (rc) return rc;
-    std::vector<int32_t> h(in->Ppad);
-    rc = in->grow(&in->d_tmp, &in->tmpCap, (size_t) in->Ppad * sizeof(int32_t));
-    if (rc) return rc;
-    MBAMD_LAUNCH(k_gather_ints, (unsigned) ((in->Ppad + 255) / 256), 256, 0, in->stream,
-                 (const int32_t*) in->scale[srcScalingIndex], in->Ppad, in->geom.sstride, (int32_t*) in->d_tmp);
-    HIP_TRY(hipGetLastError());
-    HIP_TRY(hipStreamSynchronize(in->stream));
-    HIP_TRY(hipMemcpy(h.data(), in->d_tmp, (size_t) in->Ppad * sizeof(int32_t), hipMemcpyDeviceToHost));
-    for (int c = 0; c < in->P; ++c) outScaleFactors[c] = (double) h[c] * 0.69314718055994530942;
+    for (int c = 0; c < in->P; ++c) {
+        int m = e[c];
+        for (int k = 1; k < in->K; ++k) m = std::max(m, e[(size_t) k * in->P + c]);
+        outScaleFactors[c] = (double) m * 0.69314718055994530942;
+    }
     return BEAGLE_SUCCESS;
 }
 int beagleCalculateRootLogLikelihoods(int instance, const int* bufferIndices, const int* categoryWeightsIndices,

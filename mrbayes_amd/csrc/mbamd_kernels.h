@@ -1,7 +1,7 @@
 // mbamd_kernels.h -- hand-written HIP kernels (gfx950 / CDNA4) of the conditional-likelihood engine.
 //
 // Replaces, on the device, the reference's native loops in src/likelihood.c:
-//   k_walk_s4            CondLikeDown/Root_NUC4* + CondLikeScaler_NUC4* + RemoveNodeScalers (4-state)
+//   k_walk4              CondLikeDown/Root_NUC4* + CondLikeScaler_NUC4* + RemoveNodeScalers (4-state, mbamd_walk4.h)
 //   k_partials_gen       CondLikeDown_Gen / _NY98 (general state count), k_rescale_gen = CondLikeScaler_Gen
 //   k_transition_matrices TiProbs_Gen / TiProbs_GenCov (src/likelihood.c:9424-9700)
 //   k_integrate_lnl      Likelihood_Gen / _NY98 / _NUC4 root integration (src/likelihood.c:5764, 6975, 6238)
@@ -9,10 +9,13 @@
 //
 // Data layout in HBM (all fp32 unless noted), P_pad = patterns rounded up to 64:
 //   4-state partials   : f4 [P_pad/64][buffer][K][64]  pattern-block-major arena: one f4 = the 4 states of
-//                        (category, pattern); everything a 64-pattern workgroup ever touches (all nodes of
-//                        all chains) is one contiguous region -> a few 2 MiB pages per workgroup (TLB), 4 KiB
-//                        contiguous per node update (DRAM pages).  Tip states and scale buffers of the
-//                        4-state path use the same block-major arrangement ([P_pad/64][buffer][64]).
+//                        (category, pattern); everything the waves of a 64-pattern block ever touch (all nodes of
+//                        all chains) is one contiguous region -> a few 2 MiB pages per block (TLB), 1 KiB
+//                        contiguous per (node update, category).  4-state tips are four 64-bit STATE BITPLANES per
+//                        (pattern block, tip): uint64 [P_pad/64][buffer][4], plane i bit l = state i compatible with
+//                        pattern l of the block (missing = all four); 4-state node exponents are int8
+//                        [P_pad/64][scale buffer][K][64] (one per pattern AND category), cumulative exponents
+//                        int32 [K][P_pad] per scale buffer, allocated when a buffer is first used that way.
 //   general partials   : float  [P_pad/32][K][S][32]   tile-major (gen_index): lanes = consecutive patterns of a
 //                        32-pattern tile -> coalesced; a tile of one buffer is one contiguous K*S*128-byte run
 //   matrices           : float  [K][SP][SP] transposed (mT[k][j][i] = P_k(i->j)), zero padded to SP
@@ -28,8 +31,11 @@
 // arithmetic; ln(scale) = e*ln2 is formed in fp64 only at the root.  One v_frexp_exp + v_ldexp
 // per value, no logf, no division.
 //
-// The kernels use no cross-lane operations and no __syncthreads, so the same source also builds
-// against tests/hostemu/hip_emu.h for CPU-only CI of the host logic (never part of the product).
+// 4-state path: the exponent is per (pattern, category) -- columns of different categories never meet before the
+// root, where k_integrate_lnl_s4 recombines them exactly (see mbamd_walk4.h).
+//
+// The kernels in this file use no cross-lane operations, so the same source also builds against
+// tests/hostemu/hip_emu.h for CPU-only CI of the host logic (never part of the product).
 #ifndef MBAMD_KERNELS_H_
 #define MBAMD_KERNELS_H_
 
@@ -68,7 +74,7 @@ template <class T> __device__ __forceinline__ const MBAMD_AS_CONST T* as_const(c
 // The general-state path keeps linear [P_pad] arrays, which is the same formula with stride 64.
 struct BlockGeom {
     unsigned long pstride;     // f4 elements between the blocks of a partials buffer
-    unsigned tstride;          // bytes between the blocks of a tip-state buffer
+    unsigned tstride;          // uint64 elements between the blocks of the tip bitplanes
     unsigned sstride;          // int32 elements between the blocks of a scale buffer
 };
 __host__ __device__ inline size_t blk_index(int c, size_t stride) { return (size_t) (c >> 6) * stride + (size_t) (c & 63); }
@@ -138,72 +144,8 @@ __device__ __forceinline__ float scale_pow2(float v, int neg_e)
 
 __device__ __forceinline__ float max4(f4 v) { return fmaxf(fmaxf(v.x, v.y), fmaxf(v.z, v.w)); }
 
-// 4x4 transition matrix times the 4 states of one (category, pattern).  The matrix is stored
-// transposed, mT[j][i] = P(i->j); it is wave-uniform data.  On the GPU each lane fetches only the
-// 16-byte row (lane & 3) of mT -- one dwordx4 load per matrix, four distinct addresses per wave --
-// and element (i, j) reaches every lane through a DPP quad broadcast from quad-lane j: a 4x4 matrix
-// costs 4 VGPRs and one vector load instead of 16 scalar registers, so all 2K matrices of an
-// operation are requested in one batch (one L2 round trip) and the scalar-register file no longer
-// limits how many are in flight.
-struct Mat4 {
-#if defined(MBAMD_HOST_EMU)
-    const float* m;
-#else
-    f4 col;       // (P(0->j), P(1->j), P(2->j), P(3->j)) with j = lane & 3
-#endif
-};
-__device__ __forceinline__ Mat4 mat4_load(const float* mT, int lane)
-{
-    Mat4 r;
-#if defined(MBAMD_HOST_EMU)
-    (void) lane;
-    r.m = mT;
-#else
-    r.col = as_global(reinterpret_cast<const f4*>(mT))[lane & 3];
-#endif
-    return r;
-}
-__device__ __forceinline__ f4 mat4_mul(const Mat4& M, f4 v)
-{
-    f4 r;
-#if defined(MBAMD_HOST_EMU)
-    const float* m = M.m;
-    r.x = fmaf(m[12], v.w, fmaf(m[8], v.z, fmaf(m[4], v.y, m[0] * v.x)));
-    r.y = fmaf(m[13], v.w, fmaf(m[9], v.z, fmaf(m[5], v.y, m[1] * v.x)));
-    r.z = fmaf(m[14], v.w, fmaf(m[10], v.z, fmaf(m[6], v.y, m[2] * v.x)));
-    r.w = fmaf(m[15], v.w, fmaf(m[11], v.z, fmaf(m[7], v.y, m[3] * v.x)));
-#else
-    // r_i = fma(P(i->3), v.w, fma(P(i->2), v.z, fma(P(i->1), v.y, P(i->0) * v.x))), P(i->j) read from
-    // quad-lane j of M.col[i] by the DPP source modifier of v_mul/v_fmac (no broadcast temporaries).
-    // The DPP operands come from ds_read/global loads; the leading s_nop covers the 2 wait states a
-    // compiler-inserted VALU copy of them would need before a DPP read.
-    float rx, ry, rz, rw;
-    asm("s_nop 1\n\t"
-        "v_mul_f32_dpp %0, %4, %8 quad_perm:[0,0,0,0] row_mask:0xf bank_mask:0xf\n\t"
-        "v_mul_f32_dpp %1, %5, %8 quad_perm:[0,0,0,0] row_mask:0xf bank_mask:0xf\n\t"
-        "v_mul_f32_dpp %2, %6, %8 quad_perm:[0,0,0,0] row_mask:0xf bank_mask:0xf\n\t"
-        "v_mul_f32_dpp %3, %7, %8 quad_perm:[0,0,0,0] row_mask:0xf bank_mask:0xf\n\t"
-        "v_fmac_f32_dpp %0, %4, %9 quad_perm:[1,1,1,1] row_mask:0xf bank_mask:0xf\n\t"
-        "v_fmac_f32_dpp %1, %5, %9 quad_perm:[1,1,1,1] row_mask:0xf bank_mask:0xf\n\t"
-        "v_fmac_f32_dpp %2, %6, %9 quad_perm:[1,1,1,1] row_mask:0xf bank_mask:0xf\n\t"
-        "v_fmac_f32_dpp %3, %7, %9 quad_perm:[1,1,1,1] row_mask:0xf bank_mask:0xf\n\t"
-        "v_fmac_f32_dpp %0, %4, %10 quad_perm:[2,2,2,2] row_mask:0xf bank_mask:0xf\n\t"
-        "v_fmac_f32_dpp %1, %5, %10 quad_perm:[2,2,2,2] row_mask:0xf bank_mask:0xf\n\t"
-        "v_fmac_f32_dpp %2, %6, %10 quad_perm:[2,2,2,2] row_mask:0xf bank_mask:0xf\n\t"
-        "v_fmac_f32_dpp %3, %7, %10 quad_perm:[2,2,2,2] row_mask:0xf bank_mask:0xf\n\t"
-        "v_fmac_f32_dpp %0, %4, %11 quad_perm:[3,3,3,3] row_mask:0xf bank_mask:0xf\n\t"
-        "v_fmac_f32_dpp %1, %5, %11 quad_perm:[3,3,3,3] row_mask:0xf bank_mask:0xf\n\t"
-        "v_fmac_f32_dpp %2, %6, %11 quad_perm:[3,3,3,3] row_mask:0xf bank_mask:0xf\n\t"
-        "v_fmac_f32_dpp %3, %7, %11 quad_perm:[3,3,3,3] row_mask:0xf bank_mask:0xf"
-        : "=&v"(rx), "=&v"(ry), "=&v"(rz), "=&v"(rw)
-        : "v"(M.col.x), "v"(M.col.y), "v"(M.col.z), "v"(M.col.w), "v"(v.x), "v"(v.y), "v"(v.z), "v"(v.w));
-    r.x = rx; r.y = ry; r.z = rz; r.w = rw;
-#endif
-    return r;
-}
-
 }  // namespace mbamd
-#include "mbamd_walk_s4.h"
+#include "mbamd_walk4.h"
 namespace mbamd {
 
 // ---------------------------------------------------------------------------------------------
@@ -427,20 +369,11 @@ struct IntegrateArgs {
     int            count;
 };
 
-template <bool S4>
-__device__ __forceinline__ float part_at(const float* p, int S, int K, size_t pstride, int k, int c, int i)
-{
-    return S4 ? p[(blk_index(c, pstride) + (size_t) k * 64) * 4 + i] : p[gen_index(K, S, k, i, c)];
-}
-template <bool S4>
-__device__ __forceinline__ float mat_at(const float* m, int SP, int k, int i, int j)
-{
-    return S4 ? m[k * 16 + j * 4 + i] : m[(size_t) k * SP * SP + (size_t) j * SP + i];
-}
+__device__ __forceinline__ float part_at(const float* p, int S, int K, int k, int c, int i) { return p[gen_index(K, S, k, i, c)]; }
+__device__ __forceinline__ float mat_at(const float* m, int SP, int k, int i, int j) { return m[(size_t) k * SP * SP + (size_t) j * SP + i]; }
 
-template <bool S4>
 __global__ void __launch_bounds__(64)
-k_integrate_lnl(IntegrateArgs a, int S, int SP, int K, int P, int Ppad, BlockGeom g,
+k_integrate_lnl(IntegrateArgs a, int S, int SP, int K, int P, int Ppad,
                 const double* __restrict__ pattern_weights, double* __restrict__ site, double* __restrict__ wsite)
 {
     const int c = blockIdx.x * 64 + threadIdx.x;
@@ -448,7 +381,7 @@ k_integrate_lnl(IntegrateArgs a, int S, int SP, int K, int P, int Ppad, BlockGeo
     if (c < P) {
     int emax = -2147483647;
     for (int n = 0; n < a.count; ++n) {
-        const int e = a.cum[n] ? a.cum[n][blk_index(c, g.sstride)] : 0;
+        const int e = a.cum[n] ? a.cum[n][c] : 0;
         emax = e > emax ? e : emax;
     }
     double total = 0.0;
@@ -457,25 +390,25 @@ k_integrate_lnl(IntegrateArgs a, int S, int SP, int K, int P, int Ppad, BlockGeo
         for (int k = 0; k < K; ++k) {
             double cat = 0.0;
             if (a.child[n] == nullptr) {
-                for (int i = 0; i < S; ++i) cat += (double) part_at<S4>(a.parent[n], S, K, g.pstride, k, c, i) * a.freqs[n][i];
+                for (int i = 0; i < S; ++i) cat += (double) part_at(a.parent[n], S, K, k, c, i) * a.freqs[n][i];
             } else if (a.child_kind[n] == CHILD_STATES) {
-                const unsigned s = reinterpret_cast<const uint8_t*>(a.child[n])[blk_index(c, g.tstride)];
+                const unsigned s = reinterpret_cast<const uint8_t*>(a.child[n])[c];
                 for (int i = 0; i < S; ++i) {
-                    const float pc = (s >= (unsigned) S) ? 1.0f : mat_at<S4>(a.matrix[n], SP, k, i, (int) s);
-                    cat += (double) (part_at<S4>(a.parent[n], S, K, g.pstride, k, c, i) * pc) * a.freqs[n][i];
+                    const float pc = (s >= (unsigned) S) ? 1.0f : mat_at(a.matrix[n], SP, k, i, (int) s);
+                    cat += (double) (part_at(a.parent[n], S, K, k, c, i) * pc) * a.freqs[n][i];
                 }
             } else {
                 const float* ch = reinterpret_cast<const float*>(a.child[n]);
                 for (int i = 0; i < S; ++i) {
                     float acc = 0.0f;
                     for (int j = 0; j < S; ++j)
-                        acc = fmaf(mat_at<S4>(a.matrix[n], SP, k, i, j), part_at<S4>(ch, S, K, g.pstride, k, c, j), acc);
-                    cat += (double) (part_at<S4>(a.parent[n], S, K, g.pstride, k, c, i) * acc) * a.freqs[n][i];
+                        acc = fmaf(mat_at(a.matrix[n], SP, k, i, j), part_at(ch, S, K, k, c, j), acc);
+                    cat += (double) (part_at(a.parent[n], S, K, k, c, i) * acc) * a.freqs[n][i];
                 }
             }
             like += cat * a.weights[n][k];
         }
-        const int e = a.cum[n] ? a.cum[n][blk_index(c, g.sstride)] : 0;
+        const int e = a.cum[n] ? a.cum[n][c] : 0;
         total += ldexp(like, e - emax);
     }
     const double lnl = log(total) + (double) emax * 0.69314718055994530942;
@@ -496,43 +429,134 @@ k_integrate_lnl(IntegrateArgs a, int S, int SP, int K, int P, int Ppad, BlockGeo
 #endif
 }
 
+// 4-state root / edge integration (Likelihood_NUC4, src/likelihood.c:6238-6366; edge form as above).  One thread per
+// pattern; the cumulative exponent is per (pattern, category):
+//   lnL_c = log( sum_n sum_k w_nk 2^(E_nkc - Emax_c) sum_i pi_ni parent_n[k,c,i] f_n[k,c,i] ) + Emax_c ln2
+// with f = 1 (root form), the matrix column of the tip's state mask (compact tip: sum over compatible states), or the
+// matrix-vector product with the child's partials.
+struct IntegrateArgs4 {
+    const f4*      parent[MBAMD_MAX_SUBSETS];
+    const void*    child[MBAMD_MAX_SUBSETS];      // nullptr: root integration
+    const float*   matrix[MBAMD_MAX_SUBSETS];     // [K][4][4] transposed
+    const double*  weights[MBAMD_MAX_SUBSETS];
+    const double*  freqs[MBAMD_MAX_SUBSETS];
+    const int32_t* cum[MBAMD_MAX_SUBSETS];        // wide cumulative exponents [K][Ppad] or nullptr
+    uint8_t        child_kind[MBAMD_MAX_SUBSETS];
+    int            count;
+};
+__global__ void __launch_bounds__(64)
+k_integrate_lnl_s4(IntegrateArgs4 a, int K, int P, int Ppad, BlockGeom g,
+                   const double* __restrict__ pattern_weights, double* __restrict__ site, double* __restrict__ wsite)
+{
+    const int c = blockIdx.x * 64 + threadIdx.x;
+    const size_t pb = (size_t) blockIdx.x * g.pstride + threadIdx.x;           // f4 index of (block, category 0, lane)
+    double wl = 0.0;
+    if (c < P) {
+        int emax = -2147483647;
+        for (int n = 0; n < a.count; ++n)
+            for (int k = 0; k < K; ++k) {
+                const int e = a.cum[n] ? a.cum[n][(size_t) k * Ppad + c] : 0;
+                emax = e > emax ? e : emax;
+            }
+        double total = 0.0;
+        for (int n = 0; n < a.count; ++n) {
+            const double* __restrict__ pi = a.freqs[n];
+            unsigned mask = 0;
+            if (a.child[n] != nullptr && a.child_kind[n] == CHILD_STATES) {     // state bitplanes of this block
+                const uint64_t* planes = reinterpret_cast<const uint64_t*>(a.child[n]) + (size_t) blockIdx.x * g.tstride;
+                for (int i = 0; i < 4; ++i) mask |= (unsigned) (planes[i] >> threadIdx.x & 1u) << i;
+            }
+            for (int k = 0; k < K; ++k) {
+                const f4 p = a.parent[n][pb + (size_t) k * 64];
+                float f[4] = {1.0f, 1.0f, 1.0f, 1.0f};
+                if (a.child[n] != nullptr) {
+                    const float* __restrict__ mT = a.matrix[n] + k * 16;                   // mT[j][i] = P(i->j)
+                    float v[4];
+                    if (a.child_kind[n] == CHILD_STATES) {
+                        for (int j = 0; j < 4; ++j) v[j] = (mask >> j & 1u) ? 1.0f : 0.0f;
+                    } else {
+                        const f4 q = reinterpret_cast<const f4*>(a.child[n])[pb + (size_t) k * 64];
+                        v[0] = q.x; v[1] = q.y; v[2] = q.z; v[3] = q.w;
+                    }
+                    for (int i = 0; i < 4; ++i)
+                        f[i] = fmaf(mT[12 + i], v[3], fmaf(mT[8 + i], v[2], fmaf(mT[4 + i], v[1], mT[i] * v[0])));
+                }
+                const double cat = (double) (p.x * f[0]) * pi[0] + (double) (p.y * f[1]) * pi[1] + (double) (p.z * f[2]) * pi[2] +
+                                   (double) (p.w * f[3]) * pi[3];
+                const int e = a.cum[n] ? a.cum[n][(size_t) k * Ppad + c] : 0;
+                total += ldexp(cat * a.weights[n][k], e - emax);
+            }
+        }
+        const double lnl = log(total) + (double) emax * 0.69314718055994530942;
+        site[c] = lnl;
+        wl = lnl * pattern_weights[c];
+    } else if (c < Ppad) {
+        site[c] = 0.0;
+    }
+#if defined(MBAMD_HOST_EMU)
+    if (threadIdx.x == 0) wsite[blockIdx.x] = 0.0;
+    wsite[blockIdx.x] += wl;
+#else
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) wl += __shfl_down(wl, off);
+    if (threadIdx.x == 0) wsite[blockIdx.x] = wl;
+#endif
+}
+
 // ---------------------------------------------------------------------------------------------
 // cumulative scale-factor bookkeeping (exact integer arithmetic)
 // ---------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(256)
-k_scale_accumulate(const int32_t* const* __restrict__ src, int count, int sign, int n, unsigned sstride,
-                   int32_t* __restrict__ cum)
+k_scale_accumulate(const int32_t* const* __restrict__ src, int count, int sign, int n, int32_t* __restrict__ cum)
 {
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= n) return;
-    const size_t o = blk_index(c, sstride);
     int acc = 0;
-    for (int i = 0; i < count; ++i) acc += src[i][o];
-    cum[o] += sign * acc;
+    for (int i = 0; i < count; ++i) acc += src[i][c];
+    cum[c] += sign * acc;
 }
 
-// dst[c] = src ? src[c] : 0 over one (possibly block-major) scale buffer
+// dst[c] = src ? src[c] : 0 over one scale buffer
 __global__ void __launch_bounds__(256)
-k_scale_copy(const int32_t* __restrict__ src, int n, unsigned sstride, int32_t* __restrict__ dst)
+k_scale_copy(const int32_t* __restrict__ src, int n, int32_t* __restrict__ dst)
 {
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= n) return;
-    const size_t o = blk_index(c, sstride);
-    dst[o] = src ? src[o] : 0;
+    dst[c] = src ? src[c] : 0;
 }
 
-// linear [n] <-> block-major conversion of byte / int32 arrays (tip states in, scale factors out)
-__global__ void __launch_bounds__(256)
-k_scatter_bytes(const uint8_t* __restrict__ linear, int n, unsigned tstride, uint8_t* __restrict__ out)
+// ---- 4-state path: node exponents int8 [block][scale buffer][K][64] (arena), cumulative int32 [K][Ppad] -------------
+// element (k, c) of node-exponent buffer `idx`
+__host__ __device__ inline size_t exp_index(unsigned estride, int K, int idx, int k, int c)
 {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c < n) out[blk_index(c, tstride)] = linear[c];
+    return (size_t) (c >> 6) * estride + ((size_t) idx * K + k) * 64 + (c & 63);
+}
+struct ExpSource { const int32_t* wide; int narrow; int pad_; };      // a cumulative (wide) buffer, or arena buffer index `narrow`
+__global__ void __launch_bounds__(256)
+k_exp_accumulate(const ExpSource* __restrict__ src, int count, int sign, int K, int Ppad, const int8_t* __restrict__ arena,
+                 unsigned estride, int32_t* __restrict__ cum)
+{
+    const int g = blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= K * Ppad) return;
+    const int k = g / Ppad, c = g % Ppad;
+    int acc = 0;
+    for (int i = 0; i < count; ++i) acc += src[i].wide ? src[i].wide[g] : (int) arena[exp_index(estride, K, src[i].narrow, k, c)];
+    cum[g] += sign * acc;
+}
+// narrow -> wide (a node buffer that is then used as a cumulative one) and narrow -> narrow copies (src < 0: zero fill)
+__global__ void __launch_bounds__(256)
+k_exp_widen(const int8_t* __restrict__ arena, unsigned estride, int idx, int K, int Ppad, int32_t* __restrict__ wide)
+{
+    const int g = blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= K * Ppad) return;
+    wide[g] = arena[exp_index(estride, K, idx, g / Ppad, g % Ppad)];
 }
 __global__ void __launch_bounds__(256)
-k_gather_ints(const int32_t* __restrict__ in, int n, unsigned sstride, int32_t* __restrict__ linear)
+k_exp_copy(int8_t* __restrict__ arena, unsigned estride, int src, int dst, int K, int Ppad)
 {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c < n) linear[c] = in[blk_index(c, sstride)];
+    const int g = blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= K * Ppad) return;
+    arena[exp_index(estride, K, dst, g / Ppad, g % Ppad)] = src >= 0 ? arena[exp_index(estride, K, src, g / Ppad, g % Ppad)] : (int8_t) 0;
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -107,17 +107,19 @@ def check_single_operations(lib, oracle, nstates, ncat, npat, seed=1):
             inst.update_partials(np.array([[4, -1, -1, c1, 0, c2, 1]], dtype=np.int32), bg.BEAGLE_OP_NONE)
             got = inst.get_partials(4)
             assert close_partials(got, want), (name, np.abs(got - want).max())
-            # with rescaling: got2 * 2^e == unscaled, max over (k,i) in [0.5, 1)
+            # with rescaling: got2 * 2^e == unscaled.  The 4-state path rescales every (pattern, category) column on its
+            # own (max over the states in [0.5, 1)), the general-state path every pattern (max over categories and states)
             inst.reset_scale_factors(1)
             inst.update_partials(np.array([[5, 0, -1, c1, 0, c2, 1]], dtype=np.int32), 1)
             got2 = inst.get_partials(5)
+            e = inst.get_scale_exponents(0).astype(np.float64)              # [K][P]
+            assert np.array_equal(e, inst.get_scale_exponents(1))
             lnsc = inst.get_scale_factors(0)
-            cum = inst.get_scale_factors(1)
-            assert np.allclose(lnsc, cum)
-            e = np.rint(lnsc / math.log(2.0))
-            assert np.allclose(e * math.log(2.0), lnsc, atol=1e-9)
-            assert np.allclose(got2 * np.exp2(e)[None, :, None], got, rtol=1e-6, atol=0)
-            mx = got2.max(axis=(0, 2))
+            assert np.allclose(lnsc, e.max(axis=0) * math.log(2.0), atol=1e-9)
+            assert np.allclose(inst.get_scale_factors(1), lnsc)
+            assert np.allclose(got2 * np.exp2(e)[:, :, None], got, rtol=1e-6, atol=0)
+            per_category = "tree-walk" in inst.details.implName.decode()
+            mx = got2.max(axis=2) if per_category else np.broadcast_to(got2.max(axis=(0, 2)), (K, P))
             assert np.all((mx >= 0.5 - 1e-6) & (mx < 1.0 + 1e-6))
             # "divide by the factors already stored" (dynamic scaling's no-rescale pass)
             inst.update_partials(np.array([[6, -1, 0, c1, 0, c2, 1]], dtype=np.int32), bg.BEAGLE_OP_NONE)
@@ -125,11 +127,55 @@ def check_single_operations(lib, oracle, nstates, ncat, npat, seed=1):
             assert np.array_equal(got3, got2)
             # remove / accumulate are exact inverses
             inst.remove_scale_factors([0], 1)
-            assert np.all(inst.get_scale_factors(1) == 0.0)
+            assert np.all(inst.get_scale_exponents(1) == 0)
             inst.accumulate_scale_factors([0, 0], 1)
-            assert np.allclose(inst.get_scale_factors(1), 2 * lnsc)
+            assert np.array_equal(inst.get_scale_exponents(1), 2 * inst.get_scale_exponents(0))
     finally:
         inst.finalize()
+
+
+def check_hazard_lists(lib, nstates, ncat, npat, seed=5):
+    """Operation lists MrBayes never issues but the API allows: a destination that an earlier operation of the same list
+    read (write-after-read) or wrote (write-after-write), an exponent buffer written by one operation and read by a
+    later one, two independent lists back to back.  One call must give what one call per operation gives."""
+    rng = np.random.default_rng(seed)
+    S, K, P = nstates, ncat, npat
+
+    def run(split):
+        inst = bg.BeagleInstance(lib, 2, 10, 2, S, P, 1, 4, K, 6)
+        try:
+            for m in range(4):
+                ti = rng2.random((K, S, S)) + 0.05
+                inst.set_transition_matrix(m, ti / ti.sum(axis=2, keepdims=True))
+            inst.set_tip_states(0, st1)
+            inst.set_tip_states(1, st2)
+            inst.set_partials(2, pa)
+            ops = np.array([[3, 0, -1, 0, 0, 1, 1],       # 3 = f(tip0, tip1), writes exponents 0
+                            [4, 1, -1, 3, 2, 2, 3],       # 4 = f(3, 2), writes exponents 1
+                            [5, -1, 0, 3, 1, 4, 0],       # 5 = f(3, 4) divided by the exponents 0 (written above)
+                            [3, 2, -1, 4, 2, 5, 3],       # 3 overwritten after it was read (WAR) and written (WAW)
+                            [6, -1, 1, 3, 0, 5, 1],       # reads the new 3, divides by exponents 1
+                            [4, 0, -1, 6, 1, 3, 2]],      # 4 overwritten; exponents 0 written a second time
+                           dtype=np.int32)
+            inst.reset_scale_factors(5)
+            if split:
+                for o in ops:
+                    inst.update_partials(o[None, :], 5)
+            else:
+                inst.update_partials(ops, 5)
+            return [inst.get_partials(b) for b in (3, 4, 5, 6)] + [inst.get_scale_exponents(i) for i in (0, 1, 2, 5)]
+        finally:
+            inst.finalize()
+
+    st1 = rng.integers(0, S + 1, size=P).astype(np.int32)
+    st2 = rng.integers(0, S + 1, size=P).astype(np.int32)
+    pa = rng.random((K, P, S)) * 0.9 + 0.05
+    rng2 = np.random.default_rng(seed + 1)
+    one = run(False)
+    rng2 = np.random.default_rng(seed + 1)
+    many = run(True)
+    for a, b in zip(one, many):
+        assert np.array_equal(a, b)
 
 
 def engine_lnl(lib, div, scaling=lk.MB_BEAGLE_SCALE_ALWAYS, nchains=1, chain=0):

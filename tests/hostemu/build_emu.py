@@ -9,8 +9,9 @@ OUT = os.path.join(HERE, "_build", "libmbamd_hostemu_TESTONLY.so")
 
 
 def build():
-    deps = [SRC, os.path.join(ROOT, "mrbayes_amd", "csrc", "mbamd_kernels.h"), os.path.join(HERE, "hip_emu.h"),
-            os.path.join(ROOT, "include", "libhmsbeagle", "beagle.h")]
+    csrc = os.path.join(ROOT, "mrbayes_amd", "csrc")
+    deps = [os.path.join(csrc, f) for f in os.listdir(csrc)] + [os.path.join(HERE, "hip_emu.h"),
+                                                               os.path.join(ROOT, "include", "libhmsbeagle", "beagle.h")]
     if os.path.exists(OUT) and all(os.path.getmtime(d) <= os.path.getmtime(OUT) for d in deps):
         return OUT
     os.makedirs(os.path.dirname(OUT), exist_ok=True)

@@ -1,7 +1,8 @@
 // hip_emu.h -- TEST INFRASTRUCTURE ONLY.  A few dozen lines of "HIP on the host" so that the engine's
 // host logic (buffer bookkeeping, operation scheduling, LDS-slot allocation, layout conversion, the
 // BEAGLE call protocol) can be exercised by `pytest -m "not gpu"` in a container without a GPU.
-// Kernels are run one thread after another (they use no barriers / cross-lane operations).
+// Kernels are run one thread after another; kernels that use workgroup barriers are launched with
+// MBAMD_LAUNCH_BARRIER, which runs the threads of a block as fibers (ucontext) that yield at every barrier.
 //
 // It is compiled only into tests/hostemu/_build/libmbamd_hostemu_TESTONLY.so.  The product library
 // (mrbayes_amd/libhmsbeagle.so) is always built by hipcc for gfx950 against the real HIP runtime and has
@@ -18,6 +19,7 @@
 #include <cstring>
 #include <memory>
 #include <vector>
+#include <ucontext.h>
 
 #define __global__
 #define __device__
@@ -74,6 +76,9 @@ template <class T> inline hipError_t hipHostMalloc(T** p, size_t n, unsigned f =
 inline hipError_t hipHostFree(void* p) { std::free(p); return hipSuccess; }
 inline hipError_t hipHostGetDevicePointer(void** d, void* h, unsigned) { *d = h; return hipSuccess; }
 inline hipError_t hipMemcpy(void* d, const void* s, size_t n, hipMemcpyKind) { std::memcpy(d, s, n); return hipSuccess; }
+inline hipError_t hipMemcpy2D(void* d, size_t dpitch, const void* s, size_t spitch, size_t width, size_t height, hipMemcpyKind) {
+    for (size_t r = 0; r < height; ++r) std::memcpy((char*) d + r * dpitch, (const char*) s + r * spitch, width);
+    return hipSuccess; }
 inline hipError_t hipMemcpyAsync(void* d, const void* s, size_t n, hipMemcpyKind, hipStream_t) { std::memcpy(d, s, n); return hipSuccess; }
 inline hipError_t hipMemsetAsync(void* d, int v, size_t n, hipStream_t) { std::memset(d, v, n); return hipSuccess; }
 inline hipError_t hipMemset(void* d, int v, size_t n) { std::memset(d, v, n); return hipSuccess; }
@@ -110,5 +115,73 @@ inline void emu_launch(Kernel kernel, dim3 grid, dim3 block, size_t lds_bytes, A
             }
 }
 #define MBAMD_LAUNCH(kernel, grid, block, lds, stream, ...) emu_launch(kernel, dim3(grid), dim3(block), lds, __VA_ARGS__)
+
+// ---- workgroup barriers: the threads of one block as fibers ---------------------------------------------------
+struct EmuFibers {
+    ucontext_t scheduler;
+    std::vector<ucontext_t> ctx;
+    std::vector<std::vector<unsigned char>> stacks;
+    std::vector<char> done;
+    int current = -1;
+    void (*body)(void*) = nullptr;
+    void* arg = nullptr;
+};
+inline EmuFibers& emu_fibers() { static thread_local EmuFibers f; return f; }
+inline void mbamd_emu_barrier()
+{
+    EmuFibers& f = emu_fibers();
+    if (f.current < 0) return;                       // plain launch: threads run to completion one after another
+    swapcontext(&f.ctx[f.current], &f.scheduler);    // every thread of the block stops here; the scheduler resumes them in order
+}
+inline void emu_fiber_entry()
+{
+    EmuFibers& f = emu_fibers();
+    f.body(f.arg);
+    f.done[f.current] = 1;
+    swapcontext(&f.ctx[f.current], &f.scheduler);
+}
+template <class Kernel, class... Args>
+inline void emu_launch_barrier(Kernel kernel, dim3 grid, dim3 block, size_t lds_bytes, Args... args)
+{
+    std::vector<unsigned char> lds(lds_bytes + 64);
+    emu_gridDim() = grid;
+    emu_blockDim() = block;
+    EmuFibers& f = emu_fibers();
+    const unsigned T = block.x;
+    if (f.ctx.size() < T) { f.ctx.resize(T); f.stacks.resize(T); }
+    for (unsigned t = 0; t < T; ++t) if (f.stacks[t].empty()) f.stacks[t].resize(256 * 1024);
+    f.done.assign(T, 0);
+    auto call = [&]() { kernel(args...); };
+    f.body = [](void* p) { (*static_cast<decltype(call)*>(p))(); };
+    f.arg = &call;
+    for (unsigned by = 0; by < grid.y; ++by)
+        for (unsigned bx = 0; bx < grid.x; ++bx) {
+            emu_blockIdx() = dim3(bx, by, 0);
+            void* base = lds.data();
+            size_t space = lds.size();
+            emu_lds_ptr() = std::align(16, lds_bytes, base, space);
+            std::fill(f.done.begin(), f.done.end(), 0);
+            for (unsigned t = 0; t < T; ++t) {
+                getcontext(&f.ctx[t]);
+                f.ctx[t].uc_stack.ss_sp = f.stacks[t].data();
+                f.ctx[t].uc_stack.ss_size = f.stacks[t].size();
+                f.ctx[t].uc_link = &f.scheduler;
+                makecontext(&f.ctx[t], (void (*)()) emu_fiber_entry, 0);
+            }
+            unsigned live = T;
+            while (live > 0) {                       // one pass = every live thread runs to its next barrier (or to its end)
+                live = 0;
+                for (unsigned t = 0; t < T; ++t) {
+                    if (f.done[t]) continue;
+                    emu_threadIdx() = dim3(t, 0, 0);
+                    f.current = (int) t;
+                    swapcontext(&f.scheduler, &f.ctx[t]);
+                    if (!f.done[t]) ++live;
+                }
+            }
+            f.current = -1;
+        }
+}
+#define MBAMD_LAUNCH_BARRIER(kernel, grid, block, lds, stream, ...) emu_launch_barrier(kernel, dim3(grid), dim3(block), lds, __VA_ARGS__)
 
 #endif

@@ -100,7 +100,7 @@ def test_vector_kernels_on_protein_and_codon(gpu, oracle, golden_dir, monkeypatc
 
 
 def test_lds_stack_eviction(gpu, oracle, monkeypatch):
-    monkeypatch.setenv("MBAMD_MAX_LDS_SLOTS", "2")
+    monkeypatch.setenv("MBAMD_MAX_LDS_SLOTS", "3")
     div = synthetic_division("gtr", 60, 130, seed=41, tree_seed=42)
     lnl = ec.engine_lnl(gpu, div)
     want = oracle.tree_loglike(div, use_shortcuts=False)
@@ -112,14 +112,20 @@ def test_lds_stack_eviction(gpu, oracle, monkeypatch):
     assert abs(lnl - want) / abs(want) < ec.REL_FP64
 
 
-@pytest.mark.parametrize("waves", [2, 4, 8])
-def test_walk_waves_agree(gpu, oracle, monkeypatch, waves):
-    """The tree-walk kernel scheduled over 1/3/7 compute waves (+ the writer wave) per pattern block gives bit-identical partials
-    (the arithmetic per node does not depend on which wave executes it), hence identical lnL."""
+@pytest.mark.parametrize("waves,slots", [(2, 16), (4, 7), (8, 4), (3, 3)])
+def test_walk_waves_agree(gpu, oracle, monkeypatch, waves, slots):
+    """The tree walk compiled for 1..8 waves per (pattern block, category) workgroup gives bit-identical partials (the
+    arithmetic per node does not depend on which wave executes it or where its inputs were staged), hence identical lnL;
+    so do waiting for every memory operation instead of counting (MBAMD_WALK_SAFE) and no look-ahead prefetching."""
     div = synthetic_division("gtr", 150, 1000, seed=51, tree_seed=52, p_gap=0.05)
-    monkeypatch.setenv("MBAMD_WALK_WAVES", "2")
+    monkeypatch.setenv("MBAMD_WALK_WAVES", "1")
     base = ec.engine_lnl(gpu, div)
     monkeypatch.setenv("MBAMD_WALK_WAVES", str(waves))
+    monkeypatch.setenv("MBAMD_MAX_LDS_SLOTS", str(slots))
+    assert ec.engine_lnl(gpu, div) == base
+    monkeypatch.setenv("MBAMD_WALK_PREFETCH", "0")
+    assert ec.engine_lnl(gpu, div) == base
+    monkeypatch.setenv("MBAMD_WALK_SAFE", "1")
     assert ec.engine_lnl(gpu, div) == base
     want = oracle.tree_loglike(div, use_shortcuts=False)
     assert abs(base - want) / abs(want) < ec.REL_FP64
@@ -331,15 +337,44 @@ def test_protein_other_category_counts(gpu, oracle, ncat):
     ec.check_partial_update_and_reject(gpu, oracle, div, scaling=lk.MB_BEAGLE_SCALE_ALWAYS)
 
 
-def test_walk_category_split_agrees(gpu, monkeypatch):
+def test_walk_counted_waits_agree_on_partial_updates(gpu, oracle, monkeypatch):
+    """Root-ward paths (every operation prefetches its sibling from HBM by LDS-DMA, waits are by count): same bits as
+    with every wait draining the memory queue, for several prefetch distances."""
     div = synthetic_division("gtr", 120, 700, seed=71, tree_seed=72, p_gap=0.04)
-    a, sa = _lnl_and_sites(gpu, div)
-    monkeypatch.setenv("MBAMD_WALK_KSPLIT", "1")
-    b, sb = _lnl_and_sites(gpu, div)
-    assert a == b and np.array_equal(sa, sb)
-    monkeypatch.setenv("MBAMD_WALK_IN_ORDER", "1")          # strict list order, one compute wave
-    c, sc = _lnl_and_sites(gpu, div)
-    assert a == c and np.array_equal(sa, sc)
+
+    def path_values():
+        bd = lk.BeagleDivision(div, gpu)
+        vals = [bd.LogLike(0)]
+        bd.AcceptMove(0)
+        for node in (3, 17, 60, 101):
+            div.tree.length[node] *= 1.7
+            bd.TouchBranch(0, node)
+            vals.append(bd.LogLike(0))
+            bd.AcceptMove(0)
+        for node in (3, 17, 60, 101):
+            div.tree.length[node] /= 1.7
+        bd.finalize()
+        return vals
+
+    base = path_values()
+    for env in ({"MBAMD_WALK_SAFE": "1"}, {"MBAMD_WALK_PREFETCH": "0"}, {"MBAMD_WALK_PREFETCH": "9"}, {"MBAMD_MAX_LDS_SLOTS": "3"}):
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        assert path_values() == base
+        for k in env:
+            monkeypatch.delenv(k)
+
+
+@pytest.mark.parametrize("ncat", [1, 2, 5, 16])
+def test_dna_other_category_counts(gpu, oracle, ncat):
+    div = synthetic_division("gtr", 30, 140, seed=45, tree_seed=46, p_gap=0.03, ncat=ncat)
+    ec.check_partial_update_and_reject(gpu, oracle, div, scaling=lk.MB_BEAGLE_SCALE_DYNAMIC)
+    ec.check_partial_update_and_reject(gpu, oracle, div, scaling=lk.MB_BEAGLE_SCALE_ALWAYS)
+
+
+def test_lists_with_hazards_are_cut_into_segments(gpu, oracle):
+    ec.check_hazard_lists(gpu, 4, 4, 100)
+    ec.check_hazard_lists(gpu, 20, 4, 40)
 
 
 def test_instances_created_and_destroyed_repeatedly(gpu):

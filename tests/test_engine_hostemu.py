@@ -79,8 +79,8 @@ def test_generic_kernels_on_dna(emu, oracle, golden_dir, monkeypatch):
 
 
 def test_lds_stack_eviction(emu, oracle, monkeypatch):
-    """With only two LDS slots the tree-walk scheduler must evict and re-read its own stores."""
-    monkeypatch.setenv("MBAMD_MAX_LDS_SLOTS", "2")
+    """With only three LDS slots per wave the tree-walk scheduler must evict results and prefetch its own stores back."""
+    monkeypatch.setenv("MBAMD_MAX_LDS_SLOTS", "3")
     div = synthetic_division("gtr", 60, 130, seed=41, tree_seed=42)
     lnl = ec.engine_lnl(emu, div)
     want = oracle.tree_loglike(div, use_shortcuts=False)
@@ -105,20 +105,21 @@ def test_error_codes(emu):
     inst.finalize()
 
 
-@pytest.mark.parametrize("waves", [2, 4, 8])
-@pytest.mark.parametrize("slots", [2, 3, 7, 16])
-@pytest.mark.parametrize("reverse", [False, True])
-def test_walk_schedule(emu, oracle, monkeypatch, waves, slots, reverse):
-    """The W-wave step schedule + LDS slot allocation of the tree-walk path (host logic): the result is
-    bit-identical for every W / slot budget / intra-step order, because each node's arithmetic does not
-    depend on where its inputs were staged."""
+@pytest.mark.parametrize("waves", [2, 3, 4, 8])
+@pytest.mark.parametrize("slots", [3, 4, 7, 16])
+@pytest.mark.parametrize("prefetch", [0, 4])
+def test_walk_schedule(emu, oracle, monkeypatch, waves, slots, prefetch):
+    """Per-wave programs of the tree-walk path (host logic: subtree bins, barrier phases, slot allocation, prefetches of
+    values that cross waves): the result is bit-identical for every W / slot budget / prefetch distance, because each
+    node's arithmetic does not depend on which wave runs it or where its inputs were staged.  (The host emulation
+    runs the waves of a workgroup as fibers that meet at the barriers.)"""
     div = synthetic_division("gtr", 90, 130, seed=61, tree_seed=62, p_gap=0.03)
-    monkeypatch.setenv("MBAMD_WALK_WAVES", "2")
+    monkeypatch.setenv("MBAMD_WALK_WAVES", "1")
     base = ec.engine_lnl(emu, div)
     monkeypatch.setenv("MBAMD_WALK_WAVES", str(waves))
     monkeypatch.setenv("MBAMD_MAX_LDS_SLOTS", str(slots))
-    if reverse:
-        monkeypatch.setenv("MBAMD_EMU_REVERSE_STEP", "1")
+    monkeypatch.setenv("MBAMD_WALK_PREFETCH", str(prefetch))
+    monkeypatch.setenv("MBAMD_WALK_SMALL_PHASE", "4")
     assert ec.engine_lnl(emu, div) == base
     bd = lk.BeagleDivision(div, emu)
     bd.LogLike(0)
@@ -131,3 +132,16 @@ def test_walk_schedule(emu, oracle, monkeypatch, waves, slots, reverse):
     want = oracle.tree_loglike(div, use_shortcuts=False)
     t.length[3] /= 2.0
     assert abs(got - want) / abs(want) < ec.REL_FP64
+
+
+@pytest.mark.parametrize("ncat", [1, 2, 5, 16])
+def test_dna_other_category_counts(emu, oracle, ncat):
+    """The tree walk runs one wave per (pattern block, category): any category count."""
+    div = synthetic_division("gtr", 30, 140, seed=45, tree_seed=46, p_gap=0.03, ncat=ncat)
+    ec.check_partial_update_and_reject(emu, oracle, div, scaling=lk.MB_BEAGLE_SCALE_DYNAMIC)
+    ec.check_partial_update_and_reject(emu, oracle, div, scaling=lk.MB_BEAGLE_SCALE_ALWAYS)
+
+
+def test_lists_with_hazards_are_cut_into_segments(emu, oracle):
+    ec.check_hazard_lists(emu, 4, 4, 100)
+    ec.check_hazard_lists(emu, 20, 4, 40)

@@ -228,6 +228,34 @@ def main():
              synth={"ntaxa": 30, "nsites": 600, "nstates": 61, "seed": 6, "p_mut": 0.15, "p_gap": 0.0,
                     "tree_seed": 10, "brlen": 0.05})
 
+    # ---- the bench.py workloads themselves (BASELINE configs 2-5 at full size): bench.py's printed lnL is pinned
+    # against these reference values.  Same generator seeds / parameters as bench.CONFIGS + synthetic_division.
+    def bench_case(case, kind, ntaxa, nsites, seed, tree_seed):
+        nstates = {"gtr": 4, "wag": 20, "m3": 61}[kind]
+        st = mbdata.synthetic_states(ntaxa, nsites, nstates, seed=seed, p_mut=0.15)
+        names = ["t%d" % (i + 1) for i in range(ntaxa)]
+        tr = mbtree.random_tree(ntaxa, seed=tree_seed, brlen=0.05)
+        synth = {"ntaxa": ntaxa, "nsites": nsites, "nstates": nstates, "seed": seed, "p_mut": 0.15, "p_gap": 0.0,
+                 "tree_seed": tree_seed, "brlen": 0.05}
+        if kind == "gtr":
+            emit(case, "dna", names, states_to_seqs(st, "dna"), tr, "lset nst=6 rates=gamma ngammacat=4;", "",
+                 "Revmat=%s Pi=%s Alpha=(1.0)" % (fmt_vec(rev), fmt_vec(pi)),
+                 {"kind": "gtr", "revmat": rev, "pi": pi, "alpha": 1.0, "ncat": 4, "pinvar": 0.0},
+                 store_patterns=False, synth=synth)
+        elif kind == "wag":
+            emit(case, "protein", names, states_to_seqs(st, "protein"), tr, "lset rates=gamma ngammacat=4;",
+                 "prset aamodelpr=fixed(wag);", "Alpha=(1.0)", {"kind": "wag", "alpha": 1.0, "ncat": 4, "pinvar": 0.0},
+                 store_patterns=False, synth=synth)
+        else:
+            emit(case, "codon", names, states_to_seqs(st, "codon"), tr, "lset nucmodel=codon omegavar=M3;",
+                 "prset statefreqpr=fixed(equal);", "",
+                 {"kind": "m3", "nst": 1, "omega": None, "omega_freq": None, "pi": "equal"}, store_patterns=False,
+                 synth=synth)
+    for case, cfg in (("bench_c2", ("gtr", 500, 20000, 7, 3)), ("bench_c3", ("wag", 200, 10000, 5, 9)),
+                      ("bench_c5", ("m3", 100, 5000, 6, 10)), ("bench_c4", ("gtr", 1000, 50000, 6, 10))):
+        if case in only:                 # (minutes of reference CPU time each: only on request)
+            bench_case(case, *cfg)
+
 
 if __name__ == "__main__":
     main()
