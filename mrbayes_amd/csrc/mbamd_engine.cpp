@@ -356,8 +356,9 @@ int Instance::create(int tipCount_, int partialsBufferCount, int compactBufferCo
     nMatrices = matrixBufferCount;
     nScale = scaleBufferCount;
     const bool forceGeneric = std::getenv("MBAMD_FORCE_GENERIC") != nullptr;
-    // the 4-state tree walk addresses buffers with 16-bit indices (Walk4Entry)
-    s4 = (S == 4 && !forceGeneric && nBuffers < 65536 && nMatrices < 65536 && nScale + 1 < 65536 && K <= 1024);
+    // the 4-state tree walk addresses buffers with 32-bit byte offsets inside a (block, category) column set (Walk4Entry)
+    s4 = (S == 4 && !forceGeneric && (size_t) nBuffers * K * 1024 < ((size_t) 1 << 32) && (size_t) nMatrices * K * 64 < ((size_t) 1 << 32) &&
+          (size_t) (nScale + 1) * K * 64 < ((size_t) 1 << 32));
     if (s4) SP = 4;
     else if (S <= 4) SP = 4;
     else if (S <= 8) SP = 8;
@@ -490,8 +491,10 @@ int Instance::configureWalk()
     const long wgs = (long) (Ppad / 64) * K;
     const int perCU = (int) std::max(1L, (wgs + numCU - 1) / numCU);          // workgroups a CU must host for full residency
     const int ldsPerWG = (160 * 1024) / std::min(perCU, 32) - 64;
-    auto slotsFor = [&](int W) { return ldsPerWG / W / 1024; };
-    int W = std::max(1, std::min(MBAMD_W4_MAXW, 32 / std::min(perCU, 32)));
+    auto slotsFor = [&](int W) { return (ldsPerWG / W - MBAMD_W4_STAGE) / 1024; };
+    // measured (profiles/): about 10-12 waves per CU (2.5-3 per SIMD) is the sweet spot -- fewer leave the scalar-load
+    // latency uncovered, more cost LDS (slots) and tree-partition efficiency (phases, padding) without buying anything
+    int W = (int) std::max(1L, std::min((long) MBAMD_W4_MAXW, (12L * numCU + wgs / 2) / wgs));
     while (W > 1 && slotsFor(W) < 7) --W;
     if (const char* e = std::getenv("MBAMD_WALK_WAVES")) W = std::max(1, std::min(MBAMD_W4_MAXW, std::atoi(e)));
     int slots = std::max(3, std::min(48, slotsFor(W)));
@@ -1126,7 +1129,8 @@ int Instance::buildWalk(Plan& plan, const BeagleOperation* ops, int n)
                 auto p2 = seg[o].tip2 ? writer.end() : writer.find(seg[o].c2);
                 key.push_back(p1 == writer.end() ? -1 : p1->second);
                 key.push_back(p2 == writer.end() ? -1 : p2->second);
-                key.push_back((int) seg[o].tip1 | ((int) seg[o].tip2 << 1) | ((!seg[o].tip1 && !seg[o].tip2 && seg[o].c1 == seg[o].c2) ? 4 : 0));
+                key.push_back((int) seg[o].tip1 | ((int) seg[o].tip2 << 1) | ((!seg[o].tip1 && !seg[o].tip2 && seg[o].c1 == seg[o].c2) ? 4 : 0) |
+                              ((seg[o].scaleWrite < 0 && seg[o].scaleRead >= 0) ? 8 : 0));   // (SCALE_READ entries wait for an exponent DMA)
                 writer[seg[o].dst] = (int) o;
             }
         }
@@ -1157,28 +1161,39 @@ int Instance::buildWalk(Plan& plan, const BeagleOperation* ops, int n)
         sg.W = t.W; sg.entries = t.entries; sg.nslots = t.nslots;
         plan.segments.push_back(sg);
         w4table.resize(sg.first + t.prog.size());
+        const uint32_t pbuf = (uint32_t) K * 1024u, ebuf = (uint32_t) K * 64u, mbuf = (uint32_t) K * 64u;   // bytes per buffer
         for (size_t i = 0; i < t.prog.size(); ++i) {
             const Walk4Template::Entry& te = t.prog[i];
             Walk4Entry& e = w4table[sg.first + i];
             std::memset(&e, 0, sizeof e);
-            e.dst = 0xFF0000u | ((uint32_t) te.flags << 24);
-            e.scale = (uint32_t) scratchScale | ((uint32_t) SCALE_NONE << 16) | ((uint32_t) te.vmwait << 24);
-            e.sread = (uint32_t) scratchScale;
-            for (int q = 0; q < 2; ++q) {
-                if (te.pfOp[q] < 0) continue;
-                const Walk4Op& po = seg[te.pfOp[q]];
-                const uint32_t word = (uint32_t) (te.pfChild[q] == 0 ? po.c1 : po.c2) | ((uint32_t) te.pfSlot[q] << 16) | (1u << 24);
-                (q == 0 ? e.pf0 : e.pf1) = word;
+            uint32_t flags = te.flags, mode = SCALE_NONE, keep = 0;
+            e.ewrite = (uint32_t) scratchScale * ebuf;
+            e.eread = (uint32_t) scratchScale * ebuf;
+            if (te.pfOp[0] >= 0) {                          // PF entry
+                const Walk4Op& p0 = seg[te.pfOp[0]];
+                e.dst = (uint32_t) (te.pfChild[0] == 0 ? p0.c1 : p0.c2) * pbuf;
+                e.c1 = (uint32_t) te.pfSlot[0] * 1024u;
+                flags |= MBAMD_W4_PF0 | MBAMD_W4_NOP;
+                if (te.pfOp[1] >= 0) {
+                    const Walk4Op& p1 = seg[te.pfOp[1]];
+                    e.c2 = (uint32_t) (te.pfChild[1] == 0 ? p1.c1 : p1.c2) * pbuf;
+                    e.m1 = (uint32_t) te.pfSlot[1] * 1024u;
+                    flags |= MBAMD_W4_PF1;
+                }
+            } else if (te.op >= 0) {
+                const Walk4Op& op = seg[te.op];
+                e.dst = (uint32_t) op.dst * pbuf;
+                if (op.tip1) { e.c1 = (uint32_t) op.c1 * 32u; flags |= MBAMD_W4_TIP1; } else e.c1 = (uint32_t) te.c1slot * 1024u;
+                if (op.tip2) { e.c2 = (uint32_t) op.c2 * 32u; flags |= MBAMD_W4_TIP2; } else e.c2 = (uint32_t) te.c2slot * 1024u;
+                e.m1 = (uint32_t) op.m1 * mbuf;
+                e.m2 = (uint32_t) op.m2 * mbuf;
+                if (te.dslot != 0xFF) { keep = te.dslot; flags |= MBAMD_W4_KEEP; }
+                mode = op.scaleWrite >= 0 ? SCALE_WRITE : (op.scaleRead >= 0 ? SCALE_READ : SCALE_NONE);
+                if (op.scaleWrite >= 0) e.ewrite = (uint32_t) op.scaleWrite * ebuf;
+                if (op.scaleRead >= 0) e.eread = (uint32_t) op.scaleRead * ebuf;
             }
-            if (te.op < 0) continue;
-            const Walk4Op& op = seg[te.op];
-            e.dst = (uint32_t) op.dst | ((uint32_t) te.dslot << 16) | ((uint32_t) te.flags << 24);
-            e.c1 = op.tip1 ? ((uint32_t) op.c1 | (MBAMD_W4_TIP << 24)) : ((uint32_t) te.c1slot << 16);
-            e.c2 = op.tip2 ? ((uint32_t) op.c2 | (MBAMD_W4_TIP << 24)) : ((uint32_t) te.c2slot << 16);
-            e.mats = (uint32_t) op.m1 | ((uint32_t) op.m2 << 16);
-            const uint32_t mode = op.scaleWrite >= 0 ? SCALE_WRITE : (op.scaleRead >= 0 ? SCALE_READ : SCALE_NONE);
-            e.scale = (uint32_t) (op.scaleWrite >= 0 ? op.scaleWrite : scratchScale) | (mode << 16) | ((uint32_t) te.vmwait << 24);
-            e.sread = (uint32_t) (op.scaleRead >= 0 ? op.scaleRead : scratchScale);
+            if (te.vmwait != 0xFF) flags |= MBAMD_W4_VMWAIT;
+            e.ctl = flags | (mode << 8) | ((uint32_t) (te.vmwait == 0xFF ? 0 : te.vmwait) << 10) | (keep << 16);
         }
         lastWalkW = t.W; lastWalkSlots = t.nslots; lastWalkEntries = t.entries; lastWalkPhases = t.phases;
         seg.clear();
@@ -1274,7 +1289,8 @@ int Instance::runWalk(const Plan& plan, int32_t* cum)
         a.cum = cum;
         a.K = K;
         a.Ppad = Ppad;
-        MBAMD_LAUNCH_BARRIER(k_walk4, dim3((unsigned) (Ppad / 64), (unsigned) K), 64 * sg.W, walk4_lds_bytes(sg.W, sg.nslots), stream, a);
+        a.nblocks = Ppad / 64;
+        MBAMD_LAUNCH_BARRIER(k_walk4, walk4_grid(Ppad / 64, K), 64 * sg.W, walk4_lds_bytes(sg.W, sg.nslots), stream, a);
         HIP_TRY(hipGetLastError());
         pendingLaunches += 1;
     }

@@ -22,8 +22,7 @@
 // operands: no matrix VGPRs, no LDS staging, no cross-lane broadcast -- and the compact tips, which are stored as
 // four 64-bit STATE BITPLANES per (tip, pattern block): plane i, bit l = "state i is compatible with pattern l"
 // (ambiguity codes included).  A plane in a scalar register pair is a lane mask: the tip's 0/1 vector is four
-// v_cndmask_b32.  Stored exponents (dynamic rescaling's "divide by the existing factors" pass) are 64 bytes per
-// wave: a scalar load, sixteen v_writelane and one ds_bpermute spread them over the lanes.
+// v_cndmask_b32.
 //
 // Why: the vector-memory counter (vmcnt) retires in order and is shared by loads and stores, so a wave that waits for
 // ANY vector load also waits for all its older stores -- microseconds under a saturated write stream.  With the above
@@ -31,35 +30,48 @@
 // children that live in HBM (results of earlier launches on a partial update, values that crossed waves or were
 // evicted): they are LDS-DMA prefetches (global_load_lds_dwordx4, no destination register) issued through inline asm as
 // early as the host can place them -- all of a root-ward path's siblings before the first store when the slots allow
-// -- and their consumer waits with the exact s_waitcnt vmcnt(N) the host computed by replaying the instruction
-// sequence (Walk4Entry vmwait): per iteration [0-2 prefetches] [wait] [2 stores unless NOP].
+// -- and the stored exponents of dynamic rescaling's "divide by the existing factors" pass (one byte per lane: an LDS-DMA
+// of the next entry's 64 bytes into a two-deep staging area).  Their consumer waits with the exact s_waitcnt vmcnt(N) the
+// host computed by replaying the instruction sequence (Walk4Entry vmwait): per iteration
+// [0-2 prefetches (PF entries only)] [wait] [exponent DMA for the next entry if it is SCALE_READ] [2 stores if an operation].
+// The stores are non-temporal: a result is never read again in the launch that wrote it (parents read the LDS copy), and
+// letting 0.7 GB of write-allocated lines stream through L2 evicted the matrices and programs every wave keeps
+// re-reading -- every scalar load then paid an HBM round trip (measured: 1.6x on the whole kernel).
 #ifndef MBAMD_WALK4_H_
 #define MBAMD_WALK4_H_
 
 namespace mbamd {
 
-#define MBAMD_W4_NOP      1u     // Walk4Entry flags: no operation (padding so that all waves meet at the barriers)
-#define MBAMD_W4_BARRIER  2u     // drain this wave's stores and meet the other waves before reading this entry's children
-#define MBAMD_W4_TIP      1u     // child kind: compact tip (state bitplanes); 0 = LDS slot
+// Walk4Entry::ctl flag bits
+#define MBAMD_W4_NOP      0x01u  // no operation (padding so that all waves meet at the barriers; PF entries)
+#define MBAMD_W4_BARRIER  0x02u  // drain this wave's stores and meet the other waves before reading this entry's children
+#define MBAMD_W4_PF0      0x04u  // PF entry: LDS-DMA prefetch 0 (and, with PF1, prefetch 1)
+#define MBAMD_W4_PF1      0x08u
+#define MBAMD_W4_VMWAIT   0x10u  // this entry reads something an LDS-DMA brought: s_waitcnt vmcnt(vmwait) first
+#define MBAMD_W4_TIP1     0x20u  // child 1 / 2 is a compact tip (state bitplanes); otherwise an LDS slot
+#define MBAMD_W4_TIP2     0x40u
+#define MBAMD_W4_KEEP     0x80u  // the result is also written to LDS slot `keep`
+#define MBAMD_W4_RARE     (MBAMD_W4_NOP | MBAMD_W4_BARRIER | MBAMD_W4_PF0 | MBAMD_W4_VMWAIT)
 #define MBAMD_W4_MAXW     8
-#define MBAMD_W4_NOWAIT   63u    // vmwait value: this entry reads no prefetched child
 
-// One step of a wave's program (wave-uniform; fetched with one s_load_dwordx8).
+// One step of a wave's program (wave-uniform; fetched with one s_load_dwordx8).  Addresses are ready-made byte
+// offsets from a base the wave computes once (scalar adds only, no multiplications in the loop).
 struct alignas(32) Walk4Entry {
-    uint32_t dst;      // [15:0] destination partials buffer   [23:16] LDS slot that keeps the result (0xFF: none)   [31:24] flags
-    uint32_t c1;       // [15:0] tip buffer (kind TIP)          [23:16] LDS slot (kind SLOT)                         [31:24] kind
+    uint32_t ctl;      // [7:0] flags   [9:8] ScaleMode   [15:10] vmwait   [23:16] slot that keeps the result (flag KEEP)
+    uint32_t dst;      // destination partials buffer: byte offset inside this wave's (block, category) column set
+    uint32_t c1;       // child 1: tip -> byte offset of its 4 bitplanes inside the block's tip area; else LDS byte offset of its slot
     uint32_t c2;
-    uint32_t mats;     // [15:0] transition matrix of child 1   [31:16] of child 2
-    uint32_t scale;    // [15:0] exponent buffer written (scratch unless SCALE_WRITE)   [23:16] ScaleMode   [31:24] vmwait
-    uint32_t pf0;      // LDS-DMA prefetch: [15:0] partials buffer   [23:16] LDS slot   [24] valid (pf1 valid only if pf0 is)
-    uint32_t pf1;
-    uint32_t sread;    // [15:0] exponent buffer read (SCALE_READ)
+    uint32_t m1;       // transition matrices: byte offsets (this wave's category)
+    uint32_t m2;
+    uint32_t ewrite;   // exponent buffer written (the scratch buffer unless SCALE_WRITE): byte offset
+    uint32_t eread;    // exponent buffer read (SCALE_READ): byte offset
+    // PF entry (flags NOP | PF0 [| PF1]): dst / c1 = partials byte offset -> LDS slot byte offset of prefetch 0, c2 / m1 of prefetch 1
 };
 static_assert(sizeof(Walk4Entry) == 32, "Walk4Entry is 8 dwords");
 
 struct Walk4Args {
     const Walk4Entry* prog;      // [W][entries]
-    int entries;                 // per wave, including two trailing NOP entries (read-ahead)
+    int entries;                 // per wave: even, including two trailing NOP entries (read-ahead)
     int nslots;                  // LDS slots per wave
     f4* partials;                // arena f4 [block][buffer][K][64]
     unsigned long pstride;       // f4 elements between blocks
@@ -69,19 +81,22 @@ struct Walk4Args {
     unsigned estride;            // bytes between blocks
     const float* matrices;       // [matrix][K][4][4] transposed
     int32_t* cum;                // wide cumulative buffer int32 [K][Ppad], or nullptr
-    int K, Ppad;
+    int K, Ppad, nblocks;
 };
 
-__host__ __device__ inline size_t walk4_lds_bytes(int W, int nslots) { return (size_t) W * nslots * 1024; }
+#define MBAMD_W4_STAGE 512       // bytes per wave in front of its slots: two 64-dword landing areas for stored exponents
+__host__ __device__ inline size_t walk4_lds_bytes(int W, int nslots) { return (size_t) W * (MBAMD_W4_STAGE + (size_t) nslots * 1024); }
+// The grid is one-dimensional and XCD-aware: workgroup id -> XCD id % 8 (observed dispatch rule), and the K category
+// workgroups of one pattern block get consecutive positions on ONE XCD, so that the tip bitplanes and the matrix
+// lines they all read are fetched into that XCD's L2 once.
+__host__ __device__ inline unsigned walk4_grid(int nblocks, int K) { return 8u * (unsigned) K * (unsigned) ((nblocks + 7) / 8); }
 
 struct Walk4Planes { uint64_t p[4]; };
-struct Walk4Exps { uint32_t d[16]; };
 
 #if defined(MBAMD_HOST_EMU)
 struct Walk4Mat { float m[16]; };
 __device__ inline Walk4Mat walk4_load_matrix(const float* p) { Walk4Mat r; for (int i = 0; i < 16; ++i) r.m[i] = p[i]; return r; }
 __device__ inline Walk4Planes walk4_load_planes(const uint64_t* p) { Walk4Planes r; for (int i = 0; i < 4; ++i) r.p[i] = p[i]; return r; }
-__device__ inline Walk4Exps walk4_load_exps(const int8_t* p) { Walk4Exps r; std::memcpy(r.d, p, 64); return r; }
 __device__ inline f4 walk4_tip_vector(const Walk4Planes& t, unsigned lane)
 {
     f4 v;
@@ -89,8 +104,8 @@ __device__ inline f4 walk4_tip_vector(const Walk4Planes& t, unsigned lane)
     v.z = (float) (t.p[2] >> lane & 1u); v.w = (float) (t.p[3] >> lane & 1u);
     return v;
 }
-__device__ inline int walk4_lane_exponent(const Walk4Exps& x, unsigned lane) { return (int) (int8_t) (x.d[lane >> 2] >> (8 * (lane & 3))); }
 __device__ inline void walk4_dma(const f4* base, unsigned lane, f4* slot) { slot[lane] = base[lane]; }
+__device__ inline void walk4_dma_exps(const int8_t* base, unsigned lane, int* stage) { stage[lane] = base[lane]; }
 __device__ inline void walk4_wait_vm(unsigned) {}
 __device__ inline void walk4_barrier() { mbamd_emu_barrier(); }
 __device__ inline Walk4Entry walk4_load_entry(const Walk4Entry* p) { return *p; }
@@ -112,7 +127,7 @@ __device__ __forceinline__ Walk4Entry walk4_load_entry(const Walk4Entry* p)
 {
     const u8v v = *reinterpret_cast<const MBAMD_AS_CONST u8v*>((uintptr_t) p);
     Walk4Entry e;
-    e.dst = v[0]; e.c1 = v[1]; e.c2 = v[2]; e.mats = v[3]; e.scale = v[4]; e.pf0 = v[5]; e.pf1 = v[6]; e.sread = v[7];
+    e.ctl = v[0]; e.dst = v[1]; e.c1 = v[2]; e.c2 = v[3]; e.m1 = v[4]; e.m2 = v[5]; e.ewrite = v[6]; e.eread = v[7];
     return e;
 }
 __device__ __forceinline__ Walk4Planes walk4_load_planes(const uint64_t* p)
@@ -120,14 +135,6 @@ __device__ __forceinline__ Walk4Planes walk4_load_planes(const uint64_t* p)
     const ul4v v = *reinterpret_cast<const MBAMD_AS_CONST ul4v*>((uintptr_t) p);
     Walk4Planes r;
     r.p[0] = v[0]; r.p[1] = v[1]; r.p[2] = v[2]; r.p[3] = v[3];
-    return r;
-}
-__device__ __forceinline__ Walk4Exps walk4_load_exps(const int8_t* p)
-{
-    const u16v v = *reinterpret_cast<const MBAMD_AS_CONST u16v*>((uintptr_t) p);
-    Walk4Exps r;
-#pragma unroll
-    for (int i = 0; i < 16; ++i) r.d[i] = v[i];
     return r;
 }
 // a bitplane in a scalar register pair IS a lane mask: one v_cndmask_b32 per state
@@ -140,16 +147,6 @@ __device__ __forceinline__ f4 walk4_tip_vector(const Walk4Planes& t, unsigned)
     asm("v_cndmask_b32_e64 %0, 0, 1.0, %1" : "=v"(v.w) : "s"(t.p[3]));
     return v;
 }
-// 64 exponent bytes in 16 scalar registers -> lane l gets byte l: the dwords go to lanes 0-15 of one VGPR
-// (v_writelane), every lane fetches dword l/4 through the LDS crossbar (ds_bpermute) and extracts its byte
-__device__ __forceinline__ int walk4_lane_exponent(const Walk4Exps& x, unsigned lane)
-{
-    int t = 0;
-#pragma unroll
-    for (int i = 0; i < 16; ++i) asm("v_writelane_b32 %0, %1, %2" : "+v"(t) : "s"(x.d[i]), "i"(i));
-    const int dw = __builtin_amdgcn_ds_bpermute((int) (lane & ~3u), t);          // byte address of lane l/4
-    return (int) (int8_t) ((unsigned) dw >> (8 * (lane & 3u)));
-}
 // LDS-DMA: 64 lanes x 16 bytes (base + lane16 each) straight into the 1 KiB LDS slot at byte address lds_dst
 // (lane-linear).  `base` is wave-uniform (scalar registers).  M0 is compiler-reserved: saved and restored inside.
 __device__ __forceinline__ void walk4_dma(const f4* base, unsigned lane16, unsigned lds_dst)
@@ -160,6 +157,13 @@ __device__ __forceinline__ void walk4_dma(const f4* base, unsigned lane16, unsig
     asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2 sc0 sc1\n\ts_mov_b32 m0, %0"
                  : "=&s"(keep) : "v"(lane16), "s"(base), "s"(lds_dst) : "memory");
 }
+// one signed byte per lane (base + lane) -> a dword per lane at LDS byte address lds_dst + 4 * lane
+__device__ __forceinline__ void walk4_dma_exps(const int8_t* base, unsigned lane, unsigned lds_dst)
+{
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_sbyte %1, %2\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(lane), "s"(base), "s"(lds_dst) : "memory");
+}
 // wait until at most n vector-memory instructions of this wave are outstanding (s_waitcnt takes an immediate: the
 // host rounds n down to one of these values; only entries that read a prefetched child come here)
 __device__ __forceinline__ void walk4_wait_vm(unsigned n)
@@ -168,7 +172,7 @@ __device__ __forceinline__ void walk4_wait_vm(unsigned n)
     switch (n) {
         MBAMD_W4_WAIT(1) MBAMD_W4_WAIT(2) MBAMD_W4_WAIT(3) MBAMD_W4_WAIT(4) MBAMD_W4_WAIT(5) MBAMD_W4_WAIT(6)
         MBAMD_W4_WAIT(8) MBAMD_W4_WAIT(10) MBAMD_W4_WAIT(12) MBAMD_W4_WAIT(16) MBAMD_W4_WAIT(20) MBAMD_W4_WAIT(24)
-        MBAMD_W4_WAIT(32) MBAMD_W4_WAIT(40) MBAMD_W4_WAIT(48) MBAMD_W4_WAIT(56)
+        MBAMD_W4_WAIT(32) MBAMD_W4_WAIT(40) MBAMD_W4_WAIT(48)
         default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
     }
 #undef MBAMD_W4_WAIT
@@ -183,7 +187,7 @@ __device__ __forceinline__ void walk4_barrier()
 // the values walk4_wait_vm implements, for the host: the largest supported count <= n
 __host__ __device__ inline unsigned walk4_round_wait(long n)
 {
-    const unsigned ok[] = {0, 1, 2, 3, 4, 5, 6, 8, 10, 12, 16, 20, 24, 32, 40, 48, 56};
+    const unsigned ok[] = {0, 1, 2, 3, 4, 5, 6, 8, 10, 12, 16, 20, 24, 32, 40, 48};
     unsigned r = 0;
     for (unsigned v : ok) if ((long) v <= n) r = v;
     return r;
@@ -215,97 +219,125 @@ __device__ __forceinline__ f4 walk4_matvec(const Walk4Mat& M, f4 v)
     return r;
 }
 
-// blockDim.x = 64 * W; grid = (pattern blocks, K).  Dynamic LDS: walk4_lds_bytes(W, nslots).
+// byte-offset addressing helpers (wave-uniform base + 32-bit offset: two scalar adds)
+template <class T> __device__ __forceinline__ T* walk4_at(T* base, unsigned byteOffset)
+{
+    return reinterpret_cast<T*>(reinterpret_cast<uintptr_t>(base) + byteOffset);
+}
+
+// blockDim.x = 64 * W; grid = walk4_grid(nblocks, K) workgroups.  Dynamic LDS: walk4_lds_bytes(W, nslots).
 __global__ void __launch_bounds__(64 * MBAMD_W4_MAXW)
 k_walk4(Walk4Args A)
 {
     const unsigned lane = threadIdx.x & 63;
 #if defined(MBAMD_HOST_EMU)
     const int wave = (int) (threadIdx.x >> 6);
-    f4* lds = reinterpret_cast<f4*>(mbamd_emu_dyn_lds());
+    char* lds = reinterpret_cast<char*>(mbamd_emu_dyn_lds());
 #else
     const int wave = __builtin_amdgcn_readfirstlane((int) (threadIdx.x >> 6));
     extern __shared__ f4 lds_walk4[];
-    f4* lds = lds_walk4;
+    char* lds = reinterpret_cast<char*>(lds_walk4);
 #endif
-    const unsigned blk = blockIdx.x, k = blockIdx.y;
     const unsigned K = (unsigned) A.K;
-    f4* const slots = lds + (size_t) wave * A.nslots * 64;                     // this wave's private slots
-    // this wave's columns (wave-uniform bases; lane offsets are added by the memory instructions):
-    // buffer i of each kind is `i * stride` further
+    // workgroup id -> (pattern block, category): see walk4_grid
+    const unsigned xcd = blockIdx.x & 7u, pos = blockIdx.x >> 3;
+    const unsigned blk = (pos / K) * 8u + xcd, k = pos % K;
+    if (blk >= (unsigned) A.nblocks) return;
+    char* const mine = lds + (size_t) wave * (MBAMD_W4_STAGE + (size_t) A.nslots * 1024);
+    int* const stage = reinterpret_cast<int*>(mine);                           // [2][64] landing areas of stored exponents
+    char* const slots = mine + MBAMD_W4_STAGE + lane * 16;                     // this wave's private slots, this lane's f4
+    // this wave's columns: wave-uniform bases, the entries hold byte offsets from them
     f4* const P0 = A.partials + (size_t) blk * A.pstride + (size_t) k * 64;
-    const unsigned pbuf = K * 64u;                                             // f4 per partials buffer within a block
-    const uint64_t* const T0 = A.tips + (size_t) blk * A.tstride;              // 4 planes per tip buffer
+    const uint64_t* const T0 = A.tips + (size_t) blk * A.tstride;
     int8_t* const E0 = A.exps + (size_t) blk * A.estride + (size_t) k * 64;
-    const unsigned ebuf = K * 64u;
     const float* const M0 = A.matrices + (size_t) k * 16;
-    const unsigned mbuf = K * 16u;
 #if defined(MBAMD_HOST_EMU)
-#define MBAMD_W4_PREFETCH(WORD) walk4_dma(P0 + ((WORD) & 0xFFFFu) * pbuf, lane, slots + (((WORD) >> 16) & 0xFFu) * 64)
+#define MBAMD_W4_PREFETCH(SRC, DST) walk4_dma(walk4_at(P0, SRC), lane, reinterpret_cast<f4*>(slots - lane * 16 + (DST)))
+#define MBAMD_W4_EXPS(OFF, PARITY) walk4_dma_exps(walk4_at(E0, OFF), lane, stage + 64 * (PARITY))
 #else
     const unsigned lane16 = lane * 16u;
-    const unsigned slots_lds = (unsigned) (uintptr_t) (__attribute__((address_space(3))) char*) slots;
-#define MBAMD_W4_PREFETCH(WORD) walk4_dma(P0 + ((WORD) & 0xFFFFu) * pbuf, lane16, slots_lds + (((WORD) >> 16) & 0xFFu) * 1024u)
+    const unsigned stage_lds = (unsigned) (uintptr_t) (__attribute__((address_space(3))) char*) mine;
+    const unsigned slots_lds = stage_lds + MBAMD_W4_STAGE;
+#define MBAMD_W4_PREFETCH(SRC, DST) walk4_dma(walk4_at(P0, SRC), lane16, slots_lds + (DST))
+#define MBAMD_W4_EXPS(OFF, PARITY) walk4_dma_exps(walk4_at(E0, OFF), lane, stage_lds + 256u * (PARITY))
 #endif
 
     const Walk4Entry* prog = A.prog + (size_t) wave * A.entries;
     const int n = A.entries - 2;
-    Walk4Entry D0 = walk4_load_entry(prog), D1 = walk4_load_entry(prog + 1);
-    Walk4Mat M1 = walk4_load_matrix(M0 + (D0.mats & 0xFFFFu) * mbuf);
-    Walk4Mat M2 = walk4_load_matrix(M0 + (D0.mats >> 16) * mbuf);
-    // inputs of entry 0 that come through the scalar path, already in their per-lane form
-    f4 tipA = walk4_tip_vector(walk4_load_planes(T0 + (D0.c1 & 0xFFFFu) * 4u), lane);
-    f4 tipB = walk4_tip_vector(walk4_load_planes(T0 + (D0.c2 & 0xFFFFu) * 4u), lane);
-    int eread = 0;
-    if (((D0.scale >> 16) & 0xFFu) == SCALE_READ) eread = walk4_lane_exponent(walk4_load_exps(E0 + (D0.sread & 0xFFFFu) * ebuf), lane);
+    Walk4Entry DA = walk4_load_entry(prog), DB = walk4_load_entry(prog + 1);
+    // inputs of entry 0
+    Walk4Mat M1 = walk4_load_matrix(walk4_at(M0, DA.m1));
+    Walk4Mat M2 = walk4_load_matrix(walk4_at(M0, DA.m2));
+    Walk4Planes T1 = walk4_load_planes(walk4_at(T0, (DA.ctl & MBAMD_W4_TIP1) ? DA.c1 : 0u));
+    Walk4Planes T2 = walk4_load_planes(walk4_at(T0, (DA.ctl & MBAMD_W4_TIP2) ? DA.c2 : 0u));
+    if (((DA.ctl >> 8) & 3u) == SCALE_READ) MBAMD_W4_EXPS(DA.eread, 0);
     int cum_e = 0;
 
-    // Vector-memory instruction sequence of iteration j (the host's vmwait counts on exactly this):
-    //     [DMA pf0] [DMA pf1]   s_waitcnt vmcnt(vmwait_j) if the entry reads a prefetched child   [2 stores, unless NOP]
-    // Everything wave-uniform is a scalar branch or a scalar select (no divergent control flow).
-    for (int j = 0; j < n; ++j) {
-        const Walk4Entry D2 = walk4_load_entry(prog + j + 2);
-        // scalar-path inputs of the NEXT entry: requested now, turned into per-lane values at the end of this iteration
-        // (a child that is not a tip reads the planes of buffer 0: a valid address, the value is not used)
-        const Walk4Planes np1 = walk4_load_planes(T0 + (D1.c1 & 0xFFFFu) * 4u);
-        const Walk4Planes np2 = walk4_load_planes(T0 + (D1.c2 & 0xFFFFu) * 4u);
-        // prefetches riding on this entry: children of this or later operations that live in HBM -> LDS slots
-        if (D0.pf0 & (1u << 24)) {
-            MBAMD_W4_PREFETCH(D0.pf0);
-            if (D0.pf1 & (1u << 24)) MBAMD_W4_PREFETCH(D0.pf1);
+    // One iteration = one entry.  Vector-memory instruction sequence (the host's vmwait counts on exactly this):
+    //     [DMA pf0] [DMA pf1] (PF entries)   s_waitcnt vmcnt(vmwait) (flag VMWAIT)
+    //     [exponent DMA for the next entry, if that is SCALE_READ]   [2 stores, if this entry is an operation]
+    // Everything wave-uniform is a scalar branch or a scalar select (no divergent control flow).  The loop is unrolled by
+    // two so that the two entry descriptors in flight keep their registers (no moves): `cur` is executed, `nxt` is the
+    // next one, and cur's registers receive entry j + 2.  ALL scalar loads of an iteration (next entry's matrices and tip
+    // planes, the entry after next) are issued in one burst as soon as this entry's matrix products are done, and are
+    // consumed after the next iteration's LDS reads: one lgkmcnt(0) per iteration covers both.
+    auto step = [&](Walk4Entry& cur, const Walk4Entry& nxt, int j, int parity) {
+        const unsigned ctl = cur.ctl;
+        bool run = true;
+        if (ctl & MBAMD_W4_RARE) {
+            if (ctl & MBAMD_W4_PF0) {
+                // PF entry: children of later operations that live in HBM -> LDS slots
+                MBAMD_W4_PREFETCH(cur.dst, cur.c1);
+                if (ctl & MBAMD_W4_PF1) MBAMD_W4_PREFETCH(cur.c2, cur.m1);
+            }
+            if (ctl & MBAMD_W4_VMWAIT) walk4_wait_vm((ctl >> 10) & 63u);       // what an LDS-DMA brought for this entry has landed
+            if (ctl & MBAMD_W4_BARRIER) walk4_barrier();
+            run = !(ctl & MBAMD_W4_NOP);
         }
-        const unsigned vmwait = D0.scale >> 24;
-        if (vmwait != MBAMD_W4_NOWAIT) walk4_wait_vm(vmwait);                   // the prefetched children this entry reads have landed
-        const unsigned flags = D0.dst >> 24;
-        if (flags & MBAMD_W4_BARRIER) walk4_barrier();
-        if (!(flags & MBAMD_W4_NOP)) {
-            const bool tip1 = (D0.c1 >> 24) == MBAMD_W4_TIP, tip2 = (D0.c2 >> 24) == MBAMD_W4_TIP;
-            f4 a = tipA, b = tipB;
-            if (!tip1) a = slots[((D0.c1 >> 16) & 0xFFu) * 64 + lane];
-            if (!tip2) b = slots[((D0.c2 >> 16) & 0xFFu) * 64 + lane];
+        const unsigned mode = (ctl >> 8) & 3u;
+        f4 out = {0.0f, 0.0f, 0.0f, 0.0f};
+        int er = 0;
+        if (run) {
+            f4 a, b;
+            if (ctl & MBAMD_W4_TIP1) a = walk4_tip_vector(T1, lane); else a = *reinterpret_cast<const f4*>(slots + cur.c1);
+            if (ctl & MBAMD_W4_TIP2) b = walk4_tip_vector(T2, lane); else b = *reinterpret_cast<const f4*>(slots + cur.c2);
+            if (mode == SCALE_READ) er = stage[64 * parity + lane];
             const f4 f1 = walk4_matvec(M1, a);
             const f4 f2 = walk4_matvec(M2, b);
-            f4 out;
             out.x = f1.x * f2.x; out.y = f1.y * f2.y; out.z = f1.z * f2.z; out.w = f1.w * f2.w;
-            const unsigned mode = (D0.scale >> 16) & 0xFFu;
+        }
+        // the scalar-load burst for the next entry (the registers of this entry's matrices / planes are free now); a
+        // child that is not a tip reads the planes at offset 0 -- a valid address, the value is not used
+        const unsigned dst = cur.dst, ewrite = cur.ewrite;
+        M1 = walk4_load_matrix(walk4_at(M0, nxt.m1));
+        M2 = walk4_load_matrix(walk4_at(M0, nxt.m2));
+        T1 = walk4_load_planes(walk4_at(T0, (nxt.ctl & MBAMD_W4_TIP1) ? nxt.c1 : 0u));
+        T2 = walk4_load_planes(walk4_at(T0, (nxt.ctl & MBAMD_W4_TIP2) ? nxt.c2 : 0u));
+        if (((nxt.ctl >> 8) & 3u) == SCALE_READ) MBAMD_W4_EXPS(nxt.eread, parity ^ 1);
+        cur = walk4_load_entry(prog + j + 2);
+        if (run) {
             const int wm = mode == SCALE_WRITE ? -1 : 0, rm = mode == SCALE_READ ? -1 : 0;
-            const int e = (scale_exponent(max4(out)) & wm) | (eread & rm);
+            const int e = (scale_exponent(max4(out)) & wm) | (er & rm);
             cum_e += e & wm;
             out.x = scale_pow2(out.x, -e); out.y = scale_pow2(out.y, -e);       // (2^0 is exact: no branch)
             out.z = scale_pow2(out.z, -e); out.w = scale_pow2(out.w, -e);
-            const unsigned dslot = (D0.dst >> 16) & 0xFFu;
-            if (dslot != 0xFFu) slots[dslot * 64 + lane] = out;
-            as_global(P0 + (D0.dst & 0xFFFFu) * pbuf)[lane] = out;              // 1 KiB contiguous per wave; never waited for
-            as_global(E0 + (D0.scale & 0xFFFFu) * ebuf)[lane] = (int8_t) e;
+            if (ctl & MBAMD_W4_KEEP) *reinterpret_cast<f4*>(slots + ((ctl >> 6) & 0x3FC00u)) = out;
+#if defined(MBAMD_HOST_EMU)
+            walk4_at(P0, dst)[lane] = out;
+            walk4_at(E0, ewrite)[lane] = (int8_t) e;
+#else
+            // 1 KiB contiguous per wave; never waited for.  Non-temporal: the result is not read again in this launch
+            // (parents read the LDS copy), so it must not push the matrices and programs out of L2
+            __builtin_nontemporal_store(out, as_global(walk4_at(P0, dst)) + lane);
+            __builtin_nontemporal_store((int8_t) e, as_global(walk4_at(E0, ewrite)) + lane);
+#endif
         }
-        // the next entry's matrices (the registers of this entry's are free now), its tips and its stored exponents
-        M1 = walk4_load_matrix(M0 + (D1.mats & 0xFFFFu) * mbuf);
-        M2 = walk4_load_matrix(M0 + (D1.mats >> 16) * mbuf);
-        tipA = walk4_tip_vector(np1, lane);
-        tipB = walk4_tip_vector(np2, lane);
-        if (((D1.scale >> 16) & 0xFFu) == SCALE_READ) eread = walk4_lane_exponent(walk4_load_exps(E0 + (D1.sread & 0xFFFFu) * ebuf), lane);
-        D0 = D1; D1 = D2;
+    };
+    for (int j = 0; j < n; j += 2) {
+        step(DA, DB, j, 0);
+        step(DB, DA, j + 1, 1);
     }
+#undef MBAMD_W4_EXPS
 #undef MBAMD_W4_PREFETCH
     if (A.cum != nullptr && cum_e != 0) atomicAdd(A.cum + (size_t) k * A.Ppad + (size_t) blk * 64 + lane, cum_e);
 }

@@ -40,11 +40,11 @@ struct Walk4Op {
 
 struct Walk4Template {
     struct Entry {
-        int op = -1;                               // -1: NOP
-        uint8_t flags = 0;
+        int op = -1;                               // -1: NOP or PF entry
+        uint8_t flags = 0;                         // NOP / BARRIER
         uint8_t c1slot = 0xFF, c2slot = 0xFF, dslot = 0xFF;   // child in an LDS slot (not a tip) / result kept in a slot
-        uint8_t vmwait = 0;
-        int pfOp[2] = {-1, -1};                    // prefetch: child pfChild of operation pfOp ...
+        uint8_t vmwait = 0xFF;                     // 0xFF: no wait
+        int pfOp[2] = {-1, -1};                    // PF entry: prefetch child pfChild of operation pfOp ...
         uint8_t pfChild[2] = {0, 0}, pfSlot[2] = {0, 0};      // ... into this slot
     };
     std::vector<int> key;
@@ -236,13 +236,11 @@ inline bool Walk4Builder::build(const std::vector<Walk4Op>& ops, Walk4Template& 
         }
     size_t longest = 0;
     for (int w = 0; w < W; ++w) longest = std::max(longest, items[w].size());
-    const int entries = (int) longest + 2;
     t.W = W;
-    t.entries = entries;
     t.phases = nphases;
     t.reloads = t.externals = 0;
-    t.prog.assign((size_t) W * entries, Walk4Template::Entry());
-    for (Walk4Template::Entry& e : t.prog) e.flags = MBAMD_W4_NOP;
+    std::vector<std::vector<Walk4Template::Entry>> fin(W);     // final per-wave programs (PF entries inserted)
+    std::vector<Walk4Template::Entry> scan;
 
     // ---- slots, prefetches, wait counts: one linear scan per wave -------------------------------------------------
     int slotsUsed = 1;
@@ -257,7 +255,8 @@ inline bool Walk4Builder::build(const std::vector<Walk4Op>& ops, Walk4Template& 
     std::vector<int> freeFrom(S);                              // slot is free for a DMA issued at positions >= freeFrom
     for (int w = 0; w < W; ++w) {
         const int L = (int) items[w].size();
-        Walk4Template::Entry* prog = t.prog.data() + (size_t) w * entries;
+        scan.assign((size_t) L, Walk4Template::Entry());
+        Walk4Template::Entry* prog = scan.data();
         std::fill(slotHolder.begin(), slotHolder.end(), -1);
         std::fill(freeFrom.begin(), freeFrom.end(), 0);
         // last same-wave use of every result of this wave
@@ -423,12 +422,30 @@ inline bool Walk4Builder::build(const std::vector<Walk4Op>& ops, Walk4Template& 
                 }
             }
         }
-        // 4. wait counts: replay the vector-memory instruction sequence of the kernel loop
-        //    iteration j: [pf DMAs] WAIT [2 stores unless NOP]
-        long issued = 0;                                        // instructions issued so far
+        // 4. final program: a PF entry in front of every entry that carries prefetches
+        std::vector<Walk4Template::Entry>& out = fin[w];
+        out.clear();
+        for (int j = 0; j < L; ++j) {
+            Walk4Template::Entry e = prog[j];
+            if (e.pfOp[0] >= 0) {
+                Walk4Template::Entry pf;
+                pf.flags = MBAMD_W4_NOP;
+                for (int q = 0; q < 2; ++q) { pf.pfOp[q] = e.pfOp[q]; pf.pfChild[q] = e.pfChild[q]; pf.pfSlot[q] = e.pfSlot[q]; }
+                out.push_back(pf);
+                e.pfOp[0] = e.pfOp[1] = -1;
+            }
+            out.push_back(e);
+        }
+        // 5. wait counts: replay the vector-memory instruction sequence of the kernel loop (mbamd_walk4.h)
+        //    prologue: [exponent DMA for entry 0 if SCALE_READ]
+        //    iteration: [PF DMAs] WAIT [exponent DMA for the next entry if SCALE_READ] [2 stores if an operation]
+        auto reads = [&](const Walk4Template::Entry& e) { return e.op >= 0 && ops[e.op].scaleRead >= 0 && ops[e.op].scaleWrite < 0; };
+        long issued = 0;
+        long expSeq = -1;                                       // sequence number of the exponent DMA of the entry about to run
+        if (!out.empty() && reads(out[0])) expSeq = issued++;
         std::vector<long> pfSeq(mems.size(), -1);
-        for (int j = 0; j < entries; ++j) {
-            Walk4Template::Entry& e = prog[j];
+        for (size_t j = 0; j < out.size(); ++j) {
+            Walk4Template::Entry& e = out[j];
             for (int q = 0; q < 2; ++q)
                 if (e.pfOp[q] >= 0) {
                     for (size_t mi = 0; mi < mems.size(); ++mi)
@@ -437,14 +454,25 @@ inline bool Walk4Builder::build(const std::vector<Walk4Op>& ops, Walk4Template& 
                     ++issued;
                 }
             long needed = -1;
-            if (e.op >= 0)
+            if (e.op >= 0) {
                 for (size_t mi = 0; mi < mems.size(); ++mi)
                     if (mems[mi].op == e.op && pfSeq[mi] >= 0) needed = std::max(needed, pfSeq[mi]);
-            if (needed < 0) e.vmwait = MBAMD_W4_NOWAIT;
+                if (reads(e)) needed = std::max(needed, expSeq);
+            }
+            if (needed < 0) e.vmwait = 0xFF;                        // (no wait)
             else e.vmwait = safeWaits ? 0 : (uint8_t) walk4_round_wait(issued - (needed + 1));
-            if (!(e.flags & MBAMD_W4_NOP)) issued += 2;
+            expSeq = -1;
+            if (j + 1 < out.size() && reads(out[j + 1])) expSeq = issued++;
+            if (e.op >= 0) issued += 2;
         }
     }
+    size_t longestFinal = 0;
+    for (int w = 0; w < W; ++w) longestFinal = std::max(longestFinal, fin[w].size());
+    const int entries = (((int) longestFinal + 1) & ~1) + 2;     // even (the kernel loop is unrolled by two) + two read-ahead NOPs
+    t.entries = entries;
+    t.prog.assign((size_t) W * entries, Walk4Template::Entry());
+    for (Walk4Template::Entry& e : t.prog) e.flags = MBAMD_W4_NOP;
+    for (int w = 0; w < W; ++w) std::copy(fin[w].begin(), fin[w].end(), t.prog.begin() + (size_t) w * entries);
     t.nslots = slotsUsed;
     return true;
 }
