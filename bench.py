@@ -4,12 +4,21 @@
 integration) issued through the C ABI exactly as MrBayes' src/mbbeagle.c issues it for a generation whose
 move dirties the whole tree (reference src/proposal.c:17682, src/mbbeagle.c:400-537).
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--config c2|c3|c4|c5] [--no-cpu-baseline]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--config c2|c3|c4|c5] [--no-cpu-baseline] [--no-also] [--no-mcmc]
+
+Default workload: BASELINE configs[3]'s shape, synthetic DNA 1000 taxa x 50 000 patterns GTR+G4 (the shape the
+>=100x target is quoted on; it fits one GPU), one chain per GPU.  At N=1 the line also carries, under "also", the
+same measurement on configs[1] (DNA 500 x 20 000) and, under "mcmc_gen_per_s", whole-MCMC generations/s of the
+unmodified MrBayes binary on this engine next to its native CPU kernels (short windows; --no-also / --no-mcmc skip
+them).  Every workload is a committed golden case (tests/golden/bench_c*.json): alignment seeds, tree and parameters
+are those the REAL reference was run on by tools/gen_golden.py, and the lnL printed in "config" is asserted against
+the reference's value before anything is timed.
 
 N > 1 (launched by torch.distributed.run, one rank per GPU): every rank owns one heated chain of the same
 shape on its own GPU (chain-parallel MCMCMC, the reference's MPI strategy, src/mcmc.c:18331-18384); the only
 exchange is the per-generation swap attempt: the two ranks that own the drawn chains send each other (lnL,
-lnPrior, heat) over RCCL, everybody else carries on (src/mcmc.c:653-668).  Weak scaling.
+lnPrior, heat) over RCCL, everybody else carries on (src/mcmc.c:653-668).  Weak scaling.  (A scaling harness: every
+rank replays full evaluations of its own chain state; the swap decision is made but does not change what is replayed.)
 
 Prints ONE JSON line on rank 0.  Unit of work = node-pattern update: one interior-node
 conditional-likelihood update of one unique site pattern over all categories, rescale included.
@@ -22,16 +31,18 @@ import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+GOLD = os.path.join(ROOT, "tests", "golden")
 
 CONFIGS = {
-    # name: (kind, ntaxa, npatterns, alignment seed, tree seed, description)
-    "c2": ("gtr", 500, 20000, 7, 3, "synthetic DNA 500 taxa x 20000 unique patterns, GTR+G4, 1 chain per GPU"),
-    "c3": ("wag", 200, 10000, 5, 9, "synthetic amino-acid 200 taxa x 10000 patterns, WAG+G4"),
-    "c4": ("gtr", 1000, 50000, 6, 10, "synthetic DNA 1000 taxa x 50000 patterns, GTR+G4, 1 chain per GPU"),
-    "c5": ("m3", 100, 5000, 6, 10, "synthetic codon M3 (61 states, 3 omega classes) 100 taxa x 5000 patterns"),
+    # name: (golden case, model kind, description)
+    "c2": ("bench_c2", "gtr", "synthetic DNA 500 taxa x 20000 unique patterns, GTR+G4, 1 chain per GPU"),
+    "c3": ("bench_c3", "wag", "synthetic amino-acid 200 taxa x 10000 patterns, WAG+G4"),
+    "c4": ("bench_c4", "gtr", "synthetic DNA 1000 taxa x 50000 patterns, GTR+G4, 1 chain per GPU"),
+    "c5": ("bench_c5", "m3", "synthetic codon M3 (61 states, 3 omega classes) 100 taxa x 5000 patterns"),
 }
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy)
 FP32_PEAK_TFLOPS = 157.3       # fp32 MFMA = fp32 vector peak
+REL_FP64 = 2e-6                # lnL vs the reference's fp64 build (tests/engine_checks.py)
 
 
 def algorithmic_bytes_per_eval(S, K, P, N):
@@ -43,28 +54,32 @@ def flops_per_eval(S, K, P, N):
     return P * (N - 2) * K * (2 * S * S * 2 + S)
 
 
-def cpu_baseline(kind, ntaxa, seed, tree_seed, budget_patterns):
-    """The reference CPU likelihood on this box's host cores, on a bounded sample of the same workload."""
+def cpu_baseline(kind, gold, sample_patterns):
+    """The reference CPU likelihood (oracle/_ref/mb, the real reference's FMA/SSE kernels, one core) on this box's
+    host cores, on a bounded sample of the SAME alignment and tree: its first `sample_patterns` columns."""
     from mrbayes_amd import data as mbdata
     from mrbayes_amd import tree as mbtree
     from tools import refrun
-    if kind == "gtr" and refrun.reference_available():
-        npat = budget_patterns
-        st = mbdata.synthetic_states(ntaxa, npat, 4, seed, 0.15, 0.0)
-        tr = mbtree.random_tree(ntaxa, tree_seed, brlen=0.05)
-        lo, hi = 10, 110
-        r = refrun.time_reference_dna(st, tr, lo, hi)
-        p = r.get("npatterns", npat)
+    sy = gold["synthetic"]
+    ntaxa = sy["ntaxa"]
+    tr = mbtree.parse_newick(gold["newick"])
+    if refrun.reference_available():
+        st = mbdata.synthetic_states(ntaxa, sy["nsites"], sy["nstates"], sy["seed"], sy["p_mut"], sy["p_gap"])[:, :sample_patterns]
+        lo, hi = {"gtr": (10, 70), "wag": (4, 28), "m3": (2, 14)}[kind]
+        r = refrun.time_reference(kind, st, tr, lo, hi)
+        p = r.get("npatterns", sample_patterns)
         ups = (ntaxa - 2) * p / r["sec_per_eval"]
         return {"value": ups / 1e6, "unit": "M updates/s", "cores": 1, "kind": "reference",
-                "sample": "oracle/_ref/mb (%s kernels), same tree, first %d patterns, fixed-tree two-point CPU time "
-                          "ngen=%d vs %d: %.4f s per full-tree evaluation" % (r["calculator"], p, lo, hi, r["sec_per_eval"])}
+                "sample": "oracle/_ref/mb (%s kernels, single-threaded like the reference), same tree, the first %d of the %d "
+                          "patterns of the same alignment, fixed-tree two-point CPU time ngen=%d vs %d: %.4f s per full-tree evaluation"
+                          % (r["calculator"], p, sy["nsites"], lo, hi, r["sec_per_eval"])}
     # port: the plain-C oracle (scalar restatement), one core
-    from mrbayes_amd.division import synthetic_division
+    from mrbayes_amd.division import division_from_golden
     from tests import oracle_lib
-    npat = max(64, budget_patterns // (8 if kind == "gtr" else 40 if kind == "wag" else 400))
-    div = synthetic_division(kind, ntaxa, npat, seed=seed, tree_seed=tree_seed,
-                             golden_dir=os.path.join(ROOT, "tests", "golden"))
+    div = division_from_golden(GOLD, gold["case"])
+    npat = max(64, sample_patterns // (8 if kind == "gtr" else 10))
+    div.weights = div.weights[:npat]
+    div.tip_states = [s[:npat].copy() for s in div.tip_states]
     orc = oracle_lib.load()
     t0 = time.time()
     reps = 0
@@ -76,24 +91,28 @@ def cpu_baseline(kind, ntaxa, seed, tree_seed, budget_patterns):
             "sample": "oracle/mb_oracle.c (scalar), same tree, first %d patterns, %d evaluations" % (npat, reps)}
 
 
-def mcmc_gen_per_s(ntaxa, npat, seed, tree_seed, nchains=1):
-    """Secondary metric: generations/s of the UNMODIFIED MrBayes (default move mix, GTR+G4) driving this engine
-    (oracle/_ref/mb_amd) next to the same binary's native CPU kernels (oracle/_ref/mb), two-point differenced
-    so that parsing / pattern compression / set-up cancel.  Only where the reference binaries were built."""
+def mcmc_gen_per_s(gold, nchains=1, quick=True):
+    """Secondary metric: generations/s of the UNMODIFIED MrBayes (GTR+G4) driving this engine (oracle/_ref/mb_amd)
+    next to the same binary's native CPU kernels (oracle/_ref/mb), two-point differenced so that parsing / pattern
+    compression / set-up cancel.  Only where the reference binaries were built."""
     from mrbayes_amd import data as mbdata
     from mrbayes_amd import tree as mbtree
     from tools import refrun
     if not (os.path.exists(refrun.REF_MB_AMD) and os.path.exists(refrun.REF_MB)):
         return None
-    st = mbdata.synthetic_states(ntaxa, npat, 4, seed, 0.15, 0.0)
-    tr = mbtree.random_tree(ntaxa, tree_seed, brlen=0.05)
-    out = {"nchains": nchains, "note": "default mix: 11.5% of the moves are ParsSPR/ParsTBR, whose O(taxa x patterns) parsimony "
-           "scoring runs on the host in both builds (SURVEY 8(f) item 4); fixed_topology = branch-length and "
-           "substitution-parameter moves only (prset topologypr=fixed)"}
+    sy = gold["synthetic"]
+    st = mbdata.synthetic_states(sy["ntaxa"], sy["nsites"], 4, sy["seed"], sy["p_mut"], sy["p_gap"])
+    tr = mbtree.parse_newick(gold["newick"])
+    out = {"workload": gold["case"], "nchains": nchains,
+           "note": "default_moves: MrBayes' default proposal mix; 11.5% of its moves are ParsSPR/ParsTBR, whose O(taxa x "
+                   "patterns) parsimony scoring runs on the host in both builds (SURVEY 8(f) item 4) and bounds the rate; "
+                   "fixed_topology = branch-length and substitution-parameter moves only (prset topologypr=fixed)"}
+    windows = {(False, "engine"): (300, 1300) if quick else (500, 2500), (True, "engine"): (2000, 12000) if quick else (2000, 22000),
+               (False, "reference_cpu"): (10, 40) if quick else (20, 80), (True, "reference_cpu"): (20, 70) if quick else (20, 120)}
     for mix, fixed in (("default_moves", False), ("fixed_topology", True)):
         res = {}
-        for tag, binary, beagle, lo, hi in (("engine", refrun.REF_MB_AMD, "dynamic", 2000 if fixed else 500, 22000 if fixed else 2500),
-                                            ("reference_cpu", refrun.REF_MB, None, 20, 120 if fixed else 80)):
+        for tag, binary, beagle in (("engine", refrun.REF_MB_AMD, "dynamic"), ("reference_cpu", refrun.REF_MB, None)):
+            lo, hi = windows[(fixed, tag)]
             walls = []
             for ngen in (lo, hi):
                 _, wall = refrun.run_mb(binary, refrun.mcmc_nexus(st, tr, ngen, beagle=beagle, nchains=nchains,
@@ -106,16 +125,152 @@ def mcmc_gen_per_s(ntaxa, npat, seed, tree_seed, nchains=1):
     return out
 
 
+def measure(args, cfg, steps, warmup, rank, local_rank, world, dist, device, emulate, lib, want_cpu_baseline):
+    """One workload: build the division from its golden case, check the lnL against the reference's, time `steps`
+    full-tree evaluations.  Returns the JSON object (rank 0) or None."""
+    import torch
+    from mrbayes_amd import likelihood as lk
+    from mrbayes_amd.division import division_from_golden, synthetic_division
+
+    case, kind, desc = CONFIGS[cfg]
+    with open(os.path.join(GOLD, case + ".json")) as fh:
+        gold = json.load(fh)
+    if emulate:
+        desc = "EMULATED (invalid as a measurement): " + desc
+        div = synthetic_division(kind, 16, 200, seed=3, tree_seed=4, golden_dir=GOLD)
+    else:
+        div = division_from_golden(GOLD, case)
+    if world > 1:                      # every chain has its own state: perturb the branch lengths per rank
+        import random
+        rng = random.Random(1000 + rank)
+        div.tree.length = [l * (0.8 + 0.4 * rng.random()) for l in div.tree.length]
+    bd = lk.BeagleDivision(div, lib, nchains=1, scaling=lk.MB_BEAGLE_SCALE_ALWAYS, resource=0 if emulate else local_rank)
+    impl = bd.inst.details.implName.decode()
+    lnl0 = bd.LogLike(0)
+    ref_lnl = gold["lnL"]["fp64"]
+    pinned = world == 1 and not emulate
+    if pinned:                         # the workload IS the golden case: its lnL is the reference's, or nothing is timed
+        assert abs(lnl0 - ref_lnl) <= REL_FP64 * abs(ref_lnl), (cfg, lnl0, ref_lnl)
+    bd.AcceptMove(0)
+    evals = [lk.record_evaluation(bd), lk.record_evaluation(bd)]      # the two alternating buffer-flip states
+    S, K, P, N = div.nstates, div.ncat * div.n_cijk_parts, div.npatterns, div.ntaxa
+    units_per_step = (N - 2) * P
+
+    from mrbayes_amd import chains as mbchains
+    exchange = mbchains.ChainExchange(world, dist=dist, device=device) if dist is not None else None
+    if exchange is not None:
+        exchange.warm_up()             # open the pairwise connections outside the timed region
+
+    def step(i):
+        rc, lnl = evals[i & 1].run()
+        if rc != 0:
+            raise RuntimeError("evaluation failed with code %d" % rc)
+        if exchange is not None:       # per-generation swap attempt: the two ranks that own the chains exchange states (RCCL)
+            exchange.swap_generation({rank: lnl})
+        return lnl
+
+    def fence():
+        if dist is not None:
+            dist.barrier()
+        if not emulate:
+            torch.cuda.synchronize()
+
+    for i in range(warmup):
+        step(i)
+    bd.inst.kernel_timing(True)
+    bd.inst.get_kernel_timing(reset=True)
+    fence()
+    t0 = time.perf_counter()
+    lnl = None
+    for i in range(steps):
+        lnl = step(i)
+    fence()
+    dt = time.perf_counter() - t0
+    kms, klaunches = bd.inst.get_kernel_timing(reset=True)
+    bd.inst.kernel_timing(False)
+    if dist is not None:
+        tmax = torch.tensor([dt], dtype=torch.float64, device=device)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dt = float(tmax.item())
+    assert abs(lnl - lnl0) <= 1e-9 * abs(lnl0), (lnl, lnl0)
+    bd.finalize()
+    if rank != 0:
+        return None
+
+    ms_per_step = dt / steps * 1e3
+    value = units_per_step * world * steps / dt / 1e6
+    k_ms = kms / max(steps, 1)                # the partials kernels (the dominant ones) per evaluation, HIP events on the engine's stream
+    abytes = algorithmic_bytes_per_eval(S, K, P, N)
+    aflops = flops_per_eval(S, K, P, N)
+    if S == 61:
+        roof = {"bound": "mfma", "achieved": aflops / (k_ms * 1e-3) / 1e12, "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s"}
+    else:
+        roof = {"bound": "hbm", "achieved": abytes / (k_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s"}
+    roof["frac"] = roof["achieved"] / roof["peak"]
+    roof["definition"] = ("achieved = ALGORITHMIC %s per evaluation (SURVEY 8(d)) / time of the partials kernels only (transition-matrix "
+                          "and root-integration kernels excluded: a few us each, profiles/).  The kernels keep children in LDS, so the "
+                          "physical traffic is lower: see traffic / physical_*" % ("flops" if S == 61 else "bytes"))
+    roof["traffic"] = None                    # HBM bytes per evaluation from committed PMC passes of this workload, if any
+    try:
+        with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as fh:
+            pmc = json.load(fh).get(cfg)
+        if pmc and not emulate:
+            roof["traffic"] = pmc["traffic_bytes"]
+            roof["traffic_source"] = pmc["source"]
+            roof["physical_achieved_GBs"] = pmc["traffic_bytes"] / (k_ms * 1e-3) / 1e9
+            roof["physical_frac"] = roof["physical_achieved_GBs"] / HBM_PEAK_GBS
+            for key in ("mfma_issued_tflops", "mfma_issued_frac", "mfma_busy_fraction"):
+                if key in pmc:
+                    roof[key] = pmc[key]
+    except (OSError, ValueError):
+        pass
+    roof["kernel"] = impl
+    roof["kernel_ms_per_step"] = k_ms
+    roof["launches_per_step"] = klaunches / max(steps, 1)
+    roof["algorithmic_bytes_per_step"] = abytes
+    roof["flops_per_step"] = aflops
+    if S == 20:
+        roof["secondary_tflops"] = aflops / (k_ms * 1e-3) / 1e12
+    out = {
+        "metric": "site-pattern lnL (node-pattern conditional-likelihood) updates/sec",
+        "value": value, "unit": "M updates/s", "n_gpus": world, "steps": steps, "warmup": warmup,
+        "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "f32", "data": "synthetic" if not emulate else "INVALID: emulated control-flow test",
+        "config": {"workload": desc, "golden_case": case, "states": S, "categories": K, "patterns": P, "taxa": N,
+                   "chains": world, "parallelism": "chain-parallel (1 chain per GPU)" if world > 1 else "1 chain",
+                   "units_per_step": units_per_step, "lnL": lnl,
+                   "lnL_reference_fp64": ref_lnl if pinned else None,
+                   "lnL_pinned": bool(pinned)},
+        "pattern_lnl_per_s": P * world * steps / dt,
+        "full_tree_evals_per_s": world * steps / dt,
+        "roofline": roof,
+    }
+    if world > 1:
+        out["config"]["note"] = ("scaling harness: every rank replays full evaluations of its own (perturbed) chain state; the "
+                                 "per-generation swap attempt is exchanged over RCCL but does not change what is replayed")
+    if want_cpu_baseline and world == 1 and not emulate:
+        try:
+            sample = {"gtr": args.cpu_sample_patterns, "wag": args.cpu_sample_patterns // 4, "m3": args.cpu_sample_patterns // 16}[kind]
+            gold["case"] = case
+            out["cpu_baseline"] = cpu_baseline(kind, gold, sample)
+            out["speedup_vs_cpu_baseline"] = value / out["cpu_baseline"]["value"]
+        except Exception as exc:          # the baseline is a report, never a reason to lose the bench line
+            out["cpu_baseline"] = {"value": None, "unit": "M updates/s", "cores": 1, "kind": "port",
+                                   "sample": "failed: %r" % (exc,)}
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
-    ap.add_argument("--config", default="c2", choices=sorted(CONFIGS))
+    ap.add_argument("--config", default="c4", choices=sorted(CONFIGS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-sample-patterns", type=int, default=4000)
-    ap.add_argument("--mcmc", action="store_true", help="also time whole MCMC generations of the unmodified MrBayes "
-                    "binary on this engine vs its native CPU kernels (adds minutes)")
+    ap.add_argument("--cpu-sample-patterns", type=int, default=8000)
+    ap.add_argument("--no-also", action="store_true", help="skip the second workload (configs[1], DNA 500 x 20000) at N=1")
+    ap.add_argument("--no-mcmc", action="store_true", help="skip whole-MCMC generations/s of the unmodified MrBayes binary")
+    ap.add_argument("--mcmc", action="store_true", help="longer MCMC windows (adds minutes)")
     ap.add_argument("--emulate", action="store_true",
                     help="TEST ONLY: run the control flow on the CPU (host-emulation engine, gloo, tiny workload); "
                          "the JSON line is marked invalid")
@@ -145,125 +300,30 @@ def main():
         dist = dist_
 
     from mrbayes_amd import beagle as bg
-    from mrbayes_amd import likelihood as lk
-    from mrbayes_amd.division import synthetic_division
-
-    kind, ntaxa, npat, seed, tree_seed, desc = CONFIGS[args.config]
-    if emulate:
-        ntaxa, npat, desc = 16, 200, "EMULATED (invalid as a measurement): " + desc
-    div = synthetic_division(kind, ntaxa, npat, seed=seed, tree_seed=tree_seed,
-                             golden_dir=os.path.join(ROOT, "tests", "golden"))
-    if world > 1:                      # every chain has its own state: perturb the branch lengths per rank
-        import random
-        rng = random.Random(1000 + rank)
-        div.tree.length = [l * (0.8 + 0.4 * rng.random()) for l in div.tree.length]
     if emulate:
         from tests.hostemu import build_emu
         lib = bg.library(build_emu.build())
     else:
         lib = bg.library()
-    bd = lk.BeagleDivision(div, lib, nchains=1, scaling=lk.MB_BEAGLE_SCALE_ALWAYS, resource=0 if emulate else local_rank)
-    impl = bd.inst.details.implName.decode()
-    lnl0 = bd.LogLike(0)
-    bd.AcceptMove(0)
-    evals = [lk.record_evaluation(bd), lk.record_evaluation(bd)]      # the two alternating buffer-flip states
-    S, K, P, N = div.nstates, div.ncat * div.n_cijk_parts, div.npatterns, div.ntaxa
-    units_per_step = (N - 2) * P
 
-    from mrbayes_amd import chains as mbchains
-    exchange = mbchains.ChainExchange(world, dist=dist, device=device) if dist is not None else None
-    if exchange is not None:
-        exchange.warm_up()             # open the pairwise connections outside the timed region
-
-    def step(i):
-        rc, lnl = evals[i & 1].run()
-        if rc != 0:
-            raise RuntimeError("evaluation failed with code %d" % rc)
-        if exchange is not None:       # per-generation swap attempt: the two ranks that own the chains exchange states (RCCL)
-            exchange.swap_generation({rank: lnl})
-        return lnl
-
-    def fence():
-        if dist is not None:
-            dist.barrier()
-        if not emulate:
-            torch.cuda.synchronize()
-
-    for i in range(args.warmup):
-        step(i)
-    bd.inst.kernel_timing(True)
-    bd.inst.get_kernel_timing(reset=True)
-    fence()
-    t0 = time.perf_counter()
-    lnl = None
-    for i in range(args.steps):
-        lnl = step(i)
-    fence()
-    dt = time.perf_counter() - t0
-    kms, klaunches = bd.inst.get_kernel_timing(reset=True)
-    bd.inst.kernel_timing(False)
-    if dist is not None:
-        tmax = torch.tensor([dt], dtype=torch.float64, device=device)
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        dt = float(tmax.item())
-    assert abs(lnl - lnl0) <= 1e-9 * abs(lnl0), (lnl, lnl0)
-
-    if rank == 0:
-        ms_per_step = dt / args.steps * 1e3
-        value = units_per_step * world * args.steps / dt / 1e6
-        k_ms = kms / max(args.steps, 1)               # partials pass (dominant kernel) per evaluation
-        abytes = algorithmic_bytes_per_eval(S, K, P, N)
-        aflops = flops_per_eval(S, K, P, N)
-        if S == 61:
-            roof = {"bound": "mfma", "achieved": aflops / (k_ms * 1e-3) / 1e12, "peak": FP32_PEAK_TFLOPS,
-                    "unit": "TFLOP/s"}
-        else:
-            roof = {"bound": "hbm", "achieved": abytes / (k_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s"}
-        roof["frac"] = roof["achieved"] / roof["peak"]
-        roof["traffic"] = None            # HBM bytes per launch from committed PMC passes of this workload, if any
-        try:
-            with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as fh:
-                pmc = json.load(fh).get(args.config)
-            if pmc and not emulate:
-                roof["traffic"] = pmc["traffic_bytes"]
-                roof["traffic_source"] = pmc["source"]
-                if "mfma_busy_fraction" in pmc:       # SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE x CUs), same PMC passes
-                    roof["mfma_busy_fraction"] = pmc["mfma_busy_fraction"]
-        except (OSError, ValueError):
-            pass
-        roof["kernel"] = impl
-        roof["kernel_ms_per_step"] = k_ms
-        roof["launches_per_step"] = klaunches / max(args.steps, 1)
-        roof["algorithmic_bytes_per_step"] = abytes
-        roof["flops_per_step"] = aflops
-        if S == 20:
-            roof["secondary_tflops"] = aflops / (k_ms * 1e-3) / 1e12
-        out = {
-            "metric": "site-pattern lnL (node-pattern conditional-likelihood) updates/sec",
-            "value": value, "unit": "M updates/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32", "data": "synthetic" if not emulate else "INVALID: emulated control-flow test",
-            "config": {"workload": desc, "states": S, "categories": K, "patterns": P, "taxa": N,
-                       "chains": world, "parallelism": "chain-parallel (1 chain per GPU)" if world > 1 else "1 chain",
-                       "units_per_step": units_per_step, "lnL": lnl},
-            "pattern_lnl_per_s": P * world * args.steps / dt,
-            "full_tree_evals_per_s": world * args.steps / dt,
-            "roofline": roof,
-        }
-        if not args.no_cpu_baseline and world == 1 and not emulate:
+    out = measure(args, args.config, args.steps, args.warmup, rank, local_rank, world, dist, device, emulate, lib,
+                  not args.no_cpu_baseline)
+    if rank == 0 and world == 1 and not emulate:
+        if not args.no_also and args.config != "c2":
             try:
-                out["cpu_baseline"] = cpu_baseline(kind, ntaxa, seed, tree_seed, args.cpu_sample_patterns)
-                out["speedup_vs_cpu_baseline"] = value / out["cpu_baseline"]["value"]
-            except Exception as exc:          # the baseline is a report, never a reason to lose the bench line
-                out["cpu_baseline"] = {"value": None, "unit": "M updates/s", "cores": 1, "kind": "port",
-                                       "sample": "failed: %r" % (exc,)}
-        if args.mcmc and world == 1 and not emulate and kind == "gtr":
+                also = measure(args, "c2", max(args.steps, 200), args.warmup, 0, local_rank, 1, None, device, False, lib,
+                               not args.no_cpu_baseline)
+                out["also"] = [also]
+            except Exception as exc:
+                out["also"] = [{"error": repr(exc)}]
+        if not args.no_mcmc:
             try:
-                out["mcmc_gen_per_s"] = mcmc_gen_per_s(ntaxa, npat, seed, tree_seed)
+                with open(os.path.join(GOLD, "bench_c2.json")) as fh:
+                    out["mcmc_gen_per_s"] = mcmc_gen_per_s(json.load(fh), quick=not args.mcmc)
             except Exception as exc:
                 out["mcmc_gen_per_s"] = {"error": repr(exc)}
+    if rank == 0:
         print(json.dumps(out))
-    bd.finalize()
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()

@@ -54,6 +54,56 @@ void mbo_tiprobs_gen(int n, int K, const double *eigvals, const double *cijk,
         tiprobs_one(n, eigvals, cijk, length * rate[k], bs, out + (size_t) k * n * n);
 }
 
+/* Closed-form 4x4 transition probabilities of the nst=2 (HKY85 / F84-style kappa) and nst=1 (Jukes-Cantor) models:
+ * TiProbs_Hky (src/likelihood.c:9709-9838) and TiProbs_JukesCantor (src/likelihood.c:9846-9960), t = length*rate[k]
+ * (rate[k] = baseRate*catRate[k]), identity below TIME_MIN, stationary above TIME_MAX (src/bayes.h:321-322).
+ * The BEAGLE seam never calls them (MrBayes sends an eigen-system for every nst), so these are the reference for
+ * "the engine's eigen path reproduces the closed forms". */
+#define MBO_TIME_MIN 1.0E-11
+#define MBO_TIME_MAX 100.0
+void mbo_tiprobs_hky(int K, double kap, const double *pis, double length, const double *rate, float *out)
+{
+    double beta = 0.5 / ((pis[0] + pis[2]) * (pis[1] + pis[3]) + kap * ((pis[0] * pis[2]) + (pis[1] * pis[3])));
+    double bigPi_j[4] = {pis[0] + pis[2], pis[1] + pis[3], pis[0] + pis[2], pis[1] + pis[3]};
+    int index = 0;
+    for (int k = 0; k < K; k++) {
+        double t = length * rate[k];
+        for (int i = 0; i < 4; i++)
+            for (int j = 0; j < 4; j++) {
+                if (t < MBO_TIME_MIN) { out[index++] = (i == j) ? 1.0f : 0.0f; continue; }
+                if (t > MBO_TIME_MAX) { out[index++] = (float) pis[j]; continue; }
+                double bigPij = bigPi_j[j], pij = pis[j];
+                double u = 1.0 / bigPij - 1.0;
+                double w = -beta * (1.0 + bigPij * (kap - 1.0));
+                double x = exp(-beta * t);
+                double y = exp(w * t);
+                double z = (bigPij - pij) / bigPij;
+                if (i == j)
+                    out[index++] = (float) (pij + pij * u * x + z * y);
+                else if ((i == 0 && j == 2) || (i == 2 && j == 0) || (i == 1 && j == 3) || (i == 3 && j == 1))
+                    out[index++] = (float) (pij + pij * u * x - (pij / bigPij) * y);
+                else
+                    out[index++] = (float) (pij * (1.0 - x));
+            }
+    }
+}
+
+void mbo_tiprobs_jc(int K, double length, const double *rate, float *out)
+{
+    int index = 0;
+    for (int k = 0; k < K; k++) {
+        double t = length * rate[k];
+        float pChange = (float) (0.25 - 0.25 * exp(-(4.0 / 3.0) * t));
+        float pNoChange = (float) (0.25 + 0.75 * exp(-(4.0 / 3.0) * t));
+        for (int i = 0; i < 4; i++)
+            for (int j = 0; j < 4; j++) {
+                if (t < MBO_TIME_MIN) out[index++] = (i == j) ? 1.0f : 0.0f;
+                else if (t > MBO_TIME_MAX) out[index++] = 0.25f;
+                else out[index++] = (i == j) ? pNoChange : pChange;
+            }
+    }
+}
+
 void mbo_tiprobs_gencov(int n, int K, const double *eigvals, const double *cijk,
                         double t, const double *bs, float *out)
 {

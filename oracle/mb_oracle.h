@@ -68,6 +68,11 @@ int mbo_likelihood(int n, int K, int P, const float *clP, const double *bs, cons
                    const float *lnScaler, const float *nSitesOfPat,
                    double pInvar, const float *clInvar, double *lnL, double *siteLnL);
 
+/* Closed-form 4x4 transition probabilities: TiProbs_Hky (src/likelihood.c:9709) and TiProbs_JukesCantor (:9846);
+ * out[k][i][j], rate[k] = baseRate*catRate[k]. */
+void mbo_tiprobs_hky(int K, double kap, const double *pis, double length, const double *rate, float *out);
+void mbo_tiprobs_jc(int K, double length, const double *rate, float *out);
+
 /* Whole-tree evaluation in the order of LaunchLogLikeForDivision (native back-end),
  * src/likelihood.c:7851-7972, all nodes dirty, rescale at every interior non-root node.
  *   left/right/length: [2N-2]; intDownPass: [N-2] post-order; rootTip: tip used as calculation

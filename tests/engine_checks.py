@@ -57,6 +57,71 @@ def check_transition_matrices(lib, oracle, div):
         bd.finalize()
 
 
+def check_closed_form_matrices(lib, oracle):
+    """nst=2 (HKY) and nst=1 (Jukes-Cantor): the reference's native path uses the closed forms TiProbs_Hky /
+    TiProbs_JukesCantor (src/likelihood.c:9709, 9846); at the BEAGLE seam MrBayes sends an eigen-system for every
+    nst, so the engine's eigen path must reproduce the closed forms (short, ordinary and very long branches)."""
+    tr = mbtree.random_tree(12, seed=5, brlen=None, brlen_mean=0.08)
+    tr.length[2], tr.length[5], tr.length[7] = 1e-8, 2.5, 100.0
+    w = np.ones(8)
+    tips = [np.zeros(8, dtype=np.int32) for _ in range(12)]
+    for kappa, pi in ((2.0, [0.35, 0.25, 0.15, 0.25]), (7.5, [0.1, 0.4, 0.3, 0.2]), (1.0, [0.25] * 4)):
+        div = build_division("gtr", tr, w, tips, [None] * 12, revmat=[1.0, kappa, 1.0, 1.0, kappa, 1.0], pi=pi, alpha=0.7, ncat=4)
+        bd = lk.BeagleDivision(div, lib)
+        try:
+            bd.UpDateCijk(0)
+            bd.TreeTiProbs_Beagle(0)
+            for p in tr.all_down_pass:
+                if p == tr.root:
+                    continue
+                idx = bd.tiProbsIndex[0][p]
+                length = min(max(tr.length[p], lk.BRLENS_MIN), lk.BRLENS_MAX)
+                got = bd.inst.get_transition_matrix(idx)
+                want = oracle.tiprobs_hky(kappa, pi, length, div.cat_rates)
+                assert np.allclose(got, want, rtol=1e-5, atol=2e-7), (kappa, p, np.abs(got - want).max())
+                if kappa == 1.0:
+                    assert np.allclose(got, oracle.tiprobs_jc(length, div.cat_rates), rtol=1e-5, atol=2e-7)
+        finally:
+            bd.finalize()
+
+
+def check_root_equals_edge(lib, oracle, div, scaling=lk.MB_BEAGLE_SCALE_ALWAYS):
+    """beagleCalculateRootLogLikelihoods (rooted / clock trees, reference src/mbbeagle.c:1251-1257) against the edge form
+    MrBayes uses for unrooted trees: fold the root branch into one more partials operation (identity matrix for the
+    interior node, the branch's matrix for the root tip) and integrate the result at the root.  Same lnL, same per-site
+    values; and the oracle's value."""
+    bd = lk.BeagleDivision(div, lib, scaling=scaling)
+    try:
+        want = bd.LogLike(0)
+        site_edge = bd.inst.get_site_log_likelihoods()
+        inst, t = bd.inst, div.tree
+        S, K = div.nstates, div.ncat
+        p = t.root_left
+        step = bd.step
+        parents = [bd.condLikeIndex[0][p] + i for i in range(step)]
+        children = [bd.condLikeIndex[0][t.root]] * step
+        mats = [bd.tiProbsIndex[0][p] + i for i in range(step)]
+        wts = frq = [bd.cijkIndex[0] + i for i in range(step)]
+        cums = [bd.siteScalerIndex[0] + i for i in range(step)]
+        ident = np.broadcast_to(np.eye(S), (K, S, S)).copy()
+        roots = []
+        for n in range(step):                              # the scratch set of node p is free between evaluations
+            inst.set_transition_matrix(bd.tiProbsScratchIndex[p] + n, ident)
+            dst = bd.condLikeScratchIndex[p] + n
+            inst.update_partials(np.array([[dst, -1, -1, parents[n], bd.tiProbsScratchIndex[p] + n, children[n], mats[n]]],
+                                          dtype=np.int32), bg.BEAGLE_OP_NONE)
+            roots.append(dst)
+        rc, got = inst.calculate_root_log_likelihoods(roots, wts, frq, cums)
+        assert rc == 0
+        site_root = inst.get_site_log_likelihoods()
+        assert abs(got - want) <= 1e-10 * abs(want), (got, want)
+        assert np.allclose(site_root, site_edge, rtol=1e-12, atol=1e-9)
+        ref = oracle.tree_loglike(div, use_shortcuts=False)
+        assert abs(got - ref) / abs(ref) < REL_FP64
+    finally:
+        bd.finalize()
+
+
 def _dense_tip(states, nstates, ncat):
     P = len(states)
     cl = np.zeros((ncat, P, nstates), dtype=np.float32)

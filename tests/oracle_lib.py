@@ -61,6 +61,21 @@ class Oracle:
                                     C.c_double(length * div.cat_rates[0]), _p(pi, _dp), _p(out, _fp))
         return out
 
+    def tiprobs_hky(self, kappa, pis, length, rates):
+        """TiProbs_Hky (nst=2), out[k][i][j]"""
+        rates = np.ascontiguousarray(rates, dtype=np.float64)
+        pis = np.ascontiguousarray(pis, dtype=np.float64)
+        out = np.empty((len(rates), 4, 4), dtype=np.float32)
+        self.lib.mbo_tiprobs_hky(C.c_int(len(rates)), C.c_double(kappa), _p(pis, _dp), C.c_double(length), _p(rates, _dp), _p(out, _fp))
+        return out
+
+    def tiprobs_jc(self, length, rates):
+        """TiProbs_JukesCantor (nst=1), out[k][i][j]"""
+        rates = np.ascontiguousarray(rates, dtype=np.float64)
+        out = np.empty((len(rates), 4, 4), dtype=np.float32)
+        self.lib.mbo_tiprobs_jc(C.c_int(len(rates)), C.c_double(length), _p(rates, _dp), _p(out, _fp))
+        return out
+
     def condlike_down(self, n, K, P, clL, stL, tiL, clR, stR, tiR):
         out = np.empty((K, P, n), dtype=np.float32)
         self.lib.mbo_condlike_down(C.c_int(n), C.c_int(K), C.c_int(P), _p(clL, _fp), _p(stL, _ip), _p(tiL, _fp),

@@ -131,6 +131,16 @@ def test_walk_waves_agree(gpu, oracle, monkeypatch, waves, slots):
     assert abs(base - want) / abs(want) < ec.REL_FP64
 
 
+def test_closed_form_matrices(gpu, oracle):
+    ec.check_closed_form_matrices(gpu, oracle)
+
+
+@pytest.mark.parametrize("case", ["primates_gtr_g4", "synth_dna_gaps", "avian_wag_g4", "replicase_m3"])
+@pytest.mark.parametrize("scaling", [lk.MB_BEAGLE_SCALE_ALWAYS, lk.MB_BEAGLE_SCALE_DYNAMIC])
+def test_root_integration_equals_edge_integration(gpu, oracle, golden_dir, case, scaling):
+    ec.check_root_equals_edge(gpu, oracle, division_from_golden(golden_dir, case), scaling)
+
+
 def test_error_codes(gpu):
     inst = bg.BeagleInstance(gpu, 2, 4, 2, 4, 10, 1, 2, 4, 2)
     with pytest.raises(bg.BeagleError) as e:
@@ -154,6 +164,26 @@ def test_config2_dna_500x20k_against_reference(gpu, golden_dir):
         lnl = ec.engine_lnl(gpu, div, scaling)
         assert abs(lnl - g["lnL"]["fp64"]) / abs(g["lnL"]["fp64"]) < ec.REL_FP64, (scaling, lnl)
         assert abs(lnl - g["lnL"]["fma"]) / abs(g["lnL"]["fma"]) < ec.REL_FMA, (scaling, lnl)
+
+
+@pytest.mark.parametrize("case", ["bench_c2", "bench_c3", "bench_c5", "bench_c4"])
+def test_bench_workloads_against_reference(gpu, golden_dir, case):
+    """configs[1..4] at FULL size (the bench.py workloads themselves): the engine's lnL vs what the real reference printed
+    for the same alignment, tree and parameters -- its fp64 build (2e-6) and its FMA/SSE build (1e-5); both scaling schemes
+    (the 6.4 GB case: rescale-always only).  Goldens: tools/gen_golden.py bench_c2 bench_c3 bench_c5 bench_c4."""
+    import json
+    with open(os.path.join(golden_dir, case + ".json")) as fh:
+        g = json.load(fh)
+    div = division_from_golden(golden_dir, case)
+    assert div.npatterns == g["npatterns"] and div.ntaxa == g["ntaxa"]
+    schemes = (lk.MB_BEAGLE_SCALE_ALWAYS,) if case == "bench_c4" else (lk.MB_BEAGLE_SCALE_ALWAYS, lk.MB_BEAGLE_SCALE_DYNAMIC)
+    for scaling in schemes:
+        lnl = ec.engine_lnl(gpu, div, scaling)
+        assert abs(lnl - g["lnL"]["fp64"]) / abs(g["lnL"]["fp64"]) < ec.REL_FP64, (scaling, lnl, g["lnL"])
+        assert abs(lnl - g["lnL"]["fma"]) / abs(g["lnL"]["fma"]) < ec.REL_FMA, (scaling, lnl, g["lnL"])
+        # about as close to the fp64 reference as the reference's own fp32 build is (floor: 1e-3 or 2e-8 relative -- the
+        # parameter values themselves travel through the .p file with 15 digits and a different eigen-solver)
+        assert abs(lnl - g["lnL"]["fp64"]) <= 2.0 * abs(g["lnL"]["fma"] - g["lnL"]["fp64"]) + max(1e-3, 2e-8 * abs(lnl))
 
 
 def _additivity(gpu, kind, ntaxa, npat, cut, **kw):

@@ -145,3 +145,12 @@ def test_dna_other_category_counts(emu, oracle, ncat):
 def test_lists_with_hazards_are_cut_into_segments(emu, oracle):
     ec.check_hazard_lists(emu, 4, 4, 100)
     ec.check_hazard_lists(emu, 20, 4, 40)
+
+
+def test_closed_form_matrices(emu, oracle):
+    ec.check_closed_form_matrices(emu, oracle)
+
+
+@pytest.mark.parametrize("case", ["primates_gtr_g4", "avian_wag_g4", "replicase_m3"])
+def test_root_integration_equals_edge_integration(emu, oracle, golden_dir, case):
+    ec.check_root_equals_edge(emu, oracle, division_from_golden(golden_dir, case))

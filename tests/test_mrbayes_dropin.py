@@ -64,6 +64,58 @@ def test_unmodified_mrbayes_on_mi355x(scaling):
     assert "Analysis completed" in out, out[-1500:]
 
 
+# ---- rooted (clock) trees: MrBayes integrates at the root with beagleCalculateRootLogLikelihoods (src/mbbeagle.c:1251-1257)
+def _clock_nexus(beagle, ngen=1):
+    import random
+    st, _ = _case(24, 500, 0.02)
+    names = ["t%d" % (i + 1) for i in range(st.shape[0])]
+    seqs = ["".join("ACGT-"[x] for x in row) for row in st]
+    rng = random.Random(5)
+    nodes = [(n, 0.0) for n in names]                          # (newick, height): a random ultrametric tree
+    while len(nodes) > 1:
+        i, j = sorted(rng.sample(range(len(nodes)), 2))
+        b = nodes.pop(j)
+        a = nodes.pop(i)
+        h = max(a[1], b[1]) + 0.03 * (0.5 + rng.random())
+        nodes.append(("(%s:%.12f,%s:%.12f)" % (a[0], h - a[1], b[0], h - b[1]), h))
+    s = "#NEXUS\nbegin data;\n  dimensions ntax=%d nchar=%d;\n" % (len(names), len(seqs[0]))
+    s += "  format datatype=dna interleave=no gap=- missing=?;\n  matrix\n"
+    for n, q in zip(names, seqs):
+        s += "%s  %s\n" % (n, q)
+    s += "  ;\nend;\nbegin mrbayes;\n  set autoclose=yes nowarnings=yes seed=12345 swapseed=12345 precision=15;\n"
+    s += "  lset nst=6 rates=gamma ngammacat=4;\n  prset brlenspr=clock:uniform;\n"
+    if beagle:
+        s += "  set usebeagle=yes beagledevice=gpu beagleprecision=single beaglescaling=%s;\n" % beagle
+    s += "end;\nbegin trees;\n  tree t = [&R] %s;\nend;\n" % nodes[0][0]
+    s += "begin mrbayes;\n  startvals tau=t V=t Revmat=(0.10,0.30,0.05,0.08,0.40,0.07) Pi=(0.35,0.25,0.15,0.25) Alpha=(0.6);\n"
+    s += "  mcmc ngen=%d nchains=1 nruns=1 samplefreq=%d printfreq=%d diagnfreq=%d filename=ck;\nend;\n" % (ngen, ngen, ngen, ngen)
+    return s
+
+
+@pytest.mark.parametrize("scaling", ["dynamic", "always"])
+def test_clock_tree_on_emulated_engine(scaling):
+    if not os.path.exists(refrun.REF_MB_EMU):
+        pytest.skip("oracle/_ref/mb_emu not built (build container only)")
+    native = refrun.initial_lnl(refrun.run_mb(refrun.REF_MB, _clock_nexus(None))[0])
+    out, _ = refrun.run_mb(refrun.REF_MB_EMU, _clock_nexus(scaling), env={"MBAMD_API_TRACE": "1"})
+    assert "beagleCalculateRootLogLikelihoods" in out and "beagleCalculateEdgeLogLikelihoods" not in out
+    assert abs(refrun.initial_lnl(out) - native) / abs(native) < 1e-5
+
+
+@pytest.mark.gpu
+def test_clock_tree_on_mi355x():
+    if not os.path.exists(refrun.REF_MB_AMD):
+        pytest.skip("oracle/_ref/mb_amd was not built (needs the reference sources at build time)")
+    out, _ = refrun.run_mb(refrun.REF_MB_AMD, _clock_nexus("dynamic"), env={"MBAMD_API_TRACE": "1"})
+    assert "mbamd HIP gfx950" in out and "beagleCalculateRootLogLikelihoods" in out
+    ours = refrun.initial_lnl(out)
+    if os.path.exists(refrun.REF_MB):
+        native = refrun.initial_lnl(refrun.run_mb(refrun.REF_MB, _clock_nexus(None))[0])
+        assert abs(ours - native) / abs(native) < 1e-5, (ours, native)
+    out, _ = refrun.run_mb(refrun.REF_MB_AMD, _clock_nexus("always", ngen=300))       # clock moves, rooted integration every generation
+    assert "Analysis completed" in out, out[-1500:]
+
+
 # ---- partially ambiguous tips (IUPAC codes): those taxa reach the engine as tip PARTIALS ------------------------
 def _ambiguous_nexus(beagle):
     st, tr = _case(20, 500, 0.02)

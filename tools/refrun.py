@@ -112,6 +112,29 @@ def initial_lnl(stdout):
     return float(m.group(1))
 
 
+def time_reference(kind, states, tree, ngen_lo, ngen_hi):
+    """Seconds per full-tree evaluation of the reference's own kernels for kind "gtr" (DNA GTR+G4), "wag" (protein, fixed
+    WAG+G4) or "m3" (codon M3): fixed tree AND fixed branch lengths, so every generation is a substitution-parameter move
+    that re-evaluates the whole tree (for M3 that includes the reference's host-side Q / eigen update, as in a real run)."""
+    if kind == "gtr":
+        return time_reference_dna(states, tree, ngen_lo, ngen_hi)
+    names = ["t%d" % (i + 1) for i in range(states.shape[0])]
+    out = {}
+    with tempfile.TemporaryDirectory() as wd:
+        for tag, ngen in (("lo", ngen_lo), ("hi", ngen_hi)):
+            text = model_nexus(kind, states, tree, ngen=ngen, fname="bench", fixed_topology=True)
+            text = text.replace("prset topologypr=fixed(t); startvals V=t", "prset topologypr=fixed(t) brlenspr=fixed(t)")
+            cpu, wall, stdout = _run(text, wd)
+            out[tag] = (ngen, cpu, wall)
+            calc = re.search(r"Using standard (\S+) likelihood calculator", stdout)
+            out["calculator"] = calc.group(1) if calc else "?"
+            npat = re.search(r"has (\d+) unique site patterns", stdout)
+            if npat:
+                out["npatterns"] = int(npat.group(1))
+    out["sec_per_eval"] = (out["hi"][1] - out["lo"][1]) / (out["hi"][0] - out["lo"][0])
+    return out
+
+
 def mcmc_nexus(states, tree_or_none, ngen, beagle=None, nchains=1, fname="mc", fixed_topology=False):
     """A default-move-mix MCMC run (GTR+G4) on the given alignment: what `MCMC gen/s` is quoted on."""
     names = ["t%d" % (i + 1) for i in range(states.shape[0])]
