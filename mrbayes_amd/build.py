@@ -41,6 +41,8 @@ def build_library(force=False, verbose=False):
            "-I", os.path.join(ROOT, "include"), "-I", os.path.join(HERE, "csrc"), SRC, "-o", LIB]
     if verbose:
         cmd.insert(1, "-Rpass-analysis=kernel-resource-usage")
+    for d in os.environ.get("MBAMD_BUILD_DEFINES", "").split():      # experiments: extra -D switches
+        cmd.insert(1, "-D" + d)
     subprocess.check_call(cmd)
     return LIB
 

@@ -877,7 +877,16 @@ int Instance::flushPending()
     ++launchClock;
     for (auto& w : work) w.first->lastLaunch = launchClock;
     auto cumOf = [&](int idx) { return idx >= 0 ? scale[idx] : (int32_t*) nullptr; };
-    if (work.size() == 1) return timedRun(*work[0].first, cumOf(work[0].second));
+    // merged launches need a per-factor-tile kernel for this shape (launch_mfma_split); other shapes -- e.g. three rate
+    // categories -- run their lists one after the other, in submission order
+    const bool mergeable = (NT == 1 && (K == 1 || K == 2 || K == 4)) || (NT == 2 && (K == 1 || K == 2));
+    if (work.size() == 1 || !mergeable) {
+        for (auto& w : work) {
+            const int rc = timedRun(*w.first, cumOf(w.second));
+            if (rc) return rc;
+        }
+        return BEAGLE_SUCCESS;
+    }
 #if !defined(MBAMD_HOST_EMU)
     hipEvent_t ev0{}, ev1{};
     if (timing) {

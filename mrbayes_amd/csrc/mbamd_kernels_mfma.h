@@ -37,6 +37,7 @@ namespace mbamd {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
+
 // floats of the MFMA-packed copy of one category's matrix: NT i-tiles x T j-pairs x 64 lanes
 __host__ __device__ inline int mfma_tiles(int S) { return (S + 31) / 32; }
 __host__ __device__ inline int mfma_pairs(int S) { return (S + 1) / 2; }

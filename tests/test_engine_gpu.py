@@ -367,6 +367,31 @@ def test_protein_other_category_counts(gpu, oracle, ncat):
     ec.check_partial_update_and_reject(gpu, oracle, div, scaling=lk.MB_BEAGLE_SCALE_ALWAYS)
 
 
+def test_deferred_lists_without_a_merge_kernel(gpu, oracle):
+    """Two independent operation lists back to back on a shape that has no merged-launch kernel (20 states, three
+    categories): the deferred lists must run one after the other, not be dropped."""
+    rng = np.random.default_rng(11)
+    S, K, P = 20, 3, 70
+    inst = bg.BeagleInstance(gpu, 2, 8, 2, S, P, 1, 4, K, 4)
+    try:
+        ti = rng.random((K, S, S)) + 0.05
+        ti /= ti.sum(axis=2, keepdims=True)
+        for m in range(2):
+            inst.set_transition_matrix(m, ti)
+        st1 = rng.integers(0, S + 1, size=P).astype(np.int32)
+        st2 = rng.integers(0, S + 1, size=P).astype(np.int32)
+        inst.set_tip_states(0, st1)
+        inst.set_tip_states(1, st2)
+        t = np.ascontiguousarray(ti, dtype=np.float32)
+        want = oracle.condlike_down(S, K, P, None, st1, t, None, st2, t)
+        inst.update_partials(np.array([[4, -1, -1, 0, 0, 1, 1]], dtype=np.int32), bg.BEAGLE_OP_NONE)
+        inst.update_partials(np.array([[5, -1, -1, 1, 1, 0, 0]], dtype=np.int32), bg.BEAGLE_OP_NONE)   # independent of the first
+        assert ec.close_partials(inst.get_partials(4), want)
+        assert ec.close_partials(inst.get_partials(5), oracle.condlike_down(S, K, P, None, st2, t, None, st1, t))
+    finally:
+        inst.finalize()
+
+
 def test_walk_counted_waits_agree_on_partial_updates(gpu, oracle, monkeypatch):
     """Root-ward paths (every operation prefetches its sibling from HBM by LDS-DMA, waits are by count): same bits as
     with every wait draining the memory queue, for several prefetch distances."""
