@@ -51,6 +51,7 @@ struct Walk4Template {
     int W = 1, entries = 0, nslots = 1;            // entries per wave (incl. the two trailing NOPs)
     std::vector<Entry> prog;                       // [W][entries]
     int phases = 1, reloads = 0, externals = 0;
+    int evictions = 0;                             // results evicted from a wave's slots and re-read by the same wave
 };
 
 struct Walk4Scratch {
@@ -66,6 +67,11 @@ public:
     int prefetchDistance = 6;  // entries a child prefetch is issued ahead of its consumer (if a slot is free)
     bool safeWaits = false;    // debug: every wait is vmcnt(0)
     int smallPhase = 16;       // a phase with at most this many operations runs on one wave
+    // general-state tree walk (k_partials_mfma_walk): children that live in HBM are loaded straight into registers (no
+    // slot, no prefetch entry), and every result needs a slot at least until the next entry (the writer wave copies it out)
+    bool memSlots = true;
+    bool alwaysKeep = false;
+    bool phasesAreLaunches = false;  // every phase is its own kernel launch: nothing stays in LDS across a phase boundary
 
     // ops: one hazard-free segment (no buffer is written twice, none is written after it was read, a buffer read
     // after it was written is a dependency).  Fills `t` (structure) -- the caller turns it into Walk4Entry words.
@@ -238,7 +244,7 @@ inline bool Walk4Builder::build(const std::vector<Walk4Op>& ops, Walk4Template& 
     for (int w = 0; w < W; ++w) longest = std::max(longest, items[w].size());
     t.W = W;
     t.phases = nphases;
-    t.reloads = t.externals = 0;
+    t.reloads = t.externals = t.evictions = 0;
     std::vector<std::vector<Walk4Template::Entry>> fin(W);     // final per-wave programs (PF entries inserted)
     std::vector<Walk4Template::Entry> scan;
 
@@ -266,7 +272,8 @@ inline bool Walk4Builder::build(const std::vector<Walk4Op>& ops, Walk4Template& 
             if (o < 0) continue;
             const int pr[2] = {prod1[o], prod2[o]};
             for (int c = 0; c < 2; ++c)
-                if (pr[c] >= 0 && waveOf[pr[c]] == w && posOf[pr[c]] < j) lastUse[pr[c]] = j;
+                if (pr[c] >= 0 && waveOf[pr[c]] == w && posOf[pr[c]] < j && (!phasesAreLaunches || phaseOf[pr[c]] == phaseOf[o]))
+                    lastUse[pr[c]] = j;
         }
         // children that must come from memory (known up front): external buffers and results of other waves
         mems.clear();
@@ -283,8 +290,8 @@ inline bool Walk4Builder::build(const std::vector<Walk4Op>& ops, Walk4Template& 
             for (int c = 0; c < 2; ++c) {
                 if (tip[c]) continue;
                 if (c == 1 && !tip[0] && ops[o].c2 == ops[o].c1) continue;        // same buffer twice: one copy serves both
-                if (pr[c] < 0) { mems.push_back(Mem{o, c, 0, j, -1, false}); t.externals++; }
-                else if (waveOf[pr[c]] != w) { mems.push_back(Mem{o, c, phaseLo(j), j, -1, false}); t.reloads++; }
+                if (pr[c] < 0) { if (memSlots) mems.push_back(Mem{o, c, 0, j, -1, false}); t.externals++; }
+                else if (waveOf[pr[c]] != w) { if (memSlots) mems.push_back(Mem{o, c, phaseLo(j), j, -1, false}); t.reloads++; }
             }
         }
         auto nextUseOfValue = [&](int v, int from) {           // next same-wave consumer position of value v at or after `from`
@@ -308,6 +315,7 @@ inline bool Walk4Builder::build(const std::vector<Walk4Op>& ops, Walk4Template& 
             const int v = slotHolder[best];
             slotOfVal[v] = -1;
             slotHolder[best] = -1;
+            t.evictions++;
             // its remaining consumers read it from memory: no earlier than now, no earlier than its store was issued
             for (int u = std::max(j, posOf[v] + 1); u < L; ++u) {
                 const int o = items[w][u].op;
@@ -328,6 +336,13 @@ inline bool Walk4Builder::build(const std::vector<Walk4Op>& ops, Walk4Template& 
             e.op = o;
             e.flags = items[w][j].flags;
             npfAt = 0;
+            if (phasesAreLaunches && (e.flags & MBAMD_W4_BARRIER)) {      // a new launch starts with empty slots
+                for (int q = 0; q < S; ++q) {
+                    if (slotHolder[q] >= 0) slotOfVal[slotHolder[q]] = -1;
+                    slotHolder[q] = -1;
+                    freeFrom[q] = j;
+                }
+            }
             const int pr[2] = {o >= 0 ? prod1[o] : -1, o >= 0 ? prod2[o] : -1};
             // 1. prefetches issued with this entry: mandatory ones (consumer == this entry) first, then look-ahead
             for (int pass = 0; pass < 2; ++pass) {
@@ -369,24 +384,34 @@ inline bool Walk4Builder::build(const std::vector<Walk4Op>& ops, Walk4Template& 
                 int found = -1;
                 for (size_t mi = 0; mi < mems.size(); ++mi)
                     if (mems[mi].op == o && mems[mi].child == c && mems[mi].issued) { found = (int) mi; break; }
-                if (found < 0) return false;
+                if (found < 0) {
+                    if (!memSlots) { *cslot[c] = 0xFF; continue; }       // read from HBM by the kernel itself
+                    return false;
+                }
                 *cslot[c] = (uint8_t) mems[found].slot;
             }
             // children read for the last time release their slots: usable by this entry's result, by DMAs from j+1 on
             for (int c = 0; c < 2; ++c) {
                 if (tip[c] || (c == 1 && !tip[0] && ops[o].c2 == ops[o].c1)) continue;
                 const int sl = *cslot[c];
+                if (sl == 0xFF) continue;
                 const int v = slotHolder[sl];
                 if (v <= -2) { slotHolder[sl] = -1; freeFrom[sl] = j + 1; }
                 else if (v >= 0 && lastUse[v] <= j) { slotHolder[sl] = -1; freeFrom[sl] = j + 1; slotOfVal[v] = -1; }
             }
+            // (alwaysKeep) results nobody in this wave reads again were copied out by the writer during the previous entry
+            if (alwaysKeep)
+                for (int q = 0; q < S; ++q) {
+                    const int v = slotHolder[q];
+                    if (v >= 0 && lastUse[v] < 0 && posOf[v] < j) { slotHolder[q] = -1; freeFrom[q] = j + 1; slotOfVal[v] = -1; }
+                }
             // 3. the result: kept in a slot if this wave reads it again
-            if (lastUse[o] > j) {
+            if (lastUse[o] > j || alwaysKeep) {
                 int sl = -1;
                 for (int q = 0; q < S; ++q) if (slotHolder[q] == -1) { sl = q; break; }   // (freed children included: reads precede the write)
                 if (sl < 0) {
                     // evict the value needed farthest in the future -- possibly this result itself
-                    const int mine = nextUseOfValue(o, j + 1);
+                    const int mine = alwaysKeep ? -1 : nextUseOfValue(o, j + 1);     // (alwaysKeep: this result must get a slot)
                     int best = -1, bestUse = mine;
                     for (int q = 0; q < S; ++q) {
                         const int v = slotHolder[q];
@@ -398,6 +423,7 @@ inline bool Walk4Builder::build(const std::vector<Walk4Op>& ops, Walk4Template& 
                         const int v = slotHolder[best];
                         slotOfVal[v] = -1;
                         slotHolder[best] = -1;
+                        t.evictions++;
                         for (int u = j + 1; u < L; ++u) {
                             const int q = items[w][u].op;
                             if (q < 0) continue;
@@ -413,6 +439,7 @@ inline bool Walk4Builder::build(const std::vector<Walk4Op>& ops, Walk4Template& 
                     e.dslot = (uint8_t) sl;
                     slotsUsed = std::max(slotsUsed, sl + 1);
                 } else {
+                    t.evictions++;
                     for (int u = j + 1; u < L; ++u) {           // not kept: its consumers prefetch it (after this entry's store)
                         const int q = items[w][u].op;
                         if (q < 0) continue;

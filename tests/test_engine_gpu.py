@@ -367,6 +367,24 @@ def test_protein_other_category_counts(gpu, oracle, ncat):
     ec.check_partial_update_and_reject(gpu, oracle, div, scaling=lk.MB_BEAGLE_SCALE_ALWAYS)
 
 
+@pytest.mark.parametrize("case", ["replicase_m3", "avian_wag_g4", "synth_aa_wag"])
+def test_general_state_tree_walk_agrees(gpu, golden_dir, monkeypatch, case):
+    """MBAMD_GWALK=1: subtree bins walked by one workgroup per (tile, bin) with results resident in LDS slots, one launch
+    per phase (k_partials_mfma_walk) -- same bits as the level launches."""
+    div = division_from_golden(golden_dir, case)
+    a, sa = _lnl_and_sites(gpu, div)
+    monkeypatch.setenv("MBAMD_GWALK", "1")
+    for env in ({}, {"MBAMD_GWALK_BINS": "2"}, {"MBAMD_GWALK_SLOTS": "3"}):
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        b, sb = _lnl_and_sites(gpu, div)
+        assert a == b and np.array_equal(sa, sb)
+        b, sb = _lnl_and_sites(gpu, div, lk.MB_BEAGLE_SCALE_DYNAMIC)
+        assert abs(a - b) <= 1e-9 * abs(a)
+        for k in env:
+            monkeypatch.delenv(k)
+
+
 def test_deferred_lists_without_a_merge_kernel(gpu, oracle):
     """Two independent operation lists back to back on a shape that has no merged-launch kernel (20 states, three
     categories): the deferred lists must run one after the other, not be dropped."""
