@@ -271,6 +271,63 @@ BEAGLE_DLLEXPORT int beagleGetSiteLogLikelihoods(int instance, double* outLogLik
  * engine extensions (not part of the upstream API; used by bench.py / the multi-GPU driver)
  * ------------------------------------------------------------------------------------------- */
 /* Block until all queued device work of the instance has finished. */
+/* ---------------------------------------------------------------------------------------------
+ * BEAGLE v3 surface (compiled into MrBayes when the library exports beagleSetCPUThreadCount, reference
+ * configure.ac:220-223): resource benchmark, multi-partition instances.  A multi-partition instance holds the site
+ * patterns of ALL data divisions (same state / category / eigen-part counts); operations, scale-factor bookkeeping and
+ * log-likelihood calls name the partition they act on.  In this engine such an instance is a facade over one child engine
+ * per partition: the children run on their own streams, only the sums meet on the host.
+ * ------------------------------------------------------------------------------------------- */
+/* reference src/mbbeagle.c:232-245 */
+BEAGLE_DLLEXPORT BeagleBenchmarkedResourceList* beagleGetBenchmarkedResourceList(
+    int tipCount, int compactBufferCount, int stateCount, int patternCount, int categoryCount, int* resourceList,
+    int resourceCount, long preferenceFlags, long requirementFlags, int eigenModelCount, int partitionCount,
+    int calculateDerivatives, long benchmarkFlags);
+/* reference src/mbbeagle.c:386 (CPU implementations only; a no-op here) */
+BEAGLE_DLLEXPORT int beagleSetCPUThreadCount(int instance, int threadCount);
+/* reference src/mcmc.c:6464: patternCount ints, partitions are contiguous increasing pattern ranges; call before the
+ * first matrix / partials update (tip data and pattern weights may already be set) */
+BEAGLE_DLLEXPORT int beagleSetPatternPartitions(int instance, int partitionCount, const int* inPatternPartitions);
+/* reference src/mbbeagle.c:2055 */
+BEAGLE_DLLEXPORT int beagleSetCategoryRatesWithIndex(int instance, int categoryRatesIndex, const double* inCategoryRates);
+/* reference src/mbbeagle.c:2140-2147 */
+BEAGLE_DLLEXPORT int beagleUpdateTransitionMatricesWithMultipleModels(int instance, const int* eigenIndices,
+                                                                      const int* categoryRateIndices,
+                                                                      const int* probabilityIndices,
+                                                                      const int* firstDerivativeIndices,
+                                                                      const int* secondDerivativeIndices,
+                                                                      const double* edgeLengths, int count);
+/* reference src/mbbeagle.c:2292, 2440, 2616 */
+BEAGLE_DLLEXPORT int beagleUpdatePartialsByPartition(int instance, const BeagleOperationByPartition* operations, int operationCount);
+/* reference src/likelihood.c:8096-8103, 8134; src/mbbeagle.c:593, 1736, 1913, 2566 */
+BEAGLE_DLLEXPORT int beagleAccumulateScaleFactorsByPartition(int instance, const int* scaleIndices, int count,
+                                                             int cumulativeScaleIndex, int partitionIndex);
+BEAGLE_DLLEXPORT int beagleRemoveScaleFactorsByPartition(int instance, const int* scaleIndices, int count,
+                                                         int cumulativeScaleIndex, int partitionIndex);
+BEAGLE_DLLEXPORT int beagleResetScaleFactorsByPartition(int instance, int cumulativeScaleIndex, int partitionIndex);
+/* reference src/mbbeagle.c:2817-2850: index arrays are [count][partitionCount]; outSumLogLikelihoodByPartition has one
+ * value per named partition */
+BEAGLE_DLLEXPORT int beagleCalculateRootLogLikelihoodsByPartition(int instance, const int* bufferIndices,
+                                                                  const int* categoryWeightsIndices,
+                                                                  const int* stateFrequenciesIndices,
+                                                                  const int* cumulativeScaleIndices,
+                                                                  const int* partitionIndices, int partitionCount, int count,
+                                                                  double* outSumLogLikelihoodByPartition,
+                                                                  double* outSumLogLikelihood);
+BEAGLE_DLLEXPORT int beagleCalculateEdgeLogLikelihoodsByPartition(
+    int instance, const int* parentBufferIndices, const int* childBufferIndices, const int* probabilityIndices,
+    const int* firstDerivativeIndices, const int* secondDerivativeIndices, const int* categoryWeightsIndices,
+    const int* stateFrequenciesIndices, const int* cumulativeScaleIndices, const int* partitionIndices, int partitionCount,
+    int count, double* outSumLogLikelihoodByPartition, double* outSumLogLikelihood, double* outSumFirstDerivativeByPartition,
+    double* outSumFirstDerivative, double* outSumSecondDerivativeByPartition, double* outSumSecondDerivative);
+
+/* ---------------------------------------------------------------------------------------------
+ * engine extensions (mbamd*)
+ * ------------------------------------------------------------------------------------------- */
+/* child engines behind an instance: pattern partitions x shards (1: an ordinary instance).  Site patterns of one
+ * partition are sharded over several GPUs when beagleCreateInstance names several resources, or MBAMD_SHARD=<g> is set
+ * (MrBayes names at most one resource, reference src/mbbeagle.c:322-323). */
+BEAGLE_DLLEXPORT int mbamdGetChildCount(int instance);
 BEAGLE_DLLEXPORT int mbamdSynchronize(int instance);
 /* The binary exponents behind a scale buffer: out[k * patternCount + c].  The 4-state path keeps one exponent per
  * (pattern, category) -- beagleGetScaleFactors reports the largest of a pattern's exponents times ln 2; the general-state

@@ -63,7 +63,12 @@ EXPORTS = [
     "beagleGetScaleFactors", "beagleCalculateRootLogLikelihoods", "beagleCalculateEdgeLogLikelihoods",
     "beagleGetSiteLogLikelihoods", "mbamdSynchronize", "mbamdGetLastError", "mbamdKernelTiming",
     "mbamdGetKernelTiming", "mbamdSetKernelPath", "mbamdSetDeferredResult", "mbamdFetchLogLikelihood",
-    "mbamdGetScaleExponents",
+    "mbamdGetScaleExponents", "mbamdGetChildCount",
+    # BEAGLE v3 surface (multi-partition instances, resource benchmark)
+    "beagleGetBenchmarkedResourceList", "beagleSetCPUThreadCount", "beagleSetPatternPartitions",
+    "beagleSetCategoryRatesWithIndex", "beagleUpdateTransitionMatricesWithMultipleModels", "beagleUpdatePartialsByPartition",
+    "beagleAccumulateScaleFactorsByPartition", "beagleRemoveScaleFactorsByPartition", "beagleResetScaleFactorsByPartition",
+    "beagleCalculateRootLogLikelihoodsByPartition", "beagleCalculateEdgeLogLikelihoodsByPartition",
 ]
 
 _dp = C.POINTER(C.c_double)
@@ -306,6 +311,65 @@ class BeagleInstance:
                                                         C.byref(out), None, None)
         self._chk(rc, "beagleCalculateEdgeLogLikelihoods", allow=(BEAGLE_ERROR_FLOATING_POINT,))
         return rc, out.value
+
+    # ---- BEAGLE v3: multi-partition instances (reference src/mbbeagle.c:1500-3010) -------------------------------
+    def child_count(self) -> int:
+        return int(self.lib.mbamdGetChildCount(self.id))
+
+    def set_pattern_partitions(self, partition_count, pattern_partitions):
+        a = _i(pattern_partitions)
+        self._chk(self.lib.beagleSetPatternPartitions(self.id, partition_count, a.ctypes.data_as(_ip)), "beagleSetPatternPartitions")
+
+    def set_category_rates_with_index(self, index, rates):
+        a = _d(rates)
+        self._chk(self.lib.beagleSetCategoryRatesWithIndex(self.id, index, a.ctypes.data_as(_dp)), "beagleSetCategoryRatesWithIndex")
+
+    def update_transition_matrices_with_multiple_models(self, eigen_indices, rate_indices, prob_indices, edge_lengths):
+        g, r, p, e = _i(eigen_indices), _i(rate_indices), _i(prob_indices), _d(edge_lengths)
+        self._chk(self.lib.beagleUpdateTransitionMatricesWithMultipleModels(
+            self.id, g.ctypes.data_as(_ip), r.ctypes.data_as(_ip), p.ctypes.data_as(_ip), None, None, e.ctypes.data_as(_dp), len(p)),
+            "beagleUpdateTransitionMatricesWithMultipleModels")
+
+    def update_partials_by_partition(self, operations):
+        """operations: int array [n][9] in BeagleOperationByPartition field order."""
+        a = _i(operations).reshape(-1, 9)
+        self._chk(self.lib.beagleUpdatePartialsByPartition(self.id, a.ctypes.data_as(C.c_void_p), a.shape[0]),
+                  "beagleUpdatePartialsByPartition")
+
+    def reset_scale_factors_by_partition(self, cum, partition):
+        self._chk(self.lib.beagleResetScaleFactorsByPartition(self.id, cum, partition), "beagleResetScaleFactorsByPartition")
+
+    def accumulate_scale_factors_by_partition(self, idx, cum, partition):
+        a = _i(idx)
+        self._chk(self.lib.beagleAccumulateScaleFactorsByPartition(self.id, a.ctypes.data_as(_ip), len(a), cum, partition),
+                  "beagleAccumulateScaleFactorsByPartition")
+
+    def remove_scale_factors_by_partition(self, idx, cum, partition):
+        a = _i(idx)
+        self._chk(self.lib.beagleRemoveScaleFactorsByPartition(self.id, a.ctypes.data_as(_ip), len(a), cum, partition),
+                  "beagleRemoveScaleFactorsByPartition")
+
+    def calculate_edge_log_likelihoods_by_partition(self, parents, children, probs, weights, freqs, cums, partitions, count):
+        """index arrays laid out [count][len(partitions)]; returns (rc, per-partition sums, total)"""
+        p, ch, pr, w, f, c, pt = _i(parents), _i(children), _i(probs), _i(weights), _i(freqs), _i(cums), _i(partitions)
+        by = np.zeros(len(pt))
+        out = C.c_double(0.0)
+        rc = self.lib.beagleCalculateEdgeLogLikelihoodsByPartition(
+            self.id, p.ctypes.data_as(_ip), ch.ctypes.data_as(_ip), pr.ctypes.data_as(_ip), None, None, w.ctypes.data_as(_ip),
+            f.ctypes.data_as(_ip), c.ctypes.data_as(_ip), pt.ctypes.data_as(_ip), len(pt), count, by.ctypes.data_as(_dp),
+            C.byref(out), None, None, None, None)
+        self._chk(rc, "beagleCalculateEdgeLogLikelihoodsByPartition", allow=(BEAGLE_ERROR_FLOATING_POINT,))
+        return rc, by, out.value
+
+    def calculate_root_log_likelihoods_by_partition(self, buffers, weights, freqs, cums, partitions, count):
+        b, w, f, c, pt = _i(buffers), _i(weights), _i(freqs), _i(cums), _i(partitions)
+        by = np.zeros(len(pt))
+        out = C.c_double(0.0)
+        rc = self.lib.beagleCalculateRootLogLikelihoodsByPartition(
+            self.id, b.ctypes.data_as(_ip), w.ctypes.data_as(_ip), f.ctypes.data_as(_ip), c.ctypes.data_as(_ip),
+            pt.ctypes.data_as(_ip), len(pt), count, by.ctypes.data_as(_dp), C.byref(out))
+        self._chk(rc, "beagleCalculateRootLogLikelihoodsByPartition", allow=(BEAGLE_ERROR_FLOATING_POINT,))
+        return rc, by, out.value
 
     def get_site_log_likelihoods(self) -> np.ndarray:
         out = np.empty(self.pattern_count)

@@ -126,6 +126,37 @@ struct Plan {
 };
 
 struct Instance {
+    // ---- facade: an instance whose site patterns are split over child instances -- one per pattern PARTITION
+    // (BEAGLE v3 multi-partition mode, reference src/mbbeagle.c:1500-3010) and/or per SHARD (pattern blocks of one
+    // partition on different GPUs).  Site patterns are independent through the whole recursion, so every
+    // call fans out to the children (each with its own stream, possibly its own device) and only the log-likelihood
+    // sums meet again on the host.  A facade owns no device memory itself.
+    struct Child { Instance* in; int start, count, partition; };
+    std::vector<Child> children;
+    bool facade() const { return !children.empty(); }
+    int createArgs[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+    std::vector<int> shardDevices;   // devices the patterns of every partition are spread over (size 1: no sharding)
+    int partitionCount = 1;
+    bool released = false;           // device buffers handed back (became a facade)
+    // tip data and pattern weights as the client gave them, kept until the first computation: a v3 client sets them
+    // BEFORE it declares the partitions (reference src/mbbeagle.c:1655-1700 then src/mcmc.c:6461-6466)
+    bool logOpen = true;
+    std::vector<std::pair<int, std::vector<int>>> logTipStates;
+    std::vector<std::pair<int, std::vector<double>>> logTipPartials;
+    std::vector<double> logWeights;
+    int makeChildren(const std::vector<std::pair<int, int>>& partitionRanges);
+    void destroyChildren();
+    int getSites(double* out);
+    int getScaleExponents(int idx, int* out);
+    void closeLog()                  // the first computation: the set-up data is where it belongs, drop the host copies
+    {
+        if (!logOpen) return;
+        logOpen = false;
+        std::vector<std::pair<int, std::vector<int>>>().swap(logTipStates);
+        std::vector<std::pair<int, std::vector<double>>>().swap(logTipPartials);
+        std::vector<double>().swap(logWeights);
+    }
+
     int device = 0;
     hipStream_t stream{};
     int tipCount = 0, nBuffers = 0, S = 0, SP = 0, P = 0, Ppad = 0, nEigen = 0, nMatrices = 0, K = 0, nScale = 0;
@@ -175,7 +206,8 @@ struct Instance {
     bool siteToHost = false, siteOnHost = false;   // mode / where the latest evaluation put its values
     bool noSiteHost = false;                       // MBAMD_NO_SITE_HOST: always copy from device memory (comparison switch)
     int nblocks = 0;                  // partial sums of the weighted site log-likelihoods (one per integration workgroup)
-    RatesArg rates{};                 // category rates, passed to kernels by value
+    std::vector<RatesArg> rateSets;   // category rates by index (beagleSetCategoryRatesWithIndex; index 0 = beagleSetCategoryRates), passed to kernels by value
+    int pendingRateSet = 0;           // the rate set of the queued transition-matrix jobs
     bool haveSite = false;
 
     // growable device scratch
@@ -294,7 +326,8 @@ struct Instance {
     int importPartials(int idx, const double* in, bool hasCategories);
     int getPartials(int idx, double* out);
     int setEigen(int idx, const double* U, const double* Ui, const double* lam);
-    int updateMatrices(int eigenIndex, const int* probIdx, const double* lengths, int count);
+    int updateMatrices(int eigenIndex, const int* probIdx, const double* lengths, int count, int rateSet = 0);
+    int setRates(int index, const double* r);
     int setMatrix(int idx, const double* in);
     int getMatrix(int idx, double* out);
     int updatePartials(const BeagleOperation* ops, int n, int cumIdx);
@@ -472,7 +505,8 @@ int Instance::create(int tipCount_, int partialsBufferCount, int compactBufferCo
     // defaults: unit rates, uniform category weights, unit pattern weights (BEAGLE clients normally set them)
     std::vector<double> ones(std::max(Ppad, K), 1.0);
     HIP_TRY(hipMemcpy(d_rates, ones.data(), (size_t) K * sizeof(double), hipMemcpyHostToDevice));
-    for (int k = 0; k < MBAMD_MAX_RATES; ++k) rates.r[k] = 1.0;
+    rateSets.assign(1, RatesArg{});
+    for (int k = 0; k < MBAMD_MAX_RATES; ++k) rateSets[0].r[k] = 1.0;
     std::vector<double> pw(Ppad, 0.0);
     std::fill(pw.begin(), pw.begin() + P, 1.0);
     HIP_TRY(hipMemcpy(d_pweights, pw.data(), (size_t) Ppad * sizeof(double), hipMemcpyHostToDevice));
@@ -640,8 +674,23 @@ int Instance::setEigen(int idx, const double* U, const double* Ui, const double*
 
 // beagleUpdateTransitionMatrices only queues its jobs: MrBayes calls it once per eigen-system part (reference
 // src/mbbeagle.c:1475-1486), and all parts of an evaluation go out as ONE launch when the next other call arrives.
-int Instance::updateMatrices(int eigenIndex, const int* probIdx, const double* lengths, int count)
+int Instance::setRates(int index, const double* r)
 {
+    if (index < 0 || index > 65535) return fail(BEAGLE_ERROR_OUT_OF_RANGE, "category rates: index");
+    if (K > MBAMD_MAX_RATES) return fail(BEAGLE_ERROR_NO_IMPLEMENTATION, "more than 16 rate categories");
+    if ((size_t) index >= rateSets.size()) rateSets.resize((size_t) index + 1, rateSets[0]);
+    for (int k = 0; k < K; ++k) rateSets[index].r[k] = r[k];
+    return BEAGLE_SUCCESS;
+}
+
+int Instance::updateMatrices(int eigenIndex, const int* probIdx, const double* lengths, int count, int rateSet)
+{
+    if (rateSet < 0 || (size_t) rateSet >= rateSets.size()) return fail(BEAGLE_ERROR_OUT_OF_RANGE, "beagleUpdateTransitionMatrices: category rates index");
+    if (!pendingJobs.empty() && rateSet != pendingRateSet) {       // one rate set per launch
+        int frc = flushMatrices();
+        if (frc) return frc;
+    }
+    pendingRateSet = rateSet;
     if (eigenIndex < 0 || eigenIndex >= nEigen) return fail(BEAGLE_ERROR_OUT_OF_RANGE, "beagleUpdateTransitionMatrices: eigen index");
     if (count <= 0) return BEAGLE_SUCCESS;
     if (K > MBAMD_MAX_RATES) return fail(BEAGLE_ERROR_NO_IMPLEMENTATION, "more than 16 rate categories");
@@ -670,6 +719,7 @@ int Instance::updateMatrices(int eigenIndex, const int* probIdx, const double* l
 int Instance::flushMatrices()
 {
     if (pendingJobs.empty()) return BEAGLE_SUCCESS;
+    const RatesArg rates = rateSets[pendingRateSet];
     const int count = (int) pendingJobs.size();
     const MatrixJob* djobs = nullptr;
     int rc = stageDirect(pendingJobs.data(), sizeof(MatrixJob) * count, (const void**) &djobs);
@@ -2055,6 +2105,103 @@ static void buildResources()
 
 }  // namespace mbamd
 
+// ---------------------------------------------------------------------------------------------
+// per-pattern read-outs as Instance methods (the facade gathers them from its children)
+// ---------------------------------------------------------------------------------------------
+namespace mbamd {
+
+int Instance::getSites(double* out)
+{
+    if (!haveSite) return fail(BEAGLE_ERROR_GENERAL, "beagleGetSiteLogLikelihoods: no likelihood computed yet");
+    HIP_TRY(hipStreamSynchronize(stream));
+    if (siteOnHost) {
+        std::memcpy(out, h_site, (size_t) P * sizeof(double));
+    } else {
+        HIP_TRY(hipMemcpy(out, d_site, (size_t) P * sizeof(double), hipMemcpyDeviceToHost));
+        if (!h_site && hipHostMalloc((void**) &h_site, (size_t) Ppad * sizeof(double), hipHostMallocDefault) == hipSuccess) {
+            if (hipHostGetDevicePointer((void**) &h_site_dev, h_site, 0) != hipSuccess) h_site_dev = nullptr;
+        }
+        siteToHost = h_site_dev != nullptr && !noSiteHost;   // this client reads them: later evaluations write to the host directly
+    }
+    return BEAGLE_SUCCESS;
+}
+
+// the binary exponents behind a scale buffer, out[k * P + c]
+int Instance::getScaleExponents(int idx, int* out)
+{
+    if (idx < 0 || idx >= nScale) return fail(BEAGLE_ERROR_OUT_OF_RANGE, "scale exponents: index");
+    HIP_TRY(hipStreamSynchronize(stream));
+    if (!s4) {
+        int rc = ensureScale(idx);
+        if (rc) return rc;
+        std::vector<int32_t> h(Ppad);
+        HIP_TRY(hipStreamSynchronize(stream));
+        HIP_TRY(hipMemcpy(h.data(), scale[idx], (size_t) Ppad * sizeof(int32_t), hipMemcpyDeviceToHost));
+        for (int k = 0; k < K; ++k) for (int c = 0; c < P; ++c) out[(size_t) k * P + c] = h[c];
+        return BEAGLE_SUCCESS;
+    }
+    const int st = scaleState[idx];
+    if (st == 0) { std::fill(out, out + (size_t) K * P, 0); return BEAGLE_SUCCESS; }
+    std::vector<int32_t> h((size_t) K * Ppad);
+    if (st == 2) {
+        HIP_TRY(hipMemcpy(h.data(), wideScale[idx], h.size() * sizeof(int32_t), hipMemcpyDeviceToHost));
+    } else {
+        int rc = grow(&d_tmp, &tmpCap, h.size() * sizeof(int32_t));
+        if (rc) return rc;
+        MBAMD_LAUNCH(k_exp_widen, (unsigned) ((h.size() + 255) / 256), 256, 0, stream, (const int8_t*) arenaExp, estride, idx, K, Ppad,
+                     (int32_t*) d_tmp);
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipStreamSynchronize(stream));
+        HIP_TRY(hipMemcpy(h.data(), d_tmp, h.size() * sizeof(int32_t), hipMemcpyDeviceToHost));
+    }
+    for (int k = 0; k < K; ++k) for (int c = 0; c < P; ++c) out[(size_t) k * P + c] = h[(size_t) k * Ppad + c];
+    return BEAGLE_SUCCESS;
+}
+
+void Instance::destroyChildren()
+{
+    for (Child& ch : children) { ch.in->destroy(); delete ch.in; }
+    children.clear();
+}
+
+// Split the patterns into child instances: every partition range (start, count) is cut into one shard per device of
+// shardDevices (whole 64-pattern blocks, the last shard takes the remainder), then the recorded tip data and pattern
+// weights are replayed into the children.
+int Instance::makeChildren(const std::vector<std::pair<int, int>>& ranges)
+{
+    destroyChildren();
+    const int G = std::max<int>(1, (int) shardDevices.size());
+    for (size_t p = 0; p < ranges.size(); ++p) {
+        const int start = ranges[p].first, count = ranges[p].second;
+        const int blocks = (count + 63) / 64;
+        const int g = std::max(1, std::min(G, blocks));
+        int done = 0;
+        for (int i = 0; i < g; ++i) {
+            const int b0 = (int) ((long) blocks * i / g), b1 = (int) ((long) blocks * (i + 1) / g);
+            const int n = (i == g - 1) ? count - done : (b1 - b0) * 64;
+            if (n <= 0) continue;
+            Instance* c = new Instance();
+            c->flags = flags;
+            const int dev = shardDevices.empty() ? device : shardDevices[i % shardDevices.size()];
+            int rc = c->create(createArgs[0], createArgs[1], createArgs[2], createArgs[3], n, createArgs[5], createArgs[6],
+                               createArgs[7], createArgs[8], dev);
+            if (rc) { c->destroy(); delete c; destroyChildren(); return rc; }
+            c->logOpen = false;
+            children.push_back(Child{c, start + done, n, (int) p});
+            done += n;
+        }
+    }
+    for (Child& ch : children) {
+        (void) hipSetDevice(ch.in->device);
+        for (auto& ts : logTipStates) { int rc = ch.in->setTipStates(ts.first, ts.second.data() + ch.start); if (rc) return rc; }
+        for (auto& tp : logTipPartials) { int rc = ch.in->importPartials(tp.first, tp.second.data() + (size_t) ch.start * S, false); if (rc) return rc; }
+        if (!logWeights.empty()) { int rc = ch.in->upload(ch.in->d_pweights, logWeights.data() + ch.start, sizeof(double) * ch.count); if (rc) return rc; }
+    }
+    return BEAGLE_SUCCESS;
+}
+
+}  // namespace mbamd
+
 // =============================================================================================
 // C ABI
 // =============================================================================================
@@ -2071,10 +2218,80 @@ using namespace mbamd;
         int frc_ = in->flushPending();                                                               \
         if (frc_ != BEAGLE_SUCCESS) return frc_;                                                     \
     }
+// a facade forwards the call to every child (`c`, its pattern range in `ch`) and returns
+#define FACADE_EACH(FLUSH, ...)                                                                      \
+    if (in->facade()) {                                                                              \
+        for (Instance::Child& ch : in->children) {                                                   \
+            Instance* c = ch.in;                                                                     \
+            (void) ch;                                                                               \
+            (void) hipSetDevice(c->device);                                                          \
+            if (FLUSH && (!c->pending.empty() || !c->pendingJobs.empty())) {                         \
+                int frc_ = c->flushPending();                                                        \
+                if (frc_ != BEAGLE_SUCCESS) return frc_;                                             \
+            }                                                                                        \
+            int crc_ = (__VA_ARGS__);                                                                \
+            if (crc_ != BEAGLE_SUCCESS) return crc_;                                                 \
+        }                                                                                            \
+        return BEAGLE_SUCCESS;                                                                       \
+    }
+#define FACADE_ALL(...) FACADE_EACH(true, __VA_ARGS__)
+
+// the engine proper for one log-likelihood call; facade: per-child sums, FLOATING_POINT if any child says so
+static int integrate_any(Instance* in, const int* parent, const int* child, const int* prob, const int* wIdx, const int* fIdx,
+                         const int* cumIdx, int count, const int* partitionIndices, int partitionCount, double* outByPartition,
+                         double* outSum)
+{
+    if (!in->facade()) return in->integrate(parent, child, prob, wIdx, fIdx, cumIdx, count, outSum);
+    // arrays are laid out [count][partitionCount] when partitionIndices is given (reference src/mbbeagle.c:2781-2800)
+    const int pc = partitionIndices ? partitionCount : 1;
+    std::vector<int> pa(count), ca(count), pr(count), wa(count), fa(count), cu(count);
+    std::vector<Instance*> launched;
+    std::vector<int> slotOf;
+    for (Instance::Child& ch : in->children) {
+        int dpos = 0;
+        if (partitionIndices) {
+            dpos = -1;
+            for (int d = 0; d < pc; ++d) if (partitionIndices[d] == ch.partition) dpos = d;
+            if (dpos < 0) continue;                     // this partition is not part of the call
+        }
+        for (int i = 0; i < count; ++i) {
+            const int j = i * pc + dpos;
+            pa[i] = parent[j]; wa[i] = wIdx[j]; fa[i] = fIdx[j];
+            cu[i] = cumIdx ? cumIdx[j] : BEAGLE_OP_NONE;
+            if (child) { ca[i] = child[j]; pr[i] = prob[j]; }
+        }
+        Instance* c = ch.in;
+        (void) hipSetDevice(c->device);
+        if (!c->pending.empty() || !c->pendingJobs.empty()) { int frc = c->flushPending(); if (frc) return frc; }
+        const bool was = c->deferred;
+        c->deferred = true;                             // launch everywhere first, collect afterwards
+        const int rc = c->integrate(pa.data(), child ? ca.data() : nullptr, child ? pr.data() : nullptr, wa.data(), fa.data(),
+                                    cumIdx ? cu.data() : nullptr, count, nullptr);
+        c->deferred = was;
+        if (rc) return rc;
+        launched.push_back(c);
+        slotOf.push_back(dpos);
+    }
+    double total = 0.0;
+    int result = BEAGLE_SUCCESS;
+    if (outByPartition) for (int d = 0; d < pc; ++d) outByPartition[d] = 0.0;
+    for (size_t i = 0; i < launched.size(); ++i) {
+        (void) hipSetDevice(launched[i]->device);
+        double v = 0.0;
+        const int rc = launched[i]->fetchResult(&v);
+        if (rc == BEAGLE_ERROR_FLOATING_POINT) result = rc;
+        else if (rc) return rc;
+        total += v;
+        if (outByPartition) outByPartition[slotOf[i]] += v;
+    }
+    if (outSum) *outSum = total;
+    in->haveSite = true;
+    return result;
+}
 
 extern "C" {
 
-const char* beagleGetVersion(void) { return "mbamd-0.1 (HIP/gfx950; BEAGLE API 3.x compatible subset)"; }
+const char* beagleGetVersion(void) { return "mbamd-0.2 (HIP/gfx950; BEAGLE API 3.x compatible subset)"; }
 const char* beagleGetCitation(void)
 {
     return "mrbayes_amd: MI355X-native conditional-likelihood engine behind the BEAGLE API used by MrBayes";
@@ -2088,6 +2305,41 @@ BeagleResourceList* beagleGetResourceList(void)
     return &g_resources;
 }
 
+// v3: "benchmark" every resource for a problem size and let the client pick the fastest (reference
+// src/mbbeagle.c:220-307).  Every resource is an MI355X running the same kernels: nothing is timed, the list is the
+// resource list in order with a nominal, equal result -- the client's "first fastest" rule then picks resource 0
+// unless the user named one.
+BeagleBenchmarkedResourceList* beagleGetBenchmarkedResourceList(int tipCount, int compactBufferCount, int stateCount, int patternCount,
+                                                                int categoryCount, int* resourceList, int resourceCount,
+                                                                long preferenceFlags, long requirementFlags, int eigenModelCount,
+                                                                int partitionCount, int calculateDerivatives, long benchmarkFlags)
+{
+    (void) tipCount; (void) compactBufferCount; (void) stateCount; (void) patternCount; (void) categoryCount; (void) resourceList;
+    (void) resourceCount; (void) preferenceFlags; (void) requirementFlags; (void) eigenModelCount; (void) partitionCount;
+    (void) calculateDerivatives;
+    static BeagleBenchmarkedResourceList list = {nullptr, 0};
+    static std::vector<BeagleBenchmarkedResource> vec;
+    std::lock_guard<std::mutex> lk(g_mutex);
+    buildResources();
+    vec.resize(std::max(1, g_resources.length));
+    for (int i = 0; i < g_resources.length; ++i) {
+        BeagleBenchmarkedResource& r = vec[i];
+        r.number = i;
+        r.name = g_resources.list[i].name;
+        r.description = g_resources.list[i].description;
+        r.supportFlags = g_resources.list[i].supportFlags;
+        r.requiredFlags = 0;
+        r.returnCode = BEAGLE_SUCCESS;
+        r.implName = const_cast<char*>("mbamd HIP gfx950");
+        r.benchedFlags = kSupport | (benchmarkFlags & BEAGLE_BENCHFLAG_SCALING_ALWAYS ? BEAGLE_FLAG_SCALING_ALWAYS : BEAGLE_FLAG_SCALING_DYNAMIC);
+        r.benchmarkResult = 1.0;
+        r.performanceRatio = 1.0;
+    }
+    list.list = vec.data();
+    list.length = g_resources.length;
+    return list.length > 0 ? &list : nullptr;
+}
+
 int beagleCreateInstance(int tipCount, int partialsBufferCount, int compactBufferCount, int stateCount,
                          int patternCount, int eigenBufferCount, int matrixBufferCount, int categoryCount,
                          int scaleBufferCount, int* resourceList, int resourceCount, long preferenceFlags,
@@ -2096,30 +2348,58 @@ int beagleCreateInstance(int tipCount, int partialsBufferCount, int compactBuffe
     API_TRACE("beagleCreateInstance(tips=%d, partials=%d, compact=%d, states=%d, patterns=%d, eigen=%d, matrices=%d, categories=%d, scale=%d)",
               tipCount, partialsBufferCount, compactBufferCount, stateCount, patternCount, eigenBufferCount, matrixBufferCount,
               categoryCount, scaleBufferCount);
-    (void) preferenceFlags;
     if (tipCount < 0 || partialsBufferCount < 0 || compactBufferCount < 0 || stateCount < 2 || patternCount < 1 ||
         eigenBufferCount < 0 || matrixBufferCount < 0 || categoryCount < 1 || scaleBufferCount < 0)
         return fail(BEAGLE_ERROR_OUT_OF_RANGE, "beagleCreateInstance: bad dimensions");
     if (stateCount > 64) return fail(BEAGLE_ERROR_NO_IMPLEMENTATION, "beagleCreateInstance: more than 64 states");
+    if (categoryCount > MBAMD_MAX_RATES) return fail(BEAGLE_ERROR_NO_IMPLEMENTATION, "beagleCreateInstance: more than 16 rate categories");
     if (requirementFlags & (BEAGLE_FLAG_PRECISION_DOUBLE | BEAGLE_FLAG_EIGEN_COMPLEX | BEAGLE_FLAG_PROCESSOR_CPU |
                             BEAGLE_FLAG_FRAMEWORK_CUDA | BEAGLE_FLAG_FRAMEWORK_OPENCL | BEAGLE_FLAG_SCALERS_RAW))
         return fail(BEAGLE_ERROR_NO_IMPLEMENTATION, "beagleCreateInstance: unsupported requirement flags");
+    if ((preferenceFlags & BEAGLE_FLAG_PRECISION_DOUBLE) && std::getenv("MBAMD_VERBOSE"))
+        std::fprintf(stderr, "[mbamd] note: double precision was preferred; this engine computes conditional likelihoods in fp32 "
+                             "(sums and logarithms in fp64) like the reference's default CLFlt\n");
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
         return fail(BEAGLE_ERROR_NO_RESOURCE, "beagleCreateInstance: no HIP device (this engine has no CPU path)");
-    int dev = 0;
+    std::vector<int> devices;                      // a resource list with several GPUs = shard the patterns over them
     if (resourceList && resourceCount > 0) {
-        dev = -1;
         for (int i = 0; i < resourceCount; ++i)
-            if (resourceList[i] >= 0 && resourceList[i] < ndev) { dev = resourceList[i]; break; }
-        if (dev < 0) return fail(BEAGLE_ERROR_NO_RESOURCE, "beagleCreateInstance: requested resource not available");
+            if (resourceList[i] >= 0 && resourceList[i] < ndev) devices.push_back(resourceList[i]);
+        if (devices.empty()) return fail(BEAGLE_ERROR_NO_RESOURCE, "beagleCreateInstance: requested resource not available");
+    } else {
+        devices.push_back(0);
     }
+    if (const char* e = std::getenv("MBAMD_SHARD")) {      // MrBayes names at most one resource: shard over g devices from there
+        const int g = std::max(1, std::min(64, std::atoi(e)));
+        const int first = devices[0];
+        devices.clear();
+        for (int i = 0; i < g; ++i) devices.push_back((first + i) % ndev);
+    }
+    const int dev = devices[0];
     Instance* in = new Instance();
     in->flags = kSupport | (requirementFlags & (BEAGLE_FLAG_SCALING_ALWAYS | BEAGLE_FLAG_SCALING_DYNAMIC));
-    int rc = in->create(tipCount, partialsBufferCount, compactBufferCount, stateCount, patternCount, eigenBufferCount,
+    const int args[9] = {tipCount, partialsBufferCount, compactBufferCount, stateCount, patternCount, eigenBufferCount,
+                         matrixBufferCount, categoryCount, scaleBufferCount};
+    std::memcpy(in->createArgs, args, sizeof args);
+    in->shardDevices = devices;
+    int rc;
+    if (devices.size() > 1 && patternCount > 64) {
+        // facade from the start: dimensions only, the children own the device memory
+        in->device = dev;
+        in->tipCount = tipCount; in->nBuffers = partialsBufferCount + compactBufferCount; in->S = stateCount; in->P = patternCount;
+        in->Ppad = round_up(patternCount, 64); in->K = categoryCount; in->nEigen = eigenBufferCount; in->nMatrices = matrixBufferCount;
+        in->nScale = scaleBufferCount;
+        in->released = true;
+        rc = in->makeChildren(std::vector<std::pair<int, int>>(1, std::make_pair(0, patternCount)));
+    } else {
+        in->shardDevices.assign(1, dev);
+        rc = in->create(tipCount, partialsBufferCount, compactBufferCount, stateCount, patternCount, eigenBufferCount,
                         matrixBufferCount, categoryCount, scaleBufferCount, dev);
+    }
     if (rc != BEAGLE_SUCCESS) {
-        in->destroy();
+        in->destroyChildren();
+        if (!in->released) in->destroy();
         delete in;
         return rc;
     }
@@ -2134,11 +2414,12 @@ int beagleCreateInstance(int tipCount, int partialsBufferCount, int compactBuffe
         g_instances[id] = in;
     }
     if (returnInfo) {
+        const Instance* first = in->facade() ? in->children[0].in : in;
         returnInfo->resourceNumber = dev;
         returnInfo->resourceName = (dev < g_resources.length) ? g_resources.list[dev].name : const_cast<char*>("HIP device");
-        returnInfo->implName = const_cast<char*>(in->s4 ? "mbamd HIP gfx950: 4-state tree-walk kernels"
-                                                 : in->mfma ? "mbamd HIP gfx950: general-state MFMA (v_mfma_f32_32x32x2_f32) kernels"
-                                                            : "mbamd HIP gfx950: general-state vector kernels");
+        returnInfo->implName = const_cast<char*>(first->s4 ? "mbamd HIP gfx950: 4-state tree-walk kernels"
+                                                 : first->mfma ? "mbamd HIP gfx950: general-state MFMA (v_mfma_f32_32x32x2_f32) kernels"
+                                                               : "mbamd HIP gfx950: general-state vector kernels");
         returnInfo->implDescription = const_cast<char*>("hand-written HIP kernels for AMD CDNA4 (MI355X)");
         returnInfo->flags = in->flags;
     }
@@ -2162,7 +2443,8 @@ int beagleFinalizeInstance(int instance)
             std::fprintf(stderr, "[mbamd]   %-34s %9ld calls %10.3f ms total %9.2f us/call\n", a.name, a.calls,
                          a.seconds * 1e3, a.calls ? a.seconds * 1e6 / a.calls : 0.0);
     }
-    in->destroy();
+    in->destroyChildren();
+    if (!in->released) in->destroy();
     delete in;
     return BEAGLE_SUCCESS;
 }
@@ -2175,31 +2457,98 @@ int beagleFinalize(void)
         all.swap(g_instances);
     }
     for (Instance* in : all)
-        if (in) { in->destroy(); delete in; }
+        if (in) { in->destroyChildren(); if (!in->released) in->destroy(); delete in; }
     return BEAGLE_SUCCESS;
+}
+
+// v3: only meaningful for a CPU implementation (reference src/mbbeagle.c:384-387); its presence in the library is what
+// makes MrBayes' configure compile the v3 code path (configure.ac:220-223)
+int beagleSetCPUThreadCount(int instance, int threadCount)
+{
+    (void) threadCount;
+    GET_INSTANCE_NOFLUSH(instance);
+    return BEAGLE_SUCCESS;
+}
+
+// v3 multi-partition mode (reference src/mcmc.c:6464): patternPartitions[c] = partition of pattern c, partitions are
+// contiguous pattern ranges (MrBayes lists its divisions one after the other).  From here on the instance is a facade over
+// one child per partition (times the shards); tip data and pattern weights set so far are replayed into the children.
+int beagleSetPatternPartitions(int instance, int partitionCount, const int* inPatternPartitions)
+{
+    GET_INSTANCE(instance);
+    API_TRACE("beagleSetPatternPartitions(%d partitions)", partitionCount);
+    if (partitionCount < 1 || !inPatternPartitions) return fail(BEAGLE_ERROR_OUT_OF_RANGE, "beagleSetPatternPartitions: arguments");
+    if (!in->logOpen) return fail(BEAGLE_ERROR_GENERAL, "beagleSetPatternPartitions: call it before the first matrix / partials update");
+    std::vector<std::pair<int, int>> ranges;
+    for (int c = 0; c < in->P; ++c) {
+        const int p = inPatternPartitions[c];
+        if (p < 0 || p >= partitionCount) return fail(BEAGLE_ERROR_OUT_OF_RANGE, "beagleSetPatternPartitions: partition index");
+        if ((int) ranges.size() == p) ranges.emplace_back(c, 1);
+        else if ((int) ranges.size() == p + 1 && ranges[p].first + ranges[p].second == c) ranges[p].second++;
+        else return fail(BEAGLE_ERROR_NO_IMPLEMENTATION, "beagleSetPatternPartitions: partitions must be contiguous, increasing pattern ranges");
+    }
+    if ((int) ranges.size() != partitionCount) return fail(BEAGLE_ERROR_OUT_OF_RANGE, "beagleSetPatternPartitions: empty partition");
+    in->partitionCount = partitionCount;
+    if (partitionCount == 1 && !in->facade()) return BEAGLE_SUCCESS;
+    if (!in->released) {                          // hand the single-partition buffers back
+        in->destroy();
+        in->released = true;
+    }
+    return in->makeChildren(ranges);
 }
 
 int beagleSetTipStates(int instance, int tipIndex, const int* inStates)
 {
     GET_INSTANCE(instance);
     API_TRACE("beagleSetTipStates(tip=%d, states=%s...)", tipIndex, trace_ints(inStates, std::min(8, in->P)).c_str());
+    if (in->logOpen) in->logTipStates.emplace_back(tipIndex, std::vector<int>(inStates, inStates + in->P));
+    FACADE_ALL(c->setTipStates(tipIndex, inStates + ch.start));
     return in->setTipStates(tipIndex, inStates);
 }
 int beagleSetTipPartials(int instance, int tipIndex, const double* inPartials)
 {
     GET_INSTANCE(instance);
     API_TRACE("beagleSetTipPartials(tip=%d, %s...)", tipIndex, trace_doubles(inPartials, std::min(8, in->S)).c_str());
+    if (in->logOpen) in->logTipPartials.emplace_back(tipIndex, std::vector<double>(inPartials, inPartials + (size_t) in->P * in->S));
+    FACADE_ALL(c->importPartials(tipIndex, inPartials + (size_t) ch.start * in->S, false));
     return in->importPartials(tipIndex, inPartials, false);
 }
 int beagleSetPartials(int instance, int bufferIndex, const double* inPartials)
 {
     GET_INSTANCE(instance);
+    if (in->facade()) {
+        std::vector<double> part;
+        for (Instance::Child& ch : in->children) {
+            part.resize((size_t) in->K * ch.count * in->S);
+            for (int k = 0; k < in->K; ++k)
+                std::memcpy(part.data() + (size_t) k * ch.count * in->S, inPartials + ((size_t) k * in->P + ch.start) * in->S,
+                            sizeof(double) * ch.count * in->S);
+            (void) hipSetDevice(ch.in->device);
+            const int rc = ch.in->importPartials(bufferIndex, part.data(), true);
+            if (rc) return rc;
+        }
+        return BEAGLE_SUCCESS;
+    }
     return in->importPartials(bufferIndex, inPartials, true);
 }
 int beagleGetPartials(int instance, int bufferIndex, int scaleIndex, double* outPartials)
 {
     GET_INSTANCE(instance);
     if (scaleIndex != BEAGLE_OP_NONE) return fail(BEAGLE_ERROR_NO_IMPLEMENTATION, "beagleGetPartials: scaleIndex must be BEAGLE_OP_NONE");
+    if (in->facade()) {
+        std::vector<double> part;
+        for (Instance::Child& ch : in->children) {
+            part.resize((size_t) in->K * ch.count * in->S);
+            (void) hipSetDevice(ch.in->device);
+            if (!ch.in->pending.empty() || !ch.in->pendingJobs.empty()) { int frc = ch.in->flushPending(); if (frc) return frc; }
+            const int rc = ch.in->getPartials(bufferIndex, part.data());
+            if (rc) return rc;
+            for (int k = 0; k < in->K; ++k)
+                std::memcpy(outPartials + ((size_t) k * in->P + ch.start) * in->S, part.data() + (size_t) k * ch.count * in->S,
+                            sizeof(double) * ch.count * in->S);
+        }
+        return BEAGLE_SUCCESS;
+    }
     return in->getPartials(bufferIndex, outPartials);
 }
 int beagleSetEigenDecomposition(int instance, int eigenIndex, const double* inEigenVectors,
@@ -2208,6 +2557,7 @@ int beagleSetEigenDecomposition(int instance, int eigenIndex, const double* inEi
     StatTimer st_(ST_SET);
     GET_INSTANCE(instance);
     API_TRACE("beagleSetEigenDecomposition(eigen=%d, values=%s...)", eigenIndex, trace_doubles(inEigenValues, std::min(6, in->S)).c_str());
+    FACADE_ALL(c->setEigen(eigenIndex, inEigenVectors, inInverseEigenVectors, inEigenValues));
     return in->setEigen(eigenIndex, inEigenVectors, inInverseEigenVectors, inEigenValues);
 }
 int beagleSetStateFrequencies(int instance, int idx, const double* f)
@@ -2216,6 +2566,7 @@ int beagleSetStateFrequencies(int instance, int idx, const double* f)
     GET_INSTANCE(instance);
     API_TRACE("beagleSetStateFrequencies(%d, %s...)", idx, trace_doubles(f, std::min(6, in->S)).c_str());
     if (idx < 0 || idx >= in->nEigen) return fail(BEAGLE_ERROR_OUT_OF_RANGE, "beagleSetStateFrequencies: index");
+    FACADE_ALL(c->uploadIfChanged(c->h_freqs, (size_t) idx * c->S, c->d_freqs, f, c->S));
     return in->uploadIfChanged(in->h_freqs, (size_t) idx * in->S, in->d_freqs, f, in->S);
 }
 int beagleSetCategoryWeights(int instance, int idx, const double* w)
@@ -2224,6 +2575,7 @@ int beagleSetCategoryWeights(int instance, int idx, const double* w)
     GET_INSTANCE(instance);
     API_TRACE("beagleSetCategoryWeights(%d, %s)", idx, trace_doubles(w, in->K).c_str());
     if (idx < 0 || idx >= in->nEigen) return fail(BEAGLE_ERROR_OUT_OF_RANGE, "beagleSetCategoryWeights: index");
+    FACADE_ALL(c->uploadIfChanged(c->h_weights, (size_t) idx * c->K, c->d_weights, w, c->K));
     return in->uploadIfChanged(in->h_weights, (size_t) idx * in->K, in->d_weights, w, in->K);
 }
 int beagleSetCategoryRates(int instance, const double* r)
@@ -2231,13 +2583,23 @@ int beagleSetCategoryRates(int instance, const double* r)
     StatTimer st_(ST_SET);
     GET_INSTANCE(instance);
     API_TRACE("beagleSetCategoryRates(%s)", trace_doubles(r, in->K).c_str());
-    if (in->K > MBAMD_MAX_RATES) return fail(BEAGLE_ERROR_NO_IMPLEMENTATION, "more than 16 rate categories");
-    for (int k = 0; k < in->K; ++k) in->rates.r[k] = r[k];
-    return BEAGLE_SUCCESS;
+    FACADE_ALL(c->setRates(0, r));
+    return in->setRates(0, r);
+}
+// v3 (reference src/mbbeagle.c:2055): one rate vector per partition, named by index in beagleUpdateTransitionMatricesWithMultipleModels
+int beagleSetCategoryRatesWithIndex(int instance, int categoryRatesIndex, const double* r)
+{
+    StatTimer st_(ST_SET);
+    GET_INSTANCE(instance);
+    API_TRACE("beagleSetCategoryRatesWithIndex(%d, %s)", categoryRatesIndex, trace_doubles(r, in->K).c_str());
+    FACADE_ALL(c->setRates(categoryRatesIndex, r));
+    return in->setRates(categoryRatesIndex, r);
 }
 int beagleSetPatternWeights(int instance, const double* w)
 {
     GET_INSTANCE(instance);
+    if (in->logOpen) in->logWeights.assign(w, w + in->P);
+    FACADE_ALL(c->upload(c->d_pweights, w + ch.start, sizeof(double) * ch.count));
     return in->upload(in->d_pweights, w, sizeof(double) * in->P);
 }
 int beagleUpdateTransitionMatrices(int instance, int eigenIndex, const int* probabilityIndices,
@@ -2248,23 +2610,60 @@ int beagleUpdateTransitionMatrices(int instance, int eigenIndex, const int* prob
     GET_INSTANCE_NOFLUSH(instance);
     API_TRACE("beagleUpdateTransitionMatrices(eigen=%d, count=%d, indices=%s..., lengths=%s...)", eigenIndex, count,
               trace_ints(probabilityIndices, std::min(6, count)).c_str(), trace_doubles(edgeLengths, std::min(6, count)).c_str());
+    if (firstDerivativeIndices || secondDerivativeIndices)
+        return fail(BEAGLE_ERROR_NO_IMPLEMENTATION, "beagleUpdateTransitionMatrices: derivatives");
+    in->closeLog();
+    FACADE_EACH(false, (c->pending.empty() ? BEAGLE_SUCCESS : c->flushPending()) != BEAGLE_SUCCESS
+                           ? BEAGLE_ERROR_GENERAL : c->updateMatrices(eigenIndex, probabilityIndices, edgeLengths, count));
     if (!in->pending.empty()) {                  // deferred lists read the matrices about to be replaced
         int frc_ = in->flushPending();
         if (frc_ != BEAGLE_SUCCESS) return frc_;
     }
-    if (firstDerivativeIndices || secondDerivativeIndices)
-        return fail(BEAGLE_ERROR_NO_IMPLEMENTATION, "beagleUpdateTransitionMatrices: derivatives");
     return in->updateMatrices(eigenIndex, probabilityIndices, edgeLengths, count);
+}
+// v3 (reference src/mbbeagle.c:2140-2147): every matrix names its own eigen-system and category-rate vector
+int beagleUpdateTransitionMatricesWithMultipleModels(int instance, const int* eigenIndices, const int* categoryRateIndices,
+                                                     const int* probabilityIndices, const int* firstDerivativeIndices,
+                                                     const int* secondDerivativeIndices, const double* edgeLengths, int count)
+{
+    StatTimer st_(ST_MATRICES);
+    GET_INSTANCE_NOFLUSH(instance);
+    API_TRACE("beagleUpdateTransitionMatricesWithMultipleModels(count=%d, eigen=%s..., rates=%s...)", count,
+              trace_ints(eigenIndices, std::min(6, count)).c_str(), trace_ints(categoryRateIndices, std::min(6, count)).c_str());
+    if (firstDerivativeIndices || secondDerivativeIndices)
+        return fail(BEAGLE_ERROR_NO_IMPLEMENTATION, "beagleUpdateTransitionMatricesWithMultipleModels: derivatives");
+    in->closeLog();
+    auto run = [&](Instance* c) {
+        if (!c->pending.empty()) { int frc = c->flushPending(); if (frc) return frc; }
+        int i = 0;
+        while (i < count) {                      // runs of equal (eigen-system, rate vector)
+            int j = i + 1;
+            while (j < count && eigenIndices[j] == eigenIndices[i] && categoryRateIndices[j] == categoryRateIndices[i]) ++j;
+            const int rc = c->updateMatrices(eigenIndices[i], probabilityIndices + i, edgeLengths + i, j - i, categoryRateIndices[i]);
+            if (rc) return rc;
+            i = j;
+        }
+        return (int) BEAGLE_SUCCESS;
+    };
+    FACADE_EACH(false, run(c));
+    return run(in);
 }
 int beagleSetTransitionMatrix(int instance, int matrixIndex, const double* inMatrix, double paddedValue)
 {
     (void) paddedValue;
     GET_INSTANCE(instance);
+    FACADE_ALL(c->setMatrix(matrixIndex, inMatrix));
     return in->setMatrix(matrixIndex, inMatrix);
 }
 int beagleGetTransitionMatrix(int instance, int matrixIndex, double* outMatrix)
 {
     GET_INSTANCE(instance);
+    if (in->facade()) {
+        Instance* c = in->children[0].in;
+        (void) hipSetDevice(c->device);
+        if (!c->pending.empty() || !c->pendingJobs.empty()) { int frc = c->flushPending(); if (frc) return frc; }
+        return c->getMatrix(matrixIndex, outMatrix);
+    }
     return in->getMatrix(matrixIndex, outMatrix);
 }
 int beagleUpdatePartials(int instance, const BeagleOperation* operations, int operationCount, int cumulativeScaleIndex)
@@ -2274,118 +2673,174 @@ int beagleUpdatePartials(int instance, const BeagleOperation* operations, int op
     API_TRACE("beagleUpdatePartials(count=%d, cumulative=%d, first=%s, last=%s)", operationCount, cumulativeScaleIndex,
               trace_ints(reinterpret_cast<const int*>(operations), operationCount > 0 ? 7 : 0).c_str(),
               trace_ints(reinterpret_cast<const int*>(operations + std::max(0, operationCount - 1)), operationCount > 0 ? 7 : 0).c_str());
+    in->closeLog();
+    FACADE_EACH(false, c->updatePartials(operations, operationCount, cumulativeScaleIndex));
     return in->updatePartials(operations, operationCount, cumulativeScaleIndex);
+}
+// v3 (reference src/mbbeagle.c:2292, 2440, 2616): operations of several partitions in one array; every operation names its
+// partition and its cumulative scale buffer.  Each partition's operations, in order, are one list for that partition's child.
+int beagleUpdatePartialsByPartition(int instance, const BeagleOperationByPartition* operations, int operationCount)
+{
+    StatTimer st_(ST_PARTIALS);
+    GET_INSTANCE_NOFLUSH(instance);
+    API_TRACE("beagleUpdatePartialsByPartition(count=%d)", operationCount);
+    in->closeLog();
+    std::vector<BeagleOperation> list;
+    auto runFor = [&](Instance* c, int partition) {
+        int i = 0;
+        while (i < operationCount) {
+            while (i < operationCount && partition >= 0 && operations[i].partition != partition) ++i;
+            if (i >= operationCount) break;
+            const int cum = operations[i].cumulativeScaleIndex;
+            list.clear();
+            while (i < operationCount && operations[i].cumulativeScaleIndex == cum) {
+                if (partition < 0 || operations[i].partition == partition) {
+                    BeagleOperation o;
+                    std::memcpy(&o, &operations[i], sizeof o);       // the first seven ints are the plain operation
+                    list.push_back(o);
+                }
+                ++i;
+            }
+            if (!list.empty()) { const int rc = c->updatePartials(list.data(), (int) list.size(), cum); if (rc) return rc; }
+        }
+        return (int) BEAGLE_SUCCESS;
+    };
+    FACADE_EACH(false, runFor(c, in->partitionCount > 1 ? ch.partition : -1));
+    for (int i = 0; i < operationCount; ++i)
+        if (operations[i].partition != 0) return fail(BEAGLE_ERROR_OUT_OF_RANGE, "beagleUpdatePartialsByPartition: partition index (no partitions were set)");
+    return runFor(in, -1);
 }
 int beagleWaitForPartials(int instance, const int* destinationPartials, int destinationPartialsCount)
 {
     (void) destinationPartials; (void) destinationPartialsCount;
     GET_INSTANCE(instance);
+    FACADE_ALL(hipStreamSynchronize(c->stream) == hipSuccess ? BEAGLE_SUCCESS : BEAGLE_ERROR_GENERAL);
     HIP_TRY(hipStreamSynchronize(in->stream));
+    return BEAGLE_SUCCESS;
+}
+
+// scale-factor bookkeeping; `partition` < 0: all patterns
+static int scale_accumulate(Instance* in, const int* scaleIndices, int count, int cumulativeScaleIndex, int sign, int partition)
+{
+    (void) hipSetDevice(in->device);
+    FACADE_ALL((partition >= 0 && in->partitionCount > 1 && ch.partition != partition) ? BEAGLE_SUCCESS
+               : (c->s4 ? c->accumulate4(scaleIndices, count, cumulativeScaleIndex, sign) : c->accumulate(scaleIndices, count, cumulativeScaleIndex, sign)));
+    if (in->s4) return in->accumulate4(scaleIndices, count, cumulativeScaleIndex, sign);
+    return in->accumulate(scaleIndices, count, cumulativeScaleIndex, sign);
+}
+static int scale_reset(Instance* in, int idx)
+{
+    if (idx < 0 || idx >= in->nScale) return fail(BEAGLE_ERROR_OUT_OF_RANGE, "beagleResetScaleFactors: index");
+    if (in->s4) {
+        // MrBayes resets every scale buffer once at start-up (reference src/mcmc.c:6270): nothing is allocated or
+        // launched for a buffer until it is used -- "never written" reads as zero everywhere
+        if (in->scaleState[idx] == 1) {           // node exponents in the arena: later reads must see zeros
+            MBAMD_LAUNCH(k_exp_copy, (unsigned) (((size_t) in->K * in->Ppad + 255) / 256), 256, 0, in->stream, in->arenaExp, in->estride,
+                         -1, idx, in->K, in->Ppad);
+            HIP_TRY(hipGetLastError());
+        }
+        in->scaleState[idx] = 0;
+        return BEAGLE_SUCCESS;
+    }
+    if (!in->scale[idx]) return in->ensureScale(idx);   // allocated zeroed
+    MBAMD_LAUNCH(k_scale_copy, (unsigned) ((in->Ppad + 255) / 256), 256, 0, in->stream, (const int32_t*) nullptr, in->Ppad, in->scale[idx]);
+    HIP_TRY(hipGetLastError());
+    return BEAGLE_SUCCESS;
+}
+static int scale_copy(Instance* in, int dst, int src)
+{
+    if (dst < 0 || dst >= in->nScale || src < 0 || src >= in->nScale) return fail(BEAGLE_ERROR_OUT_OF_RANGE, "beagleCopyScaleFactors: index");
+    if (in->s4) {
+        const int st = in->scaleState[src];
+        if (st == 2) {
+            in->scaleState[dst] = 0;
+            int rc4 = in->ensureWide(dst);
+            if (rc4) return rc4;
+            HIP_TRY(hipMemcpyAsync(in->wideScale[dst], in->wideScale[src], (size_t) in->K * in->Ppad * sizeof(int32_t),
+                                   hipMemcpyDeviceToDevice, in->stream));
+        } else if (st == 1) {
+            MBAMD_LAUNCH(k_exp_copy, (unsigned) (((size_t) in->K * in->Ppad + 255) / 256), 256, 0, in->stream, in->arenaExp, in->estride,
+                         src, dst, in->K, in->Ppad);
+            HIP_TRY(hipGetLastError());
+            in->scaleState[dst] = 1;
+        } else {
+            return scale_reset(in, dst);
+        }
+        return BEAGLE_SUCCESS;
+    }
+    int rc = in->ensureScale(dst);
+    if (rc) return rc;
+    rc = in->ensureScale(src);
+    if (rc) return rc;
+    MBAMD_LAUNCH(k_scale_copy, (unsigned) ((in->Ppad + 255) / 256), 256, 0, in->stream, (const int32_t*) in->scale[src], in->Ppad, in->scale[dst]);
+    HIP_TRY(hipGetLastError());
     return BEAGLE_SUCCESS;
 }
 int beagleAccumulateScaleFactors(int instance, const int* scaleIndices, int count, int cumulativeScaleIndex)
 {
     StatTimer st_(ST_SCALE);
     GET_INSTANCE(instance);
-    if (in->s4) return in->accumulate4(scaleIndices, count, cumulativeScaleIndex, +1);
-    return in->accumulate(scaleIndices, count, cumulativeScaleIndex, +1);
+    return scale_accumulate(in, scaleIndices, count, cumulativeScaleIndex, +1, -1);
 }
 int beagleRemoveScaleFactors(int instance, const int* scaleIndices, int count, int cumulativeScaleIndex)
 {
     StatTimer st_(ST_SCALE);
     GET_INSTANCE(instance);
-    if (in->s4) return in->accumulate4(scaleIndices, count, cumulativeScaleIndex, -1);
-    return in->accumulate(scaleIndices, count, cumulativeScaleIndex, -1);
+    return scale_accumulate(in, scaleIndices, count, cumulativeScaleIndex, -1, -1);
 }
 int beagleResetScaleFactors(int instance, int cumulativeScaleIndex)
 {
     StatTimer st_(ST_SCALE);
     GET_INSTANCE(instance);
-    if (cumulativeScaleIndex < 0 || cumulativeScaleIndex >= in->nScale)
-        return fail(BEAGLE_ERROR_OUT_OF_RANGE, "beagleResetScaleFactors: index");
-    if (in->s4) {
-        // MrBayes resets every scale buffer once at start-up (reference src/mcmc.c:6270): nothing is allocated or
-        // launched for a buffer until it is used -- "never written" reads as zero everywhere
-        if (in->scaleState[cumulativeScaleIndex] == 1) {           // node exponents in the arena: later reads must see zeros
-            MBAMD_LAUNCH(k_exp_copy, (unsigned) (((size_t) in->K * in->Ppad + 255) / 256), 256, 0, in->stream, in->arenaExp, in->estride,
-                         -1, cumulativeScaleIndex, in->K, in->Ppad);
-            HIP_TRY(hipGetLastError());
-        }
-        in->scaleState[cumulativeScaleIndex] = 0;
-        return BEAGLE_SUCCESS;
-    }
-    if (!in->scale[cumulativeScaleIndex]) return in->ensureScale(cumulativeScaleIndex);   // allocated zeroed
-    MBAMD_LAUNCH(k_scale_copy, (unsigned) ((in->Ppad + 255) / 256), 256, 0, in->stream, (const int32_t*) nullptr, in->Ppad,
-                 in->scale[cumulativeScaleIndex]);
-    HIP_TRY(hipGetLastError());
-    return BEAGLE_SUCCESS;
+    FACADE_ALL(scale_reset(c, cumulativeScaleIndex));
+    return scale_reset(in, cumulativeScaleIndex);
 }
 int beagleCopyScaleFactors(int instance, int destScalingIndex, int srcScalingIndex)
 {
     StatTimer st_(ST_SCALE);
     GET_INSTANCE(instance);
-    if (destScalingIndex < 0 || destScalingIndex >= in->nScale || srcScalingIndex < 0 || srcScalingIndex >= in->nScale)
-        return fail(BEAGLE_ERROR_OUT_OF_RANGE, "beagleCopyScaleFactors: index");
-    if (in->s4) {
-        const int st = in->scaleState[srcScalingIndex];
-        if (st == 2) {
-            in->scaleState[destScalingIndex] = 0;
-            int rc4 = in->ensureWide(destScalingIndex);
-            if (rc4) return rc4;
-            HIP_TRY(hipMemcpyAsync(in->wideScale[destScalingIndex], in->wideScale[srcScalingIndex],
-                                   (size_t) in->K * in->Ppad * sizeof(int32_t), hipMemcpyDeviceToDevice, in->stream));
-        } else if (st == 1) {
-            MBAMD_LAUNCH(k_exp_copy, (unsigned) (((size_t) in->K * in->Ppad + 255) / 256), 256, 0, in->stream, in->arenaExp, in->estride,
-                         srcScalingIndex, destScalingIndex, in->K, in->Ppad);
-            HIP_TRY(hipGetLastError());
-            in->scaleState[destScalingIndex] = 1;
-        } else {
-            return beagleResetScaleFactors(instance, destScalingIndex);
-        }
-        return BEAGLE_SUCCESS;
-    }
-    int rc = in->ensureScale(destScalingIndex);
-    if (rc) return rc;
-    rc = in->ensureScale(srcScalingIndex);
-    if (rc) return rc;
-    MBAMD_LAUNCH(k_scale_copy, (unsigned) ((in->Ppad + 255) / 256), 256, 0, in->stream,
-                 (const int32_t*) in->scale[srcScalingIndex], in->Ppad, in->scale[destScalingIndex]);
-    HIP_TRY(hipGetLastError());
-    return BEAGLE_SUCCESS;
+    FACADE_ALL(scale_copy(c, destScalingIndex, srcScalingIndex));
+    return scale_copy(in, destScalingIndex, srcScalingIndex);
+}
+// v3 (reference src/likelihood.c:8096-8103, src/mbbeagle.c:2566): the same on one partition's patterns
+int beagleAccumulateScaleFactorsByPartition(int instance, const int* scaleIndices, int count, int cumulativeScaleIndex, int partitionIndex)
+{
+    StatTimer st_(ST_SCALE);
+    GET_INSTANCE(instance);
+    return scale_accumulate(in, scaleIndices, count, cumulativeScaleIndex, +1, partitionIndex);
+}
+int beagleRemoveScaleFactorsByPartition(int instance, const int* scaleIndices, int count, int cumulativeScaleIndex, int partitionIndex)
+{
+    StatTimer st_(ST_SCALE);
+    GET_INSTANCE(instance);
+    return scale_accumulate(in, scaleIndices, count, cumulativeScaleIndex, -1, partitionIndex);
+}
+int beagleResetScaleFactorsByPartition(int instance, int cumulativeScaleIndex, int partitionIndex)
+{
+    StatTimer st_(ST_SCALE);
+    GET_INSTANCE(instance);
+    FACADE_ALL((in->partitionCount > 1 && ch.partition != partitionIndex) ? BEAGLE_SUCCESS : scale_reset(c, cumulativeScaleIndex));
+    return scale_reset(in, cumulativeScaleIndex);
 }
 // engine extension: the binary exponents behind a scale buffer, out[k * patternCount + c] (the general-state
 // path keeps one exponent per pattern: every category row is the same)
 int mbamdGetScaleExponents(int instance, int srcScalingIndex, int* out)
 {
     GET_INSTANCE(instance);
-    if (srcScalingIndex < 0 || srcScalingIndex >= in->nScale) return fail(BEAGLE_ERROR_OUT_OF_RANGE, "scale exponents: index");
-    const int K = in->K, P = in->P, Ppad = in->Ppad;
-    HIP_TRY(hipStreamSynchronize(in->stream));
-    if (!in->s4) {
-        int rc = in->ensureScale(srcScalingIndex);
-        if (rc) return rc;
-        std::vector<int32_t> h(Ppad);
-        HIP_TRY(hipStreamSynchronize(in->stream));
-        HIP_TRY(hipMemcpy(h.data(), in->scale[srcScalingIndex], (size_t) Ppad * sizeof(int32_t), hipMemcpyDeviceToHost));
-        for (int k = 0; k < K; ++k) for (int c = 0; c < P; ++c) out[(size_t) k * P + c] = h[c];
+    if (in->facade()) {
+        std::vector<int> part;
+        for (Instance::Child& ch : in->children) {
+            part.resize((size_t) in->K * ch.count);
+            (void) hipSetDevice(ch.in->device);
+            if (!ch.in->pending.empty() || !ch.in->pendingJobs.empty()) { int frc = ch.in->flushPending(); if (frc) return frc; }
+            const int rc = ch.in->getScaleExponents(srcScalingIndex, part.data());
+            if (rc) return rc;
+            for (int k = 0; k < in->K; ++k)
+                std::memcpy(out + (size_t) k * in->P + ch.start, part.data() + (size_t) k * ch.count, sizeof(int) * ch.count);
+        }
         return BEAGLE_SUCCESS;
     }
-    const int st = in->scaleState[srcScalingIndex];
-    if (st == 0) { std::fill(out, out + (size_t) K * P, 0); return BEAGLE_SUCCESS; }
-    std::vector<int32_t> h((size_t) K * Ppad);
-    if (st == 2) {
-        HIP_TRY(hipMemcpy(h.data(), in->wideScale[srcScalingIndex], h.size() * sizeof(int32_t), hipMemcpyDeviceToHost));
-    } else {
-        int rc = in->grow(&in->d_tmp, &in->tmpCap, h.size() * sizeof(int32_t));
-        if (rc) return rc;
-        MBAMD_LAUNCH(k_exp_widen, (unsigned) ((h.size() + 255) / 256), 256, 0, in->stream, (const int8_t*) in->arenaExp, in->estride,
-                     srcScalingIndex, K, Ppad, (int32_t*) in->d_tmp);
-        HIP_TRY(hipGetLastError());
-        HIP_TRY(hipStreamSynchronize(in->stream));
-        HIP_TRY(hipMemcpy(h.data(), in->d_tmp, h.size() * sizeof(int32_t), hipMemcpyDeviceToHost));
-    }
-    for (int k = 0; k < K; ++k) for (int c = 0; c < P; ++c) out[(size_t) k * P + c] = h[(size_t) k * Ppad + c];
-    return BEAGLE_SUCCESS;
+    return in->getScaleExponents(srcScalingIndex, out);
 }
 // BEAGLE's scale factors are one log value per pattern.  The 4-state path keeps an exponent per (pattern, category):
 // reported here is the largest of a pattern's exponents (times ln 2), the factor a per-pattern scaler would have used.
@@ -2409,8 +2864,8 @@ int beagleCalculateRootLogLikelihoods(int instance, const int* bufferIndices, co
 {
     StatTimer st_(ST_LNL);
     GET_INSTANCE(instance);
-    const int rc_ = in->integrate(bufferIndices, nullptr, nullptr, categoryWeightsIndices, stateFrequenciesIndices,
-                                  cumulativeScaleIndices, count, outSumLogLikelihood);
+    const int rc_ = integrate_any(in, bufferIndices, nullptr, nullptr, categoryWeightsIndices, stateFrequenciesIndices,
+                                  cumulativeScaleIndices, count, nullptr, 1, nullptr, outSumLogLikelihood);
     API_TRACE("beagleCalculateRootLogLikelihoods(buffers=%s, weights=%s, freqs=%s, cumulative=%s) -> %d, lnL %.6f",
               trace_ints(bufferIndices, count).c_str(), trace_ints(categoryWeightsIndices, count).c_str(),
               trace_ints(stateFrequenciesIndices, count).c_str(), trace_ints(cumulativeScaleIndices, count).c_str(), rc_,
@@ -2428,8 +2883,8 @@ int beagleCalculateEdgeLogLikelihoods(int instance, const int* parentBufferIndic
     GET_INSTANCE(instance);
     if (firstDerivativeIndices || secondDerivativeIndices || outSumFirstDerivative || outSumSecondDerivative)
         return fail(BEAGLE_ERROR_NO_IMPLEMENTATION, "beagleCalculateEdgeLogLikelihoods: derivatives");
-    const int rc_ = in->integrate(parentBufferIndices, childBufferIndices, probabilityIndices, categoryWeightsIndices,
-                                  stateFrequenciesIndices, cumulativeScaleIndices, count, outSumLogLikelihood);
+    const int rc_ = integrate_any(in, parentBufferIndices, childBufferIndices, probabilityIndices, categoryWeightsIndices,
+                                  stateFrequenciesIndices, cumulativeScaleIndices, count, nullptr, 1, nullptr, outSumLogLikelihood);
     API_TRACE("beagleCalculateEdgeLogLikelihoods(parents=%s, children=%s, matrices=%s, weights=%s, freqs=%s, cumulative=%s) -> %d, lnL %.6f",
               trace_ints(parentBufferIndices, count).c_str(), trace_ints(childBufferIndices, count).c_str(),
               trace_ints(probabilityIndices, count).c_str(), trace_ints(categoryWeightsIndices, count).c_str(),
@@ -2437,54 +2892,110 @@ int beagleCalculateEdgeLogLikelihoods(int instance, const int* parentBufferIndic
               outSumLogLikelihood ? *outSumLogLikelihood : 0.0);
     return rc_;
 }
+// v3 (reference src/mbbeagle.c:2817-2850): index arrays are [count][partitionCount]; one sum per named partition + the total
+int beagleCalculateRootLogLikelihoodsByPartition(int instance, const int* bufferIndices, const int* categoryWeightsIndices,
+                                                 const int* stateFrequenciesIndices, const int* cumulativeScaleIndices,
+                                                 const int* partitionIndices, int partitionCount, int count,
+                                                 double* outSumLogLikelihoodByPartition, double* outSumLogLikelihood)
+{
+    StatTimer st_(ST_LNL);
+    GET_INSTANCE(instance);
+    if (!in->facade() && (partitionCount != 1 || partitionIndices[0] != 0))
+        return fail(BEAGLE_ERROR_OUT_OF_RANGE, "beagleCalculateRootLogLikelihoodsByPartition: no partitions were set");
+    double total = 0.0;
+    const int rc_ = integrate_any(in, bufferIndices, nullptr, nullptr, categoryWeightsIndices, stateFrequenciesIndices,
+                                  cumulativeScaleIndices, count, partitionIndices, partitionCount, outSumLogLikelihoodByPartition, &total);
+    if (!in->facade() && outSumLogLikelihoodByPartition) outSumLogLikelihoodByPartition[0] = total;
+    if (outSumLogLikelihood) *outSumLogLikelihood = total;
+    API_TRACE("beagleCalculateRootLogLikelihoodsByPartition(%d partitions) -> %d, lnL %.6f", partitionCount, rc_, total);
+    return rc_;
+}
+int beagleCalculateEdgeLogLikelihoodsByPartition(int instance, const int* parentBufferIndices, const int* childBufferIndices,
+                                                 const int* probabilityIndices, const int* firstDerivativeIndices,
+                                                 const int* secondDerivativeIndices, const int* categoryWeightsIndices,
+                                                 const int* stateFrequenciesIndices, const int* cumulativeScaleIndices,
+                                                 const int* partitionIndices, int partitionCount, int count,
+                                                 double* outSumLogLikelihoodByPartition, double* outSumLogLikelihood,
+                                                 double* outSumFirstDerivativeByPartition, double* outSumFirstDerivative,
+                                                 double* outSumSecondDerivativeByPartition, double* outSumSecondDerivative)
+{
+    StatTimer st_(ST_LNL);
+    GET_INSTANCE(instance);
+    if (firstDerivativeIndices || secondDerivativeIndices || outSumFirstDerivativeByPartition || outSumFirstDerivative ||
+        outSumSecondDerivativeByPartition || outSumSecondDerivative)
+        return fail(BEAGLE_ERROR_NO_IMPLEMENTATION, "beagleCalculateEdgeLogLikelihoodsByPartition: derivatives");
+    if (!in->facade() && (partitionCount != 1 || partitionIndices[0] != 0))
+        return fail(BEAGLE_ERROR_OUT_OF_RANGE, "beagleCalculateEdgeLogLikelihoodsByPartition: no partitions were set");
+    double total = 0.0;
+    const int rc_ = integrate_any(in, parentBufferIndices, childBufferIndices, probabilityIndices, categoryWeightsIndices,
+                                  stateFrequenciesIndices, cumulativeScaleIndices, count, partitionIndices, partitionCount,
+                                  outSumLogLikelihoodByPartition, &total);
+    if (!in->facade() && outSumLogLikelihoodByPartition) outSumLogLikelihoodByPartition[0] = total;
+    if (outSumLogLikelihood) *outSumLogLikelihood = total;
+    API_TRACE("beagleCalculateEdgeLogLikelihoodsByPartition(%d partitions) -> %d, lnL %.6f", partitionCount, rc_, total);
+    return rc_;
+}
 int beagleGetSiteLogLikelihoods(int instance, double* outLogLikelihoods)
 {
     StatTimer st_(ST_SITE);
     GET_INSTANCE(instance);
-    if (!in->haveSite) return fail(BEAGLE_ERROR_GENERAL, "beagleGetSiteLogLikelihoods: no likelihood computed yet");
-    HIP_TRY(hipStreamSynchronize(in->stream));
-    if (in->siteOnHost) {
-        std::memcpy(outLogLikelihoods, in->h_site, (size_t) in->P * sizeof(double));
-    } else {
-        HIP_TRY(hipMemcpy(outLogLikelihoods, in->d_site, (size_t) in->P * sizeof(double), hipMemcpyDeviceToHost));
-        if (!in->h_site && hipHostMalloc((void**) &in->h_site, (size_t) in->Ppad * sizeof(double), hipHostMallocDefault) == hipSuccess) {
-            if (hipHostGetDevicePointer((void**) &in->h_site_dev, in->h_site, 0) != hipSuccess) in->h_site_dev = nullptr;
-        }
-        in->siteToHost = in->h_site_dev != nullptr && !in->noSiteHost;   // this client reads them: later evaluations write to the host directly
-    }
-    return BEAGLE_SUCCESS;
+    FACADE_ALL(c->haveSite ? c->getSites(outLogLikelihoods + ch.start) : BEAGLE_SUCCESS);
+    return in->getSites(outLogLikelihoods);
 }
 
 // ---- engine extensions ---------------------------------------------------------------------
 int mbamdSynchronize(int instance)
 {
     GET_INSTANCE(instance);
+    FACADE_ALL(hipStreamSynchronize(c->stream) == hipSuccess ? BEAGLE_SUCCESS : BEAGLE_ERROR_GENERAL);
     HIP_TRY(hipStreamSynchronize(in->stream));
     return BEAGLE_SUCCESS;
 }
 int mbamdKernelTiming(int instance, int enable)
 {
     GET_INSTANCE(instance);
+    if (in->facade()) { for (Instance::Child& ch : in->children) ch.in->timing = enable != 0; return BEAGLE_SUCCESS; }
     in->timing = enable != 0;
     return BEAGLE_SUCCESS;
 }
-int mbamdGetKernelTiming(int instance, double* outMilliseconds, long* outLaunches, int reset)
+static int kernel_timing_of(Instance* in, double* ms, long* launches, int reset)
 {
-    GET_INSTANCE(instance);
+    (void) hipSetDevice(in->device);
     HIP_TRY(hipStreamSynchronize(in->stream));
     for (auto& ev : in->events) {
-        float ms = 0.0f;
-        HIP_TRY(hipEventElapsedTime(&ms, ev.first, ev.second));
-        in->timedMs += ms;
+        float t = 0.0f;
+        HIP_TRY(hipEventElapsedTime(&t, ev.first, ev.second));
+        in->timedMs += t;
         (void) hipEventDestroy(ev.first);
         (void) hipEventDestroy(ev.second);
     }
     in->events.clear();
     in->timedLaunches += in->pendingLaunches;
     in->pendingLaunches = 0;
-    if (outMilliseconds) *outMilliseconds = in->timedMs;
-    if (outLaunches) *outLaunches = in->timedLaunches;
+    *ms += in->timedMs;
+    *launches += in->timedLaunches;
     if (reset) { in->timedMs = 0.0; in->timedLaunches = 0; }
+    return BEAGLE_SUCCESS;
+}
+// (a facade reports the LARGEST kernel time of its children -- they run side by side -- and the sum of the launches)
+int mbamdGetKernelTiming(int instance, double* outMilliseconds, long* outLaunches, int reset)
+{
+    GET_INSTANCE(instance);
+    double ms = 0.0;
+    long launches = 0;
+    if (in->facade()) {
+        for (Instance::Child& ch : in->children) {
+            double m = 0.0;
+            int rc = kernel_timing_of(ch.in, &m, &launches, reset);
+            if (rc) return rc;
+            ms = std::max(ms, m);
+        }
+    } else {
+        int rc = kernel_timing_of(in, &ms, &launches, reset);
+        if (rc) return rc;
+    }
+    if (outMilliseconds) *outMilliseconds = ms;
+    if (outLaunches) *outLaunches = launches;
     return BEAGLE_SUCCESS;
 }
 int mbamdSetKernelPath(int instance, int path)
@@ -2505,15 +3016,23 @@ int mbamdWalkTrace(int instance, long long* out, int maxSteps, int* outSteps, in
     if (outWaves) *outWaves = in->walkWaves + 1;
     return BEAGLE_SUCCESS;
 }
+// the number of child instances behind this instance (1: none) -- pattern partitions x shards
+int mbamdGetChildCount(int instance)
+{
+    GET_INSTANCE_NOFLUSH(instance);
+    return in->facade() ? (int) in->children.size() : 1;
+}
 int mbamdSetDeferredResult(int instance, int enable)
 {
     GET_INSTANCE(instance);
+    if (in->facade()) return enable ? fail(BEAGLE_ERROR_NO_IMPLEMENTATION, "mbamdSetDeferredResult: not on a partitioned / sharded instance") : BEAGLE_SUCCESS;
     in->deferred = enable != 0;
     return BEAGLE_SUCCESS;
 }
 int mbamdFetchLogLikelihood(int instance, double* outSumLogLikelihood)
 {
     GET_INSTANCE(instance);
+    if (in->facade()) return fail(BEAGLE_ERROR_NO_IMPLEMENTATION, "mbamdFetchLogLikelihood: not on a partitioned / sharded instance");
     return in->fetchResult(outSumLogLikelihood);
 }
 

@@ -243,6 +243,106 @@ def check_hazard_lists(lib, nstates, ncat, npat, seed=5):
         assert np.array_equal(a, b)
 
 
+def check_sharded_instance(lib, oracle, div, monkeypatch, shards=3):
+    """Site-pattern sharding inside one instance: MBAMD_SHARD=<g> (or a resource list with several GPUs)
+    splits the patterns over g child engines -- here g children on the same device.  Every read-out equals the unsharded
+    instance's: lnL to the last bit of the per-pattern values (the sum is formed per child), partial updates, rejects."""
+    base = lk.BeagleDivision(div, lib)
+    want = base.LogLike(0)
+    want_sites = base.inst.get_site_log_likelihoods()
+    base.finalize()
+    monkeypatch.setenv("MBAMD_SHARD", str(shards))
+    for scaling in (lk.MB_BEAGLE_SCALE_ALWAYS, lk.MB_BEAGLE_SCALE_DYNAMIC):
+        bd = lk.BeagleDivision(div, lib, scaling=scaling)
+        try:
+            assert bd.inst.child_count() == min(shards, (div.npatterns + 63) // 64)
+            got = bd.LogLike(0)
+            sites = bd.inst.get_site_log_likelihoods()
+            if scaling == lk.MB_BEAGLE_SCALE_ALWAYS:
+                assert np.array_equal(sites, want_sites)
+            assert abs(got - want) <= 1e-10 * abs(want)
+            assert abs(sites.sum() * 0 + (sites * div.weights).sum() - got) <= 1e-9 * abs(got)
+            bd.AcceptMove(0)
+            t = div.tree
+            node = t.int_down_pass[0]
+            old = t.length[node]
+            t.length[node] = old * 1.9
+            bd.TouchBranch(0, node)
+            moved = bd.LogLike(0)
+            ref = oracle.tree_loglike(div, use_shortcuts=False)
+            assert abs(moved - ref) / abs(ref) < REL_FP64
+            t.length[node] = old
+            bd.ResetFlips(0)
+            assert abs(bd.LogLike(0) - got) <= 1e-12 * abs(got)
+        finally:
+            bd.finalize()
+    monkeypatch.delenv("MBAMD_SHARD")
+
+
+def check_multi_partition_instance(lib, oracle, div_a, div_b):
+    """BEAGLE v3 multi-partition mode (reference src/mbbeagle.c:1500-3010): ONE instance holds the patterns of two data
+    divisions with their own eigen-systems, category rates, branch lengths and operation lists; per-partition
+    log-likelihoods must equal two separate single-division instances (and the oracle)."""
+    assert div_a.nstates == div_b.nstates and div_a.ncat == div_b.ncat and div_a.ntaxa == div_b.ntaxa
+    S, K, N = div_a.nstates, div_a.ncat, div_a.ntaxa
+    divs = [div_a, div_b]
+    want = [engine_lnl(lib, d) for d in divs]
+    Pa, Pb = div_a.npatterns, div_b.npatterns
+    P = Pa + Pb
+    nInt, nNodes = N - 2, 2 * N - 2
+    # one chain; buffer indices as MrBayes lays them out: tips 0..N-1, interior N..; matrices / eigen offset by division
+    inst = bg.BeagleInstance(lib, N, N + nInt, N, S, P, 2, 2 * nNodes, K, nInt + 2)
+    try:
+        for t in range(N):
+            inst.set_tip_states(t, np.concatenate([div_a.tip_states[t], div_b.tip_states[t]]).astype(np.int32))
+        inst.set_pattern_weights(np.concatenate([div_a.weights, div_b.weights]))
+        inst.set_pattern_partitions(2, np.concatenate([np.zeros(Pa, dtype=np.int32), np.ones(Pb, dtype=np.int32)]))
+        assert inst.child_count() == 2
+        ops = []
+        eig_idx, rate_idx, prob_idx, lengths = [], [], [], []
+        for d, dv in enumerate(divs):
+            es = dv.eigen[0]
+            inst.set_eigen_decomposition(d, es.evec, es.ivec, es.eval)
+            inst.set_state_frequencies(d, dv.pi)
+            inst.set_category_weights(d, dv.category_weights(0))
+            inst.set_category_rates_with_index(d, dv.cat_rates)
+            tr = dv.tree
+            for p in tr.all_down_pass:
+                if p == tr.root:
+                    continue
+                eig_idx.append(d); rate_idx.append(d); prob_idx.append(d * nNodes + p)
+                lengths.append(min(max(tr.length[p], lk.BRLENS_MIN), lk.BRLENS_MAX))
+            for p in tr.int_down_pass:
+                l, r = tr.left[p], tr.right[p]
+                ops.append([p, p - N, -1, l, d * nNodes + l, r, d * nNodes + r, d, nInt + d])
+        inst.update_transition_matrices_with_multiple_models(eig_idx, rate_idx, prob_idx, lengths)
+        for d in range(2):
+            inst.reset_scale_factors_by_partition(nInt + d, d)
+        # the two divisions' operations interleaved, as MrBayes' operationsAll is (src/mbbeagle.c:2262-2290)
+        ops_a, ops_b = ops[:nInt], ops[nInt:]
+        mixed = [x for pair in zip(ops_a, ops_b) for x in pair]
+        inst.update_partials_by_partition(np.array(mixed, dtype=np.int32))
+        parents = [divs[d].tree.root_left for d in range(2)]
+        children = [divs[d].tree.root for d in range(2)]
+        probs = [d * nNodes + divs[d].tree.root_left for d in range(2)]
+        rc, by, total = inst.calculate_edge_log_likelihoods_by_partition(parents, children, probs, [0, 1], [0, 1],
+                                                                         [nInt, nInt + 1], [0, 1], 1)
+        assert rc == 0
+        for d in range(2):
+            assert abs(by[d] - want[d]) <= 1e-10 * abs(want[d]), (d, by[d], want[d])
+            ref = oracle.tree_loglike(divs[d], use_shortcuts=False)
+            assert abs(by[d] - ref) / abs(ref) < REL_FP64
+        assert abs(total - sum(want)) <= 1e-10 * abs(total)
+        sites = inst.get_site_log_likelihoods()
+        assert abs((sites[:Pa] * div_a.weights).sum() - want[0]) <= 1e-9 * abs(want[0])
+        # only partition 1 re-evaluated (its branch lengths doubled): partition 0's value must not move
+        only = [1]
+        rc, by1, _ = inst.calculate_edge_log_likelihoods_by_partition([parents[1]], [children[1]], [probs[1]], [1], [1], [nInt + 1], only, 1)
+        assert abs(by1[0] - want[1]) <= 1e-10 * abs(want[1])
+    finally:
+        inst.finalize()
+
+
 def engine_lnl(lib, div, scaling=lk.MB_BEAGLE_SCALE_ALWAYS, nchains=1, chain=0):
     bd = lk.BeagleDivision(div, lib, nchains=nchains, scaling=scaling)
     try:

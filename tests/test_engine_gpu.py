@@ -466,3 +466,16 @@ def test_instances_created_and_destroyed_repeatedly(gpu):
     for bd in keep:
         bd.finalize()
     assert len(vals) == 1
+
+
+@pytest.mark.parametrize("kind,ntaxa,npat", [("gtr", 40, 700), ("wag", 20, 300)])
+def test_patterns_sharded_inside_one_instance(gpu, oracle, golden_dir, monkeypatch, kind, ntaxa, npat):
+    div = synthetic_division(kind, ntaxa, npat, seed=81, tree_seed=82, p_gap=0.03, golden_dir=golden_dir)
+    ec.check_sharded_instance(gpu, oracle, div, monkeypatch, shards=3)
+
+
+@pytest.mark.parametrize("kind", ["gtr", "wag"])
+def test_multi_partition_instance(gpu, oracle, golden_dir, kind):
+    a = synthetic_division(kind, 24, 330, seed=91, tree_seed=92, p_gap=0.02, golden_dir=golden_dir, alpha=0.5)
+    b = synthetic_division(kind, 24, 150, seed=93, tree_seed=94, p_gap=0.02, golden_dir=golden_dir, alpha=1.7, brlen=0.11)
+    ec.check_multi_partition_instance(gpu, oracle, a, b)

@@ -154,3 +154,16 @@ def test_closed_form_matrices(emu, oracle):
 @pytest.mark.parametrize("case", ["primates_gtr_g4", "avian_wag_g4", "replicase_m3"])
 def test_root_integration_equals_edge_integration(emu, oracle, golden_dir, case):
     ec.check_root_equals_edge(emu, oracle, division_from_golden(golden_dir, case))
+
+
+@pytest.mark.parametrize("kind,ntaxa,npat", [("gtr", 40, 700), ("wag", 20, 300)])
+def test_patterns_sharded_inside_one_instance(emu, oracle, golden_dir, monkeypatch, kind, ntaxa, npat):
+    div = synthetic_division(kind, ntaxa, npat, seed=81, tree_seed=82, p_gap=0.03, golden_dir=golden_dir)
+    ec.check_sharded_instance(emu, oracle, div, monkeypatch, shards=3)
+
+
+@pytest.mark.parametrize("kind", ["gtr", "wag"])
+def test_multi_partition_instance(emu, oracle, golden_dir, kind):
+    a = synthetic_division(kind, 24, 330, seed=91, tree_seed=92, p_gap=0.02, golden_dir=golden_dir, alpha=0.5)
+    b = synthetic_division(kind, 24, 150, seed=93, tree_seed=94, p_gap=0.02, golden_dir=golden_dir, alpha=1.7, brlen=0.11)
+    ec.check_multi_partition_instance(emu, oracle, a, b)

@@ -157,7 +157,9 @@ def test_ambiguity_codes_on_mi355x():
 
 
 # ---- partitioned analysis: one engine instance per division, both alive in the same MrBayes process -------------
-def _partitioned_nexus(beagle, ngen=1):
+def _partitioned_nexus(beagle, ngen=1, same_shape=False):
+    """same_shape: both divisions GTR+G4 (same state / category / eigen-part counts) -- what MrBayes' v3 build merges into
+    ONE multi-partition instance (reference src/mbbeagle.c:1519-1546); otherwise GTR+G4 next to HKY+I."""
     st, tr = _case(16, 600, 0.02)
     names = ["t%d" % (i + 1) for i in range(st.shape[0])]
     seqs = ["".join("ACGT-"[x] for x in row) for row in st]
@@ -167,7 +169,10 @@ def _partitioned_nexus(beagle, ngen=1):
         s += "%s  %s\n" % (n, q)
     s += "  ;\nend;\nbegin mrbayes;\n  set autoclose=yes nowarnings=yes seed=12345 swapseed=12345 precision=15;\n"
     s += "  charset first = 1-350;\n  charset second = 351-600;\n  partition genes = 2: first, second;\n  set partition=genes;\n"
-    s += "  lset applyto=(1) nst=6 rates=gamma ngammacat=4;\n  lset applyto=(2) nst=2 rates=propinv;\n"
+    if same_shape:
+        s += "  lset applyto=(all) nst=6 rates=gamma ngammacat=4;\n"
+    else:
+        s += "  lset applyto=(1) nst=6 rates=gamma ngammacat=4;\n  lset applyto=(2) nst=2 rates=propinv;\n"
     s += "  unlink revmat=(all) tratio=(all) statefreq=(all) shape=(all) pinvar=(all);\n  prset applyto=(all) ratepr=variable;\n"
     if beagle:
         s += "  set usebeagle=yes beagledevice=gpu beagleprecision=single beaglescaling=%s;\n" % beagle
@@ -186,6 +191,39 @@ def _check_partitioned(binary, marker):
     assert abs(ours - native) / abs(native) < 1e-5, (ours, native)
     out, _ = refrun.run_mb(binary, _partitioned_nexus("dynamic", ngen=400))
     assert "Analysis completed" in out, out[-1500:]
+
+
+def _check_multi_partition(binary):
+    """MrBayes' BEAGLE v3 build: resource benchmark, then ONE multi-partition instance for both divisions
+    (beagleSetPatternPartitions, *ByPartition calls) -- same lnL as the native kernels, and a default-move run completes
+    (per-division partial updates, rejects, dynamic rescaling through the ByPartition scale-factor calls)."""
+    native = refrun.initial_lnl(refrun.run_mb(refrun.REF_MB, _partitioned_nexus(None, same_shape=True))[0])
+    for scaling in ("dynamic", "always"):
+        out, _ = refrun.run_mb(binary, _partitioned_nexus(scaling, same_shape=True), env={"MBAMD_API_TRACE": "1"})
+        assert "for 2 divisions" in out, out[-2500:]                 # "Using BEAGLE v... resource 0 for 2 divisions"
+        assert "beagleSetPatternPartitions(2 partitions)" in out and "beagleUpdatePartialsByPartition" in out
+        assert "beagleCalculateEdgeLogLikelihoodsByPartition" in out
+        ours = refrun.initial_lnl(out)
+        assert abs(ours - native) / abs(native) < 1e-5, (scaling, ours, native)
+    out, _ = refrun.run_mb(binary, _partitioned_nexus("dynamic", ngen=400, same_shape=True))
+    assert "Analysis completed" in out, out[-1500:]
+    # divisions of different shape cannot be merged: the v3 build falls back to one instance per division
+    native = refrun.initial_lnl(refrun.run_mb(refrun.REF_MB, _partitioned_nexus(None))[0])
+    out, _ = refrun.run_mb(binary, _partitioned_nexus("dynamic"))
+    assert abs(refrun.initial_lnl(out) - native) / abs(native) < 1e-5
+
+
+def test_multi_partition_v3_on_emulated_engine():
+    if not (os.path.exists(refrun.REF_MB_EMU_V3) and os.path.exists(refrun.REF_MB)):
+        pytest.skip("oracle/_ref binaries not built (build container only)")
+    _check_multi_partition(refrun.REF_MB_EMU_V3)
+
+
+@pytest.mark.gpu
+def test_multi_partition_v3_on_mi355x():
+    if not (os.path.exists(refrun.REF_MB_AMD_V3) and os.path.exists(refrun.REF_MB)):
+        pytest.skip("oracle/_ref/mb_amd_v3 was not built (needs the reference sources at build time)")
+    _check_multi_partition(refrun.REF_MB_AMD_V3)
 
 
 def test_partitioned_analysis_on_emulated_engine():

@@ -16,6 +16,9 @@ REF_MB = os.path.join(ROOT, "oracle", "_ref", "mb")
 REF_MB_AMD = os.path.join(ROOT, "oracle", "_ref", "mb_amd")     # the unmodified reference linked to OUR libhmsbeagle.so
 REF_MB_EMU = os.path.join(ROOT, "oracle", "_ref", "mb_emu")     # same objects, TEST-ONLY host-emulation engine
 
+REF_MB_AMD_V3 = os.path.join(ROOT, "oracle", "_ref", "mb_amd_v3")   # ... with MrBayes' BEAGLE v3 code path compiled in
+REF_MB_EMU_V3 = os.path.join(ROOT, "oracle", "_ref", "mb_emu_v3")
+
 _NUC = "ACGT-"
 
 
