@@ -71,6 +71,7 @@ class ChainExchange:
         self.rng = SwapRng(swap_seed)
         self.swaps_tried = 0
         self.swaps_done = 0
+        self._swaps_led = 0                          # accepted swaps in which this rank owned chain a (counted once globally)
         self._buf = None
         self.pairwise = True                         # False: swap attempts use the all-reduce of all chains' states
 
@@ -133,17 +134,19 @@ class ChainExchange:
         import torch
         first = torch.zeros(1, dtype=torch.float64, device=self.device or "cpu")
         self.dist.all_reduce(first)
-        ok = 1.0
-        try:
-            for i in range(self.world):
-                for j in range(i + 1, self.world):
-                    if self.rank in (i, j):
-                        self._pair_exchange(j if self.rank == i else i, [0.0, 0.0, 0.0])
-        except Exception:                      # a backend without subset send/recv: everybody falls back together
-            ok = 0.0
+        # Capability is decided BEFORE anybody blocks in a pairwise exchange (a rank that raised while its peer waits in
+        # req.wait() would leave the agreement all-reduce hanging): both backends this engine runs on have batched
+        # point-to-point operations; anything else takes the collective path on every rank.
+        ok = 1.0 if (hasattr(self.dist, "batch_isend_irecv") and self.dist.get_backend() in ("nccl", "gloo")) else 0.0
         agree = torch.tensor([ok], dtype=torch.float64, device=self.device or "cpu")
         self.dist.all_reduce(agree, op=self.dist.ReduceOp.MIN)
         self.pairwise = bool(agree.item() > 0.5)
+        if not self.pairwise:
+            return
+        for i in range(self.world):
+            for j in range(i + 1, self.world):
+                if self.rank in (i, j):
+                    self._pair_exchange(j if self.rank == i else i, [0.0, 0.0, 0.0])
 
     def swap_generation(self, lnl: Dict[int, float], lnprior: Optional[Dict[int, float]] = None):
         """One swap attempt of this generation (RunChain picks the pair, src/mcmc.c:16941-16957; AttemptSwap,
@@ -179,7 +182,31 @@ class ChainExchange:
             ida, idb = int(state[a][2]), int(state[b][2])
             self.chain_id[a], self.chain_id[b] = idb, ida   # (entries of chains this rank does not own are not used)
             self.swaps_done += 1
+            if self.rank == ra:
+                self._swaps_led += 1
         return a, b, ok
 
     def cold_chain(self) -> int:
-        return self.chain_id.index(0)
+        """The chain that currently runs at heat 0.  In pairwise mode a rank only learns the outcome of swaps it takes part
+        in (like a reference rank), so `chain_id` is authoritative for the rank's OWN chains only: the global answer needs
+        everybody -- one all-reduce of "the cold chain among mine" (reporting path, not the per-generation path)."""
+        if self.dist is None or self.world < 2 or not self.pairwise:
+            return self.chain_id.index(0)
+        import torch
+        mine = [c for c in self.local if self.chain_id[c] == 0]
+        v = torch.tensor([float(mine[0]) if mine else -1.0], dtype=torch.float64, device=self.device or "cpu")
+        self.dist.all_reduce(v, op=self.dist.ReduceOp.MAX)
+        cold = int(v.item())
+        if cold < 0:
+            raise RuntimeError("no rank owns the cold chain: chain_id tables are inconsistent")
+        return cold
+
+    def swap_counts(self) -> Tuple[int, int]:
+        """(attempted, accepted) over the whole run: `swaps_tried` counts on every rank, `swaps_done` only on the ranks that
+        took part -- the global number of accepted swaps is the all-reduced count of the lower-ranked participant."""
+        if self.dist is None or self.world < 2 or not self.pairwise:
+            return self.swaps_tried, self.swaps_done
+        import torch
+        v = torch.tensor([float(self._swaps_led)], dtype=torch.float64, device=self.device or "cpu")
+        self.dist.all_reduce(v)
+        return self.swaps_tried, int(v.item())

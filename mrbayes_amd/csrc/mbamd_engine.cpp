@@ -178,6 +178,7 @@ struct Instance {
     std::vector<int32_t*> wideScale; // cumulative exponents int32 [K][Ppad], allocated on first use
     std::vector<char> scaleState;    // 0 = never written (zero), 1 = node exponents in the arena, 2 = cumulative (wide)
     int lastWalkW = 0, lastWalkSlots = 0, lastWalkEntries = 0, lastWalkPhases = 0;
+    bool walkCumFresh = false;       // the cumulative buffer of the list being submitted holds nothing yet (store, do not add)
     uint64_t launchClock = 0, syncedClock = 0;   // launches issued / launches known complete (last stream synchronisation)
     std::vector<double> h_freqs, h_weights;      // host mirrors of d_freqs / d_weights (uploadIfChanged)
     long long* d_trace = nullptr;    // MBAMD_WALK_TRACE: per-step clock stamps of workgroup 0 (timing experiments)
@@ -1130,6 +1131,16 @@ int Instance::timedRun(const Plan& plan, int32_t* cum)
     if (timing) {
         HIP_TRY(hipEventRecord(ev1, stream));
         events.emplace_back(ev0, ev1);
+        if (events.size() > 4096) {               // a client that never asks: fold the finished ones into the running total
+            HIP_TRY(hipStreamSynchronize(stream));
+            for (auto& ev : events) {
+                float t = 0.0f;
+                if (hipEventElapsedTime(&t, ev.first, ev.second) == hipSuccess) timedMs += t;
+                (void) hipEventDestroy(ev.first);
+                (void) hipEventDestroy(ev.second);
+            }
+            events.clear();
+        }
     }
     return rc;
 }
@@ -1157,9 +1168,17 @@ int Instance::ensureWide(int idx)
 int Instance::updatePartials4(const BeagleOperation* ops, int n, int cumIdx)
 {
     int32_t* cumPtr = nullptr;
+    walkCumFresh = false;
     if (cumIdx != BEAGLE_OP_NONE) {
-        int rc = ensureWide(cumIdx);
-        if (rc) return rc;
+        if (scaleState[cumIdx] == 0) {
+            // a freshly reset cumulative buffer (the rescale-everything pass): the kernel STORES its sums, no zero-fill launch
+            if (!wideScale[cumIdx]) HIP_TRY(hipMalloc(&wideScale[cumIdx], (size_t) K * Ppad * sizeof(int32_t)));
+            scaleState[cumIdx] = 2;
+            walkCumFresh = true;
+        } else {
+            int rc = ensureWide(cumIdx);
+            if (rc) return rc;
+        }
         cumPtr = wideScale[cumIdx];
     }
     // ---- plan cache ------------------------------------------------------------------------
@@ -1395,6 +1414,7 @@ int Instance::runWalk(const Plan& plan, int32_t* cum)
         a.estride = estride;
         a.matrices = matrices;
         a.cum = cum;
+        a.cumFresh = (walkCumFresh && &sg == &plan.segments.front()) ? 1 : 0;
         a.K = K;
         a.Ppad = Ppad;
         a.nblocks = Ppad / 64;
@@ -1546,6 +1566,9 @@ int Instance::buildGeneric(Plan& plan, std::vector<PartialsOp>& dev, const std::
 {
     const int n = (int) dev.size();
     std::vector<int> lastWrite(nBuffers, -1), lastRead(nBuffers, -1), level(n, 0);
+    // scale buffers are dependencies too: an operation that divides by the factors of a buffer (SCALE_READ) must run after
+    // the operation of this list that writes them, a second writer after the first writer and all its readers
+    std::unordered_map<const void*, std::pair<int, int>> scaleLevels;     // scale buffer -> (last write level, last read level)
     int nLevels = 0;
     for (int o = 0; o < n; ++o) {
         int l = 0;
@@ -1553,7 +1576,18 @@ int Instance::buildGeneric(Plan& plan, std::vector<PartialsOp>& dev, const std::
         l = std::max(l, lastWrite[c2Idx[o]] + 1);
         l = std::max(l, lastWrite[dstIdx[o]] + 1);
         l = std::max(l, lastRead[dstIdx[o]] + 1);
+        if (dev[o].scale_mode != SCALE_NONE) {
+            auto it = scaleLevels.find(dev[o].scale);
+            if (it != scaleLevels.end()) {
+                l = std::max(l, it->second.first + 1);
+                if (dev[o].scale_mode == SCALE_WRITE) l = std::max(l, it->second.second + 1);
+            }
+        }
         level[o] = l;
+        if (dev[o].scale_mode != SCALE_NONE) {
+            auto& sl = scaleLevels.emplace(dev[o].scale, std::make_pair(-1, -1)).first->second;
+            if (dev[o].scale_mode == SCALE_WRITE) sl.first = l; else sl.second = std::max(sl.second, l);
+        }
         lastWrite[dstIdx[o]] = l;
         lastRead[c1Idx[o]] = std::max(lastRead[c1Idx[o]], l);
         lastRead[c2Idx[o]] = std::max(lastRead[c2Idx[o]], l);

@@ -81,6 +81,7 @@ struct Walk4Args {
     unsigned estride;            // bytes between blocks
     const float* matrices;       // [matrix][K][4][4] transposed
     int32_t* cum;                // wide cumulative buffer int32 [K][Ppad], or nullptr
+    int cumFresh;                // the cumulative buffer holds nothing yet: store the sums instead of adding them
     int K, Ppad, nblocks;
 };
 
@@ -339,7 +340,22 @@ k_walk4(Walk4Args A)
     }
 #undef MBAMD_W4_EXPS
 #undef MBAMD_W4_PREFETCH
-    if (A.cum != nullptr && cum_e != 0) atomicAdd(A.cum + (size_t) k * A.Ppad + (size_t) blk * 64 + lane, cum_e);
+    // cumulative exponents of this workgroup's 64 columns: the waves' sums meet in LDS, wave 0 owns the memory update
+    // (nobody else touches these 64 entries: no atomics; a fresh buffer is simply stored)
+    if (A.cum != nullptr) {
+        const int W = (int) (blockDim.x >> 6);
+        if (W > 1) {
+            stage[lane] = cum_e;
+            walk4_barrier();
+            if (wave != 0) return;
+            cum_e = 0;
+            for (int w = 0; w < W; ++w)
+                cum_e += reinterpret_cast<const int*>(lds + (size_t) w * (MBAMD_W4_STAGE + (size_t) A.nslots * 1024))[lane];
+        }
+        int32_t* dst = A.cum + (size_t) k * A.Ppad + (size_t) blk * 64 + lane;
+        if (A.cumFresh) *dst = cum_e;
+        else if (cum_e != 0) *dst += cum_e;
+    }
 }
 
 }  // namespace mbamd

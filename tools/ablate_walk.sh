@@ -1,6 +1,6 @@
 #!/bin/bash
 cd "${GRAFT_REPO_ROOT:-/root/repo}"; mkdir -p gpurun_out; export TMPDIR=/tmp
-run() { MBAMD_VERBOSE=1 timeout 300 python bench.py --config ${CFG:-c2} --steps 30 --warmup 3 --no-cpu-baseline 2>&1 | python -c "
+run() { MBAMD_VERBOSE=1 timeout 300 python bench.py --config ${CFG:-c2} --steps 30 --warmup 3 --no-cpu-baseline --no-also --no-mcmc 2>&1 | python -c "
 import sys,json
 seen=False
 for l in sys.stdin:

@@ -13,7 +13,7 @@ if [[ "$WHAT" == all || "$WHAT" == tests ]]; then
 fi
 if [[ "$WHAT" == all || "$WHAT" == bench ]]; then
   for c in c2 c3 c5 c4; do
-    extra="--no-cpu-baseline"; [[ $c == c2 ]] && extra=""
+    extra="--no-cpu-baseline --no-also --no-mcmc --no-also --no-mcmc"; [[ $c == c2 ]] && extra=""
     timeout 900 python bench.py --config $c --steps 50 --warmup 5 $extra > $OUT/bench_$c.json 2> $OUT/bench_$c.err; echo "bench $c exit $?"
     cat $OUT/bench_$c.json
   done
