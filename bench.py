@@ -219,9 +219,9 @@ def measure(args, cfg, steps, warmup, rank, local_rank, world, dist, device, emu
             roof["traffic_source"] = pmc["source"]
             roof["physical_achieved_GBs"] = pmc["traffic_bytes"] / (k_ms * 1e-3) / 1e9
             roof["physical_frac"] = roof["physical_achieved_GBs"] / HBM_PEAK_GBS
-            for key in ("mfma_issued_tflops", "mfma_issued_frac", "mfma_busy_fraction"):
-                if key in pmc:
-                    roof[key] = pmc[key]
+            if "mfma_issued_gflop" in pmc:        # matrix-core work actually issued (tip children are gathers, not MFMAs)
+                roof["mfma_issued_tflops"] = pmc["mfma_issued_gflop"] * 1e9 / (k_ms * 1e-3) / 1e12
+                roof["mfma_issued_frac"] = roof["mfma_issued_tflops"] / FP32_PEAK_TFLOPS
     except (OSError, ValueError):
         pass
     roof["kernel"] = impl
