@@ -161,6 +161,8 @@ struct Instance {
     hipStream_t stream{};
     int tipCount = 0, nBuffers = 0, S = 0, SP = 0, P = 0, Ppad = 0, nEigen = 0, nMatrices = 0, K = 0, nScale = 0;
     bool s4 = false;                 // 4-state float4 layout + tree-walk kernel
+    bool wg = false;                 // 20/61-state tree-walk kernel on the matrix cores (mbamd_walkg.h) + its arenas
+    bool arena() const { return s4 || wg; }   // buffers are slices of arenas, exponents are per (pattern, category)
     bool mfma = false;               // general-state path on the matrix cores (mbamd_kernels_mfma.h)
     bool mfmaWhole = false;          // MBAMD_MFMA_WHOLE: one wave per (operation, 32 patterns) instead of per factor tile
     int walkWaves = 1, lastWalkSteps = 0;   // (kernel trace bookkeeping of the serial MFMA kernels, tools/trace_*.py)
@@ -179,6 +181,21 @@ struct Instance {
     std::vector<char> scaleState;    // 0 = never written (zero), 1 = node exponents in the arena, 2 = cumulative (wide)
     int lastWalkW = 0, lastWalkSlots = 0, lastWalkEntries = 0, lastWalkPhases = 0;
     bool walkCumFresh = false;       // the cumulative buffer of the list being submitted holds nothing yet (store, do not add)
+    // ---- 20/61-state tree walk: lists are deferred and merged (MrBayes submits one list per eigen-system part of a codon
+    // model, reference src/mbbeagle.c:1095-1104; together they are ONE forest for the program compiler)
+    std::vector<BeagleOperation> wgOps;          // operations of the deferred lists, concatenated
+    std::vector<int> wgListStart, wgListCum;     // first operation / cumulative scale index (or BEAGLE_OP_NONE) of each list
+    int32_t* wgCum[MBAMD_WG_MAXLISTS] = {nullptr, nullptr, nullptr, nullptr};
+    int wgFresh = 0;
+    uint8_t* arenaTipStates = nullptr;           // uint8 [tile][buffer][32]
+    unsigned long wgTileBytes = 0;               // partials arena: bytes between 32-pattern tiles
+    unsigned wgTipTileBytes = 0;
+    size_t wgTabFloats = 0;                      // first float of the tree-walk tables inside a matrix buffer
+    bool hasPending() const { return !pending.empty() || !wgListCum.empty(); }
+    int updatePartialsG(const BeagleOperation* ops, int n, int cumIdx);
+    int flushWalkG();
+    int runWalkG(const Plan& plan);
+    bool scaleOpsIndependentOfPending(const int* idx, int n, int cumIdx) const;
     uint64_t launchClock = 0, syncedClock = 0;   // launches issued / launches known complete (last stream synchronisation)
     std::vector<double> h_freqs, h_weights;      // host mirrors of d_freqs / d_weights (uploadIfChanged)
     long long* d_trace = nullptr;    // MBAMD_WALK_TRACE: per-step clock stamps of workgroup 0 (timing experiments)
@@ -298,7 +315,7 @@ struct Instance {
     int ensurePartials(int idx)
     {
         if (partials[idx]) return BEAGLE_SUCCESS;
-        if (s4) return fail(BEAGLE_ERROR_GENERAL, "4-state arena not initialised");
+        if (arena()) return fail(BEAGLE_ERROR_GENERAL, "partials arena not initialised");
         float* p = nullptr;
         HIP_TRY(hipMalloc(&p, partialsFloats * sizeof(float)));
         HIP_TRY(hipMemsetAsync(p, 0, partialsFloats * sizeof(float), stream));
@@ -308,7 +325,7 @@ struct Instance {
     int ensureScale(int idx)
     {
         if (scale[idx]) return BEAGLE_SUCCESS;
-        if (s4) return fail(BEAGLE_ERROR_GENERAL, "4-state arena not initialised");
+        if (arena()) return fail(BEAGLE_ERROR_GENERAL, "exponent arena not initialised");
         int32_t* p = nullptr;
         HIP_TRY(hipMalloc(&p, (size_t) Ppad * sizeof(int32_t)));
         HIP_TRY(hipMemsetAsync(p, 0, (size_t) Ppad * sizeof(int32_t), stream));
@@ -333,7 +350,7 @@ struct Instance {
     int getMatrix(int idx, double* out);
     int updatePartials(const BeagleOperation* ops, int n, int cumIdx);
     int updatePartials4(const BeagleOperation* ops, int n, int cumIdx);
-    int buildWalk(Plan& plan, const BeagleOperation* ops, int n);
+    int buildWalk(Plan& plan, const BeagleOperation* ops, int n, const int* listOf = nullptr);
     int ensureWide(int idx);
     int accumulate4(const int* idx, int n, int cumIdx, int sign);
     int integrate4(const int* parent, const int* child, const int* prob, const int* wIdx, const int* fIdx,
@@ -404,6 +421,13 @@ int Instance::create(int tipCount_, int partialsBufferCount, int compactBufferCo
     // the 4-state tree walk addresses buffers with 32-bit byte offsets inside a (block, category) column set (Walk4Entry)
     s4 = (S == 4 && !forceGeneric && (size_t) nBuffers * K * 1024 < ((size_t) 1 << 32) && (size_t) nMatrices * K * 64 < ((size_t) 1 << 32) &&
           (size_t) (nScale + 1) * K * 64 < ((size_t) 1 << 32));
+    // 20 / 61 states: the tree-walk kernel on the matrix cores (MBAMD_NO_WALKG=1: the level kernels of mbamd_kernels_mfma.h)
+    {
+        const size_t tb = wg_block_bytes(S), mf = (size_t) K * 64 * 64 + (size_t) K * wg_table_floats(S);
+        wg = !s4 && (S == 20 || S == 61) && K <= 16 && !forceGeneric && std::getenv("MBAMD_NO_WALKG") == nullptr &&
+             (size_t) (nBuffers + 1) * K * tb < ((size_t) 1 << 32) && (size_t) nMatrices * mf * 4 < ((size_t) 1 << 32) &&
+             (size_t) (nScale + 1) * K * 64 < ((size_t) 1 << 32) && (size_t) nBuffers * 32 < ((size_t) 1 << 32);
+    }
     if (s4) SP = 4;
     else if (S <= 4) SP = 4;
     else if (S <= 8) SP = 8;
@@ -414,7 +438,7 @@ int Instance::create(int tipCount_, int partialsBufferCount, int compactBufferCo
 #if !defined(MBAMD_HOST_EMU)
     NT = (S + 31) / 32;
     T = (S + 1) / 2;
-    mfma = !s4 && S >= 5 && S <= 64 && ((NT == 1 && K <= 4) || (NT == 2 && K <= 2)) &&
+    mfma = !s4 && !wg && S >= 5 && S <= 64 && ((NT == 1 && K <= 4) || (NT == 2 && K <= 2)) &&
            std::getenv("MBAMD_NO_MFMA") == nullptr;
     if (mfma) SP = 32 * NT;          // transposed matrices padded to the MFMA tile height
     mfmaWhole = std::getenv("MBAMD_MFMA_WHOLE") != nullptr;
@@ -453,7 +477,11 @@ int Instance::create(int tipCount_, int partialsBufferCount, int compactBufferCo
     noSiteHost = std::getenv("MBAMD_NO_SITE_HOST") != nullptr;
     partialsFloats = s4 ? (size_t) K * Ppad * 4 : (size_t) K * S * Ppad;
     matrixFloats = (size_t) K * SP * SP + (mfma ? (size_t) K * NT * T * 64 : 0);
-    if (s4) {
+    if (wg) {
+        wgTabFloats = (size_t) K * SP * SP;
+        matrixFloats = wgTabFloats + (size_t) K * wg_table_floats(S);
+    }
+    if (arena()) {
         int rc = configureWalk();
         if (rc) return rc;
     }
@@ -484,9 +512,34 @@ int Instance::create(int tipCount_, int partialsBufferCount, int compactBufferCo
                          (void*) arenaPartials, pBytes, (void*) arenaTips, tBytes, (void*) arenaExp, eBytes);
         for (int i = 0; i < nBuffers; ++i) partials[i] = arenaPartials + (size_t) i * K * 64 * 4;
     }
+    if (wg) {
+        // the same for the 20/61-state tree walk (mbamd_walkg.h): tile-major arenas, one extra partials buffer per tile as
+        // the sink of NOP entries; exponents in the 4-state path's format (two tiles per 64-pattern block)
+        const size_t nt = (size_t) Ppad / 32, nb = (size_t) Ppad / 64, tb = wg_block_bytes(S);
+        wgTileBytes = (unsigned long) (nBuffers + 1) * K * tb;
+        wgTipTileBytes = (unsigned) nBuffers * 32;
+        estride = (unsigned) (scale.size() + 1) * K * 64;
+        const size_t pBytes = nt * wgTileBytes, tBytes = nt * wgTipTileBytes, eBytes = nb * (size_t) estride;
+        HIP_TRY(hipMalloc(&arenaPartials, pBytes));
+        HIP_TRY(hipMalloc(&arenaTipStates, tBytes));
+        HIP_TRY(hipMalloc(&arenaExp, eBytes));
+        HIP_TRY(hipMemsetAsync(arenaPartials, 0, pBytes, stream));
+        HIP_TRY(hipMemsetAsync(arenaTipStates, S, tBytes, stream));           // (a tip never set = missing data)
+        HIP_TRY(hipMemsetAsync(arenaExp, 0, eBytes, stream));
+        wideScale.assign(scale.size(), nullptr);
+        scaleState.assign(scale.size(), 0);
+        if (envVerbose)
+            std::fprintf(stderr, "[mbamd] arenas: partials +%zu, tips +%zu, exponents +%zu bytes\n", pBytes, tBytes, eBytes);
+        for (int i = 0; i < nBuffers; ++i) partials[i] = arenaPartials + (size_t) i * K * tb / 4;
+    }
 
     HIP_TRY(hipMalloc(&matrices, std::max<size_t>(1, (size_t) nMatrices * matrixFloats) * sizeof(float)));
     HIP_TRY(hipMemsetAsync(matrices, 0, std::max<size_t>(1, (size_t) nMatrices * matrixFloats) * sizeof(float), stream));
+    if (wg && nMatrices > 0) {                   // the constant "missing data" column of every gather table
+        const int total = nMatrices * K * S;
+        MBAMD_LAUNCH(k_wg_init_tables, (unsigned) ((total + 255) / 256), 256, 0, stream, matrices, matrixFloats, wgTabFloats, S, K, total);
+        HIP_TRY(hipGetLastError());
+    }
     HIP_TRY(hipMalloc(&d_eigen, std::max<size_t>(1, (size_t) nEigen * eigenDoubles) * sizeof(double)));
     HIP_TRY(hipMalloc(&d_freqs, std::max<size_t>(1, (size_t) nEigen * S) * sizeof(double)));
     HIP_TRY(hipMalloc(&d_weights, std::max<size_t>(1, (size_t) nEigen * K) * sizeof(double)));
@@ -521,8 +574,8 @@ void Instance::destroy()
 {
     (void) hipSetDevice(device);
     (void) hipStreamSynchronize(stream);
-    if (s4) {
-        void* arenas[] = {arenaPartials, arenaTips, arenaExp};
+    if (arena()) {
+        void* arenas[] = {arenaPartials, arenaTips, arenaTipStates, arenaExp};
         for (void* a : arenas) if (a) (void) hipFree(a);
         for (int32_t* w : wideScale) if (w) (void) hipFree(w);
     } else {
@@ -531,6 +584,7 @@ void Instance::destroy()
         for (int32_t* p : scale) if (p) (void) hipFree(p);
     }
     pending.clear();
+    wgOps.clear(); wgListStart.clear(); wgListCum.clear();
     for (Plan* pl : plans) { if (pl->d_table) (void) hipFree(pl->d_table); if (pl->d_walk) (void) hipFree(pl->d_walk); delete pl; }
     plans.clear();
     void* bufs[] = {matrices, d_eigen, d_freqs, d_weights, d_rates, d_pweights, d_site,
@@ -554,9 +608,39 @@ int Instance::configureWalk()
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0) numCU = prop.multiProcessorCount;
     const int maxLds = 160 * 1024;
-    if (hipFuncSetAttribute((const void*) k_walk4, hipFuncAttributeMaxDynamicSharedMemorySize, maxLds) != hipSuccess)
+    if (s4 && hipFuncSetAttribute((const void*) k_walk4, hipFuncAttributeMaxDynamicSharedMemorySize, maxLds) != hipSuccess)
         (void) hipGetLastError();
 #endif
+    if (wg) {
+        // one wave = (32-pattern tile, category); registers bound the residency: 20 states ~3 waves per SIMD, 61 states 1
+        const int maxW = S == 61 ? 4 : 8, wavesPerCU = S == 61 ? 4 : 12;
+        const unsigned slotBytes = wg_block_bytes(S);
+#if !defined(MBAMD_HOST_EMU)
+        hipError_t aerr = S == 61 ? hipFuncSetAttribute((const void*) k_walkg<61, 4, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, maxLds)
+                                  : hipFuncSetAttribute((const void*) k_walkg<20, 8, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, maxLds);
+        if (aerr != hipSuccess) (void) hipGetLastError();
+#endif
+        const long wgsG = (long) (Ppad / 32) * K;
+        const int perCUG = (int) std::max(1L, (wgsG + numCU - 1) / numCU);
+        const int ldsPerWGG = (160 * 1024) / std::min(perCUG, 32) - 64;
+        auto slotsForG = [&](int W) { return (int) ((ldsPerWGG / W - MBAMD_WG_STAGE) / (int) slotBytes); };
+        int W = (int) std::max(1L, std::min((long) maxW, ((long) wavesPerCU * numCU + wgsG / 2) / wgsG));
+        while (W > 1 && slotsForG(W) < 4) --W;
+        if (const char* e = std::getenv("MBAMD_WALK_WAVES")) W = std::max(1, std::min(maxW, std::atoi(e)));
+        int slots = std::max(3, std::min(24, slotsForG(W)));
+        if (const char* e = std::getenv("MBAMD_MAX_LDS_SLOTS")) slots = std::max(3, std::min((int) ((160 * 1024 / W - MBAMD_WG_STAGE) / slotBytes), std::atoi(e)));
+        w4.maxW = W;
+        w4.maxSlots = slots;
+        w4.maxSlots1 = std::max(slots, std::min(24, slotsForG(1)));
+        if (std::getenv("MBAMD_MAX_LDS_SLOTS")) w4.maxSlots1 = slots;
+        w4.memSlots = false;
+        w4.leadNops = MBAMD_WG_LEAD; w4.unroll = 3; w4.tailNops = MBAMD_WG_TAIL;
+        w4.prefetchDistance = 0;
+        if (const char* e = std::getenv("MBAMD_WALK_SMALL_PHASE")) w4.smallPhase = std::max(1, std::atoi(e));
+        if (envVerbose) std::fprintf(stderr, "[mbamd] tree walk (%d states): %ld workgroups (%d per CU), up to %d waves x %d slots of %u bytes\n",
+                                     S, wgsG, perCUG, W, slots, slotBytes);
+        return BEAGLE_SUCCESS;
+    }
     const long wgs = (long) (Ppad / 64) * K;
     const int perCU = (int) std::max(1L, (wgs + numCU - 1) / numCU);          // workgroups a CU must host for full residency
     const int ldsPerWG = (160 * 1024) / std::min(perCU, 32) - 64;
@@ -603,6 +687,13 @@ int Instance::setTipStates(int tip, const int* states)
         for (int c = 0; c < Ppad; ++c) h[c] = (uint8_t) (h[c] >= 4 ? 0xF : 1u << h[c]);   // state masks (mbamd_walk4.h)
         return setTipMasks(tip, h);
     }
+    if (wg) {                                    // 32 state codes per (tile, tip) in the tip arena
+        HIP_TRY(hipStreamSynchronize(stream));
+        HIP_TRY(hipMemcpy2D(arenaTipStates + (size_t) tip * 32, (size_t) wgTipTileBytes, h.data(), 32, 32, (size_t) Ppad / 32, hipMemcpyHostToDevice));
+        if (!tipStates[tip]) layoutEpoch++;
+        tipStates[tip] = arenaTipStates + (size_t) tip * 32;
+        return BEAGLE_SUCCESS;
+    }
     if (!tipStates[tip]) { HIP_TRY(hipMalloc(&tipStates[tip], (size_t) Ppad)); layoutEpoch++; }
     return upload(tipStates[tip], h.data(), (size_t) Ppad);
 }
@@ -635,13 +726,14 @@ int Instance::importPartials(int idx, const double* in, bool hasCategories)
     HIP_TRY(hipMemcpy(d_tmp, in, nIn * sizeof(double), hipMemcpyHostToDevice));
     const size_t total = (size_t) K * P * S;
     const unsigned blocks = (unsigned) ((total + 255) / 256);
-    if (s4) MBAMD_LAUNCH(k_import_partials<true>, blocks, 256, 0, stream, (const double*) d_tmp, hasCategories ? 1 : 0, S, K, P, Ppad, (size_t) geom.pstride, partials[idx]);
-    else    MBAMD_LAUNCH(k_import_partials<false>, blocks, 256, 0, stream, (const double*) d_tmp, hasCategories ? 1 : 0, S, K, P, Ppad, (size_t) geom.pstride, partials[idx]);
+    if (s4) MBAMD_LAUNCH(k_import_partials<1>, blocks, 256, 0, stream, (const double*) d_tmp, hasCategories ? 1 : 0, S, K, P, Ppad, (size_t) geom.pstride, partials[idx]);
+    else if (wg) MBAMD_LAUNCH(k_import_partials<2>, blocks, 256, 0, stream, (const double*) d_tmp, hasCategories ? 1 : 0, S, K, P, Ppad, (size_t) (wgTileBytes / 4), partials[idx]);
+    else    MBAMD_LAUNCH(k_import_partials<0>, blocks, 256, 0, stream, (const double*) d_tmp, hasCategories ? 1 : 0, S, K, P, Ppad, (size_t) geom.pstride, partials[idx]);
     HIP_TRY(hipGetLastError());
     valid[idx] = 1;
     if (tipStates[idx]) {                        // a tip switches from compact to partials form
         HIP_TRY(hipStreamSynchronize(stream));
-        if (!s4) (void) hipFree(tipStates[idx]);
+        if (!arena()) (void) hipFree(tipStates[idx]);
         tipStates[idx] = nullptr;
         layoutEpoch++;
     }
@@ -655,8 +747,9 @@ int Instance::getPartials(int idx, double* out)
     int rc = grow(&d_tmp, &tmpCap, total * sizeof(double));
     if (rc) return rc;
     const unsigned blocks = (unsigned) ((total + 255) / 256);
-    if (s4) MBAMD_LAUNCH(k_export_partials<true>, blocks, 256, 0, stream, (const float*) partials[idx], S, K, P, Ppad, (size_t) geom.pstride, (double*) d_tmp);
-    else    MBAMD_LAUNCH(k_export_partials<false>, blocks, 256, 0, stream, (const float*) partials[idx], S, K, P, Ppad, (size_t) geom.pstride, (double*) d_tmp);
+    if (s4) MBAMD_LAUNCH(k_export_partials<1>, blocks, 256, 0, stream, (const float*) partials[idx], S, K, P, Ppad, (size_t) geom.pstride, (double*) d_tmp);
+    else if (wg) MBAMD_LAUNCH(k_export_partials<2>, blocks, 256, 0, stream, (const float*) partials[idx], S, K, P, Ppad, (size_t) (wgTileBytes / 4), (double*) d_tmp);
+    else    MBAMD_LAUNCH(k_export_partials<0>, blocks, 256, 0, stream, (const float*) partials[idx], S, K, P, Ppad, (size_t) geom.pstride, (double*) d_tmp);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipStreamSynchronize(stream));
     HIP_TRY(hipMemcpy(out, d_tmp, total * sizeof(double), hipMemcpyDeviceToHost));
@@ -737,11 +830,12 @@ int Instance::flushMatrices()
     if (S > 8 && S <= 64) {                       // fp64 matrix cores, one wave per 16 rows
         const unsigned grid = (unsigned) (count * K);
         const int packedT = mfma ? T : 0;
+        const size_t wgTab = wg ? wgTabFloats : 0;
         switch ((S + 15) / 16) {
-            case 1: MBAMD_LAUNCH(k_transition_matrices_mfma<1>, grid, 64, 0, stream, djobs, rates, S, SP, K, packedT); break;
-            case 2: MBAMD_LAUNCH(k_transition_matrices_mfma<2>, grid, 128, 0, stream, djobs, rates, S, SP, K, packedT); break;
-            case 3: MBAMD_LAUNCH(k_transition_matrices_mfma<3>, grid, 192, 0, stream, djobs, rates, S, SP, K, packedT); break;
-            default: MBAMD_LAUNCH(k_transition_matrices_mfma<4>, grid, 256, 0, stream, djobs, rates, S, SP, K, packedT); break;
+            case 1: MBAMD_LAUNCH(k_transition_matrices_mfma<1>, grid, 64, 0, stream, djobs, rates, S, SP, K, packedT, wgTab); break;
+            case 2: MBAMD_LAUNCH(k_transition_matrices_mfma<2>, grid, 128, 0, stream, djobs, rates, S, SP, K, packedT, wgTab); break;
+            case 3: MBAMD_LAUNCH(k_transition_matrices_mfma<3>, grid, 192, 0, stream, djobs, rates, S, SP, K, packedT, wgTab); break;
+            default: MBAMD_LAUNCH(k_transition_matrices_mfma<4>, grid, 256, 0, stream, djobs, rates, S, SP, K, packedT, wgTab); break;
         }
         HIP_TRY(hipGetLastError());
         return BEAGLE_SUCCESS;
@@ -753,7 +847,7 @@ int Instance::flushMatrices()
     MBAMD_LAUNCH(k_eigen_exponentials, (unsigned) ((nev + 255) / 256), 256, 0, stream, djobs, rates, S, K, (int) nev, d_ev);
     const int threads = std::min(256, round_up(S * S, 64));
     MBAMD_LAUNCH(k_transition_matrices_ev, (unsigned) (count * K), threads, 0, stream, djobs, (const double*) d_ev, S, SP, K, 1,
-                 mfma ? T : 0);
+                 mfma ? T : 0, wg ? wgTabFloats : (size_t) 0);
     HIP_TRY(hipGetLastError());
     return BEAGLE_SUCCESS;
 }
@@ -769,7 +863,11 @@ int Instance::setMatrix(int idx, const double* in)
                 h[(size_t) k * SP * SP + (size_t) j * SP + i] = v;
                 if (mfma)
                     h[(size_t) K * SP * SP + ((size_t) (k * NT + i / 32) * T + j / 2) * 64 + (i % 32) + 32 * (j % 2)] = v;
+                if (wg) wg_table_put(h.data() + wgTabFloats + (size_t) k * wg_table_floats(S), S, i, j, v);
             }
+    if (wg)
+        for (int k = 0; k < K; ++k)
+            for (int i = 0; i < S; ++i) wg_table_put_missing(h.data() + wgTabFloats + (size_t) k * wg_table_floats(S), S, i);
     return upload(matrixPtr(idx), h.data(), matrixFloats * sizeof(float));
 }
 
@@ -796,6 +894,7 @@ int Instance::updatePartials(const BeagleOperation* ops, int n, int cumIdx)
     if (cumIdx != BEAGLE_OP_NONE && (cumIdx < 0 || cumIdx >= nScale))
         return fail(BEAGLE_ERROR_OUT_OF_RANGE, "beagleUpdatePartials: cumulative scale index");
     if (s4) return updatePartials4(ops, n, cumIdx);
+    if (wg) return updatePartialsG(ops, n, cumIdx);
     int32_t* cumPtr = nullptr;
     if (cumIdx != BEAGLE_OP_NONE) {
         int rc = ensureScale(cumIdx);
@@ -956,6 +1055,7 @@ int Instance::flushPending()
 {
     int mrc = flushMatrices();                   // (queued matrix jobs precede the lists that read them)
     if (mrc) return mrc;
+    if (wg) return flushWalkG();
     if (pending.empty()) return BEAGLE_SUCCESS;
     std::vector<std::pair<Plan*, int>> work;
     work.swap(pending);
@@ -1127,7 +1227,7 @@ int Instance::timedRun(const Plan& plan, int32_t* cum)
         HIP_TRY(hipEventCreate(&ev1));
         HIP_TRY(hipEventRecord(ev0, stream));
     }
-    const int rc = s4 ? runWalk(plan, cum) : runGeneric(plan, cum);
+    const int rc = s4 ? runWalk(plan, cum) : (wg ? runWalkG(plan) : runGeneric(plan, cum));
     if (timing) {
         HIP_TRY(hipEventRecord(ev1, stream));
         events.emplace_back(ev0, ev1);
@@ -1231,9 +1331,10 @@ int Instance::updatePartials4(const BeagleOperation* ops, int n, int cumIdx)
 
 // Compile one operation list: validate, cut into hazard-free segments, build (or re-use) the structural template of
 // each segment and fill it with this list's buffer / matrix / scale indices.
-int Instance::buildWalk(Plan& plan, const BeagleOperation* ops, int n)
+int Instance::buildWalk(Plan& plan, const BeagleOperation* ops, int n, const int* listOf)
 {
     const int scratchScale = (int) scale.size();              // sink / source of entries that do not rescale
+    std::vector<int> segList;                                  // (20/61-state walk) merged-list index of each operation of the segment
     std::vector<char> written(nBuffers, 0);
     w4table.clear();
     plan.segments.clear();
@@ -1288,7 +1389,9 @@ int Instance::buildWalk(Plan& plan, const BeagleOperation* ops, int n)
         sg.W = t.W; sg.entries = t.entries; sg.nslots = t.nslots;
         plan.segments.push_back(sg);
         w4table.resize(sg.first + t.prog.size());
-        const uint32_t pbuf = (uint32_t) K * 1024u, ebuf = (uint32_t) K * 64u, mbuf = (uint32_t) K * 64u;   // bytes per buffer
+        // bytes per buffer inside a block / tile, bytes per LDS slot
+        const uint32_t slotb = wg ? wg_block_bytes(S) : 1024u;
+        const uint32_t pbuf = (uint32_t) K * slotb, ebuf = (uint32_t) K * 64u, mbuf = wg ? (uint32_t) (matrixFloats * 4) : (uint32_t) K * 64u;
         for (size_t i = 0; i < t.prog.size(); ++i) {
             const Walk4Template::Entry& te = t.prog[i];
             Walk4Entry& e = w4table[sg.first + i];
@@ -1296,6 +1399,31 @@ int Instance::buildWalk(Plan& plan, const BeagleOperation* ops, int n)
             uint32_t flags = te.flags, mode = SCALE_NONE, keep = 0;
             e.ewrite = (uint32_t) scratchScale * ebuf;
             e.eread = (uint32_t) scratchScale * ebuf;
+            if (wg) {
+                // k_walkg (mbamd_walkg.h): no prefetch entries; a child that is neither a tip nor in a slot is read from
+                // HBM by the operand pipeline; NOP entries store zeros to the extra buffer of the tile
+                e.dst = (uint32_t) nBuffers * pbuf;
+                if (te.op >= 0) {
+                    const Walk4Op& op = seg[te.op];
+                    e.dst = (uint32_t) op.dst * pbuf;
+                    if (op.tip1) { e.c1 = (uint32_t) op.c1 * 32u; flags |= MBAMD_W4_TIP1; }
+                    else if (te.c1slot == 0xFF) { e.c1 = (uint32_t) op.c1 * pbuf; flags |= MBAMD_WG_MEM1; }
+                    else e.c1 = (uint32_t) te.c1slot * slotb;
+                    if (op.tip2) { e.c2 = (uint32_t) op.c2 * 32u; flags |= MBAMD_W4_TIP2; }
+                    else if (te.c2slot == 0xFF) { e.c2 = (uint32_t) op.c2 * pbuf; flags |= MBAMD_WG_MEM2; }
+                    else e.c2 = (uint32_t) te.c2slot * slotb;
+                    e.m1 = (uint32_t) op.m1 * mbuf;
+                    e.m2 = (uint32_t) op.m2 * mbuf;
+                    if (te.dslot != 0xFF) { keep = te.dslot; flags |= MBAMD_W4_KEEP; }
+                    mode = op.scaleWrite >= 0 ? SCALE_WRITE : (op.scaleRead >= 0 ? SCALE_READ : SCALE_NONE);
+                    if (op.scaleWrite >= 0) e.ewrite = (uint32_t) op.scaleWrite * ebuf;
+                    if (op.scaleRead >= 0) e.eread = (uint32_t) op.scaleRead * ebuf;
+                    e.ctl = flags | (mode << 8) | ((uint32_t) segList[te.op] << 10) | (keep << 16);
+                } else {
+                    e.ctl = (flags & (MBAMD_W4_NOP | MBAMD_W4_BARRIER)) | MBAMD_W4_NOP;
+                }
+                continue;
+            }
             if (te.pfOp[0] >= 0) {                          // PF entry
                 const Walk4Op& p0 = seg[te.pfOp[0]];
                 e.dst = (uint32_t) (te.pfChild[0] == 0 ? p0.c1 : p0.c2) * pbuf;
@@ -1324,6 +1452,7 @@ int Instance::buildWalk(Plan& plan, const BeagleOperation* ops, int n)
         }
         lastWalkW = t.W; lastWalkSlots = t.nslots; lastWalkEntries = t.entries; lastWalkPhases = t.phases;
         seg.clear();
+        segList.clear();
         std::fill(segRead.begin(), segRead.end(), 0);
         std::fill(segWritten.begin(), segWritten.end(), 0);
         std::fill(segScale.begin(), segScale.end(), 0);
@@ -1377,6 +1506,7 @@ int Instance::buildWalk(Plan& plan, const BeagleOperation* ops, int n)
         if (w.scaleRead >= 0 && !segScale[w.scaleRead]) segScale[w.scaleRead] = 1;
         written[w.dst] = 1;
         seg.push_back(w);
+        segList.push_back(listOf ? listOf[o] : 0);
     }
     int rc = flushSegment();
     if (rc) return rc;
@@ -1419,6 +1549,147 @@ int Instance::runWalk(const Plan& plan, int32_t* cum)
         a.Ppad = Ppad;
         a.nblocks = Ppad / 64;
         MBAMD_LAUNCH_BARRIER(k_walk4, walk4_grid(Ppad / 64, K), 64 * sg.W, walk4_lds_bytes(sg.W, sg.nslots), stream, a);
+        HIP_TRY(hipGetLastError());
+        pendingLaunches += 1;
+    }
+    return BEAGLE_SUCCESS;
+}
+
+// ---------------------------------------------------------------------------------------------
+// 20/61-state tree walk (mbamd_walkg.h).  beagleUpdatePartials only queues: MrBayes submits one list per eigen-system
+// part of a codon model (reference src/mbbeagle.c:1095-1104), and a forest of three trees fills the chip where one tree
+// cannot.  The queue runs -- as ONE program per wave, hazards cut into segments like any list -- when the next call
+// arrives that depends on it.
+// ---------------------------------------------------------------------------------------------
+int Instance::updatePartialsG(const BeagleOperation* ops, int n, int cumIdx)
+{
+    bool clash = (int) wgListCum.size() >= MBAMD_WG_MAXLISTS;
+    if (cumIdx != BEAGLE_OP_NONE)
+        for (int c : wgListCum) clash |= c == cumIdx;            // one list per cumulative buffer and launch
+    if (clash) {
+        int rc = flushPending();
+        if (rc) return rc;
+    }
+    wgListStart.push_back((int) wgOps.size());
+    wgListCum.push_back(cumIdx);
+    wgOps.insert(wgOps.end(), ops, ops + n);
+    if (noDefer) return flushPending();
+    return BEAGLE_SUCCESS;
+}
+
+// does a beagle{Accumulate,Remove}ScaleFactors call commute with the queued lists?  (MrBayes removes the old node factors
+// of part j+1 between the lists of parts j and j+1, reference src/mbbeagle.c:1086-1104)
+bool Instance::scaleOpsIndependentOfPending(const int* idx, int n, int cumIdx) const
+{
+    for (int c : wgListCum) if (c == cumIdx) return false;
+    for (const BeagleOperation& b : wgOps) {
+        if (b.destinationScaleWrite == cumIdx || b.destinationScaleRead == cumIdx) return false;
+        for (int i = 0; i < n; ++i)
+            if (b.destinationScaleWrite == idx[i]) return false;
+    }
+    for (int i = 0; i < n; ++i)
+        for (int c : wgListCum) if (c == idx[i]) return false;
+    return true;
+}
+
+int Instance::flushWalkG()
+{
+    if (wgListCum.empty()) return BEAGLE_SUCCESS;
+    std::vector<BeagleOperation> ops;
+    std::vector<int> starts, cums;
+    ops.swap(wgOps); starts.swap(wgListStart); cums.swap(wgListCum);
+    const int n = (int) ops.size(), nl = (int) cums.size();
+    std::vector<int> listOf(n, 0);
+    for (int q = 0; q < nl; ++q)
+        for (int o = starts[q]; o < (q + 1 < nl ? starts[q + 1] : n); ++o) listOf[o] = q;
+    wgFresh = 0;
+    for (int q = 0; q < MBAMD_WG_MAXLISTS; ++q) wgCum[q] = nullptr;
+    for (int q = 0; q < nl; ++q) {
+        const int ci = cums[q];
+        if (ci == BEAGLE_OP_NONE) continue;
+        if (scaleState[ci] == 0) {
+            // a freshly reset cumulative buffer (the rescale-everything pass): the kernel STORES its sums, no zero-fill launch
+            if (!wideScale[ci]) HIP_TRY(hipMalloc(&wideScale[ci], (size_t) K * Ppad * sizeof(int32_t)));
+            scaleState[ci] = 2;
+            wgFresh |= 1 << q;
+        } else {
+            int rc = ensureWide(ci);
+            if (rc) return rc;
+        }
+        wgCum[q] = wideScale[ci];
+    }
+    // ---- plan cache: the operations, the list boundaries, the layout epoch -------------------------------------------
+    const int* raw = reinterpret_cast<const int*>(ops.data());
+    const size_t nints = (size_t) n * 7;
+    std::vector<int> key(raw, raw + nints);
+    for (int q = 0; q < nl; ++q) key.push_back(starts[q]);
+    key.push_back(layoutEpoch);
+    uint64_t h = 1469598103934665603ull;
+    for (int v : key) h = (h ^ (uint64_t) (uint32_t) v) * 1099511628211ull;
+    Plan* plan = nullptr;
+    for (Plan* pl : plans)
+        if (pl->hash == h && pl->key == key) {
+            pl->lastUse = ++planClock;
+            planHits++;
+            plan = pl;
+            break;
+        }
+    if (!plan) {
+        planMisses++;
+        const size_t maxPlans = 24;
+        if (plans.size() < maxPlans) {
+            plan = new Plan();
+            plans.push_back(plan);
+        } else {
+            plan = plans[0];
+            for (Plan* pl : plans) if (pl->lastUse < plan->lastUse) plan = pl;
+        }
+        plan->key = key;
+        plan->hash = h;
+        plan->lastUse = ++planClock;
+        int rc;
+        {
+            StatTimer st_(ST_PLAN);
+            rc = buildWalk(*plan, ops.data(), n, listOf.data());
+        }
+        if (rc) { plan->hash = 0; plan->key.clear(); return rc; }
+    }
+    for (int o = 0; o < n; ++o) {
+        valid[ops[o].destinationPartials] = 1;
+        if (ops[o].destinationScaleWrite != BEAGLE_OP_NONE) scaleState[ops[o].destinationScaleWrite] = 1;
+    }
+    return timedRun(*plan, nullptr);
+}
+
+template <int SC_, int WMAX_, int DEPTH_>
+static void launch_walkg_t(Instance& in, const WalkGArgs& a, int W, int nslots)
+{
+    auto kern = k_walkg<SC_, WMAX_, DEPTH_>;
+    MBAMD_LAUNCH_BARRIER(kern, walkg_grid(in.Ppad / 32, in.K), 64 * W, wg_lds_bytes(W, nslots, in.S), in.stream, a);
+}
+
+int Instance::runWalkG(const Plan& plan)
+{
+    for (const Plan::Segment& sg : plan.segments) {
+        WalkGArgs a;
+        std::memset(&a, 0, sizeof a);
+        a.prog = reinterpret_cast<const Walk4Entry*>(plan.d_table) + sg.first;
+        a.entries = sg.entries;
+        a.nslots = sg.nslots;
+        a.partials = arenaPartials;
+        a.tileBytes = wgTileBytes;
+        a.tips = arenaTipStates;
+        a.tipTileBytes = wgTipTileBytes;
+        a.exps = arenaExp;
+        a.estride = estride;
+        a.matrices = matrices;
+        a.tabOff = (unsigned) (wgTabFloats * 4);
+        a.tabBytes = (unsigned) (wg_table_floats(S) * 4);
+        for (int q = 0; q < MBAMD_WG_MAXLISTS; ++q) a.cum[q] = wgCum[q];
+        a.cumFresh = (&sg == &plan.segments.front()) ? wgFresh : 0;
+        a.K = K; a.Ppad = Ppad; a.ntiles = Ppad / 32; a.S = S; a.SP = SP;
+        if (S == 61) launch_walkg_t<61, 4, 1>(*this, a, sg.W, sg.nslots);
+        else launch_walkg_t<20, 8, 2>(*this, a, sg.W, sg.nslots);
         HIP_TRY(hipGetLastError());
         pendingLaunches += 1;
     }
@@ -1993,7 +2264,7 @@ int Instance::integrate(const int* parent, const int* child, const int* prob, co
                         const int* cumIdx, int count, double* out)
 {
     if (count < 1 || count > MBAMD_MAX_SUBSETS) return fail(BEAGLE_ERROR_NO_IMPLEMENTATION, "log-likelihood: subset count");
-    if (s4) {
+    if (arena()) {
         int rc = integrate4(parent, child, prob, wIdx, fIdx, cumIdx, count);
         if (rc) return rc;
         haveSite = true;
@@ -2082,7 +2353,13 @@ int Instance::integrate4(const int* parent, const int* child, const int* prob, c
     }
     double* const siteOut = (siteToHost && h_site_dev) ? h_site_dev : d_site;
     siteOnHost = siteOut != d_site;
-    MBAMD_LAUNCH(k_integrate_lnl_s4, (unsigned) nblocks, 64, 0, stream, a, K, P, Ppad, geom, (const double*) d_pweights, siteOut, h_sums_dev);
+    if (wg) {
+        WgGeom g;
+        g.tileFloats = wgTileBytes / 4; g.tipTileBytes = wgTipTileBytes; g.TP = wg_pairs_padded(S);
+        MBAMD_LAUNCH(k_integrate_lnl_wg, (unsigned) nblocks, 64, 0, stream, a, S, SP, K, P, Ppad, g, (const double*) d_pweights, siteOut, h_sums_dev);
+    } else {
+        MBAMD_LAUNCH(k_integrate_lnl_s4, (unsigned) nblocks, 64, 0, stream, a, K, P, Ppad, geom, (const double*) d_pweights, siteOut, h_sums_dev);
+    }
     HIP_TRY(hipGetLastError());
     return BEAGLE_SUCCESS;
 }
@@ -2165,7 +2442,7 @@ int Instance::getScaleExponents(int idx, int* out)
 {
     if (idx < 0 || idx >= nScale) return fail(BEAGLE_ERROR_OUT_OF_RANGE, "scale exponents: index");
     HIP_TRY(hipStreamSynchronize(stream));
-    if (!s4) {
+    if (!arena()) {
         int rc = ensureScale(idx);
         if (rc) return rc;
         std::vector<int32_t> h(Ppad);
@@ -2248,7 +2525,7 @@ using namespace mbamd;
 // every entry point except beagleUpdatePartials first runs the lists deferred so far
 #define GET_INSTANCE(id)                                                                             \
     GET_INSTANCE_NOFLUSH(id);                                                                        \
-    if (!in->pending.empty() || !in->pendingJobs.empty()) {                                          \
+    if (in->hasPending() || !in->pendingJobs.empty()) {                                          \
         int frc_ = in->flushPending();                                                               \
         if (frc_ != BEAGLE_SUCCESS) return frc_;                                                     \
     }
@@ -2259,7 +2536,7 @@ using namespace mbamd;
             Instance* c = ch.in;                                                                     \
             (void) ch;                                                                               \
             (void) hipSetDevice(c->device);                                                          \
-            if (FLUSH && (!c->pending.empty() || !c->pendingJobs.empty())) {                         \
+            if (FLUSH && (c->hasPending() || !c->pendingJobs.empty())) {                         \
                 int frc_ = c->flushPending();                                                        \
                 if (frc_ != BEAGLE_SUCCESS) return frc_;                                             \
             }                                                                                        \
@@ -2296,7 +2573,7 @@ static int integrate_any(Instance* in, const int* parent, const int* child, cons
         }
         Instance* c = ch.in;
         (void) hipSetDevice(c->device);
-        if (!c->pending.empty() || !c->pendingJobs.empty()) { int frc = c->flushPending(); if (frc) return frc; }
+        if (c->hasPending() || !c->pendingJobs.empty()) { int frc = c->flushPending(); if (frc) return frc; }
         const bool was = c->deferred;
         c->deferred = true;                             // launch everywhere first, collect afterwards
         const int rc = c->integrate(pa.data(), child ? ca.data() : nullptr, child ? pr.data() : nullptr, wa.data(), fa.data(),
@@ -2574,7 +2851,7 @@ int beagleGetPartials(int instance, int bufferIndex, int scaleIndex, double* out
         for (Instance::Child& ch : in->children) {
             part.resize((size_t) in->K * ch.count * in->S);
             (void) hipSetDevice(ch.in->device);
-            if (!ch.in->pending.empty() || !ch.in->pendingJobs.empty()) { int frc = ch.in->flushPending(); if (frc) return frc; }
+            if (ch.in->hasPending() || !ch.in->pendingJobs.empty()) { int frc = ch.in->flushPending(); if (frc) return frc; }
             const int rc = ch.in->getPartials(bufferIndex, part.data());
             if (rc) return rc;
             for (int k = 0; k < in->K; ++k)
@@ -2647,9 +2924,9 @@ int beagleUpdateTransitionMatrices(int instance, int eigenIndex, const int* prob
     if (firstDerivativeIndices || secondDerivativeIndices)
         return fail(BEAGLE_ERROR_NO_IMPLEMENTATION, "beagleUpdateTransitionMatrices: derivatives");
     in->closeLog();
-    FACADE_EACH(false, (c->pending.empty() ? BEAGLE_SUCCESS : c->flushPending()) != BEAGLE_SUCCESS
+    FACADE_EACH(false, (!c->hasPending() ? BEAGLE_SUCCESS : c->flushPending()) != BEAGLE_SUCCESS
                            ? BEAGLE_ERROR_GENERAL : c->updateMatrices(eigenIndex, probabilityIndices, edgeLengths, count));
-    if (!in->pending.empty()) {                  // deferred lists read the matrices about to be replaced
+    if (in->hasPending()) {                      // deferred lists read the matrices about to be replaced
         int frc_ = in->flushPending();
         if (frc_ != BEAGLE_SUCCESS) return frc_;
     }
@@ -2668,7 +2945,7 @@ int beagleUpdateTransitionMatricesWithMultipleModels(int instance, const int* ei
         return fail(BEAGLE_ERROR_NO_IMPLEMENTATION, "beagleUpdateTransitionMatricesWithMultipleModels: derivatives");
     in->closeLog();
     auto run = [&](Instance* c) {
-        if (!c->pending.empty()) { int frc = c->flushPending(); if (frc) return frc; }
+        if (c->hasPending()) { int frc = c->flushPending(); if (frc) return frc; }
         int i = 0;
         while (i < count) {                      // runs of equal (eigen-system, rate vector)
             int j = i + 1;
@@ -2695,7 +2972,7 @@ int beagleGetTransitionMatrix(int instance, int matrixIndex, double* outMatrix)
     if (in->facade()) {
         Instance* c = in->children[0].in;
         (void) hipSetDevice(c->device);
-        if (!c->pending.empty() || !c->pendingJobs.empty()) { int frc = c->flushPending(); if (frc) return frc; }
+        if (c->hasPending() || !c->pendingJobs.empty()) { int frc = c->flushPending(); if (frc) return frc; }
         return c->getMatrix(matrixIndex, outMatrix);
     }
     return in->getMatrix(matrixIndex, outMatrix);
@@ -2756,16 +3033,31 @@ int beagleWaitForPartials(int instance, const int* destinationPartials, int dest
 // scale-factor bookkeeping; `partition` < 0: all patterns
 static int scale_accumulate(Instance* in, const int* scaleIndices, int count, int cumulativeScaleIndex, int sign, int partition)
 {
-    (void) hipSetDevice(in->device);
-    FACADE_ALL((partition >= 0 && in->partitionCount > 1 && ch.partition != partition) ? BEAGLE_SUCCESS
-               : (c->s4 ? c->accumulate4(scaleIndices, count, cumulativeScaleIndex, sign) : c->accumulate(scaleIndices, count, cumulativeScaleIndex, sign)));
-    if (in->s4) return in->accumulate4(scaleIndices, count, cumulativeScaleIndex, sign);
-    return in->accumulate(scaleIndices, count, cumulativeScaleIndex, sign);
+    // queued 20/61-state lists run first unless the call commutes with them (MrBayes removes the old node factors of
+    // eigen-system part j+1 between the lists of parts j and j+1: flushing there would undo the merge of the parts)
+    auto one = [&](Instance* c) -> int {
+        (void) hipSetDevice(c->device);
+        if (c->hasPending() && !(c->wg && c->scaleOpsIndependentOfPending(scaleIndices, count, cumulativeScaleIndex))) {
+            int frc = c->flushPending();
+            if (frc != BEAGLE_SUCCESS) return frc;
+        }
+        return c->arena() ? c->accumulate4(scaleIndices, count, cumulativeScaleIndex, sign)
+                          : c->accumulate(scaleIndices, count, cumulativeScaleIndex, sign);
+    };
+    if (in->facade()) {
+        for (Instance::Child& ch : in->children) {
+            if (partition >= 0 && in->partitionCount > 1 && ch.partition != partition) continue;
+            const int rc = one(ch.in);
+            if (rc != BEAGLE_SUCCESS) return rc;
+        }
+        return BEAGLE_SUCCESS;
+    }
+    return one(in);
 }
 static int scale_reset(Instance* in, int idx)
 {
     if (idx < 0 || idx >= in->nScale) return fail(BEAGLE_ERROR_OUT_OF_RANGE, "beagleResetScaleFactors: index");
-    if (in->s4) {
+    if (in->arena()) {
         // MrBayes resets every scale buffer once at start-up (reference src/mcmc.c:6270): nothing is allocated or
         // launched for a buffer until it is used -- "never written" reads as zero everywhere
         if (in->scaleState[idx] == 1) {           // node exponents in the arena: later reads must see zeros
@@ -2784,7 +3076,7 @@ static int scale_reset(Instance* in, int idx)
 static int scale_copy(Instance* in, int dst, int src)
 {
     if (dst < 0 || dst >= in->nScale || src < 0 || src >= in->nScale) return fail(BEAGLE_ERROR_OUT_OF_RANGE, "beagleCopyScaleFactors: index");
-    if (in->s4) {
+    if (in->arena()) {
         const int st = in->scaleState[src];
         if (st == 2) {
             in->scaleState[dst] = 0;
@@ -2813,13 +3105,13 @@ static int scale_copy(Instance* in, int dst, int src)
 int beagleAccumulateScaleFactors(int instance, const int* scaleIndices, int count, int cumulativeScaleIndex)
 {
     StatTimer st_(ST_SCALE);
-    GET_INSTANCE(instance);
+    GET_INSTANCE_NOFLUSH(instance);
     return scale_accumulate(in, scaleIndices, count, cumulativeScaleIndex, +1, -1);
 }
 int beagleRemoveScaleFactors(int instance, const int* scaleIndices, int count, int cumulativeScaleIndex)
 {
     StatTimer st_(ST_SCALE);
-    GET_INSTANCE(instance);
+    GET_INSTANCE_NOFLUSH(instance);
     return scale_accumulate(in, scaleIndices, count, cumulativeScaleIndex, -1, -1);
 }
 int beagleResetScaleFactors(int instance, int cumulativeScaleIndex)
@@ -2840,13 +3132,13 @@ int beagleCopyScaleFactors(int instance, int destScalingIndex, int srcScalingInd
 int beagleAccumulateScaleFactorsByPartition(int instance, const int* scaleIndices, int count, int cumulativeScaleIndex, int partitionIndex)
 {
     StatTimer st_(ST_SCALE);
-    GET_INSTANCE(instance);
+    GET_INSTANCE_NOFLUSH(instance);
     return scale_accumulate(in, scaleIndices, count, cumulativeScaleIndex, +1, partitionIndex);
 }
 int beagleRemoveScaleFactorsByPartition(int instance, const int* scaleIndices, int count, int cumulativeScaleIndex, int partitionIndex)
 {
     StatTimer st_(ST_SCALE);
-    GET_INSTANCE(instance);
+    GET_INSTANCE_NOFLUSH(instance);
     return scale_accumulate(in, scaleIndices, count, cumulativeScaleIndex, -1, partitionIndex);
 }
 int beagleResetScaleFactorsByPartition(int instance, int cumulativeScaleIndex, int partitionIndex)
@@ -2866,7 +3158,7 @@ int mbamdGetScaleExponents(int instance, int srcScalingIndex, int* out)
         for (Instance::Child& ch : in->children) {
             part.resize((size_t) in->K * ch.count);
             (void) hipSetDevice(ch.in->device);
-            if (!ch.in->pending.empty() || !ch.in->pendingJobs.empty()) { int frc = ch.in->flushPending(); if (frc) return frc; }
+            if (ch.in->hasPending() || !ch.in->pendingJobs.empty()) { int frc = ch.in->flushPending(); if (frc) return frc; }
             const int rc = ch.in->getScaleExponents(srcScalingIndex, part.data());
             if (rc) return rc;
             for (int k = 0; k < in->K; ++k)

@@ -146,6 +146,7 @@ __device__ __forceinline__ float max4(f4 v) { return fmaxf(fmaxf(v.x, v.y), fmax
 
 }  // namespace mbamd
 #include "mbamd_walk4.h"
+#include "mbamd_walkg.h"
 namespace mbamd {
 
 // ---------------------------------------------------------------------------------------------
@@ -325,9 +326,10 @@ k_transition_matrices_s4(const MatrixJob* __restrict__ jobs, RatesArg rates, int
 
 // packedT > 0: additionally write the MFMA A-operand copy behind the K transposed matrices:
 //   packed[((k*NT + i/32)*T + j/2)*64 + (i%32) + 32*(j%2)] = P_k(i->j),  NT = ceil(S/32), T = packedT = ceil(S/2)
+// wgTab > 0: additionally scatter into the tree-walk tables of category k, wgTab floats into the buffer (mbamd_walkg.h)
 __global__ void __launch_bounds__(256)
 k_transition_matrices_ev(const MatrixJob* __restrict__ jobs, const double* __restrict__ ev, int S, int SP, int K,
-                         int transposed, int packedT)
+                         int transposed, int packedT, size_t wgTab)
 {
     const int b = blockIdx.x / K, k = blockIdx.x % K;
     const double* __restrict__ U = jobs[b].eig;
@@ -347,6 +349,7 @@ k_transition_matrices_ev(const MatrixJob* __restrict__ jobs, const double* __res
             float* __restrict__ packed = jobs[b].out + (size_t) K * SP * SP;
             packed[((size_t) (k * NT + i / 32) * packedT + j / 2) * 64 + (i % 32) + 32 * (j % 2)] = v;
         }
+        if (wgTab > 0) wg_table_put(jobs[b].out + wgTab + (size_t) k * wg_table_floats(S), S, i, j, v);
     }
 }
 
@@ -503,6 +506,73 @@ k_integrate_lnl_s4(IntegrateArgs4 a, int K, int P, int Ppad, BlockGeom g,
 #endif
 }
 
+// 20/61-state tree-walk layout (mbamd_walkg.h): partials float [tile][buffer][K][T][64], tip states uint8 [tile][buffer][32],
+// cumulative exponents per (pattern, category) like the 4-state path.  Same arithmetic as k_integrate_lnl, the categories
+// recombined as in k_integrate_lnl_s4.  One thread per pattern.
+struct WgGeom { unsigned long tileFloats; unsigned tipTileBytes; int TP; };
+__global__ void __launch_bounds__(64)
+k_integrate_lnl_wg(IntegrateArgs4 a, int S, int SP, int K, int P, int Ppad, WgGeom g,
+                   const double* __restrict__ pattern_weights, double* __restrict__ site, double* __restrict__ wsite)
+{
+    const int c = blockIdx.x * 64 + threadIdx.x;
+    const size_t pb = (size_t) (c >> 5) * g.tileFloats;                         // float index of (tile, category 0) of the buffer
+    const size_t kstride = (size_t) g.TP * 64;
+    const int p = c & 31;
+    double wl = 0.0;
+    if (c < P) {
+        int emax = -2147483647;
+        for (int n = 0; n < a.count; ++n)
+            for (int k = 0; k < K; ++k) {
+                const int e = a.cum[n] ? a.cum[n][(size_t) k * Ppad + c] : 0;
+                emax = e > emax ? e : emax;
+            }
+        double total = 0.0;
+        for (int n = 0; n < a.count; ++n) {
+            const double* __restrict__ pi = a.freqs[n];
+            const float* __restrict__ par = reinterpret_cast<const float*>(a.parent[n]) + pb;
+            unsigned s = 0;
+            if (a.child[n] != nullptr && a.child_kind[n] == CHILD_STATES)
+                s = reinterpret_cast<const uint8_t*>(a.child[n])[(size_t) (c >> 5) * g.tipTileBytes + (c & 31)];
+            for (int k = 0; k < K; ++k) {
+                const float* __restrict__ pk = par + (size_t) k * kstride;
+                double cat = 0.0;
+                if (a.child[n] == nullptr) {
+                    for (int i = 0; i < S; ++i) cat += (double) pk[wg_elem(S, i, p)] * pi[i];
+                } else if (a.child_kind[n] == CHILD_STATES) {
+                    const float* __restrict__ mrow = a.matrix[n] + (size_t) k * SP * SP + (size_t) (s < (unsigned) S ? s : 0) * SP;
+                    for (int i = 0; i < S; ++i) {
+                        const float pc = (s >= (unsigned) S) ? 1.0f : mrow[i];
+                        cat += (double) (pk[wg_elem(S, i, p)] * pc) * pi[i];
+                    }
+                } else {
+                    const float* __restrict__ ch = reinterpret_cast<const float*>(a.child[n]) + pb + (size_t) k * kstride;
+                    const float* __restrict__ m = a.matrix[n] + (size_t) k * SP * SP;
+                    for (int i = 0; i < S; ++i) {
+                        float acc = 0.0f;
+                        for (int j = 0; j < S; ++j) acc = fmaf(m[(size_t) j * SP + i], ch[wg_elem(S, j, p)], acc);
+                        cat += (double) (pk[wg_elem(S, i, p)] * acc) * pi[i];
+                    }
+                }
+                const int e = a.cum[n] ? a.cum[n][(size_t) k * Ppad + c] : 0;
+                total += ldexp(cat * a.weights[n][k], e - emax);
+            }
+        }
+        const double lnl = log(total) + (double) emax * 0.69314718055994530942;
+        site[c] = lnl;
+        wl = lnl * pattern_weights[c];
+    } else if (c < Ppad) {
+        site[c] = 0.0;
+    }
+#if defined(MBAMD_HOST_EMU)
+    if (threadIdx.x == 0) wsite[blockIdx.x] = 0.0;
+    wsite[blockIdx.x] += wl;
+#else
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) wl += __shfl_down(wl, off);
+    if (threadIdx.x == 0) wsite[blockIdx.x] = wl;
+#endif
+}
+
 // ---------------------------------------------------------------------------------------------
 // cumulative scale-factor bookkeeping (exact integer arithmetic)
 // ---------------------------------------------------------------------------------------------
@@ -562,7 +632,13 @@ k_exp_copy(int8_t* __restrict__ arena, unsigned estride, int src, int dst, int K
 // ---------------------------------------------------------------------------------------------
 // layout conversion between the boundary's [category][pattern][state] doubles and device layouts
 // ---------------------------------------------------------------------------------------------
-template <bool S4>
+// LAYOUT: 0 general tile-major buffer, 1 4-state arena (pstride = f4 elements between blocks), 2 20/61-state tree-walk
+// arena (pstride = floats between tiles; `out` / `in` = the buffer's block in tile 0)
+__host__ __device__ inline size_t wg_index(int S, size_t tileFloats, int k, int i, int c)
+{
+    return (size_t) (c >> 5) * tileFloats + (size_t) k * wg_pairs_padded(S) * 64 + wg_elem(S, i, c & 31);
+}
+template <int LAYOUT>
 __global__ void __launch_bounds__(256)
 k_import_partials(const double* __restrict__ in, int in_has_categories, int S, int K, int P, int Ppad, size_t pstride,
                   float* __restrict__ out)
@@ -574,11 +650,12 @@ k_import_partials(const double* __restrict__ in, int in_has_categories, int S, i
     const int c = (int) ((g / S) % P);
     const int k = (int) (g / ((size_t) S * P));
     const double v = in_has_categories ? in[g] : in[(size_t) c * S + i];
-    if (S4) out[(blk_index(c, pstride) + (size_t) k * 64) * 4 + i] = (float) v;
-    else    out[gen_index(K, S, k, i, c)] = (float) v;
+    if (LAYOUT == 1) out[(blk_index(c, pstride) + (size_t) k * 64) * 4 + i] = (float) v;
+    else if (LAYOUT == 2) out[wg_index(S, pstride, k, i, c)] = (float) v;
+    else out[gen_index(K, S, k, i, c)] = (float) v;
 }
 
-template <bool S4>
+template <int LAYOUT>
 __global__ void __launch_bounds__(256)
 k_export_partials(const float* __restrict__ in, int S, int K, int P, int Ppad, size_t pstride, double* __restrict__ out)
 {
@@ -588,7 +665,8 @@ k_export_partials(const float* __restrict__ in, int S, int K, int P, int Ppad, s
     const int i = (int) (g % S);
     const int c = (int) ((g / S) % P);
     const int k = (int) (g / ((size_t) S * P));
-    out[g] = S4 ? (double) in[(blk_index(c, pstride) + (size_t) k * 64) * 4 + i] : (double) in[gen_index(K, S, k, i, c)];
+    out[g] = LAYOUT == 1 ? (double) in[(blk_index(c, pstride) + (size_t) k * 64) * 4 + i]
+           : LAYOUT == 2 ? (double) in[wg_index(S, pstride, k, i, c)] : (double) in[gen_index(K, S, k, i, c)];
 }
 
 }  // namespace mbamd

@@ -941,7 +941,7 @@ typedef double f64x4 __attribute__((ext_vector_type(4)));
 
 template <int NJ>
 __global__ void __launch_bounds__(64 * NJ)
-k_transition_matrices_mfma(const MatrixJob* __restrict__ jobs, RatesArg rates, int S, int SP, int K, int packedT)
+k_transition_matrices_mfma(const MatrixJob* __restrict__ jobs, RatesArg rates, int S, int SP, int K, int packedT, size_t wgTab)
 {
     __shared__ double ev[64];
     const int b = blockIdx.x / K, k = blockIdx.x % K;
@@ -992,6 +992,7 @@ k_transition_matrices_mfma(const MatrixJob* __restrict__ jobs, RatesArg rates, i
                 const float v = (sum < 0.0) ? 0.0f : (float) sum;
                 out[(size_t) j * SP + row] = v;
                 if (packedT > 0) packed[((size_t) (k * NT + row / 32) * packedT + j / 2) * 64 + (row % 32) + 32 * (j % 2)] = v;
+                if (wgTab > 0) wg_table_put(job.out + wgTab + (size_t) k * wg_table_floats(S), S, row, j, v);   // tree-walk tables (mbamd_walkg.h)
             }
         }
 }

@@ -67,11 +67,14 @@ public:
     int prefetchDistance = 6;  // entries a child prefetch is issued ahead of its consumer (if a slot is free)
     bool safeWaits = false;    // debug: every wait is vmcnt(0)
     int smallPhase = 16;       // a phase with at most this many operations runs on one wave
-    // general-state tree walk (k_partials_mfma_walk): children that live in HBM are loaded straight into registers (no
-    // slot, no prefetch entry), and every result needs a slot at least until the next entry (the writer wave copies it out)
+    // general-state tree walk (k_walkg, mbamd_walkg.h): memSlots = false -- children that live in HBM are loaded straight
+    // into registers by the kernel's operand pipeline (no slot, no prefetch entry; c?slot = 0xFF marks them); the loads of
+    // entry j are issued during entry j-1, so a value this wave re-reads from HBM must have been stored by entry j-2 or earlier
     bool memSlots = true;
     bool alwaysKeep = false;
     bool phasesAreLaunches = false;  // every phase is its own kernel launch: nothing stays in LDS across a phase boundary
+    // program frame: leading NOP entries, loop unroll factor of the kernel, trailing (read-ahead) NOP entries
+    int leadNops = 0, unroll = 2, tailNops = 2;
 
     // ops: one hazard-free segment (no buffer is written twice, none is written after it was read, a buffer read
     // after it was written is a dependency).  Fills `t` (structure) -- the caller turns it into Walk4Entry words.
@@ -320,8 +323,8 @@ inline bool Walk4Builder::build(const std::vector<Walk4Op>& ops, Walk4Template& 
             for (int u = std::max(j, posOf[v] + 1); u < L; ++u) {
                 const int o = items[w][u].op;
                 if (o < 0) continue;
-                if (prod1[o] == v) { mems.push_back(Mem{o, 0, std::max(j, posOf[v] + 1), u, -1, false}); t.reloads++; }
-                if (prod2[o] == v && !(prod1[o] == v)) { mems.push_back(Mem{o, 1, std::max(j, posOf[v] + 1), u, -1, false}); t.reloads++; }
+                if (prod1[o] == v) { if (memSlots) mems.push_back(Mem{o, 0, std::max(j, posOf[v] + 1), u, -1, false}); t.reloads++; }
+                if (prod2[o] == v && !(prod1[o] == v)) { if (memSlots) mems.push_back(Mem{o, 1, std::max(j, posOf[v] + 1), u, -1, false}); t.reloads++; }
             }
             return best;
         };
@@ -385,7 +388,12 @@ inline bool Walk4Builder::build(const std::vector<Walk4Op>& ops, Walk4Template& 
                 for (size_t mi = 0; mi < mems.size(); ++mi)
                     if (mems[mi].op == o && mems[mi].child == c && mems[mi].issued) { found = (int) mi; break; }
                 if (found < 0) {
-                    if (!memSlots) { *cslot[c] = 0xFF; continue; }       // read from HBM by the kernel itself
+                    if (!memSlots) {                                     // read from HBM by the kernel itself
+                        // (its loads are issued one entry ahead: a value of this wave must have been stored before that)
+                        if (pr[c] >= 0 && waveOf[pr[c]] == w && posOf[pr[c]] >= j - 1) return false;
+                        *cslot[c] = 0xFF;
+                        continue;
+                    }
                     return false;
                 }
                 *cslot[c] = (uint8_t) mems[found].slot;
@@ -427,8 +435,8 @@ inline bool Walk4Builder::build(const std::vector<Walk4Op>& ops, Walk4Template& 
                         for (int u = j + 1; u < L; ++u) {
                             const int q = items[w][u].op;
                             if (q < 0) continue;
-                            if (prod1[q] == v) { mems.push_back(Mem{q, 0, j + 1, u, -1, false}); t.reloads++; }
-                            if (prod2[q] == v && prod1[q] != v) { mems.push_back(Mem{q, 1, j + 1, u, -1, false}); t.reloads++; }
+                            if (prod1[q] == v) { if (memSlots) mems.push_back(Mem{q, 0, j + 1, u, -1, false}); t.reloads++; }
+                            if (prod2[q] == v && prod1[q] != v) { if (memSlots) mems.push_back(Mem{q, 1, j + 1, u, -1, false}); t.reloads++; }
                         }
                         sl = best;
                     }
@@ -443,8 +451,8 @@ inline bool Walk4Builder::build(const std::vector<Walk4Op>& ops, Walk4Template& 
                     for (int u = j + 1; u < L; ++u) {           // not kept: its consumers prefetch it (after this entry's store)
                         const int q = items[w][u].op;
                         if (q < 0) continue;
-                        if (prod1[q] == o) { mems.push_back(Mem{q, 0, j + 1, u, -1, false}); t.reloads++; }
-                        if (prod2[q] == o && prod1[q] != o) { mems.push_back(Mem{q, 1, j + 1, u, -1, false}); t.reloads++; }
+                        if (prod1[q] == o) { if (memSlots) mems.push_back(Mem{q, 0, j + 1, u, -1, false}); t.reloads++; }
+                        if (prod2[q] == o && prod1[q] != o) { if (memSlots) mems.push_back(Mem{q, 1, j + 1, u, -1, false}); t.reloads++; }
                     }
                 }
             }
@@ -495,11 +503,13 @@ inline bool Walk4Builder::build(const std::vector<Walk4Op>& ops, Walk4Template& 
     }
     size_t longestFinal = 0;
     for (int w = 0; w < W; ++w) longestFinal = std::max(longestFinal, fin[w].size());
-    const int entries = (((int) longestFinal + 1) & ~1) + 2;     // even (the kernel loop is unrolled by two) + two read-ahead NOPs
+    // frame: leading NOPs, the programs padded to a multiple of the kernel's loop unroll factor, read-ahead NOPs
+    const int body = (leadNops + (int) longestFinal + unroll - 1) / unroll * unroll;
+    const int entries = body + tailNops;
     t.entries = entries;
     t.prog.assign((size_t) W * entries, Walk4Template::Entry());
     for (Walk4Template::Entry& e : t.prog) e.flags = MBAMD_W4_NOP;
-    for (int w = 0; w < W; ++w) std::copy(fin[w].begin(), fin[w].end(), t.prog.begin() + (size_t) w * entries);
+    for (int w = 0; w < W; ++w) std::copy(fin[w].begin(), fin[w].end(), t.prog.begin() + (size_t) w * entries + leadNops);
     t.nslots = slotsUsed;
     return true;
 }

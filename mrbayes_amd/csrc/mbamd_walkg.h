@@ -1,0 +1,392 @@
+// mbamd_walkg.h -- the 20/61-state tree-walk kernel on the matrix cores (included by mbamd_kernels_mfma.h).
+//
+// Replaces CondLikeDown_Gen[_SSE] / CondLikeDown_NY98[_SSE] + CondLikeScaler_Gen / _NY98 + RemoveNodeScalers
+// (reference src/likelihood.c:204-588, 1575-1900, 4939-5070, 5413-5545, 7981-8070) for whole operation lists --
+// all eigen-system parts of a codon model together -- in ONE launch.
+//
+// Same decomposition as the 4-state walk (mbamd_walk4.h), with the matrix-vector products on v_mfma_f32_32x32x2_f32:
+//     wave      = one 32-pattern tile, ONE rate category, interpreting a host-compiled program (Walk4Entry): a
+//                 straight list of operations; no data ever crosses waves inside a phase, and the rescaling exponent is
+//                 per (pattern, category) (exact powers of two, recombined exactly at the root: k_integrate_lnl_wg)
+//     workgroup = W waves (tree parallelism: subtrees packed into W bins, dependent phases separated by a barrier)
+//     grid      = (tiles, categories), XCD-aware
+// A child's conditional likelihoods live as the MFMA B operand wants them: [T = ceil(S/2)][64] floats per (tile, buffer,
+// category) -- row t holds states 2t (lanes 0..31) and 2t+1 (lanes 32..63) of the 32 patterns, which is the tile-major
+// layout [S][32] -- in HBM and, for results the same wave consumes again, in LDS slots private to the wave.
+// The A operand (transition matrix) comes from a table whose ROWS ARE PERMUTED so that the 32x32 output tile lands in
+// exactly that layout: register r of lane-half h holds state 32 it + 2 r + h.  A result is therefore T contiguous
+// 256-byte stores to HBM and T ds_writes to its slot straight from the accumulators -- no LDS turn-around, no cross-wave
+// exchange, no barrier per operation (the level kernels of mbamd_kernels_mfma.h spend three).  A compact tip needs no
+// MFMA: its factor is a gather from a second table laid out for the same registers.
+//
+// Pipelining.  All vector-memory operations are compiler-visible (the waitcnt pass counts them), and their number per
+// entry is THE SAME on every path (dummy loads hit L1, NOP entries store zeros to a scratch buffer): vmcnt retires in order
+// and is shared by loads and stores, so only with a uniform sequence can the compiler wait for "the operands issued two
+// jobs ago" without also waiting for the stores issued since.  A job = one child factor.  While job u computes, the
+// operands of job u+2 are fetched into the third of three register sets: the A rows (or the tip's gather rows) and, for
+// a child that lives in HBM (result of an earlier launch, of another wave, or evicted), its B rows.  Tip states are
+// fetched one entry earlier still, entry descriptors three entries ahead through the scalar cache.
+#ifndef MBAMD_WALKG_H_
+#define MBAMD_WALKG_H_
+
+namespace mbamd {
+
+// Walk4Entry::ctl in this kernel: NOP / BARRIER / TIP1 / TIP2 / KEEP as in mbamd_walk4.h, and
+#define MBAMD_WG_MEM1     0x04u  // child 1 / 2 is read from HBM (c1 / c2 = byte offset inside the tile's partials)
+#define MBAMD_WG_MEM2     0x08u
+#define MBAMD_WG_LIST(ctl) (((ctl) >> 10) & 3u)   // which of the merged lists the entry belongs to (cumulative buffer)
+#define MBAMD_WG_MAXLISTS 4
+#define MBAMD_WG_LEAD     2      // leading NOP entries (they fill the operand pipeline)
+#define MBAMD_WG_TAIL     3      // trailing NOP entries (descriptor read-ahead)
+#define MBAMD_WG_STAGE    256    // bytes per wave in front of its slots (cumulative-exponent hand-over)
+
+__host__ __device__ inline int wg_pairs(int S) { return (S + 1) / 2; }                    // T: MFMA steps (two states each)
+__host__ __device__ inline int wg_tiles(int S) { return (S + 31) / 32; }                  // NT: 32-row output tiles
+__host__ __device__ inline int wg_vec(int S) { return S > 32 ? 4 : 2; }                   // V: floats per lane and memory instruction
+__host__ __device__ inline int wg_pairs_padded(int S) { return (wg_pairs(S) + wg_vec(S) - 1) / wg_vec(S) * wg_vec(S); }   // TP
+__host__ __device__ inline int wg_rows(int S) { return wg_pairs_padded(S) * wg_tiles(S); }      // NAP: 256-byte rows of a table
+__host__ __device__ inline int wg_subtables(int S) { return S / 32 + 1; }                 // gather tables: states 0..S in groups of 32 (S = "missing")
+__host__ __device__ inline unsigned wg_block_bytes(int S) { return (unsigned) wg_pairs_padded(S) * 256u; }   // one (tile, buffer, category) = one LDS slot
+__host__ __device__ inline size_t wg_table_floats(int S) { return (size_t) (1 + wg_subtables(S)) * wg_rows(S) * 64; }   // per category
+__host__ __device__ inline size_t wg_lds_bytes(int W, int nslots, int S) { return (size_t) W * (MBAMD_WG_STAGE + (size_t) nslots * wg_block_bytes(S)); }
+// A block holds [TP rows][64 lanes]: row t, lane 32 h + p = state 2t + h of pattern p; V consecutive rows are interleaved
+// per lane so that one dwordx2 / dwordx4 per lane moves V rows (1/2 - 1 KiB contiguous per wave instruction).
+// float offset of (row r, lane / column c) inside a block or table:
+__host__ __device__ inline unsigned wg_at(int V, int r, int c) { return (unsigned) ((r / V) * 64 * V + c * V + r % V); }
+__host__ __device__ inline unsigned wg_elem(int S, int i, int p) { return wg_at(wg_vec(S), i >> 1, (i & 1) * 32 + p); }   // state i, pattern p
+
+// Tables of one (matrix, category): rows n = t * NT + it (< NAP), 64 columns, stored like blocks (wg_at):
+//   A'  (n, lane)        = P(row_state(it, lane & 31) -> 2t + (lane >> 5))      MFMA A operand of step t, tile it
+//   G_u (n, 2 s5 + h)    = P(32 it + 2t + h -> 32 u + s5),  t < 16              tip gather: lane (pattern with state
+//                          32u + s5, half h) reads column 2 s5 + h of the rows n -> register (it, r = t)
+//       the column of state S ("missing") holds 1 for every existing from-state.
+// row_state: the state carried by row i of output tile it such that register r, half h ends up with state 32 it + 2 r + h
+__host__ __device__ inline int wg_row_state(int it, int i) { return 32 * it + 2 * ((i & 3) + 4 * (i >> 3)) + ((i >> 2) & 1); }
+// scatter P_k(i -> j) = v into the tables of category k (tab = first float of that category's tables)
+__host__ __device__ inline void wg_table_put(float* tab, int S, int i, int j, float v)
+{
+    const int NT = wg_tiles(S), NAP = wg_rows(S), V = wg_vec(S);
+    const int it = i >> 5, r = (i & 31) >> 1, h = i & 1;
+    const int row = (r & 3) + 8 * (r >> 2) + 4 * h;                        // MFMA row that carries state i
+    tab[wg_at(V, (j >> 1) * NT + it, row + 32 * (j & 1))] = v;             // A'
+    tab[(size_t) (1 + (j >> 5)) * NAP * 64 + wg_at(V, r * NT + it, 2 * (j & 31) + h)] = v;   // G_u
+}
+// the "missing" column (constant): from-state i
+__host__ __device__ inline void wg_table_put_missing(float* tab, int S, int i)
+{
+    const int NT = wg_tiles(S), NAP = wg_rows(S), V = wg_vec(S);
+    const int it = i >> 5, r = (i & 31) >> 1, h = i & 1;
+    tab[(size_t) (1 + (S >> 5)) * NAP * 64 + wg_at(V, r * NT + it, 2 * (S & 31) + h)] = 1.0f;
+}
+// one thread per (matrix, category, state): the constant column of every matrix buffer, once per instance
+__global__ void __launch_bounds__(256)
+k_wg_init_tables(float* __restrict__ matrices, size_t matrixFloats, size_t tabOffFloats, int S, int K, int total)
+{
+    const int g = blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= total) return;
+    const int i = g % S, mk = g / S;
+    wg_table_put_missing(matrices + (size_t) (mk / K) * matrixFloats + tabOffFloats + (size_t) (mk % K) * wg_table_floats(S), S, i);
+}
+
+struct WalkGArgs {
+    const Walk4Entry* prog;      // [W][entries]
+    int entries;                 // per wave: MBAMD_WG_LEAD NOPs + program, padded to a multiple of 3, + MBAMD_WG_TAIL NOPs
+    int nslots;
+    float* partials;             // arena float [tile][buffer][K] blocks of wg_block_bytes (wg_at layout)
+    unsigned long tileBytes;     // bytes between tiles
+    const uint8_t* tips;         // arena uint8 [tile][buffer][32]   state codes, S = missing
+    unsigned tipTileBytes;
+    int8_t* exps;                // arena int8 [tile / 2][scale buffer][K][64] (the 4-state path's format)
+    unsigned estride;            // bytes between 64-pattern blocks
+    const float* matrices;       // matrix buffers; entries hold the byte offset of a buffer
+    unsigned tabOff, tabBytes;   // byte offset of the table area inside a matrix buffer / bytes per category
+    int32_t* cum[MBAMD_WG_MAXLISTS];   // wide cumulative buffers int32 [K][Ppad] per merged list, or nullptr
+    int cumFresh;                // bit q: list q's cumulative buffer holds nothing yet (store, do not add)
+    int K, Ppad, ntiles, S, SP;
+};
+__host__ __device__ inline unsigned walkg_grid(int ntiles, int K) { return 8u * (unsigned) K * (unsigned) ((ntiles + 7) / 8); }
+
+#if defined(MBAMD_HOST_EMU)
+// ---- host-emulation twin (CPU CI of the host logic: arenas, programs, slots, phases): lane 0 of every wave walks the
+// program with plain loops over the 32 patterns; children come from the emulated LDS slots exactly as scheduled
+template <int SC, int WMAX, int DEPTH>
+__global__ void k_walkg(WalkGArgs A)
+{
+    const unsigned lane = threadIdx.x & 63;
+    const int wave = (int) (threadIdx.x >> 6), W = (int) (blockDim.x >> 6);
+    const int S = A.S, SP = A.SP, TP = wg_pairs_padded(S);
+    const unsigned SLOTB = wg_block_bytes(S);
+    const unsigned K = (unsigned) A.K;
+    const unsigned xcd = blockIdx.x & 7u, pos = blockIdx.x >> 3;
+    const unsigned tile = (pos / K) * 8u + xcd, k = pos % K;
+    if (tile >= (unsigned) A.ntiles) return;
+    char* lds = reinterpret_cast<char*>(mbamd_emu_dyn_lds());
+    char* const mine = lds + (size_t) wave * (MBAMD_WG_STAGE + (size_t) A.nslots * SLOTB);
+    float* const slots = reinterpret_cast<float*>(mine + MBAMD_WG_STAGE);
+    char* const P0 = reinterpret_cast<char*>(A.partials) + (size_t) tile * A.tileBytes + (size_t) k * SLOTB;
+    const uint8_t* const T0 = A.tips + (size_t) tile * A.tipTileBytes;
+    int8_t* const E0 = A.exps + (size_t) (tile >> 1) * A.estride + (size_t) k * 64 + (tile & 1u) * 32u;
+    const Walk4Entry* prog = A.prog + (size_t) wave * A.entries;
+    int cum_e[MBAMD_WG_MAXLISTS][32];
+    for (auto& row : cum_e) for (int& v : row) v = 0;
+    for (int j = 0; j < A.entries; ++j) {
+        const Walk4Entry e = prog[j];
+        if (e.ctl & MBAMD_W4_BARRIER) mbamd_emu_barrier();
+        if (lane != 0 || (e.ctl & MBAMD_W4_NOP)) continue;
+        const unsigned mode = (e.ctl >> 8) & 3u;
+        float* dst = reinterpret_cast<float*>(P0 + e.dst);
+        float res[64][32];
+        for (int c = 0; c < 32; ++c) {
+            float f[2][64];
+            for (int ch = 0; ch < 2; ++ch) {
+                const bool tip = e.ctl & (ch ? MBAMD_W4_TIP2 : MBAMD_W4_TIP1), mem = e.ctl & (ch ? MBAMD_WG_MEM2 : MBAMD_WG_MEM1);
+                const unsigned coff = ch ? e.c2 : e.c1;
+                const float* mT = reinterpret_cast<const float*>(reinterpret_cast<const char*>(A.matrices) + (ch ? e.m2 : e.m1)) + (size_t) k * SP * SP;
+                if (tip) {
+                    const unsigned s = T0[coff + c];
+                    for (int i = 0; i < S; ++i) f[ch][i] = s >= (unsigned) S ? 1.0f : mT[(size_t) s * SP + i];
+                } else {
+                    const float* cl = mem ? reinterpret_cast<const float*>(P0 + coff) : slots + coff / 4;
+                    for (int i = 0; i < S; ++i) {
+                        float acc = 0.0f;
+                        for (int jj = 0; jj < S; ++jj) acc = fmaf(mT[(size_t) jj * SP + i], cl[wg_elem(S, jj, c)], acc);
+                        f[ch][i] = acc;
+                    }
+                }
+            }
+            float mx = 0.0f;
+            for (int i = 0; i < S; ++i) { res[i][c] = f[0][i] * f[1][i]; mx = fmaxf(mx, res[i][c]); }
+            int ex = 0;
+            if (mode == SCALE_WRITE) { ex = scale_exponent(mx); cum_e[MBAMD_WG_LIST(e.ctl)][c] += ex; }
+            else if (mode == SCALE_READ) ex = E0[e.eread + c];
+            for (int i = 0; i < S; ++i) res[i][c] = scale_pow2(res[i][c], -ex);
+            E0[e.ewrite + c] = (int8_t) ex;
+        }
+        for (int i = 0; i < 2 * TP; ++i)
+            for (int c = 0; c < 32; ++c) {
+                const float v = i < S ? res[i][c] : 0.0f;
+                dst[wg_elem(S, i, c)] = v;
+                if (e.ctl & MBAMD_W4_KEEP) slots[((e.ctl >> 16) & 0xFFu) * (SLOTB / 4) + wg_elem(S, i, c)] = v;
+            }
+    }
+    // cumulative exponents: the waves' sums meet in LDS, wave 0 owns the memory update
+    for (int q = 0; q < MBAMD_WG_MAXLISTS; ++q) {
+        if (A.cum[q] == nullptr) continue;
+        int* stage = reinterpret_cast<int*>(mine);
+        if (W > 1) {
+            if (q > 0) mbamd_emu_barrier();
+            if (lane == 0) for (int c = 0; c < 32; ++c) stage[c] = cum_e[q][c];
+            mbamd_emu_barrier();
+        }
+        if (wave == 0 && lane == 0)
+            for (int c = 0; c < 32; ++c) {
+                int sum = cum_e[q][c];
+                for (int w = 1; w < W; ++w) sum += reinterpret_cast<const int*>(lds + (size_t) w * (MBAMD_WG_STAGE + (size_t) A.nslots * SLOTB))[c];
+                int32_t* d = A.cum[q] + (size_t) k * A.Ppad + (size_t) tile * 32 + c;
+                if (A.cumFresh >> q & 1) *d = sum; else *d += sum;
+            }
+    }
+}
+#else
+
+typedef float wg_f16 __attribute__((ext_vector_type(16)));
+
+template <int SC> struct WgShape {
+    static constexpr int T = (SC + 1) / 2, NT = (SC + 31) / 32, V = SC > 32 ? 4 : 2;
+    static constexpr int TP = (T + V - 1) / V * V, NAP = NT * TP;
+    typedef float vec __attribute__((ext_vector_type(V)));
+};
+template <int SC> struct WgOperands {
+    typename WgShape<SC>::vec a[WgShape<SC>::NAP / WgShape<SC>::V];   // A rows of the job (or the tip's gather rows), V rows per register group
+    typename WgShape<SC>::vec b[WgShape<SC>::TP / WgShape<SC>::V];    // B rows of a child read from HBM
+};
+struct WgDesc {
+    Walk4Entry e;
+    unsigned s1, s2;           // tip states of this lane's pattern (children 1, 2)
+};
+
+// blockDim.x = 64 * W (W <= WMAX); grid = walkg_grid(ntiles, K); dynamic LDS = wg_lds_bytes(W, nslots, SC).
+// DEPTH: jobs an operand fetch runs ahead of its consumer.  20 states: 2 (a job is 10 MFMAs = 640 cycles, less than a
+// memory round trip; three register sets rotate).  61 states: 1 (a job is 62 MFMAs = 4000 cycles; two sets of 96
+// registers are what fits beside 64 accumulators without moving loaded values between register files).
+template <int SC, int WMAX, int DEPTH>
+__global__ void __launch_bounds__(64 * WMAX)
+k_walkg(WalkGArgs A)
+{
+    typedef WgShape<SC> Sh;
+    typedef typename Sh::vec vec;
+    constexpr int T = Sh::T, NT = Sh::NT, V = Sh::V, TP = Sh::TP, NAP = Sh::NAP, NAV = NAP / V, TV = TP / V;
+    constexpr unsigned SLOTB = TP * 256u;
+    const unsigned lane = threadIdx.x & 63, half = lane >> 5, col = lane & 31;
+    const int wave = __builtin_amdgcn_readfirstlane((int) (threadIdx.x >> 6));
+    extern __shared__ float lds_walkg[];
+    const unsigned K = (unsigned) A.K;
+    const unsigned xcd = blockIdx.x & 7u, pos = blockIdx.x >> 3;
+    const unsigned tile = (pos / K) * 8u + xcd, k = pos % K;
+    if (tile >= (unsigned) A.ntiles) return;
+    char* const mine = reinterpret_cast<char*>(lds_walkg) + (size_t) wave * (MBAMD_WG_STAGE + (size_t) A.nslots * SLOTB);
+    vec* const slots = reinterpret_cast<vec*>(mine + MBAMD_WG_STAGE) + lane;          // this lane's V rows of row group 0, slot 0
+    // wave-uniform bases; the entries hold byte offsets from them
+    char* const P0 = reinterpret_cast<char*>(A.partials) + (size_t) tile * A.tileBytes + (size_t) k * SLOTB;
+    const uint8_t* const T0 = A.tips + (size_t) tile * A.tipTileBytes;
+    int8_t* const E0 = A.exps + (size_t) (tile >> 1) * A.estride + (size_t) k * 64 + (tile & 1u) * 32u;
+    const char* const Mk = reinterpret_cast<const char*>(A.matrices) + A.tabOff + (size_t) k * A.tabBytes;
+
+    const Walk4Entry* prog = A.prog + (size_t) wave * A.entries;
+    const int n = A.entries - MBAMD_WG_TAIL;
+    WgDesc DA, DB, DC;
+    DA.e = walk4_load_entry(prog); DB.e = walk4_load_entry(prog + 1); DC.e = walk4_load_entry(prog + 2);
+    DA.s1 = DA.s2 = DB.s1 = DB.s2 = DC.s1 = DC.s2 = 0;
+    WgOperands<SC> X, Y, Z;
+#pragma unroll
+    for (int i = 0; i < NAV; ++i) X.a[i] = Y.a[i] = Z.a[i] = (vec) (0.0f);
+#pragma unroll
+    for (int i = 0; i < TV; ++i) X.b[i] = Y.b[i] = Z.b[i] = (vec) (0.0f);
+    int er = 0;                                      // stored exponent of the entry about to run (SCALE_READ)
+    int cum_e[MBAMD_WG_MAXLISTS] = {0, 0, 0, 0};
+
+    // operands of one job (child `ch` of entry d) -> register set o.  Always NAV + TV loads, outside any branch.
+    auto fetch = [&](const WgDesc& d, int ch, WgOperands<SC>& o) {
+        const unsigned ctl = d.e.ctl;
+        const bool tip = ctl & (ch ? MBAMD_W4_TIP2 : MBAMD_W4_TIP1), mem = ctl & (ch ? MBAMD_WG_MEM2 : MBAMD_WG_MEM1);
+        const unsigned coff = ch ? d.e.c2 : d.e.c1, moff = ch ? d.e.m2 : d.e.m1;
+        const unsigned s = ch ? d.s2 : d.s1;
+        // a: A' (column = lane) or the tip's gather table (column = 2 * (state & 31) + half of sub-table state >> 5)
+        const unsigned aoff = tip ? (1u + (s >> 5)) * (unsigned) (NAP * 256) + ((s & 31u) * 2u + half) * (unsigned) (V * 4) : lane * (unsigned) (V * 4);
+        const MBAMD_AS_GLOBAL vec* pa = reinterpret_cast<const MBAMD_AS_GLOBAL vec*>((uintptr_t) (Mk + moff) + aoff);
+#pragma unroll
+        for (int i = 0; i < NAV; ++i) o.a[i] = pa[i * 64];
+        const char* bbase = mem ? P0 + coff : Mk;    // (not a memory child: a resident line, value unused)
+        const MBAMD_AS_GLOBAL vec* pb = reinterpret_cast<const MBAMD_AS_GLOBAL vec*>((uintptr_t) bbase) + lane;
+#pragma unroll
+        for (int i = 0; i < TV; ++i) o.b[i] = pb[i * 64];
+    };
+    // one child factor: registers (it, r) = state 32 it + 2 r + half of this lane's pattern.  No vector-memory operation in here.
+    auto factor = [&](const WgDesc& d, int ch, const WgOperands<SC>& o, wg_f16 (&f)[NT]) {
+        const unsigned ctl = d.e.ctl;
+        const bool tip = ctl & (ch ? MBAMD_W4_TIP2 : MBAMD_W4_TIP1), mem = ctl & (ch ? MBAMD_WG_MEM2 : MBAMD_WG_MEM1);
+#pragma unroll
+        for (int it = 0; it < NT; ++it)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) f[it][r] = 0.0f;
+        if (tip) {
+#pragma unroll
+            for (int it = 0; it < NT; ++it)
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    if (16 * it + r < T) f[it][r] = o.a[(r * NT + it) / V][(r * NT + it) % V];
+        } else if (mem) {
+#pragma unroll
+            for (int t = 0; t < T; ++t)
+#pragma unroll
+                for (int it = 0; it < NT; ++it)
+                    f[it] = __builtin_amdgcn_mfma_f32_32x32x2f32(o.a[(t * NT + it) / V][(t * NT + it) % V], o.b[t / V][t % V], f[it], 0, 0, 0);
+        } else {
+            const vec* sl = reinterpret_cast<const vec*>(reinterpret_cast<const char*>(slots) + (ch ? d.e.c2 : d.e.c1));
+            vec b[TV];
+#pragma unroll
+            for (int i = 0; i < TV; ++i) b[i] = sl[i * 64];
+#pragma unroll
+            for (int t = 0; t < T; ++t)
+#pragma unroll
+                for (int it = 0; it < NT; ++it)
+                    f[it] = __builtin_amdgcn_mfma_f32_32x32x2f32(o.a[(t * NT + it) / V][(t * NT + it) % V], b[t / V][t % V], f[it], 0, 0, 0);
+        }
+    };
+
+    // One iteration = one entry `cur` (jobs on register sets S0, S1); fetches the operands of entry `n1` into (S2, S0)
+    // (DEPTH 1: of cur's second child into S1 and n1's first child into S0), the tip states of entry `n2`, and replaces
+    // cur's descriptor by entry j + 3.  Vector-memory sequence, identical on
+    // every path:  1 exponent load | 2 state loads | NAV + TV operand loads | NAV + TV operand loads | TV + 1 stores
+    auto step = [&](WgDesc& cur, const WgDesc& n1, WgDesc& n2, WgOperands<SC>& S0, WgOperands<SC>& S1, WgOperands<SC>& S2, int j) {
+        const unsigned ctl = cur.e.ctl;
+        if (ctl & MBAMD_W4_BARRIER) {
+            // values other waves produced in the previous phase are read from here on: drain this wave's stores, meet
+            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+        }
+        const bool run = !(ctl & MBAMD_W4_NOP);
+        const unsigned mode = (ctl >> 8) & 3u;
+        // (issued before the operand fetches: what the next entry needs first must not queue behind them)
+        const int er_next = as_global(E0 + n1.e.eread)[col];
+        n2.s1 = as_global(T0 + ((n2.e.ctl & MBAMD_W4_TIP1) ? n2.e.c1 : 0u))[col];
+        n2.s2 = as_global(T0 + ((n2.e.ctl & MBAMD_W4_TIP2) ? n2.e.c2 : 0u))[col];
+        wg_f16 f1[NT], f2[NT];
+        if (DEPTH == 2) {
+            fetch(n1, 0, S2);
+            if (run) factor(cur, 0, S0, f1);
+            fetch(n1, 1, S0);
+            if (run) factor(cur, 1, S1, f2);
+        } else {
+            fetch(cur, 1, S1);
+            if (run) factor(cur, 0, S0, f1);
+            fetch(n1, 0, S0);
+            if (run) factor(cur, 1, S1, f2);
+        }
+        const unsigned dst = cur.e.dst, ewrite = cur.e.ewrite;
+        cur.e = walk4_load_entry(prog + j + 3);
+        float out[TP];
+        float mx = 0.0f;
+#pragma unroll
+        for (int t = 0; t < TP; ++t) {
+            out[t] = (run && t < T) ? f1[t >> 4][t & 15] * f2[t >> 4][t & 15] : 0.0f;
+            mx = fmaxf(mx, out[t]);
+        }
+        mx = fmaxf(mx, __shfl_xor(mx, 32));
+        const int wm = mode == SCALE_WRITE ? -1 : 0, rm = mode == SCALE_READ ? -1 : 0;
+        const int e = (scale_exponent(mx) & wm) | (er & rm);
+        er = er_next;
+        const unsigned list = MBAMD_WG_LIST(ctl);
+#pragma unroll
+        for (int q = 0; q < MBAMD_WG_MAXLISTS; ++q) cum_e[q] += (list == (unsigned) q) ? (e & wm) : 0;
+        vec ov[TV];
+#pragma unroll
+        for (int t = 0; t < TP; ++t) ov[t / V][t % V] = scale_pow2(out[t], -e);   // (2^0 is exact: no branch)
+        if (ctl & MBAMD_W4_KEEP) {
+            vec* keep = reinterpret_cast<vec*>(reinterpret_cast<char*>(slots) + ((ctl >> 16) & 0xFFu) * SLOTB);
+#pragma unroll
+            for (int i = 0; i < TV; ++i) keep[i * 64] = ov[i];
+        }
+        MBAMD_AS_GLOBAL vec* pd = reinterpret_cast<MBAMD_AS_GLOBAL vec*>((uintptr_t) (P0 + dst)) + lane;
+#pragma unroll
+        for (int i = 0; i < TV; ++i) __builtin_nontemporal_store(ov[i], pd + i * 64);   // 64 * V * 4 contiguous bytes per instruction
+        if (half == 0) __builtin_nontemporal_store((int8_t) e, as_global(E0 + ewrite) + col);
+    };
+    for (int j = 0; j < n; j += 3) {
+        if (DEPTH == 2) {
+            step(DA, DB, DC, X, Y, Z, j);
+            step(DB, DC, DA, Z, X, Y, j + 1);
+            step(DC, DA, DB, Y, Z, X, j + 2);
+        } else {
+            step(DA, DB, DC, X, Y, Z, j);
+            step(DB, DC, DA, X, Y, Z, j + 1);
+            step(DC, DA, DB, X, Y, Z, j + 2);
+        }
+    }
+    // cumulative exponents of this workgroup's 32 columns: the waves' sums meet in LDS, wave 0 owns the memory update
+    const int W = (int) (blockDim.x >> 6);
+    int* const stage = reinterpret_cast<int*>(mine);
+#pragma unroll
+    for (int q = 0; q < MBAMD_WG_MAXLISTS; ++q) {
+        if (A.cum[q] == nullptr) continue;
+        int sum = cum_e[q];
+        if (W > 1) {
+            if (q > 0) __syncthreads();
+            stage[lane] = sum;
+            __syncthreads();
+            if (wave == 0)
+                for (int w = 1; w < W; ++w)
+                    sum += reinterpret_cast<const int*>(reinterpret_cast<const char*>(lds_walkg) + (size_t) w * (MBAMD_WG_STAGE + (size_t) A.nslots * SLOTB))[lane];
+        }
+        if (wave == 0 && half == 0) {
+            int32_t* d = A.cum[q] + (size_t) k * A.Ppad + (size_t) tile * 32 + col;
+            if (A.cumFresh >> q & 1) *d = sum;
+            else if (sum != 0) *d += sum;
+        }
+    }
+}
+#endif
+
+}  // namespace mbamd
+#endif
