@@ -108,6 +108,7 @@ struct Plan {
     size_t cap = 0;                  // bytes allocated for d_table
     struct Segment { size_t first; int W, entries, nslots; };   // tree-walk path: one launch per hazard-free segment
     std::vector<Segment> segments;               // (Walk4Entry index of its program in d_table, geometry)
+    int lists = 1;                               // 20/61-state walk: > 1 = the segments are that many independent lists, ONE launch
     std::vector<int> start;                      // general path: first table entry of each dependency level
     bool anyScale = false;
     bool narrow = false;                         // general path: few operations per level -> one serial launch
@@ -339,6 +340,7 @@ struct Instance {
     void destroy();
 
     int configureWalk();
+    void wgGeometry(int lists, int& W, int& slots) const;
     int setTipStates(int tip, const int* states);
     int setTipMasks(int tip, const std::vector<uint8_t>& masks);
     int importPartials(int idx, const double* in, bool hasCategories);
@@ -350,7 +352,7 @@ struct Instance {
     int getMatrix(int idx, double* out);
     int updatePartials(const BeagleOperation* ops, int n, int cumIdx);
     int updatePartials4(const BeagleOperation* ops, int n, int cumIdx);
-    int buildWalk(Plan& plan, const BeagleOperation* ops, int n, const int* listOf = nullptr);
+    int buildWalk(Plan& plan, const BeagleOperation* ops, int n, const int* listOf = nullptr, bool perList = false);
     int ensureWide(int idx);
     int accumulate4(const int* idx, int n, int cumIdx, int sign);
     int integrate4(const int* parent, const int* child, const int* prob, const int* wIdx, const int* fIdx,
@@ -612,33 +614,26 @@ int Instance::configureWalk()
         (void) hipGetLastError();
 #endif
     if (wg) {
-        // one wave = (32-pattern tile, category); registers bound the residency: 20 states ~3 waves per SIMD, 61 states 1
-        const int maxW = S == 61 ? 4 : 8, wavesPerCU = S == 61 ? 4 : 12;
+        // one wave = (32-pattern tile, category); registers bound the residency: 20 states 4 waves per SIMD, 61 states 2
         const unsigned slotBytes = wg_block_bytes(S);
 #if !defined(MBAMD_HOST_EMU)
-        hipError_t aerr = S == 61 ? hipFuncSetAttribute((const void*) k_walkg<61, 4, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, maxLds)
-                                  : hipFuncSetAttribute((const void*) k_walkg<20, 8, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, maxLds);
+        hipError_t aerr = S == 61 ? hipFuncSetAttribute((const void*) k_walkg<61, 4, 2, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, maxLds)
+                                  : hipFuncSetAttribute((const void*) k_walkg<20, 8, 1, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, maxLds);
         if (aerr != hipSuccess) (void) hipGetLastError();
 #endif
-        const long wgsG = (long) (Ppad / 32) * K;
-        const int perCUG = (int) std::max(1L, (wgsG + numCU - 1) / numCU);
-        const int ldsPerWGG = (160 * 1024) / std::min(perCUG, 32) - 64;
-        auto slotsForG = [&](int W) { return (int) ((ldsPerWGG / W - MBAMD_WG_STAGE) / (int) slotBytes); };
-        int W = (int) std::max(1L, std::min((long) maxW, ((long) wavesPerCU * numCU + wgsG / 2) / wgsG));
-        while (W > 1 && slotsForG(W) < 4) --W;
-        if (const char* e = std::getenv("MBAMD_WALK_WAVES")) W = std::max(1, std::min(maxW, std::atoi(e)));
-        int slots = std::max(3, std::min(24, slotsForG(W)));
-        if (const char* e = std::getenv("MBAMD_MAX_LDS_SLOTS")) slots = std::max(3, std::min((int) ((160 * 1024 / W - MBAMD_WG_STAGE) / slotBytes), std::atoi(e)));
-        w4.maxW = W;
-        w4.maxSlots = slots;
-        w4.maxSlots1 = std::max(slots, std::min(24, slotsForG(1)));
-        if (std::getenv("MBAMD_MAX_LDS_SLOTS")) w4.maxSlots1 = slots;
+        wgGeometry(1, w4.maxW, w4.maxSlots);
+        w4.maxSlots1 = w4.maxSlots;
+        if (!std::getenv("MBAMD_WALK_WAVES") && !std::getenv("MBAMD_MAX_LDS_SLOTS")) {   // a single-wave program may use the LDS of the whole workgroup
+            const long wgsG = (long) (Ppad / 32) * K;
+            const int perCUG = (int) std::max(1L, (wgsG + numCU - 1) / numCU);
+            w4.maxSlots1 = std::max(w4.maxSlots, std::min(24, (int) (((160 * 1024) / std::min(perCUG, 32) - 64 - MBAMD_WG_STAGE) / (int) slotBytes)));
+        }
         w4.memSlots = false;
         w4.leadNops = MBAMD_WG_LEAD; w4.unroll = 3; w4.tailNops = MBAMD_WG_TAIL;
         w4.prefetchDistance = 0;
         if (const char* e = std::getenv("MBAMD_WALK_SMALL_PHASE")) w4.smallPhase = std::max(1, std::atoi(e));
-        if (envVerbose) std::fprintf(stderr, "[mbamd] tree walk (%d states): %ld workgroups (%d per CU), up to %d waves x %d slots of %u bytes\n",
-                                     S, wgsG, perCUG, W, slots, slotBytes);
+        if (envVerbose) std::fprintf(stderr, "[mbamd] tree walk (%d states): %ld workgroups, up to %d waves x %d slots of %u bytes\n",
+                                     S, (long) (Ppad / 32) * K, w4.maxW, w4.maxSlots, slotBytes);
         return BEAGLE_SUCCESS;
     }
     const long wgs = (long) (Ppad / 64) * K;
@@ -661,6 +656,31 @@ int Instance::configureWalk()
     if (const char* e = std::getenv("MBAMD_WALK_SMALL_PHASE")) w4.smallPhase = std::max(1, std::atoi(e));
     if (envVerbose) std::fprintf(stderr, "[mbamd] tree walk: %ld workgroups (%d per CU), up to %d waves x %d slots\n", wgs, perCU, W, slots);
     return BEAGLE_SUCCESS;
+}
+
+// 20/61-state walk: waves per workgroup and LDS slots per wave for (tiles x categories x lists) workgroups.  Waves per
+// workgroup are a power of two (two-wave workgroups are launched as four, see k_walkg; three or five leave SIMDs idle).
+void Instance::wgGeometry(int lists, int& W, int& slots) const
+{
+    int numCU = 256;
+#if !defined(MBAMD_HOST_EMU)
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0) numCU = prop.multiProcessorCount;
+#endif
+    // registers bound the residency: 20 states 4 waves per SIMD, 61 states 2
+    const int maxW = S == 61 ? 4 : 8, wavesPerCU = S == 61 ? 6 : 12;
+    const int slotBytes = (int) wg_block_bytes(S);
+    const long wgs = (long) (Ppad / 32) * K * lists;
+    const int perCU = (int) std::max(1L, (wgs + numCU - 1) / numCU);
+    const int ldsPerWG = (160 * 1024) / std::min(perCU, 32) - 64;
+    auto slotsFor = [&](int w) { return (ldsPerWG / w - MBAMD_WG_STAGE) / slotBytes; };
+    long want = std::max(1L, std::min((long) maxW, ((long) wavesPerCU * numCU + wgs / 2) / wgs));
+    W = 1;
+    while (W * 2 <= want) W *= 2;
+    while (W > 1 && slotsFor(W) < 4) W /= 2;
+    if (const char* e = std::getenv("MBAMD_WALK_WAVES")) W = std::max(1, std::min(maxW, std::atoi(e)));
+    slots = std::max(3, std::min(24, slotsFor(W)));
+    if (const char* e = std::getenv("MBAMD_MAX_LDS_SLOTS")) slots = std::max(3, std::min((160 * 1024 / W - MBAMD_WG_STAGE) / slotBytes, std::atoi(e)));
 }
 
 // 4-state path: one tip's state masks (bit i = state i compatible) -> four 64-bit bitplanes per pattern block
@@ -1331,7 +1351,7 @@ int Instance::updatePartials4(const BeagleOperation* ops, int n, int cumIdx)
 
 // Compile one operation list: validate, cut into hazard-free segments, build (or re-use) the structural template of
 // each segment and fill it with this list's buffer / matrix / scale indices.
-int Instance::buildWalk(Plan& plan, const BeagleOperation* ops, int n, const int* listOf)
+int Instance::buildWalk(Plan& plan, const BeagleOperation* ops, int n, const int* listOf, bool perList)
 {
     const int scratchScale = (int) scale.size();              // sink / source of entries that do not rescale
     std::vector<int> segList;                                  // (20/61-state walk) merged-list index of each operation of the segment
@@ -1493,6 +1513,7 @@ int Instance::buildWalk(Plan& plan, const BeagleOperation* ops, int n, const int
         // hazards that the in-launch dependency analysis does not cover end the segment (MrBayes never produces them):
         // a buffer written twice or written after it was read, an exponent buffer touched twice unless only read
         bool hazard = segWritten[w.dst] || segRead[w.dst];
+        if (perList && o > 0 && listOf[o] != listOf[o - 1]) hazard = true;       // (independent lists: one program set each)
         if (w.scaleWrite >= 0 && segScale[w.scaleWrite]) hazard = true;
         if (w.scaleRead >= 0 && segScale[w.scaleRead] == 2) hazard = true;
         if (hazard) {
@@ -1647,10 +1668,56 @@ int Instance::flushWalkG()
         plan->key = key;
         plan->hash = h;
         plan->lastUse = ++planClock;
+        // Mutually independent lists (the eigen-system parts of a codon model) run as separate workgroups of ONE launch --
+        // three times the workgroups for a grid that does not fill the chip otherwise -- if they compile to the same geometry;
+        // anything else is one merged forest.
+        bool independent = nl > 1;
+        if (independent) {
+            std::vector<int> wr(nBuffers, -1), rd(nBuffers, -1);
+            std::vector<int> sc(scale.size(), -1);
+            for (int o = 0; o < n && independent; ++o) {
+                const BeagleOperation& b = ops[o];
+                const int q = listOf[o];
+                auto clash = [&](std::vector<int>& v, int i) { if (i < 0 || i >= (int) v.size()) return false; if (v[i] >= 0 && v[i] != q) return true; v[i] = q; return false; };
+                if (clash(wr, b.destinationPartials) || (b.destinationPartials >= 0 && b.destinationPartials < nBuffers && rd[b.destinationPartials] >= 0 && rd[b.destinationPartials] != q)) independent = false;
+                for (int c : {b.child1Partials, b.child2Partials})
+                    if (c >= 0 && c < nBuffers && !(tipStates[c] && wr[c] < 0)) {
+                        if (wr[c] >= 0 && wr[c] != q) independent = false;
+                        if (rd[c] < 0) rd[c] = q; else if (rd[c] != q) rd[c] = 1 << 20;      // (read by several lists: fine unless one writes it)
+                    }
+                if (b.destinationScaleWrite != BEAGLE_OP_NONE && clash(sc, b.destinationScaleWrite)) independent = false;
+                if (b.destinationScaleRead != BEAGLE_OP_NONE && b.destinationScaleRead >= 0 && b.destinationScaleRead < (int) sc.size() &&
+                    sc[b.destinationScaleRead] >= 0 && sc[b.destinationScaleRead] != q) independent = false;
+            }
+            for (int o = 0; o < n && independent; ++o)                  // a buffer one list writes must not be read by another
+                for (int c : {ops[o].child1Partials, ops[o].child2Partials})
+                    if (c >= 0 && c < nBuffers && wr[c] >= 0 && wr[c] != listOf[o]) independent = false;
+        }
         int rc;
         {
             StatTimer st_(ST_PLAN);
-            rc = buildWalk(*plan, ops.data(), n, listOf.data());
+            plan->lists = 1;
+            rc = BEAGLE_SUCCESS;
+            bool done = false;
+            if (independent) {
+                const int keepW = w4.maxW, keepS = w4.maxSlots, keepS1 = w4.maxSlots1;
+                wgGeometry(nl, w4.maxW, w4.maxSlots);
+                w4.maxSlots1 = w4.maxSlots;
+                rc = buildWalk(*plan, ops.data(), n, listOf.data(), true);
+                w4.maxW = keepW; w4.maxSlots = keepS; w4.maxSlots1 = keepS1;
+                bool same = rc == BEAGLE_SUCCESS && (int) plan->segments.size() == nl;
+                for (size_t i = 1; same && i < plan->segments.size(); ++i)
+                    same = plan->segments[i].W == plan->segments[0].W && plan->segments[i].entries == plan->segments[0].entries &&
+                           plan->segments[i].first == plan->segments[0].first + i * (size_t) plan->segments[0].W * plan->segments[0].entries;
+                if (same) {
+                    int ns = 0;
+                    for (const Plan::Segment& sg : plan->segments) ns = std::max(ns, sg.nslots);
+                    for (Plan::Segment& sg : plan->segments) sg.nslots = ns;
+                    plan->lists = nl;
+                    done = true;
+                }
+            }
+            if (!done) rc = buildWalk(*plan, ops.data(), n, listOf.data(), false);
         }
         if (rc) { plan->hash = 0; plan->key.clear(); return rc; }
     }
@@ -1661,16 +1728,17 @@ int Instance::flushWalkG()
     return timedRun(*plan, nullptr);
 }
 
-template <int SC_, int WMAX_, int DEPTH_>
+template <int SC_, int WMAX_, int CH_, int DEPTH_>
 static void launch_walkg_t(Instance& in, const WalkGArgs& a, int W, int nslots)
 {
-    auto kern = k_walkg<SC_, WMAX_, DEPTH_>;
-    MBAMD_LAUNCH_BARRIER(kern, walkg_grid(in.Ppad / 32, in.K), 64 * W, wg_lds_bytes(W, nslots, in.S), in.stream, a);
+    auto kern = k_walkg<SC_, WMAX_, CH_, DEPTH_>;
+    MBAMD_LAUNCH_BARRIER(kern, walkg_grid(in.Ppad / 32, in.K * a.lists), 64 * W * (a.spread ? 2 : 1), wg_lds_bytes(W, nslots, in.S), in.stream, a);
 }
 
 int Instance::runWalkG(const Plan& plan)
 {
     for (const Plan::Segment& sg : plan.segments) {
+        if (plan.lists > 1 && &sg != &plan.segments.front()) break;     // (independent lists: one launch covers all segments)
         WalkGArgs a;
         std::memset(&a, 0, sizeof a);
         a.prog = reinterpret_cast<const Walk4Entry*>(plan.d_table) + sg.first;
@@ -1688,8 +1756,20 @@ int Instance::runWalkG(const Plan& plan)
         for (int q = 0; q < MBAMD_WG_MAXLISTS; ++q) a.cum[q] = wgCum[q];
         a.cumFresh = (&sg == &plan.segments.front()) ? wgFresh : 0;
         a.K = K; a.Ppad = Ppad; a.ntiles = Ppad / 32; a.S = S; a.SP = SP;
-        if (S == 61) launch_walkg_t<61, 4, 1>(*this, a, sg.W, sg.nslots);
-        else launch_walkg_t<20, 8, 2>(*this, a, sg.W, sg.nslots);
+        a.lists = plan.lists;
+#if !defined(MBAMD_HOST_EMU)
+        a.spread = sg.W == 2 ? 1 : 0;
+#endif
+        if (envTrace && !d_trace) {
+            if (hipMalloc(&d_trace, (size_t) 4096 * 8 * 3 * sizeof(long long)) != hipSuccess) d_trace = nullptr;
+        }
+        if (d_trace) {
+            (void) hipMemsetAsync(d_trace, 0, (size_t) 4096 * 8 * 3 * sizeof(long long), stream);
+            a.trace = sg.entries <= 4096 ? d_trace : nullptr;
+            lastWalkSteps = sg.entries - MBAMD_WG_TAIL; walkWaves = sg.W - 1;
+        }
+        if (S == 61) launch_walkg_t<61, 4, 2, 1>(*this, a, sg.W, sg.nslots);
+        else launch_walkg_t<20, 8, 1, 2>(*this, a, sg.W, sg.nslots);
         HIP_TRY(hipGetLastError());
         pendingLaunches += 1;
     }

@@ -19,10 +19,13 @@
 // exchange, no barrier per operation (the level kernels of mbamd_kernels_mfma.h spend three).  A compact tip needs no
 // MFMA: its factor is a gather from a second table laid out for the same registers.
 //
-// Pipelining.  All vector-memory operations are compiler-visible (the waitcnt pass counts them), and their number per
-// entry is THE SAME on every path (dummy loads hit L1, NOP entries store zeros to a scratch buffer): vmcnt retires in order
-// and is shared by loads and stores, so only with a uniform sequence can the compiler wait for "the operands issued two
-// jobs ago" without also waiting for the stores issued since.  A job = one child factor.  While job u computes, the
+// Pipelining.  All vector-memory operations are compiler-visible (the waitcnt pass counts them), and the operand loads and
+// result stores of an entry are THE SAME NUMBER on every path (NOP entries store zeros to a scratch buffer, the loads sit
+// outside every branch): vmcnt retires in order and is shared by loads and stores, so only with a uniform sequence can the
+// compiler wait for "the operands issued two jobs ago" without also waiting for the stores issued since -- one conditional
+// instruction (even an exec-masked byte store) makes every such wait one instruction stricter, and that instruction is the
+// oldest store of the previous entry.  Only the rows of a child that lives in HBM are loaded conditionally (rare in a full
+// evaluation; unconditional dummies had the kernel bound by the 64 bytes per clock of the vector L1, measured).  A job = one child factor.  While job u computes, the
 // operands of job u+2 are fetched into the third of three register sets: the A rows (or the tip's gather rows) and, for
 // a child that lives in HBM (result of an earlier launch, of another wave, or evicted), its B rows.  Tip states are
 // fetched one entry earlier still, entry descriptors three entries ahead through the scalar cache.
@@ -103,22 +106,25 @@ struct WalkGArgs {
     int32_t* cum[MBAMD_WG_MAXLISTS];   // wide cumulative buffers int32 [K][Ppad] per merged list, or nullptr
     int cumFresh;                // bit q: list q's cumulative buffer holds nothing yet (store, do not add)
     int K, Ppad, ntiles, S, SP;
+    int lists;                   // > 1: mutually independent lists run as separate workgroups (programs [list][W][entries]); else 1
+    int spread;                  // 1: the workgroup is launched with 2 W waves and only the even ones work (see k_walkg)
+    long long* trace;            // MBAMD_WALK_TRACE: clock stamps [entry][8 waves][3] of one workgroup (timing experiments), or nullptr
 };
-__host__ __device__ inline unsigned walkg_grid(int ntiles, int K) { return 8u * (unsigned) K * (unsigned) ((ntiles + 7) / 8); }
+__host__ __device__ inline unsigned walkg_grid(int ntiles, int KL) { return 8u * (unsigned) KL * (unsigned) ((ntiles + 7) / 8); }   // KL = categories x lists
 
 #if defined(MBAMD_HOST_EMU)
 // ---- host-emulation twin (CPU CI of the host logic: arenas, programs, slots, phases): lane 0 of every wave walks the
 // program with plain loops over the 32 patterns; children come from the emulated LDS slots exactly as scheduled
-template <int SC, int WMAX, int DEPTH>
+template <int SC, int WMAX, int CH, int DEPTH>
 __global__ void k_walkg(WalkGArgs A)
 {
     const unsigned lane = threadIdx.x & 63;
     const int wave = (int) (threadIdx.x >> 6), W = (int) (blockDim.x >> 6);
     const int S = A.S, SP = A.SP, TP = wg_pairs_padded(S);
     const unsigned SLOTB = wg_block_bytes(S);
-    const unsigned K = (unsigned) A.K;
+    const unsigned K = (unsigned) A.K, KL = K * (unsigned) A.lists;
     const unsigned xcd = blockIdx.x & 7u, pos = blockIdx.x >> 3;
-    const unsigned tile = (pos / K) * 8u + xcd, k = pos % K;
+    const unsigned tile = (pos / KL) * 8u + xcd, k = (pos % KL) % K, list = (pos % KL) / K;
     if (tile >= (unsigned) A.ntiles) return;
     char* lds = reinterpret_cast<char*>(mbamd_emu_dyn_lds());
     char* const mine = lds + (size_t) wave * (MBAMD_WG_STAGE + (size_t) A.nslots * SLOTB);
@@ -126,7 +132,7 @@ __global__ void k_walkg(WalkGArgs A)
     char* const P0 = reinterpret_cast<char*>(A.partials) + (size_t) tile * A.tileBytes + (size_t) k * SLOTB;
     const uint8_t* const T0 = A.tips + (size_t) tile * A.tipTileBytes;
     int8_t* const E0 = A.exps + (size_t) (tile >> 1) * A.estride + (size_t) k * 64 + (tile & 1u) * 32u;
-    const Walk4Entry* prog = A.prog + (size_t) wave * A.entries;
+    const Walk4Entry* prog = A.prog + ((size_t) list * W + wave) * A.entries;
     int cum_e[MBAMD_WG_MAXLISTS][32];
     for (auto& row : cum_e) for (int& v : row) v = 0;
     for (int j = 0; j < A.entries; ++j) {
@@ -171,7 +177,7 @@ __global__ void k_walkg(WalkGArgs A)
     }
     // cumulative exponents: the waves' sums meet in LDS, wave 0 owns the memory update
     for (int q = 0; q < MBAMD_WG_MAXLISTS; ++q) {
-        if (A.cum[q] == nullptr) continue;
+        if (A.cum[q] == nullptr || (A.lists > 1 && q != (int) list)) continue;
         int* stage = reinterpret_cast<int*>(mine);
         if (W > 1) {
             if (q > 0) mbamd_emu_barrier();
@@ -196,33 +202,56 @@ template <int SC> struct WgShape {
     static constexpr int TP = (T + V - 1) / V * V, NAP = NT * TP;
     typedef float vec __attribute__((ext_vector_type(V)));
 };
-template <int SC> struct WgOperands {
-    typename WgShape<SC>::vec a[WgShape<SC>::NAP / WgShape<SC>::V];   // A rows of the job (or the tip's gather rows), V rows per register group
-    typename WgShape<SC>::vec b[WgShape<SC>::TP / WgShape<SC>::V];    // B rows of a child read from HBM
+// one CHUNK of a job's operands: a job (one child factor) is CH chunks of T / CH MFMA steps
+template <int SC, int CH> struct WgOperands {
+    typename WgShape<SC>::vec a[WgShape<SC>::NAP / WgShape<SC>::V / CH];   // A rows of the chunk (or the tip's gather rows), V rows per register group
+    typename WgShape<SC>::vec b[WgShape<SC>::TP / WgShape<SC>::V / CH];    // B rows of a child read from HBM
 };
 struct WgDesc {
     Walk4Entry e;
     unsigned s1, s2;           // tip states of this lane's pattern (children 1, 2)
 };
+template <int I, class O> __device__ __forceinline__ O& wg_pick(O& a, O& b, O& c)
+{
+    if constexpr (I == 0) return a;
+    else if constexpr (I == 1) return b;
+    else return c;
+}
+template <int I> struct WgInt { static constexpr int value = I; };
 
 // blockDim.x = 64 * W (W <= WMAX); grid = walkg_grid(ntiles, K); dynamic LDS = wg_lds_bytes(W, nslots, SC).
-// DEPTH: jobs an operand fetch runs ahead of its consumer.  20 states: 2 (a job is 10 MFMAs = 640 cycles, less than a
-// memory round trip; three register sets rotate).  61 states: 1 (a job is 62 MFMAs = 4000 cycles; two sets of 96
-// registers are what fits beside 64 accumulators without moving loaded values between register files).
-template <int SC, int WMAX, int DEPTH>
+// The operand pipeline works in CHUNKS: a job (one child factor, T MFMA steps per row tile) is CH chunks, an entry 2 CH,
+// and the operands of a chunk are fetched DEPTH chunks ahead into one of DEPTH + 1 rotating register sets.
+//   20 states: CH 1, DEPTH 2 -- a job is 10 MFMAs = 640 cycles, less than a memory round trip; three sets of 15 registers;
+//   61 states: CH 2, DEPTH 1 -- a chunk is 31 MFMAs = 2000 cycles; two sets of 48 registers fit beside the 64 accumulators
+//              (whole jobs did not: the allocator shuttled LOADED operands through AccVGPRs, a vmcnt(0) per job).
+template <int SC, int WMAX, int CH, int DEPTH>
 __global__ void __launch_bounds__(64 * WMAX)
 k_walkg(WalkGArgs A)
 {
     typedef WgShape<SC> Sh;
     typedef typename Sh::vec vec;
+    typedef WgOperands<SC, CH> Ops;
     constexpr int T = Sh::T, NT = Sh::NT, V = Sh::V, TP = Sh::TP, NAP = Sh::NAP, NAV = NAP / V, TV = TP / V;
+    constexpr int TPC = TP / CH, NAVC = NAV / CH, TVC = TV / CH;      // per chunk: MFMA steps, A register groups, B register groups
+    constexpr int NQ = 2 * CH, NS = DEPTH + 1;                        // chunks per entry, register sets
+    static_assert(TP % CH == 0 && TPC % V == 0 && NS <= 3 && DEPTH <= NQ && TPC <= 16, "chunk geometry");
     constexpr unsigned SLOTB = TP * 256u;
     const unsigned lane = threadIdx.x & 63, half = lane >> 5, col = lane & 31;
-    const int wave = __builtin_amdgcn_readfirstlane((int) (threadIdx.x >> 6));
+    int wave = __builtin_amdgcn_readfirstlane((int) (threadIdx.x >> 6));
+    int W = (int) (blockDim.x >> 6);
+    // Two-wave workgroups land on one SIMD pair of the CU and leave the other pair's matrix cores idle (measured: 73 against
+    // 140 TFLOP/s of dense MFMA with waves {0, 1} against {0, 2} of a four-wave workgroup): such workgroups are launched
+    // with twice the waves, and the odd ones leave at once.
+    if (A.spread) {
+        if (wave & 1) return;
+        wave >>= 1;
+        W >>= 1;
+    }
     extern __shared__ float lds_walkg[];
-    const unsigned K = (unsigned) A.K;
+    const unsigned K = (unsigned) A.K, KL = K * (unsigned) A.lists;
     const unsigned xcd = blockIdx.x & 7u, pos = blockIdx.x >> 3;
-    const unsigned tile = (pos / K) * 8u + xcd, k = pos % K;
+    const unsigned tile = (pos / KL) * 8u + xcd, k = (pos % KL) % K, list = (pos % KL) / K;
     if (tile >= (unsigned) A.ntiles) return;
     char* const mine = reinterpret_cast<char*>(lds_walkg) + (size_t) wave * (MBAMD_WG_STAGE + (size_t) A.nslots * SLOTB);
     vec* const slots = reinterpret_cast<vec*>(mine + MBAMD_WG_STAGE) + lane;          // this lane's V rows of row group 0, slot 0
@@ -232,74 +261,110 @@ k_walkg(WalkGArgs A)
     int8_t* const E0 = A.exps + (size_t) (tile >> 1) * A.estride + (size_t) k * 64 + (tile & 1u) * 32u;
     const char* const Mk = reinterpret_cast<const char*>(A.matrices) + A.tabOff + (size_t) k * A.tabBytes;
 
-    const Walk4Entry* prog = A.prog + (size_t) wave * A.entries;
+    const Walk4Entry* prog = A.prog + ((size_t) list * W + wave) * A.entries;
     const int n = A.entries - MBAMD_WG_TAIL;
+#if defined(MBAMD_WGX_STAGGER)
+    // Waves of different tiles run the SAME program: left alone they march in lockstep -- all waves of a SIMD in their MFMA
+    // chains at once, then all in their epilogues with the matrix pipe idle.  A start offset per workgroup persists.
+    for (unsigned d = ((blockIdx.x >> 3) * 2654435761u >> 16) % MBAMD_WGX_STAGGER; d > 0; --d) __builtin_amdgcn_s_sleep(8);
+#endif
     WgDesc DA, DB, DC;
     DA.e = walk4_load_entry(prog); DB.e = walk4_load_entry(prog + 1); DC.e = walk4_load_entry(prog + 2);
     DA.s1 = DA.s2 = DB.s1 = DB.s2 = DC.s1 = DC.s2 = 0;
-    WgOperands<SC> X, Y, Z;
+    Ops X, Y, Z;
 #pragma unroll
-    for (int i = 0; i < NAV; ++i) X.a[i] = Y.a[i] = Z.a[i] = (vec) (0.0f);
+    for (int i = 0; i < NAVC; ++i) X.a[i] = Y.a[i] = Z.a[i] = (vec) (0.0f);
 #pragma unroll
-    for (int i = 0; i < TV; ++i) X.b[i] = Y.b[i] = Z.b[i] = (vec) (0.0f);
+    for (int i = 0; i < TVC; ++i) X.b[i] = Y.b[i] = Z.b[i] = (vec) (0.0f);
     int er = 0;                                      // stored exponent of the entry about to run (SCALE_READ)
     int cum_e[MBAMD_WG_MAXLISTS] = {0, 0, 0, 0};
 
-    // operands of one job (child `ch` of entry d) -> register set o.  Always NAV + TV loads, outside any branch.
-    auto fetch = [&](const WgDesc& d, int ch, WgOperands<SC>& o) {
+    // operands of chunk q (child q / CH, part q % CH) of entry d -> register set o: NAVC loads outside any branch
+    // (+ TVC for a child that lives in HBM)
+    auto fetch = [&](const WgDesc& d, int q, Ops& o) {
+        const int ch = q / CH, h = q % CH;
         const unsigned ctl = d.e.ctl;
         const bool tip = ctl & (ch ? MBAMD_W4_TIP2 : MBAMD_W4_TIP1), mem = ctl & (ch ? MBAMD_WG_MEM2 : MBAMD_WG_MEM1);
         const unsigned coff = ch ? d.e.c2 : d.e.c1, moff = ch ? d.e.m2 : d.e.m1;
         const unsigned s = ch ? d.s2 : d.s1;
         // a: A' (column = lane) or the tip's gather table (column = 2 * (state & 31) + half of sub-table state >> 5)
         const unsigned aoff = tip ? (1u + (s >> 5)) * (unsigned) (NAP * 256) + ((s & 31u) * 2u + half) * (unsigned) (V * 4) : lane * (unsigned) (V * 4);
-        const MBAMD_AS_GLOBAL vec* pa = reinterpret_cast<const MBAMD_AS_GLOBAL vec*>((uintptr_t) (Mk + moff) + aoff);
+        const MBAMD_AS_GLOBAL vec* pa = reinterpret_cast<const MBAMD_AS_GLOBAL vec*>((uintptr_t) (Mk + moff) + aoff) + h * NAVC * 64;
+#if !defined(MBAMD_WGX_NOFETCH)
 #pragma unroll
-        for (int i = 0; i < NAV; ++i) o.a[i] = pa[i * 64];
-        const char* bbase = mem ? P0 + coff : Mk;    // (not a memory child: a resident line, value unused)
-        const MBAMD_AS_GLOBAL vec* pb = reinterpret_cast<const MBAMD_AS_GLOBAL vec*>((uintptr_t) bbase) + lane;
+        for (int i = 0; i < NAVC; ++i) o.a[i] = pa[i * 64];
+#else
+        (void) pa;
+#endif
+        if (mem) {
+            const MBAMD_AS_GLOBAL vec* pb = reinterpret_cast<const MBAMD_AS_GLOBAL vec*>((uintptr_t) (P0 + coff)) + lane + h * TVC * 64;
 #pragma unroll
-        for (int i = 0; i < TV; ++i) o.b[i] = pb[i * 64];
+            for (int i = 0; i < TVC; ++i) o.b[i] = pb[i * 64];
+        }
     };
-    // one child factor: registers (it, r) = state 32 it + 2 r + half of this lane's pattern.  No vector-memory operation in here.
-    auto factor = [&](const WgDesc& d, int ch, const WgOperands<SC>& o, wg_f16 (&f)[NT]) {
-        const unsigned ctl = d.e.ctl;
-        const bool tip = ctl & (ch ? MBAMD_W4_TIP2 : MBAMD_W4_TIP1), mem = ctl & (ch ? MBAMD_WG_MEM2 : MBAMD_WG_MEM1);
+    // chunk q of an entry: MFMA steps [h TPC, (h + 1) TPC) of one child factor; registers (it, r) of f = state 32 it + 2 r +
+    // half of this lane's pattern.  No vector-memory operation in here.  Two halves: the B rows into registers (the only LDS
+    // wait), then the MFMA chain (or the tip's gather rows) -- the caller may issue scalar loads in between.
+    auto operandB = [&](const Walk4Entry& de, int q, const Ops& o, vec (&b)[TVC]) {
+        const int ch = q / CH, h = q % CH;
+        if (de.ctl & (ch ? MBAMD_WG_MEM2 : MBAMD_WG_MEM1)) {
 #pragma unroll
-        for (int it = 0; it < NT; ++it)
+            for (int i = 0; i < TVC; ++i) b[i] = o.b[i];
+        } else {
+            const vec* sl = reinterpret_cast<const vec*>(reinterpret_cast<const char*>(slots) + (ch ? de.c2 : de.c1)) + h * TVC * 64;
+#if !defined(MBAMD_WGX_NOLDS)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) f[it][r] = 0.0f;
+            for (int i = 0; i < TVC; ++i) b[i] = sl[i * 64];
+#else
+            (void) sl;
+#pragma unroll
+            for (int i = 0; i < TVC; ++i) b[i] = (vec) (1.0f);
+#endif
+        }
+    };
+    auto compute = [&](bool tip, int q, const Ops& o, const vec (&b)[TVC], wg_f16 (&f)[NT]) {
+        const int h = q % CH;
         if (tip) {
+            if (h == 0) {                            // all 16 registers of every row tile come from the first chunk's rows
+#pragma unroll
+                for (int it = 0; it < NT; ++it)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) f[it][r] = (16 * it + r < T) ? o.a[(r * NT + it) / V][(r * NT + it) % V] : 0.0f;
+            }
+            return;
+        }
+        if (h == 0) {
 #pragma unroll
             for (int it = 0; it < NT; ++it)
 #pragma unroll
-                for (int r = 0; r < 16; ++r)
-                    if (16 * it + r < T) f[it][r] = o.a[(r * NT + it) / V][(r * NT + it) % V];
-        } else if (mem) {
-#pragma unroll
-            for (int t = 0; t < T; ++t)
-#pragma unroll
-                for (int it = 0; it < NT; ++it)
-                    f[it] = __builtin_amdgcn_mfma_f32_32x32x2f32(o.a[(t * NT + it) / V][(t * NT + it) % V], o.b[t / V][t % V], f[it], 0, 0, 0);
-        } else {
-            const vec* sl = reinterpret_cast<const vec*>(reinterpret_cast<const char*>(slots) + (ch ? d.e.c2 : d.e.c1));
-            vec b[TV];
-#pragma unroll
-            for (int i = 0; i < TV; ++i) b[i] = sl[i * 64];
-#pragma unroll
-            for (int t = 0; t < T; ++t)
-#pragma unroll
-                for (int it = 0; it < NT; ++it)
-                    f[it] = __builtin_amdgcn_mfma_f32_32x32x2f32(o.a[(t * NT + it) / V][(t * NT + it) % V], b[t / V][t % V], f[it], 0, 0, 0);
+                for (int r = 0; r < 16; ++r) f[it][r] = 0.0f;
         }
+#if !defined(MBAMD_WGX_NOMFMA)
+#pragma unroll
+        for (int tc = 0; tc < TPC; ++tc)
+            if (h * TPC + tc < T) {
+#pragma unroll
+                for (int it = 0; it < NT; ++it)
+                    f[it] = __builtin_amdgcn_mfma_f32_32x32x2f32(o.a[(tc * NT + it) / V][(tc * NT + it) % V], b[tc / V][tc % V], f[it], 0, 0, 0);
+            }
+#else
+#pragma unroll
+        for (int tc = 0; tc < TPC; ++tc) f[0][tc & 15] += o.a[(tc * NT) / V][(tc * NT) % V] * b[tc / V][tc % V];
+#endif
     };
 
-    // One iteration = one entry `cur` (jobs on register sets S0, S1); fetches the operands of entry `n1` into (S2, S0)
-    // (DEPTH 1: of cur's second child into S1 and n1's first child into S0), the tip states of entry `n2`, and replaces
-    // cur's descriptor by entry j + 3.  Vector-memory sequence, identical on
-    // every path:  1 exponent load | 2 state loads | NAV + TV operand loads | NAV + TV operand loads | TV + 1 stores
-    auto step = [&](WgDesc& cur, const WgDesc& n1, WgDesc& n2, WgOperands<SC>& S0, WgOperands<SC>& S1, WgOperands<SC>& S2, int j) {
+    // One iteration = one entry `cur`: its NQ chunks run on the register sets (S0, S1, S2, S0, ...) while the chunks DEPTH
+    // further on -- of cur, then of entry `n1` -- are fetched; the tip states of entry `n2` are fetched, and cur's descriptor
+    // is replaced by entry j + 3.  Vector-memory sequence, identical on every path:
+    //     NQ x NAVC operand loads | TV + 1 stores      (+ the rare conditional loads)
+#if defined(MBAMD_WG_TRACE)      // timing experiments only (MBAMD_BUILD_DEFINES=MBAMD_WG_TRACE): the stamps cost scalar-memory waits
+    const bool tracing = A.trace != nullptr && blockIdx.x == 8 && lane == 0;
+#else
+    constexpr bool tracing = false;
+#endif
+    auto step = [&](WgDesc& cur, const WgDesc& n1, WgDesc& n2, Ops& S0, Ops& S1, Ops& S2, int j) {
         const unsigned ctl = cur.e.ctl;
+        if (tracing) A.trace[((size_t) j * 8 + wave) * 3 + 0] = (long long) __builtin_amdgcn_s_memtime();
         if (ctl & MBAMD_W4_BARRIER) {
             // values other waves produced in the previous phase are read from here on: drain this wave's stores, meet
             asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
@@ -309,31 +374,66 @@ k_walkg(WalkGArgs A)
         const bool run = !(ctl & MBAMD_W4_NOP);
         const unsigned mode = (ctl >> 8) & 3u;
         // (issued before the operand fetches: what the next entry needs first must not queue behind them)
+        // (three tiny loads, unconditional: every conditional vector-memory instruction makes the compiler's vmcnt waits one
+        //  instruction stricter -- and the instruction they then wait for is the oldest STORE of the previous entry)
+#if !defined(MBAMD_WGX_NOTINY)
         const int er_next = as_global(E0 + n1.e.eread)[col];
         n2.s1 = as_global(T0 + ((n2.e.ctl & MBAMD_W4_TIP1) ? n2.e.c1 : 0u))[col];
         n2.s2 = as_global(T0 + ((n2.e.ctl & MBAMD_W4_TIP2) ? n2.e.c2 : 0u))[col];
+#else
+        const int er_next = 0;
+#endif
         wg_f16 f1[NT], f2[NT];
-        if (DEPTH == 2) {
-            fetch(n1, 0, S2);
-            if (run) factor(cur, 0, S0, f1);
-            fetch(n1, 1, S0);
-            if (run) factor(cur, 1, S1, f2);
-        } else {
-            fetch(cur, 1, S1);
-            if (run) factor(cur, 0, S0, f1);
-            fetch(n1, 0, S0);
-            if (run) factor(cur, 1, S1, f2);
-        }
-        const unsigned dst = cur.e.dst, ewrite = cur.e.ewrite;
-        cur.e = walk4_load_entry(prog + j + 3);
+        const Walk4Entry ce = cur.e;
+        auto chunk = [&](auto qc) {
+            constexpr int q = decltype(qc)::value;
+            if constexpr (q < NQ) {
+                constexpr int qf = q + DEPTH;        // the chunk fetched now
+                if constexpr (qf < NQ) {
+                    WgDesc t;
+                    t.e = ce; t.s1 = cur.s1; t.s2 = cur.s2;
+                    fetch(t, qf, wg_pick<qf % NS>(S0, S1, S2));
+                } else {
+                    fetch(n1, qf - NQ, wg_pick<qf % NS>(S0, S1, S2));
+                }
+                const bool tip = ce.ctl & (q / CH ? MBAMD_W4_TIP2 : MBAMD_W4_TIP1);
+                // The descriptor of entry j + 3 replaces this entry's: a scalar load, and scalar loads share lgkmcnt with LDS
+                // and return out of order -- any LDS wait while it is in flight is a wait for IT.  It is issued when the
+                // last LDS read of the entry has landed (the epilogue has none): the last chunk's MFMA chain covers it.
+                if (run && !tip) {
+                    vec b[TVC];
+                    operandB(ce, q, wg_pick<q % NS>(S0, S1, S2), b);
+                    if constexpr (q == NQ - 1) {
+#pragma unroll
+                        for (int i = 0; i < TVC; ++i) asm volatile("" :: "v"(b[i]) : "memory");
+                        cur.e = walk4_load_entry(prog + j + 3);
+                    }
+                    compute(false, q, wg_pick<q % NS>(S0, S1, S2), b, q < CH ? f1 : f2);
+                } else {
+                    if constexpr (q == NQ - 1) cur.e = walk4_load_entry(prog + j + 3);
+                    vec b[TVC];
+                    if (run) compute(true, q, wg_pick<q % NS>(S0, S1, S2), b, q < CH ? f1 : f2);
+                }
+            }
+        };
+        chunk(WgInt<0>{}); chunk(WgInt<1>{}); chunk(WgInt<2>{}); chunk(WgInt<3>{});
+        if (tracing) A.trace[((size_t) j * 8 + wave) * 3 + 1] = (long long) __builtin_amdgcn_s_memtime();
+        const unsigned dst = ce.dst, ewrite = ce.ewrite;
         float out[TP];
         float mx = 0.0f;
 #pragma unroll
         for (int t = 0; t < TP; ++t) {
+#if !defined(MBAMD_WGX_NOEPI)
             out[t] = (run && t < T) ? f1[t >> 4][t & 15] * f2[t >> 4][t & 15] : 0.0f;
+#else
+            out[t] = (t == 0 && run) ? f1[0][0] + f2[0][0] : 0.0f;
+#endif
             mx = fmaxf(mx, out[t]);
         }
-        mx = fmaxf(mx, __shfl_xor(mx, 32));
+        {   // the other half of the states of this pattern sits 32 lanes away: v_permlane32_swap (VALU, no LDS round trip)
+            const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(mx), __float_as_uint(mx), false, false);
+            mx = fmaxf(__uint_as_float(sw[0]), __uint_as_float(sw[1]));
+        }
         const int wm = mode == SCALE_WRITE ? -1 : 0, rm = mode == SCALE_READ ? -1 : 0;
         const int e = (scale_exponent(mx) & wm) | (er & rm);
         er = er_next;
@@ -343,33 +443,38 @@ k_walkg(WalkGArgs A)
         vec ov[TV];
 #pragma unroll
         for (int t = 0; t < TP; ++t) ov[t / V][t % V] = scale_pow2(out[t], -e);   // (2^0 is exact: no branch)
+#if !defined(MBAMD_WGX_NOLDS)
         if (ctl & MBAMD_W4_KEEP) {
             vec* keep = reinterpret_cast<vec*>(reinterpret_cast<char*>(slots) + ((ctl >> 16) & 0xFFu) * SLOTB);
 #pragma unroll
             for (int i = 0; i < TV; ++i) keep[i * 64] = ov[i];
         }
+#endif
         MBAMD_AS_GLOBAL vec* pd = reinterpret_cast<MBAMD_AS_GLOBAL vec*>((uintptr_t) (P0 + dst)) + lane;
+#if !defined(MBAMD_WGX_NOSTORE)
 #pragma unroll
         for (int i = 0; i < TV; ++i) __builtin_nontemporal_store(ov[i], pd + i * 64);   // 64 * V * 4 contiguous bytes per instruction
-        if (half == 0) __builtin_nontemporal_store((int8_t) e, as_global(E0 + ewrite) + col);
+#else
+        if (ov[0][0] == 123.456f) __builtin_nontemporal_store(ov[0], pd);
+#endif
+#if !defined(MBAMD_WGX_NOTINY)
+        __builtin_nontemporal_store((int8_t) e, as_global(E0 + ewrite) + col);   // (both halves hold the same e: no exec-mask branch)
+#else
+        if (e == 12345) __builtin_nontemporal_store((int8_t) e, as_global(E0 + ewrite) + col);
+#endif
+        if (tracing) A.trace[((size_t) j * 8 + wave) * 3 + 2] = (long long) (ctl & 0xFFFu);   // (flags and mode of the entry, for the reader)
     };
+    // the sets rotate by NQ positions per entry; three entries bring every (NS <= 3) rotation back to the start
     for (int j = 0; j < n; j += 3) {
-        if (DEPTH == 2) {
-            step(DA, DB, DC, X, Y, Z, j);
-            step(DB, DC, DA, Z, X, Y, j + 1);
-            step(DC, DA, DB, Y, Z, X, j + 2);
-        } else {
-            step(DA, DB, DC, X, Y, Z, j);
-            step(DB, DC, DA, X, Y, Z, j + 1);
-            step(DC, DA, DB, X, Y, Z, j + 2);
-        }
+        step(DA, DB, DC, wg_pick<0>(X, Y, Z), wg_pick<1 % NS>(X, Y, Z), wg_pick<2 % NS>(X, Y, Z), j);
+        step(DB, DC, DA, wg_pick<NQ % NS>(X, Y, Z), wg_pick<(NQ + 1) % NS>(X, Y, Z), wg_pick<(NQ + 2) % NS>(X, Y, Z), j + 1);
+        step(DC, DA, DB, wg_pick<(2 * NQ) % NS>(X, Y, Z), wg_pick<(2 * NQ + 1) % NS>(X, Y, Z), wg_pick<(2 * NQ + 2) % NS>(X, Y, Z), j + 2);
     }
     // cumulative exponents of this workgroup's 32 columns: the waves' sums meet in LDS, wave 0 owns the memory update
-    const int W = (int) (blockDim.x >> 6);
     int* const stage = reinterpret_cast<int*>(mine);
 #pragma unroll
     for (int q = 0; q < MBAMD_WG_MAXLISTS; ++q) {
-        if (A.cum[q] == nullptr) continue;
+        if (A.cum[q] == nullptr || (A.lists > 1 && q != (int) list)) continue;      // (separate lists: a workgroup holds one list)
         int sum = cum_e[q];
         if (W > 1) {
             if (q > 0) __syncthreads();
