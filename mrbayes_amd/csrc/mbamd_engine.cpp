@@ -37,6 +37,9 @@
 
 #include <chrono>
 
+#if !defined(MBAMD_WG_DEPTH20)
+#define MBAMD_WG_DEPTH20 2
+#endif
 namespace mbamd {
 
 // MBAMD_STATS=1: per-entry-point call counts and host wall time, printed when an instance is finalized
@@ -550,7 +553,7 @@ int Instance::create(int tipCount_, int partialsBufferCount, int compactBufferCo
     HIP_TRY(hipMalloc(&d_site, (size_t) Ppad * sizeof(double)));
     nblocks = Ppad / 64;
 #if !defined(MBAMD_HOST_EMU)
-    if (!s4 && S >= 8) nblocks = Ppad / 32;      // k_integrate_lnl_wide: one block sum per 32-pattern tile
+    if (!s4 && S >= 8) nblocks = Ppad / 32;      // k_integrate_lnl_wide / _wg_wide: one block sum per 32-pattern tile
 #endif
     HIP_TRY(hipHostMalloc(&h_sums, (size_t) nblocks * sizeof(double), hipHostMallocDefault));
     HIP_TRY(hipHostGetDevicePointer((void**) &h_sums_dev, h_sums, 0));
@@ -618,7 +621,7 @@ int Instance::configureWalk()
         const unsigned slotBytes = wg_block_bytes(S);
 #if !defined(MBAMD_HOST_EMU)
         hipError_t aerr = S == 61 ? hipFuncSetAttribute((const void*) k_walkg<61, 4, 2, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, maxLds)
-                                  : hipFuncSetAttribute((const void*) k_walkg<20, 8, 1, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, maxLds);
+                                  : hipFuncSetAttribute((const void*) k_walkg<20, 8, 1, MBAMD_WG_DEPTH20>, hipFuncAttributeMaxDynamicSharedMemorySize, maxLds);
         if (aerr != hipSuccess) (void) hipGetLastError();
 #endif
         wgGeometry(1, w4.maxW, w4.maxSlots);
@@ -1769,7 +1772,7 @@ int Instance::runWalkG(const Plan& plan)
             lastWalkSteps = sg.entries - MBAMD_WG_TAIL; walkWaves = sg.W - 1;
         }
         if (S == 61) launch_walkg_t<61, 4, 2, 1>(*this, a, sg.W, sg.nslots);
-        else launch_walkg_t<20, 8, 1, 2>(*this, a, sg.W, sg.nslots);
+        else launch_walkg_t<20, 8, 1, MBAMD_WG_DEPTH20>(*this, a, sg.W, sg.nslots);
         HIP_TRY(hipGetLastError());
         pendingLaunches += 1;
     }
@@ -2436,7 +2439,11 @@ int Instance::integrate4(const int* parent, const int* child, const int* prob, c
     if (wg) {
         WgGeom g;
         g.tileFloats = wgTileBytes / 4; g.tipTileBytes = wgTipTileBytes; g.TP = wg_pairs_padded(S);
+#if !defined(MBAMD_HOST_EMU)
+        MBAMD_LAUNCH(k_integrate_lnl_wg_wide, (unsigned) nblocks, 256, 0, stream, a, S, SP, K, P, Ppad, g, (const double*) d_pweights, siteOut, h_sums_dev);
+#else
         MBAMD_LAUNCH(k_integrate_lnl_wg, (unsigned) nblocks, 64, 0, stream, a, S, SP, K, P, Ppad, g, (const double*) d_pweights, siteOut, h_sums_dev);
+#endif
     } else {
         MBAMD_LAUNCH(k_integrate_lnl_s4, (unsigned) nblocks, 64, 0, stream, a, K, P, Ppad, geom, (const double*) d_pweights, siteOut, h_sums_dev);
     }

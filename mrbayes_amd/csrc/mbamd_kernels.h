@@ -508,8 +508,9 @@ k_integrate_lnl_s4(IntegrateArgs4 a, int K, int P, int Ppad, BlockGeom g,
 
 // 20/61-state tree-walk layout (mbamd_walkg.h): partials float [tile][buffer][K][T][64], tip states uint8 [tile][buffer][32],
 // cumulative exponents per (pattern, category) like the 4-state path.  Same arithmetic as k_integrate_lnl, the categories
-// recombined as in k_integrate_lnl_s4.  One thread per pattern.
+// recombined as in k_integrate_lnl_s4.  One thread per pattern (host-emulation build).
 struct WgGeom { unsigned long tileFloats; unsigned tipTileBytes; int TP; };
+#if defined(MBAMD_HOST_EMU)      // (the GPU build integrates with k_integrate_lnl_wg_wide, mbamd_kernels_mfma.h: eight threads per pattern)
 __global__ void __launch_bounds__(64)
 k_integrate_lnl_wg(IntegrateArgs4 a, int S, int SP, int K, int P, int Ppad, WgGeom g,
                    const double* __restrict__ pattern_weights, double* __restrict__ site, double* __restrict__ wsite)
@@ -572,6 +573,8 @@ k_integrate_lnl_wg(IntegrateArgs4 a, int S, int SP, int K, int P, int Ppad, WgGe
     if (threadIdx.x == 0) wsite[blockIdx.x] = wl;
 #endif
 }
+
+#endif
 
 // ---------------------------------------------------------------------------------------------
 // cumulative scale-factor bookkeeping (exact integer arithmetic)

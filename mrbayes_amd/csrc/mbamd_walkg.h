@@ -452,8 +452,13 @@ k_walkg(WalkGArgs A)
 #endif
         MBAMD_AS_GLOBAL vec* pd = reinterpret_cast<MBAMD_AS_GLOBAL vec*>((uintptr_t) (P0 + dst)) + lane;
 #if !defined(MBAMD_WGX_NOSTORE)
+#if defined(MBAMD_WGX_PLAINSTORE)
+#pragma unroll
+        for (int i = 0; i < TV; ++i) pd[i * 64] = ov[i];
+#else
 #pragma unroll
         for (int i = 0; i < TV; ++i) __builtin_nontemporal_store(ov[i], pd + i * 64);   // 64 * V * 4 contiguous bytes per instruction
+#endif
 #else
         if (ov[0][0] == 123.456f) __builtin_nontemporal_store(ov[0], pd);
 #endif
