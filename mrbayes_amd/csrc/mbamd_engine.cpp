@@ -122,11 +122,6 @@ struct Plan {
     int serialFrom = 0;                          // general path: levels >= serialFrom are narrow (the spine towards the
                                                  // root): they run as one serial launch after the level launches
     std::vector<int> bufsRead, bufsWritten, scalesUsed;   // buffer / scale indices the list touches (deferral hazards)
-    // general-state tree walk (k_partials_mfma_walk): per phase (= launch) the tables (first entry in d_walk, operations)
-    std::vector<std::vector<std::pair<int, int>>> walkPhases;
-    PartialsOp* d_walk = nullptr;
-    size_t walkCap = 0;
-    int walkSlots = 0;
 };
 
 struct Instance {
@@ -374,11 +369,6 @@ struct Instance {
     bool noDefer = false;            // MBAMD_NO_DEFER: run every list at once
     bool envVerbose = false, envTrace = false;   // MBAMD_VERBOSE, MBAMD_WALK_TRACE (read once)
     bool noSpine = false;            // MBAMD_NO_SPINE: serial launches use the plain (not software-pipelined) kernel
-    bool gwalk = false;              // general-state tree walk (k_partials_mfma_walk) switched on for this instance (MBAMD_GWALK=1)
-    int gwalkSlots = 6, gwalkBins = 8;
-    Walk4Builder gw;
-    int buildGenericWalk(Plan& plan, const std::vector<PartialsOp>& dev, const std::vector<int>& dstIdx, const std::vector<int>& c1Idx,
-                         const std::vector<int>& c2Idx);
     int spineWidth = 1;              // MBAMD_SPINE_WIDTH: trailing levels of at most this many operations join the serial launch
     int serialRatio = 4;             // MBAMD_MFMA_SERIAL: lists with <= ratio * levels operations run as ONE serial launch (0 = never)
     bool independentOfPending(const Plan& plan, int cumIdx);
@@ -389,7 +379,6 @@ struct Instance {
 };
 
 #if !defined(MBAMD_HOST_EMU)
-static int run_gwalk(Instance& in, const std::vector<std::pair<const Plan*, int32_t*>>& work, bool& done);
 static bool launch_mfma_split(Instance& in, const OpTables& tabs, int count);
 static bool launch_mfma_serial(Instance& in, const OpTables& tabs, int ntables);
 static bool launch_tips(Instance& in, const OpTables& tabs, int count);
@@ -451,29 +440,6 @@ int Instance::create(int tipCount_, int partialsBufferCount, int compactBufferCo
     if (const char* e = std::getenv("MBAMD_MFMA_SERIAL")) serialRatio = std::max(0, std::atoi(e));
     noSpine = std::getenv("MBAMD_NO_SPINE") != nullptr;
     if (const char* e = std::getenv("MBAMD_SPINE_WIDTH")) spineWidth = std::max(1, std::atoi(e));
-    // (opt-in, MBAMD_GWALK=1: measured slower than the level launches at the BASELINE shapes -- 0.51 vs 0.38 ms on 200 x 10 000
-    //  WAG, 0.52 vs 0.30 ms on codon M3: a workgroup's serial chain of ~3 barriers per operation costs more than the
-    //  HBM round trip of the children it saves; profiles/r02_c3_gwalk.txt)
-    gwalk = mfma && !mfmaWhole && std::getenv("MBAMD_GWALK") != nullptr &&
-            ((NT == 1 && S == 20 && (K == 4 || K == 1)) || (NT == 2 && S == 61 && K == 1));
-    if (gwalk) {
-        const int NP = 2 * K * NT;
-        const size_t staging = (size_t) NP * (8 * 64 + 32) * sizeof(float), tile = (size_t) K * S * 32 * sizeof(float);
-        gwalkSlots = (int) std::max<size_t>(3, std::min<size_t>(12, (80 * 1024 - staging) / tile));     // two workgroups per CU
-        if (const char* e = std::getenv("MBAMD_GWALK_SLOTS")) gwalkSlots = std::max(3, std::min(14, std::atoi(e)));
-        if (const char* e = std::getenv("MBAMD_GWALK_BINS")) gwalkBins = std::max(1, std::min(MBAMD_W4_MAXW, std::atoi(e)));
-        gw.memSlots = false;
-        gw.alwaysKeep = true;
-        gw.phasesAreLaunches = true;
-        gw.maxSlots = gw.maxSlots1 = gwalkSlots;
-        gw.smallPhase = 12;
-        hipError_t aerr = hipSuccess;
-        const int maxLds = 160 * 1024;
-        if (NT == 1 && K == 4) aerr = hipFuncSetAttribute((const void*) k_partials_mfma_walk<1, 20, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, maxLds);
-        else if (NT == 1) aerr = hipFuncSetAttribute((const void*) k_partials_mfma_walk<1, 20, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, maxLds);
-        else aerr = hipFuncSetAttribute((const void*) k_partials_mfma_walk<2, 61, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, maxLds);
-        if (aerr != hipSuccess) { (void) hipGetLastError(); gwalk = false; }
-    }
     // serial / spine kernels exist for these shapes only (other category counts: level launches throughout)
     if (!((NT == 1 && (K == 1 || K == 2 || K == 4)) || (NT == 2 && (K == 1 || K == 2)))) serialRatio = 0;
 #endif
@@ -590,7 +556,7 @@ void Instance::destroy()
     }
     pending.clear();
     wgOps.clear(); wgListStart.clear(); wgListCum.clear();
-    for (Plan* pl : plans) { if (pl->d_table) (void) hipFree(pl->d_table); if (pl->d_walk) (void) hipFree(pl->d_walk); delete pl; }
+    for (Plan* pl : plans) { if (pl->d_table) (void) hipFree(pl->d_table); delete pl; }
     plans.clear();
     void* bufs[] = {matrices, d_eigen, d_freqs, d_weights, d_rates, d_pweights, d_site,
                     d_ev, d_tmp, d_trace};
@@ -1101,21 +1067,6 @@ int Instance::flushPending()
         HIP_TRY(hipEventCreate(&ev0));
         HIP_TRY(hipEventCreate(&ev1));
         HIP_TRY(hipEventRecord(ev0, stream));
-    }
-    {
-        // every pending list has tree-walk tables: their phases run side by side, one launch per phase
-        std::vector<std::pair<const Plan*, int32_t*>> all;
-        for (auto& w : work) all.emplace_back(w.first, cumOf(w.second));
-        bool done = false;
-        const int wrc = run_gwalk(*this, all, done);
-        if (wrc) return wrc;
-        if (done) {
-            if (timing) {
-                HIP_TRY(hipEventRecord(ev1, stream));
-                events.emplace_back(ev0, ev1);
-            }
-            return BEAGLE_SUCCESS;
-        }
     }
     size_t maxLevels = 0;
     bool allNarrow = true;
@@ -2046,154 +1997,11 @@ int Instance::buildGeneric(Plan& plan, std::vector<PartialsOp>& dev, const std::
             }
         }
     }
-    plan.walkPhases.clear();
-#if !defined(MBAMD_HOST_EMU)
-    if (gwalk && n >= 6) {
-        const int wrc = buildGenericWalk(plan, dev, dstIdx, c1Idx, c2Idx);
-        if (wrc) return wrc;
-    }
-#endif
     return planTable(plan, sorted);
 }
 
-#if !defined(MBAMD_HOST_EMU)
-// General-state tree walk: the list's operation forest cut into bins of whole subtrees (one table each, Sethi-Ullman
-// order, LDS slots for results) and the small cap of their ancestors as later phases -- Walk4Builder with "waves" read as
-// tables and "barriers" as launch boundaries.  Lists with buffer hazards, or whose subtrees need more slots than a
-// workgroup has (a result would have to be re-read from HBM inside the launch that wrote it), keep the level launches.
-int Instance::buildGenericWalk(Plan& plan, const std::vector<PartialsOp>& dev, const std::vector<int>& dstIdx, const std::vector<int>& c1Idx,
-                               const std::vector<int>& c2Idx)
-{
-    const int n = (int) dev.size();
-    std::vector<Walk4Op> ops(n);
-    {
-        std::vector<char> rd(nBuffers, 0), wr(nBuffers, 0);
-        std::unordered_map<const void*, int> scaleSeen;
-        for (int o = 0; o < n; ++o) {
-            if (wr[dstIdx[o]] || rd[dstIdx[o]]) return BEAGLE_SUCCESS;              // WAW / WAR: not for this path
-            if (dev[o].scale_mode != SCALE_NONE && scaleSeen[dev[o].scale]++) return BEAGLE_SUCCESS;
-            wr[dstIdx[o]] = 1;
-            Walk4Op& w = ops[o];
-            w.dst = dstIdx[o]; w.c1 = c1Idx[o]; w.c2 = c2Idx[o];
-            w.tip1 = dev[o].c1_kind == CHILD_STATES; w.tip2 = dev[o].c2_kind == CHILD_STATES;
-            if (!w.tip1) rd[w.c1] = 1;
-            if (!w.tip2) rd[w.c2] = 1;
-            w.m1 = w.m2 = 0;
-            w.scaleWrite = w.scaleRead = -1;
-        }
-    }
-    gw.maxW = std::max(1, std::min(gwalkBins, n / 12));
-    Walk4Template t;
-    if (!gw.build(ops, t) || t.evictions > 0) return BEAGLE_SUCCESS;
-    std::vector<PartialsOp> tab;
-    plan.walkPhases.clear();
-    for (int w = 0; w < t.W; ++w) {
-        int phase = 0;
-        int first = -1;
-        auto close = [&]() {
-            if (first >= 0 && (int) tab.size() > first) {
-                if ((int) plan.walkPhases.size() <= phase) plan.walkPhases.resize(phase + 1);
-                plan.walkPhases[phase].emplace_back(first, (int) tab.size() - first);
-            }
-            first = -1;
-        };
-        for (int j = 0; j < t.entries; ++j) {
-            const Walk4Template::Entry& e = t.prog[(size_t) w * t.entries + j];
-            if (e.flags & MBAMD_W4_BARRIER) { close(); ++phase; }
-            if (e.op < 0) continue;
-            if (first < 0) first = (int) tab.size();
-            PartialsOp d = dev[e.op];
-            if (d.c1_kind != CHILD_STATES) { d.c1_kind = e.c1slot != 0xFF ? CHILD_LDS : CHILD_PARTIALS; d.c1_slot = e.c1slot; }
-            if (d.c2_kind != CHILD_STATES) { d.c2_kind = e.c2slot != 0xFF ? CHILD_LDS : CHILD_PARTIALS; d.c2_slot = e.c2slot; }
-            if (e.dslot == 0xFF) { plan.walkPhases.clear(); return BEAGLE_SUCCESS; }      // (cannot happen with alwaysKeep)
-            d.dst_slot = e.dslot;
-            tab.push_back(d);
-        }
-        close();
-    }
-    for (auto& ph : plan.walkPhases)
-        if ((int) ph.size() > MBAMD_WALK_TABLES) { plan.walkPhases.clear(); return BEAGLE_SUCCESS; }
-    plan.walkSlots = t.nslots;
-    const size_t bytes = tab.size() * sizeof(PartialsOp);
-    if (bytes > plan.walkCap || plan.lastLaunch > syncedClock) {
-        if (plan.lastLaunch > syncedClock) { HIP_TRY(hipStreamSynchronize(stream)); syncedClock = launchClock; }
-        if (bytes > plan.walkCap) {
-            if (plan.d_walk) HIP_TRY(hipFree(plan.d_walk));
-            plan.d_walk = nullptr;
-            plan.walkCap = 0;
-            HIP_TRY(hipMalloc(&plan.d_walk, bytes + bytes / 2));
-            plan.walkCap = bytes + bytes / 2;
-        }
-    }
-    if (envVerbose) {
-        std::fprintf(stderr, "[mbamd] general-state walk: %d ops, %zu phase(s), %d slots:", n, plan.walkPhases.size(), plan.walkSlots);
-        for (auto& ph : plan.walkPhases) std::fprintf(stderr, " %zu tables", ph.size());
-        std::fprintf(stderr, "\n");
-    }
-    return upload(plan.d_walk, tab.data(), bytes);
-}
-
-// one launch = one phase of up to MBAMD_WALK_TABLES tables (of one or several lists)
-static bool launch_gwalk(Instance& in, const WalkTables& tabs, int ntables, int nslots)
-{
-    const int S = in.S, K = in.K, NT = in.NT;
-    const int NP = 2 * K * NT, gx = in.Ppad / 32;
-    const size_t lds = ((size_t) NP * (8 * 64 + 32) + (size_t) nslots * K * S * 32) * sizeof(float);
-    const unsigned grid = (unsigned) (gx * ntables), block = 64u * (NP + 1);
-    if (NT == 1 && S == 20 && K == 4) MBAMD_LAUNCH((k_partials_mfma_walk<1, 20, 4>), grid, block, lds, in.stream, tabs, in.SP, gx, nslots);
-    else if (NT == 1 && S == 20 && K == 1) MBAMD_LAUNCH((k_partials_mfma_walk<1, 20, 1>), grid, block, lds, in.stream, tabs, in.SP, gx, nslots);
-    else if (NT == 2 && S == 61 && K == 1) MBAMD_LAUNCH((k_partials_mfma_walk<2, 61, 1>), grid, block, lds, in.stream, tabs, in.SP, gx, nslots);
-    else return false;
-    return true;
-}
-// run the walk phases of several plans side by side (false: some plan has no walk tables)
-static int run_gwalk(Instance& in, const std::vector<std::pair<const Plan*, int32_t*>>& work, bool& done)
-{
-    done = false;
-    size_t phases = 0;
-    int nslots = 1;
-    for (auto& w : work) {
-        if (w.first->walkPhases.empty()) return BEAGLE_SUCCESS;
-        phases = std::max(phases, w.first->walkPhases.size());
-        nslots = std::max(nslots, w.first->walkSlots);
-    }
-    for (size_t ph = 0; ph < phases; ++ph) {
-        WalkTables tabs;
-        std::memset(&tabs, 0, sizeof tabs);
-        int nt = 0;
-        auto flush = [&]() {
-            if (nt > 0 && launch_gwalk(in, tabs, nt, nslots)) in.pendingLaunches += 1;
-            std::memset(&tabs, 0, sizeof tabs);
-            nt = 0;
-        };
-        for (auto& w : work) {
-            if (ph >= w.first->walkPhases.size()) continue;
-            for (auto& tb : w.first->walkPhases[ph]) {
-                if (nt == MBAMD_WALK_TABLES) flush();
-                tabs.ops[nt] = w.first->d_walk + tb.first;
-                tabs.cum[nt] = w.second;
-                tabs.count[nt] = tb.second;
-                ++nt;
-            }
-        }
-        flush();
-    }
-    HIP_TRY(hipGetLastError());
-    done = true;
-    return BEAGLE_SUCCESS;
-}
-#endif
-
 int Instance::runGeneric(const Plan& plan, int32_t* cum)
 {
-#if !defined(MBAMD_HOST_EMU)
-    if (!plan.walkPhases.empty()) {
-        bool done = false;
-        std::vector<std::pair<const Plan*, int32_t*>> one(1, std::make_pair(&plan, cum));
-        const int rc = run_gwalk(*this, one, done);
-        if (rc || done) return rc;
-    }
-#endif
     const std::vector<int>& start = plan.start;
     const int nLevels = (int) start.size() - 1;
     const bool anyScale = plan.anyScale;

@@ -753,180 +753,6 @@ k_partials_mfma_spine(OpTables tabs, int SP, int gx, long long* __restrict__ tra
 }
 
 // ---------------------------------------------------------------------------------------------
-// General-state TREE WALK: the spine kernel above with host-assigned LDS slots instead of "the last two results".
-// A workgroup owns one 32-pattern tile and executes ONE TABLE of operations (a bin of whole subtrees, ordered by
-// Sethi-Ullman numbers) in list order; every result lives in an LDS slot (K*S*32 floats) from which the writer wave
-// copies it to HBM and from which later operations of the same table read it as their B operand -- interior
-// conditional likelihoods are written once and never read back inside a launch.  Tables of one launch are mutually
-// independent (grid = tiles x tables); values that cross tables travel through HBM between launches (the "phases" of
-// Walk4Builder, mbamd_walk4_host.h: subtree bins first, then the small cap of their ancestors).
-// Child kinds: CHILD_STATES (one-hot B operand), CHILD_LDS (slot c?_slot), CHILD_PARTIALS (HBM, written by an earlier
-// launch: loaded one operation ahead like the spine kernel does).
-// ---------------------------------------------------------------------------------------------
-#define MBAMD_WALK_TABLES 32
-struct WalkTables {
-    const PartialsOp* ops[MBAMD_WALK_TABLES];
-    int32_t* cum[MBAMD_WALK_TABLES];
-    int count[MBAMD_WALK_TABLES];
-};
-
-template <int NT, int SC, int KC>
-__device__ __forceinline__ void gwalk_prefetch(const SpineDesc& d, int SP, int k, int c, int it, int c0, int lane, SpineOperands<SC>& n)
-{
-    constexpr int T = (SC + 1) / 2;
-    const int col = lane & 31;
-    const int kind = (d.kinds >> (8 * c)) & 0xFF;
-    const int mode = (d.modes >> 8) & 0xFF;
-    const uint64_t child = c ? d.c2 : d.c1;
-    const float* mbase = reinterpret_cast<const float*>(c ? d.m2 : d.m1);
-    const MBAMD_AS_GLOBAL float* __restrict__ pa =
-        as_global(mbase) + (size_t) KC * SP * SP + ((size_t) (k * NT + it) * T) * 64 + lane;
-    const MBAMD_AS_GLOBAL float* __restrict__ cl =
-        (kind == CHILD_PARTIALS) ? as_global(reinterpret_cast<const float*>(child)) + gen_index(KC, SC, k, 0, c0) + lane : pa;
-    const MBAMD_AS_GLOBAL uint8_t* st = (kind == CHILD_STATES) ? as_global(reinterpret_cast<const uint8_t*>(child)) + c0 + col
-                                                                : reinterpret_cast<const MBAMD_AS_GLOBAL uint8_t*>(pa);
-    const MBAMD_AS_GLOBAL int32_t* er = (mode == SCALE_READ) ? as_global(reinterpret_cast<const int32_t*>(d.scale)) + c0 + col
-                                                              : reinterpret_cast<const MBAMD_AS_GLOBAL int32_t*>(pa);
-#pragma unroll
-    for (int t = 0; t < T; ++t) n.a[t] = pa[(size_t) t * 64];
-#pragma unroll
-    for (int t = 0; t < T; ++t) n.b[t] = cl[64 * min(t, (SC - 1 - (lane >> 5)) / 2)];   // (odd S: lanes >= 32 have no row S)
-    n.state = *st;
-    n.eread = *er;
-}
-
-template <int NT, int SC, int KC>
-__device__ __forceinline__ void gwalk_compute(const SpineDesc& d, int k, int c, int it, int wave, int lane, const SpineOperands<SC>& cur,
-                                              float* tiles, float* smax, float* slots)
-{
-    constexpr int NP = 2 * KC * NT;
-    constexpr int S = SC, T = (SC + 1) / 2, Tfull = SC / 2;
-    constexpr int TILE = KC * SC * 32;
-    const int half = lane >> 5, col = lane & 31;
-    const int mode = (d.modes >> 8) & 0xFF;
-    const int kind = (d.kinds >> (8 * c)) & 0xFF;
-    const int cslot = (d.kinds >> (16 + 8 * c)) & 0xFF;
-    float* mySlot = slots + (size_t) (d.modes & 0xFF) * TILE;
-    float b[T];
-    bool missing = false;
-    if (kind == CHILD_STATES) {                     // one-hot column selector (a missing state is patched below)
-        missing = cur.state >= (unsigned) S;
-#pragma unroll
-        for (int t = 0; t < T; ++t) b[t] = (cur.state == (unsigned) (2 * t + half)) ? 1.0f : 0.0f;
-    } else if (kind == CHILD_LDS) {                 // a result of this table, resident in its slot
-        const float* fl = slots + (size_t) cslot * TILE + (size_t) k * S * 32 + lane;
-#pragma unroll
-        for (int t = 0; t < Tfull; ++t) b[t] = fl[64 * t];
-        if (SC & 1) b[T - 1] = half ? 0.0f : fl[64 * Tfull];
-    } else {
-#pragma unroll
-        for (int t = 0; t < T; ++t) b[t] = cur.b[t];
-        if (SC & 1) b[T - 1] = half ? 0.0f : b[T - 1];
-    }
-    f32x16 acc;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
-#pragma unroll
-    for (int t = 0; t < T; ++t) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(cur.a[t], b[t], acc, 0, 0, 0);
-    if (kind == CHILD_STATES) {
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int i = 32 * it + (r & 3) + 8 * (r >> 2) + 4 * half;
-            acc[r] = missing ? ((i < S) ? 1.0f : 0.0f) : acc[r];
-        }
-    }
-    // hand the eight registers this wave does not keep to its partner (other child, same k and it)
-    float* mine = tiles + (size_t) wave * 8 * 64;
-    float keep[8];
-    if (c) {
-#pragma unroll
-        for (int j = 0; j < 8; ++j) { mine[j * 64 + lane] = acc[j]; keep[j] = acc[8 + j]; }
-    } else {
-#pragma unroll
-        for (int j = 0; j < 8; ++j) { mine[j * 64 + lane] = acc[8 + j]; keep[j] = acc[j]; }
-    }
-    __syncthreads();                                // (all B operands have been read: the result may reuse a child's slot)
-    const float* other = tiles + (size_t) ((k * 2 + (1 - c)) * NT + it) * 8 * 64;
-    float out[8];
-    float mx = 0.0f;
-#pragma unroll
-    for (int j = 0; j < 8; ++j) {
-        const float v = keep[j] * other[j * 64 + lane];
-        out[j] = v;
-        const int i = 32 * it + 16 * c + (j & 3) + 8 * (j >> 2) + 4 * half;
-        mx = fmaxf(mx, (i < S) ? v : 0.0f);
-    }
-    int e = 0;
-    if (mode == SCALE_WRITE) {
-        mx = fmaxf(mx, __shfl_xor(mx, 32));
-        if (half == 0) smax[wave * 32 + col] = mx;
-        __syncthreads();
-        float m = 0.0f;
-#pragma unroll
-        for (int p = 0; p < NP; ++p) m = fmaxf(m, smax[p * 32 + col]);
-        e = scale_exponent(m);
-    } else if (mode == SCALE_READ) {
-        e = cur.eread;
-    }
-    float* frow = mySlot + ((size_t) k * S + 32 * it + 16 * c) * 32;
-#pragma unroll
-    for (int j = 0; j < 8; ++j) {
-        const int lr = (j & 3) + 4 * half + 8 * (j >> 2);
-        if (32 * it + 16 * c + lr < S) frow[lr * 32 + col] = (mode != SCALE_NONE) ? scale_pow2(out[j], -e) : out[j];
-    }
-    __syncthreads();
-}
-
-// grid = (P_pad / 32) * tables; block = 64 * (2*K*NT + 1); dynamic LDS = NP * (2 KiB + 128 B) + nslots * K*S*32 floats.
-template <int NT, int SC, int KC>
-__global__ void __launch_bounds__(64 * (2 * KC * NT + 1))
-k_partials_mfma_walk(WalkTables tabs, int SP, int gx, int nslots)
-{
-    static_assert(SC > 0, "compile-time state count required");
-    constexpr int NP = 2 * KC * NT;
-    constexpr int TILE = KC * SC * 32;
-    extern __shared__ float lds_f[];
-    float* tiles = lds_f;                           // [NP][8][64]
-    float* smax = lds_f + NP * 8 * 64;              // [NP][32]
-    float* slots = smax + NP * 32;                  // [nslots][K][S][32]
-    (void) nslots;
-    const int bx = blockIdx.x % gx, tsel = blockIdx.x / gx;
-    const int wave = __builtin_amdgcn_readfirstlane((int) (threadIdx.x >> 6)), lane = threadIdx.x & 63;
-    const int c0 = bx * 32;
-    const MBAMD_AS_CONST PartialsOp* __restrict__ ops = as_const(tabs.ops[tsel]);
-    int32_t* __restrict__ cumulative = tabs.cum[tsel];
-    const int count = tabs.count[tsel];
-    if (count <= 0) return;
-    if (wave == NP) {                               // ---- writer wave
-        for (int o = 0; o < count; ++o) {
-            const SpineDesc d = spine_desc(ops + o);
-            spine_write<NT, SC, KC>(d, cumulative, c0, lane, smax, slots + (size_t) (d.modes & 0xFF) * TILE);
-        }
-        return;
-    }
-    const int k = wave / (2 * NT), c = (wave / NT) & 1, it = wave % NT;
-    SpineOperands<SC> A, B;
-    SpineDesc d = spine_desc(ops);                                  // operation o
-    SpineDesc dn = spine_desc(ops + (count > 1 ? 1 : 0));           // operation o + 1
-    gwalk_prefetch<NT, SC, KC>(d, SP, k, c, it, c0, lane, A);
-    for (int o = 0; o < count; o += 2) {
-        {
-            const SpineDesc dnn = spine_desc(ops + min(o + 2, count - 1));
-            gwalk_prefetch<NT, SC, KC>(dn, SP, k, c, it, c0, lane, B);       // (harmless repeat of the last operation at the end)
-            gwalk_compute<NT, SC, KC>(d, k, c, it, wave, lane, A, tiles, smax, slots);
-            d = dn; dn = dnn;
-        }
-        if (o + 1 >= count) break;
-        {
-            const SpineDesc dnn = spine_desc(ops + min(o + 3, count - 1));
-            gwalk_prefetch<NT, SC, KC>(dn, SP, k, c, it, c0, lane, A);
-            gwalk_compute<NT, SC, KC>(d, k, c, it, wave, lane, B, tiles, smax, slots);
-            d = dn; dn = dnn;
-        }
-    }
-}
-
-// ---------------------------------------------------------------------------------------------
 // Transition matrices for larger state counts (TiProbs_Gen / TiProbs_GenCov, reference
 // src/likelihood.c:9424-9700): P_k = U diag(exp(lambda t r_k)) U^-1 in fp64, clamped at 0, stored as
 // fp32 transposed + in MFMA A-operand order.  The S x S x S contraction runs on the fp64 matrix cores

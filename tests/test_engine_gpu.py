@@ -368,21 +368,26 @@ def test_protein_other_category_counts(gpu, oracle, ncat):
 
 
 @pytest.mark.parametrize("case", ["replicase_m3", "avian_wag_g4", "synth_aa_wag"])
-def test_general_state_tree_walk_agrees(gpu, golden_dir, monkeypatch, case):
-    """MBAMD_GWALK=1: subtree bins walked by one workgroup per (tile, bin) with results resident in LDS slots, one launch
-    per phase (k_partials_mfma_walk) -- same bits as the level launches."""
+def test_general_state_tree_walk_schedules_agree(gpu, golden_dir, monkeypatch, case):
+    """20/61-state tree walk (k_walkg): waves per workgroup, LDS slots (children re-read from HBM instead), lists run one by
+    one instead of merged -- every schedule gives the same bits; the level kernels (MBAMD_NO_WALKG=1: a scaler per pattern
+    instead of per pattern and category, another summation order) agree to rounding."""
     div = division_from_golden(golden_dir, case)
     a, sa = _lnl_and_sites(gpu, div)
-    monkeypatch.setenv("MBAMD_GWALK", "1")
-    for env in ({}, {"MBAMD_GWALK_BINS": "2"}, {"MBAMD_GWALK_SLOTS": "3"}):
+    for env in ({"MBAMD_WALK_WAVES": "1"}, {"MBAMD_WALK_WAVES": "4"}, {"MBAMD_WALK_WAVES": "2", "MBAMD_MAX_LDS_SLOTS": "3"},
+                {"MBAMD_NO_DEFER": "1"}):
         for k, v in env.items():
             monkeypatch.setenv(k, v)
         b, sb = _lnl_and_sites(gpu, div)
-        assert a == b and np.array_equal(sa, sb)
+        assert a == b and np.array_equal(sa, sb), env
         b, sb = _lnl_and_sites(gpu, div, lk.MB_BEAGLE_SCALE_DYNAMIC)
         assert abs(a - b) <= 1e-9 * abs(a)
         for k in env:
             monkeypatch.delenv(k)
+    monkeypatch.setenv("MBAMD_NO_WALKG", "1")
+    b, sb = _lnl_and_sites(gpu, div)
+    assert abs(a - b) <= 2e-7 * abs(a)
+    assert np.allclose(sa, sb, rtol=2e-6, atol=2e-5)
 
 
 def test_deferred_lists_without_a_merge_kernel(gpu, oracle):

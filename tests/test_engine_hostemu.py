@@ -134,6 +134,37 @@ def test_walk_schedule(emu, oracle, monkeypatch, waves, slots, prefetch):
     assert abs(got - want) / abs(want) < ec.REL_FP64
 
 
+@pytest.mark.parametrize("model", ["wag", "m3"])
+@pytest.mark.parametrize("waves,slots", [(2, 3), (4, 3), (8, 4), (2, 12)])
+def test_general_walk_schedule(emu, oracle, monkeypatch, model, waves, slots):
+    """The same for the 20/61-state tree walk (k_walkg): children that are not in an LDS slot are re-read from HBM by the
+    kernel's operand pipeline; the eigen-system parts of the codon model run as separate workgroups or -- with
+    MBAMD_NO_DEFER -- one list at a time.  Every schedule gives the same bits."""
+    div = synthetic_division(model, 40, 70, seed=63, tree_seed=64, p_gap=0.03)
+    monkeypatch.setenv("MBAMD_WALK_WAVES", "1")
+    base = ec.engine_lnl(emu, div)
+    want = oracle.tree_loglike(div, use_shortcuts=False)
+    assert abs(base - want) / abs(want) < ec.REL_FP64
+    monkeypatch.setenv("MBAMD_WALK_WAVES", str(waves))
+    monkeypatch.setenv("MBAMD_MAX_LDS_SLOTS", str(slots))
+    monkeypatch.setenv("MBAMD_WALK_SMALL_PHASE", "4")
+    assert ec.engine_lnl(emu, div) == base
+    monkeypatch.setenv("MBAMD_NO_DEFER", "1")
+    assert ec.engine_lnl(emu, div) == base
+    monkeypatch.delenv("MBAMD_NO_DEFER")
+    bd = lk.BeagleDivision(div, emu, scaling=lk.MB_BEAGLE_SCALE_DYNAMIC)
+    bd.LogLike(0)
+    bd.AcceptMove(0)
+    t = div.tree
+    t.length[3] *= 2.0
+    bd.TouchBranch(0, 3)
+    got = bd.LogLike(0)
+    bd.finalize()
+    want = oracle.tree_loglike(div, use_shortcuts=False)
+    t.length[3] /= 2.0
+    assert abs(got - want) / abs(want) < ec.REL_FP64
+
+
 @pytest.mark.parametrize("ncat", [1, 2, 5, 16])
 def test_dna_other_category_counts(emu, oracle, ncat):
     """The tree walk runs one wave per (pattern block, category): any category count."""
