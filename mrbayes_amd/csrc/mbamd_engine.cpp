@@ -1573,10 +1573,60 @@ int Instance::flushWalkG()
     std::vector<BeagleOperation> ops;
     std::vector<int> starts, cums;
     ops.swap(wgOps); starts.swap(wgListStart); cums.swap(wgListCum);
-    const int n = (int) ops.size(), nl = (int) cums.size();
+    const int n = (int) ops.size();
+    int nl = (int) cums.size();
     std::vector<int> listOf(n, 0);
     for (int q = 0; q < nl; ++q)
         for (int o = starts[q]; o < (q + 1 < nl ? starts[q + 1] : n); ++o) listOf[o] = q;
+    // ---- plan cache key: the operations as submitted, the list boundaries, the layout epoch ------------------------------
+    std::vector<int> key(reinterpret_cast<const int*>(ops.data()), reinterpret_cast<const int*>(ops.data()) + (size_t) n * 7);
+    for (int q = 0; q < nl; ++q) key.push_back(starts[q]);
+    key.push_back(layoutEpoch);
+    // One list that does not rescale may hold several independent trees: without a cumulative buffer MrBayes submits the
+    // operations of all eigen-system parts as ONE list (reference src/mbbeagle.c:1029-1104, No_Rescale), and a move dirties
+    // the same root-ward path in each part.  Its connected components are treated like lists of their own.
+    if (nl == 1 && cums[0] == BEAGLE_OP_NONE && n >= 2) {
+        std::vector<int> comp(n);
+        for (int o = 0; o < n; ++o) comp[o] = o;
+        auto find = [&](int x) { while (comp[x] != x) x = comp[x] = comp[comp[x]]; return x; };
+        std::unordered_map<int, int> writer, scaleUser;
+        bool ok = true;
+        for (int o = 0; o < n && ok; ++o) {
+            const BeagleOperation& b = ops[o];
+            for (int c : {b.child1Partials, b.child2Partials}) {
+                auto it = writer.find(c);
+                if (it != writer.end()) comp[find(o)] = find(it->second);
+            }
+            if (writer.count(b.destinationPartials)) ok = false;            // (written twice: leave it to the hazard segments)
+            writer[b.destinationPartials] = o;
+            for (int sc : {b.destinationScaleWrite, b.destinationScaleRead})
+                if (sc != BEAGLE_OP_NONE) {
+                    auto it = scaleUser.find(sc);
+                    if (it != scaleUser.end()) comp[find(o)] = find(it->second); else scaleUser[sc] = o;
+                }
+        }
+        for (int o = 0; o < n && ok; ++o)                                    // a buffer read before a later operation writes it
+            for (int c : {ops[o].child1Partials, ops[o].child2Partials}) {
+                auto it = writer.find(c);
+                if (it != writer.end() && it->second > o) ok = false;
+            }
+        std::vector<int> roots;
+        for (int o = 0; o < n && ok; ++o) if (find(o) == o) roots.push_back(o);
+        if (ok && roots.size() >= 2 && roots.size() <= (size_t) MBAMD_WG_MAXLISTS) {
+            std::vector<BeagleOperation> sorted;
+            sorted.reserve(n);
+            starts.clear();
+            for (size_t q = 0; q < roots.size(); ++q) {
+                starts.push_back((int) sorted.size());
+                for (int o = 0; o < n; ++o) if (find(o) == roots[q]) sorted.push_back(ops[o]);
+            }
+            ops.swap(sorted);
+            nl = (int) roots.size();
+            cums.assign(nl, BEAGLE_OP_NONE);
+            for (int q = 0; q < nl; ++q)
+                for (int o = starts[q]; o < (q + 1 < nl ? starts[q + 1] : n); ++o) listOf[o] = q;
+        }
+    }
     wgFresh = 0;
     for (int q = 0; q < MBAMD_WG_MAXLISTS; ++q) wgCum[q] = nullptr;
     for (int q = 0; q < nl; ++q) {
@@ -1593,12 +1643,6 @@ int Instance::flushWalkG()
         }
         wgCum[q] = wideScale[ci];
     }
-    // ---- plan cache: the operations, the list boundaries, the layout epoch -------------------------------------------
-    const int* raw = reinterpret_cast<const int*>(ops.data());
-    const size_t nints = (size_t) n * 7;
-    std::vector<int> key(raw, raw + nints);
-    for (int q = 0; q < nl; ++q) key.push_back(starts[q]);
-    key.push_back(layoutEpoch);
     uint64_t h = 1469598103934665603ull;
     for (int v : key) h = (h ^ (uint64_t) (uint32_t) v) * 1099511628211ull;
     Plan* plan = nullptr;
@@ -1646,6 +1690,7 @@ int Instance::flushWalkG()
             for (int o = 0; o < n && independent; ++o)                  // a buffer one list writes must not be read by another
                 for (int c : {ops[o].child1Partials, ops[o].child2Partials})
                     if (c >= 0 && c < nBuffers && wr[c] >= 0 && wr[c] != listOf[o]) independent = false;
+            if (envVerbose) std::fprintf(stderr, "[mbamd] %d queued lists, %d operations: %s\n", nl, n, independent ? "independent" : "one forest");
         }
         int rc;
         {
