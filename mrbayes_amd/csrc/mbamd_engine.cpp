@@ -2669,6 +2669,7 @@ int beagleCreateInstance(int tipCount, int partialsBufferCount, int compactBuffe
         returnInfo->resourceNumber = dev;
         returnInfo->resourceName = (dev < g_resources.length) ? g_resources.list[dev].name : const_cast<char*>("HIP device");
         returnInfo->implName = const_cast<char*>(first->s4 ? "mbamd HIP gfx950: 4-state tree-walk kernels"
+                                                 : first->wg ? "mbamd HIP gfx950: 20/61-state tree-walk kernels (v_mfma_f32_32x32x2_f32)"
                                                  : first->mfma ? "mbamd HIP gfx950: general-state MFMA (v_mfma_f32_32x32x2_f32) kernels"
                                                                : "mbamd HIP gfx950: general-state vector kernels");
         returnInfo->implDescription = const_cast<char*>("hand-written HIP kernels for AMD CDNA4 (MI355X)");
