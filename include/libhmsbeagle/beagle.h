@@ -333,6 +333,13 @@ BEAGLE_DLLEXPORT int mbamdSynchronize(int instance);
  * (pattern, category) -- beagleGetScaleFactors reports the largest of a pattern's exponents times ln 2; the general-state
  * path keeps one per pattern (every category row is the same). */
 BEAGLE_DLLEXPORT int mbamdGetScaleExponents(int instance, int srcScalingIndex, int* out);
+/* Eigen-systems computed ON THE DEVICE (the host step it replaces: UpDateCijk -> GetEigens, reference
+ * src/likelihood.c:10476-10804, src/utils.c:11201): `count` reversible rate matrices q (count x S x S doubles, row-major,
+ * rows summing to zero; mode 1: symmetric exchangeabilities r_ij instead, Q_ij = r_ij pi_j is built and normalised on the
+ * device) with stationary frequencies pi (all positive) -> [U | U^-1 | lambda] of eigen buffers firstEigenIndex ...
+ * The unmodified MrBayes does not call it (the BEAGLE API takes finished eigen-systems: beagleSetEigenDecomposition);
+ * hosts that own their model code do (mrbayes_amd/likelihood.py, device_eigen=True). */
+BEAGLE_DLLEXPORT int mbamdSetRateMatrices(int instance, int firstEigenIndex, int count, const double* q, const double* pi, int mode);
 /* Last HIP/engine error text of the calling thread ("" if none). */
 BEAGLE_DLLEXPORT const char* mbamdGetLastError(void);
 /* Device-side timing of the partials kernels: accumulates HIP-event time (ms) and launch count of every

@@ -63,7 +63,7 @@ EXPORTS = [
     "beagleGetScaleFactors", "beagleCalculateRootLogLikelihoods", "beagleCalculateEdgeLogLikelihoods",
     "beagleGetSiteLogLikelihoods", "mbamdSynchronize", "mbamdGetLastError", "mbamdKernelTiming",
     "mbamdGetKernelTiming", "mbamdSetKernelPath", "mbamdSetDeferredResult", "mbamdFetchLogLikelihood",
-    "mbamdGetScaleExponents", "mbamdGetChildCount",
+    "mbamdGetScaleExponents", "mbamdGetChildCount", "mbamdSetRateMatrices",
     # BEAGLE v3 surface (multi-partition instances, resource benchmark)
     "beagleGetBenchmarkedResourceList", "beagleSetCPUThreadCount", "beagleSetPatternPartitions",
     "beagleSetCategoryRatesWithIndex", "beagleUpdateTransitionMatricesWithMultipleModels", "beagleUpdatePartialsByPartition",
@@ -220,6 +220,14 @@ class BeagleInstance:
         a, b, c = _d(evec), _d(ivec), _d(evals)
         self._chk(self.lib.beagleSetEigenDecomposition(self.id, idx, a.ctypes.data_as(_dp), b.ctypes.data_as(_dp),
                                                        c.ctypes.data_as(_dp)), "beagleSetEigenDecomposition")
+
+    def set_rate_matrices(self, first, qs, pi, exchangeabilities=False):
+        """Extension: eigen-systems of reversible rate matrices computed on the device (mbamdSetRateMatrices)."""
+        a, b = _d(np.asarray(qs, dtype=np.float64)), _d(pi)
+        n = a.size // (len(b) * len(b))
+        self.lib.mbamdSetRateMatrices.argtypes = [C.c_int, C.c_int, C.c_int, _dp, _dp, C.c_int]
+        self._chk(self.lib.mbamdSetRateMatrices(self.id, first, n, a.ctypes.data_as(_dp), b.ctypes.data_as(_dp),
+                                                1 if exchangeabilities else 0), "mbamdSetRateMatrices")
 
     def set_state_frequencies(self, idx, f):
         a = _d(f)

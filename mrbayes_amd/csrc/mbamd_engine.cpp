@@ -344,6 +344,7 @@ struct Instance {
     int importPartials(int idx, const double* in, bool hasCategories);
     int getPartials(int idx, double* out);
     int setEigen(int idx, const double* U, const double* Ui, const double* lam);
+    int setRateMatrices(int first, int count, const double* q, const double* pi, int mode);
     int updateMatrices(int eigenIndex, const int* probIdx, const double* lengths, int count, int rateSet = 0);
     int setRates(int index, const double* r);
     int setMatrix(int idx, const double* in);
@@ -742,6 +743,46 @@ int Instance::getPartials(int idx, double* out)
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipStreamSynchronize(stream));
     HIP_TRY(hipMemcpy(out, d_tmp, total * sizeof(double), hipMemcpyDeviceToHost));
+    return BEAGLE_SUCCESS;
+}
+
+// Eigen-systems from rate matrices (or exchangeabilities), computed on the device: k_eigen_reversible (mbamd_kernels.h)
+int Instance::setRateMatrices(int first, int count, const double* q, const double* pi, int mode)
+{
+    if (count <= 0) return BEAGLE_SUCCESS;
+    if (first < 0 || first + count > nEigen) return fail(BEAGLE_ERROR_OUT_OF_RANGE, "mbamdSetRateMatrices: eigen index");
+    for (int i = 0; i < S; ++i)
+        if (!(pi[i] > 0.0)) return fail(BEAGLE_ERROR_NO_IMPLEMENTATION, "mbamdSetRateMatrices: a state frequency is not positive (no symmetric form)");
+    const size_t qd = (size_t) count * S * S, bytes = (qd + S) * sizeof(double);
+    int rc = grow(&d_tmp, &tmpCap, bytes);
+    if (rc) return rc;
+    std::vector<double> h(qd + S);
+    std::memcpy(h.data(), q, qd * sizeof(double));
+    std::memcpy(h.data() + qd, pi, (size_t) S * sizeof(double));
+    HIP_TRY(hipStreamSynchronize(stream));                       // (d_tmp may still be read by an earlier import)
+    HIP_TRY(hipMemcpyAsync(d_tmp, h.data(), bytes, hipMemcpyHostToDevice, stream));
+    HIP_TRY(hipStreamSynchronize(stream));
+    std::vector<EigenJob> jobs(count);
+    for (int i = 0; i < count; ++i) {
+        jobs[i].q = reinterpret_cast<const double*>(d_tmp) + (size_t) i * S * S;
+        jobs[i].pi = reinterpret_cast<const double*>(d_tmp) + qd;
+        jobs[i].out = d_eigen + (size_t) (first + i) * eigenDoubles;
+        jobs[i].mode = mode;
+        jobs[i].pad_ = 0;
+    }
+    const EigenJob* djobs = nullptr;
+    rc = stageDirect(jobs.data(), sizeof(EigenJob) * count, (const void**) &djobs);
+    if (rc) return rc;
+    if (S > 64) return fail(BEAGLE_ERROR_NO_IMPLEMENTATION, "mbamdSetRateMatrices: more than 64 states");
+#if !defined(MBAMD_HOST_EMU)
+    static bool ldsRaised = false;
+    if (!ldsRaised) {
+        if (hipFuncSetAttribute((const void*) k_eigen_reversible, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) (void) hipGetLastError();
+        ldsRaised = true;
+    }
+#endif
+    MBAMD_LAUNCH_BARRIER(k_eigen_reversible, (unsigned) count, 256, eigen_lds_doubles(S) * sizeof(double), stream, djobs, S, 30);
+    HIP_TRY(hipGetLastError());
     return BEAGLE_SUCCESS;
 }
 
@@ -2811,6 +2852,17 @@ int beagleSetEigenDecomposition(int instance, int eigenIndex, const double* inEi
     API_TRACE("beagleSetEigenDecomposition(eigen=%d, values=%s...)", eigenIndex, trace_doubles(inEigenValues, std::min(6, in->S)).c_str());
     FACADE_ALL(c->setEigen(eigenIndex, inEigenVectors, inInverseEigenVectors, inEigenValues));
     return in->setEigen(eigenIndex, inEigenVectors, inInverseEigenVectors, inEigenValues);
+}
+// extension: eigen-systems of `count` reversible rate matrices computed on the device and stored in the eigen
+// buffers firstEigenIndex ...; q: count x S x S row-major rates (mode 0) or exchangeabilities (mode 1: Q is built and
+// normalised on the device too); pi: S state frequencies, all positive.  Replaces beagleSetEigenDecomposition + the host's
+// eigen-solver for these models.
+int mbamdSetRateMatrices(int instance, int firstEigenIndex, int count, const double* q, const double* pi, int mode)
+{
+    GET_INSTANCE(instance);
+    if (!q || !pi || (mode != 0 && mode != 1)) return fail(BEAGLE_ERROR_OUT_OF_RANGE, "mbamdSetRateMatrices: arguments");
+    FACADE_ALL(c->setRateMatrices(firstEigenIndex, count, q, pi, mode));
+    return in->setRateMatrices(firstEigenIndex, count, q, pi, mode);
 }
 int beagleSetStateFrequencies(int instance, int idx, const double* f)
 {

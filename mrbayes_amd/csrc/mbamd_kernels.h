@@ -354,6 +354,200 @@ k_transition_matrices_ev(const MatrixJob* __restrict__ jobs, const double* __res
 }
 
 // ---------------------------------------------------------------------------------------------
+// Eigen-systems of reversible rate matrices ON THE DEVICE (replaces the host step UpDateCijk ->
+// GetEigens -> EigensForRealMatrix: balance, Hessenberg, shifted QR, reference src/likelihood.c:10476-10804,
+// src/utils.c:10251-11339, for the models whose Q is reversible -- GTR, every amino-acid matrix, the NY98 codon categories).
+// With d = sqrt(pi), B = D Q D^-1 is symmetric: a cyclic Jacobi iteration in fp64 (round-robin pairing: n/2 disjoint
+// rotations per step, rows then columns, all 256 threads busy) gives B = V L V^T, and
+//     U = D^-1 V,   U^-1 = V^T D,   lambda = diag(L)
+// is what beagleSetEigenDecomposition receives -- written straight into the instance's eigen buffers
+// [U | U^-1 | lambda] (k_transition_matrices_* read them from there).  mode 1: `q` holds exchangeabilities r_ij instead of
+// rates; Q_ij = r_ij pi_j, rows sum to zero, scaled to one expected substitution per unit time (SetProteinQMatrix,
+// src/likelihood.c:8765-8880) -- the Q build on the device as well.
+// One workgroup of 256 threads per matrix, S <= 64; dynamic LDS: eigen_lds_doubles(S) doubles (62 KiB at 61 states).
+// ---------------------------------------------------------------------------------------------
+#if defined(MBAMD_HOST_EMU)
+#define MBAMD_SYNC() mbamd_emu_barrier()
+#else
+#define MBAMD_SYNC() __syncthreads()
+#endif
+struct EigenJob { const double* q; const double* pi; double* out; int mode; int pad_; };
+// n = S rounded up to even (an odd S gets a dummy index whose row and column stay zero: its rotations are identities)
+__host__ __device__ inline size_t eigen_lds_doubles(int S) { const size_t n = (size_t) ((S + 1) & ~1); return 2 * n * (n + 1) + 4 * (n / 2 + 1) + 264; }
+__global__ void __launch_bounds__(256)
+k_eigen_reversible(const EigenJob* __restrict__ jobs, int S, int sweeps)
+{
+#if defined(MBAMD_HOST_EMU)
+    double* lds = reinterpret_cast<double*>(mbamd_emu_dyn_lds());
+#else
+    extern __shared__ double lds_eigen[];
+    double* lds = lds_eigen;
+#endif
+    const EigenJob job = jobs[blockIdx.x];
+    const int n = (S + 1) & ~1, m = n / 2, LD = n + 1;
+    double* A = lds;                         // [n][LD]  the symmetrised matrix, diagonalised in place
+    double* V = A + (size_t) n * LD;         // [n][LD]  accumulated rotations
+    double* rc = V + (size_t) n * LD;        // [m] cosines
+    double* rs = rc + (m + 1);               // [m] sines
+    int* rp = reinterpret_cast<int*>(rs + (m + 1));   // [m] pair (p, q), p < q
+    int* rq = rp + 2 * (m + 1);
+    double* red = rs + (m + 1) + 2 * (m + 1);         // [256 + 8] reduction scratch
+    const int tid = threadIdx.x;
+    const int ty = tid >> 5, tx = tid & 31;  // an 8 x 32 thread grid over (pair | row, pair): no divisions in the loops
+    // ---- B = D Q D^-1, symmetrised (mode 1: Q from exchangeabilities first) ---------------------------------------------
+    double scale = 1.0;
+    if (job.mode == 1) {
+        double part = 0.0;
+        for (int i = ty; i < S; i += 8) {
+            double row = 0.0;
+            for (int j2 = tx; j2 < S; j2 += 32) if (j2 != i) row += job.q[(size_t) i * S + j2] * job.pi[j2];
+            part += job.pi[i] * row;
+        }
+        red[tid] = part;
+        MBAMD_SYNC();
+        if (tid == 0) { double tot = 0.0; for (int t = 0; t < 256; ++t) tot += red[t]; red[256] = 1.0 / tot; }
+        MBAMD_SYNC();
+        scale = red[256];
+        MBAMD_SYNC();
+    }
+    for (int i = ty; i < n; i += 8)
+        for (int j2 = tx; j2 < n; j2 += 32) {
+            double b = 0.0;
+            if (i != j2 && i < S && j2 < S) {
+                const double di = sqrt(job.pi[i]), dj = sqrt(job.pi[j2]);
+                const double qij = job.mode == 1 ? job.q[(size_t) i * S + j2] * job.pi[j2] * scale : job.q[(size_t) i * S + j2];
+                const double qji = job.mode == 1 ? job.q[(size_t) j2 * S + i] * job.pi[i] * scale : job.q[(size_t) j2 * S + i];
+                b = 0.5 * (di * qij / dj + dj * qji / di);
+            }
+            A[i * LD + j2] = b;
+            V[i * LD + j2] = (i == j2) ? 1.0 : 0.0;
+        }
+    MBAMD_SYNC();
+    for (int i = tid; i < S; i += 256) {     // the diagonal: minus the row sum of Q (what makes the rows of Q sum to zero)
+        double row = 0.0;
+        for (int j2 = 0; j2 < S; ++j2)
+            if (j2 != i) row += job.mode == 1 ? job.q[(size_t) i * S + j2] * job.pi[j2] * scale : job.q[(size_t) i * S + j2];
+        A[i * LD + i] = -row;
+    }
+    if (tid == 0) red[259] = 0.0;
+    MBAMD_SYNC();
+    for (int sweep = 0; sweep < sweeps; ++sweep) {
+        for (int r = 0; r < n - 1; ++r) {
+            // round-robin: pair 0 = (n-1, r), pair i = ((r + i) mod (n-1), (r - i) mod (n-1)): n/2 disjoint rotations
+            if (tid < m) {
+                int p = r + tid, q = r - tid;                     // (mod n-1 without a division: r, tid < n-1)
+                if (p >= n - 1) p -= n - 1;
+                if (q < 0) q += n - 1;
+                if (tid == 0) { p = n - 1; q = r; }
+                if (p > q) { const int t = p; p = q; q = t; }
+                double c = 1.0, sn = 0.0;
+                const double apq = A[p * LD + q];
+                if (fabs(apq) > 1e-300) {
+#if defined(MBAMD_HOST_EMU)
+                    const double tau = (A[q * LD + q] - A[p * LD + p]) / (2.0 * apq);
+                    const double t = (tau >= 0.0 ? 1.0 : -1.0) / (fabs(tau) + sqrt(1.0 + tau * tau));
+                    c = 1.0 / sqrt(1.0 + t * t);
+#else
+                    // The ANGLE may be approximate (a Jacobi iteration corrects itself), the rotation must be orthogonal: hardware
+                    // reciprocal / square root for tau and t, one Newton step on the reciprocal square root that normalises (c, s).
+                    // (The correctly rounded divisions and roots were the longest part of a step, on one wave, before a barrier.)
+                    const double tau = (A[q * LD + q] - A[p * LD + p]) * 0.5 * __builtin_amdgcn_rcp(apq);
+                    const double at = fabs(tau);
+                    double t = at < 1e150 ? __builtin_amdgcn_rcp(at + __builtin_amdgcn_sqrt(1.0 + at * at)) : 0.0;
+                    t = tau >= 0.0 ? t : -t;
+                    const double w = 1.0 + t * t;
+                    const double c0 = __builtin_amdgcn_rsq(w);
+                    c = c0 * (1.5 - 0.5 * w * c0 * c0);
+                    c = c * (1.5 - 0.5 * w * c * c);
+#endif
+                    sn = t * c;
+                }
+                rc[tid] = c; rs[tid] = sn; rp[tid] = p; rq[tid] = q;
+            }
+            MBAMD_SYNC();
+            // A <- J^T A J, one 2 x 2 block per (row pair a, column pair b): every element belongs to exactly one block.
+            // All loads of a thread first, then the arithmetic, then all stores: one LDS round trip per step instead of one
+            // per block (the compiler cannot reorder loads over stores to the same array).
+            if (tx < m) {
+                const int p2 = rp[tx], q2 = rq[tx];
+                const double c2 = rc[tx], s2 = rs[tx];
+                double x[4][4], v[8][2];
+                int pa[4], qa[4];
+                double ca[4], sa[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int a = (ty + 8 * u < m) ? ty + 8 * u : m - 1;
+                    pa[u] = rp[a]; qa[u] = rq[a]; ca[u] = rc[a]; sa[u] = rs[a];
+                    x[u][0] = A[pa[u] * LD + p2]; x[u][1] = A[pa[u] * LD + q2];
+                    x[u][2] = A[qa[u] * LD + p2]; x[u][3] = A[qa[u] * LD + q2];
+                }
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const int k = (ty + 8 * u < n) ? ty + 8 * u : n - 1;
+                    v[u][0] = V[k * LD + p2]; v[u][1] = V[k * LD + q2];
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+                    if (ty + 8 * u < m) {
+                        const double y11 = ca[u] * x[u][0] - sa[u] * x[u][2], y12 = ca[u] * x[u][1] - sa[u] * x[u][3];
+                        const double y21 = sa[u] * x[u][0] + ca[u] * x[u][2], y22 = sa[u] * x[u][1] + ca[u] * x[u][3];
+                        A[pa[u] * LD + p2] = c2 * y11 - s2 * y12; A[pa[u] * LD + q2] = s2 * y11 + c2 * y12;
+                        A[qa[u] * LD + p2] = c2 * y21 - s2 * y22; A[qa[u] * LD + q2] = s2 * y21 + c2 * y22;
+                    }
+#pragma unroll
+                for (int u = 0; u < 8; ++u)
+                    if (ty + 8 * u < n) {                         // V <- V J
+                        const int k = ty + 8 * u;
+                        V[k * LD + p2] = c2 * v[u][0] - s2 * v[u][1];
+                        V[k * LD + q2] = s2 * v[u][0] + c2 * v[u][1];
+                    }
+            }
+            MBAMD_SYNC();
+        }
+        // converged?  (sum of squared off-diagonal elements against the squared diagonal)
+        double off = 0.0, diag = 0.0;
+        for (int i = ty; i < n; i += 8)
+            for (int j2 = tx; j2 < n; j2 += 32) { const double v = A[i * LD + j2]; if (i == j2) diag += v * v; else off += v * v; }
+#if !defined(MBAMD_HOST_EMU)
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) { off += __shfl_down(off, o); diag += __shfl_down(diag, o); }
+        if ((tid & 63) == 0) { red[tid >> 6] = off; red[8 + (tid >> 6)] = diag; }
+        MBAMD_SYNC();
+        if (tid == 0) {
+            const double o4 = (red[0] + red[1]) + (red[2] + red[3]), d4 = (red[8] + red[9]) + (red[10] + red[11]);
+#else
+        red[tid] = off;
+        MBAMD_SYNC();
+        if (tid == 0) { double t = 0.0; for (int u = 0; u < 256; ++u) t += red[u]; red[257] = t; }
+        MBAMD_SYNC();
+        red[tid] = diag;
+        MBAMD_SYNC();
+        if (tid == 0) {
+            double d4 = 0.0;
+            for (int u = 0; u < 256; ++u) d4 += red[u];
+            const double o4 = red[257];
+#endif
+            // (quadratic convergence: once the off-diagonal mass is below 1e-20 of the diagonal's, one more sweep takes it to rounding)
+            red[258] = (o4 <= 1e-20 * d4) ? red[259] + 1.0 : 0.0;
+            red[259] = red[258];
+        }
+        MBAMD_SYNC();
+        if (red[258] >= 2.0) break;
+    }
+    // ---- U = D^-1 V, U^-1 = V^T D, lambda ------------------------------------------------------------------------------
+    double* U = job.out;
+    double* Ui = job.out + (size_t) S * S;
+    double* lam = job.out + (size_t) 2 * S * S;
+    for (int i = ty; i < S; i += 8)
+        for (int s2 = tx; s2 < S; s2 += 32) {
+            const double di = sqrt(job.pi[i]);
+            U[(size_t) i * S + s2] = V[i * LD + s2] / di;
+            Ui[(size_t) s2 * S + i] = V[i * LD + s2] * di;
+        }
+    for (int i = tid; i < S; i += 256) lam[i] = A[i * LD + i];
+}
+
+// ---------------------------------------------------------------------------------------------
 // Root / edge integration (Likelihood_*; BEAGLE calculateRoot/EdgeLogLikelihoods semantics,
 // SURVEY Appendix B).  One thread per pattern:
 //   L_n = sum_k w_nk sum_i pi_ni parent_n[k,c,i] * (sum_j P_nk[i,j] child_n[k,c,j])    (edge)

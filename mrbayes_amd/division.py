@@ -34,6 +34,7 @@ class Division:
     pinvar: float = 0.0
     inv_condlikes: Optional[np.ndarray] = None   # [P][S] float32: invariable-site conditional likelihoods
     brlen_factor: float = 1.0          # GenCov: t = length*correction with no category rate
+    rate_matrices: Optional[List[np.ndarray]] = None   # the Q behind each eigen part (device-side eigen: mbamdSetRateMatrices)
 
     @property
     def npatterns(self) -> int:
@@ -99,20 +100,23 @@ def build_division(kind: str, tree, weights, tip_states, tip_partials, *, revmat
     if kind == "gtr":
         s = 4
         pi = np.asarray(pi, dtype=np.float64)
-        eig = [mbmodel.eigen_reversible(mbmodel.gtr_q(revmat, pi), pi)]
+        qmats = [mbmodel.gtr_q(revmat, pi)]
+        eig = [mbmodel.eigen_reversible(qmats[0], pi)]
         corr = 1.0
         part_w = np.ones(1)
     elif kind == "wag":
         s = 20
         exch, wpi = wag
         pi = wpi / wpi.sum() if pi is None else np.asarray(pi, dtype=np.float64)
-        eig = [mbmodel.eigen_reversible(mbmodel.exchangeability_q(exch, pi), pi)]
+        qmats = [mbmodel.exchangeability_q(exch, pi)]
+        eig = [mbmodel.eigen_reversible(qmats[0], pi)]
         corr = 1.0
         part_w = np.ones(1)
     elif kind == "m3":
         s = 61
         pi = np.full(61, 1.0 / 61) if (pi is None or isinstance(pi, str)) else np.asarray(pi, dtype=np.float64)
         qs = mbmodel.m3_qs(omegas, omega_freqs, pi, nst=nst, rates=revmat)
+        qmats = list(qs)
         eig = [mbmodel.eigen_reversible(q, pi) for q in qs]
         corr = 3.0                                   # codon correction factor, src/mbbeagle.c:1385-1386
         part_w = np.asarray(omega_freqs, dtype=np.float64)
@@ -124,7 +128,7 @@ def build_division(kind: str, tree, weights, tip_states, tip_partials, *, revmat
         base_rate /= (1.0 - pinvar)                  # src/mbbeagle.c:1393-1395
     inv = _inv_condlikes(tip_states, tip_partials, s, npat) if pinvar > 0.0 else None
     return Division(s, ncat, tree, np.asarray(weights, dtype=np.float64), tip_states, tip_partials, eig, pi,
-                    base_rate * rates * corr, part_w, pinvar, inv, corr)
+                    base_rate * rates * corr, part_w, pinvar, inv, corr, qmats)
 
 
 def division_from_golden(golden_dir: str, case: str) -> Division:

@@ -38,8 +38,9 @@ class BeagleDivision:
     """ModelInfo-like state of one division driven through the BEAGLE ABI for `nchains` local chains."""
 
     def __init__(self, div: Division, lib: Optional[bg.BeagleLibrary] = None, nchains: int = 1,
-                 scaling: int = MB_BEAGLE_SCALE_ALWAYS, resource: Optional[int] = None):
+                 scaling: int = MB_BEAGLE_SCALE_ALWAYS, resource: Optional[int] = None, device_eigen: bool = False):
         self.div = div
+        self.device_eigen = device_eigen and div.rate_matrices is not None and bool(np.all(np.asarray(div.pi) > 0))
         self.lib = lib or bg.library()
         self.nchains = nchains
         self.scaling = scaling
@@ -177,8 +178,13 @@ class BeagleDivision:
     # ---- UpDateCijk (BEAGLE branch, src/likelihood.c:10636-10660, 10736-10757) ----------------------
     def UpDateCijk(self, chain):
         self.FlipCijkSpace(chain)
-        for i, es in enumerate(self.div.eigen):
-            self.inst.set_eigen_decomposition(self.cijkIndex[chain] + i, es.evec, es.ivec, es.eval)
+        if self.device_eigen:
+            # extension: the eigen-systems are computed on the device from the rate matrices -- an
+            # unmodified MrBayes has no call for this, it sends finished eigen-systems like the branch below
+            self.inst.set_rate_matrices(self.cijkIndex[chain], np.stack(self.div.rate_matrices), self.div.pi)
+        else:
+            for i, es in enumerate(self.div.eigen):
+                self.inst.set_eigen_decomposition(self.cijkIndex[chain] + i, es.evec, es.ivec, es.eval)
         self.upDateAll[chain] = True
 
     # ---- TreeTiProbs_Beagle ------------------------------------------------------------------------

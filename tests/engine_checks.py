@@ -85,6 +85,49 @@ def check_closed_form_matrices(lib, oracle):
             bd.finalize()
 
 
+def check_device_eigen(lib, kind):
+    """mbamdSetRateMatrices: eigen-systems computed on the device by a Jacobi iteration on the symmetrised
+    rate matrix.  The transition matrices built from them must be exp(Q t) -- checked against scipy's Pade expm, which shares
+    nothing with either eigen-solver -- and the tree likelihood must be the one the host's eigen-systems give.  Also the
+    exchangeability form (Q built and normalised on the device)."""
+    from scipy.linalg import expm
+    from mrbayes_amd.division import synthetic_division
+    from mrbayes_amd import model as mbmodel
+    div = synthetic_division(kind, 14, 60, seed=17, tree_seed=18, p_gap=0.02)
+    host = lk.BeagleDivision(div, lib)
+    dev = lk.BeagleDivision(div, lib, device_eigen=True)
+    try:
+        assert dev.device_eigen
+        a, b = host.LogLike(0), dev.LogLike(0)
+        assert abs(a - b) <= 1e-9 * abs(a), (a, b)
+        t = div.tree
+        S = div.nstates
+        for p in t.all_down_pass[:6]:
+            if p == t.root:
+                continue
+            length = min(max(t.length[p], lk.BRLENS_MIN), lk.BRLENS_MAX)
+            for part, q in enumerate(div.rate_matrices):
+                got = dev.inst.get_transition_matrix(dev.tiProbsIndex[0][p] + part)
+                for k, r in enumerate(div.cat_rates):
+                    want = expm(q * (length * r))
+                    assert np.allclose(got[k], want, rtol=2e-5, atol=3e-7), (kind, p, part, k, np.abs(got[k] - want).max())
+        if kind == "wag":                            # exchangeabilities in, Q built on the device
+            exch = div.rate_matrices[0] / np.asarray(div.pi)[None, :]
+            np.fill_diagonal(exch, 0.0)
+            exch = 0.5 * (exch + exch.T) * 3.7       # any scale: the device normalises to one substitution per unit time
+            dev.inst.set_rate_matrices(dev.cijkIndex[0], exch[None], div.pi, exchangeabilities=True)
+            idx = dev.tiProbsIndex[0][t.all_down_pass[0]]
+            length = min(max(t.length[t.all_down_pass[0]], lk.BRLENS_MIN), lk.BRLENS_MAX)
+            dev.inst.set_category_rates(div.cat_rates)
+            dev.inst.update_transition_matrices(dev.cijkIndex[0], np.asarray([idx], dtype=np.int32), [length])
+            got = dev.inst.get_transition_matrix(idx)
+            want = expm(div.rate_matrices[0] * (length * div.cat_rates[0]))
+            assert np.allclose(got[0], want, rtol=2e-5, atol=3e-7), np.abs(got[0] - want).max()
+    finally:
+        host.finalize()
+        dev.finalize()
+
+
 def check_root_equals_edge(lib, oracle, div, scaling=lk.MB_BEAGLE_SCALE_ALWAYS):
     """beagleCalculateRootLogLikelihoods (rooted / clock trees, reference src/mbbeagle.c:1251-1257) against the edge form
     MrBayes uses for unrooted trees: fold the root branch into one more partials operation (identity matrix for the

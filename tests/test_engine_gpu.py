@@ -367,6 +367,12 @@ def test_protein_other_category_counts(gpu, oracle, ncat):
     ec.check_partial_update_and_reject(gpu, oracle, div, scaling=lk.MB_BEAGLE_SCALE_ALWAYS)
 
 
+@pytest.mark.parametrize("kind", ["gtr", "wag", "m3"])
+def test_device_eigen(gpu, kind):
+    """Eigen-systems from rate matrices on the device (mbamdSetRateMatrices, k_eigen_reversible)."""
+    ec.check_device_eigen(gpu, kind)
+
+
 @pytest.mark.parametrize("case", ["replicase_m3", "avian_wag_g4", "synth_aa_wag"])
 def test_general_state_tree_walk_schedules_agree(gpu, golden_dir, monkeypatch, case):
     """20/61-state tree walk (k_walkg): waves per workgroup, LDS slots (children re-read from HBM instead), lists run one by

@@ -134,6 +134,11 @@ def test_walk_schedule(emu, oracle, monkeypatch, waves, slots, prefetch):
     assert abs(got - want) / abs(want) < ec.REL_FP64
 
 
+@pytest.mark.parametrize("kind", ["gtr", "wag", "m3"])
+def test_device_eigen(emu, kind):
+    ec.check_device_eigen(emu, kind)
+
+
 @pytest.mark.parametrize("model", ["wag", "m3"])
 @pytest.mark.parametrize("waves,slots", [(2, 3), (4, 3), (8, 4), (2, 12)])
 def test_general_walk_schedule(emu, oracle, monkeypatch, model, waves, slots):
