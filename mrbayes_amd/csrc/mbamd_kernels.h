@@ -702,74 +702,12 @@ k_integrate_lnl_s4(IntegrateArgs4 a, int K, int P, int Ppad, BlockGeom g,
 
 // 20/61-state tree-walk layout (mbamd_walkg.h): partials float [tile][buffer][K][T][64], tip states uint8 [tile][buffer][32],
 // cumulative exponents per (pattern, category) like the 4-state path.  Same arithmetic as k_integrate_lnl, the categories
-// recombined as in k_integrate_lnl_s4.  One thread per pattern (host-emulation build).
+// recombined as in k_integrate_lnl_s4: k_integrate_lnl_wg_wide (mbamd_kernels_mfma.h; the host-emulation build has a one-thread-
+// per-pattern twin in tests/hostemu/mbamd_walkg_emu.h).
 struct WgGeom { unsigned long tileFloats; unsigned tipTileBytes; int TP; };
-#if defined(MBAMD_HOST_EMU)      // (the GPU build integrates with k_integrate_lnl_wg_wide, mbamd_kernels_mfma.h: eight threads per pattern)
-__global__ void __launch_bounds__(64)
-k_integrate_lnl_wg(IntegrateArgs4 a, int S, int SP, int K, int P, int Ppad, WgGeom g,
-                   const double* __restrict__ pattern_weights, double* __restrict__ site, double* __restrict__ wsite)
-{
-    const int c = blockIdx.x * 64 + threadIdx.x;
-    const size_t pb = (size_t) (c >> 5) * g.tileFloats;                         // float index of (tile, category 0) of the buffer
-    const size_t kstride = (size_t) g.TP * 64;
-    const int p = c & 31;
-    double wl = 0.0;
-    if (c < P) {
-        int emax = -2147483647;
-        for (int n = 0; n < a.count; ++n)
-            for (int k = 0; k < K; ++k) {
-                const int e = a.cum[n] ? a.cum[n][(size_t) k * Ppad + c] : 0;
-                emax = e > emax ? e : emax;
-            }
-        double total = 0.0;
-        for (int n = 0; n < a.count; ++n) {
-            const double* __restrict__ pi = a.freqs[n];
-            const float* __restrict__ par = reinterpret_cast<const float*>(a.parent[n]) + pb;
-            unsigned s = 0;
-            if (a.child[n] != nullptr && a.child_kind[n] == CHILD_STATES)
-                s = reinterpret_cast<const uint8_t*>(a.child[n])[(size_t) (c >> 5) * g.tipTileBytes + (c & 31)];
-            for (int k = 0; k < K; ++k) {
-                const float* __restrict__ pk = par + (size_t) k * kstride;
-                double cat = 0.0;
-                if (a.child[n] == nullptr) {
-                    for (int i = 0; i < S; ++i) cat += (double) pk[wg_elem(S, i, p)] * pi[i];
-                } else if (a.child_kind[n] == CHILD_STATES) {
-                    const float* __restrict__ mrow = a.matrix[n] + (size_t) k * SP * SP + (size_t) (s < (unsigned) S ? s : 0) * SP;
-                    for (int i = 0; i < S; ++i) {
-                        const float pc = (s >= (unsigned) S) ? 1.0f : mrow[i];
-                        cat += (double) (pk[wg_elem(S, i, p)] * pc) * pi[i];
-                    }
-                } else {
-                    const float* __restrict__ ch = reinterpret_cast<const float*>(a.child[n]) + pb + (size_t) k * kstride;
-                    const float* __restrict__ m = a.matrix[n] + (size_t) k * SP * SP;
-                    for (int i = 0; i < S; ++i) {
-                        float acc = 0.0f;
-                        for (int j = 0; j < S; ++j) acc = fmaf(m[(size_t) j * SP + i], ch[wg_elem(S, j, p)], acc);
-                        cat += (double) (pk[wg_elem(S, i, p)] * acc) * pi[i];
-                    }
-                }
-                const int e = a.cum[n] ? a.cum[n][(size_t) k * Ppad + c] : 0;
-                total += ldexp(cat * a.weights[n][k], e - emax);
-            }
-        }
-        const double lnl = log(total) + (double) emax * 0.69314718055994530942;
-        site[c] = lnl;
-        wl = lnl * pattern_weights[c];
-    } else if (c < Ppad) {
-        site[c] = 0.0;
-    }
 #if defined(MBAMD_HOST_EMU)
-    if (threadIdx.x == 0) wsite[blockIdx.x] = 0.0;
-    wsite[blockIdx.x] += wl;
-#else
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) wl += __shfl_down(wl, off);
-    if (threadIdx.x == 0) wsite[blockIdx.x] = wl;
+#include "mbamd_integrate_wg_emu.h"   // tests/hostemu/ (test build only)
 #endif
-}
-
-#endif
-
 // ---------------------------------------------------------------------------------------------
 // cumulative scale-factor bookkeeping (exact integer arithmetic)
 // ---------------------------------------------------------------------------------------------

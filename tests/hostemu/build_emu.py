@@ -10,7 +10,7 @@ OUT = os.path.join(HERE, "_build", "libmbamd_hostemu_TESTONLY.so")
 
 def build():
     csrc = os.path.join(ROOT, "mrbayes_amd", "csrc")
-    deps = [os.path.join(csrc, f) for f in os.listdir(csrc)] + [os.path.join(HERE, "hip_emu.h"),
+    deps = [os.path.join(csrc, f) for f in os.listdir(csrc)] + [os.path.join(HERE, "hip_emu.h"), os.path.join(HERE, "mbamd_walkg_emu.h"), os.path.join(HERE, "mbamd_integrate_wg_emu.h"),
                                                                os.path.join(ROOT, "include", "libhmsbeagle", "beagle.h")]
     if os.path.exists(OUT) and all(os.path.getmtime(d) <= os.path.getmtime(OUT) for d in deps):
         return OUT
