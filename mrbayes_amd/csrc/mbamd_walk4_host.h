@@ -22,6 +22,7 @@
 #define MBAMD_WALK4_HOST_H_
 
 #include <algorithm>
+#include <functional>
 #include <cstdint>
 #include <cstring>
 #include <queue>
@@ -192,9 +193,41 @@ inline bool Walk4Builder::build(const std::vector<Walk4Op>& ops, Walk4Template& 
         for (int r : roots) heap.push(r);
         const int target = (remaining + W - 1) / W;
         int splits = 0, capSize = 0;
-        while (!heap.empty() && splits < 16 * W) {
+        // Every split moves one node into the cap -- the next, partly serial phase -- and makes the pieces pack better.
+        // Dry run: the cost (fullest bin + cap) after every split; then split exactly as often as the cheapest point says.
+        auto fullestBin = [&](const std::vector<int>& nodes) {
+            std::vector<int> pieces;
+            for (int v : nodes) pieces.push_back(size[v]);
+            std::sort(pieces.begin(), pieces.end(), std::greater<int>());
+            std::vector<int> load(W, 0);
+            for (int sz : pieces) *std::min_element(load.begin(), load.end()) += sz;
+            return *std::max_element(load.begin(), load.end());
+        };
+        int bestSplits = 0;
+        {
+            auto dry = heap;
+            std::vector<int> nodes;
+            { auto c2 = dry; while (!c2.empty()) { nodes.push_back(c2.top()); c2.pop(); } }
+            long bestCost = (long) fullestBin(nodes) + 0;
+            if ((int) nodes.size() < W) bestCost = 1L << 40;          // (fewer pieces than bins: keep splitting)
+            int k = 0, capNow = 0;
+            while (!dry.empty() && k < 16 * W) {
+                const int v = dry.top();
+                if (size[v] <= std::max(target / 3, 4)) break;
+                dry.pop();
+                ++k; ++capNow;
+                nodes.erase(std::find(nodes.begin(), nodes.end(), v));
+                int a = prod1[v], b = (prod2[v] != prod1[v]) ? prod2[v] : -1;
+                if (a >= 0 && phaseOf[a] < 0 && parent[a] == v) { dry.push(a); nodes.push_back(a); }
+                if (b >= 0 && phaseOf[b] < 0 && parent[b] == v) { dry.push(b); nodes.push_back(b); }
+                if ((int) nodes.size() < W) continue;
+                // the cap runs on one wave (the others wait): its operations count fully; + the barrier entry
+                const long cost = (long) fullestBin(nodes) + capNow + 1;
+                if (cost < bestCost) { bestCost = cost; bestSplits = k; }
+            }
+        }
+        while (!heap.empty() && splits < bestSplits) {
             const int v = heap.top();
-            if (size[v] <= std::max(target / 3, 4)) break;
             heap.pop();
             cap[v] = 1; ++capSize; ++splits;
             int a = prod1[v], b = (prod2[v] != prod1[v]) ? prod2[v] : -1;
