@@ -37,9 +37,6 @@
 
 #include <chrono>
 
-#if !defined(MBAMD_WG_DEPTH20)
-#define MBAMD_WG_DEPTH20 2
-#endif
 namespace mbamd {
 
 // MBAMD_STATS=1: per-entry-point call counts and host wall time, printed when an instance is finalized
@@ -96,6 +93,31 @@ static int fail(int code, const char* what, const char* detail = "")
     } while (0)
 
 static inline int round_up(int v, int m) { return (v + m - 1) / m * m; }
+
+// state counts the 20/61-state tree walk (mbamd_walkg.h) is instantiated for: amino acids, doublets, and the sense codons of
+// every genetic code MrBayes knows (60 vertebrate mitochondrial ... 63; reference src/model.c SetCode)
+static inline bool wg_compiled(int S) { return S == 16 || S == 20 || (S >= 60 && S <= 63); }
+// FN<SC, WMAX, CH, DEPTH>: one row tile -> whole jobs two ahead; two row tiles -> half jobs one ahead (see k_walkg)
+#define MBAMD_WG_DISPATCH(S, FN, ...)                                   \
+    switch (S) {                                                        \
+        case 16: FN<16, 8, 1, 2>(__VA_ARGS__); break;                   \
+        case 20: FN<20, 8, 1, 2>(__VA_ARGS__); break;                   \
+        case 60: FN<60, 4, 2, 1>(__VA_ARGS__); break;                   \
+        case 61: FN<61, 4, 2, 1>(__VA_ARGS__); break;                   \
+        case 62: FN<62, 4, 2, 1>(__VA_ARGS__); break;                   \
+        default: FN<63, 4, 2, 1>(__VA_ARGS__); break;                   \
+    }
+
+template <int SC_, int WMAX_, int CH_, int DEPTH_>
+static void raise_walkg_lds(int maxLds)
+{
+#if !defined(MBAMD_HOST_EMU)
+    if (hipFuncSetAttribute((const void*) k_walkg<SC_, WMAX_, CH_, DEPTH_>, hipFuncAttributeMaxDynamicSharedMemorySize, maxLds) != hipSuccess)
+        (void) hipGetLastError();
+#else
+    (void) maxLds;
+#endif
+}
 
 enum KernelPath { PATH_AUTO = 0, PATH_GENERIC = 1, PATH_WALK = 2, PATH_MFMA = 3 };
 
@@ -419,7 +441,7 @@ int Instance::create(int tipCount_, int partialsBufferCount, int compactBufferCo
     // 20 / 61 states: the tree-walk kernel on the matrix cores (MBAMD_NO_WALKG=1: the level kernels of mbamd_kernels_mfma.h)
     {
         const size_t tb = wg_block_bytes(S), mf = (size_t) K * 64 * 64 + (size_t) K * wg_table_floats(S);
-        wg = !s4 && (S == 20 || S == 61) && K <= 16 && !forceGeneric && std::getenv("MBAMD_NO_WALKG") == nullptr &&
+        wg = !s4 && wg_compiled(S) && K <= 16 && !forceGeneric && std::getenv("MBAMD_NO_WALKG") == nullptr &&
              (size_t) (nBuffers + 1) * K * tb < ((size_t) 1 << 32) && (size_t) nMatrices * mf * 4 < ((size_t) 1 << 32) &&
              (size_t) (nScale + 1) * K * 64 < ((size_t) 1 << 32) && (size_t) nBuffers * 32 < ((size_t) 1 << 32);
     }
@@ -587,9 +609,7 @@ int Instance::configureWalk()
         // one wave = (32-pattern tile, category); registers bound the residency: 20 states 4 waves per SIMD, 61 states 2
         const unsigned slotBytes = wg_block_bytes(S);
 #if !defined(MBAMD_HOST_EMU)
-        hipError_t aerr = S == 61 ? hipFuncSetAttribute((const void*) k_walkg<61, 4, 2, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, maxLds)
-                                  : hipFuncSetAttribute((const void*) k_walkg<20, 8, 1, MBAMD_WG_DEPTH20>, hipFuncAttributeMaxDynamicSharedMemorySize, maxLds);
-        if (aerr != hipSuccess) (void) hipGetLastError();
+        MBAMD_WG_DISPATCH(S, raise_walkg_lds, maxLds);
 #endif
         wgGeometry(1, w4.maxW, w4.maxSlots);
         w4.maxSlots1 = w4.maxSlots;
@@ -638,7 +658,7 @@ void Instance::wgGeometry(int lists, int& W, int& slots) const
     if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0) numCU = prop.multiProcessorCount;
 #endif
     // registers bound the residency: 20 states 4 waves per SIMD, 61 states 2
-    const int maxW = S == 61 ? 4 : 8, wavesPerCU = S == 61 ? 6 : 12;
+    const int maxW = S > 32 ? 4 : 8, wavesPerCU = S > 32 ? 6 : 12;
     const int slotBytes = (int) wg_block_bytes(S);
     const long wgs = (long) (Ppad / 32) * K * lists;
     const int perCU = (int) std::max(1L, (wgs + numCU - 1) / numCU);
@@ -1808,8 +1828,7 @@ int Instance::runWalkG(const Plan& plan)
             a.trace = sg.entries <= 4096 ? d_trace : nullptr;
             lastWalkSteps = sg.entries - MBAMD_WG_TAIL; walkWaves = sg.W - 1;
         }
-        if (S == 61) launch_walkg_t<61, 4, 2, 1>(*this, a, sg.W, sg.nslots);
-        else launch_walkg_t<20, 8, 1, MBAMD_WG_DEPTH20>(*this, a, sg.W, sg.nslots);
+        MBAMD_WG_DISPATCH(S, launch_walkg_t, *this, a, sg.W, sg.nslots);
         HIP_TRY(hipGetLastError());
         pendingLaunches += 1;
     }

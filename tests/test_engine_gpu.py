@@ -45,7 +45,8 @@ def test_transition_matrices(gpu, oracle, golden_dir, case):
 @pytest.mark.parametrize("nstates,ncat,npat", [(4, 4, 100), (4, 1, 64), (4, 3, 65), (4, 8, 130), (20, 4, 70),
                                                  (20, 1, 200), (61, 1, 33), (61, 1, 129), (61, 3, 40),
                                                  (16, 2, 10), (2, 4, 5), (20, 4, 1), (4, 4, 1),
-                                                 (20, 3, 95), (20, 2, 64), (61, 2, 70), (33, 1, 50), (5, 4, 40), (64, 1, 31)])
+                                                 (20, 3, 95), (20, 2, 64), (61, 2, 70), (33, 1, 50), (5, 4, 40), (64, 1, 31),
+                                                 (60, 1, 45), (62, 2, 33), (63, 1, 70), (16, 4, 97)])
 def test_single_operations(gpu, oracle, nstates, ncat, npat):
     ec.check_single_operations(gpu, oracle, nstates, ncat, npat)
 

@@ -34,7 +34,7 @@ def test_transition_matrices(emu, oracle, golden_dir, case):
 
 
 @pytest.mark.parametrize("nstates,ncat,npat", [(4, 4, 100), (4, 1, 64), (4, 3, 65), (20, 4, 70), (61, 1, 33),
-                                                 (16, 2, 10), (2, 4, 5)])
+                                                 (16, 2, 10), (2, 4, 5), (60, 1, 45), (63, 2, 33), (16, 4, 40)])
 def test_single_operations(emu, oracle, nstates, ncat, npat):
     ec.check_single_operations(emu, oracle, nstates, ncat, npat)
 
