@@ -183,6 +183,7 @@ struct Instance {
     int tipCount = 0, nBuffers = 0, S = 0, SP = 0, P = 0, Ppad = 0, nEigen = 0, nMatrices = 0, K = 0, nScale = 0;
     bool s4 = false;                 // 4-state float4 layout + tree-walk kernel
     bool wg = false;                 // 20/61-state tree-walk kernel on the matrix cores (mbamd_walkg.h) + its arenas
+    bool noWalkG = false;            // the arenas of that path did not fit: level kernels with buffers allocated on first use
     bool arena() const { return s4 || wg; }   // buffers are slices of arenas, exponents are per (pattern, category)
     bool mfma = false;               // general-state path on the matrix cores (mbamd_kernels_mfma.h)
     bool mfmaWhole = false;          // MBAMD_MFMA_WHOLE: one wave per (operation, 32 patterns) instead of per factor tile
@@ -410,6 +411,27 @@ static bool launch_tips(Instance& in, const OpTables& tabs, int count);
 static std::mutex g_mutex;
 static std::vector<Instance*> g_instances;
 
+// A new engine for one device.  The 20/61-state tree walk allocates every buffer up front (arenas); if that does not fit,
+// the same instance is set up once more on the level kernels, which allocate a buffer when it is first written.
+static int new_engine(Instance*& out, long flags, int tipCount, int partialsBufferCount, int compactBufferCount, int stateCount,
+                      int patternCount, int eigenBufferCount, int matrixBufferCount, int categoryCount, int scaleBufferCount, int dev)
+{
+    for (int attempt = 0; attempt < 2; ++attempt) {
+        Instance* c = new Instance();
+        c->flags = flags;
+        c->noWalkG = attempt == 1;
+        const int rc = c->create(tipCount, partialsBufferCount, compactBufferCount, stateCount, patternCount, eigenBufferCount,
+                                 matrixBufferCount, categoryCount, scaleBufferCount, dev);
+        if (rc == BEAGLE_SUCCESS) { out = c; return rc; }
+        const bool retry = rc == BEAGLE_ERROR_OUT_OF_MEMORY && c->wg && attempt == 0;
+        c->destroy();
+        delete c;
+        (void) hipGetLastError();
+        if (!retry) return rc;
+    }
+    return BEAGLE_ERROR_OUT_OF_MEMORY;
+}
+
 static Instance* lookup(int id)
 {
     std::lock_guard<std::mutex> lk(g_mutex);
@@ -441,7 +463,7 @@ int Instance::create(int tipCount_, int partialsBufferCount, int compactBufferCo
     // 20 / 61 states: the tree-walk kernel on the matrix cores (MBAMD_NO_WALKG=1: the level kernels of mbamd_kernels_mfma.h)
     {
         const size_t tb = wg_block_bytes(S), mf = (size_t) K * 64 * 64 + (size_t) K * wg_table_floats(S);
-        wg = !s4 && wg_compiled(S) && K <= 16 && !forceGeneric && std::getenv("MBAMD_NO_WALKG") == nullptr &&
+        wg = !s4 && wg_compiled(S) && K <= 16 && !forceGeneric && !noWalkG && std::getenv("MBAMD_NO_WALKG") == nullptr &&
              (size_t) (nBuffers + 1) * K * tb < ((size_t) 1 << 32) && (size_t) nMatrices * mf * 4 < ((size_t) 1 << 32) &&
              (size_t) (nScale + 1) * K * 64 < ((size_t) 1 << 32) && (size_t) nBuffers * 32 < ((size_t) 1 << 32);
     }
@@ -2491,12 +2513,11 @@ int Instance::makeChildren(const std::vector<std::pair<int, int>>& ranges)
             const int b0 = (int) ((long) blocks * i / g), b1 = (int) ((long) blocks * (i + 1) / g);
             const int n = (i == g - 1) ? count - done : (b1 - b0) * 64;
             if (n <= 0) continue;
-            Instance* c = new Instance();
-            c->flags = flags;
+            Instance* c = nullptr;
             const int dev = shardDevices.empty() ? device : shardDevices[i % shardDevices.size()];
-            int rc = c->create(createArgs[0], createArgs[1], createArgs[2], createArgs[3], n, createArgs[5], createArgs[6],
-                               createArgs[7], createArgs[8], dev);
-            if (rc) { c->destroy(); delete c; destroyChildren(); return rc; }
+            int rc = new_engine(c, flags, createArgs[0], createArgs[1], createArgs[2], createArgs[3], n, createArgs[5], createArgs[6],
+                                createArgs[7], createArgs[8], dev);
+            if (rc) { destroyChildren(); return rc; }
             c->logOpen = false;
             children.push_back(Child{c, start + done, n, (int) p});
             done += n;
@@ -2707,6 +2728,20 @@ int beagleCreateInstance(int tipCount, int partialsBufferCount, int compactBuffe
         in->shardDevices.assign(1, dev);
         rc = in->create(tipCount, partialsBufferCount, compactBufferCount, stateCount, patternCount, eigenBufferCount,
                         matrixBufferCount, categoryCount, scaleBufferCount, dev);
+        if (rc == BEAGLE_ERROR_OUT_OF_MEMORY && in->wg) {
+            // the arenas of the 20/61-state tree walk did not fit: once more on the level kernels (buffers allocated on first use)
+            const long fl = in->flags;
+            in->destroy();
+            delete in;
+            (void) hipGetLastError();
+            in = new Instance();
+            in->flags = fl;
+            in->noWalkG = true;
+            std::memcpy(in->createArgs, args, sizeof args);
+            in->shardDevices.assign(1, dev);
+            rc = in->create(tipCount, partialsBufferCount, compactBufferCount, stateCount, patternCount, eigenBufferCount,
+                            matrixBufferCount, categoryCount, scaleBufferCount, dev);
+        }
     }
     if (rc != BEAGLE_SUCCESS) {
         in->destroyChildren();

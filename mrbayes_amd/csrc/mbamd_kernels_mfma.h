@@ -916,6 +916,7 @@ k_integrate_lnl_wg_wide(IntegrateArgs4 a, int S, int SP, int K, int P, int Ppad,
 {
     __shared__ double part[8][32];
     const int p = threadIdx.x & 31, g = threadIdx.x >> 5;
+    const int sh = S > 32 ? 2 : 1;                   // rows interleaved per lane: wg_vec(S) = 1 << sh
     const int c = blockIdx.x * 32 + p;
     const bool live = c < P;
     const size_t pb = (size_t) blockIdx.x * geo.tileFloats, kstride = (size_t) geo.TP * 64;
@@ -943,7 +944,7 @@ k_integrate_lnl_wg_wide(IntegrateArgs4 a, int S, int SP, int K, int P, int Ppad,
 #pragma unroll
                         for (int u = 0; u < 8; ++u) {
                             const int i = i0 + g + 8 * u;
-                            v[u] = (i < S) ? pk[wg_elem(S, i, p)] : 0.0f;
+                            v[u] = (i < S) ? pk[wg_elem_sh(sh, i, p)] : 0.0f;
                             f[u] = (i < S) ? fr[i] : 0.0;
                         }
 #pragma unroll
@@ -953,15 +954,15 @@ k_integrate_lnl_wg_wide(IntegrateArgs4 a, int S, int SP, int K, int P, int Ppad,
                     const float* __restrict__ mrow = a.matrix[n] + (size_t) k * SP * SP + (size_t) (s < (unsigned) S ? s : 0) * SP;
                     for (int i = g; i < S; i += 8) {
                         const float pc = (s >= (unsigned) S) ? 1.0f : mrow[i];
-                        cat += (double) (pk[wg_elem(S, i, p)] * pc) * fr[i];
+                        cat += (double) (pk[wg_elem_sh(sh, i, p)] * pc) * fr[i];
                     }
                 } else {
                     const float* __restrict__ ch = reinterpret_cast<const float*>(a.child[n]) + pb + (size_t) k * kstride;
                     const float* __restrict__ m = a.matrix[n] + (size_t) k * SP * SP;
                     for (int i = g; i < S; i += 8) {
                         float acc = 0.0f;
-                        for (int j = 0; j < S; ++j) acc = fmaf(m[(size_t) j * SP + i], ch[wg_elem(S, j, p)], acc);
-                        cat += (double) (pk[wg_elem(S, i, p)] * acc) * fr[i];
+                        for (int j = 0; j < S; ++j) acc = fmaf(m[(size_t) j * SP + i], ch[wg_elem_sh(sh, j, p)], acc);
+                        cat += (double) (pk[wg_elem_sh(sh, i, p)] * acc) * fr[i];
                     }
                 }
                 const int e = a.cum[n] ? a.cum[n][(size_t) k * Ppad + c] : 0;

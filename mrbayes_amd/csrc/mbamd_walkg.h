@@ -56,6 +56,8 @@ __host__ __device__ inline size_t wg_lds_bytes(int W, int nslots, int S) { retur
 // per lane so that one dwordx2 / dwordx4 per lane moves V rows (1/2 - 1 KiB contiguous per wave instruction).
 // float offset of (row r, lane / column c) inside a block or table:
 __host__ __device__ inline unsigned wg_at(int V, int r, int c) { return (unsigned) ((r / V) * 64 * V + c * V + r % V); }
+// the same with V = 1 << sh (V is 2 or 4): no integer division in a kernel's inner loop
+__host__ __device__ inline unsigned wg_elem_sh(int sh, int i, int p) { const int r = i >> 1; return (unsigned) (((r >> sh) << (6 + sh)) + ((((i & 1) << 5) + p) << sh) + (r & ((1 << sh) - 1))); }
 __host__ __device__ inline unsigned wg_elem(int S, int i, int p) { return wg_at(wg_vec(S), i >> 1, (i & 1) * 32 + p); }   // state i, pattern p
 
 // Tables of one (matrix, category): rows n = t * NT + it (< NAP), 64 columns, stored like blocks (wg_at):
