@@ -2537,6 +2537,9 @@ int Instance::makeChildren(const std::vector<std::pair<int, int>>& ranges)
 // =============================================================================================
 // C ABI
 // =============================================================================================
+#include "libhmsbeagle/mbamd_parsimony.h"
+#include "mbamd_parsimony.h"
+
 using namespace mbamd;
 
 #define GET_INSTANCE_NOFLUSH(id)                                                                     \
@@ -3407,6 +3410,95 @@ int mbamdFetchLogLikelihood(int instance, double* outSumLogLikelihood)
     GET_INSTANCE(instance);
     if (in->facade()) return fail(BEAGLE_ERROR_NO_IMPLEMENTATION, "mbamdFetchLogLikelihood: not on a partitioned / sharded instance");
     return in->fetchResult(outSumLogLikelihood);
+}
+
+
+// ---- Fitch parsimony (include/libhmsbeagle/mbamd_parsimony.h) --------------------------------------------------
+#define GET_PARS(id)                                                                                 \
+    ParsInstance* pi = pars_lookup(id);                                                              \
+    if (!pi) return fail(BEAGLE_ERROR_UNINITIALIZED_INSTANCE, "no such parsimony instance");         \
+    (void) hipSetDevice(pi->device)
+
+int mbamdParsCreateInstance(int setCount, int patternCount, int wordsPerSet, int setBits, int likelihoodInstance)
+{
+    API_TRACE("mbamdParsCreateInstance(sets=%d, patterns=%d, words=%d, bits=%d, like=%d)", setCount, patternCount, wordsPerSet, setBits, likelihoodInstance);
+    if (setCount < 1 || patternCount < 1 || (wordsPerSet != 1 && wordsPerSet != 2) || setBits < 1 || setBits > 64 * wordsPerSet)
+        return fail(BEAGLE_ERROR_OUT_OF_RANGE, "mbamdParsCreateInstance: bad dimensions");
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
+        return fail(BEAGLE_ERROR_NO_RESOURCE, "mbamdParsCreateInstance: no HIP device (this engine has no CPU path)");
+    int dev = 0;
+    if (likelihoodInstance >= 0) {
+        Instance* in = lookup(likelihoodInstance);
+        if (!in) return fail(BEAGLE_ERROR_UNINITIALIZED_INSTANCE, "mbamdParsCreateInstance: no such likelihood instance");
+        dev = in->facade() ? in->children[0].in->device : in->device;
+    }
+    ParsInstance* pi = new ParsInstance();
+    int rc = pi->create(setCount, patternCount, wordsPerSet, setBits, dev);
+    if (rc != BEAGLE_SUCCESS) {
+        delete pi;
+        return rc;
+    }
+    std::lock_guard<std::mutex> lock(g_parsMutex);
+    for (size_t i = 0; i < g_pars.size(); ++i)
+        if (!g_pars[i]) {
+            g_pars[i] = pi;
+            return (int) i;
+        }
+    g_pars.push_back(pi);
+    return (int) g_pars.size() - 1;
+}
+int mbamdParsFinalizeInstance(int pars)
+{
+    ParsInstance* pi = nullptr;
+    {
+        std::lock_guard<std::mutex> lock(g_parsMutex);
+        if (pars < 0 || pars >= (int) g_pars.size() || !g_pars[pars])
+            return fail(BEAGLE_ERROR_UNINITIALIZED_INSTANCE, "no such parsimony instance");
+        pi = g_pars[pars];
+        g_pars[pars] = nullptr;
+    }
+    delete pi;
+    return BEAGLE_SUCCESS;
+}
+int mbamdParsSetSets(int pars, int setIndex, const unsigned long long* sets)
+{
+    GET_PARS(pars);
+    if (!sets) return fail(BEAGLE_ERROR_OUT_OF_RANGE, "mbamdParsSetSets: null");
+    return pi->setSets(setIndex, sets);
+}
+int mbamdParsGetSets(int pars, int setIndex, unsigned long long* outSets)
+{
+    GET_PARS(pars);
+    if (!outSets) return fail(BEAGLE_ERROR_OUT_OF_RANGE, "mbamdParsGetSets: null");
+    return pi->getSets(setIndex, outSets);
+}
+int mbamdParsSetPatternWeights(int pars, const float* weights)
+{
+    GET_PARS(pars);
+    if (!weights) return fail(BEAGLE_ERROR_OUT_OF_RANGE, "mbamdParsSetPatternWeights: null");
+    return pi->setWeights(weights);
+}
+int mbamdParsDownPass(int pars, const int* ops, int count, double* outLength)
+{
+    GET_PARS(pars);
+    API_TRACE("mbamdParsDownPass(%d ops%s)", count, outLength ? ", length" : "");
+    if (count < 0 || (count > 0 && !ops)) return fail(BEAGLE_ERROR_OUT_OF_RANGE, "mbamdParsDownPass: arguments");
+    return pi->downPass(ops, count, outLength);
+}
+int mbamdParsFinalPass(int pars, const int* ops, int count)
+{
+    GET_PARS(pars);
+    API_TRACE("mbamdParsFinalPass(%d nodes)", count);
+    if (count < 0 || (count > 0 && !ops)) return fail(BEAGLE_ERROR_OUT_OF_RANGE, "mbamdParsFinalPass: arguments");
+    return pi->finalPass(ops, count);
+}
+int mbamdParsScore(int pars, const int* tuples, int count, double* outLengths)
+{
+    GET_PARS(pars);
+    API_TRACE("mbamdParsScore(%d tuples)", count);
+    if (count < 0 || (count > 0 && (!tuples || !outLengths))) return fail(BEAGLE_ERROR_OUT_OF_RANGE, "mbamdParsScore: arguments");
+    return pi->score(tuples, count, outLengths);
 }
 
 }  // extern "C"

@@ -10,13 +10,15 @@ Tolerances (stated once, used everywhere):
   * log-likelihood vs the oracle on the same inputs: relative 2e-6; vs the fp64 reference also
     |diff| <= 2 x (the reference's own |fp32 - fp64| on that data set) + 1e-3;
   * partials / transition matrices element-wise: 2e-6 absolute + 2e-5 relative (fp32 round-off with
-    a different summation order / FMA contraction than the scalar reference).
+    a different summation order / FMA contraction than the scalar reference);
+  * parsimony state sets and lengths: bit-exact (integer work; lengths are sums of integer-valued weights).
 """
 import json
 import math
 import os
 
 import numpy as np
+import pytest
 
 from mrbayes_amd import beagle as bg
 from mrbayes_amd import likelihood as lk
@@ -519,3 +521,82 @@ def check_dynamic_rescaling_state_machine(lib, oracle, div):
     lnl = engine_lnl(lib, div, scaling=lk.MB_BEAGLE_SCALE_DYNAMIC)
     want = oracle.tree_loglike(div, use_shortcuts=False)
     assert abs(lnl - want) / abs(want) < REL_FP64, (lnl, want)
+
+
+# ---- Fitch parsimony on the device -----------------------------------------------------------
+def check_parsimony(lib, ntaxa, npat, nstates, seed=3, words=1, gaps=0.05):
+    """Down-pass, final pass and candidate lengths of a random tree against the oracle's restatement of GetFitchPartials /
+    GetParsFP / the ParsSPR1 candidate loops -- sets word for word, lengths exactly (integer-valued weights)."""
+    from mrbayes_amd import parsimony as mp
+    from mrbayes_amd import tree as mbtree
+    from tests import oracle_lib as ol
+    rng = np.random.default_rng(seed)
+    t = mbtree.random_tree(ntaxa, seed)
+    nsets = t.n_nodes
+    # tips: a random walk over the tree would be more realistic; independent states stress the empty-intersection branch
+    base = rng.integers(0, nstates, size=npat)
+    states = np.where(rng.random((ntaxa, npat)) < 0.3, rng.integers(0, nstates, size=(ntaxa, npat)), base[None, :])
+    sets = np.zeros((nsets, npat * words), dtype=np.uint64)
+    for i in range(ntaxa):
+        for v in range(words):
+            lo, hi = 64 * v, min(nstates, 64 * (v + 1))
+            if hi <= lo:
+                continue
+            s = states[i]
+            word = np.where((s >= lo) & (s < hi), np.left_shift(np.uint64(1), np.clip(s - lo, 0, 63).astype(np.uint64)), np.uint64(0))
+            amb = rng.random(npat) < gaps
+            full = np.uint64((1 << (hi - lo)) - 1) if hi - lo < 64 else np.uint64(0xFFFFFFFFFFFFFFFF)
+            sets[i, v::words] = np.where(amb, full, word)
+        # a partially ambiguous tip set now and then
+        k = rng.integers(0, npat)
+        sets[i, k * words] |= np.uint64(1) << np.uint64(rng.integers(0, min(nstates, 64)))
+    # interior sets start as whatever an earlier move left: random subsets, uploaded like everything else
+    for i in range(ntaxa, nsets):
+        sets[i, :] = rng.integers(0, 1 << min(nstates, 62), size=npat * words, dtype=np.uint64) if words == 1 else 0
+    w = rng.integers(1, 9, size=npat).astype(np.float32)
+    inst = mp.ParsimonyInstance(nsets, npat, nstates if words == 1 else 64 * words, words, lib=lib)
+    try:
+        for i in range(nsets):
+            inst.set_sets(i, sets[i])
+        inst.set_pattern_weights(w)
+        np.testing.assert_array_equal(inst.all_sets(), sets)
+        ref = sets.copy()
+        # GetParsDP(t, root->left) + GetParsFP(t, root->left)
+        dops = mp.down_pass_ops(t, t.root_left)
+        assert len(dops) == t.n_int_nodes
+        total, node_len = ol.pars_down(ref, dops, w)
+        got = inst.down_pass(dops)
+        assert got == total, (got, total)
+        np.testing.assert_array_equal(inst.all_sets(), ref)
+        assert mp.GetParsimonyLength(inst, t) == total + ol.pars_score(ref, [[t.root_left, -1, t.root, -1]], w)[0]
+        # per-node lengths as Likelihood_Pars keeps them: score tuples over the children
+        np.testing.assert_array_equal(inst.score([[o[1], -1, o[2], -1] for o in dops]), node_len)
+        fops = mp.final_pass_ops(t, t.root_left)
+        ol.pars_final(ref, fops, npat)
+        inst.final_pass(fops)
+        np.testing.assert_array_equal(inst.all_sets(), ref)
+        # a clipped subtree: down-pass without waiting for the length, final pass against a stale ancestor set
+        v = next(n for n in t.int_down_pass if n != t.root_left)
+        sub = mp.down_pass_ops(t, v)
+        ol.pars_down(ref, sub, w)
+        assert inst.down_pass(sub, want_length=False) is None
+        subf = mp.final_pass_ops(t, v)
+        ol.pars_final(ref, subf, npat)
+        inst.final_pass(subf)
+        np.testing.assert_array_equal(inst.all_sets(), ref)
+        # candidate positions: the three shapes ParsSPR1 uses and the four-set shape of ParsTBR1
+        nodes = [n for n in t.all_down_pass if t.anc[n] >= 0]
+        tuples = []
+        for n in nodes[:40]:
+            tuples += [[n, t.anc[n], v, -1], [v, -1, n, t.anc[n]], [n, t.anc[n], nodes[(n * 7) % len(nodes)], t.anc[nodes[(n * 7) % len(nodes)]]]]
+        np.testing.assert_array_equal(inst.score(tuples), ol.pars_score(ref, tuples, w))
+        # errors: out-of-range indices, bits beyond the declared width
+        with pytest.raises(bg.BeagleError):
+            inst.down_pass([[nsets, 0, 1, -1]])
+        with pytest.raises(bg.BeagleError):
+            inst.final_pass([[ntaxa, 0, 1, -1]])
+        if words == 1 and nstates < 64:
+            with pytest.raises(bg.BeagleError):
+                inst.set_sets(0, np.full(npat, 1 << nstates, dtype=np.uint64))
+    finally:
+        inst.finalize()

@@ -17,9 +17,9 @@ _ip = C.POINTER(C.c_int)
 
 def build():
     so = os.path.join(ODIR, "liboracle.so")
-    src = os.path.join(ODIR, "mb_oracle.c")
-    if not os.path.exists(so) or os.path.getmtime(so) < os.path.getmtime(src):
-        subprocess.check_call(["gcc", "-O2", "-fPIC", "-shared", "-std=c99", "-o", so, src, "-lm"], cwd=ODIR)
+    srcs = [os.path.join(ODIR, "mb_oracle.c"), os.path.join(ODIR, "pars_oracle.c")]
+    if not os.path.exists(so) or any(os.path.getmtime(so) < os.path.getmtime(src) for src in srcs):
+        subprocess.check_call(["gcc", "-O2", "-fPIC", "-shared", "-std=c99", "-o", so] + srcs + ["-lm"], cwd=ODIR)
     return so
 
 
@@ -147,3 +147,35 @@ def load():
     if _lib is None:
         _lib = Oracle(C.CDLL(build()))
     return _lib
+
+
+# ---- Fitch parsimony (oracle/pars_oracle.c) ---------------------------------------------------------------------
+_up = C.POINTER(C.c_uint64)
+
+
+def pars_down(sets, ops, w):
+    """sets uint64 [setCount][P*words] (modified in place); returns (total length, per-operation lengths)."""
+    lib = load().lib
+    lib.mbo_pars_down.restype = C.c_double
+    ops = np.ascontiguousarray(ops, dtype=np.int32).reshape(-1, 4)
+    w = np.ascontiguousarray(w, dtype=np.float32)
+    P = w.size
+    words = sets.shape[1] // P
+    node_len = np.zeros(ops.shape[0])
+    total = lib.mbo_pars_down(_p(sets, _up), C.c_int(P), C.c_int(words), _p(ops, _ip), C.c_int(ops.shape[0]), _p(w, _fp), _p(node_len, _dp))
+    return total, node_len
+
+
+def pars_final(sets, ops, P):
+    lib = load().lib
+    ops = np.ascontiguousarray(ops, dtype=np.int32).reshape(-1, 4)
+    lib.mbo_pars_final(_p(sets, _up), C.c_int(P), C.c_int(sets.shape[1] // P), _p(ops, _ip), C.c_int(ops.shape[0]))
+
+
+def pars_score(sets, tuples, w):
+    lib = load().lib
+    tuples = np.ascontiguousarray(tuples, dtype=np.int32).reshape(-1, 4)
+    w = np.ascontiguousarray(w, dtype=np.float32)
+    out = np.zeros(tuples.shape[0])
+    lib.mbo_pars_score(_p(sets, _up), C.c_int(w.size), C.c_int(sets.shape[1] // w.size), _p(tuples, _ip), C.c_int(tuples.shape[0]), _p(w, _fp), _p(out, _dp))
+    return out

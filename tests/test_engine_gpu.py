@@ -491,3 +491,10 @@ def test_multi_partition_instance(gpu, oracle, golden_dir, kind):
     a = synthetic_division(kind, 24, 330, seed=91, tree_seed=92, p_gap=0.02, golden_dir=golden_dir, alpha=0.5)
     b = synthetic_division(kind, 24, 150, seed=93, tree_seed=94, p_gap=0.02, golden_dir=golden_dir, alpha=1.7, brlen=0.11)
     ec.check_multi_partition_instance(gpu, oracle, a, b)
+
+
+@pytest.mark.parametrize("ntaxa,npat,nstates,words", [(12, 100, 4, 1), (200, 5000, 4, 1), (50, 1000, 20, 1), (30, 700, 61, 1), (7, 65, 64, 1),
+                                                       (10, 50, 10, 1), (16, 300, 70, 2)])
+def test_parsimony(gpu, ntaxa, npat, nstates, words):
+    """Device Fitch parsimony (mbamdPars*) against the oracle: u8 / u16 / u32 / u64 / 2 x u64 sets."""
+    ec.check_parsimony(gpu, ntaxa, npat, nstates, words=words)
