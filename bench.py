@@ -104,14 +104,20 @@ def mcmc_gen_per_s(gold, nchains=1, quick=True):
     st = mbdata.synthetic_states(sy["ntaxa"], sy["nsites"], 4, sy["seed"], sy["p_mut"], sy["p_gap"])
     tr = mbtree.parse_newick(gold["newick"])
     out = {"workload": gold["case"], "nchains": nchains,
-           "note": "default_moves: MrBayes' default proposal mix; 11.5% of its moves are ParsSPR/ParsTBR, whose O(taxa x "
-                   "patterns) parsimony scoring runs on the host in both builds (SURVEY 8(f) item 4) and bounds the rate; "
+           "note": "default_moves: MrBayes' default proposal mix; 11.5% of its moves are ParsSPR1/ParsTBR1, whose O(taxa x "
+                   "patterns) parsimony scoring runs on the host in the unmodified binary (`engine`, `reference_cpu`) and bounds "
+                   "its rate; `engine_device_parsimony` = the same sources plus the device-parsimony binding (SURVEY 8(f) item 4, "
+                   "integration/mrbayes/, same proposals and chain as the unmodified binary); "
                    "fixed_topology = branch-length and substitution-parameter moves only (prset topologypr=fixed)"}
     windows = {(False, "engine"): (300, 1300) if quick else (500, 2500), (True, "engine"): (2000, 12000) if quick else (2000, 22000),
                (False, "reference_cpu"): (10, 40) if quick else (20, 80), (True, "reference_cpu"): (20, 70) if quick else (20, 120)}
     for mix, fixed in (("default_moves", False), ("fixed_topology", True)):
         res = {}
-        for tag, binary, beagle in (("engine", refrun.REF_MB_AMD, "dynamic"), ("reference_cpu", refrun.REF_MB, None)):
+        runs = [("engine", refrun.REF_MB_AMD, "dynamic"), ("reference_cpu", refrun.REF_MB, None)]
+        if not fixed and os.path.exists(refrun.REF_MB_AMD_PARS):
+            runs.insert(1, ("engine_device_parsimony", refrun.REF_MB_AMD_PARS, "dynamic"))
+            windows[(False, "engine_device_parsimony")] = (1000, 6000) if quick else (2000, 22000)
+        for tag, binary, beagle in runs:
             lo, hi = windows[(fixed, tag)]
             walls = []
             for ngen in (lo, hi):
@@ -121,6 +127,8 @@ def mcmc_gen_per_s(gold, nchains=1, quick=True):
             res[tag] = (hi - lo) / max(walls[1] - walls[0], 1e-9)
             res[tag + "_ngen"] = [lo, hi]
         res["speedup"] = res["engine"] / res["reference_cpu"]
+        if "engine_device_parsimony" in res:
+            res["speedup_device_parsimony"] = res["engine_device_parsimony"] / res["reference_cpu"]
         out[mix] = res
     return out
 

@@ -9,6 +9,7 @@ src/mbbeagle.c, compared with the same reference's native CPU kernels on the sam
 """
 import json
 import os
+import re
 import subprocess
 
 import numpy as np
@@ -332,3 +333,57 @@ def test_tap_style_run_on_mi355x():
     assert res["completed"] == 1, out[-1500:]
     assert abs(res["best_cold_lnL_run1"] - want["best_cold_lnL_run1"]) < 15.0, (res, want)
     assert abs(res["TL_mean"] - want["TL_mean"]) < 0.35 * want["TL_mean"], (res, want)
+
+
+# ---- device parsimony: the reference + integration/mrbayes/mbamd_pars_glue.c ----------------------
+def _trajectory(out):
+    """the per-generation chain lines of MrBayes' screen output, without the time-remaining column"""
+    return [re.sub(r" -- \d+:\d\d:\d\d\s*$", "", l) for l in out.split("\n") if re.match(r"\s+\d+ -- [\[\(-]", l)]
+
+
+def _pars_nexus(ngen, nchains=2, kind="dna"):
+    if kind == "dna":
+        st, _ = _case(20, 400, 0.03)
+        nex = refrun.mcmc_nexus(st, None, ngen, beagle="dynamic", nchains=nchains)
+    else:
+        st, tr = _general_case("wag", 12, 120)
+        nex = refrun.model_nexus("wag", st, tr, ngen=ngen, beagle="dynamic")
+    return nex.replace("printfreq=%d" % ngen, "printfreq=%d" % max(ngen // 20, 1))
+
+
+def _check_device_parsimony(plain, patched, ngen, kind="dna"):
+    nex = _pars_nexus(ngen, kind=kind)
+    ref_out, _ = refrun.run_mb(plain, nex)
+    # 1. every GetParsDP / GetParsFP / candidate loop also runs in the reference's own host functions, inside the
+    #    same process, and is compared word for word (the glue exits non-zero on the first difference)
+    chk_out, _ = refrun.run_mb(patched, nex, env={"MBAMD_PARS_CHECK": "1", "MBAMD_API_TRACE": "1"})
+    text = chk_out
+    assert "Analysis completed" in chk_out, text[-2000:]
+    m = re.search(r"mbamd parsimony check: (\d+) comparisons against the host functions, all equal", text)
+    assert m and int(m.group(1)) > 1000, text[-2000:]
+    assert "mbamdParsDownPass" in text and "mbamdParsFinalPass" in text and "mbamdParsScore" in text
+    # 2. device only: the same proposals, hence the same chain, generation for generation
+    dev_out, _ = refrun.run_mb(patched, nex)
+    assert "Analysis completed" in dev_out
+    a, b, c = _trajectory(ref_out), _trajectory(chk_out), _trajectory(dev_out)
+    assert len(a) > 10 and a == b and a == c, (a[-1], b[-1], c[-1])
+    # 3. switched off (MBAMD_DEVICE_PARSIMONY=0) the patched binary is the reference
+    off_out, _ = refrun.run_mb(patched, nex, env={"MBAMD_DEVICE_PARSIMONY": "0", "MBAMD_API_TRACE": "1"})
+    assert "mbamdPars" not in off_out and _trajectory(off_out) == a
+
+
+@pytest.mark.parametrize("kind", ["dna", "wag"])
+def test_device_parsimony_on_emulated_engine(kind):
+    if not os.path.isdir("/root/reference/src"):
+        pytest.skip("reference sources not present (build container only)")
+    from tests.hostemu import build_emu
+    build_emu.build()
+    subprocess.check_call(["make", "-C", os.path.join(ROOT, "oracle"), "_ref/mb_emu", "_ref/mb_emu_pars"], stdout=subprocess.DEVNULL)
+    _check_device_parsimony(refrun.REF_MB_EMU, refrun.REF_MB_EMU_PARS, 1500 if kind == "dna" else 300, kind)
+
+
+@pytest.mark.gpu
+def test_device_parsimony_on_mi355x():
+    if not os.path.exists(refrun.REF_MB_AMD_PARS):
+        pytest.skip("oracle/_ref/mb_amd_pars was not built (needs the reference sources at build time)")
+    _check_device_parsimony(refrun.REF_MB_AMD, refrun.REF_MB_AMD_PARS, 3000)

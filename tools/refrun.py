@@ -18,6 +18,9 @@ REF_MB_EMU = os.path.join(ROOT, "oracle", "_ref", "mb_emu")     # same objects, 
 
 REF_MB_AMD_V3 = os.path.join(ROOT, "oracle", "_ref", "mb_amd_v3")   # ... with MrBayes' BEAGLE v3 code path compiled in
 REF_MB_EMU_V3 = os.path.join(ROOT, "oracle", "_ref", "mb_emu_v3")
+# the reference + our ABI + the device-parsimony binding (integration/mrbayes/, oracle/patch_pars.py)
+REF_MB_AMD_PARS = os.path.join(ROOT, "oracle", "_ref", "mb_amd_pars")
+REF_MB_EMU_PARS = os.path.join(ROOT, "oracle", "_ref", "mb_emu_pars")
 
 _NUC = "ACGT-"
 
