@@ -28,24 +28,148 @@ struct ParsOp {
     int a, b, c, d;
 };
 
-// GetFitchPartials (reference src/mcmc.c:4794-4846) for every operation of a down-pass (GetParsDP's post-order,
-// :4849-4876).  One thread = one pattern; `partial` (may be null): one length per 64-pattern block, added up by the host.
-template <class T>
-__global__ void __launch_bounds__(64)
-k_pars_down(const ParsOp* __restrict__ ops, int n, T* sets, size_t stride, const float* __restrict__ w, double* partial)
+// One step of a compiled pass program (ParsInstance::flush): a Fitch down-pass operation (GetFitchPartials, reference
+// src/mcmc.c:4794-4846, in GetParsDP's post-order :4849-4876) or a final-pass node (GetParsFP, :4881-4954).  All steps
+// of a chunk are of one kind (the host pads with no-ops where the kind changes: sources = the all-ones row, destination =
+// the junk row).  Every operand names BOTH a set in HBM (prefetched a chunk ahead; the all-ones row when unused) and a
+// ring code: 0xFF = take the prefetched value, else the LDS ring slot where a step of this or the previous chunk left it.
+struct ParsStep {
+    int kind;            // 0 down-pass, 1 final pass (the kind of step 0 of a chunk is the chunk's)
+    int dest;
+    int g[4];            // down: {source1, source2, -, -};  final: {node, left, right, ancestor}
+    unsigned ring;       // four 8-bit ring codes
+    int pad_;
+};
+enum { PARS_DOWN = 0, PARS_FINAL = 1 };
+
+// The descriptors of one chunk (CH steps x 8 dwords <= 64 dwords): ONE vector load, lane l holding dword l, fetched two
+// chunks ahead; the uniform fields come back out with v_readlane.  (Scalar loads would do, but a wave that is alone on its
+// CU misses the scalar cache on every one of them.)
+#if defined(MBAMD_HOST_EMU)
+struct ParsDesc {
+    const int* p;
+    int get(int i) const { return p[i]; }
+};
+template <int CH> static inline ParsDesc pars_desc_load(const ParsStep* steps, int ch, int)
 {
-    const size_t c = (size_t) blockIdx.x * 64 + threadIdx.x;
+    return {reinterpret_cast<const int*>(steps + (size_t) ch * CH)};
+}
+#else
+struct ParsDesc {
+    int v;
+    __device__ __forceinline__ int get(int i) const { return __builtin_amdgcn_readlane(v, i); }
+};
+template <int CH> __device__ __forceinline__ ParsDesc pars_desc_load(const ParsStep* steps, int ch, int lane)
+{
+    return {reinterpret_cast<const int*>(steps + (size_t) ch * CH)[lane & (CH * 8 - 1)]};
+}
+#endif
+
+// the type a set is computed in: 32 bits for the narrow storage types (no sub-dword packing in registers or in LDS)
+template <class T> struct ParsWide { typedef uint32_t type; };
+template <> struct ParsWide<uint64_t> { typedef uint64_t type; };
+template <> struct ParsWide<u128> { typedef u128 type; };
+template <class T, class X> __device__ __host__ __forceinline__ T pars_narrow(X x) { return (T) x; }
+template <> __device__ __host__ __forceinline__ u128 pars_narrow<u128, u128>(u128 x) { return x; }
+
+// The walk: one thread = one pattern runs the whole program, so there is no inter-thread dependency and no barrier.  With
+// one wave per SIMD at best (P / 64 waves for 1024 SIMDs) the bound is that wave's own instruction stream and the latency
+// of its dependency chain, so the kernel is built to keep both short.  Three stages a chunk (CH steps) apart: descriptors
+// (one vector load), operands (loaded into a second register set through scalar row addresses), execution.  A step's
+// operands come from the LDS ring when a step of the last two chunks produced them (results are forwarded through a
+// wave-private ring of 2 CH slots: ds_write -> ds_read instead of an L2 round trip of the store and the load) and from
+// HBM otherwise.  Hardware keeps a wave's loads behind its own earlier stores to the same address, so "produced before the
+// previous chunk began" is all the operand prefetch needs.  Within a kind every step issues the same loads, one store and
+// one ring write, so the compiler's vmcnt waits are exact.  The host pads the program with two chunks of no-ops that are
+// fetched but never run.
+template <class T, int CH>
+__global__ void __launch_bounds__(64)
+k_pars_walk(const ParsStep* __restrict__ steps, int nchunks, T* sets, unsigned stride, const float* __restrict__ w, double* partial)
+{
+    typedef typename ParsWide<T>::type X;
+#if defined(MBAMD_HOST_EMU)
+    X* ring = reinterpret_cast<X*>(mbamd_emu_dyn_lds());
+#else
+    extern __shared__ unsigned char pars_lds[];
+    X* ring = reinterpret_cast<X*>(pars_lds);
+#endif
+    const unsigned lane = threadIdx.x;
+    const unsigned c = blockIdx.x * 64u + lane;                  // (nSets + 2) * P_pad < 2^32, checked at create
     const float wc = w[c];
     double len = 0.0;
-    for (int i = 0; i < n; ++i) {
-        const ParsOp o = ops[i];
-        const T l = sets[(size_t) o.b * stride + c], r = sets[(size_t) o.c * stride + c];
-        T x = l & r;
-        if (pars_empty(x)) {
-            x = l | r;
-            len += wc;
+    X A[CH][4], B[CH][4];
+
+    auto row = [&](int set) { return sets + (size_t) ((unsigned) set * stride); };      // uniform: a scalar address
+    auto prefetch = [&](const ParsDesc& d, X (&buf)[CH][4]) {
+        const bool fin = d.get(0) == PARS_FINAL;
+#pragma unroll
+        for (int k = 0; k < CH; ++k) {
+#if defined(MBAMD_PARSX_NOFETCH)
+            buf[k][0] = pars_none<X>();
+            buf[k][1] = pars_none<X>();
+#else
+            buf[k][0] = (X) row(d.get(8 * k + 2))[c];
+            buf[k][1] = (X) row(d.get(8 * k + 3))[c];
+#endif
         }
-        sets[(size_t) o.a * stride + c] = x;
+        if (fin) {
+#pragma unroll
+            for (int k = 0; k < CH; ++k) {
+                buf[k][2] = (X) row(d.get(8 * k + 4))[c];
+                buf[k][3] = (X) row(d.get(8 * k + 5))[c];
+            }
+        }
+    };
+    auto operand = [&](unsigned codes, int j, X fetched) {
+        const unsigned code = (codes >> (8 * j)) & 0xFFu;
+#if defined(MBAMD_PARSX_NORING)
+        return fetched;
+#else
+        return code != 0xFFu ? ring[code * 64 + lane] : fetched;
+#endif
+    };
+    auto run = [&](int half, const ParsDesc& d, X (&buf)[CH][4]) {
+        if (d.get(0) == PARS_DOWN) {
+#pragma unroll
+            for (int k = 0; k < CH; ++k) {
+                const unsigned codes = (unsigned) d.get(8 * k + 6);
+                const X a = operand(codes, 0, buf[k][0]), b = operand(codes, 1, buf[k][1]);
+                X x = a & b;
+                if (pars_empty(x)) {                      // no common state: the union, and one more step of length
+                    x = a | b;
+                    len += wc;
+                }
+#if !defined(MBAMD_PARSX_NOSTORE)
+                row(d.get(8 * k + 1))[c] = pars_narrow<T, X>(x);
+#endif
+                ring[(half * CH + k) * 64 + lane] = x;
+            }
+        } else {
+#pragma unroll
+            for (int k = 0; k < CH; ++k) {
+                const unsigned codes = (unsigned) d.get(8 * k + 6);
+                const X p = operand(codes, 0, buf[k][0]), l = operand(codes, 1, buf[k][1]);
+                const X r = operand(codes, 2, buf[k][2]), a = operand(codes, 3, buf[k][3]);
+                X x = p & a;
+                if (!pars_same(x, a))                     // a change between the node and its ancestor is allowed:
+                    x = !pars_empty(l & r) ? (((l | r) & a) | p)       // one change through the node, or
+                                           : (p | a);                   // two (any ancestor state)
+                row(d.get(8 * k + 1))[c] = pars_narrow<T, X>(x);
+                ring[(half * CH + k) * 64 + lane] = x;
+            }
+        }
+    };
+    ParsDesc d0 = pars_desc_load<CH>(steps, 0, lane), d1 = pars_desc_load<CH>(steps, 1, lane);
+    prefetch(d0, A);
+    for (int ch = 0; ch < nchunks; ch += 2) {          // (nchunks is even: the ring slot of a step is a compile-time constant)
+        ParsDesc d2 = pars_desc_load<CH>(steps, ch + 2, lane);
+        prefetch(d1, B);
+        run(0, d0, A);
+        ParsDesc d3 = pars_desc_load<CH>(steps, ch + 3, lane);
+        prefetch(d2, A);
+        run(1, d1, B);
+        d0 = d2;
+        d1 = d3;
     }
     if (!partial) return;
 #if defined(MBAMD_HOST_EMU)
@@ -56,27 +180,6 @@ k_pars_down(const ParsOp* __restrict__ ops, int n, T* sets, size_t stride, const
     for (int off = 32; off > 0; off >>= 1) len += __shfl_down(len, off);
     if (threadIdx.x == 0) partial[blockIdx.x] = len;
 #endif
-}
-
-// GetParsFP (reference src/mcmc.c:4881-4954) for the nodes of a pre-order list: {node, left, right, ancestor}.
-template <class T>
-__global__ void __launch_bounds__(64)
-k_pars_final(const ParsOp* __restrict__ ops, int n, T* sets, size_t stride)
-{
-    const size_t c = (size_t) blockIdx.x * 64 + threadIdx.x;
-    for (int i = 0; i < n; ++i) {
-        const ParsOp o = ops[i];
-        const T p = sets[(size_t) o.a * stride + c], a = sets[(size_t) o.d * stride + c];
-        const T l = sets[(size_t) o.b * stride + c], r = sets[(size_t) o.c * stride + c];
-        T x = p & a;
-        if (!pars_same(x, a)) {                      // a change of state between the node and its ancestor is allowed
-            if (!pars_empty(l & r))
-                x = ((l | r) & a) | p;               // one change through the node: ancestor states a child also has
-            else
-                x = p | a;                           // two changes: any ancestor state
-        }
-        sets[(size_t) o.a * stride + c] = x;
-    }
 }
 
 // candidate lengths (reference src/proposal.c:10783-10876 and the like): block (i, y) sums its share of the patterns
@@ -110,7 +213,9 @@ k_pars_score(const ParsOp* __restrict__ tuples, const T* __restrict__ sets, size
 }
 
 // ------------------------------------------------------------------------------------------------------------------
-// host object behind a parsimony handle
+// host object behind a parsimony handle.  Down-pass and final-pass calls only append to a program; it is compiled (ring
+// codes, padding) and run as ONE launch when a value is asked for -- a ParsSPR1 move (two down-passes, two final passes,
+// one candidate matrix: reference src/proposal.c:10700-10743) is two launches and one wait.
 class ParsInstance {
 public:
     int device = 0;
@@ -118,16 +223,16 @@ public:
     int width = 1;                                  // bytes per set on the device: 1, 2, 4, 8, 16
     hipStream_t stream{};
     bool live = false;
-    void* d_sets = nullptr;
+    void* d_sets = nullptr;                          // nSets + 2 rows: [nSets] takes what no-op steps store, [nSets + 1] is all ones (their sources)
     float* d_w = nullptr;
     std::vector<float> h_w;                          // what d_w holds
-    static constexpr int RING = 8;
+    static constexpr int RING = 4;
     struct Slot {
-        ParsOp* h = nullptr;                         // pinned
-        ParsOp* d = nullptr;
-        int cap = 0;
-        hipEvent_t done = nullptr;
-        bool busy = false;
+        void* h = nullptr;                           // pinned
+        void* d = nullptr;
+        size_t cap = 0;
+        hipEvent_t done{};
+        bool haveEvent = false, busy = false;
     } ring[RING];
     int next = 0;
     double* d_out = nullptr;                         // per-block partial sums
@@ -135,8 +240,15 @@ public:
     size_t outCap = 0;
     void* h_stage = nullptr;                         // pinned: one set in the device type
     static constexpr int SCORE_Y = 4;
+    struct Pending {
+        int kind, a, b, c, d;
+    };
+    std::vector<Pending> pending;
+    std::vector<int> lastWrite;                      // per set: the step of the program being compiled that wrote it
+    std::vector<ParsStep> compiled;
 
     ~ParsInstance() { destroy(); }
+    int chunk() const { return width == 16 ? 2 : width == 8 ? 4 : 8; }
 
     int create(int setCount, int patterns, int wordsPerSet, int setBits, int dev)
     {
@@ -147,16 +259,20 @@ public:
         words = wordsPerSet;
         bits = setBits;
         width = words == 2 ? 16 : bits <= 8 ? 1 : bits <= 16 ? 2 : bits <= 32 ? 4 : 8;
+        if (((size_t) nSets + 2) * (size_t) Ppad >= ((size_t) 1 << 32))
+            return fail(BEAGLE_ERROR_OUT_OF_RANGE, "mbamdParsCreateInstance", "more than 2^32 (set, pattern) pairs");
         HIP_TRY(hipSetDevice(device));
         HIP_TRY(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
         live = true;
-        const size_t bytes = (size_t) nSets * Ppad * width;
+        const size_t rowBytes = (size_t) Ppad * width, bytes = (size_t) (nSets + 2) * rowBytes;
         HIP_TRY(hipMalloc(&d_sets, bytes));
-        HIP_TRY(hipMemsetAsync(d_sets, 0, bytes, stream));                 // SafeCalloc'ed in the reference (src/mcmc.c:6892)
+        HIP_TRY(hipMemsetAsync(d_sets, 0, bytes - rowBytes, stream));      // SafeCalloc'ed in the reference (src/mcmc.c:6892)
+        HIP_TRY(hipMemsetAsync(static_cast<char*>(d_sets) + bytes - rowBytes, 0xFF, rowBytes, stream));
         HIP_TRY(hipMalloc(&d_w, (size_t) Ppad * sizeof(float)));
         HIP_TRY(hipMemsetAsync(d_w, 0, (size_t) Ppad * sizeof(float), stream));
         HIP_TRY(hipHostMalloc(&h_stage, (size_t) Ppad * 16, hipHostMallocDefault));
         HIP_TRY(hipStreamSynchronize(stream));
+        lastWrite.assign((size_t) nSets + 2, -(1 << 30));
         return BEAGLE_SUCCESS;
     }
 
@@ -168,7 +284,7 @@ public:
         for (Slot& s : ring) {
             if (s.h) (void) hipHostFree(s.h);
             if (s.d) (void) hipFree(s.d);
-            if (s.done) (void) hipEventDestroy(s.done);
+            if (s.haveEvent) (void) hipEventDestroy(s.done);
             s = Slot();
         }
         if (d_sets) (void) hipFree(d_sets);
@@ -190,6 +306,8 @@ public:
     int setSets(int idx, const unsigned long long* src)
     {
         int rc = checkIndex(idx, false, "mbamdParsSetSets");
+        if (rc) return rc;
+        rc = flush(nullptr);
         if (rc) return rc;
         HIP_TRY(hipStreamSynchronize(stream));                              // (h_stage may still be in flight)
         const unsigned long long limit = bits >= 64 ? ~0ull : ((1ull << bits) - 1);
@@ -223,6 +341,8 @@ public:
     {
         int rc = checkIndex(idx, false, "mbamdParsGetSets");
         if (rc) return rc;
+        rc = flush(nullptr);
+        if (rc) return rc;
         HIP_TRY(hipStreamSynchronize(stream));
         HIP_TRY(hipMemcpyAsync(h_stage, static_cast<char*>(d_sets) + (size_t) idx * Ppad * width, (size_t) Ppad * width,
                                hipMemcpyDeviceToHost, stream));
@@ -242,6 +362,8 @@ public:
     int setWeights(const float* w)
     {
         if (h_w.size() == (size_t) P && std::memcmp(h_w.data(), w, (size_t) P * sizeof(float)) == 0) return BEAGLE_SUCCESS;
+        int rc = flush(nullptr);
+        if (rc) return rc;
         HIP_TRY(hipStreamSynchronize(stream));                              // (kernels in flight read the old weights; h_w is the source of the copy)
         h_w.assign(w, w + P);
         HIP_TRY(hipMemcpyAsync(d_w, h_w.data(), (size_t) P * sizeof(float), hipMemcpyHostToDevice, stream));
@@ -249,31 +371,29 @@ public:
         return BEAGLE_SUCCESS;
     }
 
-    // copy an operation list into the next ring slot (pinned host -> device, stream-ordered)
-    int stage(const int* ops, int n, bool allowNone, const char* what, const ParsOp** out, Slot** used)
+    // copy `bytes` of host data into the next ring slot (pinned host -> device, stream-ordered)
+    int stage(const void* src, size_t bytes, const void** out, Slot** used)
     {
-        for (int i = 0; i < 4 * n; ++i) {
-            const bool none = allowNone || (i & 3) == 3;                     // (the fourth field of a down-pass operation is unused)
-            int rc = checkIndex(ops[i], none, what);
-            if (rc) return rc;
-        }
         Slot& s = ring[next];
         next = (next + 1) % RING;
         if (s.busy) {
             HIP_TRY(hipEventSynchronize(s.done));
             s.busy = false;
         }
-        if (s.cap < n) {
+        if (s.cap < bytes) {
             if (s.h) (void) hipHostFree(s.h);
             if (s.d) (void) hipFree(s.d);
             s.h = nullptr; s.d = nullptr;
-            s.cap = std::max(2 * n, 1024);
-            HIP_TRY(hipHostMalloc(&s.h, (size_t) s.cap * sizeof(ParsOp), hipHostMallocDefault));
-            HIP_TRY(hipMalloc(&s.d, (size_t) s.cap * sizeof(ParsOp)));
+            s.cap = std::max(2 * bytes, (size_t) 65536);
+            HIP_TRY(hipHostMalloc(&s.h, s.cap, hipHostMallocDefault));
+            HIP_TRY(hipMalloc(&s.d, s.cap));
         }
-        if (!s.done) HIP_TRY(hipEventCreate(&s.done));
-        std::memcpy(s.h, ops, (size_t) n * sizeof(ParsOp));
-        HIP_TRY(hipMemcpyAsync(s.d, s.h, (size_t) n * sizeof(ParsOp), hipMemcpyHostToDevice, stream));
+        if (!s.haveEvent) {
+            HIP_TRY(hipEventCreate(&s.done));
+            s.haveEvent = true;
+        }
+        std::memcpy(s.h, src, bytes);
+        HIP_TRY(hipMemcpyAsync(s.d, s.h, bytes, hipMemcpyHostToDevice, stream));
         *out = s.d;
         *used = &s;
         return BEAGLE_SUCCESS;
@@ -297,43 +417,102 @@ public:
         return BEAGLE_SUCCESS;
     }
 
-    template <class T> void launchDown(const ParsOp* ops, int n, double* partial)
+    template <class T, int CH> void launchWalkT(const ParsStep* steps, int nchunks, double* partial)
     {
-        MBAMD_LAUNCH(k_pars_down<T>, (unsigned) (Ppad / 64), 64, 0, stream, ops, n, static_cast<T*>(d_sets), (size_t) Ppad, d_w, partial);
-    }
-    template <class T> void launchFinal(const ParsOp* ops, int n)
-    {
-        MBAMD_LAUNCH(k_pars_final<T>, (unsigned) (Ppad / 64), 64, 0, stream, ops, n, static_cast<T*>(d_sets), (size_t) Ppad);
+        auto kernel = k_pars_walk<T, CH>;
+        MBAMD_LAUNCH(kernel, (unsigned) (Ppad / 64), 64, (size_t) 2 * CH * 64 * sizeof(typename ParsWide<T>::type), stream, steps, nchunks,
+                     static_cast<T*>(d_sets), (unsigned) Ppad, d_w, partial);
     }
     template <class T> void launchScore(const ParsOp* tuples, int n)
     {
         MBAMD_LAUNCH(k_pars_score<T>, dim3((unsigned) n, SCORE_Y), 64, 0, stream, tuples, static_cast<const T*>(d_sets), (size_t) Ppad, Ppad, d_w, d_out);
     }
-#define MBAMD_PARS_DISPATCH(FN, ...)                         \
-    switch (width) {                                         \
-        case 1: FN<uint8_t>(__VA_ARGS__); break;             \
-        case 2: FN<uint16_t>(__VA_ARGS__); break;            \
-        case 4: FN<uint32_t>(__VA_ARGS__); break;            \
-        case 8: FN<uint64_t>(__VA_ARGS__); break;            \
-        default: FN<u128>(__VA_ARGS__); break;               \
+    void launchWalk(const ParsStep* steps, int nchunks, double* partial)
+    {
+        switch (width) {
+            case 1: launchWalkT<uint8_t, 8>(steps, nchunks, partial); break;
+            case 2: launchWalkT<uint16_t, 8>(steps, nchunks, partial); break;
+            case 4: launchWalkT<uint32_t, 8>(steps, nchunks, partial); break;
+            case 8: launchWalkT<uint64_t, 4>(steps, nchunks, partial); break;
+            default: launchWalkT<u128, 2>(steps, nchunks, partial); break;
+        }
     }
 
-    int downPass(const int* ops, int n, double* outLength)
+    // validate and queue
+    int enqueue(int kind, const int* ops, int n, const char* what)
     {
-        if (n <= 0) {
+        for (int i = 0; i < n; ++i) {
+            const int* o = ops + 4 * i;
+            for (int j = 0; j < 4; ++j) {
+                int rc = checkIndex(o[j], kind == PARS_DOWN && j == 3, what);      // (the fourth field of a down-pass operation is unused)
+                if (rc) return rc;
+            }
+        }
+        for (int i = 0; i < n; ++i) pending.push_back({kind, ops[4 * i], ops[4 * i + 1], ops[4 * i + 2], ops[4 * i + 3]});
+        return BEAGLE_SUCCESS;
+    }
+
+    // compile the queued steps (ring codes: an operand written by a step of this or the previous chunk is taken from the
+    // LDS ring, anything older was stored before the chunk's prefetch is issued) and run them as one launch
+    int flush(double* outLength)
+    {
+        if (pending.empty()) {
             if (outLength) *outLength = 0.0;
             return BEAGLE_SUCCESS;
         }
+        const int CH = chunk(), NSLOT = 2 * CH;
+        const int n = (int) pending.size();
+        const ParsStep nop{PARS_DOWN, nSets, {nSets + 1, nSets + 1, nSets + 1, nSets + 1}, 0xFFFFFFFFu, 0};
+        compiled.clear();
+        auto padTo = [&](int kind) {                                        // no-ops up to the next chunk boundary
+            while (compiled.size() % (size_t) CH) {
+                compiled.push_back(nop);
+                compiled.back().kind = kind;
+            }
+        };
+        for (int q0 = 0; q0 < n; ++q0) {
+            const Pending& q = pending[q0];
+            if (!compiled.empty() && compiled.back().kind != q.kind) padTo(compiled.back().kind);
+            const int i = (int) compiled.size();
+            ParsStep st = nop;
+            const int src[4] = {q.kind == PARS_DOWN ? q.b : q.a, q.kind == PARS_DOWN ? q.c : q.b, q.kind == PARS_DOWN ? -1 : q.c,
+                                q.kind == PARS_DOWN ? -1 : q.d};
+            const int windowStart = (i / CH) * CH - CH;
+            st.kind = q.kind;
+            st.dest = q.a;
+            st.ring = 0;
+            for (int j = 0; j < 4; ++j) {
+                unsigned code = 0xFFu;
+                if (src[j] >= 0) {
+                    const int wr = lastWrite[src[j]];
+                    if (wr >= windowStart) code = (unsigned) (wr % NSLOT);
+                    else st.g[j] = src[j];
+                }
+                st.ring |= code << (8 * j);
+            }
+            compiled.push_back(st);
+            lastWrite[q.a] = i;
+        }
+        padTo(compiled.back().kind);
+        int nchunks = (int) compiled.size() / CH;
+        if (nchunks & 1) {
+            for (int k = 0; k < CH; ++k) compiled.push_back(nop);
+            ++nchunks;
+        }
+        for (int k = 0; k < 2 * CH; ++k) compiled.push_back(nop);            // two more chunks of no-ops: fetched ahead, never run
+        const int total = (int) compiled.size();
+        for (const Pending& q : pending) lastWrite[q.a] = -(1 << 30);
+        pending.clear();
         const int blocks = Ppad / 64;
         if (outLength) {
             int rc = growOut((size_t) blocks);
             if (rc) return rc;
         }
-        const ParsOp* d = nullptr;
+        const void* d = nullptr;
         Slot* s = nullptr;
-        int rc = stage(ops, n, false, "mbamdParsDownPass", &d, &s);
+        int rc = stage(compiled.data(), (size_t) total * sizeof(ParsStep), &d, &s);
         if (rc) return rc;
-        MBAMD_PARS_DISPATCH(launchDown, d, n, outLength ? d_out : nullptr);
+        launchWalk(static_cast<const ParsStep*>(d), nchunks, outLength ? d_out : nullptr);
         HIP_TRY(hipGetLastError());
         rc = release(s);
         if (rc) return rc;
@@ -347,30 +526,40 @@ public:
         return BEAGLE_SUCCESS;
     }
 
-    int finalPass(const int* ops, int n)
+    int downPass(const int* ops, int n, double* outLength)
     {
-        if (n <= 0) return BEAGLE_SUCCESS;
-        for (int i = 0; i < n; ++i)
-            if (ops[4 * i + 3] < 0) return fail(BEAGLE_ERROR_OUT_OF_RANGE, "mbamdParsFinalPass", "a node without ancestor");
-        const ParsOp* d = nullptr;
-        Slot* s = nullptr;
-        int rc = stage(ops, n, false, "mbamdParsFinalPass", &d, &s);
+        if (!outLength) return enqueue(PARS_DOWN, ops, n, "mbamdParsDownPass");
+        int rc = flush(nullptr);                     // the length asked for is this pass's alone
         if (rc) return rc;
-        MBAMD_PARS_DISPATCH(launchFinal, d, n);
-        HIP_TRY(hipGetLastError());
-        return release(s);
+        rc = enqueue(PARS_DOWN, ops, n, "mbamdParsDownPass");
+        if (rc) return rc;
+        return flush(outLength);
     }
+
+    int finalPass(const int* ops, int n) { return enqueue(PARS_FINAL, ops, n, "mbamdParsFinalPass"); }
 
     int score(const int* tuples, int n, double* out)
     {
+        for (int i = 0; i < 4 * n; ++i) {
+            int rc = checkIndex(tuples[i], true, "mbamdParsScore");
+            if (rc) return rc;
+        }
+        int rc = flush(nullptr);
+        if (rc) return rc;
         if (n <= 0) return BEAGLE_SUCCESS;
-        int rc = growOut((size_t) n * SCORE_Y);
+        rc = growOut((size_t) n * SCORE_Y);
         if (rc) return rc;
-        const ParsOp* d = nullptr;
+        const void* d = nullptr;
         Slot* s = nullptr;
-        rc = stage(tuples, n, true, "mbamdParsScore", &d, &s);
+        rc = stage(tuples, (size_t) n * sizeof(ParsOp), &d, &s);
         if (rc) return rc;
-        MBAMD_PARS_DISPATCH(launchScore, d, n);
+        switch (width) {
+            case 1: launchScore<uint8_t>(static_cast<const ParsOp*>(d), n); break;
+            case 2: launchScore<uint16_t>(static_cast<const ParsOp*>(d), n); break;
+            case 4: launchScore<uint32_t>(static_cast<const ParsOp*>(d), n); break;
+            case 8: launchScore<uint64_t>(static_cast<const ParsOp*>(d), n); break;
+            default: launchScore<u128>(static_cast<const ParsOp*>(d), n); break;
+        }
         HIP_TRY(hipGetLastError());
         rc = release(s);
         if (rc) return rc;
