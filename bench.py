@@ -116,7 +116,7 @@ def mcmc_gen_per_s(gold, nchains=1, quick=True):
         runs = [("engine", refrun.REF_MB_AMD, "dynamic"), ("reference_cpu", refrun.REF_MB, None)]
         if not fixed and os.path.exists(refrun.REF_MB_AMD_PARS):
             runs.insert(1, ("engine_device_parsimony", refrun.REF_MB_AMD_PARS, "dynamic"))
-            windows[(False, "engine_device_parsimony")] = (1000, 6000) if quick else (2000, 22000)
+            windows[(False, "engine_device_parsimony")] = (2000, 17000) if quick else (2000, 42000)
         for tag, binary, beagle in runs:
             lo, hi = windows[(fixed, tag)]
             walls = []

@@ -46,8 +46,9 @@ struct ApiStats {
     double seconds = 0.0;
 };
 static ApiStats g_stats[] = {{"beagleUpdateTransitionMatrices"}, {"beagleUpdatePartials"}, {"beagleCalculate*LogLikelihoods"},
-                             {"beagle*ScaleFactors"}, {"beagleSet*"}, {"beagleGetSiteLogLikelihoods"}, {"plan build"}};
-enum { ST_MATRICES = 0, ST_PARTIALS, ST_LNL, ST_SCALE, ST_SET, ST_SITE, ST_PLAN };
+                             {"beagle*ScaleFactors"}, {"beagleSet*"}, {"beagleGetSiteLogLikelihoods"}, {"plan build"},
+                             {"mbamdParsDownPass/FinalPass"}, {"mbamdParsScore"}};
+enum { ST_MATRICES = 0, ST_PARTIALS, ST_LNL, ST_SCALE, ST_SET, ST_SITE, ST_PLAN, ST_PARS_PASS, ST_PARS_SCORE };
 static const bool g_statsOn = std::getenv("MBAMD_STATS") != nullptr;
 // MBAMD_API_TRACE=1: one stderr line per C-ABI call (integration debugging: what does the client really send?)
 static const bool g_apiTrace = std::getenv("MBAMD_API_TRACE") != nullptr;
@@ -3481,6 +3482,7 @@ int mbamdParsSetPatternWeights(int pars, const float* weights)
 }
 int mbamdParsDownPass(int pars, const int* ops, int count, double* outLength)
 {
+    StatTimer st_(ST_PARS_PASS);
     GET_PARS(pars);
     API_TRACE("mbamdParsDownPass(%d ops%s)", count, outLength ? ", length" : "");
     if (count < 0 || (count > 0 && !ops)) return fail(BEAGLE_ERROR_OUT_OF_RANGE, "mbamdParsDownPass: arguments");
@@ -3488,6 +3490,7 @@ int mbamdParsDownPass(int pars, const int* ops, int count, double* outLength)
 }
 int mbamdParsFinalPass(int pars, const int* ops, int count)
 {
+    StatTimer st_(ST_PARS_PASS);
     GET_PARS(pars);
     API_TRACE("mbamdParsFinalPass(%d nodes)", count);
     if (count < 0 || (count > 0 && !ops)) return fail(BEAGLE_ERROR_OUT_OF_RANGE, "mbamdParsFinalPass: arguments");
@@ -3495,6 +3498,7 @@ int mbamdParsFinalPass(int pars, const int* ops, int count)
 }
 int mbamdParsScore(int pars, const int* tuples, int count, double* outLengths)
 {
+    StatTimer st_(ST_PARS_SCORE);
     GET_PARS(pars);
     API_TRACE("mbamdParsScore(%d tuples)", count);
     if (count < 0 || (count > 0 && (!tuples || !outLengths))) return fail(BEAGLE_ERROR_OUT_OF_RANGE, "mbamdParsScore: arguments");
