@@ -47,8 +47,9 @@ struct ApiStats {
 };
 static ApiStats g_stats[] = {{"beagleUpdateTransitionMatrices"}, {"beagleUpdatePartials"}, {"beagleCalculate*LogLikelihoods"},
                              {"beagle*ScaleFactors"}, {"beagleSet*"}, {"beagleGetSiteLogLikelihoods"}, {"plan build"},
-                             {"mbamdParsDownPass/FinalPass"}, {"mbamdParsScore"}};
-enum { ST_MATRICES = 0, ST_PARTIALS, ST_LNL, ST_SCALE, ST_SET, ST_SITE, ST_PLAN, ST_PARS_PASS, ST_PARS_SCORE };
+                             {"mbamdParsDownPass/FinalPass"}, {"mbamdParsScore"},
+                             {"  (launching the deferred work)"}, {"  (waiting for the device)"}};
+enum { ST_MATRICES = 0, ST_PARTIALS, ST_LNL, ST_SCALE, ST_SET, ST_SITE, ST_PLAN, ST_PARS_PASS, ST_PARS_SCORE, ST_FLUSH, ST_WAIT };
 static const bool g_statsOn = std::getenv("MBAMD_STATS") != nullptr;
 // MBAMD_API_TRACE=1: one stderr line per C-ABI call (integration debugging: what does the client really send?)
 static const bool g_apiTrace = std::getenv("MBAMD_API_TRACE") != nullptr;
@@ -1126,6 +1127,7 @@ bool Instance::independentOfPending(const Plan& plan, int cumIdx)
 
 int Instance::flushPending()
 {
+    StatTimer st_(ST_FLUSH);
     int mrc = flushMatrices();                   // (queued matrix jobs precede the lists that read them)
     if (mrc) return mrc;
     if (wg) return flushWalkG();
@@ -2390,7 +2392,10 @@ int Instance::integrate4(const int* parent, const int* child, const int* prob, c
 int Instance::fetchResult(double* out)
 {
     if (!pendingResult) return fail(BEAGLE_ERROR_GENERAL, "no log-likelihood pending");
-    HIP_TRY(hipStreamSynchronize(stream));
+    {
+        StatTimer st_(ST_WAIT);
+        HIP_TRY(hipStreamSynchronize(stream));
+    }
     syncedClock = launchClock;
     pendingResult = false;
     double s = 0.0;
