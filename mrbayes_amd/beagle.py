@@ -26,6 +26,7 @@ BEAGLE_ERROR_FLOATING_POINT = -8
 BEAGLE_OP_NONE = -1
 
 BEAGLE_FLAG_PRECISION_SINGLE = 1 << 0
+BEAGLE_FLAG_PRECISION_DOUBLE = 1 << 1
 BEAGLE_FLAG_SCALING_ALWAYS = 1 << 8
 BEAGLE_FLAG_SCALERS_LOG = 1 << 10
 BEAGLE_FLAG_PROCESSOR_GPU = 1 << 16

@@ -226,6 +226,7 @@ struct Instance {
 
     int NT = 0, T = 0;               // MFMA packing: i-tiles of 32 rows, j-pairs
     long flags = 0;
+    class Engine64* f64 = nullptr;        // BEAGLE_FLAG_PRECISION_DOUBLE: this object is only the handle, the engine is mbamd_f64.h
     size_t partialsFloats = 0, matrixFloats = 0, eigenDoubles = 0;
     int path = PATH_AUTO;
 
@@ -2435,7 +2436,7 @@ static void buildResources()
         g_resourceDescs[i] = buf;
         g_resourceVec[i].name = const_cast<char*>(g_resourceNames[i].c_str());
         g_resourceVec[i].description = const_cast<char*>(g_resourceDescs[i].c_str());
-        g_resourceVec[i].supportFlags = kSupport;
+        g_resourceVec[i].supportFlags = kSupport | BEAGLE_FLAG_PRECISION_DOUBLE;
         g_resourceVec[i].requiredFlags = 0;
     }
     g_resources.list = g_resourceVec.data();
@@ -2545,6 +2546,7 @@ int Instance::makeChildren(const std::vector<std::pair<int, int>>& ranges)
 // =============================================================================================
 #include "libhmsbeagle/mbamd_parsimony.h"
 #include "mbamd_parsimony.h"
+#include "mbamd_f64.h"
 
 using namespace mbamd;
 
@@ -2694,12 +2696,16 @@ int beagleCreateInstance(int tipCount, int partialsBufferCount, int compactBuffe
         return fail(BEAGLE_ERROR_OUT_OF_RANGE, "beagleCreateInstance: bad dimensions");
     if (stateCount > 64) return fail(BEAGLE_ERROR_NO_IMPLEMENTATION, "beagleCreateInstance: more than 64 states");
     if (categoryCount > MBAMD_MAX_RATES) return fail(BEAGLE_ERROR_NO_IMPLEMENTATION, "beagleCreateInstance: more than 16 rate categories");
-    if (requirementFlags & (BEAGLE_FLAG_PRECISION_DOUBLE | BEAGLE_FLAG_EIGEN_COMPLEX | BEAGLE_FLAG_PROCESSOR_CPU |
+    if (requirementFlags & (BEAGLE_FLAG_EIGEN_COMPLEX | BEAGLE_FLAG_PROCESSOR_CPU |
                             BEAGLE_FLAG_FRAMEWORK_CUDA | BEAGLE_FLAG_FRAMEWORK_OPENCL | BEAGLE_FLAG_SCALERS_RAW))
         return fail(BEAGLE_ERROR_NO_IMPLEMENTATION, "beagleCreateInstance: unsupported requirement flags");
-    if ((preferenceFlags & BEAGLE_FLAG_PRECISION_DOUBLE) && std::getenv("MBAMD_VERBOSE"))
-        std::fprintf(stderr, "[mbamd] note: double precision was preferred; this engine computes conditional likelihoods in fp32 "
-                             "(sums and logarithms in fp64) like the reference's default CLFlt\n");
+    if ((requirementFlags & BEAGLE_FLAG_PRECISION_DOUBLE) && (requirementFlags & BEAGLE_FLAG_PRECISION_SINGLE))
+        return fail(BEAGLE_ERROR_NO_IMPLEMENTATION, "beagleCreateInstance: both precisions required");
+    // double precision when it is required, or preferred and single is neither required nor preferred as well (MrBayes puts
+    // `set beagleprecision=` into the preference flags, reference src/mbbeagle.c:186; single is the faster engine)
+    const bool wantDouble = (requirementFlags & BEAGLE_FLAG_PRECISION_DOUBLE) ||
+                            ((preferenceFlags & BEAGLE_FLAG_PRECISION_DOUBLE) && !(preferenceFlags & BEAGLE_FLAG_PRECISION_SINGLE) &&
+                             !(requirementFlags & BEAGLE_FLAG_PRECISION_SINGLE));
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
         return fail(BEAGLE_ERROR_NO_RESOURCE, "beagleCreateInstance: no HIP device (this engine has no CPU path)");
@@ -2725,7 +2731,16 @@ int beagleCreateInstance(int tipCount, int partialsBufferCount, int compactBuffe
     std::memcpy(in->createArgs, args, sizeof args);
     in->shardDevices = devices;
     int rc;
-    if (devices.size() > 1 && patternCount > 64) {
+    if (wantDouble) {
+        // the handle only: every entry point forwards to the fp64 engine (mbamd_f64.h); one device, no shards
+        in->device = dev;
+        in->S = stateCount; in->P = patternCount; in->K = categoryCount; in->nEigen = eigenBufferCount;
+        in->released = true;
+        in->flags = (in->flags & ~BEAGLE_FLAG_PRECISION_SINGLE) | BEAGLE_FLAG_PRECISION_DOUBLE;
+        in->f64 = new Engine64();
+        rc = in->f64->create(tipCount, partialsBufferCount, compactBufferCount, stateCount, patternCount, eigenBufferCount,
+                             matrixBufferCount, categoryCount, scaleBufferCount, dev);
+    } else if (devices.size() > 1 && patternCount > 64) {
         // facade from the start: dimensions only, the children own the device memory
         in->device = dev;
         in->tipCount = tipCount; in->nBuffers = partialsBufferCount + compactBufferCount; in->S = stateCount; in->P = patternCount;
@@ -2755,6 +2770,7 @@ int beagleCreateInstance(int tipCount, int partialsBufferCount, int compactBuffe
     if (rc != BEAGLE_SUCCESS) {
         in->destroyChildren();
         if (!in->released) in->destroy();
+        delete in->f64;
         delete in;
         return rc;
     }
@@ -2772,7 +2788,8 @@ int beagleCreateInstance(int tipCount, int partialsBufferCount, int compactBuffe
         const Instance* first = in->facade() ? in->children[0].in : in;
         returnInfo->resourceNumber = dev;
         returnInfo->resourceName = (dev < g_resources.length) ? g_resources.list[dev].name : const_cast<char*>("HIP device");
-        returnInfo->implName = const_cast<char*>(first->s4 ? "mbamd HIP gfx950: 4-state tree-walk kernels"
+        returnInfo->implName = const_cast<char*>(first->f64 ? "mbamd HIP gfx950: double-precision level kernels"
+                                                 : first->s4 ? "mbamd HIP gfx950: 4-state tree-walk kernels"
                                                  : first->wg ? "mbamd HIP gfx950: 20/61-state tree-walk kernels (v_mfma_f32_32x32x2_f32)"
                                                  : first->mfma ? "mbamd HIP gfx950: general-state MFMA (v_mfma_f32_32x32x2_f32) kernels"
                                                                : "mbamd HIP gfx950: general-state vector kernels");
@@ -2801,6 +2818,7 @@ int beagleFinalizeInstance(int instance)
     }
     in->destroyChildren();
     if (!in->released) in->destroy();
+    delete in->f64;
     delete in;
     return BEAGLE_SUCCESS;
 }
@@ -2823,6 +2841,7 @@ int beagleSetCPUThreadCount(int instance, int threadCount)
 {
     (void) threadCount;
     GET_INSTANCE_NOFLUSH(instance);
+    if (in->f64) return BEAGLE_SUCCESS;
     return BEAGLE_SUCCESS;
 }
 
@@ -2832,6 +2851,7 @@ int beagleSetCPUThreadCount(int instance, int threadCount)
 int beagleSetPatternPartitions(int instance, int partitionCount, const int* inPatternPartitions)
 {
     GET_INSTANCE(instance);
+    if (in->f64) return fail(BEAGLE_ERROR_NO_IMPLEMENTATION, "beagleSetPatternPartitions: not on a double-precision instance");
     API_TRACE("beagleSetPatternPartitions(%d partitions)", partitionCount);
     if (partitionCount < 1 || !inPatternPartitions) return fail(BEAGLE_ERROR_OUT_OF_RANGE, "beagleSetPatternPartitions: arguments");
     if (!in->logOpen) return fail(BEAGLE_ERROR_GENERAL, "beagleSetPatternPartitions: call it before the first matrix / partials update");
@@ -2856,6 +2876,7 @@ int beagleSetPatternPartitions(int instance, int partitionCount, const int* inPa
 int beagleSetTipStates(int instance, int tipIndex, const int* inStates)
 {
     GET_INSTANCE(instance);
+    if (in->f64) return in->f64->setTipStates(tipIndex, inStates);
     API_TRACE("beagleSetTipStates(tip=%d, states=%s...)", tipIndex, trace_ints(inStates, std::min(8, in->P)).c_str());
     if (in->logOpen) in->logTipStates.emplace_back(tipIndex, std::vector<int>(inStates, inStates + in->P));
     FACADE_ALL(c->setTipStates(tipIndex, inStates + ch.start));
@@ -2864,6 +2885,7 @@ int beagleSetTipStates(int instance, int tipIndex, const int* inStates)
 int beagleSetTipPartials(int instance, int tipIndex, const double* inPartials)
 {
     GET_INSTANCE(instance);
+    if (in->f64) return in->f64->setPartials(tipIndex, inPartials, false);
     API_TRACE("beagleSetTipPartials(tip=%d, %s...)", tipIndex, trace_doubles(inPartials, std::min(8, in->S)).c_str());
     if (in->logOpen) in->logTipPartials.emplace_back(tipIndex, std::vector<double>(inPartials, inPartials + (size_t) in->P * in->S));
     FACADE_ALL(c->importPartials(tipIndex, inPartials + (size_t) ch.start * in->S, false));
@@ -2872,6 +2894,7 @@ int beagleSetTipPartials(int instance, int tipIndex, const double* inPartials)
 int beagleSetPartials(int instance, int bufferIndex, const double* inPartials)
 {
     GET_INSTANCE(instance);
+    if (in->f64) return in->f64->setPartials(bufferIndex, inPartials, true);
     if (in->facade()) {
         std::vector<double> part;
         for (Instance::Child& ch : in->children) {
@@ -2890,6 +2913,7 @@ int beagleSetPartials(int instance, int bufferIndex, const double* inPartials)
 int beagleGetPartials(int instance, int bufferIndex, int scaleIndex, double* outPartials)
 {
     GET_INSTANCE(instance);
+    if (in->f64) return in->f64->getPartials(bufferIndex, outPartials);
     if (scaleIndex != BEAGLE_OP_NONE) return fail(BEAGLE_ERROR_NO_IMPLEMENTATION, "beagleGetPartials: scaleIndex must be BEAGLE_OP_NONE");
     if (in->facade()) {
         std::vector<double> part;
@@ -2912,6 +2936,7 @@ int beagleSetEigenDecomposition(int instance, int eigenIndex, const double* inEi
 {
     StatTimer st_(ST_SET);
     GET_INSTANCE(instance);
+    if (in->f64) return in->f64->setEigen(eigenIndex, inEigenVectors, inInverseEigenVectors, inEigenValues);
     API_TRACE("beagleSetEigenDecomposition(eigen=%d, values=%s...)", eigenIndex, trace_doubles(inEigenValues, std::min(6, in->S)).c_str());
     FACADE_ALL(c->setEigen(eigenIndex, inEigenVectors, inInverseEigenVectors, inEigenValues));
     return in->setEigen(eigenIndex, inEigenVectors, inInverseEigenVectors, inEigenValues);
@@ -2923,6 +2948,7 @@ int beagleSetEigenDecomposition(int instance, int eigenIndex, const double* inEi
 int mbamdSetRateMatrices(int instance, int firstEigenIndex, int count, const double* q, const double* pi, int mode)
 {
     GET_INSTANCE(instance);
+    if (in->f64) return fail(BEAGLE_ERROR_NO_IMPLEMENTATION, "mbamdSetRateMatrices: not on a double-precision instance");
     if (!q || !pi || (mode != 0 && mode != 1)) return fail(BEAGLE_ERROR_OUT_OF_RANGE, "mbamdSetRateMatrices: arguments");
     FACADE_ALL(c->setRateMatrices(firstEigenIndex, count, q, pi, mode));
     return in->setRateMatrices(firstEigenIndex, count, q, pi, mode);
@@ -2931,6 +2957,7 @@ int beagleSetStateFrequencies(int instance, int idx, const double* f)
 {
     StatTimer st_(ST_SET);
     GET_INSTANCE(instance);
+    if (in->f64) return in->f64->setFreqs(idx, f);
     API_TRACE("beagleSetStateFrequencies(%d, %s...)", idx, trace_doubles(f, std::min(6, in->S)).c_str());
     if (idx < 0 || idx >= in->nEigen) return fail(BEAGLE_ERROR_OUT_OF_RANGE, "beagleSetStateFrequencies: index");
     FACADE_ALL(c->uploadIfChanged(c->h_freqs, (size_t) idx * c->S, c->d_freqs, f, c->S));
@@ -2940,6 +2967,7 @@ int beagleSetCategoryWeights(int instance, int idx, const double* w)
 {
     StatTimer st_(ST_SET);
     GET_INSTANCE(instance);
+    if (in->f64) return in->f64->setWeights(idx, w);
     API_TRACE("beagleSetCategoryWeights(%d, %s)", idx, trace_doubles(w, in->K).c_str());
     if (idx < 0 || idx >= in->nEigen) return fail(BEAGLE_ERROR_OUT_OF_RANGE, "beagleSetCategoryWeights: index");
     FACADE_ALL(c->uploadIfChanged(c->h_weights, (size_t) idx * c->K, c->d_weights, w, c->K));
@@ -2949,6 +2977,7 @@ int beagleSetCategoryRates(int instance, const double* r)
 {
     StatTimer st_(ST_SET);
     GET_INSTANCE(instance);
+    if (in->f64) return in->f64->setRates(0, r);
     API_TRACE("beagleSetCategoryRates(%s)", trace_doubles(r, in->K).c_str());
     FACADE_ALL(c->setRates(0, r));
     return in->setRates(0, r);
@@ -2958,6 +2987,7 @@ int beagleSetCategoryRatesWithIndex(int instance, int categoryRatesIndex, const 
 {
     StatTimer st_(ST_SET);
     GET_INSTANCE(instance);
+    if (in->f64) return in->f64->setRates(categoryRatesIndex, r);
     API_TRACE("beagleSetCategoryRatesWithIndex(%d, %s)", categoryRatesIndex, trace_doubles(r, in->K).c_str());
     FACADE_ALL(c->setRates(categoryRatesIndex, r));
     return in->setRates(categoryRatesIndex, r);
@@ -2965,6 +2995,7 @@ int beagleSetCategoryRatesWithIndex(int instance, int categoryRatesIndex, const 
 int beagleSetPatternWeights(int instance, const double* w)
 {
     GET_INSTANCE(instance);
+    if (in->f64) return in->f64->setPatternWeights(w);
     if (in->logOpen) in->logWeights.assign(w, w + in->P);
     FACADE_ALL(c->upload(c->d_pweights, w + ch.start, sizeof(double) * ch.count));
     return in->upload(in->d_pweights, w, sizeof(double) * in->P);
@@ -2975,6 +3006,7 @@ int beagleUpdateTransitionMatrices(int instance, int eigenIndex, const int* prob
 {
     StatTimer st_(ST_MATRICES);
     GET_INSTANCE_NOFLUSH(instance);
+    if (in->f64) return in->f64->updateMatrices(eigenIndex, 0, probabilityIndices, edgeLengths, count);
     API_TRACE("beagleUpdateTransitionMatrices(eigen=%d, count=%d, indices=%s..., lengths=%s...)", eigenIndex, count,
               trace_ints(probabilityIndices, std::min(6, count)).c_str(), trace_doubles(edgeLengths, std::min(6, count)).c_str());
     if (firstDerivativeIndices || secondDerivativeIndices)
@@ -2995,6 +3027,7 @@ int beagleUpdateTransitionMatricesWithMultipleModels(int instance, const int* ei
 {
     StatTimer st_(ST_MATRICES);
     GET_INSTANCE_NOFLUSH(instance);
+    if (in->f64) return fail(BEAGLE_ERROR_NO_IMPLEMENTATION, "beagleUpdateTransitionMatricesWithMultipleModels: not on a double-precision instance");
     API_TRACE("beagleUpdateTransitionMatricesWithMultipleModels(count=%d, eigen=%s..., rates=%s...)", count,
               trace_ints(eigenIndices, std::min(6, count)).c_str(), trace_ints(categoryRateIndices, std::min(6, count)).c_str());
     if (firstDerivativeIndices || secondDerivativeIndices)
@@ -3019,12 +3052,14 @@ int beagleSetTransitionMatrix(int instance, int matrixIndex, const double* inMat
 {
     (void) paddedValue;
     GET_INSTANCE(instance);
+    if (in->f64) return in->f64->setMatrix(matrixIndex, inMatrix);
     FACADE_ALL(c->setMatrix(matrixIndex, inMatrix));
     return in->setMatrix(matrixIndex, inMatrix);
 }
 int beagleGetTransitionMatrix(int instance, int matrixIndex, double* outMatrix)
 {
     GET_INSTANCE(instance);
+    if (in->f64) return in->f64->getMatrix(matrixIndex, outMatrix);
     if (in->facade()) {
         Instance* c = in->children[0].in;
         (void) hipSetDevice(c->device);
@@ -3037,6 +3072,7 @@ int beagleUpdatePartials(int instance, const BeagleOperation* operations, int op
 {
     StatTimer st_(ST_PARTIALS);
     GET_INSTANCE_NOFLUSH(instance);
+    if (in->f64) return in->f64->updatePartials(operations, operationCount, cumulativeScaleIndex);
     API_TRACE("beagleUpdatePartials(count=%d, cumulative=%d, first=%s, last=%s)", operationCount, cumulativeScaleIndex,
               trace_ints(reinterpret_cast<const int*>(operations), operationCount > 0 ? 7 : 0).c_str(),
               trace_ints(reinterpret_cast<const int*>(operations + std::max(0, operationCount - 1)), operationCount > 0 ? 7 : 0).c_str());
@@ -3050,6 +3086,7 @@ int beagleUpdatePartialsByPartition(int instance, const BeagleOperationByPartiti
 {
     StatTimer st_(ST_PARTIALS);
     GET_INSTANCE_NOFLUSH(instance);
+    if (in->f64) return fail(BEAGLE_ERROR_NO_IMPLEMENTATION, "beagleUpdatePartialsByPartition: not on a double-precision instance");
     API_TRACE("beagleUpdatePartialsByPartition(count=%d)", operationCount);
     in->closeLog();
     std::vector<BeagleOperation> list;
@@ -3081,6 +3118,7 @@ int beagleWaitForPartials(int instance, const int* destinationPartials, int dest
 {
     (void) destinationPartials; (void) destinationPartialsCount;
     GET_INSTANCE(instance);
+    if (in->f64) return in->f64->synchronize();
     FACADE_ALL(hipStreamSynchronize(c->stream) == hipSuccess ? BEAGLE_SUCCESS : BEAGLE_ERROR_GENERAL);
     HIP_TRY(hipStreamSynchronize(in->stream));
     return BEAGLE_SUCCESS;
@@ -3162,18 +3200,21 @@ int beagleAccumulateScaleFactors(int instance, const int* scaleIndices, int coun
 {
     StatTimer st_(ST_SCALE);
     GET_INSTANCE_NOFLUSH(instance);
+    if (in->f64) return in->f64->accumulateScale(scaleIndices, count, cumulativeScaleIndex, +1);
     return scale_accumulate(in, scaleIndices, count, cumulativeScaleIndex, +1, -1);
 }
 int beagleRemoveScaleFactors(int instance, const int* scaleIndices, int count, int cumulativeScaleIndex)
 {
     StatTimer st_(ST_SCALE);
     GET_INSTANCE_NOFLUSH(instance);
+    if (in->f64) return in->f64->accumulateScale(scaleIndices, count, cumulativeScaleIndex, -1);
     return scale_accumulate(in, scaleIndices, count, cumulativeScaleIndex, -1, -1);
 }
 int beagleResetScaleFactors(int instance, int cumulativeScaleIndex)
 {
     StatTimer st_(ST_SCALE);
     GET_INSTANCE(instance);
+    if (in->f64) return in->f64->resetScale(cumulativeScaleIndex);
     FACADE_ALL(scale_reset(c, cumulativeScaleIndex));
     return scale_reset(in, cumulativeScaleIndex);
 }
@@ -3181,6 +3222,7 @@ int beagleCopyScaleFactors(int instance, int destScalingIndex, int srcScalingInd
 {
     StatTimer st_(ST_SCALE);
     GET_INSTANCE(instance);
+    if (in->f64) return in->f64->copyScale(destScalingIndex, srcScalingIndex);
     FACADE_ALL(scale_copy(c, destScalingIndex, srcScalingIndex));
     return scale_copy(in, destScalingIndex, srcScalingIndex);
 }
@@ -3189,18 +3231,21 @@ int beagleAccumulateScaleFactorsByPartition(int instance, const int* scaleIndice
 {
     StatTimer st_(ST_SCALE);
     GET_INSTANCE_NOFLUSH(instance);
+    if (in->f64) return fail(BEAGLE_ERROR_NO_IMPLEMENTATION, "beagleAccumulateScaleFactorsByPartition: not on a double-precision instance");
     return scale_accumulate(in, scaleIndices, count, cumulativeScaleIndex, +1, partitionIndex);
 }
 int beagleRemoveScaleFactorsByPartition(int instance, const int* scaleIndices, int count, int cumulativeScaleIndex, int partitionIndex)
 {
     StatTimer st_(ST_SCALE);
     GET_INSTANCE_NOFLUSH(instance);
+    if (in->f64) return fail(BEAGLE_ERROR_NO_IMPLEMENTATION, "beagleRemoveScaleFactorsByPartition: not on a double-precision instance");
     return scale_accumulate(in, scaleIndices, count, cumulativeScaleIndex, -1, partitionIndex);
 }
 int beagleResetScaleFactorsByPartition(int instance, int cumulativeScaleIndex, int partitionIndex)
 {
     StatTimer st_(ST_SCALE);
     GET_INSTANCE(instance);
+    if (in->f64) return fail(BEAGLE_ERROR_NO_IMPLEMENTATION, "beagleResetScaleFactorsByPartition: not on a double-precision instance");
     FACADE_ALL((in->partitionCount > 1 && ch.partition != partitionIndex) ? BEAGLE_SUCCESS : scale_reset(c, cumulativeScaleIndex));
     return scale_reset(in, cumulativeScaleIndex);
 }
@@ -3209,6 +3254,7 @@ int beagleResetScaleFactorsByPartition(int instance, int cumulativeScaleIndex, i
 int mbamdGetScaleExponents(int instance, int srcScalingIndex, int* out)
 {
     GET_INSTANCE(instance);
+    if (in->f64) return in->f64->getScaleExponents(srcScalingIndex, out);
     if (in->facade()) {
         std::vector<int> part;
         for (Instance::Child& ch : in->children) {
@@ -3229,6 +3275,7 @@ int mbamdGetScaleExponents(int instance, int srcScalingIndex, int* out)
 int beagleGetScaleFactors(int instance, int srcScalingIndex, double* outScaleFactors)
 {
     GET_INSTANCE(instance);
+    if (in->f64) return in->f64->getScaleFactors(srcScalingIndex, outScaleFactors);
     if (srcScalingIndex < 0 || srcScalingIndex >= in->nScale) return fail(BEAGLE_ERROR_OUT_OF_RANGE, "beagleGetScaleFactors: index");
     std::vector<int> e((size_t) in->K * in->P);
     int rc = mbamdGetScaleExponents(instance, srcScalingIndex, e.data());
@@ -3246,6 +3293,7 @@ int beagleCalculateRootLogLikelihoods(int instance, const int* bufferIndices, co
 {
     StatTimer st_(ST_LNL);
     GET_INSTANCE(instance);
+    if (in->f64) return in->f64->logLikelihoods(bufferIndices, nullptr, nullptr, categoryWeightsIndices, stateFrequenciesIndices, cumulativeScaleIndices, count, outSumLogLikelihood);
     const int rc_ = integrate_any(in, bufferIndices, nullptr, nullptr, categoryWeightsIndices, stateFrequenciesIndices,
                                   cumulativeScaleIndices, count, nullptr, 1, nullptr, outSumLogLikelihood);
     API_TRACE("beagleCalculateRootLogLikelihoods(buffers=%s, weights=%s, freqs=%s, cumulative=%s) -> %d, lnL %.6f",
@@ -3263,6 +3311,7 @@ int beagleCalculateEdgeLogLikelihoods(int instance, const int* parentBufferIndic
 {
     StatTimer st_(ST_LNL);
     GET_INSTANCE(instance);
+    if (in->f64) return (firstDerivativeIndices || secondDerivativeIndices || outSumFirstDerivative || outSumSecondDerivative) ? fail(BEAGLE_ERROR_NO_IMPLEMENTATION, "beagleCalculateEdgeLogLikelihoods: derivatives") : in->f64->logLikelihoods(parentBufferIndices, childBufferIndices, probabilityIndices, categoryWeightsIndices, stateFrequenciesIndices, cumulativeScaleIndices, count, outSumLogLikelihood);
     if (firstDerivativeIndices || secondDerivativeIndices || outSumFirstDerivative || outSumSecondDerivative)
         return fail(BEAGLE_ERROR_NO_IMPLEMENTATION, "beagleCalculateEdgeLogLikelihoods: derivatives");
     const int rc_ = integrate_any(in, parentBufferIndices, childBufferIndices, probabilityIndices, categoryWeightsIndices,
@@ -3282,6 +3331,7 @@ int beagleCalculateRootLogLikelihoodsByPartition(int instance, const int* buffer
 {
     StatTimer st_(ST_LNL);
     GET_INSTANCE(instance);
+    if (in->f64) return fail(BEAGLE_ERROR_NO_IMPLEMENTATION, "beagleCalculateRootLogLikelihoodsByPartition: not on a double-precision instance");
     if (!in->facade() && (partitionCount != 1 || partitionIndices[0] != 0))
         return fail(BEAGLE_ERROR_OUT_OF_RANGE, "beagleCalculateRootLogLikelihoodsByPartition: no partitions were set");
     double total = 0.0;
@@ -3303,6 +3353,7 @@ int beagleCalculateEdgeLogLikelihoodsByPartition(int instance, const int* parent
 {
     StatTimer st_(ST_LNL);
     GET_INSTANCE(instance);
+    if (in->f64) return fail(BEAGLE_ERROR_NO_IMPLEMENTATION, "beagleCalculateEdgeLogLikelihoodsByPartition: not on a double-precision instance");
     if (firstDerivativeIndices || secondDerivativeIndices || outSumFirstDerivativeByPartition || outSumFirstDerivative ||
         outSumSecondDerivativeByPartition || outSumSecondDerivative)
         return fail(BEAGLE_ERROR_NO_IMPLEMENTATION, "beagleCalculateEdgeLogLikelihoodsByPartition: derivatives");
@@ -3321,6 +3372,7 @@ int beagleGetSiteLogLikelihoods(int instance, double* outLogLikelihoods)
 {
     StatTimer st_(ST_SITE);
     GET_INSTANCE(instance);
+    if (in->f64) return in->f64->getSites(outLogLikelihoods);
     FACADE_ALL(c->haveSite ? c->getSites(outLogLikelihoods + ch.start) : BEAGLE_SUCCESS);
     return in->getSites(outLogLikelihoods);
 }
@@ -3329,6 +3381,7 @@ int beagleGetSiteLogLikelihoods(int instance, double* outLogLikelihoods)
 int mbamdSynchronize(int instance)
 {
     GET_INSTANCE(instance);
+    if (in->f64) return in->f64->synchronize();
     FACADE_ALL(hipStreamSynchronize(c->stream) == hipSuccess ? BEAGLE_SUCCESS : BEAGLE_ERROR_GENERAL);
     HIP_TRY(hipStreamSynchronize(in->stream));
     return BEAGLE_SUCCESS;
@@ -3336,6 +3389,7 @@ int mbamdSynchronize(int instance)
 int mbamdKernelTiming(int instance, int enable)
 {
     GET_INSTANCE(instance);
+    if (in->f64) return BEAGLE_SUCCESS;
     if (in->facade()) { for (Instance::Child& ch : in->children) ch.in->timing = enable != 0; return BEAGLE_SUCCESS; }
     in->timing = enable != 0;
     return BEAGLE_SUCCESS;
@@ -3363,6 +3417,7 @@ static int kernel_timing_of(Instance* in, double* ms, long* launches, int reset)
 int mbamdGetKernelTiming(int instance, double* outMilliseconds, long* outLaunches, int reset)
 {
     GET_INSTANCE(instance);
+    if (in->f64) return fail(BEAGLE_ERROR_NO_IMPLEMENTATION, "mbamdGetKernelTiming: not on a double-precision instance");
     double ms = 0.0;
     long launches = 0;
     if (in->facade()) {
@@ -3383,6 +3438,7 @@ int mbamdGetKernelTiming(int instance, double* outMilliseconds, long* outLaunche
 int mbamdSetKernelPath(int instance, int path)
 {
     GET_INSTANCE(instance);
+    if (in->f64) return BEAGLE_SUCCESS;
     if (path < 0 || path > 3) return fail(BEAGLE_ERROR_OUT_OF_RANGE, "mbamdSetKernelPath");
     in->path = path;
     return BEAGLE_SUCCESS;
@@ -3390,6 +3446,7 @@ int mbamdSetKernelPath(int instance, int path)
 int mbamdWalkTrace(int instance, long long* out, int maxSteps, int* outSteps, int* outWaves)
 {
     GET_INSTANCE(instance);
+    if (in->f64) return fail(BEAGLE_ERROR_NO_IMPLEMENTATION, "mbamdWalkTrace: not on a double-precision instance");
     if (!in->d_trace) return fail(BEAGLE_ERROR_GENERAL, "set MBAMD_WALK_TRACE before creating the instance");
     HIP_TRY(hipStreamSynchronize(in->stream));
     const int n = std::min(maxSteps, std::min(4096, in->lastWalkSteps));
@@ -3407,6 +3464,7 @@ int mbamdGetChildCount(int instance)
 int mbamdSetDeferredResult(int instance, int enable)
 {
     GET_INSTANCE(instance);
+    if (in->f64) return enable ? fail(BEAGLE_ERROR_NO_IMPLEMENTATION, "mbamdSetDeferredResult: not on a double-precision instance") : BEAGLE_SUCCESS;
     if (in->facade()) return enable ? fail(BEAGLE_ERROR_NO_IMPLEMENTATION, "mbamdSetDeferredResult: not on a partitioned / sharded instance") : BEAGLE_SUCCESS;
     in->deferred = enable != 0;
     return BEAGLE_SUCCESS;
@@ -3414,6 +3472,7 @@ int mbamdSetDeferredResult(int instance, int enable)
 int mbamdFetchLogLikelihood(int instance, double* outSumLogLikelihood)
 {
     GET_INSTANCE(instance);
+    if (in->f64) return fail(BEAGLE_ERROR_NO_IMPLEMENTATION, "mbamdFetchLogLikelihood: not on a double-precision instance");
     if (in->facade()) return fail(BEAGLE_ERROR_NO_IMPLEMENTATION, "mbamdFetchLogLikelihood: not on a partitioned / sharded instance");
     return in->fetchResult(outSumLogLikelihood);
 }

@@ -1,0 +1,658 @@
+// mbamd_f64.h -- the double-precision engine behind BEAGLE_FLAG_PRECISION_DOUBLE (`set beagleprecision=double`, reference
+// src/command.c:6760-6766; the build it corresponds to is the reference with CLFlt = double, src/bayes.h:110-112).
+// Included by mbamd_engine.cpp.  A compact, level-synchronous engine for any state count <= 64: conditional likelihoods,
+// transition matrices, sums and logarithms all in fp64; rescaling by exact powers of two with integer exponents, like the
+// fp32 engine.  First correct path: one launch per dependency level and kind, no tree walk, no matrix cores -- the fp32
+// engines are the optimised ones, this one exists so that the precision flag of the seam means what it says.
+//
+// HBM layout: partials double [buffer][K][S][P_pad] (a thread owns one pattern; every access is coalesced across
+// patterns), compact tips uint8 [P_pad], matrices double [buffer][K][S][S] (row = from-state, for the edge integration)
+// followed by the transposed copy [K][S][SPAD] with zero-padded rows (the operand of the partials kernel: wave-uniform,
+// read through the scalar cache), scale buffers int32 [P_pad] (binary exponents; cumulative buffers are their sums).
+#ifndef MBAMD_F64_H_
+#define MBAMD_F64_H_
+
+namespace mbamd {
+
+struct Op64 {
+    double* dst;
+    const void* c1;              // partials (double) or compact states (uint8)
+    const void* c2;
+    const double* m1T;           // transposed matrices of child 1: [K][S][SPAD]
+    const double* m2T;
+    int32_t* scale;              // exponents written (mode 1) or read (mode 2)
+    int c1_tip, c2_tip, mode, pad_;
+};
+
+template <int IB>
+__device__ __forceinline__ void f64_child_factor(const void* ptr, int tip, const double* __restrict__ mT, int S, int SPAD, int k,
+                                                 size_t Ppad, size_t c, int i0, double (&f)[IB])
+{
+    if (tip) {
+        const unsigned s = reinterpret_cast<const uint8_t*>(ptr)[c];
+        if (s >= (unsigned) S) {
+#pragma unroll
+            for (int i = 0; i < IB; ++i) f[i] = 1.0;
+        } else {
+            const double* col = mT + (size_t) s * SPAD + i0;           // P(i -> s), all i: contiguous
+#pragma unroll
+            for (int i = 0; i < IB; ++i) f[i] = col[i];
+        }
+    } else {
+        const double* cl = reinterpret_cast<const double*>(ptr) + (size_t) k * S * Ppad + c;
+#pragma unroll
+        for (int i = 0; i < IB; ++i) f[i] = 0.0;
+        for (int j = 0; j < S; ++j) {
+            const double vj = cl[(size_t) j * Ppad];
+            const double* __restrict__ col = mT + (size_t) j * SPAD + i0;
+#pragma unroll
+            for (int i = 0; i < IB; ++i) f[i] = fma(col[i], vj, f[i]);
+        }
+    }
+}
+
+// CondLikeDown_* in fp64 (reference src/likelihood.c:204-375 with CLFlt = double): grid (P_pad/64, operations of a level)
+template <int IB>
+__global__ void __launch_bounds__(64)
+k64_partials(const Op64* __restrict__ ops, int S, int SPAD, int K, int Ppad_)
+{
+    const Op64& op = ops[blockIdx.y];
+    const size_t Ppad = (size_t) Ppad_, c = (size_t) blockIdx.x * 64 + threadIdx.x;
+    for (int k = 0; k < K; ++k)
+        for (int i0 = 0; i0 < S; i0 += IB) {
+            double f1[IB], f2[IB];
+            f64_child_factor<IB>(op.c1, op.c1_tip, op.m1T + (size_t) k * S * SPAD, S, SPAD, k, Ppad, c, i0, f1);
+            f64_child_factor<IB>(op.c2, op.c2_tip, op.m2T + (size_t) k * S * SPAD, S, SPAD, k, Ppad, c, i0, f2);
+#pragma unroll
+            for (int i = 0; i < IB; ++i)
+                if (i0 + i < S) op.dst[((size_t) k * S + i0 + i) * Ppad + c] = f1[i] * f2[i];
+        }
+}
+
+// The same with the rescale fused (K == KF categories, S <= IB: all K x S results of a pattern stay in registers): one pass
+// over HBM instead of three.  Instantiated for four states and the default four gamma categories (at 20 states the K x S
+// results need all 256 VGPRs and the fused kernel is no faster: measured, dropped).
+template <int IB, int KF>
+__global__ void __launch_bounds__(64)
+k64_partials_fused(const Op64* __restrict__ ops, int S, int SPAD, int Ppad_, int32_t* __restrict__ cumulative)
+{
+    const Op64& op = ops[blockIdx.y];
+    const size_t Ppad = (size_t) Ppad_, c = (size_t) blockIdx.x * 64 + threadIdx.x;
+    double out[KF][IB];
+    double mx = 0.0;
+#pragma unroll
+    for (int k = 0; k < KF; ++k) {
+        double f2[IB];
+        f64_child_factor<IB>(op.c1, op.c1_tip, op.m1T + (size_t) k * S * SPAD, S, SPAD, k, Ppad, c, 0, out[k]);
+        f64_child_factor<IB>(op.c2, op.c2_tip, op.m2T + (size_t) k * S * SPAD, S, SPAD, k, Ppad, c, 0, f2);
+#pragma unroll
+        for (int i = 0; i < IB; ++i) {
+            out[k][i] *= f2[i];
+            if (i < S) mx = fmax(mx, out[k][i]);
+        }
+    }
+    int e = 0;
+    if (op.mode == 1) {
+        if (mx > 0.0 && mx < 1.0e300) (void) frexp(mx, &e);
+        e = e < -1000 ? -1000 : e;
+        op.scale[c] = e;
+        if (cumulative != nullptr && e != 0) atomicAdd(cumulative + c, e);
+    } else if (op.mode == 2) {
+        e = op.scale[c];
+    }
+#pragma unroll
+    for (int k = 0; k < KF; ++k)
+#pragma unroll
+        for (int i = 0; i < IB; ++i)
+            if (i < S) op.dst[((size_t) k * S + i) * Ppad + c] = e != 0 ? ldexp(out[k][i], -e) : out[k][i];
+}
+
+// CondLikeScaler_* (reference src/likelihood.c:4939-4988): per-pattern maximum over categories and states, exact
+// power-of-two rescale, exponent kept (and added to the cumulative buffer of the call)
+__global__ void __launch_bounds__(64)
+k64_rescale(const Op64* __restrict__ ops, int S, int K, int Ppad_, int32_t* __restrict__ cumulative)
+{
+    const Op64& op = ops[blockIdx.y];
+    if (op.mode == 0) return;
+    const size_t Ppad = (size_t) Ppad_, c = (size_t) blockIdx.x * 64 + threadIdx.x;
+    double* dst = op.dst + c;
+    const int n = K * S;
+    int e = 0;
+    if (op.mode == 1) {
+        double mx = 0.0;
+        for (int r = 0; r < n; ++r) mx = fmax(mx, dst[(size_t) r * Ppad]);
+        if (mx > 0.0 && mx < 1.0e300) (void) frexp(mx, &e);
+        e = e < -1000 ? -1000 : e;
+        op.scale[c] = e;
+        if (cumulative != nullptr && e != 0) atomicAdd(cumulative + c, e);
+    } else {
+        e = op.scale[c];
+    }
+    if (e != 0)
+        for (int r = 0; r < n; ++r) dst[(size_t) r * Ppad] = ldexp(dst[(size_t) r * Ppad], -e);
+}
+
+struct MatrixJob64 {
+    double* out;                 // [K][S][S] then transposed [K][S][SPAD]
+    double length;
+    const double* eig;           // [U | U^-1 | lambda]
+    double pad_;
+};
+__global__ void __launch_bounds__(256)
+k64_exponentials(const MatrixJob64* __restrict__ jobs, RatesArg rates, int S, int K, int total, double* __restrict__ ev)
+{
+    const int g = blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= total) return;
+    const int s = g % S, bk = g / S;
+    const int b = bk / K, k = bk % K;
+    ev[g] = exp(jobs[b].eig[(size_t) 2 * S * S + s] * jobs[b].length * rates.r[k]);
+}
+// TiProbs_Gen (reference src/likelihood.c:9498-9545): P_k = U diag(exp(lambda t r_k)) U^-1, negatives clamped to zero
+__global__ void __launch_bounds__(256)
+k64_matrices(const MatrixJob64* __restrict__ jobs, const double* __restrict__ ev, int S, int SPAD, int K)
+{
+    const int b = blockIdx.x / K, k = blockIdx.x % K;
+    const double* __restrict__ U = jobs[b].eig;
+    const double* __restrict__ Ui = jobs[b].eig + (size_t) S * S;
+    const double* __restrict__ e = ev + (size_t) blockIdx.x * S;
+    double* __restrict__ M = jobs[b].out + (size_t) k * S * S;
+    double* __restrict__ MT = jobs[b].out + (size_t) K * S * S + (size_t) k * S * SPAD;
+    for (int idx = threadIdx.x; idx < S * S; idx += blockDim.x) {
+        const int i = idx / S, j = idx % S;
+        double sum = 0.0;
+        for (int s = 0; s < S; ++s) sum += U[i * S + s] * e[s] * Ui[s * S + j];
+        const double v = sum < 0.0 ? 0.0 : sum;
+        M[(size_t) i * S + j] = v;
+        MT[(size_t) j * SPAD + i] = v;
+    }
+}
+
+// Likelihood_* (reference src/likelihood.c:5764-5917, 6975-7040) with BEAGLE's root / edge semantics; one thread per pattern
+struct IntegrateArgs64 {
+    const double*  parent[MBAMD_MAX_SUBSETS];
+    const void*    child[MBAMD_MAX_SUBSETS];      // nullptr: root integration
+    const double*  matrix[MBAMD_MAX_SUBSETS];     // [K][S][S]
+    const double*  weights[MBAMD_MAX_SUBSETS];
+    const double*  freqs[MBAMD_MAX_SUBSETS];
+    const int32_t* cum[MBAMD_MAX_SUBSETS];
+    uint8_t        child_tip[MBAMD_MAX_SUBSETS];
+    int            count;
+};
+__global__ void __launch_bounds__(64)
+k64_integrate(IntegrateArgs64 a, int S, int K, int P, int Ppad_, const double* __restrict__ pattern_weights,
+              double* __restrict__ site, double* __restrict__ wsite)
+{
+    const size_t Ppad = (size_t) Ppad_, c = (size_t) blockIdx.x * 64 + threadIdx.x;
+    double wl = 0.0;
+    if (c < (size_t) P) {
+        int emax = -2147483647;
+        for (int n = 0; n < a.count; ++n) {
+            const int e = a.cum[n] ? a.cum[n][c] : 0;
+            emax = e > emax ? e : emax;
+        }
+        double total = 0.0;
+        for (int n = 0; n < a.count; ++n) {
+            double like = 0.0;
+            for (int k = 0; k < K; ++k) {
+                const double* par = a.parent[n] + (size_t) k * S * Ppad + c;
+                double cat = 0.0;
+                if (a.child[n] == nullptr) {
+                    for (int i = 0; i < S; ++i) cat += par[(size_t) i * Ppad] * a.freqs[n][i];
+                } else if (a.child_tip[n]) {
+                    const unsigned s = reinterpret_cast<const uint8_t*>(a.child[n])[c];
+                    for (int i = 0; i < S; ++i) {
+                        const double pc = s >= (unsigned) S ? 1.0 : a.matrix[n][((size_t) k * S + i) * S + s];
+                        cat += par[(size_t) i * Ppad] * pc * a.freqs[n][i];
+                    }
+                } else {
+                    const double* ch = reinterpret_cast<const double*>(a.child[n]) + (size_t) k * S * Ppad + c;
+                    for (int i = 0; i < S; ++i) {
+                        const double* row = a.matrix[n] + ((size_t) k * S + i) * S;
+                        double acc = 0.0;
+                        for (int j = 0; j < S; ++j) acc = fma(row[j], ch[(size_t) j * Ppad], acc);
+                        cat += par[(size_t) i * Ppad] * acc * a.freqs[n][i];
+                    }
+                }
+                like += cat * a.weights[n][k];
+            }
+            const int e = a.cum[n] ? a.cum[n][c] : 0;
+            total += ldexp(like, e - emax);
+        }
+        const double lnl = log(total) + (double) emax * 0.69314718055994530942;
+        site[c] = lnl;
+        wl = lnl * pattern_weights[c];
+    } else if (c < Ppad) {
+        site[c] = 0.0;
+    }
+#if defined(MBAMD_HOST_EMU)
+    if (threadIdx.x == 0) wsite[blockIdx.x] = 0.0;
+    wsite[blockIdx.x] += wl;
+#else
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) wl += __shfl_down(wl, off);
+    if (threadIdx.x == 0) wsite[blockIdx.x] = wl;
+#endif
+}
+
+__global__ void __launch_bounds__(256)
+k64_scale_accumulate(const int32_t* const* __restrict__ src, int count, int sign, int n, int32_t* __restrict__ cum)
+{
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= n) return;
+    int s = 0;
+    for (int i = 0; i < count; ++i) s += src[i][c];
+    cum[c] += sign * s;
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+class Engine64 {
+public:
+    int device = 0, tipCount = 0, nBuffers = 0, S = 0, SPAD = 0, IB = 4, P = 0, Ppad = 0, K = 1, nEigen = 0, nMatrices = 0, nScale = 0;
+    hipStream_t stream{};
+    bool live = false;
+    double* d_partials = nullptr;          // [nBuffers][K*S*Ppad]
+    uint8_t* d_states = nullptr;           // [tipCount][Ppad]
+    std::vector<char> isTip, valid;
+    std::vector<int> stateSlot;            // buffer -> row of d_states (MrBayes numbers its tips i * nCijkParts, reference src/mbbeagle.c:148)
+    int slotsUsed = 0;
+    double* d_matrices = nullptr;          // [nMatrices][K*S*S + K*S*SPAD]
+    double* d_eigen = nullptr;             // [nEigen][2*S*S + S]
+    double* d_freqs = nullptr;             // [nEigen][S]
+    double* d_weights = nullptr;           // [nEigen][K]
+    double* d_pweights = nullptr;          // [Ppad]
+    int32_t* d_scale = nullptr;            // [nScale][Ppad]
+    double* d_site = nullptr;              // [Ppad]
+    double* d_sums = nullptr;              // [Ppad/64]
+    double* d_ev = nullptr;
+    size_t evCap = 0;
+    void* d_stage = nullptr;
+    size_t stageCap = 0;
+    std::vector<RatesArg> rateSets;
+    bool haveSite = false;
+    size_t bufDoubles = 0, matDoubles = 0, eigDoubles = 0;
+
+    ~Engine64() { destroy(); }
+
+    static int blockOf(int S) { return S <= 4 ? 4 : S <= 8 ? 8 : S <= 16 ? 16 : S <= 20 ? 20 : 32; }
+
+    int create(int tips, int partialsBuffers, int compactBuffers, int states, int patterns, int eigens, int matrices, int cats, int scales, int dev)
+    {
+        device = dev; tipCount = tips; nBuffers = partialsBuffers + compactBuffers; S = states; P = patterns; Ppad = round_up(patterns, 64);
+        K = cats; nEigen = eigens; nMatrices = matrices; nScale = scales;
+        IB = blockOf(S);
+        SPAD = (S + IB - 1) / IB * IB;
+        bufDoubles = (size_t) K * S * Ppad;
+        matDoubles = (size_t) K * S * S + (size_t) K * S * SPAD;
+        eigDoubles = (size_t) 2 * S * S + S;
+        HIP_TRY(hipSetDevice(device));
+        HIP_TRY(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
+        live = true;
+        HIP_TRY(hipMalloc(&d_partials, std::max<size_t>(1, (size_t) nBuffers * bufDoubles) * sizeof(double)));
+        HIP_TRY(hipMalloc(&d_states, std::max<size_t>(1, (size_t) tipCount * Ppad)));
+        HIP_TRY(hipMalloc(&d_matrices, std::max<size_t>(1, (size_t) nMatrices * matDoubles) * sizeof(double)));
+        HIP_TRY(hipMemsetAsync(d_matrices, 0, std::max<size_t>(1, (size_t) nMatrices * matDoubles) * sizeof(double), stream));
+        HIP_TRY(hipMalloc(&d_eigen, std::max<size_t>(1, (size_t) nEigen * eigDoubles) * sizeof(double)));
+        HIP_TRY(hipMalloc(&d_freqs, std::max<size_t>(1, (size_t) nEigen * S) * sizeof(double)));
+        HIP_TRY(hipMalloc(&d_weights, std::max<size_t>(1, (size_t) nEigen * K) * sizeof(double)));
+        HIP_TRY(hipMalloc(&d_pweights, (size_t) Ppad * sizeof(double)));
+        HIP_TRY(hipMemsetAsync(d_pweights, 0, (size_t) Ppad * sizeof(double), stream));
+        HIP_TRY(hipMalloc(&d_scale, std::max<size_t>(1, (size_t) nScale * Ppad) * sizeof(int32_t)));
+        HIP_TRY(hipMemsetAsync(d_scale, 0, std::max<size_t>(1, (size_t) nScale * Ppad) * sizeof(int32_t), stream));
+        HIP_TRY(hipMalloc(&d_site, (size_t) Ppad * sizeof(double)));
+        HIP_TRY(hipMalloc(&d_sums, (size_t) (Ppad / 64) * sizeof(double)));
+        isTip.assign((size_t) nBuffers, 0);
+        stateSlot.assign((size_t) nBuffers, -1);
+        valid.assign((size_t) nBuffers, 0);
+        rateSets.assign(1, RatesArg());
+        for (int k = 0; k < MBAMD_MAX_RATES; ++k) rateSets[0].r[k] = 1.0;
+        std::vector<double> ones((size_t) Ppad, 0.0);
+        for (int c = 0; c < P; ++c) ones[c] = 1.0;
+        HIP_TRY(hipMemcpyAsync(d_pweights, ones.data(), (size_t) Ppad * sizeof(double), hipMemcpyHostToDevice, stream));
+        HIP_TRY(hipStreamSynchronize(stream));
+        return BEAGLE_SUCCESS;
+    }
+    void destroy()
+    {
+        if (!live) return;
+        (void) hipSetDevice(device);
+        (void) hipStreamSynchronize(stream);
+        void* all[] = {d_partials, d_states, d_matrices, d_eigen, d_freqs, d_weights, d_pweights, d_scale, d_site, d_sums, d_ev, d_stage};
+        for (void* p : all)
+            if (p) (void) hipFree(p);
+        (void) hipStreamDestroy(stream);
+        live = false;
+    }
+    int stage(const void* src, size_t bytes, void** out)
+    {
+        HIP_TRY(hipStreamSynchronize(stream));                  // (the staging buffer is re-used: wait for its last reader)
+        if (bytes > stageCap) {
+            if (d_stage) (void) hipFree(d_stage);
+            d_stage = nullptr;
+            stageCap = std::max(bytes * 2, (size_t) 65536);
+            HIP_TRY(hipMalloc(&d_stage, stageCap));
+        }
+        HIP_TRY(hipMemcpyAsync(d_stage, src, bytes, hipMemcpyHostToDevice, stream));
+        *out = d_stage;
+        return BEAGLE_SUCCESS;
+    }
+    int upload(void* dst, const void* src, size_t bytes)
+    {
+        HIP_TRY(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, stream));
+        HIP_TRY(hipStreamSynchronize(stream));
+        return BEAGLE_SUCCESS;
+    }
+    double* partialsPtr(int b) const { return d_partials + (size_t) b * bufDoubles; }
+    uint8_t* statesPtr(int b) const { return d_states + (size_t) stateSlot[b] * Ppad; }
+    double* matrixPtr(int m) const { return d_matrices + (size_t) m * matDoubles; }
+
+    int setTipStates(int tip, const int* states)
+    {
+        if (tip < 0 || tip >= nBuffers) return fail(BEAGLE_ERROR_OUT_OF_RANGE, "beagleSetTipStates: tip index");
+        if (stateSlot[tip] < 0) {
+            if (slotsUsed >= tipCount) return fail(BEAGLE_ERROR_OUT_OF_RANGE, "beagleSetTipStates: more compact buffers than tips");
+            stateSlot[tip] = slotsUsed++;
+        }
+        std::vector<uint8_t> h((size_t) Ppad, (uint8_t) S);
+        for (int c = 0; c < P; ++c) h[c] = (uint8_t) ((states[c] < 0 || states[c] >= S) ? S : states[c]);
+        isTip[tip] = 1;
+        valid[tip] = 1;
+        return upload(statesPtr(tip), h.data(), (size_t) Ppad);
+    }
+    // in: [K][P][S] (withCategories) or [P][S] replicated over the categories
+    int setPartials(int idx, const double* in, bool withCategories)
+    {
+        if (idx < 0 || idx >= nBuffers) return fail(BEAGLE_ERROR_OUT_OF_RANGE, "beagleSetPartials: buffer index");
+        std::vector<double> h(bufDoubles, 0.0);
+        for (int k = 0; k < K; ++k)
+            for (int c = 0; c < P; ++c)
+                for (int i = 0; i < S; ++i)
+                    h[((size_t) k * S + i) * Ppad + c] = in[((size_t) (withCategories ? k : 0) * P + c) * S + i];
+        isTip[idx] = 0;
+        valid[idx] = 1;
+        return upload(partialsPtr(idx), h.data(), bufDoubles * sizeof(double));
+    }
+    int getPartials(int idx, double* out)
+    {
+        if (idx < 0 || idx >= nBuffers || !valid[idx]) return fail(BEAGLE_ERROR_OUT_OF_RANGE, "beagleGetPartials: buffer index");
+        if (isTip[idx]) return fail(BEAGLE_ERROR_OUT_OF_RANGE, "beagleGetPartials: a compact (tip state) buffer");
+        std::vector<double> h(bufDoubles);
+        HIP_TRY(hipStreamSynchronize(stream));
+        HIP_TRY(hipMemcpy(h.data(), partialsPtr(idx), bufDoubles * sizeof(double), hipMemcpyDeviceToHost));
+        for (int k = 0; k < K; ++k)
+            for (int c = 0; c < P; ++c)
+                for (int i = 0; i < S; ++i) out[((size_t) k * P + c) * S + i] = h[((size_t) k * S + i) * Ppad + c];
+        return BEAGLE_SUCCESS;
+    }
+    int setEigen(int idx, const double* U, const double* Ui, const double* lam)
+    {
+        if (idx < 0 || idx >= nEigen) return fail(BEAGLE_ERROR_OUT_OF_RANGE, "beagleSetEigenDecomposition: eigen index");
+        std::vector<double> h(eigDoubles);
+        std::memcpy(h.data(), U, sizeof(double) * S * S);
+        std::memcpy(h.data() + (size_t) S * S, Ui, sizeof(double) * S * S);
+        std::memcpy(h.data() + (size_t) 2 * S * S, lam, sizeof(double) * S);
+        return upload(d_eigen + (size_t) idx * eigDoubles, h.data(), eigDoubles * sizeof(double));
+    }
+    int setFreqs(int idx, const double* f)
+    {
+        if (idx < 0 || idx >= nEigen) return fail(BEAGLE_ERROR_OUT_OF_RANGE, "beagleSetStateFrequencies: index");
+        return upload(d_freqs + (size_t) idx * S, f, (size_t) S * sizeof(double));
+    }
+    int setWeights(int idx, const double* w)
+    {
+        if (idx < 0 || idx >= nEigen) return fail(BEAGLE_ERROR_OUT_OF_RANGE, "beagleSetCategoryWeights: index");
+        return upload(d_weights + (size_t) idx * K, w, (size_t) K * sizeof(double));
+    }
+    int setRates(int index, const double* r)
+    {
+        if (index < 0 || index > 65535) return fail(BEAGLE_ERROR_OUT_OF_RANGE, "category rates: index");
+        if ((size_t) index >= rateSets.size()) rateSets.resize((size_t) index + 1, rateSets[0]);
+        for (int k = 0; k < K; ++k) rateSets[index].r[k] = r[k];
+        return BEAGLE_SUCCESS;
+    }
+    int setPatternWeights(const double* w)
+    {
+        std::vector<double> h((size_t) Ppad, 0.0);
+        std::memcpy(h.data(), w, (size_t) P * sizeof(double));
+        return upload(d_pweights, h.data(), (size_t) Ppad * sizeof(double));
+    }
+    int updateMatrices(int eigenIdx, int rateIdx, const int* prob, const double* lengths, int count)
+    {
+        if (count <= 0) return BEAGLE_SUCCESS;
+        if (eigenIdx < 0 || eigenIdx >= nEigen) return fail(BEAGLE_ERROR_OUT_OF_RANGE, "beagleUpdateTransitionMatrices: eigen index");
+        if (rateIdx < 0 || (size_t) rateIdx >= rateSets.size()) return fail(BEAGLE_ERROR_OUT_OF_RANGE, "beagleUpdateTransitionMatrices: rate index");
+        std::vector<MatrixJob64> jobs((size_t) count);
+        for (int i = 0; i < count; ++i) {
+            if (prob[i] < 0 || prob[i] >= nMatrices) return fail(BEAGLE_ERROR_OUT_OF_RANGE, "beagleUpdateTransitionMatrices: matrix index");
+            jobs[i] = {matrixPtr(prob[i]), lengths[i], d_eigen + (size_t) eigenIdx * eigDoubles, 0.0};
+        }
+        void* dj = nullptr;
+        int rc = stage(jobs.data(), jobs.size() * sizeof(MatrixJob64), &dj);
+        if (rc) return rc;
+        const size_t need = (size_t) count * K * S;
+        if (need > evCap) {
+            HIP_TRY(hipStreamSynchronize(stream));
+            if (d_ev) (void) hipFree(d_ev);
+            d_ev = nullptr;
+            evCap = need * 2;
+            HIP_TRY(hipMalloc(&d_ev, evCap * sizeof(double)));
+        }
+        const int total = count * K * S;
+        MBAMD_LAUNCH(k64_exponentials, (unsigned) ((total + 255) / 256), 256, 0, stream, (const MatrixJob64*) dj, rateSets[rateIdx], S, K, total, d_ev);
+        MBAMD_LAUNCH(k64_matrices, (unsigned) (count * K), 256, 0, stream, (const MatrixJob64*) dj, (const double*) d_ev, S, SPAD, K);
+        HIP_TRY(hipGetLastError());
+        return BEAGLE_SUCCESS;
+    }
+    // in: [K][S][S] row = from-state (BEAGLE's order)
+    int setMatrix(int idx, const double* m)
+    {
+        if (idx < 0 || idx >= nMatrices) return fail(BEAGLE_ERROR_OUT_OF_RANGE, "beagleSetTransitionMatrix: matrix index");
+        std::vector<double> h(matDoubles, 0.0);
+        for (int k = 0; k < K; ++k)
+            for (int i = 0; i < S; ++i)
+                for (int j = 0; j < S; ++j) {
+                    const double v = m[((size_t) k * S + i) * S + j];
+                    h[((size_t) k * S + i) * S + j] = v;
+                    h[(size_t) K * S * S + ((size_t) k * S + j) * SPAD + i] = v;
+                }
+        return upload(matrixPtr(idx), h.data(), matDoubles * sizeof(double));
+    }
+    int getMatrix(int idx, double* out)
+    {
+        if (idx < 0 || idx >= nMatrices) return fail(BEAGLE_ERROR_OUT_OF_RANGE, "beagleGetTransitionMatrix: matrix index");
+        HIP_TRY(hipStreamSynchronize(stream));
+        HIP_TRY(hipMemcpy(out, matrixPtr(idx), (size_t) K * S * S * sizeof(double), hipMemcpyDeviceToHost));
+        return BEAGLE_SUCCESS;
+    }
+
+    template <int IB_> void launchPartials(const Op64* ops, int n)
+    {
+        MBAMD_LAUNCH(k64_partials<IB_>, dim3((unsigned) (Ppad / 64), (unsigned) n), 64, 0, stream, ops, S, SPAD, K, Ppad);
+    }
+    // One launch per dependency level: an operation goes one level above the last operation that wrote a buffer it reads,
+    // read or wrote the buffer it writes, or touched its scale buffer.
+    int updatePartials(const BeagleOperation* ops, int n, int cumIdx)
+    {
+        if (n <= 0) return BEAGLE_SUCCESS;
+        if (cumIdx != BEAGLE_OP_NONE && (cumIdx < 0 || cumIdx >= nScale)) return fail(BEAGLE_ERROR_OUT_OF_RANGE, "beagleUpdatePartials: cumulative scale index");
+        std::vector<int> level((size_t) n, 0), lastTouchBuf((size_t) nBuffers, -1), lastWriteBuf((size_t) nBuffers, -1), lastTouchScale((size_t) std::max(nScale, 1), -1);
+        int nLevels = 0;
+        std::vector<Op64> h((size_t) n);
+        for (int i = 0; i < n; ++i) {
+            const BeagleOperation& o = ops[i];
+            const int d = o.destinationPartials, c1 = o.child1Partials, c2 = o.child2Partials;
+            if (d < 0 || d >= nBuffers || c1 < 0 || c1 >= nBuffers || c2 < 0 || c2 >= nBuffers)
+                return fail(BEAGLE_ERROR_OUT_OF_RANGE, "beagleUpdatePartials: buffer index");
+            if (o.child1TransitionMatrix < 0 || o.child1TransitionMatrix >= nMatrices || o.child2TransitionMatrix < 0 || o.child2TransitionMatrix >= nMatrices)
+                return fail(BEAGLE_ERROR_OUT_OF_RANGE, "beagleUpdatePartials: matrix index");
+            if (!valid[c1] || !valid[c2]) return fail(BEAGLE_ERROR_OUT_OF_RANGE, "beagleUpdatePartials: a child buffer was never written");
+            if (isTip[d]) return fail(BEAGLE_ERROR_OUT_OF_RANGE, "beagleUpdatePartials: destination is a compact tip buffer");
+            const int sw = o.destinationScaleWrite, sr = o.destinationScaleRead;
+            if ((sw != BEAGLE_OP_NONE && (sw < 0 || sw >= nScale)) || (sr != BEAGLE_OP_NONE && (sr < 0 || sr >= nScale)))
+                return fail(BEAGLE_ERROR_OUT_OF_RANGE, "beagleUpdatePartials: scale index");
+            int lv = std::max(std::max(lastWriteBuf[c1], lastWriteBuf[c2]), lastTouchBuf[d]) + 1;
+            const int sc = sw != BEAGLE_OP_NONE ? sw : sr;
+            if (sc != BEAGLE_OP_NONE) lv = std::max(lv, lastTouchScale[sc] + 1);
+            level[i] = lv;
+            nLevels = std::max(nLevels, lv + 1);
+            lastWriteBuf[d] = lv;
+            lastTouchBuf[d] = std::max(lastTouchBuf[d], lv);
+            lastTouchBuf[c1] = std::max(lastTouchBuf[c1], lv);
+            lastTouchBuf[c2] = std::max(lastTouchBuf[c2], lv);
+            if (sc != BEAGLE_OP_NONE) lastTouchScale[sc] = lv;
+            Op64& q = h[i];
+            q.dst = partialsPtr(d);
+            q.c1 = isTip[c1] ? (const void*) statesPtr(c1) : (const void*) partialsPtr(c1);
+            q.c2 = isTip[c2] ? (const void*) statesPtr(c2) : (const void*) partialsPtr(c2);
+            q.c1_tip = isTip[c1];
+            q.c2_tip = isTip[c2];
+            q.m1T = matrixPtr(o.child1TransitionMatrix) + (size_t) K * S * S;
+            q.m2T = matrixPtr(o.child2TransitionMatrix) + (size_t) K * S * S;
+            q.mode = sw != BEAGLE_OP_NONE ? 1 : sr != BEAGLE_OP_NONE ? 2 : 0;
+            q.scale = sc != BEAGLE_OP_NONE ? d_scale + (size_t) sc * Ppad : nullptr;
+            q.pad_ = 0;
+            valid[d] = 1;
+            isTip[d] = 0;
+        }
+        // operations sorted by level (stable), one contiguous run per level
+        std::vector<int> order((size_t) n), start((size_t) nLevels + 1, 0);
+        for (int i = 0; i < n; ++i) start[(size_t) level[i] + 1]++;
+        for (int l = 0; l < nLevels; ++l) start[(size_t) l + 1] += start[l];
+        std::vector<int> fill(start.begin(), start.end() - 1);
+        for (int i = 0; i < n; ++i) order[(size_t) fill[level[i]]++] = i;
+        std::vector<Op64> sorted((size_t) n);
+        for (int i = 0; i < n; ++i) sorted[i] = h[order[i]];
+        void* dv = nullptr;
+        int rc = stage(sorted.data(), sorted.size() * sizeof(Op64), &dv);
+        if (rc) return rc;
+        const Op64* dops = static_cast<const Op64*>(dv);
+        int32_t* cum = cumIdx != BEAGLE_OP_NONE ? d_scale + (size_t) cumIdx * Ppad : nullptr;
+        const bool fused = K == 4 && IB == 4 && S <= IB && std::getenv("MBAMD_F64_UNFUSED") == nullptr;
+        for (int l = 0; l < nLevels; ++l) {
+            const int first = start[l], cnt = start[(size_t) l + 1] - first;
+            if (cnt <= 0) continue;
+            if (fused) {
+                const dim3 grid((unsigned) (Ppad / 64), (unsigned) cnt);
+                auto kern = k64_partials_fused<4, 4>;
+                MBAMD_LAUNCH(kern, grid, 64, 0, stream, dops + first, S, SPAD, Ppad, cum);
+                continue;
+            }
+            switch (IB) {
+                case 4: launchPartials<4>(dops + first, cnt); break;
+                case 8: launchPartials<8>(dops + first, cnt); break;
+                case 16: launchPartials<16>(dops + first, cnt); break;
+                case 20: launchPartials<20>(dops + first, cnt); break;
+                default: launchPartials<32>(dops + first, cnt); break;
+            }
+            bool anyScale = false;
+            for (int i = first; i < first + cnt; ++i) anyScale |= sorted[i].mode != 0;
+            if (anyScale)
+                MBAMD_LAUNCH(k64_rescale, dim3((unsigned) (Ppad / 64), (unsigned) cnt), 64, 0, stream, dops + first, S, K, Ppad, cum);
+        }
+        HIP_TRY(hipGetLastError());
+        return BEAGLE_SUCCESS;
+    }
+
+    int resetScale(int idx)
+    {
+        if (idx < 0 || idx >= nScale) return fail(BEAGLE_ERROR_OUT_OF_RANGE, "beagleResetScaleFactors: index");
+        HIP_TRY(hipMemsetAsync(d_scale + (size_t) idx * Ppad, 0, (size_t) Ppad * sizeof(int32_t), stream));
+        return BEAGLE_SUCCESS;
+    }
+    int accumulateScale(const int* idx, int count, int cumIdx, int sign)
+    {
+        if (count <= 0) return BEAGLE_SUCCESS;
+        if (cumIdx < 0 || cumIdx >= nScale) return fail(BEAGLE_ERROR_OUT_OF_RANGE, "scale factors: cumulative index");
+        std::vector<const int32_t*> src((size_t) count);
+        for (int i = 0; i < count; ++i) {
+            if (idx[i] < 0 || idx[i] >= nScale) return fail(BEAGLE_ERROR_OUT_OF_RANGE, "scale factors: index");
+            src[i] = d_scale + (size_t) idx[i] * Ppad;
+        }
+        void* dv = nullptr;
+        int rc = stage(src.data(), src.size() * sizeof(const int32_t*), &dv);
+        if (rc) return rc;
+        MBAMD_LAUNCH(k64_scale_accumulate, (unsigned) ((Ppad + 255) / 256), 256, 0, stream, (const int32_t* const*) dv, count, sign, Ppad, d_scale + (size_t) cumIdx * Ppad);
+        HIP_TRY(hipGetLastError());
+        return BEAGLE_SUCCESS;
+    }
+    int copyScale(int dst, int src)
+    {
+        if (dst < 0 || dst >= nScale || src < 0 || src >= nScale) return fail(BEAGLE_ERROR_OUT_OF_RANGE, "beagleCopyScaleFactors: index");
+        HIP_TRY(hipMemcpyAsync(d_scale + (size_t) dst * Ppad, d_scale + (size_t) src * Ppad, (size_t) Ppad * sizeof(int32_t), hipMemcpyDeviceToDevice, stream));
+        return BEAGLE_SUCCESS;
+    }
+    int getScaleExponents(int idx, int* out)            // [K][P]: every category row the same
+    {
+        if (idx < 0 || idx >= nScale) return fail(BEAGLE_ERROR_OUT_OF_RANGE, "scale factors: index");
+        std::vector<int32_t> h((size_t) Ppad);
+        HIP_TRY(hipStreamSynchronize(stream));
+        HIP_TRY(hipMemcpy(h.data(), d_scale + (size_t) idx * Ppad, (size_t) Ppad * sizeof(int32_t), hipMemcpyDeviceToHost));
+        for (int k = 0; k < K; ++k)
+            for (int c = 0; c < P; ++c) out[(size_t) k * P + c] = h[c];
+        return BEAGLE_SUCCESS;
+    }
+    int getScaleFactors(int idx, double* out)
+    {
+        if (idx < 0 || idx >= nScale) return fail(BEAGLE_ERROR_OUT_OF_RANGE, "beagleGetScaleFactors: index");
+        std::vector<int32_t> h((size_t) Ppad);
+        HIP_TRY(hipStreamSynchronize(stream));
+        HIP_TRY(hipMemcpy(h.data(), d_scale + (size_t) idx * Ppad, (size_t) Ppad * sizeof(int32_t), hipMemcpyDeviceToHost));
+        for (int c = 0; c < P; ++c) out[c] = h[c] * 0.69314718055994530942;
+        return BEAGLE_SUCCESS;
+    }
+
+    int logLikelihoods(const int* parent, const int* child, const int* prob, const int* wIdx, const int* fIdx, const int* cumIdx, int count, double* out)
+    {
+        if (count < 1 || count > MBAMD_MAX_SUBSETS) return fail(BEAGLE_ERROR_NO_IMPLEMENTATION, "log-likelihood: more than 8 subsets");
+        IntegrateArgs64 a;
+        std::memset(&a, 0, sizeof a);
+        a.count = count;
+        for (int n = 0; n < count; ++n) {
+            if (parent[n] < 0 || parent[n] >= nBuffers || !valid[parent[n]] || isTip[parent[n]])
+                return fail(BEAGLE_ERROR_OUT_OF_RANGE, "log-likelihood: parent buffer");
+            a.parent[n] = partialsPtr(parent[n]);
+            if (child) {
+                const int ci = child[n];
+                if (ci < 0 || ci >= nBuffers || !valid[ci] || prob[n] < 0 || prob[n] >= nMatrices)
+                    return fail(BEAGLE_ERROR_OUT_OF_RANGE, "edge log-likelihood: child buffer / matrix");
+                a.child[n] = isTip[ci] ? (const void*) statesPtr(ci) : (const void*) partialsPtr(ci);
+                a.child_tip[n] = (uint8_t) isTip[ci];
+                a.matrix[n] = matrixPtr(prob[n]);
+            }
+            if (wIdx[n] < 0 || wIdx[n] >= nEigen || fIdx[n] < 0 || fIdx[n] >= nEigen)
+                return fail(BEAGLE_ERROR_OUT_OF_RANGE, "log-likelihood: weights / frequencies index");
+            a.weights[n] = d_weights + (size_t) wIdx[n] * K;
+            a.freqs[n] = d_freqs + (size_t) fIdx[n] * S;
+            if (cumIdx && cumIdx[n] != BEAGLE_OP_NONE) {
+                if (cumIdx[n] < 0 || cumIdx[n] >= nScale) return fail(BEAGLE_ERROR_OUT_OF_RANGE, "log-likelihood: cumulative scale index");
+                a.cum[n] = d_scale + (size_t) cumIdx[n] * Ppad;
+            }
+        }
+        const int nblocks = Ppad / 64;
+        MBAMD_LAUNCH(k64_integrate, (unsigned) nblocks, 64, 0, stream, a, S, K, P, Ppad, (const double*) d_pweights, d_site, d_sums);
+        HIP_TRY(hipGetLastError());
+        std::vector<double> h((size_t) nblocks);
+        HIP_TRY(hipMemcpyAsync(h.data(), d_sums, (size_t) nblocks * sizeof(double), hipMemcpyDeviceToHost, stream));
+        HIP_TRY(hipStreamSynchronize(stream));
+        double s = 0.0;
+        for (int i = 0; i < nblocks; ++i) s += h[i];
+        haveSite = true;
+        if (out) *out = s;
+        if (!(s == s) || s > 1.79e308 || s < -1.79e308) return BEAGLE_ERROR_FLOATING_POINT;
+        return BEAGLE_SUCCESS;
+    }
+    int getSites(double* out)
+    {
+        if (!haveSite) return fail(BEAGLE_ERROR_GENERAL, "beagleGetSiteLogLikelihoods: no log-likelihood was calculated");
+        HIP_TRY(hipStreamSynchronize(stream));
+        HIP_TRY(hipMemcpy(out, d_site, (size_t) P * sizeof(double), hipMemcpyDeviceToHost));
+        return BEAGLE_SUCCESS;
+    }
+    int synchronize()
+    {
+        HIP_TRY(hipStreamSynchronize(stream));
+        return BEAGLE_SUCCESS;
+    }
+};
+
+}  // namespace mbamd
+#endif

@@ -38,8 +38,10 @@ class BeagleDivision:
     """ModelInfo-like state of one division driven through the BEAGLE ABI for `nchains` local chains."""
 
     def __init__(self, div: Division, lib: Optional[bg.BeagleLibrary] = None, nchains: int = 1,
-                 scaling: int = MB_BEAGLE_SCALE_ALWAYS, resource: Optional[int] = None, device_eigen: bool = False):
+                 scaling: int = MB_BEAGLE_SCALE_ALWAYS, resource: Optional[int] = None, device_eigen: bool = False,
+                 double_precision: bool = False):
         self.div = div
+        self.double_precision = double_precision        # `set beagleprecision=double` (src/command.c:6765-6766): a preference flag
         self.device_eigen = device_eigen and div.rate_matrices is not None and bool(np.all(np.asarray(div.pi) > 0))
         self.lib = lib or bg.library()
         self.nchains = nchains
@@ -98,7 +100,8 @@ class BeagleDivision:
         self.inst = bg.BeagleInstance(
             self.lib, self.N, self.numCondLikes * self.step, self.N - num_part_ambig, d.nstates, d.npatterns,
             (self.nchains + 1) * self.step, self.numTiProbs * self.step, d.ncat, self.numScalers * self.step,
-            resource=resource, preference_flags=bg.BEAGLE_FLAG_PRECISION_SINGLE, requirement_flags=req)
+            resource=resource, requirement_flags=req,
+            preference_flags=bg.BEAGLE_FLAG_PRECISION_DOUBLE if self.double_precision else bg.BEAGLE_FLAG_PRECISION_SINGLE)
         for i in range(self.N):                                           # src/mbbeagle.c:123-167
             if not part_ambig[i]:
                 self.inst.set_tip_states(i * self.step, d.tip_states[i])

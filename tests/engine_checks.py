@@ -600,3 +600,59 @@ def check_parsimony(lib, ntaxa, npat, nstates, seed=3, words=1, gaps=0.05):
                 inst.set_sets(0, np.full(npat, 1 << nstates, dtype=np.uint64))
     finally:
         inst.finalize()
+
+
+# ---- double precision (BEAGLE_FLAG_PRECISION_DOUBLE; `set beagleprecision=double`) ---------------------------------
+ABS_F64 = 2e-6          # the reference prints its log-likelihood with six (known-answer files: eight) decimals
+REL_F64 = 2e-9          # how closely the model parameters themselves are reproduced outside the reference (its discrete-gamma
+                        # quantiles and eigen-solver iterate to ~1e-6 .. 1e-9: seen as 7e-10 on the WAG case); the fp32 engine sits
+                        # at 1e-7 .. 1e-6 on the same cases
+
+
+def check_double_precision(lib, golden_dir, case):
+    """The fp64 engine against the reference's double build (oracle/_ref/mb_fp64: CLFlt = double, src/bayes.h:110-112):
+    log-likelihood to the printed digits for both scaling schemes, site values consistent with the sum, a partial update equal
+    to a fresh evaluation, a reject restoring the value, several chains independent."""
+    g = gold(golden_dir, case)
+    ref64 = g["lnL"]["fp64"]
+    div = division_from_golden(golden_dir, case)
+    single = engine_lnl(lib, div)
+    vals = []
+    for scaling in (lk.MB_BEAGLE_SCALE_ALWAYS, lk.MB_BEAGLE_SCALE_DYNAMIC):
+        bd = lk.BeagleDivision(div, lib, scaling=scaling, double_precision=True, nchains=2)
+        try:
+            assert bd.inst.details.flags & bg.BEAGLE_FLAG_PRECISION_DOUBLE and not bd.inst.details.flags & bg.BEAGLE_FLAG_PRECISION_SINGLE
+            assert b"double-precision" in bd.inst.details.implName
+            lnl = bd.LogLike(0)
+            bd.AcceptMove(0)
+            assert abs(lnl - ref64) <= ABS_F64 + REL_F64 * abs(ref64), (case, scaling, lnl, ref64)
+            assert abs(lnl - ref64) <= abs(single - ref64) + ABS_F64, (case, lnl, single, ref64)
+            vals.append(lnl)
+            if div.pinvar == 0.0:                     # (with +I the host mixes the invariable-site term into the sum, src/mbbeagle.c:1322-1358)
+                site = bd.inst.get_site_log_likelihoods()
+                assert abs(float(np.dot(site, div.weights)) - lnl) <= 1e-9 * abs(lnl)
+            assert abs(bd.LogLike(1) - lnl) <= 1e-12 * abs(lnl)            # the second chain: its own buffers, the same state
+            bd.AcceptMove(1)
+            # a partial update == a fresh evaluation of the new state; a reject restores the old value exactly
+            t = div.tree
+            deep = max(range(t.ntaxa), key=lambda i: _depth(t, i))
+            old = t.length[deep]
+            t.length[deep] = old * 2.5
+            try:
+                bd.TouchBranch(0, deep)
+                moved = bd.LogLike(0)
+                fresh = lk.BeagleDivision(div, lib, scaling=scaling, double_precision=True)
+                try:
+                    want = fresh.LogLike(0)
+                finally:
+                    fresh.finalize()
+                assert abs(moved - want) <= 1e-12 * abs(want), (moved, want)
+                assert abs(moved - lnl) > 1e-9 * abs(lnl)
+            finally:
+                t.length[deep] = old
+            bd.ResetFlips(0)
+            assert bd.LogLike(0) == lnl
+            bd.AcceptMove(0)
+        finally:
+            bd.finalize()
+    assert abs(vals[0] - vals[1]) <= 1e-11 * abs(vals[0]), vals

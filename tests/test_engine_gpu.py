@@ -498,3 +498,10 @@ def test_multi_partition_instance(gpu, oracle, golden_dir, kind):
 def test_parsimony(gpu, ntaxa, npat, nstates, words):
     """Device Fitch parsimony (mbamdPars*) against the oracle: u8 / u16 / u32 / u64 / 2 x u64 sets."""
     ec.check_parsimony(gpu, ntaxa, npat, nstates, words=words)
+
+
+@pytest.mark.parametrize("case", ["primates_gtr_g4", "primates_gtr_ig4", "avian_wag_g4", "replicase_m3", "synth_dna_gaps", "synth_aa_wag",
+                                  "synth_codon_m3", "bench_c2"])
+def test_double_precision(gpu, golden_dir, case):
+    """BEAGLE_FLAG_PRECISION_DOUBLE: the fp64 engine (mbamd_f64.h) against the reference's double build."""
+    ec.check_double_precision(gpu, golden_dir, case)

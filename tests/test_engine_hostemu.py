@@ -210,3 +210,9 @@ def test_multi_partition_instance(emu, oracle, golden_dir, kind):
 def test_parsimony(emu, ntaxa, npat, nstates, words):
     """Device Fitch parsimony (mbamdPars*) against the oracle: u8 / u16 / u32 / u64 / 2 x u64 sets."""
     ec.check_parsimony(emu, ntaxa, npat, nstates, words=words)
+
+
+@pytest.mark.parametrize("case", ["primates_gtr_g4", "primates_gtr_ig4", "avian_wag_g4", "replicase_m3", "synth_dna_gaps"])
+def test_double_precision(emu, golden_dir, case):
+    """BEAGLE_FLAG_PRECISION_DOUBLE: the fp64 engine (mbamd_f64.h) against the reference's double build."""
+    ec.check_double_precision(emu, golden_dir, case)

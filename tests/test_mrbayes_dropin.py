@@ -387,3 +387,37 @@ def test_device_parsimony_on_mi355x():
     if not os.path.exists(refrun.REF_MB_AMD_PARS):
         pytest.skip("oracle/_ref/mb_amd_pars was not built (needs the reference sources at build time)")
     _check_device_parsimony(refrun.REF_MB_AMD, refrun.REF_MB_AMD_PARS, 3000)
+
+
+# ---- `set beagleprecision=double`: the fp64 engine (mbamd_f64.h) behind the unmodified binary -------------------------
+def _check_double_precision(binary, marker):
+    st, tr = _case(30, 600, 0.03)
+    want, _ = _lnl(refrun.REF_MB_FP64, st, tr, None)                   # the reference's own double build, native kernels
+    native32, _ = _lnl(refrun.REF_MB, st, tr, None)
+    for scaling in ("dynamic", "always"):
+        nex = refrun.known_answer_nexus(st, tr, REVMAT, PI, ALPHA, beagle=scaling).replace("beagleprecision=single", "beagleprecision=double")
+        out, _ = refrun.run_mb(binary, nex)
+        assert marker in out and "double-precision level kernels" in out, out[-1500:]
+        ours = refrun.initial_lnl(out)
+        assert abs(ours - want) <= 2e-6 + 1e-11 * abs(want), (scaling, ours, want)     # same parameters in the same process: to the printed digits
+        assert abs(ours - want) < abs(native32 - want)                                 # and closer than the reference's fp32 build
+    # a short default-mix run (dynamic rescaling at the double-precision frequency, src/mcmc.c:6226-6228) completes
+    nex = refrun.mcmc_nexus(st, tr, 200, beagle="dynamic", nchains=2).replace("beagleprecision=single", "beagleprecision=double")
+    out, _ = refrun.run_mb(binary, nex)
+    assert "Analysis completed" in out, out[-1500:]
+
+
+def test_double_precision_on_emulated_engine():
+    if not os.path.isdir("/root/reference/src"):
+        pytest.skip("reference sources not present (build container only)")
+    from tests.hostemu import build_emu
+    build_emu.build()
+    subprocess.check_call(["make", "-C", os.path.join(ROOT, "oracle"), "_ref/mb", "_ref/mb_fp64", "_ref/mb_emu"], stdout=subprocess.DEVNULL)
+    _check_double_precision(refrun.REF_MB_EMU, "mbamd")
+
+
+@pytest.mark.gpu
+def test_double_precision_on_mi355x():
+    if not (os.path.exists(refrun.REF_MB_AMD) and os.path.exists(refrun.REF_MB_FP64)):
+        pytest.skip("oracle/_ref/mb_amd / mb_fp64 were not built (need the reference sources at build time)")
+    _check_double_precision(refrun.REF_MB_AMD, "mbamd HIP gfx950")

@@ -13,6 +13,7 @@ import time
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 REF_MB = os.path.join(ROOT, "oracle", "_ref", "mb")
+REF_MB_FP64 = os.path.join(ROOT, "oracle", "_ref", "mb_fp64")   # the reference with CLFlt = double (src/bayes.h:110-112)
 REF_MB_AMD = os.path.join(ROOT, "oracle", "_ref", "mb_amd")     # the unmodified reference linked to OUR libhmsbeagle.so
 REF_MB_EMU = os.path.join(ROOT, "oracle", "_ref", "mb_emu")     # same objects, TEST-ONLY host-emulation engine
 
