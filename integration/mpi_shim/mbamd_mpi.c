@@ -14,6 +14,7 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <time.h>
 #include <unistd.h>
 
 #define MAGIC 0x4d42414d
@@ -52,6 +53,7 @@ struct MbamdMpiRequest {
 };
 
 static int g_rank = 0, g_size = 1, g_init = 0;
+static long g_moved = 0;     /* bytes read or written so far: did a progress call change anything? */
 static Peer *g_peer = NULL;
 
 static void die(const char *what)
@@ -73,6 +75,7 @@ static void flush_peer(Peer *p)
             die("write to a peer failed (did a rank exit?)");
         }
         o->done += (size_t) n;
+        g_moved += n;
         if (o->done < o->len) return;
         p->ohead = o->next;
         if (!p->ohead) p->otail = NULL;
@@ -93,6 +96,7 @@ static void drain_peer(Peer *p)
             }
             if (n == 0) return;                         /* peer closed: nothing more will come */
             p->hdrDone += (size_t) n;
+            g_moved += n;
             if (p->hdrDone < sizeof p->hdr) return;
             if (p->hdr[2] != MAGIC) die("corrupt message header");
             p->cur = (Msg *) calloc(1, sizeof(Msg));
@@ -111,6 +115,7 @@ static void drain_peer(Peer *p)
             }
             if (n == 0) die("a peer closed its socket in the middle of a message");
             p->curDone += (size_t) n;
+            g_moved += n;
         }
         if (p->tail) p->tail->next = p->cur; else p->head = p->cur;
         p->tail = p->cur;
@@ -118,16 +123,32 @@ static void drain_peer(Peer *p)
     }
 }
 
+/* move what can be moved; if nothing could (and the caller has nothing better to do) sleep until a socket is ready */
 static void progress(int block)
 {
     struct pollfd fds[256];
     int i, n = 0;
+    const long before = g_moved;
     for (i = 0; i < g_size; i++) {
         if (i == g_rank) continue;
         flush_peer(&g_peer[i]);
         drain_peer(&g_peer[i]);
     }
-    if (!block) return;
+    if (!block || g_moved != before) return;          /* something arrived or left: let the caller look again first */
+    {   /* ranks meet every generation (swap attempts): spin a little before paying for a sleep and a wake-up */
+        struct timespec t0, t1;
+        clock_gettime(CLOCK_MONOTONIC, &t0);
+        for (;;) {
+            for (i = 0; i < g_size; i++) {
+                if (i == g_rank) continue;
+                flush_peer(&g_peer[i]);
+                drain_peer(&g_peer[i]);
+            }
+            if (g_moved != before) return;
+            clock_gettime(CLOCK_MONOTONIC, &t1);
+            if ((t1.tv_sec - t0.tv_sec) * 1000000000L + (t1.tv_nsec - t0.tv_nsec) > 200000L) break;
+        }
+    }
     for (i = 0; i < g_size && n < 256; i++) {
         if (i == g_rank) continue;
         fds[n].fd = g_peer[i].fd;
@@ -135,7 +156,7 @@ static void progress(int block)
         fds[n].revents = 0;
         n++;
     }
-    (void) poll(fds, (nfds_t) n, 10);
+    (void) poll(fds, (nfds_t) n, 100);
 }
 
 static Out *post_send(int dest, int tag, const void *buf, int bytes)
