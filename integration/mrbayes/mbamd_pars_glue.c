@@ -292,6 +292,94 @@ int MbamdParsLengths (Tree *t, int chain, int kind, TreeNode **pRoot, int nRoot,
     return (NO_ERROR);
 }
 
+static double   *markedLen = NULL;         /* [relPart][node index] lengths of the marked nodes, MbamdParsMarkedLengths */
+static int      markedParts = 0, markedNodes = 0;
+static MrBFlt   markedKept = 0.0;
+
+void MbamdParsMarkedLengths (Tree *t, int chain, TreeNode *v, CLFlt *nSitesOfPat)
+{
+    int         i, d, n, maxIndex, *q, *who;
+    double      *len;
+    TreeNode    *p;
+    ModelInfo   *m;
+
+    (void) chain;
+    if (MbamdParsActive (t) == NO)
+        return;
+    n = 0;
+    maxIndex = 0;
+    for (i=0; i<t->nNodes; i++)
+        {
+        p = t->allDownPass[i];
+        if (p->index > maxIndex)
+            maxIndex = p->index;
+        if (p->marked == YES)
+            n++;
+        }
+    if (t->nRelParts * (maxIndex + 1) > markedParts * markedNodes)
+        {
+        markedLen = (double *) realloc (markedLen, (size_t) t->nRelParts * (size_t) (maxIndex + 1) * sizeof(double));
+        if (!markedLen)
+            Die ("out of memory");
+        }
+    markedParts = t->nRelParts;
+    markedNodes = maxIndex + 1;
+    if (n == 0)
+        return;
+    q = Ops (n);
+    who = (int *) malloc ((size_t) n * sizeof(int));
+    len = (double *) malloc ((size_t) n * sizeof(double));
+    if (!who || !len)
+        Die ("out of memory");
+    n = 0;
+    for (i=0; i<t->nNodes; i++)
+        {
+        p = t->allDownPass[i];
+        if (p->marked == NO)
+            continue;
+        q[4*n] = p->index; q[4*n+1] = p->anc->index; q[4*n+2] = v->index; q[4*n+3] = -1;
+        who[n++] = p->index;
+        }
+    for (d=0; d<t->nRelParts; d++)
+        {
+        m = &modelSettings[t->relParts[d]];
+        if (mbamdParsSetPatternWeights (Handle(t->relParts[d]), nSitesOfPat + m->compCharStart) != BEAGLE_SUCCESS ||
+            mbamdParsScore (Handle(t->relParts[d]), opBuf, n, len) != BEAGLE_SUCCESS)
+            Die ("mbamdParsScore failed");
+        for (i=0; i<n; i++)
+            markedLen[(size_t) d * markedNodes + who[i]] = len[i];
+        }
+    free (who);
+    free (len);
+}
+
+int MbamdParsMarkedLength (Tree *t, int n, TreeNode *p, MrBFlt *length)
+{
+    if (MbamdParsActive (t) == NO)
+        return (NO);
+    if (n < 0 || n >= markedParts || p->index < 0 || p->index >= markedNodes)
+        Die ("MbamdParsMarkedLength: lengths were not prepared for this node");
+    if (envCheck == YES)
+        {
+        markedKept = markedLen[(size_t) n * markedNodes + p->index];
+        return (NO);
+        }
+    *length = markedLen[(size_t) n * markedNodes + p->index];
+    return (YES);
+}
+
+void MbamdParsMarkedCheck (Tree *t, int n, TreeNode *p, MrBFlt length)
+{
+    if (envCheck == NO || MbamdParsActive (t) == NO)
+        return;
+    if (length != markedKept)
+        {
+        fprintf (stderr, "mbamd parsimony check: marked node %d, part %d: device %.17g host %.17g\n", p->index, n, markedKept, length);
+        exit (1);
+        }
+    nCompared++;
+}
+
 int MbamdParsHostToo (Tree *t, MrBFlt *parLength, int n)
 {
     if (MbamdParsActive (t) == NO)

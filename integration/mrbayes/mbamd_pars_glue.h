@@ -4,7 +4,7 @@
  * Our code, written against the reference's public types (src/bayes.h); it contains no reference source.
  *
  *   #include "mbamd_pars_glue.h"                      after proposal.c's own includes
- *   #define GetParsDP MbamdGetParsDP                  around Move_ParsSPR1 and Move_ParsTBR1 (the two parsimony moves of
+ *   #define GetParsDP MbamdGetParsDP                  around the parsimony-biased moves (Move_ParsSPR1 and Move_ParsTBR1 are in
  *   #define GetParsFP MbamdGetParsFP                  the default mix, src/model.c:22628, 22755), #undef'd after them
  *   the candidate loop ("cycle through the possibilities and record the parsimony length", src/proposal.c:10782-10884,
  *   13429-13474) is bracketed:
@@ -31,6 +31,13 @@ void    MbamdGetParsFP (Tree *t, TreeNode *p, int chain);
 int     MbamdParsLengths (Tree *t, int chain, int kind, TreeNode **pRoot, int nRoot, TreeNode **pCrown, int nCrown,
                           TreeNode *a, TreeNode *b, TreeNode *u, TreeNode *v, CLFlt *nSitesOfPat, MrBFlt warpFactor,
                           MrBFlt *parLength);
+/* The node-length shape of Move_ParsSPR, Move_ParsSPRClock and Move_ParsSPRClock_Fossil (src/proposal.c:10241-10296,
+ * 12179-12234, 12840-12895): for every marked node p the length of (P | A) & V, A the node's ancestor, V = v.
+ * MbamdParsMarkedLengths computes them all in one device call before the node loop; MbamdParsMarkedLength hands one out
+ * (YES: `*length` is set, skip the host loop; NO: run it -- not active, or check mode); MbamdParsMarkedCheck compares. */
+void    MbamdParsMarkedLengths (Tree *t, int chain, TreeNode *v, CLFlt *nSitesOfPat);
+int     MbamdParsMarkedLength (Tree *t, int n, TreeNode *p, MrBFlt *length);
+void    MbamdParsMarkedCheck (Tree *t, int n, TreeNode *p, MrBFlt length);
 /* YES: run the reference's host loop as well (device not active, or MBAMD_PARS_CHECK=1: the device result is kept aside) */
 int     MbamdParsHostToo (Tree *t, MrBFlt *parLength, int n);
 /* MBAMD_PARS_CHECK=1: compare what the host loop just wrote with the device result; abort on any difference */

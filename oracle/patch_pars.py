@@ -6,10 +6,12 @@ src/proposal.c -- test infrastructure: oracle/Makefile calls this for _ref/mb_am
 
 The edits are located by the reference's own function names and comments (no reference text is stored here):
   * the glue header is included after proposal.c's last #include;
-  * Move_ParsSPR1 and Move_ParsTBR1 are bracketed by #define/#undef of GetParsDP / GetParsFP to the glue's versions;
-  * inside each, the candidate loop between the comments "cycle through the possibilities and record the parsimony
-    length" and "find the min length and the sum for the forward move" is kept, wrapped in `if (MbamdParsHostToo ...)`,
-    with the device call in front of it and the comparison (MBAMD_PARS_CHECK=1) behind it.
+  * the seven parsimony-biased moves (Move_ParsSPR, _ParsSPR1, _ParsSPR2, _ParsSPRClock, _ParsSPRClock_Fossil, _ParsTBR1,
+    _ParsTBR2) are bracketed by #define/#undef of GetParsDP / GetParsFP to the glue's versions;
+  * inside each, the loop between the comments "cycle through the possibilities and record the parsimony length" and
+    "find the min length and the sum for the forward move" is kept: the candidate-matrix moves get it wrapped in
+    `if (MbamdParsHostToo ...)` with the device call in front and the comparison (MBAMD_PARS_CHECK=1) behind; the
+    node-length moves get the per-pattern loop of a marked node wrapped in `if (MbamdParsMarkedLength ...)`.
 The output is written outside the repository (the Makefile passes a path under $(OBJ), /tmp by default).
 """
 import re
@@ -47,20 +49,42 @@ def patch(src: str) -> str:
             end -= 1
         return start, end
 
-    for name, call in (("Move_ParsTBR1", TBR1_CALL), ("Move_ParsSPR1", SPR1_CALL)):      # later function first: indices stay valid
+    # later functions first: indices stay valid
+    for name, call in (("Move_ParsTBR2", TBR1_CALL), ("Move_ParsTBR1", TBR1_CALL), ("Move_ParsSPRClock_Fossil", None), ("Move_ParsSPRClock", None),
+                       ("Move_ParsSPR2", SPR1_CALL), ("Move_ParsSPR1", SPR1_CALL), ("Move_ParsSPR", None)):
         start, end = function_range(name)
         body = range(start, end)
         b = [i for i in body if BEGIN in lines[i]]
         e = [i for i in body if END in lines[i]]
         assert len(b) == 1 and len(e) == 1 and b[0] < e[0], (name, b, e)
-        assert any("errorExit:" in lines[i] for i in body), name
-        new = (lines[:start] + ["#define GetParsDP MbamdGetParsDP", "#define GetParsFP MbamdGetParsFP"] + lines[start:b[0] + 1]
-               + call.rstrip("\n").split("\n")
-               + ["    if (MbamdParsHostToo (t, parLength, nRoot * nCrown) == YES)", "    {"]
-               + lines[b[0] + 1:e[0]]
-               + ["    }", "    MbamdParsCompare (parLength, nRoot * nCrown);", ""]
-               + lines[e[0]:end] + ["#undef GetParsDP", "#undef GetParsFP"] + lines[end:])
-        lines = new
+        if call is not None:
+            # candidate-matrix shape: parLength[i + j*nRoot]
+            assert any("errorExit:" in lines[i] for i in body), name
+            middle = (call.rstrip("\n").split("\n")
+                      + ["    if (MbamdParsHostToo (t, parLength, nRoot * nCrown) == YES)", "    {"]
+                      + lines[b[0] + 1:e[0]]
+                      + ["    }", "    MbamdParsCompare (parLength, nRoot * nCrown);", ""])
+        else:
+            # node-length shape: `length = 0.0;` followed by the two-branch loop over the site patterns of marked node p
+            region = lines[b[0] + 1:e[0]]
+            at = [i for i, l in enumerate(region) if l.strip() == "length = 0.0;"]
+            assert len(at) == 1 and "nParsIntsPerSite == 1" in region[at[0] + 1], (name, at)
+            depth, stop, seen_else = 0, None, False
+            for i in range(at[0] + 1, len(region)):        # the if { } else { } statement ends where the else-block closes
+                depth += region[i].count("{") - region[i].count("}")
+                if region[i].lstrip().startswith("else"):
+                    seen_else = True
+                if seen_else and depth == 0 and "}" in region[i]:
+                    stop = i
+                    break
+            assert stop is not None, name
+            middle = (["    MbamdParsMarkedLengths (t, chain, v, nSitesOfPat);"] + region[:at[0] + 1]
+                      + ["            if (MbamdParsMarkedLength (t, n, p, &length) == NO)", "            {"]
+                      + region[at[0] + 1:stop + 1]
+                      + ["            }", "            MbamdParsMarkedCheck (t, n, p, length);"]
+                      + region[stop + 1:])
+        lines = (lines[:start] + ["#define GetParsDP MbamdGetParsDP", "#define GetParsFP MbamdGetParsFP"] + lines[start:b[0] + 1]
+                 + middle + lines[e[0]:end] + ["#undef GetParsDP", "#undef GetParsFP"] + lines[end:])
     return "\n".join(lines)
 
 

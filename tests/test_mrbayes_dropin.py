@@ -345,6 +345,8 @@ def _pars_nexus(ngen, nchains=2, kind="dna"):
     if kind == "dna":
         st, _ = _case(20, 400, 0.03)
         nex = refrun.mcmc_nexus(st, None, ngen, beagle="dynamic", nchains=nchains)
+    elif kind == "clock":                              # rooted clock tree: Move_ParsSPRClock (the node-length shape of the binding)
+        nex = _clock_nexus("dynamic", ngen=ngen)
     else:
         st, tr = _general_case("wag", 12, 120)
         nex = refrun.model_nexus("wag", st, tr, ngen=ngen, beagle="dynamic")
@@ -361,7 +363,7 @@ def _check_device_parsimony(plain, patched, ngen, kind="dna"):
     assert "Analysis completed" in chk_out, text[-2000:]
     m = re.search(r"mbamd parsimony check: (\d+) comparisons against the host functions, all equal", text)
     assert m and int(m.group(1)) > 1000, text[-2000:]
-    assert "mbamdParsDownPass" in text and "mbamdParsFinalPass" in text and "mbamdParsScore" in text
+    assert "mbamdParsDownPass" in text and "mbamdParsScore" in text and (kind == "clock" or "mbamdParsFinalPass" in text)
     # 2. device only: the same proposals, hence the same chain, generation for generation
     dev_out, _ = refrun.run_mb(patched, nex)
     assert "Analysis completed" in dev_out
@@ -372,7 +374,7 @@ def _check_device_parsimony(plain, patched, ngen, kind="dna"):
     assert "mbamdPars" not in off_out and _trajectory(off_out) == a
 
 
-@pytest.mark.parametrize("kind", ["dna", "wag"])
+@pytest.mark.parametrize("kind", ["dna", "wag", "clock"])
 def test_device_parsimony_on_emulated_engine(kind):
     if not os.path.isdir("/root/reference/src"):
         pytest.skip("reference sources not present (build container only)")
@@ -387,6 +389,7 @@ def test_device_parsimony_on_mi355x():
     if not os.path.exists(refrun.REF_MB_AMD_PARS):
         pytest.skip("oracle/_ref/mb_amd_pars was not built (needs the reference sources at build time)")
     _check_device_parsimony(refrun.REF_MB_AMD, refrun.REF_MB_AMD_PARS, 3000)
+    _check_device_parsimony(refrun.REF_MB_AMD, refrun.REF_MB_AMD_PARS, 1500, "clock")
 
 
 # ---- `set beagleprecision=double`: the fp64 engine (mbamd_f64.h) behind the unmodified binary -------------------------
