@@ -44,8 +44,8 @@ enum BeagleReturnCodes {
 /* capability / preference / requirement flags (reference use: src/mbbeagle.c:685-753,
  * src/command.c:6637-7090, src/bayes.c:608-640) */
 enum BeagleFlags {
-    BEAGLE_FLAG_PRECISION_SINGLE    = 1 << 0,
-    BEAGLE_FLAG_PRECISION_DOUBLE    = 1 << 1,
+    BEAGLE_FLAG_PRECISION_SINGLE    = 1 << 0,   /* the tuned engines (fp32 conditional likelihoods, fp64 sums and logs) */
+    BEAGLE_FLAG_PRECISION_DOUBLE    = 1 << 1,   /* required, or preferred without SINGLE (`set beagleprecision=double`): the fp64 engine */
     BEAGLE_FLAG_COMPUTATION_SYNCH   = 1 << 2,
     BEAGLE_FLAG_COMPUTATION_ASYNCH  = 1 << 3,
     BEAGLE_FLAG_EIGEN_REAL          = 1 << 4,
