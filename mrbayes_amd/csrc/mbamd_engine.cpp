@@ -2851,7 +2851,7 @@ int beagleSetCPUThreadCount(int instance, int threadCount)
 int beagleSetPatternPartitions(int instance, int partitionCount, const int* inPatternPartitions)
 {
     GET_INSTANCE(instance);
-    if (in->f64) return fail(BEAGLE_ERROR_NO_IMPLEMENTATION, "beagleSetPatternPartitions: not on a double-precision instance");
+    if (in->f64) return (partitionCount < 1 || !inPatternPartitions) ? fail(BEAGLE_ERROR_OUT_OF_RANGE, "beagleSetPatternPartitions: arguments") : in->f64->setPartitions(partitionCount, inPatternPartitions);
     API_TRACE("beagleSetPatternPartitions(%d partitions)", partitionCount);
     if (partitionCount < 1 || !inPatternPartitions) return fail(BEAGLE_ERROR_OUT_OF_RANGE, "beagleSetPatternPartitions: arguments");
     if (!in->logOpen) return fail(BEAGLE_ERROR_GENERAL, "beagleSetPatternPartitions: call it before the first matrix / partials update");
@@ -3027,7 +3027,7 @@ int beagleUpdateTransitionMatricesWithMultipleModels(int instance, const int* ei
 {
     StatTimer st_(ST_MATRICES);
     GET_INSTANCE_NOFLUSH(instance);
-    if (in->f64) return fail(BEAGLE_ERROR_NO_IMPLEMENTATION, "beagleUpdateTransitionMatricesWithMultipleModels: not on a double-precision instance");
+    if (in->f64) return (firstDerivativeIndices || secondDerivativeIndices) ? fail(BEAGLE_ERROR_NO_IMPLEMENTATION, "beagleUpdateTransitionMatricesWithMultipleModels: derivatives") : in->f64->updateMatricesMulti(eigenIndices, categoryRateIndices, probabilityIndices, edgeLengths, count);
     API_TRACE("beagleUpdateTransitionMatricesWithMultipleModels(count=%d, eigen=%s..., rates=%s...)", count,
               trace_ints(eigenIndices, std::min(6, count)).c_str(), trace_ints(categoryRateIndices, std::min(6, count)).c_str());
     if (firstDerivativeIndices || secondDerivativeIndices)
@@ -3086,7 +3086,11 @@ int beagleUpdatePartialsByPartition(int instance, const BeagleOperationByPartiti
 {
     StatTimer st_(ST_PARTIALS);
     GET_INSTANCE_NOFLUSH(instance);
-    if (in->f64) return fail(BEAGLE_ERROR_NO_IMPLEMENTATION, "beagleUpdatePartialsByPartition: not on a double-precision instance");
+    if (in->f64) {
+        std::vector<int> part((size_t) std::max(operationCount, 0)), cum((size_t) std::max(operationCount, 0));
+        for (int i = 0; i < operationCount; ++i) { part[i] = operations[i].partition; cum[i] = operations[i].cumulativeScaleIndex; }
+        return in->f64->updatePartialsEx(operations, sizeof(BeagleOperationByPartition), operationCount, part.data(), cum.data());
+    }
     API_TRACE("beagleUpdatePartialsByPartition(count=%d)", operationCount);
     in->closeLog();
     std::vector<BeagleOperation> list;
@@ -3231,21 +3235,21 @@ int beagleAccumulateScaleFactorsByPartition(int instance, const int* scaleIndice
 {
     StatTimer st_(ST_SCALE);
     GET_INSTANCE_NOFLUSH(instance);
-    if (in->f64) return fail(BEAGLE_ERROR_NO_IMPLEMENTATION, "beagleAccumulateScaleFactorsByPartition: not on a double-precision instance");
+    if (in->f64) return in->f64->accumulateScale(scaleIndices, count, cumulativeScaleIndex, +1, partitionIndex);
     return scale_accumulate(in, scaleIndices, count, cumulativeScaleIndex, +1, partitionIndex);
 }
 int beagleRemoveScaleFactorsByPartition(int instance, const int* scaleIndices, int count, int cumulativeScaleIndex, int partitionIndex)
 {
     StatTimer st_(ST_SCALE);
     GET_INSTANCE_NOFLUSH(instance);
-    if (in->f64) return fail(BEAGLE_ERROR_NO_IMPLEMENTATION, "beagleRemoveScaleFactorsByPartition: not on a double-precision instance");
+    if (in->f64) return in->f64->accumulateScale(scaleIndices, count, cumulativeScaleIndex, -1, partitionIndex);
     return scale_accumulate(in, scaleIndices, count, cumulativeScaleIndex, -1, partitionIndex);
 }
 int beagleResetScaleFactorsByPartition(int instance, int cumulativeScaleIndex, int partitionIndex)
 {
     StatTimer st_(ST_SCALE);
     GET_INSTANCE(instance);
-    if (in->f64) return fail(BEAGLE_ERROR_NO_IMPLEMENTATION, "beagleResetScaleFactorsByPartition: not on a double-precision instance");
+    if (in->f64) return in->f64->resetScale(cumulativeScaleIndex, partitionIndex);
     FACADE_ALL((in->partitionCount > 1 && ch.partition != partitionIndex) ? BEAGLE_SUCCESS : scale_reset(c, cumulativeScaleIndex));
     return scale_reset(in, cumulativeScaleIndex);
 }
@@ -3331,7 +3335,7 @@ int beagleCalculateRootLogLikelihoodsByPartition(int instance, const int* buffer
 {
     StatTimer st_(ST_LNL);
     GET_INSTANCE(instance);
-    if (in->f64) return fail(BEAGLE_ERROR_NO_IMPLEMENTATION, "beagleCalculateRootLogLikelihoodsByPartition: not on a double-precision instance");
+    if (in->f64) return in->f64->logLikelihoods(bufferIndices, nullptr, nullptr, categoryWeightsIndices, stateFrequenciesIndices, cumulativeScaleIndices, count, outSumLogLikelihood, partitionIndices, partitionCount, outSumLogLikelihoodByPartition);
     if (!in->facade() && (partitionCount != 1 || partitionIndices[0] != 0))
         return fail(BEAGLE_ERROR_OUT_OF_RANGE, "beagleCalculateRootLogLikelihoodsByPartition: no partitions were set");
     double total = 0.0;
@@ -3353,7 +3357,11 @@ int beagleCalculateEdgeLogLikelihoodsByPartition(int instance, const int* parent
 {
     StatTimer st_(ST_LNL);
     GET_INSTANCE(instance);
-    if (in->f64) return fail(BEAGLE_ERROR_NO_IMPLEMENTATION, "beagleCalculateEdgeLogLikelihoodsByPartition: not on a double-precision instance");
+    if (in->f64)
+        return (firstDerivativeIndices || secondDerivativeIndices || outSumFirstDerivativeByPartition || outSumFirstDerivative || outSumSecondDerivativeByPartition || outSumSecondDerivative)
+                   ? fail(BEAGLE_ERROR_NO_IMPLEMENTATION, "beagleCalculateEdgeLogLikelihoodsByPartition: derivatives")
+                   : in->f64->logLikelihoods(parentBufferIndices, childBufferIndices, probabilityIndices, categoryWeightsIndices, stateFrequenciesIndices,
+                                             cumulativeScaleIndices, count, outSumLogLikelihood, partitionIndices, partitionCount, outSumLogLikelihoodByPartition);
     if (firstDerivativeIndices || secondDerivativeIndices || outSumFirstDerivativeByPartition || outSumFirstDerivative ||
         outSumSecondDerivativeByPartition || outSumSecondDerivative)
         return fail(BEAGLE_ERROR_NO_IMPLEMENTATION, "beagleCalculateEdgeLogLikelihoodsByPartition: derivatives");
@@ -3459,6 +3467,7 @@ int mbamdWalkTrace(int instance, long long* out, int maxSteps, int* outSteps, in
 int mbamdGetChildCount(int instance)
 {
     GET_INSTANCE_NOFLUSH(instance);
+    if (in->f64) return std::max<int>(1, (int) in->f64->parts.size());
     return in->facade() ? (int) in->children.size() : 1;
 }
 int mbamdSetDeferredResult(int instance, int enable)

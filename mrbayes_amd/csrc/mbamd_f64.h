@@ -21,7 +21,10 @@ struct Op64 {
     const double* m1T;           // transposed matrices of child 1: [K][S][SPAD]
     const double* m2T;
     int32_t* scale;              // exponents written (mode 1) or read (mode 2)
-    int c1_tip, c2_tip, mode, pad_;
+    int32_t* cum;                // cumulative exponents the written ones are added to, or null
+    int c1_tip, c2_tip, mode;
+    int first, last;             // the operation covers patterns [first, last): everything, or one partition (v3 *ByPartition)
+    int pad_;
 };
 
 template <int IB>
@@ -58,6 +61,7 @@ k64_partials(const Op64* __restrict__ ops, int S, int SPAD, int K, int Ppad_)
 {
     const Op64& op = ops[blockIdx.y];
     const size_t Ppad = (size_t) Ppad_, c = (size_t) blockIdx.x * 64 + threadIdx.x;
+    if (c < (size_t) op.first || c >= (size_t) op.last) return;
     for (int k = 0; k < K; ++k)
         for (int i0 = 0; i0 < S; i0 += IB) {
             double f1[IB], f2[IB];
@@ -74,10 +78,12 @@ k64_partials(const Op64* __restrict__ ops, int S, int SPAD, int K, int Ppad_)
 // results need all 256 VGPRs and the fused kernel is no faster: measured, dropped).
 template <int IB, int KF>
 __global__ void __launch_bounds__(64)
-k64_partials_fused(const Op64* __restrict__ ops, int S, int SPAD, int Ppad_, int32_t* __restrict__ cumulative)
+k64_partials_fused(const Op64* __restrict__ ops, int S, int SPAD, int Ppad_)
 {
     const Op64& op = ops[blockIdx.y];
     const size_t Ppad = (size_t) Ppad_, c = (size_t) blockIdx.x * 64 + threadIdx.x;
+    if (c < (size_t) op.first || c >= (size_t) op.last) return;
+    int32_t* cumulative = op.cum;
     double out[KF][IB];
     double mx = 0.0;
 #pragma unroll
@@ -110,11 +116,13 @@ k64_partials_fused(const Op64* __restrict__ ops, int S, int SPAD, int Ppad_, int
 // CondLikeScaler_* (reference src/likelihood.c:4939-4988): per-pattern maximum over categories and states, exact
 // power-of-two rescale, exponent kept (and added to the cumulative buffer of the call)
 __global__ void __launch_bounds__(64)
-k64_rescale(const Op64* __restrict__ ops, int S, int K, int Ppad_, int32_t* __restrict__ cumulative)
+k64_rescale(const Op64* __restrict__ ops, int S, int K, int Ppad_)
 {
     const Op64& op = ops[blockIdx.y];
     if (op.mode == 0) return;
     const size_t Ppad = (size_t) Ppad_, c = (size_t) blockIdx.x * 64 + threadIdx.x;
+    if (c < (size_t) op.first || c >= (size_t) op.last) return;
+    int32_t* cumulative = op.cum;
     double* dst = op.dst + c;
     const int n = K * S;
     int e = 0;
@@ -179,12 +187,13 @@ struct IntegrateArgs64 {
     int            count;
 };
 __global__ void __launch_bounds__(64)
-k64_integrate(IntegrateArgs64 a, int S, int K, int P, int Ppad_, const double* __restrict__ pattern_weights,
+k64_integrate(IntegrateArgs64 a, int S, int K, int first, int last, int Ppad_, const double* __restrict__ pattern_weights,
               double* __restrict__ site, double* __restrict__ wsite)
 {
-    const size_t Ppad = (size_t) Ppad_, c = (size_t) blockIdx.x * 64 + threadIdx.x;
+    // patterns [first, last): everything, or one partition; blocks are counted from the 64-pattern block that holds `first`
+    const size_t Ppad = (size_t) Ppad_, c = (size_t) (first / 64 + (int) blockIdx.x) * 64 + threadIdx.x;
     double wl = 0.0;
-    if (c < (size_t) P) {
+    if (c >= (size_t) first && c < (size_t) last) {
         int emax = -2147483647;
         for (int n = 0; n < a.count; ++n) {
             const int e = a.cum[n] ? a.cum[n][c] : 0;
@@ -221,8 +230,6 @@ k64_integrate(IntegrateArgs64 a, int S, int K, int P, int Ppad_, const double* _
         const double lnl = log(total) + (double) emax * 0.69314718055994530942;
         site[c] = lnl;
         wl = lnl * pattern_weights[c];
-    } else if (c < Ppad) {
-        site[c] = 0.0;
     }
 #if defined(MBAMD_HOST_EMU)
     if (threadIdx.x == 0) wsite[blockIdx.x] = 0.0;
@@ -235,10 +242,10 @@ k64_integrate(IntegrateArgs64 a, int S, int K, int P, int Ppad_, const double* _
 }
 
 __global__ void __launch_bounds__(256)
-k64_scale_accumulate(const int32_t* const* __restrict__ src, int count, int sign, int n, int32_t* __restrict__ cum)
+k64_scale_accumulate(const int32_t* const* __restrict__ src, int count, int sign, int first, int last, int32_t* __restrict__ cum)
 {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= n) return;
+    const int c = first + (int) (blockIdx.x * blockDim.x + threadIdx.x);
+    if (c >= last) return;
     int s = 0;
     for (int i = 0; i < count; ++i) s += src[i][c];
     cum[c] += sign * s;
@@ -262,13 +269,15 @@ public:
     double* d_pweights = nullptr;          // [Ppad]
     int32_t* d_scale = nullptr;            // [nScale][Ppad]
     double* d_site = nullptr;              // [Ppad]
-    double* d_sums = nullptr;              // [Ppad/64]
+    double* d_sums = nullptr;              // [partitions of a call][Ppad/64]
+    size_t sumsCap = 0;
     double* d_ev = nullptr;
     size_t evCap = 0;
     void* d_stage = nullptr;
     size_t stageCap = 0;
     std::vector<RatesArg> rateSets;
     bool haveSite = false;
+    std::vector<std::pair<int, int>> parts;       // v3: [first, last) of every pattern partition (empty: none were set)
     size_t bufDoubles = 0, matDoubles = 0, eigDoubles = 0;
 
     ~Engine64() { destroy(); }
@@ -299,7 +308,8 @@ public:
         HIP_TRY(hipMalloc(&d_scale, std::max<size_t>(1, (size_t) nScale * Ppad) * sizeof(int32_t)));
         HIP_TRY(hipMemsetAsync(d_scale, 0, std::max<size_t>(1, (size_t) nScale * Ppad) * sizeof(int32_t), stream));
         HIP_TRY(hipMalloc(&d_site, (size_t) Ppad * sizeof(double)));
-        HIP_TRY(hipMalloc(&d_sums, (size_t) (Ppad / 64) * sizeof(double)));
+        sumsCap = (size_t) (Ppad / 64);
+        HIP_TRY(hipMalloc(&d_sums, sumsCap * sizeof(double)));
         isTip.assign((size_t) nBuffers, 0);
         stateSlot.assign((size_t) nBuffers, -1);
         valid.assign((size_t) nBuffers, 0);
@@ -442,6 +452,19 @@ public:
         HIP_TRY(hipGetLastError());
         return BEAGLE_SUCCESS;
     }
+    // v3: an eigen-system and a category-rate vector per matrix; one launch per run of equal rate vectors
+    int updateMatricesMulti(const int* eigenIdx, const int* rateIdx, const int* prob, const double* lengths, int count)
+    {
+        int i = 0;
+        while (i < count) {
+            int j = i + 1;
+            while (j < count && eigenIdx[j] == eigenIdx[i] && rateIdx[j] == rateIdx[i]) ++j;
+            const int rc = updateMatrices(eigenIdx[i], rateIdx[i], prob + i, lengths + i, j - i);
+            if (rc) return rc;
+            i = j;
+        }
+        return BEAGLE_SUCCESS;
+    }
     // in: [K][S][S] row = from-state (BEAGLE's order)
     int setMatrix(int idx, const double* m)
     {
@@ -470,15 +493,53 @@ public:
     }
     // One launch per dependency level: an operation goes one level above the last operation that wrote a buffer it reads,
     // read or wrote the buffer it writes, or touched its scale buffer.
+    int partitionRange(int partition, int* first, int* last, const char* what) const
+    {
+        if (partition < 0) { *first = 0; *last = Ppad; return BEAGLE_SUCCESS; }
+        if (parts.empty() ? partition != 0 : partition >= (int) parts.size()) return fail(BEAGLE_ERROR_OUT_OF_RANGE, what, "partition index");
+        if (parts.empty()) { *first = 0; *last = Ppad; return BEAGLE_SUCCESS; }
+        *first = parts[partition].first;
+        *last = parts[partition].second;
+        return BEAGLE_SUCCESS;
+    }
+    int setPartitions(int count, const int* ids)
+    {
+        std::vector<std::pair<int, int>> r;
+        for (int c = 0; c < P; ++c) {
+            const int p = ids[c];
+            if (p < 0 || p >= count) return fail(BEAGLE_ERROR_OUT_OF_RANGE, "beagleSetPatternPartitions: partition index");
+            if ((int) r.size() == p) r.emplace_back(c, c + 1);
+            else if ((int) r.size() == p + 1 && r[p].second == c) r[p].second++;
+            else return fail(BEAGLE_ERROR_NO_IMPLEMENTATION, "beagleSetPatternPartitions: partitions must be contiguous, increasing pattern ranges");
+        }
+        if ((int) r.size() != count) return fail(BEAGLE_ERROR_OUT_OF_RANGE, "beagleSetPatternPartitions: empty partition");
+        parts = r;
+        return BEAGLE_SUCCESS;
+    }
     int updatePartials(const BeagleOperation* ops, int n, int cumIdx)
     {
+        std::vector<int> part((size_t) std::max(n, 0), -1), cum((size_t) std::max(n, 0), cumIdx);
+        return updatePartialsEx(ops, sizeof(BeagleOperation), n, part.data(), cum.data());
+    }
+    // `stride` bytes between operations (BeagleOperation or BeagleOperationByPartition: the first seven ints are the same);
+    // partition[i] < 0: all patterns.  Hazards are tracked per (buffer, partition): the same buffer index in two partitions
+    // is two disjoint pattern ranges.
+    int updatePartialsEx(const void* opsRaw, size_t stride, int n, const int* partition, const int* cumOf)
+    {
         if (n <= 0) return BEAGLE_SUCCESS;
-        if (cumIdx != BEAGLE_OP_NONE && (cumIdx < 0 || cumIdx >= nScale)) return fail(BEAGLE_ERROR_OUT_OF_RANGE, "beagleUpdatePartials: cumulative scale index");
-        std::vector<int> level((size_t) n, 0), lastTouchBuf((size_t) nBuffers, -1), lastWriteBuf((size_t) nBuffers, -1), lastTouchScale((size_t) std::max(nScale, 1), -1);
+        const int np = std::max<int>(1, (int) parts.size());
+        std::vector<int> level((size_t) n, 0), lastTouchBuf((size_t) nBuffers * np, -1), lastWriteBuf((size_t) nBuffers * np, -1),
+            lastTouchScale((size_t) std::max(nScale, 1) * np, -1);
         int nLevels = 0;
         std::vector<Op64> h((size_t) n);
         for (int i = 0; i < n; ++i) {
-            const BeagleOperation& o = ops[i];
+            const BeagleOperation& o = *reinterpret_cast<const BeagleOperation*>(static_cast<const char*>(opsRaw) + (size_t) i * stride);
+            const int cumIdx = cumOf[i];
+            if (cumIdx != BEAGLE_OP_NONE && (cumIdx < 0 || cumIdx >= nScale)) return fail(BEAGLE_ERROR_OUT_OF_RANGE, "beagleUpdatePartials: cumulative scale index");
+            int first = 0, last = Ppad;
+            int rcp = partitionRange(partition[i], &first, &last, "beagleUpdatePartialsByPartition");
+            if (rcp) return rcp;
+            const int p0 = partition[i] < 0 ? 0 : std::min(partition[i], np - 1), p1 = partition[i] < 0 ? np : p0 + 1;
             const int d = o.destinationPartials, c1 = o.child1Partials, c2 = o.child2Partials;
             if (d < 0 || d >= nBuffers || c1 < 0 || c1 >= nBuffers || c2 < 0 || c2 >= nBuffers)
                 return fail(BEAGLE_ERROR_OUT_OF_RANGE, "beagleUpdatePartials: buffer index");
@@ -489,16 +550,21 @@ public:
             const int sw = o.destinationScaleWrite, sr = o.destinationScaleRead;
             if ((sw != BEAGLE_OP_NONE && (sw < 0 || sw >= nScale)) || (sr != BEAGLE_OP_NONE && (sr < 0 || sr >= nScale)))
                 return fail(BEAGLE_ERROR_OUT_OF_RANGE, "beagleUpdatePartials: scale index");
-            int lv = std::max(std::max(lastWriteBuf[c1], lastWriteBuf[c2]), lastTouchBuf[d]) + 1;
             const int sc = sw != BEAGLE_OP_NONE ? sw : sr;
-            if (sc != BEAGLE_OP_NONE) lv = std::max(lv, lastTouchScale[sc] + 1);
+            int lv = 0;
+            for (int q = p0; q < p1; ++q) {
+                lv = std::max(lv, std::max(std::max(lastWriteBuf[(size_t) c1 * np + q], lastWriteBuf[(size_t) c2 * np + q]), lastTouchBuf[(size_t) d * np + q]) + 1);
+                if (sc != BEAGLE_OP_NONE) lv = std::max(lv, lastTouchScale[(size_t) sc * np + q] + 1);
+            }
             level[i] = lv;
             nLevels = std::max(nLevels, lv + 1);
-            lastWriteBuf[d] = lv;
-            lastTouchBuf[d] = std::max(lastTouchBuf[d], lv);
-            lastTouchBuf[c1] = std::max(lastTouchBuf[c1], lv);
-            lastTouchBuf[c2] = std::max(lastTouchBuf[c2], lv);
-            if (sc != BEAGLE_OP_NONE) lastTouchScale[sc] = lv;
+            for (int q = p0; q < p1; ++q) {
+                lastWriteBuf[(size_t) d * np + q] = lv;
+                lastTouchBuf[(size_t) d * np + q] = std::max(lastTouchBuf[(size_t) d * np + q], lv);
+                lastTouchBuf[(size_t) c1 * np + q] = std::max(lastTouchBuf[(size_t) c1 * np + q], lv);
+                lastTouchBuf[(size_t) c2 * np + q] = std::max(lastTouchBuf[(size_t) c2 * np + q], lv);
+                if (sc != BEAGLE_OP_NONE) lastTouchScale[(size_t) sc * np + q] = lv;
+            }
             Op64& q = h[i];
             q.dst = partialsPtr(d);
             q.c1 = isTip[c1] ? (const void*) statesPtr(c1) : (const void*) partialsPtr(c1);
@@ -509,6 +575,9 @@ public:
             q.m2T = matrixPtr(o.child2TransitionMatrix) + (size_t) K * S * S;
             q.mode = sw != BEAGLE_OP_NONE ? 1 : sr != BEAGLE_OP_NONE ? 2 : 0;
             q.scale = sc != BEAGLE_OP_NONE ? d_scale + (size_t) sc * Ppad : nullptr;
+            q.cum = cumIdx != BEAGLE_OP_NONE ? d_scale + (size_t) cumIdx * Ppad : nullptr;
+            q.first = first;
+            q.last = last;
             q.pad_ = 0;
             valid[d] = 1;
             isTip[d] = 0;
@@ -525,7 +594,6 @@ public:
         int rc = stage(sorted.data(), sorted.size() * sizeof(Op64), &dv);
         if (rc) return rc;
         const Op64* dops = static_cast<const Op64*>(dv);
-        int32_t* cum = cumIdx != BEAGLE_OP_NONE ? d_scale + (size_t) cumIdx * Ppad : nullptr;
         const bool fused = K == 4 && IB == 4 && S <= IB && std::getenv("MBAMD_F64_UNFUSED") == nullptr;
         for (int l = 0; l < nLevels; ++l) {
             const int first = start[l], cnt = start[(size_t) l + 1] - first;
@@ -533,7 +601,7 @@ public:
             if (fused) {
                 const dim3 grid((unsigned) (Ppad / 64), (unsigned) cnt);
                 auto kern = k64_partials_fused<4, 4>;
-                MBAMD_LAUNCH(kern, grid, 64, 0, stream, dops + first, S, SPAD, Ppad, cum);
+                MBAMD_LAUNCH(kern, grid, 64, 0, stream, dops + first, S, SPAD, Ppad);
                 continue;
             }
             switch (IB) {
@@ -546,21 +614,27 @@ public:
             bool anyScale = false;
             for (int i = first; i < first + cnt; ++i) anyScale |= sorted[i].mode != 0;
             if (anyScale)
-                MBAMD_LAUNCH(k64_rescale, dim3((unsigned) (Ppad / 64), (unsigned) cnt), 64, 0, stream, dops + first, S, K, Ppad, cum);
+                MBAMD_LAUNCH(k64_rescale, dim3((unsigned) (Ppad / 64), (unsigned) cnt), 64, 0, stream, dops + first, S, K, Ppad);
         }
         HIP_TRY(hipGetLastError());
         return BEAGLE_SUCCESS;
     }
 
-    int resetScale(int idx)
+    int resetScale(int idx, int partition = -1)
     {
         if (idx < 0 || idx >= nScale) return fail(BEAGLE_ERROR_OUT_OF_RANGE, "beagleResetScaleFactors: index");
-        HIP_TRY(hipMemsetAsync(d_scale + (size_t) idx * Ppad, 0, (size_t) Ppad * sizeof(int32_t), stream));
+        int first = 0, last = Ppad;
+        int rc = partitionRange(partition, &first, &last, "beagleResetScaleFactorsByPartition");
+        if (rc) return rc;
+        HIP_TRY(hipMemsetAsync(d_scale + (size_t) idx * Ppad + first, 0, (size_t) (last - first) * sizeof(int32_t), stream));
         return BEAGLE_SUCCESS;
     }
-    int accumulateScale(const int* idx, int count, int cumIdx, int sign)
+    int accumulateScale(const int* idx, int count, int cumIdx, int sign, int partition = -1)
     {
         if (count <= 0) return BEAGLE_SUCCESS;
+        int first = 0, last = Ppad;
+        int rcp = partitionRange(partition, &first, &last, "scale factors by partition");
+        if (rcp) return rcp;
         if (cumIdx < 0 || cumIdx >= nScale) return fail(BEAGLE_ERROR_OUT_OF_RANGE, "scale factors: cumulative index");
         std::vector<const int32_t*> src((size_t) count);
         for (int i = 0; i < count; ++i) {
@@ -570,7 +644,7 @@ public:
         void* dv = nullptr;
         int rc = stage(src.data(), src.size() * sizeof(const int32_t*), &dv);
         if (rc) return rc;
-        MBAMD_LAUNCH(k64_scale_accumulate, (unsigned) ((Ppad + 255) / 256), 256, 0, stream, (const int32_t* const*) dv, count, sign, Ppad, d_scale + (size_t) cumIdx * Ppad);
+        MBAMD_LAUNCH(k64_scale_accumulate, (unsigned) ((last - first + 255) / 256), 256, 0, stream, (const int32_t* const*) dv, count, sign, first, last, d_scale + (size_t) cumIdx * Ppad);
         HIP_TRY(hipGetLastError());
         return BEAGLE_SUCCESS;
     }
@@ -600,44 +674,72 @@ public:
         return BEAGLE_SUCCESS;
     }
 
-    int logLikelihoods(const int* parent, const int* child, const int* prob, const int* wIdx, const int* fIdx, const int* cumIdx, int count, double* out)
+    // index arrays are [count][partitionCount] when `partitions` is given (reference src/mbbeagle.c:2781-2800), else [count]
+    int logLikelihoods(const int* parent, const int* child, const int* prob, const int* wIdx, const int* fIdx, const int* cumIdx, int count,
+                       double* out, const int* partitions = nullptr, int partitionCount = 1, double* outByPartition = nullptr)
     {
         if (count < 1 || count > MBAMD_MAX_SUBSETS) return fail(BEAGLE_ERROR_NO_IMPLEMENTATION, "log-likelihood: more than 8 subsets");
-        IntegrateArgs64 a;
-        std::memset(&a, 0, sizeof a);
-        a.count = count;
-        for (int n = 0; n < count; ++n) {
-            if (parent[n] < 0 || parent[n] >= nBuffers || !valid[parent[n]] || isTip[parent[n]])
-                return fail(BEAGLE_ERROR_OUT_OF_RANGE, "log-likelihood: parent buffer");
-            a.parent[n] = partialsPtr(parent[n]);
-            if (child) {
-                const int ci = child[n];
-                if (ci < 0 || ci >= nBuffers || !valid[ci] || prob[n] < 0 || prob[n] >= nMatrices)
-                    return fail(BEAGLE_ERROR_OUT_OF_RANGE, "edge log-likelihood: child buffer / matrix");
-                a.child[n] = isTip[ci] ? (const void*) statesPtr(ci) : (const void*) partialsPtr(ci);
-                a.child_tip[n] = (uint8_t) isTip[ci];
-                a.matrix[n] = matrixPtr(prob[n]);
-            }
-            if (wIdx[n] < 0 || wIdx[n] >= nEigen || fIdx[n] < 0 || fIdx[n] >= nEigen)
-                return fail(BEAGLE_ERROR_OUT_OF_RANGE, "log-likelihood: weights / frequencies index");
-            a.weights[n] = d_weights + (size_t) wIdx[n] * K;
-            a.freqs[n] = d_freqs + (size_t) fIdx[n] * S;
-            if (cumIdx && cumIdx[n] != BEAGLE_OP_NONE) {
-                if (cumIdx[n] < 0 || cumIdx[n] >= nScale) return fail(BEAGLE_ERROR_OUT_OF_RANGE, "log-likelihood: cumulative scale index");
-                a.cum[n] = d_scale + (size_t) cumIdx[n] * Ppad;
-            }
-        }
+        const int pc = partitions ? partitionCount : 1;
         const int nblocks = Ppad / 64;
-        MBAMD_LAUNCH(k64_integrate, (unsigned) nblocks, 64, 0, stream, a, S, K, P, Ppad, (const double*) d_pweights, d_site, d_sums);
+        std::vector<double> h((size_t) nblocks * pc);
+        std::vector<int> blocksOf((size_t) pc);
+        if ((size_t) nblocks * pc > sumsCap) {
+            HIP_TRY(hipStreamSynchronize(stream));
+            if (d_sums) (void) hipFree(d_sums);
+            d_sums = nullptr;
+            sumsCap = (size_t) nblocks * pc;
+            HIP_TRY(hipMalloc(&d_sums, sumsCap * sizeof(double)));
+        }
+        for (int d = 0; d < pc; ++d) {
+            int first = 0, last = P;
+            if (partitions) {
+                int rc = partitionRange(partitions[d], &first, &last, "log-likelihood by partition");
+                if (rc) return rc;
+                last = std::min(last, P);
+            }
+            IntegrateArgs64 a;
+            std::memset(&a, 0, sizeof a);
+            a.count = count;
+            for (int n = 0; n < count; ++n) {
+                const int j = n * pc + d;
+                if (parent[j] < 0 || parent[j] >= nBuffers || !valid[parent[j]] || isTip[parent[j]])
+                    return fail(BEAGLE_ERROR_OUT_OF_RANGE, "log-likelihood: parent buffer");
+                a.parent[n] = partialsPtr(parent[j]);
+                if (child) {
+                    const int ci = child[j];
+                    if (ci < 0 || ci >= nBuffers || !valid[ci] || prob[j] < 0 || prob[j] >= nMatrices)
+                        return fail(BEAGLE_ERROR_OUT_OF_RANGE, "edge log-likelihood: child buffer / matrix");
+                    a.child[n] = isTip[ci] ? (const void*) statesPtr(ci) : (const void*) partialsPtr(ci);
+                    a.child_tip[n] = (uint8_t) isTip[ci];
+                    a.matrix[n] = matrixPtr(prob[j]);
+                }
+                if (wIdx[j] < 0 || wIdx[j] >= nEigen || fIdx[j] < 0 || fIdx[j] >= nEigen)
+                    return fail(BEAGLE_ERROR_OUT_OF_RANGE, "log-likelihood: weights / frequencies index");
+                a.weights[n] = d_weights + (size_t) wIdx[j] * K;
+                a.freqs[n] = d_freqs + (size_t) fIdx[j] * S;
+                if (cumIdx && cumIdx[j] != BEAGLE_OP_NONE) {
+                    if (cumIdx[j] < 0 || cumIdx[j] >= nScale) return fail(BEAGLE_ERROR_OUT_OF_RANGE, "log-likelihood: cumulative scale index");
+                    a.cum[n] = d_scale + (size_t) cumIdx[j] * Ppad;
+                }
+            }
+            blocksOf[d] = (last + 63) / 64 - first / 64;
+            if (blocksOf[d] <= 0) continue;
+            MBAMD_LAUNCH(k64_integrate, (unsigned) blocksOf[d], 64, 0, stream, a, S, K, first, last, Ppad, (const double*) d_pweights, d_site,
+                         d_sums + (size_t) d * nblocks);
+        }
         HIP_TRY(hipGetLastError());
-        std::vector<double> h((size_t) nblocks);
-        HIP_TRY(hipMemcpyAsync(h.data(), d_sums, (size_t) nblocks * sizeof(double), hipMemcpyDeviceToHost, stream));
+        HIP_TRY(hipMemcpyAsync(h.data(), d_sums, h.size() * sizeof(double), hipMemcpyDeviceToHost, stream));
         HIP_TRY(hipStreamSynchronize(stream));
-        double s = 0.0;
-        for (int i = 0; i < nblocks; ++i) s += h[i];
+        double total = 0.0;
+        for (int d = 0; d < pc; ++d) {
+            double s = 0.0;
+            for (int i = 0; i < blocksOf[d]; ++i) s += h[(size_t) d * nblocks + i];
+            if (outByPartition) outByPartition[d] = s;
+            total += s;
+        }
         haveSite = true;
-        if (out) *out = s;
-        if (!(s == s) || s > 1.79e308 || s < -1.79e308) return BEAGLE_ERROR_FLOATING_POINT;
+        if (out) *out = total;
+        if (!(total == total) || total > 1.79e308 || total < -1.79e308) return BEAGLE_ERROR_FLOATING_POINT;
         return BEAGLE_SUCCESS;
     }
     int getSites(double* out)

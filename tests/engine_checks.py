@@ -324,20 +324,22 @@ def check_sharded_instance(lib, oracle, div, monkeypatch, shards=3):
     monkeypatch.delenv("MBAMD_SHARD")
 
 
-def check_multi_partition_instance(lib, oracle, div_a, div_b):
+def check_multi_partition_instance(lib, oracle, div_a, div_b, double_precision=False):
     """BEAGLE v3 multi-partition mode (reference src/mbbeagle.c:1500-3010): ONE instance holds the patterns of two data
     divisions with their own eigen-systems, category rates, branch lengths and operation lists; per-partition
     log-likelihoods must equal two separate single-division instances (and the oracle)."""
     assert div_a.nstates == div_b.nstates and div_a.ncat == div_b.ncat and div_a.ntaxa == div_b.ntaxa
     S, K, N = div_a.nstates, div_a.ncat, div_a.ntaxa
     divs = [div_a, div_b]
-    want = [engine_lnl(lib, d) for d in divs]
+    want = [engine_lnl(lib, d, double_precision=double_precision) for d in divs]
     Pa, Pb = div_a.npatterns, div_b.npatterns
     P = Pa + Pb
     nInt, nNodes = N - 2, 2 * N - 2
     # one chain; buffer indices as MrBayes lays them out: tips 0..N-1, interior N..; matrices / eigen offset by division
-    inst = bg.BeagleInstance(lib, N, N + nInt, N, S, P, 2, 2 * nNodes, K, nInt + 2)
+    inst = bg.BeagleInstance(lib, N, N + nInt, N, S, P, 2, 2 * nNodes, K, nInt + 2,
+                             preference_flags=bg.BEAGLE_FLAG_PRECISION_DOUBLE if double_precision else bg.BEAGLE_FLAG_PRECISION_SINGLE)
     try:
+        assert bool(inst.details.flags & bg.BEAGLE_FLAG_PRECISION_DOUBLE) == double_precision
         for t in range(N):
             inst.set_tip_states(t, np.concatenate([div_a.tip_states[t], div_b.tip_states[t]]).astype(np.int32))
         inst.set_pattern_weights(np.concatenate([div_a.weights, div_b.weights]))
@@ -388,8 +390,8 @@ def check_multi_partition_instance(lib, oracle, div_a, div_b):
         inst.finalize()
 
 
-def engine_lnl(lib, div, scaling=lk.MB_BEAGLE_SCALE_ALWAYS, nchains=1, chain=0):
-    bd = lk.BeagleDivision(div, lib, nchains=nchains, scaling=scaling)
+def engine_lnl(lib, div, scaling=lk.MB_BEAGLE_SCALE_ALWAYS, nchains=1, chain=0, double_precision=False):
+    bd = lk.BeagleDivision(div, lib, nchains=nchains, scaling=scaling, double_precision=double_precision)
     try:
         return bd.LogLike(chain)
     finally:

@@ -198,11 +198,12 @@ def test_patterns_sharded_inside_one_instance(emu, oracle, golden_dir, monkeypat
     ec.check_sharded_instance(emu, oracle, div, monkeypatch, shards=3)
 
 
+@pytest.mark.parametrize("double_precision", [False, True])
 @pytest.mark.parametrize("kind", ["gtr", "wag"])
-def test_multi_partition_instance(emu, oracle, golden_dir, kind):
+def test_multi_partition_instance(emu, oracle, golden_dir, kind, double_precision):
     a = synthetic_division(kind, 24, 330, seed=91, tree_seed=92, p_gap=0.02, golden_dir=golden_dir, alpha=0.5)
     b = synthetic_division(kind, 24, 150, seed=93, tree_seed=94, p_gap=0.02, golden_dir=golden_dir, alpha=1.7, brlen=0.11)
-    ec.check_multi_partition_instance(emu, oracle, a, b)
+    ec.check_multi_partition_instance(emu, oracle, a, b, double_precision)
 
 
 @pytest.mark.parametrize("ntaxa,npat,nstates,words", [(12, 100, 4, 1), (30, 333, 4, 1), (9, 64, 20, 1), (8, 70, 61, 1), (7, 65, 64, 1),

@@ -404,6 +404,19 @@ def _check_double_precision(binary, marker):
         ours = refrun.initial_lnl(out)
         assert abs(ours - want) <= 2e-6 + 1e-11 * abs(want), (scaling, ours, want)     # same parameters in the same process: to the printed digits
         assert abs(ours - want) < abs(native32 - want)                                 # and closer than the reference's fp32 build
+    # the v3 build puts both divisions of a partitioned analysis into ONE multi-partition instance: the *ByPartition surface in fp64
+    if "v3" in os.path.basename(binary):
+        pn = _partitioned_nexus(None, same_shape=True)
+        want2 = refrun.initial_lnl(refrun.run_mb(refrun.REF_MB_FP64, pn)[0])
+        for scaling in ("dynamic", "always"):
+            out, _ = refrun.run_mb(binary, _partitioned_nexus(scaling, same_shape=True).replace("beagleprecision=single", "beagleprecision=double"),
+                                   env={"MBAMD_API_TRACE": "1", "MBAMD_VERBOSE": "1"})
+            assert "for 2 divisions" in out and "double-precision level kernels" in out and "[mbamd] error" not in out, out[-2500:]
+            assert abs(refrun.initial_lnl(out) - want2) <= 2e-6 + 1e-11 * abs(want2), (scaling, refrun.initial_lnl(out), want2)
+        out, _ = refrun.run_mb(binary, _partitioned_nexus("dynamic", ngen=200, same_shape=True).replace("beagleprecision=single", "beagleprecision=double"),
+                               env={"MBAMD_VERBOSE": "1"})
+        assert "Analysis completed" in out and "[mbamd] error" not in out, out[-1500:]
+        return
     # a short default-mix run (dynamic rescaling at the double-precision frequency, src/mcmc.c:6226-6228) completes
     nex = refrun.mcmc_nexus(st, tr, 200, beagle="dynamic", nchains=2).replace("beagleprecision=single", "beagleprecision=double")
     out, _ = refrun.run_mb(binary, nex)
@@ -417,6 +430,8 @@ def test_double_precision_on_emulated_engine():
     build_emu.build()
     subprocess.check_call(["make", "-C", os.path.join(ROOT, "oracle"), "_ref/mb", "_ref/mb_fp64", "_ref/mb_emu"], stdout=subprocess.DEVNULL)
     _check_double_precision(refrun.REF_MB_EMU, "mbamd")
+    subprocess.check_call(["make", "-C", os.path.join(ROOT, "oracle"), "_ref/mb_emu_v3"], stdout=subprocess.DEVNULL)
+    _check_double_precision(refrun.REF_MB_EMU_V3, "mbamd")
 
 
 @pytest.mark.gpu
@@ -424,3 +439,5 @@ def test_double_precision_on_mi355x():
     if not (os.path.exists(refrun.REF_MB_AMD) and os.path.exists(refrun.REF_MB_FP64)):
         pytest.skip("oracle/_ref/mb_amd / mb_fp64 were not built (need the reference sources at build time)")
     _check_double_precision(refrun.REF_MB_AMD, "mbamd HIP gfx950")
+    if os.path.exists(refrun.REF_MB_AMD_V3):
+        _check_double_precision(refrun.REF_MB_AMD_V3, "mbamd HIP gfx950")
