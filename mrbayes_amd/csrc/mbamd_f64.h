@@ -62,15 +62,15 @@ k64_partials(const Op64* __restrict__ ops, int S, int SPAD, int K, int Ppad_)
     const Op64& op = ops[blockIdx.y];
     const size_t Ppad = (size_t) Ppad_, c = (size_t) blockIdx.x * 64 + threadIdx.x;
     if (c < (size_t) op.first || c >= (size_t) op.last) return;
-    for (int k = 0; k < K; ++k)
-        for (int i0 = 0; i0 < S; i0 += IB) {
-            double f1[IB], f2[IB];
-            f64_child_factor<IB>(op.c1, op.c1_tip, op.m1T + (size_t) k * S * SPAD, S, SPAD, k, Ppad, c, i0, f1);
-            f64_child_factor<IB>(op.c2, op.c2_tip, op.m2T + (size_t) k * S * SPAD, S, SPAD, k, Ppad, c, i0, f2);
+    // blockIdx.z = (category, state block): a few hundred waves of patterns alone leave the chip empty
+    const int nib = SPAD / IB, k = (int) blockIdx.z / nib, i0 = ((int) blockIdx.z % nib) * IB;
+    (void) K;
+    double f1[IB], f2[IB];
+    f64_child_factor<IB>(op.c1, op.c1_tip, op.m1T + (size_t) k * S * SPAD, S, SPAD, k, Ppad, c, i0, f1);
+    f64_child_factor<IB>(op.c2, op.c2_tip, op.m2T + (size_t) k * S * SPAD, S, SPAD, k, Ppad, c, i0, f2);
 #pragma unroll
-            for (int i = 0; i < IB; ++i)
-                if (i0 + i < S) op.dst[((size_t) k * S + i0 + i) * Ppad + c] = f1[i] * f2[i];
-        }
+    for (int i = 0; i < IB; ++i)
+        if (i0 + i < S) op.dst[((size_t) k * S + i0 + i) * Ppad + c] = f1[i] * f2[i];
 }
 
 // The same with the rescale fused (K == KF categories, S <= IB: all K x S results of a pattern stay in registers): one pass
@@ -489,7 +489,7 @@ public:
 
     template <int IB_> void launchPartials(const Op64* ops, int n)
     {
-        MBAMD_LAUNCH(k64_partials<IB_>, dim3((unsigned) (Ppad / 64), (unsigned) n), 64, 0, stream, ops, S, SPAD, K, Ppad);
+        MBAMD_LAUNCH(k64_partials<IB_>, dim3((unsigned) (Ppad / 64), (unsigned) n, (unsigned) (K * (SPAD / IB_))), 64, 0, stream, ops, S, SPAD, K, Ppad);
     }
     // One launch per dependency level: an operation goes one level above the last operation that wrote a buffer it reads,
     // read or wrote the buffer it writes, or touched its scale buffer.
