@@ -198,6 +198,8 @@ struct Instance {
     std::unordered_map<uint64_t, Walk4Template> w4templates;
     uint64_t scheduleHits = 0, scheduleMisses = 0;
     std::vector<Walk4Op> w4ops;      // scratch
+    std::vector<int> w4key, w4writer, w4segList;                    // buildWalk scratch: no allocation per compiled list
+    std::vector<char> w4written, w4segRead, w4segWritten, w4segScale;
     std::vector<Walk4Entry> w4table;
     int8_t* arenaExp = nullptr;      // node exponents int8 [block][scale buffer][K][64] (+ one scratch buffer)
     unsigned estride = 0;            // bytes between blocks
@@ -1395,33 +1397,37 @@ int Instance::updatePartials4(const BeagleOperation* ops, int n, int cumIdx)
 int Instance::buildWalk(Plan& plan, const BeagleOperation* ops, int n, const int* listOf, bool perList)
 {
     const int scratchScale = (int) scale.size();              // sink / source of entries that do not rescale
-    std::vector<int> segList;                                  // (20/61-state walk) merged-list index of each operation of the segment
-    std::vector<char> written(nBuffers, 0);
+    std::vector<int>& segList = w4segList;                     // (20/61-state walk) merged-list index of each operation of the segment
+    segList.clear();
+    std::vector<char>& written = w4written;
+    written.assign((size_t) nBuffers, 0);
     w4table.clear();
     plan.segments.clear();
     std::vector<Walk4Op>& seg = w4ops;
     seg.clear();
     // segment state: buffers / exponent buffers the current segment has read or written
-    std::vector<char> segRead(nBuffers, 0), segWritten(nBuffers, 0), segScale(scale.size() + 1, 0);
+    std::vector<char>&segRead = w4segRead, &segWritten = w4segWritten, &segScale = w4segScale;
+    segRead.assign((size_t) nBuffers, 0); segWritten.assign((size_t) nBuffers, 0); segScale.assign(scale.size() + 1, 0);
+    if (w4writer.size() < (size_t) nBuffers) w4writer.assign((size_t) nBuffers, -1);
     int reloads = 0, externals = 0, phases = 0;
     auto flushSegment = [&]() -> int {
         if (seg.empty()) return BEAGLE_SUCCESS;
         // structural key
-        std::vector<int> key;
+        std::vector<int>& key = w4key;
+        key.clear();
         key.reserve(seg.size() * 3 + 4);
         key.push_back((int) seg.size()); key.push_back(w4.maxW); key.push_back(w4.maxSlots + 256 * w4.maxSlots1);
         key.push_back(w4.prefetchDistance * 2 + (w4.safeWaits ? 1 : 0));
         {
-            std::unordered_map<int, int> writer;
+            std::vector<int>& writer = w4writer;          // buffer -> operation of this segment that writes it (-1 outside this block)
             for (size_t o = 0; o < seg.size(); ++o) {
-                auto p1 = seg[o].tip1 ? writer.end() : writer.find(seg[o].c1);
-                auto p2 = seg[o].tip2 ? writer.end() : writer.find(seg[o].c2);
-                key.push_back(p1 == writer.end() ? -1 : p1->second);
-                key.push_back(p2 == writer.end() ? -1 : p2->second);
+                key.push_back(seg[o].tip1 ? -1 : writer[seg[o].c1]);
+                key.push_back(seg[o].tip2 ? -1 : writer[seg[o].c2]);
                 key.push_back((int) seg[o].tip1 | ((int) seg[o].tip2 << 1) | ((!seg[o].tip1 && !seg[o].tip2 && seg[o].c1 == seg[o].c2) ? 4 : 0) |
                               ((seg[o].scaleWrite < 0 && seg[o].scaleRead >= 0) ? 8 : 0));   // (SCALE_READ entries wait for an exponent DMA)
                 writer[seg[o].dst] = (int) o;
             }
+            for (size_t o = 0; o < seg.size(); ++o) writer[seg[o].dst] = -1;
         }
         uint64_t kh = 1469598103934665603ull;
         for (int v : key) kh = (kh ^ (uint64_t) (uint32_t) v) * 1099511628211ull;

@@ -58,6 +58,11 @@ struct Walk4Template {
 struct Walk4Scratch {
     std::vector<int> prod1, prod2, parent, ncons, need, size, phaseOf, waveOf, posOf, order, stack, heapTmp;
     std::vector<char> assigned, cap;
+    // kept between builds so that compiling a short list (a root-ward path: every MCMC generation) allocates nothing
+    std::vector<int> binLoad, roots, frontier, slotHolder, lastUse, slotOfVal, freeFrom, memAt;
+    std::vector<std::vector<int>> phaseStart;
+    std::vector<Walk4Template::Entry> scan;
+    std::vector<std::vector<Walk4Template::Entry>> fin;
 };
 
 class Walk4Builder {
@@ -144,7 +149,7 @@ inline bool Walk4Builder::build(const std::vector<Walk4Op>& ops, Walk4Template& 
     int nphases = 0;
     std::vector<std::vector<std::vector<int>>> seq;            // [phase][wave] -> operations in execution order
     int remaining = n;
-    std::vector<int> binLoad, roots, frontier;
+    std::vector<int>&binLoad = s.binLoad, &roots = s.roots, &frontier = s.frontier;
     while (remaining > 0) {
         const int ph = nphases++;
         seq.emplace_back(std::vector<std::vector<int>>(W));
@@ -269,7 +274,9 @@ inline bool Walk4Builder::build(const std::vector<Walk4Op>& ops, Walk4Template& 
     std::vector<std::vector<Item>> items(W);
     std::vector<int>& posOf = s.posOf;
     posOf.assign(n, -1);
-    std::vector<std::vector<int>> phaseStart(W);               // first position after the barrier entry of each phase
+    std::vector<std::vector<int>>& phaseStart = s.phaseStart;  // first position after the barrier entry of each phase
+    if ((int) phaseStart.size() < W) phaseStart.resize(W);
+    for (int w = 0; w < W; ++w) phaseStart[w].clear();
     for (int ph = 0; ph < nphases; ++ph)
         for (int w = 0; w < W; ++w) {
             if (ph > 0) items[w].push_back(Item{-1, (uint8_t) (MBAMD_W4_NOP | MBAMD_W4_BARRIER)});
@@ -281,8 +288,10 @@ inline bool Walk4Builder::build(const std::vector<Walk4Op>& ops, Walk4Template& 
     t.W = W;
     t.phases = nphases;
     t.reloads = t.externals = t.evictions = 0;
-    std::vector<std::vector<Walk4Template::Entry>> fin(W);     // final per-wave programs (PF entries inserted)
-    std::vector<Walk4Template::Entry> scan;
+    std::vector<std::vector<Walk4Template::Entry>>& fin = s.fin;   // final per-wave programs (PF entries inserted)
+    if ((int) fin.size() < W) fin.resize(W);
+    for (int w = 0; w < W; ++w) fin[w].clear();
+    std::vector<Walk4Template::Entry>& scan = s.scan;
 
     // ---- slots, prefetches, wait counts: one linear scan per wave -------------------------------------------------
     int slotsUsed = 1;
@@ -290,11 +299,14 @@ inline bool Walk4Builder::build(const std::vector<Walk4Op>& ops, Walk4Template& 
     // a short single-wave list is a root-ward path: fetch its siblings as early as slots allow -- loads issued before the
     // first store do not wait for any store (in-order vmcnt, see mbamd_walk4.h)
     const int distance = (W == 1 && n <= 128) ? (1 << 20) : prefetchDistance;
-    std::vector<int> slotHolder(S), lastUse(n), slotOfVal(n);   // slotHolder: value (op) or -2 - (prefetch id), -1 free
+    std::vector<int>&slotHolder = s.slotHolder, &lastUse = s.lastUse, &slotOfVal = s.slotOfVal;   // slotHolder: value (op) or -2 - (prefetch id), -1 free
+    slotHolder.assign(S, 0); lastUse.assign(n, 0); slotOfVal.assign(n, 0);
     struct Mem { int op, child, lo, use; int slot; bool issued; };
     std::vector<Mem> mems;
-    std::vector<int> memAt;                                    // per position: first mem whose `use` is this position (sorted)
-    std::vector<int> freeFrom(S);                              // slot is free for a DMA issued at positions >= freeFrom
+    std::vector<int>& memAt = s.memAt;                         // per position: first mem whose `use` is this position (sorted)
+    memAt.clear();
+    std::vector<int>& freeFrom = s.freeFrom;                   // slot is free for a DMA issued at positions >= freeFrom
+    freeFrom.assign(S, 0);
     for (int w = 0; w < W; ++w) {
         const int L = (int) items[w].size();
         scan.assign((size_t) L, Walk4Template::Entry());
