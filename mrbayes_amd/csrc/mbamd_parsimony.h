@@ -1,12 +1,12 @@
 // mbamd_parsimony.h -- Fitch parsimony on the device (include/libhmsbeagle/mbamd_parsimony.h).
 // Included at the end of mbamd_engine.cpp: kernels, the host object behind a parsimony handle, and the C ABI.
 //
-// HBM layout: sets[setIndex][P_pad] of T, T the narrowest unsigned type holding the division's state bits
-// (u8 DNA/RNA/doublet halves... , u16, u32 amino acids, u64 codons, 2 x u64 beyond): one byte per node and pattern for
-// DNA where the reference moves eight (BitsLong).  Site patterns are independent through every pass, so a thread owns
-// one pattern and walks the whole operation list: no inter-thread dependency, no barrier, one launch per pass.
-// Pure integer/byte work bound by the latency of its own dependency chain (each operation reads sets the same thread
-// wrote a few operations earlier, an L2 round trip), not by HBM: at 500 taxa x 20 000 patterns a pass moves 30 MB.
+// HBM layout: sets[setIndex][P_pad] of T, T the narrowest unsigned type holding the division's state bits (u8 DNA / RNA,
+// u16, u32 amino acids, u64 codons, 2 x u64 beyond): one byte per node and pattern for DNA where the reference moves eight
+// (BitsLong).  Two more rows: a junk destination and an all-ones source for no-op steps.  Site patterns are independent
+// through every pass, so a thread owns one pattern and walks a whole compiled program (k_pars_walk): no inter-thread
+// dependency, no barrier; queued passes run as one launch.  Pure integer/byte work; with P/64 waves on 1024 SIMDs the bound
+// is one wave's instruction stream and dependency chain, not HBM (a pass at 500 taxa x 20 000 patterns moves 30 MB).
 #ifndef MBAMD_PARSIMONY_H_
 #define MBAMD_PARSIMONY_H_
 
