@@ -3,6 +3,7 @@
 src/proposal.c -- test infrastructure: oracle/Makefile calls this for _ref/mb_amd_pars and _ref/mb_emu_pars.
 
     patch_pars.py <reference src/proposal.c> <output proposal.c>
+    patch_pars.py <reference src/model.c>    <output model.c>         (pattern compression, mbamd_compress_glue.h)
 
 The edits are located by the reference's own function names and comments (no reference text is stored here):
   * the glue header is included after proposal.c's last #include;
@@ -14,6 +15,7 @@ The edits are located by the reference's own function names and comments (no ref
     node-length moves get the per-pattern loop of a marked node wrapped in `if (MbamdParsMarkedLength ...)`.
 The output is written outside the repository (the Makefile passes a path under $(OBJ), /tmp by default).
 """
+import os
 import re
 import sys
 
@@ -88,8 +90,43 @@ def patch(src: str) -> str:
     return "\n".join(lines)
 
 
+COMPRESS_BEGIN = "/* is it unique? */"
+COMPRESS_END = "/* if subject to data augmentation, it is always unique */"
+
+
+def patch_model(src: str) -> str:
+    """src/model.c, CompressData: the O(columns^2) search for an identical kept column becomes a hash-table lookup
+    (integration/mrbayes/mbamd_compress_glue.h); the reference's search is kept for the switched-off and the check mode."""
+    lines = src.split("\n")
+    last_inc = max(i for i, l in enumerate(lines[:200]) if l.startswith("#include"))
+    lines.insert(last_inc + 1, '#include "mbamd_compress_glue.h"')
+    start = next(i for i, l in enumerate(lines) if re.match(r"^int CompressData \(", l))
+    b = next(i for i in range(start, len(lines)) if COMPRESS_BEGIN in lines[i])
+    e = next(i for i in range(b, len(lines)) if COMPRESS_END in lines[i])
+    orig = lines[b + 1:e]
+    assert any("isSame = NO;" in l for l in orig[:3]) and any("isSame = YES;" in l for l in orig), "CompressData does not look as expected"
+    new = (["            if (mp->dataType != CONTINUOUS && MbamdCompressActive () == YES)",
+            "                {",
+            "                int mbamdSame, mbamdWhere;",
+            "                mbamdSame = MbamdFindSamePattern (tempMatrix, numLocalChar, numLocalTaxa, m->nCharsPerSite, m->compMatrixStart, newColumn, &mbamdWhere);",
+            "                if (MbamdCompressCheckWanted () == YES)",
+            "                    {"]
+           + orig
+           + ["                    MbamdCompressCompare (isSame, i, mbamdSame, mbamdWhere);",
+              "                    }",
+              "                isSame = mbamdSame;",
+              "                i = mbamdWhere;",
+              "                }",
+              "            else",
+              "                {"]
+           + orig
+           + ["                }"])
+    return "\n".join(lines[:b + 1] + new + lines[e:])
+
+
 if __name__ == "__main__":
     with open(sys.argv[1]) as f:
-        out = patch(f.read())
+        text = f.read()
+    out = patch_model(text) if os.path.basename(sys.argv[1]) == "model.c" else patch(text)
     with open(sys.argv[2], "w") as f:
         f.write(out)

@@ -441,3 +441,35 @@ def test_double_precision_on_mi355x():
     _check_double_precision(refrun.REF_MB_AMD, "mbamd HIP gfx950")
     if os.path.exists(refrun.REF_MB_AMD_V3):
         _check_double_precision(refrun.REF_MB_AMD_V3, "mbamd HIP gfx950")
+
+
+# ---- pattern compression (second half): CompressData's O(columns^2) search as a hash-table lookup ------
+def test_pattern_compression_binding():
+    """integration/mrbayes/mbamd_compress_glue.c inside the patched binary: the same site patterns, the same counts, the
+    same log-likelihood as the reference's own search -- which runs beside it under MBAMD_COMPRESS_CHECK=1 and must agree on
+    every column (the binding exits non-zero otherwise)."""
+    if not os.path.isdir("/root/reference/src"):
+        pytest.skip("reference sources not present (build container only)")
+    from tests.hostemu import build_emu
+    build_emu.build()
+    subprocess.check_call(["make", "-C", os.path.join(ROOT, "oracle"), "_ref/mb_emu", "_ref/mb_emu_pars"], stdout=subprocess.DEVNULL)
+    st, tr = _case(20, 300, 0.03)
+    st = np.concatenate([st, st[:, ::3], st[:, 5:200]], axis=1)               # every pattern several times, out of order
+    nex = refrun.known_answer_nexus(st, tr, REVMAT, PI, ALPHA, beagle="dynamic")
+    plain, _ = refrun.run_mb(refrun.REF_MB_EMU, nex)
+    checked, _ = refrun.run_mb(refrun.REF_MB_EMU_PARS, nex, env={"MBAMD_COMPRESS_CHECK": "1"})
+    hashed, _ = refrun.run_mb(refrun.REF_MB_EMU_PARS, nex)
+    off, _ = refrun.run_mb(refrun.REF_MB_EMU_PARS, nex, env={"MBAMD_HASH_COMPRESS": "0"})
+    m = re.search(r"mbamd compression check: (\d+) columns, the reference's search agreed on all of them", checked)
+    assert m and int(m.group(1)) >= st.shape[1], checked[-1500:]
+    pat = [re.findall(r"Division 1 has (\d+) unique site patterns", o) for o in (plain, checked, hashed, off)]
+    assert pat[0] and all(p == pat[0] for p in pat) and int(pat[0][0]) < st.shape[1] // 2, pat
+    lnl = [refrun.initial_lnl(o) for o in (plain, checked, hashed, off)]
+    assert all(v == lnl[0] for v in lnl), lnl
+    # a codon-width case exercises nCharsPerSite > 1
+    stc, trc = _general_case("m3", 10, 60)
+    nexc = refrun.model_nexus("m3", np.concatenate([stc, stc[:, :25]], axis=1), trc, ngen=1, beagle="dynamic")
+    a, _ = refrun.run_mb(refrun.REF_MB_EMU, nexc)
+    b, _ = refrun.run_mb(refrun.REF_MB_EMU_PARS, nexc, env={"MBAMD_COMPRESS_CHECK": "1"})
+    assert "agreed on all of them" in b and refrun.initial_lnl(a) == refrun.initial_lnl(b)
+    assert re.findall(r"has (\d+) unique site patterns", a) == re.findall(r"has (\d+) unique site patterns", b)
