@@ -1,7 +1,7 @@
 """Soak test: long default-move MCMC runs of the unmodified MrBayes binary on the engine (topology moves ->
 ever-changing operation lists, plan-cache churn, accept/reject buffer flips, dynamic rescaling), checked for
 completion and for a final lnL close to what the native kernels reach from the same seed.
-usage: soak_mcmc.py gtr|wag|m3 ntaxa nsites ngen nchains"""
+usage: [MB_BINARY=...] soak_mcmc.py gtr|wag|m3 ntaxa nsites ngen nchains"""
 import os, sys, re
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
 from mrbayes_amd import data as mbdata, tree as mbtree
@@ -15,7 +15,8 @@ if kind == "gtr":
     nex = refrun.mcmc_nexus(st, tr, ngen, beagle="dynamic", nchains=nchains)
 else:
     nex = refrun.model_nexus(kind, st, tr, ngen=ngen, beagle="dynamic").replace("nchains=1", "nchains=%d" % nchains)
-out, wall = refrun.run_mb(refrun.REF_MB_AMD, nex, timeout=3000, env={"MBAMD_STATS": "1"})
+binary = os.environ.get("MB_BINARY", refrun.REF_MB_AMD)            # e.g. oracle/_ref/mb_amd_pars: with the device-parsimony binding
+out, wall = refrun.run_mb(binary, nex, timeout=3000, env={"MBAMD_STATS": "1"})
 ok = "Analysis completed" in out
 last = [l for l in out.splitlines() if re.match(r"\s+%d -- " % ngen, l)]
 print("completed" if ok else "FAILED", "wall %.1f s" % wall)
