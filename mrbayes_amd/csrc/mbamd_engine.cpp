@@ -135,6 +135,7 @@ struct Plan {
     size_t cap = 0;                  // bytes allocated for d_table
     struct Segment { size_t first; int W, entries, nslots; };   // tree-walk path: one launch per hazard-free segment
     std::vector<Segment> segments;               // (Walk4Entry index of its program in d_table, geometry)
+    std::vector<Walk4Entry> inlineProg;          // 4-state walk: a short single-segment program travels in the kernel arguments instead
     int lists = 1;                               // 20/61-state walk: > 1 = the segments are that many independent lists, ONE launch
     std::vector<int> start;                      // general path: first table entry of each dependency level
     bool anyScale = false;
@@ -396,6 +397,7 @@ struct Instance {
     std::vector<char> pendingMatrixOut;          // matrix buffers the queued jobs write
     int submit(Plan* plan, int cumIdx, int32_t* cumPtr);
     bool noDefer = false;            // MBAMD_NO_DEFER: run every list at once
+    bool noInlinePrograms = false;   // MBAMD_NO_INLINE_PROGRAMS: every walk program through a device buffer
     bool envVerbose = false, envTrace = false;   // MBAMD_VERBOSE, MBAMD_WALK_TRACE (read once)
     bool noSpine = false;            // MBAMD_NO_SPINE: serial launches use the plain (not software-pipelined) kernel
     int spineWidth = 1;              // MBAMD_SPINE_WIDTH: trailing levels of at most this many operations join the serial launch
@@ -487,6 +489,7 @@ int Instance::create(int tipCount_, int partialsBufferCount, int compactBufferCo
     if (mfma) SP = 32 * NT;          // transposed matrices padded to the MFMA tile height
     mfmaWhole = std::getenv("MBAMD_MFMA_WHOLE") != nullptr;
     noDefer = std::getenv("MBAMD_NO_DEFER") != nullptr;
+    noInlinePrograms = std::getenv("MBAMD_NO_INLINE_PROGRAMS") != nullptr;
     if (const char* e = std::getenv("MBAMD_MFMA_SERIAL")) serialRatio = std::max(0, std::atoi(e));
     noSpine = std::getenv("MBAMD_NO_SPINE") != nullptr;
     if (const char* e = std::getenv("MBAMD_SPINE_WIDTH")) spineWidth = std::max(1, std::atoi(e));
@@ -629,7 +632,8 @@ int Instance::configureWalk()
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0) numCU = prop.multiProcessorCount;
     const int maxLds = 160 * 1024;
-    if (s4 && hipFuncSetAttribute((const void*) k_walk4, hipFuncAttributeMaxDynamicSharedMemorySize, maxLds) != hipSuccess)
+    if (s4 && (hipFuncSetAttribute((const void*) k_walk4_t<Walk4Args>, hipFuncAttributeMaxDynamicSharedMemorySize, maxLds) != hipSuccess ||
+               hipFuncSetAttribute((const void*) k_walk4_t<Walk4ArgsInline>, hipFuncAttributeMaxDynamicSharedMemorySize, maxLds) != hipSuccess))
         (void) hipGetLastError();
 #endif
     if (wg) {
@@ -1581,6 +1585,12 @@ int Instance::buildWalk(Plan& plan, const BeagleOperation* ops, int n, const int
     if (envVerbose)
         std::fprintf(stderr, "[mbamd] walk plan: %d ops, %zu segment(s), W=%d, %d entries/wave, %d slots/wave, %d phases, %d reloads, %d external children\n",
                      n, plan.segments.size(), lastWalkW, lastWalkEntries, lastWalkSlots, phases, reloads, externals);
+    // a short program of the 4-state walk goes out with the launch itself (k_walk4_t<Walk4ArgsInline>)
+    plan.inlineProg.clear();
+    if (!wg && !noInlinePrograms && plan.segments.size() == 1 && w4table.size() <= (size_t) MBAMD_W4_INLINE) {
+        plan.inlineProg = w4table;
+        return BEAGLE_SUCCESS;
+    }
     // upload the programs into the plan's device buffer
     const size_t bytes = w4table.size() * sizeof(Walk4Entry);
     const bool inFlight = plan.lastLaunch > syncedClock;
@@ -1616,7 +1626,17 @@ int Instance::runWalk(const Plan& plan, int32_t* cum)
         a.K = K;
         a.Ppad = Ppad;
         a.nblocks = Ppad / 64;
-        MBAMD_LAUNCH_BARRIER(k_walk4, walk4_grid(Ppad / 64, K), 64 * sg.W, walk4_lds_bytes(sg.W, sg.nslots), stream, a);
+        if (!plan.inlineProg.empty()) {
+            Walk4ArgsInline ai;
+            ai.a = a;
+            ai.a.prog = nullptr;
+            std::memcpy(ai.inl, plan.inlineProg.data(), plan.inlineProg.size() * sizeof(Walk4Entry));
+            auto kernel = k_walk4_t<Walk4ArgsInline>;
+            MBAMD_LAUNCH_BARRIER(kernel, walk4_grid(Ppad / 64, K), 64 * sg.W, walk4_lds_bytes(sg.W, sg.nslots), stream, ai);
+        } else {
+            auto kernel = k_walk4_t<Walk4Args>;
+            MBAMD_LAUNCH_BARRIER(kernel, walk4_grid(Ppad / 64, K), 64 * sg.W, walk4_lds_bytes(sg.W, sg.nslots), stream, a);
+        }
         HIP_TRY(hipGetLastError());
         pendingLaunches += 1;
     }

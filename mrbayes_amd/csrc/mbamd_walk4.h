@@ -226,10 +226,33 @@ template <class T> __device__ __forceinline__ T* walk4_at(T* base, unsigned byte
     return reinterpret_cast<T*>(reinterpret_cast<uintptr_t>(base) + byteOffset);
 }
 
-// blockDim.x = 64 * W; grid = walk4_grid(nblocks, K) workgroups.  Dynamic LDS: walk4_lds_bytes(W, nslots).
-__global__ void __launch_bounds__(64 * MBAMD_W4_MAXW)
-k_walk4(Walk4Args A)
+// A short program (a root-ward path: the partial update of an MCMC generation) travels in the kernel arguments instead of
+// a device buffer: no copy kernel in front of the walk, nothing to keep alive until the launch has run.
+#define MBAMD_W4_INLINE 96       // entries (3 KiB of the 4 KiB argument block)
+struct Walk4ArgsInline {
+    Walk4Args a;
+    Walk4Entry inl[MBAMD_W4_INLINE];
+};
+__device__ __forceinline__ const Walk4Args& walk4_args(const Walk4Args& a) { return a; }
+__device__ __forceinline__ const Walk4Args& walk4_args(const Walk4ArgsInline& a) { return a.a; }
+__device__ __forceinline__ const Walk4Entry* walk4_program(const Walk4Args& a) { return a.prog; }
+#if defined(MBAMD_HOST_EMU)
+__device__ __forceinline__ const Walk4Entry* walk4_program(const Walk4ArgsInline& a) { return a.inl; }
+#else
+// (the address of a by-value kernel parameter would be that of a private copy: read the argument block itself)
+__device__ __forceinline__ const Walk4Entry* walk4_program(const Walk4ArgsInline&)
 {
+    return reinterpret_cast<const Walk4Entry*>((uintptr_t) __builtin_amdgcn_kernarg_segment_ptr() + offsetof(Walk4ArgsInline, inl));
+}
+#endif
+
+// blockDim.x = 64 * W; grid = walk4_grid(nblocks, K) workgroups.  Dynamic LDS: walk4_lds_bytes(W, nslots).
+// ARGS = Walk4Args (program in a device buffer) or Walk4ArgsInline (program in the arguments).
+template <class ARGS>
+__global__ void __launch_bounds__(64 * MBAMD_W4_MAXW)
+k_walk4_t(ARGS AA)
+{
+    const Walk4Args& A = walk4_args(AA);
     const unsigned lane = threadIdx.x & 63;
 #if defined(MBAMD_HOST_EMU)
     const int wave = (int) (threadIdx.x >> 6);
@@ -263,7 +286,7 @@ k_walk4(Walk4Args A)
 #define MBAMD_W4_EXPS(OFF, PARITY) walk4_dma_exps(walk4_at(E0, OFF), lane, stage_lds + 256u * (PARITY))
 #endif
 
-    const Walk4Entry* prog = A.prog + (size_t) wave * A.entries;
+    const Walk4Entry* prog = walk4_program(AA) + (size_t) wave * A.entries;
     const int n = A.entries - 2;
     Walk4Entry DA = walk4_load_entry(prog), DB = walk4_load_entry(prog + 1);
     // inputs of entry 0

@@ -134,6 +134,30 @@ def test_walk_schedule(emu, oracle, monkeypatch, waves, slots, prefetch):
     assert abs(got - want) / abs(want) < ec.REL_FP64
 
 
+def test_short_walk_programs_travel_in_the_kernel_arguments(emu, monkeypatch):
+    """Partial updates (root-ward paths) compile into programs of a few dozen entries: they are handed to the kernel in its
+    arguments (k_walk4_t<Walk4ArgsInline>) instead of a device buffer -- same bits either way."""
+    div = synthetic_division("gtr", 60, 200, seed=71, tree_seed=72, p_gap=0.04)
+
+    def path_values():
+        bd = lk.BeagleDivision(div, emu, scaling=lk.MB_BEAGLE_SCALE_DYNAMIC)
+        vals = [bd.LogLike(0)]
+        bd.AcceptMove(0)
+        for node in (3, 17, 44, 70):
+            div.tree.length[node] *= 1.7
+            bd.TouchBranch(0, node)
+            vals.append(bd.LogLike(0))
+            bd.AcceptMove(0)
+        for node in (3, 17, 44, 70):
+            div.tree.length[node] /= 1.7
+        bd.finalize()
+        return vals
+
+    base = path_values()
+    monkeypatch.setenv("MBAMD_NO_INLINE_PROGRAMS", "1")
+    assert path_values() == base
+
+
 @pytest.mark.parametrize("kind", ["gtr", "wag", "m3"])
 def test_device_eigen(emu, kind):
     ec.check_device_eigen(emu, kind)
