@@ -19,3 +19,4 @@ import statistics
 print("walk launches",len(d),"median us",statistics.median(d)/1e3,"mean",sum(d)/len(d)/1e3, "p10",d[len(d)//10]/1e3,"p90",d[9*len(d)//10]/1e3)
 PY2
 grep "walk plan" /tmp/mc.log | awk "{print \$4, \$6, \$7}" | sort | uniq -c | sort -rn | head -12
+python tools/rocpd_timeline.py $(find /tmp/prof_mc -name "*.db" | head -1) 24
