@@ -2,7 +2,9 @@
  * pars_oracle.c -- TEST INFRASTRUCTURE ONLY (see mb_oracle.h): plain-C restatement of the reference's Fitch-parsimony
  * routines on `BitsLong` state sets, the checker of the device scorer (include/libhmsbeagle/mbamd_parsimony.h).
  *
- * Parity status: PINNED -- (1) tests/test_mrbayes_dropin.py runs the reference binary with the device binding
+ * Parity status: PINNED -- (0) golden vectors from the reference's own parsimony-model likelihood (Likelihood_Pars,
+ * src/likelihood.c:7593-7700; tests/golden/parsmodel.json written by tools/gen_golden_pars.py from oracle/_ref/mb with
+ * `lset parsmodel=yes`): tests/test_oracle_golden.py; (1) tests/test_mrbayes_dropin.py runs the reference binary with the device binding
  * (oracle/_ref/mb_emu_pars / mb_amd_pars, integration/mrbayes/mbamd_pars_glue.c) under MBAMD_PARS_CHECK=1, where every
  * GetParsDP / GetParsFP / candidate loop is ALSO executed by the reference's own host functions and the sets and lengths
  * are compared word for word inside the process; (2) the same binary must reproduce the unpatched binary's MCMC

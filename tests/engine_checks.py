@@ -658,3 +658,29 @@ def check_double_precision(lib, golden_dir, case):
         finally:
             bd.finalize()
     assert abs(vals[0] - vals[1]) <= 1e-11 * abs(vals[0]), vals
+
+
+def check_parsimony_model_golden(lib, golden_dir):
+    """The device Fitch down-pass against the reference's OWN parsimony-model likelihood (Likelihood_Pars,
+    src/likelihood.c:7593-7700; golden values written by tools/gen_golden_pars.py from oracle/_ref/mb with `lset parsmodel=yes`):
+    lnL = -(tree length + number of characters) ln(number of states), to the printed digits."""
+    from mrbayes_amd import data as mbdata
+    from mrbayes_amd import parsimony as mp
+    with open(os.path.join(golden_dir, "parsmodel.json")) as fh:
+        cases = json.load(fh)["cases"]
+    assert len(cases) >= 3
+    for case in cases:
+        st = mbdata.synthetic_states(case["ntaxa"], case["nsites"], case["nstates"], case["seed"], 0.15, case["p_gap"])
+        tr = mbtree.random_tree(case["ntaxa"], case["tree_seed"], brlen=0.05)
+        inst = mp.ParsimonyInstance(tr.n_nodes, st.shape[1], case["nstates"], lib=lib)
+        try:
+            sets = mp.tip_sets(st, case["nstates"])
+            for i in range(st.shape[0]):
+                inst.set_sets(i, sets[i])
+            inst.set_pattern_weights(np.ones(st.shape[1], dtype=np.float32))
+            length = mp.GetParsimonyLength(inst, tr)
+            assert length == int(length)
+            lnl = -(length + st.shape[1]) * math.log(case["nstates"])
+            assert abs(lnl - case["lnL_reference"]) <= 1e-6, (case["name"], lnl, case["lnL_reference"])
+        finally:
+            inst.finalize()

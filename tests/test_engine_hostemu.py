@@ -241,3 +241,8 @@ def test_parsimony(emu, ntaxa, npat, nstates, words):
 def test_double_precision(emu, golden_dir, case):
     """BEAGLE_FLAG_PRECISION_DOUBLE: the fp64 engine (mbamd_f64.h) against the reference's double build."""
     ec.check_double_precision(emu, golden_dir, case)
+
+
+def test_parsimony_model_golden(emu, golden_dir):
+    """device Fitch lengths == the reference's own parsimony-model likelihood (golden vectors from oracle/_ref/mb)"""
+    ec.check_parsimony_model_golden(emu, golden_dir)

@@ -44,3 +44,27 @@ def test_oracle_big_dna(oracle, golden_dir):
     lnl = oracle.tree_loglike(div)
     assert abs(lnl - g["lnL"]["fp64"]) / abs(g["lnL"]["fp64"]) < 2e-6
     assert abs(lnl - g["lnL"]["fma"]) / abs(g["lnL"]["fma"]) < 1e-5
+
+
+def test_parsimony_oracle_against_the_reference_parsimony_model(golden_dir):
+    """oracle/pars_oracle.c (GetFitchPartials restated) against golden values from the reference's own Likelihood_Pars
+    (tests/golden/parsmodel.json, written by tools/gen_golden_pars.py from oracle/_ref/mb with `lset parsmodel=yes`):
+    lnL = -(tree length + number of characters) ln 4, to the printed digits."""
+    import math
+    import numpy as np
+    from mrbayes_amd import data as mbdata
+    from mrbayes_amd import parsimony as mp
+    from mrbayes_amd import tree as mbtree
+    from tests import oracle_lib as ol
+    with open(os.path.join(golden_dir, "parsmodel.json")) as fh:
+        cases = json.load(fh)["cases"]
+    for case in cases:
+        st = mbdata.synthetic_states(case["ntaxa"], case["nsites"], case["nstates"], case["seed"], 0.15, case["p_gap"])
+        tr = mbtree.random_tree(case["ntaxa"], case["tree_seed"], brlen=0.05)
+        sets = np.zeros((tr.n_nodes, st.shape[1]), dtype=np.uint64)
+        sets[:st.shape[0]] = mp.tip_sets(st, case["nstates"])
+        w = np.ones(st.shape[1], dtype=np.float32)
+        total, _ = ol.pars_down(sets, mp.down_pass_ops(tr, tr.root_left), w)
+        total += ol.pars_score(sets, [[tr.root_left, -1, tr.root, -1]], w)[0]          # the branch to the calculation root
+        lnl = -(total + st.shape[1]) * math.log(case["nstates"])
+        assert abs(lnl - case["lnL_reference"]) <= 1e-6, (case["name"], lnl, case["lnL_reference"])
