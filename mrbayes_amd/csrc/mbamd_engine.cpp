@@ -114,7 +114,8 @@ template <int SC_, int WMAX_, int CH_, int DEPTH_>
 static void raise_walkg_lds(int maxLds)
 {
 #if !defined(MBAMD_HOST_EMU)
-    if (hipFuncSetAttribute((const void*) k_walkg<SC_, WMAX_, CH_, DEPTH_>, hipFuncAttributeMaxDynamicSharedMemorySize, maxLds) != hipSuccess)
+    if (hipFuncSetAttribute((const void*) k_walkg<SC_, WMAX_, CH_, DEPTH_>, hipFuncAttributeMaxDynamicSharedMemorySize, maxLds) != hipSuccess ||
+        hipFuncSetAttribute((const void*) k_walkg<SC_, WMAX_, CH_, DEPTH_, WalkGArgsInline>, hipFuncAttributeMaxDynamicSharedMemorySize, maxLds) != hipSuccess)
         (void) hipGetLastError();
 #else
     (void) maxLds;
@@ -1585,9 +1586,9 @@ int Instance::buildWalk(Plan& plan, const BeagleOperation* ops, int n, const int
     if (envVerbose)
         std::fprintf(stderr, "[mbamd] walk plan: %d ops, %zu segment(s), W=%d, %d entries/wave, %d slots/wave, %d phases, %d reloads, %d external children\n",
                      n, plan.segments.size(), lastWalkW, lastWalkEntries, lastWalkSlots, phases, reloads, externals);
-    // a short program of the 4-state walk goes out with the launch itself (k_walk4_t<Walk4ArgsInline>)
+    // a short program goes out with the launch itself (k_walk4_t<Walk4ArgsInline>, k_walkg<..., WalkGArgsInline>)
     plan.inlineProg.clear();
-    if (!wg && !noInlinePrograms && plan.segments.size() == 1 && w4table.size() <= (size_t) MBAMD_W4_INLINE) {
+    if (!noInlinePrograms && plan.segments.size() == 1 && w4table.size() <= (size_t) MBAMD_W4_INLINE) {
         plan.inlineProg = w4table;
         return BEAGLE_SUCCESS;
     }
@@ -1827,6 +1828,8 @@ int Instance::flushWalkG()
                     for (Plan::Segment& sg : plan->segments) sg.nslots = ns;
                     plan->lists = nl;
                     done = true;
+                    // (several independent lists = several segments, one launch: short enough, they travel in its arguments too)
+                    if (!noInlinePrograms && w4table.size() <= (size_t) MBAMD_W4_INLINE) plan->inlineProg = w4table;
                 }
             }
             if (!done) rc = buildWalk(*plan, ops.data(), n, listOf.data(), false);
@@ -1841,8 +1844,17 @@ int Instance::flushWalkG()
 }
 
 template <int SC_, int WMAX_, int CH_, int DEPTH_>
-static void launch_walkg_t(Instance& in, const WalkGArgs& a, int W, int nslots)
+static void launch_walkg_t(Instance& in, const WalkGArgs& a, int W, int nslots, const std::vector<Walk4Entry>* inlineProg)
 {
+    if (inlineProg && !inlineProg->empty()) {
+        WalkGArgsInline ai;
+        ai.a = a;
+        ai.a.prog = nullptr;
+        std::memcpy(ai.inl, inlineProg->data(), inlineProg->size() * sizeof(Walk4Entry));
+        auto kern = k_walkg<SC_, WMAX_, CH_, DEPTH_, WalkGArgsInline>;
+        MBAMD_LAUNCH_BARRIER(kern, walkg_grid(in.Ppad / 32, in.K * a.lists), 64 * W * (a.spread ? 2 : 1), wg_lds_bytes(W, nslots, in.S), in.stream, ai);
+        return;
+    }
     auto kern = k_walkg<SC_, WMAX_, CH_, DEPTH_>;
     MBAMD_LAUNCH_BARRIER(kern, walkg_grid(in.Ppad / 32, in.K * a.lists), 64 * W * (a.spread ? 2 : 1), wg_lds_bytes(W, nslots, in.S), in.stream, a);
 }
@@ -1880,7 +1892,7 @@ int Instance::runWalkG(const Plan& plan)
             a.trace = sg.entries <= 4096 ? d_trace : nullptr;
             lastWalkSteps = sg.entries - MBAMD_WG_TAIL; walkWaves = sg.W - 1;
         }
-        MBAMD_WG_DISPATCH(S, launch_walkg_t, *this, a, sg.W, sg.nslots);
+        MBAMD_WG_DISPATCH(S, launch_walkg_t, *this, a, sg.W, sg.nslots, &plan.inlineProg);
         HIP_TRY(hipGetLastError());
         pendingLaunches += 1;
     }

@@ -114,6 +114,23 @@ struct WalkGArgs {
 };
 __host__ __device__ inline unsigned walkg_grid(int ntiles, int KL) { return 8u * (unsigned) KL * (unsigned) ((ntiles + 7) / 8); }   // KL = categories x lists
 
+// a short program (a partial update) in the kernel arguments instead of a device buffer, as in mbamd_walk4.h
+struct WalkGArgsInline {
+    WalkGArgs a;
+    Walk4Entry inl[MBAMD_W4_INLINE];
+};
+__device__ __forceinline__ const WalkGArgs& wg_args(const WalkGArgs& a) { return a; }
+__device__ __forceinline__ const WalkGArgs& wg_args(const WalkGArgsInline& a) { return a.a; }
+__device__ __forceinline__ const Walk4Entry* wg_program(const WalkGArgs& a) { return a.prog; }
+#if defined(MBAMD_HOST_EMU)
+__device__ __forceinline__ const Walk4Entry* wg_program(const WalkGArgsInline& a) { return a.inl; }
+#else
+__device__ __forceinline__ const Walk4Entry* wg_program(const WalkGArgsInline&)
+{
+    return reinterpret_cast<const Walk4Entry*>((uintptr_t) __builtin_amdgcn_kernarg_segment_ptr() + offsetof(WalkGArgsInline, inl));
+}
+#endif
+
 #if defined(MBAMD_HOST_EMU)
 #include "mbamd_walkg_emu.h"     // tests/hostemu/ (test build only): a plain-loop twin of k_walkg for CPU CI of the host logic
 #else
@@ -148,10 +165,11 @@ template <int I> struct WgInt { static constexpr int value = I; };
 //   20 states: CH 1, DEPTH 2 -- a job is 10 MFMAs = 640 cycles, less than a memory round trip; three sets of 15 registers;
 //   61 states: CH 2, DEPTH 1 -- a chunk is 31 MFMAs = 2000 cycles; two sets of 48 registers fit beside the 64 accumulators
 //              (whole jobs did not: the allocator shuttled LOADED operands through AccVGPRs, a vmcnt(0) per job).
-template <int SC, int WMAX, int CH, int DEPTH>
+template <int SC, int WMAX, int CH, int DEPTH, class ARGS = WalkGArgs>
 __global__ void __launch_bounds__(64 * WMAX)
-k_walkg(WalkGArgs A)
+k_walkg(ARGS AA)
 {
+    const WalkGArgs& A = wg_args(AA);
     typedef WgShape<SC> Sh;
     typedef typename Sh::vec vec;
     typedef WgOperands<SC, CH> Ops;
@@ -184,7 +202,7 @@ k_walkg(WalkGArgs A)
     int8_t* const E0 = A.exps + (size_t) (tile >> 1) * A.estride + (size_t) k * 64 + (tile & 1u) * 32u;
     const char* const Mk = reinterpret_cast<const char*>(A.matrices) + A.tabOff + (size_t) k * A.tabBytes;
 
-    const Walk4Entry* prog = A.prog + ((size_t) list * W + wave) * A.entries;
+    const Walk4Entry* prog = wg_program(AA) + ((size_t) list * W + wave) * A.entries;
     const int n = A.entries - MBAMD_WG_TAIL;
 #if defined(MBAMD_WGX_STAGGER)
     // Waves of different tiles run the SAME program: left alone they march in lockstep -- all waves of a SIMD in their MFMA

@@ -7,9 +7,10 @@
 #define MBAMD_WALKG_EMU_H_
 // ---- host-emulation twin (CPU CI of the host logic: arenas, programs, slots, phases): lane 0 of every wave walks the
 // program with plain loops over the 32 patterns; children come from the emulated LDS slots exactly as scheduled
-template <int SC, int WMAX, int CH, int DEPTH>
-__global__ void k_walkg(WalkGArgs A)
+template <int SC, int WMAX, int CH, int DEPTH, class ARGS = WalkGArgs>
+__global__ void k_walkg(ARGS AA)
 {
+    const WalkGArgs& A = wg_args(AA);
     const unsigned lane = threadIdx.x & 63;
     const int wave = (int) (threadIdx.x >> 6), W = (int) (blockDim.x >> 6);
     const int S = A.S, SP = A.SP, TP = wg_pairs_padded(S);
@@ -24,7 +25,7 @@ __global__ void k_walkg(WalkGArgs A)
     char* const P0 = reinterpret_cast<char*>(A.partials) + (size_t) tile * A.tileBytes + (size_t) k * SLOTB;
     const uint8_t* const T0 = A.tips + (size_t) tile * A.tipTileBytes;
     int8_t* const E0 = A.exps + (size_t) (tile >> 1) * A.estride + (size_t) k * 64 + (tile & 1u) * 32u;
-    const Walk4Entry* prog = A.prog + ((size_t) list * W + wave) * A.entries;
+    const Walk4Entry* prog = wg_program(AA) + ((size_t) list * W + wave) * A.entries;
     int cum_e[MBAMD_WG_MAXLISTS][32];
     for (auto& row : cum_e) for (int& v : row) v = 0;
     for (int j = 0; j < A.entries; ++j) {

@@ -382,7 +382,7 @@ def test_general_state_tree_walk_schedules_agree(gpu, golden_dir, monkeypatch, c
     div = division_from_golden(golden_dir, case)
     a, sa = _lnl_and_sites(gpu, div)
     for env in ({"MBAMD_WALK_WAVES": "1"}, {"MBAMD_WALK_WAVES": "4"}, {"MBAMD_WALK_WAVES": "2", "MBAMD_MAX_LDS_SLOTS": "3"},
-                {"MBAMD_NO_DEFER": "1"}):
+                {"MBAMD_NO_DEFER": "1"}, {"MBAMD_NO_INLINE_PROGRAMS": "1"}):
         for k, v in env.items():
             monkeypatch.setenv(k, v)
         b, sb = _lnl_and_sites(gpu, div)
@@ -513,3 +513,29 @@ def test_double_precision(gpu, golden_dir, case):
 def test_parsimony_model_golden(gpu, golden_dir):
     """device Fitch lengths == the reference's own parsimony-model likelihood (golden vectors from oracle/_ref/mb)"""
     ec.check_parsimony_model_golden(gpu, golden_dir)
+
+
+@pytest.mark.parametrize("kind,ntaxa,npat", [("gtr", 120, 700), ("wag", 60, 300), ("m3", 30, 120)])
+def test_short_walk_programs_travel_in_the_kernel_arguments(gpu, monkeypatch, golden_dir, kind, ntaxa, npat):
+    """Partial updates (root-ward paths) compile into programs of a few dozen entries: they are handed to the kernel in its
+    arguments (k_walk4_t<Walk4ArgsInline>, k_walkg<..., WalkGArgsInline>) instead of a device buffer -- same bits either way."""
+    div = synthetic_division(kind, ntaxa, npat, seed=71, tree_seed=72, p_gap=0.04, golden_dir=golden_dir)
+
+    def path_values():
+        bd = lk.BeagleDivision(div, gpu, scaling=lk.MB_BEAGLE_SCALE_DYNAMIC)
+        vals = [bd.LogLike(0)]
+        bd.AcceptMove(0)
+        nodes = [n for n in (3, 7, 17, 44, 70) if n < div.tree.n_nodes and div.tree.anc[n] >= 0]
+        for node in nodes:
+            div.tree.length[node] *= 1.7
+            bd.TouchBranch(0, node)
+            vals.append(bd.LogLike(0))
+            bd.AcceptMove(0)
+        for node in nodes:
+            div.tree.length[node] /= 1.7
+        bd.finalize()
+        return vals
+
+    base = path_values()
+    monkeypatch.setenv("MBAMD_NO_INLINE_PROGRAMS", "1")
+    assert path_values() == base

@@ -134,21 +134,23 @@ def test_walk_schedule(emu, oracle, monkeypatch, waves, slots, prefetch):
     assert abs(got - want) / abs(want) < ec.REL_FP64
 
 
-def test_short_walk_programs_travel_in_the_kernel_arguments(emu, monkeypatch):
+@pytest.mark.parametrize("kind,ntaxa,npat", [("gtr", 60, 200), ("wag", 30, 70), ("m3", 16, 40)])
+def test_short_walk_programs_travel_in_the_kernel_arguments(emu, monkeypatch, golden_dir, kind, ntaxa, npat):
     """Partial updates (root-ward paths) compile into programs of a few dozen entries: they are handed to the kernel in its
-    arguments (k_walk4_t<Walk4ArgsInline>) instead of a device buffer -- same bits either way."""
-    div = synthetic_division("gtr", 60, 200, seed=71, tree_seed=72, p_gap=0.04)
+    arguments (k_walk4_t<Walk4ArgsInline>, k_walkg<..., WalkGArgsInline>) instead of a device buffer -- same bits either way."""
+    div = synthetic_division(kind, ntaxa, npat, seed=71, tree_seed=72, p_gap=0.04, golden_dir=golden_dir)
 
     def path_values():
         bd = lk.BeagleDivision(div, emu, scaling=lk.MB_BEAGLE_SCALE_DYNAMIC)
         vals = [bd.LogLike(0)]
         bd.AcceptMove(0)
-        for node in (3, 17, 44, 70):
+        nodes = [n for n in (3, 7, 17, 44, 70) if n < div.tree.n_nodes and div.tree.anc[n] >= 0]
+        for node in nodes:
             div.tree.length[node] *= 1.7
             bd.TouchBranch(0, node)
             vals.append(bd.LogLike(0))
             bd.AcceptMove(0)
-        for node in (3, 17, 44, 70):
+        for node in nodes:
             div.tree.length[node] /= 1.7
         bd.finalize()
         return vals
