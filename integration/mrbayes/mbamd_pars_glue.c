@@ -24,6 +24,7 @@
 extern int *chainId;
 
 static int      *parsHandle = NULL;        /* per division: device instance or -1 */
+static BitsLong ***parsOwner = NULL;       /* per division: the m->parsSets array the mirror was filled from */
 static int      nHandles = 0;
 static int      *opBuf = NULL;
 static int      opCap = 0;
@@ -80,16 +81,26 @@ static int Handle (int division)
     if (division >= nHandles)
         {
         parsHandle = (int *) realloc (parsHandle, (size_t) (division + 1) * sizeof(int));
-        if (!parsHandle)
+        parsOwner = (BitsLong ***) realloc (parsOwner, (size_t) (division + 1) * sizeof(BitsLong **));
+        if (!parsHandle || !parsOwner)
             Die ("out of memory");
         for (i=nHandles; i<=division; i++)
+            {
             parsHandle[i] = -1;
+            parsOwner[i] = NULL;
+            }
         if (nHandles == 0)
             atexit (ReportCheck);
         nHandles = division + 1;
         }
-    if (parsHandle[division] >= 0)
+    if (parsHandle[division] >= 0 && parsOwner[division] == m->parsSets)
         return parsHandle[division];
+    if (parsHandle[division] >= 0)
+        {
+        /* the host's sets were re-allocated (another analysis in the same session): the mirror is of no use any more */
+        mbamdParsFinalizeInstance (parsHandle[division]);
+        parsHandle[division] = -1;
+        }
 
     bits = 64 * m->nParsIntsPerSite;
     if (m->nParsIntsPerSite == 1)
@@ -108,6 +119,7 @@ static int Handle (int division)
         if (mbamdParsSetSets (id, i, (const unsigned long long *) m->parsSets[i]) != BEAGLE_SUCCESS)
             Die ("mbamdParsSetSets failed");
     parsHandle[division] = id;
+    parsOwner[division] = m->parsSets;
     return id;
 }
 
