@@ -8,7 +8,8 @@ move dirties the whole tree (reference src/proposal.c:17682, src/mbbeagle.c:400-
 
 Default workload: BASELINE configs[3]'s shape, synthetic DNA 1000 taxa x 50 000 patterns GTR+G4 (the shape the
 >=100x target is quoted on; it fits one GPU), one chain per GPU.  At N=1 the line also carries, under "also", the
-same measurement on configs[1] (DNA 500 x 20 000) and, under "mcmc_gen_per_s", whole-MCMC generations/s of the
+same measurement on the other three workloads (configs[1] DNA 500 x 20 000, configs[2] protein 200 x 10 000 WAG+G4,
+configs[4]'s codon M3 100 x 5 000) and, under "mcmc_gen_per_s", whole-MCMC generations/s of the
 unmodified MrBayes binary on this engine next to its native CPU kernels (short windows; --no-also / --no-mcmc skip
 them).  Every workload is a committed golden case (tests/golden/bench_c*.json): alignment seeds, tree and parameters
 are those the REAL reference was run on by tools/gen_golden.py, and the lnL printed in "config" is asserted against
@@ -106,8 +107,9 @@ def mcmc_gen_per_s(gold, nchains=1, quick=True):
     out = {"workload": gold["case"], "nchains": nchains,
            "note": "default_moves: MrBayes' default proposal mix; 11.5% of its moves are ParsSPR1/ParsTBR1, whose O(taxa x "
                    "patterns) parsimony scoring runs on the host in the unmodified binary (`engine`, `reference_cpu`) and bounds "
-                   "its rate; `engine_device_parsimony` = the same sources plus the device-parsimony binding (SURVEY 8(f) item 4, "
-                   "integration/mrbayes/, same proposals and chain as the unmodified binary); "
+                   "its rate; `engine_device_parsimony` = a PATCHED binary: the same sources with src/proposal.c and src/model.c edited on "
+                   "the fly by oracle/patch_pars.py to call the device-parsimony binding (SURVEY 8(f) item 4, integration/mrbayes/; "
+                   "same proposals and chain as the unmodified binary); "
                    "fixed_topology = branch-length and substitution-parameter moves only (prset topologypr=fixed)"}
     windows = {(False, "engine"): (300, 1300) if quick else (500, 2500), (True, "engine"): (2000, 12000) if quick else (2000, 22000),
                (False, "reference_cpu"): (10, 40) if quick else (20, 80), (True, "reference_cpu"): (20, 70) if quick else (20, 120)}
@@ -187,6 +189,7 @@ def measure(args, cfg, steps, warmup, rank, local_rank, world, dist, device, emu
         step(i)
     bd.inst.kernel_timing(True)
     bd.inst.get_kernel_timing(reset=True)
+    bd.inst.get_step_timing(reset=True)
     fence()
     t0 = time.perf_counter()
     lnl = None
@@ -195,6 +198,7 @@ def measure(args, cfg, steps, warmup, rank, local_rank, world, dist, device, emu
     fence()
     dt = time.perf_counter() - t0
     kms, klaunches = bd.inst.get_kernel_timing(reset=True)
+    span_ms, spans = bd.inst.get_step_timing(reset=True)
     bd.inst.kernel_timing(False)
     if dist is not None:
         tmax = torch.tensor([dt], dtype=torch.float64, device=device)
@@ -207,38 +211,65 @@ def measure(args, cfg, steps, warmup, rank, local_rank, world, dist, device, emu
 
     ms_per_step = dt / steps * 1e3
     value = units_per_step * world * steps / dt / 1e6
-    k_ms = kms / max(steps, 1)                # the partials kernels (the dominant ones) per evaluation, HIP events on the engine's stream
+    k_ms = kms / max(steps, 1)                # the partials kernels per evaluation, HIP events on the engine's stream
+    # every kernel of a step (transition matrices, partials, integration) and the gaps between them, HIP events on the
+    # engine's stream; the host's wait is not in it (mbamdGetStepTiming)
+    all_ms = span_ms / spans if spans > 0 else ms_per_step
     abytes = algorithmic_bytes_per_eval(S, K, P, N)
     aflops = flops_per_eval(S, K, P, N)
-    if S == 61:
-        roof = {"bound": "mfma", "achieved": aflops / (k_ms * 1e-3) / 1e12, "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s"}
-    else:
-        roof = {"bound": "hbm", "achieved": abytes / (k_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s"}
-    roof["frac"] = roof["achieved"] / roof["peak"]
-    roof["definition"] = ("achieved = ALGORITHMIC %s per evaluation (SURVEY 8(d)) / time of the partials kernels only (transition-matrix "
-                          "and root-integration kernels excluded: a few us each, profiles/).  The kernels keep children in LDS, so the "
-                          "physical traffic is lower: see traffic / physical_*" % ("flops" if S == 61 else "bytes"))
-    roof["traffic"] = None                    # HBM bytes per evaluation from committed PMC passes of this workload, if any
+    pmc = None
     try:
         with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as fh:
             pmc = json.load(fh).get(cfg)
-        if pmc and not emulate:
-            roof["traffic"] = pmc["traffic_bytes"]
-            roof["traffic_source"] = pmc["source"]
-            roof["physical_achieved_GBs"] = pmc["traffic_bytes"] / (k_ms * 1e-3) / 1e9
-            roof["physical_frac"] = roof["physical_achieved_GBs"] / HBM_PEAK_GBS
-            if "mfma_issued_gflop" in pmc:        # matrix-core work actually issued (tip children are gathers, not MFMAs)
-                roof["mfma_issued_tflops"] = pmc["mfma_issued_gflop"] * 1e9 / (k_ms * 1e-3) / 1e12
-                roof["mfma_issued_frac"] = roof["mfma_issued_tflops"] / FP32_PEAK_TFLOPS
     except (OSError, ValueError):
         pass
+    if emulate:
+        pmc = None
+    # What the hardware actually has to do per evaluation: HBM bytes (PMC) and matrix-core flops ISSUED (PMC; a compact
+    # tip's factor is a table gather, not an MFMA).  Without a PMC pass of the workload: the write-once model (every
+    # interior result and its exponents stored once, children read from LDS) and no matrix-core figure.
+    if pmc:
+        traffic = float(pmc["traffic_bytes"])
+        issued = pmc.get("mfma_issued_gflop", 0.0) * 1e9
+    else:
+        traffic = float(P) * (N - 2) * (K * S * 4 + K)
+        issued = 0.0
+    t_hbm = traffic / (HBM_PEAK_GBS * 1e9)
+    t_mfma = issued / (FP32_PEAK_TFLOPS * 1e12)
+    t_all = all_ms * 1e-3
+    if t_mfma > t_hbm:
+        roof = {"bound": "mfma", "achieved": issued / t_all / 1e12, "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s"}
+    else:
+        roof = {"bound": "hbm", "achieved": traffic / t_all / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s"}
+    roof["frac"] = roof["achieved"] / roof["peak"]
+    roof["traffic"] = traffic if pmc else None
+    roof["definition"] = (
+        "frac = max(HBM bytes moved / 8 TB/s, matrix-core flops issued / 157.3 TFLOP/s) / device time of ALL kernels of one "
+        "evaluation (transition matrices + partials + integration, HIP events on the engine's stream: all_kernels_ms_per_step). "
+        "Bytes and issued flops per evaluation are PMC counts (rocprofv3 --pmc, profiles/pmc_traffic.json: deterministic for a "
+        "workload, taken in their own profiling runs and combined with THIS run's time).  algorithmic_*: SURVEY 8(d)'s model "
+        "(every interior CL written once AND read once) over the partials kernels' time -- the kernels keep children in LDS, so "
+        "that model over-counts HBM traffic about 1.9x; kept for comparison with earlier rounds only")
+    if pmc:
+        roof["traffic_source"] = pmc["source"]
+    else:
+        roof["traffic_model_bytes"] = traffic
+    roof["hbm_GBs"] = traffic / t_all / 1e9
+    roof["hbm_frac"] = t_hbm / t_all
+    if issued > 0:
+        roof["mfma_issued_tflops"] = issued / t_all / 1e12
+        roof["mfma_issued_frac"] = t_mfma / t_all
     roof["kernel"] = impl
-    roof["kernel_ms_per_step"] = k_ms
+    roof["all_kernels_ms_per_step"] = all_ms
+    roof["partials_kernel_ms_per_step"] = k_ms
+    roof["partials_kernel_frac"] = max(t_hbm, t_mfma) / (k_ms * 1e-3) if k_ms > 0 else None
     roof["launches_per_step"] = klaunches / max(steps, 1)
     roof["algorithmic_bytes_per_step"] = abytes
     roof["flops_per_step"] = aflops
-    if S == 20:
-        roof["secondary_tflops"] = aflops / (k_ms * 1e-3) / 1e12
+    if k_ms > 0:
+        roof["algorithmic_GBs"] = abytes / (k_ms * 1e-3) / 1e9
+        roof["algorithmic_tflops"] = aflops / (k_ms * 1e-3) / 1e12
+        roof["algorithmic_frac"] = (roof["algorithmic_tflops"] / FP32_PEAK_TFLOPS) if S == 61 else (roof["algorithmic_GBs"] / HBM_PEAK_GBS)
     out = {
         "metric": "site-pattern lnL (node-pattern conditional-likelihood) updates/sec",
         "value": value, "unit": "M updates/s", "n_gpus": world, "steps": steps, "warmup": warmup,
@@ -276,7 +307,7 @@ def main():
     ap.add_argument("--config", default="c4", choices=sorted(CONFIGS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample-patterns", type=int, default=8000)
-    ap.add_argument("--no-also", action="store_true", help="skip the second workload (configs[1], DNA 500 x 20000) at N=1")
+    ap.add_argument("--no-also", action="store_true", help="skip the other three workloads (c2, c3, c5) at N=1")
     ap.add_argument("--no-mcmc", action="store_true", help="skip whole-MCMC generations/s of the unmodified MrBayes binary")
     ap.add_argument("--mcmc", action="store_true", help="longer MCMC windows (adds minutes)")
     ap.add_argument("--emulate", action="store_true",
@@ -317,13 +348,16 @@ def main():
     out = measure(args, args.config, args.steps, args.warmup, rank, local_rank, world, dist, device, emulate, lib,
                   not args.no_cpu_baseline)
     if rank == 0 and world == 1 and not emulate:
-        if not args.no_also and args.config != "c2":
-            try:
-                also = measure(args, "c2", max(args.steps, 200), args.warmup, 0, local_rank, 1, None, device, False, lib,
-                               not args.no_cpu_baseline)
-                out["also"] = [also]
-            except Exception as exc:
-                out["also"] = [{"error": repr(exc)}]
+        if not args.no_also:
+            out["also"] = []
+            for other in ("c2", "c3", "c5", "c4"):
+                if other == args.config:
+                    continue
+                try:
+                    out["also"].append(measure(args, other, max(args.steps, 200), args.warmup, 0, local_rank, 1, None, device,
+                                               False, lib, not args.no_cpu_baseline))
+                except Exception as exc:
+                    out["also"].append({"workload": other, "error": repr(exc)})
         if not args.no_mcmc:
             try:
                 with open(os.path.join(GOLD, "bench_c2.json")) as fh:

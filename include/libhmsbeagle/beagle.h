@@ -346,6 +346,10 @@ BEAGLE_DLLEXPORT const char* mbamdGetLastError(void);
  * beagleUpdatePartials since the last reset.  enable=0 turns it off (default). */
 BEAGLE_DLLEXPORT int mbamdKernelTiming(int instance, int enable);
 BEAGLE_DLLEXPORT int mbamdGetKernelTiming(int instance, double* outMilliseconds, long* outLaunches, int reset);
+/* While the timing is on: device time (ms) of whole evaluations -- from the first kernel launched after a
+ * Calculate*LogLikelihoods call to the end of the next integration kernel, i.e. every kernel of a step (transition matrices,
+ * partials, integration) and the gaps between them -- and how many such spans were closed. */
+BEAGLE_DLLEXPORT int mbamdGetStepTiming(int instance, double* outMilliseconds, long* outSteps, int reset);
 /* Select the partials kernel family: 0 = automatic, 1 = level-synchronous generic kernels,
  * 2 = tree-walk kernel (4-state), 3 = MFMA kernels (20/61-state).  For A/B measurements. */
 BEAGLE_DLLEXPORT int mbamdSetKernelPath(int instance, int path);

@@ -43,6 +43,7 @@ typedef struct {
     size_t hdrDone;
     Msg *cur;
     size_t curDone;
+    int closed;                 /* read() returned 0: the peer has exited or closed its end; nothing more will come */
 } Peer;
 
 struct MbamdMpiRequest {
@@ -60,6 +61,12 @@ static void die(const char *what)
 {
     fprintf(stderr, "mbamd_mpi[rank %d]: %s (%s)\n", g_rank, what, strerror(errno));
     _exit(70);
+}
+
+static void die_peer(int peer)
+{
+    fprintf(stderr, "mbamd_mpi[rank %d]: rank %d exited (or closed its socket) while a message from it was awaited\n", g_rank, peer);
+    _exit(71);
 }
 
 static int elem(MPI_Datatype t) { return t >> 8; }
@@ -94,7 +101,7 @@ static void drain_peer(Peer *p)
                 if (errno == EAGAIN || errno == EWOULDBLOCK || errno == EINTR) return;
                 die("read from a peer failed");
             }
-            if (n == 0) return;                         /* peer closed: nothing more will come */
+            if (n == 0) { p->closed = 1; return; }      /* peer closed: nothing more will come (the waiters check) */
             p->hdrDone += (size_t) n;
             g_moved += n;
             if (p->hdrDone < sizeof p->hdr) return;
@@ -150,7 +157,7 @@ static void progress(int block)
         }
     }
     for (i = 0; i < g_size && n < 256; i++) {
-        if (i == g_rank) continue;
+        if (i == g_rank || g_peer[i].closed) continue;  /* (a closed socket is always "ready": polling it would spin) */
         fds[n].fd = g_peer[i].fd;
         fds[n].events = (short) (POLLIN | (g_peer[i].ohead ? POLLOUT : 0));
         fds[n].revents = 0;
@@ -207,8 +214,12 @@ static int recv_blocking(int src, int tag, void *buf, int maxBytes)
 {
     int got = 0;
     if (src == g_rank) die("receive from self is not supported");
-    while (!match(src, tag, buf, maxBytes, &got)) progress(1);
-    return got;
+    for (;;) {
+        if (match(src, tag, buf, maxBytes, &got)) return got;
+        /* everything the peer ever sent is in its queue once its end is closed: no match now = no match ever */
+        if (g_peer[src].closed) die_peer(src);
+        progress(1);
+    }
 }
 
 int MPI_Init(int *argc, char ***argv)
@@ -314,6 +325,7 @@ int MPI_Waitall(int count, MPI_Request *requests, MPI_Status *statuses)
             if (!q || q->done) continue;
             if (q->isRecv) {
                 if (match(q->peer, q->tag, q->buf, q->bytes, &q->got)) q->done = 1;
+                else if (g_peer[q->peer].closed) die_peer(q->peer);
             } else if (q->out->data == NULL) {
                 free(q->out);
                 q->out = NULL;

@@ -34,7 +34,12 @@ int main(int argc, char **argv)
     }
     for (i = 0; i < n; i++) {
         pid[i] = fork();
-        if (pid[i] < 0) { perror("fork"); return 2; }
+        if (pid[i] < 0) {                               /* stop the ranks already started: they would wait for this one for ever */
+            perror("fork");
+            for (j = 0; j < i; j++) kill(pid[j], SIGTERM);
+            for (j = 0; j < i; j++) (void) waitpid(pid[j], NULL, 0);
+            return 2;
+        }
         if (pid[i] == 0) {
             char buf[32], *list = malloc((size_t) n * 12 + 1), *p = list;
             int a, b;
@@ -60,10 +65,12 @@ int main(int argc, char **argv)
         pid_t who = wait(&st);
         int code = WIFEXITED(st) ? WEXITSTATUS(st) : 128 + (WIFSIGNALED(st) ? WTERMSIG(st) : 0);
         if (who < 0) break;
+        for (i = 0; i < n; i++)
+            if (pid[i] == who) pid[i] = -1;             /* reaped: the number may belong to somebody else from now on */
         if (code != 0 && status == 0) {
             status = code;
             for (i = 0; i < n; i++)
-                if (pid[i] != who) kill(pid[i], SIGTERM);  /* exact PIDs of our own children */
+                if (pid[i] > 0) kill(pid[i], SIGTERM);  /* exact PIDs of our own children that are still running */
         }
     }
     return status;

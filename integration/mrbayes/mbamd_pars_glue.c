@@ -24,7 +24,18 @@
 extern int *chainId;
 
 static int      *parsHandle = NULL;        /* per division: device instance or -1 */
-static BitsLong ***parsOwner = NULL;       /* per division: the m->parsSets array the mirror was filled from */
+/* per division: what the mirror was filled from.  The reference frees and re-allocates m->parsSets between analyses
+   (FreeChainMemory / InitParsSets, src/mcmc.c:4437, 6870+) and malloc readily hands out the same address again, so the
+   pointer alone does not identify the sets: the shape, the likelihood instance of the run (every analysis creates a new
+   one) and a checksum of the tip rows -- which no move ever writes -- are kept next to it. */
+typedef struct
+    {
+    BitsLong    **sets, *row0;
+    int         numParsSets, numChars, nInts, beagleInstance, compCharStart, numTips;
+    BitsLong    tipSum;
+    }
+ParsOwner;
+static ParsOwner *parsOwner = NULL;
 static int      nHandles = 0;
 static int      *opBuf = NULL;
 static int      opCap = 0;
@@ -71,6 +82,42 @@ static int *Ops (int n)
     return opBuf;
 }
 
+/* a cheap checksum over the tip rows of m->parsSets (rows 0 .. numLocalTaxa-1: InitParsSets fills them, no move writes them);
+   sampled every 61st word so that the test costs microseconds per move whatever the matrix size */
+static BitsLong TipSum (ModelInfo *m, int numTips)
+{
+    int         i;
+    size_t      c, n = (size_t) m->numChars * (size_t) m->nParsIntsPerSite;
+    BitsLong    h = 1469598103934665603UL;
+
+    for (i=0; i<numTips; i++)
+        for (c=(size_t) i % 61; c<n; c+=61)
+            h = (h ^ m->parsSets[i][c]) * 1099511628211UL;
+    return h;
+}
+
+static void FillOwner (ParsOwner *o, ModelInfo *m)
+{
+    o->sets = m->parsSets;
+    o->row0 = m->parsSets[0];
+    o->numParsSets = m->numParsSets;
+    o->numChars = m->numChars;
+    o->nInts = m->nParsIntsPerSite;
+    o->beagleInstance = m->beagleInstance;
+    o->compCharStart = m->compCharStart;
+    o->numTips = numLocalTaxa < m->numParsSets ? numLocalTaxa : m->numParsSets;
+    o->tipSum = TipSum (m, o->numTips);
+}
+
+static int SameOwner (ParsOwner *o, ModelInfo *m)
+{
+    if (o->sets != m->parsSets || o->row0 != m->parsSets[0] || o->numParsSets != m->numParsSets || o->numChars != m->numChars ||
+        o->nInts != m->nParsIntsPerSite || o->beagleInstance != m->beagleInstance || o->compCharStart != m->compCharStart ||
+        o->numTips != (numLocalTaxa < m->numParsSets ? numLocalTaxa : m->numParsSets))
+        return (NO);
+    return (o->tipSum == TipSum (m, o->numTips) ? YES : NO);
+}
+
 /* the device instance of a division, created (and filled with the host's sets) on first use */
 static int Handle (int division)
 {
@@ -81,19 +128,19 @@ static int Handle (int division)
     if (division >= nHandles)
         {
         parsHandle = (int *) realloc (parsHandle, (size_t) (division + 1) * sizeof(int));
-        parsOwner = (BitsLong ***) realloc (parsOwner, (size_t) (division + 1) * sizeof(BitsLong **));
+        parsOwner = (ParsOwner *) realloc (parsOwner, (size_t) (division + 1) * sizeof(ParsOwner));
         if (!parsHandle || !parsOwner)
             Die ("out of memory");
         for (i=nHandles; i<=division; i++)
             {
             parsHandle[i] = -1;
-            parsOwner[i] = NULL;
+            memset (&parsOwner[i], 0, sizeof(ParsOwner));
             }
         if (nHandles == 0)
             atexit (ReportCheck);
         nHandles = division + 1;
         }
-    if (parsHandle[division] >= 0 && parsOwner[division] == m->parsSets)
+    if (parsHandle[division] >= 0 && SameOwner (&parsOwner[division], m) == YES)
         return parsHandle[division];
     if (parsHandle[division] >= 0)
         {
@@ -119,7 +166,7 @@ static int Handle (int division)
         if (mbamdParsSetSets (id, i, (const unsigned long long *) m->parsSets[i]) != BEAGLE_SUCCESS)
             Die ("mbamdParsSetSets failed");
     parsHandle[division] = id;
-    parsOwner[division] = m->parsSets;
+    FillOwner (&parsOwner[division], m);
     return id;
 }
 
@@ -270,6 +317,8 @@ int MbamdParsLengths (Tree *t, int chain, int kind, TreeNode **pRoot, int nRoot,
 
     (void) chain;
     n = nRoot * nCrown;
+    if (n <= 0)                 /* no candidate: nothing to score (and malloc(0) may legally return NULL) */
+        return (NO_ERROR);
     q = Ops (n);
     for (j=0; j<nCrown; j++)
         for (i=0; i<nRoot; i++, q+=4)

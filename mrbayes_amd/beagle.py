@@ -63,7 +63,7 @@ EXPORTS = [
     "beagleAccumulateScaleFactors", "beagleRemoveScaleFactors", "beagleResetScaleFactors", "beagleCopyScaleFactors",
     "beagleGetScaleFactors", "beagleCalculateRootLogLikelihoods", "beagleCalculateEdgeLogLikelihoods",
     "beagleGetSiteLogLikelihoods", "mbamdSynchronize", "mbamdGetLastError", "mbamdKernelTiming",
-    "mbamdGetKernelTiming", "mbamdSetKernelPath", "mbamdSetDeferredResult", "mbamdFetchLogLikelihood",
+    "mbamdGetKernelTiming", "mbamdGetStepTiming", "mbamdSetKernelPath", "mbamdSetDeferredResult", "mbamdFetchLogLikelihood",
     "mbamdGetScaleExponents", "mbamdGetChildCount", "mbamdSetRateMatrices",
     # BEAGLE v3 surface (multi-partition instances, resource benchmark)
     "beagleGetBenchmarkedResourceList", "beagleSetCPUThreadCount", "beagleSetPatternPartitions",
@@ -135,6 +135,7 @@ class BeagleLibrary:
                                                         _dp, _dp, _dp]
         L.beagleGetSiteLogLikelihoods.argtypes = [C.c_int, _dp]
         L.mbamdGetKernelTiming.argtypes = [C.c_int, _dp, C.POINTER(C.c_long), C.c_int]
+        L.mbamdGetStepTiming.argtypes = [C.c_int, _dp, C.POINTER(C.c_long), C.c_int]
         L.mbamdFetchLogLikelihood.argtypes = [C.c_int, _dp]
 
     def version(self) -> str:
@@ -395,6 +396,12 @@ class BeagleInstance:
     def get_kernel_timing(self, reset=True):
         ms, n = C.c_double(0.0), C.c_long(0)
         self._chk(self.lib.mbamdGetKernelTiming(self.id, C.byref(ms), C.byref(n), 1 if reset else 0), "mbamdGetKernelTiming")
+        return ms.value, n.value
+
+    def get_step_timing(self, reset=True):
+        """(ms, spans): device time of whole evaluations (all kernels of a step and the gaps between them)."""
+        ms, n = C.c_double(0.0), C.c_long(0)
+        self._chk(self.lib.mbamdGetStepTiming(self.id, C.byref(ms), C.byref(n), 1 if reset else 0), "mbamdGetStepTiming")
         return ms.value, n.value
 
     def set_deferred_result(self, enable: bool):

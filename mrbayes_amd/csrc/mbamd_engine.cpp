@@ -273,6 +273,42 @@ struct Instance {
     std::vector<std::pair<hipEvent_t, hipEvent_t>> events;
     double timedMs = 0.0;
     long timedLaunches = 0, pendingLaunches = 0;
+    // ... and of whole evaluations: from the first kernel after a log-likelihood call (transition matrices, usually) to the
+    // integration kernel's end -- every kernel of a step and the gaps between them, nothing of the host's wait
+    hipEvent_t spanEv0{};
+    bool spanOpen = false;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> spans;
+    double spanMs = 0.0;
+    long spanCount = 0;
+    int spanBegin()
+    {
+        if (!timing || spanOpen) return BEAGLE_SUCCESS;
+        HIP_TRY(hipEventCreate(&spanEv0));
+        HIP_TRY(hipEventRecord(spanEv0, stream));
+        spanOpen = true;
+        return BEAGLE_SUCCESS;
+    }
+    int spanEnd()
+    {
+        if (!spanOpen) return BEAGLE_SUCCESS;
+        hipEvent_t e1{};
+        HIP_TRY(hipEventCreate(&e1));
+        HIP_TRY(hipEventRecord(e1, stream));
+        spans.emplace_back(spanEv0, e1);
+        spanOpen = false;
+        return BEAGLE_SUCCESS;
+    }
+    int spanFold()                   // (stream synchronised by the caller)
+    {
+        for (auto& ev : spans) {
+            float t = 0.0f;
+            if (hipEventElapsedTime(&t, ev.first, ev.second) == hipSuccess) { spanMs += t; ++spanCount; }
+            (void) hipEventDestroy(ev.first);
+            (void) hipEventDestroy(ev.second);
+        }
+        spans.clear();
+        return BEAGLE_SUCCESS;
+    }
 
     bool deferred = false, pendingResult = false;
 
@@ -897,6 +933,7 @@ int Instance::flushMatrices()
     if (pendingJobs.empty()) return BEAGLE_SUCCESS;
     const RatesArg rates = rateSets[pendingRateSet];
     const int count = (int) pendingJobs.size();
+    { int src = spanBegin(); if (src) return src; }
     const MatrixJob* djobs = nullptr;
     int rc = stageDirect(pendingJobs.data(), sizeof(MatrixJob) * count, (const void**) &djobs);
     pendingJobs.clear();
@@ -1157,6 +1194,7 @@ int Instance::flushPending()
     }
 #if !defined(MBAMD_HOST_EMU)
     hipEvent_t ev0{}, ev1{};
+    { int src = spanBegin(); if (src) return src; }
     if (timing) {
         HIP_TRY(hipEventCreate(&ev0));
         HIP_TRY(hipEventCreate(&ev1));
@@ -1290,6 +1328,7 @@ int Instance::timedRun(const Plan& plan, int32_t* cum)
 {
     const_cast<Plan&>(plan).lastLaunch = ++launchClock;
     hipEvent_t ev0{}, ev1{};
+    { int src = spanBegin(); if (src) return src; }
     if (timing) {
         HIP_TRY(hipEventCreate(&ev0));
         HIP_TRY(hipEventCreate(&ev1));
@@ -1301,6 +1340,7 @@ int Instance::timedRun(const Plan& plan, int32_t* cum)
         events.emplace_back(ev0, ev1);
         if (events.size() > 4096) {               // a client that never asks: fold the finished ones into the running total
             HIP_TRY(hipStreamSynchronize(stream));
+            spanFold();
             for (auto& ev : events) {
                 float t = 0.0f;
                 if (hipEventElapsedTime(&t, ev.first, ev.second) == hipSuccess) timedMs += t;
@@ -2327,6 +2367,8 @@ int Instance::integrate(const int* parent, const int* child, const int* prob, co
     if (arena()) {
         int rc = integrate4(parent, child, prob, wIdx, fIdx, cumIdx, count);
         if (rc) return rc;
+        rc = spanEnd();
+        if (rc) return rc;
         haveSite = true;
         pendingResult = true;
         if (deferred) {
@@ -2370,6 +2412,7 @@ int Instance::integrate(const int* parent, const int* child, const int* prob, co
 #endif
         MBAMD_LAUNCH(k_integrate_lnl, (unsigned) nblocks, 64, 0, stream, a, S, SP, K, P, Ppad, (const double*) d_pweights, siteOut, h_sums_dev);
     HIP_TRY(hipGetLastError());
+    { int src = spanEnd(); if (src) return src; }
     haveSite = true;
     pendingResult = true;
     if (deferred) {
@@ -2869,7 +2912,7 @@ int beagleFinalize(void)
         all.swap(g_instances);
     }
     for (Instance* in : all)
-        if (in) { in->destroyChildren(); if (!in->released) in->destroy(); delete in; }
+        if (in) { in->destroyChildren(); if (!in->released) in->destroy(); delete in->f64; delete in; }
     return BEAGLE_SUCCESS;
 }
 
@@ -3459,6 +3502,16 @@ static int kernel_timing_of(Instance* in, double* ms, long* launches, int reset)
     if (reset) { in->timedMs = 0.0; in->timedLaunches = 0; }
     return BEAGLE_SUCCESS;
 }
+static int step_timing_of(Instance* in, double* ms, long* steps, int reset)
+{
+    (void) hipSetDevice(in->device);
+    HIP_TRY(hipStreamSynchronize(in->stream));
+    in->spanFold();
+    *ms += in->spanMs;
+    *steps += in->spanCount;
+    if (reset) { in->spanMs = 0.0; in->spanCount = 0; }
+    return BEAGLE_SUCCESS;
+}
 // (a facade reports the LARGEST kernel time of its children -- they run side by side -- and the sum of the launches)
 int mbamdGetKernelTiming(int instance, double* outMilliseconds, long* outLaunches, int reset)
 {
@@ -3479,6 +3532,32 @@ int mbamdGetKernelTiming(int instance, double* outMilliseconds, long* outLaunche
     }
     if (outMilliseconds) *outMilliseconds = ms;
     if (outLaunches) *outLaunches = launches;
+    return BEAGLE_SUCCESS;
+}
+// Device time of whole evaluations while mbamdKernelTiming is on: from the first kernel launched after a log-likelihood
+// call to the end of the next integration kernel -- every kernel of a step and the gaps between them (HIP events on the
+// engine's stream).  A facade reports the largest of its children.
+int mbamdGetStepTiming(int instance, double* outMilliseconds, long* outSteps, int reset)
+{
+    GET_INSTANCE(instance);
+    if (in->f64) return fail(BEAGLE_ERROR_NO_IMPLEMENTATION, "mbamdGetStepTiming: not on a double-precision instance");
+    double ms = 0.0;
+    long steps = 0;
+    if (in->facade()) {
+        for (Instance::Child& ch : in->children) {
+            double m = 0.0;
+            long st = 0;
+            int rc = step_timing_of(ch.in, &m, &st, reset);
+            if (rc) return rc;
+            ms = std::max(ms, m);
+            steps = std::max(steps, st);
+        }
+    } else {
+        int rc = step_timing_of(in, &ms, &steps, reset);
+        if (rc) return rc;
+    }
+    if (outMilliseconds) *outMilliseconds = ms;
+    if (outSteps) *outSteps = steps;
     return BEAGLE_SUCCESS;
 }
 int mbamdSetKernelPath(int instance, int path)

@@ -224,7 +224,12 @@ public:
     hipStream_t stream{};
     bool live = false;
     void* d_sets = nullptr;                          // nSets + 2 rows: [nSets] takes what no-op steps store, [nSets + 1] is all ones (their sources)
-    float* d_w = nullptr;
+    float* d_w = nullptr;                            // the pattern weights the next launch reads: one of d_wbuf
+    float* d_wbuf[2] = {nullptr, nullptr};           // double-buffered: an upload never touches what kernels in flight read
+    float* h_wpin[2] = {nullptr, nullptr};           // pinned sources of the asynchronous copies
+    hipEvent_t wDone[2] = {};
+    bool wBusy[2] = {false, false};
+    int wNext = 0;
     std::vector<float> h_w;                          // what d_w holds
     static constexpr int RING = 4;
     struct Slot {
@@ -268,8 +273,13 @@ public:
         HIP_TRY(hipMalloc(&d_sets, bytes));
         HIP_TRY(hipMemsetAsync(d_sets, 0, bytes - rowBytes, stream));      // SafeCalloc'ed in the reference (src/mcmc.c:6892)
         HIP_TRY(hipMemsetAsync(static_cast<char*>(d_sets) + bytes - rowBytes, 0xFF, rowBytes, stream));
-        HIP_TRY(hipMalloc(&d_w, (size_t) Ppad * sizeof(float)));
-        HIP_TRY(hipMemsetAsync(d_w, 0, (size_t) Ppad * sizeof(float), stream));
+        for (int i = 0; i < 2; ++i) {
+            HIP_TRY(hipMalloc(&d_wbuf[i], (size_t) Ppad * sizeof(float)));
+            HIP_TRY(hipMemsetAsync(d_wbuf[i], 0, (size_t) Ppad * sizeof(float), stream));
+            HIP_TRY(hipHostMalloc((void**) &h_wpin[i], (size_t) Ppad * sizeof(float), hipHostMallocDefault));
+            HIP_TRY(hipEventCreate(&wDone[i]));
+        }
+        d_w = d_wbuf[0];
         HIP_TRY(hipHostMalloc(&h_stage, (size_t) Ppad * 16, hipHostMallocDefault));
         HIP_TRY(hipStreamSynchronize(stream));
         lastWrite.assign((size_t) nSets + 2, -(1 << 30));
@@ -288,7 +298,11 @@ public:
             s = Slot();
         }
         if (d_sets) (void) hipFree(d_sets);
-        if (d_w) (void) hipFree(d_w);
+        for (int i = 0; i < 2; ++i) {
+            if (d_wbuf[i]) { (void) hipFree(d_wbuf[i]); (void) hipEventDestroy(wDone[i]); }
+            if (h_wpin[i]) (void) hipHostFree(h_wpin[i]);
+            d_wbuf[i] = nullptr; h_wpin[i] = nullptr; wBusy[i] = false;
+        }
         if (d_out) (void) hipFree(d_out);
         if (h_out) (void) hipHostFree(h_out);
         if (h_stage) (void) hipHostFree(h_stage);
@@ -362,12 +376,20 @@ public:
     int setWeights(const float* w)
     {
         if (h_w.size() == (size_t) P && std::memcmp(h_w.data(), w, (size_t) P * sizeof(float)) == 0) return BEAGLE_SUCCESS;
-        int rc = flush(nullptr);
-        if (rc) return rc;
-        HIP_TRY(hipStreamSynchronize(stream));                              // (kernels in flight read the old weights; h_w is the source of the copy)
+        // Stream-ordered, no wait: the parsimony moves re-randomise the weights for every proposal (reference
+        // src/proposal.c:10655-10667).  Passes queued so far do not read the weights (only the down pass's length sum and the
+        // score kernel do, at launch time), so they need not run first: the copy goes into the buffer no launch in flight reads.
+        const int i = wNext;
+        wNext ^= 1;
+        if (wBusy[i]) { HIP_TRY(hipEventSynchronize(wDone[i])); wBusy[i] = false; }   // (the copy from two calls ago: long done)
         h_w.assign(w, w + P);
-        HIP_TRY(hipMemcpyAsync(d_w, h_w.data(), (size_t) P * sizeof(float), hipMemcpyHostToDevice, stream));
-        HIP_TRY(hipStreamSynchronize(stream));
+        std::memcpy(h_wpin[i], w, (size_t) P * sizeof(float));
+        int rc = flush(nullptr);                     // (queued down passes sum with the weights they were queued under)
+        if (rc) return rc;
+        HIP_TRY(hipMemcpyAsync(d_wbuf[i], h_wpin[i], (size_t) P * sizeof(float), hipMemcpyHostToDevice, stream));
+        HIP_TRY(hipEventRecord(wDone[i], stream));
+        wBusy[i] = true;
+        d_w = d_wbuf[i];
         return BEAGLE_SUCCESS;
     }
 

@@ -101,15 +101,25 @@ def known_answer_nexus(states, tree, revmat, pi, alpha, beagle=None, ngen=1, fna
     return s
 
 
-def run_mb(binary, nexus_text, timeout=1800, env=None):
-    """Run a MrBayes binary on a NEXUS text in a scratch directory -> (stdout, wall seconds)."""
+def run_mb(binary, nexus_text, timeout=1800, env=None, keep=None, argv_prefix=None):
+    """Run a MrBayes binary on a NEXUS text in a scratch directory -> (stdout, wall seconds); with `keep` (file names
+    the run writes) -> (stdout, wall seconds, {name: text}).  `argv_prefix`: a launcher in front of the binary."""
     with tempfile.TemporaryDirectory() as wd:
         with open(os.path.join(wd, "run.nex"), "w") as fh:
             fh.write(nexus_text)
         t0 = time.time()
-        res = subprocess.run([binary, "run.nex"], cwd=wd, capture_output=True, text=True, timeout=timeout,
+        res = subprocess.run(list(argv_prefix or []) + [binary, "run.nex"], cwd=wd, capture_output=True, text=True, timeout=timeout,
                              env=dict(os.environ, **(env or {})))
-        return res.stdout + res.stderr, time.time() - t0
+        wall = time.time() - t0
+        if keep is None:
+            return res.stdout + res.stderr, wall
+        files = {}
+        for name in keep:
+            path = os.path.join(wd, name)
+            if os.path.exists(path):
+                with open(path) as fh:
+                    files[name] = fh.read()
+        return res.stdout + res.stderr, wall, files
 
 
 def initial_lnl(stdout):
