@@ -134,7 +134,7 @@ struct Plan {
     uint64_t lastLaunch = 0;         // Instance::launchClock value of the latest launch that reads d_table
     PartialsOp* d_table = nullptr;
     size_t cap = 0;                  // bytes allocated for d_table
-    struct Segment { size_t first; int W, entries, nslots; };   // tree-walk path: one launch per hazard-free segment
+    struct Segment { size_t first; int W, entries, nslots, tail = 2, tipAhead = 0; };   // tree-walk path: one launch per hazard-free segment
     std::vector<Segment> segments;               // (Walk4Entry index of its program in d_table, geometry)
     std::vector<Walk4Entry> inlineProg;          // 4-state walk: a short single-segment program travels in the kernel arguments instead
     int lists = 1;                               // 20/61-state walk: > 1 = the segments are that many independent lists, ONE launch
@@ -670,6 +670,7 @@ int Instance::configureWalk()
     if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0) numCU = prop.multiProcessorCount;
     const int maxLds = 160 * 1024;
     if (s4 && (hipFuncSetAttribute((const void*) k_walk4_t<Walk4Args>, hipFuncAttributeMaxDynamicSharedMemorySize, maxLds) != hipSuccess ||
+               hipFuncSetAttribute((const void*) k_walk4_t<Walk4Args, true>, hipFuncAttributeMaxDynamicSharedMemorySize, maxLds) != hipSuccess ||
                hipFuncSetAttribute((const void*) k_walk4_t<Walk4ArgsInline>, hipFuncAttributeMaxDynamicSharedMemorySize, maxLds) != hipSuccess))
         (void) hipGetLastError();
 #endif
@@ -710,6 +711,8 @@ int Instance::configureWalk()
     w4.maxSlots1 = std::max(slots, std::min(40, slotsFor(1)));
     if (std::getenv("MBAMD_MAX_LDS_SLOTS")) w4.maxSlots1 = slots;
     if (const char* e = std::getenv("MBAMD_WALK_PREFETCH")) w4.prefetchDistance = std::max(0, std::atoi(e));
+    if (const char* e = std::getenv("MBAMD_WALK_TIP_AHEAD")) w4.tipAhead = std::max(0, std::min(32, std::atoi(e)));
+    if (const char* e = std::getenv("MBAMD_WALK_TIP_FROM")) w4.tipAheadFrom = std::max(1, std::atoi(e));
     w4.safeWaits = std::getenv("MBAMD_WALK_SAFE") != nullptr;
     if (const char* e = std::getenv("MBAMD_WALK_SMALL_PHASE")) w4.smallPhase = std::max(1, std::atoi(e));
     if (envVerbose) std::fprintf(stderr, "[mbamd] tree walk: %ld workgroups (%d per CU), up to %d waves x %d slots\n", wgs, perCU, W, slots);
@@ -1462,7 +1465,7 @@ int Instance::buildWalk(Plan& plan, const BeagleOperation* ops, int n, const int
         key.clear();
         key.reserve(seg.size() * 3 + 4);
         key.push_back((int) seg.size()); key.push_back(w4.maxW); key.push_back(w4.maxSlots + 256 * w4.maxSlots1);
-        key.push_back(w4.prefetchDistance * 2 + (w4.safeWaits ? 1 : 0));
+        key.push_back(w4.prefetchDistance * 2 + (w4.safeWaits ? 1 : 0) + 1024 * w4.tipAhead + 65536 * std::min(w4.tipAheadFrom, 30000));
         {
             std::vector<int>& writer = w4writer;          // buffer -> operation of this segment that writes it (-1 outside this block)
             for (size_t o = 0; o < seg.size(); ++o) {
@@ -1498,7 +1501,7 @@ int Instance::buildWalk(Plan& plan, const BeagleOperation* ops, int n, const int
         reloads += t.reloads; externals += t.externals; phases = std::max(phases, t.phases);
         Plan::Segment sg;
         sg.first = w4table.size();
-        sg.W = t.W; sg.entries = t.entries; sg.nslots = t.nslots;
+        sg.W = t.W; sg.entries = t.entries; sg.nslots = t.nslots; sg.tail = t.tail; sg.tipAhead = t.tipAhead;
         plan.segments.push_back(sg);
         w4table.resize(sg.first + t.prog.size());
         // bytes per buffer inside a block / tile, bytes per LDS slot
@@ -1628,7 +1631,7 @@ int Instance::buildWalk(Plan& plan, const BeagleOperation* ops, int n, const int
                      n, plan.segments.size(), lastWalkW, lastWalkEntries, lastWalkSlots, phases, reloads, externals);
     // a short program goes out with the launch itself (k_walk4_t<Walk4ArgsInline>, k_walkg<..., WalkGArgsInline>)
     plan.inlineProg.clear();
-    if (!noInlinePrograms && plan.segments.size() == 1 && w4table.size() <= (size_t) MBAMD_W4_INLINE) {
+    if (!noInlinePrograms && plan.segments.size() == 1 && plan.segments[0].tipAhead == 0 && w4table.size() <= (size_t) MBAMD_W4_INLINE) {
         plan.inlineProg = w4table;
         return BEAGLE_SUCCESS;
     }
@@ -1667,7 +1670,12 @@ int Instance::runWalk(const Plan& plan, int32_t* cum)
         a.K = K;
         a.Ppad = Ppad;
         a.nblocks = Ppad / 64;
-        if (!plan.inlineProg.empty()) {
+        a.tail = sg.tail;
+        a.tipAhead = sg.tipAhead;
+        if (sg.tipAhead > 0 && plan.inlineProg.empty()) {
+            auto kernel = k_walk4_t<Walk4Args, true>;
+            MBAMD_LAUNCH_BARRIER(kernel, walk4_grid(Ppad / 64, K), 64 * sg.W, walk4_lds_bytes(sg.W, sg.nslots), stream, a);
+        } else if (!plan.inlineProg.empty()) {
             Walk4ArgsInline ai;
             ai.a = a;
             ai.a.prog = nullptr;

@@ -83,9 +83,11 @@ struct Walk4Args {
     int32_t* cum;                // wide cumulative buffer int32 [K][Ppad], or nullptr
     int cumFresh;                // the cumulative buffer holds nothing yet: store the sums instead of adding them
     int K, Ppad, nblocks;
+    int tail;                    // trailing NOP entries of every program (read-ahead): 2, or tipAhead + 1
+    int tipAhead;                // > 0: touch the tip bitplanes of the entry this far ahead (walk4_touch_planes), else 0
 };
 
-#define MBAMD_W4_STAGE 512       // bytes per wave in front of its slots: two 64-dword landing areas for stored exponents
+#define MBAMD_W4_STAGE 768       // bytes per wave in front of its slots: two 64-dword landing areas for stored exponents + one nobody reads
 __host__ __device__ inline size_t walk4_lds_bytes(int W, int nslots) { return (size_t) W * (MBAMD_W4_STAGE + (size_t) nslots * 1024); }
 // The grid is one-dimensional and XCD-aware: workgroup id -> XCD id % 8 (observed dispatch rule), and the K category
 // workgroups of one pattern block get consecutive positions on ONE XCD, so that the tip bitplanes and the matrix
@@ -107,9 +109,12 @@ __device__ inline f4 walk4_tip_vector(const Walk4Planes& t, unsigned lane)
 }
 __device__ inline void walk4_dma(const f4* base, unsigned lane, f4* slot) { slot[lane] = base[lane]; }
 __device__ inline void walk4_dma_exps(const int8_t* base, unsigned lane, int* stage) { stage[lane] = base[lane]; }
+__device__ inline void walk4_touch_planes(const uint64_t*, const uint64_t*, unsigned, int*) {}
 __device__ inline void walk4_wait_vm(unsigned) {}
 __device__ inline void walk4_barrier() { mbamd_emu_barrier(); }
 __device__ inline Walk4Entry walk4_load_entry(const Walk4Entry* p) { return *p; }
+struct Walk4Half { unsigned ctl, dst, c1, c2; };
+__device__ inline Walk4Half walk4_load_half(const Walk4Entry* p) { Walk4Half h; h.ctl = p->ctl; h.dst = p->dst; h.c1 = p->c1; h.c2 = p->c2; return h; }
 #else
 typedef float f2v __attribute__((ext_vector_type(2)));
 typedef float f16v __attribute__((ext_vector_type(16)));
@@ -130,6 +135,16 @@ __device__ __forceinline__ Walk4Entry walk4_load_entry(const Walk4Entry* p)
     Walk4Entry e;
     e.ctl = v[0]; e.dst = v[1]; e.c1 = v[2]; e.c2 = v[3]; e.m1 = v[4]; e.m2 = v[5]; e.ewrite = v[6]; e.eread = v[7];
     return e;
+}
+// the first half of an entry (ctl, dst, c1, c2): all the far-ahead tip touch needs
+struct Walk4Half { unsigned ctl, dst, c1, c2; };
+__device__ __forceinline__ Walk4Half walk4_load_half(const Walk4Entry* p)
+{
+    typedef unsigned u4v __attribute__((ext_vector_type(4)));
+    const u4v v = *reinterpret_cast<const MBAMD_AS_CONST u4v*>((uintptr_t) p);
+    Walk4Half h;
+    h.ctl = v[0]; h.dst = v[1]; h.c1 = v[2]; h.c2 = v[3];
+    return h;
 }
 __device__ __forceinline__ Walk4Planes walk4_load_planes(const uint64_t* p)
 {
@@ -164,6 +179,15 @@ __device__ __forceinline__ void walk4_dma_exps(const int8_t* base, unsigned lane
     unsigned keep;
     asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_sbyte %1, %2\n\ts_mov_b32 m0, %0"
                  : "=&s"(keep) : "v"(lane), "s"(base), "s"(lds_dst) : "memory");
+}
+// Pull the 64-byte lines that hold two sets of tip bitplanes into this XCD's L2 ahead of the scalar loads that will want
+// them: every lane asks for the same dword (one request), the LDS-DMA form has no destination register to keep alive, and
+// what lands (256 bytes at lds_dst, twice) is never read.  Two vector-memory instructions, counted by the host like the others.
+__device__ __forceinline__ void walk4_touch_planes(const uint64_t* p1, const uint64_t* p2, unsigned zero, unsigned lds_dst)
+{
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %4\n\ts_nop 0\n\tglobal_load_lds_dword %1, %2\n\tglobal_load_lds_dword %1, %3\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(zero), "s"(p1), "s"(p2), "s"(lds_dst) : "memory");
 }
 // wait until at most n vector-memory instructions of this wave are outstanding (s_waitcnt takes an immediate: the
 // host rounds n down to one of these values; only entries that read a prefetched child come here)
@@ -248,7 +272,10 @@ __device__ __forceinline__ const Walk4Entry* walk4_program(const Walk4ArgsInline
 
 // blockDim.x = 64 * W; grid = walk4_grid(nblocks, K) workgroups.  Dynamic LDS: walk4_lds_bytes(W, nslots).
 // ARGS = Walk4Args (program in a device buffer) or Walk4ArgsInline (program in the arguments).
-template <class ARGS>
+// TIPPF: the tip bitplanes of entry j + tipAhead are touched at the top of iteration j (full-tree evaluations: a tip's planes
+// are read once per launch, i.e. from HBM -- a round trip of microseconds under a saturated write stream, and the scalar load
+// that takes it is waited for one iteration after it was issued).
+template <class ARGS, bool TIPPF = false>
 __global__ void __launch_bounds__(64 * MBAMD_W4_MAXW)
 k_walk4_t(ARGS AA)
 {
@@ -287,8 +314,18 @@ k_walk4_t(ARGS AA)
 #endif
 
     const Walk4Entry* prog = walk4_program(AA) + (size_t) wave * A.entries;
-    const int n = A.entries - 2;
+    const int n = A.entries - A.tail;
     Walk4Entry DA = walk4_load_entry(prog), DB = walk4_load_entry(prog + 1);
+    const int ahead = TIPPF ? A.tipAhead : 0;
+    Walk4Half FAR = walk4_load_half(prog + ahead);               // (TIPPF) entry j + ahead, loaded during iteration j - 1
+#if defined(MBAMD_HOST_EMU)
+    int* const junk = stage + 128;
+    const unsigned vzero = 0;
+#else
+    const unsigned junk = stage_lds + 512u;
+    unsigned vzero;
+    asm volatile("v_mov_b32 %0, 0" : "=v"(vzero));
+#endif
     // inputs of entry 0
     Walk4Mat M1 = walk4_load_matrix(walk4_at(M0, DA.m1));
     Walk4Mat M2 = walk4_load_matrix(walk4_at(M0, DA.m2));
@@ -308,6 +345,9 @@ k_walk4_t(ARGS AA)
     auto step = [&](Walk4Entry& cur, const Walk4Entry& nxt, int j, int parity) {
         const unsigned ctl = cur.ctl;
         bool run = true;
+        if (TIPPF) {
+            walk4_touch_planes(walk4_at(T0, (FAR.ctl & MBAMD_W4_TIP1) ? FAR.c1 : 0u), walk4_at(T0, (FAR.ctl & MBAMD_W4_TIP2) ? FAR.c2 : 0u), vzero, junk);
+        }
         if (ctl & MBAMD_W4_RARE) {
             if (ctl & MBAMD_W4_PF0) {
                 // PF entry: children of later operations that live in HBM -> LDS slots
@@ -333,12 +373,23 @@ k_walk4_t(ARGS AA)
         // the scalar-load burst for the next entry (the registers of this entry's matrices / planes are free now); a
         // child that is not a tip reads the planes at offset 0 -- a valid address, the value is not used
         const unsigned dst = cur.dst, ewrite = cur.ewrite;
+#if defined(MBAMD_W4X_MAT0)      // (timing experiments: every matrix / every tip from one hot line -- wrong values)
+        M1 = walk4_load_matrix(walk4_at(M0, 0u));
+        M2 = walk4_load_matrix(walk4_at(M0, 0u));
+#else
         M1 = walk4_load_matrix(walk4_at(M0, nxt.m1));
         M2 = walk4_load_matrix(walk4_at(M0, nxt.m2));
+#endif
+#if defined(MBAMD_W4X_TIP0)
+        T1 = walk4_load_planes(walk4_at(T0, 0u));
+        T2 = walk4_load_planes(walk4_at(T0, 0u));
+#else
         T1 = walk4_load_planes(walk4_at(T0, (nxt.ctl & MBAMD_W4_TIP1) ? nxt.c1 : 0u));
         T2 = walk4_load_planes(walk4_at(T0, (nxt.ctl & MBAMD_W4_TIP2) ? nxt.c2 : 0u));
+#endif
         if (((nxt.ctl >> 8) & 3u) == SCALE_READ) MBAMD_W4_EXPS(nxt.eread, parity ^ 1);
         cur = walk4_load_entry(prog + j + 2);
+        if (TIPPF) FAR = walk4_load_half(prog + j + 1 + ahead);
         if (run) {
             const int wm = mode == SCALE_WRITE ? -1 : 0, rm = mode == SCALE_READ ? -1 : 0;
             const int e = (scale_exponent(max4(out)) & wm) | (er & rm);
@@ -352,8 +403,14 @@ k_walk4_t(ARGS AA)
 #else
             // 1 KiB contiguous per wave; never waited for.  Non-temporal: the result is not read again in this launch
             // (parents read the LDS copy), so it must not push the matrices and programs out of L2
+#if defined(MBAMD_W4X_NOSTORE)
+            if (e == 12345) {
+#endif
             __builtin_nontemporal_store(out, as_global(walk4_at(P0, dst)) + lane);
             __builtin_nontemporal_store((int8_t) e, as_global(walk4_at(E0, ewrite)) + lane);
+#if defined(MBAMD_W4X_NOSTORE)
+            }
+#endif
 #endif
         }
     };

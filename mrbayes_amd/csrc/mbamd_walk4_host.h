@@ -49,7 +49,8 @@ struct Walk4Template {
         uint8_t pfChild[2] = {0, 0}, pfSlot[2] = {0, 0};      // ... into this slot
     };
     std::vector<int> key;
-    int W = 1, entries = 0, nslots = 1;            // entries per wave (incl. the two trailing NOPs)
+    int W = 1, entries = 0, nslots = 1;            // entries per wave (incl. the trailing NOPs)
+    int tail = 2, tipAhead = 0;                    // trailing NOPs; tip-touch distance the wait counts were computed for (0: none)
     std::vector<Entry> prog;                       // [W][entries]
     int phases = 1, reloads = 0, externals = 0;
     int evictions = 0;                             // results evicted from a wave's slots and re-read by the same wave
@@ -81,6 +82,10 @@ public:
     bool phasesAreLaunches = false;  // every phase is its own kernel launch: nothing stays in LDS across a phase boundary
     // program frame: leading NOP entries, loop unroll factor of the kernel, trailing (read-ahead) NOP entries
     int leadNops = 0, unroll = 2, tailNops = 2;
+    // 4-state walk, long lists: the kernel touches the tip bitplanes of the entry `tipAhead` ahead at the top of EVERY
+    // iteration (two vector-memory instructions: they enter the wait counts) and reads that far beyond the program's end
+    int tipAhead = 0, tipAheadFrom = 128;      // (lists shorter than tipAheadFrom operations run without: root-ward paths)
+    int lastTipAhead = 0;                      // what the latest build() used (the caller passes it to the kernel)
 
     // ops: one hazard-free segment (no buffer is written twice, none is written after it was read, a buffer read
     // after it was written is a dependency).  Fills `t` (structure) -- the caller turns it into Walk4Entry words.
@@ -520,12 +525,14 @@ inline bool Walk4Builder::build(const std::vector<Walk4Op>& ops, Walk4Template& 
         //    prologue: [exponent DMA for entry 0 if SCALE_READ]
         //    iteration: [PF DMAs] WAIT [exponent DMA for the next entry if SCALE_READ] [2 stores if an operation]
         auto reads = [&](const Walk4Template::Entry& e) { return e.op >= 0 && ops[e.op].scaleRead >= 0 && ops[e.op].scaleWrite < 0; };
+        const int touches = (tipAhead > 0 && n >= tipAheadFrom) ? 2 : 0;
         long issued = 0;
         long expSeq = -1;                                       // sequence number of the exponent DMA of the entry about to run
         if (!out.empty() && reads(out[0])) expSeq = issued++;
         std::vector<long> pfSeq(mems.size(), -1);
         for (size_t j = 0; j < out.size(); ++j) {
             Walk4Template::Entry& e = out[j];
+            issued += touches;                                  // (top of every iteration, before anything else)
             for (int q = 0; q < 2; ++q)
                 if (e.pfOp[q] >= 0) {
                     for (size_t mi = 0; mi < mems.size(); ++mi)
@@ -550,8 +557,12 @@ inline bool Walk4Builder::build(const std::vector<Walk4Op>& ops, Walk4Template& 
     for (int w = 0; w < W; ++w) longestFinal = std::max(longestFinal, fin[w].size());
     // frame: leading NOPs, the programs padded to a multiple of the kernel's loop unroll factor, read-ahead NOPs
     const int body = (leadNops + (int) longestFinal + unroll - 1) / unroll * unroll;
-    const int entries = body + tailNops;
+    lastTipAhead = (tipAhead > 0 && n >= tipAheadFrom) ? tipAhead : 0;
+    const int tail = lastTipAhead > 0 ? std::max(tailNops, lastTipAhead + 1) : tailNops;
+    const int entries = body + tail;
     t.entries = entries;
+    t.tail = tail;
+    t.tipAhead = lastTipAhead;
     t.prog.assign((size_t) W * entries, Walk4Template::Entry());
     for (Walk4Template::Entry& e : t.prog) e.flags = MBAMD_W4_NOP;
     for (int w = 0; w < W; ++w) std::copy(fin[w].begin(), fin[w].end(), t.prog.begin() + (size_t) w * entries + leadNops);
