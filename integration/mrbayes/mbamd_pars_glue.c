@@ -82,16 +82,20 @@ static int *Ops (int n)
     return opBuf;
 }
 
-/* a cheap checksum over the tip rows of m->parsSets (rows 0 .. numLocalTaxa-1: InitParsSets fills them, no move writes them);
-   sampled every 61st word so that the test costs microseconds per move whatever the matrix size */
+/* a cheap checksum over the tip rows of m->parsSets (rows 0 .. numLocalTaxa-1: InitParsSets fills them, no move writes them):
+   about 4096 words spread over all tips, so that the test costs a few microseconds per call whatever the matrix size
+   (Handle() runs several times per proposal) */
 static BitsLong TipSum (ModelInfo *m, int numTips)
 {
     int         i;
-    size_t      c, n = (size_t) m->numChars * (size_t) m->nParsIntsPerSite;
+    size_t      c, n = (size_t) m->numChars * (size_t) m->nParsIntsPerSite, step;
     BitsLong    h = 1469598103934665603UL;
 
+    step = (n * (size_t) (numTips > 0 ? numTips : 1)) / 4096 + 1;
+    if (step % 2 == 0)
+        step++;
     for (i=0; i<numTips; i++)
-        for (c=(size_t) i % 61; c<n; c+=61)
+        for (c=(size_t) i % step; c<n; c+=step)
             h = (h ^ m->parsSets[i][c]) * 1099511628211UL;
     return h;
 }

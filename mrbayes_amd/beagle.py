@@ -63,7 +63,7 @@ EXPORTS = [
     "beagleAccumulateScaleFactors", "beagleRemoveScaleFactors", "beagleResetScaleFactors", "beagleCopyScaleFactors",
     "beagleGetScaleFactors", "beagleCalculateRootLogLikelihoods", "beagleCalculateEdgeLogLikelihoods",
     "beagleGetSiteLogLikelihoods", "mbamdSynchronize", "mbamdGetLastError", "mbamdKernelTiming",
-    "mbamdGetKernelTiming", "mbamdGetStepTiming", "mbamdSetKernelPath", "mbamdSetDeferredResult", "mbamdFetchLogLikelihood",
+    "mbamdGetKernelTiming", "mbamdGetStepTiming", "mbamdUpdateFinalPartials", "mbamdGetScaledPartials", "mbamdSetKernelPath", "mbamdSetDeferredResult", "mbamdFetchLogLikelihood",
     "mbamdGetScaleExponents", "mbamdGetChildCount", "mbamdSetRateMatrices",
     # BEAGLE v3 surface (multi-partition instances, resource benchmark)
     "beagleGetBenchmarkedResourceList", "beagleSetCPUThreadCount", "beagleSetPatternPartitions",
@@ -136,6 +136,8 @@ class BeagleLibrary:
         L.beagleGetSiteLogLikelihoods.argtypes = [C.c_int, _dp]
         L.mbamdGetKernelTiming.argtypes = [C.c_int, _dp, C.POINTER(C.c_long), C.c_int]
         L.mbamdGetStepTiming.argtypes = [C.c_int, _dp, C.POINTER(C.c_long), C.c_int]
+        L.mbamdUpdateFinalPartials.argtypes = [C.c_int, C.c_void_p, C.c_int]
+        L.mbamdGetScaledPartials.argtypes = [C.c_int, C.c_int, C.c_int, C.POINTER(C.c_float), C.POINTER(C.c_float)]
         L.mbamdFetchLogLikelihood.argtypes = [C.c_int, _dp]
 
     def version(self) -> str:
@@ -397,6 +399,21 @@ class BeagleInstance:
         ms, n = C.c_double(0.0), C.c_long(0)
         self._chk(self.lib.mbamdGetKernelTiming(self.id, C.byref(ms), C.byref(n), 1 if reset else 0), "mbamdGetKernelTiming")
         return ms.value, n.value
+
+    # ---- reports (include/libhmsbeagle/mbamd_reports.h) --------------------------------------------
+    def update_final_partials(self, operations):
+        """operations: int array [n][5] in MbamdFinalOperation field order
+        (destinationPartials, ancestorFinal, downPartials, transitionMatrix, rootTip)."""
+        a = _i(operations).reshape(-1, 5)
+        self._chk(self.lib.mbamdUpdateFinalPartials(self.id, a.ctypes.data_as(C.c_void_p), a.shape[0]), "mbamdUpdateFinalPartials")
+
+    def get_scaled_partials(self, idx, cumulative_scale_index=BEAGLE_OP_NONE):
+        """-> (partials float32 [K][P][S] with the categories of a pattern at one scale, lnScale float32 [P])."""
+        out = np.empty((self.category_count, self.pattern_count, self.state_count), dtype=np.float32)
+        ln = np.empty(self.pattern_count, dtype=np.float32)
+        self._chk(self.lib.mbamdGetScaledPartials(self.id, idx, cumulative_scale_index, out.ctypes.data_as(C.POINTER(C.c_float)),
+                                                  ln.ctypes.data_as(C.POINTER(C.c_float))), "mbamdGetScaledPartials")
+        return out, ln
 
     def get_step_timing(self, reset=True):
         """(ms, spans): device time of whole evaluations (all kernels of a step and the gaps between them)."""

@@ -30,6 +30,8 @@
 
 #include "libhmsbeagle/beagle.h"
 #include "mbamd_kernels.h"
+#include "mbamd_reports.h"
+#include "libhmsbeagle/mbamd_reports.h"
 #include "mbamd_walk4_host.h"
 #if !defined(MBAMD_HOST_EMU)
 #include "mbamd_kernels_mfma.h"
@@ -173,6 +175,8 @@ struct Instance {
     void destroyChildren();
     int getSites(double* out);
     int getScaleExponents(int idx, int* out);
+    int finalPass(const MbamdFinalOperation* ops, int count);
+    int getScaledPartials(int idx, int cumIdx, float* out, float* outLn);
     void closeLog()                  // the first computation: the set-up data is where it belongs, drop the host copies
     {
         if (!logOpen) return;
@@ -711,6 +715,9 @@ int Instance::configureWalk()
     w4.maxSlots1 = std::max(slots, std::min(40, slotsFor(1)));
     if (std::getenv("MBAMD_MAX_LDS_SLOTS")) w4.maxSlots1 = slots;
     if (const char* e = std::getenv("MBAMD_WALK_PREFETCH")) w4.prefetchDistance = std::max(0, std::atoi(e));
+    // measured (profiles/r03_exp_walk4.txt): touching the tip bitplanes 8 entries ahead buys 3 % at 1000 x 50 000 -- all that serving
+    // every tip from one hot line would -- and nothing at 500 x 20 000
+    w4.tipAhead = 8;
     if (const char* e = std::getenv("MBAMD_WALK_TIP_AHEAD")) w4.tipAhead = std::max(0, std::min(32, std::atoi(e)));
     if (const char* e = std::getenv("MBAMD_WALK_TIP_FROM")) w4.tipAheadFrom = std::max(1, std::atoi(e));
     w4.safeWaits = std::getenv("MBAMD_WALK_SAFE") != nullptr;
@@ -2587,6 +2594,79 @@ int Instance::getScaleExponents(int idx, int* out)
     return BEAGLE_SUCCESS;
 }
 
+// ---- reports (csrc/mbamd_reports.h, include/libhmsbeagle/mbamd_reports.h) -------------------------------------------
+int Instance::finalPass(const MbamdFinalOperation* ops, int count)
+{
+    if (S > MBAMD_REP_MAXS) return fail(BEAGLE_ERROR_NO_IMPLEMENTATION, "mbamdUpdateFinalPartials: more than 64 states");
+    for (int o = 0; o < count; ++o) {
+        const MbamdFinalOperation& b = ops[o];
+        if (b.destinationPartials < 0 || b.destinationPartials >= nBuffers || b.downPartials < 0 || b.downPartials >= nBuffers ||
+            b.ancestorFinal >= nBuffers || b.rootTip >= nBuffers)
+            return fail(BEAGLE_ERROR_OUT_OF_RANGE, "mbamdUpdateFinalPartials: partials index");
+        if (b.transitionMatrix < 0 || b.transitionMatrix >= nMatrices) return fail(BEAGLE_ERROR_OUT_OF_RANGE, "mbamdUpdateFinalPartials: matrix index");
+        if (!valid[b.downPartials] || tipStates[b.downPartials]) return fail(BEAGLE_ERROR_OUT_OF_RANGE, "mbamdUpdateFinalPartials: down partials were never computed");
+        if (b.ancestorFinal >= 0 && (!valid[b.ancestorFinal] || tipStates[b.ancestorFinal]))
+            return fail(BEAGLE_ERROR_OUT_OF_RANGE, "mbamdUpdateFinalPartials: the ancestor's final partials are not there");
+        if (tipStates[b.destinationPartials]) return fail(BEAGLE_ERROR_OUT_OF_RANGE, "mbamdUpdateFinalPartials: the destination holds compact tip states");
+        int rc = ensurePartials(b.destinationPartials);
+        if (rc) return rc;
+        FinalOp f;
+        std::memset(&f, 0, sizeof f);
+        f.dst = partials[b.destinationPartials];
+        f.anc = b.ancestorFinal >= 0 ? partials[b.ancestorFinal] : nullptr;
+        f.down = partials[b.downPartials];
+        f.matrix = matrixPtr(b.transitionMatrix);
+        if (b.ancestorFinal < 0 && b.rootTip >= 0) {
+            if (tipStates[b.rootTip]) { f.tip = tipStates[b.rootTip]; f.tipKind = CHILD_STATES; }
+            else if (valid[b.rootTip]) { f.tip = partials[b.rootTip]; f.tipKind = CHILD_PARTIALS; }
+            else return fail(BEAGLE_ERROR_OUT_OF_RANGE, "mbamdUpdateFinalPartials: the root tip was never set");
+        }
+        const dim3 grid((unsigned) ((P + 63) / 64), (unsigned) K);
+        if (s4) MBAMD_LAUNCH(k_final_pass<1>, grid, 64, 0, stream, f, S, SP, K, P, (size_t) geom.pstride, (size_t) geom.tstride);
+        else if (wg) MBAMD_LAUNCH(k_final_pass<2>, grid, 64, 0, stream, f, S, SP, K, P, (size_t) (wgTileBytes / 4), (size_t) wgTipTileBytes);
+        else MBAMD_LAUNCH(k_final_pass<0>, grid, 64, 0, stream, f, S, SP, K, P, (size_t) geom.pstride, (size_t) 0);
+        HIP_TRY(hipGetLastError());
+        valid[b.destinationPartials] = 1;
+    }
+    return BEAGLE_SUCCESS;
+}
+
+int Instance::getScaledPartials(int idx, int cumIdx, float* out, float* outLn)
+{
+    if (idx < 0 || idx >= nBuffers || !valid[idx] || tipStates[idx]) return fail(BEAGLE_ERROR_OUT_OF_RANGE, "mbamdGetScaledPartials: buffer");
+    if (cumIdx != BEAGLE_OP_NONE && (cumIdx < 0 || cumIdx >= nScale)) return fail(BEAGLE_ERROR_OUT_OF_RANGE, "mbamdGetScaledPartials: cumulative scale index");
+    const int32_t *wide = nullptr, *narrow = nullptr;
+    if (cumIdx != BEAGLE_OP_NONE) {
+        if (arena()) {
+            if (scaleState[cumIdx] != 0) {
+                int rc = ensureWide(cumIdx);
+                if (rc) return rc;
+                wide = wideScale[cumIdx];
+            }
+        } else {
+            int rc = ensureScale(cumIdx);
+            if (rc) return rc;
+            narrow = scale[cumIdx];
+        }
+    }
+    const size_t total = (size_t) K * P * S;
+    int rc = grow(&d_tmp, &tmpCap, (total + (size_t) Ppad) * sizeof(float));
+    if (rc) return rc;
+    float* d_out = static_cast<float*>(d_tmp);
+    float* d_ln = d_out + total;
+    const unsigned blocks = (unsigned) ((total + 255) / 256);
+    if (s4) MBAMD_LAUNCH(k_export_scaled<1>, blocks, 256, 0, stream, (const float*) partials[idx], wide, narrow, S, K, P, Ppad, (size_t) geom.pstride, d_out, d_ln);
+    else if (wg) MBAMD_LAUNCH(k_export_scaled<2>, blocks, 256, 0, stream, (const float*) partials[idx], wide, narrow, S, K, P, Ppad, (size_t) (wgTileBytes / 4), d_out, d_ln);
+    else MBAMD_LAUNCH(k_export_scaled<0>, blocks, 256, 0, stream, (const float*) partials[idx], wide, narrow, S, K, P, Ppad, (size_t) geom.pstride, d_out, d_ln);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipStreamSynchronize(stream));
+    syncedClock = launchClock;
+    HIP_TRY(hipMemcpy(out, d_out, total * sizeof(float), hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(outLn, d_ln, (size_t) P * sizeof(float), hipMemcpyDeviceToHost));
+    return BEAGLE_SUCCESS;
+}
+
+
 void Instance::destroyChildren()
 {
     for (Child& ch : children) { ch.in->destroy(); delete ch.in; }
@@ -3609,6 +3689,42 @@ int mbamdFetchLogLikelihood(int instance, double* outSumLogLikelihood)
     if (in->f64) return fail(BEAGLE_ERROR_NO_IMPLEMENTATION, "mbamdFetchLogLikelihood: not on a double-precision instance");
     if (in->facade()) return fail(BEAGLE_ERROR_NO_IMPLEMENTATION, "mbamdFetchLogLikelihood: not on a partitioned / sharded instance");
     return in->fetchResult(outSumLogLikelihood);
+}
+
+
+// ---- reports (include/libhmsbeagle/mbamd_reports.h) -------------------------------------------------------------
+int mbamdUpdateFinalPartials(int instance, const MbamdFinalOperation* operations, int operationCount)
+{
+    GET_INSTANCE(instance);
+    if (in->f64) return fail(BEAGLE_ERROR_NO_IMPLEMENTATION, "mbamdUpdateFinalPartials: not on a double-precision instance");
+    if (operationCount <= 0) return BEAGLE_SUCCESS;
+    if (!operations) return fail(BEAGLE_ERROR_OUT_OF_RANGE, "mbamdUpdateFinalPartials: null");
+    FACADE_ALL(c->finalPass(operations, operationCount));          // (site patterns are independent: every child does its range)
+    return in->finalPass(operations, operationCount);
+}
+int mbamdGetScaledPartials(int instance, int bufferIndex, int cumulativeScaleIndex, float* outPartials, float* outLnScale)
+{
+    GET_INSTANCE(instance);
+    if (in->f64) return fail(BEAGLE_ERROR_NO_IMPLEMENTATION, "mbamdGetScaledPartials: not on a double-precision instance");
+    if (!outPartials || !outLnScale) return fail(BEAGLE_ERROR_OUT_OF_RANGE, "mbamdGetScaledPartials: null");
+    if (!in->facade()) return in->getScaledPartials(bufferIndex, cumulativeScaleIndex, outPartials, outLnScale);
+    if (in->partitionCount > 1) return fail(BEAGLE_ERROR_NO_IMPLEMENTATION, "mbamdGetScaledPartials: not on a multi-partition instance");
+    // pattern shards: each child's [K][count][S] block goes to its pattern range of the caller's [K][P][S] array
+    const int S = in->createArgs[3], P = in->createArgs[4], K = in->createArgs[7];
+    std::vector<float> part, ln;
+    for (Instance::Child& ch : in->children) {
+        Instance* c = ch.in;
+        (void) hipSetDevice(c->device);
+        if (c->hasPending() || !c->pendingJobs.empty()) { int frc = c->flushPending(); if (frc) return frc; }
+        part.resize((size_t) K * ch.count * S);
+        ln.resize((size_t) ch.count);
+        int rc = c->getScaledPartials(bufferIndex, cumulativeScaleIndex, part.data(), ln.data());
+        if (rc) return rc;
+        for (int k = 0; k < K; ++k)
+            std::memcpy(outPartials + ((size_t) k * P + ch.start) * S, part.data() + (size_t) k * ch.count * S, (size_t) ch.count * S * sizeof(float));
+        std::memcpy(outLnScale + ch.start, ln.data(), (size_t) ch.count * sizeof(float));
+    }
+    return BEAGLE_SUCCESS;
 }
 
 

@@ -84,7 +84,7 @@ public:
     int leadNops = 0, unroll = 2, tailNops = 2;
     // 4-state walk, long lists: the kernel touches the tip bitplanes of the entry `tipAhead` ahead at the top of EVERY
     // iteration (two vector-memory instructions: they enter the wait counts) and reads that far beyond the program's end
-    int tipAhead = 0, tipAheadFrom = 128;      // (lists shorter than tipAheadFrom operations run without: root-ward paths)
+    int tipAhead = 0, tipAheadFrom = 128;      // (lists shorter than tipAheadFrom operations run without: root-ward paths); set by the engine
     int lastTipAhead = 0;                      // what the latest build() used (the caller passes it to the kernel)
 
     // ops: one hazard-free segment (no buffer is written twice, none is written after it was read, a buffer read

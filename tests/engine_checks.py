@@ -244,6 +244,66 @@ def check_single_operations(lib, oracle, nstates, ncat, npat, seed=1):
         inst.finalize()
 
 
+def check_final_pass(lib, nstates, ncat, npat, seed=7):
+    """mbamdUpdateFinalPartials / mbamdGetScaledPartials against a numpy restatement of the reference's CondLikeUp_Gen /
+    CondLikeUp_NUC4 (src/likelihood.c:4655-4795) on random data: a three-node path top -> a -> b, the top node with a compact
+    root tip, with a partials root tip and without one (rooted); scaled read-out against the exponents the engine reports."""
+    rng = np.random.default_rng(seed)
+    S, K, P = nstates, ncat, npat
+    inst = bg.BeagleInstance(lib, 2, 12, 2, S, P, 1, 4, K, 4)
+    try:
+        def rand_ti():
+            m = rng.random((K, S, S)) + 0.05
+            return m / m.sum(axis=2, keepdims=True)
+        ti = [rand_ti() for _ in range(3)]
+        for q in range(3):
+            inst.set_transition_matrix(q, ti[q])
+        t32 = [np.ascontiguousarray(t, dtype=np.float32) for t in ti]
+        st = rng.integers(0, S + 1, size=P).astype(np.int32)
+        inst.set_tip_states(0, st)
+        tipvec = np.zeros((P, S), dtype=np.float32)
+        for c in range(P):
+            tipvec[c] = 1.0 if st[c] >= S else 0.0
+            if st[c] < S:
+                tipvec[c, st[c]] = 1.0
+        down = [(rng.random((K, P, S)) * 0.9 + 0.05) * 10.0 ** (-q) for q in range(3)]       # down partials of top, a, b
+        amb = rng.random((K, P, S)) * 0.9 + 0.05                                              # a root tip given as partials
+        for q in range(3):
+            inst.set_partials(2 + q, down[q])
+        inst.set_partials(5, amb)
+        d32 = [np.ascontiguousarray(d, dtype=np.float32) for d in down]
+
+        def up(fa, d, t):                                # one CondLikeUp step, float32 like the reference's CLFlt
+            s = np.einsum("kai,kci->kca", t, d).astype(np.float32)
+            with np.errstate(divide="ignore", invalid="ignore"):
+                u = np.where(s != 0, fa / s, 0).astype(np.float32)
+            return (np.einsum("kci,kai->kca", u, t).astype(np.float32) * d).astype(np.float32)
+
+        for name, root_tip, factor in (("compact root tip", 0, np.einsum("kaj,cj->kca", t32[0], tipvec)),
+                                       ("partials root tip", 5, np.einsum("kaj,kcj->kca", t32[0], amb.astype(np.float32))),
+                                       ("rooted", -1, None)):
+            top = d32[0] if factor is None else (d32[0] * factor.astype(np.float32)).astype(np.float32)
+            fa = up(top, d32[1], t32[1])
+            fb = up(fa, d32[2], t32[2])
+            inst.update_final_partials(np.array([[6, -1, 2, 0, root_tip], [7, 6, 3, 1, -1], [8, 7, 4, 2, -1]], dtype=np.int32))
+            for buf, want in ((6, top), (7, fa), (8, fb)):
+                got = inst.get_partials(buf)
+                assert np.allclose(got, want, rtol=3e-5, atol=1e-30), (name, buf, np.abs(got / want - 1).max())
+            got, ln = inst.get_scaled_partials(8)
+            assert np.array_equal(got, inst.get_partials(8).astype(np.float32)) and np.all(ln == 0)
+        # the scaled read-out: categories brought to the largest exponent of the pattern
+        inst.reset_scale_factors(1)
+        inst.update_partials(np.array([[9, 0, -1, 2, 0, 3, 1]], dtype=np.int32), 1)          # rescaled, exponents also in buffer 1
+        e = inst.get_scale_exponents(1).astype(np.int64)                                      # [K][P]
+        raw = inst.get_partials(9)
+        got, ln = inst.get_scaled_partials(9, 1)
+        emax = e.max(axis=0)
+        assert np.allclose(ln, emax * math.log(2.0), rtol=1e-6)
+        assert np.array_equal(got, (raw * np.exp2(e - emax[None, :])[:, :, None]).astype(np.float32))
+    finally:
+        inst.finalize()
+
+
 def check_hazard_lists(lib, nstates, ncat, npat, seed=5):
     """Operation lists MrBayes never issues but the API allows: a destination that an earlier operation of the same list
     read (write-after-read) or wrote (write-after-write), an exponent buffer written by one operation and read by a

@@ -22,7 +22,8 @@ def test_headers_declare_the_expected_surface():
     names = _declared()
     for must in ("beagleCreateInstance", "beagleUpdatePartials", "beagleCalculateEdgeLogLikelihoods", "beagleGetSiteLogLikelihoods",
                  "beagleUpdatePartialsByPartition", "beagleSetPatternPartitions", "mbamdSetRateMatrices",
-                 "mbamdParsCreateInstance", "mbamdParsDownPass", "mbamdParsFinalPass", "mbamdParsScore"):
+                 "mbamdParsCreateInstance", "mbamdParsDownPass", "mbamdParsFinalPass", "mbamdParsScore",
+                 "mbamdUpdateFinalPartials", "mbamdGetScaledPartials", "mbamdGetStepTiming"):
         assert must in names, must
     assert len(names) == len(set(names)) and len(names) >= 55
 

@@ -51,6 +51,12 @@ def test_single_operations(gpu, oracle, nstates, ncat, npat):
     ec.check_single_operations(gpu, oracle, nstates, ncat, npat)
 
 
+@pytest.mark.parametrize("nstates,ncat,npat", [(4, 4, 1000), (4, 1, 65), (4, 3, 129), (20, 4, 700), (61, 1, 330), (61, 3, 40), (8, 4, 500),
+                                                 (40, 4, 90), (2, 3, 9), (16, 2, 100)])
+def test_final_pass_and_scaled_readout(gpu, nstates, ncat, npat):
+    ec.check_final_pass(gpu, nstates, ncat, npat)
+
+
 @pytest.mark.parametrize("case", SMALL)
 def test_golden_always_rescale(gpu, oracle, golden_dir, case):
     ec.check_golden_case(gpu, oracle, golden_dir, case, lk.MB_BEAGLE_SCALE_ALWAYS)

@@ -39,6 +39,11 @@ def test_single_operations(emu, oracle, nstates, ncat, npat):
     ec.check_single_operations(emu, oracle, nstates, ncat, npat)
 
 
+@pytest.mark.parametrize("nstates,ncat,npat", [(4, 4, 100), (4, 1, 65), (20, 4, 70), (61, 1, 33), (8, 4, 50), (2, 3, 9)])
+def test_final_pass_and_scaled_readout(emu, nstates, ncat, npat):
+    ec.check_final_pass(emu, nstates, ncat, npat)
+
+
 @pytest.mark.parametrize("case", SMALL)
 def test_golden_always_rescale(emu, oracle, golden_dir, case):
     ec.check_golden_case(emu, oracle, golden_dir, case, lk.MB_BEAGLE_SCALE_ALWAYS)

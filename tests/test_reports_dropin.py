@@ -1,0 +1,197 @@
+"""SURVEY 8(f) row 3 through the drop-in boundary: divisions that report ancestral states / site rates / positively selected
+sites / site omegas, and covarion divisions, stay on the engine (the reference switches BEAGLE off for them,
+src/mcmc.c:5760-5771).  The binary is the reference with src/mcmc.c and src/mbbeagle.c patched on the fly by
+oracle/patch_reports.py + integration/mrbayes/mbamd_reports_glue.c (oracle/Makefile: ref-amd-reports); the engine side is
+include/libhmsbeagle/mbamd_reports.h (final pass = CondLikeUp_*, scaled read-out).
+
+Pinned against the reference's OWN read-outs: the same NEXUS file (data, constraints, `report ...`, tree and every
+parameter through `startvals`) runs on oracle/_ref/mb_scalar -- the reference's native kernels; its SIMD build computes a
+wrong likelihood as soon as `report ancstates=yes` selects the scalar kernels (-584 instead of -3815 on the first case
+below), so the scalar build is the oracle here -- and on the patched engine-backed binary; the generation-0 row of the .p
+file (every reported probability / rate / omega, precision=15) must agree column by column.
+
+Site rates are the exception.  PrintSiteRates_Gen (src/mcmc.c:12297-12311) walks the top node's conditional likelihoods
+with ONE running pointer, pattern outermost and category inside -- but they are stored category outermost
+(src/likelihood.c:860-876): with more than one rate category (the only case in which the report is offered) it mixes
+the categories of different patterns, and what it prints depends on the per-pattern SCALE of the stored numbers.  The
+binding hands the function correct inputs in the layout the reference stores (checked: MBAMD_REPORTS_CHECK=1 recomputes
+the division's log-likelihood from exactly those arrays, every read-out), and the printed `r(n)` columns are compared for
+presence and sanity only.  Ancestral-state probabilities, positive-selection probabilities and site omegas index the
+array correctly and are compared to 1e-5.
+
+  * CPU (`not gpu`): oracle/_ref/mb_emu_reports (TEST-ONLY host emulation of the engine)
+  * GPU (`gpu`):     oracle/_ref/mb_amd_reports (mrbayes_amd/libhmsbeagle.so)
+"""
+import os
+import re
+import subprocess
+
+import numpy as np
+import pytest
+
+from mrbayes_amd import data as mbdata
+from mrbayes_amd import tree as mbtree
+from mrbayes_amd.model import AA_ORDER, NUC, sense_codons
+from tools import refrun
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REF_SCALAR = os.path.join(ROOT, "oracle", "_ref", "mb_scalar")
+REF_EMU_REPORTS = os.path.join(ROOT, "oracle", "_ref", "mb_emu_reports")
+REF_AMD_REPORTS = os.path.join(ROOT, "oracle", "_ref", "mb_amd_reports")
+TOL_VALUE = 1e-5          # reported probabilities, rates, omegas (fp32 conditional likelihoods on both sides)
+TOL_LNL_REL = 1e-5
+
+
+def _clades(newick):
+    out, stack = [], []
+    for m in re.finditer(r"\(|\)|t\d+", newick):
+        tok = m.group(0)
+        if tok == "(":
+            stack.append([])
+        elif tok == ")":
+            c = stack.pop()
+            out.append(c)
+            if stack:
+                stack[-1].extend(c)
+        elif stack:
+            stack[-1].append(tok)
+    return out
+
+
+def _rooted_newick(ntaxa, seed):
+    import random
+    rng = random.Random(seed)
+    nodes = [("t%d" % (i + 1), 0.0) for i in range(ntaxa)]
+    while len(nodes) > 1:
+        i, j = sorted(rng.sample(range(len(nodes)), 2))
+        b = nodes.pop(j)
+        a = nodes.pop(i)
+        h = max(a[1], b[1]) + 0.03 * (0.5 + rng.random())
+        nodes.append(("(%s:%.12f,%s:%.12f)" % (a[0], h - a[1], b[0], h - b[1]), h))
+    return nodes[0][0] + ";"
+
+
+CASES = {
+    # name: (kind, ntaxa, nsites, model commands, report, startvals after tau/V, rooted)
+    "dna_anc_rates": ("dna", 12, 300, "lset nst=6 rates=gamma ngammacat=4;", "ancstates=yes siterates=yes",
+                      "Revmat=(0.10,0.30,0.05,0.08,0.40,0.07) Pi=(0.35,0.25,0.15,0.25) Alpha=(0.6)", False),
+    "dna_invgamma_anc": ("dna", 10, 260, "lset nst=6 rates=invgamma ngammacat=4;", "ancstates=yes siterates=yes",
+                         "Revmat=(0.10,0.30,0.05,0.08,0.40,0.07) Pi=(0.35,0.25,0.15,0.25) Alpha=(0.6) Pinvar=(0.2)", False),
+    "dna_clock_anc": ("dna", 10, 200, "lset nst=6 rates=gamma ngammacat=4; prset brlenspr=clock:uniform;", "ancstates=yes",
+                      "Revmat=(0.10,0.30,0.05,0.08,0.40,0.07) Pi=(0.35,0.25,0.15,0.25) Alpha=(0.6)", True),
+    "protein_anc_rates": ("protein", 9, 120, "prset aamodelpr=fixed(wag); lset rates=gamma ngammacat=4;", "ancstates=yes siterates=yes",
+                          "Alpha=(0.8)", False),
+    "codon_m3_possel": ("codon", 7, 60, "lset nucmodel=codon omegavar=M3;", "possel=yes siteomega=yes",
+                        "Omega=(0.1,0.9,2.5,0.5,0.3,0.2)", False),
+    "covarion_dna": ("dna", 10, 240, "lset nst=6 rates=gamma ngammacat=4 covarion=yes;", "ancstates=no",
+                     "Revmat=(0.10,0.30,0.05,0.08,0.40,0.07) Pi=(0.35,0.25,0.15,0.25) Alpha=(0.6) S_cov=(0.4,0.7)", False),
+    "covarion_dna_anc": ("dna", 10, 200, "lset nst=6 rates=gamma ngammacat=4 covarion=yes;", "ancstates=yes siterates=yes",
+                         "Revmat=(0.10,0.30,0.05,0.08,0.40,0.07) Pi=(0.35,0.25,0.15,0.25) Alpha=(0.6) S_cov=(0.4,0.7)", False),
+    "covarion_protein": ("protein", 8, 90, "prset aamodelpr=fixed(wag); lset rates=gamma ngammacat=4 covarion=yes;", "ancstates=no",
+                         "Alpha=(0.8) S_cov=(0.3,0.5)", False),
+}
+
+
+def _nexus(case, beagle):
+    kind, ntaxa, nsites, model, report, vals, rooted = CASES[case]
+    names = ["t%d" % (i + 1) for i in range(ntaxa)]
+    if kind == "dna":
+        st = mbdata.synthetic_states(ntaxa, nsites, 4, 11, 0.15, 0.03)
+        seqs = ["".join((NUC + "-")[x] for x in row) for row in st]
+    elif kind == "protein":
+        st = mbdata.synthetic_states(ntaxa, nsites, 20, 5, 0.15, 0.03)
+        seqs = ["".join((AA_ORDER + "-")[x] for x in row) for row in st]
+    else:
+        st = mbdata.synthetic_states(ntaxa, nsites, 61, 6, 0.15, 0.0)
+        nucs, _ = sense_codons()
+        trip = ["".join(NUC[n] for n in c) for c in nucs]
+        seqs = ["".join(trip[x] for x in row) for row in st]
+    newick = _rooted_newick(ntaxa, 5) if rooted else mbtree.random_tree(ntaxa, 12, brlen=0.05).to_newick(names)
+    cl = [c for c in _clades(newick) if 2 <= len(c) <= max(2, ntaxa // 2)][:2]
+    s = "#NEXUS\nbegin data;\n  dimensions ntax=%d nchar=%d;\n  format datatype=%s interleave=no gap=- missing=?;\n  matrix\n" % (
+        ntaxa, len(seqs[0]), "protein" if kind == "protein" else "dna")
+    for n, q in zip(names, seqs):
+        s += "%s  %s\n" % (n, q)
+    s += "  ;\nend;\nbegin mrbayes;\n  set autoclose=yes nowarnings=yes seed=12345 swapseed=12345 precision=15;\n  %s\n" % model
+    for i, c in enumerate(cl):
+        s += "  constraint c%d = %s;\n" % (i + 1, " ".join(c))
+    s += "  prset topologypr=constraints(%s);\n" % ",".join("c%d" % (i + 1) for i in range(len(cl)))
+    s += "  report %s;\n" % report
+    if beagle:
+        s += "  set usebeagle=yes beagledevice=gpu beagleprecision=single beaglescaling=%s;\n" % beagle
+    s += "end;\nbegin trees;\n  tree t = [&%s] %s\nend;\n" % ("R" if rooted else "U", newick)
+    s += "begin mrbayes;\n  startvals tau=t V=t %s;\n" % vals
+    s += "  mcmc ngen=1 nchains=1 nruns=1 samplefreq=1 printfreq=1 diagnfreq=1 filename=rp;\nend;\n"
+    return s
+
+
+def _row0(binary, case, beagle, env=None):
+    out, _, files = refrun.run_mb(binary, _nexus(case, beagle), keep=("rp.p",), env=env)
+    assert "rp.p" in files, out[-3000:]
+    lines = [l for l in files["rp.p"].splitlines() if l and not l.startswith("[")]
+    return out, lines[0].split("\t"), [float(x) for x in lines[1].split("\t")]
+
+
+def _check(case, binary, marker):
+    _, h0, r0 = _row0(REF_SCALAR, case, None)
+    site_rate = [j for j, name in enumerate(h0) if re.fullmatch(r"r\(\d+\)", name)]
+    for scaling in ("dynamic", "always"):
+        out, h1, r1 = _row0(binary, case, scaling, env={"MBAMD_REPORTS_CHECK": "1"})
+        assert marker in out, out[-2000:]
+        if site_rate or "possel=yes" in CASES[case][4]:
+            assert re.search(r"mbamd reports check: \d+ top-node read-outs reproduced the division's log-likelihood", out), out[-1500:]
+        assert all(np.isfinite(r1[j]) and r1[j] >= 0.0 for j in site_rate)
+        assert "Non-beagle version" not in out, "the division fell back to the reference's own kernels"
+        assert h0 == h1
+        i = h0.index("lnLike")
+        assert abs(r1[i] - r0[i]) <= TOL_LNL_REL * abs(r0[i]), (case, scaling, r1[i], r0[i])
+        reported = [j for j, name in enumerate(h0) if re.match(r"(p\(|r\(\d|pr\+|omega\(\d+,)", name) or "@" in name]
+        if "ancstates=yes" in CASES[case][4] or "siterates=yes" in CASES[case][4] or "possel=yes" in CASES[case][4]:
+            assert len(reported) > 10, h0[:40]
+        cols = [j for j in range(len(h0)) if j != i and j not in site_rate]
+        worst = max((abs(r1[j] - r0[j]) for j in cols), default=0.0)
+        assert worst <= TOL_VALUE, (case, scaling, worst, [(h0[j], r0[j], r1[j]) for j in cols if abs(r1[j] - r0[j]) > TOL_VALUE][:5])
+
+
+def _build_emu():
+    if not os.path.isdir("/root/reference/src"):
+        pytest.skip("reference sources not present (build container only)")
+    from tests.hostemu import build_emu
+    build_emu.build()
+    subprocess.check_call(["make", "-C", os.path.join(ROOT, "oracle"), "_ref/mb_scalar", "_ref/mb_emu_reports"], stdout=subprocess.DEVNULL)
+
+
+@pytest.mark.parametrize("case", sorted(CASES))
+def test_reports_and_covarion_on_emulated_engine(case):
+    _build_emu()
+    _check(case, REF_EMU_REPORTS, "mbamd")
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", sorted(CASES))
+def test_reports_and_covarion_on_mi355x(case):
+    if not (os.path.exists(REF_AMD_REPORTS) and os.path.exists(REF_SCALAR)):
+        pytest.skip("oracle/_ref/mb_amd_reports / mb_scalar were not built (need the reference sources at build time)")
+    _check(case, REF_AMD_REPORTS, "mbamd HIP gfx950")
+
+
+def test_reports_binding_can_be_switched_off():
+    """MBAMD_DEVICE_REPORTS=0: the patched binary takes the reference's own decision (native kernels for the division)."""
+    _build_emu()
+    out, _, _ = _row0(REF_EMU_REPORTS, "dna_anc_rates", "dynamic", env={"MBAMD_DEVICE_REPORTS": "0"})
+    assert "Non-beagle version of conditional likelihood calculator will be used" in out
+
+
+def test_patch_sites_are_pinned():
+    """The patcher refuses a source in which one of its edit sites occurs a different number of times."""
+    if not os.path.isdir("/root/reference/src"):
+        pytest.skip("reference sources not present (build container only)")
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("patch_reports", os.path.join(ROOT, "oracle", "patch_reports.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    with open("/root/reference/src/mcmc.c") as fh:
+        src = fh.read()
+    assert "MbamdReportsUp" in mod.patch_mcmc(src)
+    with pytest.raises(SystemExit):
+        mod.patch_mcmc(src.replace("m->CondLikeUp (node, d, coldId);", "m->CondLikeUp (node, d, chain);"))
