@@ -135,6 +135,64 @@ def mcmc_gen_per_s(gold, nchains=1, quick=True):
     return out
 
 
+def mpi_mcmc(nranks, emulate=False, full=False):
+    """The reference's own chain-parallel design measured on the real binary: MrBayes' MPI build (chains spread over ranks,
+    src/mcmc.c:18331-18384; rank r computes on GPU (instance + r) mod #GPUs, src/mbbeagle.c:201-207) on the single-node MPI shim
+    (integration/mpi_shim), started as `mbamd_mpirun -n <ranks> mb_amd_mpi_pars` -- the binary with the device-parsimony binding
+    (a PATCHED binary: oracle/patch_pars.py), MrBayes' default move mix.  Two analyses, generations/s by two-point differencing:
+      * BASELINE configs[3]: DNA GTR+G4, nchains=8 (alignment: configs[1]'s 500 x 20 000 unless --mpi-full asks for 1000 x 50 000,
+        whose start-up alone takes minutes);
+      * BASELINE configs[4]: codon M3 100 x 5 000, nruns=2 x nchains=4.
+    Only where the reference binaries were built.  emulate: CPU control-flow test (host-emulation engine, tiny data)."""
+    from mrbayes_amd import data as mbdata
+    from mrbayes_amd import tree as mbtree
+    from tools import refrun
+    ref = os.path.join(ROOT, "oracle", "_ref")
+    launcher = os.path.join(ref, "mbamd_mpirun")
+    binary = os.path.join(ref, "mb_emu_mpi" if emulate else "mb_amd_mpi_pars")
+    if not (os.path.exists(launcher) and os.path.exists(binary)):
+        return None
+
+    def wall(text):
+        out, w = refrun.run_mb(binary, text, timeout=3000, argv_prefix=[launcher, "-n", str(nranks)])
+        if "Analysis completed" not in out:
+            raise RuntimeError(out[-1500:])
+        return w
+
+    def rate(nex_of, lo, hi):
+        a, b = wall(nex_of(lo)), wall(nex_of(hi))
+        return (hi - lo) / max(b - a, 1e-9)
+
+    cases = []
+    if emulate:
+        st = mbdata.synthetic_states(8, 60, 4, 11, 0.15, 0.0)
+        tr = mbtree.random_tree(8, 12, brlen=0.05)
+        dna = ("EMULATED tiny DNA, nchains=4", st, tr, 4, (20, 60))
+        cod = None
+    else:
+        with open(os.path.join(GOLD, ("bench_c4" if full else "bench_c2") + ".json")) as fh:
+            gold = json.load(fh)
+        sy = gold["synthetic"]
+        st = mbdata.synthetic_states(sy["ntaxa"], sy["nsites"], 4, sy["seed"], sy["p_mut"], sy["p_gap"])
+        dna = ("configs[3]: DNA %d x %d GTR+G4, nchains=8, default move mix" % (sy["ntaxa"], sy["nsites"]), st, mbtree.parse_newick(gold["newick"]), 8,
+               (200, 1200) if not full else (100, 400))
+        with open(os.path.join(GOLD, "bench_c5.json")) as fh:
+            g5 = json.load(fh)
+        s5 = g5["synthetic"]
+        cod = ("configs[4]: codon M3 %d x %d, nruns=2 x nchains=4, default move mix" % (s5["ntaxa"], s5["nsites"]),
+               mbdata.synthetic_states(s5["ntaxa"], s5["nsites"], 61, s5["seed"], s5["p_mut"], s5["p_gap"]), mbtree.parse_newick(g5["newick"]), (100, 500))
+    label, st, tr, nchains, (lo, hi) = dna
+    r = rate(lambda ngen: refrun.mcmc_nexus(st, tr, ngen, beagle="dynamic", nchains=nchains), lo, hi)
+    cases.append({"workload": label, "chains": nchains, "generations_per_s": r, "ngen": [lo, hi]})
+    if cod is not None:
+        label, st5, tr5, (lo, hi) = cod
+        r = rate(lambda ngen: refrun.model_nexus("m3", st5, tr5, ngen=ngen, beagle="dynamic").replace("nchains=1 nruns=1", "nchains=4 nruns=2"), lo, hi)
+        cases.append({"workload": label, "chains": 8, "generations_per_s": r, "ngen": [lo, hi]})
+    return {"ranks": nranks, "launcher": "oracle/_ref/mbamd_mpirun -n %d oracle/_ref/%s" % (nranks, os.path.basename(binary)),
+            "gpu_of_rank": "(instance + rank) mod visible GPUs (reference src/mbbeagle.c:201-207)", "cases": cases,
+            "unit": "generations/s (all chains advance one generation)"}
+
+
 def measure(args, cfg, steps, warmup, rank, local_rank, world, dist, device, emulate, lib, want_cpu_baseline):
     """One workload: build the division from its golden case, check the lnL against the reference's, time `steps`
     full-tree evaluations.  Returns the JSON object (rank 0) or None."""
@@ -311,6 +369,11 @@ def main():
     ap.add_argument("--no-also", action="store_true", help="skip the other three workloads (c2, c3, c5) at N=1")
     ap.add_argument("--no-mcmc", action="store_true", help="skip whole-MCMC generations/s of the unmodified MrBayes binary")
     ap.add_argument("--mcmc", action="store_true", help="longer MCMC windows (adds minutes)")
+    ap.add_argument("--shard", action="store_true",
+                    help="ONE chain whose site patterns are sharded over the N GPUs inside one engine instance (strong scaling; "
+                         "rank 0 drives all devices, the other ranks idle)")
+    ap.add_argument("--no-mpi", action="store_true", help="skip the MPI-build MCMC measurement (mbamd_mpirun -n N mb_amd_mpi_pars)")
+    ap.add_argument("--mpi-full", action="store_true", help="the MPI measurement's DNA analysis on the 1000 x 50000 alignment (minutes of start-up)")
     ap.add_argument("--emulate", action="store_true",
                     help="TEST ONLY: run the control flow on the CPU (host-emulation engine, gloo, tiny workload); "
                          "the JSON line is marked invalid")
@@ -333,10 +396,11 @@ def main():
     if world > 1:
         import torch.distributed as dist_
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        import datetime
         if emulate:
-            dist_.init_process_group("gloo")
+            dist_.init_process_group("gloo", timeout=datetime.timedelta(minutes=60))
         else:
-            dist_.init_process_group("nccl", device_id=device)
+            dist_.init_process_group("nccl", device_id=device, timeout=datetime.timedelta(minutes=60))
         dist = dist_
 
     from mrbayes_amd import beagle as bg
@@ -346,8 +410,21 @@ def main():
     else:
         lib = bg.library()
 
-    out = measure(args, args.config, args.steps, args.warmup, rank, local_rank, world, dist, device, emulate, lib,
-                  not args.no_cpu_baseline)
+    if args.shard and world > 1:
+        # one chain, site patterns over the N GPUs inside ONE instance (Instance::makeChildren, a child per device): the only
+        # exchange is N doubles added on the host per evaluation.  Rank 0 drives every device; the other ranks wait.
+        out = None
+        if rank == 0:
+            os.environ["MBAMD_SHARD"] = str(world)
+            out = measure(args, args.config, args.steps, args.warmup, 0, 0, 1, None, device, emulate, lib, False)
+            out["n_gpus"] = world
+            out["scaling"] = "strong"
+            out["config"]["chains"] = 1
+            out["config"]["parallelism"] = "site-pattern shards of one chain over %d GPUs inside one instance (MBAMD_SHARD)" % world
+            out["config"]["lnL_pinned"] = False
+    else:
+        out = measure(args, args.config, args.steps, args.warmup, rank, local_rank, world, dist, device, emulate, lib,
+                      not args.no_cpu_baseline)
     if rank == 0 and world == 1 and not emulate:
         if not args.no_also:
             out["also"] = []
@@ -365,6 +442,11 @@ def main():
                     out["mcmc_gen_per_s"] = mcmc_gen_per_s(json.load(fh), quick=not args.mcmc)
             except Exception as exc:
                 out["mcmc_gen_per_s"] = {"error": repr(exc)}
+    if rank == 0 and not args.no_mpi and not (world == 1 and args.no_mcmc):
+        try:
+            out["mpi_mcmc"] = mpi_mcmc(world, emulate=emulate, full=args.mpi_full)
+        except Exception as exc:
+            out["mpi_mcmc"] = {"error": repr(exc)[:600]}
     if rank == 0:
         print(json.dumps(out))
     if dist is not None:

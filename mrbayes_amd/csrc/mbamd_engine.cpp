@@ -102,14 +102,17 @@ static inline int round_up(int v, int m) { return (v + m - 1) / m * m; }
 // every genetic code MrBayes knows (60 vertebrate mitochondrial ... 63; reference src/model.c SetCode)
 static inline bool wg_compiled(int S) { return S == 16 || S == 20 || (S >= 60 && S <= 63); }
 // FN<SC, WMAX, CH, DEPTH>: one row tile -> whole jobs two ahead; two row tiles -> half jobs one ahead (see k_walkg)
+#if !defined(MBAMD_WG_DEPTH61)
+#define MBAMD_WG_DEPTH61 1       // chunks the operand fetch of the 60..63-state kernels runs ahead (experiments: 2)
+#endif
 #define MBAMD_WG_DISPATCH(S, FN, ...)                                   \
     switch (S) {                                                        \
         case 16: FN<16, 8, 1, 2>(__VA_ARGS__); break;                   \
         case 20: FN<20, 8, 1, 2>(__VA_ARGS__); break;                   \
-        case 60: FN<60, 4, 2, 1>(__VA_ARGS__); break;                   \
-        case 61: FN<61, 4, 2, 1>(__VA_ARGS__); break;                   \
-        case 62: FN<62, 4, 2, 1>(__VA_ARGS__); break;                   \
-        default: FN<63, 4, 2, 1>(__VA_ARGS__); break;                   \
+        case 60: FN<60, 4, 2, MBAMD_WG_DEPTH61>(__VA_ARGS__); break;    \
+        case 61: FN<61, 4, 2, MBAMD_WG_DEPTH61>(__VA_ARGS__); break;    \
+        case 62: FN<62, 4, 2, MBAMD_WG_DEPTH61>(__VA_ARGS__); break;    \
+        default: FN<63, 4, 2, MBAMD_WG_DEPTH61>(__VA_ARGS__); break;    \
     }
 
 template <int SC_, int WMAX_, int CH_, int DEPTH_>
@@ -513,7 +516,7 @@ int Instance::create(int tipCount_, int partialsBufferCount, int compactBufferCo
         const size_t tb = wg_block_bytes(S), mf = (size_t) K * 64 * 64 + (size_t) K * wg_table_floats(S);
         wg = !s4 && wg_compiled(S) && K <= 16 && !forceGeneric && !noWalkG && std::getenv("MBAMD_NO_WALKG") == nullptr &&
              (size_t) (nBuffers + 1) * K * tb < ((size_t) 1 << 32) && (size_t) nMatrices * mf * 4 < ((size_t) 1 << 32) &&
-             (size_t) (nScale + 1) * K * 64 < ((size_t) 1 << 32) && (size_t) nBuffers * 32 < ((size_t) 1 << 32);
+             (size_t) (nScale + 1) * K * 64 < ((size_t) 1 << 32) && (size_t) nBuffers * MBAMD_WG_TW < ((size_t) 1 << 32);
     }
     if (s4) SP = 4;
     else if (S <= 4) SP = 4;
@@ -580,9 +583,9 @@ int Instance::create(int tipCount_, int partialsBufferCount, int compactBufferCo
     if (wg) {
         // the same for the 20/61-state tree walk (mbamd_walkg.h): tile-major arenas, one extra partials buffer per tile as
         // the sink of NOP entries; exponents in the 4-state path's format (two tiles per 64-pattern block)
-        const size_t nt = (size_t) Ppad / 32, nb = (size_t) Ppad / 64, tb = wg_block_bytes(S);
+        const size_t nt = (size_t) Ppad / MBAMD_WG_TW, nb = (size_t) Ppad / 64, tb = wg_block_bytes(S);
         wgTileBytes = (unsigned long) (nBuffers + 1) * K * tb;
-        wgTipTileBytes = (unsigned) nBuffers * 32;
+        wgTipTileBytes = (unsigned) nBuffers * MBAMD_WG_TW;
         estride = (unsigned) (scale.size() + 1) * K * 64;
         const size_t pBytes = nt * wgTileBytes, tBytes = nt * wgTipTileBytes, eBytes = nb * (size_t) estride;
         HIP_TRY(hipMalloc(&arenaPartials, pBytes));
@@ -687,7 +690,7 @@ int Instance::configureWalk()
         wgGeometry(1, w4.maxW, w4.maxSlots);
         w4.maxSlots1 = w4.maxSlots;
         if (!std::getenv("MBAMD_WALK_WAVES") && !std::getenv("MBAMD_MAX_LDS_SLOTS")) {   // a single-wave program may use the LDS of the whole workgroup
-            const long wgsG = (long) (Ppad / 32) * K;
+            const long wgsG = (long) (Ppad / MBAMD_WG_TW) * K;
             const int perCUG = (int) std::max(1L, (wgsG + numCU - 1) / numCU);
             w4.maxSlots1 = std::max(w4.maxSlots, std::min(24, (int) (((160 * 1024) / std::min(perCUG, 32) - 64 - MBAMD_WG_STAGE) / (int) slotBytes)));
         }
@@ -696,7 +699,7 @@ int Instance::configureWalk()
         w4.prefetchDistance = 0;
         if (const char* e = std::getenv("MBAMD_WALK_SMALL_PHASE")) w4.smallPhase = std::max(1, std::atoi(e));
         if (envVerbose) std::fprintf(stderr, "[mbamd] tree walk (%d states): %ld workgroups, up to %d waves x %d slots of %u bytes\n",
-                                     S, (long) (Ppad / 32) * K, w4.maxW, w4.maxSlots, slotBytes);
+                                     S, (long) (Ppad / MBAMD_WG_TW) * K, w4.maxW, w4.maxSlots, slotBytes);
         return BEAGLE_SUCCESS;
     }
     const long wgs = (long) (Ppad / 64) * K;
@@ -735,10 +738,14 @@ void Instance::wgGeometry(int lists, int& W, int& slots) const
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0) numCU = prop.multiProcessorCount;
 #endif
-    // registers bound the residency: 20 states 4 waves per SIMD, 61 states 2
+    // registers bound the residency: 32-pattern tiles 4 (20 states) / 2 (61 states) waves per SIMD, 16-pattern tiles 5 / 3
+#if MBAMD_WG_TW == 32
     const int maxW = S > 32 ? 4 : 8, wavesPerCU = S > 32 ? 6 : 12;
+#else
+    const int maxW = S > 32 ? 4 : 8, wavesPerCU = S > 32 ? 12 : 20;
+#endif
     const int slotBytes = (int) wg_block_bytes(S);
-    const long wgs = (long) (Ppad / 32) * K * lists;
+    const long wgs = (long) (Ppad / MBAMD_WG_TW) * K * lists;
     const int perCU = (int) std::max(1L, (wgs + numCU - 1) / numCU);
     const int ldsPerWG = (160 * 1024) / std::min(perCU, 32) - 64;
     auto slotsFor = [&](int w) { return (ldsPerWG / w - MBAMD_WG_STAGE) / slotBytes; };
@@ -777,9 +784,9 @@ int Instance::setTipStates(int tip, const int* states)
     }
     if (wg) {                                    // 32 state codes per (tile, tip) in the tip arena
         HIP_TRY(hipStreamSynchronize(stream));
-        HIP_TRY(hipMemcpy2D(arenaTipStates + (size_t) tip * 32, (size_t) wgTipTileBytes, h.data(), 32, 32, (size_t) Ppad / 32, hipMemcpyHostToDevice));
+        HIP_TRY(hipMemcpy2D(arenaTipStates + (size_t) tip * MBAMD_WG_TW, (size_t) wgTipTileBytes, h.data(), MBAMD_WG_TW, MBAMD_WG_TW, (size_t) Ppad / MBAMD_WG_TW, hipMemcpyHostToDevice));
         if (!tipStates[tip]) layoutEpoch++;
-        tipStates[tip] = arenaTipStates + (size_t) tip * 32;
+        tipStates[tip] = arenaTipStates + (size_t) tip * MBAMD_WG_TW;
         return BEAGLE_SUCCESS;
     }
     if (!tipStates[tip]) { HIP_TRY(hipMalloc(&tipStates[tip], (size_t) Ppad)); layoutEpoch++; }
@@ -1528,10 +1535,10 @@ int Instance::buildWalk(Plan& plan, const BeagleOperation* ops, int n, const int
                 if (te.op >= 0) {
                     const Walk4Op& op = seg[te.op];
                     e.dst = (uint32_t) op.dst * pbuf;
-                    if (op.tip1) { e.c1 = (uint32_t) op.c1 * 32u; flags |= MBAMD_W4_TIP1; }
+                    if (op.tip1) { e.c1 = (uint32_t) op.c1 * (uint32_t) MBAMD_WG_TW; flags |= MBAMD_W4_TIP1; }
                     else if (te.c1slot == 0xFF) { e.c1 = (uint32_t) op.c1 * pbuf; flags |= MBAMD_WG_MEM1; }
                     else e.c1 = (uint32_t) te.c1slot * slotb;
-                    if (op.tip2) { e.c2 = (uint32_t) op.c2 * 32u; flags |= MBAMD_W4_TIP2; }
+                    if (op.tip2) { e.c2 = (uint32_t) op.c2 * (uint32_t) MBAMD_WG_TW; flags |= MBAMD_W4_TIP2; }
                     else if (te.c2slot == 0xFF) { e.c2 = (uint32_t) op.c2 * pbuf; flags |= MBAMD_WG_MEM2; }
                     else e.c2 = (uint32_t) te.c2slot * slotb;
                     e.m1 = (uint32_t) op.m1 * mbuf;
@@ -1907,11 +1914,11 @@ static void launch_walkg_t(Instance& in, const WalkGArgs& a, int W, int nslots, 
         ai.a.prog = nullptr;
         std::memcpy(ai.inl, inlineProg->data(), inlineProg->size() * sizeof(Walk4Entry));
         auto kern = k_walkg<SC_, WMAX_, CH_, DEPTH_, WalkGArgsInline>;
-        MBAMD_LAUNCH_BARRIER(kern, walkg_grid(in.Ppad / 32, in.K * a.lists), 64 * W * (a.spread ? 2 : 1), wg_lds_bytes(W, nslots, in.S), in.stream, ai);
+        MBAMD_LAUNCH_BARRIER(kern, walkg_grid(in.Ppad / MBAMD_WG_TW, in.K * a.lists), 64 * W * (a.spread ? 2 : 1), wg_lds_bytes(W, nslots, in.S), in.stream, ai);
         return;
     }
     auto kern = k_walkg<SC_, WMAX_, CH_, DEPTH_>;
-    MBAMD_LAUNCH_BARRIER(kern, walkg_grid(in.Ppad / 32, in.K * a.lists), 64 * W * (a.spread ? 2 : 1), wg_lds_bytes(W, nslots, in.S), in.stream, a);
+    MBAMD_LAUNCH_BARRIER(kern, walkg_grid(in.Ppad / MBAMD_WG_TW, in.K * a.lists), 64 * W * (a.spread ? 2 : 1), wg_lds_bytes(W, nslots, in.S), in.stream, a);
 }
 
 int Instance::runWalkG(const Plan& plan)
@@ -1934,7 +1941,7 @@ int Instance::runWalkG(const Plan& plan)
         a.tabBytes = (unsigned) (wg_table_floats(S) * 4);
         for (int q = 0; q < MBAMD_WG_MAXLISTS; ++q) a.cum[q] = wgCum[q];
         a.cumFresh = (&sg == &plan.segments.front()) ? wgFresh : 0;
-        a.K = K; a.Ppad = Ppad; a.ntiles = Ppad / 32; a.S = S; a.SP = SP;
+        a.K = K; a.Ppad = Ppad; a.ntiles = Ppad / MBAMD_WG_TW; a.S = S; a.SP = SP;
         a.lists = plan.lists;
 #if !defined(MBAMD_HOST_EMU)
         a.spread = sg.W == 2 ? 1 : 0;
@@ -2959,7 +2966,7 @@ int beagleCreateInstance(int tipCount, int partialsBufferCount, int compactBuffe
         returnInfo->resourceName = (dev < g_resources.length) ? g_resources.list[dev].name : const_cast<char*>("HIP device");
         returnInfo->implName = const_cast<char*>(first->f64 ? "mbamd HIP gfx950: double-precision level kernels"
                                                  : first->s4 ? "mbamd HIP gfx950: 4-state tree-walk kernels"
-                                                 : first->wg ? "mbamd HIP gfx950: 20/61-state tree-walk kernels (v_mfma_f32_32x32x2_f32)"
+                                                 : first->wg ? (MBAMD_WG_TW == 32 ? "mbamd HIP gfx950: 20/61-state tree-walk kernels (v_mfma_f32_32x32x2_f32)" : "mbamd HIP gfx950: 20/61-state tree-walk kernels (v_mfma_f32_16x16x4_f32)")
                                                  : first->mfma ? "mbamd HIP gfx950: general-state MFMA (v_mfma_f32_32x32x2_f32) kernels"
                                                                : "mbamd HIP gfx950: general-state vector kernels");
         returnInfo->implDescription = const_cast<char*>("hand-written HIP kernels for AMD CDNA4 (MI355X)");

@@ -771,7 +771,7 @@ k_exp_copy(int8_t* __restrict__ arena, unsigned estride, int src, int dst, int K
 // arena (pstride = floats between tiles; `out` / `in` = the buffer's block in tile 0)
 __host__ __device__ inline size_t wg_index(int S, size_t tileFloats, int k, int i, int c)
 {
-    return (size_t) (c >> 5) * tileFloats + (size_t) k * wg_pairs_padded(S) * 64 + wg_elem(S, i, c & 31);
+    return (size_t) (c / MBAMD_WG_TW) * tileFloats + (size_t) k * wg_pairs_padded(S) * 64 + wg_elem(S, i, c % MBAMD_WG_TW);
 }
 template <int LAYOUT>
 __global__ void __launch_bounds__(256)

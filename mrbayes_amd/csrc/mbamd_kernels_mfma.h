@@ -908,18 +908,19 @@ k_integrate_lnl_wide(IntegrateArgs a, int S, int SP, int K, int P, int Ppad, con
 }
 
 // The same for the tree-walk layout (mbamd_walkg.h: partials [tile][buffer][K] blocks in wg_at order, tip states
-// [tile][buffer][32], cumulative exponents per pattern AND category): eight threads per pattern, the categories recombined
-// exactly as in k_integrate_lnl_s4.  grid = P_pad/32, block = 256.
+// [tile][buffer][TW], cumulative exponents per pattern AND category): eight threads per pattern, the categories recombined
+// exactly as in k_integrate_lnl_s4.  grid = P_pad/32, block = 256 (32 patterns: one or two tiles).
 __global__ void __launch_bounds__(256)
 k_integrate_lnl_wg_wide(IntegrateArgs4 a, int S, int SP, int K, int P, int Ppad, WgGeom geo, const double* __restrict__ pattern_weights,
                         double* __restrict__ site, double* __restrict__ wsite)
 {
     __shared__ double part[8][32];
     const int p = threadIdx.x & 31, g = threadIdx.x >> 5;
-    const int sh = S > 32 ? 2 : 1;                   // rows interleaved per lane: wg_vec(S) = 1 << sh
+    const int sh = wg_vec_shift(S);                  // rows interleaved per lane: wg_vec(S) = 1 << sh
     const int c = blockIdx.x * 32 + p;
     const bool live = c < P;
-    const size_t pb = (size_t) blockIdx.x * geo.tileFloats, kstride = (size_t) geo.TP * 64;
+    const int tile = c / MBAMD_WG_TW, pt = c % MBAMD_WG_TW;      // this pattern's tile and its column there
+    const size_t pb = (size_t) tile * geo.tileFloats, kstride = (size_t) geo.TP * 64;
     int emax = -2147483647;
     double like = 0.0;
     if (live) {
@@ -933,7 +934,7 @@ k_integrate_lnl_wg_wide(IntegrateArgs4 a, int S, int SP, int K, int P, int Ppad,
             const double* __restrict__ fr = a.freqs[n];
             unsigned s = 0;
             if (a.child[n] != nullptr && a.child_kind[n] == CHILD_STATES)
-                s = reinterpret_cast<const uint8_t*>(a.child[n])[(size_t) blockIdx.x * geo.tipTileBytes + p];
+                s = reinterpret_cast<const uint8_t*>(a.child[n])[(size_t) tile * geo.tipTileBytes + pt];
             for (int k = 0; k < K; ++k) {
                 const float* __restrict__ pk = par + (size_t) k * kstride;
                 double cat = 0.0;
@@ -944,7 +945,7 @@ k_integrate_lnl_wg_wide(IntegrateArgs4 a, int S, int SP, int K, int P, int Ppad,
 #pragma unroll
                         for (int u = 0; u < 8; ++u) {
                             const int i = i0 + g + 8 * u;
-                            v[u] = (i < S) ? pk[wg_elem_sh(sh, i, p)] : 0.0f;
+                            v[u] = (i < S) ? pk[wg_elem_sh(sh, i, pt)] : 0.0f;
                             f[u] = (i < S) ? fr[i] : 0.0;
                         }
 #pragma unroll
@@ -954,15 +955,15 @@ k_integrate_lnl_wg_wide(IntegrateArgs4 a, int S, int SP, int K, int P, int Ppad,
                     const float* __restrict__ mrow = a.matrix[n] + (size_t) k * SP * SP + (size_t) (s < (unsigned) S ? s : 0) * SP;
                     for (int i = g; i < S; i += 8) {
                         const float pc = (s >= (unsigned) S) ? 1.0f : mrow[i];
-                        cat += (double) (pk[wg_elem_sh(sh, i, p)] * pc) * fr[i];
+                        cat += (double) (pk[wg_elem_sh(sh, i, pt)] * pc) * fr[i];
                     }
                 } else {
                     const float* __restrict__ ch = reinterpret_cast<const float*>(a.child[n]) + pb + (size_t) k * kstride;
                     const float* __restrict__ m = a.matrix[n] + (size_t) k * SP * SP;
                     for (int i = g; i < S; i += 8) {
                         float acc = 0.0f;
-                        for (int j = 0; j < S; ++j) acc = fmaf(m[(size_t) j * SP + i], ch[wg_elem_sh(sh, j, p)], acc);
-                        cat += (double) (pk[wg_elem_sh(sh, i, p)] * acc) * fr[i];
+                        for (int j = 0; j < S; ++j) acc = fmaf(m[(size_t) j * SP + i], ch[wg_elem_sh(sh, j, pt)], acc);
+                        cat += (double) (pk[wg_elem_sh(sh, i, pt)] * acc) * fr[i];
                     }
                 }
                 const int e = a.cum[n] ? a.cum[n][(size_t) k * Ppad + c] : 0;

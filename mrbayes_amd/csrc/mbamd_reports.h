@@ -37,7 +37,7 @@ __device__ __forceinline__ float rep_tip(const void* tip, int S, size_t tstride,
         const uint64_t* planes = reinterpret_cast<const uint64_t*>(tip) + (size_t) (c >> 6) * tstride;
         return (float) (planes[j] >> (c & 63) & 1u);
     }
-    const unsigned s = LAYOUT == 2 ? reinterpret_cast<const uint8_t*>(tip)[(size_t) (c >> 5) * tstride + (c & 31)]
+    const unsigned s = LAYOUT == 2 ? reinterpret_cast<const uint8_t*>(tip)[(size_t) (c / MBAMD_WG_TW) * tstride + (c % MBAMD_WG_TW)]
                                    : reinterpret_cast<const uint8_t*>(tip)[c];
     return (s >= (unsigned) S || s == (unsigned) j) ? 1.0f : 0.0f;
 }

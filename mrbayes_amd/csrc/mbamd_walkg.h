@@ -43,45 +43,90 @@ namespace mbamd {
 #define MBAMD_WG_TAIL     3      // trailing NOP entries (descriptor read-ahead)
 #define MBAMD_WG_STAGE    256    // bytes per wave in front of its slots (cumulative-exponent hand-over)
 
-__host__ __device__ inline int wg_pairs(int S) { return (S + 1) / 2; }                    // T: MFMA steps (two states each)
-__host__ __device__ inline int wg_tiles(int S) { return (S + 31) / 32; }                  // NT: 32-row output tiles
-__host__ __device__ inline int wg_vec(int S) { return S > 32 ? 4 : 2; }                   // V: floats per lane and memory instruction
+// Tile width: patterns per wave.  32 = v_mfma_f32_32x32x2_f32 (two states per MFMA step, lane = 32 h + pattern), 16 =
+// v_mfma_f32_16x16x4_f32 (four states per step, lane = 16 g + pattern): twice the waves for the same alignment, each with half
+// the accumulators, half the epilogue and a 40- instead of 64-cycle dependent MFMA latency.  One or the other per build.
+// MEASURED (round 3, profiles/r03_exp_walkg_tile16_ablation.txt): 16 is bit-for-bit as correct (every GPU parity test) and
+// SLOWER -- codon 100 x 5 000: 0.32 against 0.19 ms, protein 200 x 10 000: 0.34 (0.28 with one wave per workgroup) against
+// 0.23 ms -- because every wave fetches the whole A table of every child whatever its tile width: halving the tile doubles
+// that traffic, and the operand fetch is what bounds the kernel (with the fetch ablated 16 beats 32: 0.104 against 0.118 ms).
+// The product is built with 32; -DMBAMD_WG_TW=16 keeps the other one buildable (tools/build_variants.py).
+#if !defined(MBAMD_WG_TW)
+#define MBAMD_WG_TW 32
+#endif
+#define MBAMD_WG_KS (64 / MBAMD_WG_TW)    // states per row of a block = per MFMA step (2 or 4)
+__host__ __device__ inline int wg_pairs(int S) { return (S + MBAMD_WG_KS - 1) / MBAMD_WG_KS; }         // T: MFMA steps (rows of a block)
+__host__ __device__ inline int wg_tiles(int S) { return (S + MBAMD_WG_TW - 1) / MBAMD_WG_TW; }         // NT: output tiles of TW rows
+#if MBAMD_WG_TW == 32
+__host__ __device__ inline int wg_vec(int S) { return S > 32 ? 4 : 2; }                   // V: floats per lane and memory instruction (blocks)
+__host__ __device__ inline int wg_vec_a(int S) { return wg_vec(S); }                      // VA: the same for the tables
+#else
+// blocks: 61 states 16 rows (V 4), 20 states 5 rows (V 1: no padding bytes -- the time follows the bytes), 16 states 4 rows
+__host__ __device__ inline int wg_vec(int S) { const int T = wg_pairs(S); return (S > 32 || T % 4 == 0) ? 4 : (T % 2 == 0 ? 2 : 1); }
+// tables: rows n = t NT + it; 61 states 64 rows (VA 4), 20 states 10 rows (VA 2), 16 states 4 rows (VA 4)
+__host__ __device__ inline int wg_vec_a(int S) { const int n = wg_pairs(S) * wg_tiles(S); return (S > 32 || n % 4 == 0) ? 4 : (n % 2 == 0 ? 2 : 1); }
+#endif
 __host__ __device__ inline int wg_pairs_padded(int S) { return (wg_pairs(S) + wg_vec(S) - 1) / wg_vec(S) * wg_vec(S); }   // TP
-__host__ __device__ inline int wg_rows(int S) { return wg_pairs_padded(S) * wg_tiles(S); }      // NAP: 256-byte rows of a table
-__host__ __device__ inline int wg_subtables(int S) { return S / 32 + 1; }                 // gather tables: states 0..S in groups of 32 (S = "missing")
+__host__ __device__ inline int wg_rows(int S)                                             // NAP: 256-byte rows of a table
+{
+    const int n = wg_pairs_padded(S) * wg_tiles(S), va = wg_vec_a(S);
+    return (n + va - 1) / va * va;
+}
+__host__ __device__ inline int wg_subtables(int S) { return S / MBAMD_WG_TW + 1; }        // gather tables: states 0..S in groups of TW (S = "missing")
 __host__ __device__ inline unsigned wg_block_bytes(int S) { return (unsigned) wg_pairs_padded(S) * 256u; }   // one (tile, buffer, category) = one LDS slot
 __host__ __device__ inline size_t wg_table_floats(int S) { return (size_t) (1 + wg_subtables(S)) * wg_rows(S) * 64; }   // per category
 __host__ __device__ inline size_t wg_lds_bytes(int W, int nslots, int S) { return (size_t) W * (MBAMD_WG_STAGE + (size_t) nslots * wg_block_bytes(S)); }
-// A block holds [TP rows][64 lanes]: row t, lane 32 h + p = state 2t + h of pattern p; V consecutive rows are interleaved
-// per lane so that one dwordx2 / dwordx4 per lane moves V rows (1/2 - 1 KiB contiguous per wave instruction).
+// A block holds [TP rows][64 lanes]: row t, lane TW h + p = state KS t + h of pattern p; V consecutive rows are interleaved
+// per lane so that one dword / dwordx2 / dwordx4 per lane moves V rows (256 B - 1 KiB contiguous per wave instruction).
 // float offset of (row r, lane / column c) inside a block or table:
 __host__ __device__ inline unsigned wg_at(int V, int r, int c) { return (unsigned) ((r / V) * 64 * V + c * V + r % V); }
-// the same with V = 1 << sh (V is 2 or 4): no integer division in a kernel's inner loop
-__host__ __device__ inline unsigned wg_elem_sh(int sh, int i, int p) { const int r = i >> 1; return (unsigned) (((r >> sh) << (6 + sh)) + ((((i & 1) << 5) + p) << sh) + (r & ((1 << sh) - 1))); }
-__host__ __device__ inline unsigned wg_elem(int S, int i, int p) { return wg_at(wg_vec(S), i >> 1, (i & 1) * 32 + p); }   // state i, pattern p
+// the same with V = 1 << sh: no integer division in a kernel's inner loop
+__host__ __device__ inline unsigned wg_elem_sh(int sh, int i, int p)
+{
+    const int r = i / MBAMD_WG_KS, lane = (i % MBAMD_WG_KS) * MBAMD_WG_TW + p;
+    return (unsigned) (((r >> sh) << (6 + sh)) + (lane << sh) + (r & ((1 << sh) - 1)));
+}
+__host__ __device__ inline int wg_vec_shift(int S) { const int v = wg_vec(S); return v == 4 ? 2 : (v == 2 ? 1 : 0); }
+__host__ __device__ inline unsigned wg_elem(int S, int i, int p) { return wg_at(wg_vec(S), i / MBAMD_WG_KS, (i % MBAMD_WG_KS) * MBAMD_WG_TW + p); }   // state i, pattern p
 
-// Tables of one (matrix, category): rows n = t * NT + it (< NAP), 64 columns, stored like blocks (wg_at):
-//   A'  (n, lane)        = P(row_state(it, lane & 31) -> 2t + (lane >> 5))      MFMA A operand of step t, tile it
-//   G_u (n, 2 s5 + h)    = P(32 it + 2t + h -> 32 u + s5),  t < 16              tip gather: lane (pattern with state
-//                          32u + s5, half h) reads column 2 s5 + h of the rows n -> register (it, r = t)
+// Tables of one (matrix, category): rows n = t * NT + it (< NAP), 64 columns, stored like blocks (wg_at with VA):
+//   A'  (n, lane)         MFMA A operand of step t, output tile it
+//   G_u (n, column)       tip gather: the lane of a pattern with state TW u + s reads ITS column of the rows n = r NT + it
+//                         and has the factor registers (it, r) of a compact tip -- no MFMA
 //       the column of state S ("missing") holds 1 for every existing from-state.
-// row_state: the state carried by row i of output tile it such that register r, half h ends up with state 32 it + 2 r + h
-__host__ __device__ inline int wg_row_state(int it, int i) { return 32 * it + 2 * ((i & 3) + 4 * (i >> 3)) + ((i >> 2) & 1); }
+// The ROWS of A' are permuted so that the output tile lands in block layout (register r of lane group h = the state the
+// next MFMA step t = ... wants there):
+//   TW 32:  register r, half h           = state 32 it + 2 r + h;   A'(n, 32 (j & 1) + row) with row = (r & 3) + 8 (r >> 2) + 4 h
+//           G_u(n = r NT + it, 2 s + h)
+//   TW 16:  register r (0..3), group g   = state 16 it + 4 r + g;   A'(n, 16 (j & 3) + row) with row = 4 g + r
+//           G_u(n = r NT + it, 4 s + g)
 // scatter P_k(i -> j) = v into the tables of category k (tab = first float of that category's tables)
 __host__ __device__ inline void wg_table_put(float* tab, int S, int i, int j, float v)
 {
-    const int NT = wg_tiles(S), NAP = wg_rows(S), V = wg_vec(S);
+    const int NT = wg_tiles(S), NAP = wg_rows(S), VA = wg_vec_a(S);
+#if MBAMD_WG_TW == 32
     const int it = i >> 5, r = (i & 31) >> 1, h = i & 1;
     const int row = (r & 3) + 8 * (r >> 2) + 4 * h;                        // MFMA row that carries state i
-    tab[wg_at(V, (j >> 1) * NT + it, row + 32 * (j & 1))] = v;             // A'
-    tab[(size_t) (1 + (j >> 5)) * NAP * 64 + wg_at(V, r * NT + it, 2 * (j & 31) + h)] = v;   // G_u
+    tab[wg_at(VA, (j >> 1) * NT + it, row + 32 * (j & 1))] = v;            // A'
+    tab[(size_t) (1 + (j >> 5)) * NAP * 64 + wg_at(VA, r * NT + it, 2 * (j & 31) + h)] = v;   // G_u
+#else
+    const int it = i >> 4, r = (i & 15) >> 2, g = i & 3;
+    const int row = 4 * g + r;
+    tab[wg_at(VA, (j >> 2) * NT + it, row + 16 * (j & 3))] = v;            // A'
+    tab[(size_t) (1 + (j >> 4)) * NAP * 64 + wg_at(VA, r * NT + it, 4 * (j & 15) + g)] = v;   // G_u
+#endif
 }
 // the "missing" column (constant): from-state i
 __host__ __device__ inline void wg_table_put_missing(float* tab, int S, int i)
 {
-    const int NT = wg_tiles(S), NAP = wg_rows(S), V = wg_vec(S);
+    const int NT = wg_tiles(S), NAP = wg_rows(S), VA = wg_vec_a(S);
+#if MBAMD_WG_TW == 32
     const int it = i >> 5, r = (i & 31) >> 1, h = i & 1;
-    tab[(size_t) (1 + (S >> 5)) * NAP * 64 + wg_at(V, r * NT + it, 2 * (S & 31) + h)] = 1.0f;
+    tab[(size_t) (1 + (S >> 5)) * NAP * 64 + wg_at(VA, r * NT + it, 2 * (S & 31) + h)] = 1.0f;
+#else
+    const int it = i >> 4, r = (i & 15) >> 2, g = i & 3;
+    tab[(size_t) (1 + (S >> 4)) * NAP * 64 + wg_at(VA, r * NT + it, 4 * (S & 15) + g)] = 1.0f;
+#endif
 }
 // one thread per (matrix, category, state): the constant column of every matrix buffer, once per instance
 __global__ void __launch_bounds__(256)
@@ -99,7 +144,7 @@ struct WalkGArgs {
     int nslots;
     float* partials;             // arena float [tile][buffer][K] blocks of wg_block_bytes (wg_at layout)
     unsigned long tileBytes;     // bytes between tiles
-    const uint8_t* tips;         // arena uint8 [tile][buffer][32]   state codes, S = missing
+    const uint8_t* tips;         // arena uint8 [tile][buffer][TW]   state codes, S = missing
     unsigned tipTileBytes;
     int8_t* exps;                // arena int8 [tile / 2][scale buffer][K][64] (the 4-state path's format)
     unsigned estride;            // bytes between 64-pattern blocks
@@ -135,17 +180,42 @@ __device__ __forceinline__ const Walk4Entry* wg_program(const WalkGArgsInline&)
 #include "mbamd_walkg_emu.h"     // tests/hostemu/ (test build only): a plain-loop twin of k_walkg for CPU CI of the host logic
 #else
 
-typedef float wg_f16 __attribute__((ext_vector_type(16)));
+// V floats of one lane: a clang vector, or -- V = 1 -- a plain float (vectors of one element are not loadable types)
+template <int V> struct WgVecT {
+    typedef float type __attribute__((ext_vector_type(V)));
+    static __device__ __forceinline__ float get(const type& v, int i) { return v[i]; }
+    static __device__ __forceinline__ void set(type& v, int i, float x) { v[i] = x; }
+    static __device__ __forceinline__ type splat(float x) { return (type) (x); }
+};
+template <> struct WgVecT<1> {
+    typedef float type;
+    static __device__ __forceinline__ float get(const type& v, int) { return v; }
+    static __device__ __forceinline__ void set(type& v, int, float x) { v = x; }
+    static __device__ __forceinline__ type splat(float x) { return x; }
+};
 
 template <int SC> struct WgShape {
-    static constexpr int T = (SC + 1) / 2, NT = (SC + 31) / 32, V = SC > 32 ? 4 : 2;
-    static constexpr int TP = (T + V - 1) / V * V, NAP = NT * TP;
-    typedef float vec __attribute__((ext_vector_type(V)));
+    static constexpr int TW = MBAMD_WG_TW, KS = MBAMD_WG_KS;
+    static constexpr int T = (SC + KS - 1) / KS, NT = (SC + TW - 1) / TW;
+#if MBAMD_WG_TW == 32
+    static constexpr int V = SC > 32 ? 4 : 2, VA = V;
+    static constexpr int ACC = 16;                   // accumulator registers per output tile (32 x 32 / 64 lanes)
+#else
+    static constexpr int V = (SC > 32 || T % 4 == 0) ? 4 : (T % 2 == 0 ? 2 : 1);
+    static constexpr int VA = (SC > 32 || (T * NT) % 4 == 0) ? 4 : ((T * NT) % 2 == 0 ? 2 : 1);
+    static constexpr int ACC = 4;                    // 16 x 16 / 64 lanes
+#endif
+    static constexpr int TP = (T + V - 1) / V * V, NAP = (TP * NT + VA - 1) / VA * VA;
+    typedef WgVecT<V> Vb;                            // block rows (B operand, results)
+    typedef WgVecT<VA> Va;                           // table rows (A operand, tip gathers)
+    typedef typename Vb::type vec;
+    typedef typename Va::type vecA;
+    typedef float acc __attribute__((ext_vector_type(ACC)));
 };
-// one CHUNK of a job's operands: a job (one child factor) is CH chunks of T / CH MFMA steps
+// one CHUNK of a job's operands: a job (one child factor) is CH chunks of TP / CH MFMA steps
 template <int SC, int CH> struct WgOperands {
-    typename WgShape<SC>::vec a[WgShape<SC>::NAP / WgShape<SC>::V / CH];   // A rows of the chunk (or the tip's gather rows), V rows per register group
-    typename WgShape<SC>::vec b[WgShape<SC>::TP / WgShape<SC>::V / CH];    // B rows of a child read from HBM
+    typename WgShape<SC>::vecA a[WgShape<SC>::NAP / WgShape<SC>::VA / CH];  // A rows of the chunk (or the tip's gather rows), VA rows per register group
+    typename WgShape<SC>::vec b[WgShape<SC>::TP / WgShape<SC>::V / CH];     // B rows of a child read from HBM
 };
 struct WgDesc {
     Walk4Entry e;
@@ -172,13 +242,19 @@ k_walkg(ARGS AA)
     const WalkGArgs& A = wg_args(AA);
     typedef WgShape<SC> Sh;
     typedef typename Sh::vec vec;
+    typedef typename Sh::vecA vecA;
+    typedef typename Sh::Vb Vb;
+    typedef typename Sh::Va Va;
+    typedef typename Sh::acc acc_t;
     typedef WgOperands<SC, CH> Ops;
-    constexpr int T = Sh::T, NT = Sh::NT, V = Sh::V, TP = Sh::TP, NAP = Sh::NAP, NAV = NAP / V, TV = TP / V;
+    constexpr int TW = Sh::TW, KS = Sh::KS, ACC = Sh::ACC;
+    constexpr int T = Sh::T, NT = Sh::NT, V = Sh::V, VA = Sh::VA, TP = Sh::TP, NAP = Sh::NAP, NAV = NAP / VA, TV = TP / V;
     constexpr int TPC = TP / CH, NAVC = NAV / CH, TVC = TV / CH;      // per chunk: MFMA steps, A register groups, B register groups
     constexpr int NQ = 2 * CH, NS = DEPTH + 1;                        // chunks per entry, register sets
-    static_assert(TP % CH == 0 && TPC % V == 0 && NS <= 3 && DEPTH <= NQ && TPC <= 16, "chunk geometry");
+    static_assert(TP % CH == 0 && TPC % V == 0 && NAV % CH == 0 && (TPC * NT) % VA == 0 && NS <= 3 && DEPTH <= NQ && TPC <= 16, "chunk geometry");
+    static_assert((ACC < T ? ACC : T) * NT <= NAVC * VA, "a compact tip's gather rows must lie in the first chunk");
     constexpr unsigned SLOTB = TP * 256u;
-    const unsigned lane = threadIdx.x & 63, half = lane >> 5, col = lane & 31;
+    const unsigned lane = threadIdx.x & 63, half = lane / TW, col = lane % TW;      // half: which of the KS states of a row
     int wave = __builtin_amdgcn_readfirstlane((int) (threadIdx.x >> 6));
     int W = (int) (blockDim.x >> 6);
     // Two-wave workgroups land on one SIMD pair of the CU and leave the other pair's matrix cores idle (measured: 73 against
@@ -199,7 +275,7 @@ k_walkg(ARGS AA)
     // wave-uniform bases; the entries hold byte offsets from them
     char* const P0 = reinterpret_cast<char*>(A.partials) + (size_t) tile * A.tileBytes + (size_t) k * SLOTB;
     const uint8_t* const T0 = A.tips + (size_t) tile * A.tipTileBytes;
-    int8_t* const E0 = A.exps + (size_t) (tile >> 1) * A.estride + (size_t) k * 64 + (tile & 1u) * 32u;
+    int8_t* const E0 = A.exps + (size_t) ((tile * TW) >> 6) * A.estride + (size_t) k * 64 + ((tile * TW) & 63u);
     const char* const Mk = reinterpret_cast<const char*>(A.matrices) + A.tabOff + (size_t) k * A.tabBytes;
 
     const Walk4Entry* prog = wg_program(AA) + ((size_t) list * W + wave) * A.entries;
@@ -214,9 +290,9 @@ k_walkg(ARGS AA)
     DA.s1 = DA.s2 = DB.s1 = DB.s2 = DC.s1 = DC.s2 = 0;
     Ops X, Y, Z;
 #pragma unroll
-    for (int i = 0; i < NAVC; ++i) X.a[i] = Y.a[i] = Z.a[i] = (vec) (0.0f);
+    for (int i = 0; i < NAVC; ++i) X.a[i] = Y.a[i] = Z.a[i] = Va::splat(0.0f);
 #pragma unroll
-    for (int i = 0; i < TVC; ++i) X.b[i] = Y.b[i] = Z.b[i] = (vec) (0.0f);
+    for (int i = 0; i < TVC; ++i) X.b[i] = Y.b[i] = Z.b[i] = Vb::splat(0.0f);
     int er = 0;                                      // stored exponent of the entry about to run (SCALE_READ)
     int cum_e[MBAMD_WG_MAXLISTS] = {0, 0, 0, 0};
 
@@ -228,9 +304,9 @@ k_walkg(ARGS AA)
         const bool tip = ctl & (ch ? MBAMD_W4_TIP2 : MBAMD_W4_TIP1), mem = ctl & (ch ? MBAMD_WG_MEM2 : MBAMD_WG_MEM1);
         const unsigned coff = ch ? d.e.c2 : d.e.c1, moff = ch ? d.e.m2 : d.e.m1;
         const unsigned s = ch ? d.s2 : d.s1;
-        // a: A' (column = lane) or the tip's gather table (column = 2 * (state & 31) + half of sub-table state >> 5)
-        const unsigned aoff = tip ? (1u + (s >> 5)) * (unsigned) (NAP * 256) + ((s & 31u) * 2u + half) * (unsigned) (V * 4) : lane * (unsigned) (V * 4);
-        const MBAMD_AS_GLOBAL vec* pa = reinterpret_cast<const MBAMD_AS_GLOBAL vec*>((uintptr_t) (Mk + moff) + aoff) + h * NAVC * 64;
+        // a: A' (column = lane) or the tip's gather table (column = KS * (state % TW) + half of sub-table state / TW)
+        const unsigned aoff = tip ? (1u + s / TW) * (unsigned) (NAP * 256) + ((s % TW) * KS + half) * (unsigned) (VA * 4) : lane * (unsigned) (VA * 4);
+        const MBAMD_AS_GLOBAL vecA* pa = reinterpret_cast<const MBAMD_AS_GLOBAL vecA*>((uintptr_t) (Mk + moff) + aoff) + h * NAVC * 64;
 #if !defined(MBAMD_WGX_NOFETCH)
 #pragma unroll
         for (int i = 0; i < NAVC; ++i) o.a[i] = pa[i * 64];
@@ -243,9 +319,9 @@ k_walkg(ARGS AA)
             for (int i = 0; i < TVC; ++i) o.b[i] = pb[i * 64];
         }
     };
-    // chunk q of an entry: MFMA steps [h TPC, (h + 1) TPC) of one child factor; registers (it, r) of f = state 32 it + 2 r +
-    // half of this lane's pattern.  No vector-memory operation in here.  Two halves: the B rows into registers (the only LDS
-    // wait), then the MFMA chain (or the tip's gather rows) -- the caller may issue scalar loads in between.
+    // chunk q of an entry: MFMA steps [h TPC, (h + 1) TPC) of one child factor; register (it, r) of f = the state of this lane's
+    // pattern that block row ACC it + r holds in this lane.  No vector-memory operation in here.  Two halves: the B rows into
+    // registers (the only LDS wait), then the MFMA chain (or the tip's gather rows) -- the caller may issue scalar loads in between.
     auto operandB = [&](const Walk4Entry& de, int q, const Ops& o, vec (&b)[TVC]) {
         const int ch = q / CH, h = q % CH;
         if (de.ctl & (ch ? MBAMD_WG_MEM2 : MBAMD_WG_MEM1)) {
@@ -259,18 +335,18 @@ k_walkg(ARGS AA)
 #else
             (void) sl;
 #pragma unroll
-            for (int i = 0; i < TVC; ++i) b[i] = (vec) (1.0f);
+            for (int i = 0; i < TVC; ++i) b[i] = Vb::splat(1.0f);
 #endif
         }
     };
-    auto compute = [&](bool tip, int q, const Ops& o, const vec (&b)[TVC], wg_f16 (&f)[NT]) {
+    auto compute = [&](bool tip, int q, const Ops& o, const vec (&b)[TVC], acc_t (&f)[NT]) {
         const int h = q % CH;
         if (tip) {
-            if (h == 0) {                            // all 16 registers of every row tile come from the first chunk's rows
+            if (h == 0) {                            // all registers of every output tile come from the first chunk's rows
 #pragma unroll
                 for (int it = 0; it < NT; ++it)
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) f[it][r] = (16 * it + r < T) ? o.a[(r * NT + it) / V][(r * NT + it) % V] : 0.0f;
+                    for (int r = 0; r < ACC; ++r) f[it][r] = (ACC * it + r < T) ? Va::get(o.a[(r * NT + it) / VA], (r * NT + it) % VA) : 0.0f;
             }
             return;
         }
@@ -278,19 +354,25 @@ k_walkg(ARGS AA)
 #pragma unroll
             for (int it = 0; it < NT; ++it)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) f[it][r] = 0.0f;
+                for (int r = 0; r < ACC; ++r) f[it][r] = 0.0f;
         }
 #if !defined(MBAMD_WGX_NOMFMA)
 #pragma unroll
         for (int tc = 0; tc < TPC; ++tc)
             if (h * TPC + tc < T) {
 #pragma unroll
-                for (int it = 0; it < NT; ++it)
-                    f[it] = __builtin_amdgcn_mfma_f32_32x32x2f32(o.a[(tc * NT + it) / V][(tc * NT + it) % V], b[tc / V][tc % V], f[it], 0, 0, 0);
+                for (int it = 0; it < NT; ++it) {
+                    const float av = Va::get(o.a[(tc * NT + it) / VA], (tc * NT + it) % VA), bv = Vb::get(b[tc / V], tc % V);
+#if MBAMD_WG_TW == 32
+                    f[it] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, f[it], 0, 0, 0);
+#else
+                    f[it] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv, f[it], 0, 0, 0);
+#endif
+                }
             }
 #else
 #pragma unroll
-        for (int tc = 0; tc < TPC; ++tc) f[0][tc & 15] += o.a[(tc * NT) / V][(tc * NT) % V] * b[tc / V][tc % V];
+        for (int tc = 0; tc < TPC; ++tc) f[0][tc % ACC] += Va::get(o.a[(tc * NT) / VA], (tc * NT) % VA) * Vb::get(b[tc / V], tc % V);
 #endif
     };
 
@@ -324,7 +406,7 @@ k_walkg(ARGS AA)
 #else
         const int er_next = 0;
 #endif
-        wg_f16 f1[NT], f2[NT];
+        acc_t f1[NT], f2[NT];
         const Walk4Entry ce = cur.e;
         auto chunk = [&](auto qc) {
             constexpr int q = decltype(qc)::value;
@@ -365,13 +447,17 @@ k_walkg(ARGS AA)
 #pragma unroll
         for (int t = 0; t < TP; ++t) {
 #if !defined(MBAMD_WGX_NOEPI)
-            out[t] = (run && t < T) ? f1[t >> 4][t & 15] * f2[t >> 4][t & 15] : 0.0f;
+            out[t] = (run && t < T) ? f1[t / ACC][t % ACC] * f2[t / ACC][t % ACC] : 0.0f;
 #else
             out[t] = (t == 0 && run) ? f1[0][0] + f2[0][0] : 0.0f;
 #endif
             mx = fmaxf(mx, out[t]);
         }
-        {   // the other half of the states of this pattern sits 32 lanes away: v_permlane32_swap (VALU, no LDS round trip)
+        {   // the other states of this pattern sit TW lanes apart: lane swaps in the VALU, no LDS round trip
+#if MBAMD_WG_TW == 16
+            const auto sq = __builtin_amdgcn_permlane16_swap(__float_as_uint(mx), __float_as_uint(mx), false, false);
+            mx = fmaxf(__uint_as_float(sq[0]), __uint_as_float(sq[1]));
+#endif
             const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(mx), __float_as_uint(mx), false, false);
             mx = fmaxf(__uint_as_float(sw[0]), __uint_as_float(sw[1]));
         }
@@ -383,7 +469,7 @@ k_walkg(ARGS AA)
         for (int q = 0; q < MBAMD_WG_MAXLISTS; ++q) cum_e[q] += (list == (unsigned) q) ? (e & wm) : 0;
         vec ov[TV];
 #pragma unroll
-        for (int t = 0; t < TP; ++t) ov[t / V][t % V] = scale_pow2(out[t], -e);   // (2^0 is exact: no branch)
+        for (int t = 0; t < TP; ++t) Vb::set(ov[t / V], t % V, scale_pow2(out[t], -e));   // (2^0 is exact: no branch)
 #if !defined(MBAMD_WGX_NOLDS)
         if (ctl & MBAMD_W4_KEEP) {
             vec* keep = reinterpret_cast<vec*>(reinterpret_cast<char*>(slots) + ((ctl >> 16) & 0xFFu) * SLOTB);
@@ -401,10 +487,10 @@ k_walkg(ARGS AA)
         for (int i = 0; i < TV; ++i) __builtin_nontemporal_store(ov[i], pd + i * 64);   // 64 * V * 4 contiguous bytes per instruction
 #endif
 #else
-        if (ov[0][0] == 123.456f) __builtin_nontemporal_store(ov[0], pd);
+        if (Vb::get(ov[0], 0) == 123.456f) __builtin_nontemporal_store(ov[0], pd);
 #endif
 #if !defined(MBAMD_WGX_NOTINY)
-        __builtin_nontemporal_store((int8_t) e, as_global(E0 + ewrite) + col);   // (both halves hold the same e: no exec-mask branch)
+        __builtin_nontemporal_store((int8_t) e, as_global(E0 + ewrite) + col);   // (every lane group holds the same e: no exec-mask branch)
 #else
         if (e == 12345) __builtin_nontemporal_store((int8_t) e, as_global(E0 + ewrite) + col);
 #endif
@@ -416,7 +502,7 @@ k_walkg(ARGS AA)
         step(DB, DC, DA, wg_pick<NQ % NS>(X, Y, Z), wg_pick<(NQ + 1) % NS>(X, Y, Z), wg_pick<(NQ + 2) % NS>(X, Y, Z), j + 1);
         step(DC, DA, DB, wg_pick<(2 * NQ) % NS>(X, Y, Z), wg_pick<(2 * NQ + 1) % NS>(X, Y, Z), wg_pick<(2 * NQ + 2) % NS>(X, Y, Z), j + 2);
     }
-    // cumulative exponents of this workgroup's 32 columns: the waves' sums meet in LDS, wave 0 owns the memory update
+    // cumulative exponents of this workgroup's TW columns: the waves' sums meet in LDS, wave 0 owns the memory update
     int* const stage = reinterpret_cast<int*>(mine);
 #pragma unroll
     for (int q = 0; q < MBAMD_WG_MAXLISTS; ++q) {
@@ -431,7 +517,7 @@ k_walkg(ARGS AA)
                     sum += reinterpret_cast<const int*>(reinterpret_cast<const char*>(lds_walkg) + (size_t) w * (MBAMD_WG_STAGE + (size_t) A.nslots * SLOTB))[lane];
         }
         if (wave == 0 && half == 0) {
-            int32_t* d = A.cum[q] + (size_t) k * A.Ppad + (size_t) tile * 32 + col;
+            int32_t* d = A.cum[q] + (size_t) k * A.Ppad + (size_t) tile * TW + col;
             if (A.cumFresh >> q & 1) *d = sum;
             else if (sum != 0) *d += sum;
         }

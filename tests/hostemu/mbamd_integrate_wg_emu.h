@@ -10,9 +10,9 @@ k_integrate_lnl_wg(IntegrateArgs4 a, int S, int SP, int K, int P, int Ppad, WgGe
                    const double* __restrict__ pattern_weights, double* __restrict__ site, double* __restrict__ wsite)
 {
     const int c = blockIdx.x * 64 + threadIdx.x;
-    const size_t pb = (size_t) (c >> 5) * g.tileFloats;                         // float index of (tile, category 0) of the buffer
+    const size_t pb = (size_t) (c / MBAMD_WG_TW) * g.tileFloats;               // float index of (tile, category 0) of the buffer
     const size_t kstride = (size_t) g.TP * 64;
-    const int p = c & 31;
+    const int p = c % MBAMD_WG_TW;
     double wl = 0.0;
     if (c < P) {
         int emax = -2147483647;
@@ -27,7 +27,7 @@ k_integrate_lnl_wg(IntegrateArgs4 a, int S, int SP, int K, int P, int Ppad, WgGe
             const float* __restrict__ par = reinterpret_cast<const float*>(a.parent[n]) + pb;
             unsigned s = 0;
             if (a.child[n] != nullptr && a.child_kind[n] == CHILD_STATES)
-                s = reinterpret_cast<const uint8_t*>(a.child[n])[(size_t) (c >> 5) * g.tipTileBytes + (c & 31)];
+                s = reinterpret_cast<const uint8_t*>(a.child[n])[(size_t) (c / MBAMD_WG_TW) * g.tipTileBytes + (c % MBAMD_WG_TW)];
             for (int k = 0; k < K; ++k) {
                 const float* __restrict__ pk = par + (size_t) k * kstride;
                 double cat = 0.0;

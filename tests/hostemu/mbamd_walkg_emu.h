@@ -6,7 +6,7 @@
 #ifndef MBAMD_WALKG_EMU_H_
 #define MBAMD_WALKG_EMU_H_
 // ---- host-emulation twin (CPU CI of the host logic: arenas, programs, slots, phases): lane 0 of every wave walks the
-// program with plain loops over the 32 patterns; children come from the emulated LDS slots exactly as scheduled
+// program with plain loops over the tile's patterns; children come from the emulated LDS slots exactly as scheduled
 template <int SC, int WMAX, int CH, int DEPTH, class ARGS = WalkGArgs>
 __global__ void k_walkg(ARGS AA)
 {
@@ -24,9 +24,10 @@ __global__ void k_walkg(ARGS AA)
     float* const slots = reinterpret_cast<float*>(mine + MBAMD_WG_STAGE);
     char* const P0 = reinterpret_cast<char*>(A.partials) + (size_t) tile * A.tileBytes + (size_t) k * SLOTB;
     const uint8_t* const T0 = A.tips + (size_t) tile * A.tipTileBytes;
-    int8_t* const E0 = A.exps + (size_t) (tile >> 1) * A.estride + (size_t) k * 64 + (tile & 1u) * 32u;
+    constexpr int TW = MBAMD_WG_TW;
+    int8_t* const E0 = A.exps + (size_t) ((tile * TW) >> 6) * A.estride + (size_t) k * 64 + ((tile * TW) & 63u);
     const Walk4Entry* prog = wg_program(AA) + ((size_t) list * W + wave) * A.entries;
-    int cum_e[MBAMD_WG_MAXLISTS][32];
+    int cum_e[MBAMD_WG_MAXLISTS][TW];
     for (auto& row : cum_e) for (int& v : row) v = 0;
     for (int j = 0; j < A.entries; ++j) {
         const Walk4Entry e = prog[j];
@@ -34,8 +35,8 @@ __global__ void k_walkg(ARGS AA)
         if (lane != 0 || (e.ctl & MBAMD_W4_NOP)) continue;
         const unsigned mode = (e.ctl >> 8) & 3u;
         float* dst = reinterpret_cast<float*>(P0 + e.dst);
-        float res[64][32];
-        for (int c = 0; c < 32; ++c) {
+        float res[64][TW];
+        for (int c = 0; c < TW; ++c) {
             float f[2][64];
             for (int ch = 0; ch < 2; ++ch) {
                 const bool tip = e.ctl & (ch ? MBAMD_W4_TIP2 : MBAMD_W4_TIP1), mem = e.ctl & (ch ? MBAMD_WG_MEM2 : MBAMD_WG_MEM1);
@@ -61,8 +62,8 @@ __global__ void k_walkg(ARGS AA)
             for (int i = 0; i < S; ++i) res[i][c] = scale_pow2(res[i][c], -ex);
             E0[e.ewrite + c] = (int8_t) ex;
         }
-        for (int i = 0; i < 2 * TP; ++i)
-            for (int c = 0; c < 32; ++c) {
+        for (int i = 0; i < MBAMD_WG_KS * TP; ++i)
+            for (int c = 0; c < TW; ++c) {
                 const float v = i < S ? res[i][c] : 0.0f;
                 dst[wg_elem(S, i, c)] = v;
                 if (e.ctl & MBAMD_W4_KEEP) slots[((e.ctl >> 16) & 0xFFu) * (SLOTB / 4) + wg_elem(S, i, c)] = v;
@@ -74,14 +75,14 @@ __global__ void k_walkg(ARGS AA)
         int* stage = reinterpret_cast<int*>(mine);
         if (W > 1) {
             if (q > 0) mbamd_emu_barrier();
-            if (lane == 0) for (int c = 0; c < 32; ++c) stage[c] = cum_e[q][c];
+            if (lane == 0) for (int c = 0; c < TW; ++c) stage[c] = cum_e[q][c];
             mbamd_emu_barrier();
         }
         if (wave == 0 && lane == 0)
-            for (int c = 0; c < 32; ++c) {
+            for (int c = 0; c < TW; ++c) {
                 int sum = cum_e[q][c];
                 for (int w = 1; w < W; ++w) sum += reinterpret_cast<const int*>(lds + (size_t) w * (MBAMD_WG_STAGE + (size_t) A.nslots * SLOTB))[c];
-                int32_t* d = A.cum[q] + (size_t) k * A.Ppad + (size_t) tile * 32 + c;
+                int32_t* d = A.cum[q] + (size_t) k * A.Ppad + (size_t) tile * TW + c;
                 if (A.cumFresh >> q & 1) *d = sum; else *d += sum;
             }
     }

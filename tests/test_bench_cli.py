@@ -35,3 +35,19 @@ def test_two_ranks():
     assert res.returncode == 0, (res.stdout + res.stderr)[-3000:]
     d = _json_line(res.stdout)
     assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["config"]["chains"] == 2
+    # the reference's own MPI build on the shim, two ranks (only where the reference binaries were built)
+    if os.path.exists(os.path.join(ROOT, "oracle", "_ref", "mb_emu_mpi")) and os.path.exists(os.path.join(ROOT, "oracle", "_ref", "mbamd_mpirun")):
+        m = d["mpi_mcmc"]
+        assert m["ranks"] == 2 and m["cases"][0]["generations_per_s"] > 0, m
+
+
+def test_two_ranks_sharded():
+    """--shard: one chain, site patterns over the N devices inside one instance (all children on the emulated device here)."""
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1")
+    res = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                          "--master-addr", "127.0.0.1", "--master-port", "29673", "bench.py", "--gpus", "2", "--shard", "--no-mpi",
+                          "--steps", "3", "--warmup", "1", "--emulate"], cwd=ROOT, env=env, capture_output=True,
+                         text=True, timeout=900)
+    assert res.returncode == 0, (res.stdout + res.stderr)[-3000:]
+    d = _json_line(res.stdout)
+    assert d["n_gpus"] == 2 and d["scaling"] == "strong" and d["config"]["chains"] == 1 and "shards" in d["config"]["parallelism"]
