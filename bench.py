@@ -132,6 +132,32 @@ def mcmc_gen_per_s(gold, nchains=1, quick=True):
         if "engine_device_parsimony" in res:
             res["speedup_device_parsimony"] = res["engine_device_parsimony"] / res["reference_cpu"]
         out[mix] = res
+    # codon M3 (BASELINE configs[4]'s alignment), fixed topology: a third of the moves change the rate matrices -- the unpatched
+    # binary decomposes 3 x 61-state systems on the host (GetEigens), `engine_all_bindings` (a PATCHED binary, oracle/Makefile
+    # ref-amd-full: patch_eigen.py + integration/mrbayes/mbamd_eigen_glue.c) on the device, warm-started
+    try:
+        with open(os.path.join(GOLD, "bench_c5.json")) as fh:
+            g5 = json.load(fh)
+        s5 = g5["synthetic"]
+        st5 = mbdata.synthetic_states(s5["ntaxa"], s5["nsites"], 61, s5["seed"], s5["p_mut"], s5["p_gap"])
+        tr5 = mbtree.parse_newick(g5["newick"])
+        res = {}
+        runs = [("engine", refrun.REF_MB_AMD, "dynamic", (500, 3000)), ("reference_cpu", refrun.REF_MB, None, (3, 10))]
+        if os.path.exists(refrun.REF_MB_AMD_FULL):
+            runs.insert(1, ("engine_all_bindings", refrun.REF_MB_AMD_FULL, "dynamic", (500, 4500)))
+        for tag, binary, beagle, (lo, hi) in runs:
+            walls = []
+            for ngen in (lo, hi):
+                o, wall = refrun.run_mb(binary, refrun.model_nexus("m3", st5, tr5, ngen=ngen, beagle=beagle, fixed_topology=True))
+                if "Analysis completed" not in o:
+                    raise RuntimeError(o[-800:])
+                walls.append(wall)
+            res[tag] = (hi - lo) / max(walls[1] - walls[0], 1e-9)
+            res[tag + "_ngen"] = [lo, hi]
+        res["speedup"] = res["engine"] / res["reference_cpu"]
+        out["codon_m3_fixed_topology"] = res
+    except Exception as exc:
+        out["codon_m3_fixed_topology"] = {"error": repr(exc)[:400]}
     return out
 
 

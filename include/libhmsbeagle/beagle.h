@@ -340,6 +340,16 @@ BEAGLE_DLLEXPORT int mbamdGetScaleExponents(int instance, int srcScalingIndex, i
  * The unmodified MrBayes does not call it (the BEAGLE API takes finished eigen-systems: beagleSetEigenDecomposition);
  * hosts that own their model code do (mrbayes_amd/likelihood.py, device_eigen=True). */
 BEAGLE_DLLEXPORT int mbamdSetRateMatrices(int instance, int firstEigenIndex, int count, const double* q, const double* pi, int mode);
+/* The same for a client whose rate matrices change a little from call to call -- an MCMC move on the substitution parameters:
+ * warmFirstEigenIndex (>= 0) names the eigen buffers that hold the systems of the state the proposal started from (MrBayes:
+ * m->cijkScratchIndex after FlipCijkSpace, reference src/likelihood.c:5614-5622); if the device computed those too, the
+ * iteration starts from their eigenvectors and needs two or three sweeps instead of nine.  All `count` systems -- the parts of a
+ * codon or covarion model -- in ONE asynchronous launch; nothing waits.
+ * mode bit 0: q are exchangeabilities (as mbamdSetRateMatrices); bit 1 (2): shield -- the NEXT beagleSetEigenDecomposition on
+ * each of these eigen buffers is ignored, for clients whose own code path still sends its host result afterwards (the binding
+ * of reference UpDateCijk, src/likelihood.c:10476-10804: integration/mrbayes/mbamd_eigen_glue.c). */
+BEAGLE_DLLEXPORT int mbamdSetRateMatricesFrom(int instance, int firstEigenIndex, int count, const double* q, const double* pi, int mode,
+                                              int warmFirstEigenIndex);
 /* Last HIP/engine error text of the calling thread ("" if none). */
 BEAGLE_DLLEXPORT const char* mbamdGetLastError(void);
 /* Device-side timing of the partials kernels: accumulates HIP-event time (ms) and launch count of every

@@ -64,7 +64,7 @@ EXPORTS = [
     "beagleGetScaleFactors", "beagleCalculateRootLogLikelihoods", "beagleCalculateEdgeLogLikelihoods",
     "beagleGetSiteLogLikelihoods", "mbamdSynchronize", "mbamdGetLastError", "mbamdKernelTiming",
     "mbamdGetKernelTiming", "mbamdGetStepTiming", "mbamdUpdateFinalPartials", "mbamdGetScaledPartials", "mbamdSetKernelPath", "mbamdSetDeferredResult", "mbamdFetchLogLikelihood",
-    "mbamdGetScaleExponents", "mbamdGetChildCount", "mbamdSetRateMatrices",
+    "mbamdGetScaleExponents", "mbamdGetChildCount", "mbamdSetRateMatrices", "mbamdSetRateMatricesFrom",
     # BEAGLE v3 surface (multi-partition instances, resource benchmark)
     "beagleGetBenchmarkedResourceList", "beagleSetCPUThreadCount", "beagleSetPatternPartitions",
     "beagleSetCategoryRatesWithIndex", "beagleUpdateTransitionMatricesWithMultipleModels", "beagleUpdatePartialsByPartition",
@@ -232,6 +232,14 @@ class BeagleInstance:
         self.lib.mbamdSetRateMatrices.argtypes = [C.c_int, C.c_int, C.c_int, _dp, _dp, C.c_int]
         self._chk(self.lib.mbamdSetRateMatrices(self.id, first, n, a.ctypes.data_as(_dp), b.ctypes.data_as(_dp),
                                                 1 if exchangeabilities else 0), "mbamdSetRateMatrices")
+
+    def set_rate_matrices_from(self, first, qs, pi, warm_first, exchangeabilities=False, shield=False):
+        """Extension: the same, warm-started from the eigenvectors of eigen buffers warm_first ... (mbamdSetRateMatricesFrom)."""
+        a, b = _d(np.asarray(qs, dtype=np.float64)), _d(pi)
+        n = a.size // (len(b) * len(b))
+        self.lib.mbamdSetRateMatricesFrom.argtypes = [C.c_int, C.c_int, C.c_int, _dp, _dp, C.c_int, C.c_int]
+        self._chk(self.lib.mbamdSetRateMatricesFrom(self.id, first, n, a.ctypes.data_as(_dp), b.ctypes.data_as(_dp),
+                                                    (1 if exchangeabilities else 0) | (2 if shield else 0), warm_first), "mbamdSetRateMatricesFrom")
 
     def set_state_frequencies(self, idx, f):
         a = _d(f)

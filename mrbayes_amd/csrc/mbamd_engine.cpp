@@ -417,7 +417,9 @@ struct Instance {
     int importPartials(int idx, const double* in, bool hasCategories);
     int getPartials(int idx, double* out);
     int setEigen(int idx, const double* U, const double* Ui, const double* lam);
-    int setRateMatrices(int first, int count, const double* q, const double* pi, int mode);
+    int setRateMatrices(int first, int count, const double* q, const double* pi, int mode, int warmFirst = -1);
+    std::vector<int> eigenWarm;      // per eigen buffer: -1 = no orthonormal basis stored (host-set), else warm starts since the last cold one
+    std::vector<char> eigenShield;   // per eigen buffer: the next beagleSetEigenDecomposition is ignored (mbamdSetRateMatricesFrom, mode bit 1)
     int updateMatrices(int eigenIndex, const int* probIdx, const double* lengths, int count, int rateSet = 0);
     int setRates(int index, const double* r);
     int setMatrix(int idx, const double* in);
@@ -553,7 +555,7 @@ int Instance::create(int tipCount_, int partialsBufferCount, int compactBufferCo
         int rc = configureWalk();
         if (rc) return rc;
     }
-    eigenDoubles = (size_t) 2 * S * S + S;
+    eigenDoubles = (size_t) 3 * S * S + S;       // [U | U^-1 | lambda | V]: V = orthonormal eigenvectors kept for warm starts (k_eigen_reversible)
     partials.assign(nBuffers, nullptr);
     tipStates.assign(nBuffers, nullptr);
     scale.assign(std::max(nScale, 1), nullptr);
@@ -851,34 +853,53 @@ int Instance::getPartials(int idx, double* out)
     return BEAGLE_SUCCESS;
 }
 
-// Eigen-systems from rate matrices (or exchangeabilities), computed on the device: k_eigen_reversible (mbamd_kernels.h)
-int Instance::setRateMatrices(int first, int count, const double* q, const double* pi, int mode)
+// Eigen-systems from rate matrices (or exchangeabilities), computed on the device: k_eigen_reversible (mbamd_kernels.h).
+// Nothing here waits for the device: the rate matrices travel through the pinned ring and are read by the kernel from there.
+int Instance::setRateMatrices(int first, int count, const double* q, const double* pi, int mode, int warmFirst)
 {
     if (count <= 0) return BEAGLE_SUCCESS;
     if (first < 0 || first + count > nEigen) return fail(BEAGLE_ERROR_OUT_OF_RANGE, "mbamdSetRateMatrices: eigen index");
+    if (warmFirst >= 0 && warmFirst + count > nEigen) return fail(BEAGLE_ERROR_OUT_OF_RANGE, "mbamdSetRateMatricesFrom: warm-start eigen index");
+    if (S > 64) return fail(BEAGLE_ERROR_NO_IMPLEMENTATION, "mbamdSetRateMatrices: more than 64 states");
     for (int i = 0; i < S; ++i)
         if (!(pi[i] > 0.0)) return fail(BEAGLE_ERROR_NO_IMPLEMENTATION, "mbamdSetRateMatrices: a state frequency is not positive (no symmetric form)");
+    if (eigenWarm.size() != (size_t) nEigen) { eigenWarm.assign(nEigen, -1); eigenShield.assign(nEigen, 0); }
     const size_t qd = (size_t) count * S * S, bytes = (qd + S) * sizeof(double);
-    int rc = grow(&d_tmp, &tmpCap, bytes);
-    if (rc) return rc;
+    const double* dq = nullptr;
     std::vector<double> h(qd + S);
     std::memcpy(h.data(), q, qd * sizeof(double));
     std::memcpy(h.data() + qd, pi, (size_t) S * sizeof(double));
-    HIP_TRY(hipStreamSynchronize(stream));                       // (d_tmp may still be read by an earlier import)
-    HIP_TRY(hipMemcpyAsync(d_tmp, h.data(), bytes, hipMemcpyHostToDevice, stream));
-    HIP_TRY(hipStreamSynchronize(stream));
+    int rc;
+    if (bytes + 64 <= stageCap / 2) {
+        rc = stageDirect(h.data(), bytes, (const void**) &dq);
+        if (rc) return rc;
+    } else {                                                       // (many large matrices at once: a device copy)
+        rc = grow(&d_tmp, &tmpCap, bytes);
+        if (rc) return rc;
+        HIP_TRY(hipStreamSynchronize(stream));                     // (d_tmp may still be read by an earlier import)
+        HIP_TRY(hipMemcpy(d_tmp, h.data(), bytes, hipMemcpyHostToDevice));
+        dq = reinterpret_cast<const double*>(d_tmp);
+    }
     std::vector<EigenJob> jobs(count);
     for (int i = 0; i < count; ++i) {
-        jobs[i].q = reinterpret_cast<const double*>(d_tmp) + (size_t) i * S * S;
-        jobs[i].pi = reinterpret_cast<const double*>(d_tmp) + qd;
+        jobs[i].q = dq + (size_t) i * S * S;
+        jobs[i].pi = dq + qd;
         jobs[i].out = d_eigen + (size_t) (first + i) * eigenDoubles;
-        jobs[i].mode = mode;
+        jobs[i].warm = nullptr;
+        // a warm start re-uses the orthonormal basis of the source; every 64th call starts cold again (rounding drift of the basis)
+        if (warmFirst >= 0 && eigenWarm[warmFirst + i] >= 0 && eigenWarm[warmFirst + i] < 64)
+            jobs[i].warm = d_eigen + (size_t) (warmFirst + i) * eigenDoubles + (size_t) 2 * S * S + S;
+        jobs[i].mode = mode & 1;
         jobs[i].pad_ = 0;
+    }
+    for (int i = 0; i < count; ++i) {
+        const int w = jobs[i].warm ? eigenWarm[warmFirst + i] + 1 : 0;
+        eigenWarm[first + i] = w;
+        if (mode & 2) eigenShield[first + i] = 1;
     }
     const EigenJob* djobs = nullptr;
     rc = stageDirect(jobs.data(), sizeof(EigenJob) * count, (const void**) &djobs);
     if (rc) return rc;
-    if (S > 64) return fail(BEAGLE_ERROR_NO_IMPLEMENTATION, "mbamdSetRateMatrices: more than 64 states");
 #if !defined(MBAMD_HOST_EMU)
     static bool ldsRaised = false;
     if (!ldsRaised) {
@@ -894,11 +915,16 @@ int Instance::setRateMatrices(int first, int count, const double* q, const doubl
 int Instance::setEigen(int idx, const double* U, const double* Ui, const double* lam)
 {
     if (idx < 0 || idx >= nEigen) return fail(BEAGLE_ERROR_OUT_OF_RANGE, "beagleSetEigenDecomposition: eigen index");
-    std::vector<double> h(eigenDoubles);
+    if (eigenShield.size() == (size_t) nEigen && eigenShield[idx]) {     // the device computed this one (mbamdSetRateMatricesFrom, mode bit 1)
+        eigenShield[idx] = 0;
+        return BEAGLE_SUCCESS;
+    }
+    if (eigenWarm.size() == (size_t) nEigen) eigenWarm[idx] = -1;
+    std::vector<double> h((size_t) 2 * S * S + S);
     std::memcpy(h.data(), U, sizeof(double) * S * S);
     std::memcpy(h.data() + (size_t) S * S, Ui, sizeof(double) * S * S);
     std::memcpy(h.data() + (size_t) 2 * S * S, lam, sizeof(double) * S);
-    return upload(d_eigen + (size_t) idx * eigenDoubles, h.data(), eigenDoubles * sizeof(double));
+    return upload(d_eigen + (size_t) idx * eigenDoubles, h.data(), h.size() * sizeof(double));
 }
 
 // beagleUpdateTransitionMatrices only queues its jobs: MrBayes calls it once per eigen-system part (reference
@@ -3128,6 +3154,14 @@ int mbamdSetRateMatrices(int instance, int firstEigenIndex, int count, const dou
     if (!q || !pi || (mode != 0 && mode != 1)) return fail(BEAGLE_ERROR_OUT_OF_RANGE, "mbamdSetRateMatrices: arguments");
     FACADE_ALL(c->setRateMatrices(firstEigenIndex, count, q, pi, mode));
     return in->setRateMatrices(firstEigenIndex, count, q, pi, mode);
+}
+int mbamdSetRateMatricesFrom(int instance, int firstEigenIndex, int count, const double* q, const double* pi, int mode, int warmFirstEigenIndex)
+{
+    GET_INSTANCE(instance);
+    if (in->f64) return fail(BEAGLE_ERROR_NO_IMPLEMENTATION, "mbamdSetRateMatricesFrom: not on a double-precision instance");
+    if (!q || !pi) return fail(BEAGLE_ERROR_OUT_OF_RANGE, "mbamdSetRateMatricesFrom: null");
+    FACADE_ALL(c->setRateMatrices(firstEigenIndex, count, q, pi, mode, warmFirstEigenIndex));
+    return in->setRateMatrices(firstEigenIndex, count, q, pi, mode, warmFirstEigenIndex);
 }
 int beagleSetStateFrequencies(int instance, int idx, const double* f)
 {

@@ -371,9 +371,12 @@ k_transition_matrices_ev(const MatrixJob* __restrict__ jobs, const double* __res
 #else
 #define MBAMD_SYNC() __syncthreads()
 #endif
-struct EigenJob { const double* q; const double* pi; double* out; int mode; int pad_; };
+// out = [U | U^-1 | lambda | V]: V (S x S) are the orthonormal eigenvectors of the symmetrised matrix -- what a later call
+// starts from (`warm` = the V of an eigen-system of a NEARBY rate matrix, e.g. the chain's current state when a move proposes
+// new rates: two or three sweeps instead of nine), or nullptr for a cold start from the identity.
+struct EigenJob { const double* q; const double* pi; double* out; const double* warm; int mode; int pad_; };
 // n = S rounded up to even (an odd S gets a dummy index whose row and column stay zero: its rotations are identities)
-__host__ __device__ inline size_t eigen_lds_doubles(int S) { const size_t n = (size_t) ((S + 1) & ~1); return 2 * n * (n + 1) + 4 * (n / 2 + 1) + 264; }
+__host__ __device__ inline size_t eigen_lds_doubles(int S) { const size_t n = (size_t) ((S + 1) & ~1); return 3 * n * (n + 1) + 4 * (n / 2 + 1) + 264; }
 __global__ void __launch_bounds__(256)
 k_eigen_reversible(const EigenJob* __restrict__ jobs, int S, int sweeps)
 {
@@ -387,7 +390,8 @@ k_eigen_reversible(const EigenJob* __restrict__ jobs, int S, int sweeps)
     const int n = (S + 1) & ~1, m = n / 2, LD = n + 1;
     double* A = lds;                         // [n][LD]  the symmetrised matrix, diagonalised in place
     double* V = A + (size_t) n * LD;         // [n][LD]  accumulated rotations
-    double* rc = V + (size_t) n * LD;        // [m] cosines
+    double* Wt = V + (size_t) n * LD;        // [n][LD]  warm start: B V0
+    double* rc = Wt + (size_t) n * LD;       // [m] cosines
     double* rs = rc + (m + 1);               // [m] sines
     int* rp = reinterpret_cast<int*>(rs + (m + 1));   // [m] pair (p, q), p < q
     int* rq = rp + 2 * (m + 1);
@@ -431,6 +435,27 @@ k_eigen_reversible(const EigenJob* __restrict__ jobs, int S, int sweeps)
     }
     if (tid == 0) red[259] = 0.0;
     MBAMD_SYNC();
+    if (job.warm != nullptr) {
+        // A <- V0^T B V0, V <- V0: the rotations then only have to undo what the rate matrix changed since V0 was computed
+        for (int i = ty; i < n; i += 8)
+            for (int j2 = tx; j2 < n; j2 += 32) V[i * LD + j2] = (i < S && j2 < S) ? job.warm[(size_t) i * S + j2] : (i == j2 ? 1.0 : 0.0);
+        MBAMD_SYNC();
+        for (int i = ty; i < n; i += 8)
+            for (int j2 = tx; j2 < n; j2 += 32) {
+                double acc = 0.0;
+                for (int k2 = 0; k2 < n; ++k2) acc += A[i * LD + k2] * V[k2 * LD + j2];
+                Wt[i * LD + j2] = acc;
+            }
+        MBAMD_SYNC();
+        for (int i = ty; i < n; i += 8)
+            for (int j2 = tx; j2 < n; j2 += 32) {
+                double acc = 0.0;
+                for (int k2 = 0; k2 < n; ++k2) acc += V[k2 * LD + i] * Wt[k2 * LD + j2];
+                A[i * LD + j2] = acc;
+            }
+        MBAMD_SYNC();
+    }
+    const double enough = job.warm != nullptr ? 1.0 : 2.0;      // converged checks in a row that end the iteration
     for (int sweep = 0; sweep < sweeps; ++sweep) {
         for (int r = 0; r < n - 1; ++r) {
             // round-robin: pair 0 = (n-1, r), pair i = ((r + i) mod (n-1), (r - i) mod (n-1)): n/2 disjoint rotations
@@ -532,7 +557,7 @@ k_eigen_reversible(const EigenJob* __restrict__ jobs, int S, int sweeps)
             red[259] = red[258];
         }
         MBAMD_SYNC();
-        if (red[258] >= 2.0) break;
+        if (red[258] >= enough) break;
     }
     // ---- U = D^-1 V, U^-1 = V^T D, lambda ------------------------------------------------------------------------------
     double* U = job.out;
@@ -545,6 +570,9 @@ k_eigen_reversible(const EigenJob* __restrict__ jobs, int S, int sweeps)
             Ui[(size_t) s2 * S + i] = V[i * LD + s2] * di;
         }
     for (int i = tid; i < S; i += 256) lam[i] = A[i * LD + i];
+    double* Vout = job.out + (size_t) 2 * S * S + S;
+    for (int i = ty; i < S; i += 8)
+        for (int s2 = tx; s2 < S; s2 += 32) Vout[(size_t) i * S + s2] = V[i * LD + s2];
 }
 
 // ---------------------------------------------------------------------------------------------

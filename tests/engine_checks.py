@@ -130,6 +130,51 @@ def check_device_eigen(lib, kind):
         dev.finalize()
 
 
+def check_device_eigen_warm_start(lib, nstates, seed=21):
+    """mbamdSetRateMatricesFrom: a chain of slightly perturbed reversible rate matrices, each decomposed from the eigenvectors
+    of the one before (alternating between two eigen buffers like MrBayes' FlipCijkSpace), must give exp(Q t) every time
+    -- scipy's Pade expm again -- and the shield makes the next beagleSetEigenDecomposition a no-op, once."""
+    from scipy.linalg import expm
+    rng = np.random.default_rng(seed)
+    S = nstates
+    inst = bg.BeagleInstance(lib, 2, 4, 2, S, 64, 2, 2, 1, 2)
+    try:
+        pi = rng.random(S) + 0.2
+        pi /= pi.sum()
+        ex = rng.random((S, S)) + 0.1
+        ex = 0.5 * (ex + ex.T)
+        inst.set_category_rates([1.0])
+
+        def qmat(e):
+            q = e * pi[None, :]
+            np.fill_diagonal(q, 0.0)
+            np.fill_diagonal(q, -q.sum(axis=1))
+            return q / -(pi * np.diag(q)).sum()
+
+        cur = 0
+        inst.set_rate_matrices(cur, qmat(ex)[None], pi)              # cold
+        for step in range(70):                                      # (> 64: one cold restart inside)
+            ex = ex * np.exp(0.05 * (rng.random((S, S)) - 0.5))
+            ex = 0.5 * (ex + ex.T)
+            q = qmat(ex)
+            inst.set_rate_matrices_from(1 - cur, q[None], pi, cur, shield=(step == 3))
+            cur = 1 - cur
+            if step == 3:                                           # what a client's own code path sends afterwards: ignored once
+                junk = np.eye(S)
+                inst.set_eigen_decomposition(cur, junk, junk, np.zeros(S))
+            if step in (0, 3, 4, 33, 64, 65, 69):
+                inst.update_transition_matrices(cur, np.asarray([0], dtype=np.int32), [0.37])
+                got = inst.get_transition_matrix(0)[0]
+                want = expm(q * 0.37)
+                assert np.allclose(got, want, rtol=2e-5, atol=3e-7), (S, step, np.abs(got - want).max())
+        junk = np.eye(S)
+        inst.set_eigen_decomposition(cur, junk, junk, np.zeros(S))      # not shielded any more: identity eigen-system
+        inst.update_transition_matrices(cur, np.asarray([0], dtype=np.int32), [0.37])
+        assert np.allclose(inst.get_transition_matrix(0)[0], np.eye(S), atol=1e-7)
+    finally:
+        inst.finalize()
+
+
 def check_root_equals_edge(lib, oracle, div, scaling=lk.MB_BEAGLE_SCALE_ALWAYS):
     """beagleCalculateRootLogLikelihoods (rooted / clock trees, reference src/mbbeagle.c:1251-1257) against the edge form
     MrBayes uses for unrooted trees: fold the root branch into one more partials operation (identity matrix for the

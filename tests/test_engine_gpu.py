@@ -380,6 +380,11 @@ def test_device_eigen(gpu, kind):
     ec.check_device_eigen(gpu, kind)
 
 
+@pytest.mark.parametrize("nstates", [4, 20, 61])
+def test_device_eigen_warm_start(gpu, nstates):
+    ec.check_device_eigen_warm_start(gpu, nstates)
+
+
 @pytest.mark.parametrize("case", ["replicase_m3", "avian_wag_g4", "synth_aa_wag"])
 def test_general_state_tree_walk_schedules_agree(gpu, golden_dir, monkeypatch, case):
     """20/61-state tree walk (k_walkg): waves per workgroup, LDS slots (children re-read from HBM instead), lists run one by

@@ -170,6 +170,11 @@ def test_device_eigen(emu, kind):
     ec.check_device_eigen(emu, kind)
 
 
+@pytest.mark.parametrize("nstates", [4, 20, 61])
+def test_device_eigen_warm_start(emu, nstates):
+    ec.check_device_eigen_warm_start(emu, nstates)
+
+
 @pytest.mark.parametrize("model", ["wag", "m3"])
 @pytest.mark.parametrize("waves,slots", [(2, 3), (4, 3), (8, 4), (2, 12)])
 def test_general_walk_schedule(emu, oracle, monkeypatch, model, waves, slots):

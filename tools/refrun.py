@@ -22,6 +22,9 @@ REF_MB_EMU_V3 = os.path.join(ROOT, "oracle", "_ref", "mb_emu_v3")
 # the reference + our ABI + the device-parsimony binding (integration/mrbayes/, oracle/patch_pars.py)
 REF_MB_AMD_PARS = os.path.join(ROOT, "oracle", "_ref", "mb_amd_pars")
 REF_MB_EMU_PARS = os.path.join(ROOT, "oracle", "_ref", "mb_emu_pars")
+# the reference + every binding: device parsimony, pattern compression, reports / covarion, device eigen-systems (oracle/Makefile: ref-amd-full)
+REF_MB_AMD_FULL = os.path.join(ROOT, "oracle", "_ref", "mb_amd_full")
+REF_MB_EMU_FULL = os.path.join(ROOT, "oracle", "_ref", "mb_emu_full")
 
 _NUC = "ACGT-"
 
