@@ -54,5 +54,30 @@ for count in (1, 3, 8):
             inst.set_eigen_decomposition(i, e.evec, e.ivec, e.eval)
     inst.lib.mbamdSynchronize(inst.id)
     host = (time.perf_counter() - t0) / 10
-    print("%d eigen-systems of %d states: device %.0f us, host solver + beagleSetEigenDecomposition %.0f us" % (count, S, dev * 1e6, host * 1e6))
+    # warm start (mbamdSetRateMatricesFrom): a slightly perturbed model decomposed from the previous eigenvectors, like an MCMC move
+    inst2 = bg.BeagleInstance(lib, 2, 2, 2, S, 64, 2 * count, 2, 1, 1)
+    inst2.set_rate_matrices(0, qs, div.pi)
+    rng = np.random.default_rng(1)
+    pert = []
+    for rep in range(12):
+        f = np.exp(0.04 * (rng.random((S, S)) - 0.5)); f = 0.5 * (f + f.T)
+        p2 = []
+        for q in qs:
+            e = q / np.asarray(div.pi)[None, :] * f
+            q2 = e * np.asarray(div.pi)[None, :]
+            np.fill_diagonal(q2, 0.0); np.fill_diagonal(q2, -q2.sum(axis=1))
+            p2.append(q2)
+        pert.append(np.stack(p2))
+    cur = 0
+    inst2.set_rate_matrices_from(count, pert[0], div.pi, 0); cur = count
+    inst2.lib.mbamdSynchronize(inst2.id)
+    t0 = time.perf_counter()
+    for rep in range(1, 11):
+        inst2.set_rate_matrices_from(count - cur, pert[rep], div.pi, cur); cur = count - cur
+    t1 = time.perf_counter()
+    inst2.lib.mbamdSynchronize(inst2.id)
+    warm = (time.perf_counter() - t0) / 10
+    print("%d eigen-systems of %d states: device %.0f us cold, %.0f us warm-started (host time of the asynchronous call %.0f us), host solver + beagleSetEigenDecomposition %.0f us"
+          % (count, S, dev * 1e6, warm * 1e6, (t1 - t0) / 10 * 1e6, host * 1e6))
     inst.finalize()
+    inst2.finalize()
