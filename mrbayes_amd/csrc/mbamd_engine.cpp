@@ -723,6 +723,7 @@ int Instance::configureWalk()
     // measured (profiles/r03_exp_walk4.txt): touching the tip bitplanes 8 entries ahead buys 3 % at 1000 x 50 000 -- all that serving
     // every tip from one hot line would -- and nothing at 500 x 20 000
     w4.tipAhead = 8;
+    w4.forward = std::getenv("MBAMD_WALK_NO_FORWARD") == nullptr;
     if (const char* e = std::getenv("MBAMD_WALK_TIP_AHEAD")) w4.tipAhead = std::max(0, std::min(32, std::atoi(e)));
     if (const char* e = std::getenv("MBAMD_WALK_TIP_FROM")) w4.tipAheadFrom = std::max(1, std::atoi(e));
     w4.safeWaits = std::getenv("MBAMD_WALK_SAFE") != nullptr;
@@ -1505,7 +1506,7 @@ int Instance::buildWalk(Plan& plan, const BeagleOperation* ops, int n, const int
         key.clear();
         key.reserve(seg.size() * 3 + 4);
         key.push_back((int) seg.size()); key.push_back(w4.maxW); key.push_back(w4.maxSlots + 256 * w4.maxSlots1);
-        key.push_back(w4.prefetchDistance * 2 + (w4.safeWaits ? 1 : 0) + 1024 * w4.tipAhead + 65536 * std::min(w4.tipAheadFrom, 30000));
+        key.push_back(w4.prefetchDistance * 2 + (w4.safeWaits ? 1 : 0) + 1024 * w4.tipAhead + 65536 * std::min(w4.tipAheadFrom, 30000) + (w4.forward ? 512 : 0));
         {
             std::vector<int>& writer = w4writer;          // buffer -> operation of this segment that writes it (-1 outside this block)
             for (size_t o = 0; o < seg.size(); ++o) {
@@ -1593,8 +1594,12 @@ int Instance::buildWalk(Plan& plan, const BeagleOperation* ops, int n, const int
             } else if (te.op >= 0) {
                 const Walk4Op& op = seg[te.op];
                 e.dst = (uint32_t) op.dst * pbuf;
-                if (op.tip1) { e.c1 = (uint32_t) op.c1 * 32u; flags |= MBAMD_W4_TIP1; } else e.c1 = (uint32_t) te.c1slot * 1024u;
-                if (op.tip2) { e.c2 = (uint32_t) op.c2 * 32u; flags |= MBAMD_W4_TIP2; } else e.c2 = (uint32_t) te.c2slot * 1024u;
+                if (op.tip1) { e.c1 = (uint32_t) op.c1 * 32u; flags |= MBAMD_W4_TIP1; }
+                else if (te.c1slot == 0xFE) flags |= MBAMD_W4_FWD1;
+                else e.c1 = (uint32_t) te.c1slot * 1024u;
+                if (op.tip2) { e.c2 = (uint32_t) op.c2 * 32u; flags |= MBAMD_W4_TIP2; }
+                else if (te.c2slot == 0xFE) flags |= MBAMD_W4_FWD2;
+                else e.c2 = (uint32_t) te.c2slot * 1024u;
                 e.m1 = (uint32_t) op.m1 * mbuf;
                 e.m2 = (uint32_t) op.m2 * mbuf;
                 if (te.dslot != 0xFF) { keep = te.dslot; flags |= MBAMD_W4_KEEP; }

@@ -51,13 +51,15 @@ namespace mbamd {
 #define MBAMD_W4_TIP1     0x20u  // child 1 / 2 is a compact tip (state bitplanes); otherwise an LDS slot
 #define MBAMD_W4_TIP2     0x40u
 #define MBAMD_W4_KEEP     0x80u  // the result is also written to LDS slot `keep`
+#define MBAMD_W4_FWD1     0x01000000u  // child 1 / 2 is the result of the operation this wave executed last: still in registers
+#define MBAMD_W4_FWD2     0x02000000u
 #define MBAMD_W4_RARE     (MBAMD_W4_NOP | MBAMD_W4_BARRIER | MBAMD_W4_PF0 | MBAMD_W4_VMWAIT)
 #define MBAMD_W4_MAXW     8
 
 // One step of a wave's program (wave-uniform; fetched with one s_load_dwordx8).  Addresses are ready-made byte
 // offsets from a base the wave computes once (scalar adds only, no multiplications in the loop).
 struct alignas(32) Walk4Entry {
-    uint32_t ctl;      // [7:0] flags   [9:8] ScaleMode   [15:10] vmwait   [23:16] slot that keeps the result (flag KEEP)
+    uint32_t ctl;      // [7:0] flags   [9:8] ScaleMode   [15:10] vmwait   [23:16] slot that keeps the result (flag KEEP)   [25:24] FWD1 / FWD2
     uint32_t dst;      // destination partials buffer: byte offset inside this wave's (block, category) column set
     uint32_t c1;       // child 1: tip -> byte offset of its 4 bitplanes inside the block's tip area; else LDS byte offset of its slot
     uint32_t c2;
@@ -333,9 +335,10 @@ k_walk4_t(ARGS AA)
     Walk4Planes T2 = walk4_load_planes(walk4_at(T0, (DA.ctl & MBAMD_W4_TIP2) ? DA.c2 : 0u));
     if (((DA.ctl >> 8) & 3u) == SCALE_READ) MBAMD_W4_EXPS(DA.eread, 0);
     int cum_e = 0;
+    f4 prev = {0.0f, 0.0f, 0.0f, 0.0f};            // the result of the operation executed last (FWD1 / FWD2 children)
 
     // One iteration = one entry.  Vector-memory instruction sequence (the host's vmwait counts on exactly this):
-    //     [DMA pf0] [DMA pf1] (PF entries)   s_waitcnt vmcnt(vmwait) (flag VMWAIT)
+    //     [DMA pf0] [DMA pf1] (PF entries)   s_waitcnt vmcnt(vmwait) (flag VMWAIT)   [2 tip touches (TIPPF kernels)]
     //     [exponent DMA for the next entry, if that is SCALE_READ]   [2 stores, if this entry is an operation]
     // Everything wave-uniform is a scalar branch or a scalar select (no divergent control flow).  The loop is unrolled by
     // two so that the two entry descriptors in flight keep their registers (no moves): `cur` is executed, `nxt` is the
@@ -345,9 +348,6 @@ k_walk4_t(ARGS AA)
     auto step = [&](Walk4Entry& cur, const Walk4Entry& nxt, int j, int parity) {
         const unsigned ctl = cur.ctl;
         bool run = true;
-        if (TIPPF) {
-            walk4_touch_planes(walk4_at(T0, (FAR.ctl & MBAMD_W4_TIP1) ? FAR.c1 : 0u), walk4_at(T0, (FAR.ctl & MBAMD_W4_TIP2) ? FAR.c2 : 0u), vzero, junk);
-        }
         if (ctl & MBAMD_W4_RARE) {
             if (ctl & MBAMD_W4_PF0) {
                 // PF entry: children of later operations that live in HBM -> LDS slots
@@ -363,12 +363,22 @@ k_walk4_t(ARGS AA)
         int er = 0;
         if (run) {
             f4 a, b;
-            if (ctl & MBAMD_W4_TIP1) a = walk4_tip_vector(T1, lane); else a = *reinterpret_cast<const f4*>(slots + cur.c1);
-            if (ctl & MBAMD_W4_TIP2) b = walk4_tip_vector(T2, lane); else b = *reinterpret_cast<const f4*>(slots + cur.c2);
+            if (ctl & MBAMD_W4_TIP1) a = walk4_tip_vector(T1, lane);
+            else if (ctl & MBAMD_W4_FWD1) a = prev;
+            else a = *reinterpret_cast<const f4*>(slots + cur.c1);
+            if (ctl & MBAMD_W4_TIP2) b = walk4_tip_vector(T2, lane);
+            else if (ctl & MBAMD_W4_FWD2) b = prev;
+            else b = *reinterpret_cast<const f4*>(slots + cur.c2);
             if (mode == SCALE_READ) er = stage[64 * parity + lane];
             const f4 f1 = walk4_matvec(M1, a);
             const f4 f2 = walk4_matvec(M2, b);
             out.x = f1.x * f2.x; out.y = f1.y * f2.y; out.z = f1.z * f2.z; out.w = f1.w * f2.w;
+        }
+        // (TIPPF) touch the tip planes of the entry tipAhead further on.  Here -- behind the matrix products -- and not at the
+        // top of the iteration: FAR came with the previous burst, and the first instruction that reads anything of a burst
+        // waits for ALL of it (one lgkmcnt, scalar loads return out of order); the products have paid for that wait already
+        if (TIPPF) {
+            walk4_touch_planes(walk4_at(T0, (FAR.ctl & MBAMD_W4_TIP1) ? FAR.c1 : 0u), walk4_at(T0, (FAR.ctl & MBAMD_W4_TIP2) ? FAR.c2 : 0u), vzero, junk);
         }
         // the scalar-load burst for the next entry (the registers of this entry's matrices / planes are free now); a
         // child that is not a tip reads the planes at offset 0 -- a valid address, the value is not used
@@ -396,6 +406,7 @@ k_walk4_t(ARGS AA)
             cum_e += e & wm;
             out.x = scale_pow2(out.x, -e); out.y = scale_pow2(out.y, -e);       // (2^0 is exact: no branch)
             out.z = scale_pow2(out.z, -e); out.w = scale_pow2(out.w, -e);
+            prev = out;
             if (ctl & MBAMD_W4_KEEP) *reinterpret_cast<f4*>(slots + ((ctl >> 6) & 0x3FC00u)) = out;
 #if defined(MBAMD_HOST_EMU)
             walk4_at(P0, dst)[lane] = out;

@@ -60,7 +60,8 @@ struct Walk4Scratch {
     std::vector<int> prod1, prod2, parent, ncons, need, size, phaseOf, waveOf, posOf, order, stack, heapTmp;
     std::vector<char> assigned, cap;
     // kept between builds so that compiling a short list (a root-ward path: every MCMC generation) allocates nothing
-    std::vector<int> binLoad, roots, frontier, slotHolder, lastUse, slotOfVal, freeFrom, memAt;
+    std::vector<int> binLoad, roots, frontier, slotHolder, lastUse, slotOfVal, freeFrom, memAt, nextOp;
+    std::vector<char> fwd;
     std::vector<std::vector<int>> phaseStart;
     std::vector<Walk4Template::Entry> scan;
     std::vector<std::vector<Walk4Template::Entry>> fin;
@@ -86,6 +87,9 @@ public:
     // iteration (two vector-memory instructions: they enter the wait counts) and reads that far beyond the program's end
     int tipAhead = 0, tipAheadFrom = 128;      // (lists shorter than tipAheadFrom operations run without: root-ward paths); set by the engine
     int lastTipAhead = 0;                      // what the latest build() used (the caller passes it to the kernel)
+    // 4-state walk: a result whose only consumer is the NEXT operation of the same wave -- in a post-order walk every parent
+    // follows its last interior child directly -- stays in registers (c?slot = 0xFE): no LDS slot, no write / read-back round trip
+    bool forward = false;
 
     // ops: one hazard-free segment (no buffer is written twice, none is written after it was read, a buffer read
     // after it was written is a dependency).  Fills `t` (structure) -- the caller turns it into Walk4Entry words.
@@ -328,6 +332,17 @@ inline bool Walk4Builder::build(const std::vector<Walk4Op>& ops, Walk4Template& 
                 if (pr[c] >= 0 && waveOf[pr[c]] == w && posOf[pr[c]] < j && (!phasesAreLaunches || phaseOf[pr[c]] == phaseOf[o]))
                     lastUse[pr[c]] = j;
         }
+        // forwarding: the position of the next operation after each position, and which results travel in registers
+        std::vector<int>& nextOp = s.nextOp;
+        std::vector<char>& fwd = s.fwd;
+        nextOp.assign((size_t) L + 1, 1 << 30);
+        for (int j = L - 1; j >= 0; --j) nextOp[j] = (j + 1 < L && items[w][j + 1].op >= 0) ? j + 1 : nextOp[j + 1];
+        if ((int) fwd.size() < n) fwd.resize(n);
+        for (int j = 0; j < L; ++j) {
+            const int o = items[w][j].op;
+            if (o < 0) continue;
+            fwd[o] = forward && memSlots && !phasesAreLaunches && ncons[o] == 1 && lastUse[o] == nextOp[j];
+        }
         // children that must come from memory (known up front): external buffers and results of other waves
         mems.clear();
         auto phaseLo = [&](int j) {                // first position of the phase that contains position j
@@ -433,6 +448,7 @@ inline bool Walk4Builder::build(const std::vector<Walk4Op>& ops, Walk4Template& 
             for (int c = 0; c < 2; ++c) {
                 if (tip[c]) continue;
                 if (c == 1 && !tip[0] && ops[o].c2 == ops[o].c1) { e.c2slot = e.c1slot; continue; }
+                if (pr[c] >= 0 && waveOf[pr[c]] == w && fwd[pr[c]] && lastUse[pr[c]] == j) { *cslot[c] = 0xFE; continue; }   // still in registers
                 if (pr[c] >= 0 && waveOf[pr[c]] == w && slotOfVal[pr[c]] >= 0) { *cslot[c] = (uint8_t) slotOfVal[pr[c]]; continue; }
                 int found = -1;
                 for (size_t mi = 0; mi < mems.size(); ++mi)
@@ -452,7 +468,7 @@ inline bool Walk4Builder::build(const std::vector<Walk4Op>& ops, Walk4Template& 
             for (int c = 0; c < 2; ++c) {
                 if (tip[c] || (c == 1 && !tip[0] && ops[o].c2 == ops[o].c1)) continue;
                 const int sl = *cslot[c];
-                if (sl == 0xFF) continue;
+                if (sl == 0xFF || sl == 0xFE) continue;
                 const int v = slotHolder[sl];
                 if (v <= -2) { slotHolder[sl] = -1; freeFrom[sl] = j + 1; }
                 else if (v >= 0 && lastUse[v] <= j) { slotHolder[sl] = -1; freeFrom[sl] = j + 1; slotOfVal[v] = -1; }
@@ -464,7 +480,7 @@ inline bool Walk4Builder::build(const std::vector<Walk4Op>& ops, Walk4Template& 
                     if (v >= 0 && lastUse[v] < 0 && posOf[v] < j) { slotHolder[q] = -1; freeFrom[q] = j + 1; slotOfVal[v] = -1; }
                 }
             // 3. the result: kept in a slot if this wave reads it again
-            if (lastUse[o] > j || alwaysKeep) {
+            if ((lastUse[o] > j && !fwd[o]) || alwaysKeep) {
                 int sl = -1;
                 for (int q = 0; q < S; ++q) if (slotHolder[q] == -1) { sl = q; break; }   // (freed children included: reads precede the write)
                 if (sl < 0) {
@@ -523,7 +539,7 @@ inline bool Walk4Builder::build(const std::vector<Walk4Op>& ops, Walk4Template& 
         }
         // 5. wait counts: replay the vector-memory instruction sequence of the kernel loop (mbamd_walk4.h)
         //    prologue: [exponent DMA for entry 0 if SCALE_READ]
-        //    iteration: [PF DMAs] WAIT [exponent DMA for the next entry if SCALE_READ] [2 stores if an operation]
+        //    iteration: [PF DMAs] WAIT [2 tip touches (long lists)] [exponent DMA for the next entry if SCALE_READ] [2 stores if an operation]
         auto reads = [&](const Walk4Template::Entry& e) { return e.op >= 0 && ops[e.op].scaleRead >= 0 && ops[e.op].scaleWrite < 0; };
         const int touches = (tipAhead > 0 && n >= tipAheadFrom) ? 2 : 0;
         long issued = 0;
@@ -532,7 +548,6 @@ inline bool Walk4Builder::build(const std::vector<Walk4Op>& ops, Walk4Template& 
         std::vector<long> pfSeq(mems.size(), -1);
         for (size_t j = 0; j < out.size(); ++j) {
             Walk4Template::Entry& e = out[j];
-            issued += touches;                                  // (top of every iteration, before anything else)
             for (int q = 0; q < 2; ++q)
                 if (e.pfOp[q] >= 0) {
                     for (size_t mi = 0; mi < mems.size(); ++mi)
@@ -548,6 +563,7 @@ inline bool Walk4Builder::build(const std::vector<Walk4Op>& ops, Walk4Template& 
             }
             if (needed < 0) e.vmwait = 0xFF;                        // (no wait)
             else e.vmwait = safeWaits ? 0 : (uint8_t) walk4_round_wait(issued - (needed + 1));
+            issued += touches;                                  // (every iteration, behind the wait)
             expSeq = -1;
             if (j + 1 < out.size() && reads(out[j + 1])) expSeq = issued++;
             if (e.op >= 0) issued += 2;
