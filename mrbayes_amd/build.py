@@ -33,12 +33,14 @@ def hipcc():
 
 
 def build_library(force=False, verbose=False):
-    deps = DEPS + [p for p in (os.path.join(HERE, "csrc", f) for f in os.listdir(os.path.join(HERE, "csrc")))]
+    deps = list(DEPS)
+    for d in (os.path.join(HERE, "csrc"), os.path.join(HERE, "csrc", "device"), os.path.join(ROOT, "include", "libhmsbeagle")):
+        deps += [os.path.join(d, f) for f in os.listdir(d) if os.path.isfile(os.path.join(d, f))]
     if not force and not _stale(LIB, deps):
         return LIB
     cmd = [hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-x", "hip",
            "-fvisibility=hidden", "-Wall", "-Wno-unused-function",
-           "-I", os.path.join(ROOT, "include"), "-I", os.path.join(HERE, "csrc"), SRC, "-o", LIB]
+           "-I", os.path.join(ROOT, "include"), "-I", os.path.join(HERE, "csrc"), "-I", os.path.join(HERE, "csrc", "device"), SRC, "-o", LIB]
     if verbose:
         cmd.insert(1, "-Rpass-analysis=kernel-resource-usage")
     for d in os.environ.get("MBAMD_BUILD_DEFINES", "").split():      # experiments: extra -D switches

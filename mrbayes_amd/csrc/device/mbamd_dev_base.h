@@ -1,0 +1,64 @@
+// mbamd_dev_base.h (gfx950) -- the handful of device primitives the kernels are written against: address spaces, the native
+// f4, exponent intrinsics, dynamic LDS, wave / block sums.  Included as <mbamd_dev_base.h>: the product is compiled with
+// -I csrc/device; the TEST-ONLY host emulation puts tests/hostemu in front, whose header of the same name implements the same
+// primitives in plain C++ -- so the kernel sources themselves carry no second implementation and no preprocessor fork.
+#ifndef MBAMD_DEV_BASE_H_
+#define MBAMD_DEV_BASE_H_
+
+// Pointers that reach a kernel through the operation table are generic ("flat") as far as the
+// compiler knows.  Casting them to the global address space turns flat_load/flat_store into
+// global_load/global_store, and casting wave-uniform read-only data (operation table, transition
+// matrices) to the constant address space lets the compiler fetch it with scalar loads (s_load_*)
+// into SGPRs, where it feeds v_fma as a scalar operand for all 64 lanes at once.
+#define MBAMD_AS_GLOBAL __attribute__((address_space(1)))
+#define MBAMD_AS_CONST __attribute__((address_space(4)))
+#define MBAMD_SYNC() __syncthreads()
+#define MBAMD_IMPL_NAME "mbamd HIP gfx950"
+namespace mbamd {
+// a native clang vector (not HIP's f4 class) so that it can be loaded/stored through
+// address-space qualified pointers as one dwordx4 access
+typedef float f4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ int mbd_frexp_exp(float v) { return __builtin_amdgcn_frexp_expf(v); }
+__device__ __forceinline__ float mbd_ldexp(float v, int e) { return __builtin_amdgcn_ldexpf(v, e); }
+__device__ __forceinline__ int mbd_wave_index() { return __builtin_amdgcn_readfirstlane((int) (threadIdx.x >> 6)); }
+// the workgroup's dynamic LDS (one symbol per translation unit: every kernel sees the same array)
+template <class T> __device__ __forceinline__ T* mbd_dyn_lds()
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char mbd_lds_bytes[];
+    return reinterpret_cast<T*>(mbd_lds_bytes);
+}
+// sum of `v` over the 64 lanes of the (only) wave of a 64-thread block, stored by lane 0: fixed order, deterministic
+__device__ __forceinline__ void mbd_wave_sum_store(double v, double* slot)
+{
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off);
+    if (threadIdx.x == 0) *slot = v;
+}
+// sums of `off` and `diag` over the 256 threads of a block (valid in thread 0); `red`: 264 doubles of LDS scratch
+__device__ __forceinline__ void mbd_block_sum2_256(double off, double diag, double* red, int tid, double& o4, double& d4)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { off += __shfl_down(off, o); diag += __shfl_down(diag, o); }
+    if ((tid & 63) == 0) { red[tid >> 6] = off; red[8 + (tid >> 6)] = diag; }
+    __syncthreads();
+    o4 = (red[0] + red[1]) + (red[2] + red[3]);
+    d4 = (red[8] + red[9]) + (red[10] + red[11]);
+}
+// Jacobi rotation (cosine c, tangent t) that annihilates a_pq.  The ANGLE may be approximate (a Jacobi iteration corrects
+// itself), the rotation must be orthogonal: hardware reciprocal / square root for tau and t, Newton steps on the reciprocal
+// square root that normalises (c, s).  (The correctly rounded divisions and roots were the longest part of a step, on one
+// wave, before a barrier.)
+__device__ __forceinline__ void mbd_jacobi_rotation(double app, double aqq, double apq, double& c, double& t)
+{
+    const double tau = (aqq - app) * 0.5 * __builtin_amdgcn_rcp(apq);
+    const double at = fabs(tau);
+    t = at < 1e150 ? __builtin_amdgcn_rcp(at + __builtin_amdgcn_sqrt(1.0 + at * at)) : 0.0;
+    t = tau >= 0.0 ? t : -t;
+    const double w = 1.0 + t * t;
+    const double c0 = __builtin_amdgcn_rsq(w);
+    c = c0 * (1.5 - 0.5 * w * c0 * c0);
+    c = c * (1.5 - 0.5 * w * c * c);
+}
+}  // namespace mbamd
+#endif

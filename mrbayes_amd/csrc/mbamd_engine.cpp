@@ -6,15 +6,7 @@
 //
 // Built by hipcc for gfx950 (see mrbayes_amd/build.py).  There is no CPU code path in the product:
 // without a HIP device beagleCreateInstance fails with BEAGLE_ERROR_NO_RESOURCE.
-#if defined(MBAMD_HOST_EMU)
-#include <memory>
-#include "hip_emu.h"
-#else
-#include <hip/hip_runtime.h>
-#define MBAMD_LAUNCH(kernel, grid, block, lds, stream, ...) \
-    hipLaunchKernelGGL(kernel, dim3(grid), dim3(block), lds, stream, __VA_ARGS__)
-#define MBAMD_LAUNCH_BARRIER MBAMD_LAUNCH          // (the host emulation runs kernels with workgroup barriers as fibers)
-#endif
+#include <mbamd_dev_runtime.h>   // the HIP runtime + launch macros (csrc/device/; tests/hostemu/ has the CPU stand-in for the test build)
 
 #include <algorithm>
 #include <cmath>
@@ -33,7 +25,7 @@
 #include "mbamd_reports.h"
 #include "libhmsbeagle/mbamd_reports.h"
 #include "mbamd_walk4_host.h"
-#if !defined(MBAMD_HOST_EMU)
+#if MBAMD_DEV_HAS_MFMA
 #include "mbamd_kernels_mfma.h"
 #endif
 
@@ -118,13 +110,9 @@ static inline bool wg_compiled(int S) { return S == 16 || S == 20 || (S >= 60 &&
 template <int SC_, int WMAX_, int CH_, int DEPTH_>
 static void raise_walkg_lds(int maxLds)
 {
-#if !defined(MBAMD_HOST_EMU)
     if (hipFuncSetAttribute((const void*) k_walkg<SC_, WMAX_, CH_, DEPTH_>, hipFuncAttributeMaxDynamicSharedMemorySize, maxLds) != hipSuccess ||
         hipFuncSetAttribute((const void*) k_walkg<SC_, WMAX_, CH_, DEPTH_, WalkGArgsInline>, hipFuncAttributeMaxDynamicSharedMemorySize, maxLds) != hipSuccess)
         (void) hipGetLastError();
-#else
-    (void) maxLds;
-#endif
 }
 
 enum KernelPath { PATH_AUTO = 0, PATH_GENERIC = 1, PATH_WALK = 2, PATH_MFMA = 3 };
@@ -455,7 +443,7 @@ struct Instance {
     int fetchResult(double* out);
 };
 
-#if !defined(MBAMD_HOST_EMU)
+#if MBAMD_DEV_HAS_MFMA
 static bool launch_mfma_split(Instance& in, const OpTables& tabs, int count);
 static bool launch_mfma_serial(Instance& in, const OpTables& tabs, int ntables);
 static bool launch_tips(Instance& in, const OpTables& tabs, int count);
@@ -527,7 +515,7 @@ int Instance::create(int tipCount_, int partialsBufferCount, int compactBufferCo
     else if (S <= 20) SP = 20;
     else if (S <= 32) SP = 32;
     else SP = 64;
-#if !defined(MBAMD_HOST_EMU)
+#if MBAMD_DEV_HAS_MFMA
     NT = (S + 31) / 32;
     T = (S + 1) / 2;
     mfma = !s4 && !wg && S >= 5 && S <= 64 && ((NT == 1 && K <= 4) || (NT == 2 && K <= 2)) &&
@@ -617,7 +605,7 @@ int Instance::create(int tipCount_, int partialsBufferCount, int compactBufferCo
     HIP_TRY(hipMalloc(&d_pweights, (size_t) Ppad * sizeof(double)));
     HIP_TRY(hipMalloc(&d_site, (size_t) Ppad * sizeof(double)));
     nblocks = Ppad / 64;
-#if !defined(MBAMD_HOST_EMU)
+#if MBAMD_DEV_HAS_MFMA
     if (!s4 && S >= 8) nblocks = Ppad / 32;      // k_integrate_lnl_wide / _wg_wide: one block sum per 32-pattern tile
 #endif
     HIP_TRY(hipHostMalloc(&h_sums, (size_t) nblocks * sizeof(double), hipHostMallocDefault));
@@ -674,7 +662,6 @@ void Instance::destroy()
 int Instance::configureWalk()
 {
     int numCU = 256;
-#if !defined(MBAMD_HOST_EMU)
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0) numCU = prop.multiProcessorCount;
     const int maxLds = 160 * 1024;
@@ -682,13 +669,10 @@ int Instance::configureWalk()
                hipFuncSetAttribute((const void*) k_walk4_t<Walk4Args, true>, hipFuncAttributeMaxDynamicSharedMemorySize, maxLds) != hipSuccess ||
                hipFuncSetAttribute((const void*) k_walk4_t<Walk4ArgsInline>, hipFuncAttributeMaxDynamicSharedMemorySize, maxLds) != hipSuccess))
         (void) hipGetLastError();
-#endif
     if (wg) {
         // one wave = (32-pattern tile, category); registers bound the residency: 20 states 4 waves per SIMD, 61 states 2
         const unsigned slotBytes = wg_block_bytes(S);
-#if !defined(MBAMD_HOST_EMU)
         MBAMD_WG_DISPATCH(S, raise_walkg_lds, maxLds);
-#endif
         wgGeometry(1, w4.maxW, w4.maxSlots);
         w4.maxSlots1 = w4.maxSlots;
         if (!std::getenv("MBAMD_WALK_WAVES") && !std::getenv("MBAMD_MAX_LDS_SLOTS")) {   // a single-wave program may use the LDS of the whole workgroup
@@ -737,10 +721,8 @@ int Instance::configureWalk()
 void Instance::wgGeometry(int lists, int& W, int& slots) const
 {
     int numCU = 256;
-#if !defined(MBAMD_HOST_EMU)
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0) numCU = prop.multiProcessorCount;
-#endif
     // registers bound the residency: 32-pattern tiles 4 (20 states) / 2 (61 states) waves per SIMD, 16-pattern tiles 5 / 3
 #if MBAMD_WG_TW == 32
     const int maxW = S > 32 ? 4 : 8, wavesPerCU = S > 32 ? 6 : 12;
@@ -901,13 +883,11 @@ int Instance::setRateMatrices(int first, int count, const double* q, const doubl
     const EigenJob* djobs = nullptr;
     rc = stageDirect(jobs.data(), sizeof(EigenJob) * count, (const void**) &djobs);
     if (rc) return rc;
-#if !defined(MBAMD_HOST_EMU)
     static bool ldsRaised = false;
     if (!ldsRaised) {
         if (hipFuncSetAttribute((const void*) k_eigen_reversible, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) (void) hipGetLastError();
         ldsRaised = true;
     }
-#endif
     MBAMD_LAUNCH_BARRIER(k_eigen_reversible, (unsigned) count, 256, eigen_lds_doubles(S) * sizeof(double), stream, djobs, S, 30);
     HIP_TRY(hipGetLastError());
     return BEAGLE_SUCCESS;
@@ -989,7 +969,7 @@ int Instance::flushMatrices()
         HIP_TRY(hipGetLastError());
         return BEAGLE_SUCCESS;
     }
-#if !defined(MBAMD_HOST_EMU)
+#if MBAMD_DEV_HAS_MFMA
     if (S > 8 && S <= 64) {                       // fp64 matrix cores, one wave per 16 rows
         const unsigned grid = (unsigned) (count * K);
         const int packedT = mfma ? T : 0;
@@ -1182,7 +1162,7 @@ int Instance::submit(Plan* plan, int cumIdx, int32_t* cumPtr)
         int mrc = flushMatrices();
         if (mrc) return mrc;
     }
-#if !defined(MBAMD_HOST_EMU)
+#if MBAMD_DEV_HAS_MFMA
     if (!s4 && mfma && !mfmaWhole && !noDefer) {
         if ((int) pending.size() >= MBAMD_MAX_TABLES || !independentOfPending(*plan, cumIdx)) {
             int rc = flushPending();
@@ -1236,7 +1216,7 @@ int Instance::flushPending()
         }
         return BEAGLE_SUCCESS;
     }
-#if !defined(MBAMD_HOST_EMU)
+#if MBAMD_DEV_HAS_MFMA
     hipEvent_t ev0{}, ev1{};
     { int src = spanBegin(); if (src) return src; }
     if (timing) {
@@ -1974,7 +1954,7 @@ int Instance::runWalkG(const Plan& plan)
         a.cumFresh = (&sg == &plan.segments.front()) ? wgFresh : 0;
         a.K = K; a.Ppad = Ppad; a.ntiles = Ppad / MBAMD_WG_TW; a.S = S; a.SP = SP;
         a.lists = plan.lists;
-#if !defined(MBAMD_HOST_EMU)
+#if MBAMD_DEV_SPREAD
         a.spread = sg.W == 2 ? 1 : 0;
 #endif
         if (envTrace && !d_trace) {
@@ -1992,7 +1972,7 @@ int Instance::runWalkG(const Plan& plan)
     return BEAGLE_SUCCESS;
 }
 
-#if !defined(MBAMD_HOST_EMU)
+#if MBAMD_DEV_HAS_MFMA
 template <int NT_, int SC_, int KC_>
 static void launch_mfma_t(Instance& in, const PartialsOp* ops, int count, int32_t* cum)
 {
@@ -2267,7 +2247,7 @@ int Instance::runGeneric(const Plan& plan, int32_t* cum)
     const std::vector<int>& start = plan.start;
     const int nLevels = (int) start.size() - 1;
     const bool anyScale = plan.anyScale;
-#if !defined(MBAMD_HOST_EMU)
+#if MBAMD_DEV_HAS_MFMA
     if (plan.narrow && mfma && !mfmaWhole) {
         OpTables tabs;
         std::memset(&tabs, 0, sizeof tabs);
@@ -2286,13 +2266,13 @@ int Instance::runGeneric(const Plan& plan, int32_t* cum)
     }
 #endif
     int levelEnd = nLevels;
-#if !defined(MBAMD_HOST_EMU)
+#if MBAMD_DEV_HAS_MFMA
     if (mfma && !mfmaWhole) levelEnd = plan.serialFrom;
 #endif
     for (int l = 0; l < levelEnd; ++l) {
         int off = start[l];
         int remaining = start[l + 1] - start[l];
-#if !defined(MBAMD_HOST_EMU)
+#if MBAMD_DEV_HAS_MFMA
         if (l == 0 && mfma && !mfmaWhole && plan.tipTip > 0 && plan.tipTip <= 8192) {
             OpTables tabs;
             std::memset(&tabs, 0, sizeof tabs);
@@ -2310,7 +2290,7 @@ int Instance::runGeneric(const Plan& plan, int32_t* cum)
             const int count = std::min(remaining, 32768);
             const PartialsOp* ops = plan.d_table + off;
             bool fused = true;
-#if !defined(MBAMD_HOST_EMU)
+#if MBAMD_DEV_HAS_MFMA
             if (mfma && launch_mfma(*this, ops, std::min(count, 8192), cum)) {
                 const int done = std::min(count, 8192);
                 pendingLaunches += 1;
@@ -2344,7 +2324,7 @@ int Instance::runGeneric(const Plan& plan, int32_t* cum)
             remaining -= count;
         }
     }
-#if !defined(MBAMD_HOST_EMU)
+#if MBAMD_DEV_HAS_MFMA
     if (levelEnd < nLevels) {                    // the spine: one launch walks it
         OpTables tabs;
         std::memset(&tabs, 0, sizeof tabs);
@@ -2459,7 +2439,7 @@ int Instance::integrate(const int* parent, const int* child, const int* prob, co
     }
     double* const siteOut = (siteToHost && h_site_dev) ? h_site_dev : d_site;
     siteOnHost = siteOut != d_site;
-#if !defined(MBAMD_HOST_EMU)
+#if MBAMD_DEV_HAS_MFMA
     if (S >= 8) MBAMD_LAUNCH(k_integrate_lnl_wide, (unsigned) nblocks, 256, 0, stream, a, S, SP, K, P, Ppad, (const double*) d_pweights, siteOut, h_sums_dev);
     else
 #endif
@@ -2512,11 +2492,7 @@ int Instance::integrate4(const int* parent, const int* child, const int* prob, c
     if (wg) {
         WgGeom g;
         g.tileFloats = wgTileBytes / 4; g.tipTileBytes = wgTipTileBytes; g.TP = wg_pairs_padded(S);
-#if !defined(MBAMD_HOST_EMU)
-        MBAMD_LAUNCH(k_integrate_lnl_wg_wide, (unsigned) nblocks, 256, 0, stream, a, S, SP, K, P, Ppad, g, (const double*) d_pweights, siteOut, h_sums_dev);
-#else
-        MBAMD_LAUNCH(k_integrate_lnl_wg, (unsigned) nblocks, 64, 0, stream, a, S, SP, K, P, Ppad, g, (const double*) d_pweights, siteOut, h_sums_dev);
-#endif
+        MBAMD_LAUNCH(MBAMD_INTEGRATE_WG_KERNEL, (unsigned) nblocks, MBAMD_INTEGRATE_WG_THREADS, 0, stream, a, S, SP, K, P, Ppad, g, (const double*) d_pweights, siteOut, h_sums_dev);
     } else {
         MBAMD_LAUNCH(k_integrate_lnl_s4, (unsigned) nblocks, 64, 0, stream, a, K, P, Ppad, geom, (const double*) d_pweights, siteOut, h_sums_dev);
     }
@@ -2880,7 +2856,7 @@ BeagleBenchmarkedResourceList* beagleGetBenchmarkedResourceList(int tipCount, in
         r.supportFlags = g_resources.list[i].supportFlags;
         r.requiredFlags = 0;
         r.returnCode = BEAGLE_SUCCESS;
-        r.implName = const_cast<char*>("mbamd HIP gfx950");
+        r.implName = const_cast<char*>(MBAMD_IMPL_NAME);
         r.benchedFlags = kSupport | (benchmarkFlags & BEAGLE_BENCHFLAG_SCALING_ALWAYS ? BEAGLE_FLAG_SCALING_ALWAYS : BEAGLE_FLAG_SCALING_DYNAMIC);
         r.benchmarkResult = 1.0;
         r.performanceRatio = 1.0;
@@ -2995,11 +2971,11 @@ int beagleCreateInstance(int tipCount, int partialsBufferCount, int compactBuffe
         const Instance* first = in->facade() ? in->children[0].in : in;
         returnInfo->resourceNumber = dev;
         returnInfo->resourceName = (dev < g_resources.length) ? g_resources.list[dev].name : const_cast<char*>("HIP device");
-        returnInfo->implName = const_cast<char*>(first->f64 ? "mbamd HIP gfx950: double-precision level kernels"
-                                                 : first->s4 ? "mbamd HIP gfx950: 4-state tree-walk kernels"
-                                                 : first->wg ? (MBAMD_WG_TW == 32 ? "mbamd HIP gfx950: 20/61-state tree-walk kernels (v_mfma_f32_32x32x2_f32)" : "mbamd HIP gfx950: 20/61-state tree-walk kernels (v_mfma_f32_16x16x4_f32)")
-                                                 : first->mfma ? "mbamd HIP gfx950: general-state MFMA (v_mfma_f32_32x32x2_f32) kernels"
-                                                               : "mbamd HIP gfx950: general-state vector kernels");
+        returnInfo->implName = const_cast<char*>(first->f64 ? MBAMD_IMPL_NAME ": double-precision level kernels"
+                                                 : first->s4 ? MBAMD_IMPL_NAME ": 4-state tree-walk kernels"
+                                                 : first->wg ? (MBAMD_WG_TW == 32 ? MBAMD_IMPL_NAME ": 20/61-state tree-walk kernels (v_mfma_f32_32x32x2_f32)" : MBAMD_IMPL_NAME ": 20/61-state tree-walk kernels (v_mfma_f32_16x16x4_f32)")
+                                                 : first->mfma ? MBAMD_IMPL_NAME ": general-state MFMA (v_mfma_f32_32x32x2_f32) kernels"
+                                                               : MBAMD_IMPL_NAME ": general-state vector kernels");
         returnInfo->implDescription = const_cast<char*>("hand-written HIP kernels for AMD CDNA4 (MI355X)");
         returnInfo->flags = in->flags;
     }

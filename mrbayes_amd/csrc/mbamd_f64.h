@@ -231,14 +231,7 @@ k64_integrate(IntegrateArgs64 a, int S, int K, int first, int last, int Ppad_, c
         site[c] = lnl;
         wl = lnl * pattern_weights[c];
     }
-#if defined(MBAMD_HOST_EMU)
-    if (threadIdx.x == 0) wsite[blockIdx.x] = 0.0;
-    wsite[blockIdx.x] += wl;
-#else
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) wl += __shfl_down(wl, off);
-    if (threadIdx.x == 0) wsite[blockIdx.x] = wl;
-#endif
+    mbd_wave_sum_store(wl, wsite + blockIdx.x);
 }
 
 __global__ void __launch_bounds__(256)

@@ -34,29 +34,15 @@
 // 4-state path: the exponent is per (pattern, category) -- columns of different categories never meet before the
 // root, where k_integrate_lnl_s4 recombines them exactly (see mbamd_walk4.h).
 //
-// The kernels in this file use no cross-lane operations, so the same source also builds against
-// tests/hostemu/hip_emu.h for CPU-only CI of the host logic (never part of the product).
+// What is specific to gfx950 -- address spaces, intrinsics, cross-lane sums, LDS-DMA -- is reached through the small primitive
+// headers <mbamd_dev_*.h> (csrc/device/); the TEST-ONLY host emulation (tests/hostemu/) supplies plain-C++ headers of the same
+// names on its include path, so the kernel bodies below are the code the CPU CI of the host logic runs.
 #ifndef MBAMD_KERNELS_H_
 #define MBAMD_KERNELS_H_
 
 #include <stdint.h>
 
-// Pointers that reach a kernel through the operation table are generic ("flat") as far as the
-// compiler knows.  Casting them to the global address space turns flat_load/flat_store into
-// global_load/global_store, and casting wave-uniform read-only data (operation table, transition
-// matrices) to the constant address space lets the compiler fetch it with scalar loads (s_load_*)
-// into SGPRs, where it feeds v_fma as a scalar operand for all 64 lanes at once.
-#if defined(MBAMD_HOST_EMU)
-#define MBAMD_AS_GLOBAL
-#define MBAMD_AS_CONST
-namespace mbamd { typedef float4 f4; }
-#else
-#define MBAMD_AS_GLOBAL __attribute__((address_space(1)))
-#define MBAMD_AS_CONST __attribute__((address_space(4)))
-// a native clang vector (not HIP's f4 class) so that it can be loaded/stored through
-// address-space qualified pointers as one dwordx4 access
-namespace mbamd { typedef float f4 __attribute__((ext_vector_type(4))); }
-#endif
+#include <mbamd_dev_base.h>      // MBAMD_AS_GLOBAL / MBAMD_AS_CONST, f4, mbd_* primitives (csrc/device/)
 
 namespace mbamd {
 
@@ -123,23 +109,14 @@ static_assert(sizeof(PartialsOp) == 64, "PartialsOp must be 64 bytes");
 // ---------------------------------------------------------------------------------------------
 __device__ __forceinline__ int scale_exponent(float mx)
 {
-#if defined(MBAMD_HOST_EMU)
-    int e = 0;
-    if (mx > 0.0f && mx < 3.0e38f) (void) frexpf(mx, &e);
-#else
-    int e = (mx > 0.0f && mx < 3.0e38f) ? __builtin_amdgcn_frexp_expf(mx) : 0;
-#endif
+    int e = (mx > 0.0f && mx < 3.0e38f) ? mbd_frexp_exp(mx) : 0;
     e = e < -126 ? -126 : e;      // keep 2^-e a normal float even for denormal maxima
     e = e > 126 ? 126 : e;
     return e;
 }
 __device__ __forceinline__ float scale_pow2(float v, int neg_e)
 {
-#if defined(MBAMD_HOST_EMU)
-    return ldexpf(v, neg_e);
-#else
-    return __builtin_amdgcn_ldexpf(v, neg_e);
-#endif
+    return mbd_ldexp(v, neg_e);
 }
 
 __device__ __forceinline__ float max4(f4 v) { return fmaxf(fmaxf(v.x, v.y), fmaxf(v.z, v.w)); }
@@ -366,11 +343,6 @@ k_transition_matrices_ev(const MatrixJob* __restrict__ jobs, const double* __res
 // src/likelihood.c:8765-8880) -- the Q build on the device as well.
 // One workgroup of 256 threads per matrix, S <= 64; dynamic LDS: eigen_lds_doubles(S) doubles (62 KiB at 61 states).
 // ---------------------------------------------------------------------------------------------
-#if defined(MBAMD_HOST_EMU)
-#define MBAMD_SYNC() mbamd_emu_barrier()
-#else
-#define MBAMD_SYNC() __syncthreads()
-#endif
 // out = [U | U^-1 | lambda | V]: V (S x S) are the orthonormal eigenvectors of the symmetrised matrix -- what a later call
 // starts from (`warm` = the V of an eigen-system of a NEARBY rate matrix, e.g. the chain's current state when a move proposes
 // new rates: two or three sweeps instead of nine), or nullptr for a cold start from the identity.
@@ -380,12 +352,7 @@ __host__ __device__ inline size_t eigen_lds_doubles(int S) { const size_t n = (s
 __global__ void __launch_bounds__(256)
 k_eigen_reversible(const EigenJob* __restrict__ jobs, int S, int sweeps)
 {
-#if defined(MBAMD_HOST_EMU)
-    double* lds = reinterpret_cast<double*>(mbamd_emu_dyn_lds());
-#else
-    extern __shared__ double lds_eigen[];
-    double* lds = lds_eigen;
-#endif
+    double* lds = mbd_dyn_lds<double>();
     const EigenJob job = jobs[blockIdx.x];
     const int n = (S + 1) & ~1, m = n / 2, LD = n + 1;
     double* A = lds;                         // [n][LD]  the symmetrised matrix, diagonalised in place
@@ -468,23 +435,8 @@ k_eigen_reversible(const EigenJob* __restrict__ jobs, int S, int sweeps)
                 double c = 1.0, sn = 0.0;
                 const double apq = A[p * LD + q];
                 if (fabs(apq) > 1e-300) {
-#if defined(MBAMD_HOST_EMU)
-                    const double tau = (A[q * LD + q] - A[p * LD + p]) / (2.0 * apq);
-                    const double t = (tau >= 0.0 ? 1.0 : -1.0) / (fabs(tau) + sqrt(1.0 + tau * tau));
-                    c = 1.0 / sqrt(1.0 + t * t);
-#else
-                    // The ANGLE may be approximate (a Jacobi iteration corrects itself), the rotation must be orthogonal: hardware
-                    // reciprocal / square root for tau and t, one Newton step on the reciprocal square root that normalises (c, s).
-                    // (The correctly rounded divisions and roots were the longest part of a step, on one wave, before a barrier.)
-                    const double tau = (A[q * LD + q] - A[p * LD + p]) * 0.5 * __builtin_amdgcn_rcp(apq);
-                    const double at = fabs(tau);
-                    double t = at < 1e150 ? __builtin_amdgcn_rcp(at + __builtin_amdgcn_sqrt(1.0 + at * at)) : 0.0;
-                    t = tau >= 0.0 ? t : -t;
-                    const double w = 1.0 + t * t;
-                    const double c0 = __builtin_amdgcn_rsq(w);
-                    c = c0 * (1.5 - 0.5 * w * c0 * c0);
-                    c = c * (1.5 - 0.5 * w * c * c);
-#endif
+                    double t;
+                    mbd_jacobi_rotation(A[p * LD + p], A[q * LD + q], apq, c, t);
                     sn = t * c;
                 }
                 rc[tid] = c; rs[tid] = sn; rp[tid] = p; rq[tid] = q;
@@ -533,25 +485,9 @@ k_eigen_reversible(const EigenJob* __restrict__ jobs, int S, int sweeps)
         double off = 0.0, diag = 0.0;
         for (int i = ty; i < n; i += 8)
             for (int j2 = tx; j2 < n; j2 += 32) { const double v = A[i * LD + j2]; if (i == j2) diag += v * v; else off += v * v; }
-#if !defined(MBAMD_HOST_EMU)
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) { off += __shfl_down(off, o); diag += __shfl_down(diag, o); }
-        if ((tid & 63) == 0) { red[tid >> 6] = off; red[8 + (tid >> 6)] = diag; }
-        MBAMD_SYNC();
+        double o4, d4;
+        mbd_block_sum2_256(off, diag, red, tid, o4, d4);
         if (tid == 0) {
-            const double o4 = (red[0] + red[1]) + (red[2] + red[3]), d4 = (red[8] + red[9]) + (red[10] + red[11]);
-#else
-        red[tid] = off;
-        MBAMD_SYNC();
-        if (tid == 0) { double t = 0.0; for (int u = 0; u < 256; ++u) t += red[u]; red[257] = t; }
-        MBAMD_SYNC();
-        red[tid] = diag;
-        MBAMD_SYNC();
-        if (tid == 0) {
-            double d4 = 0.0;
-            for (int u = 0; u < 256; ++u) d4 += red[u];
-            const double o4 = red[257];
-#endif
             // (quadratic convergence: once the off-diagonal mass is below 1e-20 of the diagonal's, one more sweep takes it to rounding)
             red[258] = (o4 <= 1e-20 * d4) ? red[259] + 1.0 : 0.0;
             red[259] = red[258];
@@ -644,14 +580,7 @@ k_integrate_lnl(IntegrateArgs a, int S, int SP, int K, int P, int Ppad,
     }
     // one partial sum per 64-pattern block, reduced in a fixed order (deterministic); `wsite` is an
     // array of P_pad/64 doubles that may live in pinned host memory: the host adds them up
-#if defined(MBAMD_HOST_EMU)
-    if (threadIdx.x == 0) wsite[blockIdx.x] = 0.0;
-    wsite[blockIdx.x] += wl;
-#else
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) wl += __shfl_down(wl, off);
-    if (threadIdx.x == 0) wsite[blockIdx.x] = wl;
-#endif
+    mbd_wave_sum_store(wl, wsite + blockIdx.x);
 }
 
 // 4-state root / edge integration (Likelihood_NUC4, src/likelihood.c:6238-6366; edge form as above).  One thread per
@@ -718,14 +647,7 @@ k_integrate_lnl_s4(IntegrateArgs4 a, int K, int P, int Ppad, BlockGeom g,
     } else if (c < Ppad) {
         site[c] = 0.0;
     }
-#if defined(MBAMD_HOST_EMU)
-    if (threadIdx.x == 0) wsite[blockIdx.x] = 0.0;
-    wsite[blockIdx.x] += wl;
-#else
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) wl += __shfl_down(wl, off);
-    if (threadIdx.x == 0) wsite[blockIdx.x] = wl;
-#endif
+    mbd_wave_sum_store(wl, wsite + blockIdx.x);
 }
 
 // 20/61-state tree-walk layout (mbamd_walkg.h): partials float [tile][buffer][K][T][64], tip states uint8 [tile][buffer][32],
@@ -733,9 +655,7 @@ k_integrate_lnl_s4(IntegrateArgs4 a, int K, int P, int Ppad, BlockGeom g,
 // recombined as in k_integrate_lnl_s4: k_integrate_lnl_wg_wide (mbamd_kernels_mfma.h; the host-emulation build has a one-thread-
 // per-pattern twin in tests/hostemu/mbamd_walkg_emu.h).
 struct WgGeom { unsigned long tileFloats; unsigned tipTileBytes; int TP; };
-#if defined(MBAMD_HOST_EMU)
-#include "mbamd_integrate_wg_emu.h"   // tests/hostemu/ (test build only)
-#endif
+#include <mbamd_dev_integrate_wg.h>   // k_integrate_lnl_wg_wide (csrc/device/: eight threads per pattern, wave shuffles)
 // ---------------------------------------------------------------------------------------------
 // cumulative scale-factor bookkeeping (exact integer arithmetic)
 // ---------------------------------------------------------------------------------------------

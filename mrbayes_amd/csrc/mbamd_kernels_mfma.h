@@ -907,86 +907,5 @@ k_integrate_lnl_wide(IntegrateArgs a, int S, int SP, int K, int P, int Ppad, con
     if (p == 0) wsite[blockIdx.x] = wl;
 }
 
-// The same for the tree-walk layout (mbamd_walkg.h: partials [tile][buffer][K] blocks in wg_at order, tip states
-// [tile][buffer][TW], cumulative exponents per pattern AND category): eight threads per pattern, the categories recombined
-// exactly as in k_integrate_lnl_s4.  grid = P_pad/32, block = 256 (32 patterns: one or two tiles).
-__global__ void __launch_bounds__(256)
-k_integrate_lnl_wg_wide(IntegrateArgs4 a, int S, int SP, int K, int P, int Ppad, WgGeom geo, const double* __restrict__ pattern_weights,
-                        double* __restrict__ site, double* __restrict__ wsite)
-{
-    __shared__ double part[8][32];
-    const int p = threadIdx.x & 31, g = threadIdx.x >> 5;
-    const int sh = wg_vec_shift(S);                  // rows interleaved per lane: wg_vec(S) = 1 << sh
-    const int c = blockIdx.x * 32 + p;
-    const bool live = c < P;
-    const int tile = c / MBAMD_WG_TW, pt = c % MBAMD_WG_TW;      // this pattern's tile and its column there
-    const size_t pb = (size_t) tile * geo.tileFloats, kstride = (size_t) geo.TP * 64;
-    int emax = -2147483647;
-    double like = 0.0;
-    if (live) {
-        for (int n = 0; n < a.count; ++n)
-            for (int k = 0; k < K; ++k) {
-                const int e = a.cum[n] ? a.cum[n][(size_t) k * Ppad + c] : 0;
-                emax = e > emax ? e : emax;
-            }
-        for (int n = 0; n < a.count; ++n) {
-            const float* __restrict__ par = reinterpret_cast<const float*>(a.parent[n]) + pb;
-            const double* __restrict__ fr = a.freqs[n];
-            unsigned s = 0;
-            if (a.child[n] != nullptr && a.child_kind[n] == CHILD_STATES)
-                s = reinterpret_cast<const uint8_t*>(a.child[n])[(size_t) tile * geo.tipTileBytes + pt];
-            for (int k = 0; k < K; ++k) {
-                const float* __restrict__ pk = par + (size_t) k * kstride;
-                double cat = 0.0;
-                if (a.child[n] == nullptr) {
-                    for (int i0 = 0; i0 < S; i0 += 64) {
-                        float v[8];
-                        double f[8];
-#pragma unroll
-                        for (int u = 0; u < 8; ++u) {
-                            const int i = i0 + g + 8 * u;
-                            v[u] = (i < S) ? pk[wg_elem_sh(sh, i, pt)] : 0.0f;
-                            f[u] = (i < S) ? fr[i] : 0.0;
-                        }
-#pragma unroll
-                        for (int u = 0; u < 8; ++u) cat += (double) v[u] * f[u];
-                    }
-                } else if (a.child_kind[n] == CHILD_STATES) {
-                    const float* __restrict__ mrow = a.matrix[n] + (size_t) k * SP * SP + (size_t) (s < (unsigned) S ? s : 0) * SP;
-                    for (int i = g; i < S; i += 8) {
-                        const float pc = (s >= (unsigned) S) ? 1.0f : mrow[i];
-                        cat += (double) (pk[wg_elem_sh(sh, i, pt)] * pc) * fr[i];
-                    }
-                } else {
-                    const float* __restrict__ ch = reinterpret_cast<const float*>(a.child[n]) + pb + (size_t) k * kstride;
-                    const float* __restrict__ m = a.matrix[n] + (size_t) k * SP * SP;
-                    for (int i = g; i < S; i += 8) {
-                        float acc = 0.0f;
-                        for (int j = 0; j < S; ++j) acc = fmaf(m[(size_t) j * SP + i], ch[wg_elem_sh(sh, j, pt)], acc);
-                        cat += (double) (pk[wg_elem_sh(sh, i, pt)] * acc) * fr[i];
-                    }
-                }
-                const int e = a.cum[n] ? a.cum[n][(size_t) k * Ppad + c] : 0;
-                like += ldexp(cat * a.weights[n][k], e - emax);
-            }
-        }
-    }
-    part[g][p] = like;
-    __syncthreads();
-    if (g != 0) return;                              // lanes 0..31 of wave 0 finish
-    double wl = 0.0;
-    if (live) {
-        const double total = ((part[0][p] + part[1][p]) + (part[2][p] + part[3][p])) + ((part[4][p] + part[5][p]) + (part[6][p] + part[7][p]));
-        const double lnl = log(total) + (double) emax * 0.69314718055994530942;
-        site[c] = lnl;
-        wl = lnl * pattern_weights[c];
-    } else if (c < Ppad) {
-        site[c] = 0.0;
-    }
-#pragma unroll
-    for (int off = 16; off > 0; off >>= 1) wl += __shfl_down(wl, off, 32);
-    if (p == 0) wsite[blockIdx.x] = wl;
-}
-
 }  // namespace mbamd
 #endif

@@ -45,25 +45,9 @@ enum { PARS_DOWN = 0, PARS_FINAL = 1 };
 // The descriptors of one chunk (CH steps x 8 dwords <= 64 dwords): ONE vector load, lane l holding dword l, fetched two
 // chunks ahead; the uniform fields come back out with v_readlane.  (Scalar loads would do, but a wave that is alone on its
 // CU misses the scalar cache on every one of them.)
-#if defined(MBAMD_HOST_EMU)
-struct ParsDesc {
-    const int* p;
-    int get(int i) const { return p[i]; }
-};
-template <int CH> static inline ParsDesc pars_desc_load(const ParsStep* steps, int ch, int)
-{
-    return {reinterpret_cast<const int*>(steps + (size_t) ch * CH)};
-}
-#else
-struct ParsDesc {
-    int v;
-    __device__ __forceinline__ int get(int i) const { return __builtin_amdgcn_readlane(v, i); }
-};
-template <int CH> __device__ __forceinline__ ParsDesc pars_desc_load(const ParsStep* steps, int ch, int lane)
-{
-    return {reinterpret_cast<const int*>(steps + (size_t) ch * CH)[lane & (CH * 8 - 1)]};
-}
-#endif
+}  // namespace mbamd
+#include <mbamd_dev_pars.h>      // ParsDesc, pars_desc_load (csrc/device/)
+namespace mbamd {
 
 // the type a set is computed in: 32 bits for the narrow storage types (no sub-dword packing in registers or in LDS)
 template <class T> struct ParsWide { typedef uint32_t type; };
@@ -87,12 +71,7 @@ __global__ void __launch_bounds__(64)
 k_pars_walk(const ParsStep* __restrict__ steps, int nchunks, T* sets, unsigned stride, const float* __restrict__ w, double* partial)
 {
     typedef typename ParsWide<T>::type X;
-#if defined(MBAMD_HOST_EMU)
-    X* ring = reinterpret_cast<X*>(mbamd_emu_dyn_lds());
-#else
-    extern __shared__ unsigned char pars_lds[];
-    X* ring = reinterpret_cast<X*>(pars_lds);
-#endif
+    X* ring = mbd_dyn_lds<X>();
     const unsigned lane = threadIdx.x;
     const unsigned c = blockIdx.x * 64u + lane;                  // (nSets + 2) * P_pad < 2^32, checked at create
     const float wc = w[c];
@@ -172,14 +151,7 @@ k_pars_walk(const ParsStep* __restrict__ steps, int nchunks, T* sets, unsigned s
         d1 = d3;
     }
     if (!partial) return;
-#if defined(MBAMD_HOST_EMU)
-    if (threadIdx.x == 0) partial[blockIdx.x] = 0.0;
-    partial[blockIdx.x] += len;
-#else
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) len += __shfl_down(len, off);
-    if (threadIdx.x == 0) partial[blockIdx.x] = len;
-#endif
+    mbd_wave_sum_store(len, partial + blockIdx.x);
 }
 
 // candidate lengths (reference src/proposal.c:10783-10876 and the like): block (i, y) sums its share of the patterns
@@ -202,14 +174,7 @@ k_pars_score(const ParsOp* __restrict__ tuples, const T* __restrict__ sets, size
         if (pars_empty(x & y)) len += w[c];
     }
     const size_t slot = (size_t) blockIdx.x * gridDim.y + blockIdx.y;
-#if defined(MBAMD_HOST_EMU)
-    if (threadIdx.x == 0) out[slot] = 0.0;
-    out[slot] += len;
-#else
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) len += __shfl_down(len, off);
-    if (threadIdx.x == 0) out[slot] = len;
-#endif
+    mbd_wave_sum_store(len, out + slot);
 }
 
 // ------------------------------------------------------------------------------------------------------------------

@@ -97,152 +97,18 @@ __host__ __device__ inline size_t walk4_lds_bytes(int W, int nslots) { return (s
 __host__ __device__ inline unsigned walk4_grid(int nblocks, int K) { return 8u * (unsigned) K * (unsigned) ((nblocks + 7) / 8); }
 
 struct Walk4Planes { uint64_t p[4]; };
+struct Walk4Half { unsigned ctl, dst, c1, c2; };   // the first half of an entry: all the far-ahead tip touch needs
 
-#if defined(MBAMD_HOST_EMU)
-struct Walk4Mat { float m[16]; };
-__device__ inline Walk4Mat walk4_load_matrix(const float* p) { Walk4Mat r; for (int i = 0; i < 16; ++i) r.m[i] = p[i]; return r; }
-__device__ inline Walk4Planes walk4_load_planes(const uint64_t* p) { Walk4Planes r; for (int i = 0; i < 4; ++i) r.p[i] = p[i]; return r; }
-__device__ inline f4 walk4_tip_vector(const Walk4Planes& t, unsigned lane)
-{
-    f4 v;
-    v.x = (float) (t.p[0] >> lane & 1u); v.y = (float) (t.p[1] >> lane & 1u);
-    v.z = (float) (t.p[2] >> lane & 1u); v.w = (float) (t.p[3] >> lane & 1u);
-    return v;
-}
-__device__ inline void walk4_dma(const f4* base, unsigned lane, f4* slot) { slot[lane] = base[lane]; }
-__device__ inline void walk4_dma_exps(const int8_t* base, unsigned lane, int* stage) { stage[lane] = base[lane]; }
-__device__ inline void walk4_touch_planes(const uint64_t*, const uint64_t*, unsigned, int*) {}
-__device__ inline void walk4_wait_vm(unsigned) {}
-__device__ inline void walk4_barrier() { mbamd_emu_barrier(); }
-__device__ inline Walk4Entry walk4_load_entry(const Walk4Entry* p) { return *p; }
-struct Walk4Half { unsigned ctl, dst, c1, c2; };
-__device__ inline Walk4Half walk4_load_half(const Walk4Entry* p) { Walk4Half h; h.ctl = p->ctl; h.dst = p->dst; h.c1 = p->c1; h.c2 = p->c2; return h; }
-#else
-typedef float f2v __attribute__((ext_vector_type(2)));
-typedef float f16v __attribute__((ext_vector_type(16)));
-typedef unsigned u8v __attribute__((ext_vector_type(8)));
-typedef unsigned u16v __attribute__((ext_vector_type(16)));
-typedef unsigned long ul4v __attribute__((ext_vector_type(4)));
-struct Walk4Mat { f16v m; };
-// wave-uniform, read-only: constant address space -> s_load_dwordx16 / s_load_dwordx8
-__device__ __forceinline__ Walk4Mat walk4_load_matrix(const float* p)
-{
-    Walk4Mat r;
-    r.m = *reinterpret_cast<const MBAMD_AS_CONST f16v*>((uintptr_t) p);
-    return r;
-}
-__device__ __forceinline__ Walk4Entry walk4_load_entry(const Walk4Entry* p)
-{
-    const u8v v = *reinterpret_cast<const MBAMD_AS_CONST u8v*>((uintptr_t) p);
-    Walk4Entry e;
-    e.ctl = v[0]; e.dst = v[1]; e.c1 = v[2]; e.c2 = v[3]; e.m1 = v[4]; e.m2 = v[5]; e.ewrite = v[6]; e.eread = v[7];
-    return e;
-}
-// the first half of an entry (ctl, dst, c1, c2): all the far-ahead tip touch needs
-struct Walk4Half { unsigned ctl, dst, c1, c2; };
-__device__ __forceinline__ Walk4Half walk4_load_half(const Walk4Entry* p)
-{
-    typedef unsigned u4v __attribute__((ext_vector_type(4)));
-    const u4v v = *reinterpret_cast<const MBAMD_AS_CONST u4v*>((uintptr_t) p);
-    Walk4Half h;
-    h.ctl = v[0]; h.dst = v[1]; h.c1 = v[2]; h.c2 = v[3];
-    return h;
-}
-__device__ __forceinline__ Walk4Planes walk4_load_planes(const uint64_t* p)
-{
-    const ul4v v = *reinterpret_cast<const MBAMD_AS_CONST ul4v*>((uintptr_t) p);
-    Walk4Planes r;
-    r.p[0] = v[0]; r.p[1] = v[1]; r.p[2] = v[2]; r.p[3] = v[3];
-    return r;
-}
-// a bitplane in a scalar register pair IS a lane mask: one v_cndmask_b32 per state
-__device__ __forceinline__ f4 walk4_tip_vector(const Walk4Planes& t, unsigned)
-{
-    f4 v;
-    asm("v_cndmask_b32_e64 %0, 0, 1.0, %1" : "=v"(v.x) : "s"(t.p[0]));
-    asm("v_cndmask_b32_e64 %0, 0, 1.0, %1" : "=v"(v.y) : "s"(t.p[1]));
-    asm("v_cndmask_b32_e64 %0, 0, 1.0, %1" : "=v"(v.z) : "s"(t.p[2]));
-    asm("v_cndmask_b32_e64 %0, 0, 1.0, %1" : "=v"(v.w) : "s"(t.p[3]));
-    return v;
-}
-// LDS-DMA: 64 lanes x 16 bytes (base + lane16 each) straight into the 1 KiB LDS slot at byte address lds_dst
-// (lane-linear).  `base` is wave-uniform (scalar registers).  M0 is compiler-reserved: saved and restored inside.
-__device__ __forceinline__ void walk4_dma(const f4* base, unsigned lane16, unsigned lds_dst)
-{
-    // sc0 sc1: served by L2, never by this CU's vector L1 (the line is read once, and it may have been written by
-    // another wave of this workgroup a moment ago)
-    unsigned keep;
-    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2 sc0 sc1\n\ts_mov_b32 m0, %0"
-                 : "=&s"(keep) : "v"(lane16), "s"(base), "s"(lds_dst) : "memory");
-}
-// one signed byte per lane (base + lane) -> a dword per lane at LDS byte address lds_dst + 4 * lane
-__device__ __forceinline__ void walk4_dma_exps(const int8_t* base, unsigned lane, unsigned lds_dst)
-{
-    unsigned keep;
-    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_sbyte %1, %2\n\ts_mov_b32 m0, %0"
-                 : "=&s"(keep) : "v"(lane), "s"(base), "s"(lds_dst) : "memory");
-}
-// Pull the 64-byte lines that hold two sets of tip bitplanes into this XCD's L2 ahead of the scalar loads that will want
-// them: every lane asks for the same dword (one request), the LDS-DMA form has no destination register to keep alive, and
-// what lands (256 bytes at lds_dst, twice) is never read.  Two vector-memory instructions, counted by the host like the others.
-__device__ __forceinline__ void walk4_touch_planes(const uint64_t* p1, const uint64_t* p2, unsigned zero, unsigned lds_dst)
-{
-    unsigned keep;
-    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %4\n\ts_nop 0\n\tglobal_load_lds_dword %1, %2\n\tglobal_load_lds_dword %1, %3\n\ts_mov_b32 m0, %0"
-                 : "=&s"(keep) : "v"(zero), "s"(p1), "s"(p2), "s"(lds_dst) : "memory");
-}
-// wait until at most n vector-memory instructions of this wave are outstanding (s_waitcnt takes an immediate: the
-// host rounds n down to one of these values; only entries that read a prefetched child come here)
-__device__ __forceinline__ void walk4_wait_vm(unsigned n)
-{
-#define MBAMD_W4_WAIT(N) case N: asm volatile("s_waitcnt vmcnt(" #N ")" ::: "memory"); break;
-    switch (n) {
-        MBAMD_W4_WAIT(1) MBAMD_W4_WAIT(2) MBAMD_W4_WAIT(3) MBAMD_W4_WAIT(4) MBAMD_W4_WAIT(5) MBAMD_W4_WAIT(6)
-        MBAMD_W4_WAIT(8) MBAMD_W4_WAIT(10) MBAMD_W4_WAIT(12) MBAMD_W4_WAIT(16) MBAMD_W4_WAIT(20) MBAMD_W4_WAIT(24)
-        MBAMD_W4_WAIT(32) MBAMD_W4_WAIT(40) MBAMD_W4_WAIT(48)
-        default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
-    }
-#undef MBAMD_W4_WAIT
-}
-__device__ __forceinline__ void walk4_barrier()
-{
-    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-    asm volatile("" ::: "memory");
-}
-#endif
+}  // namespace mbamd
+#include <mbamd_dev_walk4.h>     // Walk4Mat, walk4_load_* / walk4_tip_vector / walk4_dma* / walk4_wait_vm / walk4_barrier / walk4_matvec / ... (csrc/device/)
+namespace mbamd {
+
 // the values walk4_wait_vm implements, for the host: the largest supported count <= n
 __host__ __device__ inline unsigned walk4_round_wait(long n)
 {
     const unsigned ok[] = {0, 1, 2, 3, 4, 5, 6, 8, 10, 12, 16, 20, 24, 32, 40, 48};
     unsigned r = 0;
     for (unsigned v : ok) if ((long) v <= n) r = v;
-    return r;
-}
-
-// f_i = sum_j P(i->j) v_j with the transposed matrix mT[j][i] in scalar registers; the same fma chain
-// (j = 0..3, first term a plain product) as the reference's scalar loop order, two rows per v_pk_fma_f32.
-__device__ __forceinline__ f4 walk4_matvec(const Walk4Mat& M, f4 v)
-{
-    f4 r;
-#if defined(MBAMD_HOST_EMU)
-    const float* m = M.m;
-    r.x = fmaf(m[12], v.w, fmaf(m[8], v.z, fmaf(m[4], v.y, m[0] * v.x)));
-    r.y = fmaf(m[13], v.w, fmaf(m[9], v.z, fmaf(m[5], v.y, m[1] * v.x)));
-    r.z = fmaf(m[14], v.w, fmaf(m[10], v.z, fmaf(m[6], v.y, m[2] * v.x)));
-    r.w = fmaf(m[15], v.w, fmaf(m[11], v.z, fmaf(m[7], v.y, m[3] * v.x)));
-#else
-    const f16v m = M.m;
-    f2v lo = f2v{m[0], m[1]} * f2v{v.x, v.x};
-    f2v hi = f2v{m[2], m[3]} * f2v{v.x, v.x};
-    lo = __builtin_elementwise_fma(f2v{m[4], m[5]}, f2v{v.y, v.y}, lo);
-    hi = __builtin_elementwise_fma(f2v{m[6], m[7]}, f2v{v.y, v.y}, hi);
-    lo = __builtin_elementwise_fma(f2v{m[8], m[9]}, f2v{v.z, v.z}, lo);
-    hi = __builtin_elementwise_fma(f2v{m[10], m[11]}, f2v{v.z, v.z}, hi);
-    lo = __builtin_elementwise_fma(f2v{m[12], m[13]}, f2v{v.w, v.w}, lo);
-    hi = __builtin_elementwise_fma(f2v{m[14], m[15]}, f2v{v.w, v.w}, hi);
-    r.x = lo[0]; r.y = lo[1]; r.z = hi[0]; r.w = hi[1];
-#endif
     return r;
 }
 
@@ -262,15 +128,9 @@ struct Walk4ArgsInline {
 __device__ __forceinline__ const Walk4Args& walk4_args(const Walk4Args& a) { return a; }
 __device__ __forceinline__ const Walk4Args& walk4_args(const Walk4ArgsInline& a) { return a.a; }
 __device__ __forceinline__ const Walk4Entry* walk4_program(const Walk4Args& a) { return a.prog; }
-#if defined(MBAMD_HOST_EMU)
-__device__ __forceinline__ const Walk4Entry* walk4_program(const Walk4ArgsInline& a) { return a.inl; }
-#else
-// (the address of a by-value kernel parameter would be that of a private copy: read the argument block itself)
-__device__ __forceinline__ const Walk4Entry* walk4_program(const Walk4ArgsInline&)
-{
-    return reinterpret_cast<const Walk4Entry*>((uintptr_t) __builtin_amdgcn_kernarg_segment_ptr() + offsetof(Walk4ArgsInline, inl));
-}
-#endif
+}  // namespace mbamd
+#include <mbamd_dev_walk4_args.h>   // walk4_program(const Walk4ArgsInline&): the program inside the kernel arguments
+namespace mbamd {
 
 // blockDim.x = 64 * W; grid = walk4_grid(nblocks, K) workgroups.  Dynamic LDS: walk4_lds_bytes(W, nslots).
 // ARGS = Walk4Args (program in a device buffer) or Walk4ArgsInline (program in the arguments).
@@ -283,14 +143,8 @@ k_walk4_t(ARGS AA)
 {
     const Walk4Args& A = walk4_args(AA);
     const unsigned lane = threadIdx.x & 63;
-#if defined(MBAMD_HOST_EMU)
-    const int wave = (int) (threadIdx.x >> 6);
-    char* lds = reinterpret_cast<char*>(mbamd_emu_dyn_lds());
-#else
-    const int wave = __builtin_amdgcn_readfirstlane((int) (threadIdx.x >> 6));
-    extern __shared__ f4 lds_walk4[];
-    char* lds = reinterpret_cast<char*>(lds_walk4);
-#endif
+    const int wave = mbd_wave_index();
+    char* lds = mbd_dyn_lds<char>();
     const unsigned K = (unsigned) A.K;
     // workgroup id -> (pattern block, category): see walk4_grid
     const unsigned xcd = blockIdx.x & 7u, pos = blockIdx.x >> 3;
@@ -304,30 +158,15 @@ k_walk4_t(ARGS AA)
     const uint64_t* const T0 = A.tips + (size_t) blk * A.tstride;
     int8_t* const E0 = A.exps + (size_t) blk * A.estride + (size_t) k * 64;
     const float* const M0 = A.matrices + (size_t) k * 16;
-#if defined(MBAMD_HOST_EMU)
-#define MBAMD_W4_PREFETCH(SRC, DST) walk4_dma(walk4_at(P0, SRC), lane, reinterpret_cast<f4*>(slots - lane * 16 + (DST)))
-#define MBAMD_W4_EXPS(OFF, PARITY) walk4_dma_exps(walk4_at(E0, OFF), lane, stage + 64 * (PARITY))
-#else
-    const unsigned lane16 = lane * 16u;
-    const unsigned stage_lds = (unsigned) (uintptr_t) (__attribute__((address_space(3))) char*) mine;
-    const unsigned slots_lds = stage_lds + MBAMD_W4_STAGE;
-#define MBAMD_W4_PREFETCH(SRC, DST) walk4_dma(walk4_at(P0, SRC), lane16, slots_lds + (DST))
-#define MBAMD_W4_EXPS(OFF, PARITY) walk4_dma_exps(walk4_at(E0, OFF), lane, stage_lds + 256u * (PARITY))
-#endif
+    const Walk4Lds L = walk4_lds(mine, lane);                                    // the same window for the LDS-DMA forms
+#define MBAMD_W4_PREFETCH(SRC, DST) walk4_prefetch(L, walk4_at(P0, SRC), (DST))
+#define MBAMD_W4_EXPS(OFF, PARITY) walk4_fetch_exps(L, walk4_at(E0, OFF), lane, (PARITY))
 
     const Walk4Entry* prog = walk4_program(AA) + (size_t) wave * A.entries;
     const int n = A.entries - A.tail;
     Walk4Entry DA = walk4_load_entry(prog), DB = walk4_load_entry(prog + 1);
     const int ahead = TIPPF ? A.tipAhead : 0;
     Walk4Half FAR = walk4_load_half(prog + ahead);               // (TIPPF) entry j + ahead, loaded during iteration j - 1
-#if defined(MBAMD_HOST_EMU)
-    int* const junk = stage + 128;
-    const unsigned vzero = 0;
-#else
-    const unsigned junk = stage_lds + 512u;
-    unsigned vzero;
-    asm volatile("v_mov_b32 %0, 0" : "=v"(vzero));
-#endif
     // inputs of entry 0
     Walk4Mat M1 = walk4_load_matrix(walk4_at(M0, DA.m1));
     Walk4Mat M2 = walk4_load_matrix(walk4_at(M0, DA.m2));
@@ -378,7 +217,7 @@ k_walk4_t(ARGS AA)
         // top of the iteration: FAR came with the previous burst, and the first instruction that reads anything of a burst
         // waits for ALL of it (one lgkmcnt, scalar loads return out of order); the products have paid for that wait already
         if (TIPPF) {
-            walk4_touch_planes(walk4_at(T0, (FAR.ctl & MBAMD_W4_TIP1) ? FAR.c1 : 0u), walk4_at(T0, (FAR.ctl & MBAMD_W4_TIP2) ? FAR.c2 : 0u), vzero, junk);
+            walk4_touch(L, walk4_at(T0, (FAR.ctl & MBAMD_W4_TIP1) ? FAR.c1 : 0u), walk4_at(T0, (FAR.ctl & MBAMD_W4_TIP2) ? FAR.c2 : 0u));
         }
         // the scalar-load burst for the next entry (the registers of this entry's matrices / planes are free now); a
         // child that is not a tip reads the planes at offset 0 -- a valid address, the value is not used
@@ -408,21 +247,7 @@ k_walk4_t(ARGS AA)
             out.z = scale_pow2(out.z, -e); out.w = scale_pow2(out.w, -e);
             prev = out;
             if (ctl & MBAMD_W4_KEEP) *reinterpret_cast<f4*>(slots + ((ctl >> 6) & 0x3FC00u)) = out;
-#if defined(MBAMD_HOST_EMU)
-            walk4_at(P0, dst)[lane] = out;
-            walk4_at(E0, ewrite)[lane] = (int8_t) e;
-#else
-            // 1 KiB contiguous per wave; never waited for.  Non-temporal: the result is not read again in this launch
-            // (parents read the LDS copy), so it must not push the matrices and programs out of L2
-#if defined(MBAMD_W4X_NOSTORE)
-            if (e == 12345) {
-#endif
-            __builtin_nontemporal_store(out, as_global(walk4_at(P0, dst)) + lane);
-            __builtin_nontemporal_store((int8_t) e, as_global(walk4_at(E0, ewrite)) + lane);
-#if defined(MBAMD_W4X_NOSTORE)
-            }
-#endif
-#endif
+            walk4_store(walk4_at(P0, dst), walk4_at(E0, ewrite), lane, out, e);
         }
     };
     for (int j = 0; j < n; j += 2) {

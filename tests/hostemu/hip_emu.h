@@ -67,7 +67,9 @@ inline hipError_t hipSetDevice(int) { return hipSuccess; }
 inline hipError_t hipGetDeviceProperties(hipDeviceProp_t* p, int) {
     std::snprintf(p->name, sizeof p->name, "host emulation (TEST ONLY)");
     std::snprintf(p->gcnArchName, sizeof p->gcnArchName, "hostemu");
-    p->totalGlobalMem = (size_t) 8 << 30; p->multiProcessorCount = 1; return hipSuccess; }
+    p->totalGlobalMem = (size_t) 8 << 30; p->multiProcessorCount = 256; return hipSuccess; }   // the geometry heuristics see an MI355X
+enum hipFuncAttribute { hipFuncAttributeMaxDynamicSharedMemorySize = 8 };
+inline hipError_t hipFuncSetAttribute(const void*, hipFuncAttribute, int) { return hipSuccess; }
 inline hipError_t hipMalloc(void** p, size_t n) { *p = std::calloc(1, n ? n : 1); return *p ? hipSuccess : hipErrorOutOfMemory; }
 template <class T> inline hipError_t hipMalloc(T** p, size_t n) { return hipMalloc((void**) p, n); }
 inline hipError_t hipFree(void* p) { std::free(p); return hipSuccess; }

@@ -1,0 +1,43 @@
+// mbamd_dev_base.h -- TEST ONLY (tests/hostemu): plain-C++ twins of the device primitives of
+// mrbayes_amd/csrc/device/mbamd_dev_base.h, found first on the include path of the host-emulation build.  Never part of the product.
+#ifndef MBAMD_DEV_BASE_H_
+#define MBAMD_DEV_BASE_H_
+#include <cmath>
+#define MBAMD_AS_GLOBAL
+#define MBAMD_AS_CONST
+#define MBAMD_SYNC() mbamd_emu_barrier()
+#define MBAMD_IMPL_NAME "mbamd HOST EMULATION (test only)"
+namespace mbamd {
+typedef float4 f4;
+inline int mbd_frexp_exp(float v) { int e = 0; (void) frexpf(v, &e); return e; }
+inline float mbd_ldexp(float v, int e) { return ldexpf(v, e); }
+inline int mbd_wave_index() { return (int) (threadIdx.x >> 6); }
+template <class T> inline T* mbd_dyn_lds() { return reinterpret_cast<T*>(mbamd_emu_dyn_lds()); }
+// (threads of a block run one after the other between barriers: thread 0 comes first)
+inline void mbd_wave_sum_store(double v, double* slot)
+{
+    if (threadIdx.x == 0) *slot = 0.0;
+    *slot += v;
+}
+inline void mbd_block_sum2_256(double off, double diag, double* red, int tid, double& o4, double& d4)
+{
+    red[tid] = off;
+    mbamd_emu_barrier();
+    if (tid == 0) { double t = 0.0; for (int u = 0; u < 256; ++u) t += red[u]; red[257] = t; }
+    mbamd_emu_barrier();
+    red[tid] = diag;
+    mbamd_emu_barrier();
+    o4 = d4 = 0.0;
+    if (tid == 0) {
+        for (int u = 0; u < 256; ++u) d4 += red[u];
+        o4 = red[257];
+    }
+}
+inline void mbd_jacobi_rotation(double app, double aqq, double apq, double& c, double& t)
+{
+    const double tau = (aqq - app) / (2.0 * apq);
+    t = (tau >= 0.0 ? 1.0 : -1.0) / (fabs(tau) + sqrt(1.0 + tau * tau));
+    c = 1.0 / sqrt(1.0 + t * t);
+}
+}  // namespace mbamd
+#endif

@@ -1,8 +1,11 @@
-// mbamd_integrate_wg_emu.h -- TEST ONLY (tests/hostemu): root / edge integration for the 20/61-state tree-walk layout with one
+// mbamd_dev_integrate_wg.h -- TEST ONLY (tests/hostemu): root / edge integration for the 20/61-state tree-walk layout with one
 // thread per pattern, for the host-emulation build (the product kernel, k_integrate_lnl_wg_wide in mbamd_kernels_mfma.h, uses
 // eight threads per pattern and wave shuffles).  Never part of the product.
-#ifndef MBAMD_INTEGRATE_WG_EMU_H_
-#define MBAMD_INTEGRATE_WG_EMU_H_
+#ifndef MBAMD_DEV_INTEGRATE_WG_H_
+#define MBAMD_DEV_INTEGRATE_WG_H_
+#define MBAMD_INTEGRATE_WG_KERNEL k_integrate_lnl_wg
+#define MBAMD_INTEGRATE_WG_THREADS 64
+#define MBAMD_INTEGRATE_WG_PATTERNS 64
 
 // root / edge integration for the tree-walk layout, one thread per pattern (the product: k_integrate_lnl_wg_wide)
 __global__ void __launch_bounds__(64)
@@ -58,14 +61,7 @@ k_integrate_lnl_wg(IntegrateArgs4 a, int S, int SP, int K, int P, int Ppad, WgGe
     } else if (c < Ppad) {
         site[c] = 0.0;
     }
-#if defined(MBAMD_HOST_EMU)
-    if (threadIdx.x == 0) wsite[blockIdx.x] = 0.0;
-    wsite[blockIdx.x] += wl;
-#else
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) wl += __shfl_down(wl, off);
-    if (threadIdx.x == 0) wsite[blockIdx.x] = wl;
-#endif
+    mbd_wave_sum_store(wl, wsite + blockIdx.x);
 }
 
 

@@ -1,10 +1,12 @@
-// mbamd_walkg_emu.h -- TEST ONLY (tests/hostemu): plain-loop twins of the 20/61-state tree-walk kernel and its root
+// mbamd_dev_walkg_kernel.h -- TEST ONLY (tests/hostemu): plain-loop twins of the 20/61-state tree-walk kernel and its root
 // integration, compiled into the host-emulation build instead of the gfx950 code of mrbayes_amd/csrc/mbamd_walkg.h /
 // mbamd_kernels_mfma.h.  They read the same arguments, programs, arenas and LDS slot schedule, so the engine's host logic
 // (arenas, program compiler, slots, phases, merged lists, exponents) is exercised on the CPU; the arithmetic order differs
 // from the MFMA kernel and is compared with a tolerance.  Never part of the product.
-#ifndef MBAMD_WALKG_EMU_H_
-#define MBAMD_WALKG_EMU_H_
+#ifndef MBAMD_DEV_WALKG_KERNEL_H_
+#define MBAMD_DEV_WALKG_KERNEL_H_
+namespace mbamd {
+inline const Walk4Entry* wg_program(const WalkGArgsInline& a) { return a.inl; }
 // ---- host-emulation twin (CPU CI of the host logic: arenas, programs, slots, phases): lane 0 of every wave walks the
 // program with plain loops over the tile's patterns; children come from the emulated LDS slots exactly as scheduled
 template <int SC, int WMAX, int CH, int DEPTH, class ARGS = WalkGArgs>
@@ -88,4 +90,5 @@ __global__ void k_walkg(ARGS AA)
     }
 }
 
+}  // namespace mbamd
 #endif

@@ -173,18 +173,19 @@ def test_config2_dna_500x20k_against_reference(gpu, golden_dir):
         assert abs(lnl - g["lnL"]["fma"]) / abs(g["lnL"]["fma"]) < ec.REL_FMA, (scaling, lnl)
 
 
-@pytest.mark.parametrize("case", ["bench_c2", "bench_c3", "bench_c5", "bench_c4"])
+@pytest.mark.parametrize("case", ["bench_c2", "bench_c3", "bench_c5", "bench_c4", "bench_c2_gaps", "bench_c3_gaps", "bench_c2_ig_gaps"])
 def test_bench_workloads_against_reference(gpu, golden_dir, case):
     """configs[1..4] at FULL size (the bench.py workloads themselves): the engine's lnL vs what the real reference printed
-    for the same alignment, tree and parameters -- its fp64 build (2e-6) and its FMA/SSE build (1e-5); both scaling schemes
-    (the 6.4 GB case: rescale-always only).  Goldens: tools/gen_golden.py bench_c2 bench_c3 bench_c5 bench_c4."""
+    for the same alignment, tree and parameters -- its fp64 build (2e-6) and its FMA/SSE build (1e-5); both scaling schemes.
+    The *_gaps cases are the same shapes with 5 % missing data (the missing-state tip path at full size),
+    bench_c2_ig_gaps adds invariable sites (the +I path: per-site values read back and mixed on the host, src/mbbeagle.c:1322-1358).
+    Goldens: tools/gen_golden.py bench_c2 bench_c3 bench_c5 bench_c4 bench_c2_gaps bench_c3_gaps bench_c2_ig_gaps."""
     import json
     with open(os.path.join(golden_dir, case + ".json")) as fh:
         g = json.load(fh)
     div = division_from_golden(golden_dir, case)
     assert div.npatterns == g["npatterns"] and div.ntaxa == g["ntaxa"]
-    schemes = (lk.MB_BEAGLE_SCALE_ALWAYS,) if case == "bench_c4" else (lk.MB_BEAGLE_SCALE_ALWAYS, lk.MB_BEAGLE_SCALE_DYNAMIC)
-    for scaling in schemes:
+    for scaling in (lk.MB_BEAGLE_SCALE_ALWAYS, lk.MB_BEAGLE_SCALE_DYNAMIC):
         lnl = ec.engine_lnl(gpu, div, scaling)
         assert abs(lnl - g["lnL"]["fp64"]) / abs(g["lnL"]["fp64"]) < ec.REL_FP64, (scaling, lnl, g["lnL"])
         assert abs(lnl - g["lnL"]["fma"]) / abs(g["lnL"]["fma"]) < ec.REL_FMA, (scaling, lnl, g["lnL"])

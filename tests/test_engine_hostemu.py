@@ -28,6 +28,23 @@ def test_emu_is_not_the_product(emu):
     assert emu.resources()[0][0].startswith("host emulation")
 
 
+def test_product_sources_have_no_emulation_fork():
+    """The shipped sources carry no host-emulation switch: the emulation is a set of same-named device-primitive headers
+    (tests/hostemu/mbamd_dev_*.h) that the TEST build puts in front on its include path; every product header of that family
+    (mrbayes_amd/csrc/device/) has a twin, and nothing under mrbayes_amd/, include/ or integration/ mentions the emulation macro."""
+    import os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for top in ("mrbayes_amd", "include", "integration"):
+        for d, _, files in os.walk(os.path.join(root, top)):
+            for f in files:
+                if f.endswith((".h", ".cpp", ".c", ".py")):
+                    text = open(os.path.join(d, f), errors="replace").read()
+                    assert "MBAMD_HOST_EMU" not in text and "hip_emu.h" not in text, os.path.join(d, f)
+    dev = os.path.join(root, "mrbayes_amd", "csrc", "device")
+    for f in os.listdir(dev):
+        assert os.path.exists(os.path.join(root, "tests", "hostemu", f)), "no emulation twin for " + f
+
+
 @pytest.mark.parametrize("case", ["primates_gtr_g4", "avian_wag_g4", "replicase_m3"])
 def test_transition_matrices(emu, oracle, golden_dir, case):
     ec.check_transition_matrices(emu, oracle, division_from_golden(golden_dir, case))

@@ -18,7 +18,7 @@ def one(spec):
     name, _, defs = spec.partition("=")
     out = os.path.join(ROOT, "build_x", "libhmsbeagle_%s.so" % name)
     cmd = [mbbuild.hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-x", "hip", "-fvisibility=hidden",
-           "-Wno-unused-function", "-I", os.path.join(ROOT, "include"), "-I", os.path.join(ROOT, "mrbayes_amd", "csrc")]
+           "-Wno-unused-function", "-I", os.path.join(ROOT, "include"), "-I", os.path.join(ROOT, "mrbayes_amd", "csrc"), "-I", os.path.join(ROOT, "mrbayes_amd", "csrc", "device")]
     cmd += ["-D" + d for d in defs.split(",") if d]
     cmd += [mbbuild.SRC, "-o", out]
     subprocess.check_call(cmd)

@@ -230,17 +230,18 @@ def main():
 
     # ---- the bench.py workloads themselves (BASELINE configs 2-5 at full size): bench.py's printed lnL is pinned
     # against these reference values.  Same generator seeds / parameters as bench.CONFIGS + synthetic_division.
-    def bench_case(case, kind, ntaxa, nsites, seed, tree_seed):
+    def bench_case(case, kind, ntaxa, nsites, seed, tree_seed, p_gap=0.0, pinvar=0.0):
         nstates = {"gtr": 4, "wag": 20, "m3": 61}[kind]
-        st = mbdata.synthetic_states(ntaxa, nsites, nstates, seed=seed, p_mut=0.15)
+        st = mbdata.synthetic_states(ntaxa, nsites, nstates, seed=seed, p_mut=0.15, p_gap=p_gap)
         names = ["t%d" % (i + 1) for i in range(ntaxa)]
         tr = mbtree.random_tree(ntaxa, seed=tree_seed, brlen=0.05)
-        synth = {"ntaxa": ntaxa, "nsites": nsites, "nstates": nstates, "seed": seed, "p_mut": 0.15, "p_gap": 0.0,
+        synth = {"ntaxa": ntaxa, "nsites": nsites, "nstates": nstates, "seed": seed, "p_mut": 0.15, "p_gap": p_gap,
                  "tree_seed": tree_seed, "brlen": 0.05}
         if kind == "gtr":
-            emit(case, "dna", names, states_to_seqs(st, "dna"), tr, "lset nst=6 rates=gamma ngammacat=4;", "",
-                 "Revmat=%s Pi=%s Alpha=(1.0)" % (fmt_vec(rev), fmt_vec(pi)),
-                 {"kind": "gtr", "revmat": rev, "pi": pi, "alpha": 1.0, "ncat": 4, "pinvar": 0.0},
+            rates = "invgamma" if pinvar > 0 else "gamma"
+            emit(case, "dna", names, states_to_seqs(st, "dna"), tr, "lset nst=6 rates=%s ngammacat=4;" % rates, "",
+                 "Revmat=%s Pi=%s Alpha=(1.0)%s" % (fmt_vec(rev), fmt_vec(pi), " Pinvar=(%.15g)" % pinvar if pinvar > 0 else ""),
+                 {"kind": "gtr", "revmat": rev, "pi": pi, "alpha": 1.0, "ncat": 4, "pinvar": pinvar},
                  store_patterns=False, synth=synth)
         elif kind == "wag":
             emit(case, "protein", names, states_to_seqs(st, "protein"), tr, "lset rates=gamma ngammacat=4;",
@@ -252,7 +253,11 @@ def main():
                  {"kind": "m3", "nst": 1, "omega": None, "omega_freq": None, "pi": "equal"}, store_patterns=False,
                  synth=synth)
     for case, cfg in (("bench_c2", ("gtr", 500, 20000, 7, 3)), ("bench_c3", ("wag", 200, 10000, 5, 9)),
-                      ("bench_c5", ("m3", 100, 5000, 6, 10)), ("bench_c4", ("gtr", 1000, 50000, 6, 10))):
+                      ("bench_c5", ("m3", 100, 5000, 6, 10)), ("bench_c4", ("gtr", 1000, 50000, 6, 10)),
+                      # the bench shapes with 5 % missing data (the missing-state tip path at full size), and
+                      # configs[1]'s shape with invariable sites on top (the +I path: per-site values read back every evaluation)
+                      ("bench_c2_gaps", ("gtr", 500, 20000, 7, 3, 0.05)), ("bench_c3_gaps", ("wag", 200, 10000, 5, 9, 0.05)),
+                      ("bench_c2_ig_gaps", ("gtr", 500, 20000, 7, 3, 0.05, 0.2))):
         if case in only:                 # (minutes of reference CPU time each: only on request)
             bench_case(case, *cfg)
 
