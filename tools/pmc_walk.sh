@@ -11,6 +11,7 @@ else
             "SQ_WAIT_INST_LDS SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_MISC SQ_INST_CYCLES_VMEM_WR SQ_INST_CYCLES_VMEM_RD SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES" \
             "GRBM_GUI_ACTIVE GRBM_COUNT" "FETCH_SIZE" "WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum")
 fi
+if [[ -n "${PMC_PASSES:-}" ]]; then IFS=';' read -r -a PASSES <<< "$PMC_PASSES"; fi     # experiments: own counter sets, ';'-separated
 for pass in "${PASSES[@]}"; do
   tag=$(echo $pass | tr ' ' '_' | cut -c1-40)
   rm -rf /tmp/pmc_$tag
@@ -28,4 +29,4 @@ for k,v in acc.items():
               'sum', {c: round(sum(x),1) for c,x in v.items() if c in ('FETCH_SIZE', 'WRITE_SIZE')})
 PY
 done
-} 2>&1 | tee $GRAFT_REPO_ROOT/gpurun_out/pmc_walk_$CFG.log
+} 2>&1 | tee $GRAFT_REPO_ROOT/gpurun_out/pmc_walk_$CFG${PMC_TAG:-}.log
