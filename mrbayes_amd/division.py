@@ -120,6 +120,15 @@ def build_division(kind: str, tree, weights, tip_states, tip_partials, *, revmat
         eig = [mbmodel.eigen_reversible(q, pi) for q in qs]
         corr = 3.0                                   # codon correction factor, src/mbbeagle.c:1385-1386
         part_w = np.asarray(omega_freqs, dtype=np.float64)
+    elif kind.startswith("gen"):                     # any reversible model of int(kind[3:]) states: restriction sites (2),
+        s = int(kind[3:])                            # covarion nucleotides (8), doublets (16), ... -- same arithmetic as "wag"
+        rng = np.random.default_rng(4321 + s)
+        ex = rng.gamma(1.0, 1.0, size=(s, s)); ex = ex + ex.T
+        pi = rng.dirichlet(np.full(s, 5.0)) if pi is None else np.asarray(pi, dtype=np.float64)
+        qmats = [mbmodel.exchangeability_q(ex, pi)]
+        eig = [mbmodel.eigen_reversible(qmats[0], pi)]
+        corr = 1.0
+        part_w = np.ones(1)
     else:
         raise ValueError(kind)
     rates = mbmodel.discrete_gamma(alpha, ncat) if (alpha is not None and ncat > 1) else np.ones(ncat)
@@ -165,7 +174,7 @@ def synthetic_division(kind: str, ntaxa: int, npatterns: int, seed: int = 7, tre
                        brlen: Optional[float] = 0.05) -> Division:
     """Synthetic inputs of the BASELINE shapes: every column is kept as its own pattern
     (weight 1) so P is exactly `npatterns`."""
-    nstates = {"gtr": 4, "wag": 20, "m3": 61}[kind]
+    nstates = int(kind[3:]) if kind.startswith("gen") else {"gtr": 4, "wag": 20, "m3": 61}[kind]
     st = mbdata.synthetic_states(ntaxa, npatterns, nstates, seed, 0.15, p_gap)
     tr = mbtree.random_tree(ntaxa, tree_seed, brlen=brlen)
     tip_states, tip_partials = _tips_from_states(st)
@@ -182,5 +191,7 @@ def synthetic_division(kind: str, ntaxa: int, npatterns: int, seed: int = 7, tre
             p = rng.dirichlet(np.full(20, 5.0))
             wag = (ex, p)
         return build_division("wag", tr, w, tip_states, tip_partials, alpha=alpha, ncat=ncat, wag=wag)
+    if kind.startswith("gen"):
+        return build_division(kind, tr, w, tip_states, tip_partials, alpha=alpha, ncat=ncat)
     return build_division("m3", tr, w, tip_states, tip_partials, omegas=[0.1, 1.0, 3.0],
                           omega_freqs=[0.5, 0.3, 0.2], ncat=1)

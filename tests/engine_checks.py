@@ -518,6 +518,19 @@ def check_golden_case(lib, oracle, golden_dir, case, scaling=lk.MB_BEAGLE_SCALE_
     return lnl
 
 
+def check_generic_states(lib, oracle, nstates, ntaxa, npat, ncat=4, p_gap=0.05):
+    """A full tree of a random reversible model with `nstates` states (restriction sites 2, covarion nucleotides 8, ...):
+    engine == oracle for both scaling schemes, per site too, and a partial update + reject behaves."""
+    from mrbayes_amd.division import synthetic_division
+    div = synthetic_division("gen%d" % nstates, ntaxa, npat, seed=11, tree_seed=5, alpha=0.7, ncat=ncat, p_gap=p_gap)
+    want = oracle.tree_loglike(div, use_shortcuts=False)
+    for scaling in (lk.MB_BEAGLE_SCALE_ALWAYS, lk.MB_BEAGLE_SCALE_DYNAMIC):
+        lnl = engine_lnl(lib, div, scaling)
+        assert abs(lnl - want) / abs(want) < REL_FP64, (nstates, scaling, lnl, want)
+    check_site_likelihoods(lib, oracle, div)
+    check_partial_update_and_reject(lib, oracle, div, lk.MB_BEAGLE_SCALE_DYNAMIC)
+
+
 def check_site_likelihoods(lib, oracle, div):
     bd = lk.BeagleDivision(div, lib)
     try:

@@ -61,6 +61,13 @@ def test_final_pass_and_scaled_readout(emu, nstates, ncat, npat):
     ec.check_final_pass(emu, nstates, ncat, npat)
 
 
+@pytest.mark.parametrize("nstates,ntaxa,npat", [(2, 12, 70), (8, 10, 45), (5, 8, 33)])
+def test_other_state_counts_on_the_tree_walk(emu, oracle, nstates, ntaxa, npat):
+    """Covarion nucleotides (8 states, CondLikeDown_Gen with TiProbs_GenCov) have their own instantiation of the 20/61-state
+    tree-walk kernel; restriction sites (2 states, CondLikeDown_Bin / Likelihood_Res), 5 and 33 states stay on the level kernels."""
+    ec.check_generic_states(emu, oracle, nstates, ntaxa, npat)
+
+
 @pytest.mark.parametrize("case", SMALL)
 def test_golden_always_rescale(emu, oracle, golden_dir, case):
     ec.check_golden_case(emu, oracle, golden_dir, case, lk.MB_BEAGLE_SCALE_ALWAYS)
@@ -234,6 +241,8 @@ def test_dna_other_category_counts(emu, oracle, ncat):
 def test_lists_with_hazards_are_cut_into_segments(emu, oracle):
     ec.check_hazard_lists(emu, 4, 4, 100)
     ec.check_hazard_lists(emu, 20, 4, 40)
+    ec.check_hazard_lists(emu, 8, 4, 70)
+    ec.check_hazard_lists(emu, 2, 2, 40)
 
 
 def test_closed_form_matrices(emu, oracle):
