@@ -3629,7 +3629,12 @@ static int step_timing_of(Instance* in, double* ms, long* steps, int reset)
 int mbamdGetKernelTiming(int instance, double* outMilliseconds, long* outLaunches, int reset)
 {
     GET_INSTANCE(instance);
-    if (in->f64) return fail(BEAGLE_ERROR_NO_IMPLEMENTATION, "mbamdGetKernelTiming: not on a double-precision instance");
+    if (in->f64) {                               // (no device timing on a double-precision instance: the partials launches are counted)
+        if (outMilliseconds) *outMilliseconds = 0.0;
+        if (outLaunches) *outLaunches = (long) (in->f64->walkLaunches + in->f64->levelLaunches);
+        if (reset) in->f64->walkLaunches = in->f64->levelLaunches = 0;
+        return BEAGLE_SUCCESS;
+    }
     double ms = 0.0;
     long launches = 0;
     if (in->facade()) {

@@ -140,6 +140,129 @@ k64_rescale(const Op64* __restrict__ ops, int S, int K, int Ppad_)
         for (int r = 0; r < n; ++r) dst[(size_t) r * Ppad] = ldexp(dst[(size_t) r * Ppad], -e);
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------------------
+// Four states: the tree walk in fp64 -- ONE launch per operation list instead of one per dependency level.  A workgroup owns 64
+// patterns, one wave per category (the rescaling maximum is per pattern, as in k64_partials_fused: the waves' maxima meet in LDS);
+// all waves interpret one program compiled by the same Walk4Builder as the fp32 walks (mbamd_walk4_host.h, register-fed mode: a
+// child is a compact tip, a slot of the workgroup's LDS, or read from HBM in place).  Results are stored once and children the wave
+// produced itself are read back from LDS: HBM sees (almost) only the write stream -- the level kernels read every child back.
+// Arithmetic and its order are those of k64_partials_fused: the two paths give the same bits (MBAMD_F64_NO_WALK=1 selects the levels).
+struct Walk64Entry {
+    double* dst;
+    const void* c1;              // tip: compact states (uint8); memory: partials; slot: unused
+    const void* c2;
+    const double* m1T;           // transposed matrices [K][4][4]
+    const double* m2T;
+    int32_t* scale;              // exponents written (mode 1) or read (mode 2)
+    uint32_t ctl0;               // kind1 | kind2 << 8 | slot1 << 16 | slot2 << 24   (kind: 0 LDS slot, 1 memory, 2 compact tip)
+    uint32_t ctl1;               // keep | mode << 8 | nop << 16                     (keep: slot the result is also written to, 0xFF none)
+    int pad_[2];
+};
+static_assert(sizeof(Walk64Entry) == 64, "Walk64Entry is one 64-byte scalar load");
+__device__ __forceinline__ Walk64Entry w64_load(const MBAMD_AS_CONST Walk64Entry* p)
+{
+    Walk64Entry e;
+    e.dst = p->dst; e.c1 = p->c1; e.c2 = p->c2; e.m1T = p->m1T; e.m2T = p->m2T; e.scale = p->scale; e.ctl0 = p->ctl0; e.ctl1 = p->ctl1;
+    return e;
+}
+
+template <int KF>
+__global__ void __launch_bounds__(64 * KF)
+k64_walk4(const Walk64Entry* __restrict__ prog, int entries, int Ppad_, int nslots, int32_t* __restrict__ cum)
+{
+    // workgroup = KF waves over the same 64 patterns, wave k = category k (four times the waves of a pattern-per-thread walk:
+    // the walk is a latency chain per wave).  The rescaling maximum is per PATTERN: the waves' maxima meet in LDS, one barrier
+    // per rescaled operation, double-buffered so that the next operation's write cannot overtake this one's reads.
+    double* const slots = mbd_dyn_lds<double>();      // [slot][KF][4][64] | exchange [2][KF][64]
+    double* const xch = slots + (size_t) nslots * KF * 4 * 64;
+    const size_t Ppad = (size_t) Ppad_;
+    const int lane = (int) threadIdx.x & 63, k = mbd_wave_index();
+    const size_t c = (size_t) blockIdx.x * 64 + lane;
+    int sum = 0, flip = 0;
+    // entries are whole 64-byte scalar loads, the next one fetched while this one runs
+    const MBAMD_AS_CONST Walk64Entry* cprog = as_const(prog);
+    Walk64Entry nxt = w64_load(cprog);
+    for (int j = 0; j < entries; ++j) {
+        const Walk64Entry e = nxt;
+        nxt = w64_load(cprog + (j + 1 < entries ? j + 1 : j));
+        const unsigned kind1 = e.ctl0 & 0xFFu, kind2 = (e.ctl0 >> 8) & 0xFFu, slot1 = (e.ctl0 >> 16) & 0xFFu, slot2 = e.ctl0 >> 24;
+        const unsigned keep = e.ctl1 & 0xFFu, mode = (e.ctl1 >> 8) & 0xFFu;
+        if ((e.ctl1 >> 16) & 1u) continue;
+        double out[4], f2[4];
+        // the matrix of (child, category) is wave-uniform: sixteen doubles through the scalar path; a compact tip is the same
+        // product with an indicator vector (adding exact zeros: the bits of the gather the level kernels do), missing data = 1
+        double ma[16], mb[16];                         // (issued first: two scalar bursts that the children's loads then overlap)
+        {
+            const MBAMD_AS_CONST double* __restrict__ pa = as_const(e.m1T) + (size_t) k * 16;
+            const MBAMD_AS_CONST double* __restrict__ pb = as_const(e.m2T) + (size_t) k * 16;
+#pragma unroll
+            for (int q = 0; q < 16; ++q) { ma[q] = pa[q]; mb[q] = pb[q]; }
+        }
+        auto factor = [&](int kind, const void* ptr, int slot, const double (&m)[16], double (&f)[4]) {
+            double v[4];
+            unsigned st = 0;
+            if (kind == 0) {
+                const double* sl = slots + ((size_t) (slot * KF + k) * 4) * 64 + lane;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) v[q] = sl[q * 64];
+            } else if (kind == 1) {
+                const MBAMD_AS_GLOBAL double* cl = as_global(reinterpret_cast<const double*>(ptr)) + (size_t) k * 4 * Ppad + c;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) v[q] = cl[(size_t) q * Ppad];
+            } else {
+                st = as_global(reinterpret_cast<const uint8_t*>(ptr))[c];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) v[q] = st == (unsigned) q ? 1.0 : 0.0;
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i) f[i] = 0.0;
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) f[i] = fma(m[q * 4 + i], v[q], f[i]);
+            if (kind == 2 && st >= 4u) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) f[i] = 1.0;
+            }
+        };
+        factor((int) kind1, e.c1, (int) slot1, ma, out);
+        factor((int) kind2, e.c2, (int) slot2, mb, f2);
+        double mx = 0.0;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            out[i] *= f2[i];
+            mx = fmax(mx, out[i]);
+        }
+        int ex = 0;
+        if (mode == 1u) {
+            if (KF > 1) {
+                double* x = xch + (size_t) flip * KF * 64;
+                flip ^= 1;
+                x[k * 64 + lane] = mx;
+                MBAMD_SYNC();
+#pragma unroll
+                for (int q = 0; q < KF; ++q) mx = fmax(mx, x[q * 64 + lane]);
+            }
+            if (mx > 0.0 && mx < 1.0e300) (void) frexp(mx, &ex);
+            ex = ex < -1000 ? -1000 : ex;
+            if (k == 0) {
+                as_global(e.scale)[c] = ex;
+                sum += ex;
+            }
+        } else if (mode == 2u) {
+            ex = as_global(e.scale)[c];
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const double v = ex != 0 ? ldexp(out[i], -ex) : out[i];
+            as_global(e.dst)[((size_t) k * 4 + i) * Ppad + c] = v;
+            if (keep != 0xFFu) slots[((size_t) (keep * KF + k) * 4 + i) * 64 + lane] = v;
+        }
+    }
+    if (k == 0 && cum != nullptr && sum != 0) as_global(cum)[c] += sum;
+}
+
 struct MatrixJob64 {
     double* out;                 // [K][S][S] then transposed [K][S][SPAD]
     double length;
@@ -271,6 +394,15 @@ public:
     std::vector<RatesArg> rateSets;
     bool haveSite = false;
     std::vector<std::pair<int, int>> parts;       // v3: [first, last) of every pattern partition (empty: none were set)
+    // four-state tree walk (k64_walk4): the program compiler, its latest program (re-used when the same list comes again)
+    Walk4Builder walkBuilder;
+    Walk4Template walkTemplate;
+    std::vector<int> walkKey;
+    std::vector<Walk4Op> walkOps;
+    std::vector<Walk64Entry> walkProg;
+    uint64_t walkLaunches = 0, levelLaunches = 0;
+    bool walkAlways = false;
+    bool walkOff = false;                          // MBAMD_F64_NO_WALK (read when the instance is created): level kernels only
     size_t bufDoubles = 0, matDoubles = 0, eigDoubles = 0;
 
     ~Engine64() { destroy(); }
@@ -282,6 +414,8 @@ public:
         device = dev; tipCount = tips; nBuffers = partialsBuffers + compactBuffers; S = states; P = patterns; Ppad = round_up(patterns, 64);
         K = cats; nEigen = eigens; nMatrices = matrices; nScale = scales;
         IB = blockOf(S);
+        walkOff = std::getenv("MBAMD_F64_NO_WALK") != nullptr;
+        walkAlways = std::getenv("MBAMD_F64_WALK_ALWAYS") != nullptr;
         SPAD = (S + IB - 1) / IB * IB;
         bufDoubles = (size_t) K * S * Ppad;
         matDoubles = (size_t) K * S * S + (size_t) K * S * SPAD;
@@ -484,6 +618,129 @@ public:
     {
         MBAMD_LAUNCH(k64_partials<IB_>, dim3((unsigned) (Ppad / 64), (unsigned) n, (unsigned) (K * (SPAD / IB_))), 64, 0, stream, ops, S, SPAD, K, Ppad);
     }
+
+    // The walk serves what MrBayes sends for nucleotides: four states, up to eight categories, no pattern partitions, one
+    // cumulative buffer for the whole list, no buffer hazards inside the list.  Returns 1 when the list is not of that kind.
+    template <int KF> void launchWalk(const Walk64Entry* prog, int entries, int nslots, int32_t* cum)
+    {
+        auto kern = k64_walk4<KF>;
+        const size_t lds = ((size_t) nslots * KF * 4 * 64 + (size_t) 2 * KF * 64) * sizeof(double);
+        static bool raised = false;
+        if (!raised) {
+            if (hipFuncSetAttribute((const void*) kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) (void) hipGetLastError();
+            raised = true;
+        }
+        MBAMD_LAUNCH_BARRIER(kern, (unsigned) (Ppad / 64), 64 * KF, lds, stream, prog, entries, Ppad, nslots, cum);
+    }
+    int tryWalk4(const void* opsRaw, size_t stride, int n, const int* partition, const int* cumOf)
+    {
+        if (walkOff || S != 4 || K > 8 || !parts.empty() || n < 2) return 1;
+        // the walk is one latency chain per wave: it wins when there are enough waves (break-even about 1.2 per SIMD) and on short lists (a
+        // root-ward path: one launch instead of one per operation); mid-sized full evaluations stay on the level kernels
+        // (measured: profiles/r03_f64_walk.txt).  MBAMD_F64_WALK_ALWAYS=1: every eligible list.
+        if (!walkAlways && n > 64 && (long) (Ppad / 64) * K < 1200) return 1;
+        StatTimer* st_ = new StatTimer(ST_PLAN);       // (MBAMD_STATS: the host side of the walk, up to the upload)
+        struct Closer { StatTimer*& t; ~Closer() { delete t; t = nullptr; } } closer_{st_};
+        std::vector<Walk4Op>& wops = walkOps;
+        wops.clear();
+        std::vector<char> written((size_t) nBuffers, 0), readB((size_t) nBuffers, 0), sc((size_t) std::max(nScale, 1), 0);
+        for (int i = 0; i < n; ++i) {
+            const BeagleOperation& o = *reinterpret_cast<const BeagleOperation*>(static_cast<const char*>(opsRaw) + (size_t) i * stride);
+            if (partition[i] >= 0 || cumOf[i] != cumOf[0]) return 1;
+            const int d = o.destinationPartials, c1 = o.child1Partials, c2 = o.child2Partials;
+            if (d < 0 || d >= nBuffers || c1 < 0 || c1 >= nBuffers || c2 < 0 || c2 >= nBuffers) return 1;     // (the level path reports the error)
+            if (o.child1TransitionMatrix < 0 || o.child1TransitionMatrix >= nMatrices || o.child2TransitionMatrix < 0 || o.child2TransitionMatrix >= nMatrices) return 1;
+            if ((!valid[c1] && !written[c1]) || (!valid[c2] && !written[c2]) || (isTip[d] && !written[d])) return 1;
+            const int sw = o.destinationScaleWrite, sr = o.destinationScaleRead;
+            if ((sw != BEAGLE_OP_NONE && (sw < 0 || sw >= nScale)) || (sr != BEAGLE_OP_NONE && (sr < 0 || sr >= nScale))) return 1;
+            if (written[d] || readB[d]) return 1;                                     // buffer hazards: levels
+            if (sw != BEAGLE_OP_NONE && sc[sw]) return 1;
+            if (sw == BEAGLE_OP_NONE && sr != BEAGLE_OP_NONE && sc[sr] == 2) return 1;
+            if (cumOf[0] != BEAGLE_OP_NONE && (sw == cumOf[0] || sr == cumOf[0])) return 1;
+            Walk4Op w;
+            w.dst = d; w.c1 = c1; w.c2 = c2; w.m1 = o.child1TransitionMatrix; w.m2 = o.child2TransitionMatrix;
+            w.tip1 = (isTip[c1] && !written[c1]) ? 1 : 0;
+            w.tip2 = (isTip[c2] && !written[c2]) ? 1 : 0;
+            w.scaleWrite = sw != BEAGLE_OP_NONE ? sw : -1;
+            w.scaleRead = (sw == BEAGLE_OP_NONE && sr != BEAGLE_OP_NONE) ? sr : -1;
+            written[d] = 1; readB[c1] = 1; readB[c2] = 1;
+            if (sw != BEAGLE_OP_NONE) sc[sw] = 2; else if (sr != BEAGLE_OP_NONE && !sc[sr]) sc[sr] = 1;
+            wops.push_back(w);
+        }
+        const int cumIdx = cumOf[0];
+        if (cumIdx != BEAGLE_OP_NONE && (cumIdx < 0 || cumIdx >= nScale)) return 1;
+        // launch geometry: every workgroup (one wave, 64 patterns) resident at once where the chip allows, the LDS of a CU split
+        // between the workgroups it hosts; a slot holds one node's K x 4 x 64 doubles
+        const int slotBytes = K * 4 * 64 * (int) sizeof(double);
+        const long wgs = Ppad / 64;
+        const int perCU = (int) std::min(4L, std::max(1L, (wgs + 255) / 256));
+        int nslots = std::max(2, std::min(24, ((160 * 1024) / perCU - 2048) / slotBytes));
+        if (const char* e = std::getenv("MBAMD_F64_WALK_SLOTS")) nslots = std::max(2, std::min((160 * 1024 - 2048) / slotBytes, std::atoi(e)));
+        // structure key: who produces whose child, which children are tips (the indices only fill the program)
+        std::vector<int> key;
+        key.reserve((size_t) n * 3 + 2);
+        key.push_back(n); key.push_back(nslots);
+        {
+            std::vector<int> writer((size_t) nBuffers, -1);
+            for (int o = 0; o < n; ++o) {
+                key.push_back(wops[o].tip1 ? -1 : writer[wops[o].c1]);
+                key.push_back(wops[o].tip2 ? -1 : writer[wops[o].c2]);
+                key.push_back((int) wops[o].tip1 | ((int) wops[o].tip2 << 1));
+                writer[wops[o].dst] = o;
+            }
+        }
+        if (key != walkKey) {
+            Walk4Builder& b = walkBuilder;
+            b.maxW = 1; b.maxSlots = nslots; b.maxSlots1 = nslots; b.prefetchDistance = 0; b.memSlots = false;
+            b.leadNops = 0; b.unroll = 1; b.tailNops = 0; b.tipAhead = 0; b.forward = false; b.smallPhase = 1 << 30;
+            if (!b.build(wops, walkTemplate)) { walkKey.clear(); return 1; }
+            walkKey = key;
+        }
+        const Walk4Template& t = walkTemplate;
+        if (t.W != 1) return 1;
+        walkProg.assign((size_t) t.entries, Walk64Entry());
+        for (int i = 0; i < t.entries; ++i) {
+            const Walk4Template::Entry& te = t.prog[i];
+            Walk64Entry& e = walkProg[i];
+            std::memset(&e, 0, sizeof e);
+            unsigned kind1 = 0, kind2 = 0, slot1 = 0, slot2 = 0;
+            if (te.op < 0) { e.ctl1 = 0xFFu | (1u << 16); continue; }
+            const Walk4Op& w = wops[te.op];
+            e.dst = partialsPtr(w.dst);
+            e.m1T = matrixPtr(w.m1) + (size_t) K * S * S;
+            e.m2T = matrixPtr(w.m2) + (size_t) K * S * S;
+            if (w.tip1) { kind1 = 2; e.c1 = statesPtr(w.c1); }
+            else if (te.c1slot == 0xFF) { kind1 = 1; e.c1 = partialsPtr(w.c1); }
+            else { kind1 = 0; slot1 = te.c1slot; }
+            if (w.tip2) { kind2 = 2; e.c2 = statesPtr(w.c2); }
+            else if (te.c2slot == 0xFF) { kind2 = 1; e.c2 = partialsPtr(w.c2); }
+            else { kind2 = 0; slot2 = te.c2slot; }
+            const unsigned mode = w.scaleWrite >= 0 ? 1u : (w.scaleRead >= 0 ? 2u : 0u);
+            e.ctl0 = kind1 | (kind2 << 8) | (slot1 << 16) | (slot2 << 24);
+            e.ctl1 = (unsigned) te.dslot | (mode << 8);
+            e.scale = w.scaleWrite >= 0 ? d_scale + (size_t) w.scaleWrite * Ppad : (w.scaleRead >= 0 ? d_scale + (size_t) w.scaleRead * Ppad : nullptr);
+        }
+        for (const Walk4Op& w : wops) { valid[w.dst] = 1; isTip[w.dst] = 0; }
+        delete st_; st_ = nullptr;
+        void* dv = nullptr;
+        int rc = stage(walkProg.data(), walkProg.size() * sizeof(Walk64Entry), &dv);
+        if (rc) return rc;
+        int32_t* cum = cumIdx != BEAGLE_OP_NONE ? d_scale + (size_t) cumIdx * Ppad : nullptr;
+        const Walk64Entry* prog = static_cast<const Walk64Entry*>(dv);
+        switch (K) {
+            case 1: launchWalk<1>(prog, t.entries, t.nslots, cum); break;
+            case 2: launchWalk<2>(prog, t.entries, t.nslots, cum); break;
+            case 3: launchWalk<3>(prog, t.entries, t.nslots, cum); break;
+            case 4: launchWalk<4>(prog, t.entries, t.nslots, cum); break;
+            case 5: launchWalk<5>(prog, t.entries, t.nslots, cum); break;
+            case 6: launchWalk<6>(prog, t.entries, t.nslots, cum); break;
+            case 7: launchWalk<7>(prog, t.entries, t.nslots, cum); break;
+            default: launchWalk<8>(prog, t.entries, t.nslots, cum); break;
+        }
+        HIP_TRY(hipGetLastError());
+        walkLaunches++;
+        return BEAGLE_SUCCESS;
+    }
     // One launch per dependency level: an operation goes one level above the last operation that wrote a buffer it reads,
     // read or wrote the buffer it writes, or touched its scale buffer.
     int partitionRange(int partition, int* first, int* last, const char* what) const
@@ -520,6 +777,10 @@ public:
     int updatePartialsEx(const void* opsRaw, size_t stride, int n, const int* partition, const int* cumOf)
     {
         if (n <= 0) return BEAGLE_SUCCESS;
+        {
+            int rcw = tryWalk4(opsRaw, stride, n, partition, cumOf);
+            if (rcw != 1) return rcw;                      // (1: not a list for the walk -- the level path below takes it)
+        }
         const int np = std::max<int>(1, (int) parts.size());
         std::vector<int> level((size_t) n, 0), lastTouchBuf((size_t) nBuffers * np, -1), lastWriteBuf((size_t) nBuffers * np, -1),
             lastTouchScale((size_t) std::max(nScale, 1) * np, -1);
@@ -591,6 +852,7 @@ public:
         for (int l = 0; l < nLevels; ++l) {
             const int first = start[l], cnt = start[(size_t) l + 1] - first;
             if (cnt <= 0) continue;
+            levelLaunches++;
             if (fused) {
                 const dim3 grid((unsigned) (Ppad / 64), (unsigned) cnt);
                 auto kern = k64_partials_fused<4, 4>;

@@ -778,6 +778,45 @@ def check_double_precision(lib, golden_dir, case):
     assert abs(vals[0] - vals[1]) <= 1e-11 * abs(vals[0]), vals
 
 
+def check_double_precision_walk(lib, golden_dir, case, monkeypatch):
+    """Four states in fp64: the tree walk (one launch per list) gives the bits of the level kernels (one launch per dependency
+    level, MBAMD_F64_NO_WALK=1), for a full evaluation, a partial update and both scaling schemes -- per site, not just the sum."""
+    div = division_from_golden(golden_dir, case)
+    t = div.tree
+    deep = max(range(t.ntaxa), key=lambda i: _depth(t, i))
+    for scaling in (lk.MB_BEAGLE_SCALE_ALWAYS, lk.MB_BEAGLE_SCALE_DYNAMIC):
+        got = {}
+        for walk in (True, False):
+            if walk:
+                monkeypatch.delenv("MBAMD_F64_NO_WALK", raising=False)
+                monkeypatch.setenv("MBAMD_F64_WALK_ALWAYS", "1")       # (mid-sized full evaluations default to the levels)
+            else:
+                monkeypatch.setenv("MBAMD_F64_NO_WALK", "1")
+            bd = lk.BeagleDivision(div, lib, scaling=scaling, double_precision=True)
+            try:
+                bd.inst.get_kernel_timing(reset=True)
+                lnl = bd.LogLike(0)
+                _, launches = bd.inst.get_kernel_timing(reset=True)
+                site = bd.inst.get_site_log_likelihoods().copy()
+                bd.AcceptMove(0)
+                old = t.length[deep]
+                t.length[deep] = old * 1.7
+                try:
+                    bd.TouchBranch(0, deep)
+                    moved = bd.LogLike(0)
+                    site2 = bd.inst.get_site_log_likelihoods().copy()
+                finally:
+                    t.length[deep] = old
+                got[walk] = (lnl, site, moved, site2, launches)
+            finally:
+                bd.finalize()
+        monkeypatch.delenv("MBAMD_F64_NO_WALK", raising=False)
+        monkeypatch.delenv("MBAMD_F64_WALK_ALWAYS", raising=False)
+        assert got[True][0] == got[False][0] and got[True][2] == got[False][2], (case, scaling, got[True][0], got[False][0])
+        assert np.array_equal(got[True][1], got[False][1]) and np.array_equal(got[True][3], got[False][3])
+        assert got[True][4] <= 2 and got[False][4] > 2 * got[True][4], (got[True][4], got[False][4])   # a launch per list against one per level
+
+
 def check_parsimony_model_golden(lib, golden_dir):
     """The device Fitch down-pass against the reference's OWN parsimony-model likelihood (Likelihood_Pars,
     src/likelihood.c:7593-7700; golden values written by tools/gen_golden_pars.py from oracle/_ref/mb with `lset parsmodel=yes`):

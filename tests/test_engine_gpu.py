@@ -531,6 +531,12 @@ def test_double_precision(gpu, golden_dir, case):
     ec.check_double_precision(gpu, golden_dir, case)
 
 
+@pytest.mark.parametrize("case", ["primates_gtr_g4", "synth_dna_gaps", "bench_c2"])
+def test_double_precision_walk_equals_levels(gpu, golden_dir, case, monkeypatch):
+    """fp64, four states: k64_walk4 (one launch per operation list) against the level kernels, bit for bit."""
+    ec.check_double_precision_walk(gpu, golden_dir, case, monkeypatch)
+
+
 def test_parsimony_model_golden(gpu, golden_dir):
     """device Fitch lengths == the reference's own parsimony-model likelihood (golden vectors from oracle/_ref/mb)"""
     ec.check_parsimony_model_golden(gpu, golden_dir)

@@ -281,6 +281,12 @@ def test_double_precision(emu, golden_dir, case):
     ec.check_double_precision(emu, golden_dir, case)
 
 
+@pytest.mark.parametrize("case", ["primates_gtr_g4", "synth_dna_gaps"])
+def test_double_precision_walk_equals_levels(emu, golden_dir, case, monkeypatch):
+    """fp64, four states: k64_walk4 (one launch per operation list) against the level kernels, bit for bit."""
+    ec.check_double_precision_walk(emu, golden_dir, case, monkeypatch)
+
+
 def test_parsimony_model_golden(emu, golden_dir):
     """device Fitch lengths == the reference's own parsimony-model likelihood (golden vectors from oracle/_ref/mb)"""
     ec.check_parsimony_model_golden(emu, golden_dir)

@@ -23,7 +23,11 @@ def main():
             ref = json.load(fh)["lnL"]["fp64"]
         div = division_from_golden(GOLD, case)
         row = []
-        for dbl in (False, True):
+        for dbl, levels in ((False, False), (True, False), (True, True)):
+            if levels:
+                os.environ["MBAMD_F64_NO_WALK"] = "1"        # (read when the instance is created)
+            else:
+                os.environ.pop("MBAMD_F64_NO_WALK", None)
             bd = lk.BeagleDivision(div, lib, scaling=lk.MB_BEAGLE_SCALE_ALWAYS, double_precision=dbl)
             lnl = bd.LogLike(0)
             bd.AcceptMove(0)
@@ -39,7 +43,8 @@ def main():
         nodes = div.tree.n_int_nodes * div.npatterns
         print("%s  %d taxa x %d patterns, %d states x %d categories" % (case, div.tree.ntaxa, div.npatterns, div.nstates, div.ncat))
         print("   reference fp64 build  lnL %.8f" % ref)
-        for name, (lnl, dt) in zip(("fp32 engine", "fp64 engine"), row):
+        os.environ.pop("MBAMD_F64_NO_WALK", None)
+        for name, (lnl, dt) in zip(("fp32 engine", "fp64 engine", "fp64 levels"), row):
             print("   %-12s lnL %.8f  |diff| %.3g (rel %.2g)   %.2f ms per evaluation incl. the Python host  (%.3g node-pattern updates/s)"
                   % (name, lnl, abs(lnl - ref), abs(lnl - ref) / abs(ref), dt * 1e3, nodes / dt))
 
