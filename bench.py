@@ -384,6 +384,78 @@ def measure(args, cfg, steps, warmup, rank, local_rank, world, dist, device, emu
     return out
 
 
+def pattern_sharded(args, cfg, steps, warmup, rank, local_rank, world, dist, device, emulate, lib):
+    """ONE chain whose site patterns are cut into `world` contiguous blocks, a block per rank / GPU (the
+    north star's "site-pattern blocks sharded across the GPUs ... RCCL all-reduce of the per-generation lnL"): every rank
+    evaluates the SAME tree state on its block, the block sums meet in one all-reduce(SUM) of a double per evaluation -- the
+    only exchange.  Strong scaling: the units of a step are those of the whole alignment.  Collective: every rank calls it."""
+    import torch
+    from mrbayes_amd import likelihood as lk
+    from mrbayes_amd.division import division_from_golden, synthetic_division
+
+    case, kind, desc = CONFIGS[cfg]
+    with open(os.path.join(GOLD, case + ".json")) as fh:
+        gold = json.load(fh)
+    div = synthetic_division(kind, 16, 200, seed=3, tree_seed=4, golden_dir=GOLD) if emulate else division_from_golden(GOLD, case)
+    P, N = div.npatterns, div.ntaxa
+    blocks = (P + 63) // 64                              # whole 64-pattern blocks per rank, the remainder to the last ranks
+    lo = min(P, (blocks * rank // world) * 64)
+    hi = min(P, (blocks * (rank + 1) // world) * 64) if rank + 1 < world else P
+    whole = None
+    if emulate and rank == 0:                            # (no golden value for the emulated toy: evaluate it unsharded once)
+        b0 = lk.BeagleDivision(div, lib, nchains=1, scaling=lk.MB_BEAGLE_SCALE_ALWAYS, resource=0)
+        whole = b0.LogLike(0)
+        b0.finalize()
+    div.weights = div.weights[lo:hi]
+    div.tip_states = [None if s is None else s[lo:hi].copy() for s in div.tip_states]
+    div.tip_partials = [None if t is None else t[lo:hi].copy() for t in div.tip_partials]
+    if div.inv_condlikes is not None:
+        div.inv_condlikes = div.inv_condlikes[lo:hi].copy()
+    bd = lk.BeagleDivision(div, lib, nchains=1, scaling=lk.MB_BEAGLE_SCALE_ALWAYS, resource=0 if emulate else local_rank)
+    bd.LogLike(0)
+    bd.AcceptMove(0)
+    evals = [lk.record_evaluation(bd), lk.record_evaluation(bd)]
+    buf = torch.zeros(1, dtype=torch.float64, device=device)
+
+    def step(i):
+        rc, lnl = evals[i & 1].run()
+        if rc != 0:
+            raise RuntimeError("evaluation failed with code %d" % rc)
+        buf[0] = lnl
+        dist.all_reduce(buf, op=dist.ReduceOp.SUM)       # the per-generation exchange: one double
+        return float(buf.item())                         # (the chain needs the value before it can accept or reject)
+
+    def fence():
+        dist.barrier()
+        if not emulate:
+            torch.cuda.synchronize()
+
+    for i in range(warmup):
+        step(i)
+    fence()
+    t0 = time.perf_counter()
+    total = None
+    for i in range(steps):
+        total = step(i)
+    fence()
+    dt = time.perf_counter() - t0
+    tmax = torch.tensor([dt], dtype=torch.float64, device=device)
+    dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    dt = float(tmax.item())
+    bd.finalize()
+    if rank != 0:
+        return None
+    ref = whole if emulate else gold["lnL"]["fp64"]
+    ok = abs(total - ref) <= REL_FP64 * abs(ref)
+    if not ok:
+        raise AssertionError("pattern-sharded lnL %r differs from the reference's %r" % (total, ref))
+    return {"what": "ONE chain, site patterns in %d contiguous blocks (one per rank / GPU), all-reduce(SUM) of one double per evaluation over %s"
+                    % (world, "gloo (EMULATED)" if emulate else "RCCL"),
+            "scaling": "strong", "n_gpus": world, "steps": steps, "ms_per_step": dt / steps * 1e3,
+            "value": (N - 2) * P * steps / dt / 1e6, "unit": "M updates/s",
+            "lnL": total, "lnL_reference_fp64": ref, "lnL_pinned": True}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -451,6 +523,15 @@ def main():
     else:
         out = measure(args, args.config, args.steps, args.warmup, rank, local_rank, world, dist, device, emulate, lib,
                       not args.no_cpu_baseline)
+    if world > 1 and not args.shard and dist is not None:
+        try:                                     # (collective: every rank takes part; failures are reported, not fatal)
+            ps = pattern_sharded(args, args.config, args.steps, args.warmup, rank, local_rank, world, dist, device, emulate, lib)
+        except AssertionError:
+            raise
+        except Exception as exc:
+            ps = {"error": repr(exc)[:600]}
+        if rank == 0:
+            out["pattern_sharded"] = ps
     if rank == 0 and world == 1 and not emulate:
         if not args.no_also:
             out["also"] = []

@@ -35,6 +35,12 @@ def test_two_ranks():
     assert res.returncode == 0, (res.stdout + res.stderr)[-3000:]
     d = _json_line(res.stdout)
     assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["config"]["chains"] == 2
+    # one chain with its site patterns split over the two ranks, the block sums all-reduced (gloo here, RCCL on GPUs): the total
+    # is the unsharded log-likelihood (asserted inside bench.py against an unsharded evaluation / the reference's value)
+    ps = d["pattern_sharded"]
+    assert "error" not in ps, ps
+    assert ps["scaling"] == "strong" and ps["n_gpus"] == 2 and ps["value"] > 0 and ps["lnL_pinned"]
+    assert abs(ps["lnL"] - ps["lnL_reference_fp64"]) <= 2e-6 * abs(ps["lnL"])
     # the reference's own MPI build on the shim, two ranks (only where the reference binaries were built)
     if os.path.exists(os.path.join(ROOT, "oracle", "_ref", "mb_emu_mpi")) and os.path.exists(os.path.join(ROOT, "oracle", "_ref", "mbamd_mpirun")):
         m = d["mpi_mcmc"]
