@@ -230,12 +230,40 @@ k_walkg(ARGS AA)
         // (issued before the operand fetches: what the next entry needs first must not queue behind them)
         // (three tiny loads, unconditional: every conditional vector-memory instruction makes the compiler's vmcnt waits one
         //  instruction stricter -- and the instruction they then wait for is the oldest STORE of the previous entry)
-#if !defined(MBAMD_WGX_NOTINY)
-        const int er_next = as_global(E0 + n1.e.eread)[col];
-        n2.s1 = as_global(T0 + ((n2.e.ctl & MBAMD_W4_TIP1) ? n2.e.c1 : 0u))[col];
-        n2.s2 = as_global(T0 + ((n2.e.ctl & MBAMD_W4_TIP2) ? n2.e.c2 : 0u))[col];
+        // Exponents of the next entry, tip states of the entry after: 32 bytes per tile each.  16 / 20 states take them through
+        // the SCALAR path -- one s_load_dwordx8 each, issued with the descriptor load below, every lane picks its byte in the
+        // epilogue: as vector loads they sit in the in-order vmcnt queue behind the previous entry's result stores and the
+        // gather addresses of a tip's operand fetch wait for them (-5 % at 20 states, -7 % at 16).  At 61 states the 24 extra
+        // scalar registers spill (+3 %), at 8 the entry is too short to cover the scalar latency (+6 %): those keep the vector
+        // loads (profiles/r03_exp_walkg_tiny.txt).
+#if MBAMD_WG_TW == 32 && !defined(MBAMD_WGX_VECTINY) && !defined(MBAMD_WGX_NOTINY)
+        constexpr bool SCALAR_TINY = SC >= 16 && SC <= 32;
 #else
-        const int er_next = 0;
+        constexpr bool SCALAR_TINY = false;
+#endif
+        typedef unsigned wg_u8v __attribute__((ext_vector_type(8)));
+        wg_u8v tinyE = {}, tiny1 = {}, tiny2 = {};
+        auto tiny_issue = [&]() {
+            if constexpr (SCALAR_TINY) {
+                tinyE = *reinterpret_cast<const MBAMD_AS_CONST wg_u8v*>((uintptr_t) (E0 + n1.e.eread));
+                tiny1 = *reinterpret_cast<const MBAMD_AS_CONST wg_u8v*>((uintptr_t) (T0 + ((n2.e.ctl & MBAMD_W4_TIP1) ? n2.e.c1 : 0u)));
+                tiny2 = *reinterpret_cast<const MBAMD_AS_CONST wg_u8v*>((uintptr_t) (T0 + ((n2.e.ctl & MBAMD_W4_TIP2) ? n2.e.c2 : 0u)));
+            }
+        };
+        auto tiny_pick = [&](const wg_u8v& w) {
+            const unsigned sel = col >> 2;
+            unsigned d = w[0];
+#pragma unroll
+            for (unsigned i = 1; i < 8; ++i) d = sel == i ? w[i] : d;
+            return (d >> ((col & 3u) * 8u)) & 0xFFu;
+        };
+        int er_next = 0;
+#if !defined(MBAMD_WGX_NOTINY)
+        if constexpr (!SCALAR_TINY) {
+            er_next = as_global(E0 + n1.e.eread)[col];
+            n2.s1 = as_global(T0 + ((n2.e.ctl & MBAMD_W4_TIP1) ? n2.e.c1 : 0u))[col];
+            n2.s2 = as_global(T0 + ((n2.e.ctl & MBAMD_W4_TIP2) ? n2.e.c2 : 0u))[col];
+        }
 #endif
         acc_t f1[NT], f2[NT];
         const Walk4Entry ce = cur.e;
@@ -261,10 +289,14 @@ k_walkg(ARGS AA)
 #pragma unroll
                         for (int i = 0; i < TVC; ++i) asm volatile("" :: "v"(b[i]) : "memory");
                         cur.e = walk4_load_entry(prog + j + 3);
+                        tiny_issue();
                     }
                     compute(false, q, wg_pick<q % NS>(S0, S1, S2), b, q < CH ? f1 : f2);
                 } else {
-                    if constexpr (q == NQ - 1) cur.e = walk4_load_entry(prog + j + 3);
+                    if constexpr (q == NQ - 1) {
+                        cur.e = walk4_load_entry(prog + j + 3);
+                        tiny_issue();
+                    }
                     vec b[TVC];
                     if (run) compute(true, q, wg_pick<q % NS>(S0, S1, S2), b, q < CH ? f1 : f2);
                 }
@@ -291,6 +323,11 @@ k_walkg(ARGS AA)
 #endif
             const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(mx), __float_as_uint(mx), false, false);
             mx = fmaxf(__uint_as_float(sw[0]), __uint_as_float(sw[1]));
+        }
+        if constexpr (SCALAR_TINY) {
+            er_next = (int) (int8_t) tiny_pick(tinyE);
+            n2.s1 = tiny_pick(tiny1);
+            n2.s2 = tiny_pick(tiny2);
         }
         const int wm = mode == SCALE_WRITE ? -1 : 0, rm = mode == SCALE_READ ? -1 : 0;
         const int e = (scale_exponent(mx) & wm) | (er & rm);

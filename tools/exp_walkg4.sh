@@ -1,0 +1,21 @@
+#!/bin/bash
+# 20-state walk: where the rest goes -- ablations of the tiny loads, the epilogue, the LDS traffic, and everything at once
+cd "${GRAFT_REPO_ROOT:-/root/repo}"; mkdir -p gpurun_out; export TMPDIR=/tmp
+run() {  # label, config, env...
+  local label=$1 cfg=$2; shift 2
+  env "$@" timeout 300 python bench.py --config $cfg --steps ${STEPS:-100} --warmup 10 --no-cpu-baseline --no-also --no-mcmc 2>/tmp/exp.err | python -c "
+import sys,json
+for l in sys.stdin:
+    if l.startswith('{'):
+        d=json.loads(l); r=d['roofline']
+        print('%-28s %s  value %9.0f  ms/step %.4f  partials %.4f  all %.4f  frac %.3f' % ('$label', '$cfg', d['value'], d['ms_per_step'], r['partials_kernel_ms_per_step'], r['all_kernels_ms_per_step'], r['frac']))
+" || { echo "$label $cfg FAILED"; tail -3 /tmp/exp.err; }
+}
+{
+for cfg in c3 c5; do
+run base $cfg X=1
+for v in g_notiny g_noepi g_nolds g_nofetch_nostore g_floor; do
+  run $v $cfg MBAMD_LIBRARY=$PWD/build_x/libhmsbeagle_$v.so MBAMD_BENCH_NO_ASSERT=1
+done
+done
+} 2>&1 | tee gpurun_out/exp_walkg4.log
