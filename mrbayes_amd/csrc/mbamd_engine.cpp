@@ -2974,7 +2974,7 @@ int beagleCreateInstance(int tipCount, int partialsBufferCount, int compactBuffe
         const Instance* first = in->facade() ? in->children[0].in : in;
         returnInfo->resourceNumber = dev;
         returnInfo->resourceName = (dev < g_resources.length) ? g_resources.list[dev].name : const_cast<char*>("HIP device");
-        returnInfo->implName = const_cast<char*>(first->f64 ? MBAMD_IMPL_NAME ": double-precision level kernels"
+        returnInfo->implName = const_cast<char*>(first->f64 ? (first->S == 4 ? MBAMD_IMPL_NAME ": double-precision kernels (four states: tree walk)" : MBAMD_IMPL_NAME ": double-precision level kernels")
                                                  : first->s4 ? MBAMD_IMPL_NAME ": 4-state tree-walk kernels"
                                                  : first->wg ? (MBAMD_WG_TW == 32 ? MBAMD_IMPL_NAME ": 20/61-state tree-walk kernels (v_mfma_f32_32x32x2_f32)" : MBAMD_IMPL_NAME ": 20/61-state tree-walk kernels (v_mfma_f32_16x16x4_f32)")
                                                  : first->mfma ? MBAMD_IMPL_NAME ": general-state MFMA (v_mfma_f32_32x32x2_f32) kernels"

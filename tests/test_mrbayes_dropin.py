@@ -400,7 +400,7 @@ def _check_double_precision(binary, marker):
     for scaling in ("dynamic", "always"):
         nex = refrun.known_answer_nexus(st, tr, REVMAT, PI, ALPHA, beagle=scaling).replace("beagleprecision=single", "beagleprecision=double")
         out, _ = refrun.run_mb(binary, nex)
-        assert marker in out and "double-precision level kernels" in out, out[-1500:]
+        assert marker in out and "double-precision" in out, out[-1500:]
         ours = refrun.initial_lnl(out)
         assert abs(ours - want) <= 2e-6 + 1e-11 * abs(want), (scaling, ours, want)     # same parameters in the same process: to the printed digits
         assert abs(ours - want) < abs(native32 - want)                                 # and closer than the reference's fp32 build
@@ -411,7 +411,7 @@ def _check_double_precision(binary, marker):
         for scaling in ("dynamic", "always"):
             out, _ = refrun.run_mb(binary, _partitioned_nexus(scaling, same_shape=True).replace("beagleprecision=single", "beagleprecision=double"),
                                    env={"MBAMD_API_TRACE": "1", "MBAMD_VERBOSE": "1"})
-            assert "for 2 divisions" in out and "double-precision level kernels" in out and "[mbamd] error" not in out, out[-2500:]
+            assert "for 2 divisions" in out and "double-precision" in out and "[mbamd] error" not in out, out[-2500:]
             assert abs(refrun.initial_lnl(out) - want2) <= 2e-6 + 1e-11 * abs(want2), (scaling, refrun.initial_lnl(out), want2)
         out, _ = refrun.run_mb(binary, _partitioned_nexus("dynamic", ngen=200, same_shape=True).replace("beagleprecision=single", "beagleprecision=double"),
                                env={"MBAMD_VERBOSE": "1"})
