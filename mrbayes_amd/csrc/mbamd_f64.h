@@ -73,6 +73,135 @@ k64_partials(const Op64* __restrict__ ops, int S, int SPAD, int K, int Ppad_)
         if (i0 + i < S) op.dst[((size_t) k * S + i0 + i) * Ppad + c] = f1[i] * f2[i];
 }
 
+
+#if MBAMD_DEV_HAS_MFMA
+// CondLikeDown_Gen / _NY98 in fp64 on the fp64 MATRIX cores (v_mfma_f64_16x16x4_f64) for 16 <= S <= 64: a wave owns 16 patterns of
+// one category and all states of the destination -- NT = ceil(S / 16) output tiles of 16 states x 16 patterns, each the sum over
+// ceil(S / 4) steps of A (16 out-states x 4 in-states, from the TRANSPOSED matrix copy: 16 consecutive doubles per lane row) times
+// B (4 in-states x 16 patterns of the child: 16 consecutive doubles).  Accumulator register r of lane (n = lane & 15, g = lane >> 4)
+// is state 16 it + g + 4 r of pattern n.  A compact tip's factor is a gather from the transposed matrix laid out for the same
+// registers.  grid (P_pad / 16, operations of a level, K).  Round 2's k64_partials<IB> ran this contraction on the vector ALU with
+// the matrix column through the scalar cache: 154 us per level at protein 200 x 10 000, 8.7 ms per codon M3 evaluation.
+// the 16-pattern product tiles of category k: p[it][r] = state 16 it + g + 4 r of pattern n
+template <int NT>
+__device__ __forceinline__ void f64_mfma_tiles(const MBAMD_AS_CONST Op64* op, int S, int SPAD, size_t Ppad, int k, size_t c, int n, int g,
+                                               double __attribute__((ext_vector_type(4))) (&p)[NT])
+{
+    typedef double d4 __attribute__((ext_vector_type(4)));
+    const int steps = (S + 3) / 4;
+    d4 f[2][NT];
+#pragma unroll
+    for (int ch = 0; ch < 2; ++ch) {
+        const void* ptr = ch ? op->c2 : op->c1;
+        const bool tip = ch ? op->c2_tip : op->c1_tip;
+        const MBAMD_AS_GLOBAL double* mT = as_global(ch ? op->m2T : op->m1T) + (size_t) k * S * SPAD;
+        if (tip) {
+            const unsigned st = as_global(reinterpret_cast<const uint8_t*>(ptr))[c];
+#pragma unroll
+            for (int it = 0; it < NT; ++it)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int i = 16 * it + g + 4 * r;
+                    f[ch][it][r] = st >= (unsigned) S ? 1.0 : (i < S ? mT[(size_t) st * SPAD + i] : 0.0);
+                }
+            continue;
+        }
+        const MBAMD_AS_GLOBAL double* cl = as_global(reinterpret_cast<const double*>(ptr)) + (size_t) k * S * Ppad + c;
+#pragma unroll
+        for (int it = 0; it < NT; ++it) f[ch][it] = (d4) (0.0);
+        for (int t0 = 0; t0 < steps; t0 += 4) {              // four steps' operands in flight
+            double b[4], a[4][NT];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int j = 4 * (t0 + u) + g;              // in-state of this lane's operand rows
+                const int jc = j < S ? j : S - 1;
+                b[u] = j < S ? cl[(size_t) jc * Ppad] : 0.0;
+#pragma unroll
+                for (int it = 0; it < NT; ++it) {
+                    const int i = 16 * it + n;               // out-state of this lane's A row
+                    a[u][it] = (j < S && i < S) ? mT[(size_t) jc * SPAD + (i < SPAD ? i : 0)] : 0.0;
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+#pragma unroll
+                for (int it = 0; it < NT; ++it) f[ch][it] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[u][it], b[u], f[ch][it], 0, 0, 0);
+        }
+    }
+#pragma unroll
+    for (int it = 0; it < NT; ++it) p[it] = f[0][it] * f[1][it];
+}
+
+// KF = 0: one category per wave (blockIdx.z), the rescale in its own pass (k64_rescale); KF = K > 0: a wave computes all K
+// categories of its 16 patterns and rescales in registers (CondLikeScaler_*: per-pattern maximum over categories and states --
+// the four lane groups of a pattern meet through two lane exchanges), one pass over HBM instead of three.
+template <int NT, int KF>
+__global__ void __launch_bounds__(64)
+k64_partials_mfma(const Op64* __restrict__ ops, int S, int SPAD, int Ppad_)
+{
+    typedef double d4 __attribute__((ext_vector_type(4)));
+    const MBAMD_AS_CONST Op64* op = as_const(ops) + blockIdx.y;
+    const size_t Ppad = (size_t) Ppad_;
+    const int lane = (int) threadIdx.x, n = lane & 15, g = lane >> 4;
+    const size_t c = (size_t) blockIdx.x * 16 + n;
+    if ((size_t) blockIdx.x * 16 + 16 <= (size_t) op->first || (size_t) blockIdx.x * 16 >= (size_t) op->last) return;   // (wave-uniform)
+    const bool mine = c >= (size_t) op->first && c < (size_t) op->last;
+    if constexpr (KF == 0) {
+        const int k = (int) blockIdx.z;
+        d4 p[NT];
+        f64_mfma_tiles<NT>(op, S, SPAD, Ppad, k, c, n, g, p);
+        MBAMD_AS_GLOBAL double* dst = as_global(op->dst) + (size_t) k * S * Ppad + c;
+        if (mine) {
+#pragma unroll
+            for (int it = 0; it < NT; ++it)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int i = 16 * it + g + 4 * r;
+                    if (i < S) dst[(size_t) i * Ppad] = p[it][r];
+                }
+        }
+    } else {
+        d4 p[KF][NT];
+        double mx = 0.0;
+#pragma unroll
+        for (int k = 0; k < KF; ++k) {
+            f64_mfma_tiles<NT>(op, S, SPAD, Ppad, k, c, n, g, p[k]);
+#pragma unroll
+            for (int it = 0; it < NT; ++it)
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    if (16 * it + g + 4 * r < S) mx = fmax(mx, p[k][it][r]);
+        }
+        mx = fmax(mx, __shfl_xor(mx, 16));
+        mx = fmax(mx, __shfl_xor(mx, 32));
+        int e = 0;
+        if (op->mode == 1) {
+            if (mx > 0.0 && mx < 1.0e300) (void) frexp(mx, &e);
+            e = e < -1000 ? -1000 : e;
+            if (mine && g == 0) {
+                as_global(op->scale)[c] = e;
+                if (op->cum != nullptr && e != 0) atomicAdd(op->cum + c, e);
+            }
+        } else if (op->mode == 2) {
+            e = as_global(op->scale)[c];
+        }
+        if (mine) {
+#pragma unroll
+            for (int k = 0; k < KF; ++k) {
+                MBAMD_AS_GLOBAL double* dst = as_global(op->dst) + (size_t) k * S * Ppad + c;
+#pragma unroll
+                for (int it = 0; it < NT; ++it)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int i = 16 * it + g + 4 * r;
+                        if (i < S) dst[(size_t) i * Ppad] = e != 0 ? ldexp(p[k][it][r], -e) : p[k][it][r];
+                    }
+            }
+        }
+    }
+}
+#endif
+
 // The same with the rescale fused (K == KF categories, S <= IB: all K x S results of a pattern stay in registers): one pass
 // over HBM instead of three.  Instantiated for four states and the default four gamma categories (at 20 states the K x S
 // results need all 256 VGPRs and the fused kernel is no faster: measured, dropped).
@@ -298,6 +427,56 @@ k64_matrices(const MatrixJob64* __restrict__ jobs, const double* __restrict__ ev
     }
 }
 
+#if MBAMD_DEV_HAS_MFMA
+// the same product on the fp64 matrix cores for 16 <= S <= 64 (one wave per 16 rows, as k_transition_matrices_mfma of the fp32 engine)
+template <int NJ>
+__global__ void __launch_bounds__(64 * NJ)
+k64_matrices_mfma(const MatrixJob64* __restrict__ jobs, const double* __restrict__ ev, int S, int SPAD, int K)
+{
+    typedef double d4 __attribute__((ext_vector_type(4)));
+    const int b = blockIdx.x / K, k = blockIdx.x % K;
+    const MBAMD_AS_GLOBAL double* __restrict__ U = as_global(jobs[b].eig);
+    const MBAMD_AS_GLOBAL double* __restrict__ Ui = U + (size_t) S * S;
+    const MBAMD_AS_GLOBAL double* __restrict__ e = as_global(ev) + (size_t) blockIdx.x * S;
+    const int wave = (int) threadIdx.x >> 6, lane = (int) threadIdx.x & 63, li = lane & 15, ls = lane >> 4;
+    const int i = 16 * wave + li, ic = i < S ? i : S - 1;
+    d4 acc[NJ];
+#pragma unroll
+    for (int jt = 0; jt < NJ; ++jt) acc[jt] = (d4) (0.0);
+    int jc[NJ];
+#pragma unroll
+    for (int jt = 0; jt < NJ; ++jt) jc[jt] = 16 * jt + li < S ? 16 * jt + li : S - 1;
+    const int steps = (S + 3) / 4;
+    for (int st0 = 0; st0 < steps; st0 += 4) {
+        double a[4], bb[4][NJ];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int s = 4 * (st0 + u) + ls, sc = s < S ? s : S - 1;
+            a[u] = (s < S && i < S) ? U[(size_t) ic * S + sc] * e[sc] : 0.0;
+#pragma unroll
+            for (int jt = 0; jt < NJ; ++jt) bb[u][jt] = Ui[(size_t) sc * S + jc[jt]];
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+            for (int jt = 0; jt < NJ; ++jt) acc[jt] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[u], bb[u][jt], acc[jt], 0, 0, 0);
+    }
+    MBAMD_AS_GLOBAL double* __restrict__ M = as_global(jobs[b].out) + (size_t) k * S * S;
+    MBAMD_AS_GLOBAL double* __restrict__ MT = as_global(jobs[b].out) + (size_t) K * S * S + (size_t) k * S * SPAD;
+#pragma unroll
+    for (int jt = 0; jt < NJ; ++jt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int row = 16 * wave + ls + 4 * r, j = 16 * jt + li;
+            if (row < S && j < S) {
+                const double v = acc[jt][r] < 0.0 ? 0.0 : acc[jt][r];
+                M[(size_t) row * S + j] = v;
+                MT[(size_t) j * SPAD + row] = v;
+            }
+        }
+}
+#endif
+
 // Likelihood_* (reference src/likelihood.c:5764-5917, 6975-7040) with BEAGLE's root / edge semantics; one thread per pattern
 struct IntegrateArgs64 {
     const double*  parent[MBAMD_MAX_SUBSETS];
@@ -402,6 +581,7 @@ public:
     std::vector<Walk64Entry> walkProg;
     uint64_t walkLaunches = 0, levelLaunches = 0;
     bool walkAlways = false;
+    bool noMfma = false;                           // MBAMD_F64_NO_MFMA: the vector-ALU level kernels for 16..64 states too
     bool walkOff = false;                          // MBAMD_F64_NO_WALK (read when the instance is created): level kernels only
     size_t bufDoubles = 0, matDoubles = 0, eigDoubles = 0;
 
@@ -416,6 +596,7 @@ public:
         IB = blockOf(S);
         walkOff = std::getenv("MBAMD_F64_NO_WALK") != nullptr;
         walkAlways = std::getenv("MBAMD_F64_WALK_ALWAYS") != nullptr;
+        noMfma = std::getenv("MBAMD_F64_NO_MFMA") != nullptr;
         SPAD = (S + IB - 1) / IB * IB;
         bufDoubles = (size_t) K * S * Ppad;
         matDoubles = (size_t) K * S * S + (size_t) K * S * SPAD;
@@ -552,6 +733,22 @@ public:
         std::memcpy(h.data(), w, (size_t) P * sizeof(double));
         return upload(d_pweights, h.data(), (size_t) Ppad * sizeof(double));
     }
+    void launchMatrices(const MatrixJob64* dj, int count)
+    {
+#if MBAMD_DEV_HAS_MFMA
+        if (S >= 16 && S <= 64 && !noMfma) {
+            const unsigned grid = (unsigned) (count * K);
+            switch ((S + 15) / 16) {
+                case 1: MBAMD_LAUNCH(k64_matrices_mfma<1>, grid, 64, 0, stream, dj, (const double*) d_ev, S, SPAD, K); break;
+                case 2: MBAMD_LAUNCH(k64_matrices_mfma<2>, grid, 128, 0, stream, dj, (const double*) d_ev, S, SPAD, K); break;
+                case 3: MBAMD_LAUNCH(k64_matrices_mfma<3>, grid, 192, 0, stream, dj, (const double*) d_ev, S, SPAD, K); break;
+                default: MBAMD_LAUNCH(k64_matrices_mfma<4>, grid, 256, 0, stream, dj, (const double*) d_ev, S, SPAD, K); break;
+            }
+            return;
+        }
+#endif
+        MBAMD_LAUNCH(k64_matrices, (unsigned) (count * K), 256, 0, stream, dj, (const double*) d_ev, S, SPAD, K);
+    }
     int updateMatrices(int eigenIdx, int rateIdx, const int* prob, const double* lengths, int count)
     {
         if (count <= 0) return BEAGLE_SUCCESS;
@@ -575,7 +772,7 @@ public:
         }
         const int total = count * K * S;
         MBAMD_LAUNCH(k64_exponentials, (unsigned) ((total + 255) / 256), 256, 0, stream, (const MatrixJob64*) dj, rateSets[rateIdx], S, K, total, d_ev);
-        MBAMD_LAUNCH(k64_matrices, (unsigned) (count * K), 256, 0, stream, (const MatrixJob64*) dj, (const double*) d_ev, S, SPAD, K);
+        launchMatrices((const MatrixJob64*) dj, count);
         HIP_TRY(hipGetLastError());
         return BEAGLE_SUCCESS;
     }
@@ -859,6 +1056,35 @@ public:
                 MBAMD_LAUNCH(kern, grid, 64, 0, stream, dops + first, S, SPAD, Ppad);
                 continue;
             }
+#if MBAMD_DEV_HAS_MFMA
+            if (S >= 16 && S <= 64 && !noMfma) {
+                const int NTr = (S + 15) / 16;
+                const bool fuse = K >= 1 && K <= 4 && NTr * K <= 8 && std::getenv("MBAMD_F64_UNFUSED") == nullptr;   // all K categories' tiles in registers
+                const dim3 grid((unsigned) (Ppad / 16), (unsigned) cnt, (unsigned) (fuse ? 1 : K));
+#define MBAMD_F64_MFMA_CASE(NT_, KF_) MBAMD_LAUNCH((k64_partials_mfma<NT_, KF_>), grid, 64, 0, stream, dops + first, S, SPAD, Ppad)
+                const int key = NTr * 8 + (fuse ? K : 0);
+                switch (key) {
+                    case 1 * 8 + 0: MBAMD_F64_MFMA_CASE(1, 0); break;
+                    case 1 * 8 + 1: MBAMD_F64_MFMA_CASE(1, 1); break;
+                    case 1 * 8 + 2: MBAMD_F64_MFMA_CASE(1, 2); break;
+                    case 1 * 8 + 3: MBAMD_F64_MFMA_CASE(1, 3); break;
+                    case 1 * 8 + 4: MBAMD_F64_MFMA_CASE(1, 4); break;
+                    case 2 * 8 + 0: MBAMD_F64_MFMA_CASE(2, 0); break;
+                    case 2 * 8 + 1: MBAMD_F64_MFMA_CASE(2, 1); break;
+                    case 2 * 8 + 2: MBAMD_F64_MFMA_CASE(2, 2); break;
+                    case 2 * 8 + 3: MBAMD_F64_MFMA_CASE(2, 3); break;
+                    case 2 * 8 + 4: MBAMD_F64_MFMA_CASE(2, 4); break;
+                    case 3 * 8 + 0: MBAMD_F64_MFMA_CASE(3, 0); break;
+                    case 3 * 8 + 1: MBAMD_F64_MFMA_CASE(3, 1); break;
+                    case 3 * 8 + 2: MBAMD_F64_MFMA_CASE(3, 2); break;
+                    case 4 * 8 + 0: MBAMD_F64_MFMA_CASE(4, 0); break;
+                    case 4 * 8 + 1: MBAMD_F64_MFMA_CASE(4, 1); break;
+                    default: MBAMD_F64_MFMA_CASE(4, 2); break;          // (4 * 8 + 2)
+                }
+#undef MBAMD_F64_MFMA_CASE
+                if (fuse) continue;
+            } else
+#endif
             switch (IB) {
                 case 4: launchPartials<4>(dops + first, cnt); break;
                 case 8: launchPartials<8>(dops + first, cnt); break;

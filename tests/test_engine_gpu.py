@@ -525,7 +525,7 @@ def test_parsimony(gpu, ntaxa, npat, nstates, words):
 
 
 @pytest.mark.parametrize("case", ["primates_gtr_g4", "primates_gtr_ig4", "avian_wag_g4", "replicase_m3", "synth_dna_gaps", "synth_aa_wag",
-                                  "synth_codon_m3", "bench_c2"])
+                                  "synth_codon_m3", "bench_c2", "bench_c3", "bench_c5"])
 def test_double_precision(gpu, golden_dir, case):
     """BEAGLE_FLAG_PRECISION_DOUBLE: the fp64 engine (mbamd_f64.h) against the reference's double build."""
     ec.check_double_precision(gpu, golden_dir, case)

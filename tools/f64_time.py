@@ -24,10 +24,12 @@ def main():
         div = division_from_golden(GOLD, case)
         row = []
         for dbl, levels in ((False, False), (True, False), (True, True)):
-            if levels:
+            if levels:                                       # round 2's kernels: no four-state walk, no fp64 matrix cores
                 os.environ["MBAMD_F64_NO_WALK"] = "1"        # (read when the instance is created)
+                os.environ["MBAMD_F64_NO_MFMA"] = "1"
             else:
                 os.environ.pop("MBAMD_F64_NO_WALK", None)
+                os.environ.pop("MBAMD_F64_NO_MFMA", None)
             bd = lk.BeagleDivision(div, lib, scaling=lk.MB_BEAGLE_SCALE_ALWAYS, double_precision=dbl)
             lnl = bd.LogLike(0)
             bd.AcceptMove(0)
@@ -44,7 +46,8 @@ def main():
         print("%s  %d taxa x %d patterns, %d states x %d categories" % (case, div.tree.ntaxa, div.npatterns, div.nstates, div.ncat))
         print("   reference fp64 build  lnL %.8f" % ref)
         os.environ.pop("MBAMD_F64_NO_WALK", None)
-        for name, (lnl, dt) in zip(("fp32 engine", "fp64 engine", "fp64 levels"), row):
+        os.environ.pop("MBAMD_F64_NO_MFMA", None)
+        for name, (lnl, dt) in zip(("fp32 engine", "fp64 engine", "fp64 round 2"), row):
             print("   %-12s lnL %.8f  |diff| %.3g (rel %.2g)   %.2f ms per evaluation incl. the Python host  (%.3g node-pattern updates/s)"
                   % (name, lnl, abs(lnl - ref), abs(lnl - ref) / abs(ref), dt * 1e3, nodes / dt))
 
