@@ -92,15 +92,16 @@ static inline int round_up(int v, int m) { return (v + m - 1) / m * m; }
 
 // state counts the 20/61-state tree walk (mbamd_walkg.h) is instantiated for: amino acids, doublets, and the sense codons of
 // every genetic code MrBayes knows (60 vertebrate mitochondrial ... 63; reference src/model.c SetCode)
-// state counts MrBayes sends: covarion nucleotides 8, doublets 16, amino acids 20, the sense codons of every genetic code 60..63
-// (4 has its own kernel; restriction sites, 2, covarion amino acids, 40, and anything else run on the level kernels)
-static inline bool wg_compiled(int S) { return S == 8 || S == 16 || S == 20 || (S >= 60 && S <= 63); }
+// state counts MrBayes sends: restriction sites 2, covarion nucleotides 8, doublets 16, amino acids 20, the sense codons of every
+// genetic code 60..63 (4 has its own kernel; covarion amino acids, 40, and anything else run on the level kernels)
+static inline bool wg_compiled(int S) { return S == 2 || S == 8 || S == 16 || S == 20 || (S >= 60 && S <= 63); }
 // FN<SC, WMAX, CH, DEPTH>: one row tile -> whole jobs two ahead; two row tiles -> half jobs one ahead (see k_walkg)
 #if !defined(MBAMD_WG_DEPTH61)
 #define MBAMD_WG_DEPTH61 1       // chunks the operand fetch of the 60..63-state kernels runs ahead (experiments: 2)
 #endif
 #define MBAMD_WG_DISPATCH(S, FN, ...)                                   \
     switch (S) {                                                        \
+        case 2: FN<2, 8, 1, 2>(__VA_ARGS__); break;                     \
         case 8: FN<8, 8, 1, 2>(__VA_ARGS__); break;                     \
         case 16: FN<16, 8, 1, 2>(__VA_ARGS__); break;                   \
         case 20: FN<20, 8, 1, 2>(__VA_ARGS__); break;                   \
@@ -609,8 +610,9 @@ int Instance::create(int tipCount_, int partialsBufferCount, int compactBufferCo
     HIP_TRY(hipMalloc(&d_site, (size_t) Ppad * sizeof(double)));
     nblocks = Ppad / 64;
 #if MBAMD_DEV_HAS_MFMA
-    if (!s4 && S >= 8) nblocks = Ppad / 32;      // k_integrate_lnl_wide / _wg_wide: one block sum per 32-pattern tile
+    if (!s4 && S >= 8) nblocks = Ppad / 32;      // k_integrate_lnl_wide: one block sum per 32-pattern tile
 #endif
+    if (wg) nblocks = Ppad / MBAMD_INTEGRATE_WG_PATTERNS;      // the tree-walk layout's integration kernel, whatever the state count
     HIP_TRY(hipHostMalloc(&h_sums, (size_t) nblocks * sizeof(double), hipHostMallocDefault));
     HIP_TRY(hipHostGetDevicePointer((void**) &h_sums_dev, h_sums, 0));
     stageCap = (size_t) 8 << 20;

@@ -59,8 +59,8 @@ def test_final_pass_and_scaled_readout(gpu, nstates, ncat, npat):
 
 @pytest.mark.parametrize("nstates,ntaxa,npat", [(2, 40, 700), (8, 60, 1500), (16, 30, 300), (5, 20, 200), (33, 12, 100)])
 def test_other_state_counts_on_the_tree_walk(gpu, oracle, nstates, ntaxa, npat):
-    """Covarion nucleotides (8 states, CondLikeDown_Gen with TiProbs_GenCov) have their own instantiation of the 20/61-state
-    tree-walk kernel; restriction sites (2 states, CondLikeDown_Bin / Likelihood_Res), 5 and 33 states stay on the level kernels."""
+    """Restriction sites (2 states, CondLikeDown_Bin / Likelihood_Res) and covarion nucleotides (8 states, CondLikeDown_Gen with
+    TiProbs_GenCov) have their own instantiations of the 20/61-state tree-walk kernel; 5 and 33 states stay on the level kernels."""
     ec.check_generic_states(gpu, oracle, nstates, ntaxa, npat)
 
 

@@ -63,8 +63,8 @@ def test_final_pass_and_scaled_readout(emu, nstates, ncat, npat):
 
 @pytest.mark.parametrize("nstates,ntaxa,npat", [(2, 12, 70), (8, 10, 45), (5, 8, 33)])
 def test_other_state_counts_on_the_tree_walk(emu, oracle, nstates, ntaxa, npat):
-    """Covarion nucleotides (8 states, CondLikeDown_Gen with TiProbs_GenCov) have their own instantiation of the 20/61-state
-    tree-walk kernel; restriction sites (2 states, CondLikeDown_Bin / Likelihood_Res), 5 and 33 states stay on the level kernels."""
+    """Restriction sites (2 states, CondLikeDown_Bin / Likelihood_Res) and covarion nucleotides (8 states, CondLikeDown_Gen with
+    TiProbs_GenCov) have their own instantiations of the 20/61-state tree-walk kernel; 5 and 33 states stay on the level kernels."""
     ec.check_generic_states(emu, oracle, nstates, ntaxa, npat)
 
 
