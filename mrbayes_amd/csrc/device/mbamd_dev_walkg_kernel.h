@@ -82,7 +82,7 @@ k_walkg(ARGS AA)
     constexpr int T = Sh::T, NT = Sh::NT, V = Sh::V, VA = Sh::VA, TP = Sh::TP, NAP = Sh::NAP, NAV = NAP / VA, TV = TP / V;
     constexpr int TPC = TP / CH, NAVC = NAV / CH, TVC = TV / CH;      // per chunk: MFMA steps, A register groups, B register groups
     constexpr int NQ = 2 * CH, NS = DEPTH + 1;                        // chunks per entry, register sets
-    static_assert(TP % CH == 0 && TPC % V == 0 && NAV % CH == 0 && (TPC * NT) % VA == 0 && NS <= 3 && DEPTH <= NQ && TPC <= 16, "chunk geometry");
+    static_assert(TP % CH == 0 && TPC % V == 0 && NAV % CH == 0 && (TPC * NT) % VA == 0 && NS <= 3 && DEPTH <= NQ && TPC <= 20, "chunk geometry");
     static_assert((ACC < T ? ACC : T) * NT <= NAVC * VA, "a compact tip's gather rows must lie in the first chunk");
     constexpr unsigned SLOTB = TP * 256u;
     const unsigned lane = threadIdx.x & 63, half = lane / TW, col = lane % TW;      // half: which of the KS states of a row

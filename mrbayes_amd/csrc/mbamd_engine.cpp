@@ -92,9 +92,9 @@ static inline int round_up(int v, int m) { return (v + m - 1) / m * m; }
 
 // state counts the 20/61-state tree walk (mbamd_walkg.h) is instantiated for: amino acids, doublets, and the sense codons of
 // every genetic code MrBayes knows (60 vertebrate mitochondrial ... 63; reference src/model.c SetCode)
-// state counts MrBayes sends: restriction sites 2, covarion nucleotides 8, doublets 16, amino acids 20, the sense codons of every
-// genetic code 60..63 (4 has its own kernel; covarion amino acids, 40, and anything else run on the level kernels)
-static inline bool wg_compiled(int S) { return S == 2 || S == 8 || S == 16 || S == 20 || (S >= 60 && S <= 63); }
+// state counts MrBayes sends: restriction sites 2, covarion nucleotides 8, doublets 16, amino acids 20, covarion amino acids 40, the
+// sense codons of every genetic code 60..63 (4 has its own kernel; anything else runs on the level kernels)
+static inline bool wg_compiled(int S) { return S == 2 || S == 8 || S == 16 || S == 20 || S == 40 || (S >= 60 && S <= 63); }
 // FN<SC, WMAX, CH, DEPTH>: one row tile -> whole jobs two ahead; two row tiles -> half jobs one ahead (see k_walkg)
 #if !defined(MBAMD_WG_DEPTH61)
 #define MBAMD_WG_DEPTH61 1       // chunks the operand fetch of the 60..63-state kernels runs ahead (experiments: 2)
@@ -105,6 +105,7 @@ static inline bool wg_compiled(int S) { return S == 2 || S == 8 || S == 16 || S 
         case 8: FN<8, 8, 1, 2>(__VA_ARGS__); break;                     \
         case 16: FN<16, 8, 1, 2>(__VA_ARGS__); break;                   \
         case 20: FN<20, 8, 1, 2>(__VA_ARGS__); break;                   \
+        case 40: FN<40, 4, 1, 1>(__VA_ARGS__); break;                   \
         case 60: FN<60, 4, 2, MBAMD_WG_DEPTH61>(__VA_ARGS__); break;    \
         case 61: FN<61, 4, 2, MBAMD_WG_DEPTH61>(__VA_ARGS__); break;    \
         case 62: FN<62, 4, 2, MBAMD_WG_DEPTH61>(__VA_ARGS__); break;    \

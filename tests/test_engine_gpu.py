@@ -46,7 +46,7 @@ def test_transition_matrices(gpu, oracle, golden_dir, case):
                                                  (20, 1, 200), (61, 1, 33), (61, 1, 129), (61, 3, 40),
                                                  (16, 2, 10), (2, 4, 5), (20, 4, 1), (4, 4, 1),
                                                  (20, 3, 95), (20, 2, 64), (61, 2, 70), (33, 1, 50), (5, 4, 40), (64, 1, 31),
-                                                 (60, 1, 45), (62, 2, 33), (63, 1, 70), (16, 4, 97), (8, 4, 50), (8, 1, 200), (8, 2, 33), (2, 1, 100), (2, 4, 70)])
+                                                 (60, 1, 45), (62, 2, 33), (63, 1, 70), (16, 4, 97), (8, 4, 50), (8, 1, 200), (8, 2, 33), (2, 1, 100), (2, 4, 70), (40, 4, 70), (40, 1, 33)])
 def test_single_operations(gpu, oracle, nstates, ncat, npat):
     ec.check_single_operations(gpu, oracle, nstates, ncat, npat)
 
@@ -57,10 +57,10 @@ def test_final_pass_and_scaled_readout(gpu, nstates, ncat, npat):
     ec.check_final_pass(gpu, nstates, ncat, npat)
 
 
-@pytest.mark.parametrize("nstates,ntaxa,npat", [(2, 40, 700), (8, 60, 1500), (16, 30, 300), (5, 20, 200), (33, 12, 100)])
+@pytest.mark.parametrize("nstates,ntaxa,npat", [(2, 40, 700), (8, 60, 1500), (16, 30, 300), (40, 30, 400), (5, 20, 200), (33, 12, 100)])
 def test_other_state_counts_on_the_tree_walk(gpu, oracle, nstates, ntaxa, npat):
-    """Restriction sites (2 states, CondLikeDown_Bin / Likelihood_Res) and covarion nucleotides (8 states, CondLikeDown_Gen with
-    TiProbs_GenCov) have their own instantiations of the 20/61-state tree-walk kernel; 5 and 33 states stay on the level kernels."""
+    """Restriction sites (2 states, CondLikeDown_Bin / Likelihood_Res), covarion nucleotides and amino acids (8 / 40 states,
+    CondLikeDown_Gen with TiProbs_GenCov) have their own instantiations of the 20/61-state tree-walk kernel; 5 and 33 states stay on the level kernels."""
     ec.check_generic_states(gpu, oracle, nstates, ntaxa, npat)
 
 
@@ -483,6 +483,7 @@ def test_lists_with_hazards_are_cut_into_segments(gpu, oracle):
     ec.check_hazard_lists(gpu, 20, 4, 40)
     ec.check_hazard_lists(gpu, 8, 4, 70)
     ec.check_hazard_lists(gpu, 2, 2, 40)
+    ec.check_hazard_lists(gpu, 40, 2, 40)
 
 
 def test_instances_created_and_destroyed_repeatedly(gpu):

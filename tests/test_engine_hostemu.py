@@ -61,10 +61,10 @@ def test_final_pass_and_scaled_readout(emu, nstates, ncat, npat):
     ec.check_final_pass(emu, nstates, ncat, npat)
 
 
-@pytest.mark.parametrize("nstates,ntaxa,npat", [(2, 12, 70), (8, 10, 45), (5, 8, 33)])
+@pytest.mark.parametrize("nstates,ntaxa,npat", [(2, 12, 70), (8, 10, 45), (40, 8, 40), (5, 8, 33)])
 def test_other_state_counts_on_the_tree_walk(emu, oracle, nstates, ntaxa, npat):
-    """Restriction sites (2 states, CondLikeDown_Bin / Likelihood_Res) and covarion nucleotides (8 states, CondLikeDown_Gen with
-    TiProbs_GenCov) have their own instantiations of the 20/61-state tree-walk kernel; 5 and 33 states stay on the level kernels."""
+    """Restriction sites (2 states, CondLikeDown_Bin / Likelihood_Res), covarion nucleotides and amino acids (8 / 40 states,
+    CondLikeDown_Gen with TiProbs_GenCov) have their own instantiations of the 20/61-state tree-walk kernel; 5 and 33 states stay on the level kernels."""
     ec.check_generic_states(emu, oracle, nstates, ntaxa, npat)
 
 
@@ -243,6 +243,7 @@ def test_lists_with_hazards_are_cut_into_segments(emu, oracle):
     ec.check_hazard_lists(emu, 20, 4, 40)
     ec.check_hazard_lists(emu, 8, 4, 70)
     ec.check_hazard_lists(emu, 2, 2, 40)
+    ec.check_hazard_lists(emu, 40, 2, 40)
 
 
 def test_closed_form_matrices(emu, oracle):
