@@ -416,6 +416,25 @@ def test_general_state_tree_walk_schedules_agree(gpu, golden_dir, monkeypatch, c
     assert np.allclose(sa, sb, rtol=2e-6, atol=2e-5)
 
 
+@pytest.mark.parametrize("nstates,ntaxa,npat", [(2, 60, 900), (8, 50, 700), (40, 24, 300)])
+def test_new_state_counts_schedules_agree(gpu, monkeypatch, nstates, ntaxa, npat):
+    """The 2-, 8- and 40-state instantiations of k_walkg: every schedule (waves per workgroup, slot budget) gives the same bits, and
+    the level kernels (MBAMD_NO_WALKG=1) agree to rounding -- per site."""
+    div = synthetic_division("gen%d" % nstates, ntaxa, npat, seed=13, tree_seed=6, alpha=0.6, ncat=4, p_gap=0.03)
+    a, sa = _lnl_and_sites(gpu, div)
+    for env in ({"MBAMD_WALK_WAVES": "1"}, {"MBAMD_WALK_WAVES": "4"}, {"MBAMD_WALK_WAVES": "2", "MBAMD_MAX_LDS_SLOTS": "3"}, {"MBAMD_NO_INLINE_PROGRAMS": "1"}):
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        b, sb = _lnl_and_sites(gpu, div)
+        assert a == b and np.array_equal(sa, sb), (nstates, env)
+        for k in env:
+            monkeypatch.delenv(k)
+    monkeypatch.setenv("MBAMD_NO_WALKG", "1")
+    b, sb = _lnl_and_sites(gpu, div)
+    assert abs(a - b) <= 2e-7 * abs(a)
+    assert np.allclose(sa, sb, rtol=2e-6, atol=2e-5)
+
+
 def test_deferred_lists_without_a_merge_kernel(gpu, oracle):
     """Two independent operation lists back to back on a shape that has no merged-launch kernel (20 states, three
     categories): the deferred lists must run one after the other, not be dropped."""
