@@ -60,7 +60,7 @@ struct Walk4Scratch {
     std::vector<int> prod1, prod2, parent, ncons, need, size, phaseOf, waveOf, posOf, order, stack, heapTmp;
     std::vector<char> assigned, cap;
     // kept between builds so that compiling a short list (a root-ward path: every MCMC generation) allocates nothing
-    std::vector<int> binLoad, roots, frontier, slotHolder, lastUse, slotOfVal, freeFrom, memAt, nextOp;
+    std::vector<int> binLoad, roots, frontier, slotHolder, lastUse, slotOfVal, freeFrom, memAt, nextOp, pieces, load, dryNodes;
     std::vector<char> fwd;
     std::vector<std::vector<int>> phaseStart;
     std::vector<Walk4Template::Entry> scan;
@@ -209,19 +209,20 @@ inline bool Walk4Builder::build(const std::vector<Walk4Op>& ops, Walk4Template& 
         int splits = 0, capSize = 0;
         // Every split moves one node into the cap -- the next, partly serial phase -- and makes the pieces pack better.
         // Dry run: the cost (fullest bin + cap) after every split; then split exactly as often as the cheapest point says.
-        auto fullestBin = [&](const std::vector<int>& nodes) {
-            std::vector<int> pieces;
+        auto fullestBin = [&](const std::vector<int>& nodes) {      // (scratch vectors: no allocation per call)
+            std::vector<int>&pieces = s.pieces, &load = s.load;
+            pieces.clear();
             for (int v : nodes) pieces.push_back(size[v]);
             std::sort(pieces.begin(), pieces.end(), std::greater<int>());
-            std::vector<int> load(W, 0);
+            load.assign(W, 0);
             for (int sz : pieces) *std::min_element(load.begin(), load.end()) += sz;
             return *std::max_element(load.begin(), load.end());
         };
         int bestSplits = 0;
         {
             auto dry = heap;
-            std::vector<int> nodes;
-            { auto c2 = dry; while (!c2.empty()) { nodes.push_back(c2.top()); c2.pop(); } }
+            std::vector<int>& nodes = s.dryNodes;
+            nodes.assign(roots.begin(), roots.end());                 // (the heap holds exactly the roots here)
             long bestCost = (long) fullestBin(nodes) + 0;
             if ((int) nodes.size() < W) bestCost = 1L << 40;          // (fewer pieces than bins: keep splitting)
             int k = 0, capNow = 0;
