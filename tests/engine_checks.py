@@ -349,7 +349,7 @@ def check_final_pass(lib, nstates, ncat, npat, seed=7):
         inst.finalize()
 
 
-def check_hazard_lists(lib, nstates, ncat, npat, seed=5):
+def check_hazard_lists(lib, nstates, ncat, npat, seed=5, double_precision=False):
     """Operation lists MrBayes never issues but the API allows: a destination that an earlier operation of the same list
     read (write-after-read) or wrote (write-after-write), an exponent buffer written by one operation and read by a
     later one, two independent lists back to back.  One call must give what one call per operation gives."""
@@ -357,7 +357,8 @@ def check_hazard_lists(lib, nstates, ncat, npat, seed=5):
     S, K, P = nstates, ncat, npat
 
     def run(split):
-        inst = bg.BeagleInstance(lib, 2, 10, 2, S, P, 1, 4, K, 6)
+        inst = bg.BeagleInstance(lib, 2, 10, 2, S, P, 1, 4, K, 6,
+                                 preference_flags=bg.BEAGLE_FLAG_PRECISION_DOUBLE if double_precision else 0)
         try:
             for m in range(4):
                 ti = rng2.random((K, S, S)) + 0.05

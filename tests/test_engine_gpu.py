@@ -503,6 +503,8 @@ def test_lists_with_hazards_are_cut_into_segments(gpu, oracle):
     ec.check_hazard_lists(gpu, 8, 4, 70)
     ec.check_hazard_lists(gpu, 2, 2, 40)
     ec.check_hazard_lists(gpu, 40, 2, 40)
+    ec.check_hazard_lists(gpu, 4, 4, 100, double_precision=True)      # (the fp64 walk hands lists with hazards to the level kernels)
+    ec.check_hazard_lists(gpu, 20, 2, 40, double_precision=True)
 
 
 def test_instances_created_and_destroyed_repeatedly(gpu):

@@ -244,6 +244,8 @@ def test_lists_with_hazards_are_cut_into_segments(emu, oracle):
     ec.check_hazard_lists(emu, 8, 4, 70)
     ec.check_hazard_lists(emu, 2, 2, 40)
     ec.check_hazard_lists(emu, 40, 2, 40)
+    ec.check_hazard_lists(emu, 4, 4, 100, double_precision=True)      # (the fp64 walk hands lists with hazards to the level kernels)
+    ec.check_hazard_lists(emu, 20, 2, 40, double_precision=True)
 
 
 def test_closed_form_matrices(emu, oracle):
