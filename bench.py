@@ -384,6 +384,38 @@ def measure(args, cfg, steps, warmup, rank, local_rank, world, dist, device, emu
     return out
 
 
+def double_precision_line(cfg, steps, lib):
+    """The same workload through the double-precision engine (BEAGLE_FLAG_PRECISION_DOUBLE, `set beagleprecision=double`): lnL
+    against the reference's double build, wall time of replayed full-tree evaluations.  A report beside the fp32 line."""
+    from mrbayes_amd import likelihood as lk
+    from mrbayes_amd.division import division_from_golden
+    case, kind, desc = CONFIGS[cfg]
+    with open(os.path.join(GOLD, case + ".json")) as fh:
+        gold = json.load(fh)
+    div = division_from_golden(GOLD, case)
+    bd = lk.BeagleDivision(div, lib, nchains=1, scaling=lk.MB_BEAGLE_SCALE_ALWAYS, double_precision=True)
+    try:
+        impl = bd.inst.details.implName.decode()
+        lnl0 = bd.LogLike(0)
+        ref = gold["lnL"]["fp64"]
+        assert abs(lnl0 - ref) <= 2e-6 + 2e-9 * abs(ref), (cfg, lnl0, ref)
+        bd.AcceptMove(0)
+        evals = [lk.record_evaluation(bd), lk.record_evaluation(bd)]
+        for i in range(5):
+            evals[i & 1].run()
+        t0 = time.perf_counter()
+        for i in range(steps):
+            rc, lnl = evals[i & 1].run()
+            if rc != 0:
+                raise RuntimeError("evaluation failed with code %d" % rc)
+        dt = time.perf_counter() - t0
+    finally:
+        bd.finalize()
+    return {"workload": desc, "golden_case": case, "dtype": "f64", "kernel": impl, "steps": steps, "ms_per_step": dt / steps * 1e3,
+            "value": (div.ntaxa - 2) * div.npatterns * steps / dt / 1e6, "unit": "M updates/s", "lnL": lnl, "lnL_reference_fp64": ref,
+            "abs_diff": abs(lnl - ref), "lnL_pinned": True}
+
+
 def pattern_sharded(args, cfg, steps, warmup, rank, local_rank, world, dist, device, emulate, lib):
     """ONE chain whose site patterns are cut into `world` contiguous blocks, a block per rank / GPU (the
     north star's "site-pattern blocks sharded across the GPUs ... RCCL all-reduce of the per-generation lnL"): every rank
@@ -543,6 +575,13 @@ def main():
                                                False, lib, not args.no_cpu_baseline))
                 except Exception as exc:
                     out["also"].append({"workload": other, "error": repr(exc)})
+        if not args.no_also:
+            out["double_precision"] = []
+            for other in (args.config, "c5"):
+                try:
+                    out["double_precision"].append(double_precision_line(other, 50, lib))
+                except Exception as exc:
+                    out["double_precision"].append({"workload": other, "error": repr(exc)[:300]})
         if not args.no_mcmc:
             try:
                 with open(os.path.join(GOLD, "bench_c2.json")) as fh:
