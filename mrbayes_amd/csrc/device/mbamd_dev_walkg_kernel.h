@@ -99,7 +99,12 @@ k_walkg(ARGS AA)
     extern __shared__ float lds_walkg[];
     const unsigned K = (unsigned) A.K, KL = K * (unsigned) A.lists;
     const unsigned xcd = blockIdx.x & 7u, pos = blockIdx.x >> 3;
+#if defined(MBAMD_WGX_REMAP)     // (experiment) category / list slowest: the workgroups a CU hosts at a time read the same tables
+    const unsigned nt8 = ((unsigned) A.ntiles + 7u) >> 3;
+    const unsigned tile = (pos % nt8) * 8u + xcd, k = (pos / nt8) % K, list = (pos / nt8) / K;
+#else
     const unsigned tile = (pos / KL) * 8u + xcd, k = (pos % KL) % K, list = (pos % KL) / K;
+#endif
     if (tile >= (unsigned) A.ntiles) return;
     char* const mine = reinterpret_cast<char*>(lds_walkg) + (size_t) wave * (MBAMD_WG_STAGE + (size_t) A.nslots * SLOTB);
     vec* const slots = reinterpret_cast<vec*>(mine + MBAMD_WG_STAGE) + lane;          // this lane's V rows of row group 0, slot 0
