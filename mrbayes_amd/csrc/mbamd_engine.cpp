@@ -17,6 +17,7 @@
 #include <mutex>
 #include <string>
 #include <limits>
+#include <memory>
 #include <unordered_map>
 #include <vector>
 

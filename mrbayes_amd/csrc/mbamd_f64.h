@@ -836,8 +836,7 @@ public:
         // root-ward path: one launch instead of one per operation); mid-sized full evaluations stay on the level kernels
         // (measured: profiles/r03_f64_walk.txt).  MBAMD_F64_WALK_ALWAYS=1: every eligible list.
         if (!walkAlways && n > 64 && (long) (Ppad / 64) * K < 1200) return 1;
-        StatTimer* st_ = new StatTimer(ST_PLAN);       // (MBAMD_STATS: the host side of the walk, up to the upload)
-        struct Closer { StatTimer*& t; ~Closer() { delete t; t = nullptr; } } closer_{st_};
+        std::unique_ptr<StatTimer> st_(new StatTimer(ST_PLAN));      // (MBAMD_STATS: the host side of the walk, up to the upload)
         std::vector<Walk4Op>& wops = walkOps;
         wops.clear();
         std::vector<char> written((size_t) nBuffers, 0), readB((size_t) nBuffers, 0), sc((size_t) std::max(nScale, 1), 0);
@@ -918,7 +917,7 @@ public:
             e.scale = w.scaleWrite >= 0 ? d_scale + (size_t) w.scaleWrite * Ppad : (w.scaleRead >= 0 ? d_scale + (size_t) w.scaleRead * Ppad : nullptr);
         }
         for (const Walk4Op& w : wops) { valid[w.dst] = 1; isTip[w.dst] = 0; }
-        delete st_; st_ = nullptr;
+        st_.reset();
         void* dv = nullptr;
         int rc = stage(walkProg.data(), walkProg.size() * sizeof(Walk64Entry), &dv);
         if (rc) return rc;
