@@ -62,8 +62,43 @@ def _doublet(beagle, npairs=60):
     return s + " startvals tau=t V=t;\n mcmc ngen=1 nchains=1 nruns=1 samplefreq=1 printfreq=1 filename=x;\nend;\n"
 
 
+_MODELS = {
+    "codon_equal": (61, " lset nucmodel=codon omegavar=equal nst=2;\n prset omegapr=fixed(0.3) tratiopr=fixed(2.0) statefreqpr=fixed(equal);\n"),
+    "codon_ny98": (61, " lset nucmodel=codon omegavar=ny98 nst=2;\n prset ny98omega1pr=fixed(0.2) ny98omega3pr=fixed(2.5) codoncatfreqs=fixed(0.5,0.3,0.2)"
+                       " tratiopr=fixed(2.0) statefreqpr=fixed(equal);\n"),
+    "propinv": (4, " lset nst=6 rates=propinv;\n prset pinvarpr=fixed(0.3) revmatpr=fixed(1,2,1,1,2,1) statefreqpr=fixed(0.3,0.2,0.2,0.3);\n"),
+    "lnorm": (4, " lset nst=2 rates=lnorm nlnormcat=5;\n prset tratiopr=fixed(2.5) statefreqpr=fixed(0.3,0.2,0.2,0.3);\n"),
+    "hky_invgamma": (4, " lset nst=2 rates=invgamma ngammacat=4;\n prset tratiopr=fixed(2.5) shapepr=fixed(0.6) pinvarpr=fixed(0.2) statefreqpr=fixed(0.3,0.2,0.2,0.3);\n"),
+    "jc": (4, " lset nst=1 rates=equal;\n prset statefreqpr=fixed(equal);\n"),
+}
+
+
+def _nucleotide_model(kind, beagle):
+    """More of SetLikeFunctions' menu on DNA data: single-omega and NY98 codon models (61 states, one / three eigen-systems), +I without
+    gamma, lognormal and invariable+gamma rate variation, HKY and JC closed-form matrices -- same harness, every parameter fixed."""
+    from mrbayes_amd import data as mbdata
+    nstates, model = _MODELS[kind]
+    tr, names = _tree()
+    if nstates == 61:
+        st = mbdata.synthetic_states(NT, 50, 61, 4, 0.15, 0.02)
+        seqs = ["".join(refrun._SENSE_CODONS[x] if x < 61 else "---" for x in row) for row in st]
+    else:
+        st = mbdata.synthetic_states(NT, 200, 4, 4, 0.15, 0.02)
+        seqs = ["".join("ACGT"[x] if x < 4 else "-" for x in row) for row in st]
+    s = "#NEXUS\nbegin data;\n dimensions ntax=%d nchar=%d;\n format datatype=dna gap=- missing=?;\n matrix\n" % (NT, len(seqs[0]))
+    for nm, r in zip(names, seqs):
+        s += "%s %s\n" % (nm, r)
+    s += ";\nend;\nbegin trees;\n tree t = [&U] %s\nend;\nbegin mrbayes;\n set autoclose=yes nowarnings=yes seed=3 swapseed=3 precision=15;\n" % tr.to_newick(names)
+    s += model
+    if beagle:
+        s += " set usebeagle=yes beagledevice=gpu beagleprecision=single beaglescaling=%s;\n" % beagle
+    return s + " startvals tau=t V=t;\n mcmc ngen=1 nchains=1 nruns=1 samplefreq=1 printfreq=1 filename=x;\nend;\n"
+
+
 CASES = {"restriction_all": lambda b: _restriction("all", b), "restriction_variable": lambda b: _restriction("variable", b),
          "restriction_noabsencesites": lambda b: _restriction("noabsencesites", b), "doublet": _doublet}
+for _k in _MODELS:
+    CASES[_k] = (lambda kind: (lambda b: _nucleotide_model(kind, b)))(_k)
 
 
 def _lnl(binary, text):
