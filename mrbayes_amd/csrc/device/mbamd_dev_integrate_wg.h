@@ -31,8 +31,47 @@ k_integrate_lnl_wg_wide(IntegrateArgs4 a, int S, int SP, int K, int P, int Ppad,
             const float* __restrict__ par = reinterpret_cast<const float*>(a.parent[n]) + pb;
             const double* __restrict__ fr = a.freqs[n];
             unsigned s = 0;
-            if (a.child[n] != nullptr && a.child_kind[n] == CHILD_STATES)
+            if (a.child[n] != nullptr && a.child_kind[n] == CHILD_STATES) {
+                // The form every unrooted evaluation ends with: the root tip as compact states.  S <= 64 on this layout: thread g of
+                // a pattern owns states g, g+8, ..., g+56.  Its loads for FOUR categories are issued together (as loops over the
+                // states and the categories these were up to 8 K dependent round trips: 17 us at 157 workgroups); the sums run in
+                // the order of the plain loops (the bits do not change).
                 s = reinterpret_cast<const uint8_t*>(a.child[n])[(size_t) tile * geo.tipTileBytes + pt];
+                double f[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) f[u] = (g + 8 * u < S) ? fr[g + 8 * u] : 0.0;
+                for (int k0 = 0; k0 < K; k0 += 4) {
+                    float v[4][8], pc[4][8];
+                    int e[4];
+                    double w[4];
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        if (k0 + q >= K) break;                       // (wave-uniform: a single category loads once, not four times)
+                        const int k = k0 + q;
+                        const float* __restrict__ pk = par + (size_t) k * kstride;
+                        const float* __restrict__ mrow = a.matrix[n] + (size_t) k * SP * SP + (size_t) (s < (unsigned) S ? s : 0) * SP;
+#pragma unroll
+                        for (int u = 0; u < 8; ++u) {
+                            const int i = g + 8 * u;
+                            const bool ok = i < S;
+                            v[q][u] = ok ? pk[wg_elem_sh(sh, ok ? i : 0, pt)] : 0.0f;
+                            pc[q][u] = (s >= (unsigned) S) ? 1.0f : (ok ? mrow[i] : 0.0f);
+                        }
+                        e[q] = a.cum[n] ? a.cum[n][(size_t) k * Ppad + c] : 0;
+                        w[q] = a.weights[n][k];
+                    }
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        if (k0 + q >= K) break;
+                        double cat = 0.0;
+#pragma unroll
+                        for (int u = 0; u < 8; ++u)
+                            if (g + 8 * u < S) cat += (double) (v[q][u] * pc[q][u]) * f[u];
+                        like += ldexp(cat * w[q], e[q] - emax);
+                    }
+                }
+                continue;
+            }
             for (int k = 0; k < K; ++k) {
                 const float* __restrict__ pk = par + (size_t) k * kstride;
                 double cat = 0.0;
@@ -48,12 +87,6 @@ k_integrate_lnl_wg_wide(IntegrateArgs4 a, int S, int SP, int K, int P, int Ppad,
                         }
 #pragma unroll
                         for (int u = 0; u < 8; ++u) cat += (double) v[u] * f[u];
-                    }
-                } else if (a.child_kind[n] == CHILD_STATES) {
-                    const float* __restrict__ mrow = a.matrix[n] + (size_t) k * SP * SP + (size_t) (s < (unsigned) S ? s : 0) * SP;
-                    for (int i = g; i < S; i += 8) {
-                        const float pc = (s >= (unsigned) S) ? 1.0f : mrow[i];
-                        cat += (double) (pk[wg_elem_sh(sh, i, pt)] * pc) * fr[i];
                     }
                 } else {
                     const float* __restrict__ ch = reinterpret_cast<const float*>(a.child[n]) + pb + (size_t) k * kstride;

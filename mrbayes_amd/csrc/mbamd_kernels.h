@@ -606,11 +606,16 @@ k_integrate_lnl_s4(IntegrateArgs4 a, int K, int P, int Ppad, BlockGeom g,
     const size_t pb = (size_t) blockIdx.x * g.pstride + threadIdx.x;           // f4 index of (block, category 0, lane)
     double wl = 0.0;
     if (c < P) {
+        // (the per-thread loads of up to eight categories -- the parent's values and the cumulative exponents -- are issued together:
+        //  as loops over k they were 2 K dependent round trips in a kernel that is nothing but latency; the sums keep their order)
         int emax = -2147483647;
         for (int n = 0; n < a.count; ++n)
-            for (int k = 0; k < K; ++k) {
-                const int e = a.cum[n] ? a.cum[n][(size_t) k * Ppad + c] : 0;
-                emax = e > emax ? e : emax;
+            for (int k0 = 0; k0 < K; k0 += 8) {
+                int e8[8];
+#pragma unroll
+                for (int q = 0; q < 8; ++q) e8[q] = (k0 + q < K && a.cum[n]) ? a.cum[n][(size_t) (k0 + q) * Ppad + c] : (k0 + q < K ? 0 : -2147483647);
+#pragma unroll
+                for (int q = 0; q < 8; ++q) emax = e8[q] > emax ? e8[q] : emax;
             }
         double total = 0.0;
         for (int n = 0; n < a.count; ++n) {
@@ -620,8 +625,21 @@ k_integrate_lnl_s4(IntegrateArgs4 a, int K, int P, int Ppad, BlockGeom g,
                 const uint64_t* planes = reinterpret_cast<const uint64_t*>(a.child[n]) + (size_t) blockIdx.x * g.tstride;
                 for (int i = 0; i < 4; ++i) mask |= (unsigned) (planes[i] >> threadIdx.x & 1u) << i;
             }
+            f4 p8[8];
+            int ec8[8];
             for (int k = 0; k < K; ++k) {
-                const f4 p = a.parent[n][pb + (size_t) k * 64];
+                if ((k & 7) == 0) {
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) {
+                        if (k + q >= K) break;
+                        p8[q] = a.parent[n][pb + (size_t) (k + q) * 64];
+                        ec8[q] = a.cum[n] ? a.cum[n][(size_t) (k + q) * Ppad + c] : 0;
+                    }
+                }
+                f4 p = p8[0];
+                int e = ec8[0];
+#pragma unroll
+                for (int q = 1; q < 8; ++q) if ((k & 7) == q) { p = p8[q]; e = ec8[q]; }
                 float f[4] = {1.0f, 1.0f, 1.0f, 1.0f};
                 if (a.child[n] != nullptr) {
                     const float* __restrict__ mT = a.matrix[n] + k * 16;                   // mT[j][i] = P(i->j)
@@ -637,7 +655,6 @@ k_integrate_lnl_s4(IntegrateArgs4 a, int K, int P, int Ppad, BlockGeom g,
                 }
                 const double cat = (double) (p.x * f[0]) * pi[0] + (double) (p.y * f[1]) * pi[1] + (double) (p.z * f[2]) * pi[2] +
                                    (double) (p.w * f[3]) * pi[3];
-                const int e = a.cum[n] ? a.cum[n][(size_t) k * Ppad + c] : 0;
                 total += ldexp(cat * a.weights[n][k], e - emax);
             }
         }
