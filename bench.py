@@ -384,6 +384,29 @@ def measure(args, cfg, steps, warmup, rank, local_rank, world, dist, device, emu
     return out
 
 
+def box_write_rate(device):
+    """What THIS box sustains for a plain write stream (torch fill_ of 2 GiB, HIP events): the boxes of the pool differ by tens of
+    per cent for HBM-bound kernels, and the tree walks are write streams.  GB/s, or None."""
+    import torch
+    try:
+        a = torch.empty(512 * 1024 * 1024, dtype=torch.float32, device=device)
+        for _ in range(3):
+            a.fill_(1.0)
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(10):
+            a.fill_(1.0)
+        e1.record()
+        torch.cuda.synchronize()
+        rate = 4.0 * a.numel() * 10 / (e0.elapsed_time(e1) * 1e-3) / 1e9
+        del a
+        torch.cuda.empty_cache()
+        return rate
+    except Exception:
+        return None
+
+
 def double_precision_line(cfg, steps, lib):
     """The same workload through the double-precision engine (BEAGLE_FLAG_PRECISION_DOUBLE, `set beagleprecision=double`): lnL
     against the reference's double build, wall time of replayed full-tree evaluations.  A report beside the fp32 line."""
@@ -565,6 +588,11 @@ def main():
         if rank == 0:
             out["pattern_sharded"] = ps
     if rank == 0 and world == 1 and not emulate:
+        fill = box_write_rate(device)
+        if fill:                                 # a box-normalised reading beside the fraction of the nominal 8 TB/s
+            for o in [out]:
+                o["roofline"]["box_write_stream_GBs"] = fill
+                o["roofline"]["hbm_frac_of_box_write_stream"] = o["roofline"]["hbm_GBs"] / fill
         if not args.no_also:
             out["also"] = []
             for other in ("c2", "c3", "c5", "c4"):
@@ -573,6 +601,9 @@ def main():
                 try:
                     out["also"].append(measure(args, other, max(args.steps, 200), args.warmup, 0, local_rank, 1, None, device,
                                                False, lib, not args.no_cpu_baseline))
+                    if fill:
+                        out["also"][-1]["roofline"]["box_write_stream_GBs"] = fill
+                        out["also"][-1]["roofline"]["hbm_frac_of_box_write_stream"] = out["also"][-1]["roofline"]["hbm_GBs"] / fill
                 except Exception as exc:
                     out["also"].append({"workload": other, "error": repr(exc)})
         if not args.no_also:
