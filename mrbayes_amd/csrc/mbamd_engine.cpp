@@ -555,14 +555,18 @@ int Instance::create(int tipCount_, int partialsBufferCount, int compactBufferCo
     scale.assign(std::max(nScale, 1), nullptr);
     valid.assign(nBuffers, 0);
     if (s4) {
-        // everything up front, like the reference's InitChainCondLikes (src/mcmc.c:5756-5834): one arena per
-        // kind, block-major so that a 64-pattern workgroup owns one contiguous slice of each
+        // everything up front, like the reference's InitChainCondLikes (src/mcmc.c:5756-5834): one arena per kind.  Partials
+        // are BUFFER-major, [buffer][block][K][64]: the waves of a launch run the same program at about the same pace, so at any
+        // moment they all write into one node's few MB -- a moving window like a fill -- instead of into a 1 KiB piece each of
+        // regions 12 MB apart (block-major, rounds 1-3: the same kernel ran C4 in 0.65 to 0.84 ms depending on the box; with the
+        // stores in one window 0.67 on a slow one, profiles/r03_exp_walk4_linear.txt).  Tips and exponents stay block-major.
         const size_t nb = (size_t) Ppad / 64;
-        geom.pstride = (unsigned long) nBuffers * K * 64;
+        if ((size_t) nBuffers * nb * K >= ((size_t) 1 << 32)) return fail(BEAGLE_ERROR_OUT_OF_MEMORY, "beagleCreateInstance: more than 4 TiB of partials");   // (program entries hold KiB offsets in 32 bits)
+        geom.pstride = (unsigned long) K * 64;
         geom.tstride = (unsigned) nBuffers * 4;
         geom.sstride = 64;
         estride = (unsigned) (scale.size() + 1) * K * 64;       // + one scratch buffer (sink of non-rescaling operations)
-        const size_t pBytes = nb * geom.pstride * 16, tBytes = nb * geom.tstride * 8, eBytes = nb * (size_t) estride;
+        const size_t pBytes = nb * (size_t) nBuffers * K * 64 * 16, tBytes = nb * geom.tstride * 8, eBytes = nb * (size_t) estride;
         HIP_TRY(hipMalloc(&arenaPartials, pBytes));
         HIP_TRY(hipMalloc(&arenaTips, tBytes));
         HIP_TRY(hipMalloc(&arenaExp, eBytes));
@@ -574,7 +578,7 @@ int Instance::create(int tipCount_, int partialsBufferCount, int compactBufferCo
         if (std::getenv("MBAMD_VERBOSE"))
             std::fprintf(stderr, "[mbamd] arenas: partials %p +%zu, tips %p +%zu, exponents %p +%zu\n",
                          (void*) arenaPartials, pBytes, (void*) arenaTips, tBytes, (void*) arenaExp, eBytes);
-        for (int i = 0; i < nBuffers; ++i) partials[i] = arenaPartials + (size_t) i * K * 64 * 4;
+        for (int i = 0; i < nBuffers; ++i) partials[i] = arenaPartials + (size_t) i * nb * K * 64 * 4;
     }
     if (wg) {
         // the same for the 20/61-state tree walk (mbamd_walkg.h): tile-major arenas, one extra partials buffer per tile as
@@ -1534,7 +1538,9 @@ int Instance::buildWalk(Plan& plan, const BeagleOperation* ops, int n, const int
         w4table.resize(sg.first + t.prog.size());
         // bytes per buffer inside a block / tile, bytes per LDS slot
         const uint32_t slotb = wg ? wg_block_bytes(S) : 1024u;
-        const uint32_t pbuf = (uint32_t) K * slotb, ebuf = (uint32_t) K * 64u, mbuf = wg ? (uint32_t) (matrixFloats * 4) : (uint32_t) K * 64u;
+        // a partials buffer inside a tile (20/61-state walk: bytes) / in the buffer-major 4-state arena (KiB: P_pad/64 x K of them)
+        const uint32_t pbuf = wg ? (uint32_t) K * slotb : (uint32_t) ((size_t) (Ppad / 64) * K);
+        const uint32_t ebuf = (uint32_t) K * 64u, mbuf = wg ? (uint32_t) (matrixFloats * 4) : (uint32_t) K * 64u;
         for (size_t i = 0; i < t.prog.size(); ++i) {
             const Walk4Template::Entry& te = t.prog[i];
             Walk4Entry& e = w4table[sg.first + i];

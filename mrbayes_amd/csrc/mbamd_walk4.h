@@ -113,6 +113,11 @@ __host__ __device__ inline unsigned walk4_round_wait(long n)
 }
 
 // byte-offset addressing helpers (wave-uniform base + 32-bit offset: two scalar adds)
+// (partials: the arena is BUFFER-major -- a buffer is P_pad/64 x K KiB, up to several MB -- and the entries hold its offset in KiB)
+template <class T> __device__ __forceinline__ T* walk4_at_kib(T* base, unsigned kib)
+{
+    return reinterpret_cast<T*>(reinterpret_cast<char*>(base) + ((size_t) kib << 10));
+}
 template <class T> __device__ __forceinline__ T* walk4_at(T* base, unsigned byteOffset)
 {
     return reinterpret_cast<T*>(reinterpret_cast<uintptr_t>(base) + byteOffset);
@@ -159,7 +164,7 @@ k_walk4_t(ARGS AA)
     int8_t* const E0 = A.exps + (size_t) blk * A.estride + (size_t) k * 64;
     const float* const M0 = A.matrices + (size_t) k * 16;
     const Walk4Lds L = walk4_lds(mine, lane);                                    // the same window for the LDS-DMA forms
-#define MBAMD_W4_PREFETCH(SRC, DST) walk4_prefetch(L, walk4_at(P0, SRC), (DST))
+#define MBAMD_W4_PREFETCH(SRC, DST) walk4_prefetch(L, walk4_at_kib(P0, SRC), (DST))
 #define MBAMD_W4_EXPS(OFF, PARITY) walk4_fetch_exps(L, walk4_at(E0, OFF), lane, (PARITY))
 
     const Walk4Entry* prog = walk4_program(AA) + (size_t) wave * A.entries;
@@ -247,7 +252,7 @@ k_walk4_t(ARGS AA)
             out.z = scale_pow2(out.z, -e); out.w = scale_pow2(out.w, -e);
             prev = out;
             if (ctl & MBAMD_W4_KEEP) *reinterpret_cast<f4*>(slots + ((ctl >> 6) & 0x3FC00u)) = out;
-            walk4_store(walk4_at(P0, dst), walk4_at(E0, ewrite), lane, out, e);
+            walk4_store(walk4_at_kib(P0, dst), walk4_at(E0, ewrite), lane, out, e);
         }
     };
     for (int j = 0; j < n; j += 2) {
