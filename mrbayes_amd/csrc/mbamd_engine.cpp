@@ -239,7 +239,7 @@ struct Instance {
     std::vector<uint8_t*> tipStates;   // non-null while the buffer holds compact tip states
     std::vector<int32_t*> scale;
     std::vector<char> valid;           // partials buffer has been written (import or operation destination)
-    // 4-state path: pattern-block-major arenas (see mbamd_kernels.h), one allocation each
+    // 4-state path: arenas (see mbamd_kernels.h: partials buffer-major, tips and exponents block-major), one allocation each
     float* arenaPartials = nullptr;
     uint64_t* arenaTips = nullptr;     // state bitplanes uint64 [block][buffer][4]
     BlockGeom geom{64, 64, 64};        // general path: linear [P_pad] arrays == block stride 64

@@ -8,10 +8,11 @@
 //   k_scale_*            Copy/Reset/RemoveNodeScalers bookkeeping (src/likelihood.c:7981-8131)
 //
 // Data layout in HBM (all fp32 unless noted), P_pad = patterns rounded up to 64:
-//   4-state partials   : f4 [P_pad/64][buffer][K][64]  pattern-block-major arena: one f4 = the 4 states of
-//                        (category, pattern); everything the waves of a 64-pattern block ever touch (all nodes of
-//                        all chains) is one contiguous region -> a few 2 MiB pages per block (TLB), 1 KiB
-//                        contiguous per (node update, category).  4-state tips are four 64-bit STATE BITPLANES per
+//   4-state partials   : f4 [buffer][P_pad/64][K][64]  buffer-major arena: one f4 = the 4 states of (category, pattern);
+//                        1 KiB contiguous per (node update, block, category).  The waves of a launch run one program at one
+//                        pace: at any moment they write into one node's few MB -- a moving window like a fill (block-major
+//                        until round 3: 1 KiB pieces into regions 12 MB apart, and a box-dependent kernel time; see
+//                        profiles/r03_exp_walk4_linear.txt).  4-state tips are four 64-bit STATE BITPLANES per
 //                        (pattern block, tip): uint64 [P_pad/64][buffer][4], plane i bit l = state i compatible with
 //                        pattern l of the block (missing = all four); 4-state node exponents are int8
 //                        [P_pad/64][scale buffer][K][64] (one per pattern AND category), cumulative exponents
