@@ -113,6 +113,34 @@ static inline bool wg_compiled(int S) { return S == 2 || S == 8 || S == 16 || S 
         default: FN<63, 4, 2, MBAMD_WG_DEPTH61>(__VA_ARGS__); break;    \
     }
 
+// k_walkg_s (tables staged in LDS, shared by the G waves of a workgroup): the state counts it is instantiated for, table chunks
+// per job, and how many chunks the LDS-DMA stream runs ahead
+static inline bool wgs_compiled(int S) { return S == 20 || (S >= 60 && S <= 63); }
+static inline int wgs_chunks(int S) { return S > 40 ? 2 : 1; }
+#if !defined(MBAMD_WGS_D)
+#define MBAMD_WGS_D 2
+#endif
+#define MBAMD_WGS_DISPATCH_G(SC, CH, G, FN, ...)                        \
+    do {                                                                \
+        if ((G) == 4) FN<SC, 4, CH, MBAMD_WGS_D>(__VA_ARGS__);          \
+        else FN<SC, 2, CH, MBAMD_WGS_D>(__VA_ARGS__);                   \
+    } while (0)
+#define MBAMD_WGS_DISPATCH(S, G, FN, ...)                               \
+    switch (S) {                                                        \
+        case 20: MBAMD_WGS_DISPATCH_G(20, 1, G, FN, __VA_ARGS__); break; \
+        case 60: MBAMD_WGS_DISPATCH_G(60, 2, G, FN, __VA_ARGS__); break; \
+        case 61: MBAMD_WGS_DISPATCH_G(61, 2, G, FN, __VA_ARGS__); break; \
+        case 62: MBAMD_WGS_DISPATCH_G(62, 2, G, FN, __VA_ARGS__); break; \
+        default: MBAMD_WGS_DISPATCH_G(63, 2, G, FN, __VA_ARGS__); break; \
+    }
+template <int SC_, int G_, int CH_, int D_>
+static void raise_walkgs_lds(int maxLds)
+{
+    if (hipFuncSetAttribute((const void*) k_walkg_s<SC_, G_, CH_, D_>, hipFuncAttributeMaxDynamicSharedMemorySize, maxLds) != hipSuccess ||
+        hipFuncSetAttribute((const void*) k_walkg_s<SC_, G_, CH_, D_, WalkGSArgsInline>, hipFuncAttributeMaxDynamicSharedMemorySize, maxLds) != hipSuccess)
+        (void) hipGetLastError();
+}
+
 template <int SC_, int WMAX_, int CH_, int DEPTH_>
 static void raise_walkg_lds(int maxLds)
 {
@@ -133,7 +161,12 @@ struct Plan {
     uint64_t lastLaunch = 0;         // Instance::launchClock value of the latest launch that reads d_table
     PartialsOp* d_table = nullptr;
     size_t cap = 0;                  // bytes allocated for d_table
-    struct Segment { size_t first; int W, entries, nslots, tail = 2, tipAhead = 0; };   // tree-walk path: one launch per hazard-free segment
+    struct Segment {                             // tree-walk path: one launch per hazard-free segment
+        size_t first; int W, entries, nslots, tail = 2, tipAhead = 0;
+        // k_walkg_s: the phases of the segment are launches, the W programs the subtree bins of a launch's grid
+        int phases = 1;
+        std::vector<unsigned> ranges;            // [phase][W]: first entry << 16 | entries of that part of program w (0: nothing)
+    };
     std::vector<Segment> segments;               // (Walk4Entry index of its program in d_table, geometry)
     std::vector<Walk4Entry> inlineProg;          // 4-state walk: a short single-segment program travels in the kernel arguments instead
     int lists = 1;                               // 20/61-state walk: > 1 = the segments are that many independent lists, ONE launch
@@ -220,6 +253,10 @@ struct Instance {
     unsigned long wgTileBytes = 0;               // partials arena: bytes between 32-pattern tiles
     unsigned wgTipTileBytes = 0;
     size_t wgTabFloats = 0;                      // first float of the tree-walk tables inside a matrix buffer
+    bool wgs = false;                            // the tables are staged in LDS and shared by the waves of a workgroup (k_walkg_s)
+    int wgsG = 4;                                // waves (adjacent tiles) per workgroup
+    void wgsGeometry(int lists, int& W, int& slots) const;
+    int runWalkGS(const Plan& plan);
     bool hasPending() const { return !pending.empty() || !wgListCum.empty(); }
     int updatePartialsG(const BeagleOperation* ops, int n, int cumIdx);
     int flushWalkG();
@@ -514,6 +551,14 @@ int Instance::create(int tipCount_, int partialsBufferCount, int compactBufferCo
              (size_t) (nBuffers + 1) * K * tb < ((size_t) 1 << 32) && (size_t) nMatrices * mf * 4 < ((size_t) 1 << 32) &&
              (size_t) (nScale + 1) * K * 64 < ((size_t) 1 << 32) && (size_t) nBuffers * MBAMD_WG_TW < ((size_t) 1 << 32);
     }
+    // k_walkg_s: G waves on G adjacent tiles share a workgroup (and the transition tables in its LDS); the pattern count is
+    // padded to whole groups of four tiles (pad patterns: weight 0, missing data -- like every pad pattern)
+    wgs = wg && wgs_compiled(S) && !(std::getenv("MBAMD_WALKG_SHARED") && std::atoi(std::getenv("MBAMD_WALKG_SHARED")) == 0);
+    if (wgs) {
+        wgsG = S > 32 ? 4 : 2;
+        if (const char* e = std::getenv("MBAMD_WALKG_G")) wgsG = std::atoi(e) >= 4 ? 4 : 2;
+        Ppad = round_up(P, MBAMD_WG_TW * 4);
+    }
     if (s4) SP = 4;
     else if (S <= 4) SP = 4;
     else if (S <= 8) SP = 8;
@@ -684,6 +729,19 @@ int Instance::configureWalk()
         // one wave = (32-pattern tile, category); registers bound the residency: 20 states 4 waves per SIMD, 61 states 2
         const unsigned slotBytes = wg_block_bytes(S);
         MBAMD_WG_DISPATCH(S, raise_walkg_lds, maxLds);
+        if (wgs) {
+            MBAMD_WGS_DISPATCH(S, wgsG, raise_walkgs_lds, maxLds);
+            wgsGeometry(1, w4.maxW, w4.maxSlots);
+            w4.maxSlots1 = w4.maxSlots;
+            w4.memSlots = false;
+            w4.phasesAreLaunches = true;         // bins are workgroups, phases launches: nothing stays in LDS across a phase
+            w4.leadNops = 0; w4.unroll = 1; w4.tailNops = MBAMD_WG_TAIL;
+            w4.prefetchDistance = 0;
+            if (const char* e = std::getenv("MBAMD_WALK_SMALL_PHASE")) w4.smallPhase = std::max(1, std::atoi(e));
+            if (envVerbose) std::fprintf(stderr, "[mbamd] tree walk (%d states, tables in LDS): %d waves per workgroup, up to %d bins x %d slots of %u bytes\n",
+                                         S, wgsG, w4.maxW, w4.maxSlots, slotBytes);
+            return BEAGLE_SUCCESS;
+        }
         wgGeometry(1, w4.maxW, w4.maxSlots);
         w4.maxSlots1 = w4.maxSlots;
         if (!std::getenv("MBAMD_WALK_WAVES") && !std::getenv("MBAMD_MAX_LDS_SLOTS")) {   // a single-wave program may use the LDS of the whole workgroup
@@ -752,6 +810,28 @@ void Instance::wgGeometry(int lists, int& W, int& slots) const
     if (const char* e = std::getenv("MBAMD_WALK_WAVES")) W = std::max(1, std::min(maxW, std::atoi(e)));
     slots = std::max(3, std::min(24, slotsFor(W)));
     if (const char* e = std::getenv("MBAMD_MAX_LDS_SLOTS")) slots = std::max(3, std::min((160 * 1024 / W - MBAMD_WG_STAGE) / slotBytes, std::atoi(e)));
+}
+
+// k_walkg_s: subtree bins (workgroups of a launch's grid per tile group, category and list) and LDS slots per wave.  A workgroup
+// holds the ring of table chunks and G waves' landing areas and slots; as many workgroups per CU as the grid needs must fit.
+void Instance::wgsGeometry(int lists, int& W, int& slots) const
+{
+    int numCU = 256;
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0) numCU = prop.multiProcessorCount;
+    const int G = wgsG, wavesPerCU = S > 32 ? 4 : 12;
+    const long slotBytes = (long) wg_block_bytes(S);
+    const long fixed = (long) (MBAMD_WGS_D + 1) * (long) wgs_chunk_bytes(S, wgs_chunks(S)) + (long) G * MBAMD_WGS_STAGE;
+    const long groups = (long) (Ppad / MBAMD_WG_TW / G) * K * lists;           // workgroups per bin
+    auto slotsFor = [&](int w) {
+        const long perCU = std::max(1L, (groups * w + numCU - 1) / numCU);
+        return (int) (((160L * 1024) / std::min(perCU, 32L / G) - 64 - fixed) / ((long) G * slotBytes));
+    };
+    W = (int) std::max(1L, std::min((long) MBAMD_WGS_MAXBINS, ((long) wavesPerCU * numCU + groups * G / 2) / (groups * G)));
+    while (W > 1 && slotsFor(W) < 4) --W;
+    if (const char* e = std::getenv("MBAMD_WALK_WAVES")) W = std::max(1, std::min(MBAMD_WGS_MAXBINS, std::atoi(e)));
+    slots = std::max(3, std::min(24, slotsFor(W)));
+    if (const char* e = std::getenv("MBAMD_MAX_LDS_SLOTS")) slots = std::max(3, std::min((int) ((160L * 1024 - 64 - fixed) / ((long) G * slotBytes)), std::atoi(e)));
 }
 
 // 4-state path: one tip's state masks (bit i = state i compatible) -> four 64-bit bitplanes per pattern block
@@ -1534,6 +1614,22 @@ int Instance::buildWalk(Plan& plan, const BeagleOperation* ops, int n, const int
         Plan::Segment sg;
         sg.first = w4table.size();
         sg.W = t.W; sg.entries = t.entries; sg.nslots = t.nslots; sg.tail = t.tail; sg.tipAhead = t.tipAhead;
+        if (wgs) {
+            // k_walkg_s: program w's part of phase p = the entries between its p-th and (p+1)-th barrier entry (trailing NOPs dropped)
+            if (t.W > MBAMD_WGS_MAXBINS || t.entries > 0xFFFF) return fail(BEAGLE_ERROR_GENERAL, "tree-walk scheduler: program too long for the shared-table kernel");
+            sg.phases = t.phases;
+            sg.ranges.assign((size_t) t.phases * t.W, 0u);
+            for (int w = 0; w < t.W; ++w) {
+                int ph = 0, first = 0;
+                auto close = [&](int end) {
+                    while (end > first && (t.prog[(size_t) w * t.entries + end - 1].flags & MBAMD_W4_NOP)) --end;
+                    if (ph < t.phases && end > first) sg.ranges[(size_t) ph * t.W + w] = ((unsigned) first << 16) | (unsigned) (end - first);
+                };
+                for (int j = 0; j < t.entries; ++j)
+                    if (t.prog[(size_t) w * t.entries + j].flags & MBAMD_W4_BARRIER) { close(j); ++ph; first = j + 1; }
+                close(t.entries);
+            }
+        }
         plan.segments.push_back(sg);
         w4table.resize(sg.first + t.prog.size());
         // bytes per buffer inside a block / tile, bytes per LDS slot
@@ -1900,7 +1996,8 @@ int Instance::flushWalkG()
             bool done = false;
             if (independent) {
                 const int keepW = w4.maxW, keepS = w4.maxSlots, keepS1 = w4.maxSlots1;
-                wgGeometry(nl, w4.maxW, w4.maxSlots);
+                if (wgs) wgsGeometry(nl, w4.maxW, w4.maxSlots);
+                else wgGeometry(nl, w4.maxW, w4.maxSlots);
                 w4.maxSlots1 = w4.maxSlots;
                 rc = buildWalk(*plan, ops.data(), n, listOf.data(), true);
                 w4.maxW = keepW; w4.maxSlots = keepS; w4.maxSlots1 = keepS1;
@@ -1945,8 +2042,82 @@ static void launch_walkg_t(Instance& in, const WalkGArgs& a, int W, int nslots, 
     MBAMD_LAUNCH_BARRIER(kern, walkg_grid(in.Ppad / MBAMD_WG_TW, in.K * a.lists), 64 * W * (a.spread ? 2 : 1), wg_lds_bytes(W, nslots, in.S), in.stream, a);
 }
 
+template <int SC_, int G_, int CH_, int D_>
+static void launch_walkgs_t(Instance& in, const WalkGSArgs& a, int nslots, const std::vector<Walk4Entry>* inlineProg)
+{
+    const unsigned grid = walkgs_grid(in.Ppad / MBAMD_WG_TW / G_, in.K * a.a.lists * a.bins);
+    const size_t lds = wgs_lds_bytes(G_, nslots, in.S, CH_, D_ + 1);
+    if (inlineProg && !inlineProg->empty()) {
+        WalkGSArgsInline ai;
+        ai.s = a;
+        ai.s.a.prog = nullptr;
+        std::memcpy(ai.inl, inlineProg->data(), inlineProg->size() * sizeof(Walk4Entry));
+        auto kern = k_walkg_s<SC_, G_, CH_, D_, WalkGSArgsInline>;
+        MBAMD_LAUNCH(kern, grid, 64 * G_, lds, in.stream, ai);
+        return;
+    }
+    auto kern = k_walkg_s<SC_, G_, CH_, D_>;
+    MBAMD_LAUNCH(kern, grid, 64 * G_, lds, in.stream, a);
+}
+
+// k_walkg_s: one launch per phase; the grid holds every (tile group, category, list, subtree bin)
+int Instance::runWalkGS(const Plan& plan)
+{
+    const size_t nseg = plan.segments.size();
+    for (size_t si = 0; si < nseg; si += (plan.lists > 1 ? nseg : 1)) {          // (independent lists: the segments are the lists of ONE launch series)
+        const Plan::Segment& sg = plan.segments[si];
+        int phases = sg.phases;
+        if (plan.lists > 1) for (const Plan::Segment& o : plan.segments) phases = std::max(phases, o.phases);
+        const bool shared = sg.W > 1 || phases > 1;           // several workgroups / launches add to the same cumulative entries
+        int fresh = (si == 0) ? wgFresh : 0;
+        if (shared && fresh) {
+            for (int q = 0; q < MBAMD_WG_MAXLISTS; ++q)
+                if ((fresh >> q & 1) && wgCum[q]) HIP_TRY(hipMemsetAsync(wgCum[q], 0, (size_t) K * Ppad * sizeof(int32_t), stream));
+            fresh = 0;
+        }
+        for (int ph = 0; ph < phases; ++ph) {
+            WalkGSArgs s;
+            std::memset(&s, 0, sizeof s);
+            WalkGArgs& a = s.a;
+            a.prog = reinterpret_cast<const Walk4Entry*>(plan.d_table) + sg.first;
+            a.entries = sg.entries;
+            a.nslots = sg.nslots;
+            a.partials = arenaPartials;
+            a.tileBytes = wgTileBytes;
+            a.tips = arenaTipStates;
+            a.tipTileBytes = wgTipTileBytes;
+            a.exps = arenaExp;
+            a.estride = estride;
+            a.matrices = matrices;
+            a.tabOff = (unsigned) (wgTabFloats * 4);
+            a.tabBytes = (unsigned) (wg_table_floats(S) * 4);
+            for (int q = 0; q < MBAMD_WG_MAXLISTS; ++q) a.cum[q] = wgCum[q];
+            a.cumFresh = fresh;
+            a.K = K; a.Ppad = Ppad; a.ntiles = Ppad / MBAMD_WG_TW; a.S = S; a.SP = SP;
+            a.lists = plan.lists;
+            s.bins = sg.W;
+            s.progW = sg.W;
+            s.atomicCum = shared ? 1 : 0;
+            bool any = false;
+            for (int q = 0; q < plan.lists; ++q) {
+                const Plan::Segment& lq = plan.lists > 1 ? plan.segments[(size_t) q] : sg;
+                if (ph >= lq.phases) continue;
+                for (int w = 0; w < lq.W; ++w) { s.range[q][w] = lq.ranges[(size_t) ph * lq.W + w]; any |= s.range[q][w] != 0; }
+            }
+            if (!any) continue;
+            if (ph > 0) fresh = 0;
+            MBAMD_WGS_DISPATCH(S, wgsG, launch_walkgs_t, *this, s, sg.nslots, &plan.inlineProg);
+            HIP_TRY(hipGetLastError());
+            pendingLaunches += 1;
+            fresh = 0;
+        }
+    }
+    return BEAGLE_SUCCESS;
+}
+
 int Instance::runWalkG(const Plan& plan)
 {
+    if (wgs) return runWalkGS(plan);
     for (const Plan::Segment& sg : plan.segments) {
         if (plan.lists > 1 && &sg != &plan.segments.front()) break;     // (independent lists: one launch covers all segments)
         WalkGArgs a;

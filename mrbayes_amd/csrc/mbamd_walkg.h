@@ -167,9 +167,40 @@ struct WalkGArgsInline {
 __device__ __forceinline__ const WalkGArgs& wg_args(const WalkGArgs& a) { return a; }
 __device__ __forceinline__ const WalkGArgs& wg_args(const WalkGArgsInline& a) { return a.a; }
 __device__ __forceinline__ const Walk4Entry* wg_program(const WalkGArgs& a) { return a.prog; }
+
+// ---- k_walkg_s: the same walk with the transition tables STAGED IN LDS and shared by the waves of a workgroup --------------
+// (BASELINE north_star: "LDS-staged Ti-prob tiles").  k_walkg's waves each fetch the whole A' table of every child from L2
+// (codon M3 100 x 5 000: 3 GB through L2 per evaluation for 0.6 GB of HBM traffic -- the measured bound, profiles/r03_c5_pmc.txt).
+// Here a workgroup is G waves on G ADJACENT TILES of one (category, list, subtree bin): they interpret the SAME program, so
+// every child's table is needed by all of them at the same time -- one cooperative LDS-DMA stream (global_load_lds) brings it
+// into a ring of NB = D + 1 chunk buffers, D chunks ahead of the MFMA chain that reads it with ds_read; a compact tip takes its
+// factor from the same staged table (a gather of ITS column: no second set of gather tables, no L2 traffic at all).  The waves
+// meet at one s_barrier per chunk.  The subtree bins of the tree-parallel schedule are separate WORKGROUPS (they run
+// different programs: in one workgroup their barriers would make every chunk as slow as its slowest bin), and the dependent
+// phases separate LAUNCHES (Walk4Builder::phasesAreLaunches; a dependent-kernel boundary is 1.5-2 us).
+#define MBAMD_WGS_MAXBINS 8
+#define MBAMD_WGS_STAGE   1536   // bytes per wave in front of its slots: [2 entry parities][exponents | tip states 1 | tip states 2][64 dwords]
+struct WalkGSArgs {
+    WalkGArgs a;                 // prog = [list][progW][a.entries]; a.lists independent lists
+    unsigned range[MBAMD_WG_MAXLISTS][MBAMD_WGS_MAXBINS];   // this launch's part of program (list, bin): first entry << 16 | entries (0: nothing)
+    int bins;                    // subtree bins in this launch's grid
+    int progW;                   // programs per list in `prog`
+    int atomicCum;               // several workgroups (bins) add to the same cumulative exponents: atomic adds into a zeroed / running buffer
+};
+struct WalkGSArgsInline {
+    WalkGSArgs s;
+    Walk4Entry inl[MBAMD_W4_INLINE];
+};
+__host__ __device__ inline unsigned walkgs_grid(int ngroups, int KLB) { return 8u * (unsigned) KLB * (unsigned) ((ngroups + 7) / 8); }   // KLB = categories x lists x bins
+__host__ __device__ inline size_t wgs_chunk_bytes(int S, int CH) { return (size_t) (wg_rows(S) / CH) * 256; }
+__host__ __device__ inline size_t wgs_lds_bytes(int G, int nslots, int S, int CH, int NB)
+{
+    return (size_t) NB * wgs_chunk_bytes(S, CH) + (size_t) G * (MBAMD_WGS_STAGE + (size_t) nslots * wg_block_bytes(S));
+}
+__device__ __forceinline__ const WalkGSArgs& wgs_args(const WalkGSArgs& a) { return a; }
+__device__ __forceinline__ const WalkGSArgs& wgs_args(const WalkGSArgsInline& a) { return a.s; }
+__device__ __forceinline__ const Walk4Entry* wgs_program(const WalkGSArgs& a) { return a.a.prog; }
 }  // namespace mbamd
 #include <mbamd_dev_walkg_kernel.h>   // wg_program(const WalkGArgsInline&) and k_walkg itself (csrc/device/: the MFMA kernel)
-namespace mbamd {
-
-}  // namespace mbamd
+#include <mbamd_dev_walkgs_kernel.h>  // k_walkg_s
 #endif
