@@ -24,14 +24,6 @@ __device__ __forceinline__ Walk4Entry walk4_load_entry(const Walk4Entry* p)
     e.ctl = v[0]; e.dst = v[1]; e.c1 = v[2]; e.c2 = v[3]; e.m1 = v[4]; e.m2 = v[5]; e.ewrite = v[6]; e.eread = v[7];
     return e;
 }
-__device__ __forceinline__ Walk4Half walk4_load_half(const Walk4Entry* p)
-{
-    typedef unsigned u4v __attribute__((ext_vector_type(4)));
-    const u4v v = *reinterpret_cast<const MBAMD_AS_CONST u4v*>((uintptr_t) p);
-    Walk4Half h;
-    h.ctl = v[0]; h.dst = v[1]; h.c1 = v[2]; h.c2 = v[3];
-    return h;
-}
 __device__ __forceinline__ Walk4Planes walk4_load_planes(const uint64_t* p)
 {
     const ul4v v = *reinterpret_cast<const MBAMD_AS_CONST ul4v*>((uintptr_t) p);
@@ -65,15 +57,6 @@ __device__ __forceinline__ void walk4_dma_exps(const int8_t* base, unsigned lane
     unsigned keep;
     asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_sbyte %1, %2\n\ts_mov_b32 m0, %0"
                  : "=&s"(keep) : "v"(lane), "s"(base), "s"(lds_dst) : "memory");
-}
-// Pull the 64-byte lines that hold two sets of tip bitplanes into this XCD's L2 ahead of the scalar loads that will want
-// them: every lane asks for the same dword (one request), the LDS-DMA form has no destination register to keep alive, and
-// what lands (256 bytes at lds_dst, twice) is never read.  Two vector-memory instructions, counted by the host like the others.
-__device__ __forceinline__ void walk4_touch_planes(const uint64_t* p1, const uint64_t* p2, unsigned zero, unsigned lds_dst)
-{
-    unsigned keep;
-    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %4\n\ts_nop 0\n\tglobal_load_lds_dword %1, %2\n\tglobal_load_lds_dword %1, %3\n\ts_mov_b32 m0, %0"
-                 : "=&s"(keep) : "v"(zero), "s"(p1), "s"(p2), "s"(lds_dst) : "memory");
 }
 // wait until at most n vector-memory instructions of this wave are outstanding (s_waitcnt takes an immediate: the
 // host rounds n down to one of these values; only entries that read a prefetched child come here)
@@ -115,30 +98,26 @@ __device__ __forceinline__ f4 walk4_matvec(const Walk4Mat& M, f4 v)
 
 
 // this wave's LDS window as the LDS-DMA forms want it: byte addresses in the LDS address space
-struct Walk4Lds { unsigned lane16, stage_lds, slots_lds, vzero; };
+struct Walk4Lds { unsigned lane16, stage_lds, slots_lds; };
 __device__ __forceinline__ Walk4Lds walk4_lds(char* mine, unsigned lane)
 {
     Walk4Lds L;
     L.lane16 = lane * 16u;
     L.stage_lds = (unsigned) (uintptr_t) (__attribute__((address_space(3))) char*) mine;
     L.slots_lds = L.stage_lds + MBAMD_W4_STAGE;
-    asm volatile("v_mov_b32 %0, 0" : "=v"(L.vzero));
     return L;
 }
 // a child that lives in HBM -> the slot at byte offset dst of this wave's slots
 __device__ __forceinline__ void walk4_prefetch(const Walk4Lds& L, const f4* src, unsigned dst) { walk4_dma(src, L.lane16, L.slots_lds + dst); }
 // stored exponents of the next entry -> landing area `parity`
 __device__ __forceinline__ void walk4_fetch_exps(const Walk4Lds& L, const int8_t* src, unsigned lane, int parity) { walk4_dma_exps(src, lane, L.stage_lds + 256u * (unsigned) parity); }
-__device__ __forceinline__ void walk4_touch(const Walk4Lds& L, const uint64_t* p1, const uint64_t* p2) { walk4_touch_planes(p1, p2, L.vzero, L.stage_lds + 512u); }
 // 1 KiB contiguous per wave; never waited for.  Non-temporal: the result is not read again in this launch (parents read the
 // LDS copy or the register), so it must not push the matrices and programs out of L2
 __device__ __forceinline__ void walk4_store(f4* P, int8_t* E, unsigned lane, f4 out, int e)
 {
-#if defined(MBAMD_W4X_NOSTORE)   // (timing experiments)
-    if (e != 12345) return;
-#endif
     __builtin_nontemporal_store(out, as_global(P) + lane);
-    __builtin_nontemporal_store((int8_t) e, as_global(E) + lane);
+    // (the byte store in the scalar-base + 32-bit lane offset form: the compiler builds a 64-bit address per lane instead)
+    asm volatile("global_store_byte %0, %1, %2 nt" :: "v"(lane), "v"(e), "s"(E) : "memory");
 }
 }  // namespace mbamd
 #endif

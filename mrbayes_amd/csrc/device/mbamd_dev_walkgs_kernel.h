@@ -35,7 +35,17 @@ template <int PIECE, int G> struct WgsDmaPlan {
     static constexpr int N16 = PIECE / 1024, N4 = (PIECE % 1024) / 256, U = N16 + N4, PER = (U + G - 1) / G;
     static_assert(PIECE % 256 == 0 && U >= 1, "table chunks are whole 256-byte rows");
 };
-template <int PIECE, int G>
+// In LDS the 16-byte units of row group i (RG bytes: VA table rows of 64 columns) are ROTATED by i units: the MFMA operand
+// reads stay one contiguous unit per lane, and the lanes of a tip's gather -- each wants ITS column of a row that depends on
+// its pattern's state -- spread over the banks instead of meeting on the few the column index alone selects (unrotated:
+// 16-way conflicts, a tip chunk took as long as an interior chunk's 32 MFMAs; profiles/r04_walkgs_trace.txt).  The rotation is
+// free: an LDS-DMA lands lane-linearly, its SOURCE address is per lane.
+template <int RG> __device__ __forceinline__ unsigned wgs_rot(unsigned d, int sign)        // piece-relative byte d -> rotated by +-16 i inside its row group
+{
+    const unsigned i = d / RG;
+    return i * RG + ((d % RG + (unsigned) sign * 16u * i) & (unsigned) (RG - 1));
+}
+template <int PIECE, int G, int RG>
 __device__ __forceinline__ void wgs_dma_piece(const char* src, unsigned lds_dst, int wave, unsigned lane)
 {
     typedef WgsDmaPlan<PIECE, G> Pl;
@@ -43,12 +53,21 @@ __device__ __forceinline__ void wgs_dma_piece(const char* src, unsigned lds_dst,
     for (int i = 0; i < Pl::PER; ++i) {
         int u = wave + i * G;
         if ((i + 1) * G > Pl::U) u = u < Pl::U ? u : u % Pl::U;
-        if (Pl::N4 == 0 || u < Pl::N16)
-            walk4_dma(reinterpret_cast<const f4*>(src + (size_t) u * 1024), lane * 16u, lds_dst + (unsigned) u * 1024u);
-        else
-            wgs_dma4(src + (size_t) Pl::N16 * 1024 + (size_t) (u - Pl::N16) * 256, lane * 4u, lds_dst + (unsigned) Pl::N16 * 1024u + (unsigned) (u - Pl::N16) * 256u);
+        if (Pl::N4 == 0 || u < Pl::N16) {
+            const unsigned d = (unsigned) u * 1024u;
+            walk4_dma(reinterpret_cast<const f4*>(src), wgs_rot<RG>(d + lane * 16u, -1), lds_dst + d);
+        } else {
+            const unsigned d = (unsigned) Pl::N16 * 1024u + (unsigned) (u - Pl::N16) * 256u;
+            wgs_dma4(src, wgs_rot<RG>(d + lane * 4u, -1), lds_dst + d);
+        }
     }
 }
+// timing experiments only (tools/build_variants.py ...=MBAMD_WGS_TRACE): clock stamps of wave 0 of one workgroup, [chunk][8 points]
+#if defined(MBAMD_WGS_TRACE)
+#define MBAMD_WGS_STAMP(P) do { if (tracing) A.trace[((size_t) j * NQ + q) * 8 + (P)] = (long long) __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define MBAMD_WGS_STAMP(P) do { } while (0)
+#endif
 template <int N> __device__ __forceinline__ void wgs_wait_vm()
 {
     static_assert(N >= 0 && N < 64, "vmcnt is a 6-bit counter");
@@ -75,6 +94,7 @@ k_walkg_s(ARGS AA)
     constexpr int TPC = TP / CH, NAVC = NAV / CH, TVC = TV / CH;      // per chunk: MFMA steps, A register groups, B register groups
     constexpr int NQ = 2 * CH, NB = D + 1;
     constexpr int PIECE = NAVC * VA * 256;                            // bytes of a table chunk
+    constexpr int RG = VA * 256;                                      // bytes of a row group of the table (VA rows x 64 columns)
     constexpr int NDMA = WgsDmaPlan<PIECE, G>::PER;                   // LDS-DMA instructions per wave and chunk
     constexpr int NSTORE = TV + 1;                                    // result stores + the exponent store of an entry
     static_assert(TP % CH == 0 && TPC % V == 0 && NAV % CH == 0 && (TPC * NT) % VA == 0 && D >= 1 && D <= 2 && D <= NQ, "chunk geometry");
@@ -105,6 +125,9 @@ k_walkg_s(ARGS AA)
     const char* const Mk = reinterpret_cast<const char*>(A.matrices) + A.tabOff + (size_t) k * A.tabBytes;
     const Walk4Entry* prog = wgs_program(AA) + ((size_t) list * AS.progW + bin) * A.entries + (rg >> 16);
 
+#if defined(MBAMD_WGS_TRACE)
+    const bool tracing = A.trace != nullptr && blockIdx.x == 8 && wave == 0 && lane == 0 && len < 1000;
+#endif
     Walk4Entry cur = walk4_load_entry(prog), n1 = walk4_load_entry(prog + 1);
     int cum_e[MBAMD_WG_MAXLISTS] = {0, 0, 0, 0};
     // B rows of a chunk whose child lives in HBM (an earlier launch's result, an evicted value): loaded one chunk ahead into the
@@ -113,6 +136,11 @@ k_walkg_s(ARGS AA)
     vec bm0[TVC], bm1[TVC];
 #pragma unroll
     for (int i = 0; i < TVC; ++i) bm0[i] = bm1[i] = Vb::splat(0.0f);
+
+    // byte offset of this lane's unit of row group i inside a staged piece (rotated, see wgs_rot)
+    unsigned aoff[NAVC];
+#pragma unroll
+    for (int i = 0; i < NAVC; ++i) aoff[i] = wgs_rot<RG>((unsigned) i * RG + lane * (unsigned) (VA * 4), +1);
 
     // stored exponents and tip states of entry e: one byte per lane -> a dword per lane in the landing area of `parity`
     auto tiny = [&](const Walk4Entry& e, unsigned parity) {
@@ -123,7 +151,10 @@ k_walkg_s(ARGS AA)
     };
     // this wave's share of the table piece of chunk q (child q / CH, part q % CH) of entry e -> ring buffer rs
     auto table = [&](const Walk4Entry& e, int q, int rs) {
-        wgs_dma_piece<PIECE, G>(Mk + ((q / CH) ? e.m2 : e.m1) + (size_t) (q % CH) * PIECE, ringLds + (unsigned) rs * PIECE, wave, lane);
+#if defined(MBAMD_WGSX_NODMA)
+        return;
+#endif
+        wgs_dma_piece<PIECE, G, RG>(Mk + ((q / CH) ? e.m2 : e.m1) + (size_t) (q % CH) * PIECE, ringLds + (unsigned) rs * PIECE, wave, lane);
     };
     // B rows of chunk q of entry e, if that child lives in HBM
     auto memrows = [&](const Walk4Entry& e, int q, vec (&bm)[TVC]) {
@@ -158,6 +189,17 @@ k_walkg_s(ARGS AA)
             constexpr int q = decltype(qc)::value;
             if constexpr (q < NQ) {
                 constexpr int ch = q / CH, h = q % CH;
+                MBAMD_WGS_STAMP(0);
+                const bool tip = ctl & (ch ? MBAMD_W4_TIP2 : MBAMD_W4_TIP1), mem = ctl & (ch ? MBAMD_WG_MEM2 : MBAMD_WG_MEM1);
+                // rows loaded from HBM for THIS chunk: waited for here, in front of this chunk's DMAs -- the compiler's wait cannot see
+                // those, and placed at the MFMA chain it would also wait for the table piece issued a moment ago
+                if (run && mem) {
+#pragma unroll
+                    for (int i = 0; i < TVC; ++i) {
+                        if constexpr (q & 1) asm volatile("" : "+v"(bm1[i]));
+                        else asm volatile("" : "+v"(bm0[i]));
+                    }
+                }
                 if constexpr (q == 0) tiny(n1, (unsigned) ((j + 1) & 1));
                 {   // the table piece D chunks ahead
                     constexpr int qf = q + D;
@@ -165,12 +207,12 @@ k_walkg_s(ARGS AA)
                     else table(n1, qf - NQ, rsD);
                     rsD = rsD + 1 == NB ? 0 : rsD + 1;
                 }
-                const bool tip = ctl & (ch ? MBAMD_W4_TIP2 : MBAMD_W4_TIP1), mem = ctl & (ch ? MBAMD_WG_MEM2 : MBAMD_WG_MEM1);
                 acc_t (&f)[NT] = *(ch ? &f2 : &f1);
                 const char* const piece = ldsBase + rsC * PIECE;
                 // the rows of the next chunk (into the other register set)
                 if constexpr (q + 1 < NQ) memrows(ce, q + 1, (q & 1) ? bm0 : bm1);
                 else memrows(n1, 0, (q & 1) ? bm0 : bm1);
+                MBAMD_WGS_STAMP(1);
                 auto chain = [&](const vec (&b)[TVC]) {
                     if constexpr (h == 0) {
 #pragma unroll
@@ -178,19 +220,18 @@ k_walkg_s(ARGS AA)
 #pragma unroll
                             for (int r = 0; r < ACC; ++r) f[it][r] = 0.0f;
                     }
-                    const vecA* ap = reinterpret_cast<const vecA*>(piece) + lane;
                     vecA a[NAVC];
 #pragma unroll
-                    for (int i = 0; i < NAVC; ++i) a[i] = ap[i * 64];
-                    if constexpr (q == NQ - 1) {
-                        // entry j + 2's descriptor: a scalar load shares lgkmcnt with LDS and returns out of order -- issued when this
-                        // chunk's operands are in registers, covered by its MFMA chain
+                    for (int i = 0; i < NAVC; ++i) a[i] = *reinterpret_cast<const vecA*>(piece + aoff[i]);
+                    // all operand reads first, then the MFMA chain: left alone the compiler issues each read right in front of its
+                    // first MFMA and the chain stalls on every one (2 640 against 2 430 cycles per 32-MFMA chunk, measured)
 #pragma unroll
-                        for (int i = 0; i < NAVC; ++i) asm volatile("" :: "v"(a[i]) : "memory");
+                    for (int i = 0; i < NAVC; ++i) asm volatile("" :: "v"(a[i]) : "memory");
 #pragma unroll
-                        for (int i = 0; i < TVC; ++i) asm volatile("" :: "v"(b[i]) : "memory");
-                        nn = walk4_load_entry(prog + j + 2);
-                    }
+                    for (int i = 0; i < TVC; ++i) asm volatile("" :: "v"(b[i]) : "memory");
+                    // entry j + 2's descriptor: a scalar load shares lgkmcnt with LDS and returns out of order -- issued when this
+                    // chunk's operands are in registers, covered by its MFMA chain
+                    if constexpr (q == NQ - 1) nn = walk4_load_entry(prog + j + 2);
 #pragma unroll
                     for (int tc = 0; tc < TPC; ++tc)
                         if (h * TPC + tc < T) {
@@ -217,21 +258,26 @@ k_walkg_s(ARGS AA)
                                 f[it][r] = (s >= (unsigned) SC && (unsigned) (TW * it + KS * r) + half < (unsigned) SC && ACC * it + r < T) ? 1.0f : 0.0f;
                     }
                     const unsigned sk = s / KS;
-                    if (s < (unsigned) SC && sk >= (unsigned) (h * TPC) && sk < (unsigned) ((h + 1) * TPC)) {
-                        const unsigned n0 = (sk - (unsigned) (h * TPC)) * NT;
-                        const float* tp = reinterpret_cast<const float*>(piece) + (n0 / VA) * (64 * VA) + (4u * half + TW * (s % KS)) * VA + n0 % VA;
-#pragma unroll
-                        for (int it = 0; it < NT; ++it)
-#pragma unroll
-                            for (int r = 0; r < ACC; ++r)
-                                if (ACC * it + r < T) {
-#if MBAMD_WG_TW == 32
-                                    const int rho = (r & 3) + 8 * (r >> 2);      // (unrolled: a constant offset of the ds_read)
+#if defined(MBAMD_WGSX_NOTIP)
+                    if (false) {
 #else
-                                    const int rho = r;
+                    if (s < (unsigned) SC && sk >= (unsigned) (h * TPC) && sk < (unsigned) ((h + 1) * TPC)) {
 #endif
-                                    f[it][r] = tp[it + rho * VA];
-                                }
+                        const unsigned n0 = (sk - (unsigned) (h * TPC)) * NT, rgi = n0 / VA;      // row group (rotated by rgi units of 16 bytes)
+                        const char* const rowp = piece + rgi * RG + (n0 % VA) * 4u;
+                        const unsigned cb = (4u * half + TW * (s % KS)) * (unsigned) (VA * 4) + 16u * rgi;
+#pragma unroll
+                        for (int r = 0; r < ACC; ++r) {
+#if MBAMD_WG_TW == 32
+                            const int rho = (r & 3) + 8 * (r >> 2);
+#else
+                            const int rho = r;
+#endif
+                            const float* tp = reinterpret_cast<const float*>(rowp + ((cb + (unsigned) (rho * VA * 4)) & (unsigned) (RG - 1)));
+#pragma unroll
+                            for (int it = 0; it < NT; ++it)
+                                if (ACC * it + r < T) f[it][r] = tp[it];
+                        }
                     }
                     if constexpr (q == NQ - 1) nn = walk4_load_entry(prog + j + 2);
                 } else if (run && mem) {
@@ -246,6 +292,7 @@ k_walkg_s(ARGS AA)
                     if constexpr (q == NQ - 1) nn = walk4_load_entry(prog + j + 2);
                 }
                 rsC = rsC + 1 == NB ? 0 : rsC + 1;
+                MBAMD_WGS_STAMP(2);
                 if constexpr (q == NQ - 1) {
                     // ---- the entry's result: product, rescale by its own power of two, LDS slot and HBM ---------------------------
                     float out[TP];
@@ -277,20 +324,37 @@ k_walkg_s(ARGS AA)
                         for (int i = 0; i < TV; ++i) keep[i * 64] = ov[i];
                     }
                     MBAMD_AS_GLOBAL vec* pd = reinterpret_cast<MBAMD_AS_GLOBAL vec*>((uintptr_t) (P0 + ce.dst)) + lane;
+#if defined(MBAMD_WGSX_NOSTORE)
+                    if (Vb::get(ov[0], 0) == 123.456f) __builtin_nontemporal_store(ov[0], pd);
+                    if (e == 12345) __builtin_nontemporal_store((int8_t) e, as_global(E0 + ce.ewrite) + col);
+#elif defined(MBAMD_WGSX_PLAIN_STORES)
+#pragma unroll
+                    for (int i = 0; i < TV; ++i) pd[i * 64] = ov[i];
+                    as_global(E0 + ce.ewrite)[col] = (int8_t) e;
+#else
 #pragma unroll
                     for (int i = 0; i < TV; ++i) __builtin_nontemporal_store(ov[i], pd + i * 64);   // 64 * V * 4 contiguous bytes per instruction
                     __builtin_nontemporal_store((int8_t) e, as_global(E0 + ce.ewrite) + col);       // (every lane group holds the same e: no exec-mask branch)
+#endif
                 }
                 // ---- the next chunk's table piece has landed (this wave's share; the barrier adds the others'), and nobody reads
                 //      the buffer this chunk used any more
+                MBAMD_WGS_STAMP(3);
 #if defined(MBAMD_WGS_SAFE_WAITS)
                 wgs_wait_vm<0>();
-#else
+#elif !defined(MBAMD_WGSX_NOWAIT)    // (ablation builds MBAMD_WGSX_*: wrong values, timing experiments only)
                 if constexpr (D == 1) wgs_wait_vm<(q == NQ - 1 ? NSTORE : 0)>();
                 else wgs_wait_vm<NDMA + (q == 0 ? NSTORE + 3 : 0) + (q == NQ - 1 ? NSTORE : 0)>();
 #endif
+                MBAMD_WGS_STAMP(4);
+#if !defined(MBAMD_WGSX_NOBARRIER)
                 __builtin_amdgcn_s_barrier();
+#endif
                 asm volatile("" ::: "memory");
+                MBAMD_WGS_STAMP(5);
+#if defined(MBAMD_WGS_TRACE)
+                if (tracing && q == 0) A.trace[((size_t) j * NQ + q) * 8 + 6] = (long long) ctl;
+#endif
             }
         };
         chunk(WgInt<0>{}); chunk(WgInt<1>{}); chunk(WgInt<2>{}); chunk(WgInt<3>{});

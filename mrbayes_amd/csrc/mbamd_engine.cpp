@@ -722,7 +722,6 @@ int Instance::configureWalk()
     if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0) numCU = prop.multiProcessorCount;
     const int maxLds = 160 * 1024;
     if (s4 && (hipFuncSetAttribute((const void*) k_walk4_t<Walk4Args>, hipFuncAttributeMaxDynamicSharedMemorySize, maxLds) != hipSuccess ||
-               hipFuncSetAttribute((const void*) k_walk4_t<Walk4Args, true>, hipFuncAttributeMaxDynamicSharedMemorySize, maxLds) != hipSuccess ||
                hipFuncSetAttribute((const void*) k_walk4_t<Walk4ArgsInline>, hipFuncAttributeMaxDynamicSharedMemorySize, maxLds) != hipSuccess))
         (void) hipGetLastError();
     if (wg) {
@@ -773,12 +772,10 @@ int Instance::configureWalk()
     w4.maxSlots1 = std::max(slots, std::min(40, slotsFor(1)));
     if (std::getenv("MBAMD_MAX_LDS_SLOTS")) w4.maxSlots1 = slots;
     if (const char* e = std::getenv("MBAMD_WALK_PREFETCH")) w4.prefetchDistance = std::max(0, std::atoi(e));
-    // measured (profiles/r03_exp_walk4.txt): touching the tip bitplanes 8 entries ahead buys 3 % at 1000 x 50 000 -- all that serving
-    // every tip from one hot line would -- and nothing at 500 x 20 000
-    w4.tipAhead = 8;
+    // (round 3's tip-plane touch -- two LDS-DMAs, a half-entry scalar load and their address arithmetic per operation for +-2 % --
+    //  left the loop in round 4: it is issue-bound)
+    w4.tipAhead = 0;
     w4.forward = std::getenv("MBAMD_WALK_NO_FORWARD") == nullptr;
-    if (const char* e = std::getenv("MBAMD_WALK_TIP_AHEAD")) w4.tipAhead = std::max(0, std::min(32, std::atoi(e)));
-    if (const char* e = std::getenv("MBAMD_WALK_TIP_FROM")) w4.tipAheadFrom = std::max(1, std::atoi(e));
     w4.safeWaits = std::getenv("MBAMD_WALK_SAFE") != nullptr;
     if (const char* e = std::getenv("MBAMD_WALK_SMALL_PHASE")) w4.smallPhase = std::max(1, std::atoi(e));
     if (envVerbose) std::fprintf(stderr, "[mbamd] tree walk: %ld workgroups (%d per CU), up to %d waves x %d slots\n", wgs, perCU, W, slots);
@@ -819,19 +816,24 @@ void Instance::wgsGeometry(int lists, int& W, int& slots) const
     int numCU = 256;
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0) numCU = prop.multiProcessorCount;
-    const int G = wgsG, wavesPerCU = S > 32 ? 4 : 12;
+    // The waves of a workgroup march in lockstep (a barrier per table chunk): what overlaps one workgroup's epilogues, tip chunks
+    // and waits with MFMA work is ANOTHER workgroup on the same CU -- at least two per CU, eight waves.  Registers allow two waves
+    // per SIMD beyond 32 states; the LDS must hold the workgroups' rings and slots, so large blocks get few slots (one: the
+    // latest result; older values come back from HBM through the operand pipeline, 8 KB per use).
+    const int G = wgsG, wavesPerCU = S > 32 ? 8 : 12;
     const long slotBytes = (long) wg_block_bytes(S);
     const long fixed = (long) (MBAMD_WGS_D + 1) * (long) wgs_chunk_bytes(S, wgs_chunks(S)) + (long) G * MBAMD_WGS_STAGE;
     const long groups = (long) (Ppad / MBAMD_WG_TW / G) * K * lists;           // workgroups per bin
+    const long minPerCU = std::max(1, 8 / G);
     auto slotsFor = [&](int w) {
-        const long perCU = std::max(1L, (groups * w + numCU - 1) / numCU);
+        const long perCU = std::max(minPerCU, (groups * w + numCU - 1) / numCU);
         return (int) (((160L * 1024) / std::min(perCU, 32L / G) - 64 - fixed) / ((long) G * slotBytes));
     };
     W = (int) std::max(1L, std::min((long) MBAMD_WGS_MAXBINS, ((long) wavesPerCU * numCU + groups * G / 2) / (groups * G)));
-    while (W > 1 && slotsFor(W) < 4) --W;
+    while (W > 1 && slotsFor(W) < 1) --W;
     if (const char* e = std::getenv("MBAMD_WALK_WAVES")) W = std::max(1, std::min(MBAMD_WGS_MAXBINS, std::atoi(e)));
-    slots = std::max(3, std::min(24, slotsFor(W)));
-    if (const char* e = std::getenv("MBAMD_MAX_LDS_SLOTS")) slots = std::max(3, std::min((int) ((160L * 1024 - 64 - fixed) / ((long) G * slotBytes)), std::atoi(e)));
+    slots = std::max(1, std::min(24, slotsFor(W)));
+    if (const char* e = std::getenv("MBAMD_MAX_LDS_SLOTS")) slots = std::max(1, std::min((int) ((160L * 1024 - 64 - fixed) / ((long) G * slotBytes)), std::atoi(e)));
 }
 
 // 4-state path: one tip's state masks (bit i = state i compatible) -> four 64-bit bitplanes per pattern block
@@ -1697,6 +1699,11 @@ int Instance::buildWalk(Plan& plan, const BeagleOperation* ops, int n, const int
                 if (op.scaleRead >= 0) e.eread = (uint32_t) op.scaleRead * ebuf;
             }
             if (te.vmwait != 0xFF) flags |= MBAMD_W4_VMWAIT;
+            // the entry in front of a SCALE_READ entry of the same wave fetches that entry's stored exponents (mbamd_walk4.h)
+            if ((i + 1) % (size_t) t.entries != 0) {
+                const Walk4Template::Entry& tn = t.prog[i + 1];
+                if (tn.op >= 0 && seg[tn.op].scaleWrite < 0 && seg[tn.op].scaleRead >= 0) flags |= MBAMD_W4_NEXT_READS;
+            }
             e.ctl = flags | (mode << 8) | ((uint32_t) (te.vmwait == 0xFF ? 0 : te.vmwait) << 10) | (keep << 16);
         }
         lastWalkW = t.W; lastWalkSlots = t.nslots; lastWalkEntries = t.entries; lastWalkPhases = t.phases;
@@ -1806,10 +1813,7 @@ int Instance::runWalk(const Plan& plan, int32_t* cum)
         a.nblocks = Ppad / 64;
         a.tail = sg.tail;
         a.tipAhead = sg.tipAhead;
-        if (sg.tipAhead > 0 && plan.inlineProg.empty()) {
-            auto kernel = k_walk4_t<Walk4Args, true>;
-            MBAMD_LAUNCH_BARRIER(kernel, walk4_grid(Ppad / 64, K), 64 * sg.W, walk4_lds_bytes(sg.W, sg.nslots), stream, a);
-        } else if (!plan.inlineProg.empty()) {
+        if (!plan.inlineProg.empty()) {
             Walk4ArgsInline ai;
             ai.a = a;
             ai.a.prog = nullptr;
@@ -2105,6 +2109,14 @@ int Instance::runWalkGS(const Plan& plan)
                 for (int w = 0; w < lq.W; ++w) { s.range[q][w] = lq.ranges[(size_t) ph * lq.W + w]; any |= s.range[q][w] != 0; }
             }
             if (!any) continue;
+            if (envTrace && ph == 0) {               // timing experiments: clock stamps of one workgroup of the first launch
+                if (!d_trace && hipMalloc(&d_trace, (size_t) 4096 * 8 * 3 * sizeof(long long)) != hipSuccess) d_trace = nullptr;
+                if (d_trace) {
+                    (void) hipMemsetAsync(d_trace, 0, (size_t) 4096 * 8 * 3 * sizeof(long long), stream);
+                    a.trace = d_trace;
+                    lastWalkSteps = 4096; walkWaves = 0;
+                }
+            }
             if (ph > 0) fresh = 0;
             MBAMD_WGS_DISPATCH(S, wgsG, launch_walkgs_t, *this, s, sg.nslots, &plan.inlineProg);
             HIP_TRY(hipGetLastError());

@@ -53,13 +53,15 @@ namespace mbamd {
 #define MBAMD_W4_KEEP     0x80u  // the result is also written to LDS slot `keep`
 #define MBAMD_W4_FWD1     0x01000000u  // child 1 / 2 is the result of the operation this wave executed last: still in registers
 #define MBAMD_W4_FWD2     0x02000000u
-#define MBAMD_W4_RARE     (MBAMD_W4_NOP | MBAMD_W4_BARRIER | MBAMD_W4_PF0 | MBAMD_W4_VMWAIT)
+#define MBAMD_W4_READS      0x00000200u  // (= ScaleMode SCALE_READ in [9:8]) this entry divides by stored exponents: they were fetched into the landing area
+#define MBAMD_W4_NEXT_READS 0x04000000u  // the NEXT entry of this wave is SCALE_READ: fetch its stored exponents now (4-state walk; set by the host)
+#define MBAMD_W4_RARE     (MBAMD_W4_NOP | MBAMD_W4_BARRIER | MBAMD_W4_PF0 | MBAMD_W4_VMWAIT | MBAMD_W4_READS | MBAMD_W4_NEXT_READS)
 #define MBAMD_W4_MAXW     8
 
 // One step of a wave's program (wave-uniform; fetched with one s_load_dwordx8).  Addresses are ready-made byte
 // offsets from a base the wave computes once (scalar adds only, no multiplications in the loop).
 struct alignas(32) Walk4Entry {
-    uint32_t ctl;      // [7:0] flags   [9:8] ScaleMode   [15:10] vmwait   [23:16] slot that keeps the result (flag KEEP)   [25:24] FWD1 / FWD2
+    uint32_t ctl;      // [7:0] flags   [9:8] ScaleMode   [15:10] vmwait   [23:16] slot that keeps the result (flag KEEP)   [25:24] FWD1 / FWD2   [26] NEXT_READS
     uint32_t dst;      // destination partials buffer: byte offset inside this wave's (block, category) column set
     uint32_t c1;       // child 1: tip -> byte offset of its 4 bitplanes inside the block's tip area; else LDS byte offset of its slot
     uint32_t c2;
@@ -85,8 +87,8 @@ struct Walk4Args {
     int32_t* cum;                // wide cumulative buffer int32 [K][Ppad], or nullptr
     int cumFresh;                // the cumulative buffer holds nothing yet: store the sums instead of adding them
     int K, Ppad, nblocks;
-    int tail;                    // trailing NOP entries of every program (read-ahead): 2, or tipAhead + 1
-    int tipAhead;                // > 0: touch the tip bitplanes of the entry this far ahead (walk4_touch_planes), else 0
+    int tail;                    // trailing NOP entries of every program (read-ahead): 2
+    int tipAhead;                // (unused since round 4: the tip-plane touch left the loop)
 };
 
 #define MBAMD_W4_STAGE 768       // bytes per wave in front of its slots: two 64-dword landing areas for stored exponents + one nobody reads
@@ -97,7 +99,6 @@ __host__ __device__ inline size_t walk4_lds_bytes(int W, int nslots) { return (s
 __host__ __device__ inline unsigned walk4_grid(int nblocks, int K) { return 8u * (unsigned) K * (unsigned) ((nblocks + 7) / 8); }
 
 struct Walk4Planes { uint64_t p[4]; };
-struct Walk4Half { unsigned ctl, dst, c1, c2; };   // the first half of an entry: all the far-ahead tip touch needs
 
 }  // namespace mbamd
 #include <mbamd_dev_walk4.h>     // Walk4Mat, walk4_load_* / walk4_tip_vector / walk4_dma* / walk4_wait_vm / walk4_barrier / walk4_matvec / ... (csrc/device/)
@@ -139,10 +140,16 @@ namespace mbamd {
 
 // blockDim.x = 64 * W; grid = walk4_grid(nblocks, K) workgroups.  Dynamic LDS: walk4_lds_bytes(W, nslots).
 // ARGS = Walk4Args (program in a device buffer) or Walk4ArgsInline (program in the arguments).
-// TIPPF: the tip bitplanes of entry j + tipAhead are touched at the top of iteration j (full-tree evaluations: a tip's planes
-// are read once per launch, i.e. from HBM -- a round trip of microseconds under a saturated write stream, and the scalar load
-// that takes it is waited for one iteration after it was issued).
-template <class ARGS, bool TIPPF = false>
+//
+// Round 4: the loop was issue-bound (profiles/r03_c4_pmc.txt: 50 VALU + 58 SALU + 6 SMEM + 4 VMEM instructions per operation and
+// wave, the scalar side -- shared by the four SIMDs of a CU -- the larger half).  What left the common path:
+//   * the tip-plane touch (two LDS-DMAs, a half-entry scalar load and their address arithmetic per operation: +-2 % in round 3);
+//   * everything that is not "an operation that rescales or does not": prefetch entries, waits, barriers, no-ops AND the two
+//     halves of dynamic rescaling's SCALE_READ pass (fetch the next entry's stored exponents / read this entry's) sit behind ONE
+//     test of the entry's flags (MBAMD_W4_RARE; the host marks the entry in front of a SCALE_READ entry with NEXT_READS);
+//   * the copy of a result into the forwarding registers (results alternate between two register sets with the loop's two halves);
+//   * per-entry address arithmetic of the program (a running pointer, one add per two entries).
+template <class ARGS>
 __global__ void __launch_bounds__(64 * MBAMD_W4_MAXW)
 k_walk4_t(ARGS AA)
 {
@@ -167,31 +174,29 @@ k_walk4_t(ARGS AA)
 #define MBAMD_W4_PREFETCH(SRC, DST) walk4_prefetch(L, walk4_at_kib(P0, SRC), (DST))
 #define MBAMD_W4_EXPS(OFF, PARITY) walk4_fetch_exps(L, walk4_at(E0, OFF), lane, (PARITY))
 
-    const Walk4Entry* prog = walk4_program(AA) + (size_t) wave * A.entries;
+    const Walk4Entry* pp = walk4_program(AA) + (size_t) wave * A.entries;       // entry j of this wave's program
     const int n = A.entries - A.tail;
-    Walk4Entry DA = walk4_load_entry(prog), DB = walk4_load_entry(prog + 1);
-    const int ahead = TIPPF ? A.tipAhead : 0;
-    Walk4Half FAR = walk4_load_half(prog + ahead);               // (TIPPF) entry j + ahead, loaded during iteration j - 1
+    Walk4Entry DA = walk4_load_entry(pp), DB = walk4_load_entry(pp + 1);
     // inputs of entry 0
     Walk4Mat M1 = walk4_load_matrix(walk4_at(M0, DA.m1));
     Walk4Mat M2 = walk4_load_matrix(walk4_at(M0, DA.m2));
     Walk4Planes T1 = walk4_load_planes(walk4_at(T0, (DA.ctl & MBAMD_W4_TIP1) ? DA.c1 : 0u));
     Walk4Planes T2 = walk4_load_planes(walk4_at(T0, (DA.ctl & MBAMD_W4_TIP2) ? DA.c2 : 0u));
-    if (((DA.ctl >> 8) & 3u) == SCALE_READ) MBAMD_W4_EXPS(DA.eread, 0);
+    if (DA.ctl & MBAMD_W4_READS) MBAMD_W4_EXPS(DA.eread, 0);
     int cum_e = 0;
-    f4 prev = {0.0f, 0.0f, 0.0f, 0.0f};            // the result of the operation executed last (FWD1 / FWD2 children)
+    f4 RA = {0.0f, 0.0f, 0.0f, 0.0f}, RB = RA;     // results of the even / odd entries (a no-op entry passes the previous one through): a FWD child reads the other set
 
     // One iteration = one entry.  Vector-memory instruction sequence (the host's vmwait counts on exactly this):
-    //     [DMA pf0] [DMA pf1] (PF entries)   s_waitcnt vmcnt(vmwait) (flag VMWAIT)   [2 tip touches (TIPPF kernels)]
+    //     [DMA pf0] [DMA pf1] (PF entries)   s_waitcnt vmcnt(vmwait) (flag VMWAIT)
     //     [exponent DMA for the next entry, if that is SCALE_READ]   [2 stores, if this entry is an operation]
     // Everything wave-uniform is a scalar branch or a scalar select (no divergent control flow).  The loop is unrolled by
     // two so that the two entry descriptors in flight keep their registers (no moves): `cur` is executed, `nxt` is the
     // next one, and cur's registers receive entry j + 2.  ALL scalar loads of an iteration (next entry's matrices and tip
     // planes, the entry after next) are issued in one burst as soon as this entry's matrix products are done, and are
     // consumed after the next iteration's LDS reads: one lgkmcnt(0) per iteration covers both.
-    auto step = [&](Walk4Entry& cur, const Walk4Entry& nxt, int j, int parity) {
+    auto step = [&](Walk4Entry& cur, const Walk4Entry& nxt, const Walk4Entry* after, int parity, f4& out, const f4& prev) {
         const unsigned ctl = cur.ctl;
-        bool run = true;
+        int er = 0;
         if (ctl & MBAMD_W4_RARE) {
             if (ctl & MBAMD_W4_PF0) {
                 // PF entry: children of later operations that live in HBM -> LDS slots
@@ -200,12 +205,11 @@ k_walk4_t(ARGS AA)
             }
             if (ctl & MBAMD_W4_VMWAIT) walk4_wait_vm((ctl >> 10) & 63u);       // what an LDS-DMA brought for this entry has landed
             if (ctl & MBAMD_W4_BARRIER) walk4_barrier();
-            run = !(ctl & MBAMD_W4_NOP);
+            if (ctl & MBAMD_W4_NEXT_READS) MBAMD_W4_EXPS(nxt.eread, parity ^ 1);
+            if (ctl & MBAMD_W4_READS) er = stage[64 * parity + lane];
         }
-        const unsigned mode = (ctl >> 8) & 3u;
-        f4 out = {0.0f, 0.0f, 0.0f, 0.0f};
-        int er = 0;
-        if (run) {
+        f4 o = prev;                                   // (a no-op entry passes the result of the operation executed last through)
+        if (!(ctl & MBAMD_W4_NOP)) {
             f4 a, b;
             if (ctl & MBAMD_W4_TIP1) a = walk4_tip_vector(T1, lane);
             else if (ctl & MBAMD_W4_FWD1) a = prev;
@@ -213,51 +217,35 @@ k_walk4_t(ARGS AA)
             if (ctl & MBAMD_W4_TIP2) b = walk4_tip_vector(T2, lane);
             else if (ctl & MBAMD_W4_FWD2) b = prev;
             else b = *reinterpret_cast<const f4*>(slots + cur.c2);
-            if (mode == SCALE_READ) er = stage[64 * parity + lane];
             const f4 f1 = walk4_matvec(M1, a);
             const f4 f2 = walk4_matvec(M2, b);
-            out.x = f1.x * f2.x; out.y = f1.y * f2.y; out.z = f1.z * f2.z; out.w = f1.w * f2.w;
-        }
-        // (TIPPF) touch the tip planes of the entry tipAhead further on.  Here -- behind the matrix products -- and not at the
-        // top of the iteration: FAR came with the previous burst, and the first instruction that reads anything of a burst
-        // waits for ALL of it (one lgkmcnt, scalar loads return out of order); the products have paid for that wait already
-        if (TIPPF) {
-            walk4_touch(L, walk4_at(T0, (FAR.ctl & MBAMD_W4_TIP1) ? FAR.c1 : 0u), walk4_at(T0, (FAR.ctl & MBAMD_W4_TIP2) ? FAR.c2 : 0u));
+            o.x = f1.x * f2.x; o.y = f1.y * f2.y; o.z = f1.z * f2.z; o.w = f1.w * f2.w;
         }
         // the scalar-load burst for the next entry (the registers of this entry's matrices / planes are free now); a
         // child that is not a tip reads the planes at offset 0 -- a valid address, the value is not used
         const unsigned dst = cur.dst, ewrite = cur.ewrite;
-#if defined(MBAMD_W4X_MAT0)      // (timing experiments: every matrix / every tip from one hot line -- wrong values)
-        M1 = walk4_load_matrix(walk4_at(M0, 0u));
-        M2 = walk4_load_matrix(walk4_at(M0, 0u));
-#else
         M1 = walk4_load_matrix(walk4_at(M0, nxt.m1));
         M2 = walk4_load_matrix(walk4_at(M0, nxt.m2));
-#endif
-#if defined(MBAMD_W4X_TIP0)
-        T1 = walk4_load_planes(walk4_at(T0, 0u));
-        T2 = walk4_load_planes(walk4_at(T0, 0u));
-#else
         T1 = walk4_load_planes(walk4_at(T0, (nxt.ctl & MBAMD_W4_TIP1) ? nxt.c1 : 0u));
         T2 = walk4_load_planes(walk4_at(T0, (nxt.ctl & MBAMD_W4_TIP2) ? nxt.c2 : 0u));
-#endif
-        if (((nxt.ctl >> 8) & 3u) == SCALE_READ) MBAMD_W4_EXPS(nxt.eread, parity ^ 1);
-        cur = walk4_load_entry(prog + j + 2);
-        if (TIPPF) FAR = walk4_load_half(prog + j + 1 + ahead);
-        if (run) {
-            const int wm = mode == SCALE_WRITE ? -1 : 0, rm = mode == SCALE_READ ? -1 : 0;
-            const int e = (scale_exponent(max4(out)) & wm) | (er & rm);
-            cum_e += e & wm;
-            out.x = scale_pow2(out.x, -e); out.y = scale_pow2(out.y, -e);       // (2^0 is exact: no branch)
-            out.z = scale_pow2(out.z, -e); out.w = scale_pow2(out.w, -e);
-            prev = out;
-            if (ctl & MBAMD_W4_KEEP) *reinterpret_cast<f4*>(slots + ((ctl >> 6) & 0x3FC00u)) = out;
-            walk4_store(walk4_at_kib(P0, dst), walk4_at(E0, ewrite), lane, out, e);
+        cur = walk4_load_entry(after);
+        if (!(ctl & MBAMD_W4_NOP)) {
+            // SCALE_WRITE: this column's own power of two; SCALE_READ (rare path): the stored one; else 2^0 (exact: no branch)
+            const int wm = (int) (ctl << 23) >> 31;                                    // mode bit 8 (SCALE_WRITE) -> all ones
+            const int ew = scale_exponent(max4(o)) & wm;
+            const int e = ew | er;
+            cum_e += ew;
+            o.x = scale_pow2(o.x, -e); o.y = scale_pow2(o.y, -e);
+            o.z = scale_pow2(o.z, -e); o.w = scale_pow2(o.w, -e);
+            if (ctl & MBAMD_W4_KEEP) *reinterpret_cast<f4*>(slots + ((ctl >> 6) & 0x3FC00u)) = o;
+            walk4_store(walk4_at_kib(P0, dst), walk4_at(E0, ewrite), lane, o, e);
         }
+        out = o;
     };
     for (int j = 0; j < n; j += 2) {
-        step(DA, DB, j, 0);
-        step(DB, DA, j + 1, 1);
+        step(DA, DB, pp + 2, 0, RA, RB);
+        step(DB, DA, pp + 3, 1, RB, RA);
+        pp += 2;
     }
 #undef MBAMD_W4_EXPS
 #undef MBAMD_W4_PREFETCH

@@ -305,7 +305,8 @@ inline bool Walk4Builder::build(const std::vector<Walk4Op>& ops, Walk4Template& 
 
     // ---- slots, prefetches, wait counts: one linear scan per wave -------------------------------------------------
     int slotsUsed = 1;
-    const int S = std::max(2, std::min(W == 1 ? std::max(maxSlots, maxSlots1) : maxSlots, 250));
+    // (the operand pipeline of the general-state kernels reads evicted values from HBM itself: one slot -- the latest result -- is a valid budget)
+    const int S = std::max(memSlots ? 2 : 1, std::min(W == 1 ? std::max(maxSlots, maxSlots1) : maxSlots, 250));
     // a short single-wave list is a root-ward path: fetch its siblings as early as slots allow -- loads issued before the
     // first store do not wait for any store (in-order vmcnt, see mbamd_walk4.h)
     const int distance = (W == 1 && n <= 128) ? (1 << 20) : prefetchDistance;

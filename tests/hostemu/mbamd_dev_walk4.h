@@ -18,7 +18,6 @@ __device__ inline void walk4_dma_exps(const int8_t* base, unsigned lane, int* st
 __device__ inline void walk4_wait_vm(unsigned) {}
 __device__ inline void walk4_barrier() { mbamd_emu_barrier(); }
 __device__ inline Walk4Entry walk4_load_entry(const Walk4Entry* p) { return *p; }
-__device__ inline Walk4Half walk4_load_half(const Walk4Entry* p) { Walk4Half h; h.ctl = p->ctl; h.dst = p->dst; h.c1 = p->c1; h.c2 = p->c2; return h; }
 
 // f_i = sum_j P(i->j) v_j with the transposed matrix mT[j][i] in scalar registers; the same fma chain
 // (j = 0..3, first term a plain product) as the reference's scalar loop order, two rows per v_pk_fma_f32.
@@ -38,7 +37,6 @@ struct Walk4Lds { char* mine; unsigned lane; };
 inline Walk4Lds walk4_lds(char* mine, unsigned lane) { return Walk4Lds{mine, lane}; }
 inline void walk4_prefetch(const Walk4Lds& L, const f4* src, unsigned dst) { walk4_dma(src, L.lane, reinterpret_cast<f4*>(L.mine + MBAMD_W4_STAGE + dst)); }
 inline void walk4_fetch_exps(const Walk4Lds& L, const int8_t* src, unsigned lane, int parity) { walk4_dma_exps(src, lane, reinterpret_cast<int*>(L.mine) + 64 * parity); }
-inline void walk4_touch(const Walk4Lds&, const uint64_t*, const uint64_t*) {}
 inline void walk4_store(f4* P, int8_t* E, unsigned lane, f4 out, int e) { P[lane] = out; E[lane] = (int8_t) e; }
 }  // namespace mbamd
 #endif
