@@ -141,11 +141,23 @@ k_walkg(ARGS AA)
         const unsigned coff = ch ? d.e.c2 : d.e.c1, moff = ch ? d.e.m2 : d.e.m1;
         const unsigned s = ch ? d.s2 : d.s1;
         // a: A' (column = lane) or the tip's gather table (column = KS * (state % TW) + half of sub-table state / TW)
-        const unsigned aoff = tip ? (1u + s / TW) * (unsigned) (NAP * 256) + ((s % TW) * KS + half) * (unsigned) (VA * 4) : lane * (unsigned) (VA * 4);
-        const MBAMD_AS_GLOBAL vecA* pa = reinterpret_cast<const MBAMD_AS_GLOBAL vecA*>((uintptr_t) (Mk + moff) + aoff) + h * NAVC * 64;
+        // (a compact tip takes every register from the FIRST chunk's rows: where a job has several chunks -- 60..63 states -- its
+        //  later chunks and no-op entries keep their loads, so that the vector-memory sequence stays uniform, but every lane reads one
+        //  and the same 16 bytes: one L2 request instead of eight lines.  A quarter of the kernel's L2 traffic, which bounds it
+        //  (profiles/r03_c5_pmc.txt).  With one chunk per job the plain form stays: a run-time stride costs the immediate offsets
+        //  of the loads -- +10 % at 20 states, measured.)
+        const bool idle = CH > 1 && ((tip && h > 0) || (ctl & MBAMD_W4_NOP));
+        const unsigned aoff = idle ? 0u : (tip ? (1u + s / TW) * (unsigned) (NAP * 256) + ((s % TW) * KS + half) * (unsigned) (VA * 4) : lane * (unsigned) (VA * 4));
+        const MBAMD_AS_GLOBAL vecA* pa = reinterpret_cast<const MBAMD_AS_GLOBAL vecA*>((uintptr_t) (Mk + moff) + aoff) + (idle ? 0 : h * NAVC * 64);
 #if !defined(MBAMD_WGX_NOFETCH)
+        if constexpr (CH > 1) {
+            const int stride = idle ? 0 : 64;
 #pragma unroll
-        for (int i = 0; i < NAVC; ++i) o.a[i] = pa[i * 64];
+            for (int i = 0; i < NAVC; ++i) o.a[i] = pa[i * stride];
+        } else {
+#pragma unroll
+            for (int i = 0; i < NAVC; ++i) o.a[i] = pa[i * 64];
+        }
 #else
         (void) pa;
 #endif

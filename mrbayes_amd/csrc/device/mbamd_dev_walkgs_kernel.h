@@ -77,8 +77,9 @@ template <int N> __device__ __forceinline__ void wgs_wait_vm()
 // blockDim.x = 64 * G; grid = walkgs_grid(ntiles / G, K * lists * bins); dynamic LDS = wgs_lds_bytes(G, nslots, SC, CH, D + 1).
 // ntiles is a multiple of G (the engine pads the pattern count).  A job (one child factor) is CH chunks; a chunk's table piece is
 // fetched D chunks ahead into a ring of D + 1 buffers.
+// (second launch bound = waves per SIMD the register budget must allow: two workgroups of four waves per CU beyond 32 states)
 template <int SC, int G, int CH, int D, class ARGS = WalkGSArgs>
-__global__ void __launch_bounds__(64 * G)
+__global__ void __launch_bounds__(64 * G, (SC > 32 ? 2 : 4))
 k_walkg_s(ARGS AA)
 {
     const WalkGSArgs& AS = wgs_args(AA);
@@ -223,15 +224,16 @@ k_walkg_s(ARGS AA)
                     vecA a[NAVC];
 #pragma unroll
                     for (int i = 0; i < NAVC; ++i) a[i] = *reinterpret_cast<const vecA*>(piece + aoff[i]);
-                    // all operand reads first, then the MFMA chain: left alone the compiler issues each read right in front of its
-                    // first MFMA and the chain stalls on every one (2 640 against 2 430 cycles per 32-MFMA chunk, measured)
-#pragma unroll
-                    for (int i = 0; i < NAVC; ++i) asm volatile("" :: "v"(a[i]) : "memory");
-#pragma unroll
-                    for (int i = 0; i < TVC; ++i) asm volatile("" :: "v"(b[i]) : "memory");
                     // entry j + 2's descriptor: a scalar load shares lgkmcnt with LDS and returns out of order -- issued when this
-                    // chunk's operands are in registers, covered by its MFMA chain
-                    if constexpr (q == NQ - 1) nn = walk4_load_entry(prog + j + 2);
+                    // chunk's operands are in registers, covered by its MFMA chain.  (Pinning the reads in front of the chain in
+                    // EVERY chunk costs 22 registers -- 260, one wave per SIMD -- and buys nothing: 2 760 against 2 640 cycles.)
+                    if constexpr (q == NQ - 1) {
+#pragma unroll
+                        for (int i = 0; i < NAVC; ++i) asm volatile("" :: "v"(a[i]) : "memory");
+#pragma unroll
+                        for (int i = 0; i < TVC; ++i) asm volatile("" :: "v"(b[i]) : "memory");
+                        nn = walk4_load_entry(prog + j + 2);
+                    }
 #pragma unroll
                     for (int tc = 0; tc < TPC; ++tc)
                         if (h * TPC + tc < T) {

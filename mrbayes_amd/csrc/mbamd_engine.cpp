@@ -553,7 +553,10 @@ int Instance::create(int tipCount_, int partialsBufferCount, int compactBufferCo
     }
     // k_walkg_s: G waves on G adjacent tiles share a workgroup (and the transition tables in its LDS); the pattern count is
     // padded to whole groups of four tiles (pad patterns: weight 0, missing data -- like every pad pattern)
-    wgs = wg && wgs_compiled(S) && !(std::getenv("MBAMD_WALKG_SHARED") && std::atoi(std::getenv("MBAMD_WALKG_SHARED")) == 0);
+    // MEASURED (round 4, profiles/r04_walkgs_*.txt): parity-green and SLOWER than k_walkg -- codon 100 x 5 000: 0.225 against 0.195 ms,
+    // protein 200 x 10 000: 0.222 against 0.222 -- the lockstep costs more (a barrier, a DMA issue phase and a tip gather per chunk)
+    // than the 4x smaller L2 stream buys.  Opt-in (MBAMD_WALKG_SHARED=1); the product runs k_walkg.
+    wgs = wg && wgs_compiled(S) && std::getenv("MBAMD_WALKG_SHARED") && std::atoi(std::getenv("MBAMD_WALKG_SHARED")) != 0;
     if (wgs) {
         wgsG = S > 32 ? 4 : 2;
         if (const char* e = std::getenv("MBAMD_WALKG_G")) wgsG = std::atoi(e) >= 4 ? 4 : 2;

@@ -493,7 +493,9 @@ inline bool Walk4Builder::build(const std::vector<Walk4Op>& ops, Walk4Template& 
                         const int v = slotHolder[q];
                         if (v < 0) continue;
                         const int u = nextUseOfValue(v, j + 1);
-                        if (u > bestUse) { bestUse = u; best = q; }
+                        // (a result the NEXT entry reads must be kept -- it cannot come back from HBM that soon -- even against a
+                        //  value needed just as soon: that one was stored long enough ago)
+                        if (u > bestUse || (!memSlots && mine == j + 1 && best < 0 && u >= bestUse)) { bestUse = u; best = q; }
                     }
                     if (best >= 0) {
                         const int v = slotHolder[best];

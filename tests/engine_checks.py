@@ -842,3 +842,30 @@ def check_parsimony_model_golden(lib, golden_dir):
             assert abs(lnl - case["lnL_reference"]) <= 1e-6, (case["name"], lnl, case["lnL_reference"])
         finally:
             inst.finalize()
+
+
+def check_shared_table_walk(lib, oracle, golden_dir, monkeypatch):
+    """k_walkg_s (MBAMD_WALKG_SHARED=1: transition tables staged in LDS and shared by the waves of a workgroup, subtree bins as
+    workgroups, phases as launches) against k_walkg, the oracle and the reference's goldens: full evaluations with both scaling
+    schemes at several bin counts / slot budgets, per-site values, partial updates with rejects."""
+    for case in ("avian_wag_g4", "replicase_m3", "synth_aa_wag", "synth_codon_m3"):
+        div = division_from_golden(golden_dir, case)
+        monkeypatch.delenv("MBAMD_WALKG_SHARED", raising=False)
+        base = engine_lnl(lib, div, lk.MB_BEAGLE_SCALE_ALWAYS)
+        for env in ({}, {"MBAMD_WALK_WAVES": "1"}, {"MBAMD_WALK_WAVES": "3", "MBAMD_MAX_LDS_SLOTS": "2"}, {"MBAMD_WALKG_G": "2"},
+                    {"MBAMD_WALKG_G": "4", "MBAMD_WALK_WAVES": "5", "MBAMD_MAX_LDS_SLOTS": "1"}):
+            monkeypatch.setenv("MBAMD_WALKG_SHARED", "1")
+            for k in ("MBAMD_WALK_WAVES", "MBAMD_MAX_LDS_SLOTS", "MBAMD_WALKG_G"):
+                monkeypatch.delenv(k, raising=False)
+            for k, v in env.items():
+                monkeypatch.setenv(k, v)
+            for scaling in (lk.MB_BEAGLE_SCALE_ALWAYS, lk.MB_BEAGLE_SCALE_DYNAMIC):
+                got = engine_lnl(lib, div, scaling)
+                assert abs(got - base) <= 2e-7 * abs(base), (case, env, scaling, got, base)
+            check_golden_case(lib, oracle, golden_dir, case, lk.MB_BEAGLE_SCALE_ALWAYS)
+    monkeypatch.setenv("MBAMD_WALKG_SHARED", "1")
+    for k in ("MBAMD_WALK_WAVES", "MBAMD_MAX_LDS_SLOTS", "MBAMD_WALKG_G"):
+        monkeypatch.delenv(k, raising=False)
+    check_site_likelihoods(lib, oracle, division_from_golden(golden_dir, "replicase_m3"))
+    check_partial_update_and_reject(lib, oracle, division_from_golden(golden_dir, "avian_wag_g4"), lk.MB_BEAGLE_SCALE_DYNAMIC)
+    check_partial_update_and_reject(lib, oracle, division_from_golden(golden_dir, "synth_codon_m3"), lk.MB_BEAGLE_SCALE_ALWAYS)

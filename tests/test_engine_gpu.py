@@ -588,3 +588,9 @@ def test_short_walk_programs_travel_in_the_kernel_arguments(gpu, monkeypatch, go
     base = path_values()
     monkeypatch.setenv("MBAMD_NO_INLINE_PROGRAMS", "1")
     assert path_values() == base
+
+
+def test_shared_table_walk(gpu, oracle, golden_dir, monkeypatch):
+    """The opt-in general-state walk with LDS-staged, workgroup-shared transition tables (k_walkg_s) is parity-green: it is not
+    the product default because it measured slower than k_walkg (profiles/r04_walkgs_*.txt)."""
+    ec.check_shared_table_walk(gpu, oracle, golden_dir, monkeypatch)

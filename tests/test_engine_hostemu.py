@@ -293,3 +293,9 @@ def test_double_precision_walk_equals_levels(emu, golden_dir, case, monkeypatch)
 def test_parsimony_model_golden(emu, golden_dir):
     """device Fitch lengths == the reference's own parsimony-model likelihood (golden vectors from oracle/_ref/mb)"""
     ec.check_parsimony_model_golden(emu, golden_dir)
+
+
+def test_shared_table_walk(emu, oracle, golden_dir, monkeypatch):
+    """The opt-in general-state walk with LDS-staged, workgroup-shared transition tables (k_walkg_s) is parity-green: it is not
+    the product default because it measured slower than k_walkg (profiles/r04_walkgs_*.txt)."""
+    ec.check_shared_table_walk(emu, oracle, golden_dir, monkeypatch)
