@@ -1,0 +1,31 @@
+/*
+ * mbamd_std_glue.h -- standard (morphology) data on the engine: the MrBayes side.
+ *
+ * The reference keeps divisions of datatype=standard on its host kernels (CondLikeDown_Std / CondLikeRoot_Std /
+ * CondLikeScaler_Std / Likelihood_Std, src/likelihood.c:1920, 4496, 5547, 7359; selected at src/mcmc.c:18296-18306; never
+ * handed to BEAGLE, src/mcmc.c:5741-5771): the characters of one division have DIFFERENT state counts (2 ... 10, ordered or
+ * unordered), which the BEAGLE API -- one state count per instance -- cannot express.  This binding groups the compressed
+ * characters of a division by their transition-matrix class (state count x ordered / unordered: exactly the classes the
+ * reference's TiProbs_Std fills, src/likelihood.c:10066) and gives every class its own engine instance; the matrices stay the
+ * reference's own (TiProbs_Std runs unchanged on the host: a few dozen numbers per branch) and go down with
+ * beagleSetTransitionMatrix; conditional likelihoods, rescaling and the root integration run on the device; the correction for
+ * unobservable patterns (coding=variable / informative: the dummy characters in front of the division) is the reference's own
+ * formula over the site values the engine returns, as for restriction sites (src/mbbeagle.c:1322-1358).
+ *
+ * Served: equal state frequencies (symdirihyperpr=fixed(infinity), the default: SYMPI_EQUAL), any rate-category count.
+ * Not served (the division stays on the host kernels, with a printed reason): unequal / estimated state frequencies (beta
+ * categories for binary characters, per-character eigen-systems).
+ *
+ * Hook (applied to a temporary copy of src/likelihood.c by integration/mrbayes/patches/patch_std.py):
+ *     LaunchLogLikeForDivision:   if (MbamdStdServes (m) == YES) { MbamdStdLogLike (chain, d, lnL); return; }
+ */
+#ifndef MBAMD_STD_GLUE_H_
+#define MBAMD_STD_GLUE_H_
+
+#include "bayes.h"
+
+int  MbamdStdServes (ModelInfo *m);                    /* YES: this division's likelihood is computed by MbamdStdLogLike */
+void MbamdStdLogLike (int chain, int d, MrBFlt *lnL);  /* replaces the host pass of LaunchLogLikeForDivision for such a division */
+void MbamdStdFinalize (void);                          /* frees the engine instances (atexit) */
+
+#endif

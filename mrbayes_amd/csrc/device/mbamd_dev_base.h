@@ -21,6 +21,9 @@ typedef float f4 __attribute__((ext_vector_type(4)));
 
 __device__ __forceinline__ int mbd_frexp_exp(float v) { return __builtin_amdgcn_frexp_expf(v); }
 __device__ __forceinline__ float mbd_ldexp(float v, int e) { return __builtin_amdgcn_ldexpf(v, e); }
+// 2^e as a float for -126 <= e <= 127 (the exponent field written directly): multiplying by it is the exact scaling ldexp does,
+// one v_pk_mul_f32 per two values instead of two v_ldexp_f32
+__device__ __forceinline__ float mbd_pow2(int e) { return __builtin_bit_cast(float, (unsigned) (127 + e) << 23); }
 __device__ __forceinline__ int mbd_wave_index() { return __builtin_amdgcn_readfirstlane((int) (threadIdx.x >> 6)); }
 // the workgroup's dynamic LDS (one symbol per translation unit: every kernel sees the same array)
 template <class T> __device__ __forceinline__ T* mbd_dyn_lds()

@@ -60,6 +60,12 @@ template <int I, class O> __device__ __forceinline__ O& wg_pick(O& a, O& b, O& c
 }
 template <int I> struct WgInt { static constexpr int value = I; };
 
+// Second launch bound = waves per SIMD the register budget must allow.  Beyond 32 states "two" makes the register file ONE file
+// (206 registers, accumulators included) instead of 174 + 32 accumulation registers: a compact tip's factor is then written where
+// the product reads it, not copied in through v_accvgpr_write (codon 100 x 5 000: 0.195 -> 0.188 ms, profiles/r04_exp_walkgs.txt).
+#if !defined(MBAMD_WG_MINWAVES)
+#define MBAMD_WG_MINWAVES(SC) ((SC) > 32 ? 2 : 1)
+#endif
 // blockDim.x = 64 * W (W <= WMAX); grid = walkg_grid(ntiles, K); dynamic LDS = wg_lds_bytes(W, nslots, SC).
 // The operand pipeline works in CHUNKS: a job (one child factor, T MFMA steps per row tile) is CH chunks, an entry 2 CH,
 // and the operands of a chunk are fetched DEPTH chunks ahead into one of DEPTH + 1 rotating register sets.
@@ -67,7 +73,7 @@ template <int I> struct WgInt { static constexpr int value = I; };
 //   61 states: CH 2, DEPTH 1 -- a chunk is 31 MFMAs = 2000 cycles; two sets of 48 registers fit beside the 64 accumulators
 //              (whole jobs did not: the allocator shuttled LOADED operands through AccVGPRs, a vmcnt(0) per job).
 template <int SC, int WMAX, int CH, int DEPTH, class ARGS = WalkGArgs>
-__global__ void __launch_bounds__(64 * WMAX)
+__global__ void __launch_bounds__(64 * WMAX, MBAMD_WG_MINWAVES(SC))
 k_walkg(ARGS AA)
 {
     const WalkGArgs& A = wg_args(AA);
@@ -352,9 +358,10 @@ k_walkg(ARGS AA)
         const unsigned list = MBAMD_WG_LIST(ctl);
 #pragma unroll
         for (int q = 0; q < MBAMD_WG_MAXLISTS; ++q) cum_e[q] += (list == (unsigned) q) ? (e & wm) : 0;
+        const float sc = mbd_pow2(-e);
         vec ov[TV];
 #pragma unroll
-        for (int t = 0; t < TP; ++t) Vb::set(ov[t / V], t % V, scale_pow2(out[t], -e));   // (2^0 is exact: no branch)
+        for (int t = 0; t < TP; ++t) Vb::set(ov[t / V], t % V, out[t] * sc);   // (exact: |e| <= 126; 2^0 needs no branch)
 #if !defined(MBAMD_WGX_NOLDS)
         if (ctl & MBAMD_W4_KEEP) {
             vec* keep = reinterpret_cast<vec*>(reinterpret_cast<char*>(slots) + ((ctl >> 16) & 0xFFu) * SLOTB);

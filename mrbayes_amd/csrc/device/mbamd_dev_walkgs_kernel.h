@@ -46,7 +46,7 @@ template <int RG> __device__ __forceinline__ unsigned wgs_rot(unsigned d, int si
     return i * RG + ((d % RG + (unsigned) sign * 16u * i) & (unsigned) (RG - 1));
 }
 template <int PIECE, int G, int RG>
-__device__ __forceinline__ void wgs_dma_piece(const char* src, unsigned lds_dst, int wave, unsigned lane)
+__device__ __forceinline__ void wgs_dma_piece(const char* src, unsigned lds_dst, int wave, unsigned lane, bool rotate)
 {
     typedef WgsDmaPlan<PIECE, G> Pl;
 #pragma unroll
@@ -54,11 +54,11 @@ __device__ __forceinline__ void wgs_dma_piece(const char* src, unsigned lds_dst,
         int u = wave + i * G;
         if ((i + 1) * G > Pl::U) u = u < Pl::U ? u : u % Pl::U;
         if (Pl::N4 == 0 || u < Pl::N16) {
-            const unsigned d = (unsigned) u * 1024u;
-            walk4_dma(reinterpret_cast<const f4*>(src), wgs_rot<RG>(d + lane * 16u, -1), lds_dst + d);
+            const unsigned d = (unsigned) u * 1024u, dl = d + lane * 16u;
+            walk4_dma(reinterpret_cast<const f4*>(src), rotate ? wgs_rot<RG>(dl, -1) : dl, lds_dst + d);
         } else {
-            const unsigned d = (unsigned) Pl::N16 * 1024u + (unsigned) (u - Pl::N16) * 256u;
-            wgs_dma4(src, wgs_rot<RG>(d + lane * 4u, -1), lds_dst + d);
+            const unsigned d = (unsigned) Pl::N16 * 1024u + (unsigned) (u - Pl::N16) * 256u, dl = d + lane * 4u;
+            wgs_dma4(src, rotate ? wgs_rot<RG>(dl, -1) : dl, lds_dst + d);
         }
     }
 }
@@ -101,6 +101,8 @@ k_walkg_s(ARGS AA)
     static_assert(TP % CH == 0 && TPC % V == 0 && NAV % CH == 0 && (TPC * NT) % VA == 0 && D >= 1 && D <= 2 && D <= NQ, "chunk geometry");
     static_assert(VA % NT == 0, "the rows of one MFMA step lie in one register group of the table");
     static_assert(CH == 1 || NAP == TP * NT, "chunks cut the table at a row-pair boundary");
+    static_assert(SC / TW + 1 == CH, "one gather table (TW states) per chunk of a job");
+    static_assert((ACC < T ? ACC : T) * NT <= NAVC * VA, "a compact tip's gather rows lie in the head of its table");
     constexpr unsigned SLOTB = TP * 256u;
     const unsigned lane = threadIdx.x & 63, half = lane / TW, col = lane % TW;      // half: which of the KS states of a row
     const int wave = __builtin_amdgcn_readfirstlane((int) (threadIdx.x >> 6));
@@ -150,12 +152,17 @@ k_walkg_s(ARGS AA)
         walk4_dma_exps(reinterpret_cast<const int8_t*>(T0 + ((e.ctl & MBAMD_W4_TIP1) ? e.c1 : 0u)), col, dst + 256u);
         walk4_dma_exps(reinterpret_cast<const int8_t*>(T0 + ((e.ctl & MBAMD_W4_TIP2) ? e.c2 : 0u)), col, dst + 512u);
     };
-    // this wave's share of the table piece of chunk q (child q / CH, part q % CH) of entry e -> ring buffer rs
+    // this wave's share of the table piece of chunk q (child q / CH, part q % CH) of entry e -> ring buffer rs.  An interior child
+    // needs part q % CH of the MFMA operand table A' (staged rotated); a compact tip the head of its GATHER table q % CH -- the one
+    // for the states [TW (q % CH), TW (q % CH + 1)), whose rows are laid out so that a lane reads the factor registers of ITS
+    // pattern's state as whole 16-byte units of its column (staged as it is).
     auto table = [&](const Walk4Entry& e, int q, int rs) {
 #if defined(MBAMD_WGSX_NODMA)
         return;
 #endif
-        wgs_dma_piece<PIECE, G, RG>(Mk + ((q / CH) ? e.m2 : e.m1) + (size_t) (q % CH) * PIECE, ringLds + (unsigned) rs * PIECE, wave, lane);
+        const bool tipc = e.ctl & ((q / CH) ? MBAMD_W4_TIP2 : MBAMD_W4_TIP1);
+        const char* src = Mk + ((q / CH) ? e.m2 : e.m1) + (tipc ? (size_t) (1 + q % CH) * (NAP * 256) : (size_t) (q % CH) * PIECE);
+        wgs_dma_piece<PIECE, G, RG>(src, ringLds + (unsigned) rs * PIECE, wave, lane, !tipc);
     };
     // B rows of chunk q of entry e, if that child lives in HBM
     auto memrows = [&](const Walk4Entry& e, int q, vec (&bm)[TVC]) {
@@ -249,36 +256,26 @@ k_walkg_s(ARGS AA)
                         }
                 };
                 if (run && tip) {
-                    // the factor of a compact tip is ITS column of the staged table: register (it, r) = P(state -> s) for the state that
-                    // block row ACC it + r holds in this lane -- row (s / KS) NT + it, column rho(r) + 4 half + TW (s % KS) of the table
+                    // the factor of a compact tip: register (it, r) = P(state of block row ACC it + r in this lane -> s), i.e. element
+                    // r NT + it of the column KS (s % TW) + half of gather table s / TW -- VA consecutive elements per 16-byte unit
                     const unsigned s = ch ? s2 : s1;
                     if constexpr (h == 0) {
 #pragma unroll
                         for (int it = 0; it < NT; ++it)
 #pragma unroll
-                            for (int r = 0; r < ACC; ++r)
-                                f[it][r] = (s >= (unsigned) SC && (unsigned) (TW * it + KS * r) + half < (unsigned) SC && ACC * it + r < T) ? 1.0f : 0.0f;
+                            for (int r = 0; r < ACC; ++r) f[it][r] = 0.0f;
                     }
-                    const unsigned sk = s / KS;
-#if defined(MBAMD_WGSX_NOTIP)
-                    if (false) {
-#else
-                    if (s < (unsigned) SC && sk >= (unsigned) (h * TPC) && sk < (unsigned) ((h + 1) * TPC)) {
-#endif
-                        const unsigned n0 = (sk - (unsigned) (h * TPC)) * NT, rgi = n0 / VA;      // row group (rotated by rgi units of 16 bytes)
-                        const char* const rowp = piece + rgi * RG + (n0 % VA) * 4u;
-                        const unsigned cb = (4u * half + TW * (s % KS)) * (unsigned) (VA * 4) + 16u * rgi;
+                    if (s / TW == (unsigned) h) {
+                        const vecA* gp = reinterpret_cast<const vecA*>(piece + (KS * (s % TW) + half) * (unsigned) (VA * 4));
+                        constexpr int NR = (ACC < T ? ACC : T) * NT;              // elements a lane needs
 #pragma unroll
-                        for (int r = 0; r < ACC; ++r) {
-#if MBAMD_WG_TW == 32
-                            const int rho = (r & 3) + 8 * (r >> 2);
-#else
-                            const int rho = r;
-#endif
-                            const float* tp = reinterpret_cast<const float*>(rowp + ((cb + (unsigned) (rho * VA * 4)) & (unsigned) (RG - 1)));
+                        for (int g = 0; g < (NR + VA - 1) / VA; ++g) {
+                            const vecA v = gp[g * 64];
 #pragma unroll
-                            for (int it = 0; it < NT; ++it)
-                                if (ACC * it + r < T) f[it][r] = tp[it];
+                            for (int el = 0; el < VA; ++el) {
+                                const int n = g * VA + el, r = n / NT, it = n % NT;
+                                if (n < NR && ACC * it + r < T) f[it][r] = Va::get(v, el);
+                            }
                         }
                     }
                     if constexpr (q == NQ - 1) nn = walk4_load_entry(prog + j + 2);
@@ -317,9 +314,10 @@ k_walkg_s(ARGS AA)
                     const unsigned lq = MBAMD_WG_LIST(ctl);
 #pragma unroll
                     for (int qq = 0; qq < MBAMD_WG_MAXLISTS; ++qq) cum_e[qq] += (lq == (unsigned) qq) ? (e & wm) : 0;
+                    const float sc = mbd_pow2(-e);
                     vec ov[TV];
 #pragma unroll
-                    for (int t = 0; t < TP; ++t) Vb::set(ov[t / V], t % V, scale_pow2(out[t], -e));   // (2^0 is exact: no branch)
+                    for (int t = 0; t < TP; ++t) Vb::set(ov[t / V], t % V, out[t] * sc);   // (exact: |e| <= 126; 2^0 needs no branch)
                     if (ctl & MBAMD_W4_KEEP) {
                         vec* keep = reinterpret_cast<vec*>(reinterpret_cast<char*>(slots) + ((ctl >> 16) & 0xFFu) * SLOTB);
 #pragma unroll

@@ -11,6 +11,7 @@ namespace mbamd {
 typedef float4 f4;
 inline int mbd_frexp_exp(float v) { int e = 0; (void) frexpf(v, &e); return e; }
 inline float mbd_ldexp(float v, int e) { return ldexpf(v, e); }
+inline float mbd_pow2(int e) { return ldexpf(1.0f, e); }
 inline int mbd_wave_index() { return (int) (threadIdx.x >> 6); }
 template <class T> inline T* mbd_dyn_lds() { return reinterpret_cast<T*>(mbamd_emu_dyn_lds()); }
 // (threads of a block run one after the other between barriers: thread 0 comes first)

@@ -1,0 +1,91 @@
+"""Standard (morphology) data cases for tests/test_std_dropin.py and tools/gen_std_fixture.py: NEXUS texts with every parameter fixed
+and the tree given, so that generation 0 of `mcmc ngen=1` is a known-answer evaluation (the recipe of tools/gen_golden.py)."""
+import numpy as np
+
+from mrbayes_amd import tree as mbtree
+
+
+def nchar_of(row):
+    n, i = 0, 0
+    while i < len(row):
+        if row[i] in "{(":
+            i = row.index("}" if row[i] == "{" else ")", i)
+        n += 1
+        i += 1
+    return n
+
+
+def _tail(beagle, ngen, moves=False):
+    s = ""
+    if beagle:
+        s += " set usebeagle=yes beagledevice=gpu beagleprecision=single beaglescaling=%s;\n" % beagle
+    return s + " startvals tau=t V=t;\n mcmc ngen=%d nchains=1 nruns=1 samplefreq=%d printfreq=%d filename=x;\nend;\n" % (ngen, 1 if ngen < 10 else 20, max(1, ngen))
+
+
+def synthetic_nexus(ntax, nchar, beagle, seed=11, coding="variable", rates="gamma", maxstates=5, ordered=(), p_missing=0.04, p_poly=0.0, ngen=1, alpha="fixed(0.7)"):
+    """ntax x nchar characters with 2 ... maxstates states each (every state of a character occurs: MrBayes takes a character's
+    state count from the symbols it sees), a share of missing entries and of two-state polymorphisms."""
+    rng = np.random.default_rng(seed)
+    tr = mbtree.random_tree(ntax, 4, brlen=0.08)
+    names = ["t%d" % (i + 1) for i in range(ntax)]
+    nst = rng.integers(2, maxstates + 1, size=nchar)
+    M = np.zeros((ntax, nchar), dtype=int)
+    for c in range(nchar):
+        n = int(nst[c])
+        col = np.full(ntax, rng.integers(0, n))
+        flip = rng.random(ntax) < 0.35
+        col[flip] = rng.integers(0, n, size=int(flip.sum()))
+        where = rng.permutation(ntax)[:n]
+        for s in range(n):
+            if (col == s).sum() == 0:
+                col[where[s]] = s
+        for s in range(n):                       # (a forced state may have overwritten the only copy of another one)
+            if (col == s).sum() == 0:
+                col[(where[0] + 1 + s) % ntax] = s
+        M[:, c] = col
+    s = "#NEXUS\nbegin data;\n dimensions ntax=%d nchar=%d;\n format datatype=standard gap=- missing=?;\n matrix\n" % (ntax, nchar)
+    for i, nm in enumerate(names):
+        row = []
+        for c in range(nchar):
+            u = rng.random()
+            if u < p_missing:
+                row.append("?")
+            elif u < p_missing + p_poly and nst[c] > 2:
+                a, b = sorted(rng.choice(int(nst[c]), size=2, replace=False))
+                row.append("(%d%d)" % (a, b))
+            else:
+                row.append(str(M[i, c]))
+        s += "%s %s\n" % (nm, "".join(row))
+    s += ";\nend;\nbegin trees;\n tree t = [&U] %s\nend;\nbegin mrbayes;\n set autoclose=yes nowarnings=yes seed=3 swapseed=3 precision=15;\n" % tr.to_newick(names)
+    if ordered:
+        s += " ctype ordered: %s;\n" % " ".join(str(x) for x in ordered)
+    s += " lset coding=%s rates=%s%s;\n" % (coding, rates, " ngammacat=4" if rates == "gamma" else "")
+    if rates == "gamma":
+        s += " prset shapepr=%s;\n" % alpha
+    return s + _tail(beagle, ngen)
+
+
+SYNTHETIC = {
+    "mk_gamma_variable": dict(ntax=9, nchar=60),
+    "mk_equal_all": dict(ntax=12, nchar=120, coding="all", rates="equal"),
+    "ordered_polymorphic": dict(ntax=10, nchar=80, ordered=(3, 7, 11, 20), p_poly=0.03, maxstates=6),
+    "informative": dict(ntax=9, nchar=60, coding="informative"),
+    "binary_only": dict(ntax=14, nchar=90, maxstates=2),
+    "ten_states": dict(ntax=24, nchar=70, maxstates=10, p_missing=0.02),
+}
+BIG = dict(ntax=100, nchar=2000, maxstates=6, seed=5)      # 100 taxa x 2 000 characters, mixed 2-6 states, gamma-4
+
+CYNMIX_CONFIGS = {"mk_gamma_variable": dict(coding="variable", rates="gamma"), "mk_equal_informative": dict(coding="informative", rates="equal")}
+
+
+def cynmix_nexus(fix, beagle, coding="variable", rates="gamma", ngen=1):
+    ntax = len(fix["names"])
+    tr = mbtree.random_tree(ntax, 9, brlen=0.06)
+    s = "#NEXUS\nbegin data;\n dimensions ntax=%d nchar=166;\n format datatype=standard gap=- missing=?;\n matrix\n" % ntax
+    for nm, row in zip(fix["names"], fix["rows"]):
+        s += "%s %s\n" % (nm, row)
+    s += ";\nend;\nbegin trees;\n tree t = [&U] %s\nend;\nbegin mrbayes;\n set autoclose=yes nowarnings=yes seed=3 swapseed=3 precision=15;\n" % tr.to_newick(fix["names"])
+    s += " lset coding=%s rates=%s%s;\n" % (coding, rates, " ngammacat=4" if rates == "gamma" else "")
+    if rates == "gamma":
+        s += " prset shapepr=fixed(0.55);\n"
+    return s + _tail(beagle, ngen)

@@ -187,7 +187,7 @@ def test_patch_sites_are_pinned():
     if not os.path.isdir("/root/reference/src"):
         pytest.skip("reference sources not present (build container only)")
     import importlib.util
-    spec = importlib.util.spec_from_file_location("patch_reports", os.path.join(ROOT, "oracle", "patch_reports.py"))
+    spec = importlib.util.spec_from_file_location("patch_reports", os.path.join(ROOT, "integration", "mrbayes", "patches", "patch_reports.py"))
     mod = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(mod)
     with open("/root/reference/src/mcmc.c") as fh:

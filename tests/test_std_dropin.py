@@ -1,0 +1,176 @@
+"""Standard (morphology) data on the engine -- the *_Std family of the reference (CondLikeDown_Std src/likelihood.c:1920, CondLikeRoot_Std
+:4496, CondLikeScaler_Std :5547, Likelihood_Std :7359, TiProbs_Std :10066; selected at src/mcmc.c:18296-18306 and never handed to
+BEAGLE, src/mcmc.c:5741-5771: the characters of a division have different state counts).  The binding
+(integration/mrbayes/mbamd_std_glue.c, patches/patch_std.py; oracle/Makefile: ref-amd-std) gives every transition-matrix class of the
+division its own engine instance; the matrices stay the reference's own TiProbs_Std.
+
+Oracle: the reference's SCALAR build (oracle/_ref/mb_scalar) on the same start state -- every parameter fixed, the tree given -- to
+the digits of the .p file: Mk with and without gamma, the three codings, ordered characters, polymorphic entries, 2 ... 10 states; the
+morphology division of the reference's own examples/cynmix.nex (fixture tests/golden/std_cynmix.json, tools/gen_std_fixture.py); at
+100 taxa x 2 000 characters; and a default-move MCMC run whose sampled log-likelihoods must be the native chain's."""
+import json
+import os
+import subprocess
+import tempfile
+
+import pytest
+
+from tests import std_cases
+from tools import refrun
+
+REF = os.path.join(refrun.ROOT, "oracle", "_ref")
+GOLD = os.path.join(refrun.ROOT, "tests", "golden", "std_cynmix.json")
+
+
+def _need(*bins):
+    for b in bins:
+        if not os.path.exists(b):
+            pytest.skip("reference binaries not built (oracle/Makefile)")
+
+
+def _build_emu():
+    """CPU tests: the host-emulation engine and the binaries linked to it are built on demand (build container only)."""
+    if not os.path.isdir("/root/reference/src"):
+        pytest.skip("reference sources not present (build container only)")
+    from tests.hostemu import build_emu
+    build_emu.build()
+    subprocess.check_call(["make", "-C", os.path.join(refrun.ROOT, "oracle"), "_ref/mb_scalar", "_ref/mb_emu_std"], stdout=subprocess.DEVNULL)
+
+
+def _lnl(binary, text, env=None):
+    out, row = refrun.run_mb_with_samples(binary, text, env=env)
+    assert "Analysis completed" in out, out[-2000:]
+    return (row["LnL"] if "LnL" in row else row["lnLike"]), out
+
+
+def _served(out, marker):
+    assert "(standard data):" in out and "transition-matrix classes on" in out and marker in out, out[-1500:]
+
+
+def _check_synthetic(case, binary, marker, scalings=("always",)):
+    _need(binary, os.path.join(REF, "mb_scalar"))
+    kw = std_cases.SYNTHETIC[case]
+    want, _ = _lnl(os.path.join(REF, "mb_scalar"), std_cases.synthetic_nexus(beagle=None, **kw))
+    for scaling in scalings:
+        got, out = _lnl(binary, std_cases.synthetic_nexus(beagle=scaling, **kw))
+        _served(out, marker)
+        assert abs(got - want) <= 1e-5 * abs(want), (case, scaling, got, want)
+    # the switch: MBAMD_DEVICE_STD=0 leaves the division on the reference's own kernels (and prints the same number)
+    off, out = _lnl(binary, std_cases.synthetic_nexus(beagle="always", **kw), env={"MBAMD_DEVICE_STD": "0"})
+    assert "(standard data):" not in out and abs(off - want) <= 1e-5 * abs(want)
+
+
+def _check_cynmix(binary, marker):
+    _need(binary, os.path.join(REF, "mb_scalar"))
+    with open(GOLD) as fh:
+        fix = json.load(fh)
+    for key, kw in std_cases.CYNMIX_CONFIGS.items():
+        got, out = _lnl(binary, std_cases.cynmix_nexus(fix, "always", **kw))
+        _served(out, marker)
+        want = fix["lnL_mb_scalar"][key]
+        assert abs(got - want) <= 1e-5 * abs(want), (key, got, want)
+        live, _ = _lnl(os.path.join(REF, "mb_scalar"), std_cases.cynmix_nexus(fix, None, **kw))
+        assert abs(live - want) <= 1e-9 * abs(want)            # (the fixture is what the reference prints here, too)
+
+
+def _samples(binary, text, env=None):
+    with tempfile.TemporaryDirectory() as wd:
+        with open(os.path.join(wd, "run.nex"), "w") as fh:
+            fh.write(text)
+        res = subprocess.run([binary, "run.nex"], cwd=wd, capture_output=True, text=True, timeout=1800, env=dict(os.environ, **(env or {})))
+        assert "Analysis completed" in res.stdout, (res.stdout + res.stderr)[-2000:]
+        with open(os.path.join(wd, "x.p")) as fh:
+            lines = [l for l in fh.read().splitlines() if l and not l.startswith("[")]
+        cols = lines[0].split("\t")
+        return [dict(zip(cols, (float(x) for x in l.split("\t")))) for l in lines[1:]], res.stdout
+
+
+def _check_mcmc(binary, marker):
+    """Default moves (topology, branch lengths, the gamma shape) for 400 generations: accepted and rejected proposals flip the
+    reference's index tables, which name the engine's buffers -- the sampled log-likelihoods are the native chain's."""
+    _need(binary)
+    kw = dict(ntax=12, nchar=150, maxstates=5, p_poly=0.02, ngen=400, alpha="exponential(1.0)")
+    # (the oracle is the SAME binary with the binding switched off: a BEAGLE build of the reference consumes random numbers the
+    #  plain build does not, so mb_scalar walks another chain; generation 0 is pinned against mb_scalar by the other tests)
+    want, wout = _samples(binary, std_cases.synthetic_nexus(beagle="always", **kw), env={"MBAMD_DEVICE_STD": "0"})
+    assert "(standard data):" not in wout
+    got, out = _samples(binary, std_cases.synthetic_nexus(beagle="always", **kw))
+    _served(out, marker)
+    assert len(got) == len(want) >= 20
+    for a, b in zip(got, want):
+        ka = "LnL" if "LnL" in a else "lnLike"
+        assert a["Gen"] == b["Gen"] and abs(a[ka] - b[ka]) <= 1e-5 * abs(b[ka]) and abs(a["TL"] - b["TL"]) <= 1e-6 * b["TL"], (a, b)
+
+
+@pytest.mark.parametrize("case", sorted(std_cases.SYNTHETIC))
+def test_standard_data_on_emulated_engine(case):
+    _build_emu()
+    _check_synthetic(case, os.path.join(REF, "mb_emu_std"), "host emulation")
+
+
+def test_cynmix_morphology_on_emulated_engine():
+    _build_emu()
+    _check_cynmix(os.path.join(REF, "mb_emu_std"), "host emulation")
+
+
+def test_standard_data_mcmc_on_emulated_engine():
+    _build_emu()
+    _check_mcmc(os.path.join(REF, "mb_emu_std"), "host emulation")
+
+
+def test_unequal_frequencies_stay_on_the_host():
+    """symdirihyperpr other than fixed(infinity) (beta categories for binary characters, per-character eigen-systems): refused with a
+    printed reason, the reference's own kernels run."""
+    _build_emu()
+    b = os.path.join(REF, "mb_emu_std")
+    kw = std_cases.SYNTHETIC["mk_gamma_variable"]
+    text = std_cases.synthetic_nexus(beagle="always", **kw).replace(" lset coding", " prset symdirihyperpr=fixed(1.0);\n lset coding")
+    out, _ = refrun.run_mb_with_samples(b, text)
+    assert "stays on the host kernels" in out and "Analysis completed" in out, out[-1500:]
+
+
+def test_patch_site_is_pinned():
+    """The one edit patch_std.py makes must apply to the reference exactly once (an upstream change fails here, not at run time)."""
+    src = "/root/reference/src/likelihood.c"
+    if not os.path.exists(src):
+        pytest.skip("reference sources not present")
+    import importlib.util
+    import sys
+    pdir = os.path.join(refrun.ROOT, "integration", "mrbayes", "patches")
+    sys.path.insert(0, pdir)
+    try:
+        spec = importlib.util.spec_from_file_location("patch_std", os.path.join(pdir, "patch_std.py"))
+        mod = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(mod)
+        with open(src) as fh:
+            out = mod.patch(fh.read())
+    finally:
+        sys.path.remove(pdir)
+    assert out.count("MbamdStdServes (m) == YES") == 1 and '#include "mbamd_std_glue.h"' in out
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", sorted(std_cases.SYNTHETIC))
+def test_standard_data_on_mi355x(case):
+    _check_synthetic(case, os.path.join(REF, "mb_amd_std"), "gfx950", scalings=("always", "dynamic"))
+
+
+@pytest.mark.gpu
+def test_cynmix_morphology_on_mi355x():
+    _check_cynmix(os.path.join(REF, "mb_amd_std"), "gfx950")
+
+
+@pytest.mark.gpu
+def test_standard_data_100x2000_on_mi355x():
+    """100 taxa x 2 000 characters, 2 ... 6 states, gamma-4."""
+    b = os.path.join(REF, "mb_amd_std")
+    _need(b, os.path.join(REF, "mb_scalar"))
+    want, _ = _lnl(os.path.join(REF, "mb_scalar"), std_cases.synthetic_nexus(beagle=None, **std_cases.BIG))
+    got, out = _lnl(b, std_cases.synthetic_nexus(beagle="always", **std_cases.BIG))
+    _served(out, "gfx950")
+    assert abs(got - want) <= 1e-5 * abs(want), (got, want)
+
+
+@pytest.mark.gpu
+def test_standard_data_mcmc_on_mi355x():
+    _check_mcmc(os.path.join(REF, "mb_amd_std"), "gfx950")
