@@ -42,9 +42,18 @@ static int EnvOff (void)
     return (s != NULL && s[0] == '0') ? YES : NO;
 }
 
+int MbamdEngineRefuses (ModelInfo *m, int divisionNumber)
+{
+    if (m->correlation == NULL)
+        return (NO);
+    MrBayesPrint ("%s   Non-beagle version of conditional likelihood calculator will be used for division %d: the\n", spacer, divisionNumber);
+    MrBayesPrint ("%s   autocorrelated gamma model (rates=adgamma) reads per-category site likelihoods the BEAGLE path does not fill.\n", spacer);
+    return (YES);
+}
+
 int MbamdEngineServes (ModelInfo *m)
 {
-    if (EnvOff () == YES || m->gibbsGamma == YES)
+    if (EnvOff () == YES || m->gibbsGamma == YES || m->correlation != NULL)
         return (NO);
     if ((beagleFlags & BEAGLE_FLAG_PRECISION_DOUBLE) != 0)
         return (NO);                /* the double-precision engine has no final pass */

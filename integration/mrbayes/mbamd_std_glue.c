@@ -204,7 +204,14 @@ int MbamdStdServes (ModelInfo *m)
         MrBayesPrint ("%s   Division %d (standard data) stays on the host kernels: unequal state frequencies are not served by the engine\n", spacer, d+1);
         return (NO);
         }
-    if ((beagleFlags & BEAGLE_FLAG_PRECISION_DOUBLE) != 0)
+    if (m->printAncStates == YES || m->printSiteRates == YES)
+        {
+        /* (the reference's read-outs -- CondLikeUp_Std, PrintAncStates_Std, src/likelihood.c:4824, src/mcmc.c -- walk the HOST arrays
+           of every node, which a division on the engine does not fill) */
+        MrBayesPrint ("%s   Division %d (standard data) stays on the host kernels: ancestral states / site rates are read from host arrays\n", spacer, d+1);
+        return (NO);
+        }
+    if ((beagleFlags & BEAGLE_FLAG_PRECISION_DOUBLE) != 0 || tryToUseBEAGLE == NO)
         return (NO);
     if (Setup (m, d) == ERROR)
         {

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Apply the reports / covarion binding (integration/mrbayes/mbamd_reports_glue.h) to TEMPORARY copies of the reference's
-src/mcmc.c and src/mbbeagle.c -- test infrastructure: oracle/Makefile calls this for _ref/mb_amd_reports / _ref/mb_emu_reports.
+src/mcmc.c and src/mbbeagle.c (oracle/Makefile calls this for _ref/mb_amd_reports / _ref/mb_emu_reports / _ref/mb_*_full).
 
     patch_reports.py <reference src/mcmc.c>     <output mcmc.c>
     patch_reports.py <reference src/mbbeagle.c> <output mbbeagle.c>
@@ -34,6 +34,8 @@ def patch_mcmc(text):
                    "                if (m->printAncStates == YES || m->printSiteRates == YES || m->printPosSel ==YES || m->printSiteOmegas==YES)\n",
                    "                if (MbamdEngineServes (m) == YES)\n"
                    "                    m->useBeagle = YES;\n"
+                   "                else if (MbamdEngineRefuses (m, d+1) == YES)\n"
+                   "                    ;\n"
                    "                else if (m->printAncStates == YES || m->printSiteRates == YES || m->printPosSel ==YES || m->printSiteOmegas==YES)\n",
                    1, "BEAGLE refusal in InitChainCondLikes")
     # 2. the read-outs of the top node's conditional likelihoods (PrintStates: column headers; PrintStatesToFiles: values)

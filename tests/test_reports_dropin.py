@@ -182,6 +182,48 @@ def test_reports_binding_can_be_switched_off():
     assert "Non-beagle version of conditional likelihood calculator will be used" in out
 
 
+def _adgamma_nexus(beagle):
+    st = mbdata.synthetic_states(9, 240, 4, 21, 0.15, 0.02)
+    names = ["t%d" % (i + 1) for i in range(9)]
+    s = "#NEXUS\nbegin data;\n  dimensions ntax=9 nchar=240;\n  format datatype=dna gap=- missing=?;\n  matrix\n"
+    for n, row in zip(names, st):
+        s += "%s  %s\n" % (n, "".join((NUC + "-")[x] for x in row))
+    s += "  ;\nend;\nbegin trees;\n  tree t = [&U] %s\nend;\n" % mbtree.random_tree(9, 12, brlen=0.05).to_newick(names)
+    s += "begin mrbayes;\n  set autoclose=yes nowarnings=yes seed=12345 swapseed=12345 precision=15;\n  lset nst=1 rates=adgamma ngammacat=4;\n"
+    s += "  prset statefreqpr=fixed(equal) shapepr=fixed(0.6) ratecorrpr=fixed(0.3);\n"
+    if beagle:
+        s += "  set usebeagle=yes beagledevice=gpu beagleprecision=single beaglescaling=%s;\n" % beagle
+    return s + "  startvals tau=t V=t;\n  mcmc ngen=1 nchains=1 nruns=1 samplefreq=1 printfreq=1 diagnfreq=1 filename=rp;\nend;\n"
+
+
+def _adgamma_check(binary):
+    """rates=adgamma: the reference lets such a division take the BEAGLE path, where the HMM term is computed from rate probabilities
+    nobody filled (src/mcmc.c:5760-5771, 7452-7490).  A binary with the bindings keeps it on the host kernels and SAYS so; what it
+    prints is then what the reference's plain build prints."""
+    out, _, files = refrun.run_mb(binary, _adgamma_nexus("dynamic"), keep=("rp.p",))
+    assert "autocorrelated gamma model (rates=adgamma)" in out and "Non-beagle version" in out, out[-2500:]
+    # (the oracle is the reference's SIMD build, the kernels the binary falls back to: for this model the reference's own builds
+    #  disagree -- its scalar build prints -2122.38 where its FMA build prints -440.63 on this alignment, DESIGN.md section 8)
+    ref, _, rfiles = refrun.run_mb(refrun.REF_MB, _adgamma_nexus(None), keep=("rp.p",))
+    rows = []
+    for f in (files, rfiles):
+        lines = [l for l in f["rp.p"].splitlines() if l and not l.startswith("[")]
+        rows.append(dict(zip(lines[0].split("\t"), (float(x) for x in lines[1].split("\t")))))
+    assert abs(rows[0]["lnLike"] - rows[1]["lnLike"]) <= 1e-6 * abs(rows[1]["lnLike"]), rows
+
+
+def test_adgamma_is_kept_off_the_engine_and_says_so():
+    _build_emu()
+    _adgamma_check(REF_EMU_REPORTS)
+
+
+@pytest.mark.gpu
+def test_adgamma_is_kept_off_the_engine_on_mi355x():
+    if not (os.path.exists(REF_AMD_REPORTS) and os.path.exists(REF_SCALAR)):
+        pytest.skip("oracle/_ref/mb_amd_reports / mb_scalar were not built (need the reference sources at build time)")
+    _adgamma_check(REF_AMD_REPORTS)
+
+
 def test_patch_sites_are_pinned():
     """The patcher refuses a source in which one of its edit sites occurs a different number of times."""
     if not os.path.isdir("/root/reference/src"):
