@@ -179,10 +179,16 @@ def mpi_mcmc(nranks, emulate=False, full=False):
     if not (os.path.exists(launcher) and os.path.exists(binary)):
         return None
 
+    devices = {}                                          # MPI rank -> PCI bus ids of the GPUs its engine instances were created on
+
     def wall(text):
-        out, w = refrun.run_mb(binary, text, timeout=3000, argv_prefix=[launcher, "-n", str(nranks)])
+        out, w = refrun.run_mb(binary, text, timeout=3000, argv_prefix=[launcher, "-n", str(nranks)], env={"MBAMD_REPORT_DEVICE": "1"})
         if "Analysis completed" not in out:
             raise RuntimeError(out[-1500:])
+        for line in out.splitlines():
+            if line.startswith("[mbamd] instance on device"):
+                f = line.split()
+                devices.setdefault(f[8], set()).add(f[6])
         return w
 
     def rate(nex_of, lo, hi):
@@ -215,7 +221,9 @@ def mpi_mcmc(nranks, emulate=False, full=False):
         r = rate(lambda ngen: refrun.model_nexus("m3", st5, tr5, ngen=ngen, beagle="dynamic").replace("nchains=1 nruns=1", "nchains=4 nruns=2"), lo, hi)
         cases.append({"workload": label, "chains": 8, "generations_per_s": r, "ngen": [lo, hi]})
     return {"ranks": nranks, "launcher": "oracle/_ref/mbamd_mpirun -n %d oracle/_ref/%s" % (nranks, os.path.basename(binary)),
-            "gpu_of_rank": "(instance + rank) mod visible GPUs (reference src/mbbeagle.c:201-207)", "cases": cases,
+            "gpu_of_rank": "(instance + rank) mod visible GPUs (reference src/mbbeagle.c:201-207)",
+            "devices_of_rank": {r: sorted(v) for r, v in sorted(devices.items())},
+            "distinct_devices": len(set(x for v in devices.values() for x in v)), "cases": cases,
             "unit": "generations/s (all chains advance one generation)"}
 
 
@@ -240,6 +248,7 @@ def measure(args, cfg, steps, warmup, rank, local_rank, world, dist, device, emu
         div.tree.length = [l * (0.8 + 0.4 * rng.random()) for l in div.tree.length]
     bd = lk.BeagleDivision(div, lib, nchains=1, scaling=lk.MB_BEAGLE_SCALE_ALWAYS, resource=0 if emulate else local_rank)
     impl = bd.inst.details.implName.decode()
+    inst_devices = [lib.pci_bus_id(r) for r in bd.inst.devices()]      # one per child engine (MBAMD_SHARD: one per GPU)
     lnl0 = bd.LogLike(0)
     ref_lnl = gold["lnL"]["fp64"]
     ablation = bool(os.environ.get("MBAMD_BENCH_NO_ASSERT"))      # timing experiments with deliberately wrong kernels (tools/exp_*.sh)
@@ -365,6 +374,7 @@ def measure(args, cfg, steps, warmup, rank, local_rank, world, dist, device, emu
                    "units_per_step": units_per_step, "lnL": lnl,
                    "lnL_reference_fp64": ref_lnl if pinned else None,
                    "lnL_pinned": bool(pinned)},
+        "instance_devices": inst_devices,
         "pattern_lnl_per_s": P * world * steps / dt,
         "full_tree_evals_per_s": world * steps / dt,
         "roofline": roof,
@@ -471,14 +481,19 @@ def pattern_sharded(args, cfg, steps, warmup, rank, local_rank, world, dist, dev
     bd.AcceptMove(0)
     evals = [lk.record_evaluation(bd), lk.record_evaluation(bd)]
     buf = torch.zeros(1, dtype=torch.float64, device=device)
+    # The block's sum never visits the host on its own: the evaluation is left pending (mbamdSetDeferredResult), the engine adds its
+    # block sums up on the device into `buf` and orders torch's stream behind that (mbamdReduceLogLikelihood), RCCL all-reduces `buf`,
+    # and the ONE host read of a step is the chain's -- it needs the number before it can accept or reject.
+    bd.inst.set_deferred_result(True)
+    stream_handle = 0 if emulate else torch.cuda.current_stream(device).cuda_stream
 
     def step(i):
-        rc, lnl = evals[i & 1].run()
+        rc, _ = evals[i & 1].run()
         if rc != 0:
             raise RuntimeError("evaluation failed with code %d" % rc)
-        buf[0] = lnl
-        dist.all_reduce(buf, op=dist.ReduceOp.SUM)       # the per-generation exchange: one double
-        return float(buf.item())                         # (the chain needs the value before it can accept or reject)
+        bd.inst.reduce_log_likelihood(buf.data_ptr(), stream_handle)
+        dist.all_reduce(buf, op=dist.ReduceOp.SUM)       # the per-generation exchange: one double, device to device
+        return float(buf.item())
 
     def fence():
         dist.barrier()
@@ -497,6 +512,7 @@ def pattern_sharded(args, cfg, steps, warmup, rank, local_rank, world, dist, dev
     tmax = torch.tensor([dt], dtype=torch.float64, device=device)
     dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     dt = float(tmax.item())
+    bd.inst.set_deferred_result(False)
     bd.finalize()
     if rank != 0:
         return None
@@ -507,6 +523,7 @@ def pattern_sharded(args, cfg, steps, warmup, rank, local_rank, world, dist, dev
     return {"what": "ONE chain, site patterns in %d contiguous blocks (one per rank / GPU), all-reduce(SUM) of one double per evaluation over %s"
                     % (world, "gloo (EMULATED)" if emulate else "RCCL"),
             "scaling": "strong", "n_gpus": world, "steps": steps, "ms_per_step": dt / steps * 1e3,
+            "host_synchronisations_per_step": 1,
             "value": (N - 2) * P * steps / dt / 1e6, "unit": "M updates/s",
             "lnL": total, "lnL_reference_fp64": ref, "lnL_pinned": True}
 
@@ -575,9 +592,23 @@ def main():
             out["config"]["chains"] = 1
             out["config"]["parallelism"] = "site-pattern shards of one chain over %d GPUs inside one instance (MBAMD_SHARD)" % world
             out["config"]["lnL_pinned"] = False
+            if len(set(out["instance_devices"])) != world and not emulate:
+                raise SystemExit("bench.py --shard: the %d shards of the instance sit on %s" % (world, out["instance_devices"]))
     else:
         out = measure(args, args.config, args.steps, args.warmup, rank, local_rank, world, dist, device, emulate, lib,
                       not args.no_cpu_baseline)
+    if world > 1 and dist is not None:
+        # which physical GPU every rank computes on (PCI bus id of its resource): a scaling line whose ranks share a device is
+        # not a scaling line -- refuse it instead of reporting it
+        mine = (("emu:rank%d" % rank) if emulate else lib.pci_bus_id(local_rank)).encode()[:63]
+        ids = torch.zeros(world, 64, dtype=torch.uint8, device=device)
+        ids[rank, :len(mine)] = torch.tensor(list(mine), dtype=torch.uint8, device=device)
+        dist.all_reduce(ids, op=dist.ReduceOp.SUM)
+        names = [bytes(int(x) for x in row if int(x) != 0).decode() for row in ids.cpu()]
+        if len(set(names)) != world and not emulate:
+            raise SystemExit("bench.py --gpus %d: ranks share a device (%s): refusing to report a scaling number" % (world, names))
+        if rank == 0 and out is not None:
+            out["ranks_devices"] = names
     if world > 1 and not args.shard and dist is not None:
         try:                                     # (collective: every rank takes part; failures are reported, not fatal)
             ps = pattern_sharded(args, args.config, args.steps, args.warmup, rank, local_rank, world, dist, device, emulate, lib)

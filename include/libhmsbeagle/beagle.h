@@ -370,6 +370,16 @@ BEAGLE_DLLEXPORT int mbamdSetDeferredResult(int instance, int enable);
  * in the environment when the instance is created); out: [steps][8][3] 64-bit stamps */
 BEAGLE_DLLEXPORT int mbamdWalkTrace(int instance, long long* out, int maxSteps, int* outSteps, int* outWaves);
 BEAGLE_DLLEXPORT int mbamdFetchLogLikelihood(int instance, double* outSumLogLikelihood);
+/* The pending (deferred) sum, added up ON THE DEVICE into *deviceOut (device memory of the instance's GPU) in a fixed order, after
+ * the integration that produced it; `waitingStream` (a hipStream_t, may be null) is made to wait for it.  No host synchronisation:
+ * a multi-GPU client all-reduces deviceOut over RCCL on its own stream and reads one number per step (bench.py, pattern_sharded).
+ * The value stays pending: mbamdFetchLogLikelihood still returns it. */
+BEAGLE_DLLEXPORT int mbamdReduceLogLikelihood(int instance, double* deviceOut, void* waitingStream);
+/* Which GPUs: the PCI bus id ("0000:c1:00.0") of a resource of beagleGetResourceList, and the resource numbers of the child engines
+ * of an instance (a plain instance: one; a sharded one: a device per shard) -- so that a multi-GPU driver can PROVE that its ranks /
+ * shards sit on different devices.  mbamdGetInstanceDevices returns the number of children (<= maxCount written). */
+BEAGLE_DLLEXPORT int mbamdGetResourcePciBusId(int resource, char* out, int length);
+BEAGLE_DLLEXPORT int mbamdGetInstanceDevices(int instance, int* outResources, int maxCount);
 
 #ifdef __cplusplus
 }

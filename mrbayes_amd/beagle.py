@@ -63,7 +63,7 @@ EXPORTS = [
     "beagleAccumulateScaleFactors", "beagleRemoveScaleFactors", "beagleResetScaleFactors", "beagleCopyScaleFactors",
     "beagleGetScaleFactors", "beagleCalculateRootLogLikelihoods", "beagleCalculateEdgeLogLikelihoods",
     "beagleGetSiteLogLikelihoods", "mbamdSynchronize", "mbamdGetLastError", "mbamdKernelTiming",
-    "mbamdGetKernelTiming", "mbamdGetStepTiming", "mbamdUpdateFinalPartials", "mbamdGetScaledPartials", "mbamdSetKernelPath", "mbamdSetDeferredResult", "mbamdFetchLogLikelihood",
+    "mbamdGetKernelTiming", "mbamdGetStepTiming", "mbamdUpdateFinalPartials", "mbamdGetScaledPartials", "mbamdSetKernelPath", "mbamdSetDeferredResult", "mbamdFetchLogLikelihood", "mbamdReduceLogLikelihood", "mbamdGetResourcePciBusId", "mbamdGetInstanceDevices",
     "mbamdGetScaleExponents", "mbamdGetChildCount", "mbamdSetRateMatrices", "mbamdSetRateMatricesFrom",
     # BEAGLE v3 surface (multi-partition instances, resource benchmark)
     "beagleGetBenchmarkedResourceList", "beagleSetCPUThreadCount", "beagleSetPatternPartitions",
@@ -139,12 +139,23 @@ class BeagleLibrary:
         L.mbamdUpdateFinalPartials.argtypes = [C.c_int, C.c_void_p, C.c_int]
         L.mbamdGetScaledPartials.argtypes = [C.c_int, C.c_int, C.c_int, C.POINTER(C.c_float), C.POINTER(C.c_float)]
         L.mbamdFetchLogLikelihood.argtypes = [C.c_int, _dp]
+        L.mbamdReduceLogLikelihood.argtypes = [C.c_int, C.c_void_p, C.c_void_p]
+        L.mbamdGetResourcePciBusId.argtypes = [C.c_int, C.c_char_p, C.c_int]
+        L.mbamdGetInstanceDevices.argtypes = [C.c_int, _ip, C.c_int]
 
     def version(self) -> str:
         return self.lib.beagleGetVersion().decode()
 
     def last_error(self) -> str:
         return self.lib.mbamdGetLastError().decode()
+
+    def pci_bus_id(self, resource: int) -> str:
+        """PCI bus id of a resource ("0000:c1:00.0"): which physical GPU a rank / shard runs on."""
+        buf = C.create_string_buffer(64)
+        rc = self.lib.mbamdGetResourcePciBusId(resource, buf, 64)
+        if rc != 0:
+            raise BeagleError(rc, "mbamdGetResourcePciBusId", self.last_error())
+        return buf.value.decode()
 
     def resources(self):
         rl = self.lib.beagleGetResourceList().contents
@@ -431,6 +442,16 @@ class BeagleInstance:
 
     def set_deferred_result(self, enable: bool):
         self._chk(self.lib.mbamdSetDeferredResult(self.id, 1 if enable else 0), "mbamdSetDeferredResult")
+
+    def reduce_log_likelihood(self, device_ptr, waiting_stream=0):
+        """The pending sum added up on the device into the double at `device_ptr`; `waiting_stream` (raw hipStream_t) waits for it."""
+        self._chk(self.lib.mbamdReduceLogLikelihood(self.id, C.c_void_p(device_ptr), C.c_void_p(waiting_stream)), "mbamdReduceLogLikelihood")
+
+    def devices(self):
+        """Resource numbers of the engine(s) behind this instance (one per shard of a sharded instance)."""
+        out = (C.c_int * 64)()
+        n = self.lib.mbamdGetInstanceDevices(self.id, C.cast(out, _ip), 64)
+        return [int(out[i]) for i in range(min(n, 64))]
 
     def fetch_log_likelihood(self):
         out = C.c_double(0.0)

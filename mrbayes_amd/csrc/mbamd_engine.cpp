@@ -334,6 +334,10 @@ struct Instance {
         HIP_TRY(hipEventRecord(e1, stream));
         spans.emplace_back(spanEv0, e1);
         spanOpen = false;
+        if (spans.size() > 4096) {                   // a client that never polls: fold the finished spans into the running total
+            HIP_TRY(hipStreamSynchronize(stream));
+            spanFold();
+        }
         return BEAGLE_SUCCESS;
     }
     int spanFold()                   // (stream synchronised by the caller)
@@ -349,6 +353,7 @@ struct Instance {
     }
 
     bool deferred = false, pendingResult = false;
+    hipEvent_t reduceEvent{};        // mbamdReduceLogLikelihood: orders a client's stream behind the device-side sum
 
     std::vector<std::pair<Plan*, int>> pending;   // deferred general-path lists (plan, cumulative scale index or -1)
     std::vector<Plan*> plans;        // small LRU cache of compiled operation lists
@@ -586,6 +591,12 @@ int Instance::create(int tipCount_, int partialsBufferCount, int compactBufferCo
 #endif
     envVerbose = std::getenv("MBAMD_VERBOSE") != nullptr;
     envTrace = std::getenv("MBAMD_WALK_TRACE") != nullptr;
+    if (std::getenv("MBAMD_REPORT_DEVICE")) {    // one line per instance: which physical GPU (multi-rank drivers collect them: bench.py mpi_mcmc)
+        char bus[64] = "?";
+        if (hipDeviceGetPCIBusId(bus, (int) sizeof bus, device) != hipSuccess) (void) hipGetLastError();
+        const char* mr = std::getenv("MBAMD_MPI_RANK");
+        std::fprintf(stderr, "[mbamd] instance on device %d pci %s mpi-rank %s\n", device, bus, mr ? mr : "-");
+    }
     noSiteHost = std::getenv("MBAMD_NO_SITE_HOST") != nullptr;
     partialsFloats = s4 ? (size_t) K * Ppad * 4 : (size_t) K * S * Ppad;
     matrixFloats = (size_t) K * SP * SP + (mfma ? (size_t) K * NT * T * 64 : 0);
@@ -711,6 +722,9 @@ void Instance::destroy()
     if (h_site) (void) hipHostFree(h_site);
     if (stage) (void) hipHostFree(stage);
     for (auto& ev : events) { (void) hipEventDestroy(ev.first); (void) hipEventDestroy(ev.second); }
+    for (auto& ev : spans) { (void) hipEventDestroy(ev.first); (void) hipEventDestroy(ev.second); }
+    if (spanOpen) (void) hipEventDestroy(spanEv0);
+    if (reduceEvent) (void) hipEventDestroy(reduceEvent);
     (void) hipStreamDestroy(stream);
 }
 
@@ -939,6 +953,10 @@ int Instance::setRateMatrices(int first, int count, const double* q, const doubl
     if (count <= 0) return BEAGLE_SUCCESS;
     if (first < 0 || first + count > nEigen) return fail(BEAGLE_ERROR_OUT_OF_RANGE, "mbamdSetRateMatrices: eigen index");
     if (warmFirst >= 0 && warmFirst + count > nEigen) return fail(BEAGLE_ERROR_OUT_OF_RANGE, "mbamdSetRateMatricesFrom: warm-start eigen index");
+    // (a block reads its source's V before it writes its own: the same range is fine, a shifted overlap would read a buffer a
+    //  neighbouring block of the same launch is writing)
+    if (warmFirst >= 0 && warmFirst != first && warmFirst < first + count && first < warmFirst + count)
+        return fail(BEAGLE_ERROR_OUT_OF_RANGE, "mbamdSetRateMatricesFrom: the warm-start range overlaps the destination range with a shift");
     if (S > 64) return fail(BEAGLE_ERROR_NO_IMPLEMENTATION, "mbamdSetRateMatrices: more than 64 states");
     for (int i = 0; i < S; ++i)
         if (!(pi[i] > 0.0)) return fail(BEAGLE_ERROR_NO_IMPLEMENTATION, "mbamdSetRateMatrices: a state frequency is not positive (no symmetric form)");
@@ -971,21 +989,23 @@ int Instance::setRateMatrices(int first, int count, const double* q, const doubl
         jobs[i].mode = mode & 1;
         jobs[i].pad_ = 0;
     }
-    for (int i = 0; i < count; ++i) {
-        const int w = jobs[i].warm ? eigenWarm[warmFirst + i] + 1 : 0;
-        eigenWarm[first + i] = w;
-        if (mode & 2) eigenShield[first + i] = 1;
-    }
+    std::vector<int> warmAfter(count);
+    for (int i = 0; i < count; ++i) warmAfter[i] = jobs[i].warm ? eigenWarm[warmFirst + i] + 1 : 0;
     const EigenJob* djobs = nullptr;
     rc = stageDirect(jobs.data(), sizeof(EigenJob) * count, (const void**) &djobs);
     if (rc) return rc;
-    static bool ldsRaised = false;
-    if (!ldsRaised) {
+    static std::vector<char> ldsRaised(64, 0);                      // per device: the attribute belongs to the device's code object
+    if (device >= 0 && device < (int) ldsRaised.size() && !ldsRaised[device]) {
         if (hipFuncSetAttribute((const void*) k_eigen_reversible, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) (void) hipGetLastError();
-        ldsRaised = true;
+        ldsRaised[device] = 1;
     }
     MBAMD_LAUNCH_BARRIER(k_eigen_reversible, (unsigned) count, 256, eigen_lds_doubles(S) * sizeof(double), stream, djobs, S, 30);
     HIP_TRY(hipGetLastError());
+    // bookkeeping only once the launch is in the stream: a failure above leaves the buffers "cold" and unshielded
+    for (int i = 0; i < count; ++i) {
+        eigenWarm[first + i] = warmAfter[i];
+        eigenShield[first + i] = (mode & 2) ? 1 : 0;                // (a rewrite without the shield bit clears a stale shield)
+    }
     return BEAGLE_SUCCESS;
 }
 
@@ -3908,6 +3928,40 @@ int mbamdSetDeferredResult(int instance, int enable)
     if (in->facade()) return enable ? fail(BEAGLE_ERROR_NO_IMPLEMENTATION, "mbamdSetDeferredResult: not on a partitioned / sharded instance") : BEAGLE_SUCCESS;
     in->deferred = enable != 0;
     return BEAGLE_SUCCESS;
+}
+int mbamdReduceLogLikelihood(int instance, double* deviceOut, void* waitingStream)
+{
+    GET_INSTANCE(instance);
+    if (in->f64 || in->facade()) return fail(BEAGLE_ERROR_NO_IMPLEMENTATION, "mbamdReduceLogLikelihood: plain single-precision instances only");
+    if (!in->pendingResult) return fail(BEAGLE_ERROR_GENERAL, "no log-likelihood pending");
+    if (deviceOut == nullptr) return fail(BEAGLE_ERROR_OUT_OF_RANGE, "mbamdReduceLogLikelihood: null output");
+    MBAMD_LAUNCH_BARRIER(k_sum_block_sums, 1u, 256, 256 * sizeof(double), in->stream, (const double*) in->h_sums_dev, in->nblocks, deviceOut);
+    HIP_TRY(hipGetLastError());
+    if (waitingStream != nullptr) {
+        if (!in->reduceEvent) HIP_TRY(hipEventCreateWithFlags(&in->reduceEvent, hipEventDisableTiming));
+        HIP_TRY(hipEventRecord(in->reduceEvent, in->stream));
+        hipStream_t ws{};
+        std::memcpy(&ws, &waitingStream, std::min(sizeof ws, sizeof waitingStream));
+        HIP_TRY(hipStreamWaitEvent(ws, in->reduceEvent, 0));
+    }
+    return BEAGLE_SUCCESS;
+}
+int mbamdGetResourcePciBusId(int resource, char* out, int length)
+{
+    if (out == nullptr || length < 2) return fail(BEAGLE_ERROR_OUT_OF_RANGE, "mbamdGetResourcePciBusId: buffer");
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || resource < 0 || resource >= n) return fail(BEAGLE_ERROR_OUT_OF_RANGE, "mbamdGetResourcePciBusId: resource");
+    HIP_TRY(hipDeviceGetPCIBusId(out, length, resource));
+    return BEAGLE_SUCCESS;
+}
+int mbamdGetInstanceDevices(int instance, int* outResources, int maxCount)
+{
+    GET_INSTANCE_NOFLUSH(instance);
+    if (in->f64) { if (outResources && maxCount > 0) outResources[0] = in->device; return 1; }
+    if (!in->facade()) { if (outResources && maxCount > 0) outResources[0] = in->device; return 1; }
+    int n = 0;
+    for (const Instance::Child& c : in->children) { if (outResources && n < maxCount) outResources[n] = c.in->device; ++n; }
+    return n;
 }
 int mbamdFetchLogLikelihood(int instance, double* outSumLogLikelihood)
 {

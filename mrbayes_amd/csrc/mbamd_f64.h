@@ -822,10 +822,10 @@ public:
     {
         auto kern = k64_walk4<KF>;
         const size_t lds = ((size_t) nslots * KF * 4 * 64 + (size_t) 2 * KF * 64) * sizeof(double);
-        static bool raised = false;
-        if (!raised) {
+        static char raised[64] = {0};                // per device (and per KF: a static of this template instance)
+        if (device >= 0 && device < 64 && !raised[device]) {
             if (hipFuncSetAttribute((const void*) kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) (void) hipGetLastError();
-            raised = true;
+            raised[device] = 1;
         }
         MBAMD_LAUNCH_BARRIER(kern, (unsigned) (Ppad / 64), 64 * KF, lds, stream, prog, entries, Ppad, nslots, cum);
     }

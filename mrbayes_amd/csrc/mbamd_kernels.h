@@ -122,6 +122,23 @@ __device__ __forceinline__ float scale_pow2(float v, int neg_e)
 
 __device__ __forceinline__ float max4(f4 v) { return fmaxf(fmaxf(v.x, v.y), fmaxf(v.z, v.w)); }
 
+// the block sums an integration kernel wrote (pinned host memory, read through its device address) -> one double in device memory,
+// in a fixed order: thread t adds the sums t, t + 256, ..., then a tree over the 256 partial sums (mbamdReduceLogLikelihood)
+__global__ void __launch_bounds__(256)
+k_sum_block_sums(const double* __restrict__ sums, int n, double* __restrict__ out)
+{
+    double* part = mbd_dyn_lds<double>();        // 256 doubles of dynamic LDS
+    double s = 0.0;
+    for (int i = threadIdx.x; i < n; i += 256) s += sums[i];
+    part[threadIdx.x] = s;
+    MBAMD_SYNC();
+    for (int w = 128; w > 0; w >>= 1) {
+        if ((int) threadIdx.x < w) part[threadIdx.x] += part[threadIdx.x + w];
+        MBAMD_SYNC();
+    }
+    if (threadIdx.x == 0) *out = part[0];
+}
+
 }  // namespace mbamd
 #include "mbamd_walk4.h"
 #include "mbamd_walkg.h"

@@ -91,6 +91,10 @@ inline hipError_t hipDeviceSynchronize() { return hipSuccess; }
 inline hipError_t hipEventCreate(hipEvent_t* e) { *e = new EmuEvent; return hipSuccess; }
 inline hipError_t hipEventDestroy(hipEvent_t e) { delete e; return hipSuccess; }
 inline hipError_t hipEventRecord(hipEvent_t e, hipStream_t) { e->t = std::chrono::steady_clock::now(); return hipSuccess; }
+#define hipEventDisableTiming 2
+inline hipError_t hipEventCreateWithFlags(hipEvent_t* e, unsigned) { *e = new EmuEvent; return hipSuccess; }
+inline hipError_t hipStreamWaitEvent(hipStream_t, hipEvent_t, unsigned) { return hipSuccess; }
+inline hipError_t hipDeviceGetPCIBusId(char* out, int len, int dev) { std::snprintf(out, (size_t) len, "emu:%02x:00.0", dev); return hipSuccess; }
 inline hipError_t hipEventSynchronize(hipEvent_t) { return hipSuccess; }
 inline hipError_t hipEventElapsedTime(float* ms, hipEvent_t a, hipEvent_t b) {
     *ms = std::chrono::duration<float, std::milli>(b->t - a->t).count(); return hipSuccess; }

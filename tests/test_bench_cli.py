@@ -35,16 +35,20 @@ def test_two_ranks():
     assert res.returncode == 0, (res.stdout + res.stderr)[-3000:]
     d = _json_line(res.stdout)
     assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["config"]["chains"] == 2
+    # the line says which device every rank computed on (PCI bus id on a GPU box; bench.py refuses to report when two ranks share one)
+    assert d["ranks_devices"] == ["emu:rank0", "emu:rank1"] and len(d["instance_devices"]) == 1
     # one chain with its site patterns split over the two ranks, the block sums all-reduced (gloo here, RCCL on GPUs): the total
     # is the unsharded log-likelihood (asserted inside bench.py against an unsharded evaluation / the reference's value)
     ps = d["pattern_sharded"]
     assert "error" not in ps, ps
     assert ps["scaling"] == "strong" and ps["n_gpus"] == 2 and ps["value"] > 0 and ps["lnL_pinned"]
+    assert ps["host_synchronisations_per_step"] == 1        # the block sums meet on the device (mbamdReduceLogLikelihood + all-reduce)
     assert abs(ps["lnL"] - ps["lnL_reference_fp64"]) <= 2e-6 * abs(ps["lnL"])
     # the reference's own MPI build on the shim, two ranks (only where the reference binaries were built)
     if os.path.exists(os.path.join(ROOT, "oracle", "_ref", "mb_emu_mpi")) and os.path.exists(os.path.join(ROOT, "oracle", "_ref", "mbamd_mpirun")):
         m = d["mpi_mcmc"]
         assert m["ranks"] == 2 and m["cases"][0]["generations_per_s"] > 0, m
+        assert set(m["devices_of_rank"]) == {"0", "1"} and m["distinct_devices"] >= 1, m      # every rank's engine reported its device
 
 
 def test_two_ranks_sharded():
@@ -57,3 +61,4 @@ def test_two_ranks_sharded():
     assert res.returncode == 0, (res.stdout + res.stderr)[-3000:]
     d = _json_line(res.stdout)
     assert d["n_gpus"] == 2 and d["scaling"] == "strong" and d["config"]["chains"] == 1 and "shards" in d["config"]["parallelism"]
+    assert len(d["instance_devices"]) == 2 and len(d["ranks_devices"]) == 2       # one child engine per shard, each reporting its device
