@@ -158,10 +158,10 @@ def test_ambiguity_codes_on_mi355x():
 
 
 # ---- partitioned analysis: one engine instance per division, both alive in the same MrBayes process -------------
-def _partitioned_nexus(beagle, ngen=1, same_shape=False):
+def _partitioned_nexus(beagle, ngen=1, same_shape=False, ntaxa=16, nsites=600, first=350):
     """same_shape: both divisions GTR+G4 (same state / category / eigen-part counts) -- what MrBayes' v3 build merges into
     ONE multi-partition instance (reference src/mbbeagle.c:1519-1546); otherwise GTR+G4 next to HKY+I."""
-    st, tr = _case(16, 600, 0.02)
+    st, tr = _case(ntaxa, nsites, 0.02)
     names = ["t%d" % (i + 1) for i in range(st.shape[0])]
     seqs = ["".join("ACGT-"[x] for x in row) for row in st]
     s = "#NEXUS\nbegin data;\n  dimensions ntax=%d nchar=%d;\n" % (len(names), len(seqs[0]))
@@ -169,7 +169,7 @@ def _partitioned_nexus(beagle, ngen=1, same_shape=False):
     for n, q in zip(names, seqs):
         s += "%s  %s\n" % (n, q)
     s += "  ;\nend;\nbegin mrbayes;\n  set autoclose=yes nowarnings=yes seed=12345 swapseed=12345 precision=15;\n"
-    s += "  charset first = 1-350;\n  charset second = 351-600;\n  partition genes = 2: first, second;\n  set partition=genes;\n"
+    s += "  charset first = 1-%d;\n  charset second = %d-%d;\n  partition genes = 2: first, second;\n  set partition=genes;\n" % (first, first + 1, nsites)
     if same_shape:
         s += "  lset applyto=(all) nst=6 rates=gamma ngammacat=4;\n"
     else:

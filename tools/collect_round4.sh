@@ -1,0 +1,10 @@
+#!/bin/bash
+# gpurun_out/ -> profiles/r04_* (run in the build container after tools/gpu_round4.sh came back)
+cd "$(dirname "$0")/.."
+cp gpurun_out/bench_default.json profiles/r04_bench_default.json
+for c in c2 c3 c4 c5; do
+  cp gpurun_out/prof_${c}_summary.txt profiles/r04_${c}_kernel_stats.txt
+  cp gpurun_out/prof_${c}_timeline.txt profiles/r04_${c}_timeline.txt
+  cp gpurun_out/pmc_walk_$c.log profiles/r04_${c}_pmc.txt
+done
+python tools/pmc_traffic.py gpurun_out r04 > /dev/null
