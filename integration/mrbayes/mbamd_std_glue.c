@@ -134,7 +134,7 @@ static int Setup (ModelInfo *m, int d)
         if (cl->instance < 0)
             return (ERROR);
         if (g == 0)
-            MrBayesPrint ("%s   Division %d (standard data): %d transition-matrix classes on %s\n", spacer, d+1, sd->nClasses, details.resourceName);
+            MrBayesPrint ("%s   Division %d (standard data): %d transition-matrix classes on %s\n", spacer, d+1, sd->nClasses, details.implName);
         /* tips: the state sets of the compressed matrix (InitChainCondLikes fills the host arrays from the same bits, src/mcmc.c:6303-6330) */
         for (i=0; i<numLocalTaxa; i++)
             {

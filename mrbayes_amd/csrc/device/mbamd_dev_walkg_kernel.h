@@ -105,12 +105,7 @@ k_walkg(ARGS AA)
     extern __shared__ float lds_walkg[];
     const unsigned K = (unsigned) A.K, KL = K * (unsigned) A.lists;
     const unsigned xcd = blockIdx.x & 7u, pos = blockIdx.x >> 3;
-#if defined(MBAMD_WGX_REMAP)     // (experiment) category / list slowest: the workgroups a CU hosts at a time read the same tables
-    const unsigned nt8 = ((unsigned) A.ntiles + 7u) >> 3;
-    const unsigned tile = (pos % nt8) * 8u + xcd, k = (pos / nt8) % K, list = (pos / nt8) / K;
-#else
     const unsigned tile = (pos / KL) * 8u + xcd, k = (pos % KL) % K, list = (pos % KL) / K;
-#endif
     if (tile >= (unsigned) A.ntiles) return;
     char* const mine = reinterpret_cast<char*>(lds_walkg) + (size_t) wave * (MBAMD_WG_STAGE + (size_t) A.nslots * SLOTB);
     vec* const slots = reinterpret_cast<vec*>(mine + MBAMD_WG_STAGE) + lane;          // this lane's V rows of row group 0, slot 0
@@ -122,11 +117,6 @@ k_walkg(ARGS AA)
 
     const Walk4Entry* prog = wg_program(AA) + ((size_t) list * W + wave) * A.entries;
     const int n = A.entries - MBAMD_WG_TAIL;
-#if defined(MBAMD_WGX_STAGGER)
-    // Waves of different tiles run the SAME program: left alone they march in lockstep -- all waves of a SIMD in their MFMA
-    // chains at once, then all in their epilogues with the matrix pipe idle.  A start offset per workgroup persists.
-    for (unsigned d = ((blockIdx.x >> 3) * 2654435761u >> 16) % MBAMD_WGX_STAGGER; d > 0; --d) __builtin_amdgcn_s_sleep(8);
-#endif
     WgDesc DA, DB, DC;
     DA.e = walk4_load_entry(prog); DB.e = walk4_load_entry(prog + 1); DC.e = walk4_load_entry(prog + 2);
     DA.s1 = DA.s2 = DB.s1 = DB.s2 = DC.s1 = DC.s2 = 0;
@@ -155,7 +145,6 @@ k_walkg(ARGS AA)
         const bool idle = CH > 1 && ((tip && h > 0) || (ctl & MBAMD_W4_NOP));
         const unsigned aoff = idle ? 0u : (tip ? (1u + s / TW) * (unsigned) (NAP * 256) + ((s % TW) * KS + half) * (unsigned) (VA * 4) : lane * (unsigned) (VA * 4));
         const MBAMD_AS_GLOBAL vecA* pa = reinterpret_cast<const MBAMD_AS_GLOBAL vecA*>((uintptr_t) (Mk + moff) + aoff) + (idle ? 0 : h * NAVC * 64);
-#if !defined(MBAMD_WGX_NOFETCH)
         if constexpr (CH > 1) {
             const int stride = idle ? 0 : 64;
 #pragma unroll
@@ -164,9 +153,6 @@ k_walkg(ARGS AA)
 #pragma unroll
             for (int i = 0; i < NAVC; ++i) o.a[i] = pa[i * 64];
         }
-#else
-        (void) pa;
-#endif
         if (mem) {
             const MBAMD_AS_GLOBAL vec* pb = reinterpret_cast<const MBAMD_AS_GLOBAL vec*>((uintptr_t) (P0 + coff)) + lane + h * TVC * 64;
 #pragma unroll
@@ -183,14 +169,8 @@ k_walkg(ARGS AA)
             for (int i = 0; i < TVC; ++i) b[i] = o.b[i];
         } else {
             const vec* sl = reinterpret_cast<const vec*>(reinterpret_cast<const char*>(slots) + (ch ? de.c2 : de.c1)) + h * TVC * 64;
-#if !defined(MBAMD_WGX_NOLDS)
 #pragma unroll
             for (int i = 0; i < TVC; ++i) b[i] = sl[i * 64];
-#else
-            (void) sl;
-#pragma unroll
-            for (int i = 0; i < TVC; ++i) b[i] = Vb::splat(1.0f);
-#endif
         }
     };
     auto compute = [&](bool tip, int q, const Ops& o, const vec (&b)[TVC], acc_t (&f)[NT]) {
@@ -210,7 +190,6 @@ k_walkg(ARGS AA)
 #pragma unroll
                 for (int r = 0; r < ACC; ++r) f[it][r] = 0.0f;
         }
-#if !defined(MBAMD_WGX_NOMFMA)
 #pragma unroll
         for (int tc = 0; tc < TPC; ++tc)
             if (h * TPC + tc < T) {
@@ -224,24 +203,14 @@ k_walkg(ARGS AA)
 #endif
                 }
             }
-#else
-#pragma unroll
-        for (int tc = 0; tc < TPC; ++tc) f[0][tc % ACC] += Va::get(o.a[(tc * NT) / VA], (tc * NT) % VA) * Vb::get(b[tc / V], tc % V);
-#endif
     };
 
     // One iteration = one entry `cur`: its NQ chunks run on the register sets (S0, S1, S2, S0, ...) while the chunks DEPTH
     // further on -- of cur, then of entry `n1` -- are fetched; the tip states of entry `n2` are fetched, and cur's descriptor
     // is replaced by entry j + 3.  Vector-memory sequence, identical on every path:
     //     NQ x NAVC operand loads | TV + 1 stores      (+ the rare conditional loads)
-#if defined(MBAMD_WG_TRACE)      // timing experiments only (MBAMD_BUILD_DEFINES=MBAMD_WG_TRACE): the stamps cost scalar-memory waits
-    const bool tracing = A.trace != nullptr && blockIdx.x == 8 && lane == 0;
-#else
-    constexpr bool tracing = false;
-#endif
     auto step = [&](WgDesc& cur, const WgDesc& n1, WgDesc& n2, Ops& S0, Ops& S1, Ops& S2, int j) {
         const unsigned ctl = cur.e.ctl;
-        if (tracing) A.trace[((size_t) j * 8 + wave) * 3 + 0] = (long long) __builtin_amdgcn_s_memtime();
         if (ctl & MBAMD_W4_BARRIER) {
             // values other waves produced in the previous phase are read from here on: drain this wave's stores, meet
             asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
@@ -259,7 +228,7 @@ k_walkg(ARGS AA)
         // gather addresses of a tip's operand fetch wait for them (-5 % at 20 states, -7 % at 16).  At 61 states the 24 extra
         // scalar registers spill (+3 %), at 8 the entry is too short to cover the scalar latency (+6 %): those keep the vector
         // loads (profiles/r03_exp_walkg_tiny.txt).
-#if MBAMD_WG_TW == 32 && !defined(MBAMD_WGX_VECTINY) && !defined(MBAMD_WGX_NOTINY)
+#if MBAMD_WG_TW == 32
         constexpr bool SCALAR_TINY = SC >= 16 && SC <= 32;
 #else
         constexpr bool SCALAR_TINY = false;
@@ -281,13 +250,11 @@ k_walkg(ARGS AA)
             return (d >> ((col & 3u) * 8u)) & 0xFFu;
         };
         int er_next = 0;
-#if !defined(MBAMD_WGX_NOTINY)
         if constexpr (!SCALAR_TINY) {
             er_next = as_global(E0 + n1.e.eread)[col];
             n2.s1 = as_global(T0 + ((n2.e.ctl & MBAMD_W4_TIP1) ? n2.e.c1 : 0u))[col];
             n2.s2 = as_global(T0 + ((n2.e.ctl & MBAMD_W4_TIP2) ? n2.e.c2 : 0u))[col];
         }
-#endif
         acc_t f1[NT], f2[NT];
         const Walk4Entry ce = cur.e;
         auto chunk = [&](auto qc) {
@@ -326,17 +293,12 @@ k_walkg(ARGS AA)
             }
         };
         chunk(WgInt<0>{}); chunk(WgInt<1>{}); chunk(WgInt<2>{}); chunk(WgInt<3>{});
-        if (tracing) A.trace[((size_t) j * 8 + wave) * 3 + 1] = (long long) __builtin_amdgcn_s_memtime();
         const unsigned dst = ce.dst, ewrite = ce.ewrite;
         float out[TP];
         float mx = 0.0f;
 #pragma unroll
         for (int t = 0; t < TP; ++t) {
-#if !defined(MBAMD_WGX_NOEPI)
             out[t] = (run && t < T) ? f1[t / ACC][t % ACC] * f2[t / ACC][t % ACC] : 0.0f;
-#else
-            out[t] = (t == 0 && run) ? f1[0][0] + f2[0][0] : 0.0f;
-#endif
             mx = fmaxf(mx, out[t]);
         }
         {   // the other states of this pattern sit TW lanes apart: lane swaps in the VALU, no LDS round trip
@@ -362,31 +324,15 @@ k_walkg(ARGS AA)
         vec ov[TV];
 #pragma unroll
         for (int t = 0; t < TP; ++t) Vb::set(ov[t / V], t % V, out[t] * sc);   // (exact: |e| <= 126; 2^0 needs no branch)
-#if !defined(MBAMD_WGX_NOLDS)
         if (ctl & MBAMD_W4_KEEP) {
             vec* keep = reinterpret_cast<vec*>(reinterpret_cast<char*>(slots) + ((ctl >> 16) & 0xFFu) * SLOTB);
 #pragma unroll
             for (int i = 0; i < TV; ++i) keep[i * 64] = ov[i];
         }
-#endif
         MBAMD_AS_GLOBAL vec* pd = reinterpret_cast<MBAMD_AS_GLOBAL vec*>((uintptr_t) (P0 + dst)) + lane;
-#if !defined(MBAMD_WGX_NOSTORE)
-#if defined(MBAMD_WGX_PLAINSTORE)
-#pragma unroll
-        for (int i = 0; i < TV; ++i) pd[i * 64] = ov[i];
-#else
 #pragma unroll
         for (int i = 0; i < TV; ++i) __builtin_nontemporal_store(ov[i], pd + i * 64);   // 64 * V * 4 contiguous bytes per instruction
-#endif
-#else
-        if (Vb::get(ov[0], 0) == 123.456f) __builtin_nontemporal_store(ov[0], pd);
-#endif
-#if !defined(MBAMD_WGX_NOTINY)
         __builtin_nontemporal_store((int8_t) e, as_global(E0 + ewrite) + col);   // (every lane group holds the same e: no exec-mask branch)
-#else
-        if (e == 12345) __builtin_nontemporal_store((int8_t) e, as_global(E0 + ewrite) + col);
-#endif
-        if (tracing) A.trace[((size_t) j * 8 + wave) * 3 + 2] = (long long) (ctl & 0xFFFu);   // (flags and mode of the entry, for the reader)
     };
     // the sets rotate by NQ positions per entry; three entries bring every (NS <= 3) rotation back to the start
     for (int j = 0; j < n; j += 3) {

@@ -38,7 +38,7 @@ template <int PIECE, int G> struct WgsDmaPlan {
 // In LDS the 16-byte units of row group i (RG bytes: VA table rows of 64 columns) are ROTATED by i units: the MFMA operand
 // reads stay one contiguous unit per lane, and the lanes of a tip's gather -- each wants ITS column of a row that depends on
 // its pattern's state -- spread over the banks instead of meeting on the few the column index alone selects (unrotated:
-// 16-way conflicts, a tip chunk took as long as an interior chunk's 32 MFMAs; profiles/r04_walkgs_trace.txt).  The rotation is
+// 16-way conflicts, a tip chunk took as long as an interior chunk's 32 MFMAs; profiles/r04_exp_walkgs.txt).  The rotation is
 // free: an LDS-DMA lands lane-linearly, its SOURCE address is per lane.
 template <int RG> __device__ __forceinline__ unsigned wgs_rot(unsigned d, int sign)        // piece-relative byte d -> rotated by +-16 i inside its row group
 {
@@ -62,12 +62,6 @@ __device__ __forceinline__ void wgs_dma_piece(const char* src, unsigned lds_dst,
         }
     }
 }
-// timing experiments only (tools/build_variants.py ...=MBAMD_WGS_TRACE): clock stamps of wave 0 of one workgroup, [chunk][8 points]
-#if defined(MBAMD_WGS_TRACE)
-#define MBAMD_WGS_STAMP(P) do { if (tracing) A.trace[((size_t) j * NQ + q) * 8 + (P)] = (long long) __builtin_amdgcn_s_memtime(); } while (0)
-#else
-#define MBAMD_WGS_STAMP(P) do { } while (0)
-#endif
 template <int N> __device__ __forceinline__ void wgs_wait_vm()
 {
     static_assert(N >= 0 && N < 64, "vmcnt is a 6-bit counter");
@@ -128,9 +122,6 @@ k_walkg_s(ARGS AA)
     const char* const Mk = reinterpret_cast<const char*>(A.matrices) + A.tabOff + (size_t) k * A.tabBytes;
     const Walk4Entry* prog = wgs_program(AA) + ((size_t) list * AS.progW + bin) * A.entries + (rg >> 16);
 
-#if defined(MBAMD_WGS_TRACE)
-    const bool tracing = A.trace != nullptr && blockIdx.x == 8 && wave == 0 && lane == 0 && len < 1000;
-#endif
     Walk4Entry cur = walk4_load_entry(prog), n1 = walk4_load_entry(prog + 1);
     int cum_e[MBAMD_WG_MAXLISTS] = {0, 0, 0, 0};
     // B rows of a chunk whose child lives in HBM (an earlier launch's result, an evicted value): loaded one chunk ahead into the
@@ -157,9 +148,6 @@ k_walkg_s(ARGS AA)
     // for the states [TW (q % CH), TW (q % CH + 1)), whose rows are laid out so that a lane reads the factor registers of ITS
     // pattern's state as whole 16-byte units of its column (staged as it is).
     auto table = [&](const Walk4Entry& e, int q, int rs) {
-#if defined(MBAMD_WGSX_NODMA)
-        return;
-#endif
         const bool tipc = e.ctl & ((q / CH) ? MBAMD_W4_TIP2 : MBAMD_W4_TIP1);
         const char* src = Mk + ((q / CH) ? e.m2 : e.m1) + (tipc ? (size_t) (1 + q % CH) * (NAP * 256) : (size_t) (q % CH) * PIECE);
         wgs_dma_piece<PIECE, G, RG>(src, ringLds + (unsigned) rs * PIECE, wave, lane, !tipc);
@@ -197,7 +185,6 @@ k_walkg_s(ARGS AA)
             constexpr int q = decltype(qc)::value;
             if constexpr (q < NQ) {
                 constexpr int ch = q / CH, h = q % CH;
-                MBAMD_WGS_STAMP(0);
                 const bool tip = ctl & (ch ? MBAMD_W4_TIP2 : MBAMD_W4_TIP1), mem = ctl & (ch ? MBAMD_WG_MEM2 : MBAMD_WG_MEM1);
                 // rows loaded from HBM for THIS chunk: waited for here, in front of this chunk's DMAs -- the compiler's wait cannot see
                 // those, and placed at the MFMA chain it would also wait for the table piece issued a moment ago
@@ -220,7 +207,6 @@ k_walkg_s(ARGS AA)
                 // the rows of the next chunk (into the other register set)
                 if constexpr (q + 1 < NQ) memrows(ce, q + 1, (q & 1) ? bm0 : bm1);
                 else memrows(n1, 0, (q & 1) ? bm0 : bm1);
-                MBAMD_WGS_STAMP(1);
                 auto chain = [&](const vec (&b)[TVC]) {
                     if constexpr (h == 0) {
 #pragma unroll
@@ -291,7 +277,6 @@ k_walkg_s(ARGS AA)
                     if constexpr (q == NQ - 1) nn = walk4_load_entry(prog + j + 2);
                 }
                 rsC = rsC + 1 == NB ? 0 : rsC + 1;
-                MBAMD_WGS_STAMP(2);
                 if constexpr (q == NQ - 1) {
                     // ---- the entry's result: product, rescale by its own power of two, LDS slot and HBM ---------------------------
                     float out[TP];
@@ -324,37 +309,16 @@ k_walkg_s(ARGS AA)
                         for (int i = 0; i < TV; ++i) keep[i * 64] = ov[i];
                     }
                     MBAMD_AS_GLOBAL vec* pd = reinterpret_cast<MBAMD_AS_GLOBAL vec*>((uintptr_t) (P0 + ce.dst)) + lane;
-#if defined(MBAMD_WGSX_NOSTORE)
-                    if (Vb::get(ov[0], 0) == 123.456f) __builtin_nontemporal_store(ov[0], pd);
-                    if (e == 12345) __builtin_nontemporal_store((int8_t) e, as_global(E0 + ce.ewrite) + col);
-#elif defined(MBAMD_WGSX_PLAIN_STORES)
-#pragma unroll
-                    for (int i = 0; i < TV; ++i) pd[i * 64] = ov[i];
-                    as_global(E0 + ce.ewrite)[col] = (int8_t) e;
-#else
 #pragma unroll
                     for (int i = 0; i < TV; ++i) __builtin_nontemporal_store(ov[i], pd + i * 64);   // 64 * V * 4 contiguous bytes per instruction
                     __builtin_nontemporal_store((int8_t) e, as_global(E0 + ce.ewrite) + col);       // (every lane group holds the same e: no exec-mask branch)
-#endif
                 }
                 // ---- the next chunk's table piece has landed (this wave's share; the barrier adds the others'), and nobody reads
                 //      the buffer this chunk used any more
-                MBAMD_WGS_STAMP(3);
-#if defined(MBAMD_WGS_SAFE_WAITS)
-                wgs_wait_vm<0>();
-#elif !defined(MBAMD_WGSX_NOWAIT)    // (ablation builds MBAMD_WGSX_*: wrong values, timing experiments only)
                 if constexpr (D == 1) wgs_wait_vm<(q == NQ - 1 ? NSTORE : 0)>();
                 else wgs_wait_vm<NDMA + (q == 0 ? NSTORE + 3 : 0) + (q == NQ - 1 ? NSTORE : 0)>();
-#endif
-                MBAMD_WGS_STAMP(4);
-#if !defined(MBAMD_WGSX_NOBARRIER)
                 __builtin_amdgcn_s_barrier();
-#endif
                 asm volatile("" ::: "memory");
-                MBAMD_WGS_STAMP(5);
-#if defined(MBAMD_WGS_TRACE)
-                if (tracing && q == 0) A.trace[((size_t) j * NQ + q) * 8 + 6] = (long long) ctl;
-#endif
             }
         };
         chunk(WgInt<0>{}); chunk(WgInt<1>{}); chunk(WgInt<2>{}); chunk(WgInt<3>{});

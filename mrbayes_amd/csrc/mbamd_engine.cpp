@@ -354,6 +354,10 @@ struct Instance {
 
     bool deferred = false, pendingResult = false;
     hipEvent_t reduceEvent{};        // mbamdReduceLogLikelihood: orders a client's stream behind the device-side sum
+    // final pass (mbamd_reports.h): per partials buffer, the exponents [K][Ppad] its final partials carry (nullptr: not final
+    // partials); owned by the top node's destination buffers
+    std::vector<int32_t*> finalExpOf;
+    std::unordered_map<int, int32_t*> finalExpOwn;
 
     std::vector<std::pair<Plan*, int>> pending;   // deferred general-path lists (plan, cumulative scale index or -1)
     std::vector<Plan*> plans;        // small LRU cache of compiled operation lists
@@ -725,6 +729,7 @@ void Instance::destroy()
     for (auto& ev : spans) { (void) hipEventDestroy(ev.first); (void) hipEventDestroy(ev.second); }
     if (spanOpen) (void) hipEventDestroy(spanEv0);
     if (reduceEvent) (void) hipEventDestroy(reduceEvent);
+    for (auto& kv : finalExpOwn) if (kv.second) (void) hipFree(kv.second);
     (void) hipStreamDestroy(stream);
 }
 
@@ -891,6 +896,7 @@ int Instance::setTipStates(int tip, const int* states)
 int Instance::importPartials(int idx, const double* in, bool hasCategories)
 {
     if (idx < 0 || idx >= nBuffers) return fail(BEAGLE_ERROR_OUT_OF_RANGE, "partials buffer index");
+    if (idx < (int) finalExpOf.size()) finalExpOf[idx] = nullptr;
     if (s4 && !hasCategories) {
         // beagleSetTipPartials with 0/1 entries (IUPAC ambiguity codes, reference src/mbbeagle.c:150-166): a state mask
         // per pattern says the same thing in one byte, and the tree walk reads it like any compact tip
@@ -1152,6 +1158,9 @@ int Instance::updatePartials(const BeagleOperation* ops, int n, int cumIdx)
     if (n <= 0) return BEAGLE_SUCCESS;
     if (cumIdx != BEAGLE_OP_NONE && (cumIdx < 0 || cumIdx >= nScale))
         return fail(BEAGLE_ERROR_OUT_OF_RANGE, "beagleUpdatePartials: cumulative scale index");
+    if (!finalExpOf.empty())                     // a buffer an operation overwrites no longer holds final partials
+        for (int o = 0; o < n; ++o)
+            if (ops[o].destinationPartials >= 0 && ops[o].destinationPartials < nBuffers) finalExpOf[ops[o].destinationPartials] = nullptr;
     if (s4) return updatePartials4(ops, n, cumIdx);
     if (wg) return updatePartialsG(ops, n, cumIdx);
     int32_t* cumPtr = nullptr;
@@ -2132,14 +2141,6 @@ int Instance::runWalkGS(const Plan& plan)
                 for (int w = 0; w < lq.W; ++w) { s.range[q][w] = lq.ranges[(size_t) ph * lq.W + w]; any |= s.range[q][w] != 0; }
             }
             if (!any) continue;
-            if (envTrace && ph == 0) {               // timing experiments: clock stamps of one workgroup of the first launch
-                if (!d_trace && hipMalloc(&d_trace, (size_t) 4096 * 8 * 3 * sizeof(long long)) != hipSuccess) d_trace = nullptr;
-                if (d_trace) {
-                    (void) hipMemsetAsync(d_trace, 0, (size_t) 4096 * 8 * 3 * sizeof(long long), stream);
-                    a.trace = d_trace;
-                    lastWalkSteps = 4096; walkWaves = 0;
-                }
-            }
             if (ph > 0) fresh = 0;
             MBAMD_WGS_DISPATCH(S, wgsG, launch_walkgs_t, *this, s, sg.nslots, &plan.inlineProg);
             HIP_TRY(hipGetLastError());
@@ -2176,14 +2177,6 @@ int Instance::runWalkG(const Plan& plan)
 #if MBAMD_DEV_SPREAD
         a.spread = sg.W == 2 ? 1 : 0;
 #endif
-        if (envTrace && !d_trace) {
-            if (hipMalloc(&d_trace, (size_t) 4096 * 8 * 3 * sizeof(long long)) != hipSuccess) d_trace = nullptr;
-        }
-        if (d_trace) {
-            (void) hipMemsetAsync(d_trace, 0, (size_t) 4096 * 8 * 3 * sizeof(long long), stream);
-            a.trace = sg.entries <= 4096 ? d_trace : nullptr;
-            lastWalkSteps = sg.entries - MBAMD_WG_TAIL; walkWaves = sg.W - 1;
-        }
         MBAMD_WG_DISPATCH(S, launch_walkg_t, *this, a, sg.W, sg.nslots, &plan.inlineProg);
         HIP_TRY(hipGetLastError());
         pendingLaunches += 1;
@@ -2843,8 +2836,20 @@ int Instance::finalPass(const MbamdFinalOperation* ops, int count)
         if (tipStates[b.destinationPartials]) return fail(BEAGLE_ERROR_OUT_OF_RANGE, "mbamdUpdateFinalPartials: the destination holds compact tip states");
         int rc = ensurePartials(b.destinationPartials);
         if (rc) return rc;
+        // the exponents of the final pass: written by the top node's launch, inherited by everything below it
+        if (finalExpOf.size() != (size_t) nBuffers) finalExpOf.assign((size_t) nBuffers, nullptr);
+        if (b.ancestorFinal < 0) {
+            int32_t*& own = finalExpOwn[b.destinationPartials];
+            if (!own) HIP_TRY(hipMalloc(&own, (size_t) K * Ppad * sizeof(int32_t)));
+            finalExpOf[b.destinationPartials] = own;
+        } else {
+            if (!finalExpOf[b.ancestorFinal]) return fail(BEAGLE_ERROR_OUT_OF_RANGE, "mbamdUpdateFinalPartials: the ancestor's buffer does not hold final partials");
+            finalExpOf[b.destinationPartials] = finalExpOf[b.ancestorFinal];
+        }
         FinalOp f;
         std::memset(&f, 0, sizeof f);
+        f.Ppad = Ppad;
+        f.fexp = finalExpOf[b.destinationPartials];
         f.dst = partials[b.destinationPartials];
         f.anc = b.ancestorFinal >= 0 ? partials[b.ancestorFinal] : nullptr;
         f.down = partials[b.downPartials];
@@ -2888,9 +2893,10 @@ int Instance::getScaledPartials(int idx, int cumIdx, float* out, float* outLn)
     float* d_out = static_cast<float*>(d_tmp);
     float* d_ln = d_out + total;
     const unsigned blocks = (unsigned) ((total + 255) / 256);
-    if (s4) MBAMD_LAUNCH(k_export_scaled<1>, blocks, 256, 0, stream, (const float*) partials[idx], wide, narrow, S, K, P, Ppad, (size_t) geom.pstride, d_out, d_ln);
-    else if (wg) MBAMD_LAUNCH(k_export_scaled<2>, blocks, 256, 0, stream, (const float*) partials[idx], wide, narrow, S, K, P, Ppad, (size_t) (wgTileBytes / 4), d_out, d_ln);
-    else MBAMD_LAUNCH(k_export_scaled<0>, blocks, 256, 0, stream, (const float*) partials[idx], wide, narrow, S, K, P, Ppad, (size_t) geom.pstride, d_out, d_ln);
+    const int32_t* extra = (idx < (int) finalExpOf.size()) ? finalExpOf[idx] : nullptr;      // final partials carry their pass's own exponents
+    if (s4) MBAMD_LAUNCH(k_export_scaled<1>, blocks, 256, 0, stream, (const float*) partials[idx], wide, narrow, extra, S, K, P, Ppad, (size_t) geom.pstride, d_out, d_ln);
+    else if (wg) MBAMD_LAUNCH(k_export_scaled<2>, blocks, 256, 0, stream, (const float*) partials[idx], wide, narrow, extra, S, K, P, Ppad, (size_t) (wgTileBytes / 4), d_out, d_ln);
+    else MBAMD_LAUNCH(k_export_scaled<0>, blocks, 256, 0, stream, (const float*) partials[idx], wide, narrow, extra, S, K, P, Ppad, (size_t) geom.pstride, d_out, d_ln);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipStreamSynchronize(stream));
     syncedClock = launchClock;

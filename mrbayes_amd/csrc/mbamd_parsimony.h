@@ -83,13 +83,8 @@ k_pars_walk(const ParsStep* __restrict__ steps, int nchunks, T* sets, unsigned s
         const bool fin = d.get(0) == PARS_FINAL;
 #pragma unroll
         for (int k = 0; k < CH; ++k) {
-#if defined(MBAMD_PARSX_NOFETCH)
-            buf[k][0] = pars_none<X>();
-            buf[k][1] = pars_none<X>();
-#else
             buf[k][0] = (X) row(d.get(8 * k + 2))[c];
             buf[k][1] = (X) row(d.get(8 * k + 3))[c];
-#endif
         }
         if (fin) {
 #pragma unroll
@@ -101,11 +96,7 @@ k_pars_walk(const ParsStep* __restrict__ steps, int nchunks, T* sets, unsigned s
     };
     auto operand = [&](unsigned codes, int j, X fetched) {
         const unsigned code = (codes >> (8 * j)) & 0xFFu;
-#if defined(MBAMD_PARSX_NORING)
-        return fetched;
-#else
         return code != 0xFFu ? ring[code * 64 + lane] : fetched;
-#endif
     };
     auto run = [&](int half, const ParsDesc& d, X (&buf)[CH][4]) {
         if (d.get(0) == PARS_DOWN) {
@@ -118,9 +109,7 @@ k_pars_walk(const ParsStep* __restrict__ steps, int nchunks, T* sets, unsigned s
                     x = a | b;
                     len += wc;
                 }
-#if !defined(MBAMD_PARSX_NOSTORE)
                 row(d.get(8 * k + 1))[c] = pars_narrow<T, X>(x);
-#endif
                 ring[(half * CH + k) * 64 + lane] = x;
             }
         } else {

@@ -14,8 +14,14 @@
 //   final(p)[a] = (sum_i up[i] P_p[a][i]) down(p)[a],   up[a] = final(anc)[a] / (sum_i P_p[a][i] down(p)[i])   (0 where that sum is 0)
 // exactly as the reference writes it (including its P[a][i] in the second sum).  Every value of category k keeps the factor
 // 2^-E_k(c) of the whole tree's cumulative exponent -- down(p) carries the exponents of p's subtree, the quotient those of
-// the rest -- so the final pass needs no exponent at all; the read-out brings the categories of a pattern to their common
-// largest exponent (exact: powers of two) and reports it as the natural-log site scaler the reference's read-outs expect.
+// the rest -- so the pass needs no exponent arithmetic of its own; the read-out brings the categories of a pattern to their
+// common largest exponent (exact: powers of two) and reports it as the natural-log site scaler the reference's read-outs expect.
+// One exception, since round 4: under MrBayes' DYNAMIC rescaling scheme (src/mbbeagle.c: no rescaling until a likelihood
+// underflows) the down-pass values of a 60-taxon tree are legitimately 1e-30 ... 1e-44 floats -- the log-likelihood is fine, but
+// the final pass multiplies and divides them (quotients beyond 1e38, products below 1e-45) and the reference's read-outs then
+// divide 0 by 0 (found by the 500 x 20 000 golden, tests/test_fullsize_dropin.py).  So the arithmetic runs in DOUBLE, and the top
+// node's column is brought to [0.5, 1) by its own power of two, recorded per (pattern, category) next to the buffer (`fexp`);
+// everything below inherits that scale (the pass is linear in the ancestor's values) and the read-out adds it to the exponents.
 #ifndef MBAMD_REPORTS_H_
 #define MBAMD_REPORTS_H_
 
@@ -49,7 +55,8 @@ struct FinalOp {
     const float* matrix;       // transposed [K][SP][SP]: this node's branch
     const void* tip;           // top node of an unrooted tree: the root tip (compact states or partials), else nullptr
     int tipKind;               // CHILD_STATES / CHILD_PARTIALS
-    int pad_;
+    int Ppad;
+    int32_t* fexp;             // top node: the column's own exponent is stored here, int32 [K][Ppad]
 };
 
 #define MBAMD_REP_MAXS 64
@@ -59,44 +66,49 @@ k_final_pass(FinalOp op, int S, int SP, int K, int P, size_t pstride, size_t tst
 {
     const int c = blockIdx.x * 64 + threadIdx.x, k = blockIdx.y;
     if (c >= P) return;
-    float d[MBAMD_REP_MAXS], u[MBAMD_REP_MAXS];
-    for (int i = 0; i < S; ++i) d[i] = op.down[rep_index<LAYOUT>(S, K, pstride, k, i, c)];
+    double d[MBAMD_REP_MAXS], u[MBAMD_REP_MAXS];
+    for (int i = 0; i < S; ++i) d[i] = (double) op.down[rep_index<LAYOUT>(S, K, pstride, k, i, c)];
     const float* m = op.matrix;
     if (op.anc == nullptr) {
+        double mx = 0.0;
         for (int a = 0; a < S; ++a) {
-            float f = 1.0f;
+            double f = 1.0;
             if (op.tip != nullptr) {
-                f = 0.0f;
+                f = 0.0;
                 for (int j = 0; j < S; ++j) {
                     const float t = op.tipKind == CHILD_STATES ? rep_tip<LAYOUT>(op.tip, S, tstride, c, j)
                                                               : reinterpret_cast<const float*>(op.tip)[rep_index<LAYOUT>(S, K, pstride, k, j, c)];
-                    f += mat_at(m, SP, k, a, j) * t;
+                    f += (double) mat_at(m, SP, k, a, j) * (double) t;
                 }
             }
             u[a] = d[a] * f;
+            mx = u[a] > mx ? u[a] : mx;
         }
-        for (int a = 0; a < S; ++a) op.dst[rep_index<LAYOUT>(S, K, pstride, k, a, c)] = u[a];
+        int e = 0;
+        if (mx > 0.0 && mx < 1.0e300) (void) frexp(mx, &e);
+        op.fexp[(size_t) k * op.Ppad + c] = e;
+        for (int a = 0; a < S; ++a) op.dst[rep_index<LAYOUT>(S, K, pstride, k, a, c)] = (float) ldexp(u[a], -e);
         return;
     }
     for (int a = 0; a < S; ++a) {
-        float sum = 0.0f;
-        for (int i = 0; i < S; ++i) sum += mat_at(m, SP, k, a, i) * d[i];
-        const float fa = op.anc[rep_index<LAYOUT>(S, K, pstride, k, a, c)];
-        u[a] = sum != 0.0f ? fa / sum : 0.0f;
+        double sum = 0.0;
+        for (int i = 0; i < S; ++i) sum += (double) mat_at(m, SP, k, a, i) * d[i];
+        const double fa = (double) op.anc[rep_index<LAYOUT>(S, K, pstride, k, a, c)];
+        u[a] = sum != 0.0 ? fa / sum : 0.0;
     }
     for (int a = 0; a < S; ++a) {
-        float sum = 0.0f;
-        for (int i = 0; i < S; ++i) sum += u[i] * mat_at(m, SP, k, a, i);
-        op.dst[rep_index<LAYOUT>(S, K, pstride, k, a, c)] = sum * d[a];
+        double sum = 0.0;
+        for (int i = 0; i < S; ++i) sum += u[i] * (double) mat_at(m, SP, k, a, i);
+        op.dst[rep_index<LAYOUT>(S, K, pstride, k, a, c)] = (float) (sum * d[a]);
     }
 }
 
 // out[k][c][i] = buffer[k][c][i] 2^(E_kc - Emax_c), lnScale[c] = Emax_c ln 2.  Exponents: `wide` int32 [K][Ppad] (arena paths,
-// per pattern and category), or `narrow` int32 [Ppad] (general path, per pattern), or neither (all zero).
+// per pattern and category), or `narrow` int32 [Ppad] (general path, per pattern), or neither (all zero); plus `extra` (final partials).
 template <int LAYOUT>
 __global__ void __launch_bounds__(256)
-k_export_scaled(const float* __restrict__ in, const int32_t* __restrict__ wide, const int32_t* __restrict__ narrow, int S, int K, int P,
-                int Ppad, size_t pstride, float* __restrict__ out, float* __restrict__ lnScale)
+k_export_scaled(const float* __restrict__ in, const int32_t* __restrict__ wide, const int32_t* __restrict__ narrow,
+                const int32_t* __restrict__ extra, int S, int K, int P, int Ppad, size_t pstride, float* __restrict__ out, float* __restrict__ lnScale)
 {
     const size_t total = (size_t) K * P * S;
     const size_t g = (size_t) blockIdx.x * blockDim.x + threadIdx.x;
@@ -104,15 +116,22 @@ k_export_scaled(const float* __restrict__ in, const int32_t* __restrict__ wide, 
     const int i = (int) (g % S);
     const int c = (int) ((g / S) % P);
     const int k = (int) (g / ((size_t) S * P));
-    int emax = 0, e = 0;
-    if (wide) {
-        emax = -2147483647;
-        for (int q = 0; q < K; ++q) { const int v = wide[(size_t) q * Ppad + c]; emax = v > emax ? v : emax; }
-        e = wide[(size_t) k * Ppad + c];
-    } else if (narrow) {
-        emax = e = narrow[c];
+    // exponent of (category q, this pattern): the cumulative buffer's, plus the final pass's own (`extra`, int32 [K][Ppad])
+    auto expo = [&](int q) { return (wide ? wide[(size_t) q * Ppad + c] : (narrow ? narrow[c] : 0)) + (extra ? extra[(size_t) q * Ppad + c] : 0); };
+    // (a category whose column is all zero -- under dynamic rescaling the slowest categories of a variable site underflow, rightly:
+    //  they carry nothing -- has no exponent to speak of: left in, its stale one can sit hundreds of binades above the others and
+    //  the common scale would flush every category that does carry the site to zero)
+    int emax = -2147483647;
+    for (int q = 0; q < K; ++q) {
+        bool any = false;
+        for (int j = 0; j < S && !any; ++j) any = in[rep_index<LAYOUT>(S, K, pstride, q, j, c)] != 0.0f;
+        const int v = expo(q);
+        if (any && v > emax) emax = v;
     }
-    out[g] = ldexpf(in[rep_index<LAYOUT>(S, K, pstride, k, i, c)], e - emax);
+    if (emax == -2147483647) emax = 0;
+    const int e = expo(k);
+    const float v = in[rep_index<LAYOUT>(S, K, pstride, k, i, c)];
+    out[g] = v == 0.0f ? 0.0f : ldexpf(v, e - emax);
     if (i == 0 && k == 0) lnScale[c] = (float) ((double) emax * 0.69314718055994530942);
 }
 

@@ -155,7 +155,7 @@ struct WalkGArgs {
     int K, Ppad, ntiles, S, SP;
     int lists;                   // > 1: mutually independent lists run as separate workgroups (programs [list][W][entries]); else 1
     int spread;                  // 1: the workgroup is launched with 2 W waves and only the even ones work (see k_walkg)
-    long long* trace;            // MBAMD_WALK_TRACE: clock stamps [entry][8 waves][3] of one workgroup (timing experiments), or nullptr
+    long long* reserved;         // (was: clock stamps of timing experiments)
 };
 __host__ __device__ inline unsigned walkg_grid(int ntiles, int KL) { return 8u * (unsigned) KL * (unsigned) ((ntiles + 7) / 8); }   // KL = categories x lists
 

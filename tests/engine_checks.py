@@ -332,10 +332,34 @@ def check_final_pass(lib, nstates, ncat, npat, seed=7):
             fb = up(fa, d32[2], t32[2])
             inst.update_final_partials(np.array([[6, -1, 2, 0, root_tip], [7, 6, 3, 1, -1], [8, 7, 4, 2, -1]], dtype=np.int32))
             for buf, want in ((6, top), (7, fa), (8, fb)):
-                got = inst.get_partials(buf)
-                assert np.allclose(got, want, rtol=3e-5, atol=1e-30), (name, buf, np.abs(got / want - 1).max())
-            got, ln = inst.get_scaled_partials(8)
-            assert np.array_equal(got, inst.get_partials(8).astype(np.float32)) and np.all(ln == 0)
+                # (the pass keeps the top node's columns in [0.5, 1) by their own powers of two; the scaled read-out reports them)
+                got, ln = inst.get_scaled_partials(buf)
+                true = got.astype(np.float64) * np.exp(ln.astype(np.float64))[None, :, None]
+                assert np.allclose(true, want, rtol=3e-5, atol=1e-30), (name, buf, np.abs(true / want - 1).max())
+            raw = inst.get_partials(6)
+            assert raw.max(axis=2).min() >= 0.5 - 1e-6 and raw.max() < 1.0 + 1e-6          # every column of the top node normalised
+        # MrBayes' dynamic rescaling scheme leaves the down pass unscaled until a likelihood underflows: on a 60-taxon tree its values
+        # are 1e-30 ... 1e-44 floats.  The final pass must survive them (it runs in double and normalises the top node): posteriors
+        # against a float64 restatement, no zero columns, nothing that is not a number.
+        tiny = [np.ascontiguousarray((rng.random((K, P, S)) * 0.9 + 0.05) * 10.0 ** (-e), dtype=np.float32) for e in (36, 28, 18)]
+        for q in range(3):
+            inst.set_partials(2 + q, tiny[q].astype(np.float64))
+        inst.update_final_partials(np.array([[6, -1, 2, 0, 0], [7, 6, 3, 1, -1], [8, 7, 4, 2, -1]], dtype=np.int32))
+        t64 = [t.astype(np.float64) for t in t32]
+        d64 = [t.astype(np.float64) for t in tiny]
+
+        def up64(fa, d, t):
+            s = np.einsum("kai,kci->kca", t, d)
+            return np.einsum("kci,kai->kca", fa / s, t) * d
+        f0 = d64[0] * np.einsum("kaj,cj->kca", t64[0], tipvec.astype(np.float64))
+        f2 = up64(up64(f0, d64[1], t64[1]), d64[2], t64[2])
+        got, ln = inst.get_scaled_partials(8)
+        assert np.all(np.isfinite(got)) and np.all(np.isfinite(ln))
+        post = got.astype(np.float64).sum(axis=0)
+        post /= post.sum(axis=1, keepdims=True)
+        want = f2.sum(axis=0)
+        want /= want.sum(axis=1, keepdims=True)
+        assert np.allclose(post, want, rtol=2e-4, atol=1e-7), np.abs(post - want).max()
         # the scaled read-out: categories brought to the largest exponent of the pattern
         inst.reset_scale_factors(1)
         inst.update_partials(np.array([[9, 0, -1, 2, 0, 3, 1]], dtype=np.int32), 1)          # rescaled, exponents also in buffer 1
@@ -839,8 +863,12 @@ def check_parsimony_model_golden(lib, golden_dir):
             length = mp.GetParsimonyLength(inst, tr)
             assert length == int(length)
             lnl = -(length + st.shape[1]) * math.log(case["nstates"])
-            # (the reference prints the value with 13 significant digits)
-            assert abs(lnl - case["lnL_reference"]) <= max(1e-6, 2e-12 * abs(lnl)), (case["name"], lnl, case["lnL_reference"])
+            # The reference prints the value with 13 significant digits -- and adds the tree length up in CLFlt (float,
+            # src/likelihood.c:7597-7672): beyond 2^24 steps its own sum is rounded (the configs[3] shape: 27 062 103 steps printed,
+            # 27 062 126 counted; the device length is an exact integer, pinned word for word against GetParsDP / GetParsFP by
+            # MBAMD_PARS_CHECK=1, tests/test_mrbayes_dropin.py).  There the golden pins to the float's resolution.
+            tol = max(1e-6, 2e-12 * abs(lnl)) if length < 2 ** 24 else 4e-6 * abs(lnl)
+            assert abs(lnl - case["lnL_reference"]) <= tol, (case["name"], lnl, case["lnL_reference"])
         finally:
             inst.finalize()
 

@@ -105,17 +105,17 @@ def _check_mcmc(binary, marker):
 @pytest.mark.parametrize("case", sorted(std_cases.SYNTHETIC))
 def test_standard_data_on_emulated_engine(case):
     _build_emu()
-    _check_synthetic(case, os.path.join(REF, "mb_emu_std"), "host emulation")
+    _check_synthetic(case, os.path.join(REF, "mb_emu_std"), "HOST EMULATION")
 
 
 def test_cynmix_morphology_on_emulated_engine():
     _build_emu()
-    _check_cynmix(os.path.join(REF, "mb_emu_std"), "host emulation")
+    _check_cynmix(os.path.join(REF, "mb_emu_std"), "HOST EMULATION")
 
 
 def test_standard_data_mcmc_on_emulated_engine():
     _build_emu()
-    _check_mcmc(os.path.join(REF, "mb_emu_std"), "host emulation")
+    _check_mcmc(os.path.join(REF, "mb_emu_std"), "HOST EMULATION")
 
 
 def test_unequal_frequencies_stay_on_the_host():

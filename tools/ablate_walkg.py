@@ -1,5 +1,5 @@
-"""Timing experiment: the 20/61-state tree-walk kernel with parts switched off (MBAMD_WGX_* builds; results are wrong on
-purpose).  python tools/ablate_walkg.py c3|c5  -- prints kernel ms per full evaluation for MBAMD_LIBRARY (or the product)."""
+"""Kernel time of the general-state tree walk per full evaluation, for MBAMD_LIBRARY (a variant built by tools/build_variants.py,
+or round 3's library) or the product, under whatever MBAMD_* switches the environment holds: python tools/ablate_walkg.py c3|c5"""
 import os, sys, time
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
 from mrbayes_amd import beagle as bg, likelihood as lk
