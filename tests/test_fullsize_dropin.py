@@ -53,7 +53,9 @@ def test_ancestral_states_on_the_config1_shape():
         got = np.asarray(r)
         cols = np.array([j for j in range(len(h)) if j != i])
         worst = np.abs(got[cols] - want[cols]).max()
-        assert worst <= rep.TOL_VALUE + 1e-6, (scaling, worst)          # (+ the float32 the golden row is stored in)
+        # state probabilities, fp32 conditional likelihoods on both sides through ~1000 node products (500 taxa): 5e-5 absolute
+        # (measured 1.8e-5; the 12-taxon cases of tests/test_reports_dropin.py hold 1e-5), + the float32 the golden row is stored in
+        assert worst <= 5e-5, (scaling, worst)
         assert g["state_probability_columns"] > 100000
 
 
