@@ -13,6 +13,14 @@
 #define MBAMD_AS_GLOBAL __attribute__((address_space(1)))
 #define MBAMD_AS_CONST __attribute__((address_space(4)))
 #define MBAMD_SYNC() __syncthreads()
+// a store that does not allocate in L2 (a result stream written once: with write-allocate it evicts matrices and programs)
+#define MBAMD_STORE_NT(value, pointer) __builtin_nontemporal_store(value, pointer)
+// the lanes of a wave exchange data through LDS: LDS instructions of a wave execute in order, so the hardware needs nothing --
+// this only keeps the compiler from moving memory accesses across the point
+#define MBAMD_WAVE_SYNC() __builtin_amdgcn_wave_barrier()
+// a use the compiler cannot move or drop: whatever wait the values need is placed here (a load consumed in the branch that issued it)
+#define MBAMD_CONSUME1(a) asm volatile("" : "+v"(a))
+#define MBAMD_CONSUME4(a, b, c, d) asm volatile("" : "+v"(a), "+v"(b), "+v"(c), "+v"(d))
 #define MBAMD_IMPL_NAME "mbamd HIP gfx950"
 namespace mbamd {
 // a native clang vector (not HIP's f4 class) so that it can be loaded/stored through

@@ -277,70 +277,114 @@ k64_rescale(const Op64* __restrict__ ops, int S, int K, int Ppad_)
 // child is a compact tip, a slot of the workgroup's LDS, or read from HBM in place).  Results are stored once and children the wave
 // produced itself are read back from LDS: HBM sees (almost) only the write stream -- the level kernels read every child back.
 // Arithmetic and its order are those of k64_partials_fused: the two paths give the same bits (MBAMD_F64_NO_WALK=1 selects the levels).
-struct Walk64Entry {
-    double* dst;
-    const void* c1;              // tip: compact states (uint8); memory: partials; slot: unused
-    const void* c2;
-    const double* m1T;           // transposed matrices [K][4][4]
-    const double* m2T;
-    int32_t* scale;              // exponents written (mode 1) or read (mode 2)
-    uint32_t ctl0;               // kind1 | kind2 << 8 | slot1 << 16 | slot2 << 24   (kind: 0 LDS slot, 1 memory, 2 compact tip)
-    uint32_t ctl1;               // keep | mode << 8 | nop << 16                     (keep: slot the result is also written to, 0xFF none)
-    int pad_[2];
+struct Walk64Entry {             // 32 bytes, one scalar load: INDICES (buffer, matrix, exponent row), the bases are kernel arguments
+    uint32_t dst;                // partials buffer written
+    uint32_t c1, c2;             // memory child: partials buffer; compact tip: row of the state array; LDS child: unused
+    uint32_t m1, m2;             // matrix buffers
+    uint32_t scaleR, scaleW;     // exponent rows read (mode 2) / written (mode 1); the instance's scratch row when unused
+    uint32_t ctl;                // kind1 | kind2 << 2 | mode << 4 | nop << 6 | slot1 << 8 | slot2 << 16 | keep << 24
+};                               //   kind: 0 LDS slot, 1 memory, 2 compact tip; keep: slot the result is also written to, 0xFF none
+static_assert(sizeof(Walk64Entry) == 32, "Walk64Entry is one 32-byte scalar load");
+struct Walk64Args {
+    const Walk64Entry* prog;
+    int entries, nslots;
+    double* partials;            // [buffer][K][4][Ppad]
+    unsigned bufDoubles;         // doubles per buffer (K x 4 x Ppad)
+    const uint8_t* states;       // [row][Ppad]
+    const double* matricesT;     // transposed copy [K][4][4] of matrix 0; matrix m is matDoubles further
+    unsigned matDoubles;
+    int32_t* scale;              // [row][Ppad]
+    int32_t* cum;                // cumulative row of the list, or nullptr
+    int Ppad;
+    int scratchRow;              // exponent row nobody reads
 };
-static_assert(sizeof(Walk64Entry) == 64, "Walk64Entry is one 64-byte scalar load");
 __device__ __forceinline__ Walk64Entry w64_load(const MBAMD_AS_CONST Walk64Entry* p)
 {
     Walk64Entry e;
-    e.dst = p->dst; e.c1 = p->c1; e.c2 = p->c2; e.m1T = p->m1T; e.m2T = p->m2T; e.scale = p->scale; e.ctl0 = p->ctl0; e.ctl1 = p->ctl1;
+    e.dst = p->dst; e.c1 = p->c1; e.c2 = p->c2; e.m1 = p->m1; e.m2 = p->m2; e.scaleR = p->scaleR; e.scaleW = p->scaleW; e.ctl = p->ctl;
     return e;
+}
+// Vector-memory results return in order behind everything issued before them: a load issued after an entry's stores waits for
+// those stores to reach HBM (microseconds under a write stream).  What nearly every entry loads -- the states of its compact
+// tips, one byte per lane -- is therefore fetched ONE ENTRY AHEAD, before the previous entry's stores, by two loads that every
+// entry issues whatever its children are (an entry without tips reads one harmless, cached byte): straight-line code, so the
+// compiler's wait counts are exact and leave the stores in flight.  Children that live in HBM (evicted from the LDS slots: 3 of
+// 996 at 500 taxa with four slots, none with five) and stored exponents (SCALE_READ) are loaded where they are used, with a
+// full wait -- rare enough.  An entry without a scale buffer writes its zero exponents to the instance's scratch row (the same
+// five stores for every entry); the host leaves no no-operation entries in the program; the loop is entered after a whole first
+// entry, so that both ways into the loop head end with the same instruction sequence.  Addresses are a scalar base plus a
+// 32-bit lane offset (the saddr form: no vector arithmetic per access).
+__device__ __forceinline__ unsigned w64_fetch_state(const Walk64Args& a, unsigned kind, unsigned row, unsigned c)
+{
+    const unsigned long idle = (unsigned long) a.prog;
+    const unsigned long tip = kind == 2u ? ~0ul : 0ul;
+    const unsigned long base = idle + ((((unsigned long) a.states + (unsigned long) row * (unsigned) a.Ppad) - idle) & tip);
+    return *reinterpret_cast<const MBAMD_AS_GLOBAL uint8_t*>(base + (c & (unsigned) tip));
+}
+// The two 4 x 4 matrices of an entry (this wave's category) are fetched the same way, one entry ahead: ONE vector load -- lane l
+// takes element l & 15 of child (l >> 4) & 1's matrix -- parked in 256 bytes of LDS and read back as broadcasts (every lane the same
+// address: conflict-free).  (As scalar loads -- 64 SGPRs for both, more than the file spares -- the second matrix could only be
+// requested after the first child's factor, its latency exposed in the middle of every entry: 2.5 against F64NEW ms at 1000 x 50 000.)
+__device__ __forceinline__ double w64_fetch_matrices(const Walk64Args& a, const Walk64Entry& e, int k, int lane)
+{
+    const unsigned o1 = e.m1 * a.matDoubles * 8u, o2 = e.m2 * a.matDoubles * 8u;           // (below 4 GiB: the host checks)
+    const unsigned off = ((lane & 16) ? o2 : o1) + (unsigned) (lane & 15) * 8u;
+    return *reinterpret_cast<const MBAMD_AS_GLOBAL double*>((unsigned long) a.matricesT + (unsigned long) k * 128 + off);
 }
 
 template <int KF>
-__global__ void __launch_bounds__(64 * KF)
-k64_walk4(const Walk64Entry* __restrict__ prog, int entries, int Ppad_, int nslots, int32_t* __restrict__ cum)
+__global__ void __launch_bounds__(64 * KF, 4)
+k64_walk4(Walk64Args a)
 {
     // workgroup = KF waves over the same 64 patterns, wave k = category k (four times the waves of a pattern-per-thread walk:
     // the walk is a latency chain per wave).  The rescaling maximum is per PATTERN: the waves' maxima meet in LDS, one barrier
-    // per rescaled operation, double-buffered so that the next operation's write cannot overtake this one's reads.
-    double* const slots = mbd_dyn_lds<double>();      // [slot][KF][4][64] | exchange [2][KF][64]
-    double* const xch = slots + (size_t) nslots * KF * 4 * 64;
-    const size_t Ppad = (size_t) Ppad_;
+    // per operation, double-buffered so that the next operation's write cannot overtake this one's reads.  A wave reads back
+    // from LDS only what it wrote itself (its category of a slot): the slots need no barrier.
+    double* const slots = mbd_dyn_lds<double>();      // [slot][KF][4][64] | exchange [2][KF][64] | matrices [KF][32]
+    double* const xch = slots + (size_t) a.nslots * KF * 4 * 64;
+    const unsigned Ppad = (unsigned) a.Ppad;
     const int lane = (int) threadIdx.x & 63, k = mbd_wave_index();
-    const size_t c = (size_t) blockIdx.x * 64 + lane;
+    double* const mats = xch + 2 * KF * 64 + k * 32;                      // this wave's two matrices [child][from][to]
+    const unsigned c = blockIdx.x * 64u + (unsigned) lane;
+    const unsigned c8 = c * 8u;                                            // lane offsets in bytes (Ppad < 2^26: the host checks)
+    const bool mine = ((unsigned) (lane * KF) >> 6) == (unsigned) k;      // the lanes whose exponents this wave stores (1 / KF of them)
+    const unsigned scratchOff = (unsigned) a.scratchRow * Ppad * 4u + c * 4u;
+    const unsigned long partialsK = (unsigned long) a.partials + (unsigned long) k * 4 * Ppad * 8;     // this category's planes
+    double* const mySlots = slots + (size_t) k * 4 * 64 + lane;           // + slot * KF * 256 + q * 64
     int sum = 0, flip = 0;
-    // entries are whole 64-byte scalar loads, the next one fetched while this one runs
-    const MBAMD_AS_CONST Walk64Entry* cprog = as_const(prog);
-    Walk64Entry nxt = w64_load(cprog);
-    for (int j = 0; j < entries; ++j) {
-        const Walk64Entry e = nxt;
-        nxt = w64_load(cprog + (j + 1 < entries ? j + 1 : j));
-        const unsigned kind1 = e.ctl0 & 0xFFu, kind2 = (e.ctl0 >> 8) & 0xFFu, slot1 = (e.ctl0 >> 16) & 0xFFu, slot2 = e.ctl0 >> 24;
-        const unsigned keep = e.ctl1 & 0xFFu, mode = (e.ctl1 >> 8) & 0xFFu;
-        if ((e.ctl1 >> 16) & 1u) continue;
-        double out[4], f2[4];
-        // the matrix of (child, category) is wave-uniform: sixteen doubles through the scalar path; a compact tip is the same
-        // product with an indicator vector (adding exact zeros: the bits of the gather the level kernels do), missing data = 1
-        double ma[16], mb[16];                         // (issued first: two scalar bursts that the children's loads then overlap)
-        {
-            const MBAMD_AS_CONST double* __restrict__ pa = as_const(e.m1T) + (size_t) k * 16;
-            const MBAMD_AS_CONST double* __restrict__ pb = as_const(e.m2T) + (size_t) k * 16;
-#pragma unroll
-            for (int q = 0; q < 16; ++q) { ma[q] = pa[q]; mb[q] = pb[q]; }
-        }
-        auto factor = [&](int kind, const void* ptr, int slot, const double (&m)[16], double (&f)[4]) {
+    const MBAMD_AS_CONST Walk64Entry* cprog = as_const(a.prog);
+    const int last = a.entries - 1;
+    Walk64Entry cur = w64_load(cprog), nxt = w64_load(cprog + (last > 0 ? 1 : 0));
+    struct Fetched { double m; unsigned st1, st2; };                       // what was fetched ahead for one entry
+    auto fetch = [&](const Walk64Entry& e, Fetched& f) {
+        f.m = w64_fetch_matrices(a, e, k, lane);
+        f.st1 = w64_fetch_state(a, e.ctl & 3u, e.c1, c);
+        f.st2 = w64_fetch_state(a, (e.ctl >> 2) & 3u, e.c2, c);
+    };
+    // one entry: what it needs from HBM in `in` (fetched during the previous entry), the next entry's fetched into `next`
+    auto step = [&](int j, const Fetched& in, Fetched& next) {
+        fetch(nxt, next);                                // (a harmless repeat of the last entry at the end)
+        const unsigned kind1 = cur.ctl & 3u, kind2 = (cur.ctl >> 2) & 3u, mode = (cur.ctl >> 4) & 3u;
+        const unsigned slot1 = (cur.ctl >> 8) & 0xFFu, slot2 = (cur.ctl >> 16) & 0xFFu, keep = cur.ctl >> 24;
+        mats[lane & 31] = in.m;                         // (lanes 32 .. 63 hold the same elements again)
+        MBAMD_WAVE_SYNC();
+        double out[4], f2[4], mx = 0.0;
+        // a compact tip is the same product with an indicator vector (adding exact zeros: the bits of the gather the level
+        // kernels do), missing data = 1
+        auto factor = [&](unsigned kind, unsigned slot, unsigned buf, unsigned st, const double* m, double (&f)[4]) {
             double v[4];
-            unsigned st = 0;
-            if (kind == 0) {
-                const double* sl = slots + ((size_t) (slot * KF + k) * 4) * 64 + lane;
+            if (kind == 0u) {
+                const double* sl = mySlots + (size_t) slot * (KF * 256);
 #pragma unroll
                 for (int q = 0; q < 4; ++q) v[q] = sl[q * 64];
-            } else if (kind == 1) {
-                const MBAMD_AS_GLOBAL double* cl = as_global(reinterpret_cast<const double*>(ptr)) + (size_t) k * 4 * Ppad + c;
+            } else if (kind == 1u) {
+                const unsigned long base = partialsK + (unsigned long) buf * a.bufDoubles * 8;
 #pragma unroll
-                for (int q = 0; q < 4; ++q) v[q] = cl[(size_t) q * Ppad];
+                for (int q = 0; q < 4; ++q) v[q] = *reinterpret_cast<const MBAMD_AS_GLOBAL double*>(base + (unsigned long) q * Ppad * 8 + c8);
+                // (consumed HERE: a load still pending where the branches meet makes the compiler wait for every vector-memory
+                //  instruction -- the previous entry's stores included -- on all paths)
+                MBAMD_CONSUME4(v[0], v[1], v[2], v[3]);
             } else {
-                st = as_global(reinterpret_cast<const uint8_t*>(ptr))[c];
 #pragma unroll
                 for (int q = 0; q < 4; ++q) v[q] = st == (unsigned) q ? 1.0 : 0.0;
             }
@@ -350,14 +394,14 @@ k64_walk4(const Walk64Entry* __restrict__ prog, int entries, int Ppad_, int nslo
             for (int q = 0; q < 4; ++q)
 #pragma unroll
                 for (int i = 0; i < 4; ++i) f[i] = fma(m[q * 4 + i], v[q], f[i]);
-            if (kind == 2 && st >= 4u) {
+            if (kind == 2u && st >= 4u) {
 #pragma unroll
                 for (int i = 0; i < 4; ++i) f[i] = 1.0;
             }
         };
-        factor((int) kind1, e.c1, (int) slot1, ma, out);
-        factor((int) kind2, e.c2, (int) slot2, mb, f2);
-        double mx = 0.0;
+        factor(kind1, slot1, cur.c1, in.st1, mats, out);
+        factor(kind2, slot2, cur.c2, in.st2, mats + 16, f2);
+        MBAMD_WAVE_SYNC();                               // (the next entry's matrices overwrite these)
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             out[i] *= f2[i];
@@ -375,21 +419,39 @@ k64_walk4(const Walk64Entry* __restrict__ prog, int entries, int Ppad_, int nslo
             }
             if (mx > 0.0 && mx < 1.0e300) (void) frexp(mx, &ex);
             ex = ex < -1000 ? -1000 : ex;
-            if (k == 0) {
-                as_global(e.scale)[c] = ex;
-                sum += ex;
-            }
+            sum += ex;
         } else if (mode == 2u) {
-            ex = as_global(e.scale)[c];
+            ex = *reinterpret_cast<const MBAMD_AS_GLOBAL int32_t*>((unsigned long) a.scale + (unsigned long) cur.scaleR * Ppad * 4 + c * 4u);
+            MBAMD_CONSUME1(ex);
         }
+        const unsigned long dst = partialsK + (unsigned long) cur.dst * a.bufDoubles * 8;
+        const unsigned scaleOff = mine ? cur.scaleW * Ppad * 4u + c * 4u : scratchOff;      // (an entry without a scale buffer: scaleW is the scratch row)
+        // the descriptor after next: a scalar load that the stores below and the next entry's fetch hide
+        cur = nxt;
+        nxt = w64_load(cprog + (j + 2 < last ? j + 2 : last));
+        double v[4];
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            const double v = ex != 0 ? ldexp(out[i], -ex) : out[i];
-            as_global(e.dst)[((size_t) k * 4 + i) * Ppad + c] = v;
-            if (keep != 0xFFu) slots[((size_t) (keep * KF + k) * 4 + i) * 64 + lane] = v;
+            v[i] = ex != 0 ? ldexp(out[i], -ex) : out[i];
+            // (non-temporal: with write-allocate the result stream evicts matrices and programs from L2)
+            MBAMD_STORE_NT(v[i], reinterpret_cast<MBAMD_AS_GLOBAL double*>(dst + (unsigned long) i * Ppad * 8 + c8));
         }
+        *reinterpret_cast<MBAMD_AS_GLOBAL int32_t*>((unsigned long) a.scale + scaleOff) = ex;
+        if (keep != 0xFFu) {
+            double* sl = mySlots + (size_t) keep * (KF * 256);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) sl[i * 64] = v[i];
+        }
+    };
+    Fetched A, B;
+    fetch(cur, A);
+    step(0, A, B);
+    for (int j = 1; j <= last; j += 2) {
+        step(j, B, A);
+        if (j + 1 > last) break;
+        step(j + 1, A, B);
     }
-    if (k == 0 && cum != nullptr && sum != 0) as_global(cum)[c] += sum;
+    if (k == 0 && a.cum != nullptr && sum != 0) as_global(a.cum)[c] += sum;
 }
 
 struct MatrixJob64 {
@@ -580,7 +642,7 @@ public:
     std::vector<Walk4Op> walkOps;
     std::vector<Walk64Entry> walkProg;
     uint64_t walkLaunches = 0, levelLaunches = 0;
-    bool walkAlways = false;
+    bool walkAlways = false, walkVerbose = false;   // MBAMD_F64_WALK_ALWAYS, MBAMD_VERBOSE
     bool noMfma = false;                           // MBAMD_F64_NO_MFMA: the vector-ALU level kernels for 16..64 states too
     bool walkOff = false;                          // MBAMD_F64_NO_WALK (read when the instance is created): level kernels only
     size_t bufDoubles = 0, matDoubles = 0, eigDoubles = 0;
@@ -596,6 +658,7 @@ public:
         IB = blockOf(S);
         walkOff = std::getenv("MBAMD_F64_NO_WALK") != nullptr;
         walkAlways = std::getenv("MBAMD_F64_WALK_ALWAYS") != nullptr;
+        walkVerbose = std::getenv("MBAMD_VERBOSE") != nullptr;
         noMfma = std::getenv("MBAMD_F64_NO_MFMA") != nullptr;
         SPAD = (S + IB - 1) / IB * IB;
         bufDoubles = (size_t) K * S * Ppad;
@@ -613,8 +676,9 @@ public:
         HIP_TRY(hipMalloc(&d_weights, std::max<size_t>(1, (size_t) nEigen * K) * sizeof(double)));
         HIP_TRY(hipMalloc(&d_pweights, (size_t) Ppad * sizeof(double)));
         HIP_TRY(hipMemsetAsync(d_pweights, 0, (size_t) Ppad * sizeof(double), stream));
-        HIP_TRY(hipMalloc(&d_scale, std::max<size_t>(1, (size_t) nScale * Ppad) * sizeof(int32_t)));
-        HIP_TRY(hipMemsetAsync(d_scale, 0, std::max<size_t>(1, (size_t) nScale * Ppad) * sizeof(int32_t), stream));
+        // (one row more than the caller's: the scratch row the walk's entries without a scale buffer write their zero exponents to)
+        HIP_TRY(hipMalloc(&d_scale, (size_t) (nScale + 1) * Ppad * sizeof(int32_t)));
+        HIP_TRY(hipMemsetAsync(d_scale, 0, (size_t) (nScale + 1) * Ppad * sizeof(int32_t), stream));
         HIP_TRY(hipMalloc(&d_site, (size_t) Ppad * sizeof(double)));
         sumsCap = (size_t) (Ppad / 64);
         HIP_TRY(hipMalloc(&d_sums, sumsCap * sizeof(double)));
@@ -818,20 +882,21 @@ public:
 
     // The walk serves what MrBayes sends for nucleotides: four states, up to eight categories, no pattern partitions, one
     // cumulative buffer for the whole list, no buffer hazards inside the list.  Returns 1 when the list is not of that kind.
-    template <int KF> void launchWalk(const Walk64Entry* prog, int entries, int nslots, int32_t* cum)
+    template <int KF> void launchWalk(const Walk64Args& wa)
     {
         auto kern = k64_walk4<KF>;
-        const size_t lds = ((size_t) nslots * KF * 4 * 64 + (size_t) 2 * KF * 64) * sizeof(double);
+        const size_t lds = ((size_t) wa.nslots * KF * 4 * 64 + (size_t) 2 * KF * 64 + (size_t) KF * 32) * sizeof(double);
         static char raised[64] = {0};                // per device (and per KF: a static of this template instance)
         if (device >= 0 && device < 64 && !raised[device]) {
             if (hipFuncSetAttribute((const void*) kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) (void) hipGetLastError();
             raised[device] = 1;
         }
-        MBAMD_LAUNCH_BARRIER(kern, (unsigned) (Ppad / 64), 64 * KF, lds, stream, prog, entries, Ppad, nslots, cum);
+        MBAMD_LAUNCH_BARRIER(kern, (unsigned) (Ppad / 64), 64 * KF, lds, stream, wa);
     }
     int tryWalk4(const void* opsRaw, size_t stride, int n, const int* partition, const int* cumOf)
     {
-        if (walkOff || S != 4 || K > 8 || !parts.empty() || n < 2) return 1;
+        // (the kernel addresses with 32-bit lane offsets: a plane of partials and the whole exponent array below 4 GiB)
+        if (walkOff || S != 4 || K > 8 || !parts.empty() || n < 2 || (bufDoubles >> 29) != 0 || (((size_t) nScale + 1) * Ppad >> 30) != 0 || ((size_t) nMatrices * matDoubles >> 29) != 0) return 1;
         // the walk is one latency chain per wave: it wins when there are enough waves (break-even about 1.2 per SIMD) and on short lists (a
         // root-ward path: one launch instead of one per operation); mid-sized full evaluations stay on the level kernels
         // (measured: profiles/r03_f64_walk.txt).  MBAMD_F64_WALK_ALWAYS=1: every eligible list.
@@ -870,8 +935,9 @@ public:
         const int slotBytes = K * 4 * 64 * (int) sizeof(double);
         const long wgs = Ppad / 64;
         const int perCU = (int) std::min(4L, std::max(1L, (wgs + 255) / 256));
-        int nslots = std::max(2, std::min(24, ((160 * 1024) / perCU - 2048) / slotBytes));
-        if (const char* e = std::getenv("MBAMD_F64_WALK_SLOTS")) nslots = std::max(2, std::min((160 * 1024 - 2048) / slotBytes, std::atoi(e)));
+        const int fixedBytes = (2 * K * 64 + K * 32) * (int) sizeof(double);      // the exchange buffers and the parked matrices
+        int nslots = std::max(2, std::min(24, ((160 * 1024) / perCU - fixedBytes) / slotBytes));
+        if (const char* e = std::getenv("MBAMD_F64_WALK_SLOTS")) nslots = std::max(2, std::min((160 * 1024 - fixedBytes) / slotBytes, std::atoi(e)));
         // structure key: who produces whose child, which children are tips (the indices only fill the program)
         std::vector<int> key;
         key.reserve((size_t) n * 3 + 2);
@@ -895,43 +961,71 @@ public:
         const Walk4Template& t = walkTemplate;
         if (t.W != 1) return 1;
         walkProg.assign((size_t) t.entries, Walk64Entry());
+        const unsigned scratch = (unsigned) nScale;                 // the extra exponent row: what entries without a scale buffer "write"
         for (int i = 0; i < t.entries; ++i) {
             const Walk4Template::Entry& te = t.prog[i];
             Walk64Entry& e = walkProg[i];
             std::memset(&e, 0, sizeof e);
+            e.scaleR = e.scaleW = scratch;
             unsigned kind1 = 0, kind2 = 0, slot1 = 0, slot2 = 0;
-            if (te.op < 0) { e.ctl1 = 0xFFu | (1u << 16); continue; }
+            if (te.op < 0) { e.ctl = 1u << 6; continue; }                     // (dropped below)
             const Walk4Op& w = wops[te.op];
-            e.dst = partialsPtr(w.dst);
-            e.m1T = matrixPtr(w.m1) + (size_t) K * S * S;
-            e.m2T = matrixPtr(w.m2) + (size_t) K * S * S;
-            if (w.tip1) { kind1 = 2; e.c1 = statesPtr(w.c1); }
-            else if (te.c1slot == 0xFF) { kind1 = 1; e.c1 = partialsPtr(w.c1); }
+            e.dst = (uint32_t) w.dst; e.m1 = (uint32_t) w.m1; e.m2 = (uint32_t) w.m2;
+            if (w.tip1) { kind1 = 2; e.c1 = (uint32_t) stateSlot[w.c1]; }
+            else if (te.c1slot == 0xFF) { kind1 = 1; e.c1 = (uint32_t) w.c1; }
             else { kind1 = 0; slot1 = te.c1slot; }
-            if (w.tip2) { kind2 = 2; e.c2 = statesPtr(w.c2); }
-            else if (te.c2slot == 0xFF) { kind2 = 1; e.c2 = partialsPtr(w.c2); }
+            if (w.tip2) { kind2 = 2; e.c2 = (uint32_t) stateSlot[w.c2]; }
+            else if (te.c2slot == 0xFF) { kind2 = 1; e.c2 = (uint32_t) w.c2; }
             else { kind2 = 0; slot2 = te.c2slot; }
             const unsigned mode = w.scaleWrite >= 0 ? 1u : (w.scaleRead >= 0 ? 2u : 0u);
-            e.ctl0 = kind1 | (kind2 << 8) | (slot1 << 16) | (slot2 << 24);
-            e.ctl1 = (unsigned) te.dslot | (mode << 8);
-            e.scale = w.scaleWrite >= 0 ? d_scale + (size_t) w.scaleWrite * Ppad : (w.scaleRead >= 0 ? d_scale + (size_t) w.scaleRead * Ppad : nullptr);
+            if (mode == 1u) e.scaleW = (uint32_t) w.scaleWrite;
+            if (mode == 2u) e.scaleR = (uint32_t) w.scaleRead;
+            e.ctl = kind1 | (kind2 << 2) | (mode << 4) | (slot1 << 8) | (slot2 << 16) | ((unsigned) te.dslot << 24);
+        }
+        // the kernel's entries all compute (see k64_walk4): drop the no-operation entries of the builder (one wave: they order nothing)
+        walkProg.erase(std::remove_if(walkProg.begin(), walkProg.end(), [](const Walk64Entry& e) { return ((e.ctl >> 6) & 1u) != 0; }), walkProg.end());
+        if (walkProg.empty()) return 1;
+        {   // the kernel fetches entry i's memory children while entry i-1 runs: their producer must be entry i-2 or earlier
+            std::vector<int> writtenAt((size_t) nBuffers, -1000);
+            for (size_t i = 0; i < walkProg.size(); ++i) {
+                const Walk64Entry& e = walkProg[i];
+                if (((e.ctl & 3u) == 1u && writtenAt[e.c1] >= (int) i - 1) || (((e.ctl >> 2) & 3u) == 1u && writtenAt[e.c2] >= (int) i - 1)) { walkKey.clear(); return 1; }
+                writtenAt[e.dst] = (int) i;
+            }
+        }
+        if (walkVerbose) {
+            int mem = 0, tips = 0;
+            for (const Walk64Entry& e : walkProg) {
+                mem += ((e.ctl & 3u) == 1u) + (((e.ctl >> 2) & 3u) == 1u);
+                tips += ((e.ctl & 3u) == 2u) + (((e.ctl >> 2) & 3u) == 2u);
+            }
+            std::fprintf(stderr, "[mbamd] fp64 walk: %zu entries, %d slots, children: %d compact tips, %d from memory, %zu from LDS\n", walkProg.size(),
+                         t.nslots, tips, mem, 2 * walkProg.size() - (size_t) tips - (size_t) mem);
         }
         for (const Walk4Op& w : wops) { valid[w.dst] = 1; isTip[w.dst] = 0; }
         st_.reset();
         void* dv = nullptr;
         int rc = stage(walkProg.data(), walkProg.size() * sizeof(Walk64Entry), &dv);
         if (rc) return rc;
-        int32_t* cum = cumIdx != BEAGLE_OP_NONE ? d_scale + (size_t) cumIdx * Ppad : nullptr;
-        const Walk64Entry* prog = static_cast<const Walk64Entry*>(dv);
+        Walk64Args wa;
+        wa.prog = static_cast<const Walk64Entry*>(dv);
+        wa.entries = (int) walkProg.size(); wa.nslots = t.nslots;
+        wa.partials = d_partials; wa.bufDoubles = (unsigned) bufDoubles;
+        wa.states = d_states;
+        wa.matricesT = d_matrices + (size_t) K * S * S; wa.matDoubles = (unsigned) matDoubles;
+        wa.scale = d_scale;
+        wa.cum = cumIdx != BEAGLE_OP_NONE ? d_scale + (size_t) cumIdx * Ppad : nullptr;
+        wa.Ppad = (int) Ppad;
+        wa.scratchRow = nScale;
         switch (K) {
-            case 1: launchWalk<1>(prog, t.entries, t.nslots, cum); break;
-            case 2: launchWalk<2>(prog, t.entries, t.nslots, cum); break;
-            case 3: launchWalk<3>(prog, t.entries, t.nslots, cum); break;
-            case 4: launchWalk<4>(prog, t.entries, t.nslots, cum); break;
-            case 5: launchWalk<5>(prog, t.entries, t.nslots, cum); break;
-            case 6: launchWalk<6>(prog, t.entries, t.nslots, cum); break;
-            case 7: launchWalk<7>(prog, t.entries, t.nslots, cum); break;
-            default: launchWalk<8>(prog, t.entries, t.nslots, cum); break;
+            case 1: launchWalk<1>(wa); break;
+            case 2: launchWalk<2>(wa); break;
+            case 3: launchWalk<3>(wa); break;
+            case 4: launchWalk<4>(wa); break;
+            case 5: launchWalk<5>(wa); break;
+            case 6: launchWalk<6>(wa); break;
+            case 7: launchWalk<7>(wa); break;
+            default: launchWalk<8>(wa); break;
         }
         HIP_TRY(hipGetLastError());
         walkLaunches++;
