@@ -108,7 +108,7 @@ def mcmc_gen_per_s(gold, nchains=1, quick=True):
            "note": "default_moves: MrBayes' default proposal mix; 11.5% of its moves are ParsSPR1/ParsTBR1, whose O(taxa x "
                    "patterns) parsimony scoring runs on the host in the unmodified binary (`engine`, `reference_cpu`) and bounds "
                    "its rate; `engine_device_parsimony` = a PATCHED binary: the same sources with src/proposal.c and src/model.c edited on "
-                   "the fly by oracle/patch_pars.py to call the device-parsimony binding (SURVEY 8(f) item 4, integration/mrbayes/; "
+                   "the fly by integration/mrbayes/patches/patch_pars.py to call the device-parsimony binding (SURVEY 8(f) item 4, integration/mrbayes/; "
                    "same proposals and chain as the unmodified binary); "
                    "fixed_topology = branch-length and substitution-parameter moves only (prset topologypr=fixed)"}
     windows = {(False, "engine"): (300, 1300) if quick else (500, 2500), (True, "engine"): (2000, 12000) if quick else (2000, 22000),
@@ -165,7 +165,7 @@ def mpi_mcmc(nranks, emulate=False, full=False):
     """The reference's own chain-parallel design measured on the real binary: MrBayes' MPI build (chains spread over ranks,
     src/mcmc.c:18331-18384; rank r computes on GPU (instance + r) mod #GPUs, src/mbbeagle.c:201-207) on the single-node MPI shim
     (integration/mpi_shim), started as `mbamd_mpirun -n <ranks> mb_amd_mpi_pars` -- the binary with the device-parsimony binding
-    (a PATCHED binary: oracle/patch_pars.py), MrBayes' default move mix.  Two analyses, generations/s by two-point differencing:
+    (a PATCHED binary: integration/mrbayes/patches/patch_pars.py), MrBayes' default move mix.  Two analyses, generations/s by two-point differencing:
       * BASELINE configs[3]: DNA GTR+G4, nchains=8 (alignment: configs[1]'s 500 x 20 000 unless --mpi-full asks for 1000 x 50 000,
         whose start-up alone takes minutes);
       * BASELINE configs[4]: codon M3 100 x 5 000, nruns=2 x nchains=4.

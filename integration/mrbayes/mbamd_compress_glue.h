@@ -16,7 +16,7 @@
  *         { ...the reference's search, unchanged... }
  *
  * MBAMD_HASH_COMPRESS=0 switches it off; MBAMD_COMPRESS_CHECK=1 runs the reference's search as well and compares.
- * oracle/patch_pars.py applies the edit to a temporary copy of model.c for the _ref/mb_*_pars binaries.
+ * integration/mrbayes/patches/patch_pars.py applies the edit to a temporary copy of model.c for the _ref/mb_*_pars binaries.
  */
 #ifndef MBAMD_COMPRESS_GLUE_H_
 #define MBAMD_COMPRESS_GLUE_H_

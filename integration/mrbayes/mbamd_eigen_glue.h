@@ -4,7 +4,7 @@
  *       isComplex = GetEigens (n, q[..], eigenValues, ...)
  * become
  *       isComplex = MbamdGetEigens (m, whichChain, q, <part>, n, q[..], eigenValues, ...)
- * (oracle/patch_eigen.py does exactly this to a temporary copy; oracle/Makefile: ref-amd-full).  For a division that does not
+ * (integration/mrbayes/patches/patch_eigen.py does exactly this to a temporary copy; oracle/Makefile: ref-amd-full).  For a division that does not
  * run on the engine -- or MBAMD_DEVICE_EIGEN=0 -- the call IS GetEigens.  Otherwise the first part's call sends ALL rate
  * matrices of the division (the omega classes of a codon model, the rate categories of a covarion model: the reference builds
  * them all before it decomposes the first, src/likelihood.c:10688-10716) to mbamdSetRateMatricesFrom in one asynchronous

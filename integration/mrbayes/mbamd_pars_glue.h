@@ -11,7 +11,7 @@
  *       if (MbamdParsActive (t) == YES && MbamdParsLengths (...) == ERROR) goto errorExit;
  *       if (MbamdParsHostToo (t, parLength, nRoot*nCrown) == YES) { ...the reference's loop, unchanged... }
  *       MbamdParsCompare (parLength, nRoot*nCrown);
- * oracle/patch_pars.py applies exactly this to a temporary copy of proposal.c when oracle/Makefile builds
+ * integration/mrbayes/patches/patch_pars.py applies exactly this to a temporary copy of proposal.c when oracle/Makefile builds
  * _ref/mb_amd_pars and _ref/mb_emu_pars.
  */
 #ifndef MBAMD_PARS_GLUE_H_

@@ -34,6 +34,13 @@ __device__ __forceinline__ float mbd_ldexp(float v, int e) { return __builtin_am
 __device__ __forceinline__ float mbd_pow2(int e) { return __builtin_bit_cast(float, (unsigned) (127 + e) << 23); }
 __device__ __forceinline__ int mbd_wave_index() { return __builtin_amdgcn_readfirstlane((int) (threadIdx.x >> 6)); }
 // the workgroup's dynamic LDS (one symbol per translation unit: every kernel sees the same array)
+// maximum over the lanes l, l ^ PW, l ^ 2 PW, ... of a wave (lane = group * PW + member: the same member of every group)
+template <int PW> __device__ __forceinline__ double mbd_max_across_groups(double v)
+{
+#pragma unroll
+    for (int d = PW; d < 64; d <<= 1) v = fmax(v, __shfl_xor(v, d));
+    return v;
+}
 template <class T> __device__ __forceinline__ T* mbd_dyn_lds()
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char mbd_lds_bytes[];

@@ -3852,6 +3852,7 @@ int mbamdGetKernelTiming(int instance, double* outMilliseconds, long* outLaunche
 {
     GET_INSTANCE(instance);
     if (in->f64) {                               // (no device timing on a double-precision instance: the partials launches are counted)
+        { const int rcq = in->f64->flushQueue(); if (rcq) return rcq; }
         if (outMilliseconds) *outMilliseconds = 0.0;
         if (outLaunches) *outLaunches = (long) (in->f64->walkLaunches + in->f64->levelLaunches);
         if (reset) in->f64->walkLaunches = in->f64->levelLaunches = 0;

@@ -271,12 +271,18 @@ k64_rescale(const Op64* __restrict__ ops, int S, int K, int Ppad_)
 
 
 // ---------------------------------------------------------------------------------------------------------------------------
-// Four states: the tree walk in fp64 -- ONE launch per operation list instead of one per dependency level.  A workgroup owns 64
-// patterns, one wave per category (the rescaling maximum is per pattern, as in k64_partials_fused: the waves' maxima meet in LDS);
-// all waves interpret one program compiled by the same Walk4Builder as the fp32 walks (mbamd_walk4_host.h, register-fed mode: a
-// child is a compact tip, a slot of the workgroup's LDS, or read from HBM in place).  Results are stored once and children the wave
-// produced itself are read back from LDS: HBM sees (almost) only the write stream -- the level kernels read every child back.
-// Arithmetic and its order are those of k64_partials_fused: the two paths give the same bits (MBAMD_F64_NO_WALK=1 selects the levels).
+// Four states: the tree walk in fp64 -- ONE launch per operation list instead of one per dependency level.  A WAVE owns PW = 64 / KP
+// patterns with all their categories: lane = category * PW + pattern (KP = the category count rounded up to a power of two; the
+// lanes of a category beyond the last repeat the last one, bit for bit, and store the same values to the same addresses).  The
+// rescaling maximum is per PATTERN (CondLikeScaler_*): the categories of a pattern meet through log2(KP) lane exchanges -- no
+// barrier, no LDS exchange, a workgroup is one wave.  All waves interpret one program compiled by the same Walk4Builder as the
+// fp32 walks (mbamd_walk4_host.h, register-fed mode: a child is a compact tip, a slot of the wave's LDS, or read from HBM in
+// place).  Results are stored once and children the wave produced itself are read back from LDS: HBM sees (almost) only the
+// write stream -- the level kernels read every child back.  Arithmetic and its order are those of k64_partials_fused: the two
+// paths give the same bits (MBAMD_F64_NO_WALK=1 selects the levels).
+// (Round 3's version -- a workgroup of K waves, one per category, the maxima exchanged through LDS behind a barrier per
+//  operation, matrices as scalar operands, every load issued where it was used: 2.50 ms per evaluation at 1000 x 50 000, the
+//  barrier version with this file's fetch-ahead 1.64 ms; 782 four-wave workgroups also spread unevenly over 256 CUs.)
 struct Walk64Entry {             // 32 bytes, one scalar load: INDICES (buffer, matrix, exponent row), the bases are kernel arguments
     uint32_t dst;                // partials buffer written
     uint32_t c1, c2;             // memory child: partials buffer; compact tip: row of the state array; LDS child: unused
@@ -297,6 +303,7 @@ struct Walk64Args {
     int32_t* cum;                // cumulative row of the list, or nullptr
     int Ppad;
     int scratchRow;              // exponent row nobody reads
+    int K;                       // categories (<= KP of the instantiation)
 };
 __device__ __forceinline__ Walk64Entry w64_load(const MBAMD_AS_CONST Walk64Entry* p)
 {
@@ -305,15 +312,15 @@ __device__ __forceinline__ Walk64Entry w64_load(const MBAMD_AS_CONST Walk64Entry
     return e;
 }
 // Vector-memory results return in order behind everything issued before them: a load issued after an entry's stores waits for
-// those stores to reach HBM (microseconds under a write stream).  What nearly every entry loads -- the states of its compact
-// tips, one byte per lane -- is therefore fetched ONE ENTRY AHEAD, before the previous entry's stores, by two loads that every
-// entry issues whatever its children are (an entry without tips reads one harmless, cached byte): straight-line code, so the
-// compiler's wait counts are exact and leave the stores in flight.  Children that live in HBM (evicted from the LDS slots: 3 of
-// 996 at 500 taxa with four slots, none with five) and stored exponents (SCALE_READ) are loaded where they are used, with a
-// full wait -- rare enough.  An entry without a scale buffer writes its zero exponents to the instance's scratch row (the same
-// five stores for every entry); the host leaves no no-operation entries in the program; the loop is entered after a whole first
-// entry, so that both ways into the loop head end with the same instruction sequence.  Addresses are a scalar base plus a
-// 32-bit lane offset (the saddr form: no vector arithmetic per access).
+// those stores to reach HBM (microseconds under a write stream).  What every entry loads -- the states of its compact tips (a
+// byte per lane) and its two 4 x 4 matrices per category -- is therefore fetched ONE ENTRY AHEAD, before the previous entry's
+// stores, by loads that every entry issues whatever its children are (an entry without tips reads one harmless, cached byte):
+// straight-line code, so the compiler's wait counts are exact and leave the stores in flight.  Children that live in HBM (evicted
+// from the LDS slots: 3 of 996 at 500 taxa with four slots, none with five) and stored exponents (SCALE_READ) are loaded where
+// they are used and CONSUMED there (a load still pending where branches meet makes the compiler wait for every vector-memory
+// instruction, the previous entry's stores included, on all paths).  An entry without a scale buffer writes its zero exponents
+// to the instance's scratch row (the same five stores for every entry); the host leaves no no-operation entries in the program;
+// the loop is entered after a whole first entry, so that both ways into the loop head end with the same instruction sequence.
 __device__ __forceinline__ unsigned w64_fetch_state(const Walk64Args& a, unsigned kind, unsigned row, unsigned c)
 {
     const unsigned long idle = (unsigned long) a.prog;
@@ -321,72 +328,82 @@ __device__ __forceinline__ unsigned w64_fetch_state(const Walk64Args& a, unsigne
     const unsigned long base = idle + ((((unsigned long) a.states + (unsigned long) row * (unsigned) a.Ppad) - idle) & tip);
     return *reinterpret_cast<const MBAMD_AS_GLOBAL uint8_t*>(base + (c & (unsigned) tip));
 }
-// The two 4 x 4 matrices of an entry (this wave's category) are fetched the same way, one entry ahead: ONE vector load -- lane l
-// takes element l & 15 of child (l >> 4) & 1's matrix -- parked in 256 bytes of LDS and read back as broadcasts (every lane the same
-// address: conflict-free).  (As scalar loads -- 64 SGPRs for both, more than the file spares -- the second matrix could only be
-// requested after the first child's factor, its latency exposed in the middle of every entry: 2.5 against F64NEW ms at 1000 x 50 000.)
-__device__ __forceinline__ double w64_fetch_matrices(const Walk64Args& a, const Walk64Entry& e, int k, int lane)
+// The matrices of an entry: 2 children x KP categories x 16 doubles = KP / 2 doubles per lane (element g = t * 64 + lane:
+// child g / (16 KP), category (g / 16) % KP, entry g % 16), parked in LDS as [child][category][18] (the two pad doubles keep
+// the KP lane groups, which read at the same offset of different categories, on different banks) and read back by every lane
+// from ITS category's rows.
+template <int KP> struct Walk64Fetched {
+    static constexpr int NL = KP >= 2 ? KP / 2 : 1;
+    double m[NL];
+    unsigned st1, st2;
+};
+template <int KP>
+__device__ __forceinline__ void w64_fetch(const Walk64Args& a, const Walk64Entry& e, unsigned c, int lane, Walk64Fetched<KP>& f)
 {
     const unsigned o1 = e.m1 * a.matDoubles * 8u, o2 = e.m2 * a.matDoubles * 8u;           // (below 4 GiB: the host checks)
-    const unsigned off = ((lane & 16) ? o2 : o1) + (unsigned) (lane & 15) * 8u;
-    return *reinterpret_cast<const MBAMD_AS_GLOBAL double*>((unsigned long) a.matricesT + (unsigned long) k * 128 + off);
+#pragma unroll
+    for (int t = 0; t < Walk64Fetched<KP>::NL; ++t) {
+        const int g = (t * 64 + lane) & (32 * KP - 1);                                     // (KP = 1: lanes 32 .. 63 repeat)
+        const int child = g / (16 * KP), cat = (g / 16) % KP, el = g % 16;
+        const int kc = cat < a.K ? cat : a.K - 1;
+        const unsigned off = (child ? o2 : o1) + (unsigned) (kc * 16 + el) * 8u;
+        f.m[t] = *reinterpret_cast<const MBAMD_AS_GLOBAL double*>((unsigned long) a.matricesT + off);
+    }
+    f.st1 = w64_fetch_state(a, e.ctl & 3u, e.c1, c);
+    f.st2 = w64_fetch_state(a, (e.ctl >> 2) & 3u, e.c2, c);
 }
 
-template <int KF>
-__global__ void __launch_bounds__(64 * KF, 4)
+template <int KP>
+__global__ void __launch_bounds__(64, 4)
 k64_walk4(Walk64Args a)
 {
-    // workgroup = KF waves over the same 64 patterns, wave k = category k (four times the waves of a pattern-per-thread walk:
-    // the walk is a latency chain per wave).  The rescaling maximum is per PATTERN: the waves' maxima meet in LDS, one barrier
-    // per operation, double-buffered so that the next operation's write cannot overtake this one's reads.  A wave reads back
-    // from LDS only what it wrote itself (its category of a slot): the slots need no barrier.
-    double* const slots = mbd_dyn_lds<double>();      // [slot][KF][4][64] | exchange [2][KF][64] | matrices [KF][32]
-    double* const xch = slots + (size_t) a.nslots * KF * 4 * 64;
+    constexpr int PW = 64 / KP;                        // patterns per wave
+    constexpr int NL = Walk64Fetched<KP>::NL;
+    double* const slots = mbd_dyn_lds<double>();      // [slot][4][64] | matrices [2][KP][18]
+    double* const mats = slots + (size_t) a.nslots * 4 * 64;
     const unsigned Ppad = (unsigned) a.Ppad;
-    const int lane = (int) threadIdx.x & 63, k = mbd_wave_index();
-    double* const mats = xch + 2 * KF * 64 + k * 32;                      // this wave's two matrices [child][from][to]
-    const unsigned c = blockIdx.x * 64u + (unsigned) lane;
-    const unsigned c8 = c * 8u;                                            // lane offsets in bytes (Ppad < 2^26: the host checks)
-    const bool mine = ((unsigned) (lane * KF) >> 6) == (unsigned) k;      // the lanes whose exponents this wave stores (1 / KF of them)
+    const int lane = (int) threadIdx.x & 63, kk = lane / PW;
+    const int kc = kk < a.K ? kk : a.K - 1;            // (lanes beyond the last category repeat it)
+    const unsigned c = blockIdx.x * (unsigned) PW + (unsigned) (lane % PW);
+    const unsigned laneOff = ((unsigned) kc * 4u * Ppad + c) * 8u;        // this lane's (category, pattern) inside a buffer, bytes
     const unsigned scratchOff = (unsigned) a.scratchRow * Ppad * 4u + c * 4u;
-    const unsigned long partialsK = (unsigned long) a.partials + (unsigned long) k * 4 * Ppad * 8;     // this category's planes
-    double* const mySlots = slots + (size_t) k * 4 * 64 + lane;           // + slot * KF * 256 + q * 64
-    int sum = 0, flip = 0;
+    double* const mySlots = slots + lane;              // + slot * 256 + q * 64
+    const double* const myMats = mats + kk * 18;       // + child * KP * 18
+    int sum = 0;
     const MBAMD_AS_CONST Walk64Entry* cprog = as_const(a.prog);
     const int last = a.entries - 1;
     Walk64Entry cur = w64_load(cprog), nxt = w64_load(cprog + (last > 0 ? 1 : 0));
-    struct Fetched { double m; unsigned st1, st2; };                       // what was fetched ahead for one entry
-    auto fetch = [&](const Walk64Entry& e, Fetched& f) {
-        f.m = w64_fetch_matrices(a, e, k, lane);
-        f.st1 = w64_fetch_state(a, e.ctl & 3u, e.c1, c);
-        f.st2 = w64_fetch_state(a, (e.ctl >> 2) & 3u, e.c2, c);
-    };
     // one entry: what it needs from HBM in `in` (fetched during the previous entry), the next entry's fetched into `next`
-    auto step = [&](int j, const Fetched& in, Fetched& next) {
-        fetch(nxt, next);                                // (a harmless repeat of the last entry at the end)
+    auto step = [&](int j, const Walk64Fetched<KP>& in, Walk64Fetched<KP>& next) {
+        w64_fetch<KP>(a, nxt, c, lane, next);          // (a harmless repeat of the last entry at the end)
         const unsigned kind1 = cur.ctl & 3u, kind2 = (cur.ctl >> 2) & 3u, mode = (cur.ctl >> 4) & 3u;
         const unsigned slot1 = (cur.ctl >> 8) & 0xFFu, slot2 = (cur.ctl >> 16) & 0xFFu, keep = cur.ctl >> 24;
-        mats[lane & 31] = in.m;                         // (lanes 32 .. 63 hold the same elements again)
+#pragma unroll
+        for (int t = 0; t < NL; ++t) {
+            const int g = (t * 64 + lane) & (32 * KP - 1);
+            mats[(g / 16) * 18 + g % 16] = in.m[t];
+        }
         MBAMD_WAVE_SYNC();
         double out[4], f2[4], mx = 0.0;
-        // a compact tip is the same product with an indicator vector (adding exact zeros: the bits of the gather the level
-        // kernels do), missing data = 1
+        // a compact tip's factor is the row of its state (the gather the level kernels do; the product with an indicator vector
+        // would add exact zeros to the same bits), missing data = 1
         auto factor = [&](unsigned kind, unsigned slot, unsigned buf, unsigned st, const double* m, double (&f)[4]) {
+            if (kind == 2u) {
+                const double* row = m + (st < 4u ? st : 0u) * 4;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) f[i] = st < 4u ? row[i] : 1.0;
+                return;
+            }
             double v[4];
             if (kind == 0u) {
-                const double* sl = mySlots + (size_t) slot * (KF * 256);
+                const double* sl = mySlots + (size_t) slot * 256;
 #pragma unroll
                 for (int q = 0; q < 4; ++q) v[q] = sl[q * 64];
-            } else if (kind == 1u) {
-                const unsigned long base = partialsK + (unsigned long) buf * a.bufDoubles * 8;
-#pragma unroll
-                for (int q = 0; q < 4; ++q) v[q] = *reinterpret_cast<const MBAMD_AS_GLOBAL double*>(base + (unsigned long) q * Ppad * 8 + c8);
-                // (consumed HERE: a load still pending where the branches meet makes the compiler wait for every vector-memory
-                //  instruction -- the previous entry's stores included -- on all paths)
-                MBAMD_CONSUME4(v[0], v[1], v[2], v[3]);
             } else {
+                const unsigned long base = (unsigned long) a.partials + (unsigned long) buf * a.bufDoubles * 8;
 #pragma unroll
-                for (int q = 0; q < 4; ++q) v[q] = st == (unsigned) q ? 1.0 : 0.0;
+                for (int q = 0; q < 4; ++q) v[q] = *reinterpret_cast<const MBAMD_AS_GLOBAL double*>(base + (unsigned long) q * Ppad * 8 + laneOff);
+                MBAMD_CONSUME4(v[0], v[1], v[2], v[3]);
             }
 #pragma unroll
             for (int i = 0; i < 4; ++i) f[i] = 0.0;
@@ -394,13 +411,9 @@ k64_walk4(Walk64Args a)
             for (int q = 0; q < 4; ++q)
 #pragma unroll
                 for (int i = 0; i < 4; ++i) f[i] = fma(m[q * 4 + i], v[q], f[i]);
-            if (kind == 2u && st >= 4u) {
-#pragma unroll
-                for (int i = 0; i < 4; ++i) f[i] = 1.0;
-            }
         };
-        factor(kind1, slot1, cur.c1, in.st1, mats, out);
-        factor(kind2, slot2, cur.c2, in.st2, mats + 16, f2);
+        factor(kind1, slot1, cur.c1, in.st1, myMats, out);
+        factor(kind2, slot2, cur.c2, in.st2, myMats + KP * 18, f2);
         MBAMD_WAVE_SYNC();                               // (the next entry's matrices overwrite these)
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
@@ -409,14 +422,7 @@ k64_walk4(Walk64Args a)
         }
         int ex = 0;
         if (mode == 1u) {
-            if (KF > 1) {
-                double* x = xch + (size_t) flip * KF * 64;
-                flip ^= 1;
-                x[k * 64 + lane] = mx;
-                MBAMD_SYNC();
-#pragma unroll
-                for (int q = 0; q < KF; ++q) mx = fmax(mx, x[q * 64 + lane]);
-            }
+            mx = mbd_max_across_groups<PW>(mx);
             if (mx > 0.0 && mx < 1.0e300) (void) frexp(mx, &ex);
             ex = ex < -1000 ? -1000 : ex;
             sum += ex;
@@ -424,8 +430,9 @@ k64_walk4(Walk64Args a)
             ex = *reinterpret_cast<const MBAMD_AS_GLOBAL int32_t*>((unsigned long) a.scale + (unsigned long) cur.scaleR * Ppad * 4 + c * 4u);
             MBAMD_CONSUME1(ex);
         }
-        const unsigned long dst = partialsK + (unsigned long) cur.dst * a.bufDoubles * 8;
-        const unsigned scaleOff = mine ? cur.scaleW * Ppad * 4u + c * 4u : scratchOff;      // (an entry without a scale buffer: scaleW is the scratch row)
+        const unsigned long dst = (unsigned long) a.partials + (unsigned long) cur.dst * a.bufDoubles * 8;
+        // (category 0's lanes store the pattern's exponent; an entry without a scale buffer: scaleW is the scratch row)
+        const unsigned scaleOff = kk == 0 ? cur.scaleW * Ppad * 4u + c * 4u : scratchOff;
         // the descriptor after next: a scalar load that the stores below and the next entry's fetch hide
         cur = nxt;
         nxt = w64_load(cprog + (j + 2 < last ? j + 2 : last));
@@ -434,24 +441,24 @@ k64_walk4(Walk64Args a)
         for (int i = 0; i < 4; ++i) {
             v[i] = ex != 0 ? ldexp(out[i], -ex) : out[i];
             // (non-temporal: with write-allocate the result stream evicts matrices and programs from L2)
-            MBAMD_STORE_NT(v[i], reinterpret_cast<MBAMD_AS_GLOBAL double*>(dst + (unsigned long) i * Ppad * 8 + c8));
+            MBAMD_STORE_NT(v[i], reinterpret_cast<MBAMD_AS_GLOBAL double*>(dst + (unsigned long) i * Ppad * 8 + laneOff));
         }
         *reinterpret_cast<MBAMD_AS_GLOBAL int32_t*>((unsigned long) a.scale + scaleOff) = ex;
         if (keep != 0xFFu) {
-            double* sl = mySlots + (size_t) keep * (KF * 256);
+            double* sl = mySlots + (size_t) keep * 256;
 #pragma unroll
             for (int i = 0; i < 4; ++i) sl[i * 64] = v[i];
         }
     };
-    Fetched A, B;
-    fetch(cur, A);
+    Walk64Fetched<KP> A, B;
+    w64_fetch<KP>(a, cur, c, lane, A);
     step(0, A, B);
     for (int j = 1; j <= last; j += 2) {
         step(j, B, A);
         if (j + 1 > last) break;
         step(j + 1, A, B);
     }
-    if (k == 0 && a.cum != nullptr && sum != 0) as_global(a.cum)[c] += sum;
+    if (kk == 0 && a.cum != nullptr && sum != 0) as_global(a.cum)[c] += sum;
 }
 
 struct MatrixJob64 {
@@ -598,6 +605,68 @@ k64_integrate(IntegrateArgs64 a, int S, int K, int first, int last, int Ppad_, c
     mbd_wave_sum_store(wl, wsite + blockIdx.x);
 }
 
+// The same for larger state counts: eight threads per pattern (thread group g takes the from-states i = g, g + 8, ...), their
+// partial sums added in a fixed order by the pattern's first thread -- an eighth of the serial chain (61 states, three omega
+// classes, one thread per pattern: 78 us for 5 000 patterns).  block = 512: thread = g * 64 + pattern.
+__global__ void __launch_bounds__(512)
+k64_integrate_wide(IntegrateArgs64 a, int S, int K, int first, int last, int Ppad_, const double* __restrict__ pattern_weights,
+                   double* __restrict__ site, double* __restrict__ wsite)
+{
+    double (*part)[8][64] = reinterpret_cast<double (*)[8][64]>(mbd_dyn_lds<double>());       // [subset][group][pattern]
+    const int p = (int) threadIdx.x & 63, g = (int) threadIdx.x >> 6;
+    const size_t Ppad = (size_t) Ppad_, c = (size_t) (first / 64 + (int) blockIdx.x) * 64 + p;
+    const bool live = c >= (size_t) first && c < (size_t) last;
+    for (int n = 0; n < a.count; ++n) {
+        double like = 0.0;
+        if (live) {
+            for (int k = 0; k < K; ++k) {
+                const double* par = a.parent[n] + (size_t) k * S * Ppad + c;
+                double cat = 0.0;
+                if (a.child[n] == nullptr) {
+                    for (int i = g; i < S; i += 8) cat += par[(size_t) i * Ppad] * a.freqs[n][i];
+                } else if (a.child_tip[n]) {
+                    const unsigned s = reinterpret_cast<const uint8_t*>(a.child[n])[c];
+                    for (int i = g; i < S; i += 8) {
+                        const double pc = s >= (unsigned) S ? 1.0 : a.matrix[n][((size_t) k * S + i) * S + s];
+                        cat += par[(size_t) i * Ppad] * pc * a.freqs[n][i];
+                    }
+                } else {
+                    const double* ch = reinterpret_cast<const double*>(a.child[n]) + (size_t) k * S * Ppad + c;
+                    for (int i = g; i < S; i += 8) {
+                        const double* row = a.matrix[n] + ((size_t) k * S + i) * S;
+                        double acc = 0.0;
+                        for (int j = 0; j < S; ++j) acc = fma(row[j], ch[(size_t) j * Ppad], acc);
+                        cat += par[(size_t) i * Ppad] * acc * a.freqs[n][i];
+                    }
+                }
+                like += cat * a.weights[n][k];
+            }
+        }
+        part[n][g][p] = like;
+    }
+    MBAMD_SYNC();
+    if (g != 0) return;
+    double wl = 0.0;
+    if (live) {
+        int emax = -2147483647;
+        for (int n = 0; n < a.count; ++n) {
+            const int e = a.cum[n] ? a.cum[n][c] : 0;
+            emax = e > emax ? e : emax;
+        }
+        double total = 0.0;
+        for (int n = 0; n < a.count; ++n) {
+            const double like = ((part[n][0][p] + part[n][1][p]) + (part[n][2][p] + part[n][3][p])) +
+                                ((part[n][4][p] + part[n][5][p]) + (part[n][6][p] + part[n][7][p]));
+            const int e = a.cum[n] ? a.cum[n][c] : 0;
+            total += ldexp(like, e - emax);
+        }
+        const double lnl = log(total) + (double) emax * 0.69314718055994530942;
+        site[c] = lnl;
+        wl = lnl * pattern_weights[c];
+    }
+    mbd_wave_sum_store(wl, wsite + blockIdx.x);
+}
+
 __global__ void __launch_bounds__(256)
 k64_scale_accumulate(const int32_t* const* __restrict__ src, int count, int sign, int first, int last, int32_t* __restrict__ cum)
 {
@@ -641,6 +710,10 @@ public:
     std::vector<int> walkKey;
     std::vector<Walk4Op> walkOps;
     std::vector<Walk64Entry> walkProg;
+    // operation lists waiting to run (see updatePartialsEx)
+    struct QueuedOp { BeagleOperation op; int partition, cum; char tip1, tip2; };
+    std::vector<QueuedOp> queue;
+    std::vector<char> queuedScale;          // [nScale]: an exponent buffer some queued operation reads, writes or accumulates into
     uint64_t walkLaunches = 0, levelLaunches = 0;
     bool walkAlways = false, walkVerbose = false;   // MBAMD_F64_WALK_ALWAYS, MBAMD_VERBOSE
     bool noMfma = false;                           // MBAMD_F64_NO_MFMA: the vector-ALU level kernels for 16..64 states too
@@ -729,6 +802,7 @@ public:
 
     int setTipStates(int tip, const int* states)
     {
+        { const int rcq = flushQueue(); if (rcq) return rcq; }
         if (tip < 0 || tip >= nBuffers) return fail(BEAGLE_ERROR_OUT_OF_RANGE, "beagleSetTipStates: tip index");
         if (stateSlot[tip] < 0) {
             if (slotsUsed >= tipCount) return fail(BEAGLE_ERROR_OUT_OF_RANGE, "beagleSetTipStates: more compact buffers than tips");
@@ -743,6 +817,7 @@ public:
     // in: [K][P][S] (withCategories) or [P][S] replicated over the categories
     int setPartials(int idx, const double* in, bool withCategories)
     {
+        { const int rcq = flushQueue(); if (rcq) return rcq; }
         if (idx < 0 || idx >= nBuffers) return fail(BEAGLE_ERROR_OUT_OF_RANGE, "beagleSetPartials: buffer index");
         std::vector<double> h(bufDoubles, 0.0);
         for (int k = 0; k < K; ++k)
@@ -755,6 +830,7 @@ public:
     }
     int getPartials(int idx, double* out)
     {
+        { const int rcq = flushQueue(); if (rcq) return rcq; }
         if (idx < 0 || idx >= nBuffers || !valid[idx]) return fail(BEAGLE_ERROR_OUT_OF_RANGE, "beagleGetPartials: buffer index");
         if (isTip[idx]) return fail(BEAGLE_ERROR_OUT_OF_RANGE, "beagleGetPartials: a compact (tip state) buffer");
         std::vector<double> h(bufDoubles);
@@ -767,6 +843,7 @@ public:
     }
     int setEigen(int idx, const double* U, const double* Ui, const double* lam)
     {
+        { const int rcq = flushQueue(); if (rcq) return rcq; }
         if (idx < 0 || idx >= nEigen) return fail(BEAGLE_ERROR_OUT_OF_RANGE, "beagleSetEigenDecomposition: eigen index");
         std::vector<double> h(eigDoubles);
         std::memcpy(h.data(), U, sizeof(double) * S * S);
@@ -776,16 +853,19 @@ public:
     }
     int setFreqs(int idx, const double* f)
     {
+        { const int rcq = flushQueue(); if (rcq) return rcq; }
         if (idx < 0 || idx >= nEigen) return fail(BEAGLE_ERROR_OUT_OF_RANGE, "beagleSetStateFrequencies: index");
         return upload(d_freqs + (size_t) idx * S, f, (size_t) S * sizeof(double));
     }
     int setWeights(int idx, const double* w)
     {
+        { const int rcq = flushQueue(); if (rcq) return rcq; }
         if (idx < 0 || idx >= nEigen) return fail(BEAGLE_ERROR_OUT_OF_RANGE, "beagleSetCategoryWeights: index");
         return upload(d_weights + (size_t) idx * K, w, (size_t) K * sizeof(double));
     }
     int setRates(int index, const double* r)
     {
+        { const int rcq = flushQueue(); if (rcq) return rcq; }
         if (index < 0 || index > 65535) return fail(BEAGLE_ERROR_OUT_OF_RANGE, "category rates: index");
         if ((size_t) index >= rateSets.size()) rateSets.resize((size_t) index + 1, rateSets[0]);
         for (int k = 0; k < K; ++k) rateSets[index].r[k] = r[k];
@@ -793,6 +873,7 @@ public:
     }
     int setPatternWeights(const double* w)
     {
+        { const int rcq = flushQueue(); if (rcq) return rcq; }
         std::vector<double> h((size_t) Ppad, 0.0);
         std::memcpy(h.data(), w, (size_t) P * sizeof(double));
         return upload(d_pweights, h.data(), (size_t) Ppad * sizeof(double));
@@ -815,6 +896,7 @@ public:
     }
     int updateMatrices(int eigenIdx, int rateIdx, const int* prob, const double* lengths, int count)
     {
+        { const int rcq = flushQueue(); if (rcq) return rcq; }
         if (count <= 0) return BEAGLE_SUCCESS;
         if (eigenIdx < 0 || eigenIdx >= nEigen) return fail(BEAGLE_ERROR_OUT_OF_RANGE, "beagleUpdateTransitionMatrices: eigen index");
         if (rateIdx < 0 || (size_t) rateIdx >= rateSets.size()) return fail(BEAGLE_ERROR_OUT_OF_RANGE, "beagleUpdateTransitionMatrices: rate index");
@@ -843,6 +925,7 @@ public:
     // v3: an eigen-system and a category-rate vector per matrix; one launch per run of equal rate vectors
     int updateMatricesMulti(const int* eigenIdx, const int* rateIdx, const int* prob, const double* lengths, int count)
     {
+        { const int rcq = flushQueue(); if (rcq) return rcq; }
         int i = 0;
         while (i < count) {
             int j = i + 1;
@@ -856,6 +939,7 @@ public:
     // in: [K][S][S] row = from-state (BEAGLE's order)
     int setMatrix(int idx, const double* m)
     {
+        { const int rcq = flushQueue(); if (rcq) return rcq; }
         if (idx < 0 || idx >= nMatrices) return fail(BEAGLE_ERROR_OUT_OF_RANGE, "beagleSetTransitionMatrix: matrix index");
         std::vector<double> h(matDoubles, 0.0);
         for (int k = 0; k < K; ++k)
@@ -869,6 +953,7 @@ public:
     }
     int getMatrix(int idx, double* out)
     {
+        { const int rcq = flushQueue(); if (rcq) return rcq; }
         if (idx < 0 || idx >= nMatrices) return fail(BEAGLE_ERROR_OUT_OF_RANGE, "beagleGetTransitionMatrix: matrix index");
         HIP_TRY(hipStreamSynchronize(stream));
         HIP_TRY(hipMemcpy(out, matrixPtr(idx), (size_t) K * S * S * sizeof(double), hipMemcpyDeviceToHost));
@@ -882,18 +967,18 @@ public:
 
     // The walk serves what MrBayes sends for nucleotides: four states, up to eight categories, no pattern partitions, one
     // cumulative buffer for the whole list, no buffer hazards inside the list.  Returns 1 when the list is not of that kind.
-    template <int KF> void launchWalk(const Walk64Args& wa)
+    template <int KP> void launchWalk(const Walk64Args& wa)
     {
-        auto kern = k64_walk4<KF>;
-        const size_t lds = ((size_t) wa.nslots * KF * 4 * 64 + (size_t) 2 * KF * 64 + (size_t) KF * 32) * sizeof(double);
-        static char raised[64] = {0};                // per device (and per KF: a static of this template instance)
+        auto kern = k64_walk4<KP>;
+        const size_t lds = ((size_t) wa.nslots * 4 * 64 + (size_t) 2 * KP * 18) * sizeof(double);
+        static char raised[64] = {0};                // per device (and per KP: a static of this template instance)
         if (device >= 0 && device < 64 && !raised[device]) {
             if (hipFuncSetAttribute((const void*) kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) (void) hipGetLastError();
             raised[device] = 1;
         }
-        MBAMD_LAUNCH_BARRIER(kern, (unsigned) (Ppad / 64), 64 * KF, lds, stream, wa);
+        MBAMD_LAUNCH_BARRIER(kern, (unsigned) (Ppad / (64 / KP)), 64, lds, stream, wa);
     }
-    int tryWalk4(const void* opsRaw, size_t stride, int n, const int* partition, const int* cumOf)
+    int tryWalk4(const QueuedOp* q, int n)
     {
         // (the kernel addresses with 32-bit lane offsets: a plane of partials and the whole exponent array below 4 GiB)
         if (walkOff || S != 4 || K > 8 || !parts.empty() || n < 2 || (bufDoubles >> 29) != 0 || (((size_t) nScale + 1) * Ppad >> 30) != 0 || ((size_t) nMatrices * matDoubles >> 29) != 0) return 1;
@@ -906,36 +991,33 @@ public:
         wops.clear();
         std::vector<char> written((size_t) nBuffers, 0), readB((size_t) nBuffers, 0), sc((size_t) std::max(nScale, 1), 0);
         for (int i = 0; i < n; ++i) {
-            const BeagleOperation& o = *reinterpret_cast<const BeagleOperation*>(static_cast<const char*>(opsRaw) + (size_t) i * stride);
-            if (partition[i] >= 0 || cumOf[i] != cumOf[0]) return 1;
+            const BeagleOperation& o = q[i].op;                                       // (indices were checked when the list was queued)
+            if (q[i].partition >= 0 || q[i].cum != q[0].cum) return 1;
             const int d = o.destinationPartials, c1 = o.child1Partials, c2 = o.child2Partials;
-            if (d < 0 || d >= nBuffers || c1 < 0 || c1 >= nBuffers || c2 < 0 || c2 >= nBuffers) return 1;     // (the level path reports the error)
-            if (o.child1TransitionMatrix < 0 || o.child1TransitionMatrix >= nMatrices || o.child2TransitionMatrix < 0 || o.child2TransitionMatrix >= nMatrices) return 1;
-            if ((!valid[c1] && !written[c1]) || (!valid[c2] && !written[c2]) || (isTip[d] && !written[d])) return 1;
             const int sw = o.destinationScaleWrite, sr = o.destinationScaleRead;
-            if ((sw != BEAGLE_OP_NONE && (sw < 0 || sw >= nScale)) || (sr != BEAGLE_OP_NONE && (sr < 0 || sr >= nScale))) return 1;
             if (written[d] || readB[d]) return 1;                                     // buffer hazards: levels
             if (sw != BEAGLE_OP_NONE && sc[sw]) return 1;
             if (sw == BEAGLE_OP_NONE && sr != BEAGLE_OP_NONE && sc[sr] == 2) return 1;
-            if (cumOf[0] != BEAGLE_OP_NONE && (sw == cumOf[0] || sr == cumOf[0])) return 1;
+            if (q[0].cum != BEAGLE_OP_NONE && (sw == q[0].cum || sr == q[0].cum)) return 1;
             Walk4Op w;
             w.dst = d; w.c1 = c1; w.c2 = c2; w.m1 = o.child1TransitionMatrix; w.m2 = o.child2TransitionMatrix;
-            w.tip1 = (isTip[c1] && !written[c1]) ? 1 : 0;
-            w.tip2 = (isTip[c2] && !written[c2]) ? 1 : 0;
+            w.tip1 = q[i].tip1;
+            w.tip2 = q[i].tip2;
             w.scaleWrite = sw != BEAGLE_OP_NONE ? sw : -1;
             w.scaleRead = (sw == BEAGLE_OP_NONE && sr != BEAGLE_OP_NONE) ? sr : -1;
             written[d] = 1; readB[c1] = 1; readB[c2] = 1;
             if (sw != BEAGLE_OP_NONE) sc[sw] = 2; else if (sr != BEAGLE_OP_NONE && !sc[sr]) sc[sr] = 1;
             wops.push_back(w);
         }
-        const int cumIdx = cumOf[0];
-        if (cumIdx != BEAGLE_OP_NONE && (cumIdx < 0 || cumIdx >= nScale)) return 1;
-        // launch geometry: every workgroup (one wave, 64 patterns) resident at once where the chip allows, the LDS of a CU split
-        // between the workgroups it hosts; a slot holds one node's K x 4 x 64 doubles
-        const int slotBytes = K * 4 * 64 * (int) sizeof(double);
-        const long wgs = Ppad / 64;
-        const int perCU = (int) std::min(4L, std::max(1L, (wgs + 255) / 256));
-        const int fixedBytes = (2 * K * 64 + K * 32) * (int) sizeof(double);      // the exchange buffers and the parked matrices
+        const int cumIdx = q[0].cum;
+        // launch geometry: a wave owns 64 / KP patterns (KP = K rounded up to a power of two) and is its own workgroup; every wave
+        // resident at once where the chip allows, the LDS of a CU split between the waves it hosts; a slot holds one node's
+        // 4 x 64 doubles of the wave
+        const int KP = K <= 1 ? 1 : (K <= 2 ? 2 : (K <= 4 ? 4 : 8));
+        const int slotBytes = 4 * 64 * (int) sizeof(double);
+        const long waves = Ppad / (64 / KP);
+        const int perCU = (int) std::min(16L, std::max(1L, (waves + 255) / 256));
+        const int fixedBytes = 2 * KP * 18 * (int) sizeof(double) + 64;      // the parked matrices (+ allocation granularity)
         int nslots = std::max(2, std::min(24, ((160 * 1024) / perCU - fixedBytes) / slotBytes));
         if (const char* e = std::getenv("MBAMD_F64_WALK_SLOTS")) nslots = std::max(2, std::min((160 * 1024 - fixedBytes) / slotBytes, std::atoi(e)));
         // structure key: who produces whose child, which children are tips (the indices only fill the program)
@@ -1002,7 +1084,6 @@ public:
             std::fprintf(stderr, "[mbamd] fp64 walk: %zu entries, %d slots, children: %d compact tips, %d from memory, %zu from LDS\n", walkProg.size(),
                          t.nslots, tips, mem, 2 * walkProg.size() - (size_t) tips - (size_t) mem);
         }
-        for (const Walk4Op& w : wops) { valid[w.dst] = 1; isTip[w.dst] = 0; }
         st_.reset();
         void* dv = nullptr;
         int rc = stage(walkProg.data(), walkProg.size() * sizeof(Walk64Entry), &dv);
@@ -1017,14 +1098,11 @@ public:
         wa.cum = cumIdx != BEAGLE_OP_NONE ? d_scale + (size_t) cumIdx * Ppad : nullptr;
         wa.Ppad = (int) Ppad;
         wa.scratchRow = nScale;
-        switch (K) {
+        wa.K = K;
+        switch (KP) {
             case 1: launchWalk<1>(wa); break;
             case 2: launchWalk<2>(wa); break;
-            case 3: launchWalk<3>(wa); break;
             case 4: launchWalk<4>(wa); break;
-            case 5: launchWalk<5>(wa); break;
-            case 6: launchWalk<6>(wa); break;
-            case 7: launchWalk<7>(wa); break;
             default: launchWalk<8>(wa); break;
         }
         HIP_TRY(hipGetLastError());
@@ -1044,6 +1122,7 @@ public:
     }
     int setPartitions(int count, const int* ids)
     {
+        { const int rcq = flushQueue(); if (rcq) return rcq; }
         std::vector<std::pair<int, int>> r;
         for (int c = 0; c < P; ++c) {
             const int p = ids[c];
@@ -1062,13 +1141,62 @@ public:
         return updatePartialsEx(ops, sizeof(BeagleOperation), n, part.data(), cum.data());
     }
     // `stride` bytes between operations (BeagleOperation or BeagleOperationByPartition: the first seven ints are the same);
-    // partition[i] < 0: all patterns.  Hazards are tracked per (buffer, partition): the same buffer index in two partitions
-    // is two disjoint pattern ranges.
+    // partition[i] < 0: all patterns.
+    // Lists are QUEUED, not run: MrBayes submits one list per eigen-system part of a codon model (reference src/mbbeagle.c:1088-1104,
+    // with at most a beagleRemoveScaleFactors of the next part's buffers in between), and a launch per dependency level of every
+    // list is three times the launches of one launch per level of all of them (codon M3 100 x 5 000: 51 -> 17 launches, 1.37 -> 1.0 ms per evaluation).
+    // Every other call of the engine runs the queue first (flushQueue); everything that can fail is checked here, when the list comes.
     int updatePartialsEx(const void* opsRaw, size_t stride, int n, const int* partition, const int* cumOf)
     {
         if (n <= 0) return BEAGLE_SUCCESS;
+        const size_t mark = queue.size();
+        const int np = std::max<int>(1, (int) parts.size());
+        for (int i = 0; i < n; ++i) {
+            const BeagleOperation& o = *reinterpret_cast<const BeagleOperation*>(static_cast<const char*>(opsRaw) + (size_t) i * stride);
+            const int cumIdx = cumOf[i];
+            int rc = BEAGLE_SUCCESS;
+            int first = 0, last = Ppad;
+            const int d = o.destinationPartials, c1 = o.child1Partials, c2 = o.child2Partials;
+            const int sw = o.destinationScaleWrite, sr = o.destinationScaleRead;
+            if (cumIdx != BEAGLE_OP_NONE && (cumIdx < 0 || cumIdx >= nScale)) rc = fail(BEAGLE_ERROR_OUT_OF_RANGE, "beagleUpdatePartials: cumulative scale index");
+            else if ((rc = partitionRange(partition[i], &first, &last, "beagleUpdatePartialsByPartition")) != BEAGLE_SUCCESS) { }
+            else if (d < 0 || d >= nBuffers || c1 < 0 || c1 >= nBuffers || c2 < 0 || c2 >= nBuffers)
+                rc = fail(BEAGLE_ERROR_OUT_OF_RANGE, "beagleUpdatePartials: buffer index");
+            else if (o.child1TransitionMatrix < 0 || o.child1TransitionMatrix >= nMatrices || o.child2TransitionMatrix < 0 || o.child2TransitionMatrix >= nMatrices)
+                rc = fail(BEAGLE_ERROR_OUT_OF_RANGE, "beagleUpdatePartials: matrix index");
+            else if (!valid[c1] || !valid[c2]) rc = fail(BEAGLE_ERROR_OUT_OF_RANGE, "beagleUpdatePartials: a child buffer was never written");
+            else if (isTip[d]) rc = fail(BEAGLE_ERROR_OUT_OF_RANGE, "beagleUpdatePartials: destination is a compact tip buffer");
+            else if ((sw != BEAGLE_OP_NONE && (sw < 0 || sw >= nScale)) || (sr != BEAGLE_OP_NONE && (sr < 0 || sr >= nScale)))
+                rc = fail(BEAGLE_ERROR_OUT_OF_RANGE, "beagleUpdatePartials: scale index");
+            if (rc != BEAGLE_SUCCESS) { queue.resize(mark); return rc; }          // (nothing of a rejected list runs)
+            QueuedOp e;
+            e.op = o; e.partition = partition[i]; e.cum = cumIdx;
+            e.tip1 = isTip[c1]; e.tip2 = isTip[c2];                                // (what the children are NOW: a later operation may overwrite a tip buffer)
+            queue.push_back(e);
+            valid[d] = 1;
+            isTip[d] = 0;
+            if (queuedScale.size() != (size_t) std::max(nScale, 1)) queuedScale.assign((size_t) std::max(nScale, 1), 0);
+            if (sw != BEAGLE_OP_NONE) queuedScale[sw] = 1;
+            if (sr != BEAGLE_OP_NONE) queuedScale[sr] = 1;
+            if (cumIdx != BEAGLE_OP_NONE) queuedScale[cumIdx] = 1;
+        }
+        (void) np;
+        return BEAGLE_SUCCESS;
+    }
+    // run what updatePartials queued; called first by every other entry point
+    int flushQueue()
+    {
+        if (queue.empty()) return BEAGLE_SUCCESS;
+        std::vector<QueuedOp> q;
+        q.swap(queue);
+        std::fill(queuedScale.begin(), queuedScale.end(), 0);
+        return runPartials(q.data(), (int) q.size());
+    }
+    // Hazards are tracked per (buffer, partition): the same buffer index in two partitions is two disjoint pattern ranges.
+    int runPartials(const QueuedOp* qd, int n)
+    {
         {
-            int rcw = tryWalk4(opsRaw, stride, n, partition, cumOf);
+            int rcw = tryWalk4(qd, n);
             if (rcw != 1) return rcw;                      // (1: not a list for the walk -- the level path below takes it)
         }
         const int np = std::max<int>(1, (int) parts.size());
@@ -1077,28 +1205,20 @@ public:
         int nLevels = 0;
         std::vector<Op64> h((size_t) n);
         for (int i = 0; i < n; ++i) {
-            const BeagleOperation& o = *reinterpret_cast<const BeagleOperation*>(static_cast<const char*>(opsRaw) + (size_t) i * stride);
-            const int cumIdx = cumOf[i];
-            if (cumIdx != BEAGLE_OP_NONE && (cumIdx < 0 || cumIdx >= nScale)) return fail(BEAGLE_ERROR_OUT_OF_RANGE, "beagleUpdatePartials: cumulative scale index");
+            const BeagleOperation& o = qd[i].op;
+            const int cumIdx = qd[i].cum;
             int first = 0, last = Ppad;
-            int rcp = partitionRange(partition[i], &first, &last, "beagleUpdatePartialsByPartition");
+            int rcp = partitionRange(qd[i].partition, &first, &last, "beagleUpdatePartialsByPartition");
             if (rcp) return rcp;
-            const int p0 = partition[i] < 0 ? 0 : std::min(partition[i], np - 1), p1 = partition[i] < 0 ? np : p0 + 1;
+            const int p0 = qd[i].partition < 0 ? 0 : std::min(qd[i].partition, np - 1), p1 = qd[i].partition < 0 ? np : p0 + 1;
             const int d = o.destinationPartials, c1 = o.child1Partials, c2 = o.child2Partials;
-            if (d < 0 || d >= nBuffers || c1 < 0 || c1 >= nBuffers || c2 < 0 || c2 >= nBuffers)
-                return fail(BEAGLE_ERROR_OUT_OF_RANGE, "beagleUpdatePartials: buffer index");
-            if (o.child1TransitionMatrix < 0 || o.child1TransitionMatrix >= nMatrices || o.child2TransitionMatrix < 0 || o.child2TransitionMatrix >= nMatrices)
-                return fail(BEAGLE_ERROR_OUT_OF_RANGE, "beagleUpdatePartials: matrix index");
-            if (!valid[c1] || !valid[c2]) return fail(BEAGLE_ERROR_OUT_OF_RANGE, "beagleUpdatePartials: a child buffer was never written");
-            if (isTip[d]) return fail(BEAGLE_ERROR_OUT_OF_RANGE, "beagleUpdatePartials: destination is a compact tip buffer");
             const int sw = o.destinationScaleWrite, sr = o.destinationScaleRead;
-            if ((sw != BEAGLE_OP_NONE && (sw < 0 || sw >= nScale)) || (sr != BEAGLE_OP_NONE && (sr < 0 || sr >= nScale)))
-                return fail(BEAGLE_ERROR_OUT_OF_RANGE, "beagleUpdatePartials: scale index");
             const int sc = sw != BEAGLE_OP_NONE ? sw : sr;
             int lv = 0;
             for (int q = p0; q < p1; ++q) {
                 lv = std::max(lv, std::max(std::max(lastWriteBuf[(size_t) c1 * np + q], lastWriteBuf[(size_t) c2 * np + q]), lastTouchBuf[(size_t) d * np + q]) + 1);
                 if (sc != BEAGLE_OP_NONE) lv = std::max(lv, lastTouchScale[(size_t) sc * np + q] + 1);
+                // (lists of several calls run as one: two operations adding to the same cumulative buffer in one launch are atomic adds)
             }
             level[i] = lv;
             nLevels = std::max(nLevels, lv + 1);
@@ -1111,10 +1231,10 @@ public:
             }
             Op64& q = h[i];
             q.dst = partialsPtr(d);
-            q.c1 = isTip[c1] ? (const void*) statesPtr(c1) : (const void*) partialsPtr(c1);
-            q.c2 = isTip[c2] ? (const void*) statesPtr(c2) : (const void*) partialsPtr(c2);
-            q.c1_tip = isTip[c1];
-            q.c2_tip = isTip[c2];
+            q.c1 = qd[i].tip1 ? (const void*) statesPtr(c1) : (const void*) partialsPtr(c1);
+            q.c2 = qd[i].tip2 ? (const void*) statesPtr(c2) : (const void*) partialsPtr(c2);
+            q.c1_tip = qd[i].tip1;
+            q.c2_tip = qd[i].tip2;
             q.m1T = matrixPtr(o.child1TransitionMatrix) + (size_t) K * S * S;
             q.m2T = matrixPtr(o.child2TransitionMatrix) + (size_t) K * S * S;
             q.mode = sw != BEAGLE_OP_NONE ? 1 : sr != BEAGLE_OP_NONE ? 2 : 0;
@@ -1123,8 +1243,6 @@ public:
             q.first = first;
             q.last = last;
             q.pad_ = 0;
-            valid[d] = 1;
-            isTip[d] = 0;
         }
         // operations sorted by level (stable), one contiguous run per level
         std::vector<int> order((size_t) n), start((size_t) nLevels + 1, 0);
@@ -1196,6 +1314,7 @@ public:
 
     int resetScale(int idx, int partition = -1)
     {
+        { const int rcq = flushQueue(); if (rcq) return rcq; }
         if (idx < 0 || idx >= nScale) return fail(BEAGLE_ERROR_OUT_OF_RANGE, "beagleResetScaleFactors: index");
         int first = 0, last = Ppad;
         int rc = partitionRange(partition, &first, &last, "beagleResetScaleFactorsByPartition");
@@ -1205,6 +1324,12 @@ public:
     }
     int accumulateScale(const int* idx, int count, int cumIdx, int sign, int partition = -1)
     {
+        {   // (between the lists of a codon model's parts MrBayes removes the NEXT part's scale factors from ITS cumulative buffer:
+            //  buffers no queued operation touches -- that may run ahead of the queue)
+            bool touches = cumIdx >= 0 && cumIdx < (int) queuedScale.size() && queuedScale[cumIdx];
+            for (int i = 0; i < count && !touches; ++i) touches = idx[i] >= 0 && idx[i] < (int) queuedScale.size() && queuedScale[idx[i]];
+            if (touches || queuedScale.empty()) { const int rcq = flushQueue(); if (rcq) return rcq; }
+        }
         if (count <= 0) return BEAGLE_SUCCESS;
         int first = 0, last = Ppad;
         int rcp = partitionRange(partition, &first, &last, "scale factors by partition");
@@ -1224,12 +1349,14 @@ public:
     }
     int copyScale(int dst, int src)
     {
+        { const int rcq = flushQueue(); if (rcq) return rcq; }
         if (dst < 0 || dst >= nScale || src < 0 || src >= nScale) return fail(BEAGLE_ERROR_OUT_OF_RANGE, "beagleCopyScaleFactors: index");
         HIP_TRY(hipMemcpyAsync(d_scale + (size_t) dst * Ppad, d_scale + (size_t) src * Ppad, (size_t) Ppad * sizeof(int32_t), hipMemcpyDeviceToDevice, stream));
         return BEAGLE_SUCCESS;
     }
     int getScaleExponents(int idx, int* out)            // [K][P]: every category row the same
     {
+        { const int rcq = flushQueue(); if (rcq) return rcq; }
         if (idx < 0 || idx >= nScale) return fail(BEAGLE_ERROR_OUT_OF_RANGE, "scale factors: index");
         std::vector<int32_t> h((size_t) Ppad);
         HIP_TRY(hipStreamSynchronize(stream));
@@ -1240,6 +1367,7 @@ public:
     }
     int getScaleFactors(int idx, double* out)
     {
+        { const int rcq = flushQueue(); if (rcq) return rcq; }
         if (idx < 0 || idx >= nScale) return fail(BEAGLE_ERROR_OUT_OF_RANGE, "beagleGetScaleFactors: index");
         std::vector<int32_t> h((size_t) Ppad);
         HIP_TRY(hipStreamSynchronize(stream));
@@ -1252,6 +1380,7 @@ public:
     int logLikelihoods(const int* parent, const int* child, const int* prob, const int* wIdx, const int* fIdx, const int* cumIdx, int count,
                        double* out, const int* partitions = nullptr, int partitionCount = 1, double* outByPartition = nullptr)
     {
+        { const int rcq = flushQueue(); if (rcq) return rcq; }
         if (count < 1 || count > MBAMD_MAX_SUBSETS) return fail(BEAGLE_ERROR_NO_IMPLEMENTATION, "log-likelihood: more than 8 subsets");
         const int pc = partitions ? partitionCount : 1;
         const int nblocks = Ppad / 64;
@@ -1298,8 +1427,12 @@ public:
             }
             blocksOf[d] = (last + 63) / 64 - first / 64;
             if (blocksOf[d] <= 0) continue;
-            MBAMD_LAUNCH(k64_integrate, (unsigned) blocksOf[d], 64, 0, stream, a, S, K, first, last, Ppad, (const double*) d_pweights, d_site,
-                         d_sums + (size_t) d * nblocks);
+            if (S >= 16)
+                MBAMD_LAUNCH_BARRIER(k64_integrate_wide, (unsigned) blocksOf[d], 512, (size_t) a.count * 8 * 64 * sizeof(double), stream, a, S, K, first, last, Ppad, (const double*) d_pweights, d_site,
+                                     d_sums + (size_t) d * nblocks);
+            else
+                MBAMD_LAUNCH(k64_integrate, (unsigned) blocksOf[d], 64, 0, stream, a, S, K, first, last, Ppad, (const double*) d_pweights, d_site,
+                             d_sums + (size_t) d * nblocks);
         }
         HIP_TRY(hipGetLastError());
         HIP_TRY(hipMemcpyAsync(h.data(), d_sums, h.size() * sizeof(double), hipMemcpyDeviceToHost, stream));
@@ -1318,6 +1451,7 @@ public:
     }
     int getSites(double* out)
     {
+        { const int rcq = flushQueue(); if (rcq) return rcq; }
         if (!haveSite) return fail(BEAGLE_ERROR_GENERAL, "beagleGetSiteLogLikelihoods: no log-likelihood was calculated");
         HIP_TRY(hipStreamSynchronize(stream));
         HIP_TRY(hipMemcpy(out, d_site, (size_t) P * sizeof(double), hipMemcpyDeviceToHost));
@@ -1325,6 +1459,7 @@ public:
     }
     int synchronize()
     {
+        { const int rcq = flushQueue(); if (rcq) return rcq; }
         HIP_TRY(hipStreamSynchronize(stream));
         return BEAGLE_SUCCESS;
     }

@@ -842,6 +842,60 @@ def check_double_precision_walk(lib, golden_dir, case, monkeypatch):
         assert got[True][4] <= 2 and got[False][4] > 2 * got[True][4], (got[True][4], got[False][4])   # a launch per list against one per level
 
 
+def check_double_precision_walk_categories(lib, monkeypatch, ntips=24, npat=200, seed=11):
+    """The fp64 four-state walk keeps a pattern's categories in the lanes of ONE wave (category count rounded up to a power of two,
+    the surplus lanes repeating the last category): every category count 1 ... 8 must give the bits of the level kernels --
+    partials, exponents and the cumulative exponents of a whole tree, with one child held in memory (more nodes than LDS slots)."""
+    rng = np.random.default_rng(seed)
+    S, P = 4, npat
+    nodes = 2 * ntips - 2                                    # tips 0 .. ntips-1, interior ntips .. nodes-1 (a caterpillar + cherries)
+    for K in (1, 2, 3, 4, 5, 8):
+        states = [rng.integers(0, S + 1, size=P).astype(np.int32) for _ in range(ntips)]
+        mats = []
+        for m in range(nodes):
+            ti = rng.random((K, S, S)) + 0.02
+            mats.append(ti / ti.sum(axis=2, keepdims=True) * 1e-3)       # (small values: the exponents are not all zero)
+        # a random binary tree: repeatedly join two roots
+        roots = list(range(ntips))
+        ops = []
+        nxt = ntips
+        order = rng.permutation(ntips).tolist()
+        roots = order
+        while len(roots) > 1 and nxt < nodes + 1:
+            i, j = sorted(rng.choice(len(roots), size=2, replace=False).tolist())
+            a, b = roots[i], roots[j]
+            ops.append([nxt, nxt - ntips, -1, a, a, b, b])
+            del roots[j]
+            roots[i] = nxt
+            nxt += 1
+        ops = np.array(ops, dtype=np.int32)
+        nint = len(ops)
+        got = {}
+        for walk in (True, False):
+            if walk:
+                monkeypatch.delenv("MBAMD_F64_NO_WALK", raising=False)
+                monkeypatch.setenv("MBAMD_F64_WALK_ALWAYS", "1")
+                monkeypatch.setenv("MBAMD_F64_WALK_SLOTS", "2")      # (children fall out of LDS: the memory path runs too)
+            else:
+                monkeypatch.setenv("MBAMD_F64_NO_WALK", "1")
+            inst = bg.BeagleInstance(lib, ntips, nint, ntips, S, P, 1, nodes + 1, K, nint + 1, preference_flags=bg.BEAGLE_FLAG_PRECISION_DOUBLE)
+            try:
+                for m in range(nodes):
+                    inst.set_transition_matrix(m, mats[m])
+                for i in range(ntips):
+                    inst.set_tip_states(i, states[i])
+                inst.reset_scale_factors(nint)
+                inst.update_partials(ops, nint)
+                got[walk] = [inst.get_partials(int(o[0])) for o in ops] + [inst.get_scale_exponents(i) for i in range(nint + 1)]
+            finally:
+                inst.finalize()
+        for k in ("MBAMD_F64_NO_WALK", "MBAMD_F64_WALK_ALWAYS", "MBAMD_F64_WALK_SLOTS"):
+            monkeypatch.delenv(k, raising=False)
+        for x, y in zip(got[True], got[False]):
+            assert np.array_equal(x, y), K
+        assert any(np.any(e != 0) for e in got[True][nint:]), K
+
+
 def check_parsimony_model_golden(lib, golden_dir):
     """The device Fitch down-pass against the reference's OWN parsimony-model likelihood (Likelihood_Pars,
     src/likelihood.c:7593-7700; golden values written by tools/gen_golden_pars.py from oracle/_ref/mb with `lset parsmodel=yes`):

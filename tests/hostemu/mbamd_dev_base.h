@@ -17,6 +17,17 @@ inline int mbd_frexp_exp(float v) { int e = 0; (void) frexpf(v, &e); return e; }
 inline float mbd_ldexp(float v, int e) { return ldexpf(v, e); }
 inline float mbd_pow2(int e) { return ldexpf(1.0f, e); }
 inline int mbd_wave_index() { return (int) (threadIdx.x >> 6); }
+template <int PW> inline double mbd_max_across_groups(double v)      // (threads are fibers: through a buffer, between two barriers)
+{
+    static double buf[1024];
+    const int t = (int) threadIdx.x, base = t & ~63;
+    buf[t] = v;
+    mbamd_emu_barrier();
+    double m = v;
+    for (int l = (t & 63) % PW; l < 64; l += PW) m = fmax(m, buf[base + l]);
+    mbamd_emu_barrier();
+    return m;
+}
 template <class T> inline T* mbd_dyn_lds() { return reinterpret_cast<T*>(mbamd_emu_dyn_lds()); }
 // (threads of a block run one after the other between barriers: thread 0 comes first)
 inline void mbd_wave_sum_store(double v, double* slot)

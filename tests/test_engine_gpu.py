@@ -559,6 +559,11 @@ def test_double_precision_walk_equals_levels(gpu, golden_dir, case, monkeypatch)
     ec.check_double_precision_walk(gpu, golden_dir, case, monkeypatch)
 
 
+def test_double_precision_walk_category_counts(gpu, monkeypatch):
+    """fp64, four states: every category count 1 ... 8 on the walk (categories in the lanes of one wave) against the level kernels."""
+    ec.check_double_precision_walk_categories(gpu, monkeypatch)
+
+
 def test_parsimony_model_golden(gpu, golden_dir):
     """device Fitch lengths == the reference's own parsimony-model likelihood (golden vectors from oracle/_ref/mb)"""
     ec.check_parsimony_model_golden(gpu, golden_dir)

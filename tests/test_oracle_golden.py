@@ -67,4 +67,7 @@ def test_parsimony_oracle_against_the_reference_parsimony_model(golden_dir):
         total, _ = ol.pars_down(sets, mp.down_pass_ops(tr, tr.root_left), w)
         total += ol.pars_score(sets, [[tr.root_left, -1, tr.root, -1]], w)[0]          # the branch to the calculation root
         lnl = -(total + st.shape[1]) * math.log(case["nstates"])
-        assert abs(lnl - case["lnL_reference"]) <= 1e-6, (case["name"], lnl, case["lnL_reference"])
+        # (the reference adds the tree length up in float, src/likelihood.c:7597-7672: beyond 2^24 steps -- the configs[3] shape -- its own
+        #  sum is rounded; there the golden pins to the float's resolution, as in tests/engine_checks.py::check_parsimony_model_golden)
+        tol = 1e-6 if total < 2 ** 24 else 4e-6 * abs(lnl)
+        assert abs(lnl - case["lnL_reference"]) <= tol, (case["name"], lnl, case["lnL_reference"])

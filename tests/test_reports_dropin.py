@@ -1,7 +1,7 @@
 """SURVEY 8(f) row 3 through the drop-in boundary: divisions that report ancestral states / site rates / positively selected
 sites / site omegas, and covarion divisions, stay on the engine (the reference switches BEAGLE off for them,
 src/mcmc.c:5760-5771).  The binary is the reference with src/mcmc.c and src/mbbeagle.c patched on the fly by
-oracle/patch_reports.py + integration/mrbayes/mbamd_reports_glue.c (oracle/Makefile: ref-amd-reports); the engine side is
+integration/mrbayes/patches/patch_reports.py + integration/mrbayes/mbamd_reports_glue.c (oracle/Makefile: ref-amd-reports); the engine side is
 include/libhmsbeagle/mbamd_reports.h (final pass = CondLikeUp_*, scaled read-out).
 
 Pinned against the reference's OWN read-outs: the same NEXUS file (data, constraints, `report ...`, tree and every

@@ -19,7 +19,7 @@ REF_MB_EMU = os.path.join(ROOT, "oracle", "_ref", "mb_emu")     # same objects, 
 
 REF_MB_AMD_V3 = os.path.join(ROOT, "oracle", "_ref", "mb_amd_v3")   # ... with MrBayes' BEAGLE v3 code path compiled in
 REF_MB_EMU_V3 = os.path.join(ROOT, "oracle", "_ref", "mb_emu_v3")
-# the reference + our ABI + the device-parsimony binding (integration/mrbayes/, oracle/patch_pars.py)
+# the reference + our ABI + the device-parsimony binding (integration/mrbayes/, integration/mrbayes/patches/patch_pars.py)
 REF_MB_AMD_PARS = os.path.join(ROOT, "oracle", "_ref", "mb_amd_pars")
 REF_MB_EMU_PARS = os.path.join(ROOT, "oracle", "_ref", "mb_emu_pars")
 # the reference + every binding: device parsimony, pattern compression, reports / covarion, device eigen-systems (oracle/Makefile: ref-amd-full)
