@@ -13,6 +13,7 @@
 #include "model.h"
 #include "utils.h"
 #include "libhmsbeagle/beagle.h"
+#include "libhmsbeagle/mbamd_reports.h"
 #include "mbamd_std_glue.h"
 
 #include <math.h>
@@ -51,6 +52,10 @@ typedef struct
     BeagleOperation *ops;
     int         *scaleIdx;
     double      *mat, *site, *lnSite;
+    int         *off;       /* ancestral states: first state of character c inside one rate category of a host row ... */
+    int         numReps;    /* ... and the states of all characters together */
+    double      *part;      /* a node's conditional likelihoods of one class [category][character][state] */
+    float       *partF, *lnScaleF;
     } StdDivision;
 
 static StdDivision  *stdDiv = NULL;
@@ -204,11 +209,10 @@ int MbamdStdServes (ModelInfo *m)
         MrBayesPrint ("%s   Division %d (standard data) stays on the host kernels: unequal state frequencies are not served by the engine\n", spacer, d+1);
         return (NO);
         }
-    if (m->printAncStates == YES || m->printSiteRates == YES)
+    if (m->printSiteRates == YES)
         {
-        /* (the reference's read-outs -- CondLikeUp_Std, PrintAncStates_Std, src/likelihood.c:4824, src/mcmc.c -- walk the HOST arrays
-           of every node, which a division on the engine does not fill) */
-        MrBayesPrint ("%s   Division %d (standard data) stays on the host kernels: ancestral states / site rates are read from host arrays\n", spacer, d+1);
+        /* (ancestral states are served: MbamdStdMaterialise below; the site-rate read-out is not) */
+        MrBayesPrint ("%s   Division %d (standard data) stays on the host kernels: site rates are read from host arrays\n", spacer, d+1);
         return (NO);
         }
     if ((beagleFlags & BEAGLE_FLAG_PRECISION_DOUBLE) != 0 || tryToUseBEAGLE == NO)
@@ -342,4 +346,94 @@ void MbamdStdLogLike (int chain, int d, MrBFlt *lnL)
     if (pObserved < LIKE_EPSILON)
         pObserved = LIKE_EPSILON;
     (*lnL) -= log (pObserved) * (m->numUncompressedChars);
+}
+
+/*
+ * Ancestral states (report ancstates=yes) for a division on the engine.  The reference's final pass and read-out -- CondLikeUp_Std
+ * (src/likelihood.c:4824-4930) and PrintAncStates_Std (src/mcmc.c:11074) -- run UNCHANGED on the host arrays of the division
+ * (a standard division is not a BEAGLE division to the reference, so InitChainCondLikes allocated them); this function fills
+ * them, once per printed sample, with the down-pass conditional likelihoods the device holds: called in front of the final-pass
+ * loop of PrintStates (src/mcmc.c:13138).  CondLikeUp_Std is homogeneous of degree 0 in a node's own down-pass values, per
+ * category, so every node but the top one may come with whatever power-of-two scale the device stored; the top node's values
+ * start the recursion and are read with all categories of a character at ONE scale (mbamdGetScaledPartials) -- the reference's
+ * own arrays have that property because CondLikeScaler_Std scales a character's categories together.  On an unrooted tree the
+ * top node of the reference carries the root tip as a third child (CondLikeRoot_Std, src/likelihood.c:4496): that factor is
+ * multiplied in here (the device folds it into the edge integration instead).
+ * Returns YES when the division is served (the host arrays are now filled), NO otherwise (nothing done).
+ */
+int MbamdStdMaterialise (int chain, int d)
+{
+    int             a, c, g, i, j, k, s, n, nK, rc, buf;
+    size_t          len;
+    double          sum;
+    ModelInfo       *m = &modelSettings[d];
+    StdDivision     *sd;
+    Tree            *tree;
+    TreeNode        *p, *top;
+    CLFlt           *host, *tiP;
+    BitsLong        *bits;
+
+    if (stdDiv == NULL || d < 0 || d >= stdDivCount || stdDiv[d].ready != 1)
+        return (NO);
+    sd = &stdDiv[d];
+    nK = m->numRateCats;
+    if (sd->off == NULL)
+        {
+        sd->off = (int *) SafeCalloc (m->numChars + 1, sizeof(int));
+        len = (size_t) nK * (m->numChars + 1) * MAX_STD_STATES;
+        sd->part = (double *) SafeCalloc (len, sizeof(double));
+        sd->partF = (float *) SafeCalloc (len, sizeof(float));
+        sd->lnScaleF = (float *) SafeCalloc (m->numChars + 1, sizeof(float));
+        if (!sd->off || !sd->part || !sd->partF || !sd->lnScaleF)
+            Die ("out of memory");
+        for (c=0, sd->numReps=0; c<m->numChars; c++)
+            {
+            sd->off[c] = sd->numReps;
+            sd->numReps += m->nStates[c];
+            }
+        }
+    tree = GetTree (m->brlens, chain, state[chain]);
+    top = tree->root->left;
+    for (i=0; i<tree->nIntNodes; i++)
+        {
+        p = tree->intDownPass[i];
+        buf = m->condLikeIndex[chain][p->index];
+        host = m->condLikes[buf];
+        for (g=0; g<sd->nClasses; g++)
+            {
+            n = sd->cls[g].nStates;
+            if (p == top)
+                rc = mbamdGetScaledPartials (sd->cls[g].instance, buf, m->siteScalerIndex[chain], sd->partF, sd->lnScaleF);
+            else
+                rc = beagleGetPartials (sd->cls[g].instance, buf, BEAGLE_OP_NONE, sd->part);
+            if (rc != BEAGLE_SUCCESS)
+                Die (mbamdGetLastError());
+            for (k=0; k<nK; k++)
+                for (j=0; j<sd->cls[g].nChars; j++)
+                    for (s=0; s<n; s++)
+                        {
+                        len = ((size_t) k * sd->cls[g].nChars + j) * n + s;
+                        host[(size_t) k * sd->numReps + sd->off[sd->cls[g].chars[j]] + s] = (p == top) ? (CLFlt) sd->partF[len] : (CLFlt) sd->part[len];
+                        }
+            }
+        }
+    if (tree->isRooted == NO)
+        {
+        host = m->condLikes[m->condLikeIndex[chain][top->index]];
+        for (k=0; k<nK; k++)
+            for (c=0; c<m->numChars; c++)
+                {
+                n = m->nStates[c];
+                tiP = m->tiProbs[m->tiProbsIndex[chain][top->index]] + m->tiIndex[c] + k * n * n;
+                bits = m->parsSets[tree->root->index] + (size_t) c * m->nParsIntsPerSite;
+                for (a=0; a<n; a++)
+                    {
+                    for (j=0, sum=0.0; j<n; j++)
+                        if (IsBitSet (j, bits))
+                            sum += tiP[a*n + j];
+                    host[(size_t) k * sd->numReps + sd->off[c] + a] *= (CLFlt) sum;
+                    }
+                }
+        }
+    return (YES);
 }

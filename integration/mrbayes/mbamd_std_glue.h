@@ -13,11 +13,14 @@
  * formula over the site values the engine returns, as for restriction sites (src/mbbeagle.c:1322-1358).
  *
  * Served: equal state frequencies (symdirihyperpr=fixed(infinity), the default: SYMPI_EQUAL), any rate-category count.
+ * Ancestral states (report ancstates=yes): the reference's own final pass and read-out run on host arrays that
+ * MbamdStdMaterialise fills from the device once per printed sample.
  * Not served (the division stays on the host kernels, with a printed reason): unequal / estimated state frequencies (beta
- * categories for binary characters, per-character eigen-systems).
+ * categories for binary characters, per-character eigen-systems); report siterates.
  *
- * Hook (applied to a temporary copy of src/likelihood.c by integration/mrbayes/patches/patch_std.py):
+ * Hooks (applied to temporary copies of src/likelihood.c and src/mcmc.c by integration/mrbayes/patches/patch_std.py):
  *     LaunchLogLikeForDivision:   if (MbamdStdServes (m) == YES) { MbamdStdLogLike (chain, d, lnL); return; }
+ *     PrintStates, in front of the final-pass loop of a division that reports ancestral states:   MbamdStdMaterialise (coldId, d);
  */
 #ifndef MBAMD_STD_GLUE_H_
 #define MBAMD_STD_GLUE_H_
@@ -27,5 +30,6 @@
 int  MbamdStdServes (ModelInfo *m);                    /* YES: this division's likelihood is computed by MbamdStdLogLike */
 void MbamdStdLogLike (int chain, int d, MrBFlt *lnL);  /* replaces the host pass of LaunchLogLikeForDivision for such a division */
 void MbamdStdFinalize (void);                          /* frees the engine instances (atexit) */
+int  MbamdStdMaterialise (int chain, int d);           /* report ancstates: fills the division's host arrays from the device (YES) or does nothing (NO) */
 
 #endif

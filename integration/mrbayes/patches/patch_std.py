@@ -3,8 +3,9 @@
 src/likelihood.c (oracle/Makefile: _ref/mb_amd_std, _ref/mb_emu_std, and -- on top of patch_eigen.py -- _ref/mb_*_full).
 
     patch_std.py <src/likelihood.c, possibly already patched by patch_eigen.py> <output likelihood.c>
+    patch_std.py --mcmc <src/mcmc.c, possibly already patched by patch_reports.py> <output mcmc.c>
 
-One exact-text replacement of a code fragment with an asserted count (see patch_reports.py): an upstream change stops the build."""
+Exact-text replacements of a code fragment with an asserted count (see patch_reports.py): an upstream change stops the build."""
 import sys
 
 from patch_reports import replace
@@ -24,8 +25,24 @@ def patch(text):
     return text
 
 
+def patch_mcmc(text):
+    lines = text.split("\n")
+    last_inc = max(i for i, l in enumerate(lines[:200]) if l.startswith("#include"))
+    lines.insert(last_inc + 1, '#include "mbamd_std_glue.h"')
+    text = "\n".join(lines)
+    # PrintStates: a standard-data division on the engine gets its host arrays filled before the reference's final pass reads them
+    text = replace(text,
+                   "                for (i=j=tree->nIntNodes - 1; i>=0; i--)\n",
+                   "                (void) MbamdStdMaterialise (coldId, d);\n"
+                   "                for (i=j=tree->nIntNodes - 1; i>=0; i--)\n",
+                   1, "final-pass loop of PrintStates")
+    return text
+
+
 if __name__ == "__main__":
-    with open(sys.argv[1]) as f:
+    mcmc = sys.argv[1] == "--mcmc"
+    args = sys.argv[2:] if mcmc else sys.argv[1:]
+    with open(args[0]) as f:
         src = f.read()
-    with open(sys.argv[2], "w") as f:
-        f.write(patch(src))
+    with open(args[1], "w") as f:
+        f.write(patch_mcmc(src) if mcmc else patch(src))

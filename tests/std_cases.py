@@ -22,9 +22,29 @@ def _tail(beagle, ngen, moves=False):
     return s + " startvals tau=t V=t;\n mcmc ngen=%d nchains=1 nruns=1 samplefreq=%d printfreq=%d filename=x;\nend;\n" % (ngen, 1 if ngen < 10 else 20, max(1, ngen))
 
 
-def synthetic_nexus(ntax, nchar, beagle, seed=11, coding="variable", rates="gamma", maxstates=5, ordered=(), p_missing=0.04, p_poly=0.0, ngen=1, alpha="fixed(0.7)"):
-    """ntax x nchar characters with 2 ... maxstates states each (every state of a character occurs: MrBayes takes a character's
-    state count from the symbols it sees), a share of missing entries and of two-state polymorphisms."""
+def _clades(newick):
+    import re
+    out, stack = [], []
+    for m in re.finditer(r"\(|\)|t\d+", newick):
+        tok = m.group(0)
+        if tok == "(":
+            stack.append([])
+        elif tok == ")":
+            c = stack.pop()
+            out.append(c)
+            if stack:
+                stack[-1].extend(c)
+        elif stack:
+            stack[-1].append(tok)
+    return out
+
+
+def synthetic_nexus(ntax, nchar, beagle, seed=11, coding="variable", rates="gamma", maxstates=5, ordered=(), p_missing=0.04, p_poly=0.0, ngen=1, alpha="fixed(0.7)",
+                    ancstates=0):
+    """`ancstates` > 0: that many hard constraints taken from the tree and `report ancstates=yes` (the .p file then carries the
+    state probabilities of every character at the constrained nodes)."""
+    # ntax x nchar characters with 2 ... maxstates states each (every state of a character occurs: MrBayes takes a character's
+    # state count from the symbols it sees), a share of missing entries and of two-state polymorphisms.
     rng = np.random.default_rng(seed)
     tr = mbtree.random_tree(ntax, 4, brlen=0.08)
     names = ["t%d" % (i + 1) for i in range(ntax)]
@@ -62,6 +82,11 @@ def synthetic_nexus(ntax, nchar, beagle, seed=11, coding="variable", rates="gamm
     s += " lset coding=%s rates=%s%s;\n" % (coding, rates, " ngammacat=4" if rates == "gamma" else "")
     if rates == "gamma":
         s += " prset shapepr=%s;\n" % alpha
+    if ancstates:
+        cl = [c for c in _clades(tr.to_newick(names)) if 2 <= len(c) <= max(2, ntax // 2)][:ancstates]
+        for i, c in enumerate(cl):
+            s += " constraint c%d = %s;\n" % (i + 1, " ".join(c))
+        s += " prset topologypr=constraints(%s);\n report ancstates=yes;\n" % ",".join("c%d" % (i + 1) for i in range(len(cl)))
     return s + _tail(beagle, ngen)
 
 
@@ -72,6 +97,11 @@ SYNTHETIC = {
     "informative": dict(ntax=9, nchar=60, coding="informative"),
     "binary_only": dict(ntax=14, nchar=90, maxstates=2),
     "ten_states": dict(ntax=24, nchar=70, maxstates=10, p_missing=0.02),
+}
+ANCSTATES = {       # report ancstates=yes on a standard division (CondLikeUp_Std / PrintAncStates_Std on host arrays filled from the device)
+    "anc_gamma": dict(ntax=12, nchar=80, ancstates=2),
+    "anc_equal_ordered_rooted_like": dict(ntax=16, nchar=100, rates="equal", ordered=(2, 5, 9), maxstates=6, ancstates=3, coding="all"),
+    "anc_binary_gamma": dict(ntax=20, nchar=120, maxstates=2, ancstates=3, coding="informative"),
 }
 BIG = dict(ntax=100, nchar=2000, maxstates=6, seed=5)      # 100 taxa x 2 000 characters, mixed 2-6 states, gamma-4
 

@@ -73,6 +73,32 @@ def _check_cynmix(binary, marker):
         assert abs(live - want) <= 1e-9 * abs(want)            # (the fixture is what the reference prints here, too)
 
 
+def _p_row(binary, text, env=None):
+    """header and first sample row of the run's .p file"""
+    out, _, files = refrun.run_mb(binary, text, keep=("x.p",), env=env)
+    assert "Analysis completed" in out and "x.p" in files, out[-2000:]
+    lines = [l for l in files["x.p"].splitlines() if l and not l.startswith("[")]
+    return out, lines[0].split("\t"), [float(x) for x in lines[1].split("\t")]
+
+
+def _check_ancstates(case, binary, marker):
+    """report ancstates=yes: every reported state probability of the constrained nodes against the reference's scalar build."""
+    _need(binary, os.path.join(REF, "mb_scalar"))
+    kw = std_cases.ANCSTATES[case]
+    _, h0, r0 = _p_row(os.path.join(REF, "mb_scalar"), std_cases.synthetic_nexus(beagle=None, **kw))
+    probs = [j for j, name in enumerate(h0) if name.startswith("p(")]
+    assert len(probs) > 20, h0[:30]
+    for scaling in ("always", "dynamic"):
+        out, h1, r1 = _p_row(binary, std_cases.synthetic_nexus(beagle=scaling, **kw))
+        _served(out, marker)
+        assert h1 == h0
+        i = h0.index("LnL") if "LnL" in h0 else h0.index("lnLike")
+        assert abs(r1[i] - r0[i]) <= 1e-5 * abs(r0[i]), (case, scaling, r1[i], r0[i])
+        worst = max(abs(r1[j] - r0[j]) for j in probs)
+        assert worst <= 1e-5, (case, scaling, worst, [(h0[j], r0[j], r1[j]) for j in probs if abs(r1[j] - r0[j]) > 1e-5][:5])
+        assert all(0.0 <= r1[j] <= 1.0 for j in probs)
+
+
 def _samples(binary, text, env=None):
     with tempfile.TemporaryDirectory() as wd:
         with open(os.path.join(wd, "run.nex"), "w") as fh:
@@ -113,6 +139,13 @@ def test_cynmix_morphology_on_emulated_engine():
     _check_cynmix(os.path.join(REF, "mb_emu_std"), "HOST EMULATION")
 
 
+@pytest.mark.parametrize("case", sorted(std_cases.ANCSTATES))
+def test_standard_data_ancestral_states_on_emulated_engine(case):
+    """ancestral states of a standard-data division that lives on the engine."""
+    _build_emu()
+    _check_ancstates(case, os.path.join(REF, "mb_emu_std"), "HOST EMULATION")
+
+
 def test_standard_data_mcmc_on_emulated_engine():
     _build_emu()
     _check_mcmc(os.path.join(REF, "mb_emu_std"), "HOST EMULATION")
@@ -130,7 +163,7 @@ def test_unequal_frequencies_stay_on_the_host():
 
 
 def test_patch_site_is_pinned():
-    """The one edit patch_std.py makes must apply to the reference exactly once (an upstream change fails here, not at run time)."""
+    """The edits patch_std.py makes (one in likelihood.c, one in mcmc.c) must each apply to the reference exactly once (an upstream change fails here, not at run time)."""
     src = "/root/reference/src/likelihood.c"
     if not os.path.exists(src):
         pytest.skip("reference sources not present")
@@ -144,9 +177,12 @@ def test_patch_site_is_pinned():
         spec.loader.exec_module(mod)
         with open(src) as fh:
             out = mod.patch(fh.read())
+        with open("/root/reference/src/mcmc.c") as fh:
+            out2 = mod.patch_mcmc(fh.read())
     finally:
         sys.path.remove(pdir)
     assert out.count("MbamdStdServes (m) == YES") == 1 and '#include "mbamd_std_glue.h"' in out
+    assert out2.count("MbamdStdMaterialise (coldId, d)") == 1 and '#include "mbamd_std_glue.h"' in out2
 
 
 @pytest.mark.gpu
@@ -158,6 +194,12 @@ def test_standard_data_on_mi355x(case):
 @pytest.mark.gpu
 def test_cynmix_morphology_on_mi355x():
     _check_cynmix(os.path.join(REF, "mb_amd_std"), "gfx950")
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", sorted(std_cases.ANCSTATES))
+def test_standard_data_ancestral_states_on_mi355x(case):
+    _check_ancstates(case, os.path.join(REF, "mb_amd_std"), "gfx950")
 
 
 @pytest.mark.gpu
