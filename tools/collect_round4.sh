@@ -7,4 +7,5 @@ for c in c2 c3 c4 c5; do
   cp gpurun_out/prof_${c}_timeline.txt profiles/r04_${c}_timeline.txt
   cp gpurun_out/pmc_walk_$c.log profiles/r04_${c}_pmc.txt
 done
+cp gpurun_out/prof_f64_summary.txt profiles/r04_f64_kernel_stats.txt
 python tools/pmc_traffic.py gpurun_out r04 > /dev/null
