@@ -64,6 +64,15 @@ int MbamdEngineServes (ModelInfo *m)
     return (NO);
 }
 
+int MbamdEngineServesAny (void)
+{
+    int d;
+    for (d=0; d<numCurrentDivisions; d++)
+        if (MbamdEngineServes (&modelSettings[d]) == YES)
+            return (YES);
+    return (NO);
+}
+
 /* the host arrays the reference's read-outs index: pointer tables over every buffer index, rows allocated when first needed */
 static int Parts (ModelInfo *m)
 {

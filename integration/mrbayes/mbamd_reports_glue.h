@@ -26,6 +26,9 @@ int     MbamdEngineServes (ModelInfo *m);
  * (m->rateProbs) that only the host's Likelihood_Adgamma fills; on the BEAGLE path nobody does (src/mcmc.c:7452-7478), and the
  * chain would run on a wrong likelihood without a word. */
 int     MbamdEngineRefuses (ModelInfo *m, int divisionNumber);
+/* YES if MbamdEngineServes answers YES for any current division (BEAGLE v3 builds: such an analysis keeps one instance per
+   division instead of one multi-partition instance, src/mcmc.c:5846-5856) */
+int     MbamdEngineServesAny (void);
 /* Before m->PrintSiteRates / m->PosSelProbs / m->SiteOmegas (they read the TOP interior node's conditional likelihoods and
  * the site scalers from host arrays): on an engine division, compute the top node's 3-way product on the device and
  * materialise it -- and the site scalers -- in the host arrays those functions read.  NO_ERROR / ERROR. */

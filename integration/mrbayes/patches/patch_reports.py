@@ -49,6 +49,12 @@ def patch_mcmc(text):
                    "                if (MbamdReportsRoot (node, d, coldId) == ERROR) goto errorExit;\n"
                    "                m->PrintSiteRates (node, d, coldId);\n",
                    1, "PrintSiteRates call")
+    # 1b. (BEAGLE v3 builds) a division the binding serves keeps its OWN instance: the binding's buffer indices carry no division
+    #     offset (the reference adds numTiProbs * nCijkParts * divisionIndex inside a multi-partition instance) and
+    #     mbamdGetScaledPartials reads one partition
+    text = replace(text, "        if (beagleResourceNumber != 0 && numCurrentDivisions > 1)\n",
+                   "        if (beagleResourceNumber != 0 && numCurrentDivisions > 1 && MbamdEngineServesAny () == NO)\n",
+                   1, "multi-partition instance decision")
     # 3. the final pass
     text = replace(text, "                    m->CondLikeUp (node, d, coldId);\n",
                    "                    if (MbamdReportsUp (tree, node, d, coldId) == NO)\n"

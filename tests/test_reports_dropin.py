@@ -246,6 +246,7 @@ def test_patch_sites_are_pinned():
     spec.loader.exec_module(mod)
     with open("/root/reference/src/mcmc.c") as fh:
         src = fh.read()
-    assert "MbamdReportsUp" in mod.patch_mcmc(src)
+    out = mod.patch_mcmc(src)
+    assert "MbamdReportsUp" in out and out.count("MbamdEngineServesAny () == NO") == 1
     with pytest.raises(SystemExit):
         mod.patch_mcmc(src.replace("m->CondLikeUp (node, d, coldId);", "m->CondLikeUp (node, d, chain);"))
