@@ -151,6 +151,50 @@ def test_standard_data_mcmc_on_emulated_engine():
     _check_mcmc(os.path.join(REF, "mb_emu_std"), "HOST EMULATION")
 
 
+def test_cynmix_as_shipped_all_partitions_on_the_emulated_engine():
+    """The reference's own examples/cynmix.nex with the model of its manual (morphology Mk+G, four DNA partitions GTR+I+G, unlinked,
+    rate multipliers): the morphology partition through the standard-data binding, the DNA partitions through the unmodified BEAGLE
+    path, one short chain -- against the same binary with every division on the reference's own kernels (usebeagle=no)."""
+    _build_emu()
+    src = "/root/reference/examples/cynmix.nex"
+    if not os.path.exists(src):
+        pytest.skip("reference examples not present (build container only)")
+    with open(src) as fh:
+        text = fh.read()
+    with open(GOLD) as fh:
+        names = json.load(fh)["names"]
+    from mrbayes_amd import tree as mbtree
+    start = mbtree.random_tree(len(names), 9, brlen=0.06).to_newick(names)      # (MrBayes draws a different random start tree with and without BEAGLE)
+    block = ("begin trees;\n tree t = [&U] " + start + "\nend;\n"
+             "begin mrbayes;\n set autoclose=yes nowarnings=yes seed=7 swapseed=7 precision=12;\n set partition=favored;\n"
+             " lset applyto=(1) rates=gamma;\n lset applyto=(2,3,4,5) rates=invgamma nst=6;\n"
+             " unlink revmat=(all) pinvar=(all) shape=(all) statefreq=(all);\n prset applyto=(all) ratepr=variable;\n%s"
+             " startvals tau=t V=t;\n mcmc ngen=60 nchains=1 nruns=1 samplefreq=10 printfreq=60 filename=x;\nend;\n")
+    on = text + block % " set usebeagle=yes beagledevice=gpu beagleprecision=single beaglescaling=always;\n"
+    off = text + block % " set usebeagle=no;\n"
+    binary = os.path.join(REF, "mb_emu_std")
+    out, _, files = refrun.run_mb(binary, on, keep=("x.p",))
+    assert "Analysis completed" in out and "(standard data):" in out, out[-2500:]
+    assert out.count("Using BEAGLE") >= 4, out[-2500:]                    # the four DNA partitions
+    out0, _, files0 = refrun.run_mb(binary, off, keep=("x.p",))
+    assert "Analysis completed" in out0 and "(standard data):" not in out0
+
+    def lnls(t):
+        rows = [l.split("\t") for l in t.splitlines() if l and not l.startswith("[")]
+        i = rows[0].index("LnL") if "LnL" in rows[0] else rows[0].index("lnLike")
+        return [float(r[i]) for r in rows[1:]]
+    a, b = lnls(files["x.p"]), lnls(files0["x.p"])
+    assert len(a) == len(b) >= 5
+    assert abs(a[0] - b[0]) <= 2e-6 * abs(b[0]), (a[0], b[0])            # the start state: a known-answer evaluation of all five partitions
+    # the chain: against the same binary with only the standard-data binding off (a BEAGLE run draws its random numbers in a different
+    # order than a run without: the usebeagle=no chain is another chain from the first move on)
+    out1, _, files1 = refrun.run_mb(binary, on, keep=("x.p",), env={"MBAMD_DEVICE_STD": "0"})
+    assert "Analysis completed" in out1 and "(standard data):" not in out1
+    c = lnls(files1["x.p"])
+    assert len(c) == len(a)
+    assert all(abs(x - y) <= 1e-5 * abs(y) for x, y in zip(a, c)), (a, c)
+
+
 def test_unequal_frequencies_stay_on_the_host():
     """symdirihyperpr other than fixed(infinity) (beta categories for binary characters, per-character eigen-systems): refused with a
     printed reason, the reference's own kernels run."""
