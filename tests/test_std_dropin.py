@@ -195,6 +195,54 @@ def test_cynmix_as_shipped_all_partitions_on_the_emulated_engine():
     assert all(abs(x - y) <= 1e-5 * abs(y) for x, y in zip(a, c)), (a, c)
 
 
+def test_hymfossil_as_shipped_all_partitions_on_the_emulated_engine():
+    """The reference's examples/hymfossil.nex with ITS OWN model block (114 taxa; a morphology partition with ordered characters,
+    excluded characters and coding=variable, six DNA partitions GTR+G, unlinked, rate multipliers; the block is commented out in
+    the shipped file and ends in a 100-million-generation run: here it is executed up to that `mcmcp` line): start state against the
+    native kernels, a short chain against the same binary with only the standard-data binding off."""
+    _build_emu()
+    src = "/root/reference/examples/hymfossil.nex"
+    if not os.path.exists(src):
+        pytest.skip("reference examples not present (build container only)")
+    with open(src) as fh:
+        text = fh.read()
+    i = text.index("[\nbegin mrbayes;")
+    data, blk = text[:i], text[i + 2:]
+    blk = blk[:blk.index("    mcmcp nruns=4")]
+    names = []
+    for line in data[data.lower().index("matrix"):].splitlines()[1:]:
+        t = line.split()
+        if not t or t[0].startswith("["):
+            continue
+        if t[0] in names:
+            break
+        names.append(t[0])
+    assert len(names) == 114
+    from mrbayes_amd import tree as mbtree
+    start = mbtree.random_tree(len(names), 9, brlen=0.05).to_newick(names)
+
+    def nexus(beagle):
+        tail = (" set autoclose=yes nowarnings=yes seed=7 swapseed=7 precision=12;\n" +
+                (" set usebeagle=yes beagledevice=gpu beagleprecision=single beaglescaling=always;\n" if beagle else " set usebeagle=no;\n") +
+                " startvals tau=t V=t;\n    mcmc ngen=20 nchains=1 nruns=1 samplefreq=5 printfreq=20 filename=x;\nend;\n")
+        return data + "begin trees;\n tree t = [&U] " + start + "\nend;\n" + blk + tail
+
+    def lnls(t):
+        rows = [l.split("\t") for l in t.splitlines() if l and not l.startswith("[")]
+        k = rows[0].index("LnL") if "LnL" in rows[0] else rows[0].index("lnLike")
+        return [float(r[k]) for r in rows[1:]]
+    binary = os.path.join(REF, "mb_emu_std")
+    out, _, files = refrun.run_mb(binary, nexus(True), keep=("x.p",))
+    assert "Analysis completed" in out and "(standard data): 9 transition-matrix classes" in out, out[-2500:]
+    assert out.count("Using BEAGLE") == 6, out[-2500:]
+    out0, _, files0 = refrun.run_mb(binary, nexus(False), keep=("x.p",))
+    out1, _, files1 = refrun.run_mb(binary, nexus(True), keep=("x.p",), env={"MBAMD_DEVICE_STD": "0"})
+    a, b, c = lnls(files["x.p"]), lnls(files0["x.p"]), lnls(files1["x.p"])
+    assert len(a) == len(c) >= 4
+    assert abs(a[0] - b[0]) <= 2e-6 * abs(b[0]), (a[0], b[0])
+    assert all(abs(x - y) <= 1e-5 * abs(y) for x, y in zip(a, c)), (a, c)
+
+
 def test_unequal_frequencies_stay_on_the_host():
     """symdirihyperpr other than fixed(infinity) (beta categories for binary characters, per-character eigen-systems): refused with a
     printed reason, the reference's own kernels run."""
