@@ -365,6 +365,11 @@ inline bool Walk4Builder::build(const std::vector<Walk4Op>& ops, Walk4Template& 
             }
         }
         auto nextUseOfValue = [&](int v, int from) {           // next same-wave consumer position of value v at or after `from`
+            if (!dag) {                                        // a forest: the one consumer of a value is its parent
+                const int p = parent[v];
+                if (p < 0 || waveOf[p] != w) return 1 << 30;
+                return posOf[p] >= std::max(from, posOf[v] + 1) ? posOf[p] : (1 << 30);
+            }
             for (int j = std::max(from, posOf[v] + 1); j < L; ++j) {
                 const int o = items[w][j].op;
                 if (o >= 0 && (prod1[o] == v || prod2[o] == v)) return j;
@@ -387,7 +392,9 @@ inline bool Walk4Builder::build(const std::vector<Walk4Op>& ops, Walk4Template& 
             slotHolder[best] = -1;
             t.evictions++;
             // its remaining consumers read it from memory: no earlier than now, no earlier than its store was issued
-            for (int u = std::max(j, posOf[v] + 1); u < L; ++u) {
+            int uLo = std::max(j, posOf[v] + 1), uHi = L;
+            if (!dag) { const int p = parent[v]; if (p >= 0 && waveOf[p] == w && posOf[p] >= uLo) { uLo = posOf[p]; uHi = uLo + 1; } else uHi = uLo; }
+            for (int u = uLo; u < uHi; ++u) {
                 const int o = items[w][u].op;
                 if (o < 0) continue;
                 if (prod1[o] == v) { if (memSlots) mems.push_back(Mem{o, 0, std::max(j, posOf[v] + 1), u, -1, false}); t.reloads++; }
@@ -502,7 +509,9 @@ inline bool Walk4Builder::build(const std::vector<Walk4Op>& ops, Walk4Template& 
                         slotOfVal[v] = -1;
                         slotHolder[best] = -1;
                         t.evictions++;
-                        for (int u = j + 1; u < L; ++u) {
+                        int uLo = j + 1, uHi = L;
+                        if (!dag) { const int p = parent[v]; if (p >= 0 && waveOf[p] == w && posOf[p] >= uLo) { uLo = posOf[p]; uHi = uLo + 1; } else uHi = uLo; }
+                        for (int u = uLo; u < uHi; ++u) {
                             const int q = items[w][u].op;
                             if (q < 0) continue;
                             if (prod1[q] == v) { if (memSlots) mems.push_back(Mem{q, 0, j + 1, u, -1, false}); t.reloads++; }
@@ -518,7 +527,9 @@ inline bool Walk4Builder::build(const std::vector<Walk4Op>& ops, Walk4Template& 
                     slotsUsed = std::max(slotsUsed, sl + 1);
                 } else {
                     t.evictions++;
-                    for (int u = j + 1; u < L; ++u) {           // not kept: its consumers prefetch it (after this entry's store)
+                    int uLo = j + 1, uHi = L;
+                    if (!dag) { const int p = parent[o]; if (p >= 0 && waveOf[p] == w && posOf[p] >= uLo) { uLo = posOf[p]; uHi = uLo + 1; } else uHi = uLo; }
+                    for (int u = uLo; u < uHi; ++u) {           // not kept: its consumers prefetch it (after this entry's store)
                         const int q = items[w][u].op;
                         if (q < 0) continue;
                         if (prod1[q] == o) { if (memSlots) mems.push_back(Mem{q, 0, j + 1, u, -1, false}); t.reloads++; }
