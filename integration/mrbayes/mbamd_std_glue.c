@@ -177,6 +177,8 @@ static int Setup (ModelInfo *m, int d)
             w[j] = 1.0;                                     /* (the weighted sum is taken on the host: dummy characters, coding correction) */
         if (beagleSetPatternWeights (cl->instance, w) != BEAGLE_SUCCESS)
             return (ERROR);
+        if (mbamdSetDeferredResult (cl->instance, 1) != BEAGLE_SUCCESS)
+            return (ERROR);
         }
     free (states);
     free (partials);
@@ -308,6 +310,8 @@ void MbamdStdLogLike (int chain, int d, MrBFlt *lnL)
     parent = m->condLikeIndex[chain][top->index];
     child = m->condLikeIndex[chain][tree->root->index];
     prob = m->tiProbsIndex[chain][top->index];
+    /* (the instances return from the integration call without waiting -- mbamdSetDeferredResult in Setup --: every class's work is
+       on its stream before the first result is waited for) */
     for (g=0; g<sd->nClasses; g++)
         {
         const int inst = sd->cls[g].instance;
@@ -319,6 +323,13 @@ void MbamdStdLogLike (int chain, int d, MrBFlt *lnL)
             j = beagleCalculateEdgeLogLikelihoods (inst, &parent, &child, &prob, NULL, NULL, &zero, &zero, &cum, 1, &sum, NULL, NULL);
         else
             j = beagleCalculateRootLogLikelihoods (inst, &parent, &zero, &zero, &cum, 1, &sum);
+        if (j != BEAGLE_SUCCESS && j != BEAGLE_ERROR_FLOATING_POINT)
+            Die (mbamdGetLastError());
+        }
+    for (g=0; g<sd->nClasses; g++)
+        {
+        const int inst = sd->cls[g].instance;
+        j = mbamdFetchLogLikelihood (inst, &sum);
         if (j != BEAGLE_SUCCESS && j != BEAGLE_ERROR_FLOATING_POINT)
             Die (mbamdGetLastError());
         if (beagleGetSiteLogLikelihoods (inst, sd->site) != BEAGLE_SUCCESS)
