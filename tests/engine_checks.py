@@ -896,6 +896,53 @@ def check_double_precision_walk_categories(lib, monkeypatch, ntips=24, npat=200,
         assert any(np.any(e != 0) for e in got[True][nint:]), K
 
 
+def check_double_precision_queue(lib, nstates=20, ncat=2, npat=150, seed=3):
+    """The fp64 engine queues operation lists and runs them together (one launch per dependency level of ALL of them): a rejected
+    list (bad index) is reported by the call that brought it and leaves nothing behind; lists split over several calls -- with a
+    beagleRemoveScaleFactors on untouched buffers in between, as MrBayes does between the parts of a codon model -- give the bits
+    of one call; reading a buffer runs what is queued."""
+    rng = np.random.default_rng(seed)
+    S, K, P = nstates, ncat, npat
+    ntips, nint = 6, 5
+    states = [rng.integers(0, S + 1, size=P).astype(np.int32) for _ in range(ntips)]
+    mats = []
+    for m in range(ntips + nint):
+        ti = rng.random((K, S, S)) + 0.02
+        mats.append(ti / ti.sum(axis=2, keepdims=True) * 1e-2)
+    ops = np.array([[6, 0, -1, 0, 0, 1, 1], [7, 1, -1, 2, 2, 3, 3], [8, 2, -1, 4, 4, 5, 5], [9, 3, -1, 6, 6, 7, 7], [10, 4, -1, 9, 9, 8, 8]], dtype=np.int32)
+
+    def make():
+        inst = bg.BeagleInstance(lib, ntips, nint, ntips, S, P, 1, ntips + nint, K, nint + 3, preference_flags=bg.BEAGLE_FLAG_PRECISION_DOUBLE)
+        for m in range(ntips + nint):
+            inst.set_transition_matrix(m, mats[m])
+        for i in range(ntips):
+            inst.set_tip_states(i, states[i])
+        return inst
+    a = make()
+    b = make()
+    try:
+        a.reset_scale_factors(5)
+        a.update_partials(ops, 5)
+        want = [a.get_partials(int(o[0])) for o in ops] + [a.get_scale_exponents(i) for i in range(6)]
+        b.reset_scale_factors(5)
+        b.reset_scale_factors(6)
+        b.update_partials(ops[:2], 5)
+        b.remove_scale_factors(np.array([7], dtype=np.int32), 6)        # buffers no queued operation touches: does not have to run the queue
+        b.update_partials(ops[2:3], 5)
+        bad = ops[3:].copy()
+        bad[1, 3] = 99                                                     # child buffer out of range in the SECOND operation of the list
+        with pytest.raises(bg.BeagleError):
+            b.update_partials(bad, 5)
+        b.update_partials(ops[3:], 5)                                      # (the rejected list left nothing queued: operation 9 is not done twice)
+        got = [b.get_partials(int(o[0])) for o in ops] + [b.get_scale_exponents(i) for i in range(6)]
+        for x, y in zip(want, got):
+            assert np.array_equal(x, y)
+        assert any(np.any(e != 0) for e in want[len(ops):])
+    finally:
+        a.finalize()
+        b.finalize()
+
+
 def check_parsimony_model_golden(lib, golden_dir):
     """The device Fitch down-pass against the reference's OWN parsimony-model likelihood (Likelihood_Pars,
     src/likelihood.c:7593-7700; golden values written by tools/gen_golden_pars.py from oracle/_ref/mb with `lset parsmodel=yes`):

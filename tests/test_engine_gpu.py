@@ -564,6 +564,12 @@ def test_double_precision_walk_category_counts(gpu, monkeypatch):
     ec.check_double_precision_walk_categories(gpu, monkeypatch)
 
 
+@pytest.mark.parametrize("nstates", [4, 20])
+def test_double_precision_queued_lists(gpu, nstates):
+    """fp64: operation lists are queued and run together; errors are reported by the call that brought the list."""
+    ec.check_double_precision_queue(gpu, nstates=nstates)
+
+
 def test_parsimony_model_golden(gpu, golden_dir):
     """device Fitch lengths == the reference's own parsimony-model likelihood (golden vectors from oracle/_ref/mb)"""
     ec.check_parsimony_model_golden(gpu, golden_dir)

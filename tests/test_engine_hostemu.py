@@ -295,6 +295,12 @@ def test_double_precision_walk_category_counts(emu, monkeypatch):
     ec.check_double_precision_walk_categories(emu, monkeypatch)
 
 
+@pytest.mark.parametrize("nstates", [4, 20])
+def test_double_precision_queued_lists(emu, nstates):
+    """fp64: operation lists are queued and run together; errors are reported by the call that brought the list."""
+    ec.check_double_precision_queue(emu, nstates=nstates)
+
+
 def test_parsimony_model_golden(emu, golden_dir):
     """device Fitch lengths == the reference's own parsimony-model likelihood (golden vectors from oracle/_ref/mb)"""
     ec.check_parsimony_model_golden(emu, golden_dir)

@@ -12,7 +12,7 @@ from tests import std_cases
 from tools import refrun
 kw = dict(std_cases.BIG, ngen=50000)
 nex = std_cases.synthetic_nexus(beagle="dynamic", **kw).replace("nchains=1", "nchains=2").replace(" startvals tau=t V=t;\n", "")
-for env in ({"MBAMD_STATS": "1"}, {"MBAMD_DEVICE_STD": "0"}):
+for env in ({"MBAMD_STATS": "1"},):
     out, wall = refrun.run_mb(os.path.join(os.getcwd(), "oracle", "_ref", "mb_amd_full"), nex, timeout=850, env=env)
     print(env, "completed" if "Analysis completed" in out else "FAILED", "wall %.1f s" % wall)
     print("\n".join(l for l in out.splitlines() if re.match(r"\s+50000 -- ", l) or "standard data" in l or "rror" in l or "Analysis used" in l)[:900])
