@@ -261,6 +261,7 @@ struct Instance {
     int updatePartialsG(const BeagleOperation* ops, int n, int cumIdx);
     int flushWalkG();
     int runWalkG(const Plan& plan);
+    void postResultFlag();
     bool scaleOpsIndependentOfPending(const int* idx, int n, int cumIdx) const;
     uint64_t launchClock = 0, syncedClock = 0;   // launches issued / launches known complete (last stream synchronisation)
     std::vector<double> h_freqs, h_weights;      // host mirrors of d_freqs / d_weights (uploadIfChanged)
@@ -304,6 +305,13 @@ struct Instance {
     size_t stageCap = 0, stageOff = 0;
     double* h_sums = nullptr;         // pinned host memory the integration kernel writes its block sums to
     double* h_sums_dev = nullptr;     // the device-side address of h_sums
+    // The result is waited for by polling a word in pinned host memory that the STREAM writes behind the integration kernel
+    // (hipStreamWriteValue32): 7 us less per evaluation than hipStreamSynchronize on the same stream (MrBayes fixed-topology
+    // generation 83 -> 76 us, profiles/r04_mcmc_fixed_topology.txt).  A long wait falls back to the runtime's own wait.
+    uint32_t* h_flag = nullptr;       // sequence number of the last integration whose results have landed
+    uint32_t* h_flag_dev = nullptr;
+    uint32_t flagSeq = 0;             // ... of the last integration launched
+    bool pollResult = false;          // (off: MBAMD_NO_POLL, or the stream refused the write)
     unsigned char* stage_dev = nullptr;   // the device-side address of the staging ring
 
     // timing of the partials kernels
@@ -684,6 +692,14 @@ int Instance::create(int tipCount_, int partialsBufferCount, int compactBufferCo
     if (wg) nblocks = Ppad / MBAMD_INTEGRATE_WG_PATTERNS;      // the tree-walk layout's integration kernel, whatever the state count
     HIP_TRY(hipHostMalloc(&h_sums, (size_t) nblocks * sizeof(double), hipHostMallocDefault));
     HIP_TRY(hipHostGetDevicePointer((void**) &h_sums_dev, h_sums, 0));
+    if (std::getenv("MBAMD_NO_POLL") == nullptr) {
+        if (hipHostMalloc((void**) &h_flag, 64, hipHostMallocDefault) == hipSuccess && hipHostGetDevicePointer((void**) &h_flag_dev, h_flag, 0) == hipSuccess) {
+            *h_flag = 0;
+            pollResult = true;
+        } else {
+            (void) hipGetLastError();
+        }
+    }
     stageCap = (size_t) 8 << 20;
     HIP_TRY(hipHostMalloc(&stage, stageCap, hipHostMallocDefault));
     HIP_TRY(hipHostGetDevicePointer((void**) &stage_dev, stage, 0));
@@ -723,6 +739,7 @@ void Instance::destroy()
                     d_ev, d_tmp, d_trace};
     for (void* b : bufs) if (b) (void) hipFree(b);
     if (h_sums) (void) hipHostFree(h_sums);
+    if (h_flag) (void) hipHostFree(h_flag);
     if (h_site) (void) hipHostFree(h_site);
     if (stage) (void) hipHostFree(stage);
     for (auto& ev : events) { (void) hipEventDestroy(ev.first); (void) hipEventDestroy(ev.second); }
@@ -2614,6 +2631,7 @@ int Instance::integrate(const int* parent, const int* child, const int* prob, co
         if (rc) return rc;
         rc = spanEnd();
         if (rc) return rc;
+        postResultFlag();
         haveSite = true;
         pendingResult = true;
         if (deferred) {
@@ -2658,6 +2676,7 @@ int Instance::integrate(const int* parent, const int* child, const int* prob, co
         MBAMD_LAUNCH(k_integrate_lnl, (unsigned) nblocks, 64, 0, stream, a, S, SP, K, P, Ppad, (const double*) d_pweights, siteOut, h_sums_dev);
     HIP_TRY(hipGetLastError());
     { int src = spanEnd(); if (src) return src; }
+    postResultFlag();
     haveSite = true;
     pendingResult = true;
     if (deferred) {
@@ -2712,12 +2731,27 @@ int Instance::integrate4(const int* parent, const int* child, const int* prob, c
     return BEAGLE_SUCCESS;
 }
 
+// the stream writes the sequence number of this integration behind its kernel: what fetchResult polls
+void Instance::postResultFlag()
+{
+    if (!pollResult) return;
+    if (hipStreamWriteValue32(stream, h_flag_dev, ++flagSeq, 0) != hipSuccess) {
+        (void) hipGetLastError();
+        pollResult = false;
+    }
+}
+
 int Instance::fetchResult(double* out)
 {
     if (!pendingResult) return fail(BEAGLE_ERROR_GENERAL, "no log-likelihood pending");
     {
         StatTimer st_(ST_WAIT);
-        HIP_TRY(hipStreamSynchronize(stream));
+        bool landed = false;
+        if (pollResult) {
+            volatile uint32_t* f = h_flag;
+            for (long spins = 0; spins < 400000L && !(landed = (*f == flagSeq)); ++spins) __builtin_ia32_pause();   // (~ a millisecond; then the runtime's wait)
+        }
+        if (!landed) HIP_TRY(hipStreamSynchronize(stream));
     }
     syncedClock = launchClock;
     pendingResult = false;

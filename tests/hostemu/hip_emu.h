@@ -94,6 +94,7 @@ inline hipError_t hipEventRecord(hipEvent_t e, hipStream_t) { e->t = std::chrono
 #define hipEventDisableTiming 2
 inline hipError_t hipEventCreateWithFlags(hipEvent_t* e, unsigned) { *e = new EmuEvent; return hipSuccess; }
 inline hipError_t hipStreamWaitEvent(hipStream_t, hipEvent_t, unsigned) { return hipSuccess; }
+inline hipError_t hipStreamWriteValue32(hipStream_t, void* ptr, uint32_t value, unsigned) { *static_cast<uint32_t*>(ptr) = value; return hipSuccess; }   // (kernels run at launch)
 inline hipError_t hipDeviceGetPCIBusId(char* out, int len, int dev) { std::snprintf(out, (size_t) len, "emu:%02x:00.0", dev); return hipSuccess; }
 inline hipError_t hipEventSynchronize(hipEvent_t) { return hipSuccess; }
 inline hipError_t hipEventElapsedTime(float* ms, hipEvent_t a, hipEvent_t b) {
