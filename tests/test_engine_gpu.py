@@ -481,8 +481,9 @@ def test_walk_counted_waits_agree_on_partial_updates(gpu, oracle, monkeypatch):
 
     base = path_values()
     # ... and with the short programs in a device buffer instead of the kernel arguments (k_walk4_t<Walk4ArgsInline>)
+    # ... and with the result waited for by hipStreamSynchronize instead of the polled word (MBAMD_NO_POLL)
     for env in ({"MBAMD_WALK_SAFE": "1"}, {"MBAMD_WALK_PREFETCH": "0"}, {"MBAMD_WALK_PREFETCH": "9"}, {"MBAMD_MAX_LDS_SLOTS": "3"},
-                {"MBAMD_NO_INLINE_PROGRAMS": "1"}):
+                {"MBAMD_NO_INLINE_PROGRAMS": "1"}, {"MBAMD_NO_POLL": "1"}):
         for k, v in env.items():
             monkeypatch.setenv(k, v)
         assert path_values() == base

@@ -187,6 +187,8 @@ def test_short_walk_programs_travel_in_the_kernel_arguments(emu, monkeypatch, go
     base = path_values()
     monkeypatch.setenv("MBAMD_NO_INLINE_PROGRAMS", "1")
     assert path_values() == base
+    monkeypatch.setenv("MBAMD_NO_POLL", "1")                 # the result waited for by the runtime instead of the polled word
+    assert path_values() == base
 
 
 @pytest.mark.parametrize("kind", ["gtr", "wag", "m3"])
