@@ -63,6 +63,18 @@ __device__ __forceinline__ void mbd_block_sum2_256(double off, double diag, doub
     o4 = (red[0] + red[1]) + (red[2] + red[3]);
     d4 = (red[8] + red[9]) + (red[10] + red[11]);
 }
+// the same for a block of NT threads (NT / 64 waves); `red`: NT + 8 doubles of LDS scratch, of which the first NT / 32 are used here
+template <int NT> __device__ __forceinline__ void mbd_block_sum2(double off, double diag, double* red, int tid, double& o4, double& d4)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { off += __shfl_down(off, o); diag += __shfl_down(diag, o); }
+    constexpr int NW = NT / 64;
+    if ((tid & 63) == 0) { red[tid >> 6] = off; red[NW + (tid >> 6)] = diag; }
+    __syncthreads();
+    o4 = d4 = 0.0;
+#pragma unroll
+    for (int w = 0; w < NW; ++w) { o4 += red[w]; d4 += red[NW + w]; }
+}
 // Jacobi rotation (cosine c, tangent t) that annihilates a_pq.  The ANGLE may be approximate (a Jacobi iteration corrects
 // itself), the rotation must be orthogonal: hardware reciprocal / square root for tau and t, Newton steps on the reciprocal
 // square root that normalises (c, s).  (The correctly rounded divisions and roots were the longest part of a step, on one

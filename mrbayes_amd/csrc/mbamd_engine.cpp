@@ -1019,10 +1019,15 @@ int Instance::setRateMatrices(int first, int count, const double* q, const doubl
     if (rc) return rc;
     static std::vector<char> ldsRaised(64, 0);                      // per device: the attribute belongs to the device's code object
     if (device >= 0 && device < (int) ldsRaised.size() && !ldsRaised[device]) {
-        if (hipFuncSetAttribute((const void*) k_eigen_reversible, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) (void) hipGetLastError();
+        if (hipFuncSetAttribute((const void*) k_eigen_reversible<8>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess ||
+            hipFuncSetAttribute((const void*) k_eigen_reversible<32>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) (void) hipGetLastError();
         ldsRaised[device] = 1;
     }
-    MBAMD_LAUNCH_BARRIER(k_eigen_reversible, (unsigned) count, 256, eigen_lds_doubles(S) * sizeof(double), stream, djobs, S, 30);
+    // (beyond 32 states a step's 2 x 2 blocks are spread over 1 024 threads: four waves per SIMD hide the LDS round trips of a Jacobi step)
+    if (S > 32 && std::getenv("MBAMD_EIGEN_256") == nullptr)
+        MBAMD_LAUNCH_BARRIER(k_eigen_reversible<32>, (unsigned) count, 1024, eigen_lds_doubles(S) * sizeof(double), stream, djobs, S, 30);
+    else
+        MBAMD_LAUNCH_BARRIER(k_eigen_reversible<8>, (unsigned) count, 256, eigen_lds_doubles(S) * sizeof(double), stream, djobs, S, 30);
     HIP_TRY(hipGetLastError());
     // bookkeeping only once the launch is in the stream: a failure above leaves the buffers "cold" and unshielded
     for (int i = 0; i < count; ++i) {

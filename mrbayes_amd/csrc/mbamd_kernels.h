@@ -359,17 +359,21 @@ k_transition_matrices_ev(const MatrixJob* __restrict__ jobs, const double* __res
 // [U | U^-1 | lambda] (k_transition_matrices_* read them from there).  mode 1: `q` holds exchangeabilities r_ij instead of
 // rates; Q_ij = r_ij pi_j, rows sum to zero, scaled to one expected substitution per unit time (SetProteinQMatrix,
 // src/likelihood.c:8765-8880) -- the Q build on the device as well.
-// One workgroup of 256 threads per matrix, S <= 64; dynamic LDS: eigen_lds_doubles(S) doubles (62 KiB at 61 states).
+// One workgroup of 256 (up to 32 states) or 1 024 threads per matrix, S <= 64; dynamic LDS: eigen_lds_doubles(S) doubles (68 KiB at 61 states).
 // ---------------------------------------------------------------------------------------------
 // out = [U | U^-1 | lambda | V]: V (S x S) are the orthonormal eigenvectors of the symmetrised matrix -- what a later call
 // starts from (`warm` = the V of an eigen-system of a NEARBY rate matrix, e.g. the chain's current state when a move proposes
 // new rates: two or three sweeps instead of nine), or nullptr for a cold start from the identity.
 struct EigenJob { const double* q; const double* pi; double* out; const double* warm; int mode; int pad_; };
 // n = S rounded up to even (an odd S gets a dummy index whose row and column stay zero: its rotations are identities)
-__host__ __device__ inline size_t eigen_lds_doubles(int S) { const size_t n = (size_t) ((S + 1) & ~1); return 3 * n * (n + 1) + 4 * (n / 2 + 1) + 264; }
-__global__ void __launch_bounds__(256)
+__host__ __device__ inline size_t eigen_lds_doubles(int S) { const size_t n = (size_t) ((S + 1) & ~1); return 3 * n * (n + 1) + 4 * (n / 2 + 1) + 1032; }
+// TY: rows of the 32-wide thread grid -- 8 (256 threads: up to 32 states) or 32 (1 024 threads beyond: a Jacobi step is a chain of LDS
+// round trips and two barriers, and with one wave per SIMD nothing hides them; four waves per SIMD do: 538 -> 366 us for three warm-started 61-state systems)
+template <int TY>
+__global__ void __launch_bounds__(32 * TY)
 k_eigen_reversible(const EigenJob* __restrict__ jobs, int S, int sweeps)
 {
+    constexpr int NTHREADS = 32 * TY, NUA = 32 / TY, NUV = 64 / TY;
     double* lds = mbd_dyn_lds<double>();
     const EigenJob job = jobs[blockIdx.x];
     const int n = (S + 1) & ~1, m = n / 2, LD = n + 1;
@@ -380,26 +384,26 @@ k_eigen_reversible(const EigenJob* __restrict__ jobs, int S, int sweeps)
     double* rs = rc + (m + 1);               // [m] sines
     int* rp = reinterpret_cast<int*>(rs + (m + 1));   // [m] pair (p, q), p < q
     int* rq = rp + 2 * (m + 1);
-    double* red = rs + (m + 1) + 2 * (m + 1);         // [256 + 8] reduction scratch
+    double* red = rs + (m + 1) + 2 * (m + 1);         // [NTHREADS + 8] reduction scratch
     const int tid = threadIdx.x;
-    const int ty = tid >> 5, tx = tid & 31;  // an 8 x 32 thread grid over (pair | row, pair): no divisions in the loops
+    const int ty = tid >> 5, tx = tid & 31;  // a TY x 32 thread grid over (pair | row, pair): no divisions in the loops
     // ---- B = D Q D^-1, symmetrised (mode 1: Q from exchangeabilities first) ---------------------------------------------
     double scale = 1.0;
     if (job.mode == 1) {
         double part = 0.0;
-        for (int i = ty; i < S; i += 8) {
+        for (int i = ty; i < S; i += TY) {
             double row = 0.0;
             for (int j2 = tx; j2 < S; j2 += 32) if (j2 != i) row += job.q[(size_t) i * S + j2] * job.pi[j2];
             part += job.pi[i] * row;
         }
         red[tid] = part;
         MBAMD_SYNC();
-        if (tid == 0) { double tot = 0.0; for (int t = 0; t < 256; ++t) tot += red[t]; red[256] = 1.0 / tot; }
+        if (tid == 0) { double tot = 0.0; for (int t = 0; t < NTHREADS; ++t) tot += red[t]; red[NTHREADS] = 1.0 / tot; }
         MBAMD_SYNC();
-        scale = red[256];
+        scale = red[NTHREADS];
         MBAMD_SYNC();
     }
-    for (int i = ty; i < n; i += 8)
+    for (int i = ty; i < n; i += TY)
         for (int j2 = tx; j2 < n; j2 += 32) {
             double b = 0.0;
             if (i != j2 && i < S && j2 < S) {
@@ -412,27 +416,27 @@ k_eigen_reversible(const EigenJob* __restrict__ jobs, int S, int sweeps)
             V[i * LD + j2] = (i == j2) ? 1.0 : 0.0;
         }
     MBAMD_SYNC();
-    for (int i = tid; i < S; i += 256) {     // the diagonal: minus the row sum of Q (what makes the rows of Q sum to zero)
+    for (int i = tid; i < S; i += NTHREADS) {     // the diagonal: minus the row sum of Q (what makes the rows of Q sum to zero)
         double row = 0.0;
         for (int j2 = 0; j2 < S; ++j2)
             if (j2 != i) row += job.mode == 1 ? job.q[(size_t) i * S + j2] * job.pi[j2] * scale : job.q[(size_t) i * S + j2];
         A[i * LD + i] = -row;
     }
-    if (tid == 0) red[259] = 0.0;
+    if (tid == 0) red[NTHREADS + 3] = 0.0;
     MBAMD_SYNC();
     if (job.warm != nullptr) {
         // A <- V0^T B V0, V <- V0: the rotations then only have to undo what the rate matrix changed since V0 was computed
-        for (int i = ty; i < n; i += 8)
+        for (int i = ty; i < n; i += TY)
             for (int j2 = tx; j2 < n; j2 += 32) V[i * LD + j2] = (i < S && j2 < S) ? job.warm[(size_t) i * S + j2] : (i == j2 ? 1.0 : 0.0);
         MBAMD_SYNC();
-        for (int i = ty; i < n; i += 8)
+        for (int i = ty; i < n; i += TY)
             for (int j2 = tx; j2 < n; j2 += 32) {
                 double acc = 0.0;
                 for (int k2 = 0; k2 < n; ++k2) acc += A[i * LD + k2] * V[k2 * LD + j2];
                 Wt[i * LD + j2] = acc;
             }
         MBAMD_SYNC();
-        for (int i = ty; i < n; i += 8)
+        for (int i = ty; i < n; i += TY)
             for (int j2 = tx; j2 < n; j2 += 32) {
                 double acc = 0.0;
                 for (int k2 = 0; k2 < n; ++k2) acc += V[k2 * LD + i] * Wt[k2 * LD + j2];
@@ -466,33 +470,33 @@ k_eigen_reversible(const EigenJob* __restrict__ jobs, int S, int sweeps)
             if (tx < m) {
                 const int p2 = rp[tx], q2 = rq[tx];
                 const double c2 = rc[tx], s2 = rs[tx];
-                double x[4][4], v[8][2];
-                int pa[4], qa[4];
-                double ca[4], sa[4];
+                double x[NUA][4], v[NUV][2];
+                int pa[NUA], qa[NUA];
+                double ca[NUA], sa[NUA];
 #pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    const int a = (ty + 8 * u < m) ? ty + 8 * u : m - 1;
+                for (int u = 0; u < NUA; ++u) {
+                    const int a = (ty + TY * u < m) ? ty + TY * u : m - 1;
                     pa[u] = rp[a]; qa[u] = rq[a]; ca[u] = rc[a]; sa[u] = rs[a];
                     x[u][0] = A[pa[u] * LD + p2]; x[u][1] = A[pa[u] * LD + q2];
                     x[u][2] = A[qa[u] * LD + p2]; x[u][3] = A[qa[u] * LD + q2];
                 }
 #pragma unroll
-                for (int u = 0; u < 8; ++u) {
-                    const int k = (ty + 8 * u < n) ? ty + 8 * u : n - 1;
+                for (int u = 0; u < NUV; ++u) {
+                    const int k = (ty + TY * u < n) ? ty + TY * u : n - 1;
                     v[u][0] = V[k * LD + p2]; v[u][1] = V[k * LD + q2];
                 }
 #pragma unroll
-                for (int u = 0; u < 4; ++u)
-                    if (ty + 8 * u < m) {
+                for (int u = 0; u < NUA; ++u)
+                    if (ty + TY * u < m) {
                         const double y11 = ca[u] * x[u][0] - sa[u] * x[u][2], y12 = ca[u] * x[u][1] - sa[u] * x[u][3];
                         const double y21 = sa[u] * x[u][0] + ca[u] * x[u][2], y22 = sa[u] * x[u][1] + ca[u] * x[u][3];
                         A[pa[u] * LD + p2] = c2 * y11 - s2 * y12; A[pa[u] * LD + q2] = s2 * y11 + c2 * y12;
                         A[qa[u] * LD + p2] = c2 * y21 - s2 * y22; A[qa[u] * LD + q2] = s2 * y21 + c2 * y22;
                     }
 #pragma unroll
-                for (int u = 0; u < 8; ++u)
-                    if (ty + 8 * u < n) {                         // V <- V J
-                        const int k = ty + 8 * u;
+                for (int u = 0; u < NUV; ++u)
+                    if (ty + TY * u < n) {                         // V <- V J
+                        const int k = ty + TY * u;
                         V[k * LD + p2] = c2 * v[u][0] - s2 * v[u][1];
                         V[k * LD + q2] = s2 * v[u][0] + c2 * v[u][1];
                     }
@@ -501,31 +505,31 @@ k_eigen_reversible(const EigenJob* __restrict__ jobs, int S, int sweeps)
         }
         // converged?  (sum of squared off-diagonal elements against the squared diagonal)
         double off = 0.0, diag = 0.0;
-        for (int i = ty; i < n; i += 8)
+        for (int i = ty; i < n; i += TY)
             for (int j2 = tx; j2 < n; j2 += 32) { const double v = A[i * LD + j2]; if (i == j2) diag += v * v; else off += v * v; }
         double o4, d4;
-        mbd_block_sum2_256(off, diag, red, tid, o4, d4);
+        mbd_block_sum2<NTHREADS>(off, diag, red, tid, o4, d4);
         if (tid == 0) {
             // (quadratic convergence: once the off-diagonal mass is below 1e-20 of the diagonal's, one more sweep takes it to rounding)
-            red[258] = (o4 <= 1e-20 * d4) ? red[259] + 1.0 : 0.0;
-            red[259] = red[258];
+            red[NTHREADS + 2] = (o4 <= 1e-20 * d4) ? red[NTHREADS + 3] + 1.0 : 0.0;
+            red[NTHREADS + 3] = red[NTHREADS + 2];
         }
         MBAMD_SYNC();
-        if (red[258] >= enough) break;
+        if (red[NTHREADS + 2] >= enough) break;
     }
     // ---- U = D^-1 V, U^-1 = V^T D, lambda ------------------------------------------------------------------------------
     double* U = job.out;
     double* Ui = job.out + (size_t) S * S;
     double* lam = job.out + (size_t) 2 * S * S;
-    for (int i = ty; i < S; i += 8)
+    for (int i = ty; i < S; i += TY)
         for (int s2 = tx; s2 < S; s2 += 32) {
             const double di = sqrt(job.pi[i]);
             U[(size_t) i * S + s2] = V[i * LD + s2] / di;
             Ui[(size_t) s2 * S + i] = V[i * LD + s2] * di;
         }
-    for (int i = tid; i < S; i += 256) lam[i] = A[i * LD + i];
+    for (int i = tid; i < S; i += NTHREADS) lam[i] = A[i * LD + i];
     double* Vout = job.out + (size_t) 2 * S * S + S;
-    for (int i = ty; i < S; i += 8)
+    for (int i = ty; i < S; i += TY)
         for (int s2 = tx; s2 < S; s2 += 32) Vout[(size_t) i * S + s2] = V[i * LD + s2];
 }
 

@@ -49,6 +49,16 @@ inline void mbd_block_sum2_256(double off, double diag, double* red, int tid, do
         o4 = red[257];
     }
 }
+template <int NT> inline void mbd_block_sum2(double off, double diag, double* red, int tid, double& o4, double& d4)
+{
+    static double a[2048], b[2048];                  // (not the kernel's scratch: thread 0 sums when every thread has written)
+    a[tid] = off; b[tid] = diag;
+    mbamd_emu_barrier();
+    o4 = d4 = 0.0;
+    if (tid == 0) for (int u = 0; u < NT; ++u) { o4 += a[u]; d4 += b[u]; }
+    mbamd_emu_barrier();
+    (void) red;
+}
 inline void mbd_jacobi_rotation(double app, double aqq, double apq, double& c, double& t)
 {
     const double tau = (aqq - app) / (2.0 * apq);
