@@ -200,6 +200,232 @@ k64_partials_mfma(const Op64* __restrict__ ops, int S, int SPAD, int Ppad_)
         }
     }
 }
+
+// The same contraction with the matrices through LDS.  On the kernel above every wave fetches both transposed matrices itself -- at 61
+// states 62 KiB through the CU's L1 for 16 patterns, 20 eight-byte loads per 16 matrix instructions, and the L1's 64 B/clk are spent
+// at a quarter of the matrix cores' rate.  Here a workgroup of four waves (64 patterns of one operation) parks the matrices of its
+// non-tip children in LDS once, in FRAGMENT order -- the 64 lanes' A operands of (step t, tile it) are 64 consecutive doubles, so a
+// wave's read is one conflict-free ds_read_b64 -- and only the child's partials (one load per four matrix instructions, the next
+// group's in flight behind the current group's arithmetic) still come through the L1.  Same instructions on the same operands in
+// the same order as above: the results are bit-identical.  grid (P_pad / 64, operations, K if unfused), 256 threads,
+// dynamic LDS 2 * max(KF, 1) * stepsP * NT * 64 doubles, stepsP = ceil(S / 4) rounded up to a multiple of four (64 KiB at 61 states).
+template <int NT>
+__device__ __forceinline__ void f64_mfma_tiles_lds(const MBAMD_AS_CONST Op64* op, int S, int SPAD, size_t Ppad, int k, size_t c, int n, int g, int lane,
+                                                   const double* lds1, const double* lds2, double __attribute__((ext_vector_type(4))) (&p)[NT])
+{
+    typedef double d4 __attribute__((ext_vector_type(4)));
+    const int stepsP = (((S + 3) / 4) + 3) & ~3;           // steps of four in-states, padded to the groups of four the loop runs
+    d4 f[2][NT];
+#pragma unroll
+    for (int ch = 0; ch < 2; ++ch) {
+        const void* ptr = ch ? op->c2 : op->c1;
+        const bool tip = ch ? op->c2_tip : op->c1_tip;
+        if (tip) {
+            const MBAMD_AS_GLOBAL double* mT = as_global(ch ? op->m2T : op->m1T) + (size_t) k * S * SPAD;
+            const unsigned st = as_global(reinterpret_cast<const uint8_t*>(ptr))[c];
+#pragma unroll
+            for (int it = 0; it < NT; ++it)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int i = 16 * it + g + 4 * r;
+                    f[ch][it][r] = st >= (unsigned) S ? 1.0 : (i < S ? mT[(size_t) st * SPAD + i] : 0.0);
+                }
+            continue;
+        }
+        const double* la = (ch ? lds2 : lds1) + lane;
+        const MBAMD_AS_GLOBAL double* cl = as_global(reinterpret_cast<const double*>(ptr)) + (size_t) k * S * Ppad + c;
+#pragma unroll
+        for (int it = 0; it < NT; ++it) f[ch][it] = (d4) (0.0);
+        // (every load below is unconditional -- clamped row, the value MULTIPLIED by one or zero: a select would be turned into a branch
+        //  around the load -- and the loop body straight-line code: a load inside a branch makes the compiler wait for ALL loads at the
+        //  join, the prefetched ones included)
+        double b[4], bn[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int j = 4 * u + g;
+            b[u] = cl[(size_t) (j < S ? j : S - 1) * Ppad] * (j < S ? 1.0 : 0.0);
+        }
+        for (int t0 = 0; t0 < stepsP; t0 += 4) {
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {                    // the next group's partials, behind this group's arithmetic
+                const int j = 4 * (t0 + 4 + u) + g;
+                bn[u] = cl[(size_t) (j < S ? j : S - 1) * Ppad] * (j < S ? 1.0 : 0.0);
+            }
+            double a[4][NT];
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+#pragma unroll
+                for (int it = 0; it < NT; ++it) a[u][it] = la[(size_t) ((t0 + u) * NT + it) * 64];      // (zero rows beyond S)
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+#pragma unroll
+                for (int it = 0; it < NT; ++it) f[ch][it] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[u][it], b[u], f[ch][it], 0, 0, 0);
+#pragma unroll
+            for (int u = 0; u < 4; ++u) b[u] = bn[u];
+        }
+    }
+#pragma unroll
+    for (int it = 0; it < NT; ++it) p[it] = f[0][it] * f[1][it];
+}
+
+template <int NT, int KF>
+__global__ void __launch_bounds__(256)
+k64_partials_mfma_lds(const Op64* __restrict__ ops, int S, int SPAD, int Ppad_)
+{
+    typedef double d4 __attribute__((ext_vector_type(4)));
+    constexpr int KL = KF > 0 ? KF : 1;
+    double* lds = mbd_dyn_lds<double>();
+    const MBAMD_AS_CONST Op64* op = as_const(ops) + blockIdx.y;
+    const size_t Ppad = (size_t) Ppad_;
+    const int tid = (int) threadIdx.x, wave = tid >> 6, lane = tid & 63, n = lane & 15, g = lane >> 4;
+    const int stepsP = (((S + 3) / 4) + 3) & ~3, frag = stepsP * NT * 64;         // doubles of one matrix in fragment order (zero rows beyond S)
+    if ((size_t) blockIdx.x * 64 + 64 <= (size_t) op->first || (size_t) blockIdx.x * 64 >= (size_t) op->last) return;   // (workgroup-uniform)
+    // ---- the matrices of the non-tip children into LDS: element (t, it, lane = (n', g')) = mT[(4 t + g') * SPAD + 16 it + n'] -------------
+    // (all of a category's loads first -- up to 16 per child and thread in flight, clamped addresses -- then the LDS stores)
+    const int nq = stepsP >> 2;                              // 256-element rounds of one matrix: nq * NT
+    for (int kk = 0; kk < KL; ++kk) {
+        const int k = KF > 0 ? kk : (int) blockIdx.z;
+        double tmp[2][4][NT];
+#pragma unroll
+        for (int ch = 0; ch < 2; ++ch) {
+            if (ch ? op->c2_tip : op->c1_tip) continue;
+            const MBAMD_AS_GLOBAL double* mT = as_global(ch ? op->m2T : op->m1T) + (size_t) k * S * SPAD;
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+#pragma unroll
+                for (int w = 0; w < NT; ++w) {
+                    const int blk = ((q < nq ? q : nq - 1) * NT + w) * 4 + wave;          // 64-lane block (t, it) of fragment order
+                    const int it = blk % NT, t = blk / NT;
+                    const int j = 4 * t + g, i = 16 * it + n;
+                    tmp[ch][q][w] = mT[(size_t) (j < S ? j : S - 1) * SPAD + (i < S ? i : 0)] * ((j < S && i < S) ? 1.0 : 0.0);
+                }
+        }
+#pragma unroll
+        for (int ch = 0; ch < 2; ++ch) {
+            if (ch ? op->c2_tip : op->c1_tip) continue;
+            double* dstl = lds + (size_t) (ch * KL + kk) * frag;
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+#pragma unroll
+                for (int w = 0; w < NT; ++w)
+                    if (q < nq) dstl[(q * NT + w) * 256 + tid] = tmp[ch][q][w];
+        }
+    }
+    MBAMD_SYNC();
+    const size_t tile0 = (size_t) blockIdx.x * 64 + (size_t) wave * 16;
+    if (tile0 + 16 <= (size_t) op->first || tile0 >= (size_t) op->last) return;            // (wave-uniform, no barrier below)
+    const size_t c = tile0 + n;
+    const bool mine = c >= (size_t) op->first && c < (size_t) op->last;
+    if constexpr (KF == 0) {
+        const int k = (int) blockIdx.z;
+        d4 p[NT];
+        f64_mfma_tiles_lds<NT>(op, S, SPAD, Ppad, k, c, n, g, lane, lds, lds + frag, p);
+        MBAMD_AS_GLOBAL double* dst = as_global(op->dst) + (size_t) k * S * Ppad + c;
+        if (mine) {
+#pragma unroll
+            for (int it = 0; it < NT; ++it)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int i = 16 * it + g + 4 * r;
+                    if (i < S) dst[(size_t) i * Ppad] = p[it][r];
+                }
+        }
+    } else {
+        d4 p[KF][NT];
+        double mx = 0.0;
+#pragma unroll
+        for (int k = 0; k < KF; ++k) {
+            f64_mfma_tiles_lds<NT>(op, S, SPAD, Ppad, k, c, n, g, lane, lds + (size_t) k * frag, lds + (size_t) (KF + k) * frag, p[k]);
+#pragma unroll
+            for (int it = 0; it < NT; ++it)
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    if (16 * it + g + 4 * r < S) mx = fmax(mx, p[k][it][r]);
+        }
+        mx = fmax(mx, __shfl_xor(mx, 16));
+        mx = fmax(mx, __shfl_xor(mx, 32));
+        int e = 0;
+        if (op->mode == 1) {
+            if (mx > 0.0 && mx < 1.0e300) (void) frexp(mx, &e);
+            e = e < -1000 ? -1000 : e;
+            if (mine && g == 0) {
+                as_global(op->scale)[c] = e;
+                if (op->cum != nullptr && e != 0) atomicAdd(op->cum + c, e);
+            }
+        } else if (op->mode == 2) {
+            e = as_global(op->scale)[c];
+        }
+        if (mine) {
+#pragma unroll
+            for (int k = 0; k < KF; ++k) {
+                MBAMD_AS_GLOBAL double* dst = as_global(op->dst) + (size_t) k * S * Ppad + c;
+#pragma unroll
+                for (int it = 0; it < NT; ++it)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int i = 16 * it + g + 4 * r;
+                        if (i < S) dst[(size_t) i * Ppad] = e != 0 ? ldexp(p[k][it][r], -e) : p[k][it][r];
+                    }
+            }
+        }
+    }
+}
+
+// Both children compact tips: no contraction, the product of two matrix columns -- a gather.  On the kernel above that is 32 scattered
+// loads and 16 stores per wave at two waves per SIMD (its accumulators), 1.2 us per codon operation against 0.5 us of stores; here a
+// lane owns states g, g + 4, ... of pattern n (NSL of them per category, KF categories: KF x NSL <= 32 products in registers), the
+// same product and the same rescale, eight waves per SIMD.  grid (P_pad / 16, operations).
+template <int NSL, int KF>
+__global__ void __launch_bounds__(64)
+k64_partials_tips(const Op64* __restrict__ ops, int S, int SPAD, int Ppad_)
+{
+    const MBAMD_AS_CONST Op64* op = as_const(ops) + blockIdx.y;
+    const size_t Ppad = (size_t) Ppad_;
+    const int lane = (int) threadIdx.x, n = lane & 15, g = lane >> 4;
+    const size_t c = (size_t) blockIdx.x * 16 + n;
+    if ((size_t) blockIdx.x * 16 + 16 <= (size_t) op->first || (size_t) blockIdx.x * 16 >= (size_t) op->last) return;   // (wave-uniform)
+    const bool mine = c >= (size_t) op->first && c < (size_t) op->last;
+    const unsigned s1 = as_global(reinterpret_cast<const uint8_t*>(op->c1))[c], s2 = as_global(reinterpret_cast<const uint8_t*>(op->c2))[c];
+    const bool gap1 = s1 >= (unsigned) S, gap2 = s2 >= (unsigned) S;
+    const MBAMD_AS_GLOBAL double* r1 = as_global(op->m1T) + (size_t) (gap1 ? 0u : s1) * SPAD;
+    const MBAMD_AS_GLOBAL double* r2 = as_global(op->m2T) + (size_t) (gap2 ? 0u : s2) * SPAD;
+    double p[KF][NSL];
+    double mx = 0.0;
+#pragma unroll
+    for (int k = 0; k < KF; ++k)
+#pragma unroll
+        for (int q = 0; q < NSL; ++q) {
+            const int i = g + 4 * q, ic = i < S ? i : S - 1;
+            const double a = r1[(size_t) k * S * SPAD + ic], b = r2[(size_t) k * S * SPAD + ic];
+            p[k][q] = i < S ? (gap1 ? 1.0 : a) * (gap2 ? 1.0 : b) : 0.0;
+            mx = fmax(mx, p[k][q]);
+        }
+    mx = fmax(mx, __shfl_xor(mx, 16));
+    mx = fmax(mx, __shfl_xor(mx, 32));
+    int e = 0;
+    if (op->mode == 1) {
+        if (mx > 0.0 && mx < 1.0e300) (void) frexp(mx, &e);
+        e = e < -1000 ? -1000 : e;
+        if (mine && g == 0) {
+            as_global(op->scale)[c] = e;
+            if (op->cum != nullptr && e != 0) atomicAdd(op->cum + c, e);
+        }
+    } else if (op->mode == 2) {
+        e = as_global(op->scale)[c];
+    }
+    if (mine) {
+#pragma unroll
+        for (int k = 0; k < KF; ++k) {
+            MBAMD_AS_GLOBAL double* dst = as_global(op->dst) + (size_t) k * S * Ppad + c;
+#pragma unroll
+            for (int q = 0; q < NSL; ++q) {
+                const int i = g + 4 * q;
+                if (i < S) dst[(size_t) i * Ppad] = e != 0 ? ldexp(p[k][q], -e) : p[k][q];
+            }
+        }
+    }
+}
+
 #endif
 
 // The same with the rescale fused (K == KF categories, S <= IB: all K x S results of a pattern stay in registers): one pass
@@ -701,6 +927,15 @@ public:
     size_t evCap = 0;
     void* d_stage = nullptr;
     size_t stageCap = 0;
+    // small host -> device transfers (operation lists, matrix jobs, weights, frequencies) go through a ring: the bytes are copied into
+    // pinned host memory, from there asynchronously into the device ring's slot of the same offset, and a slot is written again only
+    // after the ring wrapped -- one stream synchronisation per RING_BYTES instead of one per call (a codon M3 evaluation made ten).
+    static constexpr size_t RING_BYTES = 4u << 20, RING_MAX_ITEM = 256u << 10;
+    uint8_t* h_ring = nullptr;
+    uint8_t* d_ring = nullptr;
+    size_t ringPos = 0;
+    double* h_sums = nullptr;              // pinned: the block sums of a log-likelihood call
+    size_t hSumsCap = 0;
     std::vector<RatesArg> rateSets;
     bool haveSite = false;
     std::vector<std::pair<int, int>> parts;       // v3: [first, last) of every pattern partition (empty: none were set)
@@ -774,11 +1009,44 @@ public:
         void* all[] = {d_partials, d_states, d_matrices, d_eigen, d_freqs, d_weights, d_pweights, d_scale, d_site, d_sums, d_ev, d_stage};
         for (void* p : all)
             if (p) (void) hipFree(p);
+        if (d_ring) (void) hipFree(d_ring);
+        if (h_ring) (void) hipHostFree(h_ring);
+        if (h_sums) (void) hipHostFree(h_sums);
         (void) hipStreamDestroy(stream);
         live = false;
     }
+    // a ring slot holding `bytes` from src (host and device side), or nullptr when the item is too large for the ring
+    int ringPut(const void* src, size_t bytes, uint8_t** hostSlot, uint8_t** devSlot)
+    {
+        *hostSlot = *devSlot = nullptr;
+        if (bytes > RING_MAX_ITEM || std::getenv("MBAMD_F64_NO_RING") != nullptr) return BEAGLE_SUCCESS;
+        if (h_ring == nullptr) {
+            HIP_TRY(hipHostMalloc((void**) &h_ring, RING_BYTES, hipHostMallocDefault));
+            HIP_TRY(hipMalloc((void**) &d_ring, RING_BYTES));
+        }
+        const size_t need = (bytes + 255) & ~(size_t) 255;
+        if (ringPos + need > RING_BYTES) {
+            HIP_TRY(hipStreamSynchronize(stream));              // every slot's copy and its readers are behind us
+            ringPos = 0;
+        }
+        *hostSlot = h_ring + ringPos;
+        *devSlot = d_ring + ringPos;
+        ringPos += need;
+        std::memcpy(*hostSlot, src, bytes);
+        return BEAGLE_SUCCESS;
+    }
     int stage(const void* src, size_t bytes, void** out)
     {
+        {
+            uint8_t *hs, *ds;
+            int rc = ringPut(src, bytes, &hs, &ds);
+            if (rc) return rc;
+            if (ds != nullptr) {
+                HIP_TRY(hipMemcpyAsync(ds, hs, bytes, hipMemcpyHostToDevice, stream));
+                *out = ds;
+                return BEAGLE_SUCCESS;
+            }
+        }
         HIP_TRY(hipStreamSynchronize(stream));                  // (the staging buffer is re-used: wait for its last reader)
         if (bytes > stageCap) {
             if (d_stage) (void) hipFree(d_stage);
@@ -792,6 +1060,15 @@ public:
     }
     int upload(void* dst, const void* src, size_t bytes)
     {
+        {
+            uint8_t *hs, *ds;
+            int rc = ringPut(src, bytes, &hs, &ds);
+            if (rc) return rc;
+            if (hs != nullptr) {                                 // (stream order keeps it behind the earlier readers of dst)
+                HIP_TRY(hipMemcpyAsync(dst, hs, bytes, hipMemcpyHostToDevice, stream));
+                return BEAGLE_SUCCESS;
+            }
+        }
         HIP_TRY(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, stream));
         HIP_TRY(hipStreamSynchronize(stream));
         return BEAGLE_SUCCESS;
@@ -1250,6 +1527,13 @@ public:
         for (int l = 0; l < nLevels; ++l) start[(size_t) l + 1] += start[l];
         std::vector<int> fill(start.begin(), start.end() - 1);
         for (int i = 0; i < n; ++i) order[(size_t) fill[level[i]]++] = i;
+        // (within a level the operations on two compact tips first: they have a kernel of their own)
+        std::vector<int> tipsOf((size_t) nLevels, 0);
+        for (int l = 0; l < nLevels; ++l) {
+            auto mid = std::stable_partition(order.begin() + start[l], order.begin() + start[(size_t) l + 1],
+                                             [&](int i) { return h[(size_t) i].c1_tip && h[(size_t) i].c2_tip; });
+            tipsOf[l] = (int) (mid - (order.begin() + start[l]));
+        }
         std::vector<Op64> sorted((size_t) n);
         for (int i = 0; i < n; ++i) sorted[i] = h[order[i]];
         void* dv = nullptr;
@@ -1271,8 +1555,38 @@ public:
             if (S >= 16 && S <= 64 && !noMfma) {
                 const int NTr = (S + 15) / 16;
                 const bool fuse = K >= 1 && K <= 4 && NTr * K <= 8 && std::getenv("MBAMD_F64_UNFUSED") == nullptr;   // all K categories' tiles in registers
-                const dim3 grid((unsigned) (Ppad / 16), (unsigned) cnt, (unsigned) (fuse ? 1 : K));
-#define MBAMD_F64_MFMA_CASE(NT_, KF_) MBAMD_LAUNCH((k64_partials_mfma<NT_, KF_>), grid, 64, 0, stream, dops + first, S, SPAD, Ppad)
+                // operations on two compact tips: the gather kernel (fused rescale only, K x ceil(S / 4) <= 32 products per lane)
+                const int NSL = (S + 3) / 4 <= 5 ? 5 : (S + 3) / 4 <= 8 ? 8 : 16;
+                int ntt = (fuse && NSL * K <= 32 && std::getenv("MBAMD_F64_NO_TIPS_KERNEL") == nullptr) ? tipsOf[l] : 0;
+                if (ntt > 0) {
+                    const dim3 tgrid((unsigned) (Ppad / 16), (unsigned) ntt);
+#define MBAMD_F64_TIPS_CASE(NSL_, KF_) MBAMD_LAUNCH((k64_partials_tips<NSL_, KF_>), tgrid, 64, 0, stream, dops + first, S, SPAD, Ppad)
+                    switch (NSL * 8 + K) {
+                        case 5 * 8 + 1: MBAMD_F64_TIPS_CASE(5, 1); break;
+                        case 5 * 8 + 2: MBAMD_F64_TIPS_CASE(5, 2); break;
+                        case 5 * 8 + 3: MBAMD_F64_TIPS_CASE(5, 3); break;
+                        case 5 * 8 + 4: MBAMD_F64_TIPS_CASE(5, 4); break;
+                        case 8 * 8 + 1: MBAMD_F64_TIPS_CASE(8, 1); break;
+                        case 8 * 8 + 2: MBAMD_F64_TIPS_CASE(8, 2); break;
+                        case 8 * 8 + 3: MBAMD_F64_TIPS_CASE(8, 3); break;
+                        case 8 * 8 + 4: MBAMD_F64_TIPS_CASE(8, 4); break;
+                        case 16 * 8 + 1: MBAMD_F64_TIPS_CASE(16, 1); break;
+                        case 16 * 8 + 2: MBAMD_F64_TIPS_CASE(16, 2); break;
+                        default: ntt = 0; break;
+                    }
+#undef MBAMD_F64_TIPS_CASE
+                }
+                if (ntt == cnt) continue;
+                const dim3 grid((unsigned) (Ppad / 16), (unsigned) (cnt - ntt), (unsigned) (fuse ? 1 : K));
+                // (matrices through LDS, four waves per workgroup, when both fit into 64 KiB)
+                const size_t ldsBytes = (size_t) 2 * (fuse ? K : 1) * ((((S + 3) / 4) + 3) & ~3) * NTr * 64 * sizeof(double);
+                // (pays beyond 32 states -- codon M3 0.90 -> 0.81 ms per evaluation; at 20 states x 4 categories the matrices are 5 KiB each and stay
+                //  in the L1, and parking eight of them before the first matrix instruction costs more than it saves: 1.26 -> 1.38 ms)
+                const bool viaLds = NTr >= 3 && ldsBytes <= 65536 && std::getenv("MBAMD_F64_MFMA_NO_LDS") == nullptr;
+                const dim3 lgrid((unsigned) (Ppad / 64), (unsigned) (cnt - ntt), (unsigned) (fuse ? 1 : K));
+#define MBAMD_F64_MFMA_CASE(NT_, KF_) do { \
+                    if (viaLds) MBAMD_LAUNCH_BARRIER((k64_partials_mfma_lds<NT_, KF_>), lgrid, 256, ldsBytes, stream, dops + first + ntt, S, SPAD, Ppad); \
+                    else MBAMD_LAUNCH((k64_partials_mfma<NT_, KF_>), grid, 64, 0, stream, dops + first + ntt, S, SPAD, Ppad); } while (0)
                 const int key = NTr * 8 + (fuse ? K : 0);
                 switch (key) {
                     case 1 * 8 + 0: MBAMD_F64_MFMA_CASE(1, 0); break;
@@ -1384,7 +1698,15 @@ public:
         if (count < 1 || count > MBAMD_MAX_SUBSETS) return fail(BEAGLE_ERROR_NO_IMPLEMENTATION, "log-likelihood: more than 8 subsets");
         const int pc = partitions ? partitionCount : 1;
         const int nblocks = Ppad / 64;
-        std::vector<double> h((size_t) nblocks * pc);
+        const size_t nsums = (size_t) nblocks * pc;
+        if (nsums > hSumsCap) {
+            if (h_sums) (void) hipHostFree(h_sums);
+            h_sums = nullptr;
+            hSumsCap = 0;
+            HIP_TRY(hipHostMalloc((void**) &h_sums, nsums * sizeof(double), hipHostMallocDefault));
+            hSumsCap = nsums;
+        }
+        double* const h = h_sums;
         std::vector<int> blocksOf((size_t) pc);
         if ((size_t) nblocks * pc > sumsCap) {
             HIP_TRY(hipStreamSynchronize(stream));
@@ -1435,7 +1757,7 @@ public:
                              d_sums + (size_t) d * nblocks);
         }
         HIP_TRY(hipGetLastError());
-        HIP_TRY(hipMemcpyAsync(h.data(), d_sums, h.size() * sizeof(double), hipMemcpyDeviceToHost, stream));
+        HIP_TRY(hipMemcpyAsync(h, d_sums, nsums * sizeof(double), hipMemcpyDeviceToHost, stream));
         HIP_TRY(hipStreamSynchronize(stream));
         double total = 0.0;
         for (int d = 0; d < pc; ++d) {
