@@ -209,9 +209,11 @@ k64_partials_mfma(const Op64* __restrict__ ops, int S, int SPAD, int Ppad_)
 // group's in flight behind the current group's arithmetic) still come through the L1.  Same instructions on the same operands in
 // the same order as above: the results are bit-identical.  grid (P_pad / 64, operations, K if unfused), 256 threads,
 // dynamic LDS 2 * max(KF, 1) * stepsP * NT * 64 doubles, stepsP = ceil(S / 4) rounded up to a multiple of four (64 KiB at 61 states).
-template <int NT>
+// (PRE: the first group's partials of both children were loaded before the matrices were parked -- `pre`)
+template <int NT, bool PRE>
 __device__ __forceinline__ void f64_mfma_tiles_lds(const MBAMD_AS_CONST Op64* op, int S, int SPAD, size_t Ppad, int k, size_t c, int n, int g, int lane,
-                                                   const double* lds1, const double* lds2, double __attribute__((ext_vector_type(4))) (&p)[NT])
+                                                   const double* lds1, const double* lds2, const double (&pre)[2][4],
+                                                   double __attribute__((ext_vector_type(4))) (&p)[NT])
 {
     typedef double d4 __attribute__((ext_vector_type(4)));
     const int stepsP = (((S + 3) / 4) + 3) & ~3;           // steps of four in-states, padded to the groups of four the loop runs
@@ -243,7 +245,8 @@ __device__ __forceinline__ void f64_mfma_tiles_lds(const MBAMD_AS_CONST Op64* op
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
             const int j = 4 * u + g;
-            b[u] = cl[(size_t) (j < S ? j : S - 1) * Ppad] * (j < S ? 1.0 : 0.0);
+            if constexpr (PRE) b[u] = pre[ch][u] * (j < S ? 1.0 : 0.0);       // (multiplied here, not where it was loaded: that would wait for it there)
+            else b[u] = cl[(size_t) (j < S ? j : S - 1) * Ppad] * (j < S ? 1.0 : 0.0);
         }
         for (int t0 = 0; t0 < stepsP; t0 += 4) {
 #pragma unroll
@@ -268,58 +271,71 @@ __device__ __forceinline__ void f64_mfma_tiles_lds(const MBAMD_AS_CONST Op64* op
     for (int it = 0; it < NT; ++it) p[it] = f[0][it] * f[1][it];
 }
 
-template <int NT, int KF>
-__global__ void __launch_bounds__(256)
-k64_partials_mfma_lds(const Op64* __restrict__ ops, int S, int SPAD, int Ppad_)
+// NW waves per workgroup (16 NW patterns): 8 on the large levels -- the LDS the matrices take allows two workgroups per CU, and two
+// waves per SIMD leave the matrix cores idle 60 % of the time (a wave also gathers tips, stores, and waits for its stores to drain);
+// 4 on the small ones, where 8 would leave CUs without work.
+// (one operation on the workgroup's 16 NW patterns; every thread of the workgroup passes the one barrier inside.  Walking the narrow
+//  levels at the top of the tree as chains inside ONE launch of this function -- a workgroup's patterns only depend on the same patterns
+//  of the children -- was measured and dropped: 152 us against 158 us for the eleven launches it replaced, an operation is a 11 us latency
+//  chain in either form, profiles/r04_f64.txt.)
+template <int NT, int KF, int NW>
+__device__ __forceinline__ void f64_lds_operation(const MBAMD_AS_CONST Op64* op, double* lds, int S, int SPAD, size_t Ppad)
 {
     typedef double d4 __attribute__((ext_vector_type(4)));
-    constexpr int KL = KF > 0 ? KF : 1;
-    double* lds = mbd_dyn_lds<double>();
-    const MBAMD_AS_CONST Op64* op = as_const(ops) + blockIdx.y;
-    const size_t Ppad = (size_t) Ppad_;
+    constexpr int KL = KF > 0 ? KF : 1, RMAX = 64 / NW;       // (at most 16 steps x 4 tiles = 64 blocks of 64 lanes per matrix)
     const int tid = (int) threadIdx.x, wave = tid >> 6, lane = tid & 63, n = lane & 15, g = lane >> 4;
-    const int stepsP = (((S + 3) / 4) + 3) & ~3, frag = stepsP * NT * 64;         // doubles of one matrix in fragment order (zero rows beyond S)
-    if ((size_t) blockIdx.x * 64 + 64 <= (size_t) op->first || (size_t) blockIdx.x * 64 >= (size_t) op->last) return;   // (workgroup-uniform)
-    // ---- the matrices of the non-tip children into LDS: element (t, it, lane = (n', g')) = mT[(4 t + g') * SPAD + 16 it + n'] -------------
-    // (all of a category's loads first -- up to 16 per child and thread in flight, clamped addresses -- then the LDS stores)
-    const int nq = stepsP >> 2;                              // 256-element rounds of one matrix: nq * NT
-    for (int kk = 0; kk < KL; ++kk) {
-        const int k = KF > 0 ? kk : (int) blockIdx.z;
-        double tmp[2][4][NT];
+    const int stepsP = (((S + 3) / 4) + 3) & ~3, nb = stepsP * NT, frag = nb * 64;         // doubles of one matrix in fragment order (zero rows beyond S)
+    const bool inRange = !((size_t) blockIdx.x * (16 * NW) + 16 * NW <= (size_t) op->first || (size_t) blockIdx.x * (16 * NW) >= (size_t) op->last);   // (workgroup-uniform)
+    const size_t tile0 = (size_t) blockIdx.x * (16 * NW) + (size_t) wave * 16;
+    const bool waveIn = inRange && !(tile0 + 16 <= (size_t) op->first || tile0 >= (size_t) op->last);      // (wave-uniform)
+    const size_t c = tile0 + n;
+    // ---- the first group of the children's partials (first category): in flight while the matrices are parked ---------------------------------
+    double pre[2][4] = {{0.0, 0.0, 0.0, 0.0}, {0.0, 0.0, 0.0, 0.0}};
+    if (waveIn) {
+        const int k0 = KF > 0 ? 0 : (int) blockIdx.z;
 #pragma unroll
         for (int ch = 0; ch < 2; ++ch) {
             if (ch ? op->c2_tip : op->c1_tip) continue;
+            const MBAMD_AS_GLOBAL double* cl = as_global(reinterpret_cast<const double*>(ch ? op->c2 : op->c1)) + (size_t) k0 * S * Ppad + c;
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int j = 4 * u + g;
+                pre[ch][u] = cl[(size_t) (j < S ? j : S - 1) * Ppad];
+            }
+        }
+    }
+    // ---- the matrices into LDS: element (t, it, lane = (n', g')) = mT[(4 t + g') * SPAD + 16 it + n'] -----------------------------------------
+    // (branch-free -- a tip child's matrix is parked too, unused -- so that all loads of a category, up to 16 per child and thread, are in
+    //  flight together: clamped addresses, values multiplied by one or zero, then the LDS stores)
+    for (int kk = 0; inRange && kk < KL; ++kk) {
+        const int k = KF > 0 ? kk : (int) blockIdx.z;
+        double tmp[2][RMAX];
+#pragma unroll
+        for (int ch = 0; ch < 2; ++ch) {
             const MBAMD_AS_GLOBAL double* mT = as_global(ch ? op->m2T : op->m1T) + (size_t) k * S * SPAD;
 #pragma unroll
-            for (int q = 0; q < 4; ++q)
-#pragma unroll
-                for (int w = 0; w < NT; ++w) {
-                    const int blk = ((q < nq ? q : nq - 1) * NT + w) * 4 + wave;          // 64-lane block (t, it) of fragment order
-                    const int it = blk % NT, t = blk / NT;
-                    const int j = 4 * t + g, i = 16 * it + n;
-                    tmp[ch][q][w] = mT[(size_t) (j < S ? j : S - 1) * SPAD + (i < S ? i : 0)] * ((j < S && i < S) ? 1.0 : 0.0);
-                }
+            for (int r = 0; r < RMAX; ++r) {
+                const int blk = r * NW + wave, bc = blk < nb ? blk : nb - 1;          // 64-lane block (t, it) of fragment order
+                const int it = bc % NT, t = bc / NT;
+                const int j = 4 * t + g, i = 16 * it + n;
+                tmp[ch][r] = mT[(size_t) (j < S ? j : S - 1) * SPAD + (i < S ? i : 0)] * ((j < S && i < S) ? 1.0 : 0.0);
+            }
         }
 #pragma unroll
         for (int ch = 0; ch < 2; ++ch) {
-            if (ch ? op->c2_tip : op->c1_tip) continue;
             double* dstl = lds + (size_t) (ch * KL + kk) * frag;
 #pragma unroll
-            for (int q = 0; q < 4; ++q)
-#pragma unroll
-                for (int w = 0; w < NT; ++w)
-                    if (q < nq) dstl[(q * NT + w) * 256 + tid] = tmp[ch][q][w];
+            for (int r = 0; r < RMAX; ++r)
+                if (r * NW + wave < nb) dstl[(r * NW + wave) * 64 + lane] = tmp[ch][r];
         }
     }
     MBAMD_SYNC();
-    const size_t tile0 = (size_t) blockIdx.x * 64 + (size_t) wave * 16;
-    if (tile0 + 16 <= (size_t) op->first || tile0 >= (size_t) op->last) return;            // (wave-uniform, no barrier below)
-    const size_t c = tile0 + n;
+    if (!waveIn) return;                                     // (no barrier below)
     const bool mine = c >= (size_t) op->first && c < (size_t) op->last;
     if constexpr (KF == 0) {
         const int k = (int) blockIdx.z;
         d4 p[NT];
-        f64_mfma_tiles_lds<NT>(op, S, SPAD, Ppad, k, c, n, g, lane, lds, lds + frag, p);
+        f64_mfma_tiles_lds<NT, true>(op, S, SPAD, Ppad, k, c, n, g, lane, lds, lds + frag, pre, p);
         MBAMD_AS_GLOBAL double* dst = as_global(op->dst) + (size_t) k * S * Ppad + c;
         if (mine) {
 #pragma unroll
@@ -335,7 +351,8 @@ k64_partials_mfma_lds(const Op64* __restrict__ ops, int S, int SPAD, int Ppad_)
         double mx = 0.0;
 #pragma unroll
         for (int k = 0; k < KF; ++k) {
-            f64_mfma_tiles_lds<NT>(op, S, SPAD, Ppad, k, c, n, g, lane, lds + (size_t) k * frag, lds + (size_t) (KF + k) * frag, p[k]);
+            if (k == 0) f64_mfma_tiles_lds<NT, true>(op, S, SPAD, Ppad, k, c, n, g, lane, lds + (size_t) k * frag, lds + (size_t) (KF + k) * frag, pre, p[k]);
+            else f64_mfma_tiles_lds<NT, false>(op, S, SPAD, Ppad, k, c, n, g, lane, lds + (size_t) k * frag, lds + (size_t) (KF + k) * frag, pre, p[k]);
 #pragma unroll
             for (int it = 0; it < NT; ++it)
 #pragma unroll
@@ -369,6 +386,13 @@ k64_partials_mfma_lds(const Op64* __restrict__ ops, int S, int SPAD, int Ppad_)
             }
         }
     }
+}
+
+template <int NT, int KF, int NW>
+__global__ void __launch_bounds__(64 * NW, NW / 2)
+k64_partials_mfma_lds(const Op64* __restrict__ ops, int S, int SPAD, int Ppad_)
+{
+    f64_lds_operation<NT, KF, NW>(as_const(ops) + blockIdx.y, mbd_dyn_lds<double>(), S, SPAD, (size_t) Ppad_);
 }
 
 // Both children compact tips: no contraction, the product of two matrix columns -- a gather.  On the kernel above that is 32 scattered
@@ -424,6 +448,79 @@ k64_partials_tips(const Op64* __restrict__ ops, int S, int SPAD, int Ppad_)
             }
         }
     }
+}
+
+// The same for 256 patterns per workgroup with both matrices parked in LDS (rows SPAD | 1 doubles apart, so that the lanes' rows fall on
+// different banks): the gather above makes 512 L2 requests per wave of 16 patterns -- 1 GB through the L1 miss queues for 244 MB of
+// results at codon size, 121 us where the stores alone take 36 (tools/microbench/store_patterns.hip) -- here a workgroup reads its two
+// matrices once, coalesced.  lane = pattern: every store is 512 contiguous bytes.  Two passes over LDS (maximum, then products) instead
+// of K x S products in registers.  Same products, same rescale.  grid (ceil(P_pad / 256), operations), dynamic LDS 2 K S (SPAD | 1) doubles.
+__global__ void __launch_bounds__(256)
+k64_partials_tips_lds(const Op64* __restrict__ ops, int S, int SPAD, int K, int Ppad_)
+{
+    double* lds = mbd_dyn_lds<double>();
+    const MBAMD_AS_CONST Op64* op = as_const(ops) + blockIdx.y;
+    const size_t Ppad = (size_t) Ppad_;
+    const int tid = (int) threadIdx.x;
+    const int SL = SPAD | 1, rows = K * S;
+    if ((size_t) blockIdx.x * 256 + 256 <= (size_t) op->first || (size_t) blockIdx.x * 256 >= (size_t) op->last) return;   // (workgroup-uniform)
+    {   // rows [k][state] of both transposed matrices, 16 loads per thread in flight
+        const MBAMD_AS_GLOBAL double* m1 = as_global(op->m1T);
+        const MBAMD_AS_GLOBAL double* m2 = as_global(op->m2T);
+        const int total = rows * SPAD;                       // elements of one matrix (all categories)
+        for (int base = 0; base < total; base += 256 * 8) {
+            double t1[8], t2[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int idx = base + u * 256 + tid, ic = idx < total ? idx : total - 1;
+                t1[u] = m1[ic];
+                t2[u] = m2[ic];
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int idx = base + u * 256 + tid;
+                if (idx < total) {
+                    const int r = idx / SPAD, i = idx - r * SPAD;
+                    lds[(size_t) r * SL + i] = t1[u];
+                    lds[(size_t) (rows + r) * SL + i] = t2[u];
+                }
+            }
+        }
+    }
+    MBAMD_SYNC();
+    const size_t c = (size_t) blockIdx.x * 256 + tid;
+    if (c >= Ppad) return;                                   // (whole waves: P_pad is a multiple of 64; no barrier below)
+    const bool mine = c >= (size_t) op->first && c < (size_t) op->last;
+    const unsigned s1 = as_global(reinterpret_cast<const uint8_t*>(op->c1))[c], s2 = as_global(reinterpret_cast<const uint8_t*>(op->c2))[c];
+    const bool gap1 = s1 >= (unsigned) S, gap2 = s2 >= (unsigned) S;
+    const double* r1 = lds + (size_t) (gap1 ? 0u : s1) * SL;
+    const double* r2 = lds + (size_t) rows * SL + (size_t) (gap2 ? 0u : s2) * SL;
+    const size_t kstep = (size_t) S * SL;                    // a category further
+    double mx = 0.0;
+    for (int k = 0; k < K; ++k)
+        for (int i = 0; i < S; ++i) {
+            const double a = r1[k * kstep + i], b = r2[k * kstep + i];
+            mx = fmax(mx, (gap1 ? 1.0 : a) * (gap2 ? 1.0 : b));
+        }
+    int e = 0;
+    if (op->mode == 1) {
+        if (mx > 0.0 && mx < 1.0e300) (void) frexp(mx, &e);
+        e = e < -1000 ? -1000 : e;
+        if (mine) {
+            as_global(op->scale)[c] = e;
+            if (op->cum != nullptr && e != 0) atomicAdd(op->cum + c, e);
+        }
+    } else if (op->mode == 2) {
+        e = as_global(op->scale)[c];
+    }
+    if (!mine) return;
+    MBAMD_AS_GLOBAL double* dst = as_global(op->dst) + c;
+    for (int k = 0; k < K; ++k)
+        for (int i = 0; i < S; ++i) {
+            const double a = r1[k * kstep + i], b = r2[k * kstep + i];
+            const double p = (gap1 ? 1.0 : a) * (gap2 ? 1.0 : b);
+            dst[((size_t) k * S + i) * Ppad] = e != 0 ? ldexp(p, -e) : p;
+        }
 }
 
 #endif
@@ -1128,16 +1225,28 @@ public:
         std::memcpy(h.data() + (size_t) 2 * S * S, lam, sizeof(double) * S);
         return upload(d_eigen + (size_t) idx * eigDoubles, h.data(), eigDoubles * sizeof(double));
     }
+    // host mirrors of the frequencies / weights on the device (NaN = nothing sent yet): true when `v` is what the device already holds
+    std::vector<double> hostFreqs, hostWeights;
+    static bool sameAsLast(std::vector<double>& mirror, size_t total, size_t at, const double* v, size_t n)
+    {
+        if (mirror.size() != total) mirror.assign(total, std::numeric_limits<double>::quiet_NaN());
+        if (std::memcmp(mirror.data() + at, v, n * sizeof(double)) == 0) return true;      // (bitwise: a NaN pattern never equals user data by accident of -0.0 / 0.0)
+        std::memcpy(mirror.data() + at, v, n * sizeof(double));
+        return false;
+    }
     int setFreqs(int idx, const double* f)
     {
         { const int rcq = flushQueue(); if (rcq) return rcq; }
         if (idx < 0 || idx >= nEigen) return fail(BEAGLE_ERROR_OUT_OF_RANGE, "beagleSetStateFrequencies: index");
+        // (MrBayes sets the frequencies and category weights of every eigen part before every evaluation: unchanged values are not sent again)
+        if (sameAsLast(hostFreqs, (size_t) nEigen * S, (size_t) idx * S, f, (size_t) S)) return BEAGLE_SUCCESS;
         return upload(d_freqs + (size_t) idx * S, f, (size_t) S * sizeof(double));
     }
     int setWeights(int idx, const double* w)
     {
         { const int rcq = flushQueue(); if (rcq) return rcq; }
         if (idx < 0 || idx >= nEigen) return fail(BEAGLE_ERROR_OUT_OF_RANGE, "beagleSetCategoryWeights: index");
+        if (sameAsLast(hostWeights, (size_t) nEigen * K, (size_t) idx * K, w, (size_t) K)) return BEAGLE_SUCCESS;
         return upload(d_weights + (size_t) idx * K, w, (size_t) K * sizeof(double));
     }
     int setRates(int index, const double* r)
@@ -1171,17 +1280,19 @@ public:
 #endif
         MBAMD_LAUNCH(k64_matrices, (unsigned) (count * K), 256, 0, stream, dj, (const double*) d_ev, S, SPAD, K);
     }
-    int updateMatrices(int eigenIdx, int rateIdx, const int* prob, const double* lengths, int count)
+    // Matrix updates are queued like operation lists: MrBayes updates a codon model's eigen parts one call each (src/mbbeagle.c:1475-1486),
+    // and three launches of 200 matrices fill the chip worse than one of 600.  Every other entry point flushes (flushQueue); a second
+    // update of a queued matrix, or another category-rate vector, flushes first.
+    std::vector<MatrixJob64> matQueue;
+    std::vector<char> matQueued;               // per matrix buffer: an update is in the queue
+    int matQueueRate = -1;
+    int flushMatrices()
     {
-        { const int rcq = flushQueue(); if (rcq) return rcq; }
-        if (count <= 0) return BEAGLE_SUCCESS;
-        if (eigenIdx < 0 || eigenIdx >= nEigen) return fail(BEAGLE_ERROR_OUT_OF_RANGE, "beagleUpdateTransitionMatrices: eigen index");
-        if (rateIdx < 0 || (size_t) rateIdx >= rateSets.size()) return fail(BEAGLE_ERROR_OUT_OF_RANGE, "beagleUpdateTransitionMatrices: rate index");
-        std::vector<MatrixJob64> jobs((size_t) count);
-        for (int i = 0; i < count; ++i) {
-            if (prob[i] < 0 || prob[i] >= nMatrices) return fail(BEAGLE_ERROR_OUT_OF_RANGE, "beagleUpdateTransitionMatrices: matrix index");
-            jobs[i] = {matrixPtr(prob[i]), lengths[i], d_eigen + (size_t) eigenIdx * eigDoubles, 0.0};
-        }
+        if (matQueue.empty()) return BEAGLE_SUCCESS;
+        std::vector<MatrixJob64> jobs;
+        jobs.swap(matQueue);
+        std::fill(matQueued.begin(), matQueued.end(), 0);
+        const int count = (int) jobs.size();
         void* dj = nullptr;
         int rc = stage(jobs.data(), jobs.size() * sizeof(MatrixJob64), &dj);
         if (rc) return rc;
@@ -1194,10 +1305,28 @@ public:
             HIP_TRY(hipMalloc(&d_ev, evCap * sizeof(double)));
         }
         const int total = count * K * S;
-        MBAMD_LAUNCH(k64_exponentials, (unsigned) ((total + 255) / 256), 256, 0, stream, (const MatrixJob64*) dj, rateSets[rateIdx], S, K, total, d_ev);
+        MBAMD_LAUNCH(k64_exponentials, (unsigned) ((total + 255) / 256), 256, 0, stream, (const MatrixJob64*) dj, rateSets[matQueueRate], S, K, total, d_ev);
         launchMatrices((const MatrixJob64*) dj, count);
         HIP_TRY(hipGetLastError());
         return BEAGLE_SUCCESS;
+    }
+    int updateMatrices(int eigenIdx, int rateIdx, const int* prob, const double* lengths, int count)
+    {
+        if (!queue.empty()) { const int rcq = flushQueue(); if (rcq) return rcq; }        // (queued operations read the matrices as they are now)
+        if (count <= 0) return BEAGLE_SUCCESS;
+        if (eigenIdx < 0 || eigenIdx >= nEigen) return fail(BEAGLE_ERROR_OUT_OF_RANGE, "beagleUpdateTransitionMatrices: eigen index");
+        if (rateIdx < 0 || (size_t) rateIdx >= rateSets.size()) return fail(BEAGLE_ERROR_OUT_OF_RANGE, "beagleUpdateTransitionMatrices: rate index");
+        for (int i = 0; i < count; ++i)
+            if (prob[i] < 0 || prob[i] >= nMatrices) return fail(BEAGLE_ERROR_OUT_OF_RANGE, "beagleUpdateTransitionMatrices: matrix index");
+        if (!matQueue.empty() && (matQueueRate != rateIdx || matQueue.size() + (size_t) count > 60000)) { const int rc = flushMatrices(); if (rc) return rc; }
+        if (matQueued.size() != (size_t) nMatrices) matQueued.assign((size_t) nMatrices, 0);
+        matQueueRate = rateIdx;
+        for (int i = 0; i < count; ++i) {
+            if (matQueued[(size_t) prob[i]]) { const int rc = flushMatrices(); if (rc) return rc; }
+            matQueued[(size_t) prob[i]] = 1;
+            matQueue.push_back({matrixPtr(prob[i]), lengths[i], d_eigen + (size_t) eigenIdx * eigDoubles, 0.0});
+        }
+        return std::getenv("MBAMD_F64_NO_MATRIX_QUEUE") != nullptr ? flushMatrices() : BEAGLE_SUCCESS;
     }
     // v3: an eigen-system and a category-rate vector per matrix; one launch per run of equal rate vectors
     int updateMatricesMulti(const int* eigenIdx, const int* rateIdx, const int* prob, const double* lengths, int count)
@@ -1463,6 +1592,7 @@ public:
     // run what updatePartials queued; called first by every other entry point
     int flushQueue()
     {
+        { const int rcm = flushMatrices(); if (rcm) return rcm; }
         if (queue.empty()) return BEAGLE_SUCCESS;
         std::vector<QueuedOp> q;
         q.swap(queue);
@@ -1558,7 +1688,11 @@ public:
                 // operations on two compact tips: the gather kernel (fused rescale only, K x ceil(S / 4) <= 32 products per lane)
                 const int NSL = (S + 3) / 4 <= 5 ? 5 : (S + 3) / 4 <= 8 ? 8 : 16;
                 int ntt = (fuse && NSL * K <= 32 && std::getenv("MBAMD_F64_NO_TIPS_KERNEL") == nullptr) ? tipsOf[l] : 0;
-                if (ntt > 0) {
+                const size_t tipsLds = (size_t) 2 * K * S * (SPAD | 1) * sizeof(double);
+                if (ntt > 0 && tipsLds <= 65536 && std::getenv("MBAMD_F64_TIPS_NO_LDS") == nullptr) {
+                    const dim3 tgrid((unsigned) ((Ppad + 255) / 256), (unsigned) ntt);
+                    MBAMD_LAUNCH_BARRIER(k64_partials_tips_lds, tgrid, 256, tipsLds, stream, dops + first, S, SPAD, K, Ppad);
+                } else if (ntt > 0) {
                     const dim3 tgrid((unsigned) (Ppad / 16), (unsigned) ntt);
 #define MBAMD_F64_TIPS_CASE(NSL_, KF_) MBAMD_LAUNCH((k64_partials_tips<NSL_, KF_>), tgrid, 64, 0, stream, dops + first, S, SPAD, Ppad)
                     switch (NSL * 8 + K) {
@@ -1583,9 +1717,12 @@ public:
                 // (pays beyond 32 states -- codon M3 0.90 -> 0.81 ms per evaluation; at 20 states x 4 categories the matrices are 5 KiB each and stay
                 //  in the L1, and parking eight of them before the first matrix instruction costs more than it saves: 1.26 -> 1.38 ms)
                 const bool viaLds = NTr >= 3 && ldsBytes <= 65536 && std::getenv("MBAMD_F64_MFMA_NO_LDS") == nullptr;
-                const dim3 lgrid((unsigned) (Ppad / 64), (unsigned) (cnt - ntt), (unsigned) (fuse ? 1 : K));
+                // (eight waves per workgroup where that still gives every CU two workgroups)
+                const bool wide = (size_t) ((Ppad + 127) / 128) * (size_t) (cnt - ntt) >= 512 && std::getenv("MBAMD_F64_MFMA_4WAVES") == nullptr;
+                const dim3 lgrid((unsigned) (wide ? (Ppad + 127) / 128 : Ppad / 64), (unsigned) (cnt - ntt), (unsigned) (fuse ? 1 : K));
 #define MBAMD_F64_MFMA_CASE(NT_, KF_) do { \
-                    if (viaLds) MBAMD_LAUNCH_BARRIER((k64_partials_mfma_lds<NT_, KF_>), lgrid, 256, ldsBytes, stream, dops + first + ntt, S, SPAD, Ppad); \
+                    if (viaLds && wide) MBAMD_LAUNCH_BARRIER((k64_partials_mfma_lds<NT_, KF_, 8>), lgrid, 512, ldsBytes, stream, dops + first + ntt, S, SPAD, Ppad); \
+                    else if (viaLds) MBAMD_LAUNCH_BARRIER((k64_partials_mfma_lds<NT_, KF_, 4>), lgrid, 256, ldsBytes, stream, dops + first + ntt, S, SPAD, Ppad); \
                     else MBAMD_LAUNCH((k64_partials_mfma<NT_, KF_>), grid, 64, 0, stream, dops + first + ntt, S, SPAD, Ppad); } while (0)
                 const int key = NTr * 8 + (fuse ? K : 0);
                 switch (key) {

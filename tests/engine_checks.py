@@ -842,6 +842,50 @@ def check_double_precision_walk(lib, golden_dir, case, monkeypatch):
         assert got[True][4] <= 2 and got[False][4] > 2 * got[True][4], (got[True][4], got[False][4])   # a launch per list against one per level
 
 
+F64_GENERAL_SWITCHES = ("MBAMD_F64_MFMA_NO_LDS", "MBAMD_F64_NO_TIPS_KERNEL", "MBAMD_F64_NO_MATRIX_QUEUE", "MBAMD_F64_NO_RING")
+
+
+def check_double_precision_general_paths(lib, golden_dir, case, monkeypatch):
+    """More than 32 states in fp64: the kernels the engine picks by default -- operations on two tips from matrices parked in LDS, the
+    contraction with its matrices in LDS (four or eight waves per workgroup), matrix updates of several calls as one launch, lists
+    staged through the ring -- give the bits of the plain one-wave level
+    kernel with everything switched off: per site, for a full evaluation and a partial update, both scaling schemes."""
+    div = division_from_golden(golden_dir, case)
+    t = div.tree
+    deep = max(range(t.ntaxa), key=lambda i: _depth(t, i))
+    for scaling in (lk.MB_BEAGLE_SCALE_ALWAYS, lk.MB_BEAGLE_SCALE_DYNAMIC):
+        got = {}
+        for plain in (False, True):
+            for name in F64_GENERAL_SWITCHES:
+                if plain:
+                    monkeypatch.setenv(name, "1")
+                else:
+                    monkeypatch.delenv(name, raising=False)
+            bd = lk.BeagleDivision(div, lib, scaling=scaling, double_precision=True)
+            try:
+                bd.inst.get_kernel_timing(reset=True)
+                lnl = bd.LogLike(0)
+                _, launches = bd.inst.get_kernel_timing(reset=True)
+                site = bd.inst.get_site_log_likelihoods().copy()
+                bd.AcceptMove(0)
+                old = t.length[deep]
+                t.length[deep] = old * 1.7
+                try:
+                    bd.TouchBranch(0, deep)
+                    moved = bd.LogLike(0)
+                    site2 = bd.inst.get_site_log_likelihoods().copy()
+                finally:
+                    t.length[deep] = old
+                got[plain] = (lnl, site, moved, site2, launches)
+            finally:
+                bd.finalize()
+        for name in F64_GENERAL_SWITCHES:
+            monkeypatch.delenv(name, raising=False)
+        assert got[True][0] == got[False][0] and got[True][2] == got[False][2], (case, scaling, got[True][0], got[False][0])
+        assert np.array_equal(got[True][1], got[False][1]) and np.array_equal(got[True][3], got[False][3])
+        assert got[False][4] == got[True][4], (got[False][4], got[True][4])      # (a launch per dependency level either way)
+
+
 def check_double_precision_walk_categories(lib, monkeypatch, ntips=24, npat=200, seed=11):
     """The fp64 four-state walk keeps a pattern's categories in the lanes of ONE wave (category count rounded up to a power of two,
     the surplus lanes repeating the last category): every category count 1 ... 8 must give the bits of the level kernels --
@@ -941,6 +985,74 @@ def check_double_precision_queue(lib, nstates=20, ncat=2, npat=150, seed=3):
     finally:
         a.finalize()
         b.finalize()
+
+
+def check_double_precision_matrix_queue(lib, monkeypatch, nstates=20, ncat=2, seed=5):
+    """The fp64 engine queues beagleUpdateTransitionMatrices calls and computes them in one launch when something else is asked of it:
+    several calls (eigen parts, as a codon model makes them), a SECOND update of a matrix still in the queue (the later length wins),
+    another category-rate vector between two calls, more calls than the staging ring holds (it wraps), and category weights / state
+    frequencies set again to the same and to other values -- everything equal to the engine with the queue and the ring switched off."""
+    rng = np.random.default_rng(seed)
+    S, K, P = nstates, ncat, 70
+    nmat, neig = 12, 2
+
+    def system():
+        a = rng.random((S, S))
+        a = a + a.T
+        np.fill_diagonal(a, 0.0)
+        np.fill_diagonal(a, -a.sum(axis=1))
+        lam, v = np.linalg.eigh(a)
+        return v, v.T.copy(), lam
+    systems = [system() for _ in range(neig)]
+    states = [rng.integers(0, S + 1, size=P).astype(np.int32) for _ in range(2)]
+    freqs = [np.full(S, 1.0 / S), rng.dirichlet(np.ones(S))]
+    weights = [np.full(K, 1.0 / K), rng.dirichlet(np.ones(K))]
+
+    def run(plain):
+        for name in ("MBAMD_F64_NO_MATRIX_QUEUE", "MBAMD_F64_NO_RING"):
+            if plain:
+                monkeypatch.setenv(name, "1")
+            else:
+                monkeypatch.delenv(name, raising=False)
+        inst = bg.BeagleInstance(lib, 2, 1, 2, S, P, neig, nmat, K, 2, preference_flags=bg.BEAGLE_FLAG_PRECISION_DOUBLE)
+        out = []
+        try:
+            for e, (u, ui, lam) in enumerate(systems):
+                inst.set_eigen_decomposition(e, u, ui, lam)
+            for i in range(2):
+                inst.set_tip_states(i, states[i])
+            inst.set_category_rates(np.linspace(0.5, 1.5, K))
+            inst.update_transition_matrices(0, np.arange(0, 6, dtype=np.int32), np.linspace(0.01, 0.3, 6))
+            inst.update_transition_matrices(1, np.arange(6, 12, dtype=np.int32), np.linspace(0.02, 0.5, 6))
+            inst.update_transition_matrices(1, np.array([3, 7], dtype=np.int32), np.array([0.9, 0.8]))       # 3 and 7 are still queued
+            out += [inst.get_transition_matrix(m) for m in range(nmat)]
+            inst.update_transition_matrices(0, np.array([0, 1], dtype=np.int32), np.array([0.11, 0.12]))
+            inst.set_category_rates(np.linspace(0.2, 2.0, K))                                                  # (runs the queue: the old rates)
+            inst.update_transition_matrices(0, np.array([2], dtype=np.int32), np.array([0.13]))
+            out += [inst.get_transition_matrix(m) for m in range(3)]
+            for rep in range(40):                                     # 40 x 12 jobs x 3 calls and the lists below: the ring wraps several times
+                for f, w in ((0, 0), (0, 0), (1, 1), (0, 1)):
+                    inst.set_state_frequencies(0, freqs[f])
+                    inst.set_category_weights(0, weights[w])
+                    if rep in (0, 39):
+                        inst.update_transition_matrices(0, np.arange(nmat, dtype=np.int32), np.linspace(0.01, 0.4, nmat) * (1 + f))
+                        inst.update_partials(np.array([[2, -1, -1, 0, 0, 1, 1 + w]], dtype=np.int32), bg.BEAGLE_OP_NONE)
+                        out.append(np.array([inst.calculate_root_log_likelihoods(2, 0, 0, bg.BEAGLE_OP_NONE)[1]]))
+                        out.append(inst.get_site_log_likelihoods().copy())
+                    else:
+                        inst.update_transition_matrices(rep & 1, np.arange(nmat, dtype=np.int32), np.linspace(0.01, 0.4, nmat) * (1 + 0.01 * rep))
+        finally:
+            inst.finalize()
+            for name in ("MBAMD_F64_NO_MATRIX_QUEUE", "MBAMD_F64_NO_RING"):
+                monkeypatch.delenv(name, raising=False)
+        return out
+    got, want = run(False), run(True)
+    assert len(got) == len(want) and len(got) > nmat + 3
+    for x, y in zip(got, want):
+        assert np.array_equal(x, y)
+    # four different (frequencies, weights) settings: four different likelihoods (a skipped upload would repeat one)
+    lnls = [float(x[0]) for x in got[nmat + 3::2][:4]]
+    assert lnls[0] == lnls[1] and len({lnls[1], lnls[2], lnls[3]}) == 3, lnls
 
 
 def check_parsimony_model_golden(lib, golden_dir):

@@ -560,6 +560,12 @@ def test_double_precision_walk_equals_levels(gpu, golden_dir, case, monkeypatch)
     ec.check_double_precision_walk(gpu, golden_dir, case, monkeypatch)
 
 
+@pytest.mark.parametrize("case", ["synth_codon_m3", "replicase_m3", "bench_c5"])
+def test_double_precision_general_state_paths(gpu, golden_dir, case, monkeypatch):
+    """fp64 beyond 32 states: LDS-staged kernels, queued matrix updates and the staging ring against the plain level kernels, bit for bit."""
+    ec.check_double_precision_general_paths(gpu, golden_dir, case, monkeypatch)
+
+
 def test_double_precision_walk_category_counts(gpu, monkeypatch):
     """fp64, four states: every category count 1 ... 8 on the walk (categories in the lanes of one wave) against the level kernels."""
     ec.check_double_precision_walk_categories(gpu, monkeypatch)
@@ -569,6 +575,12 @@ def test_double_precision_walk_category_counts(gpu, monkeypatch):
 def test_double_precision_queued_lists(gpu, nstates):
     """fp64: operation lists are queued and run together; errors are reported by the call that brought the list."""
     ec.check_double_precision_queue(gpu, nstates=nstates)
+
+
+@pytest.mark.parametrize("nstates", [4, 20, 61])
+def test_double_precision_queued_matrix_updates(gpu, monkeypatch, nstates):
+    """fp64: transition-matrix updates of several calls run as one launch; staging ring; unchanged weights / frequencies are not re-sent."""
+    ec.check_double_precision_matrix_queue(gpu, monkeypatch, nstates=nstates)
 
 
 def test_parsimony_model_golden(gpu, golden_dir):

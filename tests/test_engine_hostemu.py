@@ -303,6 +303,12 @@ def test_double_precision_queued_lists(emu, nstates):
     ec.check_double_precision_queue(emu, nstates=nstates)
 
 
+@pytest.mark.parametrize("nstates", [4, 20, 61])
+def test_double_precision_queued_matrix_updates(emu, monkeypatch, nstates):
+    """fp64: transition-matrix updates of several calls run as one launch; staging ring; unchanged weights / frequencies are not re-sent."""
+    ec.check_double_precision_matrix_queue(emu, monkeypatch, nstates=nstates)
+
+
 def test_parsimony_model_golden(emu, golden_dir):
     """device Fitch lengths == the reference's own parsimony-model likelihood (golden vectors from oracle/_ref/mb)"""
     ec.check_parsimony_model_golden(emu, golden_dir)
