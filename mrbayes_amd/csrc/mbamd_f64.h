@@ -282,7 +282,7 @@ template <int NT, int KF, int NW>
 __device__ __forceinline__ void f64_lds_operation(const MBAMD_AS_CONST Op64* op, double* lds, int S, int SPAD, size_t Ppad)
 {
     typedef double d4 __attribute__((ext_vector_type(4)));
-    constexpr int KL = KF > 0 ? KF : 1, RMAX = 64 / NW;       // (at most 16 steps x 4 tiles = 64 blocks of 64 lanes per matrix)
+    constexpr int KL = KF > 0 ? KF : 1, RMAX = (4 * NT * NT + NW - 1) / NW;      // (at most 4 NT steps x NT tiles blocks of 64 lanes per matrix)
     const int tid = (int) threadIdx.x, wave = tid >> 6, lane = tid & 63, n = lane & 15, g = lane >> 4;
     const int stepsP = (((S + 3) / 4) + 3) & ~3, nb = stepsP * NT, frag = nb * 64;         // doubles of one matrix in fragment order (zero rows beyond S)
     const bool inRange = !((size_t) blockIdx.x * (16 * NW) + 16 * NW <= (size_t) op->first || (size_t) blockIdx.x * (16 * NW) >= (size_t) op->last);   // (workgroup-uniform)
@@ -305,29 +305,34 @@ __device__ __forceinline__ void f64_lds_operation(const MBAMD_AS_CONST Op64* op,
         }
     }
     // ---- the matrices into LDS: element (t, it, lane = (n', g')) = mT[(4 t + g') * SPAD + 16 it + n'] -----------------------------------------
-    // (branch-free -- a tip child's matrix is parked too, unused -- so that all loads of a category, up to 16 per child and thread, are in
-    //  flight together: clamped addresses, values multiplied by one or zero, then the LDS stores)
-    for (int kk = 0; inRange && kk < KL; ++kk) {
-        const int k = KF > 0 ? kk : (int) blockIdx.z;
-        double tmp[2][RMAX];
+    // (branch-free -- a tip child's matrix is parked too, unused -- so that all loads, up to 32 per thread, are in flight together:
+    //  clamped addresses, values multiplied by one or zero, then the LDS stores)
+    if (inRange) {
+        double tmp[KL][2][RMAX];
 #pragma unroll
-        for (int ch = 0; ch < 2; ++ch) {
-            const MBAMD_AS_GLOBAL double* mT = as_global(ch ? op->m2T : op->m1T) + (size_t) k * S * SPAD;
+        for (int kk = 0; kk < KL; ++kk) {
+            const int k = KF > 0 ? kk : (int) blockIdx.z;
 #pragma unroll
-            for (int r = 0; r < RMAX; ++r) {
-                const int blk = r * NW + wave, bc = blk < nb ? blk : nb - 1;          // 64-lane block (t, it) of fragment order
-                const int it = bc % NT, t = bc / NT;
-                const int j = 4 * t + g, i = 16 * it + n;
-                tmp[ch][r] = mT[(size_t) (j < S ? j : S - 1) * SPAD + (i < S ? i : 0)] * ((j < S && i < S) ? 1.0 : 0.0);
+            for (int ch = 0; ch < 2; ++ch) {
+                const MBAMD_AS_GLOBAL double* mT = as_global(ch ? op->m2T : op->m1T) + (size_t) k * S * SPAD;
+#pragma unroll
+                for (int r = 0; r < RMAX; ++r) {
+                    const int blk = r * NW + wave, bc = blk < nb ? blk : nb - 1;          // 64-lane block (t, it) of fragment order
+                    const int it = bc % NT, t = bc / NT;
+                    const int j = 4 * t + g, i = 16 * it + n;
+                    tmp[kk][ch][r] = mT[(size_t) (j < S ? j : S - 1) * SPAD + (i < S ? i : 0)] * ((j < S && i < S) ? 1.0 : 0.0);
+                }
             }
         }
 #pragma unroll
-        for (int ch = 0; ch < 2; ++ch) {
-            double* dstl = lds + (size_t) (ch * KL + kk) * frag;
+        for (int kk = 0; kk < KL; ++kk)
 #pragma unroll
-            for (int r = 0; r < RMAX; ++r)
-                if (r * NW + wave < nb) dstl[(r * NW + wave) * 64 + lane] = tmp[ch][r];
-        }
+            for (int ch = 0; ch < 2; ++ch) {
+                double* dstl = lds + (size_t) (ch * KL + kk) * frag;
+#pragma unroll
+                for (int r = 0; r < RMAX; ++r)
+                    if (r * NW + wave < nb) dstl[(r * NW + wave) * 64 + lane] = tmp[kk][ch][r];
+            }
     }
     MBAMD_SYNC();
     if (!waveIn) return;                                     // (no barrier below)
@@ -1714,11 +1719,12 @@ public:
                 const dim3 grid((unsigned) (Ppad / 16), (unsigned) (cnt - ntt), (unsigned) (fuse ? 1 : K));
                 // (matrices through LDS, four waves per workgroup, when both fit into 64 KiB)
                 const size_t ldsBytes = (size_t) 2 * (fuse ? K : 1) * ((((S + 3) / 4) + 3) & ~3) * NTr * 64 * sizeof(double);
-                // (pays beyond 32 states -- codon M3 0.90 -> 0.81 ms per evaluation; at 20 states x 4 categories the matrices are 5 KiB each and stay
-                //  in the L1, and parking eight of them before the first matrix instruction costs more than it saves: 1.26 -> 1.38 ms)
-                const bool viaLds = NTr >= 3 && ldsBytes <= 65536 && std::getenv("MBAMD_F64_MFMA_NO_LDS") == nullptr;
-                // (eight waves per workgroup where that still gives every CU two workgroups)
-                const bool wide = (size_t) ((Ppad + 127) / 128) * (size_t) (cnt - ntt) >= 512 && std::getenv("MBAMD_F64_MFMA_4WAVES") == nullptr;
+                // (codon M3 0.90 -> 0.81 ms per evaluation; at 20 states x 4 categories the matrices are 5 KiB each and stay in the L1: 1.19 -> 1.16 ms
+                //  with four waves per workgroup since all eight are parked in ONE batch of loads -- a batch per category was 1.38)
+                const bool viaLds = NTr >= 2 && ldsBytes <= 65536 && std::getenv("MBAMD_F64_MFMA_NO_LDS") == nullptr;
+                // (eight waves per workgroup where that still gives every CU two workgroups; beyond 32 states: with four categories' accumulators
+                //  the 128 registers of four waves per SIMD mean spills, 1.55 ms)
+                const bool wide = NTr >= 3 && (size_t) ((Ppad + 127) / 128) * (size_t) (cnt - ntt) >= 512 && std::getenv("MBAMD_F64_MFMA_4WAVES") == nullptr;
                 const dim3 lgrid((unsigned) (wide ? (Ppad + 127) / 128 : Ppad / 64), (unsigned) (cnt - ntt), (unsigned) (fuse ? 1 : K));
 #define MBAMD_F64_MFMA_CASE(NT_, KF_) do { \
                     if (viaLds && wide) MBAMD_LAUNCH_BARRIER((k64_partials_mfma_lds<NT_, KF_, 8>), lgrid, 512, ldsBytes, stream, dops + first + ntt, S, SPAD, Ppad); \

@@ -846,7 +846,7 @@ F64_GENERAL_SWITCHES = ("MBAMD_F64_MFMA_NO_LDS", "MBAMD_F64_NO_TIPS_KERNEL", "MB
 
 
 def check_double_precision_general_paths(lib, golden_dir, case, monkeypatch):
-    """More than 32 states in fp64: the kernels the engine picks by default -- operations on two tips from matrices parked in LDS, the
+    """16 ... 64 states in fp64: the kernels the engine picks by default -- operations on two tips from matrices parked in LDS, the
     contraction with its matrices in LDS (four or eight waves per workgroup), matrix updates of several calls as one launch, lists
     staged through the ring -- give the bits of the plain one-wave level
     kernel with everything switched off: per site, for a full evaluation and a partial update, both scaling schemes."""

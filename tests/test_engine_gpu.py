@@ -560,9 +560,9 @@ def test_double_precision_walk_equals_levels(gpu, golden_dir, case, monkeypatch)
     ec.check_double_precision_walk(gpu, golden_dir, case, monkeypatch)
 
 
-@pytest.mark.parametrize("case", ["synth_codon_m3", "replicase_m3", "bench_c5"])
+@pytest.mark.parametrize("case", ["synth_codon_m3", "replicase_m3", "bench_c5", "synth_aa_wag", "avian_wag_g4"])
 def test_double_precision_general_state_paths(gpu, golden_dir, case, monkeypatch):
-    """fp64 beyond 32 states: LDS-staged kernels, queued matrix updates and the staging ring against the plain level kernels, bit for bit."""
+    """fp64, 16 ... 64 states: LDS-staged kernels, queued matrix updates and the staging ring against the plain level kernels, bit for bit."""
     ec.check_double_precision_general_paths(gpu, golden_dir, case, monkeypatch)
 
 
