@@ -1560,6 +1560,8 @@ public:
     int updatePartialsEx(const void* opsRaw, size_t stride, int n, const int* partition, const int* cumOf)
     {
         if (n <= 0) return BEAGLE_SUCCESS;
+        // (the matrix updates are complete when the first operation list comes: the device computes them while the host queues and sorts the lists)
+        if (!matQueue.empty()) { const int rcm = flushMatrices(); if (rcm) return rcm; }
         const size_t mark = queue.size();
         const int np = std::max<int>(1, (int) parts.size());
         for (int i = 0; i < n; ++i) {
