@@ -223,14 +223,17 @@ __device__ __forceinline__ void f64_mfma_tiles_lds(const MBAMD_AS_CONST Op64* op
         const void* ptr = ch ? op->c2 : op->c1;
         const bool tip = ch ? op->c2_tip : op->c1_tip;
         if (tip) {
-            const MBAMD_AS_GLOBAL double* mT = as_global(ch ? op->m2T : op->m1T) + (size_t) k * S * SPAD;
+            // the column of the tip's state from the PARKED matrix (element (row st, column i) of fragment order; zero beyond S): gathered
+            // from global memory this was 256 L2 requests per wave, as many as everything else the wave reads
             const unsigned st = as_global(reinterpret_cast<const uint8_t*>(ptr))[c];
+            const unsigned sc = st >= (unsigned) S ? 0u : st;
+            const double* row = (ch ? lds2 : lds1) + (size_t) ((sc >> 2) * NT) * 64 + (sc & 3u) * 16 + g;
 #pragma unroll
             for (int it = 0; it < NT; ++it)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    const int i = 16 * it + g + 4 * r;
-                    f[ch][it][r] = st >= (unsigned) S ? 1.0 : (i < S ? mT[(size_t) st * SPAD + i] : 0.0);
+                    const double v = row[it * 64 + 4 * r];
+                    f[ch][it][r] = st >= (unsigned) S ? 1.0 : v;
                 }
             continue;
         }
