@@ -209,11 +209,26 @@ k64_partials_mfma(const Op64* __restrict__ ops, int S, int SPAD, int Ppad_)
 // group's in flight behind the current group's arithmetic) still come through the L1.  Same instructions on the same operands in
 // the same order as above: the results are bit-identical.  grid (P_pad / 64, operations, K if unfused), 256 threads,
 // dynamic LDS 2 * max(KF, 1) * stepsP * NT * 64 doubles, stepsP = ceil(S / 4) rounded up to a multiple of four (64 KiB at 61 states).
-// (PRE: the first group's partials of both children were loaded before the matrices were parked -- `pre`)
+#ifdef MBAMD_F64_STAMPS
+// diagnostic build: where a wave of the LDS contraction kernel spends its time (10 ns units of s_memrealtime; wave 0 of workgroup x = 5 of every operation)
+__device__ unsigned long long g_stamp_acc[2][8];
+__device__ unsigned long long g_stamp_cnt[2];
+#define MBAMD_TS(i) do { if (ts_on) { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); ts[i] = wall_clock64(); } } while (0)
+#else
+#define MBAMD_TS(i) do { } while (0)
+#endif
+// (PRE: the first group's partials of both children were loaded before the matrices were parked -- `pre`.  Requesting ALL of a child's
+//  partials ahead was measured on the four-wave workgroups of the narrow levels, where nothing else hides a cold load: at the start of
+//  its contraction 2.8 -> 3.6 us per child, before the matrices are parked 2.8 -> 2.3 us but the load phase 3.3 -> 5.0 us -- that phase is
+//  the level's read burst at HBM bandwidth (every workgroup of the level loads at the same time), not latency.  profiles/r04_f64.txt)
 template <int NT, bool PRE>
 __device__ __forceinline__ void f64_mfma_tiles_lds(const MBAMD_AS_CONST Op64* op, int S, int SPAD, size_t Ppad, int k, size_t c, int n, int g, int lane,
                                                    const double* lds1, const double* lds2, const double (&pre)[2][4],
-                                                   double __attribute__((ext_vector_type(4))) (&p)[NT])
+                                                   double __attribute__((ext_vector_type(4))) (&p)[NT]
+#ifdef MBAMD_F64_STAMPS
+                                                   , unsigned long long (&ts)[8], bool ts_on
+#endif
+                                                   )
 {
     typedef double d4 __attribute__((ext_vector_type(4)));
     const int stepsP = (((S + 3) / 4) + 3) & ~3;           // steps of four in-states, padded to the groups of four the loop runs
@@ -235,6 +250,7 @@ __device__ __forceinline__ void f64_mfma_tiles_lds(const MBAMD_AS_CONST Op64* op
                     const double v = row[it * 64 + 4 * r];
                     f[ch][it][r] = st >= (unsigned) S ? 1.0 : v;
                 }
+            MBAMD_TS(3 + ch);
             continue;
         }
         const double* la = (ch ? lds2 : lds1) + lane;
@@ -269,6 +285,7 @@ __device__ __forceinline__ void f64_mfma_tiles_lds(const MBAMD_AS_CONST Op64* op
 #pragma unroll
             for (int u = 0; u < 4; ++u) b[u] = bn[u];
         }
+        MBAMD_TS(3 + ch);
     }
 #pragma unroll
     for (int it = 0; it < NT; ++it) p[it] = f[0][it] * f[1][it];
@@ -285,10 +302,15 @@ template <int NT, int KF, int NW>
 __device__ __forceinline__ void f64_lds_operation(const MBAMD_AS_CONST Op64* op, double* lds, int S, int SPAD, size_t Ppad)
 {
     typedef double d4 __attribute__((ext_vector_type(4)));
-    constexpr int KL = KF > 0 ? KF : 1, RMAX = (4 * NT * NT + NW - 1) / NW;      // (at most 4 NT steps x NT tiles blocks of 64 lanes per matrix)
+    constexpr int KL = KF > 0 ? KF : 1;                      // (a matrix is at most 4 NT steps x NT tiles blocks of 64 lanes)
     const int tid = (int) threadIdx.x, wave = tid >> 6, lane = tid & 63, n = lane & 15, g = lane >> 4;
     const int stepsP = (((S + 3) / 4) + 3) & ~3, nb = stepsP * NT, frag = nb * 64;         // doubles of one matrix in fragment order (zero rows beyond S)
     const bool inRange = !((size_t) blockIdx.x * (16 * NW) + 16 * NW <= (size_t) op->first || (size_t) blockIdx.x * (16 * NW) >= (size_t) op->last);   // (workgroup-uniform)
+#ifdef MBAMD_F64_STAMPS
+    unsigned long long ts[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    const bool ts_on = blockIdx.x == 5 && wave == 0;
+    MBAMD_TS(0);
+#endif
     const size_t tile0 = (size_t) blockIdx.x * (16 * NW) + (size_t) wave * 16;
     const bool waveIn = inRange && !(tile0 + 16 <= (size_t) op->first || tile0 >= (size_t) op->last);      // (wave-uniform)
     const size_t c = tile0 + n;
@@ -311,7 +333,11 @@ __device__ __forceinline__ void f64_lds_operation(const MBAMD_AS_CONST Op64* op,
     // (branch-free -- a tip child's matrix is parked too, unused -- so that all loads, up to 32 per thread, are in flight together:
     //  clamped addresses, values multiplied by one or zero, then the LDS stores)
     if (inRange) {
-        double tmp[KL][2][RMAX];
+        // two adjacent columns per lane and load (16 bytes): unit u = doubles 2u, 2u + 1 of fragment order = lanes (g, n = 2 n2), (g, 2 n2 + 1)
+        // of block u / 32 -- half the load instructions of a double per lane
+        typedef double d2 __attribute__((ext_vector_type(2)));
+        constexpr int R2 = (2 * NT * NT + NW - 1) / NW;       // units per thread and matrix: 32 per block over 64 NW threads
+        d2 tmp[KL][2][R2];
 #pragma unroll
         for (int kk = 0; kk < KL; ++kk) {
             const int k = KF > 0 ? kk : (int) blockIdx.z;
@@ -319,11 +345,17 @@ __device__ __forceinline__ void f64_lds_operation(const MBAMD_AS_CONST Op64* op,
             for (int ch = 0; ch < 2; ++ch) {
                 const MBAMD_AS_GLOBAL double* mT = as_global(ch ? op->m2T : op->m1T) + (size_t) k * S * SPAD;
 #pragma unroll
-                for (int r = 0; r < RMAX; ++r) {
-                    const int blk = r * NW + wave, bc = blk < nb ? blk : nb - 1;          // 64-lane block (t, it) of fragment order
+                for (int r = 0; r < R2; ++r) {
+                    const int u = r * (64 * NW) + tid, uc = u < nb * 32 ? u : nb * 32 - 1;
+                    const int bc = uc >> 5, w = uc & 31, gg = w >> 3, n2 = w & 7;
                     const int it = bc % NT, t = bc / NT;
-                    const int j = 4 * t + g, i = 16 * it + n;
-                    tmp[kk][ch][r] = mT[(size_t) (j < S ? j : S - 1) * SPAD + (i < S ? i : 0)] * ((j < S && i < S) ? 1.0 : 0.0);
+                    const int j = 4 * t + gg, i = 16 * it + 2 * n2;
+                    const MBAMD_AS_GLOBAL double* src = mT + (size_t) (j < S ? j : S - 1) * SPAD + (i < S ? i : 0);
+                    d2 v;
+                    __builtin_memcpy(&v, (const void*) src, sizeof v);            // (one 16-byte load; the transposed copies start at an odd multiple of 8 bytes at 61 states)
+                    v.x *= (j < S && i < S) ? 1.0 : 0.0;
+                    v.y *= (j < S && i + 1 < S) ? 1.0 : 0.0;
+                    tmp[kk][ch][r] = v;
                 }
             }
         }
@@ -331,19 +363,25 @@ __device__ __forceinline__ void f64_lds_operation(const MBAMD_AS_CONST Op64* op,
         for (int kk = 0; kk < KL; ++kk)
 #pragma unroll
             for (int ch = 0; ch < 2; ++ch) {
-                double* dstl = lds + (size_t) (ch * KL + kk) * frag;
+                d2* dstl = reinterpret_cast<d2*>(lds + (size_t) (ch * KL + kk) * frag);
 #pragma unroll
-                for (int r = 0; r < RMAX; ++r)
-                    if (r * NW + wave < nb) dstl[(r * NW + wave) * 64 + lane] = tmp[kk][ch][r];
+                for (int r = 0; r < R2; ++r)
+                    if (r * (64 * NW) + tid < nb * 32) dstl[r * (64 * NW) + tid] = tmp[kk][ch][r];
             }
     }
+    MBAMD_TS(1);
     MBAMD_SYNC();
+    MBAMD_TS(2);
     if (!waveIn) return;                                     // (no barrier below)
     const bool mine = c >= (size_t) op->first && c < (size_t) op->last;
     if constexpr (KF == 0) {
         const int k = (int) blockIdx.z;
         d4 p[NT];
+#ifdef MBAMD_F64_STAMPS
+        f64_mfma_tiles_lds<NT, true>(op, S, SPAD, Ppad, k, c, n, g, lane, lds, lds + frag, pre, p, ts, ts_on);
+#else
         f64_mfma_tiles_lds<NT, true>(op, S, SPAD, Ppad, k, c, n, g, lane, lds, lds + frag, pre, p);
+#endif
         MBAMD_AS_GLOBAL double* dst = as_global(op->dst) + (size_t) k * S * Ppad + c;
         if (mine) {
 #pragma unroll
@@ -359,8 +397,13 @@ __device__ __forceinline__ void f64_lds_operation(const MBAMD_AS_CONST Op64* op,
         double mx = 0.0;
 #pragma unroll
         for (int k = 0; k < KF; ++k) {
+#ifdef MBAMD_F64_STAMPS
+            if (k == 0) f64_mfma_tiles_lds<NT, true>(op, S, SPAD, Ppad, k, c, n, g, lane, lds + (size_t) k * frag, lds + (size_t) (KF + k) * frag, pre, p[k], ts, ts_on);
+            else f64_mfma_tiles_lds<NT, false>(op, S, SPAD, Ppad, k, c, n, g, lane, lds + (size_t) k * frag, lds + (size_t) (KF + k) * frag, pre, p[k], ts, ts_on);
+#else
             if (k == 0) f64_mfma_tiles_lds<NT, true>(op, S, SPAD, Ppad, k, c, n, g, lane, lds + (size_t) k * frag, lds + (size_t) (KF + k) * frag, pre, p[k]);
             else f64_mfma_tiles_lds<NT, false>(op, S, SPAD, Ppad, k, c, n, g, lane, lds + (size_t) k * frag, lds + (size_t) (KF + k) * frag, pre, p[k]);
+#endif
 #pragma unroll
             for (int it = 0; it < NT; ++it)
 #pragma unroll
@@ -380,6 +423,7 @@ __device__ __forceinline__ void f64_lds_operation(const MBAMD_AS_CONST Op64* op,
         } else if (op->mode == 2) {
             e = as_global(op->scale)[c];
         }
+        MBAMD_TS(5);
         if (mine) {
 #pragma unroll
             for (int k = 0; k < KF; ++k) {
@@ -393,6 +437,13 @@ __device__ __forceinline__ void f64_lds_operation(const MBAMD_AS_CONST Op64* op,
                     }
             }
         }
+        MBAMD_TS(6);
+#ifdef MBAMD_F64_STAMPS
+        if (ts_on && lane == 0) {
+            for (int i = 1; i <= 6; ++i) atomicAdd(&g_stamp_acc[NW == 8 ? 0 : 1][i], ts[i] - ts[i - 1]);
+            atomicAdd(&g_stamp_cnt[NW == 8 ? 0 : 1], 1ull);
+        }
+#endif
     }
 }
 
@@ -1114,6 +1165,19 @@ public:
         void* all[] = {d_partials, d_states, d_matrices, d_eigen, d_freqs, d_weights, d_pweights, d_scale, d_site, d_sums, d_ev, d_stage};
         for (void* p : all)
             if (p) (void) hipFree(p);
+#ifdef MBAMD_F64_STAMPS
+        {
+            unsigned long long acc[2][8], cnt[2];
+            if (hipMemcpyFromSymbol(acc, HIP_SYMBOL(g_stamp_acc), sizeof acc) == hipSuccess && hipMemcpyFromSymbol(cnt, HIP_SYMBOL(g_stamp_cnt), sizeof cnt) == hipSuccess)
+                for (int v = 0; v < 2; ++v)
+                    if (cnt[v]) {
+                        std::fprintf(stderr, "[stamps] %s-wave workgroups, %llu waves: ", v == 0 ? "eight" : "four", cnt[v]);
+                        const char* names[8] = {"", "loads->LDS", "barrier", "child1", "child2", "rescale", "stores+drain", ""};
+                        for (int i = 1; i <= 6; ++i) std::fprintf(stderr, "%s %.2f us  ", names[i], (double) acc[v][i] / (double) cnt[v] * 0.01);
+                        std::fprintf(stderr, "\n");
+                    }
+        }
+#endif
         if (d_ring) (void) hipFree(d_ring);
         if (h_ring) (void) hipHostFree(h_ring);
         if (h_sums) (void) hipHostFree(h_sums);
