@@ -454,6 +454,237 @@ k64_partials_mfma_lds(const Op64* __restrict__ ops, int S, int SPAD, int Ppad_)
     f64_lds_operation<NT, KF, NW>(as_const(ops) + blockIdx.y, mbd_dyn_lds<double>(), S, SPAD, (size_t) Ppad_);
 }
 
+// (a descriptor by value, member by member: the scalar loads are issued where this is called, the wait is where a member is first used)
+__device__ __forceinline__ Op64 f64_load_op(const MBAMD_AS_CONST Op64* p)
+{
+    Op64 d;
+    d.dst = p->dst; d.c1 = p->c1; d.c2 = p->c2; d.m1T = p->m1T; d.m2T = p->m2T; d.scale = p->scale; d.cum = p->cum;
+    d.c1_tip = p->c1_tip; d.c2_tip = p->c2_tip; d.mode = p->mode; d.first = p->first; d.last = p->last; d.pad_ = p->pad_;
+    return d;
+}
+
+// A CHAIN of operations -- each one's result a child of the next: the root-ward path of an MCMC move -- in one launch, the running result
+// kept in registers.  The accumulator layout of v_mfma_f64_16x16x4_f64 IS its B layout: register r of output tile it at lane (n, g) holds
+// state 16 it + g + 4 r of pattern n, which is what step t = 4 it + r of the next contraction wants from that lane.  So the result of an
+// operation feeds the next one's matrix instructions as it stands (the rescaled values -- the same doubles that go to HBM for later
+// lists), and a level costs the matrix instructions of its two contractions instead of a launch, a read burst from HBM and a drain
+// (11 - 15 us per level on the level kernels).  Per operation: the matrices (fetched into registers during the previous operation) are
+// parked in LDS in fragment order, the SIBLING's partials (fetched then too) and the running result are contracted, product, rescale,
+// store; a tip sibling is a column of the parked matrix.  A workgroup = four waves = 64 patterns of one chain (a codon model's eigen
+// parts are chains of their own); no pattern partitions.  Op64::pad_: 0 first operation of a chain (child 1 from memory or a tip,
+// child 2 the "sibling"), 1 / 2 = child 1 / 2 is the previous result.  The same instructions on the same operands: bit-identical to
+// the level kernels.  grid (P_pad / 64, chains), 256 threads, dynamic LDS as k64_partials_mfma_lds.
+template <int NT, int KF>
+__global__ void __launch_bounds__(256)
+k64_partials_chain(const Op64* __restrict__ ops, const int* __restrict__ chainStart, int S, int SPAD, int Ppad_)
+{
+    typedef double d4 __attribute__((ext_vector_type(4)));
+    typedef double d2 __attribute__((ext_vector_type(2)));
+    constexpr int NW = 4, R2 = (2 * NT * NT + NW - 1) / NW;
+    double* lds = mbd_dyn_lds<double>();
+    const size_t Ppad = (size_t) Ppad_;
+    const int tid = (int) threadIdx.x, wave = tid >> 6, lane = tid & 63, n = lane & 15, g = lane >> 4;
+    const int stepsP = (((S + 3) / 4) + 3) & ~3, nb = stepsP * NT, frag = nb * 64;
+    const int ob = chainStart[blockIdx.y], oe = chainStart[blockIdx.y + 1];
+    const size_t c = (size_t) blockIdx.x * 64 + (size_t) wave * 16 + n;
+    d4 prev[KF][NT];                                         // the previous operation's (rescaled) result
+    d2 mt[KF][2][R2];                                        // the next operation's matrices on their way to LDS
+    double sib[KF][NT][4];                                   // the next operation's sibling partials: [category][group of four steps][step]
+#pragma unroll
+    for (int k = 0; k < KF; ++k)
+#pragma unroll
+        for (int it = 0; it < NT; ++it) {
+            prev[k][it] = (d4) (0.0);
+#pragma unroll
+            for (int u = 0; u < 4; ++u) sib[k][it][u] = 0.0;
+        }
+    auto fetchMatrices = [&](const Op64& d) {
+#pragma unroll
+        for (int k = 0; k < KF; ++k)
+#pragma unroll
+            for (int ch = 0; ch < 2; ++ch) {
+                const MBAMD_AS_GLOBAL double* mT = as_global(ch ? d.m2T : d.m1T) + (size_t) k * S * SPAD;
+#pragma unroll
+                for (int r = 0; r < R2; ++r) {
+                    const int u = r * (64 * NW) + tid, uc = u < nb * 32 ? u : nb * 32 - 1;
+                    const int bc = uc >> 5, w = uc & 31, gg = w >> 3, n2 = w & 7;
+                    const int it = bc % NT, t = bc / NT;
+                    const int j = 4 * t + gg, i = 16 * it + 2 * n2;
+                    const MBAMD_AS_GLOBAL double* src = mT + (size_t) (j < S ? j : S - 1) * SPAD + (i < S ? i : 0);
+                    d2 v;
+                    __builtin_memcpy(&v, (const void*) src, sizeof v);
+                    mt[k][ch][r] = v;                        // (as loaded: masked where it is written to LDS -- a multiplication here would wait for the load)
+                }
+            }
+    };
+    unsigned sibState = 0;                                   // the next operation's sibling, if it is a tip: its state
+    int storedExp = 0;                                       // the next operation's exponent, if it re-uses a stored one (mode 2)
+    auto fetchSibling = [&](const Op64& d) {
+        // (the same loads whatever the sibling is -- a tip's "partials" are read from the operation's own destination, a node's "state"
+        //  from the chain table, both unused: a load inside a branch would make every later wait a wait for everything in flight)
+        const int si = d.pad_ == 2 ? 0 : 1;                // the sibling is child 2 unless child 2 is the chain
+        const bool tip = si ? d.c2_tip : d.c1_tip;
+        const void* sp = si ? d.c2 : d.c1;
+        sibState = as_global(reinterpret_cast<const uint8_t*>(tip ? sp : (const void*) chainStart))[tip ? c : 0];
+        storedExp = as_global(d.mode == 2 ? (const int32_t*) d.scale : (const int32_t*) chainStart)[d.mode == 2 ? c : 0];   // (a stored exponent: ahead as well)
+        const MBAMD_AS_GLOBAL double* cl = as_global(tip ? (const double*) d.dst : reinterpret_cast<const double*>(sp)) + c;
+#pragma unroll
+        for (int k = 0; k < KF; ++k)
+#pragma unroll
+            for (int gq = 0; gq < NT; ++gq)
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int j = 4 * (4 * gq + u) + g;
+                    sib[k][gq][u] = cl[(size_t) k * S * Ppad + (size_t) (j < S ? j : S - 1) * Ppad];
+                }
+    };
+    // the descriptors through the scalar cache TWO operations ahead (a first touch is ~1 us: read where they are used, that is two or
+    // three serial misses per operation)
+    if (ob >= oe) return;
+    Op64 dcur = f64_load_op(as_const(ops) + ob), dnxt = f64_load_op(as_const(ops) + (ob + 1 < oe ? ob + 1 : ob));
+    fetchMatrices(dcur);
+    fetchSibling(dcur);
+#ifdef MBAMD_F64_STAMPS
+    unsigned long long ts[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    const bool ts_on = blockIdx.x == 5 && wave == 0;
+#define MBAMD_TSN(i) do { if (ts_on) ts[i] = wall_clock64(); } while (0)
+#else
+#define MBAMD_TSN(i) do { } while (0)
+#endif
+    for (int o = ob; o < oe; ++o) {
+        const Op64 dnn = f64_load_op(as_const(ops) + (o + 2 < oe ? o + 2 : oe - 1));
+        const Op64* op = &dcur;
+        MBAMD_TSN(0);
+#pragma unroll
+        for (int k = 0; k < KF; ++k)
+#pragma unroll
+            for (int ch = 0; ch < 2; ++ch) {
+                d2* dstl = reinterpret_cast<d2*>(lds + (size_t) (ch * KF + k) * frag);
+#pragma unroll
+                for (int r = 0; r < R2; ++r) {
+                    const int u = r * (64 * NW) + tid;
+                    if (u < nb * 32) {
+                        const int bc = u >> 5, w = u & 31, it = bc % NT, t = bc / NT;
+                        const int j = 4 * t + (w >> 3), i = 16 * it + 2 * (w & 7);
+                        d2 v = mt[k][ch][r];
+                        v.x *= (j < S && i < S) ? 1.0 : 0.0;
+                        v.y *= (j < S && i + 1 < S) ? 1.0 : 0.0;
+                        dstl[u] = v;
+                    }
+                }
+            }
+        MBAMD_TSN(1);
+        if (o + 1 < oe) fetchMatrices(dnxt);               // (in flight during this operation's arithmetic)
+        MBAMD_SYNC();
+        MBAMD_TSN(2);
+        const int cc = op->pad_, si = cc == 2 ? 0 : 1;       // chain child code, sibling's child index
+        d4 p[KF][NT];
+        double mx = 0.0;
+#pragma unroll
+        for (int k = 0; k < KF; ++k) {
+            d4 f[2][NT];
+            // one child's factor tiles: a tip's column from the parked matrix, or NT groups of four steps with b(gq, u) as operand
+            auto column = [&](int ch, unsigned st) {
+                const unsigned sc = st >= (unsigned) S ? 0u : st;
+                const double* row = lds + (size_t) (ch * KF + k) * frag + (size_t) ((sc >> 2) * NT) * 64 + (sc & 3u) * 16 + g;
+#pragma unroll
+                for (int it = 0; it < NT; ++it)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const double v = row[it * 64 + 4 * r];
+                        f[ch][it][r] = st >= (unsigned) S ? 1.0 : v;
+                    }
+            };
+            auto contract = [&](int ch, auto bval) {
+                const double* la = lds + (size_t) (ch * KF + k) * frag + lane;
+#pragma unroll
+                for (int it = 0; it < NT; ++it) f[ch][it] = (d4) (0.0);
+#pragma unroll
+                for (int gq = 0; gq < NT; ++gq) {
+                    if (4 * gq >= stepsP) break;             // (wave-uniform)
+                    double a[4][NT];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u)
+#pragma unroll
+                        for (int it = 0; it < NT; ++it) a[u][it] = la[(size_t) ((4 * gq + u) * NT + it) * 64];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        const double bu = bval(gq, u) * ((4 * (4 * gq + u) + g) < S ? 1.0 : 0.0);
+#pragma unroll
+                        for (int it = 0; it < NT; ++it) f[ch][it] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[u][it], bu, f[ch][it], 0, 0, 0);
+                    }
+                }
+            };
+            // the running result first -- it needs nothing from memory, and the sibling's partials get that much longer to arrive --
+            // or (first operation of a chain) child 1: a tip or partials in memory
+            if (cc != 0) contract(1 - si, [&](int gq, int u) { return prev[k][gq][u]; });
+            else if (op->c1_tip) column(0, as_global(reinterpret_cast<const uint8_t*>(op->c1))[c]);
+            else {
+                const MBAMD_AS_GLOBAL double* cl = as_global(reinterpret_cast<const double*>(op->c1)) + (size_t) k * S * Ppad + c;
+                double first[NT][4];
+#pragma unroll
+                for (int gq = 0; gq < NT; ++gq)
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        const int j = 4 * (4 * gq + u) + g;
+                        first[gq][u] = cl[(size_t) (j < S ? j : S - 1) * Ppad];
+                    }
+                contract(0, [&](int gq, int u) { return first[gq][u]; });
+            }
+            if (si ? op->c2_tip : op->c1_tip) column(si, sibState);
+            else contract(si, [&](int gq, int u) { return sib[k][gq][u]; });
+#pragma unroll
+            for (int it = 0; it < NT; ++it) {
+                p[k][it] = f[0][it] * f[1][it];
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    if (16 * it + g + 4 * r < S) mx = fmax(mx, p[k][it][r]);
+            }
+        }
+        MBAMD_TSN(3);
+        const int eStored = storedExp;
+        if (o + 1 < oe) fetchSibling(dnxt);                // (every category's sibling values have been used)
+        mx = fmax(mx, __shfl_xor(mx, 16));
+        mx = fmax(mx, __shfl_xor(mx, 32));
+        int e = 0;
+        if (op->mode == 1) {
+            if (mx > 0.0 && mx < 1.0e300) (void) frexp(mx, &e);
+            e = e < -1000 ? -1000 : e;
+            if (g == 0) {
+                as_global(op->scale)[c] = e;
+                if (op->cum != nullptr && e != 0) atomicAdd(op->cum + c, e);
+            }
+        } else if (op->mode == 2) {
+            e = eStored;
+        }
+#pragma unroll
+        for (int k = 0; k < KF; ++k) {
+            MBAMD_AS_GLOBAL double* dst = as_global(op->dst) + (size_t) k * S * Ppad + c;
+#pragma unroll
+            for (int it = 0; it < NT; ++it)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int i = 16 * it + g + 4 * r;
+                    const double v = e != 0 ? ldexp(p[k][it][r], -e) : p[k][it][r];
+                    prev[k][it][r] = v;
+                    if (i < S) dst[(size_t) i * Ppad] = v;
+                }
+        }
+        MBAMD_TSN(4);
+        MBAMD_SYNC();                                        // every wave is done with the parked matrices
+        MBAMD_TSN(5);
+        dcur = dnxt;
+        dnxt = dnn;
+#ifdef MBAMD_F64_STAMPS
+        if (ts_on && lane == 0) {
+            for (int i = 1; i <= 5; ++i) atomicAdd(&g_stamp_acc[0][i], ts[i] - ts[i - 1]);
+            atomicAdd(&g_stamp_cnt[0], 1ull);
+        }
+#endif
+    }
+#undef MBAMD_TSN
+}
+
 // Both children compact tips: no contraction, the product of two matrix columns -- a gather.  On the kernel above that is 32 scattered
 // loads and 16 stores per wave at two waves per SIMD (its accumulators), 1.2 us per codon operation against 0.5 us of stores; here a
 // lane owns states g, g + 4, ... of pattern n (NSL of them per category, KF categories: KF x NSL <= 32 products in registers), the
@@ -1740,6 +1971,87 @@ public:
         }
         std::vector<Op64> sorted((size_t) n);
         for (int i = 0; i < n; ++i) sorted[i] = h[order[i]];
+#if MBAMD_DEV_HAS_MFMA
+        // A list that is nothing but chains (the root-ward path of a move; one chain per eigen part): one launch of k64_partials_chain
+        {
+            const int NTr = (S + 15) / 16;
+            const size_t ldsBytes = (size_t) 2 * K * ((((S + 3) / 4) + 3) & ~3) * NTr * 64 * sizeof(double);
+            if (n >= 2 && S > 16 && S <= 64 && !noMfma && parts.empty() && K >= 1 && K <= 4 && NTr * K <= 8 && ldsBytes <= 65536 &&
+                std::getenv("MBAMD_F64_UNFUSED") == nullptr && std::getenv("MBAMD_F64_MFMA_NO_LDS") == nullptr && std::getenv("MBAMD_F64_NO_CHAIN") == nullptr) {
+                std::vector<int> root((size_t) n);
+                for (int i = 0; i < n; ++i) root[i] = i;
+                auto find = [&](int x) { while (root[x] != x) x = root[x] = root[root[x]]; return x; };
+                std::unordered_map<const void*, int> owner;
+                for (int i = 0; i < n; ++i) {
+                    const Op64& q = sorted[(size_t) i];
+                    const void* keys[4] = {q.dst, q.c1_tip ? nullptr : q.c1, q.c2_tip ? nullptr : q.c2, q.mode != 0 ? (const void*) q.scale : nullptr};
+                    for (const void* key : keys) {
+                        if (key == nullptr) continue;
+                        auto it = owner.find(key);
+                        if (it == owner.end()) owner.emplace(key, i);
+                        else { const int a = find(i), b = find(it->second); if (a != b) root[std::max(a, b)] = std::min(a, b); }
+                    }
+                }
+                std::vector<int> chainOf((size_t) n, -1);
+                std::vector<std::vector<int>> members;
+                for (int i = 0; i < n; ++i) {                 // (`sorted` is level-major: a chain's members come in dependency order)
+                    const int r = find(i);
+                    if (chainOf[r] < 0) { chainOf[r] = (int) members.size(); members.emplace_back(); }
+                    members[(size_t) chainOf[r]].push_back(i);
+                }
+                bool ok = true;
+                std::vector<Op64> chained;
+                std::vector<int> chainStart;
+                chained.reserve((size_t) n);
+                for (const auto& mem : members) {
+                    chainStart.push_back((int) chained.size());
+                    const double* last = nullptr;
+                    std::vector<const void*> written;
+                    for (size_t m = 0; m < mem.size() && ok; ++m) {
+                        Op64 q = sorted[(size_t) mem[m]];
+                        const bool one = !q.c1_tip && q.c1 == (const void*) last, two = !q.c2_tip && q.c2 == (const void*) last;
+                        if (m == 0) q.pad_ = 0;
+                        else if (one != two) q.pad_ = one ? 1 : 2;
+                        else ok = false;                     // not the previous result (or both children are): not a chain
+                        // (the other child must come from outside this launch, the scale buffer must not be one written earlier in it)
+                        const void* other = m == 0 ? nullptr : (one ? (q.c2_tip ? nullptr : q.c2) : (q.c1_tip ? nullptr : q.c1));
+                        for (const void* w : written) ok = ok && w != other && w != (const void*) q.dst && (q.mode != 2 || w != (const void*) q.scale);
+                        written.push_back(q.dst);
+                        if (q.mode == 1) written.push_back(q.scale);
+                        last = q.dst;
+                        chained.push_back(q);
+                    }
+                }
+                chainStart.push_back((int) chained.size());
+                if (ok) {
+                    void *dt = nullptr, *dc = nullptr;
+                    int rct = stage(chained.data(), chained.size() * sizeof(Op64), &dt);
+                    if (rct) return rct;
+                    rct = stage(chainStart.data(), chainStart.size() * sizeof(int), &dc);
+                    if (rct) return rct;
+                    const dim3 cgrid((unsigned) (Ppad / 64), (unsigned) members.size());
+                    const Op64* dto = static_cast<const Op64*>(dt);
+                    const int* dco = static_cast<const int*>(dc);
+#define MBAMD_F64_CHAIN_CASE(NT_, KF_) MBAMD_LAUNCH_BARRIER((k64_partials_chain<NT_, KF_>), cgrid, 256, ldsBytes, stream, dto, dco, S, SPAD, Ppad)
+                    switch (NTr * 8 + K) {
+                        case 2 * 8 + 1: MBAMD_F64_CHAIN_CASE(2, 1); break;
+                        case 2 * 8 + 2: MBAMD_F64_CHAIN_CASE(2, 2); break;
+                        case 2 * 8 + 3: MBAMD_F64_CHAIN_CASE(2, 3); break;
+                        case 2 * 8 + 4: MBAMD_F64_CHAIN_CASE(2, 4); break;
+                        case 3 * 8 + 1: MBAMD_F64_CHAIN_CASE(3, 1); break;
+                        case 4 * 8 + 1: MBAMD_F64_CHAIN_CASE(4, 1); break;
+                        default: ok = false; break;
+                    }
+#undef MBAMD_F64_CHAIN_CASE
+                    if (ok) {
+                        levelLaunches++;
+                        HIP_TRY(hipGetLastError());
+                        return BEAGLE_SUCCESS;
+                    }
+                }
+            }
+        }
+#endif
         void* dv = nullptr;
         int rc = stage(sorted.data(), sorted.size() * sizeof(Op64), &dv);
         if (rc) return rc;

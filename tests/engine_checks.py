@@ -842,7 +842,7 @@ def check_double_precision_walk(lib, golden_dir, case, monkeypatch):
         assert got[True][4] <= 2 and got[False][4] > 2 * got[True][4], (got[True][4], got[False][4])   # a launch per list against one per level
 
 
-F64_GENERAL_SWITCHES = ("MBAMD_F64_MFMA_NO_LDS", "MBAMD_F64_NO_TIPS_KERNEL", "MBAMD_F64_NO_MATRIX_QUEUE", "MBAMD_F64_NO_RING")
+F64_GENERAL_SWITCHES = ("MBAMD_F64_MFMA_NO_LDS", "MBAMD_F64_NO_TIPS_KERNEL", "MBAMD_F64_NO_CHAIN", "MBAMD_F64_NO_MATRIX_QUEUE", "MBAMD_F64_NO_RING")
 
 
 def check_double_precision_general_paths(lib, golden_dir, case, monkeypatch):

@@ -185,7 +185,7 @@ _AA = "ARNDCQEGHILKMFPSTWYV"
 _SENSE_CODONS = [a + b + c for a in "ACGT" for b in "ACGT" for c in "ACGT" if a + b + c not in ("TAA", "TAG", "TGA")]
 
 
-def model_nexus(kind, states, tree, ngen=1, beagle=None, fname="mk", fixed_topology=False):
+def model_nexus(kind, states, tree, ngen=1, beagle=None, fname="mk", fixed_topology=False, precision="single"):
     """Known-answer / short-run NEXUS text for the general-state models of the hot path: kind "wag" (protein,
     fixed WAG + gamma 4) or "m3" (codon, omegavar=M3).  states: int array [ntaxa][nsites], value >= nstates = gap."""
     names = ["t%d" % (i + 1) for i in range(states.shape[0])]
@@ -203,7 +203,7 @@ def model_nexus(kind, states, tree, ngen=1, beagle=None, fname="mk", fixed_topol
         s += "%s  %s\n" % (n, q)
     s += "  ;\nend;\nbegin mrbayes;\n  set autoclose=yes nowarnings=yes seed=12345 swapseed=12345 precision=15;\n  %s\n" % lset
     if beagle:
-        s += "  set usebeagle=yes beagledevice=gpu beagleprecision=single beaglescaling=%s;\n" % beagle
+        s += "  set usebeagle=yes beagledevice=gpu beagleprecision=%s beaglescaling=%s;\n" % (precision, beagle)
     s += "end;\nbegin trees;\n  tree t = [&U] %s\nend;\n" % tree.to_newick(names)
     s += "begin mrbayes;\n  %s;\n" % ("prset topologypr=fixed(t); startvals V=t" if fixed_topology else "startvals tau=t V=t")
     s += "  mcmc ngen=%d nchains=1 nruns=1 samplefreq=%d printfreq=%d diagnfreq=%d filename=%s;\nend;\n" % (
