@@ -848,7 +848,7 @@ F64_GENERAL_SWITCHES = ("MBAMD_F64_MFMA_NO_LDS", "MBAMD_F64_NO_TIPS_KERNEL", "MB
 def check_double_precision_general_paths(lib, golden_dir, case, monkeypatch):
     """16 ... 64 states in fp64: the kernels the engine picks by default -- operations on two tips from matrices parked in LDS, the
     contraction with its matrices in LDS (four or eight waves per workgroup), matrix updates of several calls as one launch, lists
-    staged through the ring -- give the bits of the plain one-wave level
+    staged through the ring, a root-ward path as one launch with the running result in registers -- give the bits of the plain one-wave level
     kernel with everything switched off: per site, for a full evaluation and a partial update, both scaling schemes."""
     div = division_from_golden(golden_dir, case)
     t = div.tree
@@ -872,18 +872,22 @@ def check_double_precision_general_paths(lib, golden_dir, case, monkeypatch):
                 t.length[deep] = old * 1.7
                 try:
                     bd.TouchBranch(0, deep)
+                    bd.inst.get_kernel_timing(reset=True)
                     moved = bd.LogLike(0)
+                    _, launches2 = bd.inst.get_kernel_timing(reset=True)
                     site2 = bd.inst.get_site_log_likelihoods().copy()
                 finally:
                     t.length[deep] = old
-                got[plain] = (lnl, site, moved, site2, launches)
+                got[plain] = (lnl, site, moved, site2, launches, launches2)
             finally:
                 bd.finalize()
         for name in F64_GENERAL_SWITCHES:
             monkeypatch.delenv(name, raising=False)
         assert got[True][0] == got[False][0] and got[True][2] == got[False][2], (case, scaling, got[True][0], got[False][0])
         assert np.array_equal(got[True][1], got[False][1]) and np.array_equal(got[True][3], got[False][3])
-        assert got[False][4] == got[True][4], (got[False][4], got[True][4])      # (a launch per dependency level either way)
+        assert got[False][4] == got[True][4], (got[False][4], got[True][4])      # (a whole tree: a launch per dependency level either way)
+        # the partial update is a root-ward path: ONE launch of the chain kernel per eigen part's list run together, a launch per level without it
+        assert got[False][5] == 1 and got[True][5] >= 2, (got[False][5], got[True][5])
 
 
 def check_double_precision_walk_categories(lib, monkeypatch, ntips=24, npat=200, seed=11):
