@@ -44,6 +44,14 @@ CONFIGS = {
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy)
 FP32_PEAK_TFLOPS = 157.3       # fp32 MFMA = fp32 vector peak
 REL_FP64 = 2e-6                # lnL vs the reference's fp64 build (tests/engine_checks.py)
+ROOFLINE_DEFINITION = (
+    "frac = max(HBM bytes moved / 8 TB/s, matrix-core flops issued / 157.3 TFLOP/s) / device time of ALL kernels of one "
+    "evaluation (transition matrices + partials + integration, HIP events on the engine's stream: all_kernels_ms_per_step). "
+    "Bytes and issued flops per evaluation are PMC counts (rocprofv3 --pmc, profiles/pmc_traffic.json: deterministic for a "
+    "workload, taken in their own profiling runs and combined with THIS run's time).  traffic_floor_bytes: the write-once model "
+    "(every interior result and its exponents stored once, children read from LDS, tips one byte per pattern); "
+    "algorithmic_bytes_per_step: SURVEY 8(d)'s model (every interior CL written once AND read once), about 1.9x what the "
+    "kernels move, kept as a count only")
 
 
 def algorithmic_bytes_per_eval(S, K, P, N):
@@ -55,18 +63,27 @@ def flops_per_eval(S, K, P, N):
     return P * (N - 2) * K * (2 * S * S * 2 + S)
 
 
-def cpu_baseline(kind, gold, sample_patterns):
+def cpu_baseline(kind, gold, sample_patterns, whole=False):
     """The reference CPU likelihood (oracle/_ref/mb, the real reference's FMA/SSE kernels, one core) on this box's
-    host cores, on a bounded sample of the SAME alignment and tree: its first `sample_patterns` columns."""
+    host cores, on a bounded sample of the SAME alignment and tree: its first `sample_patterns` columns (cache-resident on
+    the host: flattering for the CPU) -- or, whole=True, on the WHOLE alignment with a short two-point window (what "the
+    reference CPU likelihood on the same alignment" means; the reference's O(P^2) pattern compression runs twice beside it)."""
     from mrbayes_amd import data as mbdata
     from mrbayes_amd import tree as mbtree
     from tools import refrun
     sy = gold["synthetic"]
     ntaxa = sy["ntaxa"]
     tr = mbtree.parse_newick(gold["newick"])
+    if whole and not refrun.reference_available():
+        return None
     if refrun.reference_available():
-        st = mbdata.synthetic_states(ntaxa, sy["nsites"], sy["nstates"], sy["seed"], sy["p_mut"], sy["p_gap"])[:, :sample_patterns]
-        lo, hi = {"gtr": (10, 70), "wag": (4, 28), "m3": (2, 14)}[kind]
+        st = mbdata.synthetic_states(ntaxa, sy["nsites"], sy["nstates"], sy["seed"], sy["p_mut"], sy["p_gap"])
+        if whole:
+            sample_patterns = st.shape[1]
+            lo, hi = {"gtr": (2, 8), "wag": (2, 8), "m3": (1, 4)}[kind]
+        else:
+            st = st[:, :sample_patterns]
+            lo, hi = {"gtr": (10, 70), "wag": (4, 28), "m3": (2, 14)}[kind]
         r = refrun.time_reference(kind, st, tr, lo, hi)
         p = r.get("npatterns", sample_patterns)
         ups = (ntaxa - 2) * p / r["sec_per_eval"]
@@ -227,7 +244,7 @@ def mpi_mcmc(nranks, emulate=False, full=False):
             "unit": "generations/s (all chains advance one generation)"}
 
 
-def measure(args, cfg, steps, warmup, rank, local_rank, world, dist, device, emulate, lib, want_cpu_baseline):
+def measure(args, cfg, steps, warmup, rank, local_rank, world, dist, device, emulate, lib, want_cpu_baseline, verbose=True):
     """One workload: build the division from its golden case, check the lnL against the reference's, time `steps`
     full-tree evaluations.  Returns the JSON object (rank 0) or None."""
     import torch
@@ -337,13 +354,13 @@ def measure(args, cfg, steps, warmup, rank, local_rank, world, dist, device, emu
         roof = {"bound": "hbm", "achieved": traffic / t_all / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s"}
     roof["frac"] = roof["achieved"] / roof["peak"]
     roof["traffic"] = traffic if pmc else None
-    roof["definition"] = (
-        "frac = max(HBM bytes moved / 8 TB/s, matrix-core flops issued / 157.3 TFLOP/s) / device time of ALL kernels of one "
-        "evaluation (transition matrices + partials + integration, HIP events on the engine's stream: all_kernels_ms_per_step). "
-        "Bytes and issued flops per evaluation are PMC counts (rocprofv3 --pmc, profiles/pmc_traffic.json: deterministic for a "
-        "workload, taken in their own profiling runs and combined with THIS run's time).  algorithmic_*: SURVEY 8(d)'s model "
-        "(every interior CL written once AND read once) over the partials kernels' time -- the kernels keep children in LDS, so "
-        "that model over-counts HBM traffic about 1.9x; kept for comparison with earlier rounds only")
+    if verbose:
+        roof["definition"] = ROOFLINE_DEFINITION
+    # the least HBM traffic the path can have: every interior result and its exponents written once, children read from LDS,
+    # tips as one byte per pattern (the write-once model); traffic_over_floor = what the counters saw over that
+    floor = float(P) * ((N - 2) * (K * S * 4 + K) + N)
+    roof["traffic_floor_bytes"] = floor
+    roof["traffic_over_floor"] = (traffic / floor) if pmc else None
     if pmc:
         roof["traffic_source"] = pmc["source"]
     else:
@@ -360,10 +377,6 @@ def measure(args, cfg, steps, warmup, rank, local_rank, world, dist, device, emu
     roof["launches_per_step"] = klaunches / max(steps, 1)
     roof["algorithmic_bytes_per_step"] = abytes
     roof["flops_per_step"] = aflops
-    if k_ms > 0:
-        roof["algorithmic_GBs"] = abytes / (k_ms * 1e-3) / 1e9
-        roof["algorithmic_tflops"] = aflops / (k_ms * 1e-3) / 1e12
-        roof["algorithmic_frac"] = (roof["algorithmic_tflops"] / FP32_PEAK_TFLOPS) if S == 61 else (roof["algorithmic_GBs"] / HBM_PEAK_GBS)
     out = {
         "metric": "site-pattern lnL (node-pattern conditional-likelihood) updates/sec",
         "value": value, "unit": "M updates/s", "n_gpus": world, "steps": steps, "warmup": warmup,
@@ -388,10 +401,43 @@ def measure(args, cfg, steps, warmup, rank, local_rank, world, dist, device, emu
             gold["case"] = case
             out["cpu_baseline"] = cpu_baseline(kind, gold, sample)
             out["speedup_vs_cpu_baseline"] = value / out["cpu_baseline"]["value"]
+            if verbose and not args.no_whole_cpu_baseline:
+                # the headline workload also against the reference on the WHOLE alignment (not cache-resident on the host)
+                wb = cpu_baseline(kind, gold, sample, whole=True)
+                if wb:
+                    out["cpu_baseline_whole_alignment"] = wb
+                    out["speedup_vs_cpu_baseline_whole_alignment"] = value / wb["value"]
         except Exception as exc:          # the baseline is a report, never a reason to lose the bench line
             out["cpu_baseline"] = {"value": None, "unit": "M updates/s", "cores": 1, "kind": "port",
                                    "sample": "failed: %r" % (exc,)}
     return out
+
+
+def summary_of(out):
+    """The last object of the line, compact enough to survive a tail cut: per workload
+    [value (M updates/s), ms_per_step, all_kernels_ms_per_step, partials_kernel_ms_per_step, roofline.frac, bound]."""
+    def row(o):
+        r = o.get("roofline", {})
+        return [round(o["value"], 1), round(o["ms_per_step"], 4), round(r.get("all_kernels_ms_per_step") or 0.0, 4),
+                round(r.get("partials_kernel_ms_per_step") or 0.0, 4), round(r.get("frac") or 0.0, 4), r.get("bound")]
+    summ = {"columns": ["M_updates_per_s", "ms_per_step", "all_kernels_ms", "partials_kernel_ms", "roofline_frac", "bound"]}
+    for o in [out] + [a for a in out.get("also", []) if "config" in a]:
+        summ[o["config"]["golden_case"].replace("bench_", "")] = row(o)
+    for d in out.get("double_precision", []):
+        if "golden_case" in d:
+            summ[d["golden_case"].replace("bench_", "") + "_f64"] = [round(d["value"], 1), round(d["ms_per_step"], 4)]
+    if out.get("cpu_baseline", {}).get("value"):
+        summ["cpu_M_updates_per_s"] = {"prefix_sample": round(out["cpu_baseline"]["value"], 1)}
+        if out.get("cpu_baseline_whole_alignment", {}).get("value"):
+            summ["cpu_M_updates_per_s"]["whole_alignment"] = round(out["cpu_baseline_whole_alignment"]["value"], 1)
+    m = out.get("mcmc_gen_per_s") or {}
+    gen = {}
+    for mix in ("default_moves", "fixed_topology", "codon_m3_fixed_topology"):
+        if isinstance(m.get(mix), dict):
+            gen[mix] = {k: round(v, 1) for k, v in m[mix].items() if isinstance(v, float)}
+    if gen:
+        summ["mcmc_gen_per_s"] = gen
+    return summ
 
 
 def box_write_rate(device):
@@ -536,6 +582,8 @@ def main():
     ap.add_argument("--config", default="c4", choices=sorted(CONFIGS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample-patterns", type=int, default=8000)
+    ap.add_argument("--no-whole-cpu-baseline", action="store_true",
+                    help="skip the second CPU baseline of the headline workload: the reference on the whole alignment (about a minute at 1000 x 50000)")
     ap.add_argument("--no-also", action="store_true", help="skip the other three workloads (c2, c3, c5) at N=1")
     ap.add_argument("--no-mcmc", action="store_true", help="skip whole-MCMC generations/s of the unmodified MrBayes binary")
     ap.add_argument("--mcmc", action="store_true", help="longer MCMC windows (adds minutes)")
@@ -631,7 +679,7 @@ def main():
                     continue
                 try:
                     out["also"].append(measure(args, other, max(args.steps, 200), args.warmup, 0, local_rank, 1, None, device,
-                                               False, lib, not args.no_cpu_baseline))
+                                               False, lib, not args.no_cpu_baseline, verbose=False))
                     if fill:
                         out["also"][-1]["roofline"]["box_write_stream_GBs"] = fill
                         out["also"][-1]["roofline"]["hbm_frac_of_box_write_stream"] = out["also"][-1]["roofline"]["hbm_GBs"] / fill
@@ -656,6 +704,7 @@ def main():
         except Exception as exc:
             out["mpi_mcmc"] = {"error": repr(exc)[:600]}
     if rank == 0:
+        out["summary"] = summary_of(out)
         print(json.dumps(out))
     if dist is not None:
         dist.barrier()
