@@ -25,7 +25,7 @@ template <> struct WgVecT<1> {
     static __device__ __forceinline__ type splat(float x) { return x; }
 };
 
-template <int SC> struct WgShape {
+template <int SC, bool PAIR = false> struct WgShape {
     static constexpr int TW = MBAMD_WG_TW, KS = MBAMD_WG_KS;
     static constexpr int T = (SC + KS - 1) / KS, NT = (SC + TW - 1) / TW;
 #if MBAMD_WG_TW == 32
@@ -37,6 +37,11 @@ template <int SC> struct WgShape {
     static constexpr int ACC = 4;                    // 16 x 16 / 64 lanes
 #endif
     static constexpr int TP = (T + V - 1) / V * V, NAP = (TP * NT + VA - 1) / VA * VA;
+    // row split (k_walkg2, mbamd_walkg.h): a wave of the pair owns ONE output tile -- its rows of the tables and of the result
+    static constexpr bool SPLIT = PAIR && MBAMD_WG_TW == 32 && SC > 48;
+    static constexpr int NAW = SPLIT ? TP : NAP;      // table rows a wave fetches per interior child
+    static constexpr int TPO = SPLIT ? ACC : TP;      // block rows of the result this wave owns
+    static_assert(!SPLIT || (NT == 2 && TP == 2 * ACC && V == 4 && VA == 4), "row split: two output tiles of 16 block rows");
     typedef WgVecT<V> Vb;                            // block rows (B operand, results)
     typedef WgVecT<VA> Va;                           // table rows (A operand, tip gathers)
     typedef typename Vb::type vec;

@@ -113,34 +113,25 @@ static inline bool wg_compiled(int S) { return S == 2 || S == 8 || S == 16 || S 
         default: FN<63, 4, 2, MBAMD_WG_DEPTH61>(__VA_ARGS__); break;    \
     }
 
-// k_walkg_s (tables staged in LDS, shared by the G waves of a workgroup): the state counts it is instantiated for, table chunks
-// per job, and how many chunks the LDS-DMA stream runs ahead
-static inline bool wgs_compiled(int S) { return S == 20 || (S >= 60 && S <= 63); }
-static inline int wgs_chunks(int S) { return S > 40 ? 2 : 1; }
-#if !defined(MBAMD_WGS_D)
-#define MBAMD_WGS_D 2
-#endif
-#define MBAMD_WGS_DISPATCH_G(SC, CH, G, FN, ...)                        \
-    do {                                                                \
-        if ((G) == 4) FN<SC, 4, CH, MBAMD_WGS_D>(__VA_ARGS__);          \
-        else FN<SC, 2, CH, MBAMD_WGS_D>(__VA_ARGS__);                   \
-    } while (0)
-#define MBAMD_WGS_DISPATCH(S, G, FN, ...)                               \
+// k_walkg2 (a whole entry's operands in flight; the row-split pair): FN<SC, WMAX>
+#define MBAMD_WG2_DISPATCH(S, FN, ...)                                  \
     switch (S) {                                                        \
-        case 20: MBAMD_WGS_DISPATCH_G(20, 1, G, FN, __VA_ARGS__); break; \
-        case 60: MBAMD_WGS_DISPATCH_G(60, 2, G, FN, __VA_ARGS__); break; \
-        case 61: MBAMD_WGS_DISPATCH_G(61, 2, G, FN, __VA_ARGS__); break; \
-        case 62: MBAMD_WGS_DISPATCH_G(62, 2, G, FN, __VA_ARGS__); break; \
-        default: MBAMD_WGS_DISPATCH_G(63, 2, G, FN, __VA_ARGS__); break; \
+        case 2: FN<2, 8, false>(__VA_ARGS__); break;                    \
+        case 8: FN<8, 8, false>(__VA_ARGS__); break;                    \
+        case 16: FN<16, 8, false>(__VA_ARGS__); break;                  \
+        case 20: FN<20, 8, false>(__VA_ARGS__); break;                  \
+        case 60: FN<60, 4, true>(__VA_ARGS__); break;                   \
+        case 61: FN<61, 4, true>(__VA_ARGS__); break;                   \
+        case 62: FN<62, 4, true>(__VA_ARGS__); break;                   \
+        default: FN<63, 4, true>(__VA_ARGS__); break;                   \
     }
-template <int SC_, int G_, int CH_, int D_>
-static void raise_walkgs_lds(int maxLds)
+template <int SC_, int WMAX_, bool PAIR_>
+static void raise_walkg2_lds(int maxLds)
 {
-    if (hipFuncSetAttribute((const void*) k_walkg_s<SC_, G_, CH_, D_>, hipFuncAttributeMaxDynamicSharedMemorySize, maxLds) != hipSuccess ||
-        hipFuncSetAttribute((const void*) k_walkg_s<SC_, G_, CH_, D_, WalkGSArgsInline>, hipFuncAttributeMaxDynamicSharedMemorySize, maxLds) != hipSuccess)
+    if (hipFuncSetAttribute((const void*) k_walkg2<SC_, WMAX_, PAIR_>, hipFuncAttributeMaxDynamicSharedMemorySize, maxLds) != hipSuccess ||
+        hipFuncSetAttribute((const void*) k_walkg2<SC_, WMAX_, PAIR_, WalkGArgsInline>, hipFuncAttributeMaxDynamicSharedMemorySize, maxLds) != hipSuccess)
         (void) hipGetLastError();
 }
-
 template <int SC_, int WMAX_, int CH_, int DEPTH_>
 static void raise_walkg_lds(int maxLds)
 {
@@ -163,9 +154,6 @@ struct Plan {
     size_t cap = 0;                  // bytes allocated for d_table
     struct Segment {                             // tree-walk path: one launch per hazard-free segment
         size_t first; int W, entries, nslots, tail = 2, tipAhead = 0;
-        // k_walkg_s: the phases of the segment are launches, the W programs the subtree bins of a launch's grid
-        int phases = 1;
-        std::vector<unsigned> ranges;            // [phase][W]: first entry << 16 | entries of that part of program w (0: nothing)
     };
     std::vector<Segment> segments;               // (Walk4Entry index of its program in d_table, geometry)
     std::vector<Walk4Entry> inlineProg;          // 4-state walk: a short single-segment program travels in the kernel arguments instead
@@ -253,10 +241,8 @@ struct Instance {
     unsigned long wgTileBytes = 0;               // partials arena: bytes between 32-pattern tiles
     unsigned wgTipTileBytes = 0;
     size_t wgTabFloats = 0;                      // first float of the tree-walk tables inside a matrix buffer
-    bool wgs = false;                            // the tables are staged in LDS and shared by the waves of a workgroup (k_walkg_s)
-    int wgsG = 4;                                // waves (adjacent tiles) per workgroup
-    void wgsGeometry(int lists, int& W, int& slots) const;
-    int runWalkGS(const Plan& plan);
+    bool wg2 = false;                            // MBAMD_WALKG_PAIR=1: k_walkg2 (a whole entry's operands in flight) where it is instantiated ...
+    bool wgPair = false;                         // ... and beyond 48 states the row split: a subtree bin is a pair of waves, split table layout
     bool hasPending() const { return !pending.empty() || !wgListCum.empty(); }
     int updatePartialsG(const BeagleOperation* ops, int n, int cumIdx);
     int flushWalkG();
@@ -568,17 +554,9 @@ int Instance::create(int tipCount_, int partialsBufferCount, int compactBufferCo
              (size_t) (nBuffers + 1) * K * tb < ((size_t) 1 << 32) && (size_t) nMatrices * mf * 4 < ((size_t) 1 << 32) &&
              (size_t) (nScale + 1) * K * 64 < ((size_t) 1 << 32) && (size_t) nBuffers * MBAMD_WG_TW < ((size_t) 1 << 32);
     }
-    // k_walkg_s: G waves on G adjacent tiles share a workgroup (and the transition tables in its LDS); the pattern count is
-    // padded to whole groups of four tiles (pad patterns: weight 0, missing data -- like every pad pattern)
-    // MEASURED (round 4, profiles/r04_walkgs_*.txt): parity-green and SLOWER than k_walkg -- codon 100 x 5 000: 0.225 against 0.195 ms,
-    // protein 200 x 10 000: 0.222 against 0.222 -- the lockstep costs more (a barrier, a DMA issue phase and a tip gather per chunk)
-    // than the 4x smaller L2 stream buys.  Opt-in (MBAMD_WALKG_SHARED=1); the product runs k_walkg.
-    wgs = wg && wgs_compiled(S) && std::getenv("MBAMD_WALKG_SHARED") && std::atoi(std::getenv("MBAMD_WALKG_SHARED")) != 0;
-    if (wgs) {
-        wgsG = S > 32 ? 4 : 2;
-        if (const char* e = std::getenv("MBAMD_WALKG_G")) wgsG = std::atoi(e) >= 4 ? 4 : 2;
-        Ppad = round_up(P, MBAMD_WG_TW * 4);
-    }
+    // k_walkg2 / the row split (round 5): parity-green and no faster than k_walkg (profiles/r05_walkg_pair.txt); opt-in
+    wg2 = wg && wg2_states(S) && std::getenv("MBAMD_WALKG_PAIR") && std::atoi(std::getenv("MBAMD_WALKG_PAIR")) != 0;
+    wgPair = wg2 && wg_split_states(S);
     if (s4) SP = 4;
     else if (S <= 4) SP = 4;
     else if (S <= 8) SP = 8;
@@ -676,7 +654,7 @@ int Instance::create(int tipCount_, int partialsBufferCount, int compactBufferCo
     HIP_TRY(hipMemsetAsync(matrices, 0, std::max<size_t>(1, (size_t) nMatrices * matrixFloats) * sizeof(float), stream));
     if (wg && nMatrices > 0) {                   // the constant "missing data" column of every gather table
         const int total = nMatrices * K * S;
-        MBAMD_LAUNCH(k_wg_init_tables, (unsigned) ((total + 255) / 256), 256, 0, stream, matrices, matrixFloats, wgTabFloats, S, K, total);
+        MBAMD_LAUNCH(k_wg_init_tables, (unsigned) ((total + 255) / 256), 256, 0, stream, matrices, matrixFloats, wgTabFloats, S, K, total, wgPair ? 1 : 0);
         HIP_TRY(hipGetLastError());
     }
     HIP_TRY(hipMalloc(&d_eigen, std::max<size_t>(1, (size_t) nEigen * eigenDoubles) * sizeof(double)));
@@ -766,29 +744,18 @@ int Instance::configureWalk()
     if (wg) {
         // one wave = (32-pattern tile, category); registers bound the residency: 20 states 4 waves per SIMD, 61 states 2
         const unsigned slotBytes = wg_block_bytes(S);
-        MBAMD_WG_DISPATCH(S, raise_walkg_lds, maxLds);
-        if (wgs) {
-            MBAMD_WGS_DISPATCH(S, wgsG, raise_walkgs_lds, maxLds);
-            wgsGeometry(1, w4.maxW, w4.maxSlots);
-            w4.maxSlots1 = w4.maxSlots;
-            w4.memSlots = false;
-            w4.phasesAreLaunches = true;         // bins are workgroups, phases launches: nothing stays in LDS across a phase
-            w4.leadNops = 0; w4.unroll = 1; w4.tailNops = MBAMD_WG_TAIL;
-            w4.prefetchDistance = 0;
-            if (const char* e = std::getenv("MBAMD_WALK_SMALL_PHASE")) w4.smallPhase = std::max(1, std::atoi(e));
-            if (envVerbose) std::fprintf(stderr, "[mbamd] tree walk (%d states, tables in LDS): %d waves per workgroup, up to %d bins x %d slots of %u bytes\n",
-                                         S, wgsG, w4.maxW, w4.maxSlots, slotBytes);
-            return BEAGLE_SUCCESS;
-        }
+        if (wg2) { MBAMD_WG2_DISPATCH(S, raise_walkg2_lds, maxLds); }
+        else { MBAMD_WG_DISPATCH(S, raise_walkg_lds, maxLds); }
         wgGeometry(1, w4.maxW, w4.maxSlots);
         w4.maxSlots1 = w4.maxSlots;
         if (!std::getenv("MBAMD_WALK_WAVES") && !std::getenv("MBAMD_MAX_LDS_SLOTS")) {   // a single-wave program may use the LDS of the whole workgroup
             const long wgsG = (long) (Ppad / MBAMD_WG_TW) * K;
             const int perCUG = (int) std::max(1L, (wgsG + numCU - 1) / numCU);
-            w4.maxSlots1 = std::max(w4.maxSlots, std::min(24, (int) (((160 * 1024) / std::min(perCUG, 32) - 64 - MBAMD_WG_STAGE) / (int) slotBytes)));
+            w4.maxSlots1 = std::max(w4.maxSlots, std::min(24, (int) (((160 * 1024) / std::min(perCUG, 32) - 64 - (int) wg_stage_bytes(wgPair)) / (int) slotBytes)));
         }
         w4.memSlots = false;
         w4.leadNops = MBAMD_WG_LEAD; w4.unroll = 3; w4.tailNops = MBAMD_WG_TAIL;
+        if (wg2) { w4.leadNops = 0; w4.unroll = 2; w4.tailNops = MBAMD_WG2_TAIL; }      // k_walkg2: the loop handles two entries, the prologue fetches entries 0 and 1
         w4.prefetchDistance = 0;
         if (const char* e = std::getenv("MBAMD_WALK_SMALL_PHASE")) w4.smallPhase = std::max(1, std::atoi(e));
         if (envVerbose) std::fprintf(stderr, "[mbamd] tree walk (%d states): %ld workgroups, up to %d waves x %d slots of %u bytes\n",
@@ -830,7 +797,9 @@ void Instance::wgGeometry(int lists, int& W, int& slots) const
     if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0) numCU = prop.multiProcessorCount;
     // registers bound the residency: 32-pattern tiles 4 (20 states) / 2 (61 states) waves per SIMD, 16-pattern tiles 5 / 3
 #if MBAMD_WG_TW == 32
-    const int maxW = S > 32 ? 4 : 8, wavesPerCU = S > 32 ? 6 : 12;
+    // (row split: a bin is a pair of waves sharing its slots; two bins = the four waves of a workgroup, one per SIMD, and two
+    //  such workgroups per CU put two working waves on every SIMD)
+    const int maxW = wgPair ? 2 : (S > 32 ? 4 : 8), wavesPerCU = wgPair ? 4 : (S > 32 ? 6 : 12);
 #else
     const int maxW = S > 32 ? 4 : 8, wavesPerCU = S > 32 ? 12 : 20;
 #endif
@@ -838,41 +807,14 @@ void Instance::wgGeometry(int lists, int& W, int& slots) const
     const long wgs = (long) (Ppad / MBAMD_WG_TW) * K * lists;
     const int perCU = (int) std::max(1L, (wgs + numCU - 1) / numCU);
     const int ldsPerWG = (160 * 1024) / std::min(perCU, 32) - 64;
-    auto slotsFor = [&](int w) { return (ldsPerWG / w - MBAMD_WG_STAGE) / slotBytes; };
+    auto slotsFor = [&](int w) { return (ldsPerWG / w - (int) wg_stage_bytes(wgPair)) / slotBytes; };
     long want = std::max(1L, std::min((long) maxW, ((long) wavesPerCU * numCU + wgs / 2) / wgs));
     W = 1;
     while (W * 2 <= want) W *= 2;
     while (W > 1 && slotsFor(W) < 4) W /= 2;
     if (const char* e = std::getenv("MBAMD_WALK_WAVES")) W = std::max(1, std::min(maxW, std::atoi(e)));
     slots = std::max(3, std::min(24, slotsFor(W)));
-    if (const char* e = std::getenv("MBAMD_MAX_LDS_SLOTS")) slots = std::max(3, std::min((160 * 1024 / W - MBAMD_WG_STAGE) / slotBytes, std::atoi(e)));
-}
-
-// k_walkg_s: subtree bins (workgroups of a launch's grid per tile group, category and list) and LDS slots per wave.  A workgroup
-// holds the ring of table chunks and G waves' landing areas and slots; as many workgroups per CU as the grid needs must fit.
-void Instance::wgsGeometry(int lists, int& W, int& slots) const
-{
-    int numCU = 256;
-    hipDeviceProp_t prop;
-    if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0) numCU = prop.multiProcessorCount;
-    // The waves of a workgroup march in lockstep (a barrier per table chunk): what overlaps one workgroup's epilogues, tip chunks
-    // and waits with MFMA work is ANOTHER workgroup on the same CU -- at least two per CU, eight waves.  Registers allow two waves
-    // per SIMD beyond 32 states; the LDS must hold the workgroups' rings and slots, so large blocks get few slots (one: the
-    // latest result; older values come back from HBM through the operand pipeline, 8 KB per use).
-    const int G = wgsG, wavesPerCU = S > 32 ? 8 : 12;
-    const long slotBytes = (long) wg_block_bytes(S);
-    const long fixed = (long) (MBAMD_WGS_D + 1) * (long) wgs_chunk_bytes(S, wgs_chunks(S)) + (long) G * MBAMD_WGS_STAGE;
-    const long groups = (long) (Ppad / MBAMD_WG_TW / G) * K * lists;           // workgroups per bin
-    const long minPerCU = std::max(1, 8 / G);
-    auto slotsFor = [&](int w) {
-        const long perCU = std::max(minPerCU, (groups * w + numCU - 1) / numCU);
-        return (int) (((160L * 1024) / std::min(perCU, 32L / G) - 64 - fixed) / ((long) G * slotBytes));
-    };
-    W = (int) std::max(1L, std::min((long) MBAMD_WGS_MAXBINS, ((long) wavesPerCU * numCU + groups * G / 2) / (groups * G)));
-    while (W > 1 && slotsFor(W) < 1) --W;
-    if (const char* e = std::getenv("MBAMD_WALK_WAVES")) W = std::max(1, std::min(MBAMD_WGS_MAXBINS, std::atoi(e)));
-    slots = std::max(1, std::min(24, slotsFor(W)));
-    if (const char* e = std::getenv("MBAMD_MAX_LDS_SLOTS")) slots = std::max(1, std::min((int) ((160L * 1024 - 64 - fixed) / ((long) G * slotBytes)), std::atoi(e)));
+    if (const char* e = std::getenv("MBAMD_MAX_LDS_SLOTS")) slots = std::max(3, std::min((160 * 1024 / W - (int) wg_stage_bytes(wgPair)) / slotBytes, std::atoi(e)));
 }
 
 // 4-state path: one tip's state masks (bit i = state i compatible) -> four 64-bit bitplanes per pattern block
@@ -1117,7 +1059,7 @@ int Instance::flushMatrices()
     if (S > 8 && S <= 64) {                       // fp64 matrix cores, one wave per 16 rows
         const unsigned grid = (unsigned) (count * K);
         const int packedT = mfma ? T : 0;
-        const size_t wgTab = wg ? wgTabFloats : 0;
+        const size_t wgTab = wg ? (wgTabFloats | (wgPair ? MBAMD_WG_TAB_SPLIT : (size_t) 0)) : 0;
         switch ((S + 15) / 16) {
             case 1: MBAMD_LAUNCH(k_transition_matrices_mfma<1>, grid, 64, 0, stream, djobs, rates, S, SP, K, packedT, wgTab); break;
             case 2: MBAMD_LAUNCH(k_transition_matrices_mfma<2>, grid, 128, 0, stream, djobs, rates, S, SP, K, packedT, wgTab); break;
@@ -1134,7 +1076,7 @@ int Instance::flushMatrices()
     MBAMD_LAUNCH(k_eigen_exponentials, (unsigned) ((nev + 255) / 256), 256, 0, stream, djobs, rates, S, K, (int) nev, d_ev);
     const int threads = std::min(256, round_up(S * S, 64));
     MBAMD_LAUNCH(k_transition_matrices_ev, (unsigned) (count * K), threads, 0, stream, djobs, (const double*) d_ev, S, SP, K, 1,
-                 mfma ? T : 0, wg ? wgTabFloats : (size_t) 0);
+                 mfma ? T : 0, wg ? (wgTabFloats | (wgPair ? MBAMD_WG_TAB_SPLIT : (size_t) 0)) : (size_t) 0);
     HIP_TRY(hipGetLastError());
     return BEAGLE_SUCCESS;
 }
@@ -1150,11 +1092,11 @@ int Instance::setMatrix(int idx, const double* in)
                 h[(size_t) k * SP * SP + (size_t) j * SP + i] = v;
                 if (mfma)
                     h[(size_t) K * SP * SP + ((size_t) (k * NT + i / 32) * T + j / 2) * 64 + (i % 32) + 32 * (j % 2)] = v;
-                if (wg) wg_table_put(h.data() + wgTabFloats + (size_t) k * wg_table_floats(S), S, i, j, v);
+                if (wg) wg_table_put(h.data() + wgTabFloats + (size_t) k * wg_table_floats(S), S, i, j, v, wgPair);
             }
     if (wg)
         for (int k = 0; k < K; ++k)
-            for (int i = 0; i < S; ++i) wg_table_put_missing(h.data() + wgTabFloats + (size_t) k * wg_table_floats(S), S, i);
+            for (int i = 0; i < S; ++i) wg_table_put_missing(h.data() + wgTabFloats + (size_t) k * wg_table_floats(S), S, i, wgPair);
     return upload(matrixPtr(idx), h.data(), matrixFloats * sizeof(float));
 }
 
@@ -1670,22 +1612,6 @@ int Instance::buildWalk(Plan& plan, const BeagleOperation* ops, int n, const int
         Plan::Segment sg;
         sg.first = w4table.size();
         sg.W = t.W; sg.entries = t.entries; sg.nslots = t.nslots; sg.tail = t.tail; sg.tipAhead = t.tipAhead;
-        if (wgs) {
-            // k_walkg_s: program w's part of phase p = the entries between its p-th and (p+1)-th barrier entry (trailing NOPs dropped)
-            if (t.W > MBAMD_WGS_MAXBINS || t.entries > 0xFFFF) return fail(BEAGLE_ERROR_GENERAL, "tree-walk scheduler: program too long for the shared-table kernel");
-            sg.phases = t.phases;
-            sg.ranges.assign((size_t) t.phases * t.W, 0u);
-            for (int w = 0; w < t.W; ++w) {
-                int ph = 0, first = 0;
-                auto close = [&](int end) {
-                    while (end > first && (t.prog[(size_t) w * t.entries + end - 1].flags & MBAMD_W4_NOP)) --end;
-                    if (ph < t.phases && end > first) sg.ranges[(size_t) ph * t.W + w] = ((unsigned) first << 16) | (unsigned) (end - first);
-                };
-                for (int j = 0; j < t.entries; ++j)
-                    if (t.prog[(size_t) w * t.entries + j].flags & MBAMD_W4_BARRIER) { close(j); ++ph; first = j + 1; }
-                close(t.entries);
-            }
-        }
         plan.segments.push_back(sg);
         w4table.resize(sg.first + t.prog.size());
         // bytes per buffer inside a block / tile, bytes per LDS slot
@@ -1693,10 +1619,12 @@ int Instance::buildWalk(Plan& plan, const BeagleOperation* ops, int n, const int
         // a partials buffer inside a tile (20/61-state walk: bytes) / in the buffer-major 4-state arena (KiB: P_pad/64 x K of them)
         const uint32_t pbuf = wg ? (uint32_t) K * slotb : (uint32_t) ((size_t) (Ppad / 64) * K);
         const uint32_t ebuf = (uint32_t) K * 64u, mbuf = wg ? (uint32_t) (matrixFloats * 4) : (uint32_t) K * 64u;
+        int prevKept = -1;                           // (20/61-state walk) slot the previous operation of the same program kept its result in
         for (size_t i = 0; i < t.prog.size(); ++i) {
             const Walk4Template::Entry& te = t.prog[i];
             Walk4Entry& e = w4table[sg.first + i];
             std::memset(&e, 0, sizeof e);
+            if (i % (size_t) t.entries == 0) prevKept = -1;
             uint32_t flags = te.flags, mode = SCALE_NONE, keep = 0;
             e.ewrite = (uint32_t) scratchScale * ebuf;
             e.eread = (uint32_t) scratchScale * ebuf;
@@ -1716,6 +1644,10 @@ int Instance::buildWalk(Plan& plan, const BeagleOperation* ops, int n, const int
                     e.m1 = (uint32_t) op.m1 * mbuf;
                     e.m2 = (uint32_t) op.m2 * mbuf;
                     if (te.dslot != 0xFF) { keep = te.dslot; flags |= MBAMD_W4_KEEP; }
+                    if (te.reread) flags |= MBAMD_WG_DRAIN;
+                    if (!op.tip1 && te.c1slot != 0xFF && (int) te.c1slot == prevKept) flags |= MBAMD_WG_PREV1;
+                    if (!op.tip2 && te.c2slot != 0xFF && (int) te.c2slot == prevKept) flags |= MBAMD_WG_PREV2;
+                    prevKept = te.dslot != 0xFF ? (int) te.dslot : -1;
                     mode = op.scaleWrite >= 0 ? SCALE_WRITE : (op.scaleRead >= 0 ? SCALE_READ : SCALE_NONE);
                     if (op.scaleWrite >= 0) e.ewrite = (uint32_t) op.scaleWrite * ebuf;
                     if (op.scaleRead >= 0) e.eread = (uint32_t) op.scaleRead * ebuf;
@@ -2054,8 +1986,7 @@ int Instance::flushWalkG()
             bool done = false;
             if (independent) {
                 const int keepW = w4.maxW, keepS = w4.maxSlots, keepS1 = w4.maxSlots1;
-                if (wgs) wgsGeometry(nl, w4.maxW, w4.maxSlots);
-                else wgGeometry(nl, w4.maxW, w4.maxSlots);
+                wgGeometry(nl, w4.maxW, w4.maxSlots);
                 w4.maxSlots1 = w4.maxSlots;
                 rc = buildWalk(*plan, ops.data(), n, listOf.data(), true);
                 w4.maxW = keepW; w4.maxSlots = keepS; w4.maxSlots1 = keepS1;
@@ -2100,82 +2031,25 @@ static void launch_walkg_t(Instance& in, const WalkGArgs& a, int W, int nslots, 
     MBAMD_LAUNCH_BARRIER(kern, walkg_grid(in.Ppad / MBAMD_WG_TW, in.K * a.lists), 64 * W * (a.spread ? 2 : 1), wg_lds_bytes(W, nslots, in.S), in.stream, a);
 }
 
-template <int SC_, int G_, int CH_, int D_>
-static void launch_walkgs_t(Instance& in, const WalkGSArgs& a, int nslots, const std::vector<Walk4Entry>* inlineProg)
+template <int SC_, int WMAX_, bool PAIR_>
+static void launch_walkg2_t(Instance& in, const WalkGArgs& a, int W, int nslots, const std::vector<Walk4Entry>* inlineProg)
 {
-    const unsigned grid = walkgs_grid(in.Ppad / MBAMD_WG_TW / G_, in.K * a.a.lists * a.bins);
-    const size_t lds = wgs_lds_bytes(G_, nslots, in.S, CH_, D_ + 1);
+    const unsigned block = 64u * (unsigned) W * (unsigned) wg_waves_per_bin(in.wgPair) * (a.spread ? 2u : 1u);
     if (inlineProg && !inlineProg->empty()) {
-        WalkGSArgsInline ai;
-        ai.s = a;
-        ai.s.a.prog = nullptr;
+        WalkGArgsInline ai;
+        ai.a = a;
+        ai.a.prog = nullptr;
         std::memcpy(ai.inl, inlineProg->data(), inlineProg->size() * sizeof(Walk4Entry));
-        auto kern = k_walkg_s<SC_, G_, CH_, D_, WalkGSArgsInline>;
-        MBAMD_LAUNCH(kern, grid, 64 * G_, lds, in.stream, ai);
+        auto kern = k_walkg2<SC_, WMAX_, PAIR_, WalkGArgsInline>;
+        MBAMD_LAUNCH_BARRIER(kern, walkg_grid(in.Ppad / MBAMD_WG_TW, in.K * a.lists), block, wg_lds_bytes(W, nslots, in.S, in.wgPair), in.stream, ai);
         return;
     }
-    auto kern = k_walkg_s<SC_, G_, CH_, D_>;
-    MBAMD_LAUNCH(kern, grid, 64 * G_, lds, in.stream, a);
-}
-
-// k_walkg_s: one launch per phase; the grid holds every (tile group, category, list, subtree bin)
-int Instance::runWalkGS(const Plan& plan)
-{
-    const size_t nseg = plan.segments.size();
-    for (size_t si = 0; si < nseg; si += (plan.lists > 1 ? nseg : 1)) {          // (independent lists: the segments are the lists of ONE launch series)
-        const Plan::Segment& sg = plan.segments[si];
-        int phases = sg.phases;
-        if (plan.lists > 1) for (const Plan::Segment& o : plan.segments) phases = std::max(phases, o.phases);
-        const bool shared = sg.W > 1 || phases > 1;           // several workgroups / launches add to the same cumulative entries
-        int fresh = (si == 0) ? wgFresh : 0;
-        if (shared && fresh) {
-            for (int q = 0; q < MBAMD_WG_MAXLISTS; ++q)
-                if ((fresh >> q & 1) && wgCum[q]) HIP_TRY(hipMemsetAsync(wgCum[q], 0, (size_t) K * Ppad * sizeof(int32_t), stream));
-            fresh = 0;
-        }
-        for (int ph = 0; ph < phases; ++ph) {
-            WalkGSArgs s;
-            std::memset(&s, 0, sizeof s);
-            WalkGArgs& a = s.a;
-            a.prog = reinterpret_cast<const Walk4Entry*>(plan.d_table) + sg.first;
-            a.entries = sg.entries;
-            a.nslots = sg.nslots;
-            a.partials = arenaPartials;
-            a.tileBytes = wgTileBytes;
-            a.tips = arenaTipStates;
-            a.tipTileBytes = wgTipTileBytes;
-            a.exps = arenaExp;
-            a.estride = estride;
-            a.matrices = matrices;
-            a.tabOff = (unsigned) (wgTabFloats * 4);
-            a.tabBytes = (unsigned) (wg_table_floats(S) * 4);
-            for (int q = 0; q < MBAMD_WG_MAXLISTS; ++q) a.cum[q] = wgCum[q];
-            a.cumFresh = fresh;
-            a.K = K; a.Ppad = Ppad; a.ntiles = Ppad / MBAMD_WG_TW; a.S = S; a.SP = SP;
-            a.lists = plan.lists;
-            s.bins = sg.W;
-            s.progW = sg.W;
-            s.atomicCum = shared ? 1 : 0;
-            bool any = false;
-            for (int q = 0; q < plan.lists; ++q) {
-                const Plan::Segment& lq = plan.lists > 1 ? plan.segments[(size_t) q] : sg;
-                if (ph >= lq.phases) continue;
-                for (int w = 0; w < lq.W; ++w) { s.range[q][w] = lq.ranges[(size_t) ph * lq.W + w]; any |= s.range[q][w] != 0; }
-            }
-            if (!any) continue;
-            if (ph > 0) fresh = 0;
-            MBAMD_WGS_DISPATCH(S, wgsG, launch_walkgs_t, *this, s, sg.nslots, &plan.inlineProg);
-            HIP_TRY(hipGetLastError());
-            pendingLaunches += 1;
-            fresh = 0;
-        }
-    }
-    return BEAGLE_SUCCESS;
+    auto kern = k_walkg2<SC_, WMAX_, PAIR_>;
+    MBAMD_LAUNCH_BARRIER(kern, walkg_grid(in.Ppad / MBAMD_WG_TW, in.K * a.lists), block, wg_lds_bytes(W, nslots, in.S, in.wgPair), in.stream, a);
 }
 
 int Instance::runWalkG(const Plan& plan)
 {
-    if (wgs) return runWalkGS(plan);
     for (const Plan::Segment& sg : plan.segments) {
         if (plan.lists > 1 && &sg != &plan.segments.front()) break;     // (independent lists: one launch covers all segments)
         WalkGArgs a;
@@ -2197,9 +2071,11 @@ int Instance::runWalkG(const Plan& plan)
         a.K = K; a.Ppad = Ppad; a.ntiles = Ppad / MBAMD_WG_TW; a.S = S; a.SP = SP;
         a.lists = plan.lists;
 #if MBAMD_DEV_SPREAD
-        a.spread = sg.W == 2 ? 1 : 0;
+        a.spread = sg.W * wg_waves_per_bin(wgPair) == 2 ? 1 : 0;
 #endif
-        MBAMD_WG_DISPATCH(S, launch_walkg_t, *this, a, sg.W, sg.nslots, &plan.inlineProg);
+        a.pair = wgPair ? 1 : 0;
+        if (wg2) { MBAMD_WG2_DISPATCH(S, launch_walkg2_t, *this, a, sg.W, sg.nslots, &plan.inlineProg); }
+        else { MBAMD_WG_DISPATCH(S, launch_walkg_t, *this, a, sg.W, sg.nslots, &plan.inlineProg); }
         HIP_TRY(hipGetLastError());
         pendingLaunches += 1;
     }

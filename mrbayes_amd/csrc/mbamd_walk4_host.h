@@ -45,6 +45,7 @@ struct Walk4Template {
         uint8_t flags = 0;                         // NOP / BARRIER
         uint8_t c1slot = 0xFF, c2slot = 0xFF, dslot = 0xFF;   // child in an LDS slot (not a tip) / result kept in a slot
         uint8_t vmwait = 0xFF;                     // 0xFF: no wait
+        bool reread = false;                       // (memSlots = false) the result leaves this wave's slots and comes back from HBM later in the same phase
         int pfOp[2] = {-1, -1};                    // PF entry: prefetch child pfChild of operation pfOp ...
         uint8_t pfChild[2] = {0, 0}, pfSlot[2] = {0, 0};      // ... into this slot
     };
@@ -391,6 +392,7 @@ inline bool Walk4Builder::build(const std::vector<Walk4Op>& ops, Walk4Template& 
             slotOfVal[v] = -1;
             slotHolder[best] = -1;
             t.evictions++;
+            prog[posOf[v]].reread = true;
             // its remaining consumers read it from memory: no earlier than now, no earlier than its store was issued
             int uLo = std::max(j, posOf[v] + 1), uHi = L;
             if (!dag) { const int p = parent[v]; if (p >= 0 && waveOf[p] == w && posOf[p] >= uLo) { uLo = posOf[p]; uHi = uLo + 1; } else uHi = uLo; }
@@ -509,6 +511,7 @@ inline bool Walk4Builder::build(const std::vector<Walk4Op>& ops, Walk4Template& 
                         slotOfVal[v] = -1;
                         slotHolder[best] = -1;
                         t.evictions++;
+                        prog[posOf[v]].reread = true;
                         int uLo = j + 1, uHi = L;
                         if (!dag) { const int p = parent[v]; if (p >= 0 && waveOf[p] == w && posOf[p] >= uLo) { uLo = posOf[p]; uHi = uLo + 1; } else uHi = uLo; }
                         for (int u = uLo; u < uHi; ++u) {
@@ -527,6 +530,7 @@ inline bool Walk4Builder::build(const std::vector<Walk4Op>& ops, Walk4Template& 
                     slotsUsed = std::max(slotsUsed, sl + 1);
                 } else {
                     t.evictions++;
+                    e.reread = true;
                     int uLo = j + 1, uHi = L;
                     if (!dag) { const int p = parent[o]; if (p >= 0 && waveOf[p] == w && posOf[p] >= uLo) { uLo = posOf[p]; uHi = uLo + 1; } else uHi = uLo; }
                     for (int u = uLo; u < uHi; ++u) {           // not kept: its consumers prefetch it (after this entry's store)

@@ -41,7 +41,12 @@ namespace mbamd {
 #define MBAMD_WG_MAXLISTS 4
 #define MBAMD_WG_LEAD     2      // leading NOP entries (they fill the operand pipeline)
 #define MBAMD_WG_TAIL     3      // trailing NOP entries (descriptor read-ahead)
+#define MBAMD_WG2_TAIL    4      // ... of k_walkg2's programs
 #define MBAMD_WG_STAGE    256    // bytes per wave in front of its slots (cumulative-exponent hand-over)
+#define MBAMD_WG_STAGE_SPLIT 1024   // row split, per bin: [0, 256) the same hand-over, [256, 768) column maxima float [entry parity][half][32], [768, 776) the pair's progress counters
+#define MBAMD_WG_PREV1    0x2000u   // (row split) child 1 / 2 is the result of the operation this bin executed last: wait for the partner's rows
+#define MBAMD_WG_PREV2    0x4000u
+#define MBAMD_WG_DRAIN    0x1000u   // (row split) the result is re-read from HBM by this bin in this phase: stores complete before the pair moves on
 
 // Tile width: patterns per wave.  32 = v_mfma_f32_32x32x2_f32 (two states per MFMA step, lane = 32 h + pattern), 16 =
 // v_mfma_f32_16x16x4_f32 (four states per step, lane = 16 g + pattern): twice the waves for the same alignment, each with half
@@ -55,6 +60,18 @@ namespace mbamd {
 #define MBAMD_WG_TW 32
 #endif
 #define MBAMD_WG_KS (64 / MBAMD_WG_TW)    // states per row of a block = per MFMA step (2 or 4)
+// Row split (round 5, k_walkg2; an instance created with MBAMD_WALKG_PAIR=1): beyond 48 states (the sense codons: two 32-row
+// output tiles) a (tile, category, subtree bin) is a PAIR of waves -- wave h of the pair owns output tile h: half of A', half of
+// the MFMA chain, half of the accumulators, half of the epilogue and of the stores; the child's rows (the B operand) come from
+// the LDS slots the pair shares.  Twice the working waves for the same operand traffic (16-pattern tiles doubled it), and the
+// registers that frees hold the operands of two whole entries.  The tables of such an instance hold tile 0's rows in front of
+// tile 1's (`split` below).  MEASURED (profiles/r05_walkg_pair.txt): parity-green and no faster than k_walkg; opt-in.
+// the transition-matrix kernels take "where the tables start" as one size_t (wgTab, floats into a matrix buffer; 0: no tables):
+// its top bit says that the instance's tables have the row-split layout
+#define MBAMD_WG_TAB_SPLIT ((size_t) 1 << 63)
+__host__ __device__ inline bool wg_split_states(int S) { return MBAMD_WG_TW == 32 && S > 48; }
+// state counts k_walkg2 is instantiated for (one output tile per wave: up to 32 states, or the row split); 40 states: k_walkg only
+__host__ __device__ inline bool wg2_states(int S) { return MBAMD_WG_TW == 32 && (S <= 32 || S > 48); }
 __host__ __device__ inline int wg_pairs(int S) { return (S + MBAMD_WG_KS - 1) / MBAMD_WG_KS; }         // T: MFMA steps (rows of a block)
 __host__ __device__ inline int wg_tiles(int S) { return (S + MBAMD_WG_TW - 1) / MBAMD_WG_TW; }         // NT: output tiles of TW rows
 #if MBAMD_WG_TW == 32
@@ -75,7 +92,10 @@ __host__ __device__ inline int wg_rows(int S)                                   
 __host__ __device__ inline int wg_subtables(int S) { return S / MBAMD_WG_TW + 1; }        // gather tables: states 0..S in groups of TW (S = "missing")
 __host__ __device__ inline unsigned wg_block_bytes(int S) { return (unsigned) wg_pairs_padded(S) * 256u; }   // one (tile, buffer, category) = one LDS slot
 __host__ __device__ inline size_t wg_table_floats(int S) { return (size_t) (1 + wg_subtables(S)) * wg_rows(S) * 64; }   // per category
-__host__ __device__ inline size_t wg_lds_bytes(int W, int nslots, int S) { return (size_t) W * (MBAMD_WG_STAGE + (size_t) nslots * wg_block_bytes(S)); }
+__host__ __device__ inline unsigned wg_stage_bytes(bool split) { return split ? MBAMD_WG_STAGE_SPLIT : MBAMD_WG_STAGE; }
+// W = subtree bins of a workgroup (a bin is one wave, or a pair of waves with the row split)
+__host__ __device__ inline size_t wg_lds_bytes(int W, int nslots, int S, bool split = false) { return (size_t) W * (wg_stage_bytes(split) + (size_t) nslots * wg_block_bytes(S)); }
+__host__ __device__ inline int wg_waves_per_bin(bool split) { return split ? 2 : 1; }
 // A block holds [TP rows][64 lanes]: row t, lane TW h + p = state KS t + h of pattern p; V consecutive rows are interleaved
 // per lane so that one dword / dwordx2 / dwordx4 per lane moves V rows (256 B - 1 KiB contiguous per wave instruction).
 // float offset of (row r, lane / column c) inside a block or table:
@@ -98,17 +118,19 @@ __host__ __device__ inline unsigned wg_elem(int S, int i, int p) { return wg_at(
 // next MFMA step t = ... wants there):
 //   TW 32:  register r, half h           = state 32 it + 2 r + h;   A'(n, 32 (j & 1) + row) with row = (r & 3) + 8 (r >> 2) + 4 h
 //           G_u(n = r NT + it, 2 s + h)
+//           row split (wg_split): n = it TP + t for A', n = it TP + r for G_u -- an output tile's rows are contiguous
 //   TW 16:  register r (0..3), group g   = state 16 it + 4 r + g;   A'(n, 16 (j & 3) + row) with row = 4 g + r
 //           G_u(n = r NT + it, 4 s + g)
 // scatter P_k(i -> j) = v into the tables of category k (tab = first float of that category's tables)
-__host__ __device__ inline void wg_table_put(float* tab, int S, int i, int j, float v)
+__host__ __device__ inline void wg_table_put(float* tab, int S, int i, int j, float v, bool sp = false)
 {
     const int NT = wg_tiles(S), NAP = wg_rows(S), VA = wg_vec_a(S);
 #if MBAMD_WG_TW == 32
     const int it = i >> 5, r = (i & 31) >> 1, h = i & 1;
     const int row = (r & 3) + 8 * (r >> 2) + 4 * h;                        // MFMA row that carries state i
-    tab[wg_at(VA, (j >> 1) * NT + it, row + 32 * (j & 1))] = v;            // A'
-    tab[(size_t) (1 + (j >> 5)) * NAP * 64 + wg_at(VA, r * NT + it, 2 * (j & 31) + h)] = v;   // G_u
+    const int TP = wg_pairs_padded(S);
+    tab[wg_at(VA, sp ? it * TP + (j >> 1) : (j >> 1) * NT + it, row + 32 * (j & 1))] = v;            // A'
+    tab[(size_t) (1 + (j >> 5)) * NAP * 64 + wg_at(VA, sp ? it * TP + r : r * NT + it, 2 * (j & 31) + h)] = v;   // G_u
 #else
     const int it = i >> 4, r = (i & 15) >> 2, g = i & 3;
     const int row = 4 * g + r;
@@ -117,12 +139,12 @@ __host__ __device__ inline void wg_table_put(float* tab, int S, int i, int j, fl
 #endif
 }
 // the "missing" column (constant): from-state i
-__host__ __device__ inline void wg_table_put_missing(float* tab, int S, int i)
+__host__ __device__ inline void wg_table_put_missing(float* tab, int S, int i, bool sp = false)
 {
     const int NT = wg_tiles(S), NAP = wg_rows(S), VA = wg_vec_a(S);
 #if MBAMD_WG_TW == 32
     const int it = i >> 5, r = (i & 31) >> 1, h = i & 1;
-    tab[(size_t) (1 + (S >> 5)) * NAP * 64 + wg_at(VA, r * NT + it, 2 * (S & 31) + h)] = 1.0f;
+    tab[(size_t) (1 + (S >> 5)) * NAP * 64 + wg_at(VA, sp ? it * wg_pairs_padded(S) + r : r * NT + it, 2 * (S & 31) + h)] = 1.0f;
 #else
     const int it = i >> 4, r = (i & 15) >> 2, g = i & 3;
     tab[(size_t) (1 + (S >> 4)) * NAP * 64 + wg_at(VA, r * NT + it, 4 * (S & 15) + g)] = 1.0f;
@@ -130,12 +152,12 @@ __host__ __device__ inline void wg_table_put_missing(float* tab, int S, int i)
 }
 // one thread per (matrix, category, state): the constant column of every matrix buffer, once per instance
 __global__ void __launch_bounds__(256)
-k_wg_init_tables(float* __restrict__ matrices, size_t matrixFloats, size_t tabOffFloats, int S, int K, int total)
+k_wg_init_tables(float* __restrict__ matrices, size_t matrixFloats, size_t tabOffFloats, int S, int K, int total, int split)
 {
     const int g = blockIdx.x * blockDim.x + threadIdx.x;
     if (g >= total) return;
     const int i = g % S, mk = g / S;
-    wg_table_put_missing(matrices + (size_t) (mk / K) * matrixFloats + tabOffFloats + (size_t) (mk % K) * wg_table_floats(S), S, i);
+    wg_table_put_missing(matrices + (size_t) (mk / K) * matrixFloats + tabOffFloats + (size_t) (mk % K) * wg_table_floats(S), S, i, split != 0);
 }
 
 struct WalkGArgs {
@@ -155,6 +177,7 @@ struct WalkGArgs {
     int K, Ppad, ntiles, S, SP;
     int lists;                   // > 1: mutually independent lists run as separate workgroups (programs [list][W][entries]); else 1
     int spread;                  // 1: the workgroup is launched with 2 W waves and only the even ones work (see k_walkg)
+    int pair;                    // 1: row split (k_walkg2): a subtree bin is a pair of waves, the stage area is MBAMD_WG_STAGE_SPLIT bytes
     long long* reserved;         // (was: clock stamps of timing experiments)
 };
 __host__ __device__ inline unsigned walkg_grid(int ntiles, int KL) { return 8u * (unsigned) KL * (unsigned) ((ntiles + 7) / 8); }   // KL = categories x lists
@@ -168,39 +191,7 @@ __device__ __forceinline__ const WalkGArgs& wg_args(const WalkGArgs& a) { return
 __device__ __forceinline__ const WalkGArgs& wg_args(const WalkGArgsInline& a) { return a.a; }
 __device__ __forceinline__ const Walk4Entry* wg_program(const WalkGArgs& a) { return a.prog; }
 
-// ---- k_walkg_s: the same walk with the transition tables STAGED IN LDS and shared by the waves of a workgroup --------------
-// (BASELINE north_star: "LDS-staged Ti-prob tiles").  k_walkg's waves each fetch the whole A' table of every child from L2
-// (codon M3 100 x 5 000: 3 GB through L2 per evaluation for 0.6 GB of HBM traffic -- the measured bound, profiles/r03_c5_pmc.txt).
-// Here a workgroup is G waves on G ADJACENT TILES of one (category, list, subtree bin): they interpret the SAME program, so
-// every child's table is needed by all of them at the same time -- one cooperative LDS-DMA stream (global_load_lds) brings it
-// into a ring of NB = D + 1 chunk buffers, D chunks ahead of the MFMA chain that reads it with ds_read; a compact tip takes its
-// factor from the same staged table (a gather of ITS column: no second set of gather tables, no L2 traffic at all).  The waves
-// meet at one s_barrier per chunk.  The subtree bins of the tree-parallel schedule are separate WORKGROUPS (they run
-// different programs: in one workgroup their barriers would make every chunk as slow as its slowest bin), and the dependent
-// phases separate LAUNCHES (Walk4Builder::phasesAreLaunches; a dependent-kernel boundary is 1.5-2 us).
-#define MBAMD_WGS_MAXBINS 8
-#define MBAMD_WGS_STAGE   1536   // bytes per wave in front of its slots: [2 entry parities][exponents | tip states 1 | tip states 2][64 dwords]
-struct WalkGSArgs {
-    WalkGArgs a;                 // prog = [list][progW][a.entries]; a.lists independent lists
-    unsigned range[MBAMD_WG_MAXLISTS][MBAMD_WGS_MAXBINS];   // this launch's part of program (list, bin): first entry << 16 | entries (0: nothing)
-    int bins;                    // subtree bins in this launch's grid
-    int progW;                   // programs per list in `prog`
-    int atomicCum;               // several workgroups (bins) add to the same cumulative exponents: atomic adds into a zeroed / running buffer
-};
-struct WalkGSArgsInline {
-    WalkGSArgs s;
-    Walk4Entry inl[MBAMD_W4_INLINE];
-};
-__host__ __device__ inline unsigned walkgs_grid(int ngroups, int KLB) { return 8u * (unsigned) KLB * (unsigned) ((ngroups + 7) / 8); }   // KLB = categories x lists x bins
-__host__ __device__ inline size_t wgs_chunk_bytes(int S, int CH) { return (size_t) (wg_rows(S) / CH) * 256; }
-__host__ __device__ inline size_t wgs_lds_bytes(int G, int nslots, int S, int CH, int NB)
-{
-    return (size_t) NB * wgs_chunk_bytes(S, CH) + (size_t) G * (MBAMD_WGS_STAGE + (size_t) nslots * wg_block_bytes(S));
-}
-__device__ __forceinline__ const WalkGSArgs& wgs_args(const WalkGSArgs& a) { return a; }
-__device__ __forceinline__ const WalkGSArgs& wgs_args(const WalkGSArgsInline& a) { return a.s; }
-__device__ __forceinline__ const Walk4Entry* wgs_program(const WalkGSArgs& a) { return a.a.prog; }
 }  // namespace mbamd
 #include <mbamd_dev_walkg_kernel.h>   // wg_program(const WalkGArgsInline&) and k_walkg itself (csrc/device/: the MFMA kernel)
-#include <mbamd_dev_walkgs_kernel.h>  // k_walkg_s
+#include <mbamd_dev_walkg2_kernel.h>  // k_walkg2: a whole entry's operands in flight; the row-split pair (round 5)
 #endif

@@ -1090,18 +1090,18 @@ def check_parsimony_model_golden(lib, golden_dir):
             inst.finalize()
 
 
-def check_shared_table_walk(lib, oracle, golden_dir, monkeypatch):
-    """k_walkg_s (MBAMD_WALKG_SHARED=1: transition tables staged in LDS and shared by the waves of a workgroup, subtree bins as
-    workgroups, phases as launches) against k_walkg, the oracle and the reference's goldens: full evaluations with both scaling
-    schemes at several bin counts / slot budgets, per-site values, partial updates with rejects."""
+def check_pair_walk(lib, oracle, golden_dir, monkeypatch):
+    """k_walkg2 (MBAMD_WALKG_PAIR=1: the operands of a whole entry in flight; beyond 48 states the row split -- a subtree bin is a
+    pair of waves, each owning one output tile, split table layout) against k_walkg, the oracle and the reference's goldens: full
+    evaluations with both scaling schemes at several bin counts / slot budgets (few slots: evicted results come back from HBM, the
+    pair drains its stores first), per-site values, partial updates with rejects, other state counts."""
     for case in ("avian_wag_g4", "replicase_m3", "synth_aa_wag", "synth_codon_m3"):
         div = division_from_golden(golden_dir, case)
-        monkeypatch.delenv("MBAMD_WALKG_SHARED", raising=False)
+        monkeypatch.delenv("MBAMD_WALKG_PAIR", raising=False)
         base = engine_lnl(lib, div, lk.MB_BEAGLE_SCALE_ALWAYS)
-        for env in ({}, {"MBAMD_WALK_WAVES": "1"}, {"MBAMD_WALK_WAVES": "3", "MBAMD_MAX_LDS_SLOTS": "2"}, {"MBAMD_WALKG_G": "2"},
-                    {"MBAMD_WALKG_G": "4", "MBAMD_WALK_WAVES": "5", "MBAMD_MAX_LDS_SLOTS": "1"}):
-            monkeypatch.setenv("MBAMD_WALKG_SHARED", "1")
-            for k in ("MBAMD_WALK_WAVES", "MBAMD_MAX_LDS_SLOTS", "MBAMD_WALKG_G"):
+        for env in ({}, {"MBAMD_WALK_WAVES": "1"}, {"MBAMD_WALK_WAVES": "2", "MBAMD_MAX_LDS_SLOTS": "3"}, {"MBAMD_WALK_WAVES": "1", "MBAMD_MAX_LDS_SLOTS": "3"}):
+            monkeypatch.setenv("MBAMD_WALKG_PAIR", "1")
+            for k in ("MBAMD_WALK_WAVES", "MBAMD_MAX_LDS_SLOTS"):
                 monkeypatch.delenv(k, raising=False)
             for k, v in env.items():
                 monkeypatch.setenv(k, v)
@@ -1109,9 +1109,11 @@ def check_shared_table_walk(lib, oracle, golden_dir, monkeypatch):
                 got = engine_lnl(lib, div, scaling)
                 assert abs(got - base) <= 2e-7 * abs(base), (case, env, scaling, got, base)
             check_golden_case(lib, oracle, golden_dir, case, lk.MB_BEAGLE_SCALE_ALWAYS)
-    monkeypatch.setenv("MBAMD_WALKG_SHARED", "1")
-    for k in ("MBAMD_WALK_WAVES", "MBAMD_MAX_LDS_SLOTS", "MBAMD_WALKG_G"):
+    monkeypatch.setenv("MBAMD_WALKG_PAIR", "1")
+    for k in ("MBAMD_WALK_WAVES", "MBAMD_MAX_LDS_SLOTS"):
         monkeypatch.delenv(k, raising=False)
     check_site_likelihoods(lib, oracle, division_from_golden(golden_dir, "replicase_m3"))
     check_partial_update_and_reject(lib, oracle, division_from_golden(golden_dir, "avian_wag_g4"), lk.MB_BEAGLE_SCALE_DYNAMIC)
     check_partial_update_and_reject(lib, oracle, division_from_golden(golden_dir, "synth_codon_m3"), lk.MB_BEAGLE_SCALE_ALWAYS)
+    for nstates in (2, 8, 16):
+        check_generic_states(lib, oracle, nstates, 12, 300)

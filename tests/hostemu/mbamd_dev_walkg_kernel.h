@@ -14,16 +14,20 @@ __global__ void k_walkg(ARGS AA)
 {
     const WalkGArgs& A = wg_args(AA);
     const unsigned lane = threadIdx.x & 63;
-    const int wave = (int) (threadIdx.x >> 6), W = (int) (blockDim.x >> 6);
+    // row split (A.pair, k_walkg2): a subtree bin is a pair of waves; here the first wave of a pair does the bin's work, the second
+    // only keeps the barriers' company
     const int S = A.S, SP = A.SP, TP = wg_pairs_padded(S);
+    const int wpb = wg_waves_per_bin(A.pair != 0), hw = (int) (threadIdx.x >> 6) % wpb;
+    const int wave = (int) (threadIdx.x >> 6) / wpb, W = (int) (blockDim.x >> 6) / wpb;
+    const unsigned STAGE = wg_stage_bytes(A.pair != 0);
     const unsigned SLOTB = wg_block_bytes(S);
     const unsigned K = (unsigned) A.K, KL = K * (unsigned) A.lists;
     const unsigned xcd = blockIdx.x & 7u, pos = blockIdx.x >> 3;
     const unsigned tile = (pos / KL) * 8u + xcd, k = (pos % KL) % K, list = (pos % KL) / K;
     if (tile >= (unsigned) A.ntiles) return;
     char* lds = reinterpret_cast<char*>(mbamd_emu_dyn_lds());
-    char* const mine = lds + (size_t) wave * (MBAMD_WG_STAGE + (size_t) A.nslots * SLOTB);
-    float* const slots = reinterpret_cast<float*>(mine + MBAMD_WG_STAGE);
+    char* const mine = lds + (size_t) wave * (STAGE + (size_t) A.nslots * SLOTB);
+    float* const slots = reinterpret_cast<float*>(mine + STAGE);
     char* const P0 = reinterpret_cast<char*>(A.partials) + (size_t) tile * A.tileBytes + (size_t) k * SLOTB;
     const uint8_t* const T0 = A.tips + (size_t) tile * A.tipTileBytes;
     constexpr int TW = MBAMD_WG_TW;
@@ -34,7 +38,7 @@ __global__ void k_walkg(ARGS AA)
     for (int j = 0; j < A.entries; ++j) {
         const Walk4Entry e = prog[j];
         if (e.ctl & MBAMD_W4_BARRIER) mbamd_emu_barrier();
-        if (lane != 0 || (e.ctl & MBAMD_W4_NOP)) continue;
+        if (lane != 0 || hw != 0 || (e.ctl & MBAMD_W4_NOP)) continue;
         const unsigned mode = (e.ctl >> 8) & 3u;
         float* dst = reinterpret_cast<float*>(P0 + e.dst);
         float res[64][TW];
@@ -77,13 +81,13 @@ __global__ void k_walkg(ARGS AA)
         int* stage = reinterpret_cast<int*>(mine);
         if (W > 1) {
             if (q > 0) mbamd_emu_barrier();
-            if (lane == 0) for (int c = 0; c < TW; ++c) stage[c] = cum_e[q][c];
+            if (lane == 0 && hw == 0) for (int c = 0; c < TW; ++c) stage[c] = cum_e[q][c];
             mbamd_emu_barrier();
         }
-        if (wave == 0 && lane == 0)
+        if (wave == 0 && lane == 0 && hw == 0)
             for (int c = 0; c < TW; ++c) {
                 int sum = cum_e[q][c];
-                for (int w = 1; w < W; ++w) sum += reinterpret_cast<const int*>(lds + (size_t) w * (MBAMD_WG_STAGE + (size_t) A.nslots * SLOTB))[c];
+                for (int w = 1; w < W; ++w) sum += reinterpret_cast<const int*>(lds + (size_t) w * (STAGE + (size_t) A.nslots * SLOTB))[c];
                 int32_t* d = A.cum[q] + (size_t) k * A.Ppad + (size_t) tile * TW + c;
                 if (A.cumFresh >> q & 1) *d = sum; else *d += sum;
             }

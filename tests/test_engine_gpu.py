@@ -614,7 +614,7 @@ def test_short_walk_programs_travel_in_the_kernel_arguments(gpu, monkeypatch, go
     assert path_values() == base
 
 
-def test_shared_table_walk(gpu, oracle, golden_dir, monkeypatch):
-    """The opt-in general-state walk with LDS-staged, workgroup-shared transition tables (k_walkg_s) is parity-green: it is not
-    the product default because it measured slower than k_walkg (profiles/r04_walkgs_*.txt)."""
-    ec.check_shared_table_walk(gpu, oracle, golden_dir, monkeypatch)
+def test_pair_walk(gpu, oracle, golden_dir, monkeypatch):
+    """The opt-in general-state walk k_walkg2 (a whole entry's operands in flight, the row-split pair of waves at 60-63 states) is
+    parity-green: it is not the product default because it measured no faster than k_walkg (profiles/r05_walkg_pair.txt)."""
+    ec.check_pair_walk(gpu, oracle, golden_dir, monkeypatch)
