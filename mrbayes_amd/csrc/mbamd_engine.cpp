@@ -153,7 +153,7 @@ struct Plan {
     PartialsOp* d_table = nullptr;
     size_t cap = 0;                  // bytes allocated for d_table
     struct Segment {                             // tree-walk path: one launch per hazard-free segment
-        size_t first; int W, entries, nslots, tail = 2, tipAhead = 0;
+        size_t first; int W, entries, nslots, tail = 2;
     };
     std::vector<Segment> segments;               // (Walk4Entry index of its program in d_table, geometry)
     std::vector<Walk4Entry> inlineProg;          // 4-state walk: a short single-segment program travels in the kernel arguments instead
@@ -250,6 +250,7 @@ struct Instance {
     void postResultFlag();
     bool scaleOpsIndependentOfPending(const int* idx, int n, int cumIdx) const;
     uint64_t launchClock = 0, syncedClock = 0;   // launches issued / launches known complete (last stream synchronisation)
+    uint64_t flagClock = 0;                      // launchClock when the polled result flag was queued (postResultFlag)
     std::vector<double> h_freqs, h_weights;      // host mirrors of d_freqs / d_weights (uploadIfChanged)
     long long* d_trace = nullptr;    // MBAMD_WALK_TRACE: per-step clock stamps of workgroup 0 (timing experiments)
 
@@ -778,9 +779,6 @@ int Instance::configureWalk()
     w4.maxSlots1 = std::max(slots, std::min(40, slotsFor(1)));
     if (std::getenv("MBAMD_MAX_LDS_SLOTS")) w4.maxSlots1 = slots;
     if (const char* e = std::getenv("MBAMD_WALK_PREFETCH")) w4.prefetchDistance = std::max(0, std::atoi(e));
-    // (round 3's tip-plane touch -- two LDS-DMAs, a half-entry scalar load and their address arithmetic per operation for +-2 % --
-    //  left the loop in round 4: it is issue-bound)
-    w4.tipAhead = 0;
     w4.forward = std::getenv("MBAMD_WALK_NO_FORWARD") == nullptr;
     w4.safeWaits = std::getenv("MBAMD_WALK_SAFE") != nullptr;
     if (const char* e = std::getenv("MBAMD_WALK_SMALL_PHASE")) w4.smallPhase = std::max(1, std::atoi(e));
@@ -1575,7 +1573,7 @@ int Instance::buildWalk(Plan& plan, const BeagleOperation* ops, int n, const int
         key.clear();
         key.reserve(seg.size() * 3 + 4);
         key.push_back((int) seg.size()); key.push_back(w4.maxW); key.push_back(w4.maxSlots + 256 * w4.maxSlots1);
-        key.push_back(w4.prefetchDistance * 2 + (w4.safeWaits ? 1 : 0) + 1024 * w4.tipAhead + 65536 * std::min(w4.tipAheadFrom, 30000) + (w4.forward ? 512 : 0));
+        key.push_back(w4.prefetchDistance * 2 + (w4.safeWaits ? 1 : 0) + (w4.forward ? 512 : 0));
         {
             std::vector<int>& writer = w4writer;          // buffer -> operation of this segment that writes it (-1 outside this block)
             for (size_t o = 0; o < seg.size(); ++o) {
@@ -1611,7 +1609,7 @@ int Instance::buildWalk(Plan& plan, const BeagleOperation* ops, int n, const int
         reloads += t.reloads; externals += t.externals; phases = std::max(phases, t.phases);
         Plan::Segment sg;
         sg.first = w4table.size();
-        sg.W = t.W; sg.entries = t.entries; sg.nslots = t.nslots; sg.tail = t.tail; sg.tipAhead = t.tipAhead;
+        sg.W = t.W; sg.entries = t.entries; sg.nslots = t.nslots; sg.tail = t.tail;
         plan.segments.push_back(sg);
         w4table.resize(sg.first + t.prog.size());
         // bytes per buffer inside a block / tile, bytes per LDS slot
@@ -1758,7 +1756,7 @@ int Instance::buildWalk(Plan& plan, const BeagleOperation* ops, int n, const int
                      n, plan.segments.size(), lastWalkW, lastWalkEntries, lastWalkSlots, phases, reloads, externals);
     // a short program goes out with the launch itself (k_walk4_t<Walk4ArgsInline>, k_walkg<..., WalkGArgsInline>)
     plan.inlineProg.clear();
-    if (!noInlinePrograms && plan.segments.size() == 1 && plan.segments[0].tipAhead == 0 && w4table.size() <= (size_t) MBAMD_W4_INLINE) {
+    if (!noInlinePrograms && plan.segments.size() == 1 && w4table.size() <= (size_t) MBAMD_W4_INLINE) {
         plan.inlineProg = w4table;
         return BEAGLE_SUCCESS;
     }
@@ -1798,7 +1796,6 @@ int Instance::runWalk(const Plan& plan, int32_t* cum)
         a.Ppad = Ppad;
         a.nblocks = Ppad / 64;
         a.tail = sg.tail;
-        a.tipAhead = sg.tipAhead;
         if (!plan.inlineProg.empty()) {
             Walk4ArgsInline ai;
             ai.a = a;
@@ -2620,6 +2617,7 @@ void Instance::postResultFlag()
         (void) hipGetLastError();
         pollResult = false;
     }
+    flagClock = launchClock;                     // what the stream has finished when the flag shows flagSeq -- and nothing younger
 }
 
 int Instance::fetchResult(double* out)
@@ -2629,12 +2627,22 @@ int Instance::fetchResult(double* out)
         StatTimer st_(ST_WAIT);
         bool landed = false;
         if (pollResult) {
+            // spin on the word the stream writes behind the integration kernel, for about a millisecond of wall time; then the runtime's wait
             volatile uint32_t* f = h_flag;
-            for (long spins = 0; spins < 400000L && !(landed = (*f == flagSeq)); ++spins) __builtin_ia32_pause();   // (~ a millisecond; then the runtime's wait)
+            const auto t0 = std::chrono::steady_clock::now();
+            for (long spins = 0; !(landed = (*f == flagSeq)); ++spins) {
+                if ((spins & 1023) == 1023 && std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(1)) break;
+#if defined(__x86_64__) || defined(__i386__)
+                __builtin_ia32_pause();
+#endif
+            }
+            if (landed) __atomic_thread_fence(__ATOMIC_ACQUIRE);      // the block sums were written before the flag: read them after it
         }
-        if (!landed) HIP_TRY(hipStreamSynchronize(stream));
+        // the flag covers the launches up to the integration it follows; launches queued behind it in deferred mode (the reduction of
+        // mbamdReduceLogLikelihood, further lists) are complete only after a real synchronisation
+        if (landed) syncedClock = std::max(syncedClock, flagClock);
+        else { HIP_TRY(hipStreamSynchronize(stream)); syncedClock = launchClock; }
     }
-    syncedClock = launchClock;
     pendingResult = false;
     double s = 0.0;
     for (int i = 0; i < nblocks; ++i) s += h_sums[i];
@@ -2756,6 +2764,10 @@ int Instance::finalPass(const MbamdFinalOperation* ops, int count)
         if (b.ancestorFinal < 0) {
             int32_t*& own = finalExpOwn[b.destinationPartials];
             if (!own) HIP_TRY(hipMalloc(&own, (size_t) K * Ppad * sizeof(int32_t)));
+            // a new pass from this top node rewrites `own` in place: whatever an EARLIER pass left below it would be read with
+            // this pass's exponents from now on -- those buffers no longer hold final partials (they are re-made by this pass, or not)
+            for (size_t q = 0; q < finalExpOf.size(); ++q)
+                if (finalExpOf[q] == own && (int) q != b.destinationPartials) finalExpOf[q] = nullptr;
             finalExpOf[b.destinationPartials] = own;
         } else {
             if (!finalExpOf[b.ancestorFinal]) return fail(BEAGLE_ERROR_OUT_OF_RANGE, "mbamdUpdateFinalPartials: the ancestor's buffer does not hold final partials");

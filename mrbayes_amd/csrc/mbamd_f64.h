@@ -209,14 +209,6 @@ k64_partials_mfma(const Op64* __restrict__ ops, int S, int SPAD, int Ppad_)
 // group's in flight behind the current group's arithmetic) still come through the L1.  Same instructions on the same operands in
 // the same order as above: the results are bit-identical.  grid (P_pad / 64, operations, K if unfused), 256 threads,
 // dynamic LDS 2 * max(KF, 1) * stepsP * NT * 64 doubles, stepsP = ceil(S / 4) rounded up to a multiple of four (64 KiB at 61 states).
-#ifdef MBAMD_F64_STAMPS
-// diagnostic build: where a wave of the LDS contraction kernel spends its time (10 ns units of s_memrealtime; wave 0 of workgroup x = 5 of every operation)
-__device__ unsigned long long g_stamp_acc[2][8];
-__device__ unsigned long long g_stamp_cnt[2];
-#define MBAMD_TS(i) do { if (ts_on) { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); ts[i] = wall_clock64(); } } while (0)
-#else
-#define MBAMD_TS(i) do { } while (0)
-#endif
 // (PRE: the first group's partials of both children were loaded before the matrices were parked -- `pre`.  Requesting ALL of a child's
 //  partials ahead was measured on the four-wave workgroups of the narrow levels, where nothing else hides a cold load: at the start of
 //  its contraction 2.8 -> 3.6 us per child, before the matrices are parked 2.8 -> 2.3 us but the load phase 3.3 -> 5.0 us -- that phase is
@@ -225,9 +217,6 @@ template <int NT, bool PRE>
 __device__ __forceinline__ void f64_mfma_tiles_lds(const MBAMD_AS_CONST Op64* op, int S, int SPAD, size_t Ppad, int k, size_t c, int n, int g, int lane,
                                                    const double* lds1, const double* lds2, const double (&pre)[2][4],
                                                    double __attribute__((ext_vector_type(4))) (&p)[NT]
-#ifdef MBAMD_F64_STAMPS
-                                                   , unsigned long long (&ts)[8], bool ts_on
-#endif
                                                    )
 {
     typedef double d4 __attribute__((ext_vector_type(4)));
@@ -250,7 +239,6 @@ __device__ __forceinline__ void f64_mfma_tiles_lds(const MBAMD_AS_CONST Op64* op
                     const double v = row[it * 64 + 4 * r];
                     f[ch][it][r] = st >= (unsigned) S ? 1.0 : v;
                 }
-            MBAMD_TS(3 + ch);
             continue;
         }
         const double* la = (ch ? lds2 : lds1) + lane;
@@ -285,7 +273,6 @@ __device__ __forceinline__ void f64_mfma_tiles_lds(const MBAMD_AS_CONST Op64* op
 #pragma unroll
             for (int u = 0; u < 4; ++u) b[u] = bn[u];
         }
-        MBAMD_TS(3 + ch);
     }
 #pragma unroll
     for (int it = 0; it < NT; ++it) p[it] = f[0][it] * f[1][it];
@@ -306,11 +293,6 @@ __device__ __forceinline__ void f64_lds_operation(const MBAMD_AS_CONST Op64* op,
     const int tid = (int) threadIdx.x, wave = tid >> 6, lane = tid & 63, n = lane & 15, g = lane >> 4;
     const int stepsP = (((S + 3) / 4) + 3) & ~3, nb = stepsP * NT, frag = nb * 64;         // doubles of one matrix in fragment order (zero rows beyond S)
     const bool inRange = !((size_t) blockIdx.x * (16 * NW) + 16 * NW <= (size_t) op->first || (size_t) blockIdx.x * (16 * NW) >= (size_t) op->last);   // (workgroup-uniform)
-#ifdef MBAMD_F64_STAMPS
-    unsigned long long ts[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    const bool ts_on = blockIdx.x == 5 && wave == 0;
-    MBAMD_TS(0);
-#endif
     const size_t tile0 = (size_t) blockIdx.x * (16 * NW) + (size_t) wave * 16;
     const bool waveIn = inRange && !(tile0 + 16 <= (size_t) op->first || tile0 >= (size_t) op->last);      // (wave-uniform)
     const size_t c = tile0 + n;
@@ -369,19 +351,13 @@ __device__ __forceinline__ void f64_lds_operation(const MBAMD_AS_CONST Op64* op,
                     if (r * (64 * NW) + tid < nb * 32) dstl[r * (64 * NW) + tid] = tmp[kk][ch][r];
             }
     }
-    MBAMD_TS(1);
     MBAMD_SYNC();
-    MBAMD_TS(2);
     if (!waveIn) return;                                     // (no barrier below)
     const bool mine = c >= (size_t) op->first && c < (size_t) op->last;
     if constexpr (KF == 0) {
         const int k = (int) blockIdx.z;
         d4 p[NT];
-#ifdef MBAMD_F64_STAMPS
-        f64_mfma_tiles_lds<NT, true>(op, S, SPAD, Ppad, k, c, n, g, lane, lds, lds + frag, pre, p, ts, ts_on);
-#else
         f64_mfma_tiles_lds<NT, true>(op, S, SPAD, Ppad, k, c, n, g, lane, lds, lds + frag, pre, p);
-#endif
         MBAMD_AS_GLOBAL double* dst = as_global(op->dst) + (size_t) k * S * Ppad + c;
         if (mine) {
 #pragma unroll
@@ -397,13 +373,8 @@ __device__ __forceinline__ void f64_lds_operation(const MBAMD_AS_CONST Op64* op,
         double mx = 0.0;
 #pragma unroll
         for (int k = 0; k < KF; ++k) {
-#ifdef MBAMD_F64_STAMPS
-            if (k == 0) f64_mfma_tiles_lds<NT, true>(op, S, SPAD, Ppad, k, c, n, g, lane, lds + (size_t) k * frag, lds + (size_t) (KF + k) * frag, pre, p[k], ts, ts_on);
-            else f64_mfma_tiles_lds<NT, false>(op, S, SPAD, Ppad, k, c, n, g, lane, lds + (size_t) k * frag, lds + (size_t) (KF + k) * frag, pre, p[k], ts, ts_on);
-#else
             if (k == 0) f64_mfma_tiles_lds<NT, true>(op, S, SPAD, Ppad, k, c, n, g, lane, lds + (size_t) k * frag, lds + (size_t) (KF + k) * frag, pre, p[k]);
             else f64_mfma_tiles_lds<NT, false>(op, S, SPAD, Ppad, k, c, n, g, lane, lds + (size_t) k * frag, lds + (size_t) (KF + k) * frag, pre, p[k]);
-#endif
 #pragma unroll
             for (int it = 0; it < NT; ++it)
 #pragma unroll
@@ -423,7 +394,6 @@ __device__ __forceinline__ void f64_lds_operation(const MBAMD_AS_CONST Op64* op,
         } else if (op->mode == 2) {
             e = as_global(op->scale)[c];
         }
-        MBAMD_TS(5);
         if (mine) {
 #pragma unroll
             for (int k = 0; k < KF; ++k) {
@@ -437,18 +407,13 @@ __device__ __forceinline__ void f64_lds_operation(const MBAMD_AS_CONST Op64* op,
                     }
             }
         }
-        MBAMD_TS(6);
-#ifdef MBAMD_F64_STAMPS
-        if (ts_on && lane == 0) {
-            for (int i = 1; i <= 6; ++i) atomicAdd(&g_stamp_acc[NW == 8 ? 0 : 1][i], ts[i] - ts[i - 1]);
-            atomicAdd(&g_stamp_cnt[NW == 8 ? 0 : 1], 1ull);
-        }
-#endif
     }
 }
 
+// (second launch bound: four waves per SIMD leave 128 registers -- the wide instantiations, NT x KF >= 6, spilled 5 ... 53 of theirs to
+//  scratch at eight waves per workgroup; they get two waves per SIMD, i.e. one such workgroup per CU, and no scratch)
 template <int NT, int KF, int NW>
-__global__ void __launch_bounds__(64 * NW, NW / 2)
+__global__ void __launch_bounds__(64 * NW, (NW == 8 && NT * KF >= 6) ? 2 : NW / 2)
 k64_partials_mfma_lds(const Op64* __restrict__ ops, int S, int SPAD, int Ppad_)
 {
     f64_lds_operation<NT, KF, NW>(as_const(ops) + blockIdx.y, mbd_dyn_lds<double>(), S, SPAD, (size_t) Ppad_);
@@ -544,17 +509,9 @@ k64_partials_chain(const Op64* __restrict__ ops, const int* __restrict__ chainSt
     Op64 dcur = f64_load_op(as_const(ops) + ob), dnxt = f64_load_op(as_const(ops) + (ob + 1 < oe ? ob + 1 : ob));
     fetchMatrices(dcur);
     fetchSibling(dcur);
-#ifdef MBAMD_F64_STAMPS
-    unsigned long long ts[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    const bool ts_on = blockIdx.x == 5 && wave == 0;
-#define MBAMD_TSN(i) do { if (ts_on) ts[i] = wall_clock64(); } while (0)
-#else
-#define MBAMD_TSN(i) do { } while (0)
-#endif
     for (int o = ob; o < oe; ++o) {
         const Op64 dnn = f64_load_op(as_const(ops) + (o + 2 < oe ? o + 2 : oe - 1));
         const Op64* op = &dcur;
-        MBAMD_TSN(0);
 #pragma unroll
         for (int k = 0; k < KF; ++k)
 #pragma unroll
@@ -573,10 +530,8 @@ k64_partials_chain(const Op64* __restrict__ ops, const int* __restrict__ chainSt
                     }
                 }
             }
-        MBAMD_TSN(1);
         if (o + 1 < oe) fetchMatrices(dnxt);               // (in flight during this operation's arithmetic)
         MBAMD_SYNC();
-        MBAMD_TSN(2);
         const int cc = op->pad_, si = cc == 2 ? 0 : 1;       // chain child code, sibling's child index
         d4 p[KF][NT];
         double mx = 0.0;
@@ -641,7 +596,6 @@ k64_partials_chain(const Op64* __restrict__ ops, const int* __restrict__ chainSt
                     if (16 * it + g + 4 * r < S) mx = fmax(mx, p[k][it][r]);
             }
         }
-        MBAMD_TSN(3);
         const int eStored = storedExp;
         if (o + 1 < oe) fetchSibling(dnxt);                // (every category's sibling values have been used)
         mx = fmax(mx, __shfl_xor(mx, 16));
@@ -670,19 +624,10 @@ k64_partials_chain(const Op64* __restrict__ ops, const int* __restrict__ chainSt
                     if (i < S) dst[(size_t) i * Ppad] = v;
                 }
         }
-        MBAMD_TSN(4);
         MBAMD_SYNC();                                        // every wave is done with the parked matrices
-        MBAMD_TSN(5);
         dcur = dnxt;
         dnxt = dnn;
-#ifdef MBAMD_F64_STAMPS
-        if (ts_on && lane == 0) {
-            for (int i = 1; i <= 5; ++i) atomicAdd(&g_stamp_acc[0][i], ts[i] - ts[i - 1]);
-            atomicAdd(&g_stamp_cnt[0], 1ull);
-        }
-#endif
     }
-#undef MBAMD_TSN
 }
 
 // Both children compact tips: no contraction, the product of two matrix columns -- a gather.  On the kernel above that is 32 scattered
@@ -1396,19 +1341,6 @@ public:
         void* all[] = {d_partials, d_states, d_matrices, d_eigen, d_freqs, d_weights, d_pweights, d_scale, d_site, d_sums, d_ev, d_stage};
         for (void* p : all)
             if (p) (void) hipFree(p);
-#ifdef MBAMD_F64_STAMPS
-        {
-            unsigned long long acc[2][8], cnt[2];
-            if (hipMemcpyFromSymbol(acc, HIP_SYMBOL(g_stamp_acc), sizeof acc) == hipSuccess && hipMemcpyFromSymbol(cnt, HIP_SYMBOL(g_stamp_cnt), sizeof cnt) == hipSuccess)
-                for (int v = 0; v < 2; ++v)
-                    if (cnt[v]) {
-                        std::fprintf(stderr, "[stamps] %s-wave workgroups, %llu waves: ", v == 0 ? "eight" : "four", cnt[v]);
-                        const char* names[8] = {"", "loads->LDS", "barrier", "child1", "child2", "rescale", "stores+drain", ""};
-                        for (int i = 1; i <= 6; ++i) std::fprintf(stderr, "%s %.2f us  ", names[i], (double) acc[v][i] / (double) cnt[v] * 0.01);
-                        std::fprintf(stderr, "\n");
-                    }
-        }
-#endif
         if (d_ring) (void) hipFree(d_ring);
         if (h_ring) (void) hipHostFree(h_ring);
         if (h_sums) (void) hipHostFree(h_sums);
@@ -1530,6 +1462,10 @@ public:
     }
     // host mirrors of the frequencies / weights on the device (NaN = nothing sent yet): true when `v` is what the device already holds
     std::vector<double> hostFreqs, hostWeights;
+    static void forget(std::vector<double>& mirror, size_t at, size_t n)
+    {
+        for (size_t i = 0; i < n && at + i < mirror.size(); ++i) mirror[at + i] = std::numeric_limits<double>::quiet_NaN();
+    }
     static bool sameAsLast(std::vector<double>& mirror, size_t total, size_t at, const double* v, size_t n)
     {
         if (mirror.size() != total) mirror.assign(total, std::numeric_limits<double>::quiet_NaN());
@@ -1543,14 +1479,18 @@ public:
         if (idx < 0 || idx >= nEigen) return fail(BEAGLE_ERROR_OUT_OF_RANGE, "beagleSetStateFrequencies: index");
         // (MrBayes sets the frequencies and category weights of every eigen part before every evaluation: unchanged values are not sent again)
         if (sameAsLast(hostFreqs, (size_t) nEigen * S, (size_t) idx * S, f, (size_t) S)) return BEAGLE_SUCCESS;
-        return upload(d_freqs + (size_t) idx * S, f, (size_t) S * sizeof(double));
+        const int rc = upload(d_freqs + (size_t) idx * S, f, (size_t) S * sizeof(double));
+        if (rc) forget(hostFreqs, (size_t) idx * S, (size_t) S);       // (the device kept the old vector: the next identical call must send again)
+        return rc;
     }
     int setWeights(int idx, const double* w)
     {
         { const int rcq = flushQueue(); if (rcq) return rcq; }
         if (idx < 0 || idx >= nEigen) return fail(BEAGLE_ERROR_OUT_OF_RANGE, "beagleSetCategoryWeights: index");
         if (sameAsLast(hostWeights, (size_t) nEigen * K, (size_t) idx * K, w, (size_t) K)) return BEAGLE_SUCCESS;
-        return upload(d_weights + (size_t) idx * K, w, (size_t) K * sizeof(double));
+        const int rc = upload(d_weights + (size_t) idx * K, w, (size_t) K * sizeof(double));
+        if (rc) forget(hostWeights, (size_t) idx * K, (size_t) K);
+        return rc;
     }
     int setRates(int index, const double* r)
     {
@@ -1745,7 +1685,7 @@ public:
         if (key != walkKey) {
             Walk4Builder& b = walkBuilder;
             b.maxW = 1; b.maxSlots = nslots; b.maxSlots1 = nslots; b.prefetchDistance = 0; b.memSlots = false;
-            b.leadNops = 0; b.unroll = 1; b.tailNops = 0; b.tipAhead = 0; b.forward = false; b.smallPhase = 1 << 30;
+            b.leadNops = 0; b.unroll = 1; b.tailNops = 0; b.forward = false; b.smallPhase = 1 << 30;
             if (!b.build(wops, walkTemplate)) { walkKey.clear(); return 1; }
             walkKey = key;
         }
@@ -1895,6 +1835,8 @@ public:
         return BEAGLE_SUCCESS;
     }
     // run what updatePartials queued; called first by every other entry point
+    // (an error returned from here means the queued lists were DROPPED -- the queue is empty afterwards, whichever entry point
+    //  reported it: the client resubmits them, as after any failed beagleUpdatePartials)
     int flushQueue()
     {
         { const int rcm = flushMatrices(); if (rcm) return rcm; }
@@ -1984,7 +1926,9 @@ public:
                 std::unordered_map<const void*, int> owner;
                 for (int i = 0; i < n; ++i) {
                     const Op64& q = sorted[(size_t) i];
-                    const void* keys[4] = {q.dst, q.c1_tip ? nullptr : q.c1, q.c2_tip ? nullptr : q.c2, q.mode != 0 ? (const void*) q.scale : nullptr};
+                    // (the cumulative buffer an operation adds to is a key like its scale buffer: two operations that meet in one --
+                    //  one adding atomically, the other storing or reading it as its scale buffer -- must not run as independent chains)
+                    const void* keys[5] = {q.dst, q.c1_tip ? nullptr : q.c1, q.c2_tip ? nullptr : q.c2, q.mode != 0 ? (const void*) q.scale : nullptr, (const void*) q.cum};
                     for (const void* key : keys) {
                         if (key == nullptr) continue;
                         auto it = owner.find(key);

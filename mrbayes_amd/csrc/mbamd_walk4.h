@@ -88,7 +88,6 @@ struct Walk4Args {
     int cumFresh;                // the cumulative buffer holds nothing yet: store the sums instead of adding them
     int K, Ppad, nblocks;
     int tail;                    // trailing NOP entries of every program (read-ahead): 2
-    int tipAhead;                // (unused since round 4: the tip-plane touch left the loop)
 };
 
 #define MBAMD_W4_STAGE 768       // bytes per wave in front of its slots: two 64-dword landing areas for stored exponents + one nobody reads

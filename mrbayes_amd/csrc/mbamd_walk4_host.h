@@ -51,7 +51,7 @@ struct Walk4Template {
     };
     std::vector<int> key;
     int W = 1, entries = 0, nslots = 1;            // entries per wave (incl. the trailing NOPs)
-    int tail = 2, tipAhead = 0;                    // trailing NOPs; tip-touch distance the wait counts were computed for (0: none)
+    int tail = 2;                                  // trailing NOPs
     std::vector<Entry> prog;                       // [W][entries]
     int phases = 1, reloads = 0, externals = 0;
     int evictions = 0;                             // results evicted from a wave's slots and re-read by the same wave
@@ -84,10 +84,6 @@ public:
     bool phasesAreLaunches = false;  // every phase is its own kernel launch: nothing stays in LDS across a phase boundary
     // program frame: leading NOP entries, loop unroll factor of the kernel, trailing (read-ahead) NOP entries
     int leadNops = 0, unroll = 2, tailNops = 2;
-    // 4-state walk, long lists: the kernel touches the tip bitplanes of the entry `tipAhead` ahead at the top of EVERY
-    // iteration (two vector-memory instructions: they enter the wait counts) and reads that far beyond the program's end
-    int tipAhead = 0, tipAheadFrom = 128;      // (lists shorter than tipAheadFrom operations run without: root-ward paths); set by the engine
-    int lastTipAhead = 0;                      // what the latest build() used (the caller passes it to the kernel)
     // 4-state walk: a result whose only consumer is the NEXT operation of the same wave -- in a post-order walk every parent
     // follows its last interior child directly -- stays in registers (c?slot = 0xFE): no LDS slot, no write / read-back round trip
     bool forward = false;
@@ -558,9 +554,8 @@ inline bool Walk4Builder::build(const std::vector<Walk4Op>& ops, Walk4Template& 
         }
         // 5. wait counts: replay the vector-memory instruction sequence of the kernel loop (mbamd_walk4.h)
         //    prologue: [exponent DMA for entry 0 if SCALE_READ]
-        //    iteration: [PF DMAs] WAIT [2 tip touches (long lists)] [exponent DMA for the next entry if SCALE_READ] [2 stores if an operation]
+        //    iteration: [PF DMAs] WAIT [exponent DMA for the next entry if SCALE_READ] [2 stores if an operation]
         auto reads = [&](const Walk4Template::Entry& e) { return e.op >= 0 && ops[e.op].scaleRead >= 0 && ops[e.op].scaleWrite < 0; };
-        const int touches = (tipAhead > 0 && n >= tipAheadFrom) ? 2 : 0;
         long issued = 0;
         long expSeq = -1;                                       // sequence number of the exponent DMA of the entry about to run
         if (!out.empty() && reads(out[0])) expSeq = issued++;
@@ -582,7 +577,6 @@ inline bool Walk4Builder::build(const std::vector<Walk4Op>& ops, Walk4Template& 
             }
             if (needed < 0) e.vmwait = 0xFF;                        // (no wait)
             else e.vmwait = safeWaits ? 0 : (uint8_t) walk4_round_wait(issued - (needed + 1));
-            issued += touches;                                  // (every iteration, behind the wait)
             expSeq = -1;
             if (j + 1 < out.size() && reads(out[j + 1])) expSeq = issued++;
             if (e.op >= 0) issued += 2;
@@ -592,12 +586,10 @@ inline bool Walk4Builder::build(const std::vector<Walk4Op>& ops, Walk4Template& 
     for (int w = 0; w < W; ++w) longestFinal = std::max(longestFinal, fin[w].size());
     // frame: leading NOPs, the programs padded to a multiple of the kernel's loop unroll factor, read-ahead NOPs
     const int body = (leadNops + (int) longestFinal + unroll - 1) / unroll * unroll;
-    lastTipAhead = (tipAhead > 0 && n >= tipAheadFrom) ? tipAhead : 0;
-    const int tail = lastTipAhead > 0 ? std::max(tailNops, lastTipAhead + 1) : tailNops;
+    const int tail = tailNops;
     const int entries = body + tail;
     t.entries = entries;
     t.tail = tail;
-    t.tipAhead = lastTipAhead;
     t.prog.assign((size_t) W * entries, Walk4Template::Entry());
     for (Walk4Template::Entry& e : t.prog) e.flags = MBAMD_W4_NOP;
     for (int w = 0; w < W; ++w) std::copy(fin[w].begin(), fin[w].end(), t.prog.begin() + (size_t) w * entries + leadNops);

@@ -51,6 +51,22 @@ __device__ __forceinline__ void work(int role, int n, float* sink, float* lds)
             for (int u = 0; u < 16; ++u) x += lds[(lane + u * 64 + (int) x) & 4095];
         }
         if (x == 123.456f) sink[lane] = x;
+    } else if (role == 7 || role == 8) {
+        v16 acc = {};
+        float a = lane * 1e-3f, b = 1.0f;
+        float x0 = lane * 1e-3f, x1 = x0 + 1.0f, x2 = x0 + 2.0f, x3 = x0 + 3.0f;
+        for (int i = 0; i < n; ++i) {
+#pragma unroll
+            for (int u = 0; u < 16; ++u) {
+                if (role == 7) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0);
+                x0 = __builtin_fmaf(x0, 1.000001f, 1e-7f); x1 = __builtin_fmaf(x1, 1.000001f, 1e-7f);
+                x2 = __builtin_fmaf(x2, 1.000001f, 1e-7f); x3 = __builtin_fmaf(x3, 1.000001f, 1e-7f);
+                x0 = __builtin_fmaf(x0, 1.000001f, 1e-7f); x1 = __builtin_fmaf(x1, 1.000001f, 1e-7f);
+                x2 = __builtin_fmaf(x2, 1.000001f, 1e-7f); x3 = __builtin_fmaf(x3, 1.000001f, 1e-7f);
+                asm volatile("" : "+v"(x0), "+v"(x1), "+v"(x2), "+v"(x3));
+            }
+        }
+        if (acc[0] + x0 + x1 + x2 + x3 == 123.456f) sink[lane] = acc[3];
     } else if (role == 6) {
         float x = lane * 1e-3f;
         unsigned s = __builtin_amdgcn_readfirstlane(n);
@@ -89,8 +105,8 @@ int main()
     float* sink; long long* out;
     hipMalloc(&sink, 4096); hipMalloc(&out, blocks * 8 * 2 * sizeof(long long));
     std::vector<long long> h(blocks * 8 * 2);
-    const char* names[] = {"idle", "mfma dependent chain", "mfma two chains", "valu chain", "salu loop", "lds reads", "valu+salu"};
-    const int cases[][4] = {{1, 6, 0, 3}, {1, 6, 3, 0}, {1, 6, 0, 0}, {1, 3, 0, 3}, {1, 5, 0, 3}, {1, 1, 1, 0}, {1, 1, 0, 0}};
+    const char* names[] = {"idle", "mfma dependent chain", "mfma two chains", "valu chain", "salu loop", "lds reads", "valu+salu", "mfma + 8 valu between", "the 8 valu alone"};
+    const int cases[][4] = {{1, 0, 0, 0}, {8, 0, 0, 0}, {7, 0, 0, 0}, {7, 7, 0, 0}, {7, 8, 0, 0}};
     printf("start\n"); fflush(stdout);
     for (auto& c : cases) {
         for (int rep = 0; rep < 2; ++rep) {
