@@ -199,7 +199,7 @@ def mpi_mcmc(nranks, emulate=False, full=False):
     devices = {}                                          # MPI rank -> PCI bus ids of the GPUs its engine instances were created on
 
     def wall(text):
-        out, w = refrun.run_mb(binary, text, timeout=3000, argv_prefix=[launcher, "-n", str(nranks)], env={"MBAMD_REPORT_DEVICE": "1"})
+        out, w = refrun.run_mb(binary, text, timeout=600, argv_prefix=[launcher, "-n", str(nranks)], env={"MBAMD_REPORT_DEVICE": "1"})
         if "Analysis completed" not in out:
             raise RuntimeError(out[-1500:])
         for line in out.splitlines():
@@ -216,7 +216,7 @@ def mpi_mcmc(nranks, emulate=False, full=False):
     if emulate:
         st = mbdata.synthetic_states(8, 60, 4, 11, 0.15, 0.0)
         tr = mbtree.random_tree(8, 12, brlen=0.05)
-        dna = ("EMULATED tiny DNA, nchains=4", st, tr, 4, (20, 60))
+        dna = ("EMULATED tiny DNA, nchains=%d" % max(4, nranks), st, tr, max(4, nranks), (20, 60))
         cod = None
     else:
         with open(os.path.join(GOLD, ("bench_c4" if full else "bench_c2") + ".json")) as fh:
@@ -507,7 +507,7 @@ def pattern_sharded(args, cfg, steps, warmup, rank, local_rank, world, dist, dev
     case, kind, desc = CONFIGS[cfg]
     with open(os.path.join(GOLD, case + ".json")) as fh:
         gold = json.load(fh)
-    div = synthetic_division(kind, 16, 200, seed=3, tree_seed=4, golden_dir=GOLD) if emulate else division_from_golden(GOLD, case)
+    div = synthetic_division(kind, 16, max(200, 96 * world), seed=3, tree_seed=4, golden_dir=GOLD) if emulate else division_from_golden(GOLD, case)
     P, N = div.npatterns, div.ntaxa
     blocks = (P + 63) // 64                              # whole 64-pattern blocks per rank, the remainder to the last ranks
     lo = min(P, (blocks * rank // world) * 64)
@@ -522,10 +522,24 @@ def pattern_sharded(args, cfg, steps, warmup, rank, local_rank, world, dist, dev
     div.tip_partials = [None if t is None else t[lo:hi].copy() for t in div.tip_partials]
     if div.inv_condlikes is not None:
         div.inv_condlikes = div.inv_condlikes[lo:hi].copy()
-    bd = lk.BeagleDivision(div, lib, nchains=1, scaling=lk.MB_BEAGLE_SCALE_ALWAYS, resource=0 if emulate else local_rank)
-    bd.LogLike(0)
-    bd.AcceptMove(0)
-    evals = [lk.record_evaluation(bd), lk.record_evaluation(bd)]
+    # set-up is rank-local and may fail on one rank only (an empty block, no memory): the ranks agree on going ahead BEFORE the
+    # first collective of the timed loop, or they all return the error -- never some of them inside an all-reduce the others skipped
+    bd, evals, problem = None, None, None
+    try:
+        if hi <= lo:
+            raise RuntimeError("rank %d of %d has no site patterns (%d patterns in 64-pattern blocks)" % (rank, world, P))
+        bd = lk.BeagleDivision(div, lib, nchains=1, scaling=lk.MB_BEAGLE_SCALE_ALWAYS, resource=0 if emulate else local_rank)
+        bd.LogLike(0)
+        bd.AcceptMove(0)
+        evals = [lk.record_evaluation(bd), lk.record_evaluation(bd)]
+    except Exception as exc:
+        problem = repr(exc)[:300]
+    okflag = torch.tensor([0.0 if problem else 1.0], dtype=torch.float64, device=device)
+    dist.all_reduce(okflag, op=dist.ReduceOp.MIN)
+    if float(okflag.item()) == 0.0:
+        if bd is not None:
+            bd.finalize()
+        return {"error": problem or "set-up failed on another rank"} if rank == 0 else None
     buf = torch.zeros(1, dtype=torch.float64, device=device)
     # The block's sum never visits the host on its own: the evaluation is left pending (mbamdSetDeferredResult), the engine adds its
     # block sums up on the device into `buf` and orders torch's stream behind that (mbamdReduceLogLikelihood), RCCL all-reduces `buf`,
@@ -592,6 +606,9 @@ def main():
                          "rank 0 drives all devices, the other ranks idle)")
     ap.add_argument("--no-mpi", action="store_true", help="skip the MPI-build MCMC measurement (mbamd_mpirun -n N mb_amd_mpi_pars)")
     ap.add_argument("--mpi-full", action="store_true", help="the MPI measurement's DNA analysis on the 1000 x 50000 alignment (minutes of start-up)")
+    ap.add_argument("--secondary-timeout", type=float, default=1500.0,
+                    help="N > 1: seconds the secondary modes (pattern-sharded chain, MPI-build MCMC) may take together before every rank "
+                         "leaves and rank 0 prints the line with the modes that finished (0: no limit)")
     ap.add_argument("--emulate", action="store_true",
                     help="TEST ONLY: run the control flow on the CPU (host-emulation engine, gloo, tiny workload); "
                          "the JSON line is marked invalid")
@@ -607,9 +624,12 @@ def main():
     emulate = args.emulate
     if not emulate and not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the engine has no CPU path")
-    device = torch.device("cpu") if emulate else torch.device("cuda", local_rank)
+    # local rank -> device: the launcher may show every rank all GPUs (the usual case: device = local rank) or one each
+    # (HIP_VISIBLE_DEVICES per rank: device 0); either way the PCI bus ids gathered below must be distinct, or nothing is reported
+    dev_index = 0 if emulate else local_rank % max(1, torch.cuda.device_count())
+    device = torch.device("cpu") if emulate else torch.device("cuda", dev_index)
     if not emulate:
-        torch.cuda.set_device(local_rank)
+        torch.cuda.set_device(dev_index)
     dist = None
     if world > 1:
         import torch.distributed as dist_
@@ -643,12 +663,12 @@ def main():
             if len(set(out["instance_devices"])) != world and not emulate:
                 raise SystemExit("bench.py --shard: the %d shards of the instance sit on %s" % (world, out["instance_devices"]))
     else:
-        out = measure(args, args.config, args.steps, args.warmup, rank, local_rank, world, dist, device, emulate, lib,
+        out = measure(args, args.config, args.steps, args.warmup, rank, dev_index, world, dist, device, emulate, lib,
                       not args.no_cpu_baseline)
     if world > 1 and dist is not None:
         # which physical GPU every rank computes on (PCI bus id of its resource): a scaling line whose ranks share a device is
         # not a scaling line -- refuse it instead of reporting it
-        mine = (("emu:rank%d" % rank) if emulate else lib.pci_bus_id(local_rank)).encode()[:63]
+        mine = (("emu:rank%d" % rank) if emulate else lib.pci_bus_id(dev_index)).encode()[:63]
         ids = torch.zeros(world, 64, dtype=torch.uint8, device=device)
         ids[rank, :len(mine)] = torch.tensor(list(mine), dtype=torch.uint8, device=device)
         dist.all_reduce(ids, op=dist.ReduceOp.SUM)
@@ -657,9 +677,26 @@ def main():
             raise SystemExit("bench.py --gpus %d: ranks share a device (%s): refusing to report a scaling number" % (world, names))
         if rank == 0 and out is not None:
             out["ranks_devices"] = names
+    # The primary measurement is done.  What follows at N > 1 (pattern-sharded chain, the MPI-build MCMC) are secondary modes nobody
+    # can debug on an 8-GPU node after the fact: each is bounded, and if one hangs (a collective that never completes, a child
+    # process that never returns) every rank leaves after --secondary-timeout seconds and rank 0 prints the line with what finished.
+    watchdog = None
+    if world > 1 and dist is not None and args.secondary_timeout > 0:
+        import threading
+
+        def bail():
+            if rank == 0 and out is not None:
+                out["timed_out"] = [m for m in ("pattern_sharded", "mpi_mcmc") if m not in out and not (m == "pattern_sharded" and args.shard) and not (m == "mpi_mcmc" and args.no_mpi)]
+                out["summary"] = summary_of(out)
+                print(json.dumps(out), flush=True)
+            _rank_log(rank, "secondary modes exceeded %g s: leaving" % args.secondary_timeout)
+            os._exit(0)
+        watchdog = threading.Timer(args.secondary_timeout, bail)
+        watchdog.daemon = True
+        watchdog.start()
     if world > 1 and not args.shard and dist is not None:
         try:                                     # (collective: every rank takes part; failures are reported, not fatal)
-            ps = pattern_sharded(args, args.config, args.steps, args.warmup, rank, local_rank, world, dist, device, emulate, lib)
+            ps = pattern_sharded(args, args.config, args.steps, args.warmup, rank, dev_index, world, dist, device, emulate, lib)
         except AssertionError:
             raise
         except Exception as exc:
@@ -678,7 +715,7 @@ def main():
                 if other == args.config:
                     continue
                 try:
-                    out["also"].append(measure(args, other, max(args.steps, 200), args.warmup, 0, local_rank, 1, None, device,
+                    out["also"].append(measure(args, other, max(args.steps, 200), args.warmup, 0, dev_index, 1, None, device,
                                                False, lib, not args.no_cpu_baseline, verbose=False))
                     if fill:
                         out["also"][-1]["roofline"]["box_write_stream_GBs"] = fill
@@ -703,13 +740,32 @@ def main():
             out["mpi_mcmc"] = mpi_mcmc(world, emulate=emulate, full=args.mpi_full)
         except Exception as exc:
             out["mpi_mcmc"] = {"error": repr(exc)[:600]}
+    if watchdog is not None:
+        watchdog.cancel()
     if rank == 0:
         out["summary"] = summary_of(out)
-        print(json.dumps(out))
+        print(json.dumps(out), flush=True)
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
 
 
+def _rank_log(rank, text):
+    """A line for this rank under gpurun_out/ (scratch; merged back by gpurun): what a failed multi-GPU run leaves behind."""
+    try:
+        d = os.path.join(ROOT, "gpurun_out")
+        os.makedirs(d, exist_ok=True)
+        with open(os.path.join(d, "bench_rank%d.log" % rank), "a") as fh:
+            fh.write(text.rstrip() + "\n")
+    except OSError:
+        pass
+
+
 if __name__ == "__main__":
-    main()
+    try:
+        main()
+    except BaseException as exc:                     # (SystemExit included: a refusal to report is worth a line per rank too)
+        if not (isinstance(exc, SystemExit) and exc.code in (0, None)):
+            import traceback
+            _rank_log(int(os.environ.get("RANK", "0")), "rank %s failed:\n%s" % (os.environ.get("RANK", "0"), traceback.format_exc()))
+        raise

@@ -62,3 +62,42 @@ def test_two_ranks_sharded():
     d = _json_line(res.stdout)
     assert d["n_gpus"] == 2 and d["scaling"] == "strong" and d["config"]["chains"] == 1 and "shards" in d["config"]["parallelism"]
     assert len(d["instance_devices"]) == 2 and len(d["ranks_devices"]) == 2       # one child engine per shard, each reporting its device
+
+
+def test_eight_ranks():
+    """The launch the driver uses on an 8-GPU node, emulated (eight processes, gloo, host-emulation engine): chain-parallel replay,
+    the pattern-sharded chain and -- where the reference binaries were built -- the MPI-build MCMC on eight ranks; the JSON the
+    driver parses, a device per rank, the compact summary at the end of the line."""
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="1")
+    res = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "8",
+                          "--master-addr", "127.0.0.1", "--master-port", "29677", "bench.py", "--gpus", "8",
+                          "--steps", "2", "--warmup", "1", "--emulate"], cwd=ROOT, env=env, capture_output=True,
+                         text=True, timeout=1500)
+    assert res.returncode == 0, (res.stdout + res.stderr)[-3000:]
+    d = _json_line(res.stdout)
+    assert KEYS <= set(d) and d["n_gpus"] == 8 and d["scaling"] == "weak" and d["config"]["chains"] == 8 and d["value"] > 0
+    assert d["ranks_devices"] == ["emu:rank%d" % r for r in range(8)]
+    ps = d["pattern_sharded"]
+    assert "error" not in ps, ps
+    assert ps["n_gpus"] == 8 and ps["scaling"] == "strong" and abs(ps["lnL"] - ps["lnL_reference_fp64"]) <= 2e-6 * abs(ps["lnL"])
+    assert "timed_out" not in d and list(d)[-1] == "summary" and "columns" in d["summary"]
+    if os.path.exists(os.path.join(ROOT, "oracle", "_ref", "mb_emu_mpi")) and os.path.exists(os.path.join(ROOT, "oracle", "_ref", "mbamd_mpirun")):
+        m = d["mpi_mcmc"]
+        assert "error" not in m, m
+        assert m["ranks"] == 8 and m["cases"][0]["chains"] == 8 and m["cases"][0]["generations_per_s"] > 0, m
+        assert set(m["devices_of_rank"]) == {str(r) for r in range(8)}, m
+
+
+def test_secondary_modes_are_bounded():
+    """A secondary mode that does not come back must not cost the scaling line: with a 20 ms budget (the emulated MPI run
+    and the pattern-sharded chain taking longer) every rank leaves, rank 0 prints the primary measurement and says what it gave up on."""
+    if not (os.path.exists(os.path.join(ROOT, "oracle", "_ref", "mb_emu_mpi")) and os.path.exists(os.path.join(ROOT, "oracle", "_ref", "mbamd_mpirun"))):
+        import pytest
+        pytest.skip("needs the reference's MPI build on the shim (oracle/_ref)")
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="1")
+    res = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                          "--master-addr", "127.0.0.1", "--master-port", "29679", "bench.py", "--gpus", "2",
+                          "--steps", "2", "--warmup", "1", "--emulate", "--secondary-timeout", "0.02"], cwd=ROOT, env=env, capture_output=True,
+                         text=True, timeout=900)
+    d = _json_line(res.stdout)
+    assert d["n_gpus"] == 2 and d["value"] > 0 and d.get("timed_out"), d.get("timed_out")
