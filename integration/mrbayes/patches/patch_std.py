@@ -36,6 +36,12 @@ def patch_mcmc(text):
                    "                (void) MbamdStdMaterialise (coldId, d);\n"
                    "                for (i=j=tree->nIntNodes - 1; i>=0; i--)\n",
                    1, "final-pass loop of PrintStates")
+    # FreeChainMemory: the binding's instances and class tables go with the reference's own chain memory -- a second mcmc / execute
+    # of the session (other chains, taxa, characters, categories, priors) looks at the model again
+    text = replace(text,
+                   "void FreeChainMemory (void)\n{\n    int         i, j, k, nRates;\n    ModelInfo   *m;\n",
+                   "void FreeChainMemory (void)\n{\n    int         i, j, k, nRates;\n    ModelInfo   *m;\n\n    MbamdStdFinalize ();\n",
+                   1, "top of FreeChainMemory")
     return text
 
 

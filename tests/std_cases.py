@@ -40,7 +40,7 @@ def _clades(newick):
 
 
 def synthetic_nexus(ntax, nchar, beagle, seed=11, coding="variable", rates="gamma", maxstates=5, ordered=(), p_missing=0.04, p_poly=0.0, ngen=1, alpha="fixed(0.7)",
-                    ancstates=0):
+                    ancstates=0, symdir=None, nbetacat=None, again=None):
     """`ancstates` > 0: that many hard constraints taken from the tree and `report ancstates=yes` (the .p file then carries the
     state probabilities of every character at the constrained nodes)."""
     # ntax x nchar characters with 2 ... maxstates states each (every state of a character occurs: MrBayes takes a character's
@@ -82,11 +82,18 @@ def synthetic_nexus(ntax, nchar, beagle, seed=11, coding="variable", rates="gamm
     s += " lset coding=%s rates=%s%s;\n" % (coding, rates, " ngammacat=4" if rates == "gamma" else "")
     if rates == "gamma":
         s += " prset shapepr=%s;\n" % alpha
+    if symdir:                                   # unequal state frequencies: a symmetric Dirichlet / beta prior, discretised for binary characters
+        s += " prset symdirihyperpr=%s;\n" % symdir
+    if nbetacat:
+        s += " lset nbetacat=%d;\n" % nbetacat
     if ancstates:
         cl = [c for c in _clades(tr.to_newick(names)) if 2 <= len(c) <= max(2, ntax // 2)][:ancstates]
         for i, c in enumerate(cl):
             s += " constraint c%d = %s;\n" % (i + 1, " ".join(c))
         s += " prset topologypr=constraints(%s);\n report ancstates=yes;\n" % ",".join("c%d" % (i + 1) for i in range(len(cl)))
+    if again:                                    # a SECOND analysis in the same session, under other settings (the binding's tables are per analysis)
+        t = _tail(beagle, ngen)
+        return s + t[:t.rindex("end;")] + " %s\n startvals tau=t V=t;\n mcmc ngen=%d nchains=1 nruns=1 samplefreq=1 printfreq=1 filename=y;\nend;\n" % (again, ngen)
     return s + _tail(beagle, ngen)
 
 
@@ -97,6 +104,14 @@ SYNTHETIC = {
     "informative": dict(ntax=9, nchar=60, coding="informative"),
     "binary_only": dict(ntax=14, nchar=90, maxstates=2),
     "ten_states": dict(ntax=24, nchar=70, maxstates=10, p_missing=0.02),
+    # unequal state frequencies of binary characters: the beta categories of the prior are a mixture (numBetaCats = 5; and 3)
+    "binary_symdir_fixed": dict(ntax=14, nchar=90, maxstates=2, symdir="fixed(1.0)"),
+    "binary_symdir_exponential": dict(ntax=12, nchar=70, maxstates=2, symdir="exponential(1.0)", rates="equal", nbetacat=3, coding="all"),
+}
+# the same session runs a second analysis under other settings: other rate categories / another prior on the frequencies
+SECOND_ANALYSIS = {
+    "more_categories": dict(ntax=10, nchar=70, again="lset ngammacat=6; prset shapepr=fixed(0.25);"),
+    "frequencies_become_unequal": dict(ntax=12, nchar=80, maxstates=2, again="prset symdirihyperpr=fixed(2.0);"),
 }
 ANCSTATES = {       # report ancstates=yes on a standard division (CondLikeUp_Std / PrintAncStates_Std on host arrays filled from the device)
     "anc_gamma": dict(ntax=12, nchar=80, ancstates=2),
@@ -118,4 +133,23 @@ def cynmix_nexus(fix, beagle, coding="variable", rates="gamma", ngen=1):
     s += " lset coding=%s rates=%s%s;\n" % (coding, rates, " ngammacat=4" if rates == "gamma" else "")
     if rates == "gamma":
         s += " prset shapepr=fixed(0.55);\n"
+    return s + _tail(beagle, ngen)
+
+
+MCMC_SYMDIR = dict(ntax=12, nchar=120, maxstates=2, ngen=400, alpha="exponential(1.0)", symdir="exponential(1.0)")
+HYM_CONFIGS = {"mk_gamma_variable": dict(coding="variable", rates="gamma")}
+
+
+def hymfossil_nexus(fix, beagle, coding="variable", rates="gamma", ngen=1):
+    """The morphology of examples/hymfossil.nex (353 characters, 2 ... 7 states, 44 of them ordered, some excluded) on a fixed tree."""
+    ntax = len(fix["names"])
+    tr = mbtree.random_tree(ntax, 13, brlen=0.05)
+    s = "#NEXUS\nbegin data;\n dimensions ntax=%d nchar=%d;\n format datatype=standard gap=- missing=?;\n matrix\n" % (ntax, fix["nchar"])
+    for nm, row in zip(fix["names"], fix["rows"]):
+        s += "%s %s\n" % (nm, row)
+    s += ";\nend;\nbegin trees;\n tree t = [&U] %s\nend;\nbegin mrbayes;\n set autoclose=yes nowarnings=yes seed=3 swapseed=3 precision=15;\n" % tr.to_newick(fix["names"])
+    s += " ctype ordered: %s;\n exclude %s;\n" % (" ".join(str(x) for x in fix["ordered"]), " ".join(str(x) for x in fix["excluded"]))
+    s += " lset coding=%s rates=%s%s;\n" % (coding, rates, " ngammacat=4" if rates == "gamma" else "")
+    if rates == "gamma":
+        s += " prset shapepr=fixed(0.8);\n"
     return s + _tail(beagle, ngen)

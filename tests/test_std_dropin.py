@@ -73,6 +73,44 @@ def _check_cynmix(binary, marker):
         assert abs(live - want) <= 1e-9 * abs(want)            # (the fixture is what the reference prints here, too)
 
 
+def _check_hymfossil(binary, marker):
+    """The morphology of the reference's examples/hymfossil.nex (fixture tests/golden/std_hymfossil.json, tools/gen_std_fixture.py:
+    107 taxa x 353 characters of 2 ... 7 states, 44 ordered, 10 excluded) -- nine transition-matrix classes."""
+    _need(binary, os.path.join(REF, "mb_scalar"))
+    with open(os.path.join(refrun.ROOT, "tests", "golden", "std_hymfossil.json")) as fh:
+        fix = json.load(fh)
+    for key, kw in std_cases.HYM_CONFIGS.items():
+        for scaling in ("always", "dynamic"):
+            got, out = _lnl(binary, std_cases.hymfossil_nexus(fix, scaling, **kw))
+            _served(out, marker)
+            assert "9 transition-matrix classes" in out, out[-1500:]
+            want = fix["lnL_mb_scalar"][key]
+            assert abs(got - want) <= 1e-5 * abs(want), (key, scaling, got, want)
+
+
+def _check_second_analysis(case, binary, marker):
+    """Two analyses in one MrBayes session, the second under other settings: the binding's instances and class tables go with the
+    reference's chain memory (FreeChainMemory) and are rebuilt -- both results are the scalar build's."""
+    _need(binary, os.path.join(REF, "mb_scalar"))
+    kw = std_cases.SECOND_ANALYSIS[case]
+
+    def both(b, beagle, env=None):
+        out, _, files = refrun.run_mb(b, std_cases.synthetic_nexus(beagle=beagle, **kw), keep=("x.p", "y.p"), env=env)
+        assert out.count("Analysis completed") == 2 and "x.p" in files and "y.p" in files, out[-2500:]
+        vals = []
+        for f in ("x.p", "y.p"):
+            rows = [l.split("\t") for l in files[f].splitlines() if l and not l.startswith("[")]
+            i = rows[0].index("LnL") if "LnL" in rows[0] else rows[0].index("lnLike")
+            vals.append(float(rows[1][i]))
+        return vals, out
+    want, _ = both(os.path.join(REF, "mb_scalar"), None)
+    got, out = both(binary, "always")
+    assert out.count("(standard data):") == 2 and marker in out, out[-2500:]        # set up twice: once per analysis
+    assert abs(want[0] - want[1]) > 1e-3 * abs(want[0])                              # (the second analysis IS another model)
+    for g, w in zip(got, want):
+        assert abs(g - w) <= 1e-5 * abs(w), (case, got, want)
+
+
 def _p_row(binary, text, env=None):
     """header and first sample row of the run's .p file"""
     out, _, files = refrun.run_mb(binary, text, keep=("x.p",), env=env)
@@ -111,11 +149,12 @@ def _samples(binary, text, env=None):
         return [dict(zip(cols, (float(x) for x in l.split("\t")))) for l in lines[1:]], res.stdout
 
 
-def _check_mcmc(binary, marker):
+def _check_mcmc(binary, marker, kw=None):
     """Default moves (topology, branch lengths, the gamma shape) for 400 generations: accepted and rejected proposals flip the
-    reference's index tables, which name the engine's buffers -- the sampled log-likelihoods are the native chain's."""
+    reference's index tables, which name the engine's buffers -- the sampled log-likelihoods are the native chain's.
+    With kw: binary characters under symdirihyperpr=exponential(1): the hyperparameter moves, the beta categories' frequencies with it."""
     _need(binary)
-    kw = dict(ntax=12, nchar=150, maxstates=5, p_poly=0.02, ngen=400, alpha="exponential(1.0)")
+    kw = kw or dict(ntax=12, nchar=150, maxstates=5, p_poly=0.02, ngen=400, alpha="exponential(1.0)")
     # (the oracle is the SAME binary with the binding switched off: a BEAGLE build of the reference consumes random numbers the
     #  plain build does not, so mb_scalar walks another chain; generation 0 is pinned against mb_scalar by the other tests)
     want, wout = _samples(binary, std_cases.synthetic_nexus(beagle="always", **kw), env={"MBAMD_DEVICE_STD": "0"})
@@ -149,6 +188,23 @@ def test_standard_data_ancestral_states_on_emulated_engine(case):
 def test_standard_data_mcmc_on_emulated_engine():
     _build_emu()
     _check_mcmc(os.path.join(REF, "mb_emu_std"), "HOST EMULATION")
+
+
+def test_standard_data_mcmc_with_moving_frequencies_on_emulated_engine():
+    _build_emu()
+    _check_mcmc(os.path.join(REF, "mb_emu_std"), "HOST EMULATION", kw=std_cases.MCMC_SYMDIR)
+
+
+def test_hymfossil_morphology_on_emulated_engine():
+    _build_emu()
+    _check_hymfossil(os.path.join(REF, "mb_emu_std"), "HOST EMULATION")
+
+
+@pytest.mark.parametrize("case", sorted(std_cases.SECOND_ANALYSIS))
+def test_second_analysis_in_a_session_on_emulated_engine(case):
+    """the binding's state was decided once per process."""
+    _build_emu()
+    _check_second_analysis(case, os.path.join(REF, "mb_emu_std"), "HOST EMULATION")
 
 
 def test_cynmix_as_shipped_all_partitions_on_the_emulated_engine():
@@ -243,9 +299,10 @@ def test_hymfossil_as_shipped_all_partitions_on_the_emulated_engine():
     assert all(abs(x - y) <= 1e-5 * abs(y) for x, y in zip(a, c)), (a, c)
 
 
-def test_unequal_frequencies_stay_on_the_host():
-    """symdirihyperpr other than fixed(infinity) (beta categories for binary characters, per-character eigen-systems): refused with a
-    printed reason, the reference's own kernels run."""
+def test_unequal_frequencies_of_multistate_characters_stay_on_the_host():
+    """symdirihyperpr other than fixed(infinity) with characters of more than two states (an eigen-system per character): refused
+    with a printed reason, the reference's own kernels run.  (Binary characters under such a prior ARE served: the
+    binary_symdir_* cases.)"""
     _build_emu()
     b = os.path.join(REF, "mb_emu_std")
     kw = std_cases.SYNTHETIC["mk_gamma_variable"]
@@ -275,6 +332,7 @@ def test_patch_site_is_pinned():
         sys.path.remove(pdir)
     assert out.count("MbamdStdServes (m) == YES") == 1 and '#include "mbamd_std_glue.h"' in out
     assert out2.count("MbamdStdMaterialise (coldId, d)") == 1 and '#include "mbamd_std_glue.h"' in out2
+    assert out2.count("MbamdStdFinalize ();") == 1
 
 
 @pytest.mark.gpu
@@ -308,3 +366,19 @@ def test_standard_data_100x2000_on_mi355x():
 @pytest.mark.gpu
 def test_standard_data_mcmc_on_mi355x():
     _check_mcmc(os.path.join(REF, "mb_amd_std"), "gfx950")
+
+
+@pytest.mark.gpu
+def test_hymfossil_morphology_on_mi355x():
+    _check_hymfossil(os.path.join(REF, "mb_amd_std"), "gfx950")
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", sorted(std_cases.SECOND_ANALYSIS))
+def test_second_analysis_in_a_session_on_mi355x(case):
+    _check_second_analysis(case, os.path.join(REF, "mb_amd_std"), "gfx950")
+
+
+@pytest.mark.gpu
+def test_standard_data_mcmc_with_moving_frequencies_on_mi355x():
+    _check_mcmc(os.path.join(REF, "mb_amd_std"), "gfx950", kw=std_cases.MCMC_SYMDIR)

@@ -41,5 +41,54 @@ def main():
     print(out)
 
 
+def hymfossil():
+    """tests/golden/std_hymfossil.json: the morphology (characters 1-353, datatype standard) of examples/hymfossil.nex -- its taxa that
+    have any morphological data --, the ordered and excluded characters its MrBayes block names, and what the reference's scalar build
+    prints for it on a fixed tree."""
+    import re
+    with open("/root/reference/examples/hymfossil.nex") as fh:
+        text = fh.read()
+    body = text[text.lower().index("matrix") + 6:]
+    body = body[:body.index(";")]
+    body = re.sub(r"\[[^\]]*\]", "", body)
+    seqs, order = {}, []
+    for line in body.split("\n"):
+        f = line.split()
+        if len(f) < 2:
+            continue
+        if f[0] not in seqs:
+            seqs[f[0]] = ""
+            order.append(f[0])
+        if std_cases.nchar_of(seqs[f[0]]) < 353:
+            seqs[f[0]] += "".join(f[1:])
+    rows = []
+    for n in order:
+        r, k, i = seqs[n], 0, 0
+        while k < 353:                              # the first 353 characters (a polymorphism in braces is one)
+            if r[i] in "{(":
+                i = r.index("}" if r[i] == "{" else ")", i)
+            i += 1
+            k += 1
+        rows.append(r[:i])
+    names = [n for n, r in zip(order, rows) if set(r) - set("?-")]
+    rows = [r for r in rows if set(r) - set("?-")]
+    block = text[text.lower().index("begin mrbayes"):]
+    def charset(name):
+        m = re.search(r"charset\s+%s\s*=([^;]*);" % name, block)
+        return [int(x) for x in m.group(1).split()]
+    fix = {"source": "examples/hymfossil.nex, characters 1-353 (Ronquist et al. 2012, Syst. Biol. 61:973-999)", "names": names, "rows": rows, "nchar": 353,
+           "ordered": charset("morph_ordered"), "excluded": charset("morph_excluded") + charset("morph_constant")}
+    out = {}
+    for key, kw in std_cases.HYM_CONFIGS.items():
+        o, row = refrun.run_mb_with_samples(os.path.join(ROOT, "oracle", "_ref", "mb_scalar"), std_cases.hymfossil_nexus(fix, None, **kw))
+        assert "Analysis completed" in o, o[-1500:]
+        out[key] = row["LnL"] if "LnL" in row else row["lnLike"]
+    fix["lnL_mb_scalar"] = out
+    with open(os.path.join(ROOT, "tests", "golden", "std_hymfossil.json"), "w") as fh:
+        json.dump(fix, fh, indent=0)
+    print(len(names), "taxa", out)
+
+
 if __name__ == "__main__":
     main()
+    hymfossil()

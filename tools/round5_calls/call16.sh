@@ -1,0 +1,17 @@
+#!/bin/bash
+# round 5, call 16: standard data with the matrices on the device, beta categories, a second analysis per session -- GPU tests and the 100 x 2000 soak
+cd "$GRAFT_REPO_ROOT"; mkdir -p gpurun_out; export TMPDIR=/tmp
+timeout 900 python -m pytest tests/test_std_dropin.py -x -q -m gpu > gpurun_out/r5c16_pytest.log 2>&1; echo "pytest rc $?" >> gpurun_out/r5c16_pytest.log
+tail -5 gpurun_out/r5c16_pytest.log
+timeout 900 python - <<'PY' 2>&1 | tee gpurun_out/r5c16_soak.log
+import os, sys, re
+sys.path.insert(0, os.getcwd())
+from tests import std_cases
+from tools import refrun
+kw = dict(std_cases.BIG, ngen=20000)
+nex = std_cases.synthetic_nexus(beagle="dynamic", **kw).replace("nchains=1", "nchains=2").replace(" startvals tau=t V=t;\n", "")
+for env in ({"MBAMD_STATS": "1"}, {"MBAMD_DEVICE_STD": "0"}):
+    out, wall = refrun.run_mb(os.path.join(os.getcwd(), "oracle", "_ref", "mb_amd_full"), nex, timeout=850, env=env)
+    print(env, "completed" if "Analysis completed" in out else "FAILED", "wall %.1f s" % wall)
+    print("\n".join(l for l in out.splitlines() if re.match(r"\s+20000 -- ", l) or "standard data" in l or "rror" in l or "CPU time" in l)[:700])
+PY
