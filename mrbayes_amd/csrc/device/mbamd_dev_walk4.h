@@ -24,6 +24,28 @@ __device__ __forceinline__ Walk4Entry walk4_load_entry(const Walk4Entry* p)
     e.ctl = v[0]; e.dst = v[1]; e.c1 = v[2]; e.c2 = v[3]; e.m1 = v[4]; e.m2 = v[5]; e.ewrite = v[6]; e.eread = v[7];
     return e;
 }
+// an entry of a program that the wave copied into LDS: every lane reads the same 32 bytes, the first lane's copy goes to scalar registers
+// (k_path4: a program in the kernel arguments sits in host-visible memory -- read through the scalar cache entry by entry, every other
+//  entry was a round trip to it; one vector load per 32 entries brings the whole program in)
+__device__ __forceinline__ Walk4Entry walk4_entry_from_lds(const Walk4Entry* p)
+{
+    typedef unsigned u4v __attribute__((ext_vector_type(4)));
+    const u4v a = reinterpret_cast<const u4v*>(p)[0], b = reinterpret_cast<const u4v*>(p)[1];
+    Walk4Entry e;
+    e.ctl = __builtin_amdgcn_readfirstlane(a[0]); e.dst = __builtin_amdgcn_readfirstlane(a[1]);
+    e.c1 = __builtin_amdgcn_readfirstlane(a[2]); e.c2 = __builtin_amdgcn_readfirstlane(a[3]);
+    e.m1 = __builtin_amdgcn_readfirstlane(b[0]); e.m2 = __builtin_amdgcn_readfirstlane(b[1]);
+    e.ewrite = __builtin_amdgcn_readfirstlane(b[2]); e.eread = __builtin_amdgcn_readfirstlane(b[3]);
+    return e;
+}
+// 16 bytes per lane of a program (any memory the device can read, the kernel arguments included) -> LDS
+__device__ __forceinline__ void walk4_program_to_lds(const Walk4Entry* src, Walk4Entry* lds, int entries, unsigned lane)
+{
+    typedef unsigned u4v __attribute__((ext_vector_type(4)));
+    const MBAMD_AS_GLOBAL u4v* s = reinterpret_cast<const MBAMD_AS_GLOBAL u4v*>((uintptr_t) src);
+    u4v* d = reinterpret_cast<u4v*>(lds);
+    for (int i = (int) lane; i < 2 * entries; i += 64) d[i] = s[i];
+}
 __device__ __forceinline__ Walk4Planes walk4_load_planes(const uint64_t* p)
 {
     const ul4v v = *reinterpret_cast<const MBAMD_AS_CONST ul4v*>((uintptr_t) p);

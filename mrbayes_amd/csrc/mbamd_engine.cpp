@@ -157,6 +157,7 @@ struct Plan {
     };
     std::vector<Segment> segments;               // (Walk4Entry index of its program in d_table, geometry)
     std::vector<Walk4Entry> inlineProg;          // 4-state walk: a short single-segment program travels in the kernel arguments instead
+    bool path = false;                           // 4-state walk: the list is a root-ward path -- inlineProg holds k_path4's entries
     int lists = 1;                               // 20/61-state walk: > 1 = the segments are that many independent lists, ONE launch
     std::vector<int> start;                      // general path: first table entry of each dependency level
     bool anyScale = false;
@@ -247,6 +248,8 @@ struct Instance {
     int updatePartialsG(const BeagleOperation* ops, int n, int cumIdx);
     int flushWalkG();
     int runWalkG(const Plan& plan);
+    bool buildPath4(Plan& plan, const BeagleOperation* ops, int n);
+    bool noPath4 = false;                        // MBAMD_NO_PATH4: root-ward paths on k_walk4_t too
     void postResultFlag();
     bool scaleOpsIndependentOfPending(const int* idx, int n, int cumIdx) const;
     uint64_t launchClock = 0, syncedClock = 0;   // launches issued / launches known complete (last stream synchronisation)
@@ -574,6 +577,7 @@ int Instance::create(int tipCount_, int partialsBufferCount, int compactBufferCo
     mfmaWhole = std::getenv("MBAMD_MFMA_WHOLE") != nullptr;
     noDefer = std::getenv("MBAMD_NO_DEFER") != nullptr;
     noInlinePrograms = std::getenv("MBAMD_NO_INLINE_PROGRAMS") != nullptr;
+    noPath4 = std::getenv("MBAMD_NO_PATH4") != nullptr;
     if (const char* e = std::getenv("MBAMD_MFMA_SERIAL")) serialRatio = std::max(0, std::atoi(e));
     noSpine = std::getenv("MBAMD_NO_SPINE") != nullptr;
     if (const char* e = std::getenv("MBAMD_SPINE_WIDTH")) spineWidth = std::max(1, std::atoi(e));
@@ -1534,7 +1538,8 @@ int Instance::updatePartials4(const BeagleOperation* ops, int n, int cumIdx)
         int rc;
         {
             StatTimer st_(ST_PLAN);
-            rc = buildWalk(*plan, ops, n);
+            plan->path = false;
+            rc = buildPath4(*plan, ops, n) ? BEAGLE_SUCCESS : buildWalk(*plan, ops, n);
         }
         if (rc) { plan->hash = 0; plan->key.clear(); return rc; }
     }
@@ -1776,8 +1781,101 @@ int Instance::buildWalk(Plan& plan, const BeagleOperation* ops, int n, const int
     return upload(plan.d_table, w4table.data(), bytes);
 }
 
+// A root-ward path (the list of a move that dirtied one branch) as k_path4's entries: operation i has the result of operation i - 1
+// as one child; its other child -- and both children of operation 0 -- are compact tips or buffers the list does not write; no buffer
+// or exponent buffer is written twice or read after it is written.  Anything else (false) is compiled by buildWalk.
+bool Instance::buildPath4(Plan& plan, const BeagleOperation* ops, int n)
+{
+    if (noPath4 || n < 1 || n > MBAMD_W4_INLINE) return false;
+    const int scratchScale = (int) scale.size();
+    const uint32_t pbuf = (uint32_t) ((size_t) (Ppad / 64) * K), ebuf = (uint32_t) K * 64u, mbuf = (uint32_t) K * 64u;
+    std::vector<Walk4Entry>& prog = plan.inlineProg;
+    prog.assign((size_t) n, Walk4Entry());
+    auto inList = [&](int buf, int upto) { for (int q = 0; q < upto; ++q) if (ops[q].destinationPartials == buf) return true; return false; };
+    for (int i = 0; i < n; ++i) {
+        const BeagleOperation& b = ops[i];
+        if (b.destinationPartials < 0 || b.destinationPartials >= nBuffers || b.child1Partials < 0 || b.child1Partials >= nBuffers ||
+            b.child2Partials < 0 || b.child2Partials >= nBuffers || b.child1TransitionMatrix < 0 || b.child1TransitionMatrix >= nMatrices ||
+            b.child2TransitionMatrix < 0 || b.child2TransitionMatrix >= nMatrices) return false;      // (buildWalk reports it)
+        if (tipStates[b.destinationPartials] || inList(b.destinationPartials, i)) return false;
+        int chain, sib, mchain, msib;
+        if (i == 0) { chain = b.child1Partials; sib = b.child2Partials; mchain = b.child1TransitionMatrix; msib = b.child2TransitionMatrix; }
+        else {
+            const int prev = ops[i - 1].destinationPartials;
+            const bool one = b.child1Partials == prev, two = b.child2Partials == prev;
+            if (one == two) return false;                                  // (neither, or both: not a path)
+            chain = one ? b.child1Partials : b.child2Partials; sib = one ? b.child2Partials : b.child1Partials;
+            mchain = one ? b.child1TransitionMatrix : b.child2TransitionMatrix; msib = one ? b.child2TransitionMatrix : b.child1TransitionMatrix;
+        }
+        // what comes from outside must not be written anywhere in the list (before: a second dependency; after: a hazard)
+        for (int ext : {sib, i == 0 ? chain : -1})
+            if (ext >= 0) {
+                if (inList(ext, n)) return false;
+                if (!tipStates[ext] && !valid[ext]) return false;
+            }
+        Walk4Entry& e = prog[(size_t) i];
+        std::memset(&e, 0, sizeof e);
+        uint32_t flags = 0, mode = SCALE_NONE;
+        e.dst = (uint32_t) b.destinationPartials * pbuf;
+        if (i == 0) {
+            if (tipStates[chain]) { e.c1 = (uint32_t) chain * 32u; flags |= MBAMD_W4_TIP1; }
+            else e.c1 = (uint32_t) chain * pbuf;
+        }
+        if (tipStates[sib]) { e.c2 = (uint32_t) sib * 32u; flags |= MBAMD_W4_TIP2; }
+        else e.c2 = (uint32_t) sib * pbuf;
+        e.m1 = (uint32_t) mchain * mbuf;
+        e.m2 = (uint32_t) msib * mbuf;
+        e.ewrite = e.eread = (uint32_t) scratchScale * ebuf;
+        if (b.destinationScaleWrite != BEAGLE_OP_NONE) {
+            if (b.destinationScaleWrite < 0 || b.destinationScaleWrite >= nScale) return false;
+            for (int q = 0; q < n; ++q)
+                if (q != i && (ops[q].destinationScaleWrite == b.destinationScaleWrite || ops[q].destinationScaleRead == b.destinationScaleWrite)) return false;
+            mode = SCALE_WRITE;
+            e.ewrite = (uint32_t) b.destinationScaleWrite * ebuf;
+        } else if (b.destinationScaleRead != BEAGLE_OP_NONE) {
+            if (b.destinationScaleRead < 0 || b.destinationScaleRead >= nScale || scaleState[b.destinationScaleRead] == 2) return false;
+            mode = SCALE_READ;
+            e.eread = (uint32_t) b.destinationScaleRead * ebuf;
+        }
+        e.ctl = flags | (mode << 8);
+    }
+    plan.path = true;
+    plan.segments.clear();
+    Plan::Segment sg;
+    sg.first = 0; sg.W = 1; sg.entries = n; sg.nslots = 0; sg.tail = 0;
+    plan.segments.push_back(sg);
+    lastWalkW = 1; lastWalkSlots = 0; lastWalkEntries = n; lastWalkPhases = 1;
+    return true;
+}
+
 int Instance::runWalk(const Plan& plan, int32_t* cum)
 {
+    if (plan.path) {
+        Walk4ArgsInline ai;
+        Walk4Args& a = ai.a;
+        a.prog = nullptr;
+        a.entries = (int) plan.inlineProg.size();
+        a.nslots = 0;
+        a.partials = reinterpret_cast<f4*>(arenaPartials);
+        a.pstride = geom.pstride;
+        a.tips = arenaTips;
+        a.tstride = geom.tstride;
+        a.exps = arenaExp;
+        a.estride = estride;
+        a.matrices = matrices;
+        a.cum = cum;
+        a.cumFresh = walkCumFresh ? 1 : 0;
+        a.K = K;
+        a.Ppad = Ppad;
+        a.nblocks = Ppad / 64;
+        a.tail = 0;
+        std::memcpy(ai.inl, plan.inlineProg.data(), plan.inlineProg.size() * sizeof(Walk4Entry));
+        auto kernel = k_path4<Walk4ArgsInline>;
+        MBAMD_LAUNCH(kernel, walk4_grid(Ppad / 64, K), 64, plan.inlineProg.size() * sizeof(Walk4Entry), stream, ai);
+        HIP_TRY(hipGetLastError());
+        pendingLaunches += 1;
+        return BEAGLE_SUCCESS;
+    }
     for (const Plan::Segment& sg : plan.segments) {
         Walk4Args a;
         a.prog = reinterpret_cast<const Walk4Entry*>(plan.d_table) + sg.first;

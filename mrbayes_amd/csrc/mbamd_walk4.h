@@ -266,5 +266,127 @@ k_walk4_t(ARGS AA)
     }
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------------------------
+// k_path4 -- a ROOT-WARD PATH (round 5): the list of a move that dirtied one branch.  Every operation has the previous result as one
+// child and a "sibling" the list does not write (a compact tip, or a buffer of an earlier launch) as the other:
+//     out_j = rescale ((M1_j out_{j-1}) o (M2_j sib_j)).
+// Only the first factor depends on the chain.  k_walk4_t ran such a program entry by entry -- two matrix loads, a prefetched sibling,
+// two products, a store: ~1 us = 2 200 cycles per operation (profiles/r04_mcmc_fixed_topology.txt: 17-27 operations in 20-22 us), almost
+// all of it the scalar-load round trip of the entry's matrices in front of work that needs the previous result anyway.  Here a wave takes
+// the path in chunks of MBAMD_P4_CHUNK operations and each chunk in two passes:
+//   1. every sibling that lives in HBM and every stored exponent of the chunk is requested back to back (no store sits between them
+//      in the vmcnt order), then the sibling factors F_j = M2_j sib_j are formed -- independent work, the matrices in bursts of four;
+//   2. the chain: out_j = rescale ((M1_j out_{j-1}) o F_j), matrices in bursts of four -- four dependent v_pk_fma_f32 steps, a product,
+//      a maximum, the exponent, two multiplications and a store that nobody waits for.
+// No LDS, no slots, no barrier; F lives in registers.  Same arithmetic, operation by operation, as k_walk4_t: the same bits.
+// Entries (Walk4Entry): c1 = the chain's INPUT (entry 0 only: tip planes or a buffer), c2 = the sibling, m1 / m2 their matrices;
+// ctl: TIP1 (entry 0: the input is a compact tip), TIP2 (the sibling is one), [9:8] the scale mode.  blockDim.x = 64, grid = walk4_grid,
+// dynamic LDS = entries * 32 bytes.
+#define MBAMD_P4_CHUNK 16
+#define MBAMD_P4_GROUP 4         // matrices per burst of scalar loads (4 x 16 scalar registers)
+template <class ARGS>
+__global__ void __launch_bounds__(64)
+k_path4(ARGS AA)
+{
+    const Walk4Args& A = walk4_args(AA);
+    const unsigned lane = threadIdx.x & 63;
+    const unsigned K = (unsigned) A.K;
+    const unsigned xcd = blockIdx.x & 7u, pos = blockIdx.x >> 3;
+    const unsigned blk = (pos / K) * 8u + xcd, k = pos % K;
+    if (blk >= (unsigned) A.nblocks) return;
+    f4* const P0 = A.partials + (size_t) blk * A.pstride + (size_t) k * 64;
+    const uint64_t* const T0 = A.tips + (size_t) blk * A.tstride;
+    int8_t* const E0 = A.exps + (size_t) blk * A.estride + (size_t) k * 64;
+    const float* const M0 = A.matrices + (size_t) k * 16;
+    const int n = A.entries;
+    // the program: from the kernel arguments (host-visible memory) into LDS, one vector load per 32 entries
+    Walk4Entry* const pp = mbd_dyn_lds<Walk4Entry>();
+    walk4_program_to_lds(walk4_program(AA), pp, n, lane);
+    constexpr int C = MBAMD_P4_CHUNK;
+    f4 prev;
+    {
+        const Walk4Entry e0 = walk4_entry_from_lds(pp);
+        if (e0.ctl & MBAMD_W4_TIP1) prev = walk4_tip_vector(walk4_load_planes(walk4_at(T0, e0.c1)), lane);
+        else prev = walk4_at_kib(P0, e0.c1)[lane];
+    }
+    int cum_e = 0;
+    for (int base = 0; base < n; base += C) {
+        const int cnt = n - base < C ? n - base : C;
+        const Walk4Entry* const q = pp + base;
+        f4 F[C];
+        int er[C];
+        // 1a. what the chunk reads from HBM, back to back
+#pragma unroll
+        for (int i = 0; i < C; ++i) {
+            er[i] = 0;
+            if (i < cnt) {
+                const Walk4Entry e = walk4_entry_from_lds(q + i);
+                if (!(e.ctl & MBAMD_W4_TIP2)) F[i] = walk4_at_kib(P0, e.c2)[lane];
+                if (e.ctl & MBAMD_W4_READS) er[i] = walk4_at(E0, e.eread)[lane];
+            }
+        }
+        // 1b. the sibling factors (nothing here depends on the chain).  The matrices come through the scalar cache -- every workgroup
+        // reads the same ones, a miss is an L2 round trip of several hundred cycles against ~50 cycles of products -- in BURSTS of
+        // MBAMD_P4_GROUP: one round trip per group instead of one per operation.
+        constexpr int G = MBAMD_P4_GROUP;
+#pragma unroll
+        for (int g = 0; g < C; g += G) {
+            if (g < cnt) {
+                Walk4Entry e[G];
+                Walk4Mat M[G];
+#pragma unroll
+                for (int u = 0; u < G; ++u) {
+                    e[u] = walk4_entry_from_lds(q + (g + u < cnt ? g + u : g));
+                    M[u] = walk4_load_matrix(walk4_at(M0, e[u].m2));
+                }
+#pragma unroll
+                for (int u = 0; u < G; ++u) {
+                    if (g + u < cnt) {
+                        f4 v = F[g + u];
+                        if (e[u].ctl & MBAMD_W4_TIP2) v = walk4_tip_vector(walk4_load_planes(walk4_at(T0, e[u].c2)), lane);   // (a tip sibling: once or twice per path)
+                        F[g + u] = walk4_matvec(M[u], v);
+                    }
+                }
+            }
+        }
+        // 2. the chain
+#pragma unroll
+        for (int g = 0; g < C; g += G) {
+            if (g < cnt) {
+                Walk4Entry e[G];
+                Walk4Mat M[G];
+#pragma unroll
+                for (int u = 0; u < G; ++u) {
+                    e[u] = walk4_entry_from_lds(q + (g + u < cnt ? g + u : g));
+                    M[u] = walk4_load_matrix(walk4_at(M0, e[u].m1));
+                }
+#pragma unroll
+                for (int u = 0; u < G; ++u) {
+                    if (g + u < cnt) {
+                        const f4 f1 = walk4_matvec(M[u], prev);
+                        const f4 f2 = F[g + u];
+                        f4 o;
+                        o.x = f1.x * f2.x; o.y = f1.y * f2.y; o.z = f1.z * f2.z; o.w = f1.w * f2.w;
+                        const int wm = (int) (e[u].ctl << 23) >> 31;               // mode bit 8 (SCALE_WRITE) -> all ones
+                        const int ew = scale_exponent(max4(o)) & wm;
+                        const int ex = ew | er[g + u];
+                        cum_e += ew;
+                        o.x = scale_pow2(o.x, -ex); o.y = scale_pow2(o.y, -ex);
+                        o.z = scale_pow2(o.z, -ex); o.w = scale_pow2(o.w, -ex);
+                        walk4_store(walk4_at_kib(P0, e[u].dst), walk4_at(E0, e[u].ewrite), lane, o, ex);
+                        prev = o;
+                    }
+                }
+            }
+        }
+    }
+    if (A.cum != nullptr) {
+        int32_t* dst = A.cum + (size_t) k * A.Ppad + (size_t) blk * 64 + lane;
+        if (A.cumFresh) *dst = cum_e;
+        else if (cum_e != 0) *dst += cum_e;
+    }
+}
+
 }  // namespace mbamd
 #endif

@@ -18,6 +18,13 @@ __device__ inline void walk4_dma_exps(const int8_t* base, unsigned lane, int* st
 __device__ inline void walk4_wait_vm(unsigned) {}
 __device__ inline void walk4_barrier() { mbamd_emu_barrier(); }
 __device__ inline Walk4Entry walk4_load_entry(const Walk4Entry* p) { return *p; }
+__device__ inline Walk4Entry walk4_entry_from_lds(const Walk4Entry* p) { return *p; }
+__device__ inline void walk4_program_to_lds(const Walk4Entry* src, Walk4Entry* lds, int entries, unsigned lane)
+{
+    // (threads run one after the other here: every thread copies the whole program before it reads it)
+    (void) lane;
+    for (int i = 0; i < entries; ++i) lds[i] = src[i];
+}
 
 // f_i = sum_j P(i->j) v_j with the transposed matrix mT[j][i] in scalar registers; the same fma chain
 // (j = 0..3, first term a plain product) as the reference's scalar loop order, two rows per v_pk_fma_f32.
