@@ -38,45 +38,6 @@ __device__ __forceinline__ Walk4Entry walk4_entry_from_lds(const Walk4Entry* p)
     e.ewrite = __builtin_amdgcn_readfirstlane(b[2]); e.eread = __builtin_amdgcn_readfirstlane(b[3]);
     return e;
 }
-// a 4 x 4 matrix (transposed, as the buffers hold it) that this workgroup formed in LDS -> scalar registers.  Read as INTEGERS: with a
-// float vector and a bit cast per element in front of readfirstlane this compiler (ROCm 7.2) read elements 0, 4, 8, 12 and copied each
-// into its three neighbours (seen in the assembly, and in the likelihoods).
-__device__ __forceinline__ Walk4Mat walk4_matrix_from_lds(const float* p)
-{
-    typedef unsigned u4v __attribute__((ext_vector_type(4)));
-    Walk4Mat r;
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-        const u4v v = reinterpret_cast<const u4v*>(p)[q];
-#pragma unroll
-        for (int t = 0; t < 4; ++t) r.m[4 * q + t] = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(v[t]));
-    }
-    return r;
-}
-// P = U diag(exp(lambda t r_k)) U^-1 for the queued jobs, category k: lane 16 q + 4 i + j forms P(i -> j) of job q -- expression for
-// expression what k_transition_matrices_s4 computes --, stored transposed in LDS (and in the job's buffer if `store`)
-__device__ __forceinline__ void walk4_path_matrices(const Path4Jobs& J, unsigned k, float* ldsM, float* Mk, unsigned lane, bool store)
-{
-    const int i = (int) ((lane >> 2) & 3u), j = (int) (lane & 3u);
-#pragma unroll
-    for (int q = 0; q < MBAMD_P4_MAXJOBS; ++q) {
-        if (q < J.n && (int) (lane >> 4) == q) {
-            const MBAMD_AS_GLOBAL double* U = reinterpret_cast<const MBAMD_AS_GLOBAL double*>((uintptr_t) J.eig[q]);
-            const MBAMD_AS_GLOBAL double* Ui = U + 16;
-            const MBAMD_AS_GLOBAL double* lam = U + 32;
-            double sum = 0.0;
-            for (int s = 0; s < 4; ++s) sum += U[i * 4 + s] * exp(lam[s] * J.length[q] * J.rate[k]) * Ui[s * 4 + j];
-            const float v = (sum < 0.0) ? 0.0f : (float) sum;
-            ldsM[16 * q + j * 4 + i] = v;
-            if (store) reinterpret_cast<MBAMD_AS_GLOBAL float*>((uintptr_t) Mk + J.off[q])[j * 4 + i] = v;
-        }
-    }
-    // other LANES wrote what this lane reads next: the hardware needs nothing (a wave's LDS instructions execute in order), the compiler
-    // must be told -- to it a thread that stored one element of sixteen may read the other fifteen as anything (it did: fifteen copies)
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    MBAMD_WAVE_SYNC();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-}
 // 16 bytes per lane of a program (any memory the device can read, the kernel arguments included) -> LDS
 __device__ __forceinline__ void walk4_program_to_lds(const Walk4Entry* src, Walk4Entry* lds, int entries, unsigned lane)
 {
@@ -84,9 +45,6 @@ __device__ __forceinline__ void walk4_program_to_lds(const Walk4Entry* src, Walk
     const MBAMD_AS_GLOBAL u4v* s = reinterpret_cast<const MBAMD_AS_GLOBAL u4v*>((uintptr_t) src);
     u4v* d = reinterpret_cast<u4v*>(lds);
     for (int i = (int) lane; i < 2 * entries; i += 64) d[i] = s[i];
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");       // (lanes read each other's pieces: see walk4_path_matrices)
-    MBAMD_WAVE_SYNC();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 __device__ __forceinline__ Walk4Planes walk4_load_planes(const uint64_t* p)
 {

@@ -7,9 +7,5 @@ __device__ __forceinline__ const Walk4Entry* walk4_program(const Walk4ArgsInline
 {
     return reinterpret_cast<const Walk4Entry*>((uintptr_t) __builtin_amdgcn_kernarg_segment_ptr() + offsetof(Walk4ArgsInline, inl));
 }
-__device__ __forceinline__ const Walk4Entry* walk4_program(const Path4Args&)
-{
-    return reinterpret_cast<const Walk4Entry*>((uintptr_t) __builtin_amdgcn_kernarg_segment_ptr() + offsetof(Path4Args, inl));
-}
 }  // namespace mbamd
 #endif

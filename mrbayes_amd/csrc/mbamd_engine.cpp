@@ -250,7 +250,6 @@ struct Instance {
     int runWalkG(const Plan& plan);
     bool buildPath4(Plan& plan, const BeagleOperation* ops, int n);
     bool noPath4 = false;                        // MBAMD_NO_PATH4: root-ward paths on k_walk4_t too
-    bool noPathFuse = false;                     // MBAMD_NO_PATH_MATRICES: queued matrices always through k_transition_matrices_s4
     void postResultFlag();
     bool scaleOpsIndependentOfPending(const int* idx, int n, int cumIdx) const;
     uint64_t launchClock = 0, syncedClock = 0;   // launches issued / launches known complete (last stream synchronisation)
@@ -580,7 +579,6 @@ int Instance::create(int tipCount_, int partialsBufferCount, int compactBufferCo
     noDefer = std::getenv("MBAMD_NO_DEFER") != nullptr;
     noInlinePrograms = std::getenv("MBAMD_NO_INLINE_PROGRAMS") != nullptr;
     noPath4 = std::getenv("MBAMD_NO_PATH4") != nullptr;
-    noPathFuse = std::getenv("MBAMD_NO_PATH_MATRICES") != nullptr;
     if (const char* e = std::getenv("MBAMD_MFMA_SERIAL")) serialRatio = std::max(0, std::atoi(e));
     noSpine = std::getenv("MBAMD_NO_SPINE") != nullptr;
     if (const char* e = std::getenv("MBAMD_SPINE_WIDTH")) spineWidth = std::max(1, std::atoi(e));
@@ -1524,6 +1522,8 @@ int Instance::updatePartials4(const BeagleOperation* ops, int n, int cumIdx)
         }
     if (!plan) {
         planMisses++;
+        int mrc = flushMatrices();               // the matrix kernel runs while the host compiles the list
+        if (mrc) return mrc;
         const size_t maxPlans = 24;
         if (plans.size() < maxPlans) {
             plan = new Plan();
@@ -1540,11 +1540,7 @@ int Instance::updatePartials4(const BeagleOperation* ops, int n, int cumIdx)
         {
             StatTimer st_(ST_PLAN);
             plan->path = false;
-            if (buildPath4(*plan, ops, n)) rc = BEAGLE_SUCCESS;      // (a path takes its queued matrices along: runWalk)
-            else {
-                rc = flushMatrices();                                // the matrix kernel runs while the host compiles the list
-                if (!rc) rc = buildWalk(*plan, ops, n);
-            }
+            rc = buildPath4(*plan, ops, n) ? BEAGLE_SUCCESS : buildWalk(*plan, ops, n);
         }
         if (rc) { plan->hash = 0; plan->key.clear(); return rc; }
     }
@@ -1553,11 +1549,8 @@ int Instance::updatePartials4(const BeagleOperation* ops, int n, int cumIdx)
         valid[ops[o].destinationPartials] = 1;
         if (ops[o].destinationScaleWrite != BEAGLE_OP_NONE) scaleState[ops[o].destinationScaleWrite] = 1;
     }
-    // a root-ward path forms the few matrices that are still queued itself (k_path4); anything else needs them in their buffers first
-    if (!(plan->path && !noPathFuse && !pendingJobs.empty() && pendingJobs.size() <= (size_t) MBAMD_P4_MAXJOBS)) {
-        int mrc = flushMatrices();
-        if (mrc) return mrc;
-    }
+    int mrc = flushMatrices();
+    if (mrc) return mrc;
     return timedRun(*plan, cumPtr);
 }
 
@@ -1859,21 +1852,8 @@ bool Instance::buildPath4(Plan& plan, const BeagleOperation* ops, int n)
 int Instance::runWalk(const Plan& plan, int32_t* cum)
 {
     if (plan.path) {
-        Path4Args ai;
+        Walk4ArgsInline ai;
         Walk4Args& a = ai.a;
-        ai.jobs.n = 0;
-        if (!pendingJobs.empty()) {              // (updatePartials4 left them queued for this launch: at most MBAMD_P4_MAXJOBS)
-            const RatesArg& rs = rateSets[pendingRateSet];
-            for (int q = 0; q < 16; ++q) ai.jobs.rate[q] = q < MBAMD_MAX_RATES ? rs.r[q] : 1.0;
-            for (const MatrixJob& j : pendingJobs) {
-                const int q = ai.jobs.n++;
-                ai.jobs.off[q] = (unsigned) ((const char*) j.out - (const char*) matrices);
-                ai.jobs.length[q] = j.length;
-                ai.jobs.eig[q] = j.eig;
-            }
-            pendingJobs.clear();
-            std::fill(pendingMatrixOut.begin(), pendingMatrixOut.end(), 0);
-        }
         a.prog = nullptr;
         a.entries = (int) plan.inlineProg.size();
         a.nslots = 0;
@@ -1891,7 +1871,8 @@ int Instance::runWalk(const Plan& plan, int32_t* cum)
         a.nblocks = Ppad / 64;
         a.tail = 0;
         std::memcpy(ai.inl, plan.inlineProg.data(), plan.inlineProg.size() * sizeof(Walk4Entry));
-        MBAMD_LAUNCH(k_path4, walk4_grid(Ppad / 64, K), 64, plan.inlineProg.size() * sizeof(Walk4Entry) + MBAMD_P4_MAXJOBS * 64, stream, ai);
+        auto kernel = k_path4<Walk4ArgsInline>;
+        MBAMD_LAUNCH(kernel, walk4_grid(Ppad / 64, K), 64, plan.inlineProg.size() * sizeof(Walk4Entry), stream, ai);
         HIP_TRY(hipGetLastError());
         pendingLaunches += 1;
         return BEAGLE_SUCCESS;

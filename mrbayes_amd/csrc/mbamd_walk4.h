@@ -99,16 +99,6 @@ __host__ __device__ inline unsigned walk4_grid(int nblocks, int K) { return 8u *
 
 struct Walk4Planes { uint64_t p[4]; };
 
-// k_path4 (below): transition-matrix jobs that were still queued when a root-ward path arrived travel with its launch
-#define MBAMD_P4_MAXJOBS 4
-struct Path4Jobs {
-    int n;                                   // 0: every matrix is in its buffer already
-    unsigned off[MBAMD_P4_MAXJOBS];          // byte offset of the job's matrix buffer from Walk4Args::matrices (what entries carry in m1 / m2)
-    double length[MBAMD_P4_MAXJOBS];
-    const double* eig[MBAMD_P4_MAXJOBS];     // [U | U^-1 | lambda], as k_transition_matrices_s4 reads it
-    double rate[16];                         // category rates of the jobs' rate set
-};
-
 }  // namespace mbamd
 #include <mbamd_dev_walk4.h>     // Walk4Mat, walk4_load_* / walk4_tip_vector / walk4_dma* / walk4_wait_vm / walk4_barrier / walk4_matvec / ... (csrc/device/)
 namespace mbamd {
@@ -140,14 +130,6 @@ struct Walk4ArgsInline {
     Walk4Args a;
     Walk4Entry inl[MBAMD_W4_INLINE];
 };
-// k_path4: the program AND the transition-matrix jobs that were still queued when the list arrived (the branch a move changed: one
-// or two matrices) travel with the launch -- the path kernel forms them itself instead of waiting behind a one-workgroup kernel
-struct Path4Args {
-    Walk4Args a;
-    Path4Jobs jobs;
-    Walk4Entry inl[MBAMD_W4_INLINE];
-};
-__device__ __forceinline__ const Walk4Args& walk4_args(const Path4Args& a) { return a.a; }
 __device__ __forceinline__ const Walk4Args& walk4_args(const Walk4Args& a) { return a; }
 __device__ __forceinline__ const Walk4Args& walk4_args(const Walk4ArgsInline& a) { return a.a; }
 __device__ __forceinline__ const Walk4Entry* walk4_program(const Walk4Args& a) { return a.prog; }
@@ -300,11 +282,12 @@ k_walk4_t(ARGS AA)
 // No LDS, no slots, no barrier; F lives in registers.  Same arithmetic, operation by operation, as k_walk4_t: the same bits.
 // Entries (Walk4Entry): c1 = the chain's INPUT (entry 0 only: tip planes or a buffer), c2 = the sibling, m1 / m2 their matrices;
 // ctl: TIP1 (entry 0: the input is a compact tip), TIP2 (the sibling is one), [9:8] the scale mode.  blockDim.x = 64, grid = walk4_grid,
-// dynamic LDS = entries * 32 + MBAMD_P4_MAXJOBS * 64 bytes.
+// dynamic LDS = entries * 32 bytes.
 #define MBAMD_P4_CHUNK 16
 #define MBAMD_P4_GROUP 4         // matrices per burst of scalar loads (4 x 16 scalar registers)
+template <class ARGS>
 __global__ void __launch_bounds__(64)
-k_path4(Path4Args AA)
+k_path4(ARGS AA)
 {
     const Walk4Args& A = walk4_args(AA);
     const unsigned lane = threadIdx.x & 63;
@@ -320,17 +303,6 @@ k_path4(Path4Args AA)
     // the program: from the kernel arguments (host-visible memory) into LDS, one vector load per 32 entries
     Walk4Entry* const pp = mbd_dyn_lds<Walk4Entry>();
     walk4_program_to_lds(walk4_program(AA), pp, n, lane);
-    // the queued matrices of this category: sixteen lanes per job form them (the arithmetic of k_transition_matrices_s4) into LDS, the
-    // first pattern block's workgroup also stores them where later launches expect them
-    float* const jm = reinterpret_cast<float*>(pp + n);
-    const Path4Jobs& J = AA.jobs;
-    walk4_path_matrices(J, k, jm, const_cast<float*>(M0), lane, blk == 0);
-    auto matrix = [&](unsigned off) {
-#pragma unroll
-        for (int qj = 0; qj < MBAMD_P4_MAXJOBS; ++qj)
-            if (qj < J.n && off == J.off[qj]) return walk4_matrix_from_lds(jm + 16 * qj);
-        return walk4_load_matrix(walk4_at(M0, off));
-    };
     constexpr int C = MBAMD_P4_CHUNK;
     f4 prev;
     {
@@ -366,7 +338,7 @@ k_path4(Path4Args AA)
 #pragma unroll
                 for (int u = 0; u < G; ++u) {
                     e[u] = walk4_entry_from_lds(q + (g + u < cnt ? g + u : g));
-                    M[u] = matrix(e[u].m2);
+                    M[u] = walk4_load_matrix(walk4_at(M0, e[u].m2));
                 }
 #pragma unroll
                 for (int u = 0; u < G; ++u) {
@@ -387,7 +359,7 @@ k_path4(Path4Args AA)
 #pragma unroll
                 for (int u = 0; u < G; ++u) {
                     e[u] = walk4_entry_from_lds(q + (g + u < cnt ? g + u : g));
-                    M[u] = matrix(e[u].m1);
+                    M[u] = walk4_load_matrix(walk4_at(M0, e[u].m1));
                 }
 #pragma unroll
                 for (int u = 0; u < G; ++u) {

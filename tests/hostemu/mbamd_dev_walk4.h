@@ -19,23 +19,6 @@ __device__ inline void walk4_wait_vm(unsigned) {}
 __device__ inline void walk4_barrier() { mbamd_emu_barrier(); }
 __device__ inline Walk4Entry walk4_load_entry(const Walk4Entry* p) { return *p; }
 __device__ inline Walk4Entry walk4_entry_from_lds(const Walk4Entry* p) { return *p; }
-__device__ inline Walk4Mat walk4_matrix_from_lds(const float* p) { return walk4_load_matrix(p); }
-__device__ inline void walk4_path_matrices(const Path4Jobs& J, unsigned k, float* ldsM, float* Mk, unsigned lane, bool store)
-{
-    // (threads run one after the other here: every thread forms every element before it reads any)
-    (void) lane;
-    for (int q = 0; q < J.n; ++q) {
-        const double *U = J.eig[q], *Ui = U + 16, *lam = U + 32;
-        for (int i = 0; i < 4; ++i)
-            for (int j = 0; j < 4; ++j) {
-                double sum = 0.0;
-                for (int s = 0; s < 4; ++s) sum += U[i * 4 + s] * exp(lam[s] * J.length[q] * J.rate[k]) * Ui[s * 4 + j];
-                const float v = (sum < 0.0) ? 0.0f : (float) sum;
-                ldsM[16 * q + j * 4 + i] = v;
-                if (store) reinterpret_cast<float*>(reinterpret_cast<char*>(Mk) + J.off[q])[j * 4 + i] = v;
-            }
-    }
-}
 __device__ inline void walk4_program_to_lds(const Walk4Entry* src, Walk4Entry* lds, int entries, unsigned lane)
 {
     // (threads run one after the other here: every thread copies the whole program before it reads it)

@@ -3,6 +3,5 @@
 #define MBAMD_DEV_WALK4_ARGS_H_
 namespace mbamd {
 __device__ __forceinline__ const Walk4Entry* walk4_program(const Walk4ArgsInline& a) { return a.inl; }
-__device__ __forceinline__ const Walk4Entry* walk4_program(const Path4Args& a) { return a.inl; }
 }  // namespace mbamd
 #endif
