@@ -128,21 +128,24 @@ def mcmc_gen_per_s(gold, nchains=1, quick=True):
                    "the fly by integration/mrbayes/patches/patch_pars.py to call the device-parsimony binding (SURVEY 8(f) item 4, integration/mrbayes/; "
                    "same proposals and chain as the unmodified binary); "
                    "fixed_topology = branch-length and substitution-parameter moves only (prset topologypr=fixed)"}
-    windows = {(False, "engine"): (300, 1300) if quick else (500, 2500), (True, "engine"): (2000, 12000) if quick else (2000, 22000),
+    # (round 5: a fixed-topology generation is ~70 us and the 7.6 s of start-up in front of it vary by +-0.3 s from run to run -- a
+    #  window of 10 000 generations gave anything from 8 400 to 67 000 generations/s on one box (profiles/r05_path4.txt); the engine's
+    #  windows are long enough for +-5 %, and each point is the faster of two runs)
+    windows = {(False, "engine"): (300, 1300) if quick else (500, 2500), (True, "engine"): (2000, 42000) if quick else (2000, 82000),
                (False, "reference_cpu"): (10, 40) if quick else (20, 80), (True, "reference_cpu"): (20, 70) if quick else (20, 120)}
     for mix, fixed in (("default_moves", False), ("fixed_topology", True)):
         res = {}
         runs = [("engine", refrun.REF_MB_AMD, "dynamic"), ("reference_cpu", refrun.REF_MB, None)]
         if not fixed and os.path.exists(refrun.REF_MB_AMD_PARS):
             runs.insert(1, ("engine_device_parsimony", refrun.REF_MB_AMD_PARS, "dynamic"))
-            windows[(False, "engine_device_parsimony")] = (2000, 17000) if quick else (2000, 42000)
+            windows[(False, "engine_device_parsimony")] = (2000, 27000) if quick else (2000, 52000)
         for tag, binary, beagle in runs:
             lo, hi = windows[(fixed, tag)]
             walls = []
+            repeats = 2 if tag != "reference_cpu" and (fixed or tag == "engine_device_parsimony") else 1
             for ngen in (lo, hi):
-                _, wall = refrun.run_mb(binary, refrun.mcmc_nexus(st, tr, ngen, beagle=beagle, nchains=nchains,
-                                                                  fixed_topology=fixed))
-                walls.append(wall)
+                walls.append(min(refrun.run_mb(binary, refrun.mcmc_nexus(st, tr, ngen, beagle=beagle, nchains=nchains,
+                                                                         fixed_topology=fixed))[1] for _ in range(repeats)))
             res[tag] = (hi - lo) / max(walls[1] - walls[0], 1e-9)
             res[tag + "_ngen"] = [lo, hi]
         res["speedup"] = res["engine"] / res["reference_cpu"]

@@ -45,6 +45,11 @@ __device__ __forceinline__ void walk4_program_to_lds(const Walk4Entry* src, Walk
     const MBAMD_AS_GLOBAL u4v* s = reinterpret_cast<const MBAMD_AS_GLOBAL u4v*>((uintptr_t) src);
     u4v* d = reinterpret_cast<u4v*>(lds);
     for (int i = (int) lane; i < 2 * entries; i += 64) d[i] = s[i];
+    // other LANES wrote what this lane reads next: the hardware needs nothing (a wave's LDS instructions execute in order), the compiler
+    // must be told -- to it a thread that stored one piece may read the others as anything
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    MBAMD_WAVE_SYNC();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 __device__ __forceinline__ Walk4Planes walk4_load_planes(const uint64_t* p)
 {
