@@ -7,5 +7,4 @@
     hipLaunchKernelGGL(kernel, dim3(grid), dim3(block), lds, stream, __VA_ARGS__)
 #define MBAMD_LAUNCH_BARRIER MBAMD_LAUNCH          // (the host emulation runs kernels with workgroup barriers as fibers)
 #define MBAMD_DEV_HAS_MFMA 1                       // the matrix-core kernels of mbamd_kernels_mfma.h exist (level kernels, wide integration, fp64 MFMA matrices)
-#define MBAMD_DEV_SPREAD 1                         // two-wave workgroups of k_walkg are launched as four (see the kernel)
 #endif

@@ -1,7 +1,8 @@
-// mbamd_dev_walkg_kernel.h (gfx950) -- k_walkg, the 20/61-state tree-walk kernel on the matrix cores: the device half of
-// mbamd_walkg.h (which holds the layouts, tables and arguments, shared with the host).  The TEST-ONLY host emulation has a
-// plain-loop twin under the same name in front on its include path (tests/hostemu/), reading the same arguments, programs,
-// arenas and slot schedule.
+// mbamd_dev_walkg_kernel.h (gfx950) -- the device primitives of the 20/61-state tree-walk kernels (csrc/mbamd_walkg_kernel.h,
+// csrc/mbamd_walkg2_kernel.h): the matrix-core instruction, the lane swap, waits, barriers, where an inline program sits.  The
+// TEST-ONLY host emulation has a header of the same name in front on its include path (tests/hostemu/) that implements the same
+// primitives on fibers -- an MFMA there is a wave-wide exchange and 32 multiply-adds per lane --, so the kernels themselves, with
+// their tile loops, table layouts, register sets and LDS slots, are the code the CPU CI runs.
 #ifndef MBAMD_DEV_WALKG_KERNEL_H_
 #define MBAMD_DEV_WALKG_KERNEL_H_
 namespace mbamd {
@@ -9,362 +10,24 @@ __device__ __forceinline__ const Walk4Entry* wg_program(const WalkGArgsInline&)
 {
     return reinterpret_cast<const Walk4Entry*>((uintptr_t) __builtin_amdgcn_kernarg_segment_ptr() + offsetof(WalkGArgsInline, inl));
 }
-
-
-// V floats of one lane: a clang vector, or -- V = 1 -- a plain float (vectors of one element are not loadable types)
-template <int V> struct WgVecT {
-    typedef float type __attribute__((ext_vector_type(V)));
-    static __device__ __forceinline__ float get(const type& v, int i) { return v[i]; }
-    static __device__ __forceinline__ void set(type& v, int i, float x) { v[i] = x; }
-    static __device__ __forceinline__ type splat(float x) { return (type) (x); }
-};
-template <> struct WgVecT<1> {
-    typedef float type;
-    static __device__ __forceinline__ float get(const type& v, int) { return v; }
-    static __device__ __forceinline__ void set(type& v, int, float x) { v = x; }
-    static __device__ __forceinline__ type splat(float x) { return x; }
-};
-
-template <int SC, bool PAIR = false> struct WgShape {
-    static constexpr int TW = MBAMD_WG_TW, KS = MBAMD_WG_KS;
-    static constexpr int T = (SC + KS - 1) / KS, NT = (SC + TW - 1) / TW;
-#if MBAMD_WG_TW == 32
-    static constexpr int V = SC > 32 ? 4 : 2, VA = V;
-    static constexpr int ACC = 16;                   // accumulator registers per output tile (32 x 32 / 64 lanes)
-#else
-    static constexpr int V = (SC > 32 || T % 4 == 0) ? 4 : (T % 2 == 0 ? 2 : 1);
-    static constexpr int VA = (SC > 32 || (T * NT) % 4 == 0) ? 4 : ((T * NT) % 2 == 0 ? 2 : 1);
-    static constexpr int ACC = 4;                    // 16 x 16 / 64 lanes
-#endif
-    static constexpr int TP = (T + V - 1) / V * V, NAP = (TP * NT + VA - 1) / VA * VA;
-    // row split (k_walkg2, mbamd_walkg.h): a wave of the pair owns ONE output tile -- its rows of the tables and of the result
-    static constexpr bool SPLIT = PAIR && MBAMD_WG_TW == 32 && SC > 48;
-    static constexpr int NAW = SPLIT ? TP : NAP;      // table rows a wave fetches per interior child
-    static constexpr int TPO = SPLIT ? ACC : TP;      // block rows of the result this wave owns
-    static_assert(!SPLIT || (NT == 2 && TP == 2 * ACC && V == 4 && VA == 4), "row split: two output tiles of 16 block rows");
-    typedef WgVecT<V> Vb;                            // block rows (B operand, results)
-    typedef WgVecT<VA> Va;                           // table rows (A operand, tip gathers)
-    typedef typename Vb::type vec;
-    typedef typename Va::type vecA;
-    typedef float acc __attribute__((ext_vector_type(ACC)));
-};
-// one CHUNK of a job's operands: a job (one child factor) is CH chunks of TP / CH MFMA steps
-template <int SC, int CH> struct WgOperands {
-    typename WgShape<SC>::vecA a[WgShape<SC>::NAP / WgShape<SC>::VA / CH];  // A rows of the chunk (or the tip's gather rows), VA rows per register group
-    typename WgShape<SC>::vec b[WgShape<SC>::TP / WgShape<SC>::V / CH];     // B rows of a child read from HBM
-};
-struct WgDesc {
-    Walk4Entry e;
-    unsigned s1, s2;           // tip states of this lane's pattern (children 1, 2)
-};
-template <int I, class O> __device__ __forceinline__ O& wg_pick(O& a, O& b, O& c)
+typedef float mbd_acc16 __attribute__((ext_vector_type(16)));
+// D (32 x 32) += A (32 x 2) B (2 x 32): lane l gives A[l & 31][l >> 5] and B[l >> 5][l & 31] and holds column l & 31 of D, register r =
+// row (r & 3) + 8 (r >> 2) + 4 (l >> 5)
+__device__ __forceinline__ mbd_acc16 mbd_mfma_f32_32x32x2(float a, float b, mbd_acc16 c) { return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0); }
+// max(v, the value lane l ^ 32 holds) (v_permlane32_swap: in the VALU, no LDS round trip)
+__device__ __forceinline__ float mbd_max_lane_xor32(float v)
 {
-    if constexpr (I == 0) return a;
-    else if constexpr (I == 1) return b;
-    else return c;
+    const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    return fmaxf(__uint_as_float(sw[0]), __uint_as_float(sw[1]));
 }
-template <int I> struct WgInt { static constexpr int value = I; };
-
-// Second launch bound = waves per SIMD the register budget must allow.  Beyond 32 states "two" makes the register file ONE file
-// (206 registers, accumulators included) instead of 174 + 32 accumulation registers: a compact tip's factor is then written where
-// the product reads it, not copied in through v_accvgpr_write (codon 100 x 5 000: 0.195 -> 0.188 ms, profiles/r04_exp_walkgs.txt).
-#if !defined(MBAMD_WG_MINWAVES)
-#define MBAMD_WG_MINWAVES(SC) ((SC) > 32 ? 2 : 1)
-#endif
-// blockDim.x = 64 * W (W <= WMAX); grid = walkg_grid(ntiles, K); dynamic LDS = wg_lds_bytes(W, nslots, SC).
-// The operand pipeline works in CHUNKS: a job (one child factor, T MFMA steps per row tile) is CH chunks, an entry 2 CH,
-// and the operands of a chunk are fetched DEPTH chunks ahead into one of DEPTH + 1 rotating register sets.
-//   20 states: CH 1, DEPTH 2 -- a job is 10 MFMAs = 640 cycles, less than a memory round trip; three sets of 15 registers;
-//   61 states: CH 2, DEPTH 1 -- a chunk is 31 MFMAs = 2000 cycles; two sets of 48 registers fit beside the 64 accumulators
-//              (whole jobs did not: the allocator shuttled LOADED operands through AccVGPRs, a vmcnt(0) per job).
-template <int SC, int WMAX, int CH, int DEPTH, class ARGS = WalkGArgs>
-__global__ void __launch_bounds__(64 * WMAX, MBAMD_WG_MINWAVES(SC))
-k_walkg(ARGS AA)
-{
-    const WalkGArgs& A = wg_args(AA);
-    typedef WgShape<SC> Sh;
-    typedef typename Sh::vec vec;
-    typedef typename Sh::vecA vecA;
-    typedef typename Sh::Vb Vb;
-    typedef typename Sh::Va Va;
-    typedef typename Sh::acc acc_t;
-    typedef WgOperands<SC, CH> Ops;
-    constexpr int TW = Sh::TW, KS = Sh::KS, ACC = Sh::ACC;
-    constexpr int T = Sh::T, NT = Sh::NT, V = Sh::V, VA = Sh::VA, TP = Sh::TP, NAP = Sh::NAP, NAV = NAP / VA, TV = TP / V;
-    constexpr int TPC = TP / CH, NAVC = NAV / CH, TVC = TV / CH;      // per chunk: MFMA steps, A register groups, B register groups
-    constexpr int NQ = 2 * CH, NS = DEPTH + 1;                        // chunks per entry, register sets
-    static_assert(TP % CH == 0 && TPC % V == 0 && NAV % CH == 0 && (TPC * NT) % VA == 0 && NS <= 3 && DEPTH <= NQ && TPC <= 20, "chunk geometry");
-    static_assert((ACC < T ? ACC : T) * NT <= NAVC * VA, "a compact tip's gather rows must lie in the first chunk");
-    constexpr unsigned SLOTB = TP * 256u;
-    const unsigned lane = threadIdx.x & 63, half = lane / TW, col = lane % TW;      // half: which of the KS states of a row
-    int wave = __builtin_amdgcn_readfirstlane((int) (threadIdx.x >> 6));
-    int W = (int) (blockDim.x >> 6);
-    // Two-wave workgroups land on one SIMD pair of the CU and leave the other pair's matrix cores idle (measured: 73 against
-    // 140 TFLOP/s of dense MFMA with waves {0, 1} against {0, 2} of a four-wave workgroup): such workgroups are launched
-    // with twice the waves, and the odd ones leave at once.
-    if (A.spread) {
-        if (wave & 1) return;
-        wave >>= 1;
-        W >>= 1;
-    }
-    extern __shared__ float lds_walkg[];
-    const unsigned K = (unsigned) A.K, KL = K * (unsigned) A.lists;
-    const unsigned xcd = blockIdx.x & 7u, pos = blockIdx.x >> 3;
-    const unsigned tile = (pos / KL) * 8u + xcd, k = (pos % KL) % K, list = (pos % KL) / K;
-    if (tile >= (unsigned) A.ntiles) return;
-    char* const mine = reinterpret_cast<char*>(lds_walkg) + (size_t) wave * (MBAMD_WG_STAGE + (size_t) A.nslots * SLOTB);
-    vec* const slots = reinterpret_cast<vec*>(mine + MBAMD_WG_STAGE) + lane;          // this lane's V rows of row group 0, slot 0
-    // wave-uniform bases; the entries hold byte offsets from them
-    char* const P0 = reinterpret_cast<char*>(A.partials) + (size_t) tile * A.tileBytes + (size_t) k * SLOTB;
-    const uint8_t* const T0 = A.tips + (size_t) tile * A.tipTileBytes;
-    int8_t* const E0 = A.exps + (size_t) ((tile * TW) >> 6) * A.estride + (size_t) k * 64 + ((tile * TW) & 63u);
-    const char* const Mk = reinterpret_cast<const char*>(A.matrices) + A.tabOff + (size_t) k * A.tabBytes;
-
-    const Walk4Entry* prog = wg_program(AA) + ((size_t) list * W + wave) * A.entries;
-    const int n = A.entries - MBAMD_WG_TAIL;
-    WgDesc DA, DB, DC;
-    DA.e = walk4_load_entry(prog); DB.e = walk4_load_entry(prog + 1); DC.e = walk4_load_entry(prog + 2);
-    DA.s1 = DA.s2 = DB.s1 = DB.s2 = DC.s1 = DC.s2 = 0;
-    Ops X, Y, Z;
-#pragma unroll
-    for (int i = 0; i < NAVC; ++i) X.a[i] = Y.a[i] = Z.a[i] = Va::splat(0.0f);
-#pragma unroll
-    for (int i = 0; i < TVC; ++i) X.b[i] = Y.b[i] = Z.b[i] = Vb::splat(0.0f);
-    int er = 0;                                      // stored exponent of the entry about to run (SCALE_READ)
-    int cum_e[MBAMD_WG_MAXLISTS] = {0, 0, 0, 0};
-
-    // operands of chunk q (child q / CH, part q % CH) of entry d -> register set o: NAVC loads outside any branch
-    // (+ TVC for a child that lives in HBM)
-    auto fetch = [&](const WgDesc& d, int q, Ops& o) {
-        const int ch = q / CH, h = q % CH;
-        const unsigned ctl = d.e.ctl;
-        const bool tip = ctl & (ch ? MBAMD_W4_TIP2 : MBAMD_W4_TIP1), mem = ctl & (ch ? MBAMD_WG_MEM2 : MBAMD_WG_MEM1);
-        const unsigned coff = ch ? d.e.c2 : d.e.c1, moff = ch ? d.e.m2 : d.e.m1;
-        const unsigned s = ch ? d.s2 : d.s1;
-        // a: A' (column = lane) or the tip's gather table (column = KS * (state % TW) + half of sub-table state / TW)
-        // (a compact tip takes every register from the FIRST chunk's rows: where a job has several chunks -- 60..63 states -- its
-        //  later chunks and no-op entries keep their loads, so that the vector-memory sequence stays uniform, but every lane reads one
-        //  and the same 16 bytes: one L2 request instead of eight lines.  A quarter of the kernel's L2 traffic, which bounds it
-        //  (profiles/r03_c5_pmc.txt).  With one chunk per job the plain form stays: a run-time stride costs the immediate offsets
-        //  of the loads -- +10 % at 20 states, measured.)
-        const bool idle = CH > 1 && ((tip && h > 0) || (ctl & MBAMD_W4_NOP));
-        const unsigned aoff = idle ? 0u : (tip ? (1u + s / TW) * (unsigned) (NAP * 256) + ((s % TW) * KS + half) * (unsigned) (VA * 4) : lane * (unsigned) (VA * 4));
-        const MBAMD_AS_GLOBAL vecA* pa = reinterpret_cast<const MBAMD_AS_GLOBAL vecA*>((uintptr_t) (Mk + moff) + aoff) + (idle ? 0 : h * NAVC * 64);
-        if constexpr (CH > 1) {
-            const int stride = idle ? 0 : 64;
-#pragma unroll
-            for (int i = 0; i < NAVC; ++i) o.a[i] = pa[i * stride];
-        } else {
-#pragma unroll
-            for (int i = 0; i < NAVC; ++i) o.a[i] = pa[i * 64];
-        }
-        if (mem) {
-            const MBAMD_AS_GLOBAL vec* pb = reinterpret_cast<const MBAMD_AS_GLOBAL vec*>((uintptr_t) (P0 + coff)) + lane + h * TVC * 64;
-#pragma unroll
-            for (int i = 0; i < TVC; ++i) o.b[i] = pb[i * 64];
-        }
-    };
-    // chunk q of an entry: MFMA steps [h TPC, (h + 1) TPC) of one child factor; register (it, r) of f = the state of this lane's
-    // pattern that block row ACC it + r holds in this lane.  No vector-memory operation in here.  Two halves: the B rows into
-    // registers (the only LDS wait), then the MFMA chain (or the tip's gather rows) -- the caller may issue scalar loads in between.
-    auto operandB = [&](const Walk4Entry& de, int q, const Ops& o, vec (&b)[TVC]) {
-        const int ch = q / CH, h = q % CH;
-        if (de.ctl & (ch ? MBAMD_WG_MEM2 : MBAMD_WG_MEM1)) {
-#pragma unroll
-            for (int i = 0; i < TVC; ++i) b[i] = o.b[i];
-        } else {
-            const vec* sl = reinterpret_cast<const vec*>(reinterpret_cast<const char*>(slots) + (ch ? de.c2 : de.c1)) + h * TVC * 64;
-#pragma unroll
-            for (int i = 0; i < TVC; ++i) b[i] = sl[i * 64];
-        }
-    };
-    auto compute = [&](bool tip, int q, const Ops& o, const vec (&b)[TVC], acc_t (&f)[NT]) {
-        const int h = q % CH;
-        if (tip) {
-            if (h == 0) {                            // all registers of every output tile come from the first chunk's rows
-#pragma unroll
-                for (int it = 0; it < NT; ++it)
-#pragma unroll
-                    for (int r = 0; r < ACC; ++r) f[it][r] = (ACC * it + r < T) ? Va::get(o.a[(r * NT + it) / VA], (r * NT + it) % VA) : 0.0f;
-            }
-            return;
-        }
-        if (h == 0) {
-#pragma unroll
-            for (int it = 0; it < NT; ++it)
-#pragma unroll
-                for (int r = 0; r < ACC; ++r) f[it][r] = 0.0f;
-        }
-#pragma unroll
-        for (int tc = 0; tc < TPC; ++tc)
-            if (h * TPC + tc < T) {
-#pragma unroll
-                for (int it = 0; it < NT; ++it) {
-                    const float av = Va::get(o.a[(tc * NT + it) / VA], (tc * NT + it) % VA), bv = Vb::get(b[tc / V], tc % V);
-#if MBAMD_WG_TW == 32
-                    f[it] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, f[it], 0, 0, 0);
-#else
-                    f[it] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv, f[it], 0, 0, 0);
-#endif
-                }
-            }
-    };
-
-    // One iteration = one entry `cur`: its NQ chunks run on the register sets (S0, S1, S2, S0, ...) while the chunks DEPTH
-    // further on -- of cur, then of entry `n1` -- are fetched; the tip states of entry `n2` are fetched, and cur's descriptor
-    // is replaced by entry j + 3.  Vector-memory sequence, identical on every path:
-    //     NQ x NAVC operand loads | TV + 1 stores      (+ the rare conditional loads)
-    auto step = [&](WgDesc& cur, const WgDesc& n1, WgDesc& n2, Ops& S0, Ops& S1, Ops& S2, int j) {
-        const unsigned ctl = cur.e.ctl;
-        if (ctl & MBAMD_W4_BARRIER) {
-            // values other waves produced in the previous phase are read from here on: drain this wave's stores, meet
-            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-            __builtin_amdgcn_s_barrier();
-            asm volatile("" ::: "memory");
-        }
-        const bool run = !(ctl & MBAMD_W4_NOP);
-        const unsigned mode = (ctl >> 8) & 3u;
-        // (issued before the operand fetches: what the next entry needs first must not queue behind them)
-        // (three tiny loads, unconditional: every conditional vector-memory instruction makes the compiler's vmcnt waits one
-        //  instruction stricter -- and the instruction they then wait for is the oldest STORE of the previous entry)
-        // Exponents of the next entry, tip states of the entry after: 32 bytes per tile each.  16 / 20 states take them through
-        // the SCALAR path -- one s_load_dwordx8 each, issued with the descriptor load below, every lane picks its byte in the
-        // epilogue: as vector loads they sit in the in-order vmcnt queue behind the previous entry's result stores and the
-        // gather addresses of a tip's operand fetch wait for them (-5 % at 20 states, -7 % at 16).  At 61 states the 24 extra
-        // scalar registers spill (+3 %), at 8 the entry is too short to cover the scalar latency (+6 %): those keep the vector
-        // loads (profiles/r03_exp_walkg_tiny.txt).
-#if MBAMD_WG_TW == 32
-        constexpr bool SCALAR_TINY = SC >= 16 && SC <= 32;
-#else
-        constexpr bool SCALAR_TINY = false;
-#endif
-        typedef unsigned wg_u8v __attribute__((ext_vector_type(8)));
-        wg_u8v tinyE = {}, tiny1 = {}, tiny2 = {};
-        auto tiny_issue = [&]() {
-            if constexpr (SCALAR_TINY) {
-                tinyE = *reinterpret_cast<const MBAMD_AS_CONST wg_u8v*>((uintptr_t) (E0 + n1.e.eread));
-                tiny1 = *reinterpret_cast<const MBAMD_AS_CONST wg_u8v*>((uintptr_t) (T0 + ((n2.e.ctl & MBAMD_W4_TIP1) ? n2.e.c1 : 0u)));
-                tiny2 = *reinterpret_cast<const MBAMD_AS_CONST wg_u8v*>((uintptr_t) (T0 + ((n2.e.ctl & MBAMD_W4_TIP2) ? n2.e.c2 : 0u)));
-            }
-        };
-        auto tiny_pick = [&](const wg_u8v& w) {
-            const unsigned sel = col >> 2;
-            unsigned d = w[0];
-#pragma unroll
-            for (unsigned i = 1; i < 8; ++i) d = sel == i ? w[i] : d;
-            return (d >> ((col & 3u) * 8u)) & 0xFFu;
-        };
-        int er_next = 0;
-        if constexpr (!SCALAR_TINY) {
-            er_next = as_global(E0 + n1.e.eread)[col];
-            n2.s1 = as_global(T0 + ((n2.e.ctl & MBAMD_W4_TIP1) ? n2.e.c1 : 0u))[col];
-            n2.s2 = as_global(T0 + ((n2.e.ctl & MBAMD_W4_TIP2) ? n2.e.c2 : 0u))[col];
-        }
-        acc_t f1[NT], f2[NT];
-        const Walk4Entry ce = cur.e;
-        auto chunk = [&](auto qc) {
-            constexpr int q = decltype(qc)::value;
-            if constexpr (q < NQ) {
-                constexpr int qf = q + DEPTH;        // the chunk fetched now
-                if constexpr (qf < NQ) {
-                    WgDesc t;
-                    t.e = ce; t.s1 = cur.s1; t.s2 = cur.s2;
-                    fetch(t, qf, wg_pick<qf % NS>(S0, S1, S2));
-                } else {
-                    fetch(n1, qf - NQ, wg_pick<qf % NS>(S0, S1, S2));
-                }
-                const bool tip = ce.ctl & (q / CH ? MBAMD_W4_TIP2 : MBAMD_W4_TIP1);
-                // The descriptor of entry j + 3 replaces this entry's: a scalar load, and scalar loads share lgkmcnt with LDS
-                // and return out of order -- any LDS wait while it is in flight is a wait for IT.  It is issued when the
-                // last LDS read of the entry has landed (the epilogue has none): the last chunk's MFMA chain covers it.
-                if (run && !tip) {
-                    vec b[TVC];
-                    operandB(ce, q, wg_pick<q % NS>(S0, S1, S2), b);
-                    if constexpr (q == NQ - 1) {
-#pragma unroll
-                        for (int i = 0; i < TVC; ++i) asm volatile("" :: "v"(b[i]) : "memory");
-                        cur.e = walk4_load_entry(prog + j + 3);
-                        tiny_issue();
-                    }
-                    compute(false, q, wg_pick<q % NS>(S0, S1, S2), b, q < CH ? f1 : f2);
-                } else {
-                    if constexpr (q == NQ - 1) {
-                        cur.e = walk4_load_entry(prog + j + 3);
-                        tiny_issue();
-                    }
-                    vec b[TVC];
-                    if (run) compute(true, q, wg_pick<q % NS>(S0, S1, S2), b, q < CH ? f1 : f2);
-                }
-            }
-        };
-        chunk(WgInt<0>{}); chunk(WgInt<1>{}); chunk(WgInt<2>{}); chunk(WgInt<3>{});
-        const unsigned dst = ce.dst, ewrite = ce.ewrite;
-        float out[TP];
-        float mx = 0.0f;
-#pragma unroll
-        for (int t = 0; t < TP; ++t) {
-            out[t] = (run && t < T) ? f1[t / ACC][t % ACC] * f2[t / ACC][t % ACC] : 0.0f;
-            mx = fmaxf(mx, out[t]);
-        }
-        {   // the other states of this pattern sit TW lanes apart: lane swaps in the VALU, no LDS round trip
-#if MBAMD_WG_TW == 16
-            const auto sq = __builtin_amdgcn_permlane16_swap(__float_as_uint(mx), __float_as_uint(mx), false, false);
-            mx = fmaxf(__uint_as_float(sq[0]), __uint_as_float(sq[1]));
-#endif
-            const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(mx), __float_as_uint(mx), false, false);
-            mx = fmaxf(__uint_as_float(sw[0]), __uint_as_float(sw[1]));
-        }
-        if constexpr (SCALAR_TINY) {
-            er_next = (int) (int8_t) tiny_pick(tinyE);
-            n2.s1 = tiny_pick(tiny1);
-            n2.s2 = tiny_pick(tiny2);
-        }
-        const int wm = mode == SCALE_WRITE ? -1 : 0, rm = mode == SCALE_READ ? -1 : 0;
-        const int e = (scale_exponent(mx) & wm) | (er & rm);
-        er = er_next;
-        const unsigned list = MBAMD_WG_LIST(ctl);
-#pragma unroll
-        for (int q = 0; q < MBAMD_WG_MAXLISTS; ++q) cum_e[q] += (list == (unsigned) q) ? (e & wm) : 0;
-        const float sc = mbd_pow2(-e);
-        vec ov[TV];
-#pragma unroll
-        for (int t = 0; t < TP; ++t) Vb::set(ov[t / V], t % V, out[t] * sc);   // (exact: |e| <= 126; 2^0 needs no branch)
-        if (ctl & MBAMD_W4_KEEP) {
-            vec* keep = reinterpret_cast<vec*>(reinterpret_cast<char*>(slots) + ((ctl >> 16) & 0xFFu) * SLOTB);
-#pragma unroll
-            for (int i = 0; i < TV; ++i) keep[i * 64] = ov[i];
-        }
-        MBAMD_AS_GLOBAL vec* pd = reinterpret_cast<MBAMD_AS_GLOBAL vec*>((uintptr_t) (P0 + dst)) + lane;
-#pragma unroll
-        for (int i = 0; i < TV; ++i) __builtin_nontemporal_store(ov[i], pd + i * 64);   // 64 * V * 4 contiguous bytes per instruction
-        __builtin_nontemporal_store((int8_t) e, as_global(E0 + ewrite) + col);   // (every lane group holds the same e: no exec-mask branch)
-    };
-    // the sets rotate by NQ positions per entry; three entries bring every (NS <= 3) rotation back to the start
-    for (int j = 0; j < n; j += 3) {
-        step(DA, DB, DC, wg_pick<0>(X, Y, Z), wg_pick<1 % NS>(X, Y, Z), wg_pick<2 % NS>(X, Y, Z), j);
-        step(DB, DC, DA, wg_pick<NQ % NS>(X, Y, Z), wg_pick<(NQ + 1) % NS>(X, Y, Z), wg_pick<(NQ + 2) % NS>(X, Y, Z), j + 1);
-        step(DC, DA, DB, wg_pick<(2 * NQ) % NS>(X, Y, Z), wg_pick<(2 * NQ + 1) % NS>(X, Y, Z), wg_pick<(2 * NQ + 2) % NS>(X, Y, Z), j + 2);
-    }
-    // cumulative exponents of this workgroup's TW columns: the waves' sums meet in LDS, wave 0 owns the memory update
-    int* const stage = reinterpret_cast<int*>(mine);
-#pragma unroll
-    for (int q = 0; q < MBAMD_WG_MAXLISTS; ++q) {
-        if (A.cum[q] == nullptr || (A.lists > 1 && q != (int) list)) continue;      // (separate lists: a workgroup holds one list)
-        int sum = cum_e[q];
-        if (W > 1) {
-            if (q > 0) __syncthreads();
-            stage[lane] = sum;
-            __syncthreads();
-            if (wave == 0)
-                for (int w = 1; w < W; ++w)
-                    sum += reinterpret_cast<const int*>(reinterpret_cast<const char*>(lds_walkg) + (size_t) w * (MBAMD_WG_STAGE + (size_t) A.nslots * SLOTB))[lane];
-        }
-        if (wave == 0 && half == 0) {
-            int32_t* d = A.cum[q] + (size_t) k * A.Ppad + (size_t) tile * TW + col;
-            if (A.cumFresh >> q & 1) *d = sum;
-            else if (sum != 0) *d += sum;
-        }
-    }
-}
+// LDS as the compiler must see it for a value another wave changes (address-space inference leaves volatile accesses flat)
+#define MBAMD_AS_LDS __attribute__((address_space(3)))
+#define MBD_DRAIN_ALL() asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory")      // this wave's stores and loads have completed
+#define MBD_DRAIN_VMEM() asm volatile("s_waitcnt vmcnt(0)" ::: "memory")
+#define MBD_WG_BARRIER() __builtin_amdgcn_s_barrier()
+#define MBD_COMPILER_FENCE() asm volatile("" ::: "memory")
+#define MBD_PIN_VGPR(x) asm volatile("" :: "v"(x) : "memory")                            // the value is in its register HERE
+#define MBD_SPIN_PAUSE() __builtin_amdgcn_s_sleep(1)
+__device__ __forceinline__ int mbd_uniform(int v) { return __builtin_amdgcn_readfirstlane(v); }
 }  // namespace mbamd
 #endif

@@ -798,14 +798,10 @@ void Instance::wgGeometry(int lists, int& W, int& slots) const
     int numCU = 256;
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0) numCU = prop.multiProcessorCount;
-    // registers bound the residency: 32-pattern tiles 4 (20 states) / 2 (61 states) waves per SIMD, 16-pattern tiles 5 / 3
-#if MBAMD_WG_TW == 32
+    // registers bound the residency: 4 (20 states) / 2 (61 states) waves per SIMD
     // (row split: a bin is a pair of waves sharing its slots; two bins = the four waves of a workgroup, one per SIMD, and two
     //  such workgroups per CU put two working waves on every SIMD)
     const int maxW = wgPair ? 2 : (S > 32 ? 4 : 8), wavesPerCU = wgPair ? 4 : (S > 32 ? 6 : 12);
-#else
-    const int maxW = S > 32 ? 4 : 8, wavesPerCU = S > 32 ? 12 : 20;
-#endif
     const int slotBytes = (int) wg_block_bytes(S);
     const long wgs = (long) (Ppad / MBAMD_WG_TW) * K * lists;
     const int perCU = (int) std::max(1L, (wgs + numCU - 1) / numCU);
@@ -817,7 +813,7 @@ void Instance::wgGeometry(int lists, int& W, int& slots) const
     while (W > 1 && slotsFor(W) < 4) W /= 2;
     if (const char* e = std::getenv("MBAMD_WALK_WAVES")) W = std::max(1, std::min(maxW, std::atoi(e)));
     slots = std::max(3, std::min(24, slotsFor(W)));
-    if (const char* e = std::getenv("MBAMD_MAX_LDS_SLOTS")) slots = std::max(3, std::min((160 * 1024 / W - (int) wg_stage_bytes(wgPair)) / slotBytes, std::atoi(e)));
+    if (const char* e = std::getenv("MBAMD_MAX_LDS_SLOTS")) slots = std::max(1, std::min((160 * 1024 / W - (int) wg_stage_bytes(wgPair)) / slotBytes, std::atoi(e)));
 }
 
 // 4-state path: one tip's state masks (bit i = state i compatible) -> four 64-bit bitplanes per pattern block
@@ -2166,9 +2162,7 @@ int Instance::runWalkG(const Plan& plan)
         a.cumFresh = (&sg == &plan.segments.front()) ? wgFresh : 0;
         a.K = K; a.Ppad = Ppad; a.ntiles = Ppad / MBAMD_WG_TW; a.S = S; a.SP = SP;
         a.lists = plan.lists;
-#if MBAMD_DEV_SPREAD
-        a.spread = sg.W * wg_waves_per_bin(wgPair) == 2 ? 1 : 0;
-#endif
+        a.spread = sg.W * wg_waves_per_bin(wgPair) == 2 ? 1 : 0;     // two-wave workgroups are launched as four (see k_walkg)
         a.pair = wgPair ? 1 : 0;
         if (wg2) { MBAMD_WG2_DISPATCH(S, launch_walkg2_t, *this, a, sg.W, sg.nslots, &plan.inlineProg); }
         else { MBAMD_WG_DISPATCH(S, launch_walkg_t, *this, a, sg.W, sg.nslots, &plan.inlineProg); }
@@ -3228,7 +3222,7 @@ int beagleCreateInstance(int tipCount, int partialsBufferCount, int compactBuffe
         returnInfo->resourceName = (dev < g_resources.length) ? g_resources.list[dev].name : const_cast<char*>("HIP device");
         returnInfo->implName = const_cast<char*>(first->f64 ? (first->S == 4 ? MBAMD_IMPL_NAME ": double-precision kernels (four states: tree walk)" : MBAMD_IMPL_NAME ": double-precision level kernels")
                                                  : first->s4 ? MBAMD_IMPL_NAME ": 4-state tree-walk kernels"
-                                                 : first->wg ? (MBAMD_WG_TW == 32 ? MBAMD_IMPL_NAME ": 20/61-state tree-walk kernels (v_mfma_f32_32x32x2_f32)" : MBAMD_IMPL_NAME ": 20/61-state tree-walk kernels (v_mfma_f32_16x16x4_f32)")
+                                                 : first->wg ? MBAMD_IMPL_NAME ": 20/61-state tree-walk kernels (v_mfma_f32_32x32x2_f32)"
                                                  : first->mfma ? MBAMD_IMPL_NAME ": general-state MFMA (v_mfma_f32_32x32x2_f32) kernels"
                                                                : MBAMD_IMPL_NAME ": general-state vector kernels");
         returnInfo->implDescription = const_cast<char*>("hand-written HIP kernels for AMD CDNA4 (MI355X)");

@@ -48,17 +48,13 @@ namespace mbamd {
 #define MBAMD_WG_PREV2    0x4000u
 #define MBAMD_WG_DRAIN    0x1000u   // (row split) the result is re-read from HBM by this bin in this phase: stores complete before the pair moves on
 
-// Tile width: patterns per wave.  32 = v_mfma_f32_32x32x2_f32 (two states per MFMA step, lane = 32 h + pattern), 16 =
-// v_mfma_f32_16x16x4_f32 (four states per step, lane = 16 g + pattern): twice the waves for the same alignment, each with half
-// the accumulators, half the epilogue and a 40- instead of 64-cycle dependent MFMA latency.  One or the other per build.
-// MEASURED (round 3, profiles/r03_exp_walkg_tile16_ablation.txt): 16 is bit-for-bit as correct (every GPU parity test) and
-// SLOWER -- codon 100 x 5 000: 0.32 against 0.19 ms, protein 200 x 10 000: 0.34 (0.28 with one wave per workgroup) against
-// 0.23 ms -- because every wave fetches the whole A table of every child whatever its tile width: halving the tile doubles
-// that traffic, and the operand fetch is what bounds the kernel (with the fetch ablated 16 beats 32: 0.104 against 0.118 ms).
-// The product is built with 32; -DMBAMD_WG_TW=16 keeps the other one buildable (tools/build_variants.py).
-#if !defined(MBAMD_WG_TW)
+// Tile width: patterns per wave = 32 (v_mfma_f32_32x32x2_f32: two states per MFMA step, lane = 32 h + pattern).  A 16-pattern
+// variant on v_mfma_f32_16x16x4_f32 (twice the waves, half the accumulators and epilogue each, 40- instead of 64-cycle dependent MFMA
+// latency) was built in round 3, bit-for-bit as correct and SLOWER -- codon 100 x 5 000: 0.32 against 0.19 ms, protein 200 x 10 000:
+// 0.34 against 0.23 ms (profiles/r03_exp_walkg_tile16_ablation.txt) -- because every wave fetches the whole A table of every child
+// whatever its tile width: halving the tile doubles that traffic, and the operand fetch is what bounds the kernel.  Its branches
+// were removed in round 5 (git history has them).
 #define MBAMD_WG_TW 32
-#endif
 #define MBAMD_WG_KS (64 / MBAMD_WG_TW)    // states per row of a block = per MFMA step (2 or 4)
 // Row split (round 5, k_walkg2; an instance created with MBAMD_WALKG_PAIR=1): beyond 48 states (the sense codons: two 32-row
 // output tiles) a (tile, category, subtree bin) is a PAIR of waves -- wave h of the pair owns output tile h: half of A', half of
@@ -69,20 +65,13 @@ namespace mbamd {
 // the transition-matrix kernels take "where the tables start" as one size_t (wgTab, floats into a matrix buffer; 0: no tables):
 // its top bit says that the instance's tables have the row-split layout
 #define MBAMD_WG_TAB_SPLIT ((size_t) 1 << 63)
-__host__ __device__ inline bool wg_split_states(int S) { return MBAMD_WG_TW == 32 && S > 48; }
+__host__ __device__ inline bool wg_split_states(int S) { return S > 48; }
 // state counts k_walkg2 is instantiated for (one output tile per wave: up to 32 states, or the row split); 40 states: k_walkg only
-__host__ __device__ inline bool wg2_states(int S) { return MBAMD_WG_TW == 32 && (S <= 32 || S > 48); }
+__host__ __device__ inline bool wg2_states(int S) { return S <= 32 || S > 48; }
 __host__ __device__ inline int wg_pairs(int S) { return (S + MBAMD_WG_KS - 1) / MBAMD_WG_KS; }         // T: MFMA steps (rows of a block)
 __host__ __device__ inline int wg_tiles(int S) { return (S + MBAMD_WG_TW - 1) / MBAMD_WG_TW; }         // NT: output tiles of TW rows
-#if MBAMD_WG_TW == 32
 __host__ __device__ inline int wg_vec(int S) { return S > 32 ? 4 : 2; }                   // V: floats per lane and memory instruction (blocks)
 __host__ __device__ inline int wg_vec_a(int S) { return wg_vec(S); }                      // VA: the same for the tables
-#else
-// blocks: 61 states 16 rows (V 4), 20 states 5 rows (V 1: no padding bytes -- the time follows the bytes), 16 states 4 rows
-__host__ __device__ inline int wg_vec(int S) { const int T = wg_pairs(S); return (S > 32 || T % 4 == 0) ? 4 : (T % 2 == 0 ? 2 : 1); }
-// tables: rows n = t NT + it; 61 states 64 rows (VA 4), 20 states 10 rows (VA 2), 16 states 4 rows (VA 4)
-__host__ __device__ inline int wg_vec_a(int S) { const int n = wg_pairs(S) * wg_tiles(S); return (S > 32 || n % 4 == 0) ? 4 : (n % 2 == 0 ? 2 : 1); }
-#endif
 __host__ __device__ inline int wg_pairs_padded(int S) { return (wg_pairs(S) + wg_vec(S) - 1) / wg_vec(S) * wg_vec(S); }   // TP
 __host__ __device__ inline int wg_rows(int S)                                             // NAP: 256-byte rows of a table
 {
@@ -116,39 +105,25 @@ __host__ __device__ inline unsigned wg_elem(int S, int i, int p) { return wg_at(
 //       the column of state S ("missing") holds 1 for every existing from-state.
 // The ROWS of A' are permuted so that the output tile lands in block layout (register r of lane group h = the state the
 // next MFMA step t = ... wants there):
-//   TW 32:  register r, half h           = state 32 it + 2 r + h;   A'(n, 32 (j & 1) + row) with row = (r & 3) + 8 (r >> 2) + 4 h
-//           G_u(n = r NT + it, 2 s + h)
-//           row split (wg_split): n = it TP + t for A', n = it TP + r for G_u -- an output tile's rows are contiguous
-//   TW 16:  register r (0..3), group g   = state 16 it + 4 r + g;   A'(n, 16 (j & 3) + row) with row = 4 g + r
-//           G_u(n = r NT + it, 4 s + g)
+//   register r, half h = state 32 it + 2 r + h;   A'(n, 32 (j & 1) + row) with row = (r & 3) + 8 (r >> 2) + 4 h
+//   G_u(n = r NT + it, 2 s + h)
+//   row split (wg_split): n = it TP + t for A', n = it TP + r for G_u -- an output tile's rows are contiguous
 // scatter P_k(i -> j) = v into the tables of category k (tab = first float of that category's tables)
 __host__ __device__ inline void wg_table_put(float* tab, int S, int i, int j, float v, bool sp = false)
 {
     const int NT = wg_tiles(S), NAP = wg_rows(S), VA = wg_vec_a(S);
-#if MBAMD_WG_TW == 32
     const int it = i >> 5, r = (i & 31) >> 1, h = i & 1;
     const int row = (r & 3) + 8 * (r >> 2) + 4 * h;                        // MFMA row that carries state i
     const int TP = wg_pairs_padded(S);
     tab[wg_at(VA, sp ? it * TP + (j >> 1) : (j >> 1) * NT + it, row + 32 * (j & 1))] = v;            // A'
     tab[(size_t) (1 + (j >> 5)) * NAP * 64 + wg_at(VA, sp ? it * TP + r : r * NT + it, 2 * (j & 31) + h)] = v;   // G_u
-#else
-    const int it = i >> 4, r = (i & 15) >> 2, g = i & 3;
-    const int row = 4 * g + r;
-    tab[wg_at(VA, (j >> 2) * NT + it, row + 16 * (j & 3))] = v;            // A'
-    tab[(size_t) (1 + (j >> 4)) * NAP * 64 + wg_at(VA, r * NT + it, 4 * (j & 15) + g)] = v;   // G_u
-#endif
 }
 // the "missing" column (constant): from-state i
 __host__ __device__ inline void wg_table_put_missing(float* tab, int S, int i, bool sp = false)
 {
     const int NT = wg_tiles(S), NAP = wg_rows(S), VA = wg_vec_a(S);
-#if MBAMD_WG_TW == 32
     const int it = i >> 5, r = (i & 31) >> 1, h = i & 1;
     tab[(size_t) (1 + (S >> 5)) * NAP * 64 + wg_at(VA, sp ? it * wg_pairs_padded(S) + r : r * NT + it, 2 * (S & 31) + h)] = 1.0f;
-#else
-    const int it = i >> 4, r = (i & 15) >> 2, g = i & 3;
-    tab[(size_t) (1 + (S >> 4)) * NAP * 64 + wg_at(VA, r * NT + it, 4 * (S & 15) + g)] = 1.0f;
-#endif
 }
 // one thread per (matrix, category, state): the constant column of every matrix buffer, once per instance
 __global__ void __launch_bounds__(256)
@@ -192,6 +167,7 @@ __device__ __forceinline__ const WalkGArgs& wg_args(const WalkGArgsInline& a) { 
 __device__ __forceinline__ const Walk4Entry* wg_program(const WalkGArgs& a) { return a.prog; }
 
 }  // namespace mbamd
-#include <mbamd_dev_walkg_kernel.h>   // wg_program(const WalkGArgsInline&) and k_walkg itself (csrc/device/: the MFMA kernel)
-#include <mbamd_dev_walkg2_kernel.h>  // k_walkg2: a whole entry's operands in flight; the row-split pair (round 5)
+#include <mbamd_dev_walkg_kernel.h>   // the kernels' device primitives (csrc/device/: MFMA, lane swap, waits; tests/hostemu/: the same on fibers)
+#include "mbamd_walkg_kernel.h"       // k_walkg
+#include "mbamd_walkg2_kernel.h"      // k_walkg2: a whole entry's operands in flight; the row-split pair (round 5)
 #endif

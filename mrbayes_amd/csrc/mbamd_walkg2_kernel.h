@@ -1,4 +1,4 @@
-// mbamd_dev_walkg2_kernel.h (gfx950) -- k_walkg2: the general-state tree walk of mbamd_walkg.h with the operands of a whole ENTRY in
+// mbamd_walkg2_kernel.h -- k_walkg2: the general-state tree walk of mbamd_walkg.h with the operands of a whole ENTRY in
 // flight (round 5).  Same programs (Walk4Entry), arenas, tables, slots and decomposition as k_walkg; what differs is the pipeline:
 //
 //   * What round 5 measured (profiles/r05_mfma_shadow.txt, r05_walkg_ablation.txt): for fp32 the matrix core and the vector ALU
@@ -18,8 +18,8 @@
 //
 // blockDim.x = 64 * W * wg_waves_per_bin(S) (* 2 with `spread`); grid = walkg_grid(ntiles, K * lists); dynamic LDS = wg_lds_bytes.
 // Programs: no leading NOPs, padded to a multiple of 2, MBAMD_WG2_TAIL trailing NOPs (descriptor read-ahead).
-#ifndef MBAMD_DEV_WALKG2_KERNEL_H_
-#define MBAMD_DEV_WALKG2_KERNEL_H_
+#ifndef MBAMD_WALKG2_KERNEL_H_
+#define MBAMD_WALKG2_KERNEL_H_
 namespace mbamd {
 
 #if !defined(MBAMD_WG2_MINWAVES)
@@ -43,7 +43,7 @@ k_walkg2(ARGS AA)
     typedef typename Sh::Va Va;
     typedef typename Sh::acc acc_t;
     typedef Wg2Ops<SC, PAIR> Ops;
-    static_assert(MBAMD_WG_TW == 32 && (Sh::SPLIT || Sh::NT == 1), "k_walkg2: one output tile per wave");
+    static_assert(Sh::SPLIT || Sh::NT == 1, "k_walkg2: one output tile per wave");
     constexpr bool SPLIT = Sh::SPLIT;
     constexpr int TW = 32, KS = 2, ACC = Sh::ACC;
     constexpr int T = Sh::T, V = Sh::V, VA = Sh::VA, TP = Sh::TP, NAP = Sh::NAP, TV = TP / V;
@@ -56,7 +56,7 @@ k_walkg2(ARGS AA)
     static_assert(NG <= NA && TPO % V == 0, "operand geometry");
 
     const unsigned lane = threadIdx.x & 63, half = lane / TW, col = lane % TW;
-    int wave = __builtin_amdgcn_readfirstlane((int) (threadIdx.x >> 6));
+    int wave = mbd_wave_index();
     int W = (int) (blockDim.x >> 6);
     if (A.spread) {                                  // two-wave workgroups are launched as four (see k_walkg)
         if (wave & 1) return;
@@ -65,7 +65,7 @@ k_walkg2(ARGS AA)
     }
     const int hw = SPLIT ? (wave & 1) : 0;           // row split: the output tile this wave owns; from here on `wave`, `W` count bins
     if constexpr (SPLIT) { wave >>= 1; W >>= 1; }
-    extern __shared__ float lds_walkg[];
+    float* const lds_walkg = mbd_dyn_lds<float>();
     const unsigned K = (unsigned) A.K, KL = K * (unsigned) A.lists;
     const unsigned xcd = blockIdx.x & 7u, pos = blockIdx.x >> 3;
     const unsigned tile = (pos / KL) * 8u + xcd, k = (pos % KL) % K, list = (pos % KL) / K;
@@ -88,23 +88,23 @@ k_walkg2(ARGS AA)
     //            maxima are in the exchange area                      -> the partner may take the maxima and overwrite child slots
     //   2 n + 2  this wave's rows of result n are in their slot       -> the partner may read result n
     // (an LDS pointer in so many words: address-space inference leaves volatile accesses flat)
-    typedef __attribute__((address_space(3))) volatile int wg_lds_vint;
+    typedef MBAMD_AS_LDS volatile int wg_lds_vint;
     float* const xmax = reinterpret_cast<float*>(mine + 256);
     wg_lds_vint* const progress = (wg_lds_vint*) (mine + 768);
     int sig = 0;
     bool drained = false;
     auto pair_signal = [&]() {
-        asm volatile("" ::: "memory");
+        MBAMD_WAVE_SYNC();                           // (every lane's LDS writes are in front of the counter)
         progress[hw] = ++sig;
-        asm volatile("" ::: "memory");
+        MBD_COMPILER_FENCE();
     };
     auto pair_wait = [&]() {
-        while (__builtin_amdgcn_readfirstlane(progress[hw ^ 1]) < sig) __builtin_amdgcn_s_sleep(1);
-        asm volatile("" ::: "memory");
+        while (mbd_uniform(progress[hw ^ 1]) < sig) MBD_SPIN_PAUSE();
+        MBD_COMPILER_FENCE();
     };
     if constexpr (SPLIT) {
         progress[hw] = 0;
-        __syncthreads();
+        MBAMD_SYNC();
     }
 
     // the operand rows of entry e (both children) -> register set o: 2 NA loads on every path
@@ -147,7 +147,7 @@ k_walkg2(ARGS AA)
         if (mem) {
 #pragma unroll
             for (int t = 0; t < T; ++t)
-                f = __builtin_amdgcn_mfma_f32_32x32x2f32(Va::get(a[t / VA], t % VA), Vb::get(bm[t / V], t % V), f, 0, 0, 0);
+                f = mbd_mfma_f32_32x32x2(Va::get(a[t / VA], t % VA), Vb::get(bm[t / V], t % V), f);
             return;
         }
         const vec* sl = reinterpret_cast<const vec*>(reinterpret_cast<const char*>(slots) + coff);
@@ -159,7 +159,7 @@ k_walkg2(ARGS AA)
 #pragma unroll
         for (int t = 0; t < T; ++t) {
             const float bv = t < TH * V ? Vb::get(b0[t / V], t % V) : Vb::get(b1[(t - TH * V) / V], (t - TH * V) % V);
-            f = __builtin_amdgcn_mfma_f32_32x32x2f32(Va::get(a[t / VA], t % VA), bv, f, 0, 0, 0);
+            f = mbd_mfma_f32_32x32x2(Va::get(a[t / VA], t % VA), bv, f);
         }
     };
 
@@ -195,9 +195,9 @@ k_walkg2(ARGS AA)
         const unsigned ctl = ce.ctl;
         if (ctl & MBAMD_W4_BARRIER) {
             // values other bins produced in the previous phase are read from here on: drain this wave's stores, meet
-            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-            __builtin_amdgcn_s_barrier();
-            asm volatile("" ::: "memory");
+            MBD_DRAIN_ALL();
+            MBD_WG_BARRIER();
+            MBD_COMPILER_FENCE();
         }
         const bool run = !(ctl & MBAMD_W4_NOP);
         const unsigned mode = (ctl >> 8) & 3u;
@@ -255,10 +255,7 @@ k_walkg2(ARGS AA)
             for (int t = 0; t < TPO; ++t) out[t] = 0.0f;
         }
         fetch(d2, t1, t2, cur);                      // (the set is free: entry j + 2's operands)
-        {   // the other states of this pattern sit 32 lanes apart
-            const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(mx), __float_as_uint(mx), false, false);
-            mx = fmaxf(__uint_as_float(sw[0]), __uint_as_float(sw[1]));
-        }
+        mx = mbd_max_lane_xor32(mx);                 // the other states of this pattern sit 32 lanes apart
         if constexpr (SPLIT) {
             if (run) {                               // the column maximum over all states = the larger of the two waves' maxima
                 float* const xm = xmax + ((sig >> 1) & 1) * 64;
@@ -298,7 +295,7 @@ k_walkg2(ARGS AA)
         __builtin_nontemporal_store((int8_t) e, as_global(E0 + ce.ewrite) + col);       // (every lane group holds the same e: no exec-mask branch)
         if constexpr (SPLIT) {
             if (run && (ctl & MBAMD_WG_DRAIN)) {     // (rare: a result this bin re-reads from HBM in this phase -- evicted from its slots)
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                MBD_DRAIN_VMEM();
                 pair_signal();
                 drained = true;
             }
@@ -317,9 +314,9 @@ k_walkg2(ARGS AA)
         if (A.cum[q] == nullptr || (A.lists > 1 && q != (int) list)) continue;      // (separate lists: a workgroup holds one list)
         int sum = cum_e[q];
         if (W > 1) {
-            if (q > 0) __syncthreads();
+            if (q > 0) MBAMD_SYNC();
             if (hw == 0) stage[lane] = sum;
-            __syncthreads();
+            MBAMD_SYNC();
             if (wave == 0)
                 for (int w = 1; w < W; ++w)
                     sum += reinterpret_cast<const int*>(reinterpret_cast<const char*>(lds_walkg) + (size_t) w * (STAGE + (size_t) A.nslots * SLOTB))[lane];

@@ -123,29 +123,133 @@ inline void emu_launch(Kernel kernel, dim3 grid, dim3 block, size_t lds_bytes, A
 }
 #define MBAMD_LAUNCH(kernel, grid, block, lds, stream, ...) emu_launch(kernel, dim3(grid), dim3(block), lds, __VA_ARGS__)
 
-// ---- workgroup barriers: the threads of one block as fibers ---------------------------------------------------
+// ---- workgroup barriers and wave collectives: the threads of one block as fibers ------------------------------
+// A fiber runs until it has to wait for others (a workgroup barrier, a wave-wide exchange such as an emulated MFMA, a spin on a
+// value another wave writes) and yields; the scheduler resumes the fibers of the block in thread order, round after round.
+// Barriers COUNT arrivals -- waves of one workgroup may pass different numbers of wave-level exchanges between two workgroup
+// barriers -- and threads that have left the kernel do not count (like s_barrier).  After a barrier the threads resume in thread
+// order (thread 0 first: the plain-C++ reductions of mbamd_dev_base.h rely on it).
+#if defined(__x86_64__)
+// switching a fiber = six callee-saved registers and the stack pointer (swapcontext adds two system calls for the signal mask;
+// an emulated 61-state operation is ~8 000 switches)
+extern "C" void mbamd_emu_switch(void** save_sp, void* load_sp);
+asm(".text\n.globl mbamd_emu_switch\n.hidden mbamd_emu_switch\n.type mbamd_emu_switch,@function\nmbamd_emu_switch:\n"
+    "pushq %rbp\npushq %rbx\npushq %r12\npushq %r13\npushq %r14\npushq %r15\n"
+    "movq %rsp, (%rdi)\nmovq %rsi, %rsp\n"
+    "popq %r15\npopq %r14\npopq %r13\npopq %r12\npopq %rbx\npopq %rbp\nret\n"
+    ".size mbamd_emu_switch, .-mbamd_emu_switch\n");
+struct EmuContext { void* sp = nullptr; };
+#else
+struct EmuContext { ucontext_t uc; };
+#endif
+struct EmuWave {                                     // a wave's exchange area: what every lane contributed to the current collective
+    unsigned arrived = 0, generation = 0, live = 0;
+    uint32_t x[2][2][64];                            // [parity of the collective][operand][lane]
+    unsigned parity = 0;
+};
 struct EmuFibers {
-    ucontext_t scheduler;
-    std::vector<ucontext_t> ctx;
+    EmuContext scheduler;
+    std::vector<EmuContext> ctx;
     std::vector<std::vector<unsigned char>> stacks;
     std::vector<char> done;
+    std::vector<EmuWave> waves;
     int current = -1;
+    unsigned live = 0, arrived = 0, generation = 0;  // the workgroup barrier
     void (*body)(void*) = nullptr;
     void* arg = nullptr;
 };
 inline EmuFibers& emu_fibers() { static thread_local EmuFibers f; return f; }
+inline void emu_fiber_entry();
+inline void emu_to_scheduler(EmuFibers& f)
+{
+#if defined(__x86_64__)
+    mbamd_emu_switch(&f.ctx[f.current].sp, f.scheduler.sp);
+#else
+    swapcontext(&f.ctx[f.current].uc, &f.scheduler.uc);
+#endif
+}
+inline void emu_to_fiber(EmuFibers& f, unsigned t)
+{
+#if defined(__x86_64__)
+    mbamd_emu_switch(&f.scheduler.sp, f.ctx[t].sp);
+#else
+    swapcontext(&f.scheduler.uc, &f.ctx[t].uc);
+#endif
+}
+inline void emu_fiber_prepare(EmuFibers& f, unsigned t)
+{
+#if defined(__x86_64__)
+    uintptr_t top = (reinterpret_cast<uintptr_t>(f.stacks[t].data()) + f.stacks[t].size()) & ~(uintptr_t) 15;
+    void** sp = reinterpret_cast<void**>(top) - 8;   // r15 r14 r13 r12 rbx rbp | return address = the entry | a slot a caller would own
+    for (int i = 0; i < 8; ++i) sp[i] = nullptr;
+    sp[6] = reinterpret_cast<void*>(&emu_fiber_entry);
+    f.ctx[t].sp = sp;
+#else
+    getcontext(&f.ctx[t].uc);
+    f.ctx[t].uc.uc_stack.ss_sp = f.stacks[t].data();
+    f.ctx[t].uc.uc_stack.ss_size = f.stacks[t].size();
+    f.ctx[t].uc.uc_link = &f.scheduler.uc;
+    makecontext(&f.ctx[t].uc, (void (*)()) emu_fiber_entry, 0);
+#endif
+}
+// give the other threads of the block a turn (a spin on something another wave writes)
+inline void mbamd_emu_yield()
+{
+    EmuFibers& f = emu_fibers();
+    if (f.current >= 0) emu_to_scheduler(f);
+}
+inline bool mbamd_emu_fibers_active() { return emu_fibers().current >= 0; }
 inline void mbamd_emu_barrier()
 {
     EmuFibers& f = emu_fibers();
     if (f.current < 0) return;                       // plain launch: threads run to completion one after another
-    swapcontext(&f.ctx[f.current], &f.scheduler);    // every thread of the block stops here; the scheduler resumes them in order
+    const unsigned gen = f.generation;
+    if (++f.arrived >= f.live) { f.arrived = 0; ++f.generation; }
+    do emu_to_scheduler(f); while (f.generation == gen);   // (the last to arrive yields too: everybody resumes in thread order)
+}
+// all lanes of the calling thread's wave have arrived (only wave-uniform control flow may reach it)
+inline EmuWave& mbamd_emu_wave()
+{
+    EmuFibers& f = emu_fibers();
+    return f.waves[(unsigned) f.current >> 6];
+}
+inline void mbamd_emu_wave_sync()
+{
+    EmuFibers& f = emu_fibers();
+    if (f.current < 0) return;
+    EmuWave& w = f.waves[(unsigned) f.current >> 6];
+    const unsigned gen = w.generation;
+    if (++w.arrived >= w.live) { w.arrived = 0; ++w.generation; return; }
+    do emu_to_scheduler(f); while (w.generation == gen);
+}
+// every lane contributes two 32-bit values and sees what all lanes contributed (one synchronisation per collective: the areas of
+// consecutive collectives alternate, and nobody can be two collectives ahead of a lane that has not read yet)
+struct EmuExchange { const uint32_t* a; const uint32_t* b; };
+inline EmuExchange mbamd_emu_exchange(uint32_t a, uint32_t b)
+{
+    EmuFibers& f = emu_fibers();
+    if (f.current < 0) { std::fprintf(stderr, "host emulation: a wave-wide exchange in a kernel launched without fibers\n"); std::abort(); }
+    EmuWave& w = f.waves[(unsigned) f.current >> 6];
+    const unsigned lane = (unsigned) f.current & 63u;
+    const unsigned par = w.parity;                   // (uniform: flipped by the lane that completes the collective)
+    w.x[par][0][lane] = a;
+    w.x[par][1][lane] = b;
+    const unsigned gen = w.generation;
+    if (++w.arrived >= w.live) { w.arrived = 0; w.parity ^= 1u; ++w.generation; }
+    else do emu_to_scheduler(f); while (w.generation == gen);
+    return EmuExchange{w.x[par][0], w.x[par][1]};
 }
 inline void emu_fiber_entry()
 {
     EmuFibers& f = emu_fibers();
     f.body(f.arg);
     f.done[f.current] = 1;
-    swapcontext(&f.ctx[f.current], &f.scheduler);
+    // a thread that leaves no longer takes part in barriers: release whoever was only waiting for it
+    EmuWave& w = f.waves[(unsigned) f.current >> 6];
+    --f.live; --w.live;
+    if (f.live > 0 && f.arrived >= f.live) { f.arrived = 0; ++f.generation; }
+    if (w.live > 0 && w.arrived >= w.live) { w.arrived = 0; w.parity ^= 1u; ++w.generation; }
+    for (;;) emu_to_scheduler(f);
 }
 template <class Kernel, class... Args>
 inline void emu_launch_barrier(Kernel kernel, dim3 grid, dim3 block, size_t lds_bytes, Args... args)
@@ -158,6 +262,7 @@ inline void emu_launch_barrier(Kernel kernel, dim3 grid, dim3 block, size_t lds_
     if (f.ctx.size() < T) { f.ctx.resize(T); f.stacks.resize(T); }
     for (unsigned t = 0; t < T; ++t) if (f.stacks[t].empty()) f.stacks[t].resize(256 * 1024);
     f.done.assign(T, 0);
+    f.waves.resize((T + 63) / 64);
     auto call = [&]() { kernel(args...); };
     f.body = [](void* p) { (*static_cast<decltype(call)*>(p))(); };
     f.arg = &call;
@@ -168,21 +273,20 @@ inline void emu_launch_barrier(Kernel kernel, dim3 grid, dim3 block, size_t lds_
             size_t space = lds.size();
             emu_lds_ptr() = std::align(16, lds_bytes, base, space);
             std::fill(f.done.begin(), f.done.end(), 0);
-            for (unsigned t = 0; t < T; ++t) {
-                getcontext(&f.ctx[t]);
-                f.ctx[t].uc_stack.ss_sp = f.stacks[t].data();
-                f.ctx[t].uc_stack.ss_size = f.stacks[t].size();
-                f.ctx[t].uc_link = &f.scheduler;
-                makecontext(&f.ctx[t], (void (*)()) emu_fiber_entry, 0);
+            f.live = T; f.arrived = 0; f.generation = 0;
+            for (unsigned w = 0; w < f.waves.size(); ++w) {
+                f.waves[w].arrived = 0; f.waves[w].generation = 0; f.waves[w].parity = 0;
+                f.waves[w].live = std::min(64u, T - 64u * w);
             }
+            for (unsigned t = 0; t < T; ++t) emu_fiber_prepare(f, t);
             unsigned live = T;
-            while (live > 0) {                       // one pass = every live thread runs to its next barrier (or to its end)
+            while (live > 0) {                       // one pass = every live thread runs until it has to wait (or to its end)
                 live = 0;
                 for (unsigned t = 0; t < T; ++t) {
                     if (f.done[t]) continue;
                     emu_threadIdx() = dim3(t, 0, 0);
                     f.current = (int) t;
-                    swapcontext(&f.scheduler, &f.ctx[t]);
+                    emu_to_fiber(f, t);
                     if (!f.done[t]) ++live;
                 }
             }

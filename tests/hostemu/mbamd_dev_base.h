@@ -7,7 +7,7 @@
 #define MBAMD_AS_CONST
 #define MBAMD_SYNC() mbamd_emu_barrier()
 #define MBAMD_STORE_NT(value, pointer) (*(pointer) = (value))
-#define MBAMD_WAVE_SYNC() mbamd_emu_barrier()      // (threads are fibers here: only uniform control flow may reach it)
+#define MBAMD_WAVE_SYNC() mbamd_emu_wave_sync()    // (threads are fibers here: all lanes of the wave have arrived; wave-uniform control flow only)
 #define MBAMD_CONSUME1(a) ((void) (a))
 #define MBAMD_CONSUME4(a, b, c, d) ((void) (a), (void) (b), (void) (c), (void) (d))
 #define MBAMD_IMPL_NAME "mbamd HOST EMULATION (test only)"

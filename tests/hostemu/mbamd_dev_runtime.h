@@ -4,5 +4,4 @@
 #include <memory>
 #include "hip_emu.h"
 #define MBAMD_DEV_HAS_MFMA 0
-#define MBAMD_DEV_SPREAD 0
 #endif
