@@ -46,6 +46,16 @@ template <class T> __device__ __forceinline__ T* mbd_dyn_lds()
     extern __shared__ __attribute__((aligned(16))) unsigned char mbd_lds_bytes[];
     return reinterpret_cast<T*>(mbd_lds_bytes);
 }
+// D (16 x 16) += A (16 x 4) B (4 x 16) in fp64: lane l gives A[l & 15][l >> 4] and B[l >> 4][l & 15] and holds column l & 15 of D,
+// register r = row (l >> 4) + 4 r
+typedef double f64x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ f64x4 mbd_mfma_f64_16x16x4(double a, double b, f64x4 c) { return __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0); }
+#define MBD_SCHED_BARRIER() __builtin_amdgcn_sched_barrier(0)
+__device__ __forceinline__ float mbd_shfl_xor(float v, int d) { return __shfl_xor(v, d); }         // the value lane l ^ d holds
+__device__ __forceinline__ double mbd_shfl_xor(double v, int d) { return __shfl_xor(v, d); }
+__device__ __forceinline__ long long mbd_clock() { return (long long) __builtin_amdgcn_s_memtime(); }   // (timing experiments)
+// the value lane l + off of this lane's group of 32 holds (its own beyond the group's end)
+__device__ __forceinline__ double mbd_shfl_down_32(double v, int off) { return __shfl_down(v, off, 32); }
 // sum of `v` over the 64 lanes of the (only) wave of a 64-thread block, stored by lane 0: fixed order, deterministic
 __device__ __forceinline__ void mbd_wave_sum_store(double v, double* slot)
 {

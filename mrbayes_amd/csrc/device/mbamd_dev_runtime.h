@@ -6,5 +6,4 @@
 #define MBAMD_LAUNCH(kernel, grid, block, lds, stream, ...) \
     hipLaunchKernelGGL(kernel, dim3(grid), dim3(block), lds, stream, __VA_ARGS__)
 #define MBAMD_LAUNCH_BARRIER MBAMD_LAUNCH          // (the host emulation runs kernels with workgroup barriers as fibers)
-#define MBAMD_DEV_HAS_MFMA 1                       // the matrix-core kernels of mbamd_kernels_mfma.h exist (level kernels, wide integration, fp64 MFMA matrices)
 #endif

@@ -26,9 +26,7 @@
 #include "mbamd_reports.h"
 #include "libhmsbeagle/mbamd_reports.h"
 #include "mbamd_walk4_host.h"
-#if MBAMD_DEV_HAS_MFMA
 #include "mbamd_kernels_mfma.h"
-#endif
 
 #include <chrono>
 
@@ -494,11 +492,9 @@ struct Instance {
     int fetchResult(double* out);
 };
 
-#if MBAMD_DEV_HAS_MFMA
 static bool launch_mfma_split(Instance& in, const OpTables& tabs, int count);
 static bool launch_mfma_serial(Instance& in, const OpTables& tabs, int ntables);
 static bool launch_tips(Instance& in, const OpTables& tabs, int count);
-#endif
 
 static std::mutex g_mutex;
 static std::vector<Instance*> g_instances;
@@ -569,7 +565,6 @@ int Instance::create(int tipCount_, int partialsBufferCount, int compactBufferCo
     else if (S <= 20) SP = 20;
     else if (S <= 32) SP = 32;
     else SP = 64;
-#if MBAMD_DEV_HAS_MFMA
     NT = (S + 31) / 32;
     T = (S + 1) / 2;
     mfma = !s4 && !wg && S >= 5 && S <= 64 && ((NT == 1 && K <= 4) || (NT == 2 && K <= 2)) &&
@@ -584,7 +579,6 @@ int Instance::create(int tipCount_, int partialsBufferCount, int compactBufferCo
     if (const char* e = std::getenv("MBAMD_SPINE_WIDTH")) spineWidth = std::max(1, std::atoi(e));
     // serial / spine kernels exist for these shapes only (other category counts: level launches throughout)
     if (!((NT == 1 && (K == 1 || K == 2 || K == 4)) || (NT == 2 && (K == 1 || K == 2)))) serialRatio = 0;
-#endif
     envVerbose = std::getenv("MBAMD_VERBOSE") != nullptr;
     envTrace = std::getenv("MBAMD_WALK_TRACE") != nullptr;
     if (std::getenv("MBAMD_REPORT_DEVICE")) {    // one line per instance: which physical GPU (multi-rank drivers collect them: bench.py mpi_mcmc)
@@ -670,9 +664,7 @@ int Instance::create(int tipCount_, int partialsBufferCount, int compactBufferCo
     HIP_TRY(hipMalloc(&d_pweights, (size_t) Ppad * sizeof(double)));
     HIP_TRY(hipMalloc(&d_site, (size_t) Ppad * sizeof(double)));
     nblocks = Ppad / 64;
-#if MBAMD_DEV_HAS_MFMA
     if (!s4 && S >= 8) nblocks = Ppad / 32;      // k_integrate_lnl_wide: one block sum per 32-pattern tile
-#endif
     if (wg) nblocks = Ppad / MBAMD_INTEGRATE_WG_PATTERNS;      // the tree-walk layout's integration kernel, whatever the state count
     HIP_TRY(hipHostMalloc(&h_sums, (size_t) nblocks * sizeof(double), hipHostMallocDefault));
     HIP_TRY(hipHostGetDevicePointer((void**) &h_sums_dev, h_sums, 0));
@@ -1054,21 +1046,19 @@ int Instance::flushMatrices()
         HIP_TRY(hipGetLastError());
         return BEAGLE_SUCCESS;
     }
-#if MBAMD_DEV_HAS_MFMA
     if (S > 8 && S <= 64) {                       // fp64 matrix cores, one wave per 16 rows
         const unsigned grid = (unsigned) (count * K);
         const int packedT = mfma ? T : 0;
         const size_t wgTab = wg ? (wgTabFloats | (wgPair ? MBAMD_WG_TAB_SPLIT : (size_t) 0)) : 0;
         switch ((S + 15) / 16) {
-            case 1: MBAMD_LAUNCH(k_transition_matrices_mfma<1>, grid, 64, 0, stream, djobs, rates, S, SP, K, packedT, wgTab); break;
-            case 2: MBAMD_LAUNCH(k_transition_matrices_mfma<2>, grid, 128, 0, stream, djobs, rates, S, SP, K, packedT, wgTab); break;
-            case 3: MBAMD_LAUNCH(k_transition_matrices_mfma<3>, grid, 192, 0, stream, djobs, rates, S, SP, K, packedT, wgTab); break;
-            default: MBAMD_LAUNCH(k_transition_matrices_mfma<4>, grid, 256, 0, stream, djobs, rates, S, SP, K, packedT, wgTab); break;
+            case 1: MBAMD_LAUNCH_BARRIER(k_transition_matrices_mfma<1>, grid, 64, 0, stream, djobs, rates, S, SP, K, packedT, wgTab); break;
+            case 2: MBAMD_LAUNCH_BARRIER(k_transition_matrices_mfma<2>, grid, 128, 0, stream, djobs, rates, S, SP, K, packedT, wgTab); break;
+            case 3: MBAMD_LAUNCH_BARRIER(k_transition_matrices_mfma<3>, grid, 192, 0, stream, djobs, rates, S, SP, K, packedT, wgTab); break;
+            default: MBAMD_LAUNCH_BARRIER(k_transition_matrices_mfma<4>, grid, 256, 0, stream, djobs, rates, S, SP, K, packedT, wgTab); break;
         }
         HIP_TRY(hipGetLastError());
         return BEAGLE_SUCCESS;
     }
-#endif
     const size_t nev = (size_t) count * K * S;
     rc = grow((void**) &d_ev, &evCap, nev * sizeof(double));
     if (rc) return rc;
@@ -1250,7 +1240,6 @@ int Instance::submit(Plan* plan, int cumIdx, int32_t* cumPtr)
         int mrc = flushMatrices();
         if (mrc) return mrc;
     }
-#if MBAMD_DEV_HAS_MFMA
     if (!s4 && mfma && !mfmaWhole && !noDefer) {
         if ((int) pending.size() >= MBAMD_MAX_TABLES || !independentOfPending(*plan, cumIdx)) {
             int rc = flushPending();
@@ -1259,7 +1248,6 @@ int Instance::submit(Plan* plan, int cumIdx, int32_t* cumPtr)
         pending.emplace_back(plan, cumIdx);
         return BEAGLE_SUCCESS;
     }
-#endif
     (void) cumIdx;
     return timedRun(*plan, cumPtr);
 }
@@ -1304,7 +1292,6 @@ int Instance::flushPending()
         }
         return BEAGLE_SUCCESS;
     }
-#if MBAMD_DEV_HAS_MFMA
     hipEvent_t ev0{}, ev1{};
     { int src = spanBegin(); if (src) return src; }
     if (timing) {
@@ -1413,7 +1400,6 @@ int Instance::flushPending()
         HIP_TRY(hipEventRecord(ev1, stream));
         events.emplace_back(ev0, ev1);
     }
-#endif
     return BEAGLE_SUCCESS;
 }
 
@@ -2172,14 +2158,13 @@ int Instance::runWalkG(const Plan& plan)
     return BEAGLE_SUCCESS;
 }
 
-#if MBAMD_DEV_HAS_MFMA
 template <int NT_, int SC_, int KC_>
 static void launch_mfma_t(Instance& in, const PartialsOp* ops, int count, int32_t* cum)
 {
     const int gx = (in.Ppad + 127) / 128;
     const unsigned grid = (unsigned) (8 * ((gx + 7) / 8) * count);
     auto kern = k_partials_mfma<NT_, SC_, KC_>;
-    MBAMD_LAUNCH(kern, grid, 256, 0, in.stream, ops, in.S, in.SP, in.Ppad, gx, cum);
+    MBAMD_LAUNCH_BARRIER(kern, grid, 256, 0, in.stream, ops, in.S, in.SP, in.Ppad, gx, cum);
 }
 template <int NT_, int SC_, int KC_>
 static void launch_mfma_split_t(Instance& in, const OpTables& tabs, int count)
@@ -2187,7 +2172,7 @@ static void launch_mfma_split_t(Instance& in, const OpTables& tabs, int count)
     constexpr int NP = 2 * KC_ * NT_;
     const int gx = in.Ppad / 32;
     auto kern = k_partials_mfma_split<NT_, SC_, KC_>;
-    MBAMD_LAUNCH(kern, (unsigned) (gx * count), 64 * NP, (size_t) NP * (8 * 64 + 32 + 16 * 32) * sizeof(float), in.stream, tabs, in.S,
+    MBAMD_LAUNCH_BARRIER(kern, (unsigned) (gx * count), 64 * NP, (size_t) NP * (8 * 64 + 32 + 16 * 32) * sizeof(float), in.stream, tabs, in.S,
                  in.SP, in.Ppad, gx);
 }
 // one launch over up to four operation tables (false: no split kernel for this shape)
@@ -2209,7 +2194,7 @@ static void launch_tips_t(Instance& in, const OpTables& tabs, int count)
 {
     const int gx4 = (in.Ppad + 127) / 128;
     auto kern = k_partials_tips<SC_, KC_>;
-    MBAMD_LAUNCH(kern, (unsigned) (gx4 * count), 256, (size_t) 4 * in.S * 32 * sizeof(float), in.stream, tabs, in.S, in.SP, in.Ppad, gx4);
+    MBAMD_LAUNCH_BARRIER(kern, (unsigned) (gx4 * count), 256, (size_t) 4 * in.S * 32 * sizeof(float), in.stream, tabs, in.S, in.SP, in.Ppad, gx4);
 }
 // operations on two compact tips, up to four tables (false: no kernel for this shape)
 static bool launch_tips(Instance& in, const OpTables& tabs, int count)
@@ -2233,7 +2218,7 @@ static void launch_mfma_serial_t(Instance& in, const OpTables& tabs, int ntables
         if (hipMalloc(&in.d_trace, (size_t) 4096 * 8 * 3 * sizeof(long long)) != hipSuccess) in.d_trace = nullptr;
         else (void) hipMemset(in.d_trace, 0, (size_t) 4096 * 8 * 3 * sizeof(long long));
     }
-    MBAMD_LAUNCH(kern, (unsigned) (gx * ntables), 64 * NP, (size_t) NP * (8 * 64 + 32 + 16 * 32) * sizeof(float), in.stream, tabs, in.S,
+    MBAMD_LAUNCH_BARRIER(kern, (unsigned) (gx * ntables), 64 * NP, (size_t) NP * (8 * 64 + 32 + 16 * 32) * sizeof(float), in.stream, tabs, in.S,
                  in.SP, in.Ppad, gx, in.d_trace);
     if (in.d_trace) { in.lastWalkSteps = tabs.start[0]; in.walkWaves = NP - 1; }
 }
@@ -2247,7 +2232,7 @@ static void launch_mfma_spine_t(Instance& in, const OpTables& tabs, int ntables)
         else (void) hipMemset(in.d_trace, 0, (size_t) 4096 * 8 * 3 * sizeof(long long));
     }
     auto kern = k_partials_mfma_spine<NT_, SC_, KC_>;
-    MBAMD_LAUNCH(kern, (unsigned) (gx * ntables), 64 * (NP + 1), ((size_t) NP * (8 * 64 + 32) + (size_t) 2 * KC_ * SC_ * 32) * sizeof(float),
+    MBAMD_LAUNCH_BARRIER(kern, (unsigned) (gx * ntables), 64 * (NP + 1), ((size_t) NP * (8 * 64 + 32) + (size_t) 2 * KC_ * SC_ * 32) * sizeof(float),
                  in.stream, tabs, in.SP, gx, in.d_trace);
     if (in.d_trace) { in.lastWalkSteps = tabs.start[0]; in.walkWaves = NP - 1; }
 }
@@ -2297,7 +2282,6 @@ static bool launch_mfma(Instance& in, const PartialsOp* ops, int count, int32_t*
     }
     return true;
 }
-#endif
 
 template <int SP_, int FK_>
 static void launch_gen(Instance& in, const PartialsOp* ops, int count, int32_t* cum)
@@ -2447,7 +2431,6 @@ int Instance::runGeneric(const Plan& plan, int32_t* cum)
     const std::vector<int>& start = plan.start;
     const int nLevels = (int) start.size() - 1;
     const bool anyScale = plan.anyScale;
-#if MBAMD_DEV_HAS_MFMA
     if (plan.narrow && mfma && !mfmaWhole) {
         OpTables tabs;
         std::memset(&tabs, 0, sizeof tabs);
@@ -2464,15 +2447,11 @@ int Instance::runGeneric(const Plan& plan, int32_t* cum)
             return BEAGLE_SUCCESS;
         }
     }
-#endif
     int levelEnd = nLevels;
-#if MBAMD_DEV_HAS_MFMA
     if (mfma && !mfmaWhole) levelEnd = plan.serialFrom;
-#endif
     for (int l = 0; l < levelEnd; ++l) {
         int off = start[l];
         int remaining = start[l + 1] - start[l];
-#if MBAMD_DEV_HAS_MFMA
         if (l == 0 && mfma && !mfmaWhole && plan.tipTip > 0 && plan.tipTip <= 8192) {
             OpTables tabs;
             std::memset(&tabs, 0, sizeof tabs);
@@ -2485,12 +2464,10 @@ int Instance::runGeneric(const Plan& plan, int32_t* cum)
                 remaining -= plan.tipTip;
             }
         }
-#endif
         while (remaining > 0) {
             const int count = std::min(remaining, 32768);
             const PartialsOp* ops = plan.d_table + off;
             bool fused = true;
-#if MBAMD_DEV_HAS_MFMA
             if (mfma && launch_mfma(*this, ops, std::min(count, 8192), cum)) {
                 const int done = std::min(count, 8192);
                 pendingLaunches += 1;
@@ -2498,7 +2475,6 @@ int Instance::runGeneric(const Plan& plan, int32_t* cum)
                 remaining -= done;
                 continue;
             }
-#endif
             if (SP == 20 && K == 4) launch_gen<20, 4>(*this, ops, count, cum);
             else if (SP == 20 && K == 1) launch_gen<20, 1>(*this, ops, count, cum);
             else if (SP == 64 && K == 1) launch_gen<64, 1>(*this, ops, count, cum);
@@ -2524,7 +2500,6 @@ int Instance::runGeneric(const Plan& plan, int32_t* cum)
             remaining -= count;
         }
     }
-#if MBAMD_DEV_HAS_MFMA
     if (levelEnd < nLevels) {                    // the spine: one launch walks it
         OpTables tabs;
         std::memset(&tabs, 0, sizeof tabs);
@@ -2538,7 +2513,6 @@ int Instance::runGeneric(const Plan& plan, int32_t* cum)
         if (!launch_mfma_serial(*this, tabs, nt)) return fail(BEAGLE_ERROR_GENERAL, "no serial MFMA kernel for this shape");
         pendingLaunches += 1;
     }
-#endif
     HIP_TRY(hipGetLastError());
     return BEAGLE_SUCCESS;
 }
@@ -2640,10 +2614,8 @@ int Instance::integrate(const int* parent, const int* child, const int* prob, co
     }
     double* const siteOut = (siteToHost && h_site_dev) ? h_site_dev : d_site;
     siteOnHost = siteOut != d_site;
-#if MBAMD_DEV_HAS_MFMA
-    if (S >= 8) MBAMD_LAUNCH(k_integrate_lnl_wide, (unsigned) nblocks, 256, 0, stream, a, S, SP, K, P, Ppad, (const double*) d_pweights, siteOut, h_sums_dev);
+    if (S >= 8) MBAMD_LAUNCH_BARRIER(k_integrate_lnl_wide, (unsigned) nblocks, 256, 0, stream, a, S, SP, K, P, Ppad, (const double*) d_pweights, siteOut, h_sums_dev);
     else
-#endif
         MBAMD_LAUNCH(k_integrate_lnl, (unsigned) nblocks, 64, 0, stream, a, S, SP, K, P, Ppad, (const double*) d_pweights, siteOut, h_sums_dev);
     HIP_TRY(hipGetLastError());
     { int src = spanEnd(); if (src) return src; }
@@ -2694,7 +2666,7 @@ int Instance::integrate4(const int* parent, const int* child, const int* prob, c
     if (wg) {
         WgGeom g;
         g.tileFloats = wgTileBytes / 4; g.tipTileBytes = wgTipTileBytes; g.TP = wg_pairs_padded(S);
-        MBAMD_LAUNCH(MBAMD_INTEGRATE_WG_KERNEL, (unsigned) nblocks, MBAMD_INTEGRATE_WG_THREADS, 0, stream, a, S, SP, K, P, Ppad, g, (const double*) d_pweights, siteOut, h_sums_dev);
+        MBAMD_LAUNCH_BARRIER(k_integrate_lnl_wg_wide, (unsigned) nblocks, MBAMD_INTEGRATE_WG_THREADS, 0, stream, a, S, SP, K, P, Ppad, g, (const double*) d_pweights, siteOut, h_sums_dev);
     } else {
         MBAMD_LAUNCH(k_integrate_lnl_s4, (unsigned) nblocks, 64, 0, stream, a, K, P, Ppad, geom, (const double*) d_pweights, siteOut, h_sums_dev);
     }

@@ -74,7 +74,6 @@ k64_partials(const Op64* __restrict__ ops, int S, int SPAD, int K, int Ppad_)
 }
 
 
-#if MBAMD_DEV_HAS_MFMA
 // CondLikeDown_Gen / _NY98 in fp64 on the fp64 MATRIX cores (v_mfma_f64_16x16x4_f64) for 16 <= S <= 64: a wave owns 16 patterns of
 // one category and all states of the destination -- NT = ceil(S / 16) output tiles of 16 states x 16 patterns, each the sum over
 // ceil(S / 4) steps of A (16 out-states x 4 in-states, from the TRANSPOSED matrix copy: 16 consecutive doubles per lane row) times
@@ -125,7 +124,7 @@ __device__ __forceinline__ void f64_mfma_tiles(const MBAMD_AS_CONST Op64* op, in
 #pragma unroll
             for (int u = 0; u < 4; ++u)
 #pragma unroll
-                for (int it = 0; it < NT; ++it) f[ch][it] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[u][it], b[u], f[ch][it], 0, 0, 0);
+                for (int it = 0; it < NT; ++it) f[ch][it] = mbd_mfma_f64_16x16x4(a[u][it], b[u], f[ch][it]);
         }
     }
 #pragma unroll
@@ -172,8 +171,8 @@ k64_partials_mfma(const Op64* __restrict__ ops, int S, int SPAD, int Ppad_)
                 for (int r = 0; r < 4; ++r)
                     if (16 * it + g + 4 * r < S) mx = fmax(mx, p[k][it][r]);
         }
-        mx = fmax(mx, __shfl_xor(mx, 16));
-        mx = fmax(mx, __shfl_xor(mx, 32));
+        mx = fmax(mx, mbd_shfl_xor(mx, 16));
+        mx = fmax(mx, mbd_shfl_xor(mx, 32));
         int e = 0;
         if (op->mode == 1) {
             if (mx > 0.0 && mx < 1.0e300) (void) frexp(mx, &e);
@@ -269,7 +268,7 @@ __device__ __forceinline__ void f64_mfma_tiles_lds(const MBAMD_AS_CONST Op64* op
 #pragma unroll
             for (int u = 0; u < 4; ++u)
 #pragma unroll
-                for (int it = 0; it < NT; ++it) f[ch][it] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[u][it], b[u], f[ch][it], 0, 0, 0);
+                for (int it = 0; it < NT; ++it) f[ch][it] = mbd_mfma_f64_16x16x4(a[u][it], b[u], f[ch][it]);
 #pragma unroll
             for (int u = 0; u < 4; ++u) b[u] = bn[u];
         }
@@ -381,8 +380,8 @@ __device__ __forceinline__ void f64_lds_operation(const MBAMD_AS_CONST Op64* op,
                 for (int r = 0; r < 4; ++r)
                     if (16 * it + g + 4 * r < S) mx = fmax(mx, p[k][it][r]);
         }
-        mx = fmax(mx, __shfl_xor(mx, 16));
-        mx = fmax(mx, __shfl_xor(mx, 32));
+        mx = fmax(mx, mbd_shfl_xor(mx, 16));
+        mx = fmax(mx, mbd_shfl_xor(mx, 32));
         int e = 0;
         if (op->mode == 1) {
             if (mx > 0.0 && mx < 1.0e300) (void) frexp(mx, &e);
@@ -566,7 +565,7 @@ k64_partials_chain(const Op64* __restrict__ ops, const int* __restrict__ chainSt
                     for (int u = 0; u < 4; ++u) {
                         const double bu = bval(gq, u) * ((4 * (4 * gq + u) + g) < S ? 1.0 : 0.0);
 #pragma unroll
-                        for (int it = 0; it < NT; ++it) f[ch][it] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[u][it], bu, f[ch][it], 0, 0, 0);
+                        for (int it = 0; it < NT; ++it) f[ch][it] = mbd_mfma_f64_16x16x4(a[u][it], bu, f[ch][it]);
                     }
                 }
             };
@@ -598,8 +597,8 @@ k64_partials_chain(const Op64* __restrict__ ops, const int* __restrict__ chainSt
         }
         const int eStored = storedExp;
         if (o + 1 < oe) fetchSibling(dnxt);                // (every category's sibling values have been used)
-        mx = fmax(mx, __shfl_xor(mx, 16));
-        mx = fmax(mx, __shfl_xor(mx, 32));
+        mx = fmax(mx, mbd_shfl_xor(mx, 16));
+        mx = fmax(mx, mbd_shfl_xor(mx, 32));
         int e = 0;
         if (op->mode == 1) {
             if (mx > 0.0 && mx < 1.0e300) (void) frexp(mx, &e);
@@ -659,8 +658,8 @@ k64_partials_tips(const Op64* __restrict__ ops, int S, int SPAD, int Ppad_)
             p[k][q] = i < S ? (gap1 ? 1.0 : a) * (gap2 ? 1.0 : b) : 0.0;
             mx = fmax(mx, p[k][q]);
         }
-    mx = fmax(mx, __shfl_xor(mx, 16));
-    mx = fmax(mx, __shfl_xor(mx, 32));
+    mx = fmax(mx, mbd_shfl_xor(mx, 16));
+    mx = fmax(mx, mbd_shfl_xor(mx, 32));
     int e = 0;
     if (op->mode == 1) {
         if (mx > 0.0 && mx < 1.0e300) (void) frexp(mx, &e);
@@ -758,7 +757,6 @@ k64_partials_tips_lds(const Op64* __restrict__ ops, int S, int SPAD, int K, int 
         }
 }
 
-#endif
 
 // The same with the rescale fused (K == KF categories, S <= IB: all K x S results of a pattern stay in registers): one pass
 // over HBM instead of three.  Instantiated for four states and the default four gamma categories (at 20 states the K x S
@@ -1054,7 +1052,6 @@ k64_matrices(const MatrixJob64* __restrict__ jobs, const double* __restrict__ ev
     }
 }
 
-#if MBAMD_DEV_HAS_MFMA
 // the same product on the fp64 matrix cores for 16 <= S <= 64 (one wave per 16 rows, as k_transition_matrices_mfma of the fp32 engine)
 template <int NJ>
 __global__ void __launch_bounds__(64 * NJ)
@@ -1086,7 +1083,7 @@ k64_matrices_mfma(const MatrixJob64* __restrict__ jobs, const double* __restrict
 #pragma unroll
         for (int u = 0; u < 4; ++u)
 #pragma unroll
-            for (int jt = 0; jt < NJ; ++jt) acc[jt] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[u], bb[u][jt], acc[jt], 0, 0, 0);
+            for (int jt = 0; jt < NJ; ++jt) acc[jt] = mbd_mfma_f64_16x16x4(a[u], bb[u][jt], acc[jt]);
     }
     MBAMD_AS_GLOBAL double* __restrict__ M = as_global(jobs[b].out) + (size_t) k * S * S;
     MBAMD_AS_GLOBAL double* __restrict__ MT = as_global(jobs[b].out) + (size_t) K * S * S + (size_t) k * S * SPAD;
@@ -1102,7 +1099,6 @@ k64_matrices_mfma(const MatrixJob64* __restrict__ jobs, const double* __restrict
             }
         }
 }
-#endif
 
 // Likelihood_* (reference src/likelihood.c:5764-5917, 6975-7040) with BEAGLE's root / edge semantics; one thread per pattern
 struct IntegrateArgs64 {
@@ -1509,18 +1505,16 @@ public:
     }
     void launchMatrices(const MatrixJob64* dj, int count)
     {
-#if MBAMD_DEV_HAS_MFMA
         if (S >= 16 && S <= 64 && !noMfma) {
             const unsigned grid = (unsigned) (count * K);
             switch ((S + 15) / 16) {
-                case 1: MBAMD_LAUNCH(k64_matrices_mfma<1>, grid, 64, 0, stream, dj, (const double*) d_ev, S, SPAD, K); break;
-                case 2: MBAMD_LAUNCH(k64_matrices_mfma<2>, grid, 128, 0, stream, dj, (const double*) d_ev, S, SPAD, K); break;
-                case 3: MBAMD_LAUNCH(k64_matrices_mfma<3>, grid, 192, 0, stream, dj, (const double*) d_ev, S, SPAD, K); break;
-                default: MBAMD_LAUNCH(k64_matrices_mfma<4>, grid, 256, 0, stream, dj, (const double*) d_ev, S, SPAD, K); break;
+                case 1: MBAMD_LAUNCH_BARRIER(k64_matrices_mfma<1>, grid, 64, 0, stream, dj, (const double*) d_ev, S, SPAD, K); break;
+                case 2: MBAMD_LAUNCH_BARRIER(k64_matrices_mfma<2>, grid, 128, 0, stream, dj, (const double*) d_ev, S, SPAD, K); break;
+                case 3: MBAMD_LAUNCH_BARRIER(k64_matrices_mfma<3>, grid, 192, 0, stream, dj, (const double*) d_ev, S, SPAD, K); break;
+                default: MBAMD_LAUNCH_BARRIER(k64_matrices_mfma<4>, grid, 256, 0, stream, dj, (const double*) d_ev, S, SPAD, K); break;
             }
             return;
         }
-#endif
         MBAMD_LAUNCH(k64_matrices, (unsigned) (count * K), 256, 0, stream, dj, (const double*) d_ev, S, SPAD, K);
     }
     // Matrix updates are queued like operation lists: MrBayes updates a codon model's eigen parts one call each (src/mbbeagle.c:1475-1486),
@@ -1913,7 +1907,6 @@ public:
         }
         std::vector<Op64> sorted((size_t) n);
         for (int i = 0; i < n; ++i) sorted[i] = h[order[i]];
-#if MBAMD_DEV_HAS_MFMA
         // A list that is nothing but chains (the root-ward path of a move; one chain per eigen part): one launch of k64_partials_chain
         {
             const int NTr = (S + 15) / 16;
@@ -1995,7 +1988,6 @@ public:
                 }
             }
         }
-#endif
         void* dv = nullptr;
         int rc = stage(sorted.data(), sorted.size() * sizeof(Op64), &dv);
         if (rc) return rc;
@@ -2011,7 +2003,6 @@ public:
                 MBAMD_LAUNCH(kern, grid, 64, 0, stream, dops + first, S, SPAD, Ppad);
                 continue;
             }
-#if MBAMD_DEV_HAS_MFMA
             if (S >= 16 && S <= 64 && !noMfma) {
                 const int NTr = (S + 15) / 16;
                 const bool fuse = K >= 1 && K <= 4 && NTr * K <= 8 && std::getenv("MBAMD_F64_UNFUSED") == nullptr;   // all K categories' tiles in registers
@@ -2024,7 +2015,7 @@ public:
                     MBAMD_LAUNCH_BARRIER(k64_partials_tips_lds, tgrid, 256, tipsLds, stream, dops + first, S, SPAD, K, Ppad);
                 } else if (ntt > 0) {
                     const dim3 tgrid((unsigned) (Ppad / 16), (unsigned) ntt);
-#define MBAMD_F64_TIPS_CASE(NSL_, KF_) MBAMD_LAUNCH((k64_partials_tips<NSL_, KF_>), tgrid, 64, 0, stream, dops + first, S, SPAD, Ppad)
+#define MBAMD_F64_TIPS_CASE(NSL_, KF_) MBAMD_LAUNCH_BARRIER((k64_partials_tips<NSL_, KF_>), tgrid, 64, 0, stream, dops + first, S, SPAD, Ppad)
                     switch (NSL * 8 + K) {
                         case 5 * 8 + 1: MBAMD_F64_TIPS_CASE(5, 1); break;
                         case 5 * 8 + 2: MBAMD_F64_TIPS_CASE(5, 2); break;
@@ -2054,7 +2045,7 @@ public:
 #define MBAMD_F64_MFMA_CASE(NT_, KF_) do { \
                     if (viaLds && wide) MBAMD_LAUNCH_BARRIER((k64_partials_mfma_lds<NT_, KF_, 8>), lgrid, 512, ldsBytes, stream, dops + first + ntt, S, SPAD, Ppad); \
                     else if (viaLds) MBAMD_LAUNCH_BARRIER((k64_partials_mfma_lds<NT_, KF_, 4>), lgrid, 256, ldsBytes, stream, dops + first + ntt, S, SPAD, Ppad); \
-                    else MBAMD_LAUNCH((k64_partials_mfma<NT_, KF_>), grid, 64, 0, stream, dops + first + ntt, S, SPAD, Ppad); } while (0)
+                    else MBAMD_LAUNCH_BARRIER((k64_partials_mfma<NT_, KF_>), grid, 64, 0, stream, dops + first + ntt, S, SPAD, Ppad); } while (0)
                 const int key = NTr * 8 + (fuse ? K : 0);
                 switch (key) {
                     case 1 * 8 + 0: MBAMD_F64_MFMA_CASE(1, 0); break;
@@ -2077,7 +2068,6 @@ public:
 #undef MBAMD_F64_MFMA_CASE
                 if (fuse) continue;
             } else
-#endif
             switch (IB) {
                 case 4: launchPartials<4>(dops + first, cnt); break;
                 case 8: launchPartials<8>(dops + first, cnt); break;

@@ -1,8 +1,7 @@
-// mbamd_dev_integrate_wg.h (gfx950) -- root / edge integration for the 20/61-state tree-walk layout (included by mbamd_kernels.h
-// inside namespace mbamd).  Twin for the TEST-ONLY host emulation (one thread per pattern): tests/hostemu/.
-#ifndef MBAMD_DEV_INTEGRATE_WG_H_
-#define MBAMD_DEV_INTEGRATE_WG_H_
-#define MBAMD_INTEGRATE_WG_KERNEL k_integrate_lnl_wg_wide
+// mbamd_integrate_wg.h -- root / edge integration for the 20/61-state tree-walk layout (included by mbamd_kernels.h inside namespace
+// mbamd).  Product and TEST-ONLY host emulation compile this same kernel (the emulation runs its 256 threads as fibers).
+#ifndef MBAMD_INTEGRATE_WG_H_
+#define MBAMD_INTEGRATE_WG_H_
 #define MBAMD_INTEGRATE_WG_THREADS 256
 #define MBAMD_INTEGRATE_WG_PATTERNS 32          // patterns per workgroup (one block sum each)
 // The same for the tree-walk layout (mbamd_walkg.h: partials [tile][buffer][K] blocks in wg_at order, tip states
@@ -103,7 +102,7 @@ k_integrate_lnl_wg_wide(IntegrateArgs4 a, int S, int SP, int K, int P, int Ppad,
         }
     }
     part[g][p] = like;
-    __syncthreads();
+    MBAMD_SYNC();
     if (g != 0) return;                              // lanes 0..31 of wave 0 finish
     double wl = 0.0;
     if (live) {
@@ -115,7 +114,7 @@ k_integrate_lnl_wg_wide(IntegrateArgs4 a, int S, int SP, int K, int P, int Ppad,
         site[c] = 0.0;
     }
 #pragma unroll
-    for (int off = 16; off > 0; off >>= 1) wl += __shfl_down(wl, off, 32);
+    for (int off = 16; off > 0; off >>= 1) wl += mbd_shfl_down_32(wl, off);
     if (p == 0) wsite[blockIdx.x] = wl;
 }
 

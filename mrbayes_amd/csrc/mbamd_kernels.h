@@ -691,10 +691,9 @@ k_integrate_lnl_s4(IntegrateArgs4 a, int K, int P, int Ppad, BlockGeom g,
 
 // 20/61-state tree-walk layout (mbamd_walkg.h): partials float [tile][buffer][K][T][64], tip states uint8 [tile][buffer][32],
 // cumulative exponents per (pattern, category) like the 4-state path.  Same arithmetic as k_integrate_lnl, the categories
-// recombined as in k_integrate_lnl_s4: k_integrate_lnl_wg_wide (mbamd_kernels_mfma.h; the host-emulation build has a one-thread-
-// per-pattern twin in tests/hostemu/mbamd_walkg_emu.h).
+// recombined as in k_integrate_lnl_s4: k_integrate_lnl_wg_wide (mbamd_integrate_wg.h).
 struct WgGeom { unsigned long tileFloats; unsigned tipTileBytes; int TP; };
-#include <mbamd_dev_integrate_wg.h>   // k_integrate_lnl_wg_wide (csrc/device/: eight threads per pattern, wave shuffles)
+#include "mbamd_integrate_wg.h"       // k_integrate_lnl_wg_wide (eight threads per pattern)
 // ---------------------------------------------------------------------------------------------
 // cumulative scale-factor bookkeeping (exact integer arithmetic)
 // ---------------------------------------------------------------------------------------------
@@ -792,4 +791,5 @@ k_export_partials(const float* __restrict__ in, int S, int K, int P, int Ppad, s
 }
 
 }  // namespace mbamd
+#include "mbamd_matrices_mfma.h"      // k_transition_matrices_mfma (9 .. 64 states: the fp64 matrix cores)
 #endif

@@ -1,5 +1,6 @@
 // mbamd_kernels_mfma.h -- matrix-core (MFMA) kernels of the general-state path: 20-state amino-acid
-// and 61-state codon models (any 5 <= S <= 64).  gfx950 only; there is no host-emulation twin.
+// and 61-state codon models (any 5 <= S <= 64).  Written against the device primitives of <mbamd_dev_base.h> /
+// <mbamd_dev_walkg_kernel.h>: the TEST-ONLY host emulation compiles and runs these same kernels (an MFMA there is a wave-wide exchange).
 //
 // Replaces CondLikeDown_Gen[_SSE] / CondLikeDown_NY98[_SSE] + CondLikeScaler_Gen / _NY98
 // (reference src/likelihood.c:204-588, 1575-1900, 4939-5070, 5413-5545).
@@ -26,7 +27,7 @@
 //   k_partials_mfma_spine  narrow lists / trailing single-operation levels: one launch walks them, software-pipelined
 //   k_partials_mfma_serial   plain variant of the spine kernel for run-time state counts
 //   k_partials_mfma        one wave per (operation, tile): cross-check (MBAMD_MFMA_WHOLE=1)
-//   k_transition_matrices_mfma  P = U exp(L t) U^-1 on the fp64 matrix cores
+//   (k_transition_matrices_mfma, P = U exp(L t) U^-1 on the fp64 matrix cores: mbamd_matrices_mfma.h)
 //   k_integrate_lnl_wide   root / edge integration, 8 threads per pattern
 #ifndef MBAMD_KERNELS_MFMA_H_
 #define MBAMD_KERNELS_MFMA_H_
@@ -78,9 +79,9 @@ __device__ __forceinline__ f32x16 mfma_contract(const MBAMD_AS_GLOBAL float* __r
             b[T - 1] = 0.0f;
             if (!half) b[T - 1] = cl[64 * Tfull];
         }
-        __builtin_amdgcn_sched_barrier(0);
+        MBD_SCHED_BARRIER();
 #pragma unroll
-        for (int t = 0; t < T; ++t) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[t], b[t], acc, 0, 0, 0);
+        for (int t = 0; t < T; ++t) acc = mbd_mfma_f32_32x32x2(a[t], b[t], acc);
     } else {
         constexpr int CH = 16;                      // run-time S: chunks of 16 pairs in flight
         const int Tfull = S_rt / 2;
@@ -93,14 +94,14 @@ __device__ __forceinline__ f32x16 mfma_contract(const MBAMD_AS_GLOBAL float* __r
                 b[u] = cl[64 * t];
                 if (t0 + u >= Tfull) a[u] = 0.0f;
             }
-            __builtin_amdgcn_sched_barrier(0);
+            MBD_SCHED_BARRIER();
 #pragma unroll
-            for (int u = 0; u < CH; ++u) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[u], b[u], acc, 0, 0, 0);
+            for (int u = 0; u < CH; ++u) acc = mbd_mfma_f32_32x32x2(a[u], b[u], acc);
         }
         if (S_rt & 1) {
             float b = 0.0f;
             if (!half) b = cl[64 * Tfull];
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(pa[(size_t) Tfull * 64], b, acc, 0, 0, 0);
+            acc = mbd_mfma_f32_32x32x2(pa[(size_t) Tfull * 64], b, acc);
         }
     }
     return acc;
@@ -191,7 +192,7 @@ k_partials_mfma(const PartialsOp* __restrict__ ops, int S_rt, int SP, int Ppad, 
     }
     int e = 0;
     if (mode == SCALE_WRITE) {
-        mx = fmaxf(mx, __shfl_xor(mx, 32));
+        mx = fmaxf(mx, mbd_shfl_xor(mx, 32));
         e = scale_exponent(mx);
         if (half == 0) {
             as_global(op->scale)[c0 + col] = e;
@@ -314,7 +315,7 @@ __device__ __forceinline__ void mfma_split_op(const MBAMD_AS_CONST PartialsOp* _
         float* mine = tiles + (size_t) wave * 8 * 64;
 #pragma unroll
         for (int j = 0; j < 8; ++j) mine[j * 64 + lane] = acc[8 * (1 - c) + j];
-        __syncthreads();
+        MBAMD_SYNC();
         const float* other = tiles + (size_t) ((k * 2 + (1 - c)) * NT + it) * 8 * 64;
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
@@ -327,9 +328,9 @@ __device__ __forceinline__ void mfma_split_op(const MBAMD_AS_CONST PartialsOp* _
     }
     int e = 0;
     if (mode == SCALE_WRITE) {
-        mx = fmaxf(mx, __shfl_xor(mx, 32));
+        mx = fmaxf(mx, mbd_shfl_xor(mx, 32));
         if (half == 0) smax[wave * 32 + col] = mx;
-        __syncthreads();
+        MBAMD_SYNC();
         float m = 0.0f;
 #pragma unroll
         for (int p = 0; p < NP; ++p) m = fmaxf(m, smax[p * 32 + col]);
@@ -350,6 +351,7 @@ __device__ __forceinline__ void mfma_split_op(const MBAMD_AS_CONST PartialsOp* _
         const int lr = (j & 3) + 4 * half + 8 * (j >> 2);
         stage[lr * 32 + col] = (mode != SCALE_NONE) ? scale_pow2(out[j], -e) : out[j];
     }
+    MBAMD_WAVE_SYNC();                              // (lanes read each other's rows: the wave's LDS instructions execute in order, the compiler is told)
     MBAMD_AS_GLOBAL float* __restrict__ dst = as_global(op->dst) + gen_index(KC, S, k, 32 * it + 16 * c, c0) + 4 * (lane & 7);
 #pragma unroll
     for (int u = 0; u < 2; ++u) {
@@ -374,11 +376,11 @@ __global__ void __launch_bounds__(256, (SC > 0 ? 6 : 4))
 k_partials_tips(OpTables tabs, int S_rt, int SP, int Ppad, int gx4)
 {
     constexpr int QC = SC > 0 ? (SC + 7) / 8 : 8;   // 8-row groups per category
-    extern __shared__ float lds_f[];
+    float* const lds_f = mbd_dyn_lds<float>();
     const int S = SC > 0 ? SC : S_rt;
     const int Q = SC > 0 ? QC : (S + 7) / 8;
     const int bx = blockIdx.x % gx4, by = blockIdx.x / gx4;
-    const int wave = __builtin_amdgcn_readfirstlane((int) (threadIdx.x >> 6)), lane = threadIdx.x & 63;
+    const int wave = mbd_wave_index(), lane = threadIdx.x & 63;
     const int c0 = (bx * 4 + wave) * 32;
     if (c0 >= Ppad) return;
     int tsel = 0;
@@ -423,7 +425,7 @@ k_partials_tips(OpTables tabs, int S_rt, int SP, int Ppad, int gx4)
     }
     int e = 0;
     if (mode == SCALE_WRITE) {
-        mx = fmaxf(mx, __shfl_xor(mx, 32));
+        mx = fmaxf(mx, mbd_shfl_xor(mx, 32));
         e = scale_exponent(mx);
         if (half == 0) {
             as_global(op->scale)[c0 + col] = e;
@@ -446,6 +448,7 @@ k_partials_tips(OpTables tabs, int S_rt, int SP, int Ppad, int gx4)
             if (ib + 2 < S) strip[(ib + 2) * 32 + col] = v.z;
             if (ib + 3 < S) strip[(ib + 3) * 32 + col] = v.w;
         }
+        MBAMD_WAVE_SYNC();                          // (lanes read each other's rows, see mfma_split_op)
 #pragma unroll
         for (int u = 0; u < QC; ++u) {
             const int row = (lane >> 3) + 8 * u;
@@ -454,6 +457,7 @@ k_partials_tips(OpTables tabs, int S_rt, int SP, int Ppad, int gx4)
                 *reinterpret_cast<MBAMD_AS_GLOBAL f4*>(dst + ((size_t) k * S + row) * 32) = v;
             }
         }
+        MBAMD_WAVE_SYNC();                          // (the next category overwrites the strip)
     }
 }
 
@@ -463,11 +467,11 @@ __global__ void __launch_bounds__(64 * 2 * KC * NT)
 k_partials_mfma_split(OpTables tabs, int S_rt, int SP, int Ppad, int gx)
 {
     constexpr int NP = 2 * KC * NT;
-    extern __shared__ float lds_f[];
+    float* const lds_f = mbd_dyn_lds<float>();
     float* tiles = lds_f;                           // [NP][8][64]
     float* smax = lds_f + NP * 8 * 64;              // [NP][32]
     const int bx = blockIdx.x % gx, by = blockIdx.x / gx;       // gx = P_pad / 32 tiles
-    const int wave = __builtin_amdgcn_readfirstlane((int) (threadIdx.x >> 6)), lane = threadIdx.x & 63;
+    const int wave = mbd_wave_index(), lane = threadIdx.x & 63;
     int tsel = 0;
 #pragma unroll
     for (int t = 1; t < MBAMD_MAX_TABLES; ++t) tsel += by >= tabs.start[t] ? 1 : 0;
@@ -486,21 +490,21 @@ __global__ void __launch_bounds__(64 * 2 * KC * NT)
 k_partials_mfma_serial(OpTables tabs, int S_rt, int SP, int Ppad, int gx, long long* __restrict__ trace)
 {
     constexpr int NP = 2 * KC * NT;
-    extern __shared__ float lds_f[];
+    float* const lds_f = mbd_dyn_lds<float>();
     float* tiles = lds_f;
     float* smax = lds_f + NP * 8 * 64;
     const int bx = blockIdx.x % gx, tsel = blockIdx.x / gx;
-    const int wave = __builtin_amdgcn_readfirstlane((int) (threadIdx.x >> 6)), lane = threadIdx.x & 63;
+    const int wave = mbd_wave_index(), lane = threadIdx.x & 63;
     const MBAMD_AS_CONST PartialsOp* __restrict__ ops = as_const(tabs.ops[tsel]);
     int32_t* __restrict__ cumulative = tabs.cum[tsel];
     const int count = tabs.start[tsel];
     const bool tracing = trace != nullptr && blockIdx.x == 0 && lane == 0;      // MBAMD_WALK_TRACE (timing experiments)
     for (int o = 0; o < count; ++o) {
-        if (tracing) trace[((size_t) o * 8 + wave) * 3 + 0] = (long long) __builtin_amdgcn_s_memtime();
+        if (tracing) trace[((size_t) o * 8 + wave) * 3 + 0] = mbd_clock();
         mfma_split_op<NT, SC, KC>(ops + o, cumulative, S_rt, SP, Ppad, bx * 32, wave, lane, tiles, smax);
-        if (tracing) trace[((size_t) o * 8 + wave) * 3 + 1] = (long long) __builtin_amdgcn_s_memtime();
-        __syncthreads();                            // results visible; tiles / smax reusable
-        if (tracing) trace[((size_t) o * 8 + wave) * 3 + 2] = (long long) __builtin_amdgcn_s_memtime();
+        if (tracing) trace[((size_t) o * 8 + wave) * 3 + 1] = mbd_clock();
+        MBAMD_SYNC();                            // results visible; tiles / smax reusable
+        if (tracing) trace[((size_t) o * 8 + wave) * 3 + 2] = mbd_clock();
     }
 }
 
@@ -612,7 +616,7 @@ __device__ __forceinline__ void spine_compute(const SpineDesc& d, uint64_t prev1
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
 #pragma unroll
-    for (int t = 0; t < T; ++t) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(cur.a[t], b[t], acc, 0, 0, 0);
+    for (int t = 0; t < T; ++t) acc = mbd_mfma_f32_32x32x2(cur.a[t], b[t], acc);
     if (kind == CHILD_STATES) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
@@ -630,7 +634,7 @@ __device__ __forceinline__ void spine_compute(const SpineDesc& d, uint64_t prev1
 #pragma unroll
         for (int j = 0; j < 8; ++j) { mine[j * 64 + lane] = acc[8 + j]; keep[j] = acc[j]; }
     }
-    __syncthreads();
+    MBAMD_SYNC();
     const float* other = tiles + (size_t) ((k * 2 + (1 - c)) * NT + it) * 8 * 64;
     float out[8];
     float mx = 0.0f;
@@ -643,9 +647,9 @@ __device__ __forceinline__ void spine_compute(const SpineDesc& d, uint64_t prev1
     }
     int e = 0;
     if (mode == SCALE_WRITE) {
-        mx = fmaxf(mx, __shfl_xor(mx, 32));
+        mx = fmaxf(mx, mbd_shfl_xor(mx, 32));
         if (half == 0) smax[wave * 32 + col] = mx;
-        __syncthreads();
+        MBAMD_SYNC();
         float m = 0.0f;
 #pragma unroll
         for (int p = 0; p < NP; ++p) m = fmaxf(m, smax[p * 32 + col]);
@@ -659,7 +663,7 @@ __device__ __forceinline__ void spine_compute(const SpineDesc& d, uint64_t prev1
         const int lr = (j & 3) + 4 * half + 8 * (j >> 2);
         if (32 * it + 16 * c + lr < S) frow[lr * 32 + col] = (mode != SCALE_NONE) ? scale_pow2(out[j], -e) : out[j];
     }
-    __syncthreads();
+    MBAMD_SYNC();
 }
 
 // Writer wave: same barriers; stores the exponents (+ cumulative atomics) and copies the finished tile --
@@ -671,9 +675,9 @@ __device__ __forceinline__ void spine_write(const SpineDesc& d, int32_t* __restr
     constexpr int NP = 2 * KC * NT;
     constexpr int F4 = KC * SC * 32 / 4;            // float4s per tile
     const int mode = (d.modes >> 8) & 0xFF;
-    __syncthreads();                                // factor tiles exchanged
+    MBAMD_SYNC();                                // factor tiles exchanged
     if (mode == SCALE_WRITE) {
-        __syncthreads();                            // maxima posted
+        MBAMD_SYNC();                            // maxima posted
         if (lane < 32) {
             float m = 0.0f;
 #pragma unroll
@@ -683,7 +687,7 @@ __device__ __forceinline__ void spine_write(const SpineDesc& d, int32_t* __restr
             if (cumulative != nullptr && e != 0) atomicAdd(cumulative + c0 + lane, e);
         }
     }
-    __syncthreads();                                // result tile complete in LDS
+    MBAMD_SYNC();                                // result tile complete in LDS
     MBAMD_AS_GLOBAL f4* __restrict__ dst =
         reinterpret_cast<MBAMD_AS_GLOBAL f4*>(as_global(reinterpret_cast<float*>(d.dst)) + gen_base(KC, SC, c0));
     const f4* src = reinterpret_cast<const f4*>(mySlot);
@@ -704,12 +708,12 @@ k_partials_mfma_spine(OpTables tabs, int SP, int gx, long long* __restrict__ tra
     static_assert(SC > 0, "compile-time state count required");
     constexpr int NP = 2 * KC * NT;
     constexpr int TILE = KC * SC * 32;
-    extern __shared__ float lds_f[];
+    float* const lds_f = mbd_dyn_lds<float>();
     float* tiles = lds_f;                           // [NP][8][64]
     float* smax = lds_f + NP * 8 * 64;              // [NP][32]
     float* slots = smax + NP * 32;                  // [2][K][S][32]: the last two results
     const int bx = blockIdx.x % gx, tsel = blockIdx.x / gx;
-    const int wave = __builtin_amdgcn_readfirstlane((int) (threadIdx.x >> 6)), lane = threadIdx.x & 63;
+    const int wave = mbd_wave_index(), lane = threadIdx.x & 63;
     const int c0 = bx * 32;
     const MBAMD_AS_CONST PartialsOp* __restrict__ ops = as_const(tabs.ops[tsel]);
     int32_t* __restrict__ cumulative = tabs.cum[tsel];
@@ -733,94 +737,23 @@ k_partials_mfma_spine(OpTables tabs, int SP, int gx, long long* __restrict__ tra
         float* s0 = slots;                           // even operations write slot 0
         float* s1 = slots + TILE;
         {
-            if (tracing) trace[((size_t) o * 8 + (wave & 7)) * 3 + 0] = (long long) __builtin_amdgcn_s_memtime();
+            if (tracing) trace[((size_t) o * 8 + (wave & 7)) * 3 + 0] = mbd_clock();
             const SpineDesc dnn = spine_desc(ops + min(o + 2, count - 1));
             spine_prefetch<NT, SC, KC>(dn, d.dst, prev1, SP, k, c, it, c0, lane, B);     // (harmless repeat of the last operation at the end)
             spine_compute<NT, SC, KC>(d, prev1, prev2, k, c, it, wave, lane, A, tiles, smax, s1, s0, s0);
-            if (tracing) trace[((size_t) o * 8 + (wave & 7)) * 3 + 2] = (long long) __builtin_amdgcn_s_memtime();
+            if (tracing) trace[((size_t) o * 8 + (wave & 7)) * 3 + 2] = mbd_clock();
             prev2 = prev1; prev1 = d.dst; d = dn; dn = dnn;
         }
         if (o + 1 >= count) break;
         {
-            if (tracing) trace[((size_t) (o + 1) * 8 + (wave & 7)) * 3 + 0] = (long long) __builtin_amdgcn_s_memtime();
+            if (tracing) trace[((size_t) (o + 1) * 8 + (wave & 7)) * 3 + 0] = mbd_clock();
             const SpineDesc dnn = spine_desc(ops + min(o + 3, count - 1));
             spine_prefetch<NT, SC, KC>(dn, d.dst, prev1, SP, k, c, it, c0, lane, A);
             spine_compute<NT, SC, KC>(d, prev1, prev2, k, c, it, wave, lane, B, tiles, smax, s0, s1, s1);
-            if (tracing) trace[((size_t) (o + 1) * 8 + (wave & 7)) * 3 + 2] = (long long) __builtin_amdgcn_s_memtime();
+            if (tracing) trace[((size_t) (o + 1) * 8 + (wave & 7)) * 3 + 2] = mbd_clock();
             prev2 = prev1; prev1 = d.dst; d = dn; dn = dnn;
         }
     }
-}
-
-// ---------------------------------------------------------------------------------------------
-// Transition matrices for larger state counts (TiProbs_Gen / TiProbs_GenCov, reference
-// src/likelihood.c:9424-9700): P_k = U diag(exp(lambda t r_k)) U^-1 in fp64, clamped at 0, stored as
-// fp32 transposed + in MFMA A-operand order.  The S x S x S contraction runs on the fp64 matrix cores
-// (v_mfma_f64_16x16x4_f64): one wave per 16 rows of P,
-//     A (16 x 4)  = U[i0 + (lane&15)][4 st + (lane>>4)] * exp(lambda_s t r_k)
-//     B (4 x 16)  = U^-1[4 st + (lane>>4)][16 jt + (lane&15)]
-//     D (16 x 16) : lane holds column 16 jt + (lane&15), rows i0 + (lane>>4) + 4 reg
-// with all operands of a chunk of 8 contraction steps loaded before its MFMAs.  The eigen-system (2 S^2
-// doubles, <= 64 KiB) is L2 resident.  grid = count * K workgroups of ceil(S/16) waves; NJ = ceil(S/16).
-// ---------------------------------------------------------------------------------------------
-typedef double f64x4 __attribute__((ext_vector_type(4)));
-
-template <int NJ>
-__global__ void __launch_bounds__(64 * NJ)
-k_transition_matrices_mfma(const MatrixJob* __restrict__ jobs, RatesArg rates, int S, int SP, int K, int packedT, size_t wgTab)
-{
-    __shared__ double ev[64];
-    const int b = blockIdx.x / K, k = blockIdx.x % K;
-    const MatrixJob job = jobs[b];
-    const MBAMD_AS_GLOBAL double* __restrict__ U = as_global(job.eig);
-    const MBAMD_AS_GLOBAL double* __restrict__ Ui = U + (size_t) S * S;
-    const MBAMD_AS_GLOBAL double* __restrict__ lam = U + (size_t) 2 * S * S;
-    if ((int) threadIdx.x < S) ev[threadIdx.x] = exp(lam[threadIdx.x] * job.length * rates.r[k]);
-    __syncthreads();
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int li = lane & 15, ls = lane >> 4;
-    const int i = 16 * wave + li;                    // A row of this lane
-    const int ic = min(i, S - 1);                    // (out-of-range operands: load a valid address, feed zero)
-    f64x4 acc[NJ];
-#pragma unroll
-    for (int jt = 0; jt < NJ; ++jt) acc[jt] = (f64x4) (0.0);
-    constexpr int CH = 8;
-    const int steps = (S + 3) / 4;
-    for (int st0 = 0; st0 < steps; st0 += CH) {
-        double a[CH], bb[NJ][CH];
-#pragma unroll
-        for (int u = 0; u < CH; ++u) {
-            const int s = 4 * (st0 + u) + ls;
-            const int sc = min(s, S - 1);
-            a[u] = U[(size_t) ic * S + sc];
-#pragma unroll
-            for (int jt = 0; jt < NJ; ++jt) bb[jt][u] = Ui[(size_t) sc * S + min(16 * jt + li, S - 1)];
-        }
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int u = 0; u < CH; ++u) {
-            const int s = 4 * (st0 + u) + ls;
-            const double av = (s < S && i < S) ? a[u] * ev[min(s, S - 1)] : 0.0;      // zero A kills the padded terms
-#pragma unroll
-            for (int jt = 0; jt < NJ; ++jt) acc[jt] = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bb[jt][u], acc[jt], 0, 0, 0);
-        }
-    }
-    MBAMD_AS_GLOBAL float* __restrict__ out = as_global(job.out) + (size_t) k * SP * SP;
-    MBAMD_AS_GLOBAL float* __restrict__ packed = as_global(job.out) + (size_t) K * SP * SP;
-    const int NT = (S + 31) / 32;
-#pragma unroll
-    for (int jt = 0; jt < NJ; ++jt)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int row = 16 * wave + ls + 4 * r, j = 16 * jt + li;
-            if (row < S && j < S) {
-                const double sum = acc[jt][r];
-                const float v = (sum < 0.0) ? 0.0f : (float) sum;
-                out[(size_t) j * SP + row] = v;
-                if (packedT > 0) packed[((size_t) (k * NT + row / 32) * packedT + j / 2) * 64 + (row % 32) + 32 * (j % 2)] = v;
-                if (wgTab > 0) wg_table_put(job.out + (wgTab & ~MBAMD_WG_TAB_SPLIT) + (size_t) k * wg_table_floats(S), S, row, j, v, (wgTab & MBAMD_WG_TAB_SPLIT) != 0);   // tree-walk tables (mbamd_walkg.h)
-            }
-        }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -880,7 +813,7 @@ k_integrate_lnl_wide(IntegrateArgs a, int S, int SP, int K, int P, int Ppad, con
         }
         part[n][g][p] = like;
     }
-    __syncthreads();
+    MBAMD_SYNC();
     if (g != 0) return;                              // lanes 0..31 of wave 0 finish
     double wl = 0.0;
     if (live) {
@@ -903,7 +836,7 @@ k_integrate_lnl_wide(IntegrateArgs a, int S, int SP, int K, int P, int Ppad, con
         site[c] = 0.0;
     }
 #pragma unroll
-    for (int off = 16; off > 0; off >>= 1) wl += __shfl_down(wl, off, 32);
+    for (int off = 16; off > 0; off >>= 1) wl += mbd_shfl_down_32(wl, off);
     if (p == 0) wsite[blockIdx.x] = wl;
 }
 

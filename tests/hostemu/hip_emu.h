@@ -26,6 +26,7 @@
 #define __host__
 #define __forceinline__ inline
 #define __launch_bounds__(...)
+#define __shared__ static              // (the blocks of a launch run one after the other)
 #ifndef __restrict__
 #define __restrict__
 #endif
@@ -35,6 +36,8 @@ struct dim3 {
     dim3(unsigned x_ = 1, unsigned y_ = 1, unsigned z_ = 1) : x(x_), y(y_), z(z_) {}
 };
 struct float4 { float x, y, z, w; };
+inline int min(int a, int b) { return a < b ? a : b; }      // (HIP declares these at global scope)
+inline int max(int a, int b) { return a > b ? a : b; }
 
 inline dim3& emu_threadIdx() { static thread_local dim3 v; return v; }
 inline dim3& emu_blockIdx()  { static thread_local dim3 v; return v; }
@@ -144,7 +147,7 @@ struct EmuContext { ucontext_t uc; };
 #endif
 struct EmuWave {                                     // a wave's exchange area: what every lane contributed to the current collective
     unsigned arrived = 0, generation = 0, live = 0;
-    uint32_t x[2][2][64];                            // [parity of the collective][operand][lane]
+    uint64_t x[2][2][64];                            // [parity of the collective][operand][lane]
     unsigned parity = 0;
 };
 struct EmuFibers {
@@ -222,10 +225,10 @@ inline void mbamd_emu_wave_sync()
     if (++w.arrived >= w.live) { w.arrived = 0; ++w.generation; return; }
     do emu_to_scheduler(f); while (w.generation == gen);
 }
-// every lane contributes two 32-bit values and sees what all lanes contributed (one synchronisation per collective: the areas of
+// every lane contributes two (up to) 64-bit values and sees what all lanes contributed (one synchronisation per collective: the areas of
 // consecutive collectives alternate, and nobody can be two collectives ahead of a lane that has not read yet)
-struct EmuExchange { const uint32_t* a; const uint32_t* b; };
-inline EmuExchange mbamd_emu_exchange(uint32_t a, uint32_t b)
+struct EmuExchange { const uint64_t* a; const uint64_t* b; };
+inline EmuExchange mbamd_emu_exchange(uint64_t a, uint64_t b)
 {
     EmuFibers& f = emu_fibers();
     if (f.current < 0) { std::fprintf(stderr, "host emulation: a wave-wide exchange in a kernel launched without fibers\n"); std::abort(); }
@@ -266,9 +269,10 @@ inline void emu_launch_barrier(Kernel kernel, dim3 grid, dim3 block, size_t lds_
     auto call = [&]() { kernel(args...); };
     f.body = [](void* p) { (*static_cast<decltype(call)*>(p))(); };
     f.arg = &call;
+    for (unsigned bz = 0; bz < grid.z; ++bz)
     for (unsigned by = 0; by < grid.y; ++by)
         for (unsigned bx = 0; bx < grid.x; ++bx) {
-            emu_blockIdx() = dim3(bx, by, 0);
+            emu_blockIdx() = dim3(bx, by, bz);
             void* base = lds.data();
             size_t space = lds.size();
             emu_lds_ptr() = std::align(16, lds_bytes, base, space);

@@ -12,7 +12,7 @@
 #define MBAMD_CONSUME4(a, b, c, d) ((void) (a), (void) (b), (void) (c), (void) (d))
 #define MBAMD_IMPL_NAME "mbamd HOST EMULATION (test only)"
 namespace mbamd {
-typedef float4 f4;
+typedef float f4 __attribute__((ext_vector_type(4)));     // (the host compiler is clang: the product's own vector type)
 inline int mbd_frexp_exp(float v) { int e = 0; (void) frexpf(v, &e); return e; }
 inline float mbd_ldexp(float v, int e) { return ldexpf(v, e); }
 inline float mbd_pow2(int e) { return ldexpf(1.0f, e); }
@@ -27,6 +27,36 @@ template <int PW> inline double mbd_max_across_groups(double v)      // (threads
     for (int l = (t & 63) % PW; l < 64; l += PW) m = fmax(m, buf[base + l]);
     mbamd_emu_barrier();
     return m;
+}
+typedef double f64x4 __attribute__((ext_vector_type(4)));
+// v_mfma_f64_16x16x4_f64 (a wave-wide exchange of the operands, then this lane's four elements; k = 0 first)
+inline f64x4 mbd_mfma_f64_16x16x4(double a, double b, f64x4 c)
+{
+    const EmuExchange x = mbamd_emu_exchange(__builtin_bit_cast(uint64_t, a), __builtin_bit_cast(uint64_t, b));
+    const unsigned lane = threadIdx.x & 63u, j = lane & 15u;
+    for (unsigned r = 0; r < 4; ++r) {
+        const unsigned i = (lane >> 4) + 4u * r;
+        for (unsigned k = 0; k < 4; ++k) c[r] = fma(__builtin_bit_cast(double, x.a[i + 16u * k]), __builtin_bit_cast(double, x.b[j + 16u * k]), c[r]);
+    }
+    return c;
+}
+#define MBD_SCHED_BARRIER() ((void) 0)
+inline float mbd_shfl_xor(float v, int d)
+{
+    const EmuExchange x = mbamd_emu_exchange(__builtin_bit_cast(uint32_t, v), 0u);
+    return __builtin_bit_cast(float, (uint32_t) x.a[(threadIdx.x & 63u) ^ (unsigned) d]);
+}
+inline double mbd_shfl_xor(double v, int d)
+{
+    const EmuExchange x = mbamd_emu_exchange(__builtin_bit_cast(uint64_t, v), 0u);
+    return __builtin_bit_cast(double, x.a[(threadIdx.x & 63u) ^ (unsigned) d]);
+}
+inline long long mbd_clock() { return 0; }
+inline double mbd_shfl_down_32(double v, int off)                  // (a wave-wide exchange: every live lane of the wave must call it)
+{
+    const EmuExchange x = mbamd_emu_exchange(__builtin_bit_cast(uint64_t, v), 0u);
+    const unsigned lane = threadIdx.x & 63u, src = lane + (unsigned) off;
+    return (src >> 5) == (lane >> 5) ? __builtin_bit_cast(double, x.a[src]) : v;
 }
 template <class T> inline T* mbd_dyn_lds() { return reinterpret_cast<T*>(mbamd_emu_dyn_lds()); }
 // (threads of a block run one after the other between barriers: thread 0 comes first)

@@ -3,5 +3,4 @@
 #define MBAMD_DEV_RUNTIME_H_
 #include <memory>
 #include "hip_emu.h"
-#define MBAMD_DEV_HAS_MFMA 0
 #endif

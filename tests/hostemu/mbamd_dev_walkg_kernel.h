@@ -16,17 +16,17 @@ inline mbd_acc16 mbd_mfma_f32_32x32x2(float a, float b, mbd_acc16 c)
 {
     const EmuExchange x = mbamd_emu_exchange(__builtin_bit_cast(uint32_t, a), __builtin_bit_cast(uint32_t, b));
     const unsigned lane = threadIdx.x & 63u, n = lane & 31u, h = lane >> 5;
-    const float b0 = __builtin_bit_cast(float, x.b[n]), b1 = __builtin_bit_cast(float, x.b[32u + n]);
+    const float b0 = __builtin_bit_cast(float, (uint32_t) x.b[n]), b1 = __builtin_bit_cast(float, (uint32_t) x.b[32u + n]);
     for (unsigned r = 0; r < 16; ++r) {
         const unsigned i = (r & 3u) + 8u * (r >> 2) + 4u * h;
-        c[r] = fmaf(__builtin_bit_cast(float, x.a[32u + i]), b1, fmaf(__builtin_bit_cast(float, x.a[i]), b0, c[r]));
+        c[r] = fmaf(__builtin_bit_cast(float, (uint32_t) x.a[32u + i]), b1, fmaf(__builtin_bit_cast(float, (uint32_t) x.a[i]), b0, c[r]));
     }
     return c;
 }
 inline float mbd_max_lane_xor32(float v)
 {
     const EmuExchange x = mbamd_emu_exchange(__builtin_bit_cast(uint32_t, v), 0u);
-    return fmaxf(v, __builtin_bit_cast(float, x.a[(threadIdx.x & 63u) ^ 32u]));
+    return fmaxf(v, __builtin_bit_cast(float, (uint32_t) x.a[(threadIdx.x & 63u) ^ 32u]));
 }
 #define MBAMD_AS_LDS
 #define MBD_DRAIN_ALL() ((void) 0)
