@@ -466,6 +466,8 @@ struct Instance {
     int buildWalk(Plan& plan, const BeagleOperation* ops, int n, const int* listOf = nullptr, bool perList = false);
     int ensureWide(int idx);
     int accumulate4(const int* idx, int n, int cumIdx, int sign);
+    int deferredReset = -1;          // a beagleResetScaleFactors not launched yet (level-kernel path), see beagleAccumulateScaleFactors
+    int runDeferredReset();
     int integrate4(const int* parent, const int* child, const int* prob, const int* wIdx, const int* fIdx,
                    const int* cumIdx, int count);
     int buildGeneric(Plan& plan, std::vector<PartialsOp>& dev, const std::vector<int>& dstIdx, const std::vector<int>& c1Idx,
@@ -486,7 +488,7 @@ struct Instance {
     int spineWidth = 1;              // MBAMD_SPINE_WIDTH: trailing levels of at most this many operations join the serial launch
     int serialRatio = 4;             // MBAMD_MFMA_SERIAL: lists with <= ratio * levels operations run as ONE serial launch (0 = never)
     bool independentOfPending(const Plan& plan, int cumIdx);
-    int accumulate(const int* idx, int n, int cumIdx, int sign);
+    int accumulate(const int* idx, int n, int cumIdx, int sign, bool fresh = false);   // fresh: cumIdx was reset just before -- store, do not add
     int integrate(const int* parent, const int* child, const int* prob, const int* wIdx, const int* fIdx,
                   const int* cumIdx, int count, double* out);
     int fetchResult(double* out);
@@ -2517,7 +2519,7 @@ int Instance::runGeneric(const Plan& plan, int32_t* cum)
     return BEAGLE_SUCCESS;
 }
 
-int Instance::accumulate(const int* idx, int n, int cumIdx, int sign)
+int Instance::accumulate(const int* idx, int n, int cumIdx, int sign, bool fresh)
 {
     if (cumIdx < 0 || cumIdx >= nScale) return fail(BEAGLE_ERROR_OUT_OF_RANGE, "scale factors: cumulative index");
     if (n <= 0) return BEAGLE_SUCCESS;
@@ -2534,7 +2536,17 @@ int Instance::accumulate(const int* idx, int n, int cumIdx, int sign)
     rc = stageDirect(ptrs.data(), sizeof(void*) * n, (const void**) &dptrs);
     if (rc) return rc;
     MBAMD_LAUNCH(k_scale_accumulate, (unsigned) ((Ppad + 255) / 256), 256, 0, stream, dptrs, n, sign,
-                 Ppad, scale[cumIdx]);
+                 Ppad, scale[cumIdx], fresh ? 1 : 0);
+    HIP_TRY(hipGetLastError());
+    return BEAGLE_SUCCESS;
+}
+
+int Instance::runDeferredReset()
+{
+    const int idx = deferredReset;
+    deferredReset = -1;
+    if (idx < 0 || idx >= nScale || !scale[idx]) return BEAGLE_SUCCESS;
+    MBAMD_LAUNCH(k_scale_copy, (unsigned) ((Ppad + 255) / 256), 256, 0, stream, (const int32_t*) nullptr, Ppad, scale[idx]);
     HIP_TRY(hipGetLastError());
     return BEAGLE_SUCCESS;
 }
@@ -2555,14 +2567,22 @@ int Instance::accumulate4(const int* idx, int n, int cumIdx, int sign)
         e.pad_ = 0;
         src.push_back(e);
     }
-    int rc = ensureWide(cumIdx);
-    if (rc) return rc;
+    // a freshly reset cumulative buffer (MrBayes-style rescaling: Reset + Accumulate of every node): the kernel STORES, no zero fill
+    const bool fresh = scaleState[cumIdx] == 0 && !src.empty();
+    int rc = BEAGLE_SUCCESS;
+    if (fresh) {
+        if (!wideScale[cumIdx]) HIP_TRY(hipMalloc(&wideScale[cumIdx], (size_t) K * Ppad * sizeof(int32_t)));
+        scaleState[cumIdx] = 2;
+    } else {
+        rc = ensureWide(cumIdx);
+        if (rc) return rc;
+    }
     if (src.empty()) return BEAGLE_SUCCESS;
     const ExpSource* dsrc = nullptr;
     rc = stageDirect(src.data(), sizeof(ExpSource) * src.size(), (const void**) &dsrc);
     if (rc) return rc;
     MBAMD_LAUNCH(k_exp_accumulate, (unsigned) (((size_t) K * Ppad + 255) / 256), 256, 0, stream, dsrc, (int) src.size(), sign, K, Ppad,
-                 (const int8_t*) arenaExp, estride, wideScale[cumIdx]);
+                 (const int8_t*) arenaExp, estride, wideScale[cumIdx], fresh ? 1 : 0);
     HIP_TRY(hipGetLastError());
     return BEAGLE_SUCCESS;
 }
@@ -2954,10 +2974,17 @@ int Instance::makeChildren(const std::vector<std::pair<int, int>>& ranges)
 
 using namespace mbamd;
 
-#define GET_INSTANCE_NOFLUSH(id)                                                                     \
+#define GET_INSTANCE_RAW(id)                                                                         \
     Instance* in = lookup(id);                                                                       \
     if (!in) return fail(BEAGLE_ERROR_UNINITIALIZED_INSTANCE, "no such instance");                   \
     (void) hipSetDevice(in->device)
+// (a beagleResetScaleFactors that is still waiting for its beagleAccumulateScaleFactors -- see there -- runs before anything else)
+#define GET_INSTANCE_NOFLUSH(id)                                                                     \
+    GET_INSTANCE_RAW(id);                                                                            \
+    if (in->deferredReset >= 0) {                                                                    \
+        int drc_ = in->runDeferredReset();                                                           \
+        if (drc_ != BEAGLE_SUCCESS) return drc_;                                                     \
+    }
 // every entry point except beagleUpdatePartials first runs the lists deferred so far
 #define GET_INSTANCE(id)                                                                             \
     GET_INSTANCE_NOFLUSH(id);                                                                        \
@@ -3615,7 +3642,19 @@ static int scale_copy(Instance* in, int dst, int src)
 int beagleAccumulateScaleFactors(int instance, const int* scaleIndices, int count, int cumulativeScaleIndex)
 {
     StatTimer st_(ST_SCALE);
-    GET_INSTANCE_NOFLUSH(instance);
+    GET_INSTANCE_RAW(instance);
+    // Reset + Accumulate of one cumulative buffer, back to back (rescaling the MrBayes way, reference src/mbbeagle.c:1080-1098): the
+    // reset was not launched -- this launch stores instead of adding
+    if (in->deferredReset >= 0) {
+        const bool fuse = in->deferredReset == cumulativeScaleIndex && count > 0;
+        if (fuse) {
+            in->deferredReset = -1;
+            if (in->hasPending()) { int frc = in->flushPending(); if (frc != BEAGLE_SUCCESS) return frc; }
+            return in->accumulate(scaleIndices, count, cumulativeScaleIndex, +1, true);
+        }
+        int drc = in->runDeferredReset();
+        if (drc != BEAGLE_SUCCESS) return drc;
+    }
     if (in->f64) return in->f64->accumulateScale(scaleIndices, count, cumulativeScaleIndex, +1);
     return scale_accumulate(in, scaleIndices, count, cumulativeScaleIndex, +1, -1);
 }
@@ -3632,6 +3671,12 @@ int beagleResetScaleFactors(int instance, int cumulativeScaleIndex)
     GET_INSTANCE(instance);
     if (in->f64) return in->f64->resetScale(cumulativeScaleIndex);
     FACADE_ALL(scale_reset(c, cumulativeScaleIndex));
+    // the level-kernel path (int32 buffers): wait for the call that follows -- if it is beagleAccumulateScaleFactors into this buffer,
+    // one launch does both (any other entry point runs the reset first: GET_INSTANCE_NOFLUSH)
+    if (!in->arena() && cumulativeScaleIndex >= 0 && cumulativeScaleIndex < in->nScale && in->scale[cumulativeScaleIndex]) {
+        in->deferredReset = cumulativeScaleIndex;
+        return BEAGLE_SUCCESS;
+    }
     return scale_reset(in, cumulativeScaleIndex);
 }
 int beagleCopyScaleFactors(int instance, int destScalingIndex, int srcScalingIndex)

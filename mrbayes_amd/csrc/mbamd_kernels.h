@@ -698,13 +698,13 @@ struct WgGeom { unsigned long tileFloats; unsigned tipTileBytes; int TP; };
 // cumulative scale-factor bookkeeping (exact integer arithmetic)
 // ---------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(256)
-k_scale_accumulate(const int32_t* const* __restrict__ src, int count, int sign, int n, int32_t* __restrict__ cum)
+k_scale_accumulate(const int32_t* const* __restrict__ src, int count, int sign, int n, int32_t* __restrict__ cum, int fresh)
 {
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= n) return;
     int acc = 0;
     for (int i = 0; i < count; ++i) acc += src[i][c];
-    cum[c] += sign * acc;
+    cum[c] = (fresh ? 0 : cum[c]) + sign * acc;      // fresh: the buffer was reset just before (beagleResetScaleFactors + Accumulate = one launch)
 }
 
 // dst[c] = src ? src[c] : 0 over one scale buffer
@@ -725,14 +725,14 @@ __host__ __device__ inline size_t exp_index(unsigned estride, int K, int idx, in
 struct ExpSource { const int32_t* wide; int narrow; int pad_; };      // a cumulative (wide) buffer, or arena buffer index `narrow`
 __global__ void __launch_bounds__(256)
 k_exp_accumulate(const ExpSource* __restrict__ src, int count, int sign, int K, int Ppad, const int8_t* __restrict__ arena,
-                 unsigned estride, int32_t* __restrict__ cum)
+                 unsigned estride, int32_t* __restrict__ cum, int fresh)
 {
     const int g = blockIdx.x * blockDim.x + threadIdx.x;
     if (g >= K * Ppad) return;
     const int k = g / Ppad, c = g % Ppad;
     int acc = 0;
     for (int i = 0; i < count; ++i) acc += src[i].wide ? src[i].wide[g] : (int) arena[exp_index(estride, K, src[i].narrow, k, c)];
-    cum[g] += sign * acc;
+    cum[g] = (fresh ? 0 : cum[g]) + sign * acc;
 }
 // narrow -> wide (a node buffer that is then used as a cumulative one) and narrow -> narrow copies (src < 0: zero fill)
 __global__ void __launch_bounds__(256)

@@ -285,6 +285,22 @@ def check_single_operations(lib, oracle, nstates, ncat, npat, seed=1):
             assert np.all(inst.get_scale_exponents(1) == 0)
             inst.accumulate_scale_factors([0, 0], 1)
             assert np.array_equal(inst.get_scale_exponents(1), 2 * inst.get_scale_exponents(0))
+            # Reset + Accumulate back to back (how MrBayes rebuilds a cumulative buffer) is one launch that stores: the old
+            # content must be gone; a reset followed by anything else is a plain reset; a reset of ANOTHER buffer does not leak
+            e0 = inst.get_scale_exponents(0)
+            inst.reset_scale_factors(1)
+            inst.accumulate_scale_factors([0], 1)
+            assert np.array_equal(inst.get_scale_exponents(1), e0)
+            inst.reset_scale_factors(1)
+            inst.accumulate_scale_factors([0, 0, 0], 1)
+            assert np.array_equal(inst.get_scale_exponents(1), 3 * e0)
+            inst.reset_scale_factors(1)
+            assert np.all(inst.get_scale_exponents(1) == 0)
+            inst.accumulate_scale_factors([0], 1)
+            inst.reset_scale_factors(2)
+            inst.accumulate_scale_factors([0], 1)
+            assert np.array_equal(inst.get_scale_exponents(1), 2 * e0)
+            assert np.all(inst.get_scale_exponents(2) == 0)
     finally:
         inst.finalize()
 
