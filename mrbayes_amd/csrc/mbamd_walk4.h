@@ -283,7 +283,9 @@ k_walk4_t(ARGS AA)
 // Entries (Walk4Entry): c1 = the chain's INPUT (entry 0 only: tip planes or a buffer), c2 = the sibling, m1 / m2 their matrices;
 // ctl: TIP1 (entry 0: the input is a compact tip), TIP2 (the sibling is one), [9:8] the scale mode.  blockDim.x = 64, grid = walk4_grid,
 // dynamic LDS = entries * 32 bytes.
-#define MBAMD_P4_CHUNK 16
+#if !defined(MBAMD_P4_CHUNK)
+#define MBAMD_P4_CHUNK 24         // (8: 17.8 us, 16: 16.6, 24: 15.9, 32: 16.3 -- median of the paths of DNA 500 x 20 000, profiles/r05_path4.txt)
+#endif
 #define MBAMD_P4_GROUP 4         // matrices per burst of scalar loads (4 x 16 scalar registers)
 template <class ARGS>
 __global__ void __launch_bounds__(64)
