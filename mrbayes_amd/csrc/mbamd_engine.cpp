@@ -41,8 +41,9 @@ struct ApiStats {
 static ApiStats g_stats[] = {{"beagleUpdateTransitionMatrices"}, {"beagleUpdatePartials"}, {"beagleCalculate*LogLikelihoods"},
                              {"beagle*ScaleFactors"}, {"beagleSet*"}, {"beagleGetSiteLogLikelihoods"}, {"plan build"},
                              {"mbamdParsDownPass/FinalPass"}, {"mbamdParsScore"},
-                             {"  (launching the deferred work)"}, {"  (waiting for the device)"}};
-enum { ST_MATRICES = 0, ST_PARTIALS, ST_LNL, ST_SCALE, ST_SET, ST_SITE, ST_PLAN, ST_PARS_PASS, ST_PARS_SCORE, ST_FLUSH, ST_WAIT };
+                             {"  (launching the deferred work)"}, {"  (waiting for the device)"},
+                             {"  (parsimony: compiling the queued passes)"}, {"  (parsimony: waiting for the device)"}};
+enum { ST_MATRICES = 0, ST_PARTIALS, ST_LNL, ST_SCALE, ST_SET, ST_SITE, ST_PLAN, ST_PARS_PASS, ST_PARS_SCORE, ST_FLUSH, ST_WAIT, ST_PARS_COMPILE, ST_PARS_WAIT };
 static const bool g_statsOn = std::getenv("MBAMD_STATS") != nullptr;
 // MBAMD_API_TRACE=1: one stderr line per C-ABI call (integration debugging: what does the client really send?)
 static const bool g_apiTrace = std::getenv("MBAMD_API_TRACE") != nullptr;
@@ -62,12 +63,15 @@ struct StatTimer {
     int id;
     std::chrono::steady_clock::time_point t0;
     explicit StatTimer(int i) : id(i) { if (g_statsOn) t0 = std::chrono::steady_clock::now(); }
-    ~StatTimer()
+    bool stopped = false;
+    void stop()                                      // (a span that ends before its scope does)
     {
-        if (!g_statsOn) return;
+        if (!g_statsOn || stopped) return;
+        stopped = true;
         g_stats[id].calls++;
         g_stats[id].seconds += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
     }
+    ~StatTimer() { stop(); }
 };
 
 static thread_local std::string g_last_error;

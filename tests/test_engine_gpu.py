@@ -541,10 +541,20 @@ def test_multi_partition_instance(gpu, oracle, golden_dir, kind, double_precisio
 
 
 @pytest.mark.parametrize("ntaxa,npat,nstates,words", [(12, 100, 4, 1), (200, 5000, 4, 1), (50, 1000, 20, 1), (30, 700, 61, 1), (7, 65, 64, 1),
-                                                       (10, 50, 10, 1), (16, 300, 70, 2)])
+                                                       (10, 50, 10, 1), (16, 300, 70, 2), (500, 20000, 4, 1)])
 def test_parsimony(gpu, ntaxa, npat, nstates, words):
     """Device Fitch parsimony (mbamdPars*) against the oracle: u8 / u16 / u32 / u64 / 2 x u64 sets."""
     ec.check_parsimony(gpu, ntaxa, npat, nstates, words=words)
+
+
+@pytest.mark.parametrize("waves", [1, 2, 4, 8])
+def test_parsimony_waves_per_workgroup(gpu, monkeypatch, waves):
+    """The parsimony walk with the tree cut over 1 / 2 / 4 / 8 waves of a workgroup (phases separated by barriers, ParsInstance::flush):
+    every setting gives the oracle's sets and lengths exactly."""
+    monkeypatch.setenv("MBAMD_PARS_WAVES", str(waves))
+    ec.check_parsimony(gpu, 70, 130, 4, seed=5)
+    ec.check_parsimony(gpu, 33, 64, 20, seed=6)
+    ec.check_parsimony(gpu, 150, 2000, 61, seed=7)
 
 
 @pytest.mark.parametrize("case", ["primates_gtr_g4", "primates_gtr_ig4", "avian_wag_g4", "replicase_m3", "synth_dna_gaps", "synth_aa_wag",

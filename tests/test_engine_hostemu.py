@@ -274,10 +274,20 @@ def test_multi_partition_instance(emu, oracle, golden_dir, kind, double_precisio
 
 
 @pytest.mark.parametrize("ntaxa,npat,nstates,words", [(12, 100, 4, 1), (30, 333, 4, 1), (9, 64, 20, 1), (8, 70, 61, 1), (7, 65, 64, 1),
-                                                       (10, 50, 10, 1), (6, 40, 70, 2)])
+                                                       (10, 50, 10, 1), (6, 40, 70, 2),
+                                                       (130, 200, 4, 1), (45, 100, 20, 1), (100, 70, 61, 1)])
 def test_parsimony(emu, ntaxa, npat, nstates, words):
     """Device Fitch parsimony (mbamdPars*) against the oracle: u8 / u16 / u32 / u64 / 2 x u64 sets."""
     ec.check_parsimony(emu, ntaxa, npat, nstates, words=words)
+
+
+@pytest.mark.parametrize("waves", [1, 2, 4, 8])
+def test_parsimony_waves_per_workgroup(emu, monkeypatch, waves):
+    """The parsimony walk with the tree cut over 1 / 2 / 4 / 8 waves of a workgroup (phases separated by barriers, ParsInstance::flush):
+    every setting gives the oracle's sets and lengths exactly."""
+    monkeypatch.setenv("MBAMD_PARS_WAVES", str(waves))
+    ec.check_parsimony(emu, 70, 130, 4, seed=5)
+    ec.check_parsimony(emu, 33, 64, 20, seed=6)
 
 
 @pytest.mark.parametrize("case", ["primates_gtr_g4", "primates_gtr_ig4", "avian_wag_g4", "replicase_m3", "synth_dna_gaps"])
