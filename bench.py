@@ -609,7 +609,7 @@ def main():
                          "rank 0 drives all devices, the other ranks idle)")
     ap.add_argument("--no-mpi", action="store_true", help="skip the MPI-build MCMC measurement (mbamd_mpirun -n N mb_amd_mpi_pars)")
     ap.add_argument("--mpi-full", action="store_true", help="the MPI measurement's DNA analysis on the 1000 x 50000 alignment (minutes of start-up)")
-    ap.add_argument("--secondary-timeout", type=float, default=1500.0,
+    ap.add_argument("--secondary-timeout", type=float, default=600.0,
                     help="N > 1: seconds the secondary modes (pattern-sharded chain, MPI-build MCMC) may take together before every rank "
                          "leaves and rank 0 prints the line with the modes that finished (0: no limit)")
     ap.add_argument("--emulate", action="store_true",
