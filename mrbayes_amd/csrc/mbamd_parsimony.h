@@ -260,6 +260,7 @@ public:
     std::vector<ParsStep> compiled;
     std::vector<unsigned char> image;                // header + programs as they go to the device
     bool verbose = false;                            // MBAMD_VERBOSE
+    int phaseLimit = MBAMD_PARS_MAXPHASES;           // phases per launch (MBAMD_PARS_PHASE_LIMIT: tests force programs over several launches)
     int waves = 0;                                   // MBAMD_PARS_WAVES: waves per workgroup (0: by the length of the program; 1: one serial program)
 
     ~ParsInstance() { destroy(); }
@@ -301,6 +302,7 @@ public:
         } else {
             (void) hipGetLastError();
         }
+        if (const char* e = std::getenv("MBAMD_PARS_PHASE_LIMIT")) phaseLimit = std::max(1, std::min(MBAMD_PARS_MAXPHASES, std::atoi(e)));
         if (const char* e = std::getenv("MBAMD_PARS_WAVES")) waves = std::max(1, std::min(MBAMD_PARS_MAXW, std::atoi(e)));
         return BEAGLE_SUCCESS;
     }
@@ -545,6 +547,7 @@ public:
             if (rc) return rc;
         }
         size_t done = 0;
+        double lengthSum = 0.0;
         while (done < pending.size()) {
             StatTimer compileTimer(ST_PARS_COMPILE);
             // ---- (1) phases and waves of as many steps as fit into MBAMD_PARS_MAXPHASES.  Per set: who wrote it last (step, phase,
@@ -664,7 +667,7 @@ public:
                     if (!inBin) topMax = std::max(topMax, ph);
                     else if (ph <= topMax) { ph = topMax + 1; wq = home; }       // (later than it must: with the other subtrees)
                 }
-                if (ph >= MBAMD_PARS_MAXPHASES) break;                       // the rest in another launch
+                if (ph >= phaseLimit) break;                                 // the rest in another launch
                 phaseOf[(size_t) taken] = ph;
                 waveOf[(size_t) taken] = wq;
                 nphases = std::max(nphases, ph + 1);
@@ -756,21 +759,21 @@ public:
             Slot* sl = nullptr;
             int rc = stage(image.data(), bytes, &d, &sl);
             if (rc) return rc;
-            // (a length is asked for the LAST pass queued alone -- downPass() flushes what came before it --, so it is one launch)
-            launchWalk(static_cast<const int*>(d), nphases, W, (outLength && last) ? d_out : nullptr);
+            // (a length is asked for a pass queued alone -- downPass() flushes what came before it; should the pass need more
+            //  phases than one launch holds, every launch's sums are fetched and added)
+            launchWalk(static_cast<const int*>(d), nphases, W, outLength ? d_out : nullptr);
             HIP_TRY(hipGetLastError());
             rc = release(sl);
             if (rc) return rc;
-            if (outLength && !last) return fail(BEAGLE_ERROR_GENERAL, "mbamdParsDownPass", "a pass with a length did not fit into one launch");
+            if (outLength) {
+                rc = waitForSums();
+                if (rc) return rc;
+                for (int b = 0; b < blocks; ++b) lengthSum += h_out[b];
+            }
+            (void) last;
         }
         pending.clear();
-        if (outLength) {
-            int wrc = waitForSums();
-            if (wrc) return wrc;
-            double sum = 0.0;
-            for (int b = 0; b < blocks; ++b) sum += h_out[b];
-            *outLength = sum;
-        }
+        if (outLength) *outLength = lengthSum;
         return BEAGLE_SUCCESS;
     }
 

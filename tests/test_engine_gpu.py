@@ -553,6 +553,10 @@ def test_parsimony_waves_per_workgroup(gpu, monkeypatch, waves):
     every setting gives the oracle's sets and lengths exactly."""
     monkeypatch.setenv("MBAMD_PARS_WAVES", str(waves))
     ec.check_parsimony(gpu, 70, 130, 4, seed=5)
+    if waves == 8:                       # ... and with a program cut into launches of two phases each
+        monkeypatch.setenv("MBAMD_PARS_PHASE_LIMIT", "2")
+        ec.check_parsimony(gpu, 70, 130, 4, seed=8)
+        monkeypatch.delenv("MBAMD_PARS_PHASE_LIMIT")
     ec.check_parsimony(gpu, 33, 64, 20, seed=6)
     ec.check_parsimony(gpu, 150, 2000, 61, seed=7)
 
