@@ -97,7 +97,9 @@ static inline int round_up(int v, int m) { return (v + m - 1) / m * m; }
 // every genetic code MrBayes knows (60 vertebrate mitochondrial ... 63; reference src/model.c SetCode)
 // state counts MrBayes sends: restriction sites 2, covarion nucleotides 8, doublets 16, amino acids 20, covarion amino acids 40, the
 // sense codons of every genetic code 60..63 (4 has its own kernel; anything else runs on the level kernels)
-static inline bool wg_compiled(int S) { return S == 2 || S == 8 || S == 16 || S == 20 || S == 40 || (S >= 60 && S <= 63); }
+// (round 5: 3, 5, 6, 7, 9, 10 as well -- the state counts of standard (morphology) characters, whose transition-matrix classes are
+//  engine instances of a few hundred patterns: a launch per dependency level of the level kernels was ten launches where this is one)
+static inline bool wg_compiled(int S) { return (S >= 2 && S <= 10 && S != 4) || S == 16 || S == 20 || S == 40 || (S >= 60 && S <= 63); }
 // FN<SC, WMAX, CH, DEPTH>: one row tile -> whole jobs two ahead; two row tiles -> half jobs one ahead (see k_walkg)
 #if !defined(MBAMD_WG_DEPTH61)
 #define MBAMD_WG_DEPTH61 1       // chunks the operand fetch of the 60..63-state kernels runs ahead (experiments: 2)
@@ -105,7 +107,13 @@ static inline bool wg_compiled(int S) { return S == 2 || S == 8 || S == 16 || S 
 #define MBAMD_WG_DISPATCH(S, FN, ...)                                   \
     switch (S) {                                                        \
         case 2: FN<2, 8, 1, 2>(__VA_ARGS__); break;                     \
+        case 3: FN<3, 8, 1, 2>(__VA_ARGS__); break;                     \
+        case 5: FN<5, 8, 1, 2>(__VA_ARGS__); break;                     \
+        case 6: FN<6, 8, 1, 2>(__VA_ARGS__); break;                     \
+        case 7: FN<7, 8, 1, 2>(__VA_ARGS__); break;                     \
         case 8: FN<8, 8, 1, 2>(__VA_ARGS__); break;                     \
+        case 9: FN<9, 8, 1, 2>(__VA_ARGS__); break;                     \
+        case 10: FN<10, 8, 1, 2>(__VA_ARGS__); break;                   \
         case 16: FN<16, 8, 1, 2>(__VA_ARGS__); break;                   \
         case 20: FN<20, 8, 1, 2>(__VA_ARGS__); break;                   \
         case 40: FN<40, 4, 1, 1>(__VA_ARGS__); break;                   \
@@ -1065,13 +1073,17 @@ int Instance::flushMatrices()
         HIP_TRY(hipGetLastError());
         return BEAGLE_SUCCESS;
     }
-    const size_t nev = (size_t) count * K * S;
-    rc = grow((void**) &d_ev, &evCap, nev * sizeof(double));
-    if (rc) return rc;
-    MBAMD_LAUNCH(k_eigen_exponentials, (unsigned) ((nev + 255) / 256), 256, 0, stream, djobs, rates, S, K, (int) nev, d_ev);
     const int threads = std::min(256, round_up(S * S, 64));
-    MBAMD_LAUNCH(k_transition_matrices_ev, (unsigned) (count * K), threads, 0, stream, djobs, (const double*) d_ev, S, SP, K, 1,
-                 mfma ? T : 0, wg ? (wgTabFloats | (wgPair ? MBAMD_WG_TAB_SPLIT : (size_t) 0)) : (size_t) 0);
+    const double* evs = nullptr;                 // up to 64 states the matrix kernel forms the exponentials itself
+    if (S > 64) {
+        const size_t nev = (size_t) count * K * S;
+        rc = grow((void**) &d_ev, &evCap, nev * sizeof(double));
+        if (rc) return rc;
+        MBAMD_LAUNCH(k_eigen_exponentials, (unsigned) ((nev + 255) / 256), 256, 0, stream, djobs, rates, S, K, (int) nev, d_ev);
+        evs = d_ev;
+    }
+    MBAMD_LAUNCH_BARRIER(k_transition_matrices_ev, (unsigned) (count * K), threads, 0, stream, djobs, evs, rates, S, SP, K, 1,
+                         mfma ? T : 0, wg ? (wgTabFloats | (wgPair ? MBAMD_WG_TAB_SPLIT : (size_t) 0)) : (size_t) 0);
     HIP_TRY(hipGetLastError());
     return BEAGLE_SUCCESS;
 }
@@ -2539,7 +2551,7 @@ int Instance::accumulate(const int* idx, int n, int cumIdx, int sign, bool fresh
     const int32_t* const* dptrs = nullptr;
     rc = stageDirect(ptrs.data(), sizeof(void*) * n, (const void**) &dptrs);
     if (rc) return rc;
-    MBAMD_LAUNCH(k_scale_accumulate, (unsigned) ((Ppad + 255) / 256), 256, 0, stream, dptrs, n, sign,
+    MBAMD_LAUNCH_BARRIER(k_scale_accumulate, (unsigned) ((Ppad + 255) / 256), 256, 0, stream, dptrs, n, sign,
                  Ppad, scale[cumIdx], fresh ? 1 : 0);
     HIP_TRY(hipGetLastError());
     return BEAGLE_SUCCESS;
@@ -2571,6 +2583,8 @@ int Instance::accumulate4(const int* idx, int n, int cumIdx, int sign)
         e.pad_ = 0;
         src.push_back(e);
     }
+    // (arena buffers in front of the wide ones: the kernel sums them without a branch; the order of an integer sum is free)
+    const int nNarrow = (int) (std::stable_partition(src.begin(), src.end(), [](const ExpSource& e) { return e.wide == nullptr; }) - src.begin());
     // a freshly reset cumulative buffer (MrBayes-style rescaling: Reset + Accumulate of every node): the kernel STORES, no zero fill
     const bool fresh = scaleState[cumIdx] == 0 && !src.empty();
     int rc = BEAGLE_SUCCESS;
@@ -2585,7 +2599,7 @@ int Instance::accumulate4(const int* idx, int n, int cumIdx, int sign)
     const ExpSource* dsrc = nullptr;
     rc = stageDirect(src.data(), sizeof(ExpSource) * src.size(), (const void**) &dsrc);
     if (rc) return rc;
-    MBAMD_LAUNCH(k_exp_accumulate, (unsigned) (((size_t) K * Ppad + 255) / 256), 256, 0, stream, dsrc, (int) src.size(), sign, K, Ppad,
+    MBAMD_LAUNCH_BARRIER(k_exp_accumulate, (unsigned) (((size_t) K * Ppad + 255) / 256), 256, 0, stream, dsrc, (int) src.size(), nNarrow, sign, K, Ppad,
                  (const int8_t*) arenaExp, estride, wideScale[cumIdx], fresh ? 1 : 0);
     HIP_TRY(hipGetLastError());
     return BEAGLE_SUCCESS;

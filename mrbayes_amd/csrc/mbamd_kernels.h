@@ -323,13 +323,21 @@ k_transition_matrices_s4(const MatrixJob* __restrict__ jobs, RatesArg rates, int
 //   packed[((k*NT + i/32)*T + j/2)*64 + (i%32) + 32*(j%2)] = P_k(i->j),  NT = ceil(S/32), T = packedT = ceil(S/2)
 // wgTab > 0: additionally scatter into the tree-walk tables of category k, wgTab floats into the buffer (mbamd_walkg.h)
 __global__ void __launch_bounds__(256)
-k_transition_matrices_ev(const MatrixJob* __restrict__ jobs, const double* __restrict__ ev, int S, int SP, int K,
+k_transition_matrices_ev(const MatrixJob* __restrict__ jobs, const double* __restrict__ ev, RatesArg rates, int S, int SP, int K,
                          int transposed, int packedT, size_t wgTab)
 {
+    // ev == nullptr (up to 64 states): the block forms its own S exponentials -- the expression of k_eigen_exponentials, one launch
+    // less in front of every small-state evaluation (round 5: a standard-data class is a few hundred patterns, all launch latency)
+    __shared__ double own[64];
     const int b = blockIdx.x / K, k = blockIdx.x % K;
     const double* __restrict__ U = jobs[b].eig;
     const double* __restrict__ Ui = jobs[b].eig + (size_t) S * S;
-    const double* __restrict__ e = ev + (size_t) blockIdx.x * S;
+    if (ev == nullptr) {
+        const double* __restrict__ lam = jobs[b].eig + (size_t) 2 * S * S;
+        if ((int) threadIdx.x < S) own[threadIdx.x] = exp(lam[threadIdx.x] * jobs[b].length * rates.r[k]);
+        MBAMD_SYNC();
+    }
+    const double* __restrict__ e = ev ? ev + (size_t) blockIdx.x * S : own;
     float* __restrict__ out = jobs[b].out + (size_t) k * SP * SP;
     for (int idx = threadIdx.x; idx < S * S; idx += blockDim.x) {
         // consecutive threads take consecutive j so that U^-1 reads are coalesced
@@ -697,14 +705,26 @@ struct WgGeom { unsigned long tileFloats; unsigned tipTileBytes; int TP; };
 // ---------------------------------------------------------------------------------------------
 // cumulative scale-factor bookkeeping (exact integer arithmetic)
 // ---------------------------------------------------------------------------------------------
+// (round 5: the list of sources sits in pinned host memory -- read element by element inside every thread's loop it was a round
+//  trip over the host link per source, 33 us for the 99 interior nodes of a 100-taxon tree; a block now copies it into LDS in one
+//  parallel read and loops over the copy)
+#define MBAMD_ACC_LIST 256
 __global__ void __launch_bounds__(256)
 k_scale_accumulate(const int32_t* const* __restrict__ src, int count, int sign, int n, int32_t* __restrict__ cum, int fresh)
 {
+    __shared__ const int32_t* list[MBAMD_ACC_LIST];
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= n) return;
+    const bool live = c < n;
     int acc = 0;
-    for (int i = 0; i < count; ++i) acc += src[i][c];
-    cum[c] = (fresh ? 0 : cum[c]) + sign * acc;      // fresh: the buffer was reset just before (beagleResetScaleFactors + Accumulate = one launch)
+    for (int base = 0; base < count; base += MBAMD_ACC_LIST) {
+        const int m = count - base < MBAMD_ACC_LIST ? count - base : MBAMD_ACC_LIST;
+        if (base > 0) MBAMD_SYNC();
+        if ((int) threadIdx.x < m) list[threadIdx.x] = src[base + (int) threadIdx.x];
+        MBAMD_SYNC();
+        if (live)
+            for (int i = 0; i < m; ++i) acc += list[i][c];
+    }
+    if (live) cum[c] = (fresh ? 0 : cum[c]) + sign * acc;      // fresh: the buffer was reset just before (beagleResetScaleFactors + Accumulate = one launch)
 }
 
 // dst[c] = src ? src[c] : 0 over one scale buffer
@@ -723,16 +743,38 @@ __host__ __device__ inline size_t exp_index(unsigned estride, int K, int idx, in
     return (size_t) (c >> 6) * estride + ((size_t) idx * K + k) * 64 + (c & 63);
 }
 struct ExpSource { const int32_t* wide; int narrow; int pad_; };      // a cumulative (wide) buffer, or arena buffer index `narrow`
+// (the host lists the arena buffers -- `narrow` -- in front of the wide ones: the first nNarrow entries are summed in a loop without a
+//  branch, eight loads in flight)
 __global__ void __launch_bounds__(256)
-k_exp_accumulate(const ExpSource* __restrict__ src, int count, int sign, int K, int Ppad, const int8_t* __restrict__ arena,
+k_exp_accumulate(const ExpSource* __restrict__ src, int count, int nNarrow, int sign, int K, int Ppad, const int8_t* __restrict__ arena,
                  unsigned estride, int32_t* __restrict__ cum, int fresh)
 {
+    __shared__ ExpSource list[MBAMD_ACC_LIST];       // (the list through LDS: see k_scale_accumulate)
     const int g = blockIdx.x * blockDim.x + threadIdx.x;
-    if (g >= K * Ppad) return;
-    const int k = g / Ppad, c = g % Ppad;
+    const bool live = g < K * Ppad;
+    const int k = live ? g / Ppad : 0, c = live ? g % Ppad : 0;
+    const int8_t* const mine = arena + exp_index(estride, K, 0, k, c);      // this (pattern, category) of buffer 0
+    const size_t perBuffer = exp_index(estride, K, 1, k, c) - exp_index(estride, K, 0, k, c);
     int acc = 0;
-    for (int i = 0; i < count; ++i) acc += src[i].wide ? src[i].wide[g] : (int) arena[exp_index(estride, K, src[i].narrow, k, c)];
-    cum[g] = (fresh ? 0 : cum[g]) + sign * acc;
+    for (int base = 0; base < count; base += MBAMD_ACC_LIST) {
+        const int m = count - base < MBAMD_ACC_LIST ? count - base : MBAMD_ACC_LIST;
+        if (base > 0) MBAMD_SYNC();
+        if ((int) threadIdx.x < m) list[threadIdx.x] = src[base + (int) threadIdx.x];
+        MBAMD_SYNC();
+        if (!live) continue;
+        const int nn = nNarrow - base < 0 ? 0 : (nNarrow - base < m ? nNarrow - base : m);      // narrow entries of this piece
+        int i = 0;
+        for (; i + 8 <= nn; i += 8) {
+            int v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = mine[(size_t) list[i + u].narrow * perBuffer];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) acc += v[u];
+        }
+        for (; i < nn; ++i) acc += mine[(size_t) list[i].narrow * perBuffer];
+        for (; i < m; ++i) acc += list[i].wide[g];
+    }
+    if (live) cum[g] = (fresh ? 0 : cum[g]) + sign * acc;
 }
 // narrow -> wide (a node buffer that is then used as a cumulative one) and narrow -> narrow copies (src < 0: zero fill)
 __global__ void __launch_bounds__(256)

@@ -67,7 +67,7 @@ namespace mbamd {
 #define MBAMD_WG_TAB_SPLIT ((size_t) 1 << 63)
 __host__ __device__ inline bool wg_split_states(int S) { return S > 48; }
 // state counts k_walkg2 is instantiated for (one output tile per wave: up to 32 states, or the row split); 40 states: k_walkg only
-__host__ __device__ inline bool wg2_states(int S) { return S <= 32 || S > 48; }
+__host__ __device__ inline bool wg2_states(int S) { return S == 2 || S == 8 || S == 16 || S == 20 || S > 48; }
 __host__ __device__ inline int wg_pairs(int S) { return (S + MBAMD_WG_KS - 1) / MBAMD_WG_KS; }         // T: MFMA steps (rows of a block)
 __host__ __device__ inline int wg_tiles(int S) { return (S + MBAMD_WG_TW - 1) / MBAMD_WG_TW; }         // NT: output tiles of TW rows
 __host__ __device__ inline int wg_vec(int S) { return S > 32 ? 4 : 2; }                   // V: floats per lane and memory instruction (blocks)

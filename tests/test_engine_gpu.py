@@ -57,10 +57,12 @@ def test_final_pass_and_scaled_readout(gpu, nstates, ncat, npat):
     ec.check_final_pass(gpu, nstates, ncat, npat)
 
 
-@pytest.mark.parametrize("nstates,ntaxa,npat", [(2, 40, 700), (8, 60, 1500), (16, 30, 300), (40, 30, 400), (5, 20, 200), (33, 12, 100)])
+@pytest.mark.parametrize("nstates,ntaxa,npat", [(2, 40, 700), (8, 60, 1500), (16, 30, 300), (40, 30, 400), (5, 20, 200), (33, 12, 100),
+                                                (3, 50, 400), (6, 40, 700), (7, 20, 200), (9, 30, 300), (10, 45, 500)])
 def test_other_state_counts_on_the_tree_walk(gpu, oracle, nstates, ntaxa, npat):
     """Restriction sites (2 states, CondLikeDown_Bin / Likelihood_Res), covarion nucleotides and amino acids (8 / 40 states,
-    CondLikeDown_Gen with TiProbs_GenCov) have their own instantiations of the 20/61-state tree-walk kernel; 5 and 33 states stay on the level kernels."""
+    CondLikeDown_Gen with TiProbs_GenCov) and the state counts of standard characters (3, 5 ... 10) have their own instantiations of
+    the 20/61-state tree-walk kernel; 33 states stay on the level kernels."""
     ec.check_generic_states(gpu, oracle, nstates, ntaxa, npat)
 
 

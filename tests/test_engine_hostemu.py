@@ -61,10 +61,12 @@ def test_final_pass_and_scaled_readout(emu, nstates, ncat, npat):
     ec.check_final_pass(emu, nstates, ncat, npat)
 
 
-@pytest.mark.parametrize("nstates,ntaxa,npat", [(2, 12, 70), (8, 10, 45), (40, 8, 40), (5, 8, 33)])
+@pytest.mark.parametrize("nstates,ntaxa,npat", [(2, 12, 70), (8, 10, 45), (40, 8, 40), (5, 8, 33), (3, 9, 40), (6, 10, 70), (7, 8, 33), (9, 8, 40),
+                                                (10, 9, 65), (33, 8, 33)])
 def test_other_state_counts_on_the_tree_walk(emu, oracle, nstates, ntaxa, npat):
     """Restriction sites (2 states, CondLikeDown_Bin / Likelihood_Res), covarion nucleotides and amino acids (8 / 40 states,
-    CondLikeDown_Gen with TiProbs_GenCov) have their own instantiations of the 20/61-state tree-walk kernel; 5 and 33 states stay on the level kernels."""
+    CondLikeDown_Gen with TiProbs_GenCov) and the state counts of standard characters (3, 5 ... 10) have their own instantiations of
+    the 20/61-state tree-walk kernel; 33 states stay on the level kernels."""
     ec.check_generic_states(emu, oracle, nstates, ntaxa, npat)
 
 
