@@ -333,4 +333,4 @@ def test_parsimony_model_golden(emu, golden_dir):
 def test_pair_walk(emu, oracle, golden_dir, monkeypatch):
     """The opt-in general-state walk k_walkg2 (a whole entry's operands in flight, the row-split pair of waves at 60-63 states) is
     parity-green: it is not the product default because it measured no faster than k_walkg (profiles/r05_walkg_pair.txt)."""
-    ec.check_pair_walk(emu, oracle, golden_dir, monkeypatch)
+    ec.check_pair_walk(emu, oracle, golden_dir, monkeypatch, full=False)
