@@ -168,6 +168,7 @@ struct Plan {
     std::vector<Segment> segments;               // (Walk4Entry index of its program in d_table, geometry)
     std::vector<Walk4Entry> inlineProg;          // 4-state walk: a short single-segment program travels in the kernel arguments instead
     bool path = false;                           // 4-state walk: the list is a root-ward path -- inlineProg holds k_path4's entries
+    bool pathG = false;                          // 20/61-state walk: every list is a root-ward path of the same length -- inlineProg holds k_pathg's entries
     int lists = 1;                               // 20/61-state walk: > 1 = the segments are that many independent lists, ONE launch
     std::vector<int> start;                      // general path: first table entry of each dependency level
     bool anyScale = false;
@@ -259,6 +260,8 @@ struct Instance {
     int flushWalkG();
     int runWalkG(const Plan& plan);
     bool buildPath4(Plan& plan, const BeagleOperation* ops, int n);
+    bool buildPathG(Plan& plan, const BeagleOperation* ops, int n, const std::vector<int>& starts, int nl);
+    bool noPathG = false;                        // MBAMD_NO_PATHG: root-ward paths of the general-state walk through k_walkg
     bool noPath4 = false;                        // MBAMD_NO_PATH4: root-ward paths on k_walk4_t too
     void postResultFlag();
     bool scaleOpsIndependentOfPending(const int* idx, int n, int cumIdx) const;
@@ -588,6 +591,7 @@ int Instance::create(int tipCount_, int partialsBufferCount, int compactBufferCo
     noDefer = std::getenv("MBAMD_NO_DEFER") != nullptr;
     noInlinePrograms = std::getenv("MBAMD_NO_INLINE_PROGRAMS") != nullptr;
     noPath4 = std::getenv("MBAMD_NO_PATH4") != nullptr;
+    noPathG = std::getenv("MBAMD_NO_PATHG") != nullptr;
     if (const char* e = std::getenv("MBAMD_MFMA_SERIAL")) serialRatio = std::max(0, std::atoi(e));
     noSpine = std::getenv("MBAMD_NO_SPINE") != nullptr;
     if (const char* e = std::getenv("MBAMD_SPINE_WIDTH")) spineWidth = std::max(1, std::atoi(e));
@@ -1849,6 +1853,81 @@ bool Instance::buildPath4(Plan& plan, const BeagleOperation* ops, int n)
     return true;
 }
 
+// The same for the 20/61-state walk (k_pathg, mbamd_pathg_kernel.h): `nl` mutually independent lists (the eigen-system parts of a
+// codon model; one for a protein model), each a root-ward path, all of the same length.  Entries [list][operation] in the tile
+// arena's units (byte offsets of a buffer inside a tile, tip states at 32 bytes per buffer, matrix buffers in bytes).
+static inline bool pathg_compiled(int S) { return S == 20 || (S >= 60 && S <= 63); }
+bool Instance::buildPathG(Plan& plan, const BeagleOperation* ops, int n, const std::vector<int>& starts, int nl)
+{
+    if (noPathG || wg2 || !pathg_compiled(S) || nl < 1 || nl > MBAMD_WG_MAXLISTS || n < nl || n % nl != 0) return false;
+    const int L = n / nl;
+    if (L < 2 || (size_t) n > (size_t) MBAMD_W4_INLINE) return false;      // (a single operation gains nothing; the program travels in the kernel arguments)
+    for (int q = 0; q < nl; ++q) if (starts[(size_t) q] != q * L) return false;
+    const int scratchScale = (int) scale.size();
+    const uint32_t slotb = wg_block_bytes(S), pbuf = (uint32_t) K * slotb, ebuf = (uint32_t) K * 64u, mbuf = (uint32_t) (matrixFloats * 4);
+    auto writtenIn = [&](int buf, int lo, int hi) { for (int o = lo; o < hi; ++o) if (ops[o].destinationPartials == buf) return true; return false; };
+    std::vector<Walk4Entry>& prog = plan.inlineProg;
+    prog.assign((size_t) n, Walk4Entry());
+    for (int q = 0; q < nl; ++q) {
+        const int lo = q * L;
+        for (int i = 0; i < L; ++i) {
+            const BeagleOperation& b = ops[lo + i];
+            if (b.destinationPartials < 0 || b.destinationPartials >= nBuffers || b.child1Partials < 0 || b.child1Partials >= nBuffers ||
+                b.child2Partials < 0 || b.child2Partials >= nBuffers || b.child1TransitionMatrix < 0 || b.child1TransitionMatrix >= nMatrices ||
+                b.child2TransitionMatrix < 0 || b.child2TransitionMatrix >= nMatrices) return false;      // (buildWalk reports it)
+            if (tipStates[b.destinationPartials] || writtenIn(b.destinationPartials, 0, lo + i)) return false;
+            int chain, sib, mchain, msib;
+            if (i == 0) { chain = b.child1Partials; sib = b.child2Partials; mchain = b.child1TransitionMatrix; msib = b.child2TransitionMatrix; }
+            else {
+                const int prev = ops[lo + i - 1].destinationPartials;
+                const bool one = b.child1Partials == prev, two = b.child2Partials == prev;
+                if (one == two) return false;
+                chain = one ? b.child1Partials : b.child2Partials; sib = one ? b.child2Partials : b.child1Partials;
+                mchain = one ? b.child1TransitionMatrix : b.child2TransitionMatrix; msib = one ? b.child2TransitionMatrix : b.child1TransitionMatrix;
+            }
+            for (int ext : {sib, i == 0 ? chain : -1})
+                if (ext >= 0) {
+                    if (writtenIn(ext, 0, n)) return false;                // (nothing any of the lists writes)
+                    if (!tipStates[ext] && !valid[ext]) return false;
+                }
+            Walk4Entry& e = prog[(size_t) (lo + i)];
+            std::memset(&e, 0, sizeof e);
+            uint32_t flags = 0, mode = SCALE_NONE;
+            e.dst = (uint32_t) b.destinationPartials * pbuf;
+            if (i == 0) {
+                if (tipStates[chain]) { e.c1 = (uint32_t) chain * (uint32_t) MBAMD_WG_TW; flags |= MBAMD_W4_TIP1; }
+                else e.c1 = (uint32_t) chain * pbuf;
+            }
+            if (tipStates[sib]) { e.c2 = (uint32_t) sib * (uint32_t) MBAMD_WG_TW; flags |= MBAMD_W4_TIP2; }
+            else e.c2 = (uint32_t) sib * pbuf;
+            e.m1 = (uint32_t) mchain * mbuf;
+            e.m2 = (uint32_t) msib * mbuf;
+            e.ewrite = e.eread = (uint32_t) scratchScale * ebuf;
+            if (b.destinationScaleWrite != BEAGLE_OP_NONE) {
+                if (b.destinationScaleWrite < 0 || b.destinationScaleWrite >= nScale) return false;
+                for (int o = 0; o < n; ++o)
+                    if (o != lo + i && (ops[o].destinationScaleWrite == b.destinationScaleWrite || ops[o].destinationScaleRead == b.destinationScaleWrite)) return false;
+                mode = SCALE_WRITE;
+                e.ewrite = (uint32_t) b.destinationScaleWrite * ebuf;
+            } else if (b.destinationScaleRead != BEAGLE_OP_NONE) {
+                if (b.destinationScaleRead < 0 || b.destinationScaleRead >= nScale || scaleState[b.destinationScaleRead] == 2) return false;
+                mode = SCALE_READ;
+                e.eread = (uint32_t) b.destinationScaleRead * ebuf;
+            }
+            e.ctl = flags | (mode << 8) | ((uint32_t) q << 10);
+        }
+    }
+    if (envVerbose) std::fprintf(stderr, "[mbamd] walk plan: %d list(s) of %d operations each: root-ward paths (k_pathg)\n", nl, L);
+    plan.pathG = true;
+    plan.lists = nl;
+    plan.segments.clear();
+    Plan::Segment sg;
+    sg.first = 0; sg.W = 1; sg.entries = L; sg.nslots = 0; sg.tail = 0;
+    plan.segments.push_back(sg);
+    lastWalkW = 1; lastWalkSlots = 0; lastWalkEntries = L; lastWalkPhases = 1;
+    return true;
+}
+
 int Instance::runWalk(const Plan& plan, int32_t* cum)
 {
     if (plan.path) {
@@ -2078,9 +2157,11 @@ int Instance::flushWalkG()
         {
             StatTimer st_(ST_PLAN);
             plan->lists = 1;
+            plan->pathG = false;
             rc = BEAGLE_SUCCESS;
-            bool done = false;
-            if (independent) {
+            bool done = (nl == 1 || independent) && buildPathG(*plan, ops.data(), n, starts, nl);
+            if (!done) plan->inlineProg.clear();
+            if (!done && independent) {
                 const int keepW = w4.maxW, keepS = w4.maxSlots, keepS1 = w4.maxSlots1;
                 wgGeometry(nl, w4.maxW, w4.maxSlots);
                 w4.maxSlots1 = w4.maxSlots;
@@ -2144,8 +2225,48 @@ static void launch_walkg2_t(Instance& in, const WalkGArgs& a, int W, int nslots,
     MBAMD_LAUNCH_BARRIER(kern, walkg_grid(in.Ppad / MBAMD_WG_TW, in.K * a.lists), block, wg_lds_bytes(W, nslots, in.S, in.wgPair), in.stream, a);
 }
 
+template <int SC_>
+static void launch_pathg_t(Instance& in, const WalkGArgs& a, const std::vector<Walk4Entry>& prog)
+{
+    WalkGArgsInline ai;
+    ai.a = a;
+    ai.a.prog = nullptr;
+    std::memcpy(ai.inl, prog.data(), prog.size() * sizeof(Walk4Entry));
+    auto kern = k_pathg<SC_, WalkGArgsInline>;
+    MBAMD_LAUNCH_BARRIER(kern, walkg_grid(in.Ppad / MBAMD_WG_TW, in.K * a.lists), 128, pathg_lds_bytes(in.S), in.stream, ai);
+}
+
 int Instance::runWalkG(const Plan& plan)
 {
+    if (plan.pathG) {
+        const Plan::Segment& sg = plan.segments.front();
+        WalkGArgs a;
+        std::memset(&a, 0, sizeof a);
+        a.entries = sg.entries;
+        a.partials = arenaPartials;
+        a.tileBytes = wgTileBytes;
+        a.tips = arenaTipStates;
+        a.tipTileBytes = wgTipTileBytes;
+        a.exps = arenaExp;
+        a.estride = estride;
+        a.matrices = matrices;
+        a.tabOff = (unsigned) (wgTabFloats * 4);
+        a.tabBytes = (unsigned) (wg_table_floats(S) * 4);
+        for (int q = 0; q < MBAMD_WG_MAXLISTS; ++q) a.cum[q] = wgCum[q];
+        a.cumFresh = wgFresh;
+        a.K = K; a.Ppad = Ppad; a.ntiles = Ppad / MBAMD_WG_TW; a.S = S; a.SP = SP;
+        a.lists = plan.lists;
+        switch (S) {
+            case 20: launch_pathg_t<20>(*this, a, plan.inlineProg); break;
+            case 60: launch_pathg_t<60>(*this, a, plan.inlineProg); break;
+            case 61: launch_pathg_t<61>(*this, a, plan.inlineProg); break;
+            case 62: launch_pathg_t<62>(*this, a, plan.inlineProg); break;
+            default: launch_pathg_t<63>(*this, a, plan.inlineProg); break;
+        }
+        HIP_TRY(hipGetLastError());
+        pendingLaunches += 1;
+        return BEAGLE_SUCCESS;
+    }
     for (const Plan::Segment& sg : plan.segments) {
         if (plan.lists > 1 && &sg != &plan.segments.front()) break;     // (independent lists: one launch covers all segments)
         WalkGArgs a;

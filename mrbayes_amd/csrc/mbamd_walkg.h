@@ -170,4 +170,5 @@ __device__ __forceinline__ const Walk4Entry* wg_program(const WalkGArgs& a) { re
 #include <mbamd_dev_walkg_kernel.h>   // the kernels' device primitives (csrc/device/: MFMA, lane swap, waits; tests/hostemu/: the same on fibers)
 #include "mbamd_walkg_kernel.h"       // k_walkg
 #include "mbamd_walkg2_kernel.h"      // k_walkg2: a whole entry's operands in flight; the row-split pair (round 5)
+#include "mbamd_pathg_kernel.h"       // k_pathg: a move's root-ward path on two waves (sibling factors ahead of the chain)
 #endif

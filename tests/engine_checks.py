@@ -643,6 +643,56 @@ def check_partial_update_and_reject(lib, oracle, div, scaling=lk.MB_BEAGLE_SCALE
         bd.finalize()
 
 
+def check_general_state_path_kernel(lib, oracle, golden_dir, monkeypatch, cases=("avian_wag_g4", "synth_codon_m3")):
+    """k_pathg (a move's root-ward path at 20 / 61 states on two waves: the sibling factors formed ahead of the chain) against
+    k_walkg walking the same lists (MBAMD_NO_PATHG=1): a sequence of branch moves with accepts and rejects under both scaling
+    schemes -- log-likelihoods and per-site values bit for bit, and the oracle's value for every state."""
+    import copy
+    for case in cases:
+        for scaling in (lk.MB_BEAGLE_SCALE_DYNAMIC, lk.MB_BEAGLE_SCALE_ALWAYS):
+            runs = []
+            for no_path in (False, True):
+                if no_path:
+                    monkeypatch.setenv("MBAMD_NO_PATHG", "1")
+                else:
+                    monkeypatch.delenv("MBAMD_NO_PATHG", raising=False)
+                div = division_from_golden(golden_dir, case)
+                t = div.tree
+                bd = lk.BeagleDivision(div, lib, scaling=scaling)
+                try:
+                    seq = [bd.LogLike(0)]
+                    bd.AcceptMove(0)
+                    rng = np.random.default_rng(17)
+                    nodes = [i for i in range(len(t.anc)) if t.anc[i] != -1 and i != t.root]
+                    for rep in range(7):
+                        b = int(rng.choice(nodes))
+                        old = t.length[b]
+                        t.length[b] = old * float(np.exp(0.8 * (rng.random() - 0.5)))
+                        bd.TouchBranch(0, b)
+                        lnl = bd.LogLike(0)
+                        site = bd.inst.get_site_log_likelihoods()
+                        if not no_path and rep < 3:
+                            want = oracle.tree_loglike(div, use_shortcuts=False)
+                            assert abs(lnl - want) / abs(want) < REL_FP64, (case, scaling, rep, lnl, want)
+                        seq.append(lnl)
+                        seq.append(site.copy())
+                        if rep % 3 == 1:                    # reject: the branch back, the flips undone
+                            t.length[b] = old
+                            bd.ResetFlips(0)
+                            seq.append(bd.LogLike(0))
+                        bd.AcceptMove(0)
+                finally:
+                    bd.finalize()
+                runs.append(seq)
+            monkeypatch.delenv("MBAMD_NO_PATHG", raising=False)
+            assert len(runs[0]) == len(runs[1])
+            for x, y in zip(runs[0], runs[1]):
+                if isinstance(x, np.ndarray):
+                    assert np.array_equal(x, y), (case, scaling)
+                else:
+                    assert x == y, (case, scaling, x, y)
+
+
 def _depth(t, i):
     d = 0
     while t.anc[i] != -1 and t.anc[i] != t.root:

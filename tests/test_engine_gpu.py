@@ -630,6 +630,11 @@ def test_short_walk_programs_travel_in_the_kernel_arguments(gpu, monkeypatch, go
     assert path_values() == base
 
 
+def test_general_state_path_kernel(gpu, oracle, golden_dir, monkeypatch):
+    """A move's root-ward path at 20 / 61 states: k_pathg == k_walkg bit for bit, both == the oracle."""
+    ec.check_general_state_path_kernel(gpu, oracle, golden_dir, monkeypatch, cases=("avian_wag_g4", "synth_aa_wag", "replicase_m3", "synth_codon_m3"))
+
+
 def test_pair_walk(gpu, oracle, golden_dir, monkeypatch):
     """The opt-in general-state walk k_walkg2 (a whole entry's operands in flight, the row-split pair of waves at 60-63 states) is
     parity-green: it is not the product default because it measured no faster than k_walkg (profiles/r05_walkg_pair.txt)."""
