@@ -617,11 +617,24 @@ def main():
                          "the JSON line is marked invalid")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # Started plainly (`python bench.py --gpus N`) instead of under a launcher: without this the script would see a world of
+        # one, measure ONE GPU and print n_gpus = 1 with exit code 0.  It launches itself -- one rank per GPU, same arguments --
+        # and passes on the children's output and exit status.
+        import socket
+        import subprocess
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+               "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        raise SystemExit(subprocess.call(cmd))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world != args.gpus and world > 1:
-        raise SystemExit("WORLD_SIZE=%d but --gpus %d" % (world, args.gpus))
+    if world != args.gpus:
+        # (either direction: a launcher with more ranks than --gpus, or -- the case nobody would notice -- fewer)
+        raise SystemExit("WORLD_SIZE=%d but --gpus %d: refusing to measure another job than the one asked for" % (world, args.gpus))
 
     import torch
     emulate = args.emulate

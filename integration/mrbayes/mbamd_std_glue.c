@@ -42,7 +42,7 @@ extern int  *chainId;               /* (src/mcmc.c; the reference's likelihood.c
 #define LIKE_EPSILON 1.0e-300       /* src/likelihood.c:44 */
 #define MBAMD_STD_MAXCLASSES (3 * MAX_STD_STATES)
 
-#define MBAMD_STD_MAXBETA 32
+#define MBAMD_STD_MAXBETA 8     /* = the engine's MBAMD_MAX_SUBSETS (csrc/mbamd_kernels.h): one integration mixes at most eight buffer sets */
 
 typedef struct
     {
@@ -318,6 +318,13 @@ int MbamdStdServes (ModelInfo *m)
         if (m->printAncStates == YES)
             {
             MrBayesPrint ("%s   Division %d (standard data) stays on the host kernels: ancestral states under unequal state frequencies are read from host arrays\n", spacer, d+1);
+            return (NO);
+            }
+        if (m->numBetaCats > MBAMD_STD_MAXBETA)
+            {
+            /* (`lset nbetacat` goes up to MAX_RATE_CATS - 1; the engine's integration mixes at most eight buffer sets: saying YES here
+               would end in Die() at the first evaluation instead of on the host kernels) */
+            MrBayesPrint ("%s   Division %d (standard data) stays on the host kernels: %d beta categories, the engine mixes at most %d\n", spacer, d+1, m->numBetaCats, MBAMD_STD_MAXBETA);
             return (NO);
             }
         }

@@ -693,6 +693,68 @@ def check_general_state_path_kernel(lib, oracle, golden_dir, monkeypatch, cases=
                     assert x == y, (case, scaling, x, y)
 
 
+def check_path_kernels_at_bench_shape(lib, golden_dir, monkeypatch, case, switch):
+    """The partial-update kernels (k_path4: MBAMD_NO_PATH4; k_pathg: MBAMD_NO_PATHG) at the BASELINE shape `case` -- hundreds of
+    tiles x categories over every XCD, paths of 20-30 operations (k_path4's 24-operation chunk boundary, k_pathg's four-deep factor
+    ring wrapping several times).  Three engines step through the same branch moves (deep tips, branches next to the root, random
+    ones; accepts and rejects mixed): the path kernel, the whole-tree walk kernel on the same lists (`switch` set when the instance is
+    made), and the double-precision engine (itself pinned to the reference's fp64 build).  After every move: log-likelihood and
+    per-site values of the first two bit for bit, and the log-likelihood within REL_FP64 of the fp64 engine's.  Both scaling schemes."""
+    div = division_from_golden(golden_dir, case)
+    t = div.tree
+    base_len = list(t.length)
+    movable = [i for i in range(len(t.anc)) if t.anc[i] != -1 and i != t.root]
+    by_depth = sorted(movable, key=lambda i: _depth(t, i))
+    rng = np.random.default_rng(23)
+    moves = [by_depth[-1], by_depth[0], by_depth[-2], by_depth[1]] + [int(x) for x in rng.choice(movable, 4, replace=False)]
+    assert _depth(t, moves[0]) >= 12 and _depth(t, moves[1]) <= 1, (case, _depth(t, moves[0]), _depth(t, moves[1]))
+    with open(os.path.join(golden_dir, case + ".json")) as fh:
+        gold = json.load(fh)["lnL"]
+    for scaling in (lk.MB_BEAGLE_SCALE_DYNAMIC, lk.MB_BEAGLE_SCALE_ALWAYS):
+        t.length[:] = base_len
+        monkeypatch.delenv(switch, raising=False)
+        path = lk.BeagleDivision(div, lib, scaling=scaling)
+        monkeypatch.setenv(switch, "1")
+        walk = lk.BeagleDivision(div, lib, scaling=scaling)
+        monkeypatch.delenv(switch, raising=False)
+        f64 = lk.BeagleDivision(div, lib, scaling=scaling, double_precision=True)
+        engines = (path, walk, f64)
+        try:
+            start = [bd.LogLike(0) for bd in engines]
+            for bd in engines:
+                bd.AcceptMove(0)
+            assert start[0] == start[1] and abs(start[0] - gold["fp64"]) <= REL_FP64 * abs(gold["fp64"])
+            assert abs(start[2] - gold["fp64"]) <= 1e-9 * abs(gold["fp64"]), (case, start[2], gold["fp64"])
+            last = start[0]
+            for rep, b in enumerate(moves):
+                old = t.length[b]
+                t.length[b] = old * (2.3 if rep % 2 == 0 else 0.45)
+                vals = []
+                for bd in engines:
+                    bd.TouchBranch(0, b)
+                    vals.append(bd.LogLike(0))
+                sites = [bd.inst.get_site_log_likelihoods() for bd in engines[:2]]
+                assert vals[0] == vals[1], (case, scaling, rep, b, vals)
+                assert np.array_equal(sites[0], sites[1]), (case, scaling, rep, b)
+                assert abs(vals[0] - vals[2]) <= REL_FP64 * abs(vals[2]), (case, scaling, rep, b, vals)
+                assert vals[0] != last
+                if rep in (1, 4, 6):                        # reject: the branch back, the flips undone, the old value again
+                    t.length[b] = old
+                    back = []
+                    for bd in engines:
+                        bd.ResetFlips(0)
+                        back.append(bd.LogLike(0))
+                    assert back[0] == last and back[1] == last, (case, scaling, rep, back, last)
+                else:
+                    last = vals[0]
+                for bd in engines:
+                    bd.AcceptMove(0)
+        finally:
+            for bd in engines:
+                bd.finalize()
+            t.length[:] = base_len
+
+
 def _depth(t, i):
     d = 0
     while t.anc[i] != -1 and t.anc[i] != t.root:

@@ -51,6 +51,25 @@ def test_two_ranks():
         assert set(m["devices_of_rank"]) == {"0", "1"} and m["distinct_devices"] >= 1, m      # every rank's engine reported its device
 
 
+def test_plain_command_launches_its_own_ranks():
+    """`python bench.py --gpus 2` with NO launcher and a clean environment (what a driver that forgets torch.distributed.run would
+    type): the script starts its own ranks -- the line says n_gpus == 2 -- instead of measuring one device and reporting success."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT", "LOCAL_WORLD_SIZE", "GROUP_RANK")}
+    res = subprocess.run([sys.executable, "bench.py", "--gpus", "2", "--steps", "2", "--warmup", "1", "--emulate", "--no-mpi"], cwd=ROOT,
+                         env=env, capture_output=True, text=True, timeout=900)
+    assert res.returncode == 0, (res.stdout + res.stderr)[-3000:]
+    d = _json_line(res.stdout)
+    assert d["n_gpus"] == 2 and d["config"]["chains"] == 2 and d["ranks_devices"] == ["emu:rank0", "emu:rank1"]
+
+
+def test_world_size_must_match_gpus():
+    """A launcher whose world differs from --gpus (here: one rank for --gpus 2) is refused with a non-zero exit, not measured."""
+    env = dict(os.environ, RANK="0", LOCAL_RANK="0", WORLD_SIZE="1", MASTER_ADDR="127.0.0.1", MASTER_PORT="29683")
+    res = subprocess.run([sys.executable, "bench.py", "--gpus", "2", "--steps", "2", "--warmup", "1", "--emulate"], cwd=ROOT,
+                         env=env, capture_output=True, text=True, timeout=300)
+    assert res.returncode != 0 and "WORLD_SIZE=1 but --gpus 2" in res.stderr and not [l for l in res.stdout.splitlines() if l.startswith("{")]
+
+
 def test_two_ranks_sharded():
     """--shard: one chain, site patterns over the N devices inside one instance (all children on the emulated device here)."""
     env = dict(os.environ, MASTER_ADDR="127.0.0.1")

@@ -635,6 +635,14 @@ def test_general_state_path_kernel(gpu, oracle, golden_dir, monkeypatch):
     ec.check_general_state_path_kernel(gpu, oracle, golden_dir, monkeypatch, cases=("avian_wag_g4", "synth_aa_wag", "replicase_m3", "synth_codon_m3"))
 
 
+@pytest.mark.parametrize("case,switch", [("bench_c2", "MBAMD_NO_PATH4"), ("bench_c3", "MBAMD_NO_PATHG"), ("bench_c5", "MBAMD_NO_PATHG")])
+def test_path_kernels_at_baseline_shapes(gpu, golden_dir, monkeypatch, case, switch):
+    """k_path4 / k_pathg pinned where they were built to run: DNA 500 x 20 000, protein 200 x 10 000, codon M3 100 x 5 000 --
+    bit-equal to the whole-tree walk kernels on the same lists and within REL_FP64 of the fp64 engine after every move
+    (reference: the partial updates of src/mbbeagle.c:783-880)."""
+    ec.check_path_kernels_at_bench_shape(gpu, golden_dir, monkeypatch, case, switch)
+
+
 def test_pair_walk(gpu, oracle, golden_dir, monkeypatch):
     """The opt-in general-state walk k_walkg2 (a whole entry's operands in flight, the row-split pair of waves at 60-63 states) is
     parity-green: it is not the product default because it measured no faster than k_walkg (profiles/r05_walkg_pair.txt)."""

@@ -311,6 +311,28 @@ def test_unequal_frequencies_of_multistate_characters_stay_on_the_host():
     assert "stays on the host kernels" in out and "Analysis completed" in out, out[-1500:]
 
 
+def _check_beta_category_limit(binary, marker):
+    """`lset nbetacat` beyond what one integration of the engine mixes (eight buffer sets): the division stays on the reference's
+    kernels with a printed reason (advisor, round 5: it used to be accepted and ended in Die() at the first evaluation); eight
+    categories -- the limit itself -- are served.  Either way the scalar build's number."""
+    _need(binary, os.path.join(REF, "mb_scalar"))
+    kw = dict(std_cases.SYNTHETIC["binary_symdir_exponential"])
+    for nbeta, served in ((8, True), (10, False)):
+        kw["nbetacat"] = nbeta
+        want, _ = _lnl(os.path.join(REF, "mb_scalar"), std_cases.synthetic_nexus(beagle=None, **kw))
+        got, out = _lnl(binary, std_cases.synthetic_nexus(beagle="always", **kw))
+        if served:
+            _served(out, marker)
+        else:
+            assert "stays on the host kernels: 10 beta categories" in out and "(standard data):" not in out, out[-1500:]
+        assert abs(got - want) <= 1e-5 * abs(want), (nbeta, got, want)
+
+
+def test_beta_category_limit_on_emulated_engine():
+    _build_emu()
+    _check_beta_category_limit(os.path.join(REF, "mb_emu_std"), "HOST EMULATION")
+
+
 def test_patch_site_is_pinned():
     """The edits patch_std.py makes (one in likelihood.c, one in mcmc.c) must each apply to the reference exactly once (an upstream change fails here, not at run time)."""
     src = "/root/reference/src/likelihood.c"
@@ -339,6 +361,11 @@ def test_patch_site_is_pinned():
 @pytest.mark.parametrize("case", sorted(std_cases.SYNTHETIC))
 def test_standard_data_on_mi355x(case):
     _check_synthetic(case, os.path.join(REF, "mb_amd_std"), "gfx950", scalings=("always", "dynamic"))
+
+
+@pytest.mark.gpu
+def test_beta_category_limit_on_mi355x():
+    _check_beta_category_limit(os.path.join(REF, "mb_amd_std"), "gfx950")
 
 
 @pytest.mark.gpu

@@ -8,6 +8,8 @@
 #include <vector>
 #include <algorithm>
 typedef float v16 __attribute__((ext_vector_type(16)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned u4 __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ void work(int role, int n, float* sink, float* lds)
 {
     const unsigned lane = threadIdx.x & 63;
@@ -67,6 +69,30 @@ __device__ __forceinline__ void work(int role, int n, float* sink, float* lds)
             }
         }
         if (acc[0] + x0 + x1 + x2 + x3 == 123.456f) sink[lane] = acc[3];
+    } else if (role == 9) {
+        // round 6: the same question for the 16-bit matrix core -- 32 v_mfma_f32_32x32x16_bf16 (32 cycles each) = the 1024 cycles of role 1
+        v16 acc = {};
+        const bf16x8 a = __builtin_bit_cast(bf16x8, u4{0x3c003c00u + lane, 0x3c003c10u, 0x3c003c20u, 0x3c003c30u}), b = __builtin_bit_cast(bf16x8, u4{0x3f803f80u, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u});
+        for (int i = 0; i < n; ++i) {
+#pragma unroll
+            for (int u = 0; u < 32; ++u) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc, 0, 0, 0);
+        }
+        if (acc[0] == 123.456f) sink[lane] = acc[3];
+    } else if (role == 10 || role == 11) {
+        // 32 x (one bf16 MFMA + 4 independent v_fma_f32 behind it): do the vector instructions run in the MFMA's shadow?
+        v16 acc = {};
+        const bf16x8 a = __builtin_bit_cast(bf16x8, u4{0x3c003c00u + lane, 0x3c003c10u, 0x3c003c20u, 0x3c003c30u}), b = __builtin_bit_cast(bf16x8, u4{0x3f803f80u, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u});
+        float x0 = lane * 1e-3f, x1 = x0 + 1.0f, x2 = x0 + 2.0f, x3 = x0 + 3.0f;
+        for (int i = 0; i < n; ++i) {
+#pragma unroll
+            for (int u = 0; u < 32; ++u) {
+                if (role == 10) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc, 0, 0, 0);
+                x0 = __builtin_fmaf(x0, 1.000001f, 1e-7f); x1 = __builtin_fmaf(x1, 1.000001f, 1e-7f);
+                x2 = __builtin_fmaf(x2, 1.000001f, 1e-7f); x3 = __builtin_fmaf(x3, 1.000001f, 1e-7f);
+                asm volatile("" : "+v"(x0), "+v"(x1), "+v"(x2), "+v"(x3));
+            }
+        }
+        if (acc[0] + x0 + x1 + x2 + x3 == 123.456f) sink[lane] = acc[3];
     } else if (role == 6) {
         float x = lane * 1e-3f;
         unsigned s = __builtin_amdgcn_readfirstlane(n);
@@ -105,8 +131,10 @@ int main()
     float* sink; long long* out;
     hipMalloc(&sink, 4096); hipMalloc(&out, blocks * 8 * 2 * sizeof(long long));
     std::vector<long long> h(blocks * 8 * 2);
-    const char* names[] = {"idle", "mfma dependent chain", "mfma two chains", "valu chain", "salu loop", "lds reads", "valu+salu", "mfma + 8 valu between", "the 8 valu alone"};
-    const int cases[][4] = {{1, 0, 0, 0}, {8, 0, 0, 0}, {7, 0, 0, 0}, {7, 7, 0, 0}, {7, 8, 0, 0}};
+    const char* names[] = {"idle", "mfma dependent chain", "mfma two chains", "valu chain", "salu loop", "lds reads", "valu+salu", "mfma + 8 valu between", "the 8 valu alone", "bf16 mfma chain", "bf16 mfma + 4 valu between", "the 4 valu alone"};
+    const int cases[][4] = {{1, 0, 0, 0}, {3, 0, 0, 0}, {6, 0, 0, 0}, {1, 3, 0, 0},                       // round 5's baseline rows again (same box)
+                            {9, 0, 0, 0}, {9, 3, 0, 0}, {9, 6, 0, 0}, {9, 5, 0, 0}, {9, 9, 0, 0}, {9, 1, 0, 0},     // round 6: the 16-bit matrix core
+                            {11, 0, 0, 0}, {10, 0, 0, 0}, {10, 10, 0, 0}, {10, 11, 0, 0}};
     printf("start\n"); fflush(stdout);
     for (auto& c : cases) {
         for (int rep = 0; rep < 2; ++rep) {
