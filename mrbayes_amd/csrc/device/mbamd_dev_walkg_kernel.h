@@ -1,5 +1,5 @@
 // mbamd_dev_walkg_kernel.h (gfx950) -- the device primitives of the 20/61-state tree-walk kernels (csrc/mbamd_walkg_kernel.h,
-// csrc/mbamd_walkg2_kernel.h): the matrix-core instruction, the lane swap, waits, barriers, where an inline program sits.  The
+// csrc/mbamd_pathg_kernel.h): the matrix-core instruction, the lane swap, waits, barriers, where an inline program sits.  The
 // TEST-ONLY host emulation has a header of the same name in front on its include path (tests/hostemu/) that implements the same
 // primitives on fibers -- an MFMA there is a wave-wide exchange and 32 multiply-adds per lane --, so the kernels themselves, with
 // their tile loops, table layouts, register sets and LDS slots, are the code the CPU CI runs.
@@ -14,6 +14,25 @@ typedef float mbd_acc16 __attribute__((ext_vector_type(16)));
 // D (32 x 32) += A (32 x 2) B (2 x 32): lane l gives A[l & 31][l >> 5] and B[l >> 5][l & 31] and holds column l & 31 of D, register r =
 // row (r & 3) + 8 (r >> 2) + 4 (l >> 5)
 __device__ __forceinline__ mbd_acc16 mbd_mfma_f32_32x32x2(float a, float b, mbd_acc16 c) { return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0); }
+// D (32 x 32) += A (32 x 16) B (16 x 32) with bf16 operands, exact products, fp32 accumulation (v_mfma_f32_32x32x16_bf16, 32 cycles on
+// a pipe of its own: the vector ALU keeps issuing beside it, profiles/r06_bf16x3.txt).  Lane l = 32 h + m gives the eight bf16
+// A[m][8 h + j] and B[8 h + j][m], j = 0..7 (element j in bits 16 (j & 1) of dword j >> 1); D as above.
+typedef float mbd_f4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ mbd_acc16 mbd_mfma_bf16_32x32x16(mbd_f4 a, mbd_f4 b, mbd_acc16 c)
+{
+    typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+}
+// the bf16 nearest to lo (bits 0..15) and to hi (bits 16..31), ties to even
+__device__ __forceinline__ unsigned mbd_cvt_pk_bf16(float lo, float hi)
+{
+    // (v_cvt_pk_bf16_f32 through the compiler, not inline assembly: it pads the VALU -> MFMA-operand wait states only for
+    //  instructions it knows; the first version, an asm statement, fed stale pieces to the matrix core now and then)
+    typedef float f32x2 __attribute__((ext_vector_type(2)));
+    typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+    const f32x2 v = {lo, hi};
+    return __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2));
+}
 // max(v, the value lane l ^ 32 holds) (v_permlane32_swap: in the VALU, no LDS round trip)
 __device__ __forceinline__ float mbd_max_lane_xor32(float v)
 {

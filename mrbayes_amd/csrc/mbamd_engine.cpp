@@ -123,25 +123,6 @@ static inline bool wg_compiled(int S) { return (S >= 2 && S <= 10 && S != 4) || 
         default: FN<63, 4, 2, MBAMD_WG_DEPTH61>(__VA_ARGS__); break;    \
     }
 
-// k_walkg2 (a whole entry's operands in flight; the row-split pair): FN<SC, WMAX>
-#define MBAMD_WG2_DISPATCH(S, FN, ...)                                  \
-    switch (S) {                                                        \
-        case 2: FN<2, 8, false>(__VA_ARGS__); break;                    \
-        case 8: FN<8, 8, false>(__VA_ARGS__); break;                    \
-        case 16: FN<16, 8, false>(__VA_ARGS__); break;                  \
-        case 20: FN<20, 8, false>(__VA_ARGS__); break;                  \
-        case 60: FN<60, 4, true>(__VA_ARGS__); break;                   \
-        case 61: FN<61, 4, true>(__VA_ARGS__); break;                   \
-        case 62: FN<62, 4, true>(__VA_ARGS__); break;                   \
-        default: FN<63, 4, true>(__VA_ARGS__); break;                   \
-    }
-template <int SC_, int WMAX_, bool PAIR_>
-static void raise_walkg2_lds(int maxLds)
-{
-    if (hipFuncSetAttribute((const void*) k_walkg2<SC_, WMAX_, PAIR_>, hipFuncAttributeMaxDynamicSharedMemorySize, maxLds) != hipSuccess ||
-        hipFuncSetAttribute((const void*) k_walkg2<SC_, WMAX_, PAIR_, WalkGArgsInline>, hipFuncAttributeMaxDynamicSharedMemorySize, maxLds) != hipSuccess)
-        (void) hipGetLastError();
-}
 template <int SC_, int WMAX_, int CH_, int DEPTH_>
 static void raise_walkg_lds(int maxLds)
 {
@@ -253,8 +234,6 @@ struct Instance {
     unsigned long wgTileBytes = 0;               // partials arena: bytes between 32-pattern tiles
     unsigned wgTipTileBytes = 0;
     size_t wgTabFloats = 0;                      // first float of the tree-walk tables inside a matrix buffer
-    bool wg2 = false;                            // MBAMD_WALKG_PAIR=1: k_walkg2 (a whole entry's operands in flight) where it is instantiated ...
-    bool wgPair = false;                         // ... and beyond 48 states the row split: a subtree bin is a pair of waves, split table layout
     bool hasPending() const { return !pending.empty() || !wgListCum.empty(); }
     int updatePartialsG(const BeagleOperation* ops, int n, int cumIdx);
     int flushWalkG();
@@ -572,9 +551,6 @@ int Instance::create(int tipCount_, int partialsBufferCount, int compactBufferCo
              (size_t) (nBuffers + 1) * K * tb < ((size_t) 1 << 32) && (size_t) nMatrices * mf * 4 < ((size_t) 1 << 32) &&
              (size_t) (nScale + 1) * K * 64 < ((size_t) 1 << 32) && (size_t) nBuffers * MBAMD_WG_TW < ((size_t) 1 << 32);
     }
-    // k_walkg2 / the row split (round 5): parity-green and no faster than k_walkg (profiles/r05_walkg_pair.txt); opt-in
-    wg2 = wg && wg2_states(S) && std::getenv("MBAMD_WALKG_PAIR") && std::atoi(std::getenv("MBAMD_WALKG_PAIR")) != 0;
-    wgPair = wg2 && wg_split_states(S);
     if (s4) SP = 4;
     else if (S <= 4) SP = 4;
     else if (S <= 8) SP = 8;
@@ -672,7 +648,7 @@ int Instance::create(int tipCount_, int partialsBufferCount, int compactBufferCo
     HIP_TRY(hipMemsetAsync(matrices, 0, std::max<size_t>(1, (size_t) nMatrices * matrixFloats) * sizeof(float), stream));
     if (wg && nMatrices > 0) {                   // the constant "missing data" column of every gather table
         const int total = nMatrices * K * S;
-        MBAMD_LAUNCH(k_wg_init_tables, (unsigned) ((total + 255) / 256), 256, 0, stream, matrices, matrixFloats, wgTabFloats, S, K, total, wgPair ? 1 : 0);
+        MBAMD_LAUNCH(k_wg_init_tables, (unsigned) ((total + 255) / 256), 256, 0, stream, matrices, matrixFloats, wgTabFloats, S, K, total);
         HIP_TRY(hipGetLastError());
     }
     HIP_TRY(hipMalloc(&d_eigen, std::max<size_t>(1, (size_t) nEigen * eigenDoubles) * sizeof(double)));
@@ -760,18 +736,16 @@ int Instance::configureWalk()
     if (wg) {
         // one wave = (32-pattern tile, category); registers bound the residency: 20 states 4 waves per SIMD, 61 states 2
         const unsigned slotBytes = wg_block_bytes(S);
-        if (wg2) { MBAMD_WG2_DISPATCH(S, raise_walkg2_lds, maxLds); }
-        else { MBAMD_WG_DISPATCH(S, raise_walkg_lds, maxLds); }
+        MBAMD_WG_DISPATCH(S, raise_walkg_lds, maxLds);
         wgGeometry(1, w4.maxW, w4.maxSlots);
         w4.maxSlots1 = w4.maxSlots;
         if (!std::getenv("MBAMD_WALK_WAVES") && !std::getenv("MBAMD_MAX_LDS_SLOTS")) {   // a single-wave program may use the LDS of the whole workgroup
             const long wgsG = (long) (Ppad / MBAMD_WG_TW) * K;
             const int perCUG = (int) std::max(1L, (wgsG + numCU - 1) / numCU);
-            w4.maxSlots1 = std::max(w4.maxSlots, std::min(24, (int) (((160 * 1024) / std::min(perCUG, 32) - 64 - (int) wg_stage_bytes(wgPair)) / (int) slotBytes)));
+            w4.maxSlots1 = std::max(w4.maxSlots, std::min(24, (int) (((160 * 1024) / std::min(perCUG, 32) - 64 - MBAMD_WG_STAGE) / (int) slotBytes) - 1));
         }
         w4.memSlots = false;
         w4.leadNops = MBAMD_WG_LEAD; w4.unroll = 3; w4.tailNops = MBAMD_WG_TAIL;
-        if (wg2) { w4.leadNops = 0; w4.unroll = 2; w4.tailNops = MBAMD_WG2_TAIL; }      // k_walkg2: the loop handles two entries, the prologue fetches entries 0 and 1
         w4.prefetchDistance = 0;
         if (const char* e = std::getenv("MBAMD_WALK_SMALL_PHASE")) w4.smallPhase = std::max(1, std::atoi(e));
         if (envVerbose) std::fprintf(stderr, "[mbamd] tree walk (%d states): %ld workgroups, up to %d waves x %d slots of %u bytes\n",
@@ -809,21 +783,19 @@ void Instance::wgGeometry(int lists, int& W, int& slots) const
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0) numCU = prop.multiProcessorCount;
     // registers bound the residency: 4 (20 states) / 2 (61 states) waves per SIMD
-    // (row split: a bin is a pair of waves sharing its slots; two bins = the four waves of a workgroup, one per SIMD, and two
-    //  such workgroups per CU put two working waves on every SIMD)
-    const int maxW = wgPair ? 2 : (S > 32 ? 4 : 8), wavesPerCU = wgPair ? 4 : (S > 32 ? 6 : 12);
+    const int maxW = S > 32 ? 4 : 8, wavesPerCU = S > 32 ? 6 : 12;
     const int slotBytes = (int) wg_block_bytes(S);
     const long wgs = (long) (Ppad / MBAMD_WG_TW) * K * lists;
     const int perCU = (int) std::max(1L, (wgs + numCU - 1) / numCU);
     const int ldsPerWG = (160 * 1024) / std::min(perCU, 32) - 64;
-    auto slotsFor = [&](int w) { return (ldsPerWG / w - (int) wg_stage_bytes(wgPair)) / slotBytes; };
+    auto slotsFor = [&](int w) { return (ldsPerWG / w - MBAMD_WG_STAGE) / slotBytes - 1; };      // (- 1: the staging slot)
     long want = std::max(1L, std::min((long) maxW, ((long) wavesPerCU * numCU + wgs / 2) / wgs));
     W = 1;
     while (W * 2 <= want) W *= 2;
     while (W > 1 && slotsFor(W) < 4) W /= 2;
     if (const char* e = std::getenv("MBAMD_WALK_WAVES")) W = std::max(1, std::min(maxW, std::atoi(e)));
     slots = std::max(3, std::min(24, slotsFor(W)));
-    if (const char* e = std::getenv("MBAMD_MAX_LDS_SLOTS")) slots = std::max(1, std::min((160 * 1024 / W - (int) wg_stage_bytes(wgPair)) / slotBytes, std::atoi(e)));
+    if (const char* e = std::getenv("MBAMD_MAX_LDS_SLOTS")) slots = std::max(1, std::min((160 * 1024 / W - MBAMD_WG_STAGE) / slotBytes - 1, std::atoi(e)));
 }
 
 // 4-state path: one tip's state masks (bit i = state i compatible) -> four 64-bit bitplanes per pattern block
@@ -1067,7 +1039,7 @@ int Instance::flushMatrices()
     if (S > 8 && S <= 64) {                       // fp64 matrix cores, one wave per 16 rows
         const unsigned grid = (unsigned) (count * K);
         const int packedT = mfma ? T : 0;
-        const size_t wgTab = wg ? (wgTabFloats | (wgPair ? MBAMD_WG_TAB_SPLIT : (size_t) 0)) : 0;
+        const size_t wgTab = wg ? wgTabFloats : 0;
         switch ((S + 15) / 16) {
             case 1: MBAMD_LAUNCH_BARRIER(k_transition_matrices_mfma<1>, grid, 64, 0, stream, djobs, rates, S, SP, K, packedT, wgTab); break;
             case 2: MBAMD_LAUNCH_BARRIER(k_transition_matrices_mfma<2>, grid, 128, 0, stream, djobs, rates, S, SP, K, packedT, wgTab); break;
@@ -1087,7 +1059,7 @@ int Instance::flushMatrices()
         evs = d_ev;
     }
     MBAMD_LAUNCH_BARRIER(k_transition_matrices_ev, (unsigned) (count * K), threads, 0, stream, djobs, evs, rates, S, SP, K, 1,
-                         mfma ? T : 0, wg ? (wgTabFloats | (wgPair ? MBAMD_WG_TAB_SPLIT : (size_t) 0)) : (size_t) 0);
+                         mfma ? T : 0, wg ? wgTabFloats : (size_t) 0);
     HIP_TRY(hipGetLastError());
     return BEAGLE_SUCCESS;
 }
@@ -1103,11 +1075,11 @@ int Instance::setMatrix(int idx, const double* in)
                 h[(size_t) k * SP * SP + (size_t) j * SP + i] = v;
                 if (mfma)
                     h[(size_t) K * SP * SP + ((size_t) (k * NT + i / 32) * T + j / 2) * 64 + (i % 32) + 32 * (j % 2)] = v;
-                if (wg) wg_table_put(h.data() + wgTabFloats + (size_t) k * wg_table_floats(S), S, i, j, v, wgPair);
+                if (wg) wg_table_put(h.data() + wgTabFloats + (size_t) k * wg_table_floats(S), S, i, j, v);
             }
     if (wg)
         for (int k = 0; k < K; ++k)
-            for (int i = 0; i < S; ++i) wg_table_put_missing(h.data() + wgTabFloats + (size_t) k * wg_table_floats(S), S, i, wgPair);
+            for (int i = 0; i < S; ++i) wg_table_put_missing(h.data() + wgTabFloats + (size_t) k * wg_table_floats(S), S, i);
     return upload(matrixPtr(idx), h.data(), matrixFloats * sizeof(float));
 }
 
@@ -1628,11 +1600,12 @@ int Instance::buildWalk(Plan& plan, const BeagleOperation* ops, int n, const int
         const uint32_t pbuf = wg ? (uint32_t) K * slotb : (uint32_t) ((size_t) (Ppad / 64) * K);
         const uint32_t ebuf = (uint32_t) K * 64u, mbuf = wg ? (uint32_t) (matrixFloats * 4) : (uint32_t) K * 64u;
         int prevKept = -1;                           // (20/61-state walk) slot the previous operation of the same program kept its result in
+        int prevDst[2] = {-1, -1};                   // (20/61-state walk) destination buffers of the two entries before this one, same program
         for (size_t i = 0; i < t.prog.size(); ++i) {
             const Walk4Template::Entry& te = t.prog[i];
             Walk4Entry& e = w4table[sg.first + i];
             std::memset(&e, 0, sizeof e);
-            if (i % (size_t) t.entries == 0) prevKept = -1;
+            if (i % (size_t) t.entries == 0) { prevKept = -1; prevDst[0] = prevDst[1] = -1; }
             uint32_t flags = te.flags, mode = SCALE_NONE, keep = 0;
             e.ewrite = (uint32_t) scratchScale * ebuf;
             e.eread = (uint32_t) scratchScale * ebuf;
@@ -1652,10 +1625,13 @@ int Instance::buildWalk(Plan& plan, const BeagleOperation* ops, int n, const int
                     e.m1 = (uint32_t) op.m1 * mbuf;
                     e.m2 = (uint32_t) op.m2 * mbuf;
                     if (te.dslot != 0xFF) { keep = te.dslot; flags |= MBAMD_W4_KEEP; }
-                    if (te.reread) flags |= MBAMD_WG_DRAIN;
                     if (!op.tip1 && te.c1slot != 0xFF && (int) te.c1slot == prevKept) flags |= MBAMD_WG_PREV1;
                     if (!op.tip2 && te.c2slot != 0xFF && (int) te.c2slot == prevKept) flags |= MBAMD_WG_PREV2;
                     prevKept = te.dslot != 0xFF ? (int) te.dslot : -1;
+                    // k_walkg stores a result one entry late: rows read back from HBM two entries after they were made (the
+                    // scheduler never asks for them sooner) are requested right behind that store
+                    if (((flags & MBAMD_WG_MEM1) && (op.c1 == prevDst[0] || op.c1 == prevDst[1])) ||
+                        ((flags & MBAMD_WG_MEM2) && (op.c2 == prevDst[0] || op.c2 == prevDst[1]))) flags |= MBAMD_WG_TIGHT;
                     mode = op.scaleWrite >= 0 ? SCALE_WRITE : (op.scaleRead >= 0 ? SCALE_READ : SCALE_NONE);
                     if (op.scaleWrite >= 0) e.ewrite = (uint32_t) op.scaleWrite * ebuf;
                     if (op.scaleRead >= 0) e.eread = (uint32_t) op.scaleRead * ebuf;
@@ -1663,6 +1639,8 @@ int Instance::buildWalk(Plan& plan, const BeagleOperation* ops, int n, const int
                 } else {
                     e.ctl = (flags & (MBAMD_W4_NOP | MBAMD_W4_BARRIER)) | MBAMD_W4_NOP;
                 }
+                prevDst[1] = prevDst[0];
+                prevDst[0] = te.op >= 0 ? seg[te.op].dst : -1;
                 continue;
             }
             if (te.pfOp[0] >= 0) {                          // PF entry
@@ -1859,7 +1837,7 @@ bool Instance::buildPath4(Plan& plan, const BeagleOperation* ops, int n)
 static inline bool pathg_compiled(int S) { return S == 20 || (S >= 60 && S <= 63); }
 bool Instance::buildPathG(Plan& plan, const BeagleOperation* ops, int n, const std::vector<int>& starts, int nl)
 {
-    if (noPathG || wg2 || !pathg_compiled(S) || nl < 1 || nl > MBAMD_WG_MAXLISTS || n < nl || n % nl != 0) return false;
+    if (noPathG || !pathg_compiled(S) || nl < 1 || nl > MBAMD_WG_MAXLISTS || n < nl || n % nl != 0) return false;
     const int L = n / nl;
     if (L < 2 || (size_t) n > (size_t) MBAMD_W4_INLINE) return false;      // (a single operation gains nothing; the program travels in the kernel arguments)
     for (int q = 0; q < nl; ++q) if (starts[(size_t) q] != q * L) return false;
@@ -2208,23 +2186,6 @@ static void launch_walkg_t(Instance& in, const WalkGArgs& a, int W, int nslots, 
     MBAMD_LAUNCH_BARRIER(kern, walkg_grid(in.Ppad / MBAMD_WG_TW, in.K * a.lists), 64 * W * (a.spread ? 2 : 1), wg_lds_bytes(W, nslots, in.S), in.stream, a);
 }
 
-template <int SC_, int WMAX_, bool PAIR_>
-static void launch_walkg2_t(Instance& in, const WalkGArgs& a, int W, int nslots, const std::vector<Walk4Entry>* inlineProg)
-{
-    const unsigned block = 64u * (unsigned) W * (unsigned) wg_waves_per_bin(in.wgPair) * (a.spread ? 2u : 1u);
-    if (inlineProg && !inlineProg->empty()) {
-        WalkGArgsInline ai;
-        ai.a = a;
-        ai.a.prog = nullptr;
-        std::memcpy(ai.inl, inlineProg->data(), inlineProg->size() * sizeof(Walk4Entry));
-        auto kern = k_walkg2<SC_, WMAX_, PAIR_, WalkGArgsInline>;
-        MBAMD_LAUNCH_BARRIER(kern, walkg_grid(in.Ppad / MBAMD_WG_TW, in.K * a.lists), block, wg_lds_bytes(W, nslots, in.S, in.wgPair), in.stream, ai);
-        return;
-    }
-    auto kern = k_walkg2<SC_, WMAX_, PAIR_>;
-    MBAMD_LAUNCH_BARRIER(kern, walkg_grid(in.Ppad / MBAMD_WG_TW, in.K * a.lists), block, wg_lds_bytes(W, nslots, in.S, in.wgPair), in.stream, a);
-}
-
 template <int SC_>
 static void launch_pathg_t(Instance& in, const WalkGArgs& a, const std::vector<Walk4Entry>& prog)
 {
@@ -2287,10 +2248,8 @@ int Instance::runWalkG(const Plan& plan)
         a.cumFresh = (&sg == &plan.segments.front()) ? wgFresh : 0;
         a.K = K; a.Ppad = Ppad; a.ntiles = Ppad / MBAMD_WG_TW; a.S = S; a.SP = SP;
         a.lists = plan.lists;
-        a.spread = sg.W * wg_waves_per_bin(wgPair) == 2 ? 1 : 0;     // two-wave workgroups are launched as four (see k_walkg)
-        a.pair = wgPair ? 1 : 0;
-        if (wg2) { MBAMD_WG2_DISPATCH(S, launch_walkg2_t, *this, a, sg.W, sg.nslots, &plan.inlineProg); }
-        else { MBAMD_WG_DISPATCH(S, launch_walkg_t, *this, a, sg.W, sg.nslots, &plan.inlineProg); }
+        a.spread = sg.W == 2 ? 1 : 0;     // two-wave workgroups are launched as four (see k_walkg)
+        MBAMD_WG_DISPATCH(S, launch_walkg_t, *this, a, sg.W, sg.nslots, &plan.inlineProg);
         HIP_TRY(hipGetLastError());
         pendingLaunches += 1;
     }

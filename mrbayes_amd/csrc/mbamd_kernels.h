@@ -352,7 +352,7 @@ k_transition_matrices_ev(const MatrixJob* __restrict__ jobs, const double* __res
             float* __restrict__ packed = jobs[b].out + (size_t) K * SP * SP;
             packed[((size_t) (k * NT + i / 32) * packedT + j / 2) * 64 + (i % 32) + 32 * (j % 2)] = v;
         }
-        if (wgTab > 0) wg_table_put(jobs[b].out + (wgTab & ~MBAMD_WG_TAB_SPLIT) + (size_t) k * wg_table_floats(S), S, i, j, v, (wgTab & MBAMD_WG_TAB_SPLIT) != 0);
+        if (wgTab > 0) wg_table_put(jobs[b].out + wgTab + (size_t) k * wg_table_floats(S), S, i, j, v);
     }
 }
 

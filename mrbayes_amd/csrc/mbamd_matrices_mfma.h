@@ -70,7 +70,7 @@ k_transition_matrices_mfma(const MatrixJob* __restrict__ jobs, RatesArg rates, i
                 const float v = (sum < 0.0) ? 0.0f : (float) sum;
                 out[(size_t) j * SP + row] = v;
                 if (packedT > 0) packed[((size_t) (k * NT + row / 32) * packedT + j / 2) * 64 + (row % 32) + 32 * (j % 2)] = v;
-                if (wgTab > 0) wg_table_put(job.out + (wgTab & ~MBAMD_WG_TAB_SPLIT) + (size_t) k * wg_table_floats(S), S, row, j, v, (wgTab & MBAMD_WG_TAB_SPLIT) != 0);   // tree-walk tables (mbamd_walkg.h)
+                if (wgTab > 0) wg_table_put(job.out + wgTab + (size_t) k * wg_table_floats(S), S, row, j, v);   // tree-walk tables (mbamd_walkg.h)
             }
         }
 }

@@ -32,7 +32,9 @@ k_pathg(ARGS AA)
     typedef typename Sh::acc acc_t;
     constexpr int TW = Sh::TW, KS = Sh::KS, ACC = Sh::ACC;
     constexpr int T = Sh::T, NT = Sh::NT, V = Sh::V, VA = Sh::VA, TP = Sh::TP, NAP = Sh::NAP, NAV = NAP / VA, TV = TP / V;
-    constexpr int NG = ((ACC < T ? ACC : T) * NT + VA - 1) / VA;      // register groups a compact tip's gather needs
+    constexpr int NG = Sh::NG;                       // register groups a compact tip's gather needs
+    constexpr bool BF = Sh::BF;
+    constexpr int NKB = Sh::NKB, NGR = Sh::NGR;
     constexpr unsigned SLOTB = TP * 256u;
     const unsigned lane = threadIdx.x & 63, half = lane / TW, col = lane % TW;
     const int wave = mbd_wave_index();
@@ -67,12 +69,18 @@ k_pathg(ARGS AA)
         for (int it = 0; it < NT; ++it)
 #pragma unroll
             for (int r = 0; r < ACC; ++r) f[it][r] = 0.0f;
+        if constexpr (BF) {
+            constexpr int CHW = Sh::CHW;                 // (k_walkg's arithmetic, chunk by chunk: the same bits)
 #pragma unroll
-        for (int tc = 0; tc < TP; ++tc)
-            if (tc < T) {
+            for (int c = 0; c < CHW; ++c) wg_contract_bf16<NT, NKB / CHW, TP / CHW>(a + c * (NAV / CHW), b + c * (TP / CHW), f);
+        } else {
 #pragma unroll
-                for (int it = 0; it < NT; ++it) f[it] = mbd_mfma_f32_32x32x2(Va::get(a[(tc * NT + it) / VA], (tc * NT + it) % VA), b[tc], f[it]);
-            }
+            for (int tc = 0; tc < TP; ++tc)
+                if (tc < T) {
+#pragma unroll
+                    for (int it = 0; it < NT; ++it) f[it] = mbd_mfma_f32_32x32x2(Va::get(a[(tc * NT + it) / VA], (tc * NT + it) % VA), b[tc], f[it]);
+                }
+        }
     };
     auto load_rows = [&](unsigned coff, float (&b)[TP]) {
         const MBAMD_AS_GLOBAL vec* pb = reinterpret_cast<const MBAMD_AS_GLOBAL vec*>((uintptr_t) (P0 + coff)) + lane;
@@ -92,7 +100,7 @@ k_pathg(ARGS AA)
     auto request = [&](bool tip, unsigned moff, unsigned coff, Operands& o) {
         if (tip) {
             const unsigned s = as_global(T0 + coff)[col];
-            const unsigned aoff = (1u + s / TW) * (unsigned) (NAP * 256) + ((s % TW) * KS + half) * (unsigned) (VA * 4);
+            const unsigned aoff = ((unsigned) NAP + (s / TW) * (unsigned) NGR) * 256u + ((s % TW) * KS + half) * (unsigned) (VA * 4);
             const MBAMD_AS_GLOBAL vecA* pa = reinterpret_cast<const MBAMD_AS_GLOBAL vecA*>((uintptr_t) (Mk + moff) + aoff);
 #pragma unroll
             for (int i = 0; i < NG; ++i) o.a[i] = pa[i * 64];

@@ -41,12 +41,10 @@ namespace mbamd {
 #define MBAMD_WG_MAXLISTS 4
 #define MBAMD_WG_LEAD     2      // leading NOP entries (they fill the operand pipeline)
 #define MBAMD_WG_TAIL     3      // trailing NOP entries (descriptor read-ahead)
-#define MBAMD_WG2_TAIL    4      // ... of k_walkg2's programs
 #define MBAMD_WG_STAGE    256    // bytes per wave in front of its slots (cumulative-exponent hand-over)
-#define MBAMD_WG_STAGE_SPLIT 1024   // row split, per bin: [0, 256) the same hand-over, [256, 768) column maxima float [entry parity][half][32], [768, 776) the pair's progress counters
-#define MBAMD_WG_PREV1    0x2000u   // (row split) child 1 / 2 is the result of the operation this bin executed last: wait for the partner's rows
+#define MBAMD_WG_TIGHT    0x1000u   // a child read from HBM is the result this wave produced two entries earlier: its (delayed) store completes before the operands are requested
+#define MBAMD_WG_PREV1    0x2000u   // child 1 / 2 is the result of the entry this wave executed just before (and sits in a slot too)
 #define MBAMD_WG_PREV2    0x4000u
-#define MBAMD_WG_DRAIN    0x1000u   // (row split) the result is re-read from HBM by this bin in this phase: stores complete before the pair moves on
 
 // Tile width: patterns per wave = 32 (v_mfma_f32_32x32x2_f32: two states per MFMA step, lane = 32 h + pattern).  A 16-pattern
 // variant on v_mfma_f32_16x16x4_f32 (twice the waves, half the accumulators and epilogue each, 40- instead of 64-cycle dependent MFMA
@@ -56,35 +54,49 @@ namespace mbamd {
 // were removed in round 5 (git history has them).
 #define MBAMD_WG_TW 32
 #define MBAMD_WG_KS (64 / MBAMD_WG_TW)    // states per row of a block = per MFMA step (2 or 4)
-// Row split (round 5, k_walkg2; an instance created with MBAMD_WALKG_PAIR=1): beyond 48 states (the sense codons: two 32-row
-// output tiles) a (tile, category, subtree bin) is a PAIR of waves -- wave h of the pair owns output tile h: half of A', half of
-// the MFMA chain, half of the accumulators, half of the epilogue and of the stores; the child's rows (the B operand) come from
-// the LDS slots the pair shares.  Twice the working waves for the same operand traffic (16-pattern tiles doubled it), and the
-// registers that frees hold the operands of two whole entries.  The tables of such an instance hold tile 0's rows in front of
-// tile 1's (`split` below).  MEASURED (profiles/r05_walkg_pair.txt): parity-green and no faster than k_walkg; opt-in.
-// the transition-matrix kernels take "where the tables start" as one size_t (wgTab, floats into a matrix buffer; 0: no tables):
-// its top bit says that the instance's tables have the row-split layout
-#define MBAMD_WG_TAB_SPLIT ((size_t) 1 << 63)
-__host__ __device__ inline bool wg_split_states(int S) { return S > 48; }
-// state counts k_walkg2 is instantiated for (one output tile per wave: up to 32 states, or the row split); 40 states: k_walkg only
-__host__ __device__ inline bool wg2_states(int S) { return S == 2 || S == 8 || S == 16 || S == 20 || S > 48; }
-__host__ __device__ inline int wg_pairs(int S) { return (S + MBAMD_WG_KS - 1) / MBAMD_WG_KS; }         // T: MFMA steps (rows of a block)
+// ---- round 6: the contraction on the 16-BIT matrix cores, in fp32 arithmetic (profiles/r06_bf16x3.txt) ----------------------------
+// v_mfma_f32_32x32x2_f32 runs at the fp32 VECTOR rate (64 cycles for 4 096 flops) and shares the SIMD's vector issue port: nothing
+// else of the SIMD runs beside it.  v_mfma_f32_32x32x16_bf16 does 8 x the contraction depth in half the time on a pipe of its own.
+// From 16 states on a factor is therefore formed as   sum over pieces  a = a1 + a2 + a3,  b = b1 + b2 + b3   (each piece the
+// round-to-nearest bf16 of what the larger pieces left: 3 x 8 = 24 significant bits, the split is EXACT)  of the six products of
+// order <= 4 -- a3 b1, a1 b3, a2 b2, a2 b1, a1 b2, a1 b1, over the whole contraction in THAT order, smallest first: every product of
+// two bf16 is exact in the fp32 accumulator, what is dropped (a2 b3, a3 b2, a3 b3) is below 2^-25 of the result, and only the last
+// few accumulations round at full magnitude.  Measured against fp64 on transition-matrix x partials products: rms error 6.2e-8
+// (61 states) / 5.3e-8 (20) where the fp32 MFMA chain has 10.1e-8 / 6.2e-8.  The A pieces are made once, by the matrix kernel
+// (wg_table_put); the B pieces by the consumer, from the fp32 rows in its registers (11 VALU instructions per two values, beside
+// the MFMAs).  Blocks in HBM and in LDS, tips, exponents: unchanged -- an fp32 [T][64] block is both kernels' operand.
+#if !defined(MBAMD_WG_BF_MIN)
+#define MBAMD_WG_BF_MIN 16       // state counts from here on contract on the 16-bit matrix cores
+#endif
+__host__ __device__ inline bool wg_bf16(int S) { return S >= MBAMD_WG_BF_MIN; }
+__host__ __device__ inline int wg_kblocks(int S) { return (S + 15) / 16; }                // NKB: contraction blocks of 16 states
+// K-block kb holds the block rows t = 8 kb .. 8 kb + 7 (the lane's registers): element j of lane half h = state 16 kb + 2 j + h
+__host__ __device__ inline int wg_pairs(int S) { return (S + MBAMD_WG_KS - 1) / MBAMD_WG_KS; }         // T: rows of a block (fp32 mode: MFMA steps)
 __host__ __device__ inline int wg_tiles(int S) { return (S + MBAMD_WG_TW - 1) / MBAMD_WG_TW; }         // NT: output tiles of TW rows
 __host__ __device__ inline int wg_vec(int S) { return S > 32 ? 4 : 2; }                   // V: floats per lane and memory instruction (blocks)
-__host__ __device__ inline int wg_vec_a(int S) { return wg_vec(S); }                      // VA: the same for the tables
+__host__ __device__ inline int wg_vec_a(int S) { return wg_bf16(S) ? 4 : wg_vec(S); }     // VA: the same for the tables
 __host__ __device__ inline int wg_pairs_padded(int S) { return (wg_pairs(S) + wg_vec(S) - 1) / wg_vec(S) * wg_vec(S); }   // TP
-__host__ __device__ inline int wg_rows(int S)                                             // NAP: 256-byte rows of a table
+// 256-byte rows of the A' area of a table.  fp32 mode: one row per (MFMA step, output tile).  bf16 mode: 4 rows = one 16-byte
+// operand per lane for (K-block, output tile, piece): 3 NT NKB operands
+__host__ __device__ inline int wg_rows(int S)                                             // NAP
 {
+    if (wg_bf16(S)) return 4 * 3 * wg_tiles(S) * wg_kblocks(S);
     const int n = wg_pairs_padded(S) * wg_tiles(S), va = wg_vec_a(S);
     return (n + va - 1) / va * va;
 }
+// 256-byte rows of ONE tip-gather table: register (it, r), r < min(16, T), of a compact tip's factor = row r NT + it
+__host__ __device__ inline int wg_gather_rows(int S)                                      // NGR
+{
+    if (!wg_bf16(S)) return wg_rows(S);              // (fp32 mode: as many as A', the layout of rounds 2-5)
+    const int t = wg_pairs(S) < 16 ? wg_pairs(S) : 16, n = t * wg_tiles(S);
+    return (n + 3) / 4 * 4;
+}
 __host__ __device__ inline int wg_subtables(int S) { return S / MBAMD_WG_TW + 1; }        // gather tables: states 0..S in groups of TW (S = "missing")
 __host__ __device__ inline unsigned wg_block_bytes(int S) { return (unsigned) wg_pairs_padded(S) * 256u; }   // one (tile, buffer, category) = one LDS slot
-__host__ __device__ inline size_t wg_table_floats(int S) { return (size_t) (1 + wg_subtables(S)) * wg_rows(S) * 64; }   // per category
-__host__ __device__ inline unsigned wg_stage_bytes(bool split) { return split ? MBAMD_WG_STAGE_SPLIT : MBAMD_WG_STAGE; }
-// W = subtree bins of a workgroup (a bin is one wave, or a pair of waves with the row split)
-__host__ __device__ inline size_t wg_lds_bytes(int W, int nslots, int S, bool split = false) { return (size_t) W * (wg_stage_bytes(split) + (size_t) nslots * wg_block_bytes(S)); }
-__host__ __device__ inline int wg_waves_per_bin(bool split) { return split ? 2 : 1; }
+__host__ __device__ inline size_t wg_table_floats(int S) { return ((size_t) wg_rows(S) + (size_t) wg_subtables(S) * wg_gather_rows(S)) * 64; }   // per category
+// W = subtree bins of a workgroup = its working waves
+// per wave: the hand-over area, nslots result slots, one staging slot (k_walkg: results travel to HBM from LDS, an entry later)
+__host__ __device__ inline size_t wg_lds_bytes(int W, int nslots, int S) { return (size_t) W * (MBAMD_WG_STAGE + (size_t) (nslots + 1) * wg_block_bytes(S)); }
 // A block holds [TP rows][64 lanes]: row t, lane TW h + p = state KS t + h of pattern p; V consecutive rows are interleaved
 // per lane so that one dword / dwordx2 / dwordx4 per lane moves V rows (256 B - 1 KiB contiguous per wave instruction).
 // float offset of (row r, lane / column c) inside a block or table:
@@ -98,41 +110,59 @@ __host__ __device__ inline unsigned wg_elem_sh(int sh, int i, int p)
 __host__ __device__ inline int wg_vec_shift(int S) { const int v = wg_vec(S); return v == 4 ? 2 : (v == 2 ? 1 : 0); }
 __host__ __device__ inline unsigned wg_elem(int S, int i, int p) { return wg_at(wg_vec(S), i / MBAMD_WG_KS, (i % MBAMD_WG_KS) * MBAMD_WG_TW + p); }   // state i, pattern p
 
-// Tables of one (matrix, category): rows n = t * NT + it (< NAP), 64 columns, stored like blocks (wg_at with VA):
-//   A'  (n, lane)         MFMA A operand of step t, output tile it
-//   G_u (n, column)       tip gather: the lane of a pattern with state TW u + s reads ITS column of the rows n = r NT + it
-//                         and has the factor registers (it, r) of a compact tip -- no MFMA
+// Tables of one (matrix, category), stored like blocks (wg_at with VA): the A' area (NAP rows), then wg_subtables gather tables G_u
+// of NGR rows each.
+//   fp32 mode:  A'  (n = t NT + it, lane)   MFMA A operand of step t, output tile it
+//   bf16 mode:  A'  operand o = (kb NT + it) 3 + piece: 16 bytes per lane = the piece's eight bf16 P(i -> 16 kb + 2 j + h'), j = 0..7,
+//                   of the lane (h', m) whose MFMA row m carries from-state i
+//   G_u (n = r NT + it, column)   tip gather: the lane of a pattern with state TW u + s reads ITS column of these rows and has the
+//                         factor registers (it, r) of a compact tip -- no MFMA (fp32 in both modes)
 //       the column of state S ("missing") holds 1 for every existing from-state.
 // The ROWS of A' are permuted so that the output tile lands in block layout (register r of lane group h = the state the
-// next MFMA step t = ... wants there):
-//   register r, half h = state 32 it + 2 r + h;   A'(n, 32 (j & 1) + row) with row = (r & 3) + 8 (r >> 2) + 4 h
+// next contraction wants there):
+//   register r, half h = state 32 it + 2 r + h;   MFMA row = (r & 3) + 8 (r >> 2) + 4 h
 //   G_u(n = r NT + it, 2 s + h)
-//   row split (wg_split): n = it TP + t for A', n = it TP + r for G_u -- an output tile's rows are contiguous
-// scatter P_k(i -> j) = v into the tables of category k (tab = first float of that category's tables)
-__host__ __device__ inline void wg_table_put(float* tab, int S, int i, int j, float v, bool sp = false)
+__host__ __device__ inline uint16_t wg_bf16_rne(float v)         // the bf16 nearest to v (ties to even): what v_cvt_pk_bf16_f32 gives a finite v
 {
-    const int NT = wg_tiles(S), NAP = wg_rows(S), VA = wg_vec_a(S);
+    const uint32_t b = __builtin_bit_cast(uint32_t, v);
+    return (uint16_t) ((b + 0x7FFFu + ((b >> 16) & 1u)) >> 16);
+}
+__host__ __device__ inline float wg_bf16_float(uint16_t p) { return __builtin_bit_cast(float, (uint32_t) p << 16); }
+// scatter P_k(i -> j) = v into the tables of category k (tab = first float of that category's tables)
+__host__ __device__ inline void wg_table_put(float* tab, int S, int i, int j, float v)
+{
+    const int NT = wg_tiles(S), NAP = wg_rows(S), NGR = wg_gather_rows(S), VA = wg_vec_a(S);
     const int it = i >> 5, r = (i & 31) >> 1, h = i & 1;
     const int row = (r & 3) + 8 * (r >> 2) + 4 * h;                        // MFMA row that carries state i
-    const int TP = wg_pairs_padded(S);
-    tab[wg_at(VA, sp ? it * TP + (j >> 1) : (j >> 1) * NT + it, row + 32 * (j & 1))] = v;            // A'
-    tab[(size_t) (1 + (j >> 5)) * NAP * 64 + wg_at(VA, sp ? it * TP + r : r * NT + it, 2 * (j & 31) + h)] = v;   // G_u
+    if (wg_bf16(S)) {
+        uint16_t* t16 = reinterpret_cast<uint16_t*>(tab);
+        const int kb = j >> 4, jj = (j & 15) >> 1, lane = 32 * (j & 1) + row;
+        const size_t at = ((size_t) (kb * NT + it) * 3 * 64 + lane) * 8 + jj;        // (operand, lane, element) -> bf16 index; + 512 per piece
+        const uint16_t p1 = wg_bf16_rne(v);
+        const float r1 = v - wg_bf16_float(p1);
+        const uint16_t p2 = wg_bf16_rne(r1);
+        const uint16_t p3 = wg_bf16_rne(r1 - wg_bf16_float(p2));
+        t16[at] = p1; t16[at + 512] = p2; t16[at + 1024] = p3;
+    } else {
+        tab[wg_at(VA, (j >> 1) * NT + it, row + 32 * (j & 1))] = v;            // A'
+    }
+    tab[((size_t) NAP + (size_t) (j >> 5) * NGR) * 64 + wg_at(VA, r * NT + it, 2 * (j & 31) + h)] = v;   // G_u
 }
 // the "missing" column (constant): from-state i
-__host__ __device__ inline void wg_table_put_missing(float* tab, int S, int i, bool sp = false)
+__host__ __device__ inline void wg_table_put_missing(float* tab, int S, int i)
 {
-    const int NT = wg_tiles(S), NAP = wg_rows(S), VA = wg_vec_a(S);
+    const int NT = wg_tiles(S), NAP = wg_rows(S), NGR = wg_gather_rows(S), VA = wg_vec_a(S);
     const int it = i >> 5, r = (i & 31) >> 1, h = i & 1;
-    tab[(size_t) (1 + (S >> 5)) * NAP * 64 + wg_at(VA, sp ? it * wg_pairs_padded(S) + r : r * NT + it, 2 * (S & 31) + h)] = 1.0f;
+    tab[((size_t) NAP + (size_t) (S >> 5) * NGR) * 64 + wg_at(VA, r * NT + it, 2 * (S & 31) + h)] = 1.0f;
 }
 // one thread per (matrix, category, state): the constant column of every matrix buffer, once per instance
 __global__ void __launch_bounds__(256)
-k_wg_init_tables(float* __restrict__ matrices, size_t matrixFloats, size_t tabOffFloats, int S, int K, int total, int split)
+k_wg_init_tables(float* __restrict__ matrices, size_t matrixFloats, size_t tabOffFloats, int S, int K, int total)
 {
     const int g = blockIdx.x * blockDim.x + threadIdx.x;
     if (g >= total) return;
     const int i = g % S, mk = g / S;
-    wg_table_put_missing(matrices + (size_t) (mk / K) * matrixFloats + tabOffFloats + (size_t) (mk % K) * wg_table_floats(S), S, i, split != 0);
+    wg_table_put_missing(matrices + (size_t) (mk / K) * matrixFloats + tabOffFloats + (size_t) (mk % K) * wg_table_floats(S), S, i);
 }
 
 struct WalkGArgs {
@@ -152,7 +182,6 @@ struct WalkGArgs {
     int K, Ppad, ntiles, S, SP;
     int lists;                   // > 1: mutually independent lists run as separate workgroups (programs [list][W][entries]); else 1
     int spread;                  // 1: the workgroup is launched with 2 W waves and only the even ones work (see k_walkg)
-    int pair;                    // 1: row split (k_walkg2): a subtree bin is a pair of waves, the stage area is MBAMD_WG_STAGE_SPLIT bytes
     long long* reserved;         // (was: clock stamps of timing experiments)
 };
 __host__ __device__ inline unsigned walkg_grid(int ntiles, int KL) { return 8u * (unsigned) KL * (unsigned) ((ntiles + 7) / 8); }   // KL = categories x lists
@@ -169,6 +198,5 @@ __device__ __forceinline__ const Walk4Entry* wg_program(const WalkGArgs& a) { re
 }  // namespace mbamd
 #include <mbamd_dev_walkg_kernel.h>   // the kernels' device primitives (csrc/device/: MFMA, lane swap, waits; tests/hostemu/: the same on fibers)
 #include "mbamd_walkg_kernel.h"       // k_walkg
-#include "mbamd_walkg2_kernel.h"      // k_walkg2: a whole entry's operands in flight; the row-split pair (round 5)
 #include "mbamd_pathg_kernel.h"       // k_pathg: a move's root-ward path on two waves (sibling factors ahead of the chain)
 #endif

@@ -20,17 +20,19 @@ template <> struct WgVecT<1> {
     static __device__ __forceinline__ type splat(float x) { return x; }
 };
 
-template <int SC, bool PAIR = false> struct WgShape {
+template <int SC> struct WgShape {
     static constexpr int TW = MBAMD_WG_TW, KS = MBAMD_WG_KS;
     static constexpr int T = (SC + KS - 1) / KS, NT = (SC + TW - 1) / TW;
-    static constexpr int V = SC > 32 ? 4 : 2, VA = V;
+    static constexpr bool BF = SC >= MBAMD_WG_BF_MIN;   // wg_bf16: the contraction on v_mfma_f32_32x32x16_bf16, three bf16 pieces per value (mbamd_walkg.h)
+    static constexpr int NKB = (SC + 15) / 16;       // K-blocks of 16 states (BF)
+    static constexpr int V = SC > 32 ? 4 : 2, VA = BF ? 4 : V;
     static constexpr int ACC = 16;                   // accumulator registers per output tile (32 x 32 / 64 lanes)
-    static constexpr int TP = (T + V - 1) / V * V, NAP = (TP * NT + VA - 1) / VA * VA;
-    // row split (k_walkg2, mbamd_walkg.h): a wave of the pair owns ONE output tile -- its rows of the tables and of the result
-    static constexpr bool SPLIT = PAIR && SC > 48;
-    static constexpr int NAW = SPLIT ? TP : NAP;      // table rows a wave fetches per interior child
-    static constexpr int TPO = SPLIT ? ACC : TP;      // block rows of the result this wave owns
-    static_assert(!SPLIT || (NT == 2 && TP == 2 * ACC && V == 4 && VA == 4), "row split: two output tiles of 16 block rows");
+    static constexpr int TP = (T + V - 1) / V * V, NAP = BF ? 4 * 3 * NT * NKB : (TP * NT + VA - 1) / VA * VA;
+    static constexpr int NGR = BF ? ((T < ACC ? T : ACC) * NT + 3) / 4 * 4 : NAP;   // rows of one tip-gather table
+    static constexpr int NG = ((T < ACC ? T : ACC) * NT + VA - 1) / VA;             // register groups a compact tip's gather needs
+    // chunks per child factor in k_walkg (its CH; MBAMD_WG_DISPATCH).  With bf16 pieces the products are ordered inside a chunk, so
+    // every kernel that must give k_walkg's bits (k_pathg) forms a factor in the same chunks
+    static constexpr int CHW = SC >= 60 ? 2 : 1;
     typedef WgVecT<V> Vb;                            // block rows (B operand, results)
     typedef WgVecT<VA> Va;                           // table rows (A operand, tip gathers)
     typedef typename Vb::type vec;
@@ -42,6 +44,42 @@ template <int SC, int CH> struct WgOperands {
     typename WgShape<SC>::vecA a[WgShape<SC>::NAP / WgShape<SC>::VA / CH];  // A rows of the chunk (or the tip's gather rows), VA rows per register group
     typename WgShape<SC>::vec b[WgShape<SC>::TP / WgShape<SC>::V / CH];     // B rows of a child read from HBM
 };
+// the three bf16 pieces of two values, each pair in one dword (v0's piece in bits 0..15, v1's in 16..31): p + q + w = v EXACTLY --
+// a remainder of a 24-bit value after its nearest 8-bit neighbour has 16 significant bits, after the next 8 (mbamd_walkg.h: the
+// same arithmetic as wg_table_put's, which makes the A pieces)
+__device__ __forceinline__ void wg_split_pair(float v0, float v1, unsigned& p, unsigned& q, unsigned& w)
+{
+    p = mbd_cvt_pk_bf16(v0, v1);
+    const float r0 = v0 - __builtin_bit_cast(float, p << 16), r1 = v1 - __builtin_bit_cast(float, p & 0xFFFF0000u);
+    q = mbd_cvt_pk_bf16(r0, r1);
+    const float s0 = r0 - __builtin_bit_cast(float, q << 16), s1 = r1 - __builtin_bit_cast(float, q & 0xFFFF0000u);
+    w = mbd_cvt_pk_bf16(s0, s1);
+}
+// One child factor (or one chunk of its K-blocks) on the 16-bit matrix cores: f[it] += sum over the chunk's K-blocks and the six
+// piece pairs, SMALLEST PRODUCTS FIRST over the whole chunk (only the last accumulations round at full magnitude).
+//   a     the chunk's table operands, index (kb NT + it) 3 + piece (wg_table_put)
+//   rows  the child's block rows of the chunk: K-block kb = rows 8 kb .. 8 kb + 7 (NR of them exist; the rest are zero)
+template <int NT, int NKBC, int NR, class VECA>
+__device__ __forceinline__ void wg_contract_bf16(const VECA* a, const float* rows, mbd_acc16 (&f)[NT])
+{
+    mbd_f4 pc[3][NKBC];
+#pragma unroll
+    for (int kb = 0; kb < NKBC; ++kb)
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj) {
+            const int t0 = 8 * kb + 2 * jj;
+            unsigned p = 0, q = 0, w = 0;
+            if (t0 < NR) wg_split_pair(rows[t0 < NR ? t0 : 0], t0 + 1 < NR ? rows[t0 + 1 < NR ? t0 + 1 : 0] : 0.0f, p, q, w);
+            pc[0][kb][jj] = __builtin_bit_cast(float, p); pc[1][kb][jj] = __builtin_bit_cast(float, q); pc[2][kb][jj] = __builtin_bit_cast(float, w);
+        }
+    constexpr int PA[6] = {2, 0, 1, 1, 0, 0}, PB[6] = {0, 2, 1, 0, 1, 0};     // a3 b1, a1 b3, a2 b2, a2 b1, a1 b2, a1 b1
+#pragma unroll
+    for (int pr = 0; pr < 6; ++pr)
+#pragma unroll
+        for (int kb = 0; kb < NKBC; ++kb)
+#pragma unroll
+            for (int it = 0; it < NT; ++it) f[it] = mbd_mfma_bf16_32x32x16(a[(kb * NT + it) * 3 + PA[pr]], pc[PB[pr]][kb], f[it]);
+}
 struct WgDesc {
     Walk4Entry e;
     unsigned s1, s2;           // tip states of this lane's pattern (children 1, 2)
@@ -58,7 +96,7 @@ template <int I> struct WgInt { static constexpr int value = I; };
 // (206 registers, accumulators included) instead of 174 + 32 accumulation registers: a compact tip's factor is then written where
 // the product reads it, not copied in through v_accvgpr_write (codon 100 x 5 000: 0.195 -> 0.188 ms, profiles/r04_exp_walkgs.txt).
 #if !defined(MBAMD_WG_MINWAVES)
-#define MBAMD_WG_MINWAVES(SC) ((SC) > 32 ? 2 : 1)
+#define MBAMD_WG_MINWAVES(SC) ((SC) > 48 ? 2 : 1)     // (40 states, bf16 tables: 72 + 20 operand registers per set -- one wave per SIMD, no scratch)
 #endif
 // blockDim.x = 64 * W (W <= WMAX); grid = walkg_grid(ntiles, K); dynamic LDS = wg_lds_bytes(W, nslots, SC).
 // The operand pipeline works in CHUNKS: a job (one child factor, T MFMA steps per row tile) is CH chunks, an entry 2 CH,
@@ -80,10 +118,15 @@ k_walkg(ARGS AA)
     typedef WgOperands<SC, CH> Ops;
     constexpr int TW = Sh::TW, KS = Sh::KS, ACC = Sh::ACC;
     constexpr int T = Sh::T, NT = Sh::NT, V = Sh::V, VA = Sh::VA, TP = Sh::TP, NAP = Sh::NAP, NAV = NAP / VA, TV = TP / V;
-    constexpr int TPC = TP / CH, NAVC = NAV / CH, TVC = TV / CH;      // per chunk: MFMA steps, A register groups, B register groups
+    constexpr bool BF = Sh::BF;
+    constexpr int NKB = Sh::NKB, NKBC = NKB / CH, NGR = Sh::NGR, NG = Sh::NG;
+    constexpr int TPC = TP / CH, NAVC = NAV / CH, TVC = TV / CH;      // per chunk: block rows (fp32 mode: MFMA steps), A register groups, B register groups
     constexpr int NQ = 2 * CH, NS = DEPTH + 1;                        // chunks per entry, register sets
-    static_assert(TP % CH == 0 && TPC % V == 0 && NAV % CH == 0 && (TPC * NT) % VA == 0 && NS <= 3 && DEPTH <= NQ && TPC <= 20, "chunk geometry");
-    static_assert((ACC < T ? ACC : T) * NT <= NAVC * VA, "a compact tip's gather rows must lie in the first chunk");
+    static_assert(TP % CH == 0 && TPC % V == 0 && NAV % CH == 0 && NS <= 3 && DEPTH <= NQ && TPC <= 20, "chunk geometry");
+    static_assert(BF || (TPC * NT) % VA == 0, "chunk geometry (fp32 tables)");
+    static_assert(!BF || (NKB % CH == 0 && (CH == 1 || TP == 8 * NKB)), "chunk geometry (bf16 tables: whole K-blocks)");
+    static_assert(NG <= NAVC, "a compact tip's gather rows must lie in the first chunk");
+    static_assert(CH == Sh::CHW, "k_pathg forms its factors in WgShape::CHW chunks");
     constexpr unsigned SLOTB = TP * 256u;
     const unsigned lane = threadIdx.x & 63, half = lane / TW, col = lane % TW;      // half: which of the KS states of a row
     int wave = mbd_wave_index();
@@ -101,7 +144,8 @@ k_walkg(ARGS AA)
     const unsigned xcd = blockIdx.x & 7u, pos = blockIdx.x >> 3;
     const unsigned tile = (pos / KL) * 8u + xcd, k = (pos % KL) % K, list = (pos % KL) / K;
     if (tile >= (unsigned) A.ntiles) return;
-    char* const mine = reinterpret_cast<char*>(lds_walkg) + (size_t) wave * (MBAMD_WG_STAGE + (size_t) A.nslots * SLOTB);
+    // a wave's LDS: the hand-over area, its nslots result slots, and one STAGING slot for results no slot was assigned to
+    char* const mine = reinterpret_cast<char*>(lds_walkg) + (size_t) wave * (MBAMD_WG_STAGE + (size_t) (A.nslots + 1) * SLOTB);
     vec* const slots = reinterpret_cast<vec*>(mine + MBAMD_WG_STAGE) + lane;          // this lane's V rows of row group 0, slot 0
     // wave-uniform bases; the entries hold byte offsets from them
     char* const P0 = reinterpret_cast<char*>(A.partials) + (size_t) tile * A.tileBytes + (size_t) k * SLOTB;
@@ -121,6 +165,23 @@ k_walkg(ARGS AA)
     for (int i = 0; i < TVC; ++i) X.b[i] = Y.b[i] = Z.b[i] = Vb::splat(0.0f);
     int er = 0;                                      // stored exponent of the entry about to run (SCALE_READ)
     int cum_e[MBAMD_WG_MAXLISTS] = {0, 0, 0, 0};
+    // DELAYED RESULT STORES (round 6).  vmcnt is one in-order counter for loads and stores: a wait for operands requested after a
+    // result store is a wait for that store -- and every entry's second chunk of operands used to be requested right behind the
+    // previous entry's stores (a memory round trip per entry with nothing else to run, profiles/r05_walkg_pair.txt "operands").
+    // An entry's result now goes to LDS only (its slot, or the staging slot); the NEXT entry writes it to HBM from there, at the
+    // top of its last chunk -- behind every operand request whose wait follows within a chunk's time.  Pending: where from, where to.
+    unsigned pend_slot = (unsigned) A.nslots * SLOTB, pend_dst = DA.e.dst, pend_ew = DA.e.ewrite;    // (entry 0 is a no-operation: the scratch block)
+    int pend_e = 0;
+    auto flush_pending = [&]() {
+        const vec* src = reinterpret_cast<const vec*>(reinterpret_cast<const char*>(slots) + pend_slot);
+        vec t[TV];
+#pragma unroll
+        for (int i = 0; i < TV; ++i) t[i] = src[i * 64];
+        MBAMD_AS_GLOBAL vec* pd = reinterpret_cast<MBAMD_AS_GLOBAL vec*>((uintptr_t) (P0 + pend_dst)) + lane;
+#pragma unroll
+        for (int i = 0; i < TV; ++i) __builtin_nontemporal_store(t[i], pd + i * 64);   // 64 * V * 4 contiguous bytes per instruction
+        __builtin_nontemporal_store((int8_t) pend_e, as_global(E0 + pend_ew) + col);   // (every lane group holds the same e: no exec-mask branch)
+    };
 
     // operands of chunk q (child q / CH, part q % CH) of entry d -> register set o: NAVC loads outside any branch
     // (+ TVC for a child that lives in HBM)
@@ -137,9 +198,18 @@ k_walkg(ARGS AA)
         //  (profiles/r03_c5_pmc.txt).  With one chunk per job the plain form stays: a run-time stride costs the immediate offsets
         //  of the loads -- +10 % at 20 states, measured.)
         const bool idle = CH > 1 && ((tip && h > 0) || (ctl & MBAMD_W4_NOP));
-        const unsigned aoff = idle ? 0u : (tip ? (1u + s / TW) * (unsigned) (NAP * 256) + ((s % TW) * KS + half) * (unsigned) (VA * 4) : lane * (unsigned) (VA * 4));
+        const unsigned aoff = idle ? 0u : (tip ? ((unsigned) NAP + (s / TW) * (unsigned) NGR) * 256u + ((s % TW) * KS + half) * (unsigned) (VA * 4) : lane * (unsigned) (VA * 4));
         const MBAMD_AS_GLOBAL vecA* pa = reinterpret_cast<const MBAMD_AS_GLOBAL vecA*>((uintptr_t) (Mk + moff) + aoff) + (idle ? 0 : h * NAVC * 64);
-        if constexpr (CH > 1) {
+        if constexpr (BF && NG < NAVC) {
+            // bf16 tables: an interior child's operands are NAVC loads, a tip's gather rows the first NG of them -- the others stay in
+            // the sequence and read the tip's first row again
+            const int stride = idle ? 0 : 64, rest = (idle || tip) ? 0 : 64;
+            const MBAMD_AS_GLOBAL vecA* pr = (idle || tip) ? pa : pa + NG * 64;
+#pragma unroll
+            for (int i = 0; i < NG; ++i) o.a[i] = pa[i * stride];
+#pragma unroll
+            for (int i = NG; i < NAVC; ++i) o.a[i] = pr[(i - NG) * rest];
+        } else if constexpr (CH > 1) {
             const int stride = idle ? 0 : 64;
 #pragma unroll
             for (int i = 0; i < NAVC; ++i) o.a[i] = pa[i * stride];
@@ -184,15 +254,22 @@ k_walkg(ARGS AA)
 #pragma unroll
                 for (int r = 0; r < ACC; ++r) f[it][r] = 0.0f;
         }
+        if constexpr (BF) {
+            float rows[TPC];
 #pragma unroll
-        for (int tc = 0; tc < TPC; ++tc)
-            if (h * TPC + tc < T) {
+            for (int tc = 0; tc < TPC; ++tc) rows[tc] = Vb::get(b[tc / V], tc % V);
+            wg_contract_bf16<NT, NKBC, TPC>(o.a, rows, f);
+        } else {
 #pragma unroll
-                for (int it = 0; it < NT; ++it) {
-                    const float av = Va::get(o.a[(tc * NT + it) / VA], (tc * NT + it) % VA), bv = Vb::get(b[tc / V], tc % V);
-                    f[it] = mbd_mfma_f32_32x32x2(av, bv, f[it]);
+            for (int tc = 0; tc < TPC; ++tc)
+                if (h * TPC + tc < T) {
+#pragma unroll
+                    for (int it = 0; it < NT; ++it) {
+                        const float av = Va::get(o.a[(tc * NT + it) / VA], (tc * NT + it) % VA), bv = Vb::get(b[tc / V], tc % V);
+                        f[it] = mbd_mfma_f32_32x32x2(av, bv, f[it]);
+                    }
                 }
-            }
+        }
     };
 
     // One iteration = one entry `cur`: its NQ chunks run on the register sets (S0, S1, S2, S0, ...) while the chunks DEPTH
@@ -203,6 +280,7 @@ k_walkg(ARGS AA)
         const unsigned ctl = cur.e.ctl;
         if (ctl & MBAMD_W4_BARRIER) {
             // values other waves produced in the previous phase are read from here on: drain this wave's stores, meet
+            flush_pending();                         // (the previous entry's result is still in LDS only; the regular flush below repeats it, harmlessly)
             MBD_DRAIN_ALL();
             MBD_WG_BARRIER();
             MBD_COMPILER_FENCE();
@@ -246,6 +324,12 @@ k_walkg(ARGS AA)
         auto chunk = [&](auto qc) {
             constexpr int q = decltype(qc)::value;
             if constexpr (q < NQ) {
+                if constexpr (q == NQ - 1) {
+                    flush_pending();                 // the previous entry's result: LDS -> HBM
+                    // the operands requested next may include rows this wave stored a moment ago (a result evicted two entries
+                    // back and read again by the next entry, marked by the host): those stores complete first
+                    if (n1.e.ctl & MBAMD_WG_TIGHT) MBD_DRAIN_VMEM();
+                }
                 constexpr int qf = q + DEPTH;        // the chunk fetched now
                 if constexpr (qf < NQ) {
                     WgDesc t;
@@ -303,15 +387,12 @@ k_walkg(ARGS AA)
         vec ov[TV];
 #pragma unroll
         for (int t = 0; t < TP; ++t) Vb::set(ov[t / V], t % V, out[t] * sc);   // (exact: |e| <= 126; 2^0 needs no branch)
-        if (ctl & MBAMD_W4_KEEP) {
-            vec* keep = reinterpret_cast<vec*>(reinterpret_cast<char*>(slots) + ((ctl >> 16) & 0xFFu) * SLOTB);
+        // the result stays in LDS: in the slot the program assigned, else in the staging slot; the next entry stores it
+        const unsigned slot_off = (ctl & MBAMD_W4_KEEP) ? ((ctl >> 16) & 0xFFu) * SLOTB : (unsigned) A.nslots * SLOTB;
+        vec* keep = reinterpret_cast<vec*>(reinterpret_cast<char*>(slots) + slot_off);
 #pragma unroll
-            for (int i = 0; i < TV; ++i) keep[i * 64] = ov[i];
-        }
-        MBAMD_AS_GLOBAL vec* pd = reinterpret_cast<MBAMD_AS_GLOBAL vec*>((uintptr_t) (P0 + dst)) + lane;
-#pragma unroll
-        for (int i = 0; i < TV; ++i) __builtin_nontemporal_store(ov[i], pd + i * 64);   // 64 * V * 4 contiguous bytes per instruction
-        __builtin_nontemporal_store((int8_t) e, as_global(E0 + ewrite) + col);   // (every lane group holds the same e: no exec-mask branch)
+        for (int i = 0; i < TV; ++i) keep[i * 64] = ov[i];
+        pend_slot = slot_off; pend_dst = dst; pend_ew = ewrite; pend_e = e;
     };
     // the sets rotate by NQ positions per entry; three entries bring every (NS <= 3) rotation back to the start
     for (int j = 0; j < n; j += 3) {
@@ -319,6 +400,7 @@ k_walkg(ARGS AA)
         step(DB, DC, DA, wg_pick<NQ % NS>(X, Y, Z), wg_pick<(NQ + 1) % NS>(X, Y, Z), wg_pick<(NQ + 2) % NS>(X, Y, Z), j + 1);
         step(DC, DA, DB, wg_pick<(2 * NQ) % NS>(X, Y, Z), wg_pick<(2 * NQ + 1) % NS>(X, Y, Z), wg_pick<(2 * NQ + 2) % NS>(X, Y, Z), j + 2);
     }
+    flush_pending();                                 // the last entry's result
     // cumulative exponents of this workgroup's TW columns: the waves' sums meet in LDS, wave 0 owns the memory update
     int* const stage = reinterpret_cast<int*>(mine);
 #pragma unroll
@@ -331,7 +413,7 @@ k_walkg(ARGS AA)
             MBAMD_SYNC();
             if (wave == 0)
                 for (int w = 1; w < W; ++w)
-                    sum += reinterpret_cast<const int*>(reinterpret_cast<const char*>(lds_walkg) + (size_t) w * (MBAMD_WG_STAGE + (size_t) A.nslots * SLOTB))[lane];
+                    sum += reinterpret_cast<const int*>(reinterpret_cast<const char*>(lds_walkg) + (size_t) w * (MBAMD_WG_STAGE + (size_t) (A.nslots + 1) * SLOTB))[lane];
         }
         if (wave == 0 && half == 0) {
             int32_t* d = A.cum[q] + (size_t) k * A.Ppad + (size_t) tile * TW + col;

@@ -1218,34 +1218,3 @@ def check_parsimony_model_golden(lib, golden_dir):
             inst.finalize()
 
 
-def check_pair_walk(lib, oracle, golden_dir, monkeypatch, full=True):
-    """k_walkg2 (MBAMD_WALKG_PAIR=1: the operands of a whole entry in flight; beyond 48 states the row split -- a subtree bin is a
-    pair of waves, each owning one output tile, split table layout) against k_walkg, the oracle and the reference's goldens: full
-    evaluations with both scaling schemes at several bin counts / slot budgets (few slots: evicted results come back from HBM, the
-    pair drains its stores first), per-site values, partial updates with rejects, other state counts."""
-    # (full=False: the CPU emulation, where a 61-state operation is thousands of fiber switches -- two cases, two geometries)
-    cases = ("avian_wag_g4", "replicase_m3", "synth_aa_wag", "synth_codon_m3") if full else ("avian_wag_g4", "synth_codon_m3")
-    envs = ({}, {"MBAMD_WALK_WAVES": "1"}, {"MBAMD_WALK_WAVES": "2", "MBAMD_MAX_LDS_SLOTS": "3"}, {"MBAMD_WALK_WAVES": "1", "MBAMD_MAX_LDS_SLOTS": "3"})
-    for case in cases:
-        div = division_from_golden(golden_dir, case)
-        monkeypatch.delenv("MBAMD_WALKG_PAIR", raising=False)
-        base = engine_lnl(lib, div, lk.MB_BEAGLE_SCALE_ALWAYS)
-        for env in (envs if full else (envs[0], envs[2])):
-            monkeypatch.setenv("MBAMD_WALKG_PAIR", "1")
-            for k in ("MBAMD_WALK_WAVES", "MBAMD_MAX_LDS_SLOTS"):
-                monkeypatch.delenv(k, raising=False)
-            for k, v in env.items():
-                monkeypatch.setenv(k, v)
-            for scaling in (lk.MB_BEAGLE_SCALE_ALWAYS, lk.MB_BEAGLE_SCALE_DYNAMIC):
-                got = engine_lnl(lib, div, scaling)
-                assert abs(got - base) <= 2e-7 * abs(base), (case, env, scaling, got, base)
-            check_golden_case(lib, oracle, golden_dir, case, lk.MB_BEAGLE_SCALE_ALWAYS)
-    monkeypatch.setenv("MBAMD_WALKG_PAIR", "1")
-    for k in ("MBAMD_WALK_WAVES", "MBAMD_MAX_LDS_SLOTS"):
-        monkeypatch.delenv(k, raising=False)
-    if full:
-        check_site_likelihoods(lib, oracle, division_from_golden(golden_dir, "replicase_m3"))
-        check_partial_update_and_reject(lib, oracle, division_from_golden(golden_dir, "avian_wag_g4"), lk.MB_BEAGLE_SCALE_DYNAMIC)
-    check_partial_update_and_reject(lib, oracle, division_from_golden(golden_dir, "synth_codon_m3"), lk.MB_BEAGLE_SCALE_ALWAYS)
-    for nstates in ((2, 8, 16) if full else (2, 16)):
-        check_generic_states(lib, oracle, nstates, 12, 300 if full else 100)

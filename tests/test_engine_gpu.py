@@ -641,9 +641,3 @@ def test_path_kernels_at_baseline_shapes(gpu, golden_dir, monkeypatch, case, swi
     bit-equal to the whole-tree walk kernels on the same lists and within REL_FP64 of the fp64 engine after every move
     (reference: the partial updates of src/mbbeagle.c:783-880)."""
     ec.check_path_kernels_at_bench_shape(gpu, golden_dir, monkeypatch, case, switch)
-
-
-def test_pair_walk(gpu, oracle, golden_dir, monkeypatch):
-    """The opt-in general-state walk k_walkg2 (a whole entry's operands in flight, the row-split pair of waves at 60-63 states) is
-    parity-green: it is not the product default because it measured no faster than k_walkg (profiles/r05_walkg_pair.txt)."""
-    ec.check_pair_walk(gpu, oracle, golden_dir, monkeypatch)

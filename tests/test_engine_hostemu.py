@@ -333,9 +333,3 @@ def test_parsimony_model_golden(emu, golden_dir):
 def test_general_state_path_kernel(emu, oracle, golden_dir, monkeypatch):
     """A move's root-ward path at 20 / 61 states: k_pathg == k_walkg bit for bit, both == the oracle."""
     ec.check_general_state_path_kernel(emu, oracle, golden_dir, monkeypatch)
-
-
-def test_pair_walk(emu, oracle, golden_dir, monkeypatch):
-    """The opt-in general-state walk k_walkg2 (a whole entry's operands in flight, the row-split pair of waves at 60-63 states) is
-    parity-green: it is not the product default because it measured no faster than k_walkg (profiles/r05_walkg_pair.txt)."""
-    ec.check_pair_walk(emu, oracle, golden_dir, monkeypatch, full=False)

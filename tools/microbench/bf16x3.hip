@@ -93,6 +93,60 @@ __global__ void k_numerics(const float* A, const float* B, float* D, int mode, i
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------- 2b. numerics, variants
+// split: 0 truncation (pieces all of one sign: what is dropped is a BIAS), 1 round-to-nearest-even (v_cvt_pk_bf16_f32: signed pieces,
+// half the magnitude);  nprod 6 | 9;  order: 0 small terms first inside each K-block, 1 inside each half of K (the walk's chunk),
+// 2 over the whole of K (all a3 b1 products, then all a1 b3, ... , all a1 b1 last: only the last few MFMAs round at full magnitude)
+__device__ __forceinline__ unsigned cvt_pk_rne(float a, float b)
+{
+    unsigned r;
+    asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+__global__ void k_numerics2(const float* A, const float* B, float* D, int split, int nprod, int order, int nkb, int ntile)
+{
+    const unsigned lane = threadIdx.x, h = lane >> 5, m = lane & 31;
+    const int KW = 16 * nkb;
+    for (int it = 0; it < ntile; ++it) {
+        u4 Ap[3][4], Bp[3][4];
+        for (int kb = 0; kb < nkb; ++kb)
+            for (int jj = 0; jj < 4; ++jj) {
+                const int k0 = 16 * kb + 8 * h + 2 * jj, k1 = k0 + 1;
+                float x0 = A[(32 * it + m) * KW + k0], x1 = A[(32 * it + m) * KW + k1], y0 = B[k0 * 32 + m], y1 = B[k1 * 32 + m];
+                for (int s = 0; s < 3; ++s) {
+                    unsigned pa, pb;
+                    if (split == 0) { pa = pack_hi(x0, x1); pb = pack_hi(y0, y1); }
+                    else { pa = cvt_pk_rne(x0, x1); pb = cvt_pk_rne(y0, y1); }
+                    Ap[s][kb][jj] = pa; Bp[s][kb][jj] = pb;
+                    x0 -= __uint_as_float(pa << 16); x1 -= __uint_as_float(pa & 0xFFFF0000u);
+                    y0 -= __uint_as_float(pb << 16); y1 -= __uint_as_float(pb & 0xFFFF0000u);
+                }
+            }
+        v16 acc = {};
+        // pairs (a piece, b piece), small first
+        const int pairs9[9][2] = {{2, 2}, {2, 1}, {1, 2}, {2, 0}, {0, 2}, {1, 1}, {1, 0}, {0, 1}, {0, 0}};
+        const int first = nprod == 9 ? 0 : 3;
+        const int span = order == 0 ? 1 : (order == 1 ? (nkb >= 2 ? nkb / 2 : 1) : nkb);
+        for (int k0 = 0; k0 < nkb; k0 += span)
+            for (int pr = first; pr < 9; ++pr)
+                for (int kb = k0; kb < k0 + span && kb < nkb; ++kb)
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf(Ap[pairs9[pr][0]][kb]), as_bf(Bp[pairs9[pr][1]][kb]), acc, 0, 0, 0);
+        for (int r = 0; r < 16; ++r) D[(32 * it + (r & 3) + 8 * (r >> 2) + 4 * h) * 32 + m] = acc[r];
+    }
+}
+// fp32 chain at a general shape (k ascending, two states per step)
+__global__ void k_numerics_f32(const float* A, const float* B, float* D, int nkb, int ntile)
+{
+    const unsigned lane = threadIdx.x, h = lane >> 5, m = lane & 31;
+    const int KW = 16 * nkb;
+    for (int it = 0; it < ntile; ++it) {
+        v16 acc = {};
+        for (int t = 0; t < KW / 2; ++t)
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(A[(32 * it + m) * KW + 2 * t + h], B[(2 * t + h) * 32 + m], acc, 0, 0, 0);
+        for (int r = 0; r < 16; ++r) D[(32 * it + (r & 3) + 8 * (r >> 2) + 4 * h) * 32 + m] = acc[r];
+    }
+}
+
 // ---------------------------------------------------------------------------------------------------------------- 3. timing
 // `n` child factors per wave.  B of factor i+1 = a cheap function of factor i's result (keeps the dependence of a tree walk).
 // mode 0: 62 fp32 MFMAs (T = 31 steps x 2 output tiles);  1 / 2: the split, 4 K-blocks x 2 tiles x 6 / 9 bf16 MFMAs, the B pieces
@@ -212,6 +266,33 @@ int main()
         hipLaunchKernelGGL(k_layout, dim3(1), dim3(64), 0, 0, dA, dB, dD, 0);
         hipMemcpy(D.data(), dD, D.size() * 4, hipMemcpyDeviceToHost);
         printf("   2^-70 x 2^-70 = 2^-140 (an fp32 denormal): device %.6g (exact %.6g)\n", D[0], std::ldexp(1.0, -140));
+        // HOW does it round?  element (0,0) = sum_k A[0][k] B[k][0]; every product below is exact in fp32 on its own
+        auto run = [&](std::vector<std::pair<float, float>> terms) {
+            std::fill(A.begin(), A.end(), 0.0f); std::fill(B.begin(), B.end(), 0.0f);
+            for (size_t k = 0; k < terms.size(); ++k) { A[k] = terms[k].first; B[k * 32] = terms[k].second; }
+            hipMemcpy(dA, A.data(), A.size() * 4, hipMemcpyHostToDevice); hipMemcpy(dB, B.data(), B.size() * 4, hipMemcpyHostToDevice);
+            hipLaunchKernelGGL(k_layout, dim3(1), dim3(64), 0, 0, dA, dB, dD, 0);
+            hipMemcpy(D.data(), dD, D.size() * 4, hipMemcpyDeviceToHost);
+            return D[0];
+        };
+        const float u = std::ldexp(1.0f, -23);       // ulp of 1
+        printf("   rounding of a sum of products (ulp = 2^-23; RNE / toward zero / device), results as (x - 1) / ulp:\n");
+        struct { const char* what; std::vector<std::pair<float, float>> t; double exact; } probes[] = {
+            {"1 + 0.75 ulp                         ", {{1.0f, 1.0f}, {0.75f, u}}, 1.0 + 0.75 * u},
+            {"1 + 0.25 ulp                         ", {{1.0f, 1.0f}, {0.25f, u}}, 1.0 + 0.25 * u},
+            {"1 + 1.75 ulp                         ", {{1.0f, 1.0f}, {1.75f, u}}, 1.0 + 1.75 * u},
+            {"1 + 8 x 0.125 ulp (= 1 ulp)          ", {{1.0f, 1.0f}, {0.125f, u}, {0.125f, u}, {0.125f, u}, {0.125f, u}, {0.125f, u}, {0.125f, u}, {0.125f, u}, {0.125f, u}}, 1.0 + u},
+            {"1 + 12 x 0.0625 ulp (= 0.75 ulp)     ", {{1.0f, 1.0f}, {0.0625f, u}, {0.0625f, u}, {0.0625f, u}, {0.0625f, u}, {0.0625f, u}, {0.0625f, u}, {0.0625f, u}, {0.0625f, u}, {0.0625f, u}, {0.0625f, u}, {0.0625f, u}, {0.0625f, u}}, 1.0 + 0.75 * u},
+            {"1 + 15 x 2^-10 ulp x 64 (= 0.9375ulp)", {{1.0f, 1.0f}, {0.0625f, u}, {0.0625f, u}, {0.0625f, u}, {0.0625f, u}, {0.0625f, u}, {0.0625f, u}, {0.0625f, u}, {0.0625f, u}, {0.0625f, u}, {0.0625f, u}, {0.0625f, u}, {0.0625f, u}, {0.0625f, u}, {0.0625f, u}, {0.0625f, u}}, 1.0 + 0.9375 * u},
+            {"1.5 + 1.5 x 2^-24 .. (1.5 + 0.75 ulp)", {{1.5f, 1.0f}, {0.75f, u}}, 1.5 + 0.75 * u},
+        };
+        for (auto& pr : probes) {
+            const float dev = run(pr.t);
+            const float rne = (float) pr.exact;
+            float rtz = rne; if ((double) rtz > pr.exact) rtz = std::nextafterf(rtz, 0.0f);
+            const double base = pr.t[0].first;
+            printf("     %s exact %.4f   RNE %.0f   toward zero %.0f   device %.0f\n", pr.what, (pr.exact - base) / u, (rne - base) / u, (rtz - base) / u, (dev - base) / u);
+        }
     }
     printf("2. numerics: D[64][32] = A[64][64] B[64][32], relative error of an element against fp64 (relative to the column's largest element)\n");
     {
@@ -256,6 +337,53 @@ int main()
             }
             const char* names[4] = {"fp32 MFMA chain (today)", "bf16 x 3, six products, small first", "bf16 x 3, six products, large first", "bf16 x 3, nine products"};
             for (int c = 0; c < 4; ++c) printf("   branch %-5g %-38s max %.3g  rms %.3g   (fp32 epsilon 5.96e-8)\n", shape == 0 ? 0.05 : (shape == 1 ? 0.5 : 3.0), names[c], sums[c][0], std::sqrt(sums[c][1] / count));
+        }
+    }
+    printf("2b. numerics, variants: signed relative error of an element against fp64: mean (bias), rms, max; units of 1e-8\n");
+    for (int S : {61, 20}) {
+        const int nkb = S > 32 ? 4 : 2, ntile = S > 32 ? 2 : 1, KW = 16 * nkb, MR = 32 * ntile;
+        std::vector<float> A(MR * KW), B(KW * 32), D(MR * 32);
+        std::vector<double> R(MR * 32);
+        struct Var { const char* name; int split, nprod, order; };
+        const Var vars[] = {{"fp32 MFMA chain (today)", -1, 0, 0}, {"truncated pieces, 6, per K-block", 0, 6, 0}, {"truncated pieces, 6, whole K", 0, 6, 2},
+                            {"rounded pieces, 6, per K-block", 1, 6, 0}, {"rounded pieces, 6, per half of K", 1, 6, 1}, {"rounded pieces, 6, whole K", 1, 6, 2},
+                            {"rounded pieces, 9, per half of K", 1, 9, 1}, {"rounded pieces, 9, whole K", 1, 9, 2}};
+        const int NV = sizeof(vars) / sizeof(vars[0]);
+        for (double t : {0.05, 1.0}) {
+            double mean[NV] = {}, sq[NV] = {}, mx[NV] = {};
+            long count = 0;
+            for (int rep = 0; rep < 60; ++rep) {
+                std::uniform_real_distribution<double> U(0, 1);
+                for (int i = 0; i < MR; ++i) {
+                    double row[64], sum = 0;
+                    for (int j = 0; j < KW; ++j) { row[j] = (i < S && j < S) ? std::pow(U(g), 6.0) : 0.0; sum += (j != i) ? row[j] : 0; }
+                    const double stay = std::exp(-t);
+                    for (int j = 0; j < KW; ++j) A[i * KW + j] = (float) (i < S && j < S ? (j == i ? stay : row[j] / sum * (1 - stay)) : 0.0);
+                }
+                for (int p = 0; p < 32; ++p) {
+                    double col[64], m = 0;
+                    for (int j = 0; j < KW; ++j) { col[j] = j < S ? std::exp(-30.0 * std::pow(U(g), 2.0)) : 0.0; m = std::max(m, col[j]); }
+                    int e; std::frexp(m, &e);
+                    for (int j = 0; j < KW; ++j) B[j * 32 + p] = (float) std::ldexp(col[j], -e);
+                }
+                for (int i = 0; i < MR; ++i) for (int p = 0; p < 32; ++p) {
+                    double sum = 0;
+                    for (int j = 0; j < KW; ++j) sum += (double) A[i * KW + j] * B[j * 32 + p];
+                    R[i * 32 + p] = sum;
+                }
+                hipMemcpy(dA, A.data(), A.size() * 4, hipMemcpyHostToDevice); hipMemcpy(dB, B.data(), B.size() * 4, hipMemcpyHostToDevice);
+                for (int c = 0; c < NV; ++c) {
+                    if (vars[c].split < 0) hipLaunchKernelGGL(k_numerics_f32, dim3(1), dim3(64), 0, 0, dA, dB, dD, nkb, ntile);
+                    else hipLaunchKernelGGL(k_numerics2, dim3(1), dim3(64), 0, 0, dA, dB, dD, vars[c].split, vars[c].nprod, vars[c].order, nkb, ntile);
+                    hipMemcpy(D.data(), dD, D.size() * 4, hipMemcpyDeviceToHost);
+                    for (int i = 0; i < S; ++i) for (int p = 0; p < 32; ++p) {
+                        const double err = (D[i * 32 + p] - R[i * 32 + p]) / R[i * 32 + p];
+                        mean[c] += err; sq[c] += err * err; mx[c] = std::max(mx[c], std::fabs(err));
+                    }
+                }
+                count += S * 32;
+            }
+            for (int c = 0; c < NV; ++c) printf("   %d states, branch %-5g %-36s bias %+7.3f  rms %7.3f  max %7.2f\n", S, t, vars[c].name, mean[c] / count * 1e8, std::sqrt(sq[c] / count) * 1e8, mx[c] * 1e8);
         }
     }
     printf("3. one child factor at 61 states, cycles per factor and wave (s_memrealtime 100 MHz ticks x clock / 100 MHz), 256 workgroups\n");
