@@ -47,6 +47,17 @@ __device__ __forceinline__ float mbd_max_lane_xor32(float v)
 #define MBD_COMPILER_FENCE() asm volatile("" ::: "memory")
 #define MBD_PIN_VGPR(x) asm volatile("" :: "v"(x) : "memory")                            // the value is in its register HERE
 #define MBD_SPIN_PAUSE() __builtin_amdgcn_s_sleep(1)
+// A bounded window on memory (a raw buffer resource): loads through it take a 32-bit per-lane offset and a wave-uniform offset, need
+// no 64-bit address arithmetic in the VALU, and a lane whose offset lies OUTSIDE the window reads zeros without touching memory --
+// how k_walkb keeps the operand loads a chunk does not need in its instruction sequence for free.
+typedef __amdgpu_buffer_rsrc_t mbd_buf;
+__device__ __forceinline__ mbd_buf mbd_make_buffer(const void* p, unsigned bytes) { return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, (int) bytes, 0x00020000); }
+__device__ __forceinline__ mbd_f4 mbd_buffer_load_f4(mbd_buf b, unsigned lane_offset, unsigned wave_offset)
+{
+    typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+    return __builtin_bit_cast(mbd_f4, (u32x4) __builtin_amdgcn_raw_buffer_load_b128(b, (int) lane_offset, (int) wave_offset, 0));
+}
+#define MBD_OUTSIDE 0x80000000u                      // a lane offset outside every window
 __device__ __forceinline__ int mbd_uniform(int v) { return __builtin_amdgcn_readfirstlane(v); }
 }  // namespace mbamd
 #endif

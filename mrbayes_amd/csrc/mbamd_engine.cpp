@@ -742,7 +742,7 @@ int Instance::configureWalk()
         if (!std::getenv("MBAMD_WALK_WAVES") && !std::getenv("MBAMD_MAX_LDS_SLOTS")) {   // a single-wave program may use the LDS of the whole workgroup
             const long wgsG = (long) (Ppad / MBAMD_WG_TW) * K;
             const int perCUG = (int) std::max(1L, (wgsG + numCU - 1) / numCU);
-            w4.maxSlots1 = std::max(w4.maxSlots, std::min(24, (int) (((160 * 1024) / std::min(perCUG, 32) - 64 - MBAMD_WG_STAGE) / (int) slotBytes) - 1));
+            w4.maxSlots1 = std::max(w4.maxSlots, std::min(24, (int) (((160 * 1024) / std::min(perCUG, 32) - 64 - MBAMD_WG_STAGE) / (int) slotBytes)));
         }
         w4.memSlots = false;
         w4.leadNops = MBAMD_WG_LEAD; w4.unroll = 3; w4.tailNops = MBAMD_WG_TAIL;
@@ -788,14 +788,14 @@ void Instance::wgGeometry(int lists, int& W, int& slots) const
     const long wgs = (long) (Ppad / MBAMD_WG_TW) * K * lists;
     const int perCU = (int) std::max(1L, (wgs + numCU - 1) / numCU);
     const int ldsPerWG = (160 * 1024) / std::min(perCU, 32) - 64;
-    auto slotsFor = [&](int w) { return (ldsPerWG / w - MBAMD_WG_STAGE) / slotBytes - 1; };      // (- 1: the staging slot)
+    auto slotsFor = [&](int w) { return (ldsPerWG / w - MBAMD_WG_STAGE) / slotBytes; };
     long want = std::max(1L, std::min((long) maxW, ((long) wavesPerCU * numCU + wgs / 2) / wgs));
     W = 1;
     while (W * 2 <= want) W *= 2;
     while (W > 1 && slotsFor(W) < 4) W /= 2;
     if (const char* e = std::getenv("MBAMD_WALK_WAVES")) W = std::max(1, std::min(maxW, std::atoi(e)));
     slots = std::max(3, std::min(24, slotsFor(W)));
-    if (const char* e = std::getenv("MBAMD_MAX_LDS_SLOTS")) slots = std::max(1, std::min((160 * 1024 / W - MBAMD_WG_STAGE) / slotBytes - 1, std::atoi(e)));
+    if (const char* e = std::getenv("MBAMD_MAX_LDS_SLOTS")) slots = std::max(1, std::min((160 * 1024 / W - MBAMD_WG_STAGE) / slotBytes, std::atoi(e)));
 }
 
 // 4-state path: one tip's state masks (bit i = state i compatible) -> four 64-bit bitplanes per pattern block
@@ -1600,12 +1600,11 @@ int Instance::buildWalk(Plan& plan, const BeagleOperation* ops, int n, const int
         const uint32_t pbuf = wg ? (uint32_t) K * slotb : (uint32_t) ((size_t) (Ppad / 64) * K);
         const uint32_t ebuf = (uint32_t) K * 64u, mbuf = wg ? (uint32_t) (matrixFloats * 4) : (uint32_t) K * 64u;
         int prevKept = -1;                           // (20/61-state walk) slot the previous operation of the same program kept its result in
-        int prevDst[2] = {-1, -1};                   // (20/61-state walk) destination buffers of the two entries before this one, same program
         for (size_t i = 0; i < t.prog.size(); ++i) {
             const Walk4Template::Entry& te = t.prog[i];
             Walk4Entry& e = w4table[sg.first + i];
             std::memset(&e, 0, sizeof e);
-            if (i % (size_t) t.entries == 0) { prevKept = -1; prevDst[0] = prevDst[1] = -1; }
+            if (i % (size_t) t.entries == 0) prevKept = -1;
             uint32_t flags = te.flags, mode = SCALE_NONE, keep = 0;
             e.ewrite = (uint32_t) scratchScale * ebuf;
             e.eread = (uint32_t) scratchScale * ebuf;
@@ -1628,10 +1627,6 @@ int Instance::buildWalk(Plan& plan, const BeagleOperation* ops, int n, const int
                     if (!op.tip1 && te.c1slot != 0xFF && (int) te.c1slot == prevKept) flags |= MBAMD_WG_PREV1;
                     if (!op.tip2 && te.c2slot != 0xFF && (int) te.c2slot == prevKept) flags |= MBAMD_WG_PREV2;
                     prevKept = te.dslot != 0xFF ? (int) te.dslot : -1;
-                    // k_walkg stores a result one entry late: rows read back from HBM two entries after they were made (the
-                    // scheduler never asks for them sooner) are requested right behind that store
-                    if (((flags & MBAMD_WG_MEM1) && (op.c1 == prevDst[0] || op.c1 == prevDst[1])) ||
-                        ((flags & MBAMD_WG_MEM2) && (op.c2 == prevDst[0] || op.c2 == prevDst[1]))) flags |= MBAMD_WG_TIGHT;
                     mode = op.scaleWrite >= 0 ? SCALE_WRITE : (op.scaleRead >= 0 ? SCALE_READ : SCALE_NONE);
                     if (op.scaleWrite >= 0) e.ewrite = (uint32_t) op.scaleWrite * ebuf;
                     if (op.scaleRead >= 0) e.eread = (uint32_t) op.scaleRead * ebuf;
@@ -1639,8 +1634,6 @@ int Instance::buildWalk(Plan& plan, const BeagleOperation* ops, int n, const int
                 } else {
                     e.ctl = (flags & (MBAMD_W4_NOP | MBAMD_W4_BARRIER)) | MBAMD_W4_NOP;
                 }
-                prevDst[1] = prevDst[0];
-                prevDst[0] = te.op >= 0 ? seg[te.op].dst : -1;
                 continue;
             }
             if (te.pfOp[0] >= 0) {                          // PF entry

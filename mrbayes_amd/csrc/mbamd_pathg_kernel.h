@@ -70,9 +70,7 @@ k_pathg(ARGS AA)
 #pragma unroll
             for (int r = 0; r < ACC; ++r) f[it][r] = 0.0f;
         if constexpr (BF) {
-            constexpr int CHW = Sh::CHW;                 // (k_walkg's arithmetic, chunk by chunk: the same bits)
-#pragma unroll
-            for (int c = 0; c < CHW; ++c) wg_contract_bf16<NT, NKB / CHW, TP / CHW>(a + c * (NAV / CHW), b + c * (TP / CHW), f);
+            wg_contract_bf16<NT, NKB, TP>(a, b, f);      // (k_walkg's arithmetic: the same bits)
         } else {
 #pragma unroll
             for (int tc = 0; tc < TP; ++tc)

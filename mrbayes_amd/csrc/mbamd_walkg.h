@@ -42,7 +42,6 @@ namespace mbamd {
 #define MBAMD_WG_LEAD     2      // leading NOP entries (they fill the operand pipeline)
 #define MBAMD_WG_TAIL     3      // trailing NOP entries (descriptor read-ahead)
 #define MBAMD_WG_STAGE    256    // bytes per wave in front of its slots (cumulative-exponent hand-over)
-#define MBAMD_WG_TIGHT    0x1000u   // a child read from HBM is the result this wave produced two entries earlier: its (delayed) store completes before the operands are requested
 #define MBAMD_WG_PREV1    0x2000u   // child 1 / 2 is the result of the entry this wave executed just before (and sits in a slot too)
 #define MBAMD_WG_PREV2    0x4000u
 
@@ -57,16 +56,17 @@ namespace mbamd {
 // ---- round 6: the contraction on the 16-BIT matrix cores, in fp32 arithmetic (profiles/r06_bf16x3.txt) ----------------------------
 // v_mfma_f32_32x32x2_f32 runs at the fp32 VECTOR rate (64 cycles for 4 096 flops) and shares the SIMD's vector issue port: nothing
 // else of the SIMD runs beside it.  v_mfma_f32_32x32x16_bf16 does 8 x the contraction depth in half the time on a pipe of its own.
-// From 16 states on a factor is therefore formed as   sum over pieces  a = a1 + a2 + a3,  b = b1 + b2 + b3   (each piece the
-// round-to-nearest bf16 of what the larger pieces left: 3 x 8 = 24 significant bits, the split is EXACT)  of the six products of
-// order <= 4 -- a3 b1, a1 b3, a2 b2, a2 b1, a1 b2, a1 b1, over the whole contraction in THAT order, smallest first: every product of
-// two bf16 is exact in the fp32 accumulator, what is dropped (a2 b3, a3 b2, a3 b3) is below 2^-25 of the result, and only the last
-// few accumulations round at full magnitude.  Measured against fp64 on transition-matrix x partials products: rms error 6.2e-8
-// (61 states) / 5.3e-8 (20) where the fp32 MFMA chain has 10.1e-8 / 6.2e-8.  The A pieces are made once, by the matrix kernel
+// From MBAMD_WG_BF_MIN states on a factor is therefore formed as   sum over pieces  a = a1 + a2 + a3,  b = b1 + b2 + b3   (each piece
+// the round-to-nearest bf16 of what the larger pieces left: 3 x 8 = 24 significant bits, the split is EXACT)  of the six products of
+// order <= 4 -- a3 b1, a1 b3, a2 b2, a2 b1, a1 b2, a1 b1, in THAT order, smallest first, K-block (16 states) by K-block: every
+// product of two bf16 is exact, what is dropped (a2 b3, a3 b2, a3 b3) is below 2^-25 of the result.  Measured against fp64 on
+// transition-matrix x partials products (profiles/r06_bf16x3.txt): rms error 9.4e-8 at 61 states where the fp32 MFMA chain has
+// 10.1e-8; the matrix core aligns its addends to the largest and truncates below one guard bit, which shows as a bias of
+// -3e-8 per factor (the fp32 chain: -2.5e-8).  The A pieces are made once, by the matrix kernel
 // (wg_table_put); the B pieces by the consumer, from the fp32 rows in its registers (11 VALU instructions per two values, beside
 // the MFMAs).  Blocks in HBM and in LDS, tips, exponents: unchanged -- an fp32 [T][64] block is both kernels' operand.
 #if !defined(MBAMD_WG_BF_MIN)
-#define MBAMD_WG_BF_MIN 16       // state counts from here on contract on the 16-bit matrix cores
+#define MBAMD_WG_BF_MIN 40       // state counts from here on contract on the 16-bit matrix cores
 #endif
 __host__ __device__ inline bool wg_bf16(int S) { return S >= MBAMD_WG_BF_MIN; }
 __host__ __device__ inline int wg_kblocks(int S) { return (S + 15) / 16; }                // NKB: contraction blocks of 16 states
@@ -95,8 +95,7 @@ __host__ __device__ inline int wg_subtables(int S) { return S / MBAMD_WG_TW + 1;
 __host__ __device__ inline unsigned wg_block_bytes(int S) { return (unsigned) wg_pairs_padded(S) * 256u; }   // one (tile, buffer, category) = one LDS slot
 __host__ __device__ inline size_t wg_table_floats(int S) { return ((size_t) wg_rows(S) + (size_t) wg_subtables(S) * wg_gather_rows(S)) * 64; }   // per category
 // W = subtree bins of a workgroup = its working waves
-// per wave: the hand-over area, nslots result slots, one staging slot (k_walkg: results travel to HBM from LDS, an entry later)
-__host__ __device__ inline size_t wg_lds_bytes(int W, int nslots, int S) { return (size_t) W * (MBAMD_WG_STAGE + (size_t) (nslots + 1) * wg_block_bytes(S)); }
+__host__ __device__ inline size_t wg_lds_bytes(int W, int nslots, int S) { return (size_t) W * (MBAMD_WG_STAGE + (size_t) nslots * wg_block_bytes(S)); }
 // A block holds [TP rows][64 lanes]: row t, lane TW h + p = state KS t + h of pattern p; V consecutive rows are interleaved
 // per lane so that one dword / dwordx2 / dwordx4 per lane moves V rows (256 B - 1 KiB contiguous per wave instruction).
 // float offset of (row r, lane / column c) inside a block or table:

@@ -30,9 +30,6 @@ template <int SC> struct WgShape {
     static constexpr int TP = (T + V - 1) / V * V, NAP = BF ? 4 * 3 * NT * NKB : (TP * NT + VA - 1) / VA * VA;
     static constexpr int NGR = BF ? ((T < ACC ? T : ACC) * NT + 3) / 4 * 4 : NAP;   // rows of one tip-gather table
     static constexpr int NG = ((T < ACC ? T : ACC) * NT + VA - 1) / VA;             // register groups a compact tip's gather needs
-    // chunks per child factor in k_walkg (its CH; MBAMD_WG_DISPATCH).  With bf16 pieces the products are ordered inside a chunk, so
-    // every kernel that must give k_walkg's bits (k_pathg) forms a factor in the same chunks
-    static constexpr int CHW = SC >= 60 ? 2 : 1;
     typedef WgVecT<V> Vb;                            // block rows (B operand, results)
     typedef WgVecT<VA> Va;                           // table rows (A operand, tip gathers)
     typedef typename Vb::type vec;
@@ -55,30 +52,31 @@ __device__ __forceinline__ void wg_split_pair(float v0, float v1, unsigned& p, u
     const float s0 = r0 - __builtin_bit_cast(float, q << 16), s1 = r1 - __builtin_bit_cast(float, q & 0xFFFF0000u);
     w = mbd_cvt_pk_bf16(s0, s1);
 }
-// One child factor (or one chunk of its K-blocks) on the 16-bit matrix cores: f[it] += sum over the chunk's K-blocks and the six
-// piece pairs, SMALLEST PRODUCTS FIRST over the whole chunk (only the last accumulations round at full magnitude).
+// One child factor (or one chunk of its K-blocks) on the 16-bit matrix cores: f[it] += sum over the chunk's K-blocks, K-BLOCK BY
+// K-BLOCK, and inside a K-block over the six piece pairs SMALLEST PRODUCTS FIRST (the small ones meet while the accumulator's own
+// contribution from this K-block is still small).  The order does not depend on how a kernel cuts a child into chunks: k_walkg,
+// k_walkb and k_pathg give the same bits.
 //   a     the chunk's table operands, index (kb NT + it) 3 + piece (wg_table_put)
 //   rows  the child's block rows of the chunk: K-block kb = rows 8 kb .. 8 kb + 7 (NR of them exist; the rest are zero)
 template <int NT, int NKBC, int NR, class VECA>
 __device__ __forceinline__ void wg_contract_bf16(const VECA* a, const float* rows, mbd_acc16 (&f)[NT])
 {
-    mbd_f4 pc[3][NKBC];
+    constexpr int PA[6] = {2, 0, 1, 1, 0, 0}, PB[6] = {0, 2, 1, 0, 1, 0};     // a3 b1, a1 b3, a2 b2, a2 b1, a1 b2, a1 b1
 #pragma unroll
-    for (int kb = 0; kb < NKBC; ++kb)
+    for (int kb = 0; kb < NKBC; ++kb) {
+        mbd_f4 pc[3];
 #pragma unroll
         for (int jj = 0; jj < 4; ++jj) {
             const int t0 = 8 * kb + 2 * jj;
             unsigned p = 0, q = 0, w = 0;
             if (t0 < NR) wg_split_pair(rows[t0 < NR ? t0 : 0], t0 + 1 < NR ? rows[t0 + 1 < NR ? t0 + 1 : 0] : 0.0f, p, q, w);
-            pc[0][kb][jj] = __builtin_bit_cast(float, p); pc[1][kb][jj] = __builtin_bit_cast(float, q); pc[2][kb][jj] = __builtin_bit_cast(float, w);
+            pc[0][jj] = __builtin_bit_cast(float, p); pc[1][jj] = __builtin_bit_cast(float, q); pc[2][jj] = __builtin_bit_cast(float, w);
         }
-    constexpr int PA[6] = {2, 0, 1, 1, 0, 0}, PB[6] = {0, 2, 1, 0, 1, 0};     // a3 b1, a1 b3, a2 b2, a2 b1, a1 b2, a1 b1
 #pragma unroll
-    for (int pr = 0; pr < 6; ++pr)
+        for (int pr = 0; pr < 6; ++pr)
 #pragma unroll
-        for (int kb = 0; kb < NKBC; ++kb)
-#pragma unroll
-            for (int it = 0; it < NT; ++it) f[it] = mbd_mfma_bf16_32x32x16(a[(kb * NT + it) * 3 + PA[pr]], pc[PB[pr]][kb], f[it]);
+            for (int it = 0; it < NT; ++it) f[it] = mbd_mfma_bf16_32x32x16(a[(kb * NT + it) * 3 + PA[pr]], pc[PB[pr]], f[it]);
+    }
 }
 struct WgDesc {
     Walk4Entry e;
@@ -126,7 +124,6 @@ k_walkg(ARGS AA)
     static_assert(BF || (TPC * NT) % VA == 0, "chunk geometry (fp32 tables)");
     static_assert(!BF || (NKB % CH == 0 && (CH == 1 || TP == 8 * NKB)), "chunk geometry (bf16 tables: whole K-blocks)");
     static_assert(NG <= NAVC, "a compact tip's gather rows must lie in the first chunk");
-    static_assert(CH == Sh::CHW, "k_pathg forms its factors in WgShape::CHW chunks");
     constexpr unsigned SLOTB = TP * 256u;
     const unsigned lane = threadIdx.x & 63, half = lane / TW, col = lane % TW;      // half: which of the KS states of a row
     int wave = mbd_wave_index();
@@ -144,8 +141,7 @@ k_walkg(ARGS AA)
     const unsigned xcd = blockIdx.x & 7u, pos = blockIdx.x >> 3;
     const unsigned tile = (pos / KL) * 8u + xcd, k = (pos % KL) % K, list = (pos % KL) / K;
     if (tile >= (unsigned) A.ntiles) return;
-    // a wave's LDS: the hand-over area, its nslots result slots, and one STAGING slot for results no slot was assigned to
-    char* const mine = reinterpret_cast<char*>(lds_walkg) + (size_t) wave * (MBAMD_WG_STAGE + (size_t) (A.nslots + 1) * SLOTB);
+    char* const mine = reinterpret_cast<char*>(lds_walkg) + (size_t) wave * (MBAMD_WG_STAGE + (size_t) A.nslots * SLOTB);
     vec* const slots = reinterpret_cast<vec*>(mine + MBAMD_WG_STAGE) + lane;          // this lane's V rows of row group 0, slot 0
     // wave-uniform bases; the entries hold byte offsets from them
     char* const P0 = reinterpret_cast<char*>(A.partials) + (size_t) tile * A.tileBytes + (size_t) k * SLOTB;
@@ -165,23 +161,6 @@ k_walkg(ARGS AA)
     for (int i = 0; i < TVC; ++i) X.b[i] = Y.b[i] = Z.b[i] = Vb::splat(0.0f);
     int er = 0;                                      // stored exponent of the entry about to run (SCALE_READ)
     int cum_e[MBAMD_WG_MAXLISTS] = {0, 0, 0, 0};
-    // DELAYED RESULT STORES (round 6).  vmcnt is one in-order counter for loads and stores: a wait for operands requested after a
-    // result store is a wait for that store -- and every entry's second chunk of operands used to be requested right behind the
-    // previous entry's stores (a memory round trip per entry with nothing else to run, profiles/r05_walkg_pair.txt "operands").
-    // An entry's result now goes to LDS only (its slot, or the staging slot); the NEXT entry writes it to HBM from there, at the
-    // top of its last chunk -- behind every operand request whose wait follows within a chunk's time.  Pending: where from, where to.
-    unsigned pend_slot = (unsigned) A.nslots * SLOTB, pend_dst = DA.e.dst, pend_ew = DA.e.ewrite;    // (entry 0 is a no-operation: the scratch block)
-    int pend_e = 0;
-    auto flush_pending = [&]() {
-        const vec* src = reinterpret_cast<const vec*>(reinterpret_cast<const char*>(slots) + pend_slot);
-        vec t[TV];
-#pragma unroll
-        for (int i = 0; i < TV; ++i) t[i] = src[i * 64];
-        MBAMD_AS_GLOBAL vec* pd = reinterpret_cast<MBAMD_AS_GLOBAL vec*>((uintptr_t) (P0 + pend_dst)) + lane;
-#pragma unroll
-        for (int i = 0; i < TV; ++i) __builtin_nontemporal_store(t[i], pd + i * 64);   // 64 * V * 4 contiguous bytes per instruction
-        __builtin_nontemporal_store((int8_t) pend_e, as_global(E0 + pend_ew) + col);   // (every lane group holds the same e: no exec-mask branch)
-    };
 
     // operands of chunk q (child q / CH, part q % CH) of entry d -> register set o: NAVC loads outside any branch
     // (+ TVC for a child that lives in HBM)
@@ -200,15 +179,20 @@ k_walkg(ARGS AA)
         const bool idle = CH > 1 && ((tip && h > 0) || (ctl & MBAMD_W4_NOP));
         const unsigned aoff = idle ? 0u : (tip ? ((unsigned) NAP + (s / TW) * (unsigned) NGR) * 256u + ((s % TW) * KS + half) * (unsigned) (VA * 4) : lane * (unsigned) (VA * 4));
         const MBAMD_AS_GLOBAL vecA* pa = reinterpret_cast<const MBAMD_AS_GLOBAL vecA*>((uintptr_t) (Mk + moff) + aoff) + (idle ? 0 : h * NAVC * 64);
-        if constexpr (BF && NG < NAVC) {
-            // bf16 tables: an interior child's operands are NAVC loads, a tip's gather rows the first NG of them -- the others stay in
-            // the sequence and read the tip's first row again
-            const int stride = idle ? 0 : 64, rest = (idle || tip) ? 0 : 64;
-            const MBAMD_AS_GLOBAL vecA* pr = (idle || tip) ? pa : pa + NG * 64;
+        if constexpr (BF) {
+            // bf16 tables: an interior child's operands are NAVC loads, a tip's gather rows the first NG of them (first chunk only).
+            // All of them go through a window on the child's table (mbd_buf): one 32-bit lane offset instead of a 64-bit address per
+            // load, and the loads a chunk does not need keep their place in the sequence with a lane offset OUTSIDE the window --
+            // zeros, no memory request.
+            const bool none = (tip && h > 0) || (ctl & MBAMD_W4_NOP);
+            const mbd_buf win = mbd_make_buffer(Mk + moff, A.tabBytes);
+            const unsigned front = none ? MBD_OUTSIDE : (tip ? (s / TW) * (unsigned) (NGR * 256) + ((s % TW) * KS + half) * 16u : lane * 16u);
+            const unsigned back = (none || tip) ? MBD_OUTSIDE : lane * 16u;
+            const unsigned base = tip ? (unsigned) NAP * 256u : (unsigned) (h * NAVC) * 1024u;
 #pragma unroll
-            for (int i = 0; i < NG; ++i) o.a[i] = pa[i * stride];
+            for (int i = 0; i < NG && i < NAVC; ++i) o.a[i] = mbd_buffer_load_f4(win, front, base + i * 1024u);
 #pragma unroll
-            for (int i = NG; i < NAVC; ++i) o.a[i] = pr[(i - NG) * rest];
+            for (int i = NG; i < NAVC; ++i) o.a[i] = mbd_buffer_load_f4(win, back, base + i * 1024u);
         } else if constexpr (CH > 1) {
             const int stride = idle ? 0 : 64;
 #pragma unroll
@@ -280,7 +264,6 @@ k_walkg(ARGS AA)
         const unsigned ctl = cur.e.ctl;
         if (ctl & MBAMD_W4_BARRIER) {
             // values other waves produced in the previous phase are read from here on: drain this wave's stores, meet
-            flush_pending();                         // (the previous entry's result is still in LDS only; the regular flush below repeats it, harmlessly)
             MBD_DRAIN_ALL();
             MBD_WG_BARRIER();
             MBD_COMPILER_FENCE();
@@ -324,12 +307,6 @@ k_walkg(ARGS AA)
         auto chunk = [&](auto qc) {
             constexpr int q = decltype(qc)::value;
             if constexpr (q < NQ) {
-                if constexpr (q == NQ - 1) {
-                    flush_pending();                 // the previous entry's result: LDS -> HBM
-                    // the operands requested next may include rows this wave stored a moment ago (a result evicted two entries
-                    // back and read again by the next entry, marked by the host): those stores complete first
-                    if (n1.e.ctl & MBAMD_WG_TIGHT) MBD_DRAIN_VMEM();
-                }
                 constexpr int qf = q + DEPTH;        // the chunk fetched now
                 if constexpr (qf < NQ) {
                     WgDesc t;
@@ -387,12 +364,15 @@ k_walkg(ARGS AA)
         vec ov[TV];
 #pragma unroll
         for (int t = 0; t < TP; ++t) Vb::set(ov[t / V], t % V, out[t] * sc);   // (exact: |e| <= 126; 2^0 needs no branch)
-        // the result stays in LDS: in the slot the program assigned, else in the staging slot; the next entry stores it
-        const unsigned slot_off = (ctl & MBAMD_W4_KEEP) ? ((ctl >> 16) & 0xFFu) * SLOTB : (unsigned) A.nslots * SLOTB;
-        vec* keep = reinterpret_cast<vec*>(reinterpret_cast<char*>(slots) + slot_off);
+        if (ctl & MBAMD_W4_KEEP) {
+            vec* keep = reinterpret_cast<vec*>(reinterpret_cast<char*>(slots) + ((ctl >> 16) & 0xFFu) * SLOTB);
 #pragma unroll
-        for (int i = 0; i < TV; ++i) keep[i * 64] = ov[i];
-        pend_slot = slot_off; pend_dst = dst; pend_ew = ewrite; pend_e = e;
+            for (int i = 0; i < TV; ++i) keep[i * 64] = ov[i];
+        }
+        MBAMD_AS_GLOBAL vec* pd = reinterpret_cast<MBAMD_AS_GLOBAL vec*>((uintptr_t) (P0 + dst)) + lane;
+#pragma unroll
+        for (int i = 0; i < TV; ++i) __builtin_nontemporal_store(ov[i], pd + i * 64);   // 64 * V * 4 contiguous bytes per instruction
+        __builtin_nontemporal_store((int8_t) e, as_global(E0 + ewrite) + col);   // (every lane group holds the same e: no exec-mask branch)
     };
     // the sets rotate by NQ positions per entry; three entries bring every (NS <= 3) rotation back to the start
     for (int j = 0; j < n; j += 3) {
@@ -400,7 +380,6 @@ k_walkg(ARGS AA)
         step(DB, DC, DA, wg_pick<NQ % NS>(X, Y, Z), wg_pick<(NQ + 1) % NS>(X, Y, Z), wg_pick<(NQ + 2) % NS>(X, Y, Z), j + 1);
         step(DC, DA, DB, wg_pick<(2 * NQ) % NS>(X, Y, Z), wg_pick<(2 * NQ + 1) % NS>(X, Y, Z), wg_pick<(2 * NQ + 2) % NS>(X, Y, Z), j + 2);
     }
-    flush_pending();                                 // the last entry's result
     // cumulative exponents of this workgroup's TW columns: the waves' sums meet in LDS, wave 0 owns the memory update
     int* const stage = reinterpret_cast<int*>(mine);
 #pragma unroll
@@ -413,7 +392,7 @@ k_walkg(ARGS AA)
             MBAMD_SYNC();
             if (wave == 0)
                 for (int w = 1; w < W; ++w)
-                    sum += reinterpret_cast<const int*>(reinterpret_cast<const char*>(lds_walkg) + (size_t) w * (MBAMD_WG_STAGE + (size_t) (A.nslots + 1) * SLOTB))[lane];
+                    sum += reinterpret_cast<const int*>(reinterpret_cast<const char*>(lds_walkg) + (size_t) w * (MBAMD_WG_STAGE + (size_t) A.nslots * SLOTB))[lane];
         }
         if (wave == 0 && half == 0) {
             int32_t* d = A.cum[q] + (size_t) k * A.Ppad + (size_t) tile * TW + col;

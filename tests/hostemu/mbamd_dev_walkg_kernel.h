@@ -66,6 +66,16 @@ inline float mbd_max_lane_xor32(float v)
 #define MBD_COMPILER_FENCE() ((void) 0)
 #define MBD_PIN_VGPR(x) ((void) (x))
 #define MBD_SPIN_PAUSE() mbamd_emu_yield()
+struct mbd_buf { const char* p; unsigned bytes; };
+inline mbd_buf mbd_make_buffer(const void* p, unsigned bytes) { return mbd_buf{static_cast<const char*>(p), bytes}; }
+inline mbd_f4 mbd_buffer_load_f4(mbd_buf b, unsigned lane_offset, unsigned wave_offset)
+{
+    const unsigned long long off = (unsigned long long) lane_offset + wave_offset;
+    mbd_f4 v = (mbd_f4) (0.0f);
+    if (off + 16 <= b.bytes) std::memcpy(&v, b.p + off, 16);
+    return v;
+}
+#define MBD_OUTSIDE 0x80000000u
 inline int mbd_uniform(int v) { return v; }
 }  // namespace mbamd
 #endif
