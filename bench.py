@@ -373,6 +373,12 @@ def measure(args, cfg, steps, warmup, rank, local_rank, world, dist, device, emu
     if issued > 0:
         roof["mfma_issued_tflops"] = issued / t_all / 1e12
         roof["mfma_issued_frac"] = t_mfma / t_all
+        if S >= 40:
+            # the matrix work of the contraction counted as what the fp32 matrix path issues for it (round 5's PMC count, a property
+            # of the workload) against the fp32 matrix peak; the kernel itself issues it as bf16 pieces on the 16-bit pipe
+            roof["mfma_issued_note"] = "fp32-equivalent matrix flops (v_mfma_f32_32x32x2_f32 count of the workload) / 157.3 TFLOP/s; issued as 6 x bf16 products, see arith"
+            if pmc and pmc.get("mfma_bf16_busy_cycles"):
+                roof["bf16_pipe_busy_frac"] = pmc["mfma_bf16_busy_cycles"] / 1024.0 / (t_all * 2.1e9)
     roof["kernel"] = impl
     roof["all_kernels_ms_per_step"] = all_ms
     roof["partials_kernel_ms_per_step"] = k_ms
@@ -414,6 +420,48 @@ def measure(args, cfg, steps, warmup, rank, local_rank, world, dist, device, emu
             out["cpu_baseline"] = {"value": None, "unit": "M updates/s", "cores": 1, "kind": "port",
                                    "sample": "failed: %r" % (exc,)}
     return out
+
+
+ARITH_NOTE = ("fp32 conditional likelihoods, fp32 accumulation.  From 40 states on the matrix-vector products run on v_mfma_f32_32x32x16_bf16 with every "
+              "fp32 operand as the exact sum of three bf16 pieces (six products of order <= 4, K-block by K-block, smallest first: "
+              "profiles/r06_bf16x3.txt); fewer states: v_mfma_f32_32x32x2_f32.  site_error_vs_fp64_engine: per-site log-likelihood "
+              "against the double-precision engine (itself within 1e-11 of the reference's fp64 build)")
+
+
+def site_error(cfg, lib):
+    """Per-site log-likelihood of the single-precision engine of `lib` against its double-precision engine, on the workload."""
+    import numpy as np
+    from mrbayes_amd import likelihood as lk
+    from mrbayes_amd.division import division_from_golden
+    case = CONFIGS[cfg][0]
+    div = division_from_golden(GOLD, case)
+    vals = {}
+    for dp in (True, False):
+        bd = lk.BeagleDivision(div, lib, scaling=lk.MB_BEAGLE_SCALE_ALWAYS, double_precision=dp)
+        lnl = bd.LogLike(0)
+        site = np.array(bd.inst.get_site_log_likelihoods(), dtype=np.float64)
+        bd.finalize()
+        vals[dp] = (lnl, site)
+    d = vals[False][1] - vals[True][1]
+    return {"max": float(np.abs(d).max()), "rms": float(np.sqrt((d * d).mean())), "mean": float(d.mean()),
+            "lnL_error": vals[False][0] - vals[True][0], "patterns": int(d.size)}
+
+
+def arithmetic_report(args, cfg, o, device, lib):
+    """The general-state workloads: how far the fp32 engine is from the fp64 engine per site -- for the product's kernels and, where the
+    contraction runs on bf16 pieces (codon), for the same sources built with the fp32 MFMA chain (round 5's arithmetic, timed too)."""
+    from mrbayes_amd import beagle as bg
+    from mrbayes_amd import build as mbbuild
+    o["arith"] = ARITH_NOTE
+    o["site_error_vs_fp64_engine"] = site_error(cfg, lib)
+    if o["config"]["states"] >= 40 and os.path.exists(mbbuild.FP32_CHAIN_LIB):
+        alt = bg.BeagleLibrary(mbbuild.FP32_CHAIN_LIB)
+        m = measure(args, cfg, max(args.steps, 200), args.warmup, 0, 0, 1, None, device, False, alt, False, verbose=False)
+        o["fp32_chain_variant"] = {
+            "what": "the same sources with the contraction on v_mfma_f32_32x32x2_f32 (mrbayes_amd/libhmsbeagle_fp32chain.so, -DMBAMD_WG_BF_MIN=999)",
+            "ms_per_step": m["ms_per_step"], "all_kernels_ms_per_step": m["roofline"]["all_kernels_ms_per_step"],
+            "partials_kernel_ms_per_step": m["roofline"]["partials_kernel_ms_per_step"], "value": m["value"],
+            "site_error_vs_fp64_engine": site_error(cfg, alt)}
 
 
 def summary_of(out):
@@ -603,6 +651,7 @@ def main():
                     help="skip the second CPU baseline of the headline workload: the reference on the whole alignment (about a minute at 1000 x 50000)")
     ap.add_argument("--no-also", action="store_true", help="skip the other three workloads (c2, c3, c5) at N=1")
     ap.add_argument("--no-mcmc", action="store_true", help="skip whole-MCMC generations/s of the unmodified MrBayes binary")
+    ap.add_argument("--no-arith", action="store_true", help="skip the per-site error report of the general-state workloads (and the timing of the fp32-chain build beside the codon workload)")
     ap.add_argument("--mcmc", action="store_true", help="longer MCMC windows (adds minutes)")
     ap.add_argument("--shard", action="store_true",
                     help="ONE chain whose site patterns are sharded over the N GPUs inside one engine instance (strong scaling; "
@@ -733,11 +782,21 @@ def main():
                 try:
                     out["also"].append(measure(args, other, max(args.steps, 200), args.warmup, 0, dev_index, 1, None, device,
                                                False, lib, not args.no_cpu_baseline, verbose=False))
+                    if other in ("c3", "c5") and not args.no_arith:
+                        try:
+                            arithmetic_report(args, other, out["also"][-1], device, lib)
+                        except Exception as exc:
+                            out["also"][-1]["arith_error"] = repr(exc)[:300]
                     if fill:
                         out["also"][-1]["roofline"]["box_write_stream_GBs"] = fill
                         out["also"][-1]["roofline"]["hbm_frac_of_box_write_stream"] = out["also"][-1]["roofline"]["hbm_GBs"] / fill
                 except Exception as exc:
                     out["also"].append({"workload": other, "error": repr(exc)})
+        if args.config in ("c3", "c5") and not args.no_arith:
+            try:
+                arithmetic_report(args, args.config, out, device, lib)
+            except Exception as exc:
+                out["arith_error"] = repr(exc)[:300]
         if not args.no_also:
             out["double_precision"] = []
             for other in (args.config, "c5"):

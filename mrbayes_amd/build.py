@@ -32,7 +32,27 @@ def hipcc():
     raise RuntimeError("hipcc not found: the engine can only be built with the ROCm toolchain")
 
 
-def build_library(force=False, verbose=False):
+# A second build of the same sources with every general-state contraction on v_mfma_f32_32x32x2_f32 (round 5's arithmetic): the
+# measured A/B partner of the bf16 x 3 contraction (bench.py reports both for the codon workload; MBAMD_LIBRARY selects it).
+FP32_CHAIN_LIB = os.path.join(HERE, "libhmsbeagle_fp32chain.so")
+
+
+def build_fp32_chain_variant(force=False):
+    return build_library(force=force, target=FP32_CHAIN_LIB, defines=["MBAMD_WG_BF_MIN=999"])
+
+
+def build_library(force=False, verbose=False, target=None, defines=()):
+    global LIB
+    if target is not None:
+        saved, LIB = LIB, target
+        try:
+            return _build(force, verbose, defines)
+        finally:
+            LIB = saved
+    return _build(force, verbose, defines)
+
+
+def _build(force, verbose, defines):
     deps = list(DEPS)
     for d in (os.path.join(HERE, "csrc"), os.path.join(HERE, "csrc", "device"), os.path.join(ROOT, "include", "libhmsbeagle")):
         deps += [os.path.join(d, f) for f in os.listdir(d) if os.path.isfile(os.path.join(d, f))]
@@ -43,7 +63,7 @@ def build_library(force=False, verbose=False):
            "-I", os.path.join(ROOT, "include"), "-I", os.path.join(HERE, "csrc"), "-I", os.path.join(HERE, "csrc", "device"), SRC, "-o", LIB]
     if verbose:
         cmd.insert(1, "-Rpass-analysis=kernel-resource-usage")
-    for d in os.environ.get("MBAMD_BUILD_DEFINES", "").split():      # experiments: extra -D switches
+    for d in list(defines) + os.environ.get("MBAMD_BUILD_DEFINES", "").split():      # variants / experiments: extra -D switches
         cmd.insert(1, "-D" + d)
     subprocess.check_call(cmd)
     return LIB

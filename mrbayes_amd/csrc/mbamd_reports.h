@@ -64,10 +64,17 @@ template <int LAYOUT>
 __global__ void __launch_bounds__(64)
 k_final_pass(FinalOp op, int S, int SP, int K, int P, size_t pstride, size_t tstride)
 {
+    // a column's down-pass values (floats) and the quotients / products of the pass (doubles) live in LDS, [state][thread]: a
+    // thread walks its own column with a run-time state index -- as private arrays these were 1 040 bytes of scratch per lane
+    __shared__ float d_all[MBAMD_REP_MAXS][64];
+    __shared__ double u_all[MBAMD_REP_MAXS][64];
     const int c = blockIdx.x * 64 + threadIdx.x, k = blockIdx.y;
     if (c >= P) return;
-    double d[MBAMD_REP_MAXS], u[MBAMD_REP_MAXS];
-    for (int i = 0; i < S; ++i) d[i] = (double) op.down[rep_index<LAYOUT>(S, K, pstride, k, i, c)];
+    float (*d)[64] = reinterpret_cast<float (*)[64]>(&d_all[0][threadIdx.x]);
+    double (*u)[64] = reinterpret_cast<double (*)[64]>(&u_all[0][threadIdx.x]);
+#define D_(i) ((double) d[i][0])
+#define U_(i) (u[i][0])
+    for (int i = 0; i < S; ++i) d[i][0] = op.down[rep_index<LAYOUT>(S, K, pstride, k, i, c)];
     const float* m = op.matrix;
     if (op.anc == nullptr) {
         double mx = 0.0;
@@ -81,26 +88,28 @@ k_final_pass(FinalOp op, int S, int SP, int K, int P, size_t pstride, size_t tst
                     f += (double) mat_at(m, SP, k, a, j) * (double) t;
                 }
             }
-            u[a] = d[a] * f;
-            mx = u[a] > mx ? u[a] : mx;
+            U_(a) = D_(a) * f;
+            mx = U_(a) > mx ? U_(a) : mx;
         }
         int e = 0;
         if (mx > 0.0 && mx < 1.0e300) (void) frexp(mx, &e);
         op.fexp[(size_t) k * op.Ppad + c] = e;
-        for (int a = 0; a < S; ++a) op.dst[rep_index<LAYOUT>(S, K, pstride, k, a, c)] = (float) ldexp(u[a], -e);
+        for (int a = 0; a < S; ++a) op.dst[rep_index<LAYOUT>(S, K, pstride, k, a, c)] = (float) ldexp(U_(a), -e);
         return;
     }
     for (int a = 0; a < S; ++a) {
         double sum = 0.0;
-        for (int i = 0; i < S; ++i) sum += (double) mat_at(m, SP, k, a, i) * d[i];
+        for (int i = 0; i < S; ++i) sum += (double) mat_at(m, SP, k, a, i) * D_(i);
         const double fa = (double) op.anc[rep_index<LAYOUT>(S, K, pstride, k, a, c)];
-        u[a] = sum != 0.0 ? fa / sum : 0.0;
+        U_(a) = sum != 0.0 ? fa / sum : 0.0;
     }
     for (int a = 0; a < S; ++a) {
         double sum = 0.0;
-        for (int i = 0; i < S; ++i) sum += u[i] * (double) mat_at(m, SP, k, a, i);
-        op.dst[rep_index<LAYOUT>(S, K, pstride, k, a, c)] = (float) (sum * d[a]);
+        for (int i = 0; i < S; ++i) sum += U_(i) * (double) mat_at(m, SP, k, a, i);
+        op.dst[rep_index<LAYOUT>(S, K, pstride, k, a, c)] = (float) (sum * D_(a));
     }
+#undef D_
+#undef U_
 }
 
 // out[k][c][i] = buffer[k][c][i] 2^(E_kc - Emax_c), lnScale[c] = Emax_c ln 2.  Exponents: `wide` int32 [K][Ppad] (arena paths,

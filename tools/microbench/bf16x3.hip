@@ -103,6 +103,37 @@ __device__ __forceinline__ unsigned cvt_pk_rne(float a, float b)
     asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
     return r;
 }
+// k_numerics3: rounded pieces, six products, K-block by K-block -- into NACC separate accumulators (K-block kb -> accumulator kb % NACC),
+// added up by the VALU (round-to-nearest) at the end: does keeping the matrix core's running sum small reduce what its alignment drops?
+template <int NACC> __global__ void k_numerics3(const float* A, const float* B, float* D, int nkb, int ntile)
+{
+    const unsigned lane = threadIdx.x, h = lane >> 5, m = lane & 31;
+    const int KW = 16 * nkb;
+    for (int it = 0; it < ntile; ++it) {
+        v16 acc[NACC];
+        for (int a = 0; a < NACC; ++a) acc[a] = (v16) (0.0f);
+        for (int kb = 0; kb < nkb; ++kb) {
+            u4 Ap[3], Bp[3];
+            for (int jj = 0; jj < 4; ++jj) {
+                const int k0 = 16 * kb + 8 * h + 2 * jj, k1 = k0 + 1;
+                float x0 = A[(32 * it + m) * KW + k0], x1 = A[(32 * it + m) * KW + k1], y0 = B[k0 * 32 + m], y1 = B[k1 * 32 + m];
+                for (int s = 0; s < 3; ++s) {
+                    const unsigned pa = cvt_pk_rne(x0, x1), pb = cvt_pk_rne(y0, y1);
+                    Ap[s][jj] = pa; Bp[s][jj] = pb;
+                    x0 -= __uint_as_float(pa << 16); x1 -= __uint_as_float(pa & 0xFFFF0000u);
+                    y0 -= __uint_as_float(pb << 16); y1 -= __uint_as_float(pb & 0xFFFF0000u);
+                }
+            }
+            const int pairs[6][2] = {{2, 0}, {0, 2}, {1, 1}, {1, 0}, {0, 1}, {0, 0}};
+            for (int pr = 0; pr < 6; ++pr)
+                acc[kb % NACC] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf(Ap[pairs[pr][0]]), as_bf(Bp[pairs[pr][1]]), acc[kb % NACC], 0, 0, 0);
+        }
+        v16 sum = acc[0];
+        if (NACC == 4) sum = (acc[0] + acc[1]) + (acc[2] + acc[3]);
+        else if (NACC == 2) sum = acc[0] + acc[1];
+        for (int r = 0; r < 16; ++r) D[(32 * it + (r & 3) + 8 * (r >> 2) + 4 * h) * 32 + m] = sum[r];
+    }
+}
 __global__ void k_numerics2(const float* A, const float* B, float* D, int split, int nprod, int order, int nkb, int ntile)
 {
     const unsigned lane = threadIdx.x, h = lane >> 5, m = lane & 31;
@@ -347,7 +378,8 @@ int main()
         struct Var { const char* name; int split, nprod, order; };
         const Var vars[] = {{"fp32 MFMA chain (today)", -1, 0, 0}, {"truncated pieces, 6, per K-block", 0, 6, 0}, {"truncated pieces, 6, whole K", 0, 6, 2},
                             {"rounded pieces, 6, per K-block", 1, 6, 0}, {"rounded pieces, 6, per half of K", 1, 6, 1}, {"rounded pieces, 6, whole K", 1, 6, 2},
-                            {"rounded pieces, 9, per half of K", 1, 9, 1}, {"rounded pieces, 9, whole K", 1, 9, 2}};
+                            {"rounded pieces, 9, per half of K", 1, 9, 1}, {"rounded pieces, 9, whole K", 1, 9, 2},
+                            {"rounded, 6, per K-block, 2 accumulators + VALU", -2, 0, 0}, {"rounded, 6, per K-block, 4 accumulators + VALU", -4, 0, 0}};
         const int NV = sizeof(vars) / sizeof(vars[0]);
         for (double t : {0.05, 1.0}) {
             double mean[NV] = {}, sq[NV] = {}, mx[NV] = {};
@@ -373,7 +405,9 @@ int main()
                 }
                 hipMemcpy(dA, A.data(), A.size() * 4, hipMemcpyHostToDevice); hipMemcpy(dB, B.data(), B.size() * 4, hipMemcpyHostToDevice);
                 for (int c = 0; c < NV; ++c) {
-                    if (vars[c].split < 0) hipLaunchKernelGGL(k_numerics_f32, dim3(1), dim3(64), 0, 0, dA, dB, dD, nkb, ntile);
+                    if (vars[c].split == -2) hipLaunchKernelGGL(k_numerics3<2>, dim3(1), dim3(64), 0, 0, dA, dB, dD, nkb, ntile);
+                    else if (vars[c].split == -4) hipLaunchKernelGGL(k_numerics3<4>, dim3(1), dim3(64), 0, 0, dA, dB, dD, nkb, ntile);
+                    else if (vars[c].split < 0) hipLaunchKernelGGL(k_numerics_f32, dim3(1), dim3(64), 0, 0, dA, dB, dD, nkb, ntile);
                     else hipLaunchKernelGGL(k_numerics2, dim3(1), dim3(64), 0, 0, dA, dB, dD, vars[c].split, vars[c].nprod, vars[c].order, nkb, ntile);
                     hipMemcpy(D.data(), dD, D.size() * 4, hipMemcpyDeviceToHost);
                     for (int i = 0; i < S; ++i) for (int p = 0; p < 32; ++p) {
@@ -383,7 +417,7 @@ int main()
                 }
                 count += S * 32;
             }
-            for (int c = 0; c < NV; ++c) printf("   %d states, branch %-5g %-36s bias %+7.3f  rms %7.3f  max %7.2f\n", S, t, vars[c].name, mean[c] / count * 1e8, std::sqrt(sq[c] / count) * 1e8, mx[c] * 1e8);
+            for (int c = 0; c < NV; ++c) printf("   %d states, branch %-5g %-46s bias %+7.3f  rms %7.3f  max %7.2f\n", S, t, vars[c].name, mean[c] / count * 1e8, std::sqrt(sq[c] / count) * 1e8, mx[c] * 1e8);
         }
     }
     printf("3. one child factor at 61 states, cycles per factor and wave (s_memrealtime 100 MHz ticks x clock / 100 MHz), 256 workgroups\n");

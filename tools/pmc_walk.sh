@@ -15,7 +15,7 @@ if [[ -n "${PMC_PASSES:-}" ]]; then IFS=';' read -r -a PASSES <<< "$PMC_PASSES";
 for pass in "${PASSES[@]}"; do
   tag=$(echo $pass | tr ' ' '_' | cut -c1-40)
   rm -rf /tmp/pmc_$tag
-  timeout 300 rocprofv3 --pmc $pass --kernel-trace --output-format csv -d /tmp/pmc_$tag -o p -- python $GRAFT_REPO_ROOT/bench.py --config $CFG --steps 5 --warmup 1 --no-cpu-baseline --no-also --no-mcmc --no-also --no-mcmc > /tmp/pmc_$tag.log 2>&1
+  timeout 300 rocprofv3 --pmc $pass --kernel-trace --output-format csv -d /tmp/pmc_$tag -o p -- python $GRAFT_REPO_ROOT/bench.py --config $CFG --steps 5 --warmup 1 --no-cpu-baseline --no-also --no-mcmc --no-arith > /tmp/pmc_$tag.log 2>&1
   f=$(find /tmp/pmc_$tag -name "*counter_collection.csv" | head -1)
   echo "== PMC $pass"
   [[ -n "$f" ]] && python - "$f" <<'PY'
