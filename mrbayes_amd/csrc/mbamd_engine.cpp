@@ -234,7 +234,16 @@ struct Instance {
     unsigned long wgTileBytes = 0;               // partials arena: bytes between 32-pattern tiles
     unsigned wgTipTileBytes = 0;
     size_t wgTabFloats = 0;                      // first float of the tree-walk tables inside a matrix buffer
-    bool hasPending() const { return !pending.empty() || !wgListCum.empty(); }
+    bool hasPending() const { return !pending.empty() || !wgListCum.empty() || heldPath != nullptr; }
+    // ---- 4-state path: a root-ward path (k_path4 plan) is HELD until the next call: if that call is the log-likelihood over the
+    // path's last result, both run as one launch (k_path4_lnl); anything else runs the path first, as before
+    Plan* heldPath = nullptr;
+    int32_t* heldPathCum = nullptr;
+    bool heldPathFresh = false;
+    int heldPathDst = -1;                        // the partials buffer the path's last operation writes
+    bool noFusePath = false;                     // MBAMD_NO_FUSE_PATH: never hold a path
+    int runHeldPath();
+    int integratePath4(const int* parent, const int* child, const int* prob, const int* wIdx, const int* fIdx, const int* cumIdx);
     int updatePartialsG(const BeagleOperation* ops, int n, int cumIdx);
     int flushWalkG();
     int runWalkG(const Plan& plan);
@@ -354,7 +363,7 @@ struct Instance {
     std::vector<Plan*> plans;        // small LRU cache of compiled operation lists
     uint64_t planClock = 0;
     int layoutEpoch = 0;             // bumped whenever a buffer changes between compact-tip and partials form
-    long planHits = 0, planMisses = 0;
+    long planHits = 0, planMisses = 0, fusedPaths = 0, heldPaths = 0;
 
     // ---- helpers ----------------------------------------------------------------------------
     int grow(void** p, size_t* cap, size_t bytes)
@@ -470,7 +479,7 @@ struct Instance {
     int runGeneric(const Plan& plan, int32_t* cum);
     int planTable(Plan& plan, const std::vector<PartialsOp>& table);
     int timedRun(const Plan& plan, int32_t* cum);
-    int flushPending();
+    int flushPending(bool keepPath = false);
     int flushMatrices();
     std::vector<MatrixJob> pendingJobs;          // queued beagleUpdateTransitionMatrices work
     std::vector<char> pendingMatrixOut;          // matrix buffers the queued jobs write
@@ -567,6 +576,7 @@ int Instance::create(int tipCount_, int partialsBufferCount, int compactBufferCo
     noDefer = std::getenv("MBAMD_NO_DEFER") != nullptr;
     noInlinePrograms = std::getenv("MBAMD_NO_INLINE_PROGRAMS") != nullptr;
     noPath4 = std::getenv("MBAMD_NO_PATH4") != nullptr;
+    noFusePath = std::getenv("MBAMD_NO_FUSE_PATH") != nullptr;
     noPathG = std::getenv("MBAMD_NO_PATHG") != nullptr;
     if (const char* e = std::getenv("MBAMD_MFMA_SERIAL")) serialRatio = std::max(0, std::atoi(e));
     noSpine = std::getenv("MBAMD_NO_SPINE") != nullptr;
@@ -1264,11 +1274,21 @@ bool Instance::independentOfPending(const Plan& plan, int cumIdx)
     return true;
 }
 
-int Instance::flushPending()
+int Instance::runHeldPath()
+{
+    Plan* plan = heldPath;
+    heldPath = nullptr;
+    if (!plan) return BEAGLE_SUCCESS;
+    walkCumFresh = heldPathFresh;
+    return timedRun(*plan, heldPathCum);
+}
+
+int Instance::flushPending(bool keepPath)
 {
     StatTimer st_(ST_FLUSH);
     int mrc = flushMatrices();                   // (queued matrix jobs precede the lists that read them)
     if (mrc) return mrc;
+    if (heldPath && !keepPath) { int prc = runHeldPath(); if (prc) return prc; }
     if (wg) return flushWalkG();
     if (pending.empty()) return BEAGLE_SUCCESS;
     std::vector<std::pair<Plan*, int>> work;
@@ -1467,6 +1487,7 @@ int Instance::ensureWide(int idx)
 
 int Instance::updatePartials4(const BeagleOperation* ops, int n, int cumIdx)
 {
+    if (heldPath) { int prc = runHeldPath(); if (prc) return prc; }      // (a list behind a held path: the path runs first)
     int32_t* cumPtr = nullptr;
     walkCumFresh = false;
     if (cumIdx != BEAGLE_OP_NONE) {
@@ -1527,6 +1548,15 @@ int Instance::updatePartials4(const BeagleOperation* ops, int n, int cumIdx)
     }
     int mrc = flushMatrices();
     if (mrc) return mrc;
+    if (plan->path && !noFusePath && K <= 8 && plan->inlineProg.size() <= MBAMD_W4_INLINE) {
+        // hold it: the next call decides (runHeldPath / integratePath4)
+        heldPath = plan;
+        heldPaths++;
+        heldPathCum = cumPtr;
+        heldPathFresh = walkCumFresh;
+        heldPathDst = ops[n - 1].destinationPartials;
+        return BEAGLE_SUCCESS;
+    }
     return timedRun(*plan, cumPtr);
 }
 
@@ -2683,7 +2713,13 @@ int Instance::integrate(const int* parent, const int* child, const int* prob, co
 {
     if (count < 1 || count > MBAMD_MAX_SUBSETS) return fail(BEAGLE_ERROR_NO_IMPLEMENTATION, "log-likelihood: subset count");
     if (arena()) {
-        int rc = integrate4(parent, child, prob, wIdx, fIdx, cumIdx, count);
+        int rc;
+        if (heldPath && count == 1 && parent[0] == heldPathDst && !(child && tipStates[child[0]] == nullptr && child[0] == heldPathDst)) {
+            rc = integratePath4(parent, child, prob, wIdx, fIdx, cumIdx);      // the held path and this integration: one launch
+        } else {
+            if (heldPath) { rc = runHeldPath(); if (rc) return rc; }
+            rc = integrate4(parent, child, prob, wIdx, fIdx, cumIdx, count);
+        }
         if (rc) return rc;
         rc = spanEnd();
         if (rc) return rc;
@@ -2738,6 +2774,82 @@ int Instance::integrate(const int* parent, const int* child, const int* prob, co
         return BEAGLE_SUCCESS;
     }
     return fetchResult(out);
+}
+
+// the held root-ward path (k_path4 plan) and the log-likelihood over its last result as ONE launch (k_path4_lnl, mbamd_walk4.h)
+int Instance::integratePath4(const int* parent, const int* child, const int* prob, const int* wIdx, const int* fIdx, const int* cumIdx)
+{
+    Plan* plan = heldPath;
+    PathLnl4 t;
+    std::memset(&t, 0, sizeof t);
+    bool ok = parent[0] >= 0 && parent[0] < nBuffers && valid[parent[0]] && !tipStates[parent[0]];
+    if (ok && child) {
+        const int ci = child[0];
+        ok = ci >= 0 && ci < nBuffers && prob[0] >= 0 && prob[0] < nMatrices && (tipStates[ci] || valid[ci]);
+        if (ok) {
+            if (tipStates[ci]) { t.child = tipStates[ci]; t.child_kind = CHILD_STATES; }
+            else { t.child = partials[ci]; t.child_kind = CHILD_PARTIALS; }
+            t.matrix = matrixPtr(prob[0]);
+        }
+    }
+    ok = ok && wIdx[0] >= 0 && wIdx[0] < nEigen && fIdx[0] >= 0 && fIdx[0] < nEigen;
+    if (ok && cumIdx && cumIdx[0] != BEAGLE_OP_NONE) ok = cumIdx[0] >= 0 && cumIdx[0] < nScale;
+    if (!ok) {                                   // (let the separate kernels report what is wrong, in their own words)
+        int rc = runHeldPath();
+        if (rc) return rc;
+        return integrate4(parent, child, prob, wIdx, fIdx, cumIdx, 1);
+    }
+    t.weights = d_weights + (size_t) wIdx[0] * K;
+    t.freqs = d_freqs + (size_t) fIdx[0] * S;
+    if (cumIdx && cumIdx[0] != BEAGLE_OP_NONE && scaleState[cumIdx[0]] != 0) {
+        int rc = ensureWide(cumIdx[0]);
+        if (rc) return rc;
+        t.cum = wideScale[cumIdx[0]];
+    }
+    double* const siteOut = (siteToHost && h_site_dev) ? h_site_dev : d_site;
+    siteOnHost = siteOut != d_site;
+    t.pattern_weights = d_pweights;
+    t.site = siteOut;
+    t.wsite = h_sums_dev;
+    t.P = P;
+    heldPath = nullptr;
+    fusedPaths++;
+    plan->lastLaunch = ++launchClock;
+    { int src = spanBegin(); if (src) return src; }
+    Walk4ArgsInline ai;
+    Walk4Args& a = ai.a;
+    a.prog = nullptr;
+    a.entries = (int) plan->inlineProg.size();
+    a.nslots = 0;
+    a.partials = reinterpret_cast<f4*>(arenaPartials);
+    a.pstride = geom.pstride;
+    a.tips = arenaTips;
+    a.tstride = geom.tstride;
+    a.exps = arenaExp;
+    a.estride = estride;
+    a.matrices = matrices;
+    a.cum = heldPathCum;
+    a.cumFresh = heldPathFresh ? 1 : 0;
+    a.K = K;
+    a.Ppad = Ppad;
+    a.nblocks = Ppad / 64;
+    a.tail = 0;
+    std::memcpy(ai.inl, plan->inlineProg.data(), plan->inlineProg.size() * sizeof(Walk4Entry));
+    hipEvent_t ev0{}, ev1{};
+    if (timing) {
+        HIP_TRY(hipEventCreate(&ev0));
+        HIP_TRY(hipEventCreate(&ev1));
+        HIP_TRY(hipEventRecord(ev0, stream));
+    }
+    auto kernel = k_path4_lnl<Walk4ArgsInline>;
+    MBAMD_LAUNCH_BARRIER(kernel, 8u * (unsigned) ((Ppad / 64 + 7) / 8), 64 * K, path4_lnl_lds_bytes(a.entries, K), stream, ai, t);
+    HIP_TRY(hipGetLastError());
+    if (timing) {
+        HIP_TRY(hipEventRecord(ev1, stream));
+        events.emplace_back(ev0, ev1);
+    }
+    pendingLaunches += 1;
+    return BEAGLE_SUCCESS;
 }
 
 int Instance::integrate4(const int* parent, const int* child, const int* prob, const int* wIdx, const int* fIdx,
@@ -3083,6 +3195,14 @@ using namespace mbamd;
         int frc_ = in->flushPending();                                                               \
         if (frc_ != BEAGLE_SUCCESS) return frc_;                                                     \
     }
+// the calls between a list and its log-likelihood that do not touch partials (category weights, state frequencies) and the
+// log-likelihood calls themselves leave a held 4-state path where it is (Instance::heldPath)
+#define GET_INSTANCE_KEEPING_PATH(id)                                                                \
+    GET_INSTANCE_NOFLUSH(id);                                                                        \
+    if (!in->pending.empty() || !in->wgListCum.empty() || !in->pendingJobs.empty()) {                \
+        int frc_ = in->flushPending(true);                                                           \
+        if (frc_ != BEAGLE_SUCCESS) return frc_;                                                     \
+    }
 // a facade forwards the call to every child (`c`, its pattern range in `ch`) and returns
 #define FACADE_EACH(FLUSH, ...)                                                                      \
     if (in->facade()) {                                                                              \
@@ -3332,8 +3452,8 @@ int beagleFinalizeInstance(int instance)
         g_instances[instance] = nullptr;
     }
     if (g_statsOn) {
-        std::fprintf(stderr, "[mbamd] instance %d: plan cache %ld hits / %ld misses; tree-walk schedules re-used %llu / built %llu\n", instance,
-                     in->planHits, in->planMisses, (unsigned long long) in->scheduleHits, (unsigned long long) in->scheduleMisses);
+        std::fprintf(stderr, "[mbamd] instance %d: plan cache %ld hits / %ld misses; tree-walk schedules re-used %llu / built %llu; root-ward paths held %ld, run with their log-likelihood as one launch %ld\n", instance,
+                     in->planHits, in->planMisses, (unsigned long long) in->scheduleHits, (unsigned long long) in->scheduleMisses, in->heldPaths, in->fusedPaths);
         for (const ApiStats& a : g_stats)
             std::fprintf(stderr, "[mbamd]   %-34s %9ld calls %10.3f ms total %9.2f us/call\n", a.name, a.calls,
                          a.seconds * 1e3, a.calls ? a.seconds * 1e6 / a.calls : 0.0);
@@ -3486,7 +3606,7 @@ int mbamdSetRateMatricesFrom(int instance, int firstEigenIndex, int count, const
 int beagleSetStateFrequencies(int instance, int idx, const double* f)
 {
     StatTimer st_(ST_SET);
-    GET_INSTANCE(instance);
+    GET_INSTANCE_KEEPING_PATH(instance);
     if (in->f64) return in->f64->setFreqs(idx, f);
     API_TRACE("beagleSetStateFrequencies(%d, %s...)", idx, trace_doubles(f, std::min(6, in->S)).c_str());
     if (idx < 0 || idx >= in->nEigen) return fail(BEAGLE_ERROR_OUT_OF_RANGE, "beagleSetStateFrequencies: index");
@@ -3496,7 +3616,7 @@ int beagleSetStateFrequencies(int instance, int idx, const double* f)
 int beagleSetCategoryWeights(int instance, int idx, const double* w)
 {
     StatTimer st_(ST_SET);
-    GET_INSTANCE(instance);
+    GET_INSTANCE_KEEPING_PATH(instance);
     if (in->f64) return in->f64->setWeights(idx, w);
     API_TRACE("beagleSetCategoryWeights(%d, %s)", idx, trace_doubles(w, in->K).c_str());
     if (idx < 0 || idx >= in->nEigen) return fail(BEAGLE_ERROR_OUT_OF_RANGE, "beagleSetCategoryWeights: index");
@@ -3844,7 +3964,7 @@ int beagleCalculateRootLogLikelihoods(int instance, const int* bufferIndices, co
                                       double* outSumLogLikelihood)
 {
     StatTimer st_(ST_LNL);
-    GET_INSTANCE(instance);
+    GET_INSTANCE_KEEPING_PATH(instance);
     if (in->f64) return in->f64->logLikelihoods(bufferIndices, nullptr, nullptr, categoryWeightsIndices, stateFrequenciesIndices, cumulativeScaleIndices, count, outSumLogLikelihood);
     const int rc_ = integrate_any(in, bufferIndices, nullptr, nullptr, categoryWeightsIndices, stateFrequenciesIndices,
                                   cumulativeScaleIndices, count, nullptr, 1, nullptr, outSumLogLikelihood);
@@ -3862,7 +3982,7 @@ int beagleCalculateEdgeLogLikelihoods(int instance, const int* parentBufferIndic
                                       double* outSumSecondDerivative)
 {
     StatTimer st_(ST_LNL);
-    GET_INSTANCE(instance);
+    GET_INSTANCE_KEEPING_PATH(instance);
     if (in->f64) return (firstDerivativeIndices || secondDerivativeIndices || outSumFirstDerivative || outSumSecondDerivative) ? fail(BEAGLE_ERROR_NO_IMPLEMENTATION, "beagleCalculateEdgeLogLikelihoods: derivatives") : in->f64->logLikelihoods(parentBufferIndices, childBufferIndices, probabilityIndices, categoryWeightsIndices, stateFrequenciesIndices, cumulativeScaleIndices, count, outSumLogLikelihood);
     if (firstDerivativeIndices || secondDerivativeIndices || outSumFirstDerivative || outSumSecondDerivative)
         return fail(BEAGLE_ERROR_NO_IMPLEMENTATION, "beagleCalculateEdgeLogLikelihoods: derivatives");

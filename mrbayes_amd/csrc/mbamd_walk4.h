@@ -287,26 +287,10 @@ k_walk4_t(ARGS AA)
 #define MBAMD_P4_CHUNK 24         // (8: 17.8 us, 16: 16.6, 24: 15.9, 32: 16.3 -- median of the paths of DNA 500 x 20 000, profiles/r05_path4.txt)
 #endif
 #define MBAMD_P4_GROUP 4         // matrices per burst of scalar loads (4 x 16 scalar registers)
-template <class ARGS>
-__global__ void __launch_bounds__(64)
-k_path4(ARGS AA)
+// the path itself: `prev` starts as the chain's input and ends as the last result; returns the exponents this wave's column gained
+__device__ __forceinline__ int walk4_path_run(const Walk4Entry* pp, int n, unsigned lane, f4* P0, const uint64_t* T0, int8_t* E0, const float* M0, f4& prev)
 {
-    const Walk4Args& A = walk4_args(AA);
-    const unsigned lane = threadIdx.x & 63;
-    const unsigned K = (unsigned) A.K;
-    const unsigned xcd = blockIdx.x & 7u, pos = blockIdx.x >> 3;
-    const unsigned blk = (pos / K) * 8u + xcd, k = pos % K;
-    if (blk >= (unsigned) A.nblocks) return;
-    f4* const P0 = A.partials + (size_t) blk * A.pstride + (size_t) k * 64;
-    const uint64_t* const T0 = A.tips + (size_t) blk * A.tstride;
-    int8_t* const E0 = A.exps + (size_t) blk * A.estride + (size_t) k * 64;
-    const float* const M0 = A.matrices + (size_t) k * 16;
-    const int n = A.entries;
-    // the program: from the kernel arguments (host-visible memory) into LDS, one vector load per 32 entries
-    Walk4Entry* const pp = mbd_dyn_lds<Walk4Entry>();
-    walk4_program_to_lds(walk4_program(AA), pp, n, lane);
     constexpr int C = MBAMD_P4_CHUNK;
-    f4 prev;
     {
         const Walk4Entry e0 = walk4_entry_from_lds(pp);
         if (e0.ctl & MBAMD_W4_TIP1) prev = walk4_tip_vector(walk4_load_planes(walk4_at(T0, e0.c1)), lane);
@@ -383,11 +367,132 @@ k_path4(ARGS AA)
             }
         }
     }
+    return cum_e;
+}
+
+template <class ARGS>
+__global__ void __launch_bounds__(64)
+k_path4(ARGS AA)
+{
+    const Walk4Args& A = walk4_args(AA);
+    const unsigned lane = threadIdx.x & 63;
+    const unsigned K = (unsigned) A.K;
+    const unsigned xcd = blockIdx.x & 7u, pos = blockIdx.x >> 3;
+    const unsigned blk = (pos / K) * 8u + xcd, k = pos % K;
+    if (blk >= (unsigned) A.nblocks) return;
+    f4* const P0 = A.partials + (size_t) blk * A.pstride + (size_t) k * 64;
+    const uint64_t* const T0 = A.tips + (size_t) blk * A.tstride;
+    int8_t* const E0 = A.exps + (size_t) blk * A.estride + (size_t) k * 64;
+    const float* const M0 = A.matrices + (size_t) k * 16;
+    const int n = A.entries;
+    // the program: from the kernel arguments (host-visible memory) into LDS, one vector load per 32 entries
+    Walk4Entry* const pp = mbd_dyn_lds<Walk4Entry>();
+    walk4_program_to_lds(walk4_program(AA), pp, n, lane);
+    f4 prev;
+    const int cum_e = walk4_path_run(pp, n, lane, P0, T0, E0, M0, prev);
     if (A.cum != nullptr) {
         int32_t* dst = A.cum + (size_t) k * A.Ppad + (size_t) blk * 64 + lane;
         if (A.cumFresh) *dst = cum_e;
         else if (cum_e != 0) *dst += cum_e;
     }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------------------
+// k_path4_lnl -- the path AND the log-likelihood behind it in one launch (round 6).  A generation of a fixed-topology chain is: one or
+// two new matrices, the root-ward path of the changed branch, the integration over the root branch -- three launches of 5 + 16 + 6 us
+// with two gaps of 4-5 us between them (profiles/r05_path4.txt).  The path's last result IS the integration's parent: a workgroup here
+// is the K category waves of one 64-pattern block; each wave walks the path as k_path4 does, leaves its last result and its column's
+// cumulative exponent in LDS, the workgroup meets once, and wave 0 integrates the block -- the arithmetic of k_integrate_lnl_s4, term
+// by term: the same site values, the same block sum.  blockDim.x = 64 K (K <= 8), grid = 8 ceil(nblocks / 8) (XCD-aware as
+// walk4_grid), dynamic LDS = path4_lnl_lds_bytes(entries, K).
+struct PathLnl4 {
+    const void*    child;          // the root tip (state bitplanes) / the child's partials / nullptr (root integration)
+    const float*   matrix;         // the root branch's matrices [K][4][4] transposed
+    const double*  weights;        // K category weights
+    const double*  freqs;          // 4 state frequencies
+    const int32_t* cum;            // the integration's cumulative exponents [K][Ppad] or nullptr (may be the buffer the path adds to)
+    const double*  pattern_weights;
+    double*        site;
+    double*        wsite;
+    int            P;
+    int            child_kind;     // CHILD_STATES / CHILD_PARTIALS
+};
+__host__ __device__ inline size_t path4_lnl_lds_bytes(int entries, int K) { return (size_t) ((entries * 32 + 63) / 64 * 64) + (size_t) K * 64 * (sizeof(f4) + sizeof(int)); }
+template <class ARGS>
+__global__ void __launch_bounds__(512)
+k_path4_lnl(ARGS AA, PathLnl4 t)
+{
+    const Walk4Args& A = walk4_args(AA);
+    const unsigned lane = threadIdx.x & 63;
+    const unsigned K = (unsigned) A.K;
+    const unsigned k = (unsigned) mbd_wave_index();
+    const unsigned blk = (blockIdx.x >> 3) * 8u + (blockIdx.x & 7u);
+    if (blk >= (unsigned) A.nblocks) return;
+    f4* const P0 = A.partials + (size_t) blk * A.pstride + (size_t) k * 64;
+    const uint64_t* const T0 = A.tips + (size_t) blk * A.tstride;
+    int8_t* const E0 = A.exps + (size_t) blk * A.estride + (size_t) k * 64;
+    const float* const M0 = A.matrices + (size_t) k * 16;
+    const int n = A.entries;
+    // (every wave copies the program to the same place: the same bytes)
+    Walk4Entry* const pp = mbd_dyn_lds<Walk4Entry>();
+    walk4_program_to_lds(walk4_program(AA), pp, n, lane);
+    f4 prev;
+    const int cum_e = walk4_path_run(pp, n, lane, P0, T0, E0, M0, prev);
+    const size_t col = (size_t) k * A.Ppad + (size_t) blk * 64 + lane;
+    int e_col = 0;                                   // this column's cumulative exponent as the integration reads it
+    if (A.cum != nullptr) {
+        int32_t* dst = A.cum + col;
+        const int total = (A.cumFresh ? 0 : *dst) + cum_e;
+        if (A.cumFresh || cum_e != 0) *dst = total;
+        if (t.cum == A.cum) e_col = total;
+    }
+    if (t.cum != nullptr && t.cum != A.cum) e_col = t.cum[col];
+    char* const xb = reinterpret_cast<char*>(pp) + (size_t) ((n * 32 + 63) / 64 * 64);
+    f4* const xp = reinterpret_cast<f4*>(xb);                                  // [K][64] last results
+    int* const xe = reinterpret_cast<int*>(xb + (size_t) K * 64 * sizeof(f4));   // [K][64] exponents
+    xp[k * 64 + lane] = prev;
+    xe[k * 64 + lane] = e_col;
+    walk4_barrier();
+    if (k != 0) return;
+    // ---- wave 0: k_integrate_lnl_s4 for this block (count = 1), from LDS
+    const int c = (int) (blk * 64 + lane);
+    double wl = 0.0;
+    if (c < t.P) {
+        int emax = -2147483647;
+        for (unsigned q = 0; q < K; ++q) { const int e = t.cum ? xe[q * 64 + lane] : 0; emax = e > emax ? e : emax; }
+        unsigned mask = 0;
+        if (t.child != nullptr && t.child_kind == CHILD_STATES) {
+            const uint64_t* planes = reinterpret_cast<const uint64_t*>(t.child) + (size_t) blk * A.tstride;
+            for (int i = 0; i < 4; ++i) mask |= (unsigned) (planes[i] >> lane & 1u) << i;
+        }
+        double total = 0.0;
+        for (unsigned q = 0; q < K; ++q) {
+            const f4 p = xp[q * 64 + lane];
+            const int e = t.cum ? xe[q * 64 + lane] : 0;
+            float f[4] = {1.0f, 1.0f, 1.0f, 1.0f};
+            if (t.child != nullptr) {
+                const float* __restrict__ mT = t.matrix + q * 16;
+                float v[4];
+                if (t.child_kind == CHILD_STATES) {
+                    for (int j = 0; j < 4; ++j) v[j] = (mask >> j & 1u) ? 1.0f : 0.0f;
+                } else {
+                    const f4 cq = reinterpret_cast<const f4*>(t.child)[(size_t) blk * A.pstride + (size_t) q * 64 + lane];
+                    v[0] = cq.x; v[1] = cq.y; v[2] = cq.z; v[3] = cq.w;
+                }
+                for (int i = 0; i < 4; ++i)
+                    f[i] = fmaf(mT[12 + i], v[3], fmaf(mT[8 + i], v[2], fmaf(mT[4 + i], v[1], mT[i] * v[0])));
+            }
+            const double cat = (double) (p.x * f[0]) * t.freqs[0] + (double) (p.y * f[1]) * t.freqs[1] + (double) (p.z * f[2]) * t.freqs[2] +
+                               (double) (p.w * f[3]) * t.freqs[3];
+            total += ldexp(cat * t.weights[q], e - emax);
+        }
+        const double lnl = log(total) + (double) emax * 0.69314718055994530942;
+        t.site[c] = lnl;
+        wl = lnl * t.pattern_weights[c];
+    } else if (c < A.Ppad) {
+        t.site[c] = 0.0;
+    }
+    mbd_wave_sum_store(wl, t.wsite + blk);
 }
 
 }  // namespace mbamd

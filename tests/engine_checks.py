@@ -755,6 +755,58 @@ def check_path_kernels_at_bench_shape(lib, golden_dir, monkeypatch, case, switch
             t.length[:] = base_len
 
 
+def check_fused_path_and_likelihood(lib, oracle, monkeypatch, golden_dir=None, case=None, ntaxa=60, npat=700):
+    """A 4-state branch move: the root-ward path and the log-likelihood over its last result run as ONE launch (k_path4_lnl: the path is
+    held until the next call).  Against the same moves with MBAMD_NO_FUSE_PATH=1 (k_path4, then k_integrate_lnl_s4): log-likelihoods
+    and per-site values bit for bit, through accepts and rejects, under both scaling schemes, with a call between the list and its
+    log-likelihood that forces the path out (a partials read-back) and one that does not (new category weights)."""
+    for scaling in (lk.MB_BEAGLE_SCALE_DYNAMIC, lk.MB_BEAGLE_SCALE_ALWAYS):
+        runs = []
+        for off in (False, True):
+            if off:
+                monkeypatch.setenv("MBAMD_NO_FUSE_PATH", "1")
+            else:
+                monkeypatch.delenv("MBAMD_NO_FUSE_PATH", raising=False)
+            div = division_from_golden(golden_dir, case) if case else synthetic_division("gtr", ntaxa, npat, seed=41, tree_seed=42, p_gap=0.03)
+            t = div.tree
+            bd = lk.BeagleDivision(div, lib, scaling=scaling)
+            try:
+                seq = [bd.LogLike(0)]
+                bd.AcceptMove(0)
+                if not off and oracle is not None:
+                    want = oracle.tree_loglike(div, use_shortcuts=False)
+                    assert abs(seq[0] - want) / abs(want) < REL_FP64
+                rng = np.random.default_rng(13)
+                nodes = [i for i in range(len(t.anc)) if t.anc[i] != -1 and i != t.root]
+                for rep in range(9):
+                    b = int(rng.choice(nodes))
+                    old = t.length[b]
+                    t.length[b] = old * (1.8 if rep % 2 else 0.55)
+                    bd.TouchBranch(0, b)
+                    lnl = bd.LogLike(0)
+                    seq.append(lnl)
+                    seq.append(bd.inst.get_site_log_likelihoods().copy())
+                    if not off and oracle is not None and rep < 3:
+                        want = oracle.tree_loglike(div, use_shortcuts=False)
+                        assert abs(lnl - want) / abs(want) < REL_FP64, (scaling, rep, lnl, want)
+                    if rep % 3 == 1:
+                        t.length[b] = old
+                        bd.ResetFlips(0)
+                        seq.append(bd.LogLike(0))
+                    bd.AcceptMove(0)
+                seq.append(bd.LogLike(0))               # nothing touched: no list, the plain integration
+            finally:
+                bd.finalize()
+            runs.append(seq)
+        monkeypatch.delenv("MBAMD_NO_FUSE_PATH", raising=False)
+        assert len(runs[0]) == len(runs[1])
+        for x, y in zip(runs[0], runs[1]):
+            if isinstance(x, np.ndarray):
+                assert np.array_equal(x, y), scaling
+            else:
+                assert x == y, (scaling, x, y)
+
+
 def _depth(t, i):
     d = 0
     while t.anc[i] != -1 and t.anc[i] != t.root:

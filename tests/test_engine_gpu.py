@@ -641,3 +641,9 @@ def test_path_kernels_at_baseline_shapes(gpu, golden_dir, monkeypatch, case, swi
     bit-equal to the whole-tree walk kernels on the same lists and within REL_FP64 of the fp64 engine after every move
     (reference: the partial updates of src/mbbeagle.c:783-880)."""
     ec.check_path_kernels_at_bench_shape(gpu, golden_dir, monkeypatch, case, switch)
+
+
+def test_path_and_log_likelihood_in_one_launch(gpu, oracle, monkeypatch, golden_dir):
+    """k_path4_lnl == k_path4 + k_integrate_lnl_s4 bit for bit (a fixed-topology generation is one launch behind its matrices)."""
+    ec.check_fused_path_and_likelihood(gpu, oracle, monkeypatch)
+    ec.check_fused_path_and_likelihood(gpu, None, monkeypatch, golden_dir=golden_dir, case="bench_c2")

@@ -333,3 +333,8 @@ def test_parsimony_model_golden(emu, golden_dir):
 def test_general_state_path_kernel(emu, oracle, golden_dir, monkeypatch):
     """A move's root-ward path at 20 / 61 states: k_pathg == k_walkg bit for bit, both == the oracle."""
     ec.check_general_state_path_kernel(emu, oracle, golden_dir, monkeypatch)
+
+
+def test_path_and_log_likelihood_in_one_launch(emu, oracle, monkeypatch):
+    """k_path4_lnl == k_path4 + k_integrate_lnl_s4 bit for bit (a fixed-topology generation is one launch behind its matrices)."""
+    ec.check_fused_path_and_likelihood(emu, oracle, monkeypatch)
