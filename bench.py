@@ -416,6 +416,12 @@ def measure(args, cfg, steps, warmup, rank, local_rank, world, dist, device, emu
                 if wb:
                     out["cpu_baseline_whole_alignment"] = wb
                     out["speedup_vs_cpu_baseline_whole_alignment"] = value / wb["value"]
+                    out["cpu_baseline_note"] = ("two timings of the same reference kernels on one core of a shared host: `cpu_baseline` on the first %d "
+                                                "patterns (60 evaluations), `cpu_baseline_whole_alignment` on all of them (6 evaluations, the reference's "
+                                                "O(P^2) pattern compression subtracted by the two-point window).  Neither working set fits a cache (64 bytes "
+                                                "x patterns x nodes); they differ by the run-to-run spread of the host (+-10 %% between repeats of ONE "
+                                                "sample: 131 / 164 in round 5's driver run, 144 / 148 in this round's).  Believed: the whole alignment -- it "
+                                                "is the workload the GPU line is quoted on; the prefix is the bounded sample the contract asks for." % sample)
         except Exception as exc:          # the baseline is a report, never a reason to lose the bench line
             out["cpu_baseline"] = {"value": None, "unit": "M updates/s", "cores": 1, "kind": "port",
                                    "sample": "failed: %r" % (exc,)}

@@ -34,7 +34,15 @@ for cfg in ("c2", "c3", "c4", "c5"):
     busy = sum(v.get("SQ_VALU_MFMA_BUSY_CYCLES", 0.0) for k, v in kernels.items() if "walkg" in k or "partials" in k)
     e = {"kernels": sorted(k[:60] for k in kernels), "FETCH_SIZE_KiB": fetch, "WRITE_SIZE_KiB": write,
          "traffic_bytes": int((2 * fetch + write) * 1024), "source": "profiles/%s_%s_pmc.txt" % (tag, cfg)}
-    if busy > 0:
+    insts = sum(v.get("SQ_INSTS_MFMA", 0.0) for k, v in kernels.items() if "walkg" in k or "partials" in k)
+    if busy > 0 and insts > 0 and busy / insts < 48:
+        # the walk issues v_mfma_f32_32x32x16_bf16 (32 busy cycles each; six of them -- three bf16 pieces per operand -- do the work of
+        # eight v_mfma_f32_32x32x2_f32): the matrix work counted as what the fp32 matrix path would issue for it, and the 16-bit pipe's own time
+        e["mfma_bf16_busy_cycles"] = busy
+        e["mfma_bf16_instructions"] = insts
+        e["mfma_issued_gflop"] = insts * (8.0 / 6.0) * 4096 / 1e9
+        e["mfma_issued_note"] = "fp32-equivalent: bf16 MFMA instructions x 8/6 x 4096 flop"
+    elif busy > 0:
         e["mfma_busy_cycles"] = busy
         e["mfma_issued_gflop"] = busy * 64 / 1e9
     out[cfg] = e
