@@ -142,7 +142,9 @@ def mcmc_gen_per_s(gold, nchains=1, quick=True):
         for tag, binary, beagle in runs:
             lo, hi = windows[(fixed, tag)]
             walls = []
-            repeats = 2 if tag != "reference_cpu" and (fixed or tag == "engine_device_parsimony") else 1
+            # (the same number of repeats and the same reduction -- the faster of two runs per window point -- for the engine and for
+            #  the reference it is divided by: the start-up in front of a window varies by +-0.3 s from run to run)
+            repeats = 2 if (fixed or tag in ("engine_device_parsimony", "reference_cpu")) else 1
             for ngen in (lo, hi):
                 walls.append(min(refrun.run_mb(binary, refrun.mcmc_nexus(st, tr, ngen, beagle=beagle, nchains=nchains,
                                                                          fixed_topology=fixed))[1] for _ in range(repeats)))

@@ -3857,11 +3857,16 @@ int beagleAccumulateScaleFactors(int instance, const int* scaleIndices, int coun
     // Reset + Accumulate of one cumulative buffer, back to back (rescaling the MrBayes way, reference src/mbbeagle.c:1080-1098): the
     // reset was not launched -- this launch stores instead of adding
     if (in->deferredReset >= 0) {
-        const bool fuse = in->deferredReset == cumulativeScaleIndex && count > 0;
+        bool fuse = in->deferredReset == cumulativeScaleIndex && count > 0;
+        for (int i = 0; fuse && i < count; ++i)
+            if (scaleIndices[i] == cumulativeScaleIndex) fuse = false;     // (the buffer among its own sources: reset-then-add, not a store)
         if (fuse) {
-            in->deferredReset = -1;
             if (in->hasPending()) { int frc = in->flushPending(); if (frc != BEAGLE_SUCCESS) return frc; }
-            return in->accumulate(scaleIndices, count, cumulativeScaleIndex, +1, true);
+            const int arc = in->accumulate(scaleIndices, count, cumulativeScaleIndex, +1, true);
+            if (arc == BEAGLE_SUCCESS) { in->deferredReset = -1; return arc; }
+            // the store did not happen (an index out of range, ...): the reset the caller asked for still does, then the error is theirs
+            const int drc = in->runDeferredReset();
+            return drc != BEAGLE_SUCCESS ? drc : arc;
         }
         int drc = in->runDeferredReset();
         if (drc != BEAGLE_SUCCESS) return drc;

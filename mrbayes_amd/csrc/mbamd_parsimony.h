@@ -255,7 +255,7 @@ public:
     std::vector<SetState> state;
     int stamp = 0, passCounter = 0;
     std::vector<int> phaseOf, waveOf, bucketStart, bucketFill, order, header, binWave, sizeOf, kid1, kid2;
-    std::vector<char> isRoot;
+    std::vector<char> isRoot, below;
     std::vector<std::pair<int, int>> heap;           // (subtree size, its root step)
     std::vector<ParsStep> compiled;
     std::vector<unsigned char> image;                // header + programs as they go to the device
@@ -622,7 +622,20 @@ public:
                     const int L = q0.passLen;
                     if (q0.kind != PARS_FINAL || q0.passPos != 0 || s0 + L > n) { ++s0; continue; }
                     auto inTop = [&](const Pending& q) { const SetState& t = state[(size_t) q.a]; return !(t.binStamp == launchStamp && t.bin >= 0); };
-                    std::stable_partition(pending.begin() + (long) (done + (size_t) s0), pending.begin() + (long) (done + (size_t) (s0 + L)), inTop);
+                    // ... valid only if nothing of "the top" hangs below a subtree: a step outside the bins whose ANCESTOR's step is in
+                    // one (or below one) would be moved in front of the step that makes the final set it reads.  MrBayes' passes cover
+                    // whole trees (never so); through the public API a partial down pass followed by a full final pass can: keep the
+                    // caller's order then.
+                    bool movable = true;
+                    below.assign(state.size(), 0);
+                    for (int i = 0; i < L && movable; ++i) {
+                        const Pending& q = pending[done + (size_t) (s0 + i)];
+                        const bool under = q.d >= 0 && below[(size_t) q.d];
+                        if (inTop(q) && under) movable = false;
+                        below[(size_t) q.a] = (!inTop(q) || under) ? 1 : 0;
+                    }
+                    if (movable)
+                        std::stable_partition(pending.begin() + (long) (done + (size_t) s0), pending.begin() + (long) (done + (size_t) (s0 + L)), inTop);
                     s0 += L;
                 }
             ++stamp;

@@ -909,6 +909,15 @@ def check_parsimony(lib, ntaxa, npat, nstates, seed=3, words=1, gaps=0.05):
         ol.pars_final(ref, subf, npat)
         inst.final_pass(subf)
         np.testing.assert_array_equal(inst.all_sets(), ref)
+        # a PARTIAL down pass (a big subtree: cut into bins over the waves of a workgroup) queued in front of a FULL final pass: steps
+        # of the final pass that hang below that subtree's bins must not be moved ahead of the steps that make their ancestors' sets
+        big = max((n for n in t.int_down_pass if n != t.root_left), key=lambda n: len(mp.down_pass_ops(t, n)))
+        part = mp.down_pass_ops(t, big)
+        ol.pars_down(ref, part, w)
+        assert inst.down_pass(part, want_length=False) is None
+        ol.pars_final(ref, fops, npat)
+        inst.final_pass(fops)
+        np.testing.assert_array_equal(inst.all_sets(), ref)
         # candidate positions: the three shapes ParsSPR1 uses and the four-set shape of ParsTBR1
         nodes = [n for n in t.all_down_pass if t.anc[n] >= 0]
         tuples = []
