@@ -356,6 +356,11 @@ BEAGLE_DLLEXPORT const char* mbamdGetLastError(void);
  * beagleUpdatePartials since the last reset.  enable=0 turns it off (default). */
 BEAGLE_DLLEXPORT int mbamdKernelTiming(int instance, int enable);
 BEAGLE_DLLEXPORT int mbamdGetKernelTiming(int instance, double* outMilliseconds, long* outLaunches, int reset);
+/* How the 4-state beagleUpdatePartials lists of this instance were run since it was made: out[0] lists, out[1] of them root-ward
+ * paths (k_path4), out[2] of those forked (arms that join: the lists of topology moves), out[3] paths run together with the
+ * log-likelihood behind them as one launch, out[4] lists compiled for the tree-walk kernel, out[5] their operations.  (Counters for
+ * tests and MBAMD_STATS; a facade or a double-precision instance reports zeros.) */
+BEAGLE_DLLEXPORT int mbamdGetListCounts(int instance, long* out6);
 /* While the timing is on: device time (ms) of whole evaluations -- from the first kernel launched after a
  * Calculate*LogLikelihoods call to the end of the next integration kernel, i.e. every kernel of a step (transition matrices,
  * partials, integration) and the gaps between them -- and how many such spans were closed. */

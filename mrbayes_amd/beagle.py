@@ -63,7 +63,7 @@ EXPORTS = [
     "beagleAccumulateScaleFactors", "beagleRemoveScaleFactors", "beagleResetScaleFactors", "beagleCopyScaleFactors",
     "beagleGetScaleFactors", "beagleCalculateRootLogLikelihoods", "beagleCalculateEdgeLogLikelihoods",
     "beagleGetSiteLogLikelihoods", "mbamdSynchronize", "mbamdGetLastError", "mbamdKernelTiming",
-    "mbamdGetKernelTiming", "mbamdGetStepTiming", "mbamdUpdateFinalPartials", "mbamdGetScaledPartials", "mbamdSetKernelPath", "mbamdSetDeferredResult", "mbamdFetchLogLikelihood", "mbamdReduceLogLikelihood", "mbamdGetResourcePciBusId", "mbamdGetInstanceDevices",
+    "mbamdGetKernelTiming", "mbamdGetListCounts", "mbamdGetStepTiming", "mbamdUpdateFinalPartials", "mbamdGetScaledPartials", "mbamdSetKernelPath", "mbamdSetDeferredResult", "mbamdFetchLogLikelihood", "mbamdReduceLogLikelihood", "mbamdGetResourcePciBusId", "mbamdGetInstanceDevices",
     "mbamdGetScaleExponents", "mbamdGetChildCount", "mbamdSetRateMatrices", "mbamdSetRateMatricesFrom",
     # BEAGLE v3 surface (multi-partition instances, resource benchmark)
     "beagleGetBenchmarkedResourceList", "beagleSetCPUThreadCount", "beagleSetPatternPartitions",
@@ -135,6 +135,7 @@ class BeagleLibrary:
                                                         _dp, _dp, _dp]
         L.beagleGetSiteLogLikelihoods.argtypes = [C.c_int, _dp]
         L.mbamdGetKernelTiming.argtypes = [C.c_int, _dp, C.POINTER(C.c_long), C.c_int]
+        L.mbamdGetListCounts.argtypes = [C.c_int, C.POINTER(C.c_long)]
         L.mbamdGetStepTiming.argtypes = [C.c_int, _dp, C.POINTER(C.c_long), C.c_int]
         L.mbamdUpdateFinalPartials.argtypes = [C.c_int, C.c_void_p, C.c_int]
         L.mbamdGetScaledPartials.argtypes = [C.c_int, C.c_int, C.c_int, C.POINTER(C.c_float), C.POINTER(C.c_float)]
@@ -418,6 +419,12 @@ class BeagleInstance:
         ms, n = C.c_double(0.0), C.c_long(0)
         self._chk(self.lib.mbamdGetKernelTiming(self.id, C.byref(ms), C.byref(n), 1 if reset else 0), "mbamdGetKernelTiming")
         return ms.value, n.value
+
+    def get_list_counts(self):
+        """(lists, paths, forked paths, paths fused with their log-likelihood, tree walks, their operations) of the 4-state lists."""
+        out = (C.c_long * 6)()
+        self._chk(self.lib.mbamdGetListCounts(self.id, out), "mbamdGetListCounts")
+        return tuple(int(v) for v in out)
 
     # ---- reports (include/libhmsbeagle/mbamd_reports.h) --------------------------------------------
     def update_final_partials(self, operations):

@@ -149,6 +149,7 @@ struct Plan {
     std::vector<Segment> segments;               // (Walk4Entry index of its program in d_table, geometry)
     std::vector<Walk4Entry> inlineProg;          // 4-state walk: a short single-segment program travels in the kernel arguments instead
     bool path = false;                           // 4-state walk: the list is a root-ward path -- inlineProg holds k_path4's entries
+    bool forked = false;                         // ... of several arms that join (the list of a topology move)
     bool pathG = false;                          // 20/61-state walk: every list is a root-ward path of the same length -- inlineProg holds k_pathg's entries
     int lists = 1;                               // 20/61-state walk: > 1 = the segments are that many independent lists, ONE launch
     std::vector<int> start;                      // general path: first table entry of each dependency level
@@ -242,6 +243,7 @@ struct Instance {
     bool heldPathFresh = false;
     int heldPathDst = -1;                        // the partials buffer the path's last operation writes
     bool noFusePath = false;                     // MBAMD_NO_FUSE_PATH: never hold a path
+    bool noForkPath = false;                     // MBAMD_NO_FORK_PATH: paths that join are compiled for k_walk4_t (A/B)
     int runHeldPath();
     int integratePath4(const int* parent, const int* child, const int* prob, const int* wIdx, const int* fIdx, const int* cumIdx);
     int updatePartialsG(const BeagleOperation* ops, int n, int cumIdx);
@@ -363,7 +365,7 @@ struct Instance {
     std::vector<Plan*> plans;        // small LRU cache of compiled operation lists
     uint64_t planClock = 0;
     int layoutEpoch = 0;             // bumped whenever a buffer changes between compact-tip and partials form
-    long planHits = 0, planMisses = 0, fusedPaths = 0, heldPaths = 0;
+    long planHits = 0, planMisses = 0, fusedPaths = 0, heldPaths = 0, forkedPaths = 0, listsTotal = 0, listsPath = 0, opsWalked = 0, listsWalked = 0;
 
     // ---- helpers ----------------------------------------------------------------------------
     int grow(void** p, size_t* cap, size_t bytes)
@@ -577,6 +579,7 @@ int Instance::create(int tipCount_, int partialsBufferCount, int compactBufferCo
     noInlinePrograms = std::getenv("MBAMD_NO_INLINE_PROGRAMS") != nullptr;
     noPath4 = std::getenv("MBAMD_NO_PATH4") != nullptr;
     noFusePath = std::getenv("MBAMD_NO_FUSE_PATH") != nullptr;
+    noForkPath = std::getenv("MBAMD_NO_FORK_PATH") != nullptr;
     noPathG = std::getenv("MBAMD_NO_PATHG") != nullptr;
     if (const char* e = std::getenv("MBAMD_MFMA_SERIAL")) serialRatio = std::max(0, std::atoi(e));
     noSpine = std::getenv("MBAMD_NO_SPINE") != nullptr;
@@ -1536,7 +1539,7 @@ int Instance::updatePartials4(const BeagleOperation* ops, int n, int cumIdx)
         int rc;
         {
             StatTimer st_(ST_PLAN);
-            plan->path = false;
+            plan->path = plan->forked = false;
             rc = buildPath4(*plan, ops, n) ? BEAGLE_SUCCESS : buildWalk(*plan, ops, n);
         }
         if (rc) { plan->hash = 0; plan->key.clear(); return rc; }
@@ -1548,6 +1551,9 @@ int Instance::updatePartials4(const BeagleOperation* ops, int n, int cumIdx)
     }
     int mrc = flushMatrices();
     if (mrc) return mrc;
+    listsTotal++;
+    if (plan->path) { listsPath++; if (plan->forked) forkedPaths++; }
+    else { listsWalked++; opsWalked += n; }
     if (plan->path && !noFusePath && K <= 8 && plan->inlineProg.size() <= MBAMD_W4_INLINE) {
         // hold it: the next call decides (runHeldPath / integratePath4)
         heldPath = plan;
@@ -1789,7 +1795,10 @@ int Instance::buildWalk(Plan& plan, const BeagleOperation* ops, int n, const int
 
 // A root-ward path (the list of a move that dirtied one branch) as k_path4's entries: operation i has the result of operation i - 1
 // as one child; its other child -- and both children of operation 0 -- are compact tips or buffers the list does not write; no buffer
-// or exponent buffer is written twice or read after it is written.  Anything else (false) is compiled by buildWalk.
+// or exponent buffer is written twice or read after it is written.  Round 6: also FORKED paths (the list of a topology move: root-ward
+// paths that join, in post-order) -- an operation that does not read its predecessor's result begins a new ARM (the predecessor's
+// result is saved), an operation whose other child is the saved result JOINS the arms; one saved result at a time.  Anything else
+// (false) is compiled by buildWalk.
 bool Instance::buildPath4(Plan& plan, const BeagleOperation* ops, int n)
 {
     if (noPath4 || n < 1 || n > MBAMD_W4_INLINE) return false;
@@ -1798,6 +1807,8 @@ bool Instance::buildPath4(Plan& plan, const BeagleOperation* ops, int n)
     std::vector<Walk4Entry>& prog = plan.inlineProg;
     prog.assign((size_t) n, Walk4Entry());
     auto inList = [&](int buf, int upto) { for (int q = 0; q < upto; ++q) if (ops[q].destinationPartials == buf) return true; return false; };
+    int saved = -1;                              // buffer of the saved result (an arm that waits for its join), or -1
+    int armStart = 0, arms = 0;
     for (int i = 0; i < n; ++i) {
         const BeagleOperation& b = ops[i];
         if (b.destinationPartials < 0 || b.destinationPartials >= nBuffers || b.child1Partials < 0 || b.child1Partials >= nBuffers ||
@@ -1805,16 +1816,27 @@ bool Instance::buildPath4(Plan& plan, const BeagleOperation* ops, int n)
             b.child2TransitionMatrix < 0 || b.child2TransitionMatrix >= nMatrices) return false;      // (buildWalk reports it)
         if (tipStates[b.destinationPartials] || inList(b.destinationPartials, i)) return false;
         int chain, sib, mchain, msib;
-        if (i == 0) { chain = b.child1Partials; sib = b.child2Partials; mchain = b.child1TransitionMatrix; msib = b.child2TransitionMatrix; }
-        else {
-            const int prev = ops[i - 1].destinationPartials;
-            const bool one = b.child1Partials == prev, two = b.child2Partials == prev;
-            if (one == two) return false;                                  // (neither, or both: not a path)
+        const int prev = i == 0 ? -1 : ops[i - 1].destinationPartials;
+        const bool one = i > 0 && b.child1Partials == prev, two = i > 0 && b.child2Partials == prev;
+        if (one && two) return false;
+        const bool start = !one && !two;
+        bool join = false;
+        if (start) {
+            if (i > 0) {
+                if (noForkPath || saved >= 0) return false;                // (two results waiting: not this kernel's shape)
+                saved = prev;
+                prog[(size_t) armStart].ctl |= (uint32_t) (i - armStart) << 16;
+                armStart = i;
+            }
+            ++arms;
+            chain = b.child1Partials; sib = b.child2Partials; mchain = b.child1TransitionMatrix; msib = b.child2TransitionMatrix;
+        } else {
             chain = one ? b.child1Partials : b.child2Partials; sib = one ? b.child2Partials : b.child1Partials;
             mchain = one ? b.child1TransitionMatrix : b.child2TransitionMatrix; msib = one ? b.child2TransitionMatrix : b.child1TransitionMatrix;
+            if (saved >= 0 && sib == saved) { join = true; saved = -1; }
         }
         // what comes from outside must not be written anywhere in the list (before: a second dependency; after: a hazard)
-        for (int ext : {sib, i == 0 ? chain : -1})
+        for (int ext : {join ? -1 : sib, start ? chain : -1})
             if (ext >= 0) {
                 if (inList(ext, n)) return false;
                 if (!tipStates[ext] && !valid[ext]) return false;
@@ -1823,11 +1845,13 @@ bool Instance::buildPath4(Plan& plan, const BeagleOperation* ops, int n)
         std::memset(&e, 0, sizeof e);
         uint32_t flags = 0, mode = SCALE_NONE;
         e.dst = (uint32_t) b.destinationPartials * pbuf;
-        if (i == 0) {
+        if (start) {
+            flags |= MBAMD_P4_START;
             if (tipStates[chain]) { e.c1 = (uint32_t) chain * 32u; flags |= MBAMD_W4_TIP1; }
             else e.c1 = (uint32_t) chain * pbuf;
         }
-        if (tipStates[sib]) { e.c2 = (uint32_t) sib * 32u; flags |= MBAMD_W4_TIP2; }
+        if (join) flags |= MBAMD_P4_JOIN;
+        else if (tipStates[sib]) { e.c2 = (uint32_t) sib * 32u; flags |= MBAMD_W4_TIP2; }
         else e.c2 = (uint32_t) sib * pbuf;
         e.m1 = (uint32_t) mchain * mbuf;
         e.m2 = (uint32_t) msib * mbuf;
@@ -1845,6 +1869,9 @@ bool Instance::buildPath4(Plan& plan, const BeagleOperation* ops, int n)
         }
         e.ctl = flags | (mode << 8);
     }
+    if (saved >= 0) return false;                // (an arm nobody joins: two trees in one list)
+    prog[(size_t) armStart].ctl |= (uint32_t) (n - armStart) << 16;
+    plan.forked = arms > 1;
     plan.path = true;
     plan.segments.clear();
     Plan::Segment sg;
@@ -3432,7 +3459,8 @@ int beagleCreateInstance(int tipCount, int partialsBufferCount, int compactBuffe
         returnInfo->resourceName = (dev < g_resources.length) ? g_resources.list[dev].name : const_cast<char*>("HIP device");
         returnInfo->implName = const_cast<char*>(first->f64 ? (first->S == 4 ? MBAMD_IMPL_NAME ": double-precision kernels (four states: tree walk)" : MBAMD_IMPL_NAME ": double-precision level kernels")
                                                  : first->s4 ? MBAMD_IMPL_NAME ": 4-state tree-walk kernels"
-                                                 : first->wg ? MBAMD_IMPL_NAME ": 20/61-state tree-walk kernels (v_mfma_f32_32x32x2_f32)"
+                                                 : first->wg ? (wg_bf16(first->S) ? MBAMD_IMPL_NAME ": general-state tree-walk kernels (fp32 arithmetic as three exact bf16 pieces on v_mfma_f32_32x32x16_bf16)"
+                                                                                  : MBAMD_IMPL_NAME ": general-state tree-walk kernels (v_mfma_f32_32x32x2_f32)")
                                                  : first->mfma ? MBAMD_IMPL_NAME ": general-state MFMA (v_mfma_f32_32x32x2_f32) kernels"
                                                                : MBAMD_IMPL_NAME ": general-state vector kernels");
         returnInfo->implDescription = const_cast<char*>("hand-written HIP kernels for AMD CDNA4 (MI355X)");
@@ -3454,6 +3482,9 @@ int beagleFinalizeInstance(int instance)
     if (g_statsOn) {
         std::fprintf(stderr, "[mbamd] instance %d: plan cache %ld hits / %ld misses; tree-walk schedules re-used %llu / built %llu; root-ward paths held %ld, run with their log-likelihood as one launch %ld\n", instance,
                      in->planHits, in->planMisses, (unsigned long long) in->scheduleHits, (unsigned long long) in->scheduleMisses, in->heldPaths, in->fusedPaths);
+        if (in->listsTotal)
+            std::fprintf(stderr, "[mbamd] instance %d: 4-state lists %ld: root-ward paths %ld (of them forked %ld), tree walks %ld (%.1f operations each)\n", instance,
+                         in->listsTotal, in->listsPath, in->forkedPaths, in->listsWalked, in->listsWalked ? (double) in->opsWalked / in->listsWalked : 0.0);
         for (const ApiStats& a : g_stats)
             std::fprintf(stderr, "[mbamd]   %-34s %9ld calls %10.3f ms total %9.2f us/call\n", a.name, a.calls,
                          a.seconds * 1e3, a.calls ? a.seconds * 1e6 / a.calls : 0.0);
@@ -4130,6 +4161,16 @@ int mbamdGetKernelTiming(int instance, double* outMilliseconds, long* outLaunche
     }
     if (outMilliseconds) *outMilliseconds = ms;
     if (outLaunches) *outLaunches = launches;
+    return BEAGLE_SUCCESS;
+}
+int mbamdGetListCounts(int instance, long* out6)
+{
+    GET_INSTANCE(instance);
+    if (!out6) return fail(BEAGLE_ERROR_OUT_OF_RANGE, "mbamdGetListCounts: null output");
+    for (int i = 0; i < 6; ++i) out6[i] = 0;
+    if (in->f64 || in->facade()) return BEAGLE_SUCCESS;
+    out6[0] = in->listsTotal; out6[1] = in->listsPath; out6[2] = in->forkedPaths; out6[3] = in->fusedPaths;
+    out6[4] = in->listsWalked; out6[5] = in->opsWalked;
     return BEAGLE_SUCCESS;
 }
 // Device time of whole evaluations while mbamdKernelTiming is on: from the first kernel launched after a log-likelihood

@@ -283,6 +283,14 @@ k_walk4_t(ARGS AA)
 // Entries (Walk4Entry): c1 = the chain's INPUT (entry 0 only: tip planes or a buffer), c2 = the sibling, m1 / m2 their matrices;
 // ctl: TIP1 (entry 0: the input is a compact tip), TIP2 (the sibling is one), [9:8] the scale mode.  blockDim.x = 64, grid = walk4_grid,
 // dynamic LDS = entries * 32 bytes.
+//
+// FORKED PATHS (round 6): the list of a topology move (NNI / SPR / TBR) is two root-ward paths that JOIN -- in the list's post-order:
+// arm A, arm B, the operation whose children are the two arms' last results, the common stem.  The program is a sequence of ARMS:
+// an entry flagged START begins one (its c1 is the arm's input, as entry 0's; ctl[23:16] = the arm's length) and, if it is not entry 0,
+// the running result is SAVED in registers first; an entry flagged JOIN has the saved result as its sibling.  One saved result at a
+// time (the host compiles anything deeper for k_walk4_t).  Chunks do not cross arms.
+#define MBAMD_P4_START 0x08000000u
+#define MBAMD_P4_JOIN  0x10000000u
 #if !defined(MBAMD_P4_CHUNK)
 #define MBAMD_P4_CHUNK 24         // (8: 17.8 us, 16: 16.6, 24: 15.9, 32: 16.3 -- median of the paths of DNA 500 x 20 000, profiles/r05_path4.txt)
 #endif
@@ -291,14 +299,19 @@ k_walk4_t(ARGS AA)
 __device__ __forceinline__ int walk4_path_run(const Walk4Entry* pp, int n, unsigned lane, f4* P0, const uint64_t* T0, int8_t* E0, const float* M0, f4& prev)
 {
     constexpr int C = MBAMD_P4_CHUNK;
+    int cum_e = 0;
+    f4 saved = {0.0f, 0.0f, 0.0f, 0.0f};
+    prev = saved;
+    for (int arm0 = 0, arm1 = 0; arm0 < n; arm0 = arm1) {
     {
-        const Walk4Entry e0 = walk4_entry_from_lds(pp);
+        const Walk4Entry e0 = walk4_entry_from_lds(pp + arm0);
+        arm1 = arm0 + (int) ((e0.ctl >> 16) & 0xFFu);
+        saved = prev;                                 // (the first arm saves nothing anyone reads)
         if (e0.ctl & MBAMD_W4_TIP1) prev = walk4_tip_vector(walk4_load_planes(walk4_at(T0, e0.c1)), lane);
         else prev = walk4_at_kib(P0, e0.c1)[lane];
     }
-    int cum_e = 0;
-    for (int base = 0; base < n; base += C) {
-        const int cnt = n - base < C ? n - base : C;
+    for (int base = arm0; base < arm1; base += C) {
+        const int cnt = arm1 - base < C ? arm1 - base : C;
         const Walk4Entry* const q = pp + base;
         f4 F[C];
         int er[C];
@@ -308,7 +321,7 @@ __device__ __forceinline__ int walk4_path_run(const Walk4Entry* pp, int n, unsig
             er[i] = 0;
             if (i < cnt) {
                 const Walk4Entry e = walk4_entry_from_lds(q + i);
-                if (!(e.ctl & MBAMD_W4_TIP2)) F[i] = walk4_at_kib(P0, e.c2)[lane];
+                if (!(e.ctl & (MBAMD_W4_TIP2 | MBAMD_P4_JOIN))) F[i] = walk4_at_kib(P0, e.c2)[lane];
                 if (e.ctl & MBAMD_W4_READS) er[i] = walk4_at(E0, e.eread)[lane];
             }
         }
@@ -331,6 +344,7 @@ __device__ __forceinline__ int walk4_path_run(const Walk4Entry* pp, int n, unsig
                     if (g + u < cnt) {
                         f4 v = F[g + u];
                         if (e[u].ctl & MBAMD_W4_TIP2) v = walk4_tip_vector(walk4_load_planes(walk4_at(T0, e[u].c2)), lane);   // (a tip sibling: once or twice per path)
+                        if (e[u].ctl & MBAMD_P4_JOIN) v = saved;                     // (the other arm's last result)
                         F[g + u] = walk4_matvec(M[u], v);
                     }
                 }
@@ -366,6 +380,7 @@ __device__ __forceinline__ int walk4_path_run(const Walk4Entry* pp, int n, unsig
                 }
             }
         }
+    }
     }
     return cum_e;
 }

@@ -807,6 +807,80 @@ def check_fused_path_and_likelihood(lib, oracle, monkeypatch, golden_dir=None, c
                 assert x == y, (scaling, x, y)
 
 
+def check_forked_paths(lib, oracle, monkeypatch, golden_dir=None, case=None, ntaxa=60, npat=700):
+    """The lists of topology moves -- two root-ward paths that join (NNI / SPR / TBR leave two dirty branches) -- run on the path kernel
+    as ARMS (round 6; a third dirty branch whose arm would need a second saved result goes to the tree walk as before).  Against the same
+    moves with MBAMD_NO_FORK_PATH=1 (the tree-walk kernel on the same lists): log-likelihoods and per-site values bit for bit through
+    accepts and rejects under both scaling schemes, the oracle / the fp64 engine within REL_FP64; the engine's list counters say that
+    the forked programs ran (and ran together with their log-likelihood as one launch)."""
+    for scaling in (lk.MB_BEAGLE_SCALE_DYNAMIC, lk.MB_BEAGLE_SCALE_ALWAYS):
+        runs, launches = [], []
+        for off in (False, True):
+            if off:
+                monkeypatch.setenv("MBAMD_NO_FORK_PATH", "1")
+            else:
+                monkeypatch.delenv("MBAMD_NO_FORK_PATH", raising=False)
+            div = division_from_golden(golden_dir, case) if case else synthetic_division("gtr", ntaxa, npat, seed=43, tree_seed=44, p_gap=0.03)
+            t = div.tree
+            bd = lk.BeagleDivision(div, lib, scaling=scaling)
+            f64 = lk.BeagleDivision(div, lib, scaling=scaling, double_precision=True) if (case and not off) else None
+            try:
+                seq = [bd.LogLike(0)]
+                bd.AcceptMove(0)
+                if f64 is not None:
+                    f64.LogLike(0)
+                    f64.AcceptMove(0)
+                rng = np.random.default_rng(17)
+                nodes = [i for i in range(len(t.anc)) if t.anc[i] != -1 and i != t.root]
+                by_depth = sorted(nodes, key=lambda i: _depth(t, i))
+                sets = [(by_depth[-1], by_depth[0]), (by_depth[-1], by_depth[-3]), (by_depth[1], by_depth[0])]
+                sets += [tuple(int(x) for x in rng.choice(nodes, 2, replace=False)) for _ in range(5)]
+                sets += [tuple(int(x) for x in rng.choice(nodes, 3, replace=False)) for _ in range(2)]
+                sets.append((by_depth[-1], t.anc[by_depth[-1]]))          # a branch and the one above it: one path
+                for rep, bs in enumerate(sets):
+                    old = [t.length[b] for b in bs]
+                    for q, b in enumerate(bs):
+                        t.length[b] = old[q] * (1.7 if (rep + q) % 2 else 0.6)
+                        bd.TouchBranch(0, b)
+                    lnl = bd.LogLike(0)
+                    seq.append(lnl)
+                    seq.append(bd.inst.get_site_log_likelihoods().copy())
+                    if not off and oracle is not None and rep < 4:
+                        want = oracle.tree_loglike(div, use_shortcuts=False)
+                        assert abs(lnl - want) / abs(want) < REL_FP64, (scaling, rep, lnl, want)
+                    if f64 is not None:
+                        for b in bs:
+                            f64.TouchBranch(0, b)
+                        want = f64.LogLike(0)
+                        assert abs(lnl - want) <= REL_FP64 * abs(want), (scaling, rep, lnl, want)
+                    if rep % 3 == 1:
+                        for q, b in enumerate(bs):
+                            t.length[b] = old[q]
+                        bd.ResetFlips(0)
+                        seq.append(bd.LogLike(0))
+                        if f64 is not None:
+                            f64.ResetFlips(0)
+                            f64.LogLike(0)
+                    bd.AcceptMove(0)
+                    if f64 is not None:
+                        f64.AcceptMove(0)
+                launches.append(bd.inst.get_list_counts())
+            finally:
+                bd.finalize()
+                if f64 is not None:
+                    f64.finalize()
+            runs.append(seq)
+        monkeypatch.delenv("MBAMD_NO_FORK_PATH", raising=False)
+        assert len(runs[0]) == len(runs[1])
+        for x, y in zip(runs[0], runs[1]):
+            if isinstance(x, np.ndarray):
+                assert np.array_equal(x, y), scaling
+            else:
+                assert x == y, (scaling, x, y)
+        on, offc = launches
+        assert on[2] >= 6 and on[3] >= on[2] and offc[2] == 0 and offc[4] >= on[4] + on[2], launches      # forked paths ran, fused; without: walks
+
+
 def _depth(t, i):
     d = 0
     while t.anc[i] != -1 and t.anc[i] != t.root:

@@ -647,3 +647,11 @@ def test_path_and_log_likelihood_in_one_launch(gpu, oracle, monkeypatch, golden_
     """k_path4_lnl == k_path4 + k_integrate_lnl_s4 bit for bit (a fixed-topology generation is one launch behind its matrices)."""
     ec.check_fused_path_and_likelihood(gpu, oracle, monkeypatch)
     ec.check_fused_path_and_likelihood(gpu, None, monkeypatch, golden_dir=golden_dir, case="bench_c2")
+
+
+def test_paths_that_join_run_as_arms(gpu, oracle, monkeypatch, golden_dir):
+    """The lists of topology moves (two dirty branches: two root-ward paths and their common stem) on the path kernel == the same
+    lists on the tree-walk kernel, bit for bit -- small against the oracle, at DNA 500 x 20 000 against the fp64 engine."""
+    ec.check_forked_paths(gpu, oracle, monkeypatch)
+    ec.check_forked_paths(gpu, None, monkeypatch, golden_dir=golden_dir, case="bench_c2")
+

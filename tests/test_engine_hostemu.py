@@ -338,3 +338,10 @@ def test_general_state_path_kernel(emu, oracle, golden_dir, monkeypatch):
 def test_path_and_log_likelihood_in_one_launch(emu, oracle, monkeypatch):
     """k_path4_lnl == k_path4 + k_integrate_lnl_s4 bit for bit (a fixed-topology generation is one launch behind its matrices)."""
     ec.check_fused_path_and_likelihood(emu, oracle, monkeypatch)
+
+
+def test_paths_that_join_run_as_arms(emu, oracle, monkeypatch):
+    """The lists of topology moves (two dirty branches: two root-ward paths and their common stem) on the path kernel == the same
+    lists on the tree-walk kernel, bit for bit; three dirty branches fall back to the walk where the arms nest."""
+    ec.check_forked_paths(emu, oracle, monkeypatch)
+
