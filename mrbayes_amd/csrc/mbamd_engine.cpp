@@ -306,6 +306,14 @@ struct Instance {
     uint32_t* h_flag_dev = nullptr;
     uint32_t flagSeq = 0;             // ... of the last integration launched
     bool pollResult = false;          // (off: MBAMD_NO_POLL, or the stream refused the write)
+    // Round 6: the block sums are their own completion signal.  Before an integration is launched the host fills h_sums with a
+    // bit pattern no sum can have; fetchResult then waits for every block sum to differ from it -- no gap + stream write behind the
+    // kernel (8.6 us of every evaluation, profiles/r06_walk61.txt), and no fence in the kernel (each sum is one 8-byte store to
+    // host-coherent memory).  Armed only when nothing else can still write h_sums (no unfetched result) and not in deferred mode
+    // (mbamdReduceLogLikelihood reads them on the device).  MBAMD_NO_SUM_POLL=1: the stream's flag only (A/B).
+    bool pollSums = false, sumsArmed = false;
+    static constexpr uint64_t kSumSentinel = 0x7FF4DEADBEEF0001ull;      // a signalling NaN with a payload no arithmetic produces
+    void armSums();
     unsigned char* stage_dev = nullptr;   // the device-side address of the staging ring
 
     // timing of the partials kernels
@@ -679,6 +687,7 @@ int Instance::create(int tipCount_, int partialsBufferCount, int compactBufferCo
         if (hipHostMalloc((void**) &h_flag, 64, hipHostMallocDefault) == hipSuccess && hipHostGetDevicePointer((void**) &h_flag_dev, h_flag, 0) == hipSuccess) {
             *h_flag = 0;
             pollResult = true;
+            pollSums = std::getenv("MBAMD_NO_SUM_POLL") == nullptr;
         } else {
             (void) hipGetLastError();
         }
@@ -769,9 +778,11 @@ int Instance::configureWalk()
     const int perCU = (int) std::max(1L, (wgs + numCU - 1) / numCU);          // workgroups a CU must host for full residency
     const int ldsPerWG = (160 * 1024) / std::min(perCU, 32) - 64;
     auto slotsFor = [&](int W) { return (ldsPerWG / W - MBAMD_W4_STAGE) / 1024; };
-    // measured (profiles/): about 10-12 waves per CU (2.5-3 per SIMD) is the sweet spot -- fewer leave the scalar-load
-    // latency uncovered, more cost LDS (slots) and tree-partition efficiency (phases, padding) without buying anything
-    int W = (int) std::max(1L, std::min((long) MBAMD_W4_MAXW, (12L * numCU + wgs / 2) / wgs));
+    // measured (profiles/): about 12-15 waves per CU (3-4 per SIMD) is the sweet spot -- fewer leave the scalar-load
+    // latency uncovered, more cost LDS (slots) and tree-partition efficiency (phases, padding) without buying anything.
+    // (Round 6, profiles/r06_walk4_waves.txt: DNA 500 x 20 000 = 4.9 workgroups per CU ran two waves each until then; with three
+    //  -- 15 waves per CU, 190 entries per wave instead of 264 -- the evaluation takes 0.158-0.164 ms instead of 0.181; four: 0.192.)
+    int W = (int) std::max(1L, std::min((long) MBAMD_W4_MAXW, (14L * numCU + wgs / 2) / wgs));
     while (W > 1 && slotsFor(W) < 7) --W;
     if (const char* e = std::getenv("MBAMD_WALK_WAVES")) W = std::max(1, std::min(MBAMD_W4_MAXW, std::atoi(e)));
     int slots = std::max(3, std::min(48, slotsFor(W)));
@@ -2739,6 +2750,7 @@ int Instance::integrate(const int* parent, const int* child, const int* prob, co
                         const int* cumIdx, int count, double* out)
 {
     if (count < 1 || count > MBAMD_MAX_SUBSETS) return fail(BEAGLE_ERROR_NO_IMPLEMENTATION, "log-likelihood: subset count");
+    armSums();
     if (arena()) {
         int rc;
         if (heldPath && count == 1 && parent[0] == heldPathDst && !(child && tipStates[child[0]] == nullptr && child[0] == heldPathDst)) {
@@ -2924,6 +2936,16 @@ int Instance::integrate4(const int* parent, const int* child, const int* prob, c
     return BEAGLE_SUCCESS;
 }
 
+// the block sums as their own completion signal: fill them with the pattern fetchResult waits to see overwritten
+void Instance::armSums()
+{
+    sumsArmed = pollSums && pollResult && !pendingResult && !deferred;
+    if (!sumsArmed) return;
+    uint64_t* p = reinterpret_cast<uint64_t*>(h_sums);
+    for (int i = 0; i < nblocks; ++i) p[i] = kSumSentinel;
+    __atomic_thread_fence(__ATOMIC_RELEASE);
+}
+
 // the stream writes the sequence number of this integration behind its kernel: what fetchResult polls
 void Instance::postResultFlag()
 {
@@ -2941,8 +2963,24 @@ int Instance::fetchResult(double* out)
     if (!pendingResult) return fail(BEAGLE_ERROR_GENERAL, "no log-likelihood pending");
     {
         StatTimer st_(ST_WAIT);
-        bool landed = false;
-        if (pollResult) {
+        bool landed = false, bySums = false;
+        if (sumsArmed) {
+            // every block of the integration kernel ends with ONE store of its sum: when all have changed, the kernel has done its work
+            const volatile uint64_t* p = reinterpret_cast<const volatile uint64_t*>(h_sums);
+            const auto t0 = std::chrono::steady_clock::now();
+            int i = 0;
+            for (long spins = 0; i < nblocks; ++spins) {
+                if (p[i] != kSumSentinel) { ++i; continue; }
+                if ((spins & 1023) == 1023 && std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(1)) break;
+#if defined(__x86_64__) || defined(__i386__)
+                __builtin_ia32_pause();
+#endif
+            }
+            landed = bySums = i == nblocks;
+            if (landed) __atomic_thread_fence(__ATOMIC_ACQUIRE);
+            sumsArmed = false;
+        }
+        if (!landed && pollResult) {
             // spin on the word the stream writes behind the integration kernel, for about a millisecond of wall time; then the runtime's wait
             volatile uint32_t* f = h_flag;
             const auto t0 = std::chrono::steady_clock::now();
@@ -2958,7 +2996,8 @@ int Instance::fetchResult(double* out)
         // mbamdReduceLogLikelihood, further lists) are complete only after a real synchronisation
         if (landed) syncedClock = std::max(syncedClock, flagClock);
         else { HIP_TRY(hipStreamSynchronize(stream)); syncedClock = launchClock; }
-        seenSeq = flagSeq;
+        // (seen through the sums: the kernel's other stores -- the site values -- may still be on their way; getSites then synchronises)
+        if (!bySums || *reinterpret_cast<volatile uint32_t*>(h_flag) == flagSeq) seenSeq = flagSeq;
     }
     pendingResult = false;
     double s = 0.0;

@@ -236,6 +236,7 @@ public:
     // wait on a stream costs ~25 us); MBAMD_NO_POLL=1: hipStreamSynchronize
     uint32_t* h_flag = nullptr;                      // pinned
     uint32_t* h_flag_dev = nullptr;
+    bool pollSums = false;                           // the sums as their own completion signal (armSums)
     uint32_t flagSeq = 0;
     bool poll = false;
     void* h_stage = nullptr;                         // pinned: one set in the device type
@@ -298,6 +299,7 @@ public:
         if (std::getenv("MBAMD_NO_POLL") == nullptr && hipHostMalloc((void**) &h_flag, 64, hipHostMallocDefault) == hipSuccess &&
             hipHostGetDevicePointer((void**) &h_flag_dev, h_flag, 0) == hipSuccess) {
             *h_flag = 0;
+            pollSums = std::getenv("MBAMD_NO_SUM_POLL") == nullptr;
             poll = true;
         } else {
             (void) hipGetLastError();
@@ -461,11 +463,38 @@ public:
         HIP_TRY(hipHostGetDevicePointer((void**) &d_out, h_out, 0));
         return BEAGLE_SUCCESS;
     }
+    // Round 6: the sums are their own completion signal (as the likelihood engine's block sums, mbamd_engine.cpp armSums): the host
+    // fills the `count` sums the next launch writes with a bit pattern no sum has, and waits until all of them have changed -- no
+    // stream operation behind the kernel.  MBAMD_NO_SUM_POLL=1: the stream's flag (A/B).
+    static constexpr uint64_t kSumSentinel = 0x7FF4DEADBEEF0001ull;
+    size_t armed = 0;
+    void armSums(size_t count)
+    {
+        armed = (poll && pollSums) ? count : 0;
+        uint64_t* p = reinterpret_cast<uint64_t*>(h_out);
+        for (size_t i = 0; i < armed; ++i) p[i] = kSumSentinel;
+        __atomic_thread_fence(__ATOMIC_RELEASE);
+    }
     // the kernels queued so far have written their sums into h_out when this returns
     int waitForSums()
     {
         StatTimer st_(ST_PARS_WAIT);
         bool landed = false;
+        if (armed) {
+            const volatile uint64_t* p = reinterpret_cast<const volatile uint64_t*>(h_out);
+            const auto t0 = std::chrono::steady_clock::now();
+            size_t i = 0;
+            for (long spins = 0; i < armed; ++spins) {
+                if (p[i] != kSumSentinel) { ++i; continue; }
+                if ((spins & 1023) == 1023 && std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(2)) break;
+#if defined(__x86_64__) || defined(__i386__)
+                __builtin_ia32_pause();
+#endif
+            }
+            landed = i == armed;
+            armed = 0;
+            if (landed) { __atomic_thread_fence(__ATOMIC_ACQUIRE); return BEAGLE_SUCCESS; }
+        }
         if (poll) {
             if (hipStreamWriteValue32(stream, h_flag_dev, ++flagSeq, 0) != hipSuccess) {
                 (void) hipGetLastError();
@@ -774,6 +803,7 @@ public:
             if (rc) return rc;
             // (a length is asked for a pass queued alone -- downPass() flushes what came before it; should the pass need more
             //  phases than one launch holds, every launch's sums are fetched and added)
+            if (outLength) armSums((size_t) blocks);
             launchWalk(static_cast<const int*>(d), nphases, W, outLength ? d_out : nullptr);
             HIP_TRY(hipGetLastError());
             rc = release(sl);
@@ -817,6 +847,7 @@ public:
         Slot* s = nullptr;
         rc = stage(tuples, (size_t) n * sizeof(ParsOp), &d, &s, true);
         if (rc) return rc;
+        armSums((size_t) n * SCORE_Y);
         switch (width) {
             case 1: launchScore<uint8_t>(static_cast<const ParsOp*>(d), n); break;
             case 2: launchScore<uint16_t>(static_cast<const ParsOp*>(d), n); break;
