@@ -1711,12 +1711,36 @@ int Instance::buildWalk(Plan& plan, const BeagleOperation* ops, int n, const int
                 if (op.scaleRead >= 0) e.eread = (uint32_t) op.scaleRead * ebuf;
             }
             if (te.vmwait != 0xFF) flags |= MBAMD_W4_VMWAIT;
-            // the entry in front of a SCALE_READ entry of the same wave fetches that entry's stored exponents (mbamd_walk4.h)
-            if ((i + 1) % (size_t) t.entries != 0) {
-                const Walk4Template::Entry& tn = t.prog[i + 1];
-                if (tn.op >= 0 && seg[tn.op].scaleWrite < 0 && seg[tn.op].scaleRead >= 0) flags |= MBAMD_W4_NEXT_READS;
-            }
             e.ctl = flags | (mode << 8) | ((uint32_t) (te.vmwait == 0xFF ? 0 : te.vmwait) << 10) | (keep << 16);
+        }
+        if (!wg) {
+            // The stored exponents of a SCALE_READ entry are requested MBAMD_W4_EXP_AHEAD positions ahead of it (mbamd_walk4.h): the
+            // entry at that distance in front carries the exponent buffer in ITS eread word; those of the first positions travel in
+            // the program's last read-ahead entry (never executed, never read ahead of).
+            static_assert(MBAMD_W4_EXP_AHEAD == 6, "the prologue words of the last read-ahead entry hold six exponent buffers");
+            const int D = MBAMD_W4_EXP_AHEAD, body = t.entries - t.tail;
+            auto readsAt = [&](int w, int p) -> int {                       // exponent buffer the entry at position p of wave w reads, or -1
+                if (p >= body) return -1;
+                const Walk4Template::Entry& tn = t.prog[(size_t) w * t.entries + p];
+                return (tn.op >= 0 && tn.pfOp[0] < 0 && seg[tn.op].scaleWrite < 0 && seg[tn.op].scaleRead >= 0) ? seg[tn.op].scaleRead : -1;
+            };
+            for (int w = 0; w < t.W; ++w) {
+                Walk4Entry* const prog = &w4table[sg.first + (size_t) w * t.entries];
+                for (int p = 0; p < body; ++p) {
+                    const int r = readsAt(w, p + D);
+                    if (r >= 0) { prog[p].ctl |= MBAMD_W4_AHEAD_READS; prog[p].eread = (uint32_t) r * ebuf; }
+                }
+                if (t.tail >= 2) {
+                    Walk4Entry& h = prog[t.entries - 1];
+                    uint32_t* const word[6] = {&h.dst, &h.c1, &h.c2, &h.m1, &h.m2, &h.ewrite};
+                    h.ctl = 0;
+                    for (int p = 0; p < D; ++p) {
+                        const int r = readsAt(w, p);
+                        *word[p] = r >= 0 ? (uint32_t) r * ebuf : 0u;
+                        if (r >= 0) h.ctl |= 1u << p;
+                    }
+                }
+            }
         }
         lastWalkW = t.W; lastWalkSlots = t.nslots; lastWalkEntries = t.entries; lastWalkPhases = t.phases;
         seg.clear();
