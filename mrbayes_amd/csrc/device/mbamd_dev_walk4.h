@@ -146,5 +146,7 @@ __device__ __forceinline__ void walk4_store(f4* P, int8_t* E, unsigned lane, f4 
     // (the byte store in the scalar-base + 32-bit lane offset form: the compiler builds a 64-bit address per lane instead)
     asm volatile("global_store_byte %0, %1, %2 nt" :: "v"(lane), "v"(e), "s"(E) : "memory");
 }
+// the same without exponents (an entry that does not rescale, or divides by stored exponents: nothing to record)
+__device__ __forceinline__ void walk4_store_partials(f4* P, unsigned lane, f4 out) { __builtin_nontemporal_store(out, as_global(P) + lane); }
 }  // namespace mbamd
 #endif

@@ -568,7 +568,7 @@ int Instance::create(int tipCount_, int partialsBufferCount, int compactBufferCo
         const size_t tb = wg_block_bytes(S), mf = (size_t) K * 64 * 64 + (size_t) K * wg_table_floats(S);
         wg = !s4 && wg_compiled(S) && K <= 16 && !forceGeneric && !noWalkG && std::getenv("MBAMD_NO_WALKG") == nullptr &&
              (size_t) (nBuffers + 1) * K * tb < ((size_t) 1 << 32) && (size_t) nMatrices * mf * 4 < ((size_t) 1 << 32) &&
-             (size_t) (nScale + 1) * K * 64 < ((size_t) 1 << 32) && (size_t) nBuffers * MBAMD_WG_TW < ((size_t) 1 << 32);
+             (size_t) (nScale + MBAMD_WG_SCRATCH_ROWS) * K * 64 < ((size_t) 1 << 32) && (size_t) nBuffers * MBAMD_WG_TW < ((size_t) 1 << 32);
     }
     if (s4) SP = 4;
     else if (S <= 4) SP = 4;
@@ -650,7 +650,11 @@ int Instance::create(int tipCount_, int partialsBufferCount, int compactBufferCo
         const size_t nt = (size_t) Ppad / MBAMD_WG_TW, nb = (size_t) Ppad / 64, tb = wg_block_bytes(S);
         wgTileBytes = (unsigned long) (nBuffers + 1) * K * tb;
         wgTipTileBytes = (unsigned) nBuffers * MBAMD_WG_TW;
-        estride = (unsigned) (scale.size() + 1) * K * 64;
+        // (+ the scratch rows: sinks of entries that do not record exponents.  The general-state kernels store an exponent byte with every
+        //  entry -- a conditional store would make the compiler's counted waits stricter -- and every entry of a SCALE_READ evaluation
+        //  storing to ONE row made such an evaluation 29 % slower at 20 states (same-address stores, profiles/r06_scale_read.txt): the
+        //  entries of a program rotate over MBAMD_WG_SCRATCH_ROWS rows)
+        estride = (unsigned) (scale.size() + MBAMD_WG_SCRATCH_ROWS) * K * 64;
         const size_t pBytes = nt * wgTileBytes, tBytes = nt * wgTipTileBytes, eBytes = nb * (size_t) estride;
         HIP_TRY(hipMalloc(&arenaPartials, pBytes));
         HIP_TRY(hipMalloc(&arenaTipStates, tBytes));
@@ -1609,7 +1613,8 @@ int Instance::buildWalk(Plan& plan, const BeagleOperation* ops, int n, const int
                 key.push_back(seg[o].tip1 ? -1 : writer[seg[o].c1]);
                 key.push_back(seg[o].tip2 ? -1 : writer[seg[o].c2]);
                 key.push_back((int) seg[o].tip1 | ((int) seg[o].tip2 << 1) | ((!seg[o].tip1 && !seg[o].tip2 && seg[o].c1 == seg[o].c2) ? 4 : 0) |
-                              ((seg[o].scaleWrite < 0 && seg[o].scaleRead >= 0) ? 8 : 0));   // (SCALE_READ entries wait for an exponent DMA)
+                              ((seg[o].scaleWrite < 0 && seg[o].scaleRead >= 0) ? 8 : 0) |   // (SCALE_READ entries wait for an exponent DMA,
+                              (seg[o].scaleWrite >= 0 ? 16 : 0));                            //  SCALE_WRITE entries issue a second store: the wait counts differ)
                 writer[seg[o].dst] = (int) o;
             }
             for (size_t o = 0; o < seg.size(); ++o) writer[seg[o].dst] = -1;
@@ -1655,6 +1660,7 @@ int Instance::buildWalk(Plan& plan, const BeagleOperation* ops, int n, const int
             uint32_t flags = te.flags, mode = SCALE_NONE, keep = 0;
             e.ewrite = (uint32_t) scratchScale * ebuf;
             e.eread = (uint32_t) scratchScale * ebuf;
+            if (wg) e.ewrite = (uint32_t) (scratchScale + (int) (i % (size_t) MBAMD_WG_SCRATCH_ROWS)) * ebuf;
             if (wg) {
                 // k_walkg (mbamd_walkg.h): no prefetch entries; a child that is neither a tip nor in a slot is read from
                 // HBM by the operand pipeline; NOP entries store zeros to the extra buffer of the tile
@@ -1966,6 +1972,7 @@ bool Instance::buildPathG(Plan& plan, const BeagleOperation* ops, int n, const s
             e.m1 = (uint32_t) mchain * mbuf;
             e.m2 = (uint32_t) msib * mbuf;
             e.ewrite = e.eread = (uint32_t) scratchScale * ebuf;
+            e.ewrite = (uint32_t) (scratchScale + i % MBAMD_WG_SCRATCH_ROWS) * ebuf;      // (a different scratch row for neighbouring entries, see the arena)
             if (b.destinationScaleWrite != BEAGLE_OP_NONE) {
                 if (b.destinationScaleWrite < 0 || b.destinationScaleWrite >= nScale) return false;
                 for (int o = 0; o < n; ++o)

@@ -31,9 +31,9 @@
 // evicted): they are LDS-DMA prefetches (global_load_lds_dwordx4, no destination register) issued through inline asm as
 // early as the host can place them -- all of a root-ward path's siblings before the first store when the slots allow
 // -- and the stored exponents of dynamic rescaling's "divide by the existing factors" pass (one byte per lane: an LDS-DMA
-// of the next entry's 64 bytes into a two-deep staging area).  Their consumer waits with the exact s_waitcnt vmcnt(N) the
+// of an entry's 64 bytes into a ring of landing areas, six entries ahead).  Their consumer waits with the exact s_waitcnt vmcnt(N) the
 // host computed by replaying the instruction sequence (Walk4Entry vmwait): per iteration
-// [0-2 prefetches (PF entries only)] [wait] [exponent DMA for the next entry if it is SCALE_READ] [2 stores if an operation].
+// [0-2 prefetches (PF entries only)] [wait] [exponent DMA for a later entry if that is SCALE_READ] [1 store if an operation, 2 if SCALE_WRITE].
 // The stores are non-temporal: a result is never read again in the launch that wrote it (parents read the LDS copy), and
 // letting 0.7 GB of write-allocated lines stream through L2 evicted the matrices and programs every wave keeps
 // re-reading -- every scalar load then paid an HBM round trip (measured: 1.6x on the whole kernel).
@@ -207,7 +207,7 @@ k_walk4_t(ARGS AA)
 
     // One iteration = one entry.  Vector-memory instruction sequence (the host's vmwait counts on exactly this):
     //     [DMA pf0] [DMA pf1] (PF entries)   s_waitcnt vmcnt(vmwait) (flag VMWAIT)
-    //     [exponent DMA for the entry EXP_AHEAD positions on, if that is SCALE_READ]   [2 stores, if this entry is an operation]
+    //     [exponent DMA for the entry EXP_AHEAD positions on, if that is SCALE_READ]   [1 store, if this entry is an operation; 2 if it is SCALE_WRITE]
     // Everything wave-uniform is a scalar branch or a scalar select (no divergent control flow).  The loop is unrolled by
     // two so that the two entry descriptors in flight keep their registers (no moves): `cur` is executed, `nxt` is the
     // next one, and cur's registers receive entry j + 2.  ALL scalar loads of an iteration (next entry's matrices and tip
@@ -261,12 +261,10 @@ k_walk4_t(ARGS AA)
             o.x = scale_pow2(o.x, -e); o.y = scale_pow2(o.y, -e);
             o.z = scale_pow2(o.z, -e); o.w = scale_pow2(o.w, -e);
             if (ctl & MBAMD_W4_KEEP) *reinterpret_cast<f4*>(slots + ((ctl >> 6) & 0x3FC00u)) = o;
-#if defined(MBAMD_W4_ABL_NO_SCRATCH_STORE)
+            // (the exponents are stored only where the list asks for them: every entry of a SCALE_READ evaluation writing its byte to the
+            //  one scratch row of its block made such an evaluation a third slower -- same-address stores, profiles/r06_scale_read.txt)
             if (wm) walk4_store(walk4_at_kib(P0, dst), walk4_at(E0, ewrite), lane, o, e);
-            else __builtin_nontemporal_store(o, walk4_at_kib(P0, dst) + lane);
-#else
-            walk4_store(walk4_at_kib(P0, dst), walk4_at(E0, ewrite), lane, o, e);
-#endif
+            else walk4_store_partials(walk4_at_kib(P0, dst), lane, o);
         }
         out = o;
     };
@@ -403,7 +401,8 @@ __device__ __forceinline__ int walk4_path_run(const Walk4Entry* pp, int n, unsig
                         cum_e += ew;
                         o.x = scale_pow2(o.x, -ex); o.y = scale_pow2(o.y, -ex);
                         o.z = scale_pow2(o.z, -ex); o.w = scale_pow2(o.w, -ex);
-                        walk4_store(walk4_at_kib(P0, e[u].dst), walk4_at(E0, e[u].ewrite), lane, o, ex);
+                        if (wm) walk4_store(walk4_at_kib(P0, e[u].dst), walk4_at(E0, e[u].ewrite), lane, o, ex);
+                        else walk4_store_partials(walk4_at_kib(P0, e[u].dst), lane, o);
                         prev = o;
                     }
                 }

@@ -558,7 +558,7 @@ inline bool Walk4Builder::build(const std::vector<Walk4Op>& ops, Walk4Template& 
         }
         // 5. wait counts: replay the vector-memory instruction sequence of the kernel loop (mbamd_walk4.h)
         //    prologue: [exponent DMAs for those of the first expAhead entries that are SCALE_READ]
-        //    iteration j: [PF DMAs] WAIT [exponent DMA for entry j + expAhead if that is SCALE_READ] [2 stores if an operation]
+        //    iteration j: [PF DMAs] WAIT [exponent DMA for entry j + expAhead if that is SCALE_READ] [1 store if an operation, 2 if SCALE_WRITE]
         auto reads = [&](const Walk4Template::Entry& e) { return e.op >= 0 && ops[e.op].scaleRead >= 0 && ops[e.op].scaleWrite < 0; };
         long issued = 0;
         std::vector<long>& expSeqOf = s.expSeqOf;               // sequence number of the exponent DMA of every entry (-1: none)
@@ -583,7 +583,7 @@ inline bool Walk4Builder::build(const std::vector<Walk4Op>& ops, Walk4Template& 
             if (needed < 0) e.vmwait = 0xFF;                        // (no wait)
             else e.vmwait = safeWaits ? 0 : (uint8_t) walk4_round_wait(issued - (needed + 1));
             if (j + (size_t) expAhead < out.size() && reads(out[j + (size_t) expAhead])) expSeqOf[j + (size_t) expAhead] = issued++;
-            if (e.op >= 0) issued += 2;
+            if (e.op >= 0) issued += ops[e.op].scaleWrite >= 0 ? 2 : 1;     // (partials; the exponents only where the list records them)
         }
     }
     size_t longestFinal = 0;

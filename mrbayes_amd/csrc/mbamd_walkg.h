@@ -52,6 +52,7 @@ namespace mbamd {
 // whatever its tile width: halving the tile doubles that traffic, and the operand fetch is what bounds the kernel.  Its branches
 // were removed in round 5 (git history has them).
 #define MBAMD_WG_TW 32
+#define MBAMD_WG_SCRATCH_ROWS 32  // exponent rows behind the scale buffers that entries without SCALE_WRITE store to, in rotation (nobody reads them)
 #define MBAMD_WG_KS (64 / MBAMD_WG_TW)    // states per row of a block = per MFMA step (2 or 4)
 // ---- round 6: the contraction on the 16-BIT matrix cores, in fp32 arithmetic (profiles/r06_bf16x3.txt) ----------------------------
 // v_mfma_f32_32x32x2_f32 runs at the fp32 VECTOR rate (64 cycles for 4 096 flops) and shares the SIMD's vector issue port: nothing

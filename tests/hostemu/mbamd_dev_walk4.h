@@ -45,5 +45,6 @@ inline Walk4Lds walk4_lds(char* mine, unsigned lane) { return Walk4Lds{mine, lan
 inline void walk4_prefetch(const Walk4Lds& L, const f4* src, unsigned dst) { walk4_dma(src, L.lane, reinterpret_cast<f4*>(L.mine + MBAMD_W4_STAGE + dst)); }
 inline void walk4_fetch_exps(const Walk4Lds& L, const int8_t* src, unsigned lane, int parity) { walk4_dma_exps(src, lane, reinterpret_cast<int*>(L.mine) + 64 * parity); }
 inline void walk4_store(f4* P, int8_t* E, unsigned lane, f4 out, int e) { P[lane] = out; E[lane] = (int8_t) e; }
+inline void walk4_store_partials(f4* P, unsigned lane, f4 out) { P[lane] = out; }
 }  // namespace mbamd
 #endif
