@@ -495,6 +495,8 @@ struct Instance {
     std::vector<char> pendingMatrixOut;          // matrix buffers the queued jobs write
     int submit(Plan* plan, int cumIdx, int32_t* cumPtr);
     bool noDefer = false;            // MBAMD_NO_DEFER: run every list at once
+    bool eagerMatrices = false;      // four states (one call per evaluation): beagleUpdateTransitionMatrices launches the matrix kernel itself -- it runs while
+                                     // MrBayes assembles the operation list (+2 % on both chains, profiles/r06_scale_read.txt); MBAMD_LAZY_MATRICES=1: queued as for the other models
     bool noInlinePrograms = false;   // MBAMD_NO_INLINE_PROGRAMS: every walk program through a device buffer
     bool envVerbose = false, envTrace = false;   // MBAMD_VERBOSE, MBAMD_WALK_TRACE (read once)
     bool noSpine = false;            // MBAMD_NO_SPINE: serial launches use the plain (not software-pipelined) kernel
@@ -584,6 +586,7 @@ int Instance::create(int tipCount_, int partialsBufferCount, int compactBufferCo
     if (mfma) SP = 32 * NT;          // transposed matrices padded to the MFMA tile height
     mfmaWhole = std::getenv("MBAMD_MFMA_WHOLE") != nullptr;
     noDefer = std::getenv("MBAMD_NO_DEFER") != nullptr;
+    eagerMatrices = s4 && std::getenv("MBAMD_LAZY_MATRICES") == nullptr;
     noInlinePrograms = std::getenv("MBAMD_NO_INLINE_PROGRAMS") != nullptr;
     noPath4 = std::getenv("MBAMD_NO_PATH4") != nullptr;
     noFusePath = std::getenv("MBAMD_NO_FUSE_PATH") != nullptr;
@@ -1044,6 +1047,7 @@ int Instance::updateMatrices(int eigenIndex, const int* probIdx, const double* l
         pendingJobs.push_back(j);
         pendingMatrixOut[probIdx[i]] = 1;
     }
+    if (eagerMatrices) return flushMatrices();
     return BEAGLE_SUCCESS;
 }
 
