@@ -146,6 +146,23 @@ __device__ __forceinline__ void walk4_store(f4* P, int8_t* E, unsigned lane, f4 
     // (the byte store in the scalar-base + 32-bit lane offset form: the compiler builds a 64-bit address per lane instead)
     asm volatile("global_store_byte %0, %1, %2 nt" :: "v"(lane), "v"(e), "s"(E) : "memory");
 }
+// a plain 16-byte vector load (k_path4's matrices: eight lanes per entry)
+__device__ __forceinline__ f4 walk4_load_f4(const f4* p) { return *reinterpret_cast<const MBAMD_AS_GLOBAL f4*>((uintptr_t) p); }
+// other LANES of this wave wrote LDS that this lane reads next (or the reverse): a wave's LDS instructions execute in order, the compiler is told
+__device__ __forceinline__ void walk4_wave_lds_fence()
+{
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    MBAMD_WAVE_SYNC();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+// a 4 x 4 matrix from LDS, the same address in every lane (broadcast reads): the operand of walk4_matvec in vector registers
+__device__ __forceinline__ Walk4Mat walk4_matrix_from_lds(const f4* p)
+{
+    const f4 a = p[0], b = p[1], c = p[2], d = p[3];
+    Walk4Mat r;
+    r.m = f16v{a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w, c.x, c.y, c.z, c.w, d.x, d.y, d.z, d.w};
+    return r;
+}
 // the same without exponents (an entry that does not rescale, or divides by stored exponents: nothing to record)
 __device__ __forceinline__ void walk4_store_partials(f4* P, unsigned lane, f4 out) { __builtin_nontemporal_store(out, as_global(P) + lane); }
 }  // namespace mbamd

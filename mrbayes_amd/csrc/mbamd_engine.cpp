@@ -2025,7 +2025,7 @@ int Instance::runWalk(const Plan& plan, int32_t* cum)
         a.tail = 0;
         std::memcpy(ai.inl, plan.inlineProg.data(), plan.inlineProg.size() * sizeof(Walk4Entry));
         auto kernel = k_path4<Walk4ArgsInline>;
-        MBAMD_LAUNCH(kernel, walk4_grid(Ppad / 64, K), 64, plan.inlineProg.size() * sizeof(Walk4Entry), stream, ai);
+        MBAMD_LAUNCH_BARRIER(kernel, walk4_grid(Ppad / 64, K), 64, path4_lds_bytes((int) plan.inlineProg.size()), stream, ai);    // (lanes exchange through LDS: the emulation runs them as fibers)
         HIP_TRY(hipGetLastError());
         pendingLaunches += 1;
         return BEAGLE_SUCCESS;

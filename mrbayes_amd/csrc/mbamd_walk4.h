@@ -309,7 +309,7 @@ k_walk4_t(ARGS AA)
 // No LDS, no slots, no barrier; F lives in registers.  Same arithmetic, operation by operation, as k_walk4_t: the same bits.
 // Entries (Walk4Entry): c1 = the chain's INPUT (entry 0 only: tip planes or a buffer), c2 = the sibling, m1 / m2 their matrices;
 // ctl: TIP1 (entry 0: the input is a compact tip), TIP2 (the sibling is one), [9:8] the scale mode.  blockDim.x = 64, grid = walk4_grid,
-// dynamic LDS = entries * 32 bytes.
+// dynamic LDS = path4_lds_bytes(entries).
 //
 // FORKED PATHS (round 6): the list of a topology move (NNI / SPR / TBR) is two root-ward paths that JOIN -- in the list's post-order:
 // arm A, arm B, the operation whose children are the two arms' last results, the common stem.  The program is a sequence of ARMS:
@@ -323,9 +323,14 @@ k_walk4_t(ARGS AA)
 #endif
 #define MBAMD_P4_GROUP 4         // matrices per burst of scalar loads (4 x 16 scalar registers)
 // the path itself: `prev` starts as the chain's input and ends as the last result; returns the exponents this wave's column gained
-__device__ __forceinline__ int walk4_path_run(const Walk4Entry* pp, int n, unsigned lane, f4* P0, const uint64_t* T0, int8_t* E0, const float* M0, f4& prev)
+// `MS`: this wave's LDS area for the matrices of a chunk (MBAMD_P4_MATRIX_BYTES).  Round 6: the 2 x 24 matrices of a chunk came through
+// the scalar cache in bursts of four -- twelve dependent round trips per chunk on a wave that is alone on its SIMD; now eight lanes per
+// entry fetch them (three vector loads per chunk, in front of the sibling loads), they wait in LDS and every use is four broadcast reads.
+#define MBAMD_P4_MATRIX_BYTES (MBAMD_P4_CHUNK * 2 * 64)
+__device__ __forceinline__ int walk4_path_run(const Walk4Entry* pp, int n, unsigned lane, f4* P0, const uint64_t* T0, int8_t* E0, const float* M0, f4& prev, f4* MS)
 {
     constexpr int C = MBAMD_P4_CHUNK;
+    static_assert(C % 8 == 0, "eight entries' matrices per vector load");
     int cum_e = 0;
     f4 saved = {0.0f, 0.0f, 0.0f, 0.0f};
     prev = saved;
@@ -342,19 +347,36 @@ __device__ __forceinline__ int walk4_path_run(const Walk4Entry* pp, int n, unsig
         const Walk4Entry* const q = pp + base;
         f4 F[C];
         int er[C];
-        // 1a. what the chunk reads from HBM, back to back
+        // 1a. what the chunk reads from HBM, back to back -- its matrices first: lane -> (entry 8 r + lane / 8, child (lane / 4) & 1, quarter lane & 3)
+        f4 mq[C / 8];
+#pragma unroll
+        for (int r = 0; r < C / 8; ++r) {
+            const int i = 8 * r + (int) (lane >> 3);
+            mq[r] = f4{0.0f, 0.0f, 0.0f, 0.0f};
+            if (i < cnt) {
+                const Walk4Entry* const ep = q + i;
+                const unsigned off = (lane & 4u) ? ep->m2 : ep->m1;
+                mq[r] = walk4_load_f4(reinterpret_cast<const f4*>(walk4_at(M0, off)) + (lane & 3u));
+            }
+        }
 #pragma unroll
         for (int i = 0; i < C; ++i) {
             er[i] = 0;
             if (i < cnt) {
                 const Walk4Entry e = walk4_entry_from_lds(q + i);
+#if defined(MBAMD_P4_ABL_NO_LOAD)
+                F[i] = f4{0.25f, 0.25f, 0.25f, 0.25f};
+#else
                 if (!(e.ctl & (MBAMD_W4_TIP2 | MBAMD_P4_JOIN))) F[i] = walk4_at_kib(P0, e.c2)[lane];
+#endif
                 if (e.ctl & MBAMD_W4_READS) er[i] = walk4_at(E0, e.eread)[lane];
             }
         }
-        // 1b. the sibling factors (nothing here depends on the chain).  The matrices come through the scalar cache -- every workgroup
-        // reads the same ones, a miss is an L2 round trip of several hundred cycles against ~50 cycles of products -- in BURSTS of
-        // MBAMD_P4_GROUP: one round trip per group instead of one per operation.
+        // (the matrices land first -- loads return in order -- and go to LDS: [entry][child][16 floats])
+#pragma unroll
+        for (int r = 0; r < C / 8; ++r) MS[(size_t) r * 64 + lane] = mq[r];
+        walk4_wave_lds_fence();
+        // 1b. the sibling factors (nothing here depends on the chain)
         constexpr int G = MBAMD_P4_GROUP;
 #pragma unroll
         for (int g = 0; g < C; g += G) {
@@ -364,7 +386,7 @@ __device__ __forceinline__ int walk4_path_run(const Walk4Entry* pp, int n, unsig
 #pragma unroll
                 for (int u = 0; u < G; ++u) {
                     e[u] = walk4_entry_from_lds(q + (g + u < cnt ? g + u : g));
-                    M[u] = walk4_load_matrix(walk4_at(M0, e[u].m2));
+                    M[u] = walk4_matrix_from_lds(MS + (size_t) ((g + u < cnt ? g + u : g) * 2 + 1) * 4);
                 }
 #pragma unroll
                 for (int u = 0; u < G; ++u) {
@@ -386,7 +408,7 @@ __device__ __forceinline__ int walk4_path_run(const Walk4Entry* pp, int n, unsig
 #pragma unroll
                 for (int u = 0; u < G; ++u) {
                     e[u] = walk4_entry_from_lds(q + (g + u < cnt ? g + u : g));
-                    M[u] = walk4_load_matrix(walk4_at(M0, e[u].m1));
+                    M[u] = walk4_matrix_from_lds(MS + (size_t) ((g + u < cnt ? g + u : g) * 2) * 4);
                 }
 #pragma unroll
                 for (int u = 0; u < G; ++u) {
@@ -401,18 +423,25 @@ __device__ __forceinline__ int walk4_path_run(const Walk4Entry* pp, int n, unsig
                         cum_e += ew;
                         o.x = scale_pow2(o.x, -ex); o.y = scale_pow2(o.y, -ex);
                         o.z = scale_pow2(o.z, -ex); o.w = scale_pow2(o.w, -ex);
+#if defined(MBAMD_P4_ABL_NO_STORE)
+                        if (o.x == 123.456f) walk4_store_partials(walk4_at_kib(P0, e[u].dst), lane, o);
+#else
                         if (wm) walk4_store(walk4_at_kib(P0, e[u].dst), walk4_at(E0, e[u].ewrite), lane, o, ex);
                         else walk4_store_partials(walk4_at_kib(P0, e[u].dst), lane, o);
+#endif
                         prev = o;
                     }
                 }
             }
         }
+        walk4_wave_lds_fence();                      // (the next chunk's matrices overwrite these)
     }
     }
     return cum_e;
 }
 
+__host__ __device__ inline size_t path4_program_bytes(int entries) { return (size_t) ((entries * 32 + 63) / 64 * 64); }
+__host__ __device__ inline size_t path4_lds_bytes(int entries) { return path4_program_bytes(entries) + MBAMD_P4_MATRIX_BYTES; }
 template <class ARGS>
 __global__ void __launch_bounds__(64)
 k_path4(ARGS AA)
@@ -432,7 +461,7 @@ k_path4(ARGS AA)
     Walk4Entry* const pp = mbd_dyn_lds<Walk4Entry>();
     walk4_program_to_lds(walk4_program(AA), pp, n, lane);
     f4 prev;
-    const int cum_e = walk4_path_run(pp, n, lane, P0, T0, E0, M0, prev);
+    const int cum_e = walk4_path_run(pp, n, lane, P0, T0, E0, M0, prev, reinterpret_cast<f4*>(reinterpret_cast<char*>(pp) + path4_program_bytes(n)));
     if (A.cum != nullptr) {
         int32_t* dst = A.cum + (size_t) k * A.Ppad + (size_t) blk * 64 + lane;
         if (A.cumFresh) *dst = cum_e;
@@ -460,7 +489,7 @@ struct PathLnl4 {
     int            P;
     int            child_kind;     // CHILD_STATES / CHILD_PARTIALS
 };
-__host__ __device__ inline size_t path4_lnl_lds_bytes(int entries, int K) { return (size_t) ((entries * 32 + 63) / 64 * 64) + (size_t) K * 64 * (sizeof(f4) + sizeof(int)); }
+__host__ __device__ inline size_t path4_lnl_lds_bytes(int entries, int K) { return (size_t) ((entries * 32 + 63) / 64 * 64) + (size_t) K * 64 * (sizeof(f4) + sizeof(int)) + (size_t) K * MBAMD_P4_MATRIX_BYTES; }
 template <class ARGS>
 __global__ void __launch_bounds__(512)
 k_path4_lnl(ARGS AA, PathLnl4 t)
@@ -480,7 +509,9 @@ k_path4_lnl(ARGS AA, PathLnl4 t)
     Walk4Entry* const pp = mbd_dyn_lds<Walk4Entry>();
     walk4_program_to_lds(walk4_program(AA), pp, n, lane);
     f4 prev;
-    const int cum_e = walk4_path_run(pp, n, lane, P0, T0, E0, M0, prev);
+    char* const xb = reinterpret_cast<char*>(pp) + (size_t) ((n * 32 + 63) / 64 * 64);
+    const int cum_e = walk4_path_run(pp, n, lane, P0, T0, E0, M0, prev,
+                                     reinterpret_cast<f4*>(xb + (size_t) K * 64 * (sizeof(f4) + sizeof(int)) + (size_t) k * MBAMD_P4_MATRIX_BYTES));
     const size_t col = (size_t) k * A.Ppad + (size_t) blk * 64 + lane;
     int e_col = 0;                                   // this column's cumulative exponent as the integration reads it
     if (A.cum != nullptr) {
@@ -490,7 +521,6 @@ k_path4_lnl(ARGS AA, PathLnl4 t)
         if (t.cum == A.cum) e_col = total;
     }
     if (t.cum != nullptr && t.cum != A.cum) e_col = t.cum[col];
-    char* const xb = reinterpret_cast<char*>(pp) + (size_t) ((n * 32 + 63) / 64 * 64);
     f4* const xp = reinterpret_cast<f4*>(xb);                                  // [K][64] last results
     int* const xe = reinterpret_cast<int*>(xb + (size_t) K * 64 * sizeof(f4));   // [K][64] exponents
     xp[k * 64 + lane] = prev;

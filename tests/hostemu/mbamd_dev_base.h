@@ -60,10 +60,23 @@ inline double mbd_shfl_down_32(double v, int off)                  // (a wave-wi
 }
 template <class T> inline T* mbd_dyn_lds() { return reinterpret_cast<T*>(mbamd_emu_dyn_lds()); }
 // (threads of a block run one after the other between barriers: thread 0 comes first)
+// (as fibers the lanes of a wave reach this point in any order -- whoever completed the last collective runs on first: the lanes'
+//  values meet in a wave-wide exchange and the first thread adds them up in lane order)
 inline void mbd_wave_sum_store(double v, double* slot)
 {
-    if (threadIdx.x == 0) *slot = 0.0;
-    *slot += v;
+    if (emu_fibers().current < 0) {
+        if (threadIdx.x == 0) *slot = 0.0;
+        *slot += v;
+        return;
+    }
+    uint64_t bits;
+    std::memcpy(&bits, &v, sizeof bits);
+    const EmuExchange x = mbamd_emu_exchange(bits, 0);
+    if (threadIdx.x != 0) return;
+    double total = 0.0;
+    const unsigned n = blockDim.x < 64u ? blockDim.x : 64u;
+    for (unsigned l = 0; l < n; ++l) { double t; std::memcpy(&t, &x.a[l], sizeof t); total += t; }
+    *slot = total;
 }
 inline void mbd_block_sum2_256(double off, double diag, double* red, int tid, double& o4, double& d4)
 {

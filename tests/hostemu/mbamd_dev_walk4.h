@@ -46,5 +46,8 @@ inline void walk4_prefetch(const Walk4Lds& L, const f4* src, unsigned dst) { wal
 inline void walk4_fetch_exps(const Walk4Lds& L, const int8_t* src, unsigned lane, int parity) { walk4_dma_exps(src, lane, reinterpret_cast<int*>(L.mine) + 64 * parity); }
 inline void walk4_store(f4* P, int8_t* E, unsigned lane, f4 out, int e) { P[lane] = out; E[lane] = (int8_t) e; }
 inline void walk4_store_partials(f4* P, unsigned lane, f4 out) { P[lane] = out; }
+inline f4 walk4_load_f4(const f4* p) { return *p; }
+inline void walk4_wave_lds_fence() { MBAMD_WAVE_SYNC(); }
+inline Walk4Mat walk4_matrix_from_lds(const f4* p) { Walk4Mat r; for (int i = 0; i < 4; ++i) { r.m[4 * i] = p[i].x; r.m[4 * i + 1] = p[i].y; r.m[4 * i + 2] = p[i].z; r.m[4 * i + 3] = p[i].w; } return r; }
 }  // namespace mbamd
 #endif
