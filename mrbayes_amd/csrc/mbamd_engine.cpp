@@ -311,7 +311,7 @@ struct Instance {
     // kernel (8.6 us of every evaluation, profiles/r06_walk61.txt), and no fence in the kernel (each sum is one 8-byte store to
     // host-coherent memory).  Armed only when nothing else can still write h_sums (no unfetched result) and not in deferred mode
     // (mbamdReduceLogLikelihood reads them on the device).  MBAMD_NO_SUM_POLL=1: the stream's flag only (A/B).
-    bool pollSums = false, sumsArmed = false;
+    bool pollSums = false, sumsArmed = false, flagWritten = false;
     static constexpr uint64_t kSumSentinel = 0x7FF4DEADBEEF0001ull;      // a signalling NaN with a payload no arithmetic produces
     void armSums();
     unsigned char* stage_dev = nullptr;   // the device-side address of the staging ring
@@ -2985,7 +2985,9 @@ void Instance::armSums()
 void Instance::postResultFlag()
 {
     if (!pollResult) return;
-    if (hipStreamWriteValue32(stream, h_flag_dev, ++flagSeq, 0) != hipSuccess) {
+    flagWritten = !sumsArmed;                    // (a result awaited through its block sums needs no stream operation behind the kernel)
+    if (!flagWritten) ++flagSeq;                 // (the sequence moves on: nobody will see this number in the flag word, a later one is larger)
+    else if (hipStreamWriteValue32(stream, h_flag_dev, ++flagSeq, 0) != hipSuccess) {
         (void) hipGetLastError();
         pollResult = false;
     }
@@ -3015,7 +3017,7 @@ int Instance::fetchResult(double* out)
             if (landed) __atomic_thread_fence(__ATOMIC_ACQUIRE);
             sumsArmed = false;
         }
-        if (!landed && pollResult) {
+        if (!landed && pollResult && flagWritten) {
             // spin on the word the stream writes behind the integration kernel, for about a millisecond of wall time; then the runtime's wait
             volatile uint32_t* f = h_flag;
             const auto t0 = std::chrono::steady_clock::now();
