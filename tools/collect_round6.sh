@@ -9,3 +9,4 @@ for c in c2 c3 c4 c5; do
 done
 cp gpurun_out/mcmc_fixed_topology.txt profiles/r06_mcmc_fixed_topology.txt
 python tools/pmc_traffic.py gpurun_out r06 > /dev/null
+cp gpurun_out/scale_read_and_path.txt profiles/r06_scale_read_and_path_final.txt
