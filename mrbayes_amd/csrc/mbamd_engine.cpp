@@ -564,7 +564,7 @@ int Instance::create(int tipCount_, int partialsBufferCount, int compactBufferCo
     const bool forceGeneric = std::getenv("MBAMD_FORCE_GENERIC") != nullptr;
     // the 4-state tree walk addresses buffers with 32-bit byte offsets inside a (block, category) column set (Walk4Entry)
     s4 = (S == 4 && !forceGeneric && (size_t) nBuffers * K * 1024 < ((size_t) 1 << 32) && (size_t) nMatrices * K * 64 < ((size_t) 1 << 32) &&
-          (size_t) (nScale + 1) * K * 64 < ((size_t) 1 << 32));
+          (size_t) (nScale + MBAMD_W4_SCRATCH_ROWS) * K * 64 < ((size_t) 1 << 32));
     // 20 / 61 states: the tree-walk kernel on the matrix cores (MBAMD_NO_WALKG=1: the level kernels of mbamd_kernels_mfma.h)
     {
         const size_t tb = wg_block_bytes(S), mf = (size_t) K * 64 * 64 + (size_t) K * wg_table_floats(S);
@@ -632,7 +632,7 @@ int Instance::create(int tipCount_, int partialsBufferCount, int compactBufferCo
         geom.pstride = (unsigned long) K * 64;
         geom.tstride = (unsigned) nBuffers * 4;
         geom.sstride = 64;
-        estride = (unsigned) (scale.size() + 1) * K * 64;       // + one scratch buffer (sink of non-rescaling operations)
+        estride = (unsigned) (scale.size() + MBAMD_W4_SCRATCH_ROWS) * K * 64;       // + the scratch rows (sinks of operations that record no exponents, in rotation)
         const size_t pBytes = nb * (size_t) nBuffers * K * 64 * 16, tBytes = nb * geom.tstride * 8, eBytes = nb * (size_t) estride;
         HIP_TRY(hipMalloc(&arenaPartials, pBytes));
         HIP_TRY(hipMalloc(&arenaTips, tBytes));
@@ -1617,8 +1617,7 @@ int Instance::buildWalk(Plan& plan, const BeagleOperation* ops, int n, const int
                 key.push_back(seg[o].tip1 ? -1 : writer[seg[o].c1]);
                 key.push_back(seg[o].tip2 ? -1 : writer[seg[o].c2]);
                 key.push_back((int) seg[o].tip1 | ((int) seg[o].tip2 << 1) | ((!seg[o].tip1 && !seg[o].tip2 && seg[o].c1 == seg[o].c2) ? 4 : 0) |
-                              ((seg[o].scaleWrite < 0 && seg[o].scaleRead >= 0) ? 8 : 0) |   // (SCALE_READ entries wait for an exponent DMA,
-                              (seg[o].scaleWrite >= 0 ? 16 : 0));                            //  SCALE_WRITE entries issue a second store: the wait counts differ)
+                              ((seg[o].scaleWrite < 0 && seg[o].scaleRead >= 0) ? 8 : 0));   // (SCALE_READ entries wait for an exponent DMA)
                 writer[seg[o].dst] = (int) o;
             }
             for (size_t o = 0; o < seg.size(); ++o) writer[seg[o].dst] = -1;
@@ -1664,7 +1663,7 @@ int Instance::buildWalk(Plan& plan, const BeagleOperation* ops, int n, const int
             uint32_t flags = te.flags, mode = SCALE_NONE, keep = 0;
             e.ewrite = (uint32_t) scratchScale * ebuf;
             e.eread = (uint32_t) scratchScale * ebuf;
-            if (wg) e.ewrite = (uint32_t) (scratchScale + (int) (i % (size_t) MBAMD_WG_SCRATCH_ROWS)) * ebuf;
+            e.ewrite = (uint32_t) (scratchScale + (int) (i % (size_t) (wg ? MBAMD_WG_SCRATCH_ROWS : MBAMD_W4_SCRATCH_ROWS))) * ebuf;   // (neighbouring entries: different scratch rows)
             if (wg) {
                 // k_walkg (mbamd_walkg.h): no prefetch entries; a child that is neither a tip nor in a slot is read from
                 // HBM by the operand pipeline; NOP entries store zeros to the extra buffer of the tile
@@ -1721,36 +1720,12 @@ int Instance::buildWalk(Plan& plan, const BeagleOperation* ops, int n, const int
                 if (op.scaleRead >= 0) e.eread = (uint32_t) op.scaleRead * ebuf;
             }
             if (te.vmwait != 0xFF) flags |= MBAMD_W4_VMWAIT;
-            e.ctl = flags | (mode << 8) | ((uint32_t) (te.vmwait == 0xFF ? 0 : te.vmwait) << 10) | (keep << 16);
-        }
-        if (!wg) {
-            // The stored exponents of a SCALE_READ entry are requested MBAMD_W4_EXP_AHEAD positions ahead of it (mbamd_walk4.h): the
-            // entry at that distance in front carries the exponent buffer in ITS eread word; those of the first positions travel in
-            // the program's last read-ahead entry (never executed, never read ahead of).
-            static_assert(MBAMD_W4_EXP_AHEAD == 6, "the prologue words of the last read-ahead entry hold six exponent buffers");
-            const int D = MBAMD_W4_EXP_AHEAD, body = t.entries - t.tail;
-            auto readsAt = [&](int w, int p) -> int {                       // exponent buffer the entry at position p of wave w reads, or -1
-                if (p >= body) return -1;
-                const Walk4Template::Entry& tn = t.prog[(size_t) w * t.entries + p];
-                return (tn.op >= 0 && tn.pfOp[0] < 0 && seg[tn.op].scaleWrite < 0 && seg[tn.op].scaleRead >= 0) ? seg[tn.op].scaleRead : -1;
-            };
-            for (int w = 0; w < t.W; ++w) {
-                Walk4Entry* const prog = &w4table[sg.first + (size_t) w * t.entries];
-                for (int p = 0; p < body; ++p) {
-                    const int r = readsAt(w, p + D);
-                    if (r >= 0) { prog[p].ctl |= MBAMD_W4_AHEAD_READS; prog[p].eread = (uint32_t) r * ebuf; }
-                }
-                if (t.tail >= 2) {
-                    Walk4Entry& h = prog[t.entries - 1];
-                    uint32_t* const word[6] = {&h.dst, &h.c1, &h.c2, &h.m1, &h.m2, &h.ewrite};
-                    h.ctl = 0;
-                    for (int p = 0; p < D; ++p) {
-                        const int r = readsAt(w, p);
-                        *word[p] = r >= 0 ? (uint32_t) r * ebuf : 0u;
-                        if (r >= 0) h.ctl |= 1u << p;
-                    }
-                }
+            // the entry in front of a SCALE_READ entry of the same wave fetches that entry's stored exponents (mbamd_walk4.h)
+            if ((i + 1) % (size_t) t.entries != 0) {
+                const Walk4Template::Entry& tn = t.prog[i + 1];
+                if (tn.op >= 0 && seg[tn.op].scaleWrite < 0 && seg[tn.op].scaleRead >= 0) flags |= MBAMD_W4_NEXT_READS;
             }
+            e.ctl = flags | (mode << 8) | ((uint32_t) (te.vmwait == 0xFF ? 0 : te.vmwait) << 10) | (keep << 16);
         }
         lastWalkW = t.W; lastWalkSlots = t.nslots; lastWalkEntries = t.entries; lastWalkPhases = t.phases;
         seg.clear();
@@ -2279,6 +2254,16 @@ static void launch_walkg_t(Instance& in, const WalkGArgs& a, int W, int nslots, 
         return;
     }
     auto kern = k_walkg<SC_, WMAX_, CH_, DEPTH_>;
+#if defined(MBAMD_WG_ABL_TAIL_FENCE)
+    if (std::getenv("MBAMD_WG_TAIL_FENCE")) {     // (experiment: see the end of k_walkg)
+        static long long* counters = nullptr;
+        if (!counters) { (void) hipMalloc(&counters, (size_t) (in.Ppad / MBAMD_WG_TW) * 8); (void) hipMemset(counters, 0, (size_t) (in.Ppad / MBAMD_WG_TW) * 8); }
+        WalkGArgs b = a;
+        b.reserved = counters;
+        MBAMD_LAUNCH_BARRIER(kern, walkg_grid(in.Ppad / MBAMD_WG_TW, in.K * a.lists), 64 * W * (a.spread ? 2 : 1), wg_lds_bytes(W, nslots, in.S), in.stream, b);
+        return;
+    }
+#endif
     MBAMD_LAUNCH_BARRIER(kern, walkg_grid(in.Ppad / MBAMD_WG_TW, in.K * a.lists), 64 * W * (a.spread ? 2 : 1), wg_lds_bytes(W, nslots, in.S), in.stream, a);
 }
 

@@ -31,9 +31,9 @@
 // evicted): they are LDS-DMA prefetches (global_load_lds_dwordx4, no destination register) issued through inline asm as
 // early as the host can place them -- all of a root-ward path's siblings before the first store when the slots allow
 // -- and the stored exponents of dynamic rescaling's "divide by the existing factors" pass (one byte per lane: an LDS-DMA
-// of an entry's 64 bytes into a ring of landing areas, six entries ahead).  Their consumer waits with the exact s_waitcnt vmcnt(N) the
+// of the next entry's 64 bytes into a two-deep staging area).  Their consumer waits with the exact s_waitcnt vmcnt(N) the
 // host computed by replaying the instruction sequence (Walk4Entry vmwait): per iteration
-// [0-2 prefetches (PF entries only)] [wait] [exponent DMA for a later entry if that is SCALE_READ] [1 store if an operation, 2 if SCALE_WRITE].
+// [0-2 prefetches (PF entries only)] [wait] [exponent DMA for the next entry if it is SCALE_READ] [2 stores if an operation].
 // The stores are non-temporal: a result is never read again in the launch that wrote it (parents read the LDS copy), and
 // letting 0.7 GB of write-allocated lines stream through L2 evicted the matrices and programs every wave keeps
 // re-reading -- every scalar load then paid an HBM round trip (measured: 1.6x on the whole kernel).
@@ -54,29 +54,25 @@ namespace mbamd {
 #define MBAMD_W4_FWD1     0x01000000u  // child 1 / 2 is the result of the operation this wave executed last: still in registers
 #define MBAMD_W4_FWD2     0x02000000u
 #define MBAMD_W4_READS      0x00000200u  // (= ScaleMode SCALE_READ in [9:8]) this entry divides by stored exponents: they were fetched into the landing area
-#define MBAMD_W4_AHEAD_READS 0x04000000u // the entry MBAMD_W4_EXP_AHEAD positions further on in this wave's program is SCALE_READ: fetch ITS stored
-                                         // exponents now -- this entry's `eread` field holds that entry's exponent buffer (4-state walk; set by the host)
-#define MBAMD_W4_RARE     (MBAMD_W4_NOP | MBAMD_W4_BARRIER | MBAMD_W4_PF0 | MBAMD_W4_VMWAIT | MBAMD_W4_READS | MBAMD_W4_AHEAD_READS)
-// Stored exponents (SCALE_READ: every operation of a full-tree evaluation between two rescalings of a beaglescaling=dynamic chain) come
-// by LDS-DMA into a ring of landing areas, requested MBAMD_W4_EXP_AHEAD entries before the entry that divides by them.  vmcnt retires
-// in order: a wait for a DMA is a wait for every older store of the wave.  Requested one entry ahead (rounds 2-5) that was the stores
-// of the entry before last -- a memory round trip per entry, 0.166 against 0.123 ms per evaluation at DNA 500 x 20 000
-// (profiles/r06_scale_read.txt); six entries ahead the stores in front of the DMA are three microseconds old.
-#define MBAMD_W4_EXP_RING  8
-#define MBAMD_W4_EXP_AHEAD 6
+#define MBAMD_W4_NEXT_READS 0x04000000u  // the NEXT entry of this wave is SCALE_READ: fetch its stored exponents now (4-state walk; set by the host)
+#define MBAMD_W4_RARE     (MBAMD_W4_NOP | MBAMD_W4_BARRIER | MBAMD_W4_PF0 | MBAMD_W4_VMWAIT | MBAMD_W4_READS | MBAMD_W4_NEXT_READS)
+// (Round 6: a ring of eight landing areas with the exponents requested six entries ahead was built on the hypothesis that the wait for
+//  the DMA is a wait for the previous entry's stores -- it was not the reason SCALE_READ evaluations were slow (the scratch row was,
+//  below) and cost the SCALE_WRITE walk 1.6 % at DNA 1000 x 50 000: taken out again, profiles/r06_scale_read.txt)
+#define MBAMD_W4_SCRATCH_ROWS 32   // exponent rows behind the scale buffers: where entries that record no exponents store their byte, in rotation
 #define MBAMD_W4_MAXW     8
 
 // One step of a wave's program (wave-uniform; fetched with one s_load_dwordx8).  Addresses are ready-made byte
 // offsets from a base the wave computes once (scalar adds only, no multiplications in the loop).
 struct alignas(32) Walk4Entry {
-    uint32_t ctl;      // [7:0] flags   [9:8] ScaleMode   [15:10] vmwait   [23:16] slot that keeps the result (flag KEEP)   [25:24] FWD1 / FWD2   [26] AHEAD_READS
+    uint32_t ctl;      // [7:0] flags   [9:8] ScaleMode   [15:10] vmwait   [23:16] slot that keeps the result (flag KEEP)   [25:24] FWD1 / FWD2   [26] NEXT_READS
     uint32_t dst;      // destination partials buffer: byte offset inside this wave's (block, category) column set
     uint32_t c1;       // child 1: tip -> byte offset of its 4 bitplanes inside the block's tip area; else LDS byte offset of its slot
     uint32_t c2;
     uint32_t m1;       // transition matrices: byte offsets (this wave's category)
     uint32_t m2;
     uint32_t ewrite;   // exponent buffer written (the scratch buffer unless SCALE_WRITE): byte offset
-    uint32_t eread;    // k_path4 / k_walkg: exponent buffer read (SCALE_READ): byte offset.  k_walk4_t: the one the entry EXP_AHEAD positions on reads (flag AHEAD_READS)
+    uint32_t eread;    // exponent buffer read (SCALE_READ): byte offset
     // PF entry (flags NOP | PF0 [| PF1]): dst / c1 = partials byte offset -> LDS slot byte offset of prefetch 0, c2 / m1 of prefetch 1
 };
 static_assert(sizeof(Walk4Entry) == 32, "Walk4Entry is 8 dwords");
@@ -95,11 +91,10 @@ struct Walk4Args {
     int32_t* cum;                // wide cumulative buffer int32 [K][Ppad], or nullptr
     int cumFresh;                // the cumulative buffer holds nothing yet: store the sums instead of adding them
     int K, Ppad, nblocks;
-    int tail;                    // trailing NOP entries of every program (read-ahead): 2.  The LAST one is never executed nor read ahead of: its
-                                 // words carry the exponent buffers of the first EXP_AHEAD entries (ctl: bit p = entry p is SCALE_READ; dst, c1, c2, m1, m2, ewrite)
+    int tail;                    // trailing NOP entries of every program (read-ahead): 2
 };
 
-#define MBAMD_W4_STAGE ((MBAMD_W4_EXP_RING + 1) * 256)   // bytes per wave in front of its slots: the ring of 64-dword landing areas for stored exponents + one nobody reads
+#define MBAMD_W4_STAGE 768       // bytes per wave in front of its slots: two 64-dword landing areas for stored exponents + one nobody reads
 __host__ __device__ inline size_t walk4_lds_bytes(int W, int nslots) { return (size_t) W * (MBAMD_W4_STAGE + (size_t) nslots * 1024); }
 // The grid is one-dimensional and XCD-aware: workgroup id -> XCD id % 8 (observed dispatch rule), and the K category
 // workgroups of one pattern block get consecutive positions on ONE XCD, so that the tip bitplanes and the matrix
@@ -153,8 +148,8 @@ namespace mbamd {
 // wave, the scalar side -- shared by the four SIMDs of a CU -- the larger half).  What left the common path:
 //   * the tip-plane touch (two LDS-DMAs, a half-entry scalar load and their address arithmetic per operation: +-2 % in round 3);
 //   * everything that is not "an operation that rescales or does not": prefetch entries, waits, barriers, no-ops AND the two
-//     halves of dynamic rescaling's SCALE_READ pass (fetch a later entry's stored exponents / read this entry's) sit behind ONE
-//     test of the entry's flags (MBAMD_W4_RARE; the host marks the entry EXP_AHEAD positions in front of a SCALE_READ entry with AHEAD_READS);
+//     halves of dynamic rescaling's SCALE_READ pass (fetch the next entry's stored exponents / read this entry's) sit behind ONE
+//     test of the entry's flags (MBAMD_W4_RARE; the host marks the entry in front of a SCALE_READ entry with NEXT_READS);
 //   * the copy of a result into the forwarding registers (results alternate between two register sets with the loop's two halves);
 //   * per-entry address arithmetic of the program (a running pointer, one add per two entries).
 template <class ARGS>
@@ -180,7 +175,7 @@ k_walk4_t(ARGS AA)
     const float* const M0 = A.matrices + (size_t) k * 16;
     const Walk4Lds L = walk4_lds(mine, lane);                                    // the same window for the LDS-DMA forms
 #define MBAMD_W4_PREFETCH(SRC, DST) walk4_prefetch(L, walk4_at_kib(P0, SRC), (DST))
-#define MBAMD_W4_EXPS(OFF, POS) walk4_fetch_exps(L, walk4_at(E0, OFF), lane, (int) ((POS) & (MBAMD_W4_EXP_RING - 1)))
+#define MBAMD_W4_EXPS(OFF, PARITY) walk4_fetch_exps(L, walk4_at(E0, OFF), lane, (PARITY))
 
     const Walk4Entry* pp = walk4_program(AA) + (size_t) wave * A.entries;       // entry j of this wave's program
     const int n = A.entries - A.tail;
@@ -190,30 +185,19 @@ k_walk4_t(ARGS AA)
     Walk4Mat M2 = walk4_load_matrix(walk4_at(M0, DA.m2));
     Walk4Planes T1 = walk4_load_planes(walk4_at(T0, (DA.ctl & MBAMD_W4_TIP1) ? DA.c1 : 0u));
     Walk4Planes T2 = walk4_load_planes(walk4_at(T0, (DA.ctl & MBAMD_W4_TIP2) ? DA.c2 : 0u));
-    if (A.tail >= 2) {
-        // the stored exponents of the first EXP_AHEAD entries (their buffers travel in the program's last read-ahead entry)
-        const Walk4Entry H = walk4_load_entry(pp + A.entries - 1);
-        if (H.ctl & 0x3Fu) {
-            if (H.ctl & 1u) MBAMD_W4_EXPS(H.dst, 0);
-            if (H.ctl & 2u) MBAMD_W4_EXPS(H.c1, 1);
-            if (H.ctl & 4u) MBAMD_W4_EXPS(H.c2, 2);
-            if (H.ctl & 8u) MBAMD_W4_EXPS(H.m1, 3);
-            if (H.ctl & 16u) MBAMD_W4_EXPS(H.m2, 4);
-            if (H.ctl & 32u) MBAMD_W4_EXPS(H.ewrite, 5);
-        }
-    }
+    if (DA.ctl & MBAMD_W4_READS) MBAMD_W4_EXPS(DA.eread, 0);
     int cum_e = 0;
     f4 RA = {0.0f, 0.0f, 0.0f, 0.0f}, RB = RA;     // results of the even / odd entries (a no-op entry passes the previous one through): a FWD child reads the other set
 
     // One iteration = one entry.  Vector-memory instruction sequence (the host's vmwait counts on exactly this):
     //     [DMA pf0] [DMA pf1] (PF entries)   s_waitcnt vmcnt(vmwait) (flag VMWAIT)
-    //     [exponent DMA for the entry EXP_AHEAD positions on, if that is SCALE_READ]   [1 store, if this entry is an operation; 2 if it is SCALE_WRITE]
+    //     [exponent DMA for the next entry, if that is SCALE_READ]   [2 stores, if this entry is an operation]
     // Everything wave-uniform is a scalar branch or a scalar select (no divergent control flow).  The loop is unrolled by
     // two so that the two entry descriptors in flight keep their registers (no moves): `cur` is executed, `nxt` is the
     // next one, and cur's registers receive entry j + 2.  ALL scalar loads of an iteration (next entry's matrices and tip
     // planes, the entry after next) are issued in one burst as soon as this entry's matrix products are done, and are
     // consumed after the next iteration's LDS reads: one lgkmcnt(0) per iteration covers both.
-    auto step = [&](Walk4Entry& cur, const Walk4Entry& nxt, const Walk4Entry* after, int pos, f4& out, const f4& prev) {
+    auto step = [&](Walk4Entry& cur, const Walk4Entry& nxt, const Walk4Entry* after, int parity, f4& out, const f4& prev) {
         const unsigned ctl = cur.ctl;
         int er = 0;
         if (ctl & MBAMD_W4_RARE) {
@@ -222,14 +206,10 @@ k_walk4_t(ARGS AA)
                 MBAMD_W4_PREFETCH(cur.dst, cur.c1);
                 if (ctl & MBAMD_W4_PF1) MBAMD_W4_PREFETCH(cur.c2, cur.m1);
             }
-#if !defined(MBAMD_W4_ABL_NO_WAIT)
             if (ctl & MBAMD_W4_VMWAIT) walk4_wait_vm((ctl >> 10) & 63u);       // what an LDS-DMA brought for this entry has landed
-#endif
             if (ctl & MBAMD_W4_BARRIER) walk4_barrier();
-#if !defined(MBAMD_W4_ABL_NO_EXP_DMA)
-            if (ctl & MBAMD_W4_AHEAD_READS) MBAMD_W4_EXPS(cur.eread, pos + MBAMD_W4_EXP_AHEAD);
-#endif
-            if (ctl & MBAMD_W4_READS) er = stage[64 * (pos & (MBAMD_W4_EXP_RING - 1)) + lane];
+            if (ctl & MBAMD_W4_NEXT_READS) MBAMD_W4_EXPS(nxt.eread, parity ^ 1);
+            if (ctl & MBAMD_W4_READS) er = stage[64 * parity + lane];
         }
         f4 o = prev;                                   // (a no-op entry passes the result of the operation executed last through)
         if (!(ctl & MBAMD_W4_NOP)) {
@@ -261,16 +241,16 @@ k_walk4_t(ARGS AA)
             o.x = scale_pow2(o.x, -e); o.y = scale_pow2(o.y, -e);
             o.z = scale_pow2(o.z, -e); o.w = scale_pow2(o.w, -e);
             if (ctl & MBAMD_W4_KEEP) *reinterpret_cast<f4*>(slots + ((ctl >> 6) & 0x3FC00u)) = o;
-            // (the exponents are stored only where the list asks for them: every entry of a SCALE_READ evaluation writing its byte to the
-            //  one scratch row of its block made such an evaluation a third slower -- same-address stores, profiles/r06_scale_read.txt)
-            if (wm) walk4_store(walk4_at_kib(P0, dst), walk4_at(E0, ewrite), lane, o, e);
-            else walk4_store_partials(walk4_at_kib(P0, dst), lane, o);
+            // (two stores, always: a branch around the second cost the SCALE_WRITE walk 5 % (call 31).  An entry that records no exponents writes its
+            //  byte to one of MBAMD_W4_SCRATCH_ROWS scratch rows, in rotation: every entry of a SCALE_READ evaluation writing to ONE row
+            //  made such an evaluation a third slower -- same-address stores, profiles/r06_scale_read.txt)
+            walk4_store(walk4_at_kib(P0, dst), walk4_at(E0, ewrite), lane, o, e);
         }
         out = o;
     };
     for (int j = 0; j < n; j += 2) {
-        step(DA, DB, pp + 2, j, RA, RB);
-        step(DB, DA, pp + 3, j + 1, RB, RA);
+        step(DA, DB, pp + 2, 0, RA, RB);
+        step(DB, DA, pp + 3, 1, RB, RA);
         pp += 2;
     }
 #undef MBAMD_W4_EXPS

@@ -63,7 +63,6 @@ struct Walk4Scratch {
     // kept between builds so that compiling a short list (a root-ward path: every MCMC generation) allocates nothing
     std::vector<int> binLoad, roots, frontier, slotHolder, lastUse, slotOfVal, freeFrom, memAt, nextOp, pieces, load, dryNodes;
     std::vector<char> fwd;
-    std::vector<long> expSeqOf;
     std::vector<std::vector<int>> phaseStart;
     std::vector<Walk4Template::Entry> scan;
     std::vector<std::vector<Walk4Template::Entry>> fin;
@@ -88,9 +87,6 @@ public:
     // 4-state walk: a result whose only consumer is the NEXT operation of the same wave -- in a post-order walk every parent
     // follows its last interior child directly -- stays in registers (c?slot = 0xFE): no LDS slot, no write / read-back round trip
     bool forward = false;
-    // 4-state walk: the stored exponents of a SCALE_READ entry are requested this many positions ahead of it (the first ones in
-    // the prologue): MBAMD_W4_EXP_AHEAD of mbamd_walk4.h -- the wait counts below replay exactly that sequence
-    int expAhead = 6;
 
     // ops: one hazard-free segment (no buffer is written twice, none is written after it was read, a buffer read
     // after it was written is a dependency).  Fills `t` (structure) -- the caller turns it into Walk4Entry words.
@@ -557,13 +553,12 @@ inline bool Walk4Builder::build(const std::vector<Walk4Op>& ops, Walk4Template& 
             out.push_back(e);
         }
         // 5. wait counts: replay the vector-memory instruction sequence of the kernel loop (mbamd_walk4.h)
-        //    prologue: [exponent DMAs for those of the first expAhead entries that are SCALE_READ]
-        //    iteration j: [PF DMAs] WAIT [exponent DMA for entry j + expAhead if that is SCALE_READ] [1 store if an operation, 2 if SCALE_WRITE]
+        //    prologue: [exponent DMA for entry 0 if SCALE_READ]
+        //    iteration: [PF DMAs] WAIT [exponent DMA for the next entry if SCALE_READ] [2 stores if an operation]
         auto reads = [&](const Walk4Template::Entry& e) { return e.op >= 0 && ops[e.op].scaleRead >= 0 && ops[e.op].scaleWrite < 0; };
         long issued = 0;
-        std::vector<long>& expSeqOf = s.expSeqOf;               // sequence number of the exponent DMA of every entry (-1: none)
-        expSeqOf.assign(out.size(), -1);
-        for (size_t j = 0; j < out.size() && j < (size_t) expAhead; ++j) if (reads(out[j])) expSeqOf[j] = issued++;
+        long expSeq = -1;                                       // sequence number of the exponent DMA of the entry about to run
+        if (!out.empty() && reads(out[0])) expSeq = issued++;
         std::vector<long> pfSeq(mems.size(), -1);
         for (size_t j = 0; j < out.size(); ++j) {
             Walk4Template::Entry& e = out[j];
@@ -578,12 +573,13 @@ inline bool Walk4Builder::build(const std::vector<Walk4Op>& ops, Walk4Template& 
             if (e.op >= 0) {
                 for (size_t mi = 0; mi < mems.size(); ++mi)
                     if (mems[mi].op == e.op && pfSeq[mi] >= 0) needed = std::max(needed, pfSeq[mi]);
-                if (reads(e)) needed = std::max(needed, expSeqOf[j]);
+                if (reads(e)) needed = std::max(needed, expSeq);
             }
             if (needed < 0) e.vmwait = 0xFF;                        // (no wait)
             else e.vmwait = safeWaits ? 0 : (uint8_t) walk4_round_wait(issued - (needed + 1));
-            if (j + (size_t) expAhead < out.size() && reads(out[j + (size_t) expAhead])) expSeqOf[j + (size_t) expAhead] = issued++;
-            if (e.op >= 0) issued += ops[e.op].scaleWrite >= 0 ? 2 : 1;     // (partials; the exponents only where the list records them)
+            expSeq = -1;
+            if (j + 1 < out.size() && reads(out[j + 1])) expSeq = issued++;
+            if (e.op >= 0) issued += 2;
         }
     }
     size_t longestFinal = 0;

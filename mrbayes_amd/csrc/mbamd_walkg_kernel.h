@@ -400,6 +400,14 @@ k_walkg(ARGS AA)
             else if (sum != 0) *d += sum;
         }
     }
+#if defined(MBAMD_WG_ABL_TAIL_FENCE)
+    // (experiment, call 30: what a device-scope release + one atomic per workgroup costs at the end of the walk -- the entry fee of
+    //  an integration run by the last workgroup of a tile; A.reserved = a counter per tile)
+    if (A.reserved != nullptr) {
+        __threadfence();
+        if (threadIdx.x == 0) atomicAdd(reinterpret_cast<unsigned long long*>(A.reserved) + tile, 1ull);
+    }
+#endif
 }
 }  // namespace mbamd
 #endif
