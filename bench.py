@@ -381,6 +381,11 @@ def measure(args, cfg, steps, warmup, rank, local_rank, world, dist, device, emu
             roof["mfma_issued_note"] = "fp32-equivalent matrix flops (v_mfma_f32_32x32x2_f32 count of the workload) / 157.3 TFLOP/s; issued as 6 x bf16 products, see arith"
             if pmc and pmc.get("mfma_bf16_busy_cycles"):
                 roof["bf16_pipe_busy_frac"] = pmc["mfma_bf16_busy_cycles"] / 1024.0 / (t_all * 2.1e9)
+    if pmc and pmc.get("partials_kernel_wave_cycles"):
+        # PMC, same passes as the traffic: the share of the partials kernel's wave-cycles spent issuing or stalled at issue (the rest: s_waitcnt)
+        wcy = pmc["partials_kernel_wave_cycles"]
+        roof["partials_kernel_wave_cycles"] = wcy
+        roof["issue_bound_frac"] = wcy["issuing"] + wcy["stalled_at_issue"]
     roof["kernel"] = impl
     roof["all_kernels_ms_per_step"] = all_ms
     roof["partials_kernel_ms_per_step"] = k_ms

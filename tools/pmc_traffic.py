@@ -45,6 +45,13 @@ for cfg in ("c2", "c3", "c4", "c5"):
     elif busy > 0:
         e["mfma_busy_cycles"] = busy
         e["mfma_issued_gflop"] = busy * 64 / 1e9
+    # where the partials kernel's wave-cycles go (pass 1 of tools/pmc_walk.sh): issuing an instruction / stalled at issue (most of it behind
+    # the wave's own previous instruction: a dependent MFMA or VALU chain) / in s_waitcnt for memory or LDS
+    for k, v in kernels.items():
+        if ("walkg" in k or "walk4" in k) and v.get("SQ_WAVE_CYCLES", 0.0) > 0:
+            wc = v["SQ_WAVE_CYCLES"]
+            e["partials_kernel_wave_cycles"] = {"issuing": round(v.get("SQ_ACTIVE_INST_ANY", 0.0) / wc, 4), "stalled_at_issue": round(v.get("SQ_WAIT_INST_ANY", 0.0) / wc, 4),
+                                                "waiting_s_waitcnt": round(v.get("SQ_WAIT_ANY", 0.0) / wc, 4), "waves": v.get("SQ_WAVES", 0.0)}
     out[cfg] = e
 with open(os.path.join(ROOT, "profiles", "pmc_traffic.json"), "w") as fh:
     json.dump(out, fh, indent=1)
