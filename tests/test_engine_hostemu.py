@@ -340,8 +340,10 @@ def test_path_and_log_likelihood_in_one_launch(emu, oracle, monkeypatch):
     ec.check_fused_path_and_likelihood(emu, oracle, monkeypatch)
 
 
-def test_paths_that_join_run_as_arms(emu, oracle, monkeypatch):
+@pytest.mark.parametrize("ncat", [4, 1, 5, 16])
+def test_paths_that_join_run_as_arms(emu, oracle, monkeypatch, ncat):
     """The lists of topology moves (two dirty branches: two root-ward paths and their common stem) on the path kernel == the same
-    lists on the tree-walk kernel, bit for bit; three dirty branches fall back to the walk where the arms nest."""
-    ec.check_forked_paths(emu, oracle, monkeypatch)
+    lists on the tree-walk kernel, bit for bit; three dirty branches fall back to the walk where the arms nest.  Any category count
+    (beyond eight the path runs on k_path4 and the log-likelihood on its own kernel)."""
+    ec.check_forked_paths(emu, oracle, monkeypatch, ntaxa=60 if ncat == 4 else 40, npat=700 if ncat == 4 else 200, ncat=ncat)
 
