@@ -46,6 +46,7 @@ __device__ __forceinline__ float mbd_max_lane_xor32(float v)
 #define MBD_WG_BARRIER() __builtin_amdgcn_s_barrier()
 #define MBD_COMPILER_FENCE() asm volatile("" ::: "memory")
 #define MBD_PIN_VGPR(x) asm volatile("" :: "v"(x) : "memory")                            // the value is in its register HERE
+#define MBD_OPAQUE_VGPR(x) asm volatile("" : "+v"(x))                                       // the value comes out of HERE: not a load the optimiser may move or merge
 #define MBD_SPIN_PAUSE() __builtin_amdgcn_s_sleep(1)
 // A bounded window on memory (a raw buffer resource): loads through it take a 32-bit per-lane offset and a wave-uniform offset, need
 // no 64-bit address arithmetic in the VALU, and a lane whose offset lies OUTSIDE the window reads zeros without touching memory --

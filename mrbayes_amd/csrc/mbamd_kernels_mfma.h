@@ -372,7 +372,7 @@ __device__ __forceinline__ void mfma_split_op(const MBAMD_AS_CONST PartialsOp* _
 // grid = (P_pad / 128) * operations, block = 256 (4 waves = 4 tiles), dynamic LDS = 4 * S * 32 floats.
 // ---------------------------------------------------------------------------------------------
 template <int SC, int KC>
-__global__ void __launch_bounds__(256, (SC > 0 ? 6 : 4))
+__global__ void __launch_bounds__(256, (SC > 0 ? 6 : (KC > 1 ? 3 : 4)))     // (any state count, two categories: 128 registers spilled 11 of them)
 k_partials_tips(OpTables tabs, int S_rt, int SP, int Ppad, int gx4)
 {
     constexpr int QC = SC > 0 ? (SC + 7) / 8 : 8;   // 8-row groups per category

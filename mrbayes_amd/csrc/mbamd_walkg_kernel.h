@@ -212,9 +212,15 @@ k_walkg(ARGS AA)
     // registers (the only LDS wait), then the MFMA chain (or the tip's gather rows) -- the caller may issue scalar loads in between.
     auto operandB = [&](const Walk4Entry& de, int q, const Ops& o, vec (&b)[TVC]) {
         const int ch = q / CH, h = q % CH;
+        // (5..8 states, two row registers per set: "a load from the set or a load from the slot" became ONE load through a pointer that is
+        //  either, and the three sets lived in scratch memory from then on -- 64 bytes per lane.  The set's rows are taken outside the
+        //  branch, as values the optimiser cannot turn back into loads.)
+        vec ob[TVC];
+#pragma unroll
+        for (int i = 0; i < TVC; ++i) { ob[i] = o.b[i]; if constexpr (TVC == 2) MBD_OPAQUE_VGPR(ob[i]); }
         if (de.ctl & (ch ? MBAMD_WG_MEM2 : MBAMD_WG_MEM1)) {
 #pragma unroll
-            for (int i = 0; i < TVC; ++i) b[i] = o.b[i];
+            for (int i = 0; i < TVC; ++i) b[i] = ob[i];
         } else {
             const vec* sl = reinterpret_cast<const vec*>(reinterpret_cast<const char*>(slots) + (ch ? de.c2 : de.c1)) + h * TVC * 64;
 #pragma unroll

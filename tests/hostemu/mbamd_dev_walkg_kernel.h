@@ -65,6 +65,7 @@ inline float mbd_max_lane_xor32(float v)
 #define MBD_WG_BARRIER() mbamd_emu_barrier()
 #define MBD_COMPILER_FENCE() ((void) 0)
 #define MBD_PIN_VGPR(x) ((void) (x))
+#define MBD_OPAQUE_VGPR(x) ((void) 0)
 #define MBD_SPIN_PAUSE() mbamd_emu_yield()
 struct mbd_buf { const char* p; unsigned bytes; };
 inline mbd_buf mbd_make_buffer(const void* p, unsigned bytes) { return mbd_buf{static_cast<const char*>(p), bytes}; }
