@@ -375,7 +375,10 @@ k_walkg(ARGS AA)
 #pragma unroll
             for (int i = 0; i < TV; ++i) keep[i * 64] = ov[i];
         }
-        MBAMD_AS_GLOBAL vec* pd = reinterpret_cast<MBAMD_AS_GLOBAL vec*>((uintptr_t) (P0 + dst)) + lane;
+        // (a no-operation entry -- padding of the shorter programs of a workgroup -- keeps its TV stores, so that the vector-memory sequence
+        //  stays the same on every path, but all its lanes write one and the same 16 bytes of the tile's spare buffer, a different place from
+        //  entry to entry: TV lines instead of TV KiB.  The zeros of these entries were 12-19 % of the kernel's HBM writes at 61 states.)
+        MBAMD_AS_GLOBAL vec* pd = reinterpret_cast<MBAMD_AS_GLOBAL vec*>((uintptr_t) (P0 + dst)) + (run ? lane : ((unsigned) j & 63u));
 #pragma unroll
         for (int i = 0; i < TV; ++i) __builtin_nontemporal_store(ov[i], pd + i * 64);   // 64 * V * 4 contiguous bytes per instruction
         __builtin_nontemporal_store((int8_t) e, as_global(E0 + ewrite) + col);   // (every lane group holds the same e: no exec-mask branch)
