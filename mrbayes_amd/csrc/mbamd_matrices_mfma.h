@@ -18,7 +18,7 @@ namespace mbamd {
 // ---------------------------------------------------------------------------------------------
 
 template <int NJ>
-__global__ void __launch_bounds__(64 * NJ)
+__global__ void __launch_bounds__(64 * NJ, 3)     // (three workgroups per CU: at 61 states 141 + 32 registers allowed two, and the 594 workgroups of codon 100 x 5 000 ran in two rounds)
 k_transition_matrices_mfma(const MatrixJob* __restrict__ jobs, RatesArg rates, int S, int SP, int K, int packedT, size_t wgTab)
 {
     __shared__ double ev[64];
