@@ -397,6 +397,10 @@ struct Instance {
             HIP_TRY(hipMemcpy(dst, src, bytes, hipMemcpyHostToDevice));
             return BEAGLE_SUCCESS;
         }
+        // (round 6: small transfers -- eigen-systems, frequencies, weights, compiled programs -- go through the pinned ring and a copy
+        //  kernel of ours: hipMemcpyAsync costs the host ~10 us a call and its blit kernel left the walk behind it 30 % slower,
+        //  profiles/r06_ring_copy.txt)
+        if (!noRingCopy && bytes <= ((size_t) 256 << 10) && bytes % 4 == 0 && (reinterpret_cast<uintptr_t>(dst) & 3u) == 0) return ringCopy(dst, src, bytes);
         size_t need = (bytes + 63) & ~(size_t) 63;
         if (stageOff + need > stageCap) {
             HIP_TRY(hipStreamSynchronize(stream));
@@ -407,6 +411,7 @@ struct Instance {
         stageOff += need;
         return BEAGLE_SUCCESS;
     }
+    int ringCopy(void* dst, const void* src, size_t bytes);
 
     // MrBayes re-sends state frequencies and category weights before every evaluation (reference
     // src/mbbeagle.c:1179-1225); only a changed vector costs a stream operation.  `shadow` mirrors the device array.
@@ -495,6 +500,8 @@ struct Instance {
     std::vector<char> pendingMatrixOut;          // matrix buffers the queued jobs write
     int submit(Plan* plan, int cumIdx, int32_t* cumPtr);
     bool noDefer = false;            // MBAMD_NO_DEFER: run every list at once
+    bool noInlineJobs = false;       // MBAMD_NO_INLINE_JOBS: a branch move's matrix jobs through the pinned ring too (A/B)
+    bool noRingCopy = false;         // MBAMD_NO_RING_COPY: a walk program reaches its device buffer by hipMemcpyAsync (A/B)
     bool eagerMatrices = false;      // four states (one call per evaluation): beagleUpdateTransitionMatrices launches the matrix kernel itself -- it runs while
                                      // MrBayes assembles the operation list (+2 % on both chains, profiles/r06_scale_read.txt); MBAMD_LAZY_MATRICES=1: queued as for the other models
     bool noInlinePrograms = false;   // MBAMD_NO_INLINE_PROGRAMS: every walk program through a device buffer
@@ -586,6 +593,8 @@ int Instance::create(int tipCount_, int partialsBufferCount, int compactBufferCo
     if (mfma) SP = 32 * NT;          // transposed matrices padded to the MFMA tile height
     mfmaWhole = std::getenv("MBAMD_MFMA_WHOLE") != nullptr;
     noDefer = std::getenv("MBAMD_NO_DEFER") != nullptr;
+    noInlineJobs = std::getenv("MBAMD_NO_INLINE_JOBS") != nullptr;
+    noRingCopy = std::getenv("MBAMD_NO_RING_COPY") != nullptr;
     eagerMatrices = s4 && std::getenv("MBAMD_LAZY_MATRICES") == nullptr;
     noInlinePrograms = std::getenv("MBAMD_NO_INLINE_PROGRAMS") != nullptr;
     noPath4 = std::getenv("MBAMD_NO_PATH4") != nullptr;
@@ -1057,6 +1066,17 @@ int Instance::flushMatrices()
     const RatesArg rates = rateSets[pendingRateSet];
     const int count = (int) pendingJobs.size();
     { int src = spanBegin(); if (src) return src; }
+    if (s4 && count <= MBAMD_S4_INLINE_JOBS && count * K <= 64 && !noInlineJobs) {
+        // a branch move's one or two matrices: the jobs in the kernel arguments (mbamd_kernels.h)
+        MatrixJobs4 ja;
+        std::memset(&ja, 0, sizeof ja);
+        std::memcpy(ja.j, pendingJobs.data(), sizeof(MatrixJob) * count);
+        pendingJobs.clear();
+        std::fill(pendingMatrixOut.begin(), pendingMatrixOut.end(), 0);
+        MBAMD_LAUNCH(k_transition_matrices_s4_inline, 1u, 64, 0, stream, ja, rates, K, count * K);
+        HIP_TRY(hipGetLastError());
+        return BEAGLE_SUCCESS;
+    }
     const MatrixJob* djobs = nullptr;
     int rc = stageDirect(pendingJobs.data(), sizeof(MatrixJob) * count, (const void**) &djobs);
     pendingJobs.clear();
@@ -1811,6 +1831,23 @@ int Instance::buildWalk(Plan& plan, const BeagleOperation* ops, int n, const int
         }
     }
     return upload(plan.d_table, w4table.data(), bytes);
+}
+
+// host data -> the pinned ring -> a device buffer, by a launch of ours on the instance's stream
+int Instance::ringCopy(void* dst, const void* src, size_t bytes)
+{
+    const void* ring = nullptr;
+    int rc = stageDirect(src, bytes, &ring);
+    if (rc) return rc;
+    if (bytes % 16 == 0 && (reinterpret_cast<uintptr_t>(dst) & 15u) == 0) {
+        const unsigned n16 = (unsigned) (bytes / 16);
+        MBAMD_LAUNCH(k_copy_from_ring, (n16 + 255u) / 256u, 256, 0, stream, static_cast<const copy16_t*>(ring), static_cast<copy16_t*>(dst), n16);
+    } else {
+        const unsigned n4 = (unsigned) (bytes / 4);
+        MBAMD_LAUNCH(k_copy_from_ring4, (n4 + 255u) / 256u, 256, 0, stream, static_cast<const unsigned*>(ring), static_cast<unsigned*>(dst), n4);
+    }
+    HIP_TRY(hipGetLastError());
+    return BEAGLE_SUCCESS;
 }
 
 // A root-ward path (the list of a move that dirtied one branch) as k_path4's entries: operation i has the result of operation i - 1

@@ -319,6 +319,49 @@ k_transition_matrices_s4(const MatrixJob* __restrict__ jobs, RatesArg rates, int
         }
 }
 
+// a compiled program from the pinned ring into its device buffer (round 6: a launch of ours instead of hipMemcpyAsync, whose call and
+// blit kernel were 10-15 us of the 30-40 us between the matrix kernel and the walk of a chain's full-tree evaluation)
+typedef unsigned copy16_t __attribute__((ext_vector_type(4)));
+__global__ void __launch_bounds__(256)
+k_copy_from_ring(const copy16_t* __restrict__ src, copy16_t* __restrict__ dst, unsigned n16)
+{
+    const unsigned i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n16) dst[i] = src[i];
+}
+
+__global__ void __launch_bounds__(256)
+k_copy_from_ring4(const unsigned* __restrict__ src, unsigned* __restrict__ dst, unsigned n4)
+{
+    const unsigned i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n4) dst[i] = src[i];
+}
+
+// The same for the one or two matrices of a branch move (round 6): the jobs travel in the kernel arguments -- read from the pinned ring,
+// as the kernel above does, the first thing every thread did was a round trip over the host link (2 of the kernel's 5 us, and the
+// path kernel waits behind it in 86 % of a chain's generations).
+#define MBAMD_S4_INLINE_JOBS 8
+struct MatrixJobs4 { MatrixJob j[MBAMD_S4_INLINE_JOBS]; };
+__global__ void __launch_bounds__(64)
+k_transition_matrices_s4_inline(MatrixJobs4 jobs, RatesArg rates, int K, int total)
+{
+    const int g = blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= total) return;
+    const int b = g / K, k = g % K;
+    const MatrixJob job = jobs.j[b];
+    const double* __restrict__ U = job.eig;
+    const double* __restrict__ Ui = job.eig + 16;
+    const double* __restrict__ lam = job.eig + 32;
+    double e[4];
+    for (int s = 0; s < 4; ++s) e[s] = exp(lam[s] * job.length * rates.r[k]);
+    float* __restrict__ out = job.out + (size_t) k * 16;
+    for (int i = 0; i < 4; ++i)
+        for (int j = 0; j < 4; ++j) {
+            double sum = 0.0;
+            for (int s = 0; s < 4; ++s) sum += U[i * 4 + s] * e[s] * Ui[s * 4 + j];
+            out[j * 4 + i] = (sum < 0.0) ? 0.0f : (float) sum;
+        }
+}
+
 // packedT > 0: additionally write the MFMA A-operand copy behind the K transposed matrices:
 //   packed[((k*NT + i/32)*T + j/2)*64 + (i%32) + 32*(j%2)] = P_k(i->j),  NT = ceil(S/32), T = packedT = ceil(S/2)
 // wgTab > 0: additionally scatter into the tree-walk tables of category k, wgTab floats into the buffer (mbamd_walkg.h)

@@ -441,7 +441,16 @@ public:
             s.haveEvent = true;
         }
         std::memcpy(s.h, src, bytes);
-        if (!direct) HIP_TRY(hipMemcpyAsync(s.d, s.h, bytes, hipMemcpyHostToDevice, stream));
+        if (!direct) {
+            // (round 6: a copy kernel of ours instead of hipMemcpyAsync -- ~10 us of host time per call, profiles/r06_ring_copy.txt)
+            static const bool noRingCopy = std::getenv("MBAMD_NO_RING_COPY") != nullptr;
+            if (noRingCopy) HIP_TRY(hipMemcpyAsync(s.d, s.h, bytes, hipMemcpyHostToDevice, stream));
+            else {
+                const unsigned n4 = (unsigned) ((bytes + 3) / 4);
+                MBAMD_LAUNCH(k_copy_from_ring4, (n4 + 255u) / 256u, 256, 0, stream, static_cast<const unsigned*>(s.hdev), static_cast<unsigned*>(s.d), n4);
+                HIP_TRY(hipGetLastError());
+            }
+        }
         *out = direct ? s.hdev : s.d;
         *used = &s;
         return BEAGLE_SUCCESS;
